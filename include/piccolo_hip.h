@@ -1,0 +1,156 @@
+/*
+ * piccolo_hip.h -- C ABI of libpiccolo_hip.so: the MI355X (gfx950) evaluator for
+ * the Pade-integrator collocation constraint of Piccolo.jl / DirectTrajOpt.jl.
+ *
+ * This is the drop-in boundary for ONE path of the reference: what a
+ * `DirectTrajOpt.AbstractIntegrator` has to provide to the NLP evaluator.  Each
+ * entry point names the reference interface it replaces (paths relative to the
+ * reference checkout, harmoniqs/Piccolo.jl v2.0.2; [EXT] = un-vendored
+ * DirectTrajOpt.jl, known from Piccolo's call sites):
+ *
+ *   pcl_create            BilinearIntegrator(qtraj::UnitaryTrajectory, N)     src/control/integrators.jl:35-51
+ *                         BilinearIntegrator(qtraj::SamplingTrajectory, N)    src/control/integrators.jl:134-162
+ *                         (copies G_drift / G_drives of sys.G, quantum_systems.jl:225-226,
+ *                          composite_quantum_systems.jl:124-132, and the component ranges of the
+ *                          NamedTrajectory, named_trajectory_conversion.jl:339-351)
+ *   pcl_constraint_dim    B.dim == x_dim*(N-1), B.x_dim                        src/control/integrators.jl:307-309
+ *   pcl_eval[_dev]        evaluate!(delta, B, traj) [EXT]                      src/control/integrators.jl:311,777
+ *   pcl_jac_nnz/structure jacobian structure handed to MOI [EXT]; shape pin    src/control/integrators.jl:780-783
+ *   pcl_jac[_dev]         eval_jacobian(B, traj) [EXT]                         src/control/integrators.jl:780
+ *   pcl_eval_jac[_dev]    eval_constraint + eval_constraint_jacobian of one IPM iteration (fused)
+ *   pcl_hess_nnz/structure, pcl_hess[_dev]
+ *                         hessian_structure / Hessian-of-Lagrangian [EXT]      test/aqua.jl:6-9,
+ *                                                                              src/control/templates/spline_pulse_problem.jl:96
+ *
+ * Semantics.  With h = dt_k, G = G0 + sum_j u_{k,j} G_j (n x n, n = 2d), X_k the
+ * n x d matrix whose column c is Utilde_k[c*n .. (c+1)*n) (isomorphisms.jl:110-118):
+ *     delta_k = B^-(hG) X_{k+1} - B^+(hG) X_k ,   B^{+-}(A) = I +- A/2 + A^2/12      (Pade order 4)
+ * (BASELINE.json north_star; the reference's own constraint is the matrix
+ * exponential x_{k+1} = exp(h Ghat) x_k, docs/src/concepts/index.md:21, of which
+ * this is the (2,2) diagonal Pade discretisation -- see DESIGN.md.)
+ *
+ * Variable vector = [traj.datavec ; traj.global_data]; component i of knot k is
+ * variable k*z_dim + i (integrators.jl:781-783).  Rows: member b, interval k,
+ * component r -> b*x_dim*K + k*x_dim + r (integrators are concatenated in
+ * prob.integrators order, integrators.jl:316-317); the caller adds the row offset
+ * of this integrator block inside the full constraint vector.
+ *
+ * Jacobian values, per (member b, interval k), contiguous block of
+ * jac_nnz_per_interval = 2*d*n*n + x_dim*(m+1) doubles, blocks ordered b-major then k:
+ *     seg 0  d delta/d X_k      for c<d, j<n, i<n : -B^+[i,j]   row c*n+i, col x_off + c*n+j     (knot k)
+ *     seg 1  d delta/d X_{k+1}  same loop          :  B^-[i,j]                                    (knot k+1)
+ *     seg 2  d delta/d u_l      for l<m, r<x_dim                col u_off + l                     (knot k)
+ *     seg 3  d delta/d dt       for r<x_dim                     col dt_off                        (knot k)
+ * Hessian-of-Lagrangian values per (b,k), hess_nnz_per_interval = (m+1)(m+2)/2 + 2*x_dim*(m+1):
+ *     seg 0 (u_i,u_j) j<=i | seg 1 (dt,u_j) | seg 2 (dt,dt) | seg 3 (u_l, X_k[r]) | seg 4 (dt, X_k[r])
+ *     seg 5 (X_{k+1}[r], u_l) | seg 6 (X_{k+1}[r], dt)   -- each pair once, as (max index, min index).
+ * The order is never assumed by a caller: it is reported by pcl_*_structure.
+ *
+ * Conventions: every function returns 0 (PCL_OK) or a negative pcl_status; the
+ * message is available from pcl_last_error.  No exceptions, no abort(), no
+ * pointer retained past a call (G0/Gj/x_offs are copied by pcl_create).  The
+ * caller owns all Z/delta/vals/mu/rows/cols buffers.  A pcl_ctx is not
+ * thread-safe: one context per (host thread x GPU).  Host-pointer entry points
+ * are synchronous; *_dev entry points enqueue on the context's stream and return.
+ * There is NO CPU fallback: without a gfx950 device pcl_create fails with PCL_EHIP.
+ */
+#ifndef PICCOLO_HIP_H
+#define PICCOLO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcl_ctx pcl_ctx;
+
+typedef enum pcl_status {
+    PCL_OK = 0,
+    PCL_EINVAL = -1,  /* bad argument / descriptor */
+    PCL_ENOMEM = -2,  /* host or device allocation failed */
+    PCL_EHIP = -3,    /* HIP runtime error (incl. "no GPU") */
+    PCL_ERCCL = -4,   /* RCCL error */
+    PCL_ESHAPE = -5,  /* shape outside what the kernels support (d > PCL_MAX_D, ...) */
+    PCL_ENOTIMPL = -6 /* valid request the library does not implement (e.g. pade_order != 4) */
+} pcl_status;
+
+#define PCL_MAX_D 32 /* n = 2d <= 64: G(u_k), G^2 and the column tiles stay LDS-resident */
+
+/* batch_mode */
+#define PCL_BATCH_MEMBERS 0 /* ONE trajectory buffer; member b owns state columns at x_offs[b]; shared u, dt
+                               (SamplingTrajectory: sampling_trajectory.jl:207-237) */
+#define PCL_BATCH_TRAJ 1    /* batch independent trajectory buffers (multistart seeds), Z_b = Z + b*z_dim*N;
+                               x_offs[0] is the state offset in each */
+
+typedef struct pcl_desc {
+    int32_t struct_size; /* = sizeof(pcl_desc) (ABI check) */
+    int32_t d;           /* Hilbert-space dimension (sys.levels); n = 2d, x_dim = 2 d^2 */
+    int32_t n_drives;    /* m */
+    int32_t N;           /* knot points (traj.N); K = N-1 intervals */
+    int32_t z_dim;       /* variables per knot (traj.dim) */
+    int32_t u_off;       /* 0-based offset of the drive component inside a knot (traj.components[:u][1]-1) */
+    int32_t dt_off;      /* 0-based offset of the timestep component */
+    int32_t batch;       /* number of members / seeds (>= 1) */
+    int32_t batch_mode;  /* PCL_BATCH_MEMBERS or PCL_BATCH_TRAJ */
+    int32_t pade_order;  /* 4 */
+    int32_t device_id;   /* HIP device ordinal */
+    int32_t index_base;  /* 0 (C/Python) or 1 (Julia/MOI) for the emitted structure */
+    int32_t per_member_G0; /* 0: one G0 for all members; 1: G0 holds batch matrices (per-member H_drift) */
+    int32_t reserved;
+    int64_t global_dim;  /* traj.global_dim (trailing globals in the variable vector; only shifts nothing, kept for
+                            the column count reported by pcl_constraint_dim) */
+    const double *G0;      /* n x n column-major (x batch if per_member_G0) : G_drift = iso(-i H_drift) */
+    const double *Gj;      /* m matrices n x n column-major                  : G_drives[j] */
+    const int32_t *x_offs; /* 0-based state offsets: batch entries (MEMBERS) or 1 entry (TRAJ) */
+} pcl_desc;
+
+/* lifecycle ---------------------------------------------------------------- */
+int pcl_create(const pcl_desc *desc, pcl_ctx **out);
+void pcl_destroy(pcl_ctx *ctx);
+/* Message of the last failure on ctx (ctx == NULL: last failure of pcl_create on this thread). */
+const char *pcl_last_error(const pcl_ctx *ctx);
+const char *pcl_version(void);
+
+/* dimensions --------------------------------------------------------------- */
+/* n_rows = batch*x_dim*(N-1); n_cols = z_dim*N*(TRAJ ? batch : 1) + global_dim. Any out pointer may be NULL. */
+int pcl_constraint_dim(const pcl_ctx *ctx, int64_t *x_dim, int64_t *n_rows, int64_t *n_cols);
+int pcl_jac_nnz(const pcl_ctx *ctx, int64_t *nnz, int64_t *nnz_per_interval);
+int pcl_hess_nnz(const pcl_ctx *ctx, int64_t *nnz, int64_t *nnz_per_interval);
+/* Sparsity structure in value order. In TRAJ mode trajectory b's variables are offset by b*z_dim*N. */
+int pcl_jac_structure(const pcl_ctx *ctx, int32_t *rows, int32_t *cols);
+int pcl_jac_structure_i64(const pcl_ctx *ctx, int64_t *rows, int64_t *cols);
+int pcl_hess_structure(const pcl_ctx *ctx, int32_t *rows, int32_t *cols);
+int pcl_hess_structure_i64(const pcl_ctx *ctx, int64_t *rows, int64_t *cols);
+
+/* host-pointer evaluation (synchronous; includes H2D of Z[,mu] and D2H of the results) ---- */
+/* Z: z_dim*N doubles (MEMBERS) or batch*z_dim*N (TRAJ). delta: n_rows. vals: jac nnz. */
+int pcl_eval(pcl_ctx *ctx, const double *Z, double *delta);
+int pcl_jac(pcl_ctx *ctx, const double *Z, double *vals);
+int pcl_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *vals);
+/* mu: n_rows multipliers; vals: hess nnz. (sigma * objective Hessian is the objective's business.) */
+int pcl_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *vals);
+
+/* device-pointer evaluation (asynchronous on the context's stream; results stay in HBM) ---- */
+int pcl_set_stream(pcl_ctx *ctx, void *hip_stream); /* hipStream_t; NULL = the context's own stream */
+int pcl_sync(pcl_ctx *ctx);
+int pcl_eval_dev(pcl_ctx *ctx, const double *Z_dev, double *delta_dev);
+int pcl_eval_jac_dev(pcl_ctx *ctx, const double *Z_dev, double *delta_dev, double *vals_dev);
+int pcl_hess_dev(pcl_ctx *ctx, const double *Z_dev, const double *mu_dev, double *vals_dev);
+
+/* Compact Jacobian: the d diagonal copies of I_d (x) B^{+-} are identical, so per (b,k) only
+ * [-B^+ (n*n) | B^- (n*n) | d/du (m*x_dim) | d/ddt (x_dim)] = 2 n^2 + x_dim (m+1) doubles are unique.
+ * pcl_eval_jac_compact_dev writes those; pcl_jac_expand_dev replicates them into the full triplet order. */
+int pcl_jac_compact_nnz(const pcl_ctx *ctx, int64_t *nnz, int64_t *nnz_per_interval);
+int pcl_eval_jac_compact_dev(pcl_ctx *ctx, const double *Z_dev, double *delta_dev, double *compact_dev);
+int pcl_jac_expand_dev(pcl_ctx *ctx, const double *compact_dev, double *vals_dev);
+
+/* tuning / introspection ---------------------------------------------------- */
+/* key: "cols_per_slice" (state columns per workgroup; 0 = heuristic), "use_mfma" (1/0), "nt_stores" (1/0). */
+int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t value);
+int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PICCOLO_HIP_H */

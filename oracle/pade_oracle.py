@@ -1,0 +1,667 @@
+"""CPU oracle for the collocation-constraint hot path (numpy/scipy).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``piccolo.jl_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` use it, and only as the checker.
+
+What it restates (reference = harmoniqs/Piccolo.jl v2.0.2, paths relative to
+``/root/reference``):
+
+* isomorphisms                     src/quantum/primitives/isomorphisms.jl:74-82,110-118,350,359
+* annihilate / lift_operator       src/quantum/object_utils.jl:154, src/quantum/operators/lifted_operators.jl:22-31
+* QuantumSystem (linear drives)    src/quantum/systems/quantum_systems.jl:212-227
+* CompositeQuantumSystem           src/quantum/systems/composite_quantum_systems.jl:104-133
+* TransmonSystem / coupling / MultiTransmonSystem
+                                   src/quantum/templates/transmons/transmon_system.jl:34-96,139-171,199-263
+* knot-major NamedTrajectory layout  src/quantum/trajectories/named_trajectory_conversion.jl:289-352,
+                                   src/quantum/trajectories/sampling_trajectory.jl:181-238
+* generator closure  Ghat(u) = I_d (x) G(u)   src/control/integrators.jl:35-51,134-162
+* the constraint  x_{k+1} = exp(dt_k Ghat(u_k)) x_k   docs/src/concepts/index.md:17-34,62
+
+The arithmetic of the reference's evaluator lives in the un-vendored dependency
+DirectTrajOpt.jl (compat 0.9.5/0.10, Project.toml:8,48) and is an exp-action
+constraint with ForwardDiff Jacobians.  BASELINE.json's north_star mandates the
+diagonal-Pade residual instead, for which the reference holds NO code and NO
+golden values:  **parity unpinned** for the Pade delta/Jacobian/Hessian values.
+What IS pinned here (tests/test_oracle_pins.py): every known-answer literal the
+reference's tests hold for the iso maps / generators / operators, and the
+semantics (layout, G = iso(-iH), drive order, 2*pi, (u_k, dt_k) convention) via
+exp-residuals on trajectories solved by the reference itself (docs/data/*.jld2).
+Pade-p is then tied to exp by its truncation order (p>=6 reproduces the exp
+residual floor on those trajectories) and to itself by finite differences.
+
+Pade formulas (diagonal Pade approximant of exp):
+    B^{+-}_p(A) = sum_{j=0}^{p/2} (+-1)^j c_j A^j ,  c_0 = 1
+    delta_k = B^-_p(h G) X_{k+1} - B^+_p(h G) X_k ,  h = dt_k, G = G(u_k)
+            = sum_j c_j h^j G^j Y_j ,  Y_j = (-1)^j X_{k+1} - X_k
+"""
+from __future__ import annotations
+
+import dataclasses
+import struct
+from typing import List, Optional, Sequence
+
+import numpy as np
+import scipy.linalg
+
+# --------------------------------------------------------------------------- #
+# Pade coefficients c_1..c_{p/2} (c_0 = 1): B^+ is the numerator of the (q,q)
+# diagonal Pade approximant of exp, q = p/2:  c_j = (2q-j)! q! / ((2q)! j! (q-j)!)
+# --------------------------------------------------------------------------- #
+
+
+def pade_coeffs(order: int) -> np.ndarray:
+    if order % 2 or order < 2:
+        raise ValueError("Pade order must be even and >= 2")
+    from math import factorial as f
+
+    q = order // 2
+    return np.array(
+        [f(2 * q - j) * f(q) / (f(2 * q) * f(j) * f(q - j)) for j in range(q + 1)]
+    )
+
+
+# --------------------------------------------------------------------------- #
+# Isomorphisms  [REF isomorphisms.jl]
+# --------------------------------------------------------------------------- #
+
+_IM2 = np.array([[0.0, -1.0], [1.0, 0.0]])
+
+
+def ket_to_iso(psi):
+    """[REF isomorphisms.jl:55]"""
+    psi = np.asarray(psi, dtype=complex)
+    return np.concatenate([psi.real, psi.imag])
+
+
+def iso_to_ket(v):
+    """[REF isomorphisms.jl:62-63]"""
+    v = np.asarray(v, dtype=float)
+    h = v.size // 2
+    return v[:h] + 1j * v[h:]
+
+
+def operator_to_iso_vec(U):
+    """Column c of U -> [Re U[:,c]; Im U[:,c]], columns concatenated.
+    [REF isomorphisms.jl:110-118]"""
+    U = np.asarray(U, dtype=complex)
+    d = U.shape[0]
+    out = np.empty(2 * d * d)
+    for c in range(d):
+        out[c * 2 * d : c * 2 * d + d] = U[:, c].real
+        out[c * 2 * d + d : (c + 1) * 2 * d] = U[:, c].imag
+    return out
+
+
+def iso_vec_to_operator(v):
+    """[REF isomorphisms.jl:74-82]"""
+    v = np.asarray(v, dtype=float)
+    d = int(round(np.sqrt(v.size // 2)))
+    U = np.empty((d, d), dtype=complex)
+    for c in range(d):
+        U[:, c] = v[c * 2 * d : c * 2 * d + d] + 1j * v[c * 2 * d + d : (c + 1) * 2 * d]
+    return U
+
+
+def iso_vec_to_iso_operator(v):
+    """[REF isomorphisms.jl:89-103]"""
+    U = iso_vec_to_operator(v)
+    return np.block([[U.real, -U.imag], [U.imag, U.real]])
+
+
+def iso_operator_to_iso_vec(Ut):
+    """[REF isomorphisms.jl:125-132]"""
+    Ut = np.asarray(Ut, dtype=float)
+    d = Ut.shape[0] // 2
+    return np.concatenate([Ut[:, c] for c in range(d)])
+
+
+def iso(H):
+    """iso(H) = I2 (x) Re H + [[0,-1],[1,0]] (x) Im H.  [REF isomorphisms.jl:350]"""
+    H = np.asarray(H, dtype=complex)
+    return np.kron(np.eye(2), H.real) + np.kron(_IM2, H.imag)
+
+
+def G_of_H(H):
+    """G(H) = iso(-i H).  [REF isomorphisms.jl:359]"""
+    return iso(-1j * np.asarray(H, dtype=complex))
+
+
+def H_of_G(G):
+    """[REF isomorphisms.jl:368-373]"""
+    G = np.asarray(G, dtype=float)
+    d = G.shape[0] // 2
+    return -G[d:, :d] + 1j * G[:d, :d]
+
+
+def var_G(G, G_vars):
+    """[REF isomorphisms.jl:410-422]"""
+    n, m = G.shape
+    v = len(G_vars)
+    out = np.kron(np.eye(v + 1), G)
+    for i, Gv in enumerate(G_vars, start=1):
+        out[i * n : (i + 1) * n, :m] += Gv
+    return out
+
+
+def ad_vec(H, anti=False):
+    """kron(I, H) - (-1)^anti kron(conj(H)', I);  conj(H)' is the plain transpose.
+    [REF isomorphisms.jl:384-387]"""
+    H = np.asarray(H, dtype=complex)
+    Id = np.eye(H.shape[0])
+    return np.kron(Id, H) - (-1) ** int(anti) * np.kron(H.T, Id)
+
+
+# --------------------------------------------------------------------------- #
+# Operators and systems
+# --------------------------------------------------------------------------- #
+
+PAULIS = {
+    "I": np.eye(2, dtype=complex),
+    "X": np.array([[0, 1], [1, 0]], dtype=complex),
+    "Y": np.array([[0, -1j], [1j, 0]], dtype=complex),
+    "Z": np.array([[1, 0], [0, -1]], dtype=complex),
+}
+
+
+def annihilate(levels: int):
+    """diagm(1 => sqrt.(1:levels-1)).  [REF object_utils.jl:154]"""
+    return np.diag(np.sqrt(np.arange(1, levels)), k=1).astype(complex)
+
+
+def lift_operator(op, i: int, subsystem_levels: Sequence[int]):
+    """Kronecker lift of ``op`` onto (1-based) subsystem ``i``.
+    [REF lifted_operators.jl:22-31]"""
+    assert op.shape[0] == subsystem_levels[i - 1]
+    out = np.eye(1, dtype=complex)
+    for j, l in enumerate(subsystem_levels, start=1):
+        out = np.kron(out, op if j == i else np.eye(l, dtype=complex))
+    return out
+
+
+@dataclasses.dataclass
+class System:
+    """Linear-drive system:  H(u) = H_drift + sum_j u_j H_drives[j];
+    G(u) = G_drift + sum_j u_j G_drives[j] with G_* = iso(-i H_*).
+    [REF quantum_systems.jl:212-227, composite_quantum_systems.jl:124-133]"""
+
+    H_drift: np.ndarray
+    H_drives: List[np.ndarray]
+    drive_bounds: List[tuple]
+    subsystem_levels: Optional[List[int]] = None
+
+    @property
+    def levels(self):
+        return self.H_drift.shape[0]
+
+    @property
+    def n_drives(self):
+        return len(self.H_drives)
+
+    @property
+    def G_drift(self):
+        return G_of_H(self.H_drift)
+
+    @property
+    def G_drives(self):
+        return [G_of_H(H) for H in self.H_drives]
+
+    def G(self, u):
+        out = self.G_drift.copy()
+        for uj, Gj in zip(u, self.G_drives):
+            out += uj * Gj
+        return out
+
+
+def _norm_bounds(b):
+    return [x if isinstance(x, tuple) else (-float(x), float(x)) for x in b]
+
+
+def quantum_system(H_drift, H_drives, drive_bounds):
+    """[REF quantum_systems.jl:190-227]"""
+    return System(
+        np.asarray(H_drift, dtype=complex),
+        [np.asarray(H, dtype=complex) for H in H_drives],
+        _norm_bounds(drive_bounds),
+    )
+
+
+def transmon_system(
+    omega=4.0,
+    delta=0.2,
+    levels=3,
+    lab_frame=False,
+    frame_omega=None,
+    multiply_by_2pi=True,
+    drives=True,
+    drive_bounds=(1.0, 1.0),
+):
+    """Duffing transmon in its own rotating frame by default (frame_omega = omega).
+    [REF transmon_system.jl:34-96]"""
+    if frame_omega is None:
+        frame_omega = 0.0 if lab_frame else omega
+    a = annihilate(levels)
+    ad = a.conj().T
+    if lab_frame:
+        H_drift = omega * ad @ a - delta / 2 * ad @ ad @ a @ a
+    else:
+        H_drift = (omega - frame_omega) * ad @ a - delta / 2 * ad @ ad @ a @ a
+    H_drives = [a + ad, 1j * (a - ad)] if drives else []
+    if multiply_by_2pi:
+        H_drift = H_drift * 2 * np.pi
+        H_drives = [H * 2 * np.pi for H in H_drives]
+    return quantum_system(H_drift, H_drives, list(drive_bounds) if drives else [])
+
+
+def transmon_dipole_coupling(g_ij, pair, subsystem_levels, lab_frame=False, multiply_by_2pi=True):
+    """[REF transmon_system.jl:139-171]"""
+    i, j = pair
+    a_i = lift_operator(annihilate(subsystem_levels[i - 1]), i, subsystem_levels)
+    a_j = lift_operator(annihilate(subsystem_levels[j - 1]), j, subsystem_levels)
+    if lab_frame:
+        op = g_ij * (a_i + a_i.conj().T) @ (a_j + a_j.conj().T)
+    else:
+        op = g_ij * (a_i @ a_j.conj().T + a_i.conj().T @ a_j)
+    if multiply_by_2pi:
+        op = op * 2 * np.pi
+    return op
+
+
+def composite_system(H_coupling, subsystems: Sequence[System], coupling_drives=(), coupling_bounds=()):
+    """Drift = coupling + lifted subsystem drifts; drives = coupling drives then
+    lifted subsystem drives in subsystem order.
+    [REF composite_quantum_systems.jl:104-133]"""
+    levels = [s.levels for s in subsystems]
+    H_drift = np.asarray(H_coupling, dtype=complex).copy()
+    for i, s in enumerate(subsystems, start=1):
+        H_drift = H_drift + lift_operator(s.H_drift, i, levels)
+    H_drives = [np.asarray(H, dtype=complex) for H in coupling_drives]
+    bounds = _norm_bounds(list(coupling_bounds))
+    for i, s in enumerate(subsystems, start=1):
+        for H in s.H_drives:
+            H_drives.append(lift_operator(H, i, levels))
+        bounds.extend(s.drive_bounds)
+    return System(H_drift, H_drives, bounds, subsystem_levels=levels)
+
+
+def multi_transmon_system(omegas, deltas, gs, levels_per_transmon=3, drive_bounds=1.0, lab_frame=False):
+    """[REF transmon_system.jl:199-263]"""
+    gs = np.asarray(gs, dtype=float)
+    ns = len(omegas)
+    db = [drive_bounds, drive_bounds] if np.isscalar(drive_bounds) else list(drive_bounds)
+    subs = [
+        transmon_system(omega=w, delta=dl, levels=levels_per_transmon, lab_frame=lab_frame, drive_bounds=db)
+        for w, dl in zip(omegas, deltas)
+    ]
+    levels = [s.levels for s in subs]
+    dim = int(np.prod(levels))
+    H = np.zeros((dim, dim), dtype=complex)
+    for i in range(1, ns):
+        for j in range(i + 1, ns + 1):
+            H = H + transmon_dipole_coupling(gs[i - 1, j - 1], (i, j), levels, lab_frame=lab_frame)
+    return composite_system(H, subs)
+
+
+# --------------------------------------------------------------------------- #
+# Knot-major trajectory layout  (NamedTrajectory.datavec, z_dim x N column-major)
+# --------------------------------------------------------------------------- #
+
+
+@dataclasses.dataclass
+class Layout:
+    """0-based component offsets inside one knot column of ``datavec``.
+    SmoothPulseProblem order is [Utilde(x_dim), dt, t, u(m), du(m), ddu(m)]
+    [REF smooth_pulse_problem.jl:187-201; SURVEY section 0.3 (measured)]."""
+
+    d: int
+    m: int
+    N: int
+    z_dim: int
+    x_off: int
+    u_off: int
+    dt_off: int
+
+    @property
+    def n(self):
+        return 2 * self.d
+
+    @property
+    def x_dim(self):
+        return 2 * self.d * self.d
+
+    @property
+    def K(self):
+        return self.N - 1
+
+    @staticmethod
+    def smooth_pulse(d, m, N, n_members=1):
+        x_dim = 2 * d * d
+        xs = n_members * x_dim
+        return Layout(d=d, m=m, N=N, z_dim=xs + 2 + 3 * m, x_off=0, u_off=xs + 2, dt_off=xs)
+
+    def X(self, Z, k, x_off=None):
+        """n x d real matrix [Re U; Im U] of knot k (column c = iso-vec slice c)."""
+        o = self.x_off if x_off is None else x_off
+        return Z[k, o : o + self.x_dim].reshape(self.d, self.n).T
+
+    def u(self, Z, k):
+        return Z[k, self.u_off : self.u_off + self.m]
+
+    def dt(self, Z, k):
+        return Z[k, self.dt_off]
+
+
+def as_knots(datavec, z_dim, N):
+    """datavec (length z_dim*N, knot-major) -> array [N, z_dim] (row k = knot k)."""
+    return np.asarray(datavec, dtype=float).reshape(N, z_dim)
+
+
+# --------------------------------------------------------------------------- #
+# Residuals
+# --------------------------------------------------------------------------- #
+
+
+def exp_residual(Z, lay: Layout, G0, Gj, x_off=None):
+    """Reference constraint  delta_k = x_{k+1} - exp(dt_k (I_d (x) G(u_k))) x_k.
+    [REF docs/src/concepts/index.md:21; integrators.jl:48]  Returns [K, x_dim]."""
+    out = np.empty((lay.K, lay.x_dim))
+    for k in range(lay.K):
+        G = G0 + np.tensordot(lay.u(Z, k), Gj, axes=1) if lay.m else G0
+        E = scipy.linalg.expm(lay.dt(Z, k) * G)
+        R = lay.X(Z, k + 1, x_off) - E @ lay.X(Z, k, x_off)
+        out[k] = R.T.reshape(-1)
+    return out
+
+
+def _powers(G, q):
+    P = [np.eye(G.shape[0])]
+    for _ in range(q):
+        P.append(P[-1] @ G)
+    return P
+
+
+def pade_residual(Z, lay: Layout, G0, Gj, order=4, x_off=None):
+    """delta_k = B^-_p(h G) X_{k+1} - B^+_p(h G) X_k.  Returns [K, x_dim]
+    (row k = interval k, entries in iso-vec order: column c of the n x d block
+    at [c*n, (c+1)*n))."""
+    c = pade_coeffs(order)
+    q = order // 2
+    out = np.empty((lay.K, lay.x_dim))
+    for k in range(lay.K):
+        G = G0 + np.tensordot(lay.u(Z, k), Gj, axes=1) if lay.m else G0
+        h = lay.dt(Z, k)
+        Xn, Xc = lay.X(Z, k + 1, x_off), lay.X(Z, k, x_off)
+        P = _powers(G, q)
+        R = np.zeros_like(Xc)
+        for j in range(q + 1):
+            Y = ((-1) ** j) * Xn - Xc
+            R += c[j] * h**j * (P[j] @ Y)
+        out[k] = R.T.reshape(-1)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# Jacobian (analytic).  Triplet order per interval k, fixed by this project
+# (the C ABI reports it through pcl_jac_structure):
+#   seg 0  d delta / d X_k      : for c in 0..d-1, for j in 0..n-1, for i in 0..n-1 : -B^+[i,j]
+#   seg 1  d delta / d X_{k+1}  : same loop                                          :  B^-[i,j]
+#   seg 2  d delta / d u_l      : for l in 0..m-1, for r in 0..x_dim-1
+#   seg 3  d delta / d dt       : for r in 0..x_dim-1
+# row(delta_k[r]) = k*x_dim + r ;  col(comp i of knot k) = k*z_dim + i   (0-based)
+# --------------------------------------------------------------------------- #
+
+
+def jac_nnz_per_interval(lay: Layout):
+    return 2 * lay.d * lay.n * lay.n + lay.x_dim * (lay.m + 1)
+
+
+def jac_structure(lay: Layout, x_off=None, index_base=0):
+    o = lay.x_off if x_off is None else x_off
+    d, n, m, xd, zd = lay.d, lay.n, lay.m, lay.x_dim, lay.z_dim
+    per = jac_nnz_per_interval(lay)
+    rows = np.empty(lay.K * per, dtype=np.int64)
+    cols = np.empty_like(rows)
+    c_, j_, i_ = np.meshgrid(np.arange(d), np.arange(n), np.arange(n), indexing="ij")
+    blk_r = (c_ * n + i_).reshape(-1)
+    blk_c = (c_ * n + j_).reshape(-1)
+    r_all = np.arange(xd)
+    for k in range(lay.K):
+        p = k * per
+        nb = d * n * n
+        rows[p : p + nb] = k * xd + blk_r
+        cols[p : p + nb] = k * zd + o + blk_c
+        p += nb
+        rows[p : p + nb] = k * xd + blk_r
+        cols[p : p + nb] = (k + 1) * zd + o + blk_c
+        p += nb
+        for l in range(m):
+            rows[p : p + xd] = k * xd + r_all
+            cols[p : p + xd] = k * zd + lay.u_off + l
+            p += xd
+        rows[p : p + xd] = k * xd + r_all
+        cols[p : p + xd] = k * zd + lay.dt_off
+    return rows + index_base, cols + index_base
+
+
+def pade_jacobian_values(Z, lay: Layout, G0, Gj, order=4, x_off=None):
+    """Jacobian values in the fixed triplet order above.  Returns [K, nnz_per_interval]."""
+    c = pade_coeffs(order)
+    q = order // 2
+    d, n, m, xd = lay.d, lay.n, lay.m, lay.x_dim
+    per = jac_nnz_per_interval(lay)
+    out = np.empty((lay.K, per))
+    for k in range(lay.K):
+        G = G0 + np.tensordot(lay.u(Z, k), Gj, axes=1) if m else G0
+        h = lay.dt(Z, k)
+        Xn, Xc = lay.X(Z, k + 1, x_off), lay.X(Z, k, x_off)
+        P = _powers(G, q)
+        Bp = sum(c[j] * h**j * P[j] for j in range(q + 1))
+        Bm = sum(c[j] * (-h) ** j * P[j] for j in range(q + 1))
+        p = 0
+        nb = d * n * n
+        out[k, p : p + nb] = np.tile((-Bp).T.reshape(-1), d)  # column-major flat of -B^+
+        p += nb
+        out[k, p : p + nb] = np.tile(Bm.T.reshape(-1), d)
+        p += nb
+        Y = [((-1) ** j) * Xn - Xc for j in range(q + 1)]
+        for l in range(m):
+            R = np.zeros_like(Xc)
+            for j in range(1, q + 1):
+                dGj = sum(P[a] @ Gj[l] @ P[j - 1 - a] for a in range(j))
+                R += c[j] * h**j * (dGj @ Y[j])
+            out[k, p : p + xd] = R.T.reshape(-1)
+            p += xd
+        R = np.zeros_like(Xc)
+        for j in range(1, q + 1):
+            R += j * c[j] * h ** (j - 1) * (P[j] @ Y[j])
+        out[k, p : p + xd] = R.T.reshape(-1)
+    return out
+
+
+def pade_jacobian_dense(Z, lay: Layout, G0, Gj, order=4, x_off=None):
+    """Dense (x_dim*K) x (z_dim*N) Jacobian assembled from the triplets (small cases)."""
+    rows, cols = jac_structure(lay, x_off)
+    vals = pade_jacobian_values(Z, lay, G0, Gj, order, x_off).reshape(-1)
+    J = np.zeros((lay.x_dim * lay.K, lay.z_dim * lay.N))
+    np.add.at(J, (rows, cols), vals)
+    return J
+
+
+# --------------------------------------------------------------------------- #
+# Hessian of the Lagrangian  sum_k mu_k^T delta_k  (Pade-4 analytic).
+# Per-interval triplet order (lower triangle of the symmetric matrix, row >= col
+# in GLOBAL variable index):
+#   seg 0  (u_i,u_j), i>=j       : for i in 0..m-1, for j in 0..i
+#   seg 1  (dt,u_j) or (u_j,dt)  : for j in 0..m-1
+#   seg 2  (dt,dt)
+#   seg 3  (u_l, X_k[r])         : for l, for r        (m*x_dim)
+#   seg 4  (dt , X_k[r])         : for r
+#   seg 5  (X_{k+1}[r], u_l)     : for l, for r
+#   seg 6  (X_{k+1}[r], dt)      : for r
+# Each pair is emitted once with (row, col) = (max index, min index).
+# --------------------------------------------------------------------------- #
+
+
+def hess_nnz_per_interval(lay: Layout):
+    m = lay.m
+    return (m + 1) * (m + 2) // 2 + 2 * lay.x_dim * (m + 1)
+
+
+def hess_structure(lay: Layout, x_off=None, index_base=0):
+    o = lay.x_off if x_off is None else x_off
+    m, xd, zd = lay.m, lay.x_dim, lay.z_dim
+    per = hess_nnz_per_interval(lay)
+    rows = np.empty(lay.K * per, dtype=np.int64)
+    cols = np.empty_like(rows)
+    r_all = np.arange(xd)
+    for k in range(lay.K):
+        a, b = [], []
+        uk = k * zd + lay.u_off
+        hk = k * zd + lay.dt_off
+        for i in range(m):
+            for j in range(i + 1):
+                a.append(np.array([uk + i]))
+                b.append(np.array([uk + j]))
+        for j in range(m):
+            a.append(np.array([hk]))
+            b.append(np.array([uk + j]))
+        a.append(np.array([hk]))
+        b.append(np.array([hk]))
+        for l in range(m):
+            a.append(np.full(xd, uk + l))
+            b.append(k * zd + o + r_all)
+        a.append(np.full(xd, hk))
+        b.append(k * zd + o + r_all)
+        for l in range(m):
+            a.append((k + 1) * zd + o + r_all)
+            b.append(np.full(xd, uk + l))
+        a.append((k + 1) * zd + o + r_all)
+        b.append(np.full(xd, hk))
+        a = np.concatenate(a)
+        b = np.concatenate(b)
+        rows[k * per : (k + 1) * per] = np.maximum(a, b)
+        cols[k * per : (k + 1) * per] = np.minimum(a, b)
+    return rows + index_base, cols + index_base
+
+
+def pade4_hessian_values(Z, mu, lay: Layout, G0, Gj, x_off=None):
+    """Values of grad^2 (sum_k mu_k^T delta_k) in the order above.  ``mu`` is
+    [K, x_dim].  Returns [K, hess_nnz_per_interval]."""
+    d, n, m, xd = lay.d, lay.n, lay.m, lay.x_dim
+    per = hess_nnz_per_interval(lay)
+    out = np.empty((lay.K, per))
+    ip = lambda A, B: float(np.sum(A * B))
+    for k in range(lay.K):
+        G = G0 + np.tensordot(lay.u(Z, k), Gj, axes=1) if m else G0
+        h = lay.dt(Z, k)
+        Xn, Xc = lay.X(Z, k + 1, x_off), lay.X(Z, k, x_off)
+        S, D = Xn + Xc, Xn - Xc
+        M = mu[k].reshape(d, n).T
+        G2 = G @ G
+        p = 0
+        for i in range(m):
+            for j in range(i + 1):
+                out[k, p] = h * h / 12 * ip(M, (Gj[i] @ Gj[j] + Gj[j] @ Gj[i]) @ D)
+                p += 1
+        for j in range(m):
+            out[k, p] = -0.5 * ip(M, Gj[j] @ S) + h / 6 * ip(M, (Gj[j] @ G + G @ Gj[j]) @ D)
+            p += 1
+        out[k, p] = ip(M, G2 @ D) / 6
+        p += 1
+        Kl = [Gj[l] @ G + G @ Gj[l] for l in range(m)]
+        for l in range(m):  # (u_l, X_k): d delta/du_l is linear in X_k with coefficient below
+            A = (-h / 2 * Gj[l] - h * h / 12 * Kl[l]).T @ M
+            out[k, p : p + xd] = A.T.reshape(-1)
+            p += xd
+        A = (-G / 2 - h / 6 * G2).T @ M
+        out[k, p : p + xd] = A.T.reshape(-1)
+        p += xd
+        for l in range(m):
+            A = (-h / 2 * Gj[l] + h * h / 12 * Kl[l]).T @ M
+            out[k, p : p + xd] = A.T.reshape(-1)
+            p += xd
+        A = (-G / 2 + h / 6 * G2).T @ M
+        out[k, p : p + xd] = A.T.reshape(-1)
+    return out
+
+
+def hessian_dense(vals, lay: Layout, x_off=None):
+    rows, cols = hess_structure(lay, x_off)
+    nv = lay.z_dim * lay.N
+    Hm = np.zeros((nv, nv))
+    np.add.at(Hm, (rows, cols), np.asarray(vals).reshape(-1))
+    return Hm + np.tril(Hm, -1).T
+
+
+# --------------------------------------------------------------------------- #
+# Derivative / time-consistency rows -- host-side only
+# --------------------------------------------------------------------------- #
+
+
+def derivative_residual(Z, off_x, off_dx, m, dt_off):
+    """u_{k+1} - u_k - dt_k * du_k  [REF smooth_pulse_problem.jl:267-275]"""
+    return Z[1:, off_x : off_x + m] - Z[:-1, off_x : off_x + m] - Z[:-1, dt_off : dt_off + 1] * Z[:-1, off_dx : off_dx + m]
+
+
+# --------------------------------------------------------------------------- #
+# Synthetic benchmark inputs
+# --------------------------------------------------------------------------- #
+
+
+def config_system(config: int) -> System:
+    if config == 1:
+        return quantum_system(0.5 * PAULIS["Z"], [PAULIS["X"], PAULIS["Y"]], [1.0, 1.0])
+    if config == 2:
+        return multi_transmon_system([4.0, 4.1], [0.2, 0.2], [[0, 0.1], [0.1, 0]], levels_per_transmon=2, drive_bounds=0.1)
+    if config in (3, 4, 5):
+        return multi_transmon_system(
+            [4.0, 4.1, 4.2],
+            [0.2, 0.21, 0.22],
+            [[0, 0.01, 0.02], [0.01, 0, 0.03], [0.02, 0.03, 0]],
+            levels_per_transmon=3,
+            drive_bounds=0.1,
+        )
+    raise ValueError(config)
+
+
+def synthetic_trajectory(sys: System, N: int, seed: int, dt=0.1, u_scale=0.02, u_clip=0.1, noise=1e-3):
+    """Near-feasible iterate: X_1 = iso(I), X_{k+1} = expm(dt G(u_k)) X_k + noise.
+    Returns (Z [N, z_dim], Layout)."""
+    rng = np.random.default_rng(seed)
+    d, m = sys.levels, sys.n_drives
+    lay = Layout.smooth_pulse(d, m, N)
+    Z = np.zeros((N, lay.z_dim))
+    u = np.clip(u_scale * rng.standard_normal((N, m)), -u_clip, u_clip)
+    du = 0.01 * rng.standard_normal((N, m))
+    ddu = 0.01 * rng.standard_normal((N, m))
+    Z[:, lay.dt_off] = dt
+    Z[:, lay.dt_off + 1] = dt * np.arange(N)
+    Z[:, lay.u_off : lay.u_off + m] = u
+    Z[:, lay.u_off + m : lay.u_off + 2 * m] = du
+    Z[:, lay.u_off + 2 * m : lay.u_off + 3 * m] = ddu
+    G0, Gj = sys.G_drift, np.array(sys.G_drives)
+    X = np.vstack([np.eye(d), np.zeros((d, d))])
+    for k in range(N):
+        Z[k, : lay.x_dim] = X.T.reshape(-1)
+        if k + 1 < N:
+            G = G0 + np.tensordot(u[k], Gj, axes=1)
+            X = scipy.linalg.expm(dt * G) @ X + noise * rng.standard_normal(X.shape)
+    return Z, lay
+
+
+# --------------------------------------------------------------------------- #
+# Reading a NamedTrajectory.datavec out of a reference JLD2 cache
+# (SURVEY Appendix A): JLD2 stores Vector{Float64} raw; datavec starts with the
+# iso-vec of the identity (the initial condition of every unitary trajectory).
+# --------------------------------------------------------------------------- #
+
+
+def read_jld2_datavec(path, d, z_dim, N, n_members=1):
+    b = open(path, "rb").read()
+    x0 = operator_to_iso_vec(np.eye(d))
+    x0 = np.tile(x0, n_members)
+    off = b.find(struct.pack("<%dd" % x0.size, *x0))
+    if off < 0:
+        raise ValueError("iso(I) prefix not found in %s" % path)
+    Z = np.frombuffer(b[off : off + 8 * z_dim * N], "<f8").reshape(N, z_dim).copy()
+    return Z

@@ -1,0 +1,35 @@
+"""piccolo.jl_amd -- MI355X-native evaluator for the Pade collocation constraint of
+Piccolo.jl / DirectTrajOpt.jl (one hot path; see DESIGN.md and SURVEY.md section 8).
+
+The directory name contains a dot, so it is imported through the loader shim
+``piccolo_jl_amd.py`` at the repository root:  ``import piccolo_jl_amd as pa``.
+"""
+from . import _lib, integrators, quantum, trajectory
+from ._lib import PclError, build_library
+from .integrators import (
+    BilinearIntegrator,
+    HipPadeIntegrator,
+    HipPadeMultistart,
+    eval_hessian_of_lagrangian,
+    eval_jacobian,
+    evaluate_,
+    hessian_structure,
+    jacobian_structure,
+)
+from .quantum import (
+    GATES,
+    PAULIS,
+    CompositeQuantumSystem,
+    MultiTransmonSystem,
+    QuantumSystem,
+    TransmonDipoleCoupling,
+    TransmonSystem,
+    annihilate,
+    iso,
+    iso_vec_to_operator,
+    lift_operator,
+    operator_to_iso_vec,
+)
+from .trajectory import NamedTrajectory, add_control_derivatives, sampling_trajectory, unitary_trajectory
+
+__version__ = "0.1.0"

@@ -1,0 +1,122 @@
+"""ctypes binding of csrc/libpiccolo_hip.so (C ABI: include/piccolo_hip.h).
+
+The library is built in-tree by ``build_library`` (called from
+``__graft_entry__.build()``) with ``hipcc --offload-arch=gfx950``.  There is no
+CPU path: if the shared object is missing, or no gfx950 device is present when a
+context is created, the error is raised to the caller -- nothing falls back.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libpiccolo_hip.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+PCL_OK = 0
+PCL_EINVAL, PCL_ENOMEM, PCL_EHIP, PCL_ERCCL, PCL_ESHAPE, PCL_ENOTIMPL = -1, -2, -3, -4, -5, -6
+PCL_BATCH_MEMBERS, PCL_BATCH_TRAJ = 0, 1
+_STATUS_NAMES = {0: "PCL_OK", -1: "PCL_EINVAL", -2: "PCL_ENOMEM", -3: "PCL_EHIP", -4: "PCL_ERCCL", -5: "PCL_ESHAPE", -6: "PCL_ENOTIMPL"}
+
+# every symbol include/piccolo_hip.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "pcl_create", "pcl_destroy", "pcl_last_error", "pcl_version",
+    "pcl_constraint_dim", "pcl_jac_nnz", "pcl_hess_nnz",
+    "pcl_jac_structure", "pcl_jac_structure_i64", "pcl_hess_structure", "pcl_hess_structure_i64",
+    "pcl_eval", "pcl_jac", "pcl_eval_jac", "pcl_hess",
+    "pcl_set_stream", "pcl_sync", "pcl_eval_dev", "pcl_eval_jac_dev", "pcl_hess_dev",
+    "pcl_jac_compact_nnz", "pcl_eval_jac_compact_dev", "pcl_jac_expand_dev",
+    "pcl_set_option", "pcl_get_option",
+]  # fmt: skip
+
+
+class PclError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (_STATUS_NAMES.get(code, "PCL_E?"), code, msg))
+        self.code = code
+
+
+class pcl_desc(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_int32),
+        ("d", ctypes.c_int32),
+        ("n_drives", ctypes.c_int32),
+        ("N", ctypes.c_int32),
+        ("z_dim", ctypes.c_int32),
+        ("u_off", ctypes.c_int32),
+        ("dt_off", ctypes.c_int32),
+        ("batch", ctypes.c_int32),
+        ("batch_mode", ctypes.c_int32),
+        ("pade_order", ctypes.c_int32),
+        ("device_id", ctypes.c_int32),
+        ("index_base", ctypes.c_int32),
+        ("per_member_G0", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("global_dim", ctypes.c_int64),
+        ("G0", ctypes.POINTER(ctypes.c_double)),
+        ("Gj", ctypes.POINTER(ctypes.c_double)),
+        ("x_offs", ctypes.POINTER(ctypes.c_int32)),
+    ]
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/piccolo_hip.hip for gfx950 into csrc/libpiccolo_hip.so (in-tree)."""
+    src = os.path.join(CSRC, "piccolo_hip.hip")
+    deps = [src, os.path.join(INCLUDE, "piccolo_hip.h")]
+    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(p) for p in deps):
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-o", SO_PATH, src]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen the product library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise FileNotFoundError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH
+        )
+    L = ctypes.CDLL(SO_PATH)
+    c_i64p = ctypes.POINTER(ctypes.c_int64)
+    c_i32p = ctypes.POINTER(ctypes.c_int32)
+    vp = ctypes.c_void_p
+    L.pcl_create.argtypes = [ctypes.POINTER(pcl_desc), ctypes.POINTER(vp)]
+    L.pcl_destroy.argtypes = [vp]
+    L.pcl_destroy.restype = None
+    L.pcl_last_error.argtypes = [vp]
+    L.pcl_last_error.restype = ctypes.c_char_p
+    L.pcl_version.restype = ctypes.c_char_p
+    L.pcl_constraint_dim.argtypes = [vp, c_i64p, c_i64p, c_i64p]
+    for f in ("pcl_jac_nnz", "pcl_hess_nnz", "pcl_jac_compact_nnz"):
+        getattr(L, f).argtypes = [vp, c_i64p, c_i64p]
+    for f in ("pcl_jac_structure", "pcl_hess_structure"):
+        getattr(L, f).argtypes = [vp, c_i32p, c_i32p]
+    for f in ("pcl_jac_structure_i64", "pcl_hess_structure_i64"):
+        getattr(L, f).argtypes = [vp, c_i64p, c_i64p]
+    # data pointers are passed as integers (host numpy .ctypes.data or device data_ptr())
+    L.pcl_eval.argtypes = [vp, vp, vp]
+    L.pcl_jac.argtypes = [vp, vp, vp]
+    L.pcl_eval_jac.argtypes = [vp, vp, vp, vp]
+    L.pcl_hess.argtypes = [vp, vp, vp, vp]
+    L.pcl_set_stream.argtypes = [vp, vp]
+    L.pcl_sync.argtypes = [vp]
+    L.pcl_eval_dev.argtypes = [vp, vp, vp]
+    L.pcl_eval_jac_dev.argtypes = [vp, vp, vp, vp]
+    L.pcl_hess_dev.argtypes = [vp, vp, vp, vp]
+    L.pcl_eval_jac_compact_dev.argtypes = [vp, vp, vp, vp]
+    L.pcl_jac_expand_dev.argtypes = [vp, vp, vp]
+    L.pcl_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
+    L.pcl_get_option.argtypes = [vp, ctypes.c_char_p, c_i64p]
+    _lib = L
+    return L

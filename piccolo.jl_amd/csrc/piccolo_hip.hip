@@ -1,0 +1,1029 @@
+// piccolo_hip.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI for the Pade-4 collocation
+// constraint evaluator.  ABI and the reference interfaces it replaces: include/piccolo_hip.h.
+//
+// Kernel design (DESIGN.md has the full account):
+//   one workgroup (4 wavefronts) per (member b, interval k, column slice s).
+//   * G(u_k) = G0 + sum_l u_l G_l is assembled in LDS from the dense drift tile and the
+//     union sparsity pattern of the drives;
+//   * G^2 and G * [S | D | G_l D] run on the f64 matrix cores (v_mfma_f64_16x16x4_f64),
+//     operands read straight from LDS tiles, one 16x16 output tile per wavefront at a time;
+//   * the slice's columns of delta, d/du_l, d/ddt are combined on the VALU and stored;
+//   * the slice's share of the d replicated diagonal blocks of I_d (x) B^{+-} is formed in
+//     registers from the LDS-resident G and G^2 and streamed to HBM with 16-byte coalesced
+//     stores (this stream is >98 % of the bytes: the kernel is HBM-write-bound).
+//
+// No CPU fallback exists in this file: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "piccolo_hip.h"
+
+#define PCL_VERSION_STR "piccolo_hip 0.1.0 (gfx950, pade4)"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// Kernel parameters
+// ------------------------------------------------------------------------------------------
+struct KParams {
+    const double *Z;       // trajectory buffer(s), knot-major
+    const double *mu;      // multipliers (Hessian kernel)
+    double *delta;         // may be null
+    double *jac;           // full or compact Jacobian values; may be null
+    double *hess;          // Hessian values
+    const double *G0;      // n*n col-major (x batch if per-member)
+    const int *upos;       // union pattern of the drives: flat col-major position
+    const double *ucoef;   // n_upos x m coefficients (row-major: [q*m + l])
+    const int *csr_ptr;    // m*(n+1): CSR row pointers of every G_l (rows of G_l)
+    const int *csr_col;
+    const double *csr_val;
+    const int *csc_ptr;    // m*(n+1): CSC (= CSR of G_l^T) for the Hessian kernel
+    const int *csc_row;
+    const double *csc_val;
+    const int *x_offs;     // per-member state offsets
+    long long z_batch_stride;   // doubles between trajectories (0 in MEMBERS mode)
+    long long g0_batch_stride;  // n*n if per-member drift else 0
+    long long jac_per;          // doubles per (b,k) in `jac`
+    long long hess_per;
+    int n_upos;
+    int d, n, m, K, z_dim, u_off, dt_off, batch;
+    int nc;       // state columns per slice
+    int S;        // slices per interval
+    int LD;       // LDS leading dimension of every n-row tile
+    int compact;  // 1: write unique blocks only (jac_per is the compact size)
+    int nt;       // 1: nontemporal streaming stores
+};
+
+// ------------------------------------------------------------------------------------------
+// MFMA tile GEMM on LDS operands:  C[0:M,0:Nc] = op(A)[0:M,0:Kd] * B[0:Kd,0:Nc]
+//   column-major everywhere; op(A) = A or A^T.  v_mfma_f64_16x16x4_f64 operand maps:
+//   a: lane l holds A[i = l&15][k = l>>4], b: B[k = l>>4][j = l&15],
+//   c/d: 4 doubles per lane, col = l&15, row = (l>>4) + 4*reg.
+//   Out-of-range rows/cols/k are fed as exact zeros, so no tile padding is needed in LDS.
+//   Two output tiles are processed together so each wave has two independent accumulators.
+// ------------------------------------------------------------------------------------------
+template <bool TRANS_A>
+__device__ __forceinline__ void mfma_gemm_lds(const double *__restrict__ A, int lda, const double *__restrict__ B,
+                                              int ldb, double *__restrict__ C, int ldc, int M, int Nc, int Kd,
+                                              int wave, int nwaves, int lane) {
+    const int rt_n = (M + 15) >> 4, ct_n = (Nc + 15) >> 4, ks_n = (Kd + 3) >> 2;
+    const int nt = rt_n * ct_n;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int t0 = wave * 2; t0 < nt; t0 += nwaves * 2) {
+        const int t1 = t0 + 1;
+        const bool has1 = t1 < nt;
+        const int rt0 = t0 % rt_n, ct0 = t0 / rt_n;
+        const int rt1 = has1 ? t1 % rt_n : rt0, ct1 = has1 ? t1 / rt_n : ct0;
+        const int row0 = rt0 * 16 + li, col0 = ct0 * 16 + li;
+        const int row1 = rt1 * 16 + li, col1 = ct1 * 16 + li;
+        const bool r0 = row0 < M, c0 = col0 < Nc, r1 = has1 && row1 < M, c1 = has1 && col1 < Nc;
+        double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        for (int ks = 0; ks < ks_n; ++ks) {
+            const int k = ks * 4 + lk;
+            const bool kok = k < Kd;
+            double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
+            if (r0 && kok) a0 = TRANS_A ? A[k + lda * row0] : A[row0 + lda * k];
+            if (c0 && kok) b0 = B[k + ldb * col0];
+            if (r1 && kok) a1 = TRANS_A ? A[k + lda * row1] : A[row1 + lda * k];
+            if (c1 && kok) b1 = B[k + ldb * col1];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+        }
+        if (c0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = rt0 * 16 + lk + 4 * r;
+                if (rr < M) C[rr + ldc * col0] = acc0[r];
+            }
+        }
+        if (c1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = rt1 * 16 + lk + 4 * r;
+                if (rr < M) C[rr + ldc * col1] = acc1[r];
+            }
+        }
+    }
+}
+
+// Plain VALU version of the same contract (selected with option use_mfma = 0; used to A/B the
+// matrix-core path and as a second implementation in the parity tests).
+template <bool TRANS_A>
+__device__ __forceinline__ void valu_gemm_lds(const double *__restrict__ A, int lda, const double *__restrict__ B,
+                                              int ldb, double *__restrict__ C, int ldc, int M, int Nc, int Kd,
+                                              int tid, int nthreads) {
+    for (int e = tid; e < M * Nc; e += nthreads) {
+        const int i = e % M, j = e / M;
+        double s = 0.0;
+        for (int k = 0; k < Kd; ++k) s = fma(TRANS_A ? A[k + lda * i] : A[i + lda * k], B[k + ldb * j], s);
+        C[i + ldc * j] = s;
+    }
+}
+
+template <bool MFMA, bool TRANS_A>
+__device__ __forceinline__ void gemm_lds(const double *A, int lda, const double *B, int ldb, double *C, int ldc, int M,
+                                         int Nc, int Kd) {
+    if (MFMA)
+        mfma_gemm_lds<TRANS_A>(A, lda, B, ldb, C, ldc, M, Nc, Kd, threadIdx.x >> 6, blockDim.x >> 6,
+                               threadIdx.x & 63);
+    else
+        valu_gemm_lds<TRANS_A>(A, lda, B, ldb, C, ldc, M, Nc, Kd, threadIdx.x, blockDim.x);
+}
+
+__device__ __forceinline__ void store2(double *p, double a, double b, bool nt) {
+    double2_t v = {a, b};
+    if (nt)
+        __builtin_nontemporal_store(v, reinterpret_cast<double2_t *>(p));
+    else
+        *reinterpret_cast<double2_t *>(p) = v;
+}
+
+// Assemble G(u_k) into LDS (ld = LD):  G = G0 + sum_l u_l G_l, in drive order (deterministic).
+__device__ __forceinline__ void build_G(const KParams &p, const double *__restrict__ G0, const double *__restrict__ zk,
+                                        double *__restrict__ G, double *__restrict__ us) {
+    const int n = p.n, LD = p.LD;
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) G[(e % n) + LD * (e / n)] = G0[e];
+    if ((int)threadIdx.x < p.m) us[threadIdx.x] = zk[p.u_off + threadIdx.x];
+    __syncthreads();
+    for (int q = threadIdx.x; q < p.n_upos; q += blockDim.x) {
+        const int pos = p.upos[q];
+        const int idx = (pos % n) + LD * (pos / n);
+        double g = G[idx];
+        for (int l = 0; l < p.m; ++l) g += us[l] * p.ucoef[(long long)q * p.m + l];
+        G[idx] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused residual + Jacobian kernel.
+// LDS map (doubles):  G [LD*n] | G2 [LD*n] | M1 [LD*(2+m)*nc] | W1 [LD*(2+m)*nc] | G2D [LD*nc] | T [LD*nc] | us[8+m]
+//   M1 = [S | D | G_1 D .. G_m D] (slice columns), W1 = G*M1 = [GS | GD | G(G_l D)].
+// ------------------------------------------------------------------------------------------
+template <bool JAC, bool MFMA>
+__global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
+    extern __shared__ double lds[];
+    const int n = p.n, d = p.d, m = p.m, LD = p.LD, nc = p.nc;
+    const int tid = threadIdx.x, nth = blockDim.x;
+
+    const int bid = blockIdx.x;
+    const int s = bid % p.S;
+    const int k = (bid / p.S) % p.K;
+    const int b = bid / (p.S * p.K);
+    const int c0 = s * nc;
+    const int nce = min(nc, d - c0);  // columns actually owned by this slice
+
+    const int ncols1 = JAC ? (2 + m) * nc : 2 * nc;
+    double *G = lds;
+    double *G2 = G + LD * n;
+    double *M1 = G2 + (JAC ? LD * n : 0);
+    double *W1 = M1 + LD * ncols1;
+    double *G2D = W1 + LD * ncols1;
+    double *T = G2D + LD * nc;
+    double *us = T + LD * nc;
+
+    const double *Zb = p.Z + (long long)b * p.z_batch_stride;
+    const double *zk = Zb + (long long)k * p.z_dim;
+    const double *zn = zk + p.z_dim;
+    const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+    const double h = zk[p.dt_off];
+    const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
+    const long long xd = (long long)n * d;
+
+    build_G(p, p.G0 + (long long)b * p.g0_batch_stride, zk, G, us);
+
+    // S and D for the slice's columns (unused trailing columns are zero)
+    for (int e = tid; e < nc * n; e += nth) {
+        const int c = e / n, i = e % n;
+        double xs = 0.0, xdv = 0.0;
+        if (c < nce) {
+            const double xn = zn[x_off + (c0 + c) * n + i], xc = zk[x_off + (c0 + c) * n + i];
+            xs = xn + xc;
+            xdv = xn - xc;
+        }
+        M1[i + LD * c] = xs;
+        M1[i + LD * (nc + c)] = xdv;
+    }
+    __syncthreads();
+
+    if (JAC) {
+        // G_l D via the CSR rows of G_l
+        const double *Dm = M1 + LD * nc;
+        for (int e = tid; e < m * nc * n; e += nth) {
+            const int i = e % n, c = (e / n) % nc, l = e / (n * nc);
+            const int *rp = p.csr_ptr + l * (n + 1);
+            double acc = 0.0;
+            for (int q = rp[i]; q < rp[i + 1]; ++q) acc += p.csr_val[q] * Dm[p.csr_col[q] + LD * c];
+            M1[i + LD * ((2 + l) * nc + c)] = acc;
+        }
+        __syncthreads();
+        gemm_lds<MFMA, false>(G, LD, G, LD, G2, LD, n, n, n);
+    }
+    gemm_lds<MFMA, false>(G, LD, M1, LD, W1, LD, n, ncols1, n);
+    __syncthreads();
+
+    // pass 2: G2D = G * (G D);  T = -c1 S + c2 G D
+    gemm_lds<MFMA, false>(G, LD, W1 + LD * nc, LD, G2D, LD, n, nc, n);
+    if (JAC) {
+        for (int e = tid; e < nc * n; e += nth) {
+            const int c = e / n, i = e % n;
+            T[i + LD * c] = -c1 * M1[i + LD * c] + c2 * W1[i + LD * (nc + c)];
+        }
+    }
+    __syncthreads();
+
+    // ---- column outputs -------------------------------------------------------------------
+    const long long bk = (long long)b * p.K + k;
+    double *jb = JAC ? p.jac + bk * p.jac_per : nullptr;
+    const long long blk = p.compact ? (long long)n * n : (long long)d * n * n;  // size of seg 0 / seg 1
+    for (int e = tid; e < nce * n; e += nth) {
+        const int c = e / n, i = e % n;
+        const double gs = W1[i + LD * c], g2d = G2D[i + LD * c];
+        const long long r = (long long)(c0 + c) * n + i;
+        if (p.delta) p.delta[bk * xd + r] = M1[i + LD * (nc + c)] - c1 * gs + c2 * g2d;
+        if (JAC) jb[2 * blk + (long long)m * xd + r] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
+    }
+    if (JAC) {
+        for (int e = tid; e < m * nce * n; e += nth) {
+            const int i = e % n, c = (e / n) % nce, l = e / (n * nce);
+            const int *rp = p.csr_ptr + l * (n + 1);
+            double acc = 0.0;
+            for (int q = rp[i]; q < rp[i + 1]; ++q) acc += p.csr_val[q] * T[p.csr_col[q] + LD * c];
+            jb[2 * blk + (long long)l * xd + (long long)(c0 + c) * n + i] = acc + c2 * W1[i + LD * ((2 + l) * nc + c)];
+        }
+
+        // ---- replicated diagonal blocks: stream -B^+ and B^- ---------------------------------
+        // pair index q covers flat column-major positions 2q, 2q+1 (same column since n is even)
+        const int half = (n * n) >> 1;
+        int cbeg = c0, cend = c0 + nce;
+        if (p.compact) {  // unique blocks only: slice 0 writes the single copy
+            cbeg = 0;
+            cend = (s == 0) ? 1 : 0;
+        }
+        for (int q = tid; q < half; q += nth) {
+            const int pos = 2 * q;
+            const int i = pos % n, j = pos / n;
+            const double g0 = G[i + LD * j], g1 = G[i + 1 + LD * j];
+            const double h0 = G2[i + LD * j], h1 = G2[i + 1 + LD * j];
+            const double id0 = (i == j) ? 1.0 : 0.0, id1 = (i + 1 == j) ? 1.0 : 0.0;
+            const double e0 = id0 + c2 * h0, e1 = id1 + c2 * h1;
+            const double bp0 = -(e0 + c1 * g0), bp1 = -(e1 + c1 * g1);
+            const double bm0 = e0 - c1 * g0, bm1 = e1 - c1 * g1;
+            for (int c = cbeg; c < cend; ++c) {
+                double *o0 = jb + (long long)c * n * n + pos;
+                store2(o0, bp0, bp1, p.nt);
+                store2(o0 + blk, bm0, bm1, p.nt);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Expansion kernel: compact -> full triplet order (replicate the unique blocks d times).
+// grid.x = batch*K*d ; each block copies one (b,k,c) pair of n*n blocks; block c==0 also copies the tail.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pcl_expand_kernel(const double *__restrict__ compact, double *__restrict__ full,
+                                                         int d, int n, int m, long long n_bk, int nt) {
+    const long long nn = (long long)n * n, xd = (long long)n * d;
+    const long long cper = 2 * nn + xd * (m + 1), fper = 2 * d * nn + xd * (m + 1);
+    const long long bid = blockIdx.x;
+    const int c = (int)(bid % d);
+    const long long bk = bid / d;
+    if (bk >= n_bk) return;
+    const double *src = compact + bk * cper;
+    double *dst = full + bk * fper;
+    for (long long q = threadIdx.x; q < (nn >> 1); q += blockDim.x) {
+        const double2_t v0 = *reinterpret_cast<const double2_t *>(src + 2 * q);
+        const double2_t v1 = *reinterpret_cast<const double2_t *>(src + nn + 2 * q);
+        store2(dst + c * nn + 2 * q, v0[0], v0[1], nt);
+        store2(dst + (d + c) * nn + 2 * q, v1[0], v1[1], nt);
+    }
+    if (c == 0) {
+        const long long tail = xd * (m + 1);
+        for (long long q = threadIdx.x; q < (tail >> 1); q += blockDim.x) {
+            const double2_t v = *reinterpret_cast<const double2_t *>(src + 2 * nn + 2 * q);
+            store2(dst + 2 * d * nn + 2 * q, v[0], v[1], nt);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Hessian-of-Lagrangian kernel: one workgroup per (b, k); the d state columns are processed in
+// chunks of nc columns (columns are independent except for the (m+1)(m+2)/2 scalar entries,
+// whose per-chunk partial sums are accumulated in LDS in a fixed order -> deterministic).
+// With M = mu_k (n x d):  A1 = G^T M, A2 = G^T A1, P_l = G_l^T M, Q_l = G^T P_l, R_l = G_l^T A1,
+//                         GD = G D, E_l = G_l D.
+// LDS map: G [LD*n] | Mm | S | D | GD | A1 | A2 (each LD*nc) | P | Q | E (each m*LD*nc) | us | red | acc
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <bool MFMA>
+__global__ __launch_bounds__(256) void pcl_hess_kernel(const KParams p) {
+    extern __shared__ double lds[];
+    const int n = p.n, d = p.d, m = p.m, LD = p.LD, nc = p.nc;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int k = blockIdx.x % p.K, b = blockIdx.x / p.K;
+    const long long xd = (long long)n * d;
+    const int LDc = LD * nc;
+    const int nscal = (m + 1) * (m + 2) / 2;
+    const int nw = nth >> 6, wv = tid >> 6, lane = tid & 63;
+
+    double *G = lds;
+    double *Mm = G + LD * n;
+    double *Sm = Mm + LDc;
+    double *Dm = Sm + LDc;
+    double *GD = Dm + LDc;
+    double *A1 = GD + LDc;
+    double *A2 = A1 + LDc;
+    double *P = A2 + LDc;
+    double *Q = P + m * LDc;
+    double *E = Q + m * LDc;
+    double *us = E + m * LDc;
+    double *red = us + 8 + m;       // nw * nscal
+    double *acc = red + nw * nscal;  // nscal
+
+    const double *Zb = p.Z + (long long)b * p.z_batch_stride;
+    const double *zk = Zb + (long long)k * p.z_dim;
+    const double *zn = zk + p.z_dim;
+    const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+    const double h = zk[p.dt_off];
+    const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0), h6 = h * (1.0 / 6.0);
+    const long long bk = (long long)b * p.K + k;
+    const double *mu = p.mu + bk * xd;
+    double *H = p.hess + bk * p.hess_per;
+    double *H3 = H + nscal, *H4 = H3 + (long long)m * xd, *H5 = H4 + xd, *H6 = H5 + (long long)m * xd;
+
+    build_G(p, p.G0 + (long long)b * p.g0_batch_stride, zk, G, us);
+    for (int e = tid; e < nscal; e += nth) acc[e] = 0.0;
+
+    for (int c0 = 0; c0 < d; c0 += nc) {
+        const int nce = min(nc, d - c0);
+        __syncthreads();  // previous chunk fully consumed (and G / acc initialised)
+        for (int e = tid; e < nce * n; e += nth) {
+            const int c = e / n, i = e % n;
+            const long long g = (long long)(c0 + c) * n + i;
+            const double xn = zn[x_off + g], xc = zk[x_off + g];
+            Sm[i + LD * c] = xn + xc;
+            Dm[i + LD * c] = xn - xc;
+            Mm[i + LD * c] = mu[g];
+        }
+        __syncthreads();
+        // sparse applications: P_l = G_l^T M (CSC columns of G_l), E_l = G_l D (CSR rows)
+        for (int e = tid; e < m * nce * n; e += nth) {
+            const int i = e % n, c = (e / n) % nce, l = e / (n * nce);
+            const int *cp = p.csc_ptr + l * (n + 1);
+            double a = 0.0;
+            for (int q = cp[i]; q < cp[i + 1]; ++q) a += p.csc_val[q] * Mm[p.csc_row[q] + LD * c];
+            P[l * LDc + i + LD * c] = a;
+            const int *rp = p.csr_ptr + l * (n + 1);
+            double a2 = 0.0;
+            for (int q = rp[i]; q < rp[i + 1]; ++q) a2 += p.csr_val[q] * Dm[p.csr_col[q] + LD * c];
+            E[l * LDc + i + LD * c] = a2;
+        }
+        __syncthreads();
+        gemm_lds<MFMA, false>(G, LD, Dm, LD, GD, LD, n, nce, n);
+        gemm_lds<MFMA, true>(G, LD, Mm, LD, A1, LD, n, nce, n);
+        for (int l = 0; l < m; ++l) gemm_lds<MFMA, true>(G, LD, P + l * LDc, LD, Q + l * LDc, LD, n, nce, n);
+        __syncthreads();
+        gemm_lds<MFMA, true>(G, LD, A1, LD, A2, LD, n, nce, n);
+
+        // ---- scalar segments 0..2: per-wave partial sums -> red[w][pidx] ----------------------
+        int pidx = 0;
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j <= i; ++j, ++pidx) {
+                double v = 0.0;
+                for (int e = tid; e < nce * n; e += nth) {
+                    const int idx = (e % n) + LD * (e / n);
+                    v += P[i * LDc + idx] * E[j * LDc + idx] + P[j * LDc + idx] * E[i * LDc + idx];
+                }
+                v = wave_sum(v);
+                if (lane == 0) red[wv * nscal + pidx] = c2 * v;
+            }
+        for (int j = 0; j < m; ++j, ++pidx) {
+            double v1 = 0.0, v2 = 0.0;
+            for (int e = tid; e < nce * n; e += nth) {
+                const int idx = (e % n) + LD * (e / n);
+                v1 += P[j * LDc + idx] * Sm[idx];
+                v2 += P[j * LDc + idx] * GD[idx] + A1[idx] * E[j * LDc + idx];
+            }
+            v1 = wave_sum(v1);
+            v2 = wave_sum(v2);
+            if (lane == 0) red[wv * nscal + pidx] = -0.5 * v1 + h6 * v2;
+        }
+        {
+            double v = 0.0;
+            for (int e = tid; e < nce * n; e += nth) {
+                const int idx = (e % n) + LD * (e / n);
+                v += A1[idx] * GD[idx];
+            }
+            v = wave_sum(v);
+            if (lane == 0) red[wv * nscal + pidx] = v * (1.0 / 6.0);
+        }
+        __syncthreads();  // red complete, A2 complete
+        for (int e = tid; e < nscal; e += nth) {
+            double t = acc[e];
+            for (int w = 0; w < nw; ++w) t += red[w * nscal + e];
+            acc[e] = t;
+        }
+        // ---- vector segments 3..6 for this chunk's columns --------------------------------------
+        for (int e = tid; e < m * nce * n; e += nth) {
+            const int i = e % n, c = (e / n) % nce, l = e / (n * nce);
+            const int *cp = p.csc_ptr + l * (n + 1);
+            double r = 0.0;  // R_l = G_l^T (G^T M)
+            for (int q = cp[i]; q < cp[i + 1]; ++q) r += p.csc_val[q] * A1[p.csc_row[q] + LD * c];
+            const int idx = i + LD * c;
+            const double kt = c2 * (Q[l * LDc + idx] + r);
+            const double pl = -c1 * P[l * LDc + idx];
+            const long long o = (long long)l * xd + (long long)(c0 + c) * n + i;
+            H3[o] = pl - kt;
+            H5[o] = pl + kt;
+        }
+        for (int e = tid; e < nce * n; e += nth) {
+            const int idx = (e % n) + LD * (e / n);
+            const long long o = (long long)c0 * n + e;
+            H4[o] = -0.5 * A1[idx] - h6 * A2[idx];
+            H6[o] = -0.5 * A1[idx] + h6 * A2[idx];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < nscal; e += nth) H[e] = acc[e];
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_create_error;
+
+struct pcl_ctx {
+    pcl_desc desc;
+    int n, K;
+    long long x_dim;
+    std::vector<int32_t> x_offs;
+    int device;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // device copies
+    double *dG0 = nullptr, *ducoef = nullptr, *dcsr_val = nullptr, *dcsc_val = nullptr;
+    int *dupos = nullptr, *dcsr_ptr = nullptr, *dcsr_col = nullptr, *dcsc_ptr = nullptr, *dcsc_row = nullptr, *dxoffs = nullptr;
+    int n_upos = 0;
+    // staging for the host-pointer entry points
+    double *dZ = nullptr, *dmu = nullptr, *ddelta = nullptr, *dvals = nullptr, *dhess = nullptr;
+    // options
+    int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0;
+    int max_lds = 0;
+    int n_cu = 0;
+    mutable std::string err;
+};
+
+static int fail(const pcl_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(ctx, PCL_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static long long jac_per_full(const pcl_ctx *c) {
+    return 2LL * c->desc.d * c->n * c->n + c->x_dim * (c->desc.n_drives + 1);
+}
+static long long jac_per_compact(const pcl_ctx *c) { return 2LL * c->n * c->n + c->x_dim * (c->desc.n_drives + 1); }
+static long long hess_per(const pcl_ctx *c) {
+    const long long m = c->desc.n_drives;
+    return (m + 1) * (m + 2) / 2 + 2 * c->x_dim * (m + 1);
+}
+static long long z_len(const pcl_ctx *c) {
+    return (long long)c->desc.z_dim * c->desc.N * (c->desc.batch_mode == PCL_BATCH_TRAJ ? c->desc.batch : 1);
+}
+static long long n_rows(const pcl_ctx *c) { return (long long)c->desc.batch * c->x_dim * c->K; }
+
+extern "C" const char *pcl_version(void) { return PCL_VERSION_STR; }
+
+extern "C" const char *pcl_last_error(const pcl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+template <class T>
+static int upload(pcl_ctx *ctx, T **dst, const std::vector<T> &src) {
+    const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIP_TRY(ctx, hipMalloc((void **)dst, bytes));
+    if (!src.empty()) HIP_TRY(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return PCL_OK;
+}
+
+extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
+    if (!out) return fail(nullptr, PCL_EINVAL, "pcl_create: out is NULL");
+    *out = nullptr;
+    if (!dsc) return fail(nullptr, PCL_EINVAL, "pcl_create: desc is NULL");
+    if (dsc->struct_size != (int32_t)sizeof(pcl_desc))
+        return fail(nullptr, PCL_EINVAL, "pcl_create: desc.struct_size=%d, library expects %zu (ABI mismatch)",
+                    dsc->struct_size, sizeof(pcl_desc));
+    const int d = dsc->d, m = dsc->n_drives, n = 2 * d;
+    if (d < 1 || m < 0 || dsc->N < 2 || dsc->batch < 1)
+        return fail(nullptr, PCL_EINVAL, "pcl_create: need d>=1, n_drives>=0, N>=2, batch>=1 (got d=%d m=%d N=%d batch=%d)", d,
+                    m, dsc->N, dsc->batch);
+    if (d > PCL_MAX_D) return fail(nullptr, PCL_ESHAPE, "pcl_create: d=%d exceeds PCL_MAX_D=%d (LDS-resident tiles)", d, PCL_MAX_D);
+    if (m > 24) return fail(nullptr, PCL_ESHAPE, "pcl_create: n_drives=%d exceeds 24", m);
+    if (dsc->pade_order != 4)
+        return fail(nullptr, PCL_ENOTIMPL, "pcl_create: pade_order=%d; only the order-4 (2,2) Pade residual is implemented",
+                    dsc->pade_order);
+    if (dsc->index_base != 0 && dsc->index_base != 1) return fail(nullptr, PCL_EINVAL, "pcl_create: index_base must be 0 or 1");
+    if (dsc->batch_mode != PCL_BATCH_MEMBERS && dsc->batch_mode != PCL_BATCH_TRAJ)
+        return fail(nullptr, PCL_EINVAL, "pcl_create: unknown batch_mode %d", dsc->batch_mode);
+    if (!dsc->G0 || (m > 0 && !dsc->Gj) || !dsc->x_offs) return fail(nullptr, PCL_EINVAL, "pcl_create: G0/Gj/x_offs must be non-NULL");
+    const long long x_dim = 2LL * d * d;
+    const int n_off = dsc->batch_mode == PCL_BATCH_MEMBERS ? dsc->batch : 1;
+    for (int i = 0; i < n_off; ++i)
+        if (dsc->x_offs[i] < 0 || dsc->x_offs[i] + x_dim > dsc->z_dim)
+            return fail(nullptr, PCL_EINVAL, "pcl_create: x_offs[%d]=%d with x_dim=%lld does not fit z_dim=%d", i, dsc->x_offs[i],
+                        x_dim, dsc->z_dim);
+    if (dsc->u_off < 0 || dsc->u_off + m > dsc->z_dim || dsc->dt_off < 0 || dsc->dt_off >= dsc->z_dim)
+        return fail(nullptr, PCL_EINVAL, "pcl_create: u_off/dt_off outside the knot (z_dim=%d)", dsc->z_dim);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, PCL_EHIP, "pcl_create: no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (dsc->device_id < 0 || dsc->device_id >= ndev) return fail(nullptr, PCL_EINVAL, "pcl_create: device_id %d of %d", dsc->device_id, ndev);
+
+    pcl_ctx *ctx = new (std::nothrow) pcl_ctx();
+    if (!ctx) return fail(nullptr, PCL_ENOMEM, "pcl_create: out of host memory");
+    ctx->desc = *dsc;
+    ctx->n = n;
+    ctx->K = dsc->N - 1;
+    ctx->x_dim = x_dim;
+    ctx->x_offs.assign(dsc->x_offs, dsc->x_offs + n_off);
+    ctx->desc.x_offs = nullptr;
+    ctx->desc.G0 = ctx->desc.Gj = nullptr;
+    ctx->device = dsc->device_id;
+
+#define CREATE_TRY(expr)                                                  \
+    do {                                                                  \
+        int rc_ = (expr);                                                 \
+        if (rc_ != PCL_OK) {                                              \
+            g_create_error = ctx->err;                                    \
+            pcl_destroy(ctx);                                             \
+            return rc_;                                                   \
+        }                                                                 \
+    } while (0)
+#define CREATE_HIP(expr)                                                                               \
+    do {                                                                                               \
+        hipError_t e2_ = (expr);                                                                       \
+        if (e2_ != hipSuccess) {                                                                       \
+            fail(nullptr, PCL_EHIP, "pcl_create: %s: %s", #expr, hipGetErrorString(e2_));              \
+            pcl_destroy(ctx);                                                                          \
+            return PCL_EHIP;                                                                           \
+        }                                                                                              \
+    } while (0)
+
+    CREATE_HIP(hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    CREATE_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fail(nullptr, PCL_EHIP, "pcl_create: device %d is %s; this library is built for gfx950 only", ctx->device, prop.gcnArchName);
+        pcl_destroy(ctx);
+        return PCL_EHIP;
+    }
+    ctx->max_lds = (int)prop.maxSharedMemoryPerMultiProcessor;
+    ctx->n_cu = prop.multiProcessorCount;
+    CREATE_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+
+    // --- drive structures: union pattern (+ coefficient table), CSR and CSC of every G_l ------
+    const size_t nn = (size_t)n * n;
+    std::vector<int> upos;
+    std::vector<double> ucoef;
+    for (size_t pz = 0; pz < nn; ++pz) {
+        bool any = false;
+        for (int l = 0; l < m; ++l) any |= dsc->Gj[l * nn + pz] != 0.0;
+        if (any) {
+            upos.push_back((int)pz);
+            for (int l = 0; l < m; ++l) ucoef.push_back(dsc->Gj[l * nn + pz]);
+        }
+    }
+    ctx->n_upos = (int)upos.size();
+    std::vector<int> csr_ptr((size_t)std::max(m, 1) * (n + 1), 0), csr_col, csc_ptr((size_t)std::max(m, 1) * (n + 1), 0), csc_row;
+    std::vector<double> csr_val, csc_val;
+    for (int l = 0; l < m; ++l) {
+        const double *A = dsc->Gj + l * nn;  // column-major: A[i + n*j]
+        for (int i = 0; i < n; ++i) {
+            csr_ptr[(size_t)l * (n + 1) + i] = (int)csr_col.size();
+            for (int j = 0; j < n; ++j)
+                if (A[i + (size_t)n * j] != 0.0) {
+                    csr_col.push_back(j);
+                    csr_val.push_back(A[i + (size_t)n * j]);
+                }
+        }
+        csr_ptr[(size_t)l * (n + 1) + n] = (int)csr_col.size();
+        for (int j = 0; j < n; ++j) {
+            csc_ptr[(size_t)l * (n + 1) + j] = (int)csc_row.size();
+            for (int i = 0; i < n; ++i)
+                if (A[i + (size_t)n * j] != 0.0) {
+                    csc_row.push_back(i);
+                    csc_val.push_back(A[i + (size_t)n * j]);
+                }
+        }
+        csc_ptr[(size_t)l * (n + 1) + n] = (int)csc_row.size();
+    }
+    std::vector<double> g0(dsc->G0, dsc->G0 + nn * (dsc->per_member_G0 ? dsc->batch : 1));
+    CREATE_TRY(upload(ctx, &ctx->dG0, g0));
+    CREATE_TRY(upload(ctx, &ctx->dupos, upos));
+    CREATE_TRY(upload(ctx, &ctx->ducoef, ucoef));
+    CREATE_TRY(upload(ctx, &ctx->dcsr_ptr, csr_ptr));
+    CREATE_TRY(upload(ctx, &ctx->dcsr_col, csr_col));
+    CREATE_TRY(upload(ctx, &ctx->dcsr_val, csr_val));
+    CREATE_TRY(upload(ctx, &ctx->dcsc_ptr, csc_ptr));
+    CREATE_TRY(upload(ctx, &ctx->dcsc_row, csc_row));
+    CREATE_TRY(upload(ctx, &ctx->dcsc_val, csc_val));
+    std::vector<int> xo(ctx->x_offs.begin(), ctx->x_offs.end());
+    CREATE_TRY(upload(ctx, &ctx->dxoffs, xo));
+#undef CREATE_TRY
+#undef CREATE_HIP
+    *out = ctx;
+    return PCL_OK;
+}
+
+extern "C" void pcl_destroy(pcl_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    void *ptrs[] = {ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
+                    ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int pcl_constraint_dim(const pcl_ctx *ctx, int64_t *x_dim, int64_t *rows, int64_t *cols) {
+    if (!ctx) return PCL_EINVAL;
+    if (x_dim) *x_dim = ctx->x_dim;
+    if (rows) *rows = n_rows(ctx);
+    if (cols) *cols = z_len(ctx) + ctx->desc.global_dim;
+    return PCL_OK;
+}
+extern "C" int pcl_jac_nnz(const pcl_ctx *ctx, int64_t *nnz, int64_t *per) {
+    if (!ctx) return PCL_EINVAL;
+    if (per) *per = jac_per_full(ctx);
+    if (nnz) *nnz = jac_per_full(ctx) * ctx->desc.batch * ctx->K;
+    return PCL_OK;
+}
+extern "C" int pcl_jac_compact_nnz(const pcl_ctx *ctx, int64_t *nnz, int64_t *per) {
+    if (!ctx) return PCL_EINVAL;
+    if (per) *per = jac_per_compact(ctx);
+    if (nnz) *nnz = jac_per_compact(ctx) * ctx->desc.batch * ctx->K;
+    return PCL_OK;
+}
+extern "C" int pcl_hess_nnz(const pcl_ctx *ctx, int64_t *nnz, int64_t *per) {
+    if (!ctx) return PCL_EINVAL;
+    if (per) *per = hess_per(ctx);
+    if (nnz) *nnz = hess_per(ctx) * ctx->desc.batch * ctx->K;
+    return PCL_OK;
+}
+
+template <class I>
+static int jac_structure_impl(const pcl_ctx *ctx, I *rows, I *cols) {
+    if (!ctx) return PCL_EINVAL;
+    if (!rows || !cols) return fail(ctx, PCL_EINVAL, "pcl_jac_structure: NULL output");
+    const pcl_desc &D = ctx->desc;
+    const long long n = ctx->n, d = D.d, m = D.n_drives, xd = ctx->x_dim, zd = D.z_dim, base = D.index_base;
+    const long long per = jac_per_full(ctx);
+    for (long long b = 0; b < D.batch; ++b) {
+        const long long xo = ctx->x_offs[D.batch_mode == PCL_BATCH_MEMBERS ? b : 0];
+        const long long voff = D.batch_mode == PCL_BATCH_TRAJ ? b * zd * D.N : 0;
+        for (long long k = 0; k < ctx->K; ++k) {
+            I *r = rows + (b * ctx->K + k) * per, *c = cols + (b * ctx->K + k) * per;
+            const long long r0 = b * xd * ctx->K + k * xd + base;
+            long long p = 0;
+            for (int seg = 0; seg < 2; ++seg) {
+                const long long cb = voff + (k + seg) * zd + xo + base;
+                for (long long cc = 0; cc < d; ++cc)
+                    for (long long j = 0; j < n; ++j)
+                        for (long long i = 0; i < n; ++i, ++p) {
+                            r[p] = (I)(r0 + cc * n + i);
+                            c[p] = (I)(cb + cc * n + j);
+                        }
+            }
+            for (long long l = 0; l <= m; ++l) {
+                const long long col = voff + k * zd + (l < m ? D.u_off + l : D.dt_off) + base;
+                for (long long q = 0; q < xd; ++q, ++p) {
+                    r[p] = (I)(r0 + q);
+                    c[p] = (I)col;
+                }
+            }
+        }
+    }
+    return PCL_OK;
+}
+extern "C" int pcl_jac_structure(const pcl_ctx *ctx, int32_t *rows, int32_t *cols) {
+    if (ctx && (n_rows(ctx) + 1 > INT32_MAX || z_len(ctx) + ctx->desc.global_dim + 1 > INT32_MAX))
+        return fail(ctx, PCL_ESHAPE, "pcl_jac_structure: indices exceed int32; use pcl_jac_structure_i64");
+    return jac_structure_impl<int32_t>(ctx, rows, cols);
+}
+extern "C" int pcl_jac_structure_i64(const pcl_ctx *ctx, int64_t *rows, int64_t *cols) {
+    return jac_structure_impl<int64_t>(ctx, rows, cols);
+}
+
+template <class I>
+static int hess_structure_impl(const pcl_ctx *ctx, I *rows, I *cols) {
+    if (!ctx) return PCL_EINVAL;
+    if (!rows || !cols) return fail(ctx, PCL_EINVAL, "pcl_hess_structure: NULL output");
+    const pcl_desc &D = ctx->desc;
+    const long long m = D.n_drives, xd = ctx->x_dim, zd = D.z_dim, base = D.index_base;
+    const long long per = hess_per(ctx);
+    for (long long b = 0; b < D.batch; ++b) {
+        const long long xo = ctx->x_offs[D.batch_mode == PCL_BATCH_MEMBERS ? b : 0];
+        const long long voff = D.batch_mode == PCL_BATCH_TRAJ ? b * zd * D.N : 0;
+        for (long long k = 0; k < ctx->K; ++k) {
+            I *r = rows + (b * ctx->K + k) * per, *c = cols + (b * ctx->K + k) * per;
+            const long long uk = voff + k * zd + D.u_off, hk = voff + k * zd + D.dt_off;
+            const long long xk = voff + k * zd + xo, xn = voff + (k + 1) * zd + xo;
+            long long p = 0;
+            auto put = [&](long long a, long long bb) {
+                r[p] = (I)(std::max(a, bb) + base);
+                c[p] = (I)(std::min(a, bb) + base);
+                ++p;
+            };
+            for (long long i = 0; i < m; ++i)
+                for (long long j = 0; j <= i; ++j) put(uk + i, uk + j);
+            for (long long j = 0; j < m; ++j) put(hk, uk + j);
+            put(hk, hk);
+            for (long long l = 0; l < m; ++l)
+                for (long long q = 0; q < xd; ++q) put(uk + l, xk + q);
+            for (long long q = 0; q < xd; ++q) put(hk, xk + q);
+            for (long long l = 0; l < m; ++l)
+                for (long long q = 0; q < xd; ++q) put(xn + q, uk + l);
+            for (long long q = 0; q < xd; ++q) put(xn + q, hk);
+        }
+    }
+    return PCL_OK;
+}
+extern "C" int pcl_hess_structure(const pcl_ctx *ctx, int32_t *rows, int32_t *cols) {
+    if (ctx && z_len(ctx) + ctx->desc.global_dim + 1 > INT32_MAX)
+        return fail(ctx, PCL_ESHAPE, "pcl_hess_structure: indices exceed int32; use pcl_hess_structure_i64");
+    return hess_structure_impl<int32_t>(ctx, rows, cols);
+}
+extern "C" int pcl_hess_structure_i64(const pcl_ctx *ctx, int64_t *rows, int64_t *cols) {
+    return hess_structure_impl<int64_t>(ctx, rows, cols);
+}
+
+// --- launch helpers -------------------------------------------------------------------------
+static int lds_ld(int d) { return 2 * (d | 1); }  // 2*LD = 4*odd (mod 64): conflict-free b-operand reads
+
+static void fill_params(const pcl_ctx *ctx, KParams &p) {
+    memset(&p, 0, sizeof p);
+    const pcl_desc &D = ctx->desc;
+    p.G0 = ctx->dG0;
+    p.upos = ctx->dupos;
+    p.ucoef = ctx->ducoef;
+    p.n_upos = ctx->n_upos;
+    p.csr_ptr = ctx->dcsr_ptr;
+    p.csr_col = ctx->dcsr_col;
+    p.csr_val = ctx->dcsr_val;
+    p.csc_ptr = ctx->dcsc_ptr;
+    p.csc_row = ctx->dcsc_row;
+    p.csc_val = ctx->dcsc_val;
+    p.x_offs = ctx->dxoffs;
+    p.z_batch_stride = D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0;
+    p.g0_batch_stride = D.per_member_G0 ? (long long)ctx->n * ctx->n : 0;
+    p.d = D.d;
+    p.n = ctx->n;
+    p.m = D.n_drives;
+    p.K = ctx->K;
+    p.z_dim = D.z_dim;
+    p.u_off = D.u_off;
+    p.dt_off = D.dt_off;
+    p.batch = D.batch;
+    p.LD = lds_ld(D.d);
+    p.nt = (int)ctx->opt_nt;
+    p.hess_per = hess_per(ctx);
+}
+
+static size_t fused_lds_bytes(const KParams &p, bool jac) {
+    const size_t ncols1 = jac ? (size_t)(2 + p.m) * p.nc : 2 * (size_t)p.nc;
+    size_t dbl = (size_t)p.LD * p.n * (jac ? 2 : 1) + 2 * p.LD * ncols1 + 2 * (size_t)p.LD * p.nc + 8 + p.m;
+    return dbl * sizeof(double);
+}
+
+static int choose_cols_per_slice(const pcl_ctx *ctx, bool jac) {
+    const int d = ctx->desc.d;
+    if (ctx->opt_cols_per_slice > 0) return (int)std::min<int64_t>(ctx->opt_cols_per_slice, d);
+    if (!jac) return std::min(d, 16);
+    // Enough workgroups to cover the chip a few times over, but as few slices as possible
+    // (every slice recomputes G^2): aim at >= 3 workgroups per CU.
+    const long long bk = (long long)ctx->desc.batch * ctx->K;
+    const long long want = 3LL * std::max(ctx->n_cu, 1);
+    int best = 1;
+    for (int nc = d; nc >= 1; --nc) {
+        const long long S = (d + nc - 1) / nc;
+        if (bk * S >= want || nc == 1) {
+            best = nc;
+            break;
+        }
+    }
+    return std::max(best, 1);
+}
+
+static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *jac, bool compact) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    KParams p;
+    fill_params(ctx, p);
+    p.Z = Z;
+    p.delta = delta;
+    p.jac = jac;
+    p.compact = compact ? 1 : 0;
+    p.jac_per = compact ? jac_per_compact(ctx) : jac_per_full(ctx);
+    const bool want_jac = jac != nullptr;
+    p.nc = choose_cols_per_slice(ctx, want_jac);
+    size_t lds = fused_lds_bytes(p, want_jac);
+    while (lds > (size_t)ctx->max_lds && p.nc > 1) {
+        p.nc = (p.nc + 1) / 2;
+        lds = fused_lds_bytes(p, want_jac);
+    }
+    if (lds > (size_t)ctx->max_lds) return fail(ctx, PCL_ESHAPE, "fused kernel needs %zu B of LDS (> %d)", lds, ctx->max_lds);
+    p.S = (p.d + p.nc - 1) / p.nc;
+    const long long grid = (long long)p.batch * p.K * p.S;
+    if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "grid too large");
+    const bool mf = ctx->opt_use_mfma != 0;
+    auto kern = want_jac ? (mf ? pcl_fused_kernel<true, true> : pcl_fused_kernel<true, false>)
+                         : (mf ? pcl_fused_kernel<false, true> : pcl_fused_kernel<false, false>);
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+static size_t hess_lds_bytes(const KParams &p) {
+    const size_t nscal = (size_t)(p.m + 1) * (p.m + 2) / 2;
+    return ((size_t)p.LD * p.n + (6 + 3 * (size_t)p.m) * p.LD * p.nc + 8 + p.m + 5 * nscal) * sizeof(double);
+}
+
+static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *hess) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    KParams p;
+    fill_params(ctx, p);
+    p.Z = Z;
+    p.mu = mu;
+    p.hess = hess;
+    // column chunk: as many columns as fit in half the LDS (two workgroups per CU)
+    p.nc = p.d;
+    while (p.nc > 1 && hess_lds_bytes(p) > (size_t)ctx->max_lds / 2) p.nc = (p.nc + 1) / 2;
+    const size_t lds = hess_lds_bytes(p);
+    if (lds > (size_t)ctx->max_lds)
+        return fail(ctx, PCL_ESHAPE, "Hessian kernel needs %zu B of LDS (> %d) for d=%d, m=%d", lds, ctx->max_lds, p.d, p.m);
+    const long long grid = (long long)p.batch * p.K;
+    const bool mf = ctx->opt_use_mfma != 0;
+    auto kern = mf ? pcl_hess_kernel<true> : pcl_hess_kernel<false>;
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
+// --- device-pointer API -----------------------------------------------------------------------
+extern "C" int pcl_set_stream(pcl_ctx *ctx, void *s) {
+    if (!ctx) return PCL_EINVAL;
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return PCL_OK;
+}
+extern "C" int pcl_sync(pcl_ctx *ctx) {
+    if (!ctx) return PCL_EINVAL;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+extern "C" int pcl_eval_dev(pcl_ctx *ctx, const double *Z, double *delta) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !delta) return fail(ctx, PCL_EINVAL, "pcl_eval_dev: NULL pointer");
+    return launch_fused(ctx, Z, delta, nullptr, false);
+}
+extern "C" int pcl_eval_jac_dev(pcl_ctx *ctx, const double *Z, double *delta, double *vals) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !vals) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_dev: NULL pointer");
+    return launch_fused(ctx, Z, delta, vals, false);
+}
+extern "C" int pcl_eval_jac_compact_dev(pcl_ctx *ctx, const double *Z, double *delta, double *compact) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !compact) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_compact_dev: NULL pointer");
+    return launch_fused(ctx, Z, delta, compact, true);
+}
+extern "C" int pcl_jac_expand_dev(pcl_ctx *ctx, const double *compact, double *vals) {
+    if (!ctx) return PCL_EINVAL;
+    if (!compact || !vals) return fail(ctx, PCL_EINVAL, "pcl_jac_expand_dev: NULL pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long n_bk = (long long)ctx->desc.batch * ctx->K;
+    const long long grid = n_bk * ctx->desc.d;
+    hipLaunchKernelGGL(pcl_expand_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, compact, vals, ctx->desc.d, ctx->n,
+                       ctx->desc.n_drives, n_bk, (int)ctx->opt_nt);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCL_OK;
+}
+extern "C" int pcl_hess_dev(pcl_ctx *ctx, const double *Z, const double *mu, double *vals) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !mu || !vals) return fail(ctx, PCL_EINVAL, "pcl_hess_dev: NULL pointer");
+    return launch_hess(ctx, Z, mu, vals);
+}
+
+// --- host-pointer API (staging buffers owned by the context) --------------------------------------
+static int ensure(pcl_ctx *ctx, double **buf, long long count) {
+    if (*buf) return PCL_OK;
+    hipError_t e = hipMalloc((void **)buf, (size_t)count * sizeof(double));
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? PCL_ENOMEM : PCL_EHIP, "hipMalloc(%lld doubles): %s", count, hipGetErrorString(e));
+    return PCL_OK;
+}
+#define TRY(expr)                 \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != PCL_OK) return rc_; \
+    } while (0)
+
+static int host_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *vals) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || (!delta && !vals)) return fail(ctx, PCL_EINVAL, "NULL pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long nv = jac_per_full(ctx) * ctx->desc.batch * ctx->K;
+    TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
+    TRY(ensure(ctx, &ctx->ddelta, n_rows(ctx)));
+    if (vals) TRY(ensure(ctx, &ctx->dvals, nv));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dZ, Z, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    TRY(launch_fused(ctx, ctx->dZ, ctx->ddelta, vals ? ctx->dvals : nullptr, false));
+    if (delta) HIP_TRY(ctx, hipMemcpyAsync(delta, ctx->ddelta, n_rows(ctx) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (vals) HIP_TRY(ctx, hipMemcpyAsync(vals, ctx->dvals, nv * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+extern "C" int pcl_eval(pcl_ctx *ctx, const double *Z, double *delta) {
+    if (ctx && !delta) return fail(ctx, PCL_EINVAL, "pcl_eval: delta is NULL");
+    return host_eval_jac(ctx, Z, delta, nullptr);
+}
+extern "C" int pcl_jac(pcl_ctx *ctx, const double *Z, double *vals) {
+    if (ctx && !vals) return fail(ctx, PCL_EINVAL, "pcl_jac: vals is NULL");
+    return host_eval_jac(ctx, Z, nullptr, vals);
+}
+extern "C" int pcl_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *vals) {
+    if (ctx && (!delta || !vals)) return fail(ctx, PCL_EINVAL, "pcl_eval_jac: NULL output");
+    return host_eval_jac(ctx, Z, delta, vals);
+}
+extern "C" int pcl_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *vals) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !mu || !vals) return fail(ctx, PCL_EINVAL, "pcl_hess: NULL pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long nv = hess_per(ctx) * ctx->desc.batch * ctx->K;
+    TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
+    TRY(ensure(ctx, &ctx->dmu, n_rows(ctx)));
+    TRY(ensure(ctx, &ctx->dhess, nv));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dZ, Z, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dmu, mu, n_rows(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    TRY(launch_hess(ctx, ctx->dZ, ctx->dmu, ctx->dhess));
+    HIP_TRY(ctx, hipMemcpyAsync(vals, ctx->dhess, nv * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+
+// --- options ---------------------------------------------------------------------------------
+extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
+    if (!ctx || !key) return PCL_EINVAL;
+    if (!strcmp(key, "cols_per_slice")) {
+        if (v < 0) return fail(ctx, PCL_EINVAL, "cols_per_slice must be >= 0");
+        ctx->opt_cols_per_slice = v;
+    } else if (!strcmp(key, "use_mfma"))
+        ctx->opt_use_mfma = v != 0;
+    else if (!strcmp(key, "nt_stores"))
+        ctx->opt_nt = v != 0;
+    else
+        return fail(ctx, PCL_EINVAL, "unknown option '%s'", key);
+    return PCL_OK;
+}
+extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
+    if (!ctx || !key || !v) return PCL_EINVAL;
+    if (!strcmp(key, "cols_per_slice"))
+        *v = ctx->opt_cols_per_slice;
+    else if (!strcmp(key, "use_mfma"))
+        *v = ctx->opt_use_mfma;
+    else if (!strcmp(key, "nt_stores"))
+        *v = ctx->opt_nt;
+    else if (!strcmp(key, "effective_cols_per_slice"))
+        *v = choose_cols_per_slice(ctx, true);
+    else if (!strcmp(key, "n_cu"))
+        *v = ctx->n_cu;
+    else
+        return fail(ctx, PCL_EINVAL, "unknown option '%s'", key);
+    return PCL_OK;
+}

@@ -1,0 +1,352 @@
+"""Host-side mirror of the reference's integrator plug-in surface for the unitary
+Pade collocation constraint, backed by libpiccolo_hip.so (HIP kernels, gfx950).
+
+What the reference calls (Piccolo.jl v2.0.2; [EXT] = DirectTrajOpt.jl):
+
+  BilinearIntegrator(qtraj::UnitaryTrajectory, N)          src/control/integrators.jl:35-51
+  BilinearIntegrator(qtraj::SamplingTrajectory, N)         src/control/integrators.jl:134-162
+  B.dim, B.x_dim, B.x_name / B.x_names, B.f(x', x, u, dt)  src/control/integrators.jl:307-309,525,552
+  evaluate!(delta, B, traj) [EXT]                          src/control/integrators.jl:311,777
+  eval_jacobian(B, traj) [EXT]  -> (B.dim, traj.dim*traj.N + traj.global_dim)   :780-783
+  hessian_structure / Hessian of the Lagrangian [EXT]      test/aqua.jl:6-9
+
+Here the same names exist as Python callables (``evaluate_`` for ``evaluate!``).
+All arithmetic happens on the GPU through the C ABI; nothing in this module
+computes a residual or a Jacobian on the host, and nothing falls back to a CPU
+implementation when the library or the device is missing.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import PCL_BATCH_MEMBERS, PCL_BATCH_TRAJ, PclError
+from .trajectory import STATE, TIMESTEP, NamedTrajectory
+
+__all__ = [
+    "HipPadeIntegrator", "HipPadeMultistart", "BilinearIntegrator", "evaluate_", "eval_jacobian",
+    "jacobian_structure", "hessian_structure", "eval_hessian_of_lagrangian", "PclError",
+]  # fmt: skip
+
+
+def _colmajor(A):
+    """numpy [i, j] matrix (or stack of matrices) -> flat column-major float64 buffer."""
+    A = np.asarray(A, dtype=np.float64)
+    return np.ascontiguousarray(np.swapaxes(A, -1, -2)).reshape(-1)
+
+
+def _ptr(a):
+    """Address of a host numpy array or a torch (device) tensor."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        if a.dtype != np.float64 or not a.flags.c_contiguous:
+            raise TypeError("expected a C-contiguous float64 array")
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):  # torch tensor
+        if str(a.dtype) != "torch.float64" or not a.is_contiguous():
+            raise TypeError("expected a contiguous float64 tensor")
+        return a.data_ptr()
+    raise TypeError("unsupported buffer type %r" % type(a))
+
+
+class _PclContext:
+    """Owns one ``pcl_ctx`` (one GPU, one stream)."""
+
+    def __init__(self, *, d, m, N, z_dim, u_off, dt_off, x_offs, G0, Gj, batch, batch_mode, per_member_G0=False,
+                 global_dim=0, device=0, index_base=0, pade_order=4):  # fmt: skip
+        self._L = _lib.load()
+        self._h = None
+        n = 2 * d
+        g0 = _colmajor(G0)
+        gj = _colmajor(Gj) if m else np.zeros(1)
+        if g0.size != n * n * (batch if per_member_G0 else 1):
+            raise ValueError("G0 has %d entries, expected %d" % (g0.size, n * n * (batch if per_member_G0 else 1)))
+        if m and gj.size != m * n * n:
+            raise ValueError("Gj has %d entries, expected %d" % (gj.size, m * n * n))
+        xo = np.ascontiguousarray(np.asarray(x_offs, dtype=np.int32).reshape(-1))
+        desc = _lib.pcl_desc(
+            struct_size=ctypes.sizeof(_lib.pcl_desc), d=d, n_drives=m, N=N, z_dim=z_dim, u_off=u_off, dt_off=dt_off,
+            batch=batch, batch_mode=batch_mode, pade_order=pade_order, device_id=device, index_base=index_base,
+            per_member_G0=int(bool(per_member_G0)), reserved=0, global_dim=global_dim,
+            G0=g0.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+            Gj=gj.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+            x_offs=xo.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+        )  # fmt: skip
+        h = ctypes.c_void_p()
+        rc = self._L.pcl_create(ctypes.byref(desc), ctypes.byref(h))
+        if rc != 0:
+            raise PclError(rc, (self._L.pcl_last_error(None) or b"").decode())
+        self._h = h
+        self.d, self.n, self.m, self.N, self.K, self.z_dim = d, n, m, N, N - 1, z_dim
+        self.batch, self.batch_mode = batch, batch_mode
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self._chk(self._L.pcl_constraint_dim(h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        self.x_dim, self.n_rows, self.n_cols = a.value, b.value, c.value
+        self._chk(self._L.pcl_jac_nnz(h, ctypes.byref(a), ctypes.byref(b)))
+        self.jac_nnz, self.jac_per = a.value, b.value
+        self._chk(self._L.pcl_hess_nnz(h, ctypes.byref(a), ctypes.byref(b)))
+        self.hess_nnz, self.hess_per = a.value, b.value
+        self._chk(self._L.pcl_jac_compact_nnz(h, ctypes.byref(a), ctypes.byref(b)))
+        self.compact_nnz, self.compact_per = a.value, b.value
+        self.z_len = z_dim * N * (batch if batch_mode == PCL_BATCH_TRAJ else 1)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PclError(rc, (self._L.pcl_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pcl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- structure ----------------------------------------------------------------------------
+    def jac_structure(self, dtype=np.int64):
+        rows, cols = np.empty(self.jac_nnz, dtype), np.empty(self.jac_nnz, dtype)
+        if dtype == np.int32:
+            p = ctypes.POINTER(ctypes.c_int32)
+            self._chk(self._L.pcl_jac_structure(self._h, rows.ctypes.data_as(p), cols.ctypes.data_as(p)))
+        else:
+            p = ctypes.POINTER(ctypes.c_int64)
+            self._chk(self._L.pcl_jac_structure_i64(self._h, rows.ctypes.data_as(p), cols.ctypes.data_as(p)))
+        return rows, cols
+
+    def hess_structure(self, dtype=np.int64):
+        rows, cols = np.empty(self.hess_nnz, dtype), np.empty(self.hess_nnz, dtype)
+        if dtype == np.int32:
+            p = ctypes.POINTER(ctypes.c_int32)
+            self._chk(self._L.pcl_hess_structure(self._h, rows.ctypes.data_as(p), cols.ctypes.data_as(p)))
+        else:
+            p = ctypes.POINTER(ctypes.c_int64)
+            self._chk(self._L.pcl_hess_structure_i64(self._h, rows.ctypes.data_as(p), cols.ctypes.data_as(p)))
+        return rows, cols
+
+    # -- host-pointer calls ---------------------------------------------------------------------
+    def _z(self, Z):
+        Z = np.ascontiguousarray(Z, dtype=np.float64).reshape(-1)
+        if Z.size != self.z_len:
+            raise ValueError("trajectory buffer has %d entries, expected %d" % (Z.size, self.z_len))
+        return Z
+
+    def eval(self, Z, delta=None):
+        Z = self._z(Z)
+        delta = np.empty(self.n_rows) if delta is None else delta
+        self._chk(self._L.pcl_eval(self._h, _ptr(Z), _ptr(delta)))
+        return delta
+
+    def eval_jac(self, Z, delta=None, vals=None):
+        Z = self._z(Z)
+        delta = np.empty(self.n_rows) if delta is None else delta
+        vals = np.empty(self.jac_nnz) if vals is None else vals
+        self._chk(self._L.pcl_eval_jac(self._h, _ptr(Z), _ptr(delta), _ptr(vals)))
+        return delta, vals
+
+    def jac(self, Z, vals=None):
+        Z = self._z(Z)
+        vals = np.empty(self.jac_nnz) if vals is None else vals
+        self._chk(self._L.pcl_jac(self._h, _ptr(Z), _ptr(vals)))
+        return vals
+
+    def hess(self, Z, mu, vals=None):
+        Z = self._z(Z)
+        mu = np.ascontiguousarray(mu, dtype=np.float64).reshape(-1)
+        if mu.size != self.n_rows:
+            raise ValueError("mu has %d entries, expected %d" % (mu.size, self.n_rows))
+        vals = np.empty(self.hess_nnz) if vals is None else vals
+        self._chk(self._L.pcl_hess(self._h, _ptr(Z), _ptr(mu), _ptr(vals)))
+        return vals
+
+    # -- device-pointer calls (torch tensors on this context's GPU; asynchronous) ----------------
+    def set_stream(self, stream_handle):
+        self._chk(self._L.pcl_set_stream(self._h, ctypes.c_void_p(stream_handle or 0)))
+
+    def sync(self):
+        self._chk(self._L.pcl_sync(self._h))
+
+    def eval_dev(self, Z, delta):
+        self._chk(self._L.pcl_eval_dev(self._h, _ptr(Z), _ptr(delta)))
+
+    def eval_jac_dev(self, Z, delta, vals):
+        self._chk(self._L.pcl_eval_jac_dev(self._h, _ptr(Z), _ptr(delta), _ptr(vals)))
+
+    def eval_jac_compact_dev(self, Z, delta, compact):
+        self._chk(self._L.pcl_eval_jac_compact_dev(self._h, _ptr(Z), _ptr(delta), _ptr(compact)))
+
+    def jac_expand_dev(self, compact, vals):
+        self._chk(self._L.pcl_jac_expand_dev(self._h, _ptr(compact), _ptr(vals)))
+
+    def hess_dev(self, Z, mu, vals):
+        self._chk(self._L.pcl_hess_dev(self._h, _ptr(Z), _ptr(mu), _ptr(vals)))
+
+    def set_option(self, key, value):
+        self._chk(self._L.pcl_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = ctypes.c_int64()
+        self._chk(self._L.pcl_get_option(self._h, key.encode(), ctypes.byref(v)))
+        return v.value
+
+
+class HipPadeIntegrator:
+    """Drop-in for ``DirectTrajOpt.BilinearIntegrator`` on the unitary path.
+
+    One integrator object covers one state component (``x_name``) or, for a
+    ``SamplingTrajectory``, the M member components at once (the reference builds
+    a ``Vector{BilinearIntegrator}``, one per member, whose rows are concatenated
+    in order -- the row order here is identical: member-major).
+    """
+
+    def __init__(self, G_drift, G_drives, traj, x_name=STATE, u_name="u", *, device=0, index_base=0, pade_order=4):
+        x_names = [x_name] if isinstance(x_name, str) else list(x_name)
+        G_drives = np.asarray(G_drives, dtype=np.float64)
+        G_drift = np.asarray(G_drift, dtype=np.float64)
+        per_member = G_drift.ndim == 3
+        n = G_drift.shape[-1]
+        d = n // 2
+        m = G_drives.shape[0] if G_drives.size else 0
+        if per_member and G_drift.shape[0] != len(x_names):
+            raise ValueError("one G_drift per member expected (%d != %d)" % (G_drift.shape[0], len(x_names)))
+        for nm in x_names:
+            if nm not in traj.components:
+                raise KeyError("trajectory has no component %r" % (nm,))
+            if len(traj.components[nm]) != 2 * d * d:
+                raise ValueError("component %r has dim %d, expected 2 d^2 = %d" % (nm, len(traj.components[nm]), 2 * d * d))
+        if m and len(traj.components[u_name]) < m:
+            raise ValueError("drive component %r has dim %d < n_drives = %d" % (u_name, len(traj.components[u_name]), m))
+        self.x_names = x_names
+        self.x_name = x_names[0] if len(x_names) == 1 else tuple(x_names)
+        self.u_name = u_name
+        self.G_drift, self.G_drives = G_drift, G_drives.reshape(m, n, n)
+        self._sig = (traj.dim, traj.N)
+        self._ctx = _PclContext(
+            d=d, m=m, N=traj.N, z_dim=traj.dim, u_off=traj.components[u_name].start,
+            dt_off=traj.components[traj.timestep].start, x_offs=[traj.components[nm].start for nm in x_names],
+            G0=G_drift, Gj=self.G_drives, batch=len(x_names), batch_mode=PCL_BATCH_MEMBERS, per_member_G0=per_member,
+            global_dim=traj.global_dim, device=device, index_base=index_base, pade_order=pade_order,
+        )  # fmt: skip
+        self.x_dim = self._ctx.x_dim * len(x_names) if len(x_names) > 1 else self._ctx.x_dim
+        self.dim = self._ctx.n_rows
+        self._f_ctx = None
+
+    # ---- reference-style properties ------------------------------------------------------------
+    @property
+    def ctx(self):
+        return self._ctx
+
+    def _check(self, traj):
+        if (traj.dim, traj.N) != self._sig:
+            raise ValueError("trajectory shape (dim=%d, N=%d) differs from the one this integrator was built for %r"
+                             % (traj.dim, traj.N, self._sig))  # fmt: skip
+
+    def f(self, x_next, x, u, dt):
+        """Scalar (one-interval) form ``B.f(x_next, x, u, dt)`` [REF integrators.jl:525]."""
+        c = self._ctx
+        if len(self.x_names) != 1:
+            raise NotImplementedError("f is defined for single-state integrators")
+        if self._f_ctx is None:
+            self._f_ctx = _PclContext(d=c.d, m=c.m, N=2, z_dim=c.x_dim + 1 + c.m, u_off=c.x_dim + 1, dt_off=c.x_dim,
+                                      x_offs=[0], G0=self.G_drift, Gj=self.G_drives, batch=1,
+                                      batch_mode=PCL_BATCH_MEMBERS)  # fmt: skip
+        z = np.zeros((2, c.x_dim + 1 + c.m))
+        z[0, : c.x_dim], z[0, c.x_dim], z[0, c.x_dim + 1 :] = x, dt, np.asarray(u)[: c.m]
+        z[1, : c.x_dim] = x_next
+        return self._f_ctx.eval(z)
+
+    def close(self):
+        self._ctx.close()
+        if self._f_ctx is not None:
+            self._f_ctx.close()
+
+
+class HipPadeMultistart:
+    """B independent trajectories of identical shape evaluated in one launch (multistart
+    seeds; BASELINE.json config 5).  Not a reference type: the reference has no multistart
+    facility; each seed is its own NLP and owns rows/columns ``b``-major."""
+
+    def __init__(self, G_drift, G_drives, traj, batch, x_name=STATE, u_name="u", *, device=0, index_base=0):
+        G_drives = np.asarray(G_drives, dtype=np.float64)
+        n = np.asarray(G_drift).shape[-1]
+        m = G_drives.shape[0] if G_drives.size else 0
+        self._ctx = _PclContext(
+            d=n // 2, m=m, N=traj.N, z_dim=traj.dim, u_off=traj.components[u_name].start,
+            dt_off=traj.components[traj.timestep].start, x_offs=[traj.components[x_name].start], G0=G_drift,
+            Gj=G_drives.reshape(m, n, n), batch=batch, batch_mode=PCL_BATCH_TRAJ, device=device, index_base=index_base,
+        )  # fmt: skip
+        self.batch = batch
+        self.x_dim = self._ctx.x_dim
+        self.dim = self._ctx.n_rows
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    def close(self):
+        self._ctx.close()
+
+
+# ---------------------------------------------------------------------------
+# reference-style generic functions
+# ---------------------------------------------------------------------------
+def BilinearIntegrator(system, traj, x_name=None, u_name="u", **kw):
+    """``BilinearIntegrator(qtraj, N)`` for the time-independent unitary path.
+
+    ``system`` is one system (UnitaryTrajectory) or a list of systems sharing the
+    drives (SamplingTrajectory: one member state ``Utilde<i>`` per system)."""
+    if isinstance(system, (list, tuple)):
+        systems = list(system)
+        if any(getattr(s, "time_dependent", False) for s in systems):
+            raise NotImplementedError("time-dependent systems use TimeDependentBilinearIntegrator (out of scope)")
+        names = x_name or ["%s%d" % (STATE, i) for i in range(1, len(systems) + 1)]
+        Gd = np.array([s.G_drives_array() for s in systems])
+        if not all(np.array_equal(Gd[0], g) for g in Gd[1:]):
+            raise NotImplementedError("ensemble members must share the drive generators (per-member G_drift only)")
+        return HipPadeIntegrator(np.array([s.G_drift for s in systems]), Gd[0], traj, names, u_name, **kw)
+    if getattr(system, "time_dependent", False):
+        raise NotImplementedError("time-dependent systems use TimeDependentBilinearIntegrator (out of scope)")
+    return HipPadeIntegrator(system.G_drift, system.G_drives_array(), traj, x_name or STATE, u_name, **kw)
+
+
+def evaluate_(delta, B, traj):
+    """``evaluate!(delta, B, traj)``: fills ``delta`` (length ``B.dim``) in place."""
+    B._check(traj)
+    if delta.shape != (B.dim,):
+        raise ValueError("delta must have length B.dim = %d" % B.dim)
+    B.ctx.eval(traj.datavec, delta)
+    return delta
+
+
+def jacobian_structure(B, dtype=np.int64):
+    return B.ctx.jac_structure(dtype)
+
+
+def hessian_structure(B, dtype=np.int64):
+    return B.ctx.hess_structure(dtype)
+
+
+def eval_jacobian(B, traj):
+    """``eval_jacobian(B, traj)`` -> scipy.sparse CSR of shape
+    ``(B.dim, traj.dim*traj.N + traj.global_dim)``."""
+    import scipy.sparse as sp
+
+    B._check(traj)
+    vals = B.ctx.jac(traj.datavec)
+    rows, cols = B.ctx.jac_structure()
+    return sp.csr_matrix((vals, (rows, cols)), shape=(B.dim, traj.dim * traj.N + traj.global_dim))
+
+
+def eval_hessian_of_lagrangian(B, traj, mu):
+    """Symmetric ``sum_k mu_k^T grad^2 delta_k`` as scipy.sparse CSR (full, both triangles)."""
+    import scipy.sparse as sp
+
+    B._check(traj)
+    vals = B.ctx.hess(traj.datavec, mu)
+    rows, cols = B.ctx.hess_structure()
+    nv = traj.dim * traj.N + traj.global_dim
+    L = sp.coo_matrix((vals, (rows, cols)), shape=(nv, nv)).tocsr()
+    return L + sp.tril(L, -1).T

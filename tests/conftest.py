@@ -1,0 +1,46 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests never run implicitly on a box without a device: select them with -m gpu.
+    try:
+        import torch
+
+        have_gpu = torch.cuda.is_available()
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden_meta():
+    with open(os.path.join(GOLDEN, "golden_meta.json")) as f:
+        return json.load(f)
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden

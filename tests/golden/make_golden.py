@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/.
+
+Runs ONLY in the build container (reads /root/reference/docs/data/*.jld2, which
+does not exist on the GPU box).  Two kinds of fixture:
+
+1. ``ref_<name>.npz`` -- the ``datavec`` of a NamedTrajectory *solved by the
+   reference itself* (docs cache written by ``cached_solve!``
+   [REF src/docs_cache.jl:42-56,180-192]); pure data, extracted byte-for-byte
+   from the JLD2 file (JLD2 stores Vector{Float64} raw).  These pin layout,
+   G = iso(-iH), drive order, the 2*pi convention and the (u_k, dt_k) index
+   convention through the reference's own exp constraint
+   [REF docs/src/concepts/index.md:21].
+2. ``vec_<name>.npz`` -- seeded inputs (Z, G0, Gj, mu) and the numpy oracle's
+   outputs (delta, Jacobian values, Hessian values) for the Pade-4 evaluator,
+   in the triplet orders documented in include/piccolo_hip.h.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import pade_oracle as po  # noqa: E402
+
+REF = "/root/reference/docs/data/"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def ref_trajectories():
+    meta = {}
+    # name: (file, d, m, N, z_dim, n_members, system description)
+    cases = {
+        # MultiTransmonSystem([4.0,4.1],[0.2,0.2],g=0.1; levels=2, drive_bounds=0.1)  [REF docs/literate/two_qubit_gate_validation.jl:50-56]
+        "two_qubit_zoh": ("two_qubit_zoh_57a874f.jld2", 4, 4, 200, 46, 1),
+        # TransmonSystem(levels=5, delta=0.2, drive_bounds=[0.2,0.2])  [REF docs/literate/multilevel_transmon.jl:37-53]
+        "multilevel_transmon": ("multilevel_transmon_573ffb2.jld2", 5, 2, 50, 58, 1),
+        # QuantumSystem(0.5 Z, [X, Y], [1,1])  [REF docs/literate/first_gate.jl:42-48]
+        "first_gate": ("first_gate_5070646.jld2", 2, 2, 100, 16, 1),
+        # members [1, 1.05, 0.95] * 0.5 Z   [REF docs/literate/problem-templates/sampling.jl:79-100]
+        "sampling_robust": ("sampling_robust_573ffb2.jld2", 2, 2, 100, 28, 3),
+        # members [0.9, 0.95, 1.0, 1.05, 1.1] * 0.5 Z   [REF docs/literate/robust_control.jl:82-88]
+        "robust_sampling": ("robust_sampling_573ffb2.jld2", 2, 2, 100, 44, 5),
+    }
+    for name, (fn, d, m, N, zd, M) in cases.items():
+        Z = po.read_jld2_datavec(REF + fn, d, zd, N, n_members=M)
+        np.savez_compressed(os.path.join(OUT, "ref_%s.npz" % name), Z=Z)
+        meta[name] = dict(source="docs/data/" + fn, d=d, m=m, N=N, z_dim=zd, n_members=M)
+    return meta
+
+
+def oracle_vectors():
+    meta = {}
+    rng = np.random.default_rng(20260929)
+    cases = {"config1": (1, 7), "config2": (2, 9), "config3": (3, 3)}
+    for name, (cfg, N) in cases.items():
+        s = po.config_system(cfg)
+        Z, lay = po.synthetic_trajectory(s, N, seed=20260929 + cfg)
+        Z[:, lay.dt_off] = 0.1 + 0.05 * rng.random(N)  # non-uniform dt: the default is free timesteps
+        G0, Gj = s.G_drift, np.array(s.G_drives)
+        mu = rng.standard_normal((lay.K, lay.x_dim))
+        np.savez_compressed(
+            os.path.join(OUT, "vec_%s.npz" % name),
+            Z=Z,
+            G0=G0,
+            Gj=Gj,
+            mu=mu,
+            delta=po.pade_residual(Z, lay, G0, Gj, 4),
+            jac=po.pade_jacobian_values(Z, lay, G0, Gj, 4),
+            hess=po.pade4_hessian_values(Z, mu, lay, G0, Gj),
+            delta6=po.pade_residual(Z, lay, G0, Gj, 6),
+        )
+        meta[name] = dict(config=cfg, d=lay.d, m=lay.m, N=N, z_dim=lay.z_dim, x_off=lay.x_off, u_off=lay.u_off, dt_off=lay.dt_off)
+    return meta
+
+
+if __name__ == "__main__":
+    meta = {"reference_trajectories": ref_trajectories(), "oracle_vectors": oracle_vectors()}
+    with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))

@@ -1,0 +1,149 @@
+"""CPU tests of the drop-in boundary and the host-side logic (no GPU compute):
+the C-ABI library loads and exports every symbol include/piccolo_hip.h declares,
+argument validation is loud, no CPU fallback exists, host builders reproduce the
+reference's known answers and layout."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import piccolo_jl_amd as pa
+from oracle import pade_oracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    pa.build_library()
+    return pa._lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "piccolo_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char \*)\s*\*?\s*(pcl_\w+)\s*\(", hdr, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(pa._lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.pcl_version()
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "piccolo_hip.h"\nint main(void){ pcl_desc d; d.struct_size = (int)sizeof d; return d.struct_size == 0; }\n')
+    import subprocess
+
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "t.o")])
+
+
+def test_desc_struct_matches_header(lib):
+    # sizeof(pcl_desc) in ctypes == what the library expects (it rejects a mismatch)
+    d = pa._lib.pcl_desc()
+    d.struct_size = ctypes.sizeof(pa._lib.pcl_desc) + 8
+    h = ctypes.c_void_p()
+    rc = lib.pcl_create(ctypes.byref(d), ctypes.byref(h))
+    assert rc == pa._lib.PCL_EINVAL and b"ABI mismatch" in lib.pcl_last_error(None)
+    assert ctypes.sizeof(pa._lib.pcl_desc) == 88
+
+
+def _mk(**over):
+    kw = dict(d=2, m=2, N=5, z_dim=16, u_off=10, dt_off=8, x_offs=[0], G0=np.zeros((4, 4)), Gj=np.zeros((2, 4, 4)), batch=1,
+              batch_mode=pa._lib.PCL_BATCH_MEMBERS)  # fmt: skip
+    kw.update(over)
+    return kw
+
+
+@pytest.mark.parametrize(
+    "over,code,msg",
+    [
+        (dict(pade_order=6), pa._lib.PCL_ENOTIMPL, "order-4"),
+        (dict(d=33, G0=np.zeros((66, 66)), Gj=np.zeros((2, 66, 66)), z_dim=3000, x_offs=[0], u_off=2900, dt_off=2899), pa._lib.PCL_ESHAPE, "PCL_MAX_D"),
+        (dict(N=1), pa._lib.PCL_EINVAL, "N>=2"),
+        (dict(x_offs=[12]), pa._lib.PCL_EINVAL, "does not fit"),
+        (dict(u_off=15), pa._lib.PCL_EINVAL, "u_off"),
+        (dict(index_base=2), pa._lib.PCL_EINVAL, "index_base"),
+        (dict(batch_mode=7), pa._lib.PCL_EINVAL, "batch_mode"),
+    ],
+)
+def test_create_validates_before_touching_the_device(lib, over, code, msg):
+    with pytest.raises(pa.PclError) as ei:
+        pa.integrators._PclContext(**_mk(**over))
+    assert ei.value.code == code and msg in str(ei.value)
+
+
+def test_no_cpu_fallback(lib):
+    """Without a GPU the product path fails loudly (PCL_EHIP); it never computes on the host."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pa.PclError) as ei:
+        pa.integrators._PclContext(**_mk())
+    assert ei.value.code == pa._lib.PCL_EHIP and "no CPU path" in str(ei.value)
+    s = pa.QuantumSystem(0.5 * pa.PAULIS["Z"], [pa.PAULIS["X"], pa.PAULIS["Y"]], [1.0, 1.0])
+    t = pa.unitary_trajectory(s, np.zeros((2, 6)), np.linspace(0, 1, 6), pa.GATES["X"])
+    with pytest.raises(pa.PclError):
+        pa.BilinearIntegrator(s, t)
+
+
+def test_product_package_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "piccolo.jl_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".jl", ".cpp")):
+                txt = open(os.path.join(dp, fn), encoding="utf-8").read()
+                assert "oracle" not in txt.replace("no oracle", ""), os.path.join(dp, fn)
+
+
+# ---- host logic: builders and layout ------------------------------------------------------------
+def test_product_builders_match_reference_literals():
+    assert np.allclose(pa.quantum.G(np.array([[1, 2], [3, 4]]) + 1j * np.array([[0, 1], [1, 0]])), [[0, 1, 1, 2], [1, 0, 3, 4], [-1, -2, 0, 1], [-3, -4, 1, 0]])
+    assert np.allclose(pa.operator_to_iso_vec(np.array([[0, 1 - 1j], [1 + 1j, 0]])), [0, 1, 0, 1, 1, 0, -1, 0])
+    assert np.allclose(pa.iso_vec_to_operator([0, 1, 0, 1, 1, 0, -1, 0]), [[0, 1 - 1j], [1 + 1j, 0]])
+    assert np.allclose(pa.annihilate(3), [[0, 1, 0], [0, 0, np.sqrt(2)], [0, 0, 0]])
+    assert np.allclose(pa.quantum.iso_vec_to_iso_operator([0, 1, 0, 1, 1, 0, -1, 0]), [[0, 1, 0, 1], [1, 0, -1, 0], [0, -1, 0, 1], [1, 0, 1, 0]])
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_product_systems_match_oracle_systems(cfg):
+    o = po.config_system(cfg)
+    if cfg == 1:
+        s = pa.QuantumSystem(0.5 * pa.PAULIS["Z"], [pa.PAULIS["X"], pa.PAULIS["Y"]], [1.0, 1.0])
+    elif cfg == 2:
+        s = pa.MultiTransmonSystem([4.0, 4.1], [0.2, 0.2], [[0, 0.1], [0.1, 0]], levels_per_transmon=2, drive_bounds=0.1)
+    else:
+        s = pa.MultiTransmonSystem([4.0, 4.1, 4.2], [0.2, 0.21, 0.22], [[0, 0.01, 0.02], [0.01, 0, 0.03], [0.02, 0.03, 0]], drive_bounds=0.1)
+    assert s.levels == o.levels and s.n_drives == o.n_drives
+    assert np.allclose(s.G_drift, o.G_drift, rtol=0, atol=1e-13)
+    assert np.allclose(s.G_drives_array(), np.array(o.G_drives), rtol=0, atol=1e-13)
+    assert s.drive_bounds == o.drive_bounds
+    # Hermitian H  <=>  skew-symmetric G
+    assert np.allclose(s.G_drift, -s.G_drift.T)
+
+
+def test_named_trajectory_layout():
+    s = pa.MultiTransmonSystem([4.0, 4.1], [0.2, 0.2], [[0, 0.1], [0.1, 0]], levels_per_transmon=2, drive_bounds=0.1)
+    N = 7
+    t = pa.unitary_trajectory(s, 0.01 * np.arange(4 * N).reshape(4, N), np.linspace(0, 1, N), pa.GATES["CX"])
+    assert t.names == ("Ũ⃗", "Δt", "t", "u", "du", "ddu") and t.dim == 46 and t.N == N
+    assert t.components["Ũ⃗"] == range(0, 32) and t.components["Δt"] == range(32, 33) and t.components["u"] == range(34, 38)
+    # knot-major: knot k is contiguous; data is a dim x N view
+    assert np.array_equal(t.knot(3), t.data[:, 3]) and t.datavec.size == 46 * N
+    assert np.array_equal(t["Ũ⃗"][:, 0], pa.operator_to_iso_vec(np.eye(4)))
+    assert np.allclose(t["du"][:, 0], (t["u"][:, 1] - t["u"][:, 0]) / t["Δt"][0, 0])
+    st = pa.sampling_trajectory([s, s, s], np.zeros((4, N)), np.linspace(0, 1, N), pa.GATES["CX"])
+    assert st.names == ("Ũ⃗1", "Ũ⃗2", "Ũ⃗3", "Δt", "t", "u") and st.dim == 3 * 32 + 2 + 4
+    with pytest.raises(ValueError):
+        pa.NamedTrajectory({"a": np.zeros((2, 3)), "b": np.zeros((1, 4))})
+
+
+def test_quantum_system_validation():
+    with pytest.raises(AssertionError):
+        pa.QuantumSystem(np.array([[0, 1], [0, 0]]), [pa.PAULIS["X"]], [1.0])
+    with pytest.raises(AssertionError):
+        pa.QuantumSystem(pa.PAULIS["Z"], [np.array([[0, 1], [0, 0]])], [1.0])
+    with pytest.raises(ValueError):
+        pa.lift_operator(pa.PAULIS["X"], 1, [3, 2])

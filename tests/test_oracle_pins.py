@@ -1,0 +1,232 @@
+"""CPU tests: pin the oracle (numpy + C restatement) on everything the reference holds for
+this path -- known-answer literals of its own tests and trajectories solved by the reference
+itself -- then on itself (finite differences, numpy vs C, committed vectors)."""
+import numpy as np
+import pytest
+
+from helpers import ref_case
+from oracle import pade_oracle as po
+from oracle import ref_lib
+
+
+# ---- known-answer literals from the reference's own tests --------------------------------
+def test_iso_literals():
+    # [REF src/quantum/primitives/isomorphisms.jl:471-509]
+    assert np.allclose(po.ket_to_iso([1.0, 2.0]), [1, 2, 0, 0])
+    assert np.allclose(po.ket_to_iso([-1j, 2 + 3j]), [0, 2, -1, 3])
+    assert np.allclose(po.iso_to_ket([0, 2, -1, 3]), [-1j, 2 + 3j])
+    I = [1.0, 0, 0, 0, 0, 1.0, 0, 0]
+    assert np.allclose(po.iso_vec_to_operator(I), np.eye(2))
+    assert np.allclose(po.iso_vec_to_iso_operator(I), np.eye(4))
+    assert np.allclose(po.operator_to_iso_vec(np.eye(2)), I)
+    XY = [0, 1, 0, 1, 1, 0, -1, 0]
+    U = np.array([[0, 1 - 1j], [1 + 1j, 0]])
+    assert np.allclose(po.iso_vec_to_operator(XY), U)
+    assert np.allclose(po.iso_vec_to_iso_operator(XY), [[0, 1, 0, 1], [1, 0, -1, 0], [0, -1, 0, 1], [1, 0, 1, 0]])
+    assert np.allclose(po.operator_to_iso_vec(U), XY)
+    assert np.allclose(po.iso_operator_to_iso_vec(po.iso_vec_to_iso_operator(XY)), XY)
+
+
+def test_generator_literals():
+    # [REF isomorphisms.jl:620-643]
+    Hc = np.array([[1.0, 2.0], [3.0, 4.0]]) + 1j * np.array([[0.0, 1.0], [1.0, 0.0]])
+    GH = po.G_of_H(Hc)
+    assert np.allclose(po.H_of_G(GH), Hc)
+    assert np.allclose(GH, [[0, 1, 1, 2], [1, 0, 3, 4], [-1, -2, 0, 1], [-3, -4, 1, 0]])
+    assert np.allclose(po.iso(Hc), [[1, 2, 0, -1], [3, 4, -1, 0], [0, 1, 1, 2], [1, 0, 3, 4]])
+    assert np.allclose(po.iso(-1j * Hc), GH)
+    assert np.allclose(po.ad_vec(np.array([[0, 1], [1, 0]])), [[0, 1, -1, 0], [1, 0, 0, -1], [-1, 0, 0, 1], [0, -1, 1, 0]])
+    assert np.allclose(po.ad_vec(np.array([[0, -1j], [1j, 0]])), np.array([[0, -1j, -1j, 0], [1j, 0, 0, -1j], [1j, 0, 0, -1j], [0, 1j, 1j, 0]]))
+
+
+def test_var_G_literals():
+    # [REF isomorphisms.jl:645-671]
+    G = np.array([[1.0, 2.0], [3.0, 4.0]])
+    v1, v2 = np.array([[0.0, 1.0], [1.0, 0.0]]), np.array([[0.0, 0.0], [1.0, 1.0]])
+    assert np.allclose(po.var_G(G, [v1]), [[1, 2, 0, 0], [3, 4, 0, 0], [0, 1, 1, 2], [1, 0, 3, 4]])
+    assert np.allclose(
+        po.var_G(G, [v1, v2]),
+        [[1, 2, 0, 0, 0, 0], [3, 4, 0, 0, 0, 0], [0, 1, 1, 2, 0, 0], [1, 0, 3, 4, 0, 0], [0, 0, 0, 0, 1, 2], [1, 1, 0, 0, 3, 4]],
+    )
+
+
+def test_operator_literals():
+    # [REF src/quantum/object_utils.jl:174-176]
+    assert np.allclose(po.annihilate(2), [[0, 1], [0, 0]])
+    assert np.allclose(po.annihilate(3), [[0, 1, 0], [0, 0, np.sqrt(2)], [0, 0, 0]])
+    # [REF src/quantum/operators/lifted_operators.jl:22-31] lift = kron with identities
+    X = po.PAULIS["X"]
+    assert np.allclose(po.lift_operator(X, 1, [2, 2]), np.kron(X, np.eye(2)))
+    assert np.allclose(po.lift_operator(X, 2, [2, 3][::-1][::-1][:1] + [2]), np.kron(np.eye(2), X))
+
+
+def test_bilinear_fixture_generators():
+    # the 4x4 Gx, Gy, Gz of test/test_utils.jl:113-133 are iso(-i sigma/...) of the Paulis (up to the
+    # fixture's own sign/scale conventions): Gz is G(-Z)/..; check the structural identity G = iso(-iH)
+    Gx = np.array([[0, 0, 0, 1], [0, 0, 1, 0], [0, -1, 0, 0], [-1, 0, 0, 0]], float)
+    Gy = np.array([[0, -1, 0, 0], [1, 0, 0, 0], [0, 0, 0, -1], [0, 0, 1, 0]], float)
+    Gz = np.array([[0, 0, 1, 0], [0, 0, 0, -1], [-1, 0, 0, 0], [0, 1, 0, 0]], float)
+    assert np.allclose(po.G_of_H(po.PAULIS["X"]), Gx)
+    assert np.allclose(po.G_of_H(po.PAULIS["Y"]), Gy)
+    assert np.allclose(po.G_of_H(po.PAULIS["Z"]), Gz)
+
+
+def test_hadamard_fixture_is_iso_consistent():
+    # test/test_utils.jl:56-100: the literal Hadamard trajectory's initial/goal iso-vecs
+    init = [1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0]
+    goal_cols_last_knot = np.array([0.707107, 0.707107, 1.38778e-17, -1.52656e-16, 0.707107, -0.707107, -1.249e-16, 4.16334e-16])
+    assert np.allclose(po.operator_to_iso_vec(np.eye(2)), init)
+    Hgate = np.array([[1, 1], [1, -1]]) / np.sqrt(2)
+    assert np.allclose(po.operator_to_iso_vec(Hgate), goal_cols_last_knot, atol=1e-6)
+
+
+# ---- semantics pinned on trajectories solved by the reference itself ----------------------
+# thresholds from SURVEY.md section 0.3 / 8(c)
+@pytest.mark.parametrize(
+    "name,exp_tol,pade",
+    [
+        ("two_qubit_zoh", 1e-11, {4: (1e-9, 3e-9), 6: (0, 1e-11), 8: (0, 1e-11)}),
+        ("multilevel_transmon", 1e-9, {10: (0, 1e-7)}),
+        ("first_gate", 3e-5, {}),
+    ],
+)
+def test_reference_trajectories_single(name, exp_tol, pade, golden, golden_meta):
+    systems, lay, _ = ref_case(name, golden_meta)
+    Z = golden("ref_" + name)["Z"]
+    s = systems[0]
+    G0, Gj = s.G_drift, np.array(s.G_drives)
+    r = np.abs(po.exp_residual(Z, lay, G0, Gj)).max()
+    assert r < exp_tol, r
+    for order, (lo, hi) in pade.items():
+        rp = np.abs(po.pade_residual(Z, lay, G0, Gj, order)).max()
+        assert lo <= rp < hi, (order, rp)
+
+
+def test_first_gate_index_convention_tripwire(golden, golden_meta):
+    """(u_k, dt_k) -- not u_{k+1} -- drives interval k: the wrong choice is 100x worse."""
+    systems, lay, _ = ref_case("first_gate", golden_meta)
+    Z = golden("ref_first_gate")["Z"]
+    s = systems[0]
+    G0, Gj = s.G_drift, np.array(s.G_drives)
+    good = np.abs(po.exp_residual(Z, lay, G0, Gj)).max()
+    Zs = Z.copy()
+    Zs[:-1, lay.u_off : lay.u_off + lay.m] = Z[1:, lay.u_off : lay.u_off + lay.m]
+    bad = np.abs(po.exp_residual(Zs, lay, G0, Gj)).max()
+    assert good < 3e-5 and bad > 1e-3 and bad > 50 * good
+
+
+@pytest.mark.parametrize("name,own_tol,nominal_idx", [("sampling_robust", 1e-4, 0), ("robust_sampling", 5e-3, 2)])
+def test_reference_trajectories_ensemble(name, own_tol, nominal_idx, golden, golden_meta):
+    """Member-major state order, member -> system mapping, per-knot (free) dt."""
+    systems, lay, x_offs = ref_case(name, golden_meta)
+    Z = golden("ref_" + name)["Z"]
+    dts = Z[:, lay.dt_off]
+    assert dts.max() / dts.min() > 5  # free, non-uniform timesteps
+    assert np.abs(Z[1:, lay.dt_off + 1] - Z[:-1, lay.dt_off + 1] - dts[:-1]).max() < 1e-13  # time consistency rows
+    nom = systems[nominal_idx]
+    for i, (s, xo) in enumerate(zip(systems, x_offs)):
+        own = np.abs(po.exp_residual(Z, lay, s.G_drift, np.array(s.G_drives), x_off=xo)).max()
+        assert own < own_tol, (i, own)
+        if i != nominal_idx:
+            wrong = np.abs(po.exp_residual(Z, lay, nom.G_drift, np.array(nom.G_drives), x_off=xo)).max()
+            assert wrong > 4 * own, (i, own, wrong)
+
+
+def test_derivative_rows_on_reference_trajectory(golden, golden_meta):
+    # u_{k+1} - u_k - dt_k du_k = 0 and the same for (du, ddu)  [REF smooth_pulse_problem.jl:267-275]
+    systems, lay, _ = ref_case("two_qubit_zoh", golden_meta)
+    Z = golden("ref_two_qubit_zoh")["Z"]
+    m = lay.m
+    assert np.abs(po.derivative_residual(Z, lay.u_off, lay.u_off + m, m, lay.dt_off)).max() < 1e-6
+    assert np.abs(po.derivative_residual(Z, lay.u_off + m, lay.u_off + 2 * m, m, lay.dt_off)).max() < 1e-6
+
+
+# ---- the oracle against itself ---------------------------------------------------------------
+def test_pade_coefficients():
+    assert np.allclose(po.pade_coeffs(4), [1, 1 / 2, 1 / 12])
+    assert np.allclose(po.pade_coeffs(6), [1, 1 / 2, 1 / 10, 1 / 120])
+    assert np.allclose(po.pade_coeffs(8), [1, 1 / 2, 3 / 28, 1 / 84, 1 / 1680])
+    assert np.allclose(po.pade_coeffs(10), [1, 1 / 2, 1 / 9, 1 / 72, 1 / 1008, 1 / 30240])
+
+
+def test_pade_converges_to_exp():
+    s = po.config_system(2)
+    # exp-feasible trajectory (noise = 0): the Pade residual is then pure truncation error
+    Z, lay = po.synthetic_trajectory(s, 8, seed=11, dt=0.4, u_scale=0.1, noise=0.0)
+    G0, Gj = s.G_drift, np.array(s.G_drives)
+    assert np.abs(po.exp_residual(Z, lay, G0, Gj)).max() < 1e-13
+    errs = [np.abs(po.pade_residual(Z, lay, G0, Gj, p)).max() for p in (4, 6, 8, 10)]
+    assert errs[0] > 10 * errs[1] > 100 * errs[2] > 1000 * errs[3] and errs[3] < 1e-11, errs
+
+
+def _fd_jac(f, z0, eps=1e-6):
+    J = np.zeros((f(z0).size, z0.size))
+    for i in range(z0.size):
+        zp, zm = z0.copy(), z0.copy()
+        zp[i] += eps
+        zm[i] -= eps
+        J[:, i] = (f(zp) - f(zm)) / (2 * eps)
+    return J
+
+
+@pytest.mark.parametrize("order", [4, 6])
+def test_oracle_jacobian_finite_differences(order):
+    s = po.config_system(1)
+    Z, lay = po.synthetic_trajectory(s, 5, seed=3, noise=1e-2)
+    Z[:, lay.dt_off] = 0.1 + 0.05 * np.random.default_rng(0).random(5)
+    G0, Gj = s.G_drift, np.array(s.G_drives)
+    J = po.pade_jacobian_dense(Z, lay, G0, Gj, order)
+    Jfd = _fd_jac(lambda z: po.pade_residual(z.reshape(Z.shape), lay, G0, Gj, order).reshape(-1), Z.reshape(-1).copy())
+    assert np.abs(J - Jfd).max() < 1e-8
+
+
+def test_oracle_hessian_finite_differences():
+    s = po.config_system(1)
+    Z, lay = po.synthetic_trajectory(s, 4, seed=4, noise=1e-2)
+    Z[:, lay.dt_off] = 0.1 + 0.05 * np.random.default_rng(1).random(4)
+    G0, Gj = s.G_drift, np.array(s.G_drives)
+    mu = np.random.default_rng(2).standard_normal((lay.K, lay.x_dim))
+    Hd = po.hessian_dense(po.pade4_hessian_values(Z, mu, lay, G0, Gj), lay)
+    g = lambda z: po.pade_jacobian_dense(z.reshape(Z.shape), lay, G0, Gj, 4).T @ mu.reshape(-1)
+    Hfd = _fd_jac(g, Z.reshape(-1).copy())
+    assert np.abs(Hd - Hfd).max() < 1e-7
+    assert np.abs(Hd - Hd.T).max() == 0
+
+
+@pytest.mark.parametrize("cfg,N", [(1, 9), (2, 10), (3, 4)])
+def test_c_restatement_matches_numpy(cfg, N):
+    s = po.config_system(cfg)
+    Z, lay = po.synthetic_trajectory(s, N, seed=100 + cfg)
+    rng = np.random.default_rng(cfg)
+    Z[:, lay.dt_off] = 0.1 + 0.05 * rng.random(N)
+    G0, Gj = s.G_drift, np.array(s.G_drives)
+    d1, j1 = ref_lib.eval_jac(Z, lay, G0, Gj, nthreads=2)
+    assert np.abs(d1 - po.pade_residual(Z, lay, G0, Gj, 4)).max() < 1e-14
+    assert np.abs(j1 - po.pade_jacobian_values(Z, lay, G0, Gj, 4)).max() < 1e-13
+    mu = rng.standard_normal((lay.K, lay.x_dim))
+    h1 = ref_lib.hess(Z, mu, lay, G0, Gj, nthreads=2)
+    h0 = po.pade4_hessian_values(Z, mu, lay, G0, Gj)
+    assert np.abs(h1 - h0).max() < 1e-12 * max(1.0, np.abs(h0).max())
+
+
+@pytest.mark.parametrize("name", ["config1", "config2", "config3"])
+def test_committed_vectors_reproduce(name, golden, golden_meta):
+    """The committed golden vectors are what the oracle computes today (guards silent drift)."""
+    v = golden("vec_" + name)
+    m = golden_meta["oracle_vectors"][name]
+    lay = po.Layout(d=m["d"], m=m["m"], N=m["N"], z_dim=m["z_dim"], x_off=m["x_off"], u_off=m["u_off"], dt_off=m["dt_off"])
+    assert np.abs(po.pade_residual(v["Z"], lay, v["G0"], v["Gj"], 4) - v["delta"]).max() < 1e-14
+    d1, j1 = ref_lib.eval_jac(v["Z"], lay, v["G0"], v["Gj"])
+    assert np.abs(d1 - v["delta"]).max() < 1e-14 and np.abs(j1 - v["jac"]).max() < 1e-13
+    s = po.config_system(m["config"])
+    assert np.allclose(s.G_drift, v["G0"], rtol=0, atol=1e-14) and np.allclose(np.array(s.G_drives), v["Gj"], rtol=0, atol=1e-14)
+
+
+def test_structure_counts_match_survey_table():
+    # SURVEY.md section 8 config table
+    for cfg, (jn, hn) in {1: (88, 54), 2: (672, 335), 3: (167670, 20440)}.items():
+        s = po.config_system(cfg)
+        lay = po.Layout.smooth_pulse(s.levels, s.n_drives, 3)
+        assert po.jac_nnz_per_interval(lay) == jn and po.hess_nnz_per_interval(lay) == hn
+        assert ref_lib.lib().pade_ref_jac_nnz_per_interval(lay.d, lay.m) == jn
+        assert ref_lib.lib().pade_ref_hess_nnz_per_interval(lay.d, lay.m) == hn

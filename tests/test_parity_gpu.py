@@ -1,0 +1,363 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the
+C ABI, against the CPU oracle on identical inputs.
+
+Tolerance: fp64 throughout.  GPU and oracle evaluate the same polynomial with different
+summation orders (MFMA 4-wide k-blocks / FMA contraction), so agreement is to rounding:
+    |gpu - oracle| <= TOL * max(1, max|oracle|),  TOL = 1e-12
+(observed ~1e-15 .. 1e-14).  The Pade-vs-exp deviation is a modelling difference, not an
+error of the kernel, and is asserted separately per order in tests/test_oracle_pins.py.
+"""
+import numpy as np
+import pytest
+
+import piccolo_jl_amd as pa
+from helpers import ref_case, traj_from_Z
+from oracle import pade_oracle as po
+from oracle import ref_lib
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def close(a, b, tol=TOL):
+    a, b = np.asarray(a).reshape(-1), np.asarray(b).reshape(-1)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    assert err <= tol * max(1.0, np.abs(b).max() if b.size else 0.0), err
+    return err
+
+
+def product_system(cfg):
+    if cfg == 1:
+        return pa.QuantumSystem(0.5 * pa.PAULIS["Z"], [pa.PAULIS["X"], pa.PAULIS["Y"]], [1.0, 1.0])
+    if cfg == 2:
+        return pa.MultiTransmonSystem([4.0, 4.1], [0.2, 0.2], [[0, 0.1], [0.1, 0]], levels_per_transmon=2, drive_bounds=0.1)
+    return pa.MultiTransmonSystem([4.0, 4.1, 4.2], [0.2, 0.21, 0.22], [[0, 0.01, 0.02], [0.01, 0, 0.03], [0.02, 0.03, 0]], drive_bounds=0.1)
+
+
+def make_ctx(lay, G0, Gj, **kw):
+    args = dict(d=lay.d, m=lay.m, N=lay.N, z_dim=lay.z_dim, u_off=lay.u_off, dt_off=lay.dt_off, x_offs=[lay.x_off], G0=G0,
+                Gj=Gj, batch=1, batch_mode=pa._lib.PCL_BATCH_MEMBERS)  # fmt: skip
+    args.update(kw)
+    return pa.integrators._PclContext(**args)
+
+
+# ---- committed golden vectors ----------------------------------------------------------------
+@pytest.mark.parametrize("name", ["config1", "config2", "config3"])
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_golden_vectors(name, mfma, golden, golden_meta):
+    v = golden("vec_" + name)
+    m = golden_meta["oracle_vectors"][name]
+    lay = po.Layout(d=m["d"], m=m["m"], N=m["N"], z_dim=m["z_dim"], x_off=m["x_off"], u_off=m["u_off"], dt_off=m["dt_off"])
+    c = make_ctx(lay, v["G0"], v["Gj"])
+    c.set_option("use_mfma", mfma)
+    delta, vals = c.eval_jac(v["Z"])
+    close(delta, v["delta"])
+    close(vals, v["jac"])
+    close(c.eval(v["Z"]), v["delta"])
+    close(c.jac(v["Z"]), v["jac"])
+    close(c.hess(v["Z"], v["mu"]), v["hess"], 1e-11)
+    c.close()
+
+
+# ---- seeded inputs vs the oracle, every slicing of the state columns ------------------------------
+@pytest.mark.parametrize("cfg,N", [(1, 50), (2, 100), (3, 5)])
+def test_seeded_vs_oracle_all_slicings(cfg, N):
+    so = po.config_system(cfg)
+    Z, lay = po.synthetic_trajectory(so, N, seed=20260929 + cfg)
+    Z[:, lay.dt_off] = 0.1 + 0.05 * np.random.default_rng(cfg).random(N)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    d_ref, j_ref = ref_lib.eval_jac(Z, lay, G0, Gj)
+    c = make_ctx(lay, G0, Gj)
+    for nc in sorted({0, 1, 2, 3, 5, lay.d}):
+        if nc > lay.d:
+            continue
+        c.set_option("cols_per_slice", nc)
+        delta, vals = c.eval_jac(Z)
+        close(delta, d_ref)
+        close(vals, j_ref)
+    c.close()
+
+
+def test_structure_matches_oracle():
+    so = po.config_system(2)
+    lay = po.Layout.smooth_pulse(so.levels, so.n_drives, 6)
+    for base in (0, 1):
+        c = make_ctx(lay, so.G_drift, np.array(so.G_drives), index_base=base)
+        r, cc = c.jac_structure()
+        r0, c0 = po.jac_structure(lay, index_base=base)
+        assert np.array_equal(r, r0) and np.array_equal(cc, c0)
+        r32, c32 = c.jac_structure(np.int32)
+        assert np.array_equal(r32, r0) and np.array_equal(c32, c0)
+        hr, hc = c.hess_structure()
+        hr0, hc0 = po.hess_structure(lay, index_base=base)
+        assert np.array_equal(hr, hr0) and np.array_equal(hc, hc0)
+        assert (hr >= hc).all()
+        assert c.n_rows == lay.x_dim * lay.K and c.n_cols == lay.z_dim * lay.N
+        c.close()
+
+
+# ---- the reference-style interface ------------------------------------------------------------------
+def test_integrator_interface_pins():
+    """Structural pins of the reference's integrator tests [REF src/control/integrators.jl:306-317,780-783]."""
+    s = product_system(2)
+    N = 10
+    rng = np.random.default_rng(0)
+    t = pa.unitary_trajectory(s, 0.02 * rng.standard_normal((4, N)), np.linspace(0, 1, N), pa.GATES["CX"])
+    B = pa.BilinearIntegrator(s, t)
+    assert B.x_dim == 32 and B.dim == 32 * (N - 1) and B.x_name == "Ũ⃗" and B.x_names == ["Ũ⃗"]
+    delta = np.zeros(B.dim)
+    pa.evaluate_(delta, B, t)
+    assert np.isfinite(delta).all() and np.linalg.norm(delta) > 0
+    J = pa.eval_jacobian(B, t)
+    assert J.shape == (B.dim, t.dim * t.N + t.global_dim)
+    # scalar form f(x_next, x, u, dt) == the matching rows of evaluate!
+    k = 3
+    f = B.f(t["Ũ⃗"][:, k + 1], t["Ũ⃗"][:, k], t["u"][:, k], t["Δt"][0, k])
+    close(f, delta[k * 32 : (k + 1) * 32])
+    with pytest.raises(ValueError):
+        pa.evaluate_(np.zeros(3), B, t)
+    B.close()
+
+
+def test_test_integrator_style_finite_differences():
+    """DTO's ``test_integrator(B, traj; atol=1e-3)`` is an analytic-vs-finite-difference check of the
+    Jacobian and the Hessian of the Lagrangian [REF integrators.jl:341-359]; same check, tighter."""
+    s = product_system(1)
+    N = 6
+    rng = np.random.default_rng(5)
+    states = [np.linalg.qr(rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2)))[0] for _ in range(N)]
+    t = pa.unitary_trajectory(s, 0.3 * rng.standard_normal((2, N)), np.cumsum(0.1 + 0.05 * rng.random(N)), pa.GATES["X"], states=states)
+    B = pa.BilinearIntegrator(s, t)
+    J = pa.eval_jacobian(B, t).toarray()
+    z0 = t.datavec.copy()
+
+    def f(z):
+        t.update(z)
+        return pa.evaluate_(np.zeros(B.dim), B, t).copy()
+
+    eps = 1e-6
+    Jfd = np.zeros_like(J)
+    for i in range(z0.size):
+        zp, zm = z0.copy(), z0.copy()
+        zp[i] += eps
+        zm[i] -= eps
+        Jfd[:, i] = (f(zp) - f(zm)) / (2 * eps)
+    t.update(z0)
+    assert np.abs(J - Jfd).max() < 1e-8
+    mu = rng.standard_normal(B.dim)
+    Hm = pa.eval_hessian_of_lagrangian(B, t, mu).toarray()
+
+    def g(z):
+        t.update(z)
+        return pa.eval_jacobian(B, t).T @ mu
+
+    Hfd = np.zeros_like(Hm)
+    for i in range(z0.size):
+        zp, zm = z0.copy(), z0.copy()
+        zp[i] += eps
+        zm[i] -= eps
+        Hfd[:, i] = (g(zp) - g(zm)) / (2 * eps)
+    t.update(z0)
+    assert np.abs(Hm - Hfd).max() < 1e-7
+    B.close()
+
+
+# ---- trajectories solved by the reference itself -----------------------------------------------------------
+@pytest.mark.parametrize("name", ["two_qubit_zoh", "multilevel_transmon", "first_gate"])
+def test_reference_solved_trajectories(name, golden, golden_meta):
+    systems, lay, _ = ref_case(name, golden_meta)
+    Z = golden("ref_" + name)["Z"]
+    so = systems[0]
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    c = make_ctx(lay, G0, Gj)
+    delta, vals = c.eval_jac(Z)
+    close(delta, po.pade_residual(Z, lay, G0, Gj, 4))
+    close(vals, po.pade_jacobian_values(Z, lay, G0, Gj, 4))
+    if name == "two_qubit_zoh":  # Pade-4 residual of a converged exp-solution ~1.5e-9
+        assert 1e-9 < np.abs(delta).max() < 3e-9
+    c.close()
+
+
+@pytest.mark.parametrize("name", ["sampling_robust", "robust_sampling"])
+def test_reference_solved_ensembles(name, golden, golden_meta):
+    """SamplingTrajectory layout [U1..UM, dt, t, u], per-member drift, shared controls, free dt."""
+    systems, lay, x_offs = ref_case(name, golden_meta)
+    Z = golden("ref_" + name)["Z"]
+    M = len(systems)
+    psys = [pa.QuantumSystem(s.H_drift, s.H_drives, [1.0, 1.0]) for s in systems]
+    traj = traj_from_Z(pa, Z, lay, n_members=M)
+    B = pa.BilinearIntegrator(psys, traj)
+    assert B.dim == M * lay.x_dim * lay.K and B.x_names == ["Ũ⃗%d" % (i + 1) for i in range(M)]
+    delta = pa.evaluate_(np.zeros(B.dim), B, traj)
+    vals = B.ctx.jac(traj.datavec)
+    rows, cols = pa.jacobian_structure(B)
+    for i, (s, xo) in enumerate(zip(systems, x_offs)):
+        G0, Gj = s.G_drift, np.array(s.G_drives)
+        close(delta[i * lay.x_dim * lay.K : (i + 1) * lay.x_dim * lay.K], po.pade_residual(Z, lay, G0, Gj, 4, x_off=xo))
+        per = po.jac_nnz_per_interval(lay) * lay.K
+        close(vals[i * per : (i + 1) * per], po.pade_jacobian_values(Z, lay, G0, Gj, 4, x_off=xo))
+        r0, c0 = po.jac_structure(lay, x_off=xo)
+        assert np.array_equal(rows[i * per : (i + 1) * per], r0 + i * lay.x_dim * lay.K)
+        assert np.array_equal(cols[i * per : (i + 1) * per], c0)
+    mu = np.random.default_rng(3).standard_normal(B.dim)
+    hv = B.ctx.hess(traj.datavec, mu)
+    hper = po.hess_nnz_per_interval(lay) * lay.K
+    for i, (s, xo) in enumerate(zip(systems, x_offs)):
+        h0 = po.pade4_hessian_values(Z, mu[i * lay.x_dim * lay.K : (i + 1) * lay.x_dim * lay.K].reshape(lay.K, -1), lay, s.G_drift, np.array(s.G_drives), x_off=xo)
+        close(hv[i * hper : (i + 1) * hper], h0, 1e-11)
+    B.close()
+
+
+# ---- BASELINE.json's full sizes ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def config3_full():
+    so = po.config_system(3)
+    Z, lay = po.synthetic_trajectory(so, 100, seed=20260929 + 3)
+    return so, Z, lay
+
+
+def test_config3_full_size_vs_c_oracle(config3_full):
+    so, Z, lay = config3_full
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    d_ref, j_ref = ref_lib.eval_jac(Z, lay, G0, Gj)
+    c = make_ctx(lay, G0, Gj)
+    assert c.jac_per == 167670 and c.jac_nnz == 16599330 and c.hess_per == 20440
+    for mfma in (1, 0):
+        c.set_option("use_mfma", mfma)
+        delta, vals = c.eval_jac(Z)
+        close(delta, d_ref)
+        close(vals, j_ref)
+    mu = np.random.default_rng(9).standard_normal((lay.K, lay.x_dim))
+    close(c.hess(Z, mu), ref_lib.hess(Z, mu, lay, G0, Gj), 1e-11)
+    c.close()
+
+
+def test_config3_size_independent_properties(config3_full):
+    """Properties that hold at any size: the d diagonal blocks are identical copies; B^- - (-(-B^+)) = ... ;
+    the residual is linear in the states; Jacobian * state-part reproduces the residual (delta is linear in X)."""
+    so, Z, lay = config3_full
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    c = make_ctx(lay, G0, Gj)
+    delta, vals = c.eval_jac(Z)
+    d, n, K, xd = lay.d, lay.n, lay.K, lay.x_dim
+    V = vals.reshape(K, -1)
+    blk = V[:, : 2 * d * n * n].reshape(K, 2, d, n * n)
+    assert np.array_equal(blk, np.broadcast_to(blk[:, :, :1], blk.shape))  # bit-identical replicas
+    Bp, Bm = -blk[:, 0, 0].reshape(K, n, n).transpose(0, 2, 1), blk[:, 1, 0].reshape(K, n, n).transpose(0, 2, 1)
+    # B^+ + B^- = 2 (I + h^2/12 G^2),  B^+ - B^- = h G : skew part of a Hermitian system
+    hG = Bp - Bm
+    assert np.abs(hG + hG.transpose(0, 2, 1)).max() < 1e-14
+    assert np.abs(Bm.transpose(0, 2, 1) - Bp).max() < 1e-13  # SURVEY: G^T = -G  =>  (B^-)^T = B^+
+    # delta is linear in X: delta_k = B^- X_{k+1} - B^+ X_k
+    X = Z[:, :xd].reshape(lay.N, d, n).transpose(0, 2, 1)
+    recon = np.einsum("kij,kjc->kic", Bm, X[1:]) - np.einsum("kij,kjc->kic", Bp, X[:-1])
+    close(delta.reshape(K, d, n).transpose(0, 2, 1), recon)
+    # scaling all states by a scales delta by a (bitwise for a power of two)
+    Z2 = Z.copy()
+    Z2[:, :xd] *= 2.0
+    close(c.eval(Z2), 2.0 * delta, 0.0)
+    c.close()
+
+
+def test_compact_and_expand(config3_full):
+    import torch
+
+    so, Z, lay = config3_full
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    c = make_ctx(lay, G0, Gj)
+    delta, vals = c.eval_jac(Z)
+    Zd = torch.from_numpy(np.ascontiguousarray(Z)).cuda()
+    dd = torch.zeros(c.n_rows, dtype=torch.float64, device="cuda")
+    cd = torch.zeros(c.compact_nnz, dtype=torch.float64, device="cuda")
+    fd = torch.zeros(c.jac_nnz, dtype=torch.float64, device="cuda")
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.eval_jac_compact_dev(Zd, dd, cd)
+    c.jac_expand_dev(cd, fd)
+    torch.cuda.synchronize()
+    assert c.compact_per == 2 * lay.n**2 + lay.x_dim * (lay.m + 1)
+    assert np.array_equal(dd.cpu().numpy(), delta)
+    assert np.array_equal(fd.cpu().numpy(), vals)
+    c.close()
+
+
+def test_multistart_batch_matches_single():
+    """BASELINE config 5: B independent seeds in one launch == B single evaluations."""
+    import torch
+
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    Bn, N = 3, 6
+    Zs, lay = [], None
+    for s in range(Bn):
+        Z, lay = po.synthetic_trajectory(so, N, seed=1000 + s)
+        Zs.append(Z)
+    t = traj_from_Z(pa, Zs[0], lay)
+    ms = pa.HipPadeMultistart(G0, Gj, t, Bn)
+    delta, vals = ms.ctx.eval_jac(np.stack(Zs))
+    per_d, per_j = lay.x_dim * lay.K, po.jac_nnz_per_interval(lay) * lay.K
+    for s in range(Bn):
+        d_ref, j_ref = ref_lib.eval_jac(Zs[s], lay, G0, Gj)
+        close(delta[s * per_d : (s + 1) * per_d], d_ref)
+        close(vals[s * per_j : (s + 1) * per_j], j_ref)
+    r, cc = ms.ctx.jac_structure()
+    r0, c0 = po.jac_structure(lay)
+    assert np.array_equal(r[per_j : 2 * per_j], r0 + per_d) and np.array_equal(cc[per_j : 2 * per_j], c0 + lay.z_dim * lay.N)
+    ms.close()
+
+
+# ---- edge cases ------------------------------------------------------------------------------------------
+def _random_case(d, m, N, rng, x_off=0, pad=3):
+    n = 2 * d
+    xd = 2 * d * d
+    z_dim = x_off + xd + pad + m + 1
+    lay = po.Layout(d=d, m=m, N=N, z_dim=z_dim, x_off=x_off, u_off=x_off + xd + 1, dt_off=x_off + xd)
+    G0 = rng.standard_normal((n, n))
+    Gj = rng.standard_normal((m, n, n)) * (rng.random((m, n, n)) < 0.3) if m else np.zeros((0, n, n))
+    Z = rng.standard_normal((N, z_dim))
+    Z[:, lay.dt_off] = 0.05 + 0.1 * rng.random(N)
+    return lay, G0, Gj, Z
+
+
+@pytest.mark.parametrize(
+    "d,m,N,x_off",
+    [(1, 1, 2, 0), (1, 0, 3, 0), (2, 0, 4, 0), (3, 2, 2, 5), (4, 7, 3, 1), (8, 1, 3, 0), (16, 2, 3, 0), (27, 6, 2, 3), (32, 3, 2, 0)],
+)
+def test_edge_shapes_general_dense_generators(d, m, N, x_off):
+    """Minimum sizes (N=2 -> one interval, d=1), no drives, odd/nonzero state offsets, dense non-skew G,
+    dense-ish drives, the maximum supported d."""
+    rng = np.random.default_rng(1000 * d + 10 * m + N)
+    lay, G0, Gj, Z = _random_case(d, m, N, rng, x_off)
+    c = make_ctx(lay, G0, Gj)
+    d_ref, j_ref = ref_lib.eval_jac(Z, lay, G0, Gj)
+    for mfma in (1, 0):
+        c.set_option("use_mfma", mfma)
+        delta, vals = c.eval_jac(Z)
+        close(delta, d_ref, 1e-11)
+        close(vals, j_ref, 1e-11)
+    mu = rng.standard_normal((lay.K, lay.x_dim))
+    close(c.hess(Z, mu), ref_lib.hess(Z, mu, lay, G0, Gj), 1e-10)
+    c.close()
+
+
+def test_unsupported_requests_fail_loudly():
+    rng = np.random.default_rng(0)
+    lay, G0, Gj, Z = _random_case(2, 1, 3, rng)
+    with pytest.raises(pa.PclError) as ei:
+        make_ctx(lay, G0, Gj, pade_order=8)
+    assert ei.value.code == pa._lib.PCL_ENOTIMPL
+    c = make_ctx(lay, G0, Gj)
+    with pytest.raises(ValueError):
+        c.eval(Z[:-1])
+    with pytest.raises(pa.PclError):
+        c.set_option("no_such_option", 1)
+    c.close()
+
+
+def test_deterministic_bitwise_repeatability(config3_full):
+    so, Z, lay = config3_full
+    c = make_ctx(lay, so.G_drift, np.array(so.G_drives))
+    a = c.eval_jac(Z)
+    b = c.eval_jac(Z)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    c.close()
