@@ -132,7 +132,10 @@ int pcl_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *vals);
 int pcl_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *vals);
 
 /* device-pointer evaluation (asynchronous on the context's stream; results stay in HBM) ---- */
-int pcl_set_stream(pcl_ctx *ctx, void *hip_stream); /* hipStream_t; NULL = the context's own stream */
+/* Launch on the caller's hipStream_t (NULL = HIP's legacy default stream, which is what
+ * torch.cuda.current_stream().cuda_stream returns for the default stream). */
+int pcl_set_stream(pcl_ctx *ctx, void *hip_stream);
+int pcl_reset_stream(pcl_ctx *ctx); /* back to the context's own non-blocking stream (the initial state) */
 int pcl_sync(pcl_ctx *ctx);
 int pcl_eval_dev(pcl_ctx *ctx, const double *Z_dev, double *delta_dev);
 int pcl_eval_jac_dev(pcl_ctx *ctx, const double *Z_dev, double *delta_dev, double *vals_dev);

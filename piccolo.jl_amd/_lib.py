@@ -25,7 +25,7 @@ EXPORTS = [
     "pcl_constraint_dim", "pcl_jac_nnz", "pcl_hess_nnz",
     "pcl_jac_structure", "pcl_jac_structure_i64", "pcl_hess_structure", "pcl_hess_structure_i64",
     "pcl_eval", "pcl_jac", "pcl_eval_jac", "pcl_hess",
-    "pcl_set_stream", "pcl_sync", "pcl_eval_dev", "pcl_eval_jac_dev", "pcl_hess_dev",
+    "pcl_set_stream", "pcl_reset_stream", "pcl_sync", "pcl_eval_dev", "pcl_eval_jac_dev", "pcl_hess_dev",
     "pcl_jac_compact_nnz", "pcl_eval_jac_compact_dev", "pcl_jac_expand_dev",
     "pcl_set_option", "pcl_get_option",
 ]  # fmt: skip
@@ -110,6 +110,7 @@ def load():
     L.pcl_eval_jac.argtypes = [vp, vp, vp, vp]
     L.pcl_hess.argtypes = [vp, vp, vp, vp]
     L.pcl_set_stream.argtypes = [vp, vp]
+    L.pcl_reset_stream.argtypes = [vp]
     L.pcl_sync.argtypes = [vp]
     L.pcl_eval_dev.argtypes = [vp, vp, vp]
     L.pcl_eval_jac_dev.argtypes = [vp, vp, vp, vp]

@@ -50,6 +50,14 @@ struct KParams {
     const int *csc_row;
     const double *csc_val;
     const int *x_offs;     // per-member state offsets
+    const int *umap;       // n*n: index into the union-pattern coefficient table, or -1
+    const double *ell_val; // ELL form of the drives: [m][n][ell_w] (row-major), zero padded
+    const int *ell_col;
+    int ell_w, ell_lds;    // ELL width; 1 = stage the ELL arrays in LDS
+    const unsigned char *uell_l;  // per union entry: up to uell_w (drive index, value) pairs, zero padded
+    const double *uell_v;
+    int uell_w;
+    int iso;               // 1: G0 and every G_l are exact iso(.) images -> G^2 needs only its first d columns
     long long z_batch_stride;   // doubles between trajectories (0 in MEMBERS mode)
     long long g0_batch_stride;  // n*n if per-member drift else 0
     long long jac_per;          // doubles per (b,k) in `jac`
@@ -61,6 +69,7 @@ struct KParams {
     int LD;       // LDS leading dimension of every n-row tile
     int compact;  // 1: write unique blocks only (jac_per is the compact size)
     int nt;       // 1: nontemporal streaming stores
+    int ablate;   // DEBUG ONLY (wrong results): bit0 skip matrix products, bit1 skip block streaming, bit2 skip column outputs
 };
 
 // ------------------------------------------------------------------------------------------
@@ -225,13 +234,13 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
             M1[i + LD * ((2 + l) * nc + c)] = acc;
         }
         __syncthreads();
-        gemm_lds<MFMA, false>(G, LD, G, LD, G2, LD, n, n, n);
+        if (!(p.ablate & 1)) gemm_lds<MFMA, false>(G, LD, G, LD, G2, LD, n, n, n);
     }
-    gemm_lds<MFMA, false>(G, LD, M1, LD, W1, LD, n, ncols1, n);
+    if (!(p.ablate & 1)) gemm_lds<MFMA, false>(G, LD, M1, LD, W1, LD, n, ncols1, n);
     __syncthreads();
 
     // pass 2: G2D = G * (G D);  T = -c1 S + c2 G D
-    gemm_lds<MFMA, false>(G, LD, W1 + LD * nc, LD, G2D, LD, n, nc, n);
+    if (!(p.ablate & 1)) gemm_lds<MFMA, false>(G, LD, W1 + LD * nc, LD, G2D, LD, n, nc, n);
     if (JAC) {
         for (int e = tid; e < nc * n; e += nth) {
             const int c = e / n, i = e % n;
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
     const long long bk = (long long)b * p.K + k;
     double *jb = JAC ? p.jac + bk * p.jac_per : nullptr;
     const long long blk = p.compact ? (long long)n * n : (long long)d * n * n;  // size of seg 0 / seg 1
-    for (int e = tid; e < nce * n; e += nth) {
+    for (int e = tid; e < ((p.ablate & 4) ? 0 : nce * n); e += nth) {
         const int c = e / n, i = e % n;
         const double gs = W1[i + LD * c], g2d = G2D[i + LD * c];
         const long long r = (long long)(c0 + c) * n + i;
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
         if (JAC) jb[2 * blk + (long long)m * xd + r] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
     }
     if (JAC) {
-        for (int e = tid; e < m * nce * n; e += nth) {
+        for (int e = tid; e < ((p.ablate & 4) ? 0 : m * nce * n); e += nth) {
             const int i = e % n, c = (e / n) % nce, l = e / (n * nce);
             const int *rp = p.csr_ptr + l * (n + 1);
             double acc = 0.0;
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
             cbeg = 0;
             cend = (s == 0) ? 1 : 0;
         }
-        for (int q = tid; q < half; q += nth) {
+        for (int q = tid; q < ((p.ablate & 2) ? 0 : half); q += nth) {
             const int pos = 2 * q;
             const int i = pos % n, j = pos / n;
             const double g0 = G[i + LD * j], g1 = G[i + 1 + LD * j];
@@ -283,6 +292,295 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
                 store2(o0 + blk, bm0, bm1, p.nt);
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused residual + Jacobian kernel, version 2 (default): 8 wavefronts, wave-specialised.
+//   waves 0-3 ("matrix" waves) own one 16-row tile each and run every MFMA product;
+//   waves 4-7 ("stream" waves) apply the sparse drives (VALU) and then stream the slice's share of
+//   the replicated B^{+-} blocks to HBM while the matrix waves compute the slice's columns.
+// Phases (separated by one __syncthreads each):
+//   0  all   : G(u_k) -> LDS (one pass: drift tile + union-pattern map), S, D, ELL drives -> LDS
+//   1  matrix: G2 = G*G (first d columns + mirror if iso)      stream: M1[:, (2+l)nc..] = G_l D
+//   2  matrix: W1 = G*M1, G2D = G2*D                            stream: -B^+, B^- block copies -> HBM
+//   3  all   : delta, d/ddt, d/du_l columns -> HBM
+// LDS map (doubles): G [LD*n] | G2 [LD*n] | M1 [LD*ncols1] | W1 [LD*ncols1] | G2D [LD*nc] | ELL val/col | slack
+// MFMA operand loads are unconditional: a tile may read rows/columns past the matrix edge (the
+// neighbouring buffer); such lanes only feed output rows/columns that are never stored.
+// ------------------------------------------------------------------------------------------
+template <int MODE>  // 0: plain store; 1: store + iso mirror (C = G2 first d columns)
+__device__ __forceinline__ void wave_rowgemm(const double *__restrict__ A, int lda, const double *__restrict__ B,
+                                             int ldb, double *__restrict__ C, int ldc, int M, int Nc, int Kd, int wave,
+                                             int nwaves, int lane, int dmir) {
+    const int rt_n = (M + 15) >> 4, ct_n = (Nc + 15) >> 4;
+    const int kfull = Kd >> 2, krem = Kd & 3;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int rt = wave; rt < rt_n; rt += nwaves) {
+        const double *Ap = A + rt * 16 + li + lda * lk;
+        for (int ct = 0; ct < ct_n; ct += 2) {
+            const bool two = ct + 1 < ct_n;
+            const double *Bp0 = B + lk + ldb * (ct * 16 + li);
+            const double *Bp1 = Bp0 + (two ? ldb * 16 : 0);
+            double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            if (two) {
+#pragma unroll 2
+                for (int ks = 0; ks < kfull; ++ks) {
+                    const double a = Ap[lda * 4 * ks], b0 = Bp0[4 * ks], b1 = Bp1[4 * ks];
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+                }
+            } else {
+#pragma unroll 2
+                for (int ks = 0; ks < kfull; ++ks) {
+                    const double a = Ap[lda * 4 * ks], b0 = Bp0[4 * ks];
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
+                }
+            }
+            if (krem) {
+                const bool ok = lk < krem;
+                const double a = ok ? Ap[lda * 4 * kfull] : 0.0;
+                const double b0 = ok ? Bp0[4 * kfull] : 0.0;
+                const double b1 = ok ? Bp1[4 * kfull] : 0.0;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (t == 1 && !two) break;
+                const int col = (ct + t) * 16 + li;
+                if (col < Nc) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rt * 16 + lk + 4 * r;
+                        const double v = t ? acc1[r] : acc0[r];
+                        if (row < M) {
+                            C[row + ldc * col] = v;
+                            if (MODE == 1) {
+                                if (row < dmir)
+                                    C[row + dmir + ldc * (col + dmir)] = v;
+                                else
+                                    C[row - dmir + ldc * (col + dmir)] = -v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Persistent form: the grid is (workgroups that fit on the chip); each workgroup walks the work
+// items (b, k, s) with stride gridDim.x.  What does not depend on the item lives in registers / LDS
+// for the whole launch: every thread keeps its elements of the drift tile G0 and the (drive, value)
+// pairs of the union pattern that touch them, and the ELL form of the drives is staged in LDS once.
+// Per item only u_k, dt_k and the slice's state columns are read from memory.
+#define PCL_NGE 8  // G elements per thread: n*n <= 64*64 = 8 * 512
+
+template <bool JAC, int WU>  // WU: (drive,value) pairs per G element held in registers; -1: general (table in memory)
+__global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
+    extern __shared__ double lds[];
+    const int n = p.n, d = p.d, m = p.m, LD = p.LD, nc = p.nc;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const bool matrix_wave = wave < 4;
+    const int stid = tid - 256;  // index among the stream waves' threads
+
+    const int ncols1 = JAC ? (2 + m) * nc : 2 * nc;
+    const int n_ell = m * n * p.ell_w;
+    double *G = lds;
+    double *G2 = G + LD * n;
+    double *M1 = G2 + (JAC ? LD * n : 0);
+    double *W1 = M1 + LD * ncols1;
+    double *G2D = W1 + LD * ncols1;
+    double *ellv_l = G2D + LD * nc;
+    unsigned short *ellc_l = reinterpret_cast<unsigned short *>(ellv_l + n_ell);
+    const long long xd = (long long)n * d;
+    const int ew = p.ell_w;
+
+    // ---- launch-invariant per-thread state ----------------------------------------------------------
+    constexpr int WUR = WU > 0 ? WU : 1;
+    double g0r[PCL_NGE];
+    int gidx[PCL_NGE];
+    int uq[PCL_NGE];  // WU == -1 only
+    unsigned char ul[PCL_NGE][WUR];
+    double uv[PCL_NGE][WUR];
+#pragma unroll
+    for (int r = 0; r < PCL_NGE; ++r) {
+        const int e = tid + 512 * r;
+        gidx[r] = -1;
+        g0r[r] = 0.0;
+        uq[r] = -1;
+#pragma unroll
+        for (int w = 0; w < WUR; ++w) {
+            ul[r][w] = 0;
+            uv[r][w] = 0.0;
+        }
+        if (e < n * n) {
+            gidx[r] = (e % n) + LD * (e / n);
+            if (!p.g0_batch_stride) g0r[r] = p.G0[e];
+            const int q = (m > 0) ? p.umap[e] : -1;
+            uq[r] = q;
+            if (WU > 0 && q >= 0) {
+#pragma unroll
+                for (int w = 0; w < WUR; ++w) {
+                    ul[r][w] = p.uell_l[q * WUR + w];
+                    uv[r][w] = p.uell_v[q * WUR + w];
+                }
+            }
+        }
+    }
+    const bool stage = JAC && p.ell_lds;
+    if (stage) {
+        for (int e = tid; e < n_ell; e += 512) {
+            ellv_l[e] = p.ell_val[e];
+            ellc_l[e] = (unsigned short)p.ell_col[e];
+        }
+    }
+
+    const int n_items = p.batch * p.K * p.S;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int s = item % p.S;
+        const int k = (item / p.S) % p.K;
+        const int b = item / (p.S * p.K);
+        const int c0 = s * nc;
+        const int nce = min(nc, d - c0);
+
+        const double *Zb = p.Z + (long long)b * p.z_batch_stride;
+        const double *zk = Zb + (long long)k * p.z_dim;
+        const double *zn = zk + p.z_dim;
+        const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+        const double h = zk[p.dt_off];
+        const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
+        const double *uk = zk + p.u_off;
+
+        // ---- phase 0: G(u_k), S, D -> LDS -------------------------------------------------------------
+        if (!(p.ablate & 8)) {
+            const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
+#pragma unroll
+            for (int r = 0; r < PCL_NGE; ++r) {
+                if (gidx[r] >= 0) {
+                    double g = p.g0_batch_stride ? G0b[tid + 512 * r] : g0r[r];
+                    if (WU > 0) {
+#pragma unroll
+                        for (int w = 0; w < WUR; ++w) g += uk[ul[r][w]] * uv[r][w];
+                    } else if (WU < 0 && uq[r] >= 0) {
+                        const double *cf = p.ucoef + (long long)uq[r] * m;
+                        for (int l = 0; l < m; ++l) g += uk[l] * cf[l];
+                    }
+                    G[gidx[r]] = g;
+                }
+            }
+        }
+        for (int e = tid; e < nc * n; e += 512) {
+            const int c = e / n, i = e % n;
+            double xs = 0.0, xdv = 0.0;
+            if (c < nce) {
+                const double xn = zn[x_off + (c0 + c) * n + i], xc = zk[x_off + (c0 + c) * n + i];
+                xs = xn + xc;
+                xdv = xn - xc;
+            }
+            M1[i + LD * c] = xs;
+            M1[i + LD * (nc + c)] = xdv;
+        }
+        __syncthreads();
+
+        // ---- phase 1 ------------------------------------------------------------------------------------
+        if (JAC) {
+            if (matrix_wave) {
+                if (!(p.ablate & 1)) {
+                    if (p.iso)
+                        wave_rowgemm<1>(G, LD, G, LD, G2, LD, n, d, n, wave, 4, lane, d);
+                    else
+                        wave_rowgemm<0>(G, LD, G, LD, G2, LD, n, n, n, wave, 4, lane, 0);
+                }
+            } else if (!(p.ablate & 16)) {
+                const double *Dm = M1 + LD * nc;
+                for (int e = stid; e < m * nc * n; e += 256) {
+                    const int i = e % n, c = (e / n) % nc, l = e / (n * nc);
+                    const int base = (l * n + i) * ew;
+                    double acc = 0.0;
+                    if (stage) {
+                        for (int q = 0; q < ew; ++q) acc += ellv_l[base + q] * Dm[ellc_l[base + q] + LD * c];
+                    } else {
+                        for (int q = 0; q < ew; ++q) acc += p.ell_val[base + q] * Dm[p.ell_col[base + q] + LD * c];
+                    }
+                    M1[i + LD * ((2 + l) * nc + c)] = acc;
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- phase 2 ------------------------------------------------------------------------------------
+        const long long bk = (long long)b * p.K + k;
+        double *jb = JAC ? p.jac + bk * p.jac_per : nullptr;
+        const long long blk = p.compact ? (long long)n * n : (long long)d * n * n;  // size of seg 0 / seg 1
+        if (matrix_wave) {
+            if (!(p.ablate & 1)) {
+                wave_rowgemm<0>(G, LD, M1, LD, W1, LD, n, ncols1, n, wave, 4, lane, 0);
+                if (JAC) wave_rowgemm<0>(G2, LD, M1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
+            }
+        } else if (JAC && !(p.ablate & 2)) {
+            // pair index q covers flat column-major positions 2q, 2q+1 (same column since n is even)
+            const int half = (n * n) >> 1;
+            int cbeg = c0, cend = c0 + nce;
+            if (p.compact) {  // unique blocks only: slice 0 writes the single copy
+                cbeg = 0;
+                cend = (s == 0) ? 1 : 0;
+            }
+            for (int q = stid; q < half; q += 256) {
+                const int pos = 2 * q;
+                const int i = pos % n, j = pos / n;
+                const double g0 = G[i + LD * j], g1 = G[i + 1 + LD * j];
+                const double h0 = G2[i + LD * j], h1 = G2[i + 1 + LD * j];
+                const double id0 = (i == j) ? 1.0 : 0.0, id1 = (i + 1 == j) ? 1.0 : 0.0;
+                const double e0 = id0 + c2 * h0, e1 = id1 + c2 * h1;
+                const double bp0 = -(e0 + c1 * g0), bp1 = -(e1 + c1 * g1);
+                const double bm0 = e0 - c1 * g0, bm1 = e1 - c1 * g1;
+                for (int c = cbeg; c < cend; ++c) {
+                    double *o0 = jb + (long long)c * n * n + pos;
+                    store2(o0, bp0, bp1, p.nt);
+                    store2(o0 + blk, bm0, bm1, p.nt);
+                }
+            }
+        }
+        __syncthreads();
+        if (!JAC) {  // eval only: delta needs G (G D), a second dependent product
+            if (matrix_wave && !(p.ablate & 1)) wave_rowgemm<0>(G, LD, W1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
+            __syncthreads();
+        }
+
+        // ---- phase 3: column outputs ---------------------------------------------------------------------
+        if (!(p.ablate & 4)) {
+            for (int e = tid; e < nce * n; e += 512) {
+                const int c = e / n, i = e % n;
+                const double gs = W1[i + LD * c], g2d = G2D[i + LD * c];
+                const long long r = (long long)(c0 + c) * n + i;
+                if (p.delta) p.delta[bk * xd + r] = M1[i + LD * (nc + c)] - c1 * gs + c2 * g2d;
+                if (JAC) jb[2 * blk + (long long)m * xd + r] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
+            }
+            if (JAC) {
+                const double *GDm = W1 + LD * nc;
+                for (int e = tid; e < m * nce * n; e += 512) {
+                    const int i = e % n, c = (e / n) % nce, l = e / (n * nce);
+                    const int base = (l * n + i) * ew;
+                    double acc = 0.0;
+                    if (stage) {
+                        for (int q = 0; q < ew; ++q) {
+                            const int col = ellc_l[base + q];
+                            acc += ellv_l[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
+                        }
+                    } else {
+                        for (int q = 0; q < ew; ++q) {
+                            const int col = p.ell_col[base + q];
+                            acc += p.ell_val[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
+                        }
+                    }
+                    jb[2 * blk + (long long)l * xd + (long long)(c0 + c) * n + i] = acc + c2 * W1[i + LD * ((2 + l) * nc + c)];
+                }
+            }
+        }
+        __syncthreads();  // LDS is rewritten by the next item's phase 0
     }
 }
 
@@ -477,10 +775,17 @@ struct pcl_ctx {
     double *dG0 = nullptr, *ducoef = nullptr, *dcsr_val = nullptr, *dcsc_val = nullptr;
     int *dupos = nullptr, *dcsr_ptr = nullptr, *dcsr_col = nullptr, *dcsc_ptr = nullptr, *dcsc_row = nullptr, *dxoffs = nullptr;
     int n_upos = 0;
+    int *dumap = nullptr, *dell_col = nullptr;
+    double *dell_val = nullptr;
+    int ell_w = 0, iso = 0, uell_w = 0;
+    unsigned char *duell_l = nullptr;
+    double *duell_v = nullptr;
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dmu = nullptr, *ddelta = nullptr, *dvals = nullptr, *dhess = nullptr;
     // options
-    int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0;
+    int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_ablate = 0, opt_kernel = 2;
+    int64_t opt_grid = 0;  // 0: resident workgroups (persistent kernel)
+    size_t lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // last MaxDynamicSharedMemorySize set per kernel variant
     int max_lds = 0;
     int n_cu = 0;
     mutable std::string err;
@@ -644,6 +949,54 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
         }
         csc_ptr[(size_t)l * (n + 1) + n] = (int)csc_row.size();
     }
+    int uell_w = 0;
+    for (size_t q = 0; q < upos.size(); ++q) {
+        int cnt = 0;
+        for (int l = 0; l < m; ++l) cnt += ucoef[q * m + l] != 0.0;
+        uell_w = std::max(uell_w, cnt);
+    }
+    uell_w = std::max(uell_w, 1);
+    std::vector<unsigned char> uell_l(std::max<size_t>(upos.size(), 1) * uell_w, 0);
+    std::vector<double> uell_v(std::max<size_t>(upos.size(), 1) * uell_w, 0.0);
+    for (size_t q = 0; q < upos.size(); ++q) {
+        int cnt = 0;
+        for (int l = 0; l < m; ++l)
+            if (ucoef[q * m + l] != 0.0) {
+                uell_l[q * uell_w + cnt] = (unsigned char)l;
+                uell_v[q * uell_w + cnt] = ucoef[q * m + l];
+                ++cnt;
+            }
+    }
+    ctx->uell_w = uell_w;
+    std::vector<int> umap(nn, -1);
+    for (size_t q = 0; q < upos.size(); ++q) umap[upos[q]] = (int)q;
+    int ell_w = m > 0 ? 1 : 0;
+    for (int l = 0; l < m; ++l)
+        for (int i = 0; i < n; ++i) ell_w = std::max(ell_w, csr_ptr[(size_t)l * (n + 1) + i + 1] - csr_ptr[(size_t)l * (n + 1) + i]);
+    std::vector<int> ell_col((size_t)m * n * ell_w, 0);
+    std::vector<double> ell_val((size_t)m * n * ell_w, 0.0);
+    for (int l = 0; l < m; ++l)
+        for (int i = 0; i < n; ++i) {
+            const int beg = csr_ptr[(size_t)l * (n + 1) + i], end = csr_ptr[(size_t)l * (n + 1) + i + 1];
+            for (int q = beg; q < end; ++q) {
+                ell_col[((size_t)l * n + i) * ell_w + (q - beg)] = csr_col[q];
+                ell_val[((size_t)l * n + i) * ell_w + (q - beg)] = csr_val[q];
+            }
+        }
+    ctx->ell_w = ell_w;
+    // exact iso structure  M = [[A, -B], [B, A]]  of the drift(s) and of every drive?
+    auto is_iso = [&](const double *A) {
+        for (int j = 0; j < d; ++j)
+            for (int i = 0; i < d; ++i) {
+                if (A[(i + d) + (size_t)n * (j + d)] != A[i + (size_t)n * j]) return false;
+                if (A[i + (size_t)n * (j + d)] != -A[(i + d) + (size_t)n * j]) return false;
+            }
+        return true;
+    };
+    bool iso = true;
+    for (int bb = 0; bb < (dsc->per_member_G0 ? dsc->batch : 1); ++bb) iso = iso && is_iso(dsc->G0 + bb * nn);
+    for (int l = 0; l < m; ++l) iso = iso && is_iso(dsc->Gj + l * nn);
+    ctx->iso = iso ? 1 : 0;
     std::vector<double> g0(dsc->G0, dsc->G0 + nn * (dsc->per_member_G0 ? dsc->batch : 1));
     CREATE_TRY(upload(ctx, &ctx->dG0, g0));
     CREATE_TRY(upload(ctx, &ctx->dupos, upos));
@@ -654,6 +1007,11 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     CREATE_TRY(upload(ctx, &ctx->dcsc_ptr, csc_ptr));
     CREATE_TRY(upload(ctx, &ctx->dcsc_row, csc_row));
     CREATE_TRY(upload(ctx, &ctx->dcsc_val, csc_val));
+    CREATE_TRY(upload(ctx, &ctx->dumap, umap));
+    CREATE_TRY(upload(ctx, &ctx->duell_l, uell_l));
+    CREATE_TRY(upload(ctx, &ctx->duell_v, uell_v));
+    CREATE_TRY(upload(ctx, &ctx->dell_col, ell_col));
+    CREATE_TRY(upload(ctx, &ctx->dell_val, ell_val));
     std::vector<int> xo(ctx->x_offs.begin(), ctx->x_offs.end());
     CREATE_TRY(upload(ctx, &ctx->dxoffs, xo));
 #undef CREATE_TRY
@@ -666,7 +1024,8 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     void *ptrs[] = {ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
-                    ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess};
+                    ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
+                    ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -786,7 +1145,9 @@ extern "C" int pcl_hess_structure_i64(const pcl_ctx *ctx, int64_t *rows, int64_t
 }
 
 // --- launch helpers -------------------------------------------------------------------------
-static int lds_ld(int d) { return 2 * (d | 1); }  // 2*LD = 4*odd (mod 64): conflict-free b-operand reads
+// LD = (n rounded up to 4) + 2  ==  2*odd: conflict-free ds_read_b64 of the MFMA b operand
+// (16 columns x 2 k-rows per half-wave land on 32 distinct 8-byte bank pairs).
+static int lds_ld(int d) { return ((2 * d + 3) & ~3) + 2; }
 
 static void fill_params(const pcl_ctx *ctx, KParams &p) {
     memset(&p, 0, sizeof p);
@@ -802,6 +1163,14 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.csc_row = ctx->dcsc_row;
     p.csc_val = ctx->dcsc_val;
     p.x_offs = ctx->dxoffs;
+    p.umap = ctx->dumap;
+    p.uell_l = ctx->duell_l;
+    p.uell_v = ctx->duell_v;
+    p.uell_w = ctx->uell_w;
+    p.ell_val = ctx->dell_val;
+    p.ell_col = ctx->dell_col;
+    p.ell_w = ctx->ell_w;
+    p.iso = ctx->iso;
     p.z_batch_stride = D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0;
     p.g0_batch_stride = D.per_member_G0 ? (long long)ctx->n * ctx->n : 0;
     p.d = D.d;
@@ -814,32 +1183,66 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.batch = D.batch;
     p.LD = lds_ld(D.d);
     p.nt = (int)ctx->opt_nt;
+    p.ablate = (int)ctx->opt_ablate;
     p.hess_per = hess_per(ctx);
 }
 
-static size_t fused_lds_bytes(const KParams &p, bool jac) {
+static size_t fused_lds_bytes(const KParams &p, bool jac) {  // version-1 kernel
     const size_t ncols1 = jac ? (size_t)(2 + p.m) * p.nc : 2 * (size_t)p.nc;
     size_t dbl = (size_t)p.LD * p.n * (jac ? 2 : 1) + 2 * p.LD * ncols1 + 2 * (size_t)p.LD * p.nc + 8 + p.m;
     return dbl * sizeof(double);
 }
 
+static const size_t ELL_LDS_MAX_BYTES = 8192;
+
+static size_t fused2_lds_bytes(const KParams &p, bool jac, bool ell_lds) {  // version-2 kernel
+    const size_t ncols1 = jac ? (size_t)(2 + p.m) * p.nc : 2 * (size_t)p.nc;
+    const size_t n_ell = (size_t)p.m * p.n * p.ell_w;
+    size_t bytes = ((size_t)p.LD * p.n * (jac ? 2 : 1) + 2 * p.LD * ncols1 + (size_t)p.LD * p.nc) * sizeof(double);
+    if (jac && ell_lds) bytes += n_ell * sizeof(double) + (n_ell * sizeof(unsigned short) + 7) / 8 * 8;
+    return bytes + 128;  // slack: operand tiles may be read past the last buffer's edge
+}
+
+static bool ell_fits_lds(const pcl_ctx *ctx) {
+    const size_t n_ell = (size_t)ctx->desc.n_drives * ctx->n * ctx->ell_w;
+    return n_ell > 0 && n_ell * (sizeof(double) + sizeof(unsigned short)) <= ELL_LDS_MAX_BYTES;
+}
+
+// State columns per workgroup.  Every slice recomputes G(u_k)^2, so fewer, wider slices do less
+// arithmetic; but (i) two workgroups must fit in one CU's LDS so that one streams while the other
+// computes, and (ii) the grid has to cover the chip a few times over.
 static int choose_cols_per_slice(const pcl_ctx *ctx, bool jac) {
     const int d = ctx->desc.d;
     if (ctx->opt_cols_per_slice > 0) return (int)std::min<int64_t>(ctx->opt_cols_per_slice, d);
-    if (!jac) return std::min(d, 16);
-    // Enough workgroups to cover the chip a few times over, but as few slices as possible
-    // (every slice recomputes G^2): aim at >= 3 workgroups per CU.
+    KParams p;
+    memset(&p, 0, sizeof p);
+    p.n = ctx->n;
+    p.m = ctx->desc.n_drives;
+    p.LD = ((ctx->n + 3) & ~3) + 2;
+    p.ell_w = ctx->ell_w;
+    const bool v2 = ctx->opt_kernel == 2;
+    const bool ell = ell_fits_lds(ctx);
+    auto bytes = [&](int nc) {
+        p.nc = nc;
+        return v2 ? fused2_lds_bytes(p, jac, ell) : fused_lds_bytes(p, jac);
+    };
     const long long bk = (long long)ctx->desc.batch * ctx->K;
     const long long want = 3LL * std::max(ctx->n_cu, 1);
     int best = 1;
     for (int nc = d; nc >= 1; --nc) {
+        if (bytes(nc) > (size_t)ctx->max_lds / 2 && nc > 1) continue;  // keep two workgroups per CU
         const long long S = (d + nc - 1) / nc;
-        if (bk * S >= want || nc == 1) {
-            best = nc;
-            break;
-        }
+        best = nc;
+        if (!jac || bk * S >= want) break;
     }
-    return std::max(best, 1);
+    return best;
+}
+
+static int set_lds_attr(pcl_ctx *ctx, const void *kern, int slot, size_t lds) {
+    if (ctx->lds_set[slot] == lds) return PCL_OK;
+    HIP_TRY(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ctx->lds_set[slot] = lds;
+    return PCL_OK;
 }
 
 static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *jac, bool compact) {
@@ -852,21 +1255,39 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     p.compact = compact ? 1 : 0;
     p.jac_per = compact ? jac_per_compact(ctx) : jac_per_full(ctx);
     const bool want_jac = jac != nullptr;
+    const bool v2 = ctx->opt_kernel == 2 && ctx->opt_use_mfma != 0;
+    p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
     p.nc = choose_cols_per_slice(ctx, want_jac);
-    size_t lds = fused_lds_bytes(p, want_jac);
+    auto bytes = [&]() { return v2 ? fused2_lds_bytes(p, want_jac, p.ell_lds != 0) : fused_lds_bytes(p, want_jac); };
+    size_t lds = bytes();
     while (lds > (size_t)ctx->max_lds && p.nc > 1) {
         p.nc = (p.nc + 1) / 2;
-        lds = fused_lds_bytes(p, want_jac);
+        lds = bytes();
     }
     if (lds > (size_t)ctx->max_lds) return fail(ctx, PCL_ESHAPE, "fused kernel needs %zu B of LDS (> %d)", lds, ctx->max_lds);
     p.S = (p.d + p.nc - 1) / p.nc;
     const long long grid = (long long)p.batch * p.K * p.S;
     if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "grid too large");
-    const bool mf = ctx->opt_use_mfma != 0;
-    auto kern = want_jac ? (mf ? pcl_fused_kernel<true, true> : pcl_fused_kernel<true, false>)
-                         : (mf ? pcl_fused_kernel<false, true> : pcl_fused_kernel<false, false>);
-    HIP_TRY(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx->stream, p);
+    if (v2) {
+        typedef void (*kern_t)(const KParams);
+        const int wu = ctx->uell_w <= 2 ? ctx->uell_w : -1;
+        kern_t kern = want_jac ? (wu == 1 ? (kern_t)pcl_fused_kernel_v2<true, 1> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<true, 2> : (kern_t)pcl_fused_kernel_v2<true, -1>)
+                               : (wu == 1 ? (kern_t)pcl_fused_kernel_v2<false, 1> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<false, 2> : (kern_t)pcl_fused_kernel_v2<false, -1>);
+        int rc = set_lds_attr(ctx, (const void *)kern, want_jac ? 4 : 5, lds);  // wu is fixed per context
+        if (rc != PCL_OK) return rc;
+        // persistent grid: as many workgroups as are resident at once
+        const int per_cu = std::max(1, std::min(2, (int)((size_t)ctx->max_lds / lds)));
+        const long long resident = (long long)per_cu * std::max(ctx->n_cu, 1);
+        const long long g2 = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, grid) : std::min(grid, resident);
+        hipLaunchKernelGGL(kern, dim3((unsigned)g2), dim3(512), lds, ctx->stream, p);
+    } else {
+        const bool mf = ctx->opt_use_mfma != 0;
+        auto kern = want_jac ? (mf ? pcl_fused_kernel<true, true> : pcl_fused_kernel<true, false>)
+                             : (mf ? pcl_fused_kernel<false, true> : pcl_fused_kernel<false, false>);
+        int rc = set_lds_attr(ctx, (const void *)kern, (want_jac ? 0 : 2) + (mf ? 0 : 1), lds);
+        if (rc != PCL_OK) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx->stream, p);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return PCL_OK;
 }
@@ -901,7 +1322,12 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
 // --- device-pointer API -----------------------------------------------------------------------
 extern "C" int pcl_set_stream(pcl_ctx *ctx, void *s) {
     if (!ctx) return PCL_EINVAL;
-    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    ctx->stream = (hipStream_t)s;  // NULL is HIP's legacy default stream
+    return PCL_OK;
+}
+extern "C" int pcl_reset_stream(pcl_ctx *ctx) {
+    if (!ctx) return PCL_EINVAL;
+    ctx->stream = ctx->own_stream;
     return PCL_OK;
 }
 extern "C" int pcl_sync(pcl_ctx *ctx) {
@@ -1007,6 +1433,14 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_use_mfma = v != 0;
     else if (!strcmp(key, "nt_stores"))
         ctx->opt_nt = v != 0;
+    else if (!strcmp(key, "debug_ablate"))  // profiling aid: results are WRONG when non-zero
+        ctx->opt_ablate = v;
+    else if (!strcmp(key, "grid"))
+        ctx->opt_grid = v;
+    else if (!strcmp(key, "kernel_version")) {
+        if (v != 1 && v != 2) return fail(ctx, PCL_EINVAL, "kernel_version must be 1 or 2");
+        ctx->opt_kernel = v;
+    }
     else
         return fail(ctx, PCL_EINVAL, "unknown option '%s'", key);
     return PCL_OK;
@@ -1023,6 +1457,24 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = choose_cols_per_slice(ctx, true);
     else if (!strcmp(key, "n_cu"))
         *v = ctx->n_cu;
+    else if (!strcmp(key, "kernel_version"))
+        *v = ctx->opt_kernel;
+    else if (!strcmp(key, "occupancy_v2")) {
+        KParams p;
+        fill_params(ctx, p);
+        p.nc = choose_cols_per_slice(ctx, true);
+        const size_t lds = fused2_lds_bytes(p, true, ell_fits_lds(ctx));
+        int nb = 0;
+        (void)hipFuncSetAttribute((const void *)pcl_fused_kernel_v2<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pcl_fused_kernel_v2<true, 1>, 512, lds) != hipSuccess) nb = -1;
+        *v = nb * 1000000LL + (long long)lds;
+    }
+    else if (!strcmp(key, "iso_structured"))
+        *v = ctx->iso;
+    else if (!strcmp(key, "ell_width"))
+        *v = ctx->ell_w;
+    else if (!strcmp(key, "union_width"))
+        *v = ctx->uell_w;
     else
         return fail(ctx, PCL_EINVAL, "unknown option '%s'", key);
     return PCL_OK;

@@ -164,7 +164,12 @@ class _PclContext:
 
     # -- device-pointer calls (torch tensors on this context's GPU; asynchronous) ----------------
     def set_stream(self, stream_handle):
-        self._chk(self._L.pcl_set_stream(self._h, ctypes.c_void_p(stream_handle or 0)))
+        """Launch on this hipStream_t handle (0 = the legacy default stream); ``None`` restores
+        the context's own stream."""
+        if stream_handle is None:
+            self._chk(self._L.pcl_reset_stream(self._h))
+        else:
+            self._chk(self._L.pcl_set_stream(self._h, ctypes.c_void_p(int(stream_handle))))
 
     def sync(self):
         self._chk(self._L.pcl_sync(self._h))

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (kernel-trace stats + PMC passes) into small committed summaries."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+os.makedirs(dst, exist_ok=True)
+summary = {"tag": tag}
+
+def find(pat):
+    return sorted(glob.glob(os.path.join(src, "**", pat), recursive=True))
+
+# kernel stats
+for f in find("*kernel_stats.csv"):
+    rows = list(csv.DictReader(open(f)))
+    summary["kernel_stats"] = rows[:12]
+    with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as o:
+        o.write(open(f).read())
+# kernel trace: per-kernel durations (ns)
+for f in find("*kernel_trace.csv"):
+    dur = defaultdict(list)
+    meta = {}
+    for r in csv.DictReader(open(f)):
+        name = r.get("Kernel_Name", "?")
+        dur[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        meta[name] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
+    summary["kernel_trace"] = {k: dict(calls=len(v), avg_us=sum(v) / len(v) / 1e3, min_us=min(v) / 1e3, max_us=max(v) / 1e3, **meta[k]) for k, v in dur.items()}
+# PMC passes
+pmc = {}
+for f in find("*counter_collection.csv"):
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for kname, cs in acc.items():
+        for cname, vals in cs.items():
+            pmc.setdefault(kname, {})[cname] = dict(n=len(vals), avg=sum(vals) / len(vals), min=min(vals), max=max(vals))
+summary["pmc_per_dispatch"] = pmc
+json.dump(summary, open(os.path.join(dst, "%s_summary.json" % tag), "w"), indent=1)
+for k, v in summary.get("kernel_trace", {}).items():
+    print("%-60s calls=%d avg=%.2f us" % (k[:60], v["calls"], v["avg_us"]))
+for k, cs in pmc.items():
+    print(k[:80])
+    for c, v in sorted(cs.items()):
+        print("    %-34s avg=%.4g (n=%d)" % (c, v["avg"], v["n"]))

@@ -43,14 +43,25 @@ def make_ctx(lay, G0, Gj, **kw):
 
 
 # ---- committed golden vectors ----------------------------------------------------------------
+# kernel variants: (kernel_version, use_mfma).  (2,1) is the default wave-specialised MFMA kernel,
+# (1,1) the single-role MFMA kernel, (1,0) the plain-VALU kernel.
+VARIANTS = [(2, 1), (1, 1), (1, 0)]
+
+
+def set_variant(c, variant):
+    c.set_option("kernel_version", variant[0])
+    c.set_option("use_mfma", variant[1])
+
+
 @pytest.mark.parametrize("name", ["config1", "config2", "config3"])
-@pytest.mark.parametrize("mfma", [1, 0])
-def test_golden_vectors(name, mfma, golden, golden_meta):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_golden_vectors(name, variant, golden, golden_meta):
     v = golden("vec_" + name)
     m = golden_meta["oracle_vectors"][name]
     lay = po.Layout(d=m["d"], m=m["m"], N=m["N"], z_dim=m["z_dim"], x_off=m["x_off"], u_off=m["u_off"], dt_off=m["dt_off"])
     c = make_ctx(lay, v["G0"], v["Gj"])
-    c.set_option("use_mfma", mfma)
+    set_variant(c, variant)
+    assert c.get_option("iso_structured") == 1
     delta, vals = c.eval_jac(v["Z"])
     close(delta, v["delta"])
     close(vals, v["jac"])
@@ -69,13 +80,16 @@ def test_seeded_vs_oracle_all_slicings(cfg, N):
     G0, Gj = so.G_drift, np.array(so.G_drives)
     d_ref, j_ref = ref_lib.eval_jac(Z, lay, G0, Gj)
     c = make_ctx(lay, G0, Gj)
-    for nc in sorted({0, 1, 2, 3, 5, lay.d}):
-        if nc > lay.d:
-            continue
-        c.set_option("cols_per_slice", nc)
-        delta, vals = c.eval_jac(Z)
-        close(delta, d_ref)
-        close(vals, j_ref)
+    for variant in VARIANTS[:2]:
+        set_variant(c, variant)
+        for nc in sorted({0, 1, 2, 3, 5, lay.d}):
+            if nc > lay.d:
+                continue
+            c.set_option("cols_per_slice", nc)
+            delta, vals = c.eval_jac(Z)
+            close(delta, d_ref)
+            close(vals, j_ref)
+            close(c.eval(Z), d_ref)
     c.close()
 
 
@@ -223,8 +237,8 @@ def test_config3_full_size_vs_c_oracle(config3_full):
     d_ref, j_ref = ref_lib.eval_jac(Z, lay, G0, Gj)
     c = make_ctx(lay, G0, Gj)
     assert c.jac_per == 167670 and c.jac_nnz == 16599330 and c.hess_per == 20440
-    for mfma in (1, 0):
-        c.set_option("use_mfma", mfma)
+    for variant in VARIANTS:
+        set_variant(c, variant)
         delta, vals = c.eval_jac(Z)
         close(delta, d_ref)
         close(vals, j_ref)
@@ -253,10 +267,12 @@ def test_config3_size_independent_properties(config3_full):
     X = Z[:, :xd].reshape(lay.N, d, n).transpose(0, 2, 1)
     recon = np.einsum("kij,kjc->kic", Bm, X[1:]) - np.einsum("kij,kjc->kic", Bp, X[:-1])
     close(delta.reshape(K, d, n).transpose(0, 2, 1), recon)
-    # scaling all states by a scales delta by a (bitwise for a power of two)
+    # scaling all states by a scales delta by a (bitwise for a power of two), on both entry points
     Z2 = Z.copy()
     Z2[:, :xd] *= 2.0
-    close(c.eval(Z2), 2.0 * delta, 0.0)
+    close(c.eval(Z2), 2.0 * c.eval(Z), 0.0)
+    close(c.eval_jac(Z2)[0], 2.0 * delta, 0.0)
+    close(c.eval(Z), delta)  # evaluate! alone forms G(GD); the fused call forms (G^2)D: equal to rounding
     c.close()
 
 
@@ -330,11 +346,13 @@ def test_edge_shapes_general_dense_generators(d, m, N, x_off):
     lay, G0, Gj, Z = _random_case(d, m, N, rng, x_off)
     c = make_ctx(lay, G0, Gj)
     d_ref, j_ref = ref_lib.eval_jac(Z, lay, G0, Gj)
-    for mfma in (1, 0):
-        c.set_option("use_mfma", mfma)
+    assert c.get_option("iso_structured") == 0  # random dense generators: the general G^2 path
+    for variant in VARIANTS:
+        set_variant(c, variant)
         delta, vals = c.eval_jac(Z)
         close(delta, d_ref, 1e-11)
         close(vals, j_ref, 1e-11)
+        close(c.eval(Z), d_ref, 1e-11)
     mu = rng.standard_normal((lay.K, lay.x_dim))
     close(c.hess(Z, mu), ref_lib.hess(Z, mu, lay, G0, Gj), 1e-10)
     c.close()
