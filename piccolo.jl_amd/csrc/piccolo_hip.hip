@@ -323,19 +323,22 @@ __device__ __forceinline__ void wave_rowgemm(const double *__restrict__ A, int l
             const double *Bp0 = B + lk + ldb * (ct * 16 + li);
             const double *Bp1 = Bp0 + (two ? ldb * 16 : 0);
             double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-            if (two) {
-#pragma unroll 2
-                for (int ks = 0; ks < kfull; ++ks) {
-                    const double a = Ap[lda * 4 * ks], b0 = Bp0[4 * ks], b1 = Bp1[4 * ks];
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+            // operands of step ks+1 are requested before the MFMAs of step ks issue
+            double an = 0.0, b0n = 0.0, b1n = 0.0;
+            if (kfull > 0) {
+                an = Ap[0];
+                b0n = Bp0[0];
+                if (two) b1n = Bp1[0];
+            }
+            for (int ks = 0; ks < kfull; ++ks) {
+                const double a = an, b0 = b0n, b1 = b1n;
+                if (ks + 1 < kfull) {
+                    an = Ap[lda * 4 * (ks + 1)];
+                    b0n = Bp0[4 * (ks + 1)];
+                    if (two) b1n = Bp1[4 * (ks + 1)];
                 }
-            } else {
-#pragma unroll 2
-                for (int ks = 0; ks < kfull; ++ks) {
-                    const double a = Ap[lda * 4 * ks], b0 = Bp0[4 * ks];
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
-                }
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
             }
             if (krem) {
                 const bool ok = lk < krem;
@@ -581,6 +584,417 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
             }
         }
         __syncthreads();  // LDS is rewritten by the next item's phase 0
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused residual + Jacobian kernel, version 3 (default): ONE persistent 8-wave workgroup per CU,
+// software-pipelined across its work items (b, k, s).  In iteration `it` every wave
+//   * issues a quarter of the replicated -B^+ / B^- block stores of item it-1 (held in registers,
+//     copied out of the LDS tiles G, G^2 at the top of the iteration) and then
+//   * runs its share of one phase of item it:
+//       S1 S,D -> LDS | S2 G(u_k), G_l D | S3 G^2 (MFMA) | S4 G*M1, G^2*D (MFMA) | S5 column outputs.
+// Stores are asynchronous, so each burst drains to HBM underneath the phase that follows it: the
+// iteration time tends to max(matrix path, store stream), and the store stream is the roofline term.
+// What does not depend on the item (drift tile, union pattern of the drives, ELL drives) is staged in
+// LDS once per launch; per item only u_k, dt_k and the slice's state columns are read, one item ahead.
+// LDS map: G0 [n*n] | G [LD*n] | G2 [LD*n] | M1 [LD*ncols1] | W1 [LD*ncols1] | G2D [LD*nc] | us [2(m+1)] |
+//          union values [n_upos*uw] | ELL values [n_ell] | umap u16 [n*n] | union drive ids u8 | ELL cols u16
+// ------------------------------------------------------------------------------------------
+// One 16x16 output tile C[rt, ct] = A[rt, :] * B[:, ct] on one wavefront; operands of k-step ks+1 are
+// requested before the MFMA of step ks issues.  MODE 1 additionally writes the iso mirror of G^2.
+template <int MODE>
+__device__ __forceinline__ void wave_tile(const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
+                                          double *__restrict__ C, int ldc, int M, int Nc, int Kd, int rt, int ct,
+                                          int lane, int dmir) {
+    const int kfull = Kd >> 2, krem = Kd & 3;
+    const int li = lane & 15, lk = lane >> 4;
+    const double *Ap = A + rt * 16 + li + lda * lk;
+    const double *Bp = B + lk + ldb * (ct * 16 + li);
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    double an = 0.0, bn = 0.0;
+    if (kfull > 0) {
+        an = Ap[0];
+        bn = Bp[0];
+    }
+    for (int ks = 0; ks < kfull; ++ks) {
+        const double a = an, b = bn;
+        if (ks + 1 < kfull) {
+            an = Ap[lda * 4 * (ks + 1)];
+            bn = Bp[4 * (ks + 1)];
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    if (krem) {
+        const bool ok = lk < krem;
+        const double a = ok ? Ap[lda * 4 * kfull] : 0.0;
+        const double b = ok ? Bp[4 * kfull] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    const int col = ct * 16 + li;
+    if (col < Nc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + lk + 4 * r;
+            if (row < M) {
+                C[row + ldc * col] = acc[r];
+                if (MODE == 1) {
+                    if (row < dmir)
+                        C[row + dmir + ldc * (col + dmir)] = acc[r];
+                    else
+                        C[row - dmir + ldc * (col + dmir)] = -acc[r];
+                }
+            }
+        }
+    }
+}
+
+#define PCL_NSP 4  // B^{+-} value pairs per thread: (n*n/2) / 512 <= 4 for n <= 64
+#define PCL_NUE 4  // union-pattern entries per thread held in registers (REG path: n_upos <= 2048)
+#define PCL_NCI 4  // column steps of the element-wise passes held in registers (REG path)
+#define PCL_REGW 2 // (drive, value) pairs per union entry / ELL entries per row held in registers (REG path)
+
+// REG = true : the thread's union-pattern entries and ELL rows live in registers for the whole launch
+//              (needs union width <= 2, ELL width <= 2, n_upos <= 512*PCL_NUE, (1+m)*nc <= PCL_NCI*(512/n));
+// REG = false: general sizes, tables read from LDS / memory.
+template <bool REG>
+__global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
+    extern __shared__ double lds[];
+    const int n = p.n, d = p.d, m = p.m, LD = p.LD, nc = p.nc;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int nn = n * n;
+    const int ncols1 = (2 + m) * nc;
+    const int n_ell = m * n * p.ell_w, ew = p.ell_w;
+    const int uw = p.uell_w;
+    const long long xd = (long long)n * d;
+
+    double *G = lds;
+    double *G2 = G + LD * n;
+    double *M1 = G2 + LD * n;
+    double *W1 = M1 + LD * ncols1;
+    double *G2D = W1 + LD * ncols1;
+    double *us = G2D + LD * nc;
+    double *ellv = us + 2 * (m + 1);
+    unsigned short *ellc = reinterpret_cast<unsigned short *>(ellv + ((!REG && p.ell_lds) ? n_ell : 0));
+    const bool ell_lds = !REG && p.ell_lds;
+
+    // fixed thread coordinates: element-wise passes own row ri and walk columns; the block stream owns the
+    // row pair (pi, pi+1) and walks columns
+    const int ri = tid % n, rj0 = tid / n, rstep = 512 / n;
+    const bool ract = rj0 < rstep;
+    const int hn = n >> 1;
+    const int pi = 2 * (tid % hn), pj0 = tid / hn, pstep = max(512 / hn, 1);
+    const bool pact = pj0 < pstep;
+    const bool pf_x = nc <= rstep;  // one state element per thread: prefetchable
+    const int rt_n = (n + 15) >> 4;
+    const int g2_ct = p.iso ? (d + 15) >> 4 : rt_n;
+    const int w1_ct = (ncols1 + 15) >> 4;
+
+    // ---- launch-invariant state -------------------------------------------------------------------------
+    // G holds the drift tile everywhere except on the union pattern of the drives, which every item rewrites.
+    if (!p.g0_batch_stride)
+        for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = p.G0[e];
+    int un_idx[PCL_NUE];
+    double un_g0[PCL_NUE];
+    unsigned char un_l[PCL_NUE][PCL_REGW];
+    double un_v[PCL_NUE][PCL_REGW];
+    unsigned short el_c[PCL_NCI][PCL_REGW];
+    double el_v[PCL_NCI][PCL_REGW];
+    if (REG) {
+#pragma unroll
+        for (int r = 0; r < PCL_NUE; ++r) {
+            const int q = tid + 512 * r;
+            un_idx[r] = -1;
+            un_g0[r] = 0.0;
+#pragma unroll
+            for (int w = 0; w < PCL_REGW; ++w) {
+                un_l[r][w] = 0;
+                un_v[r][w] = 0.0;
+            }
+            if (q < p.n_upos) {
+                const int pos = p.upos[q];
+                un_idx[r] = (pos % n) + LD * (pos / n);
+                un_g0[r] = p.G0[pos];
+#pragma unroll
+                for (int w = 0; w < PCL_REGW; ++w)
+                    if (w < uw) {
+                        un_l[r][w] = p.uell_l[q * uw + w];
+                        un_v[r][w] = p.uell_v[q * uw + w];
+                    }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < PCL_NCI; ++t) {
+            const int cl = rj0 + rstep * t;  // combined column: block lb = cl / nc (0: delta/dt, 1+l: drive l)
+            const int lb = cl / nc;
+#pragma unroll
+            for (int w = 0; w < PCL_REGW; ++w) {
+                el_c[t][w] = 0;
+                el_v[t][w] = 0.0;
+                if (ract && lb >= 1 && lb <= m && w < ew) {
+                    el_c[t][w] = (unsigned short)p.ell_col[((lb - 1) * n + ri) * ew + w];
+                    el_v[t][w] = p.ell_val[((lb - 1) * n + ri) * ew + w];
+                }
+            }
+        }
+    } else if (p.ell_lds) {
+        for (int e = tid; e < n_ell; e += 512) {
+            ellv[e] = p.ell_val[e];
+            ellc[e] = (unsigned short)p.ell_col[e];
+        }
+    }
+
+    const int n_items = p.batch * p.K * p.S;
+    const int n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const long long blk = p.compact ? (long long)nn : (long long)d * nn;  // size of seg 0 / seg 1
+
+    double pf_v = 0.0, pf_xn = 0.0, pf_xc = 0.0;
+    auto request = [&](int item) {
+        const int s = item % p.S;
+        const int k = (item / p.S) % p.K;
+        const int b = item / (p.S * p.K);
+        const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
+        if (tid <= m) pf_v = zk[tid < m ? p.u_off + tid : p.dt_off];
+        pf_xn = pf_xc = 0.0;
+        if (pf_x && ract && rj0 < min(nc, d - s * nc)) {
+            const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+            const long long o = x_off + (long long)(s * nc + rj0) * n + ri;
+            pf_xc = zk[o];
+            pf_xn = zk[p.z_dim + o];
+        }
+    };
+    int cur = 0;
+    if (n_my > 0) {
+        request(blockIdx.x);
+        if (tid <= m) us[tid] = pf_v;
+    }
+    __syncthreads();  // B0: G = G0, tables staged, us[0] valid
+
+    double bpr[PCL_NSP][2], bmr[PCL_NSP][2];
+    for (int it = 0; it <= n_my; ++it) {
+        // ---- item it (computed) ------------------------------------------------------------------------
+        const bool have = it < n_my;
+        const int item = blockIdx.x + it * gridDim.x;
+        const int s = have ? item % p.S : 0;
+        const int k = have ? (item / p.S) % p.K : 0;
+        const int b = have ? item / (p.S * p.K) : 0;
+        const int c0 = s * nc;
+        const int nce = min(nc, d - c0);
+        const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
+        const double *usc = us + cur * (m + 1);
+        const double h = usc[m];
+        const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
+        // ---- item it-1 (streamed) ------------------------------------------------------------------------
+        const bool sthave = it >= 1 && pact && !(p.ablate & 2);
+        const int pitem = blockIdx.x + (it - 1) * gridDim.x;
+        const int ps = it >= 1 ? pitem % p.S : 0;
+        const int pk = it >= 1 ? (pitem / p.S) % p.K : 0;
+        const int pb = it >= 1 ? pitem / (p.S * p.K) : 0;
+        int cbeg = ps * nc, cend = ps * nc + min(nc, d - ps * nc);
+        if (p.compact) {  // unique blocks only: slice 0 writes the single copy
+            cbeg = 0;
+            cend = (ps == 0) ? 1 : 0;
+        }
+        const int ncopy = 2 * (cend - cbeg);     // -B^+ copies, then B^- copies
+        const int per_burst = (ncopy + 3) >> 2;  // four bursts, one per phase
+        double *sjb = p.jac + ((long long)pb * p.K + pk) * p.jac_per + (long long)cbeg * nn + pi;
+        auto burst = [&](int q0) {
+            if (!sthave) return;
+            const int q1 = min(ncopy, q0 + per_burst);
+            for (int q = q0; q < q1; ++q) {
+                const bool minus = q >= (ncopy >> 1);
+                double *o = sjb + (minus ? blk + (long long)(q - (ncopy >> 1)) * nn : (long long)q * nn);
+#pragma unroll
+                for (int r = 0; r < PCL_NSP; ++r) {
+                    const int j = pj0 + pstep * r;
+                    if (j < n) {
+                        if (minus)
+                            store2(o + n * j, bmr[r][0], bmr[r][1], p.nt);
+                        else
+                            store2(o + n * j, bpr[r][0], bpr[r][1], p.nt);
+                    }
+                }
+            }
+        };
+
+        // -- S1: -B^+, B^- of item it-1 -> registers ; S, D of item it -> M1 ------------------------------
+        if (sthave) {
+            const double hp = us[(cur ^ 1) * (m + 1) + m];  // dt of item it-1
+            const double d1 = 0.5 * hp, d2 = hp * hp * (1.0 / 12.0);
+#pragma unroll
+            for (int r = 0; r < PCL_NSP; ++r) {
+                const int j = pj0 + pstep * r;
+                if (j < n) {
+                    const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
+                    const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
+                    const double e0 = ((pi == j) ? 1.0 : 0.0) + d2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + d2 * h1;
+                    bpr[r][0] = -(e0 + d1 * g0);
+                    bpr[r][1] = -(e1 + d1 * g1);
+                    bmr[r][0] = e0 - d1 * g0;
+                    bmr[r][1] = e1 - d1 * g1;
+                }
+            }
+        }
+        if (have && ract) {
+            if (pf_x) {
+                if (rj0 < nc) {
+                    M1[ri + LD * rj0] = pf_xn + pf_xc;
+                    M1[ri + LD * (nc + rj0)] = pf_xn - pf_xc;
+                }
+            } else {
+                const double *zn = zk + p.z_dim;
+                const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+                for (int c = rj0; c < nc; c += rstep) {
+                    double xs = 0.0, xdv = 0.0;
+                    if (c < nce) {
+                        const double xn = zn[x_off + (c0 + c) * n + ri], xc = zk[x_off + (c0 + c) * n + ri];
+                        xs = xn + xc;
+                        xdv = xn - xc;
+                    }
+                    M1[ri + LD * c] = xs;
+                    M1[ri + LD * (nc + c)] = xdv;
+                }
+            }
+        }
+        __syncthreads();  // B1: G, G2 of item it-1 are in registers; D is in LDS
+
+        // -- S2: burst A ; G(u_k) on the union pattern ; G_l D ---------------------------------------------
+        burst(0);
+        if (!REG && p.g0_batch_stride) {  // per-member drift: the whole tile changes with b
+            if (have) {
+                const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
+                for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = G0b[e];
+            }
+            __syncthreads();  // the dense rewrite lands before the pattern update
+        }
+        if (have) {
+            if (REG) {
+#pragma unroll
+                for (int r = 0; r < PCL_NUE; ++r)
+                    if (un_idx[r] >= 0) {
+                        double g = un_g0[r];
+#pragma unroll
+                        for (int w = 0; w < PCL_REGW; ++w) g += usc[un_l[r][w]] * un_v[r][w];
+                        G[un_idx[r]] = g;
+                    }
+            } else {
+                const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
+                for (int q = tid; q < p.n_upos; q += 512) {
+                    const int pos = p.upos[q];
+                    double g = G0b[pos];
+                    const double *cf = p.ucoef + (long long)q * m;
+                    for (int l = 0; l < m; ++l) g += usc[l] * cf[l];
+                    G[(pos % n) + LD * (pos / n)] = g;
+                }
+            }
+            if (ract) {
+                const double *Dm = M1 + LD * nc;
+                if (REG) {
+#pragma unroll
+                    for (int t = 0; t < PCL_NCI; ++t) {
+                        const int cl = rj0 + rstep * t;
+                        if (cl >= nc && cl < (1 + m) * nc) {
+                            const int c = cl % nc;
+                            double acc = 0.0;
+#pragma unroll
+                            for (int w = 0; w < PCL_REGW; ++w) acc += el_v[t][w] * Dm[el_c[t][w] + LD * c];
+                            M1[ri + LD * (nc + cl)] = acc;  // column (2 + l) nc + c  ==  nc + cl
+                        }
+                    }
+                } else {
+                    for (int cl = nc + rj0; cl < (1 + m) * nc; cl += rstep) {
+                        const int l = cl / nc - 1, c = cl % nc;
+                        const int base = (l * n + ri) * ew;
+                        double acc = 0.0;
+                        if (ell_lds) {
+                            for (int q = 0; q < ew; ++q) acc += ellv[base + q] * Dm[ellc[base + q] + LD * c];
+                        } else {
+                            for (int q = 0; q < ew; ++q) acc += p.ell_val[base + q] * Dm[p.ell_col[base + q] + LD * c];
+                        }
+                        M1[ri + LD * (nc + cl)] = acc;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // B2: G, M1 complete
+
+        // -- S3: burst B ; G^2 ----------------------------------------------------------------------------------
+        burst(per_burst);
+        if (have && !(p.ablate & 1)) {
+            for (int t = wave; t < rt_n * g2_ct; t += 8) {
+                if (p.iso)
+                    wave_tile<1>(G, LD, G, LD, G2, LD, n, d, n, t % rt_n, t / rt_n, lane, d);
+                else
+                    wave_tile<0>(G, LD, G, LD, G2, LD, n, n, n, t % rt_n, t / rt_n, lane, 0);
+            }
+        }
+        __syncthreads();  // B3: G2 complete
+
+        // -- S4: burst C ; W1 = G M1 (MFMA) ; G2D = G^2 D (VALU) ; request the next item's inputs -------------
+        burst(2 * per_burst);
+        if (have && !(p.ablate & 1)) {
+            for (int t = wave; t < rt_n * w1_ct; t += 8)
+                wave_tile<0>(G, LD, M1, LD, W1, LD, n, ncols1, n, t % rt_n, t / rt_n, lane, 0);
+            if (ract) {
+                const double *Dm = M1 + LD * nc;
+                for (int c = rj0; c < nc; c += rstep) {
+                    double acc = 0.0;
+                    for (int kk = 0; kk < n; ++kk) acc = fma(G2[ri + LD * kk], Dm[kk + LD * c], acc);
+                    G2D[ri + LD * c] = acc;
+                }
+            }
+        }
+        if (it + 1 < n_my) request(item + gridDim.x);
+        __syncthreads();  // B4: W1, G2D complete
+
+        // -- S5: burst D ; column outputs: block 0 -> delta and d/ddt, block 1+l -> d/du_l -----------------
+        burst(3 * per_burst);
+        if (have && ract && !(p.ablate & 4)) {
+            const long long bk = (long long)b * p.K + k;
+            double *jb = p.jac + bk * p.jac_per;
+            const double *GDm = W1 + LD * nc;
+            auto emit = [&](int cl, int t) {
+                const int lb = cl / nc, c = cl % nc;
+                if (c >= nce) return;
+                const long long r = (long long)(c0 + c) * n + ri;
+                if (lb == 0) {
+                    const double gs = W1[ri + LD * c], g2d = G2D[ri + LD * c];
+                    if (p.delta) p.delta[bk * xd + r] = M1[ri + LD * (nc + c)] - c1 * gs + c2 * g2d;
+                    jb[2 * blk + (long long)m * xd + r] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
+                } else {
+                    const int l = lb - 1;
+                    double acc = 0.0;
+                    if (REG) {
+#pragma unroll
+                        for (int w = 0; w < PCL_REGW; ++w) {
+                            const int col = el_c[t < PCL_NCI ? t : 0][w];
+                            acc += el_v[t < PCL_NCI ? t : 0][w] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
+                        }
+                    } else {
+                        const int base = (l * n + ri) * ew;
+                        for (int q = 0; q < ew; ++q) {
+                            const int col = ell_lds ? (int)ellc[base + q] : p.ell_col[base + q];
+                            const double v = ell_lds ? ellv[base + q] : p.ell_val[base + q];
+                            acc += v * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
+                        }
+                    }
+                    jb[2 * blk + (long long)l * xd + r] = acc + c2 * W1[ri + LD * (nc + cl)];
+                }
+            };
+            if (REG) {
+#pragma unroll
+                for (int t = 0; t < PCL_NCI; ++t) {
+                    const int cl = rj0 + rstep * t;
+                    if (cl < (1 + m) * nc) emit(cl, t);
+                }
+            } else {
+                for (int cl = rj0; cl < (1 + m) * nc; cl += rstep) emit(cl, 0);
+            }
+        }
+        if (tid <= m) us[(cur ^ 1) * (m + 1) + tid] = pf_v;
+        cur ^= 1;
+        __syncthreads();  // B0: iteration boundary
     }
 }
 
@@ -1220,7 +1634,7 @@ static int choose_cols_per_slice(const pcl_ctx *ctx, bool jac) {
     p.m = ctx->desc.n_drives;
     p.LD = ((ctx->n + 3) & ~3) + 2;
     p.ell_w = ctx->ell_w;
-    const bool v2 = ctx->opt_kernel == 2;
+    const bool v2 = ctx->opt_kernel >= 2;
     const bool ell = ell_fits_lds(ctx);
     auto bytes = [&](int nc) {
         p.nc = nc;
@@ -1234,6 +1648,55 @@ static int choose_cols_per_slice(const pcl_ctx *ctx, bool jac) {
         const long long S = (d + nc - 1) / nc;
         best = nc;
         if (!jac || bk * S >= want) break;
+    }
+    return best;
+}
+
+static bool v3_reg_path(const pcl_ctx *ctx, int nc) {
+    const int rstep = 512 / ctx->n;
+    return !ctx->desc.per_member_G0 && ctx->uell_w <= 2 && ctx->ell_w <= 2 && ctx->n_upos <= 512 * 4 &&
+           (1 + ctx->desc.n_drives) * nc <= 4 * rstep;
+}
+
+static size_t fused3_lds_bytes(const pcl_ctx *ctx, const KParams &p) {  // version-3 kernel
+    const size_t ncols1 = (size_t)(2 + p.m) * p.nc;
+    const size_t n_ell = (size_t)p.m * p.n * p.ell_w;
+    size_t dbl = 2 * (size_t)p.LD * p.n + 2 * p.LD * ncols1 + (size_t)p.LD * p.nc + 2 * (p.m + 1);
+    size_t bytes = dbl * sizeof(double);
+    if (!v3_reg_path(ctx, p.nc) && ell_fits_lds(ctx)) bytes += n_ell * (sizeof(double) + 2);
+    return (bytes + 7) / 8 * 8 + 128;  // slack: operand tiles may be read past the last buffer's edge
+}
+
+// v3 cost model (one workgroup per CU, item time = max(store stream, matrix path)); picks the slice width.
+static int choose_cols_v3(const pcl_ctx *ctx) {
+    const int d = ctx->desc.d, n = ctx->n, m = ctx->desc.n_drives;
+    if (ctx->opt_cols_per_slice > 0) return (int)std::min<int64_t>(ctx->opt_cols_per_slice, d);
+    KParams p;
+    memset(&p, 0, sizeof p);
+    p.n = n;
+    p.m = m;
+    p.LD = ((n + 3) & ~3) + 2;
+    p.ell_w = ctx->ell_w;
+    const double bw_cu = 6.3e12 / std::max(ctx->n_cu, 1);  // achievable HBM bytes/s per CU when all CUs stream
+    const double clk = 2.0e9;
+    const long long bk = (long long)ctx->desc.batch * ctx->K;
+    int best = 1;
+    double best_t = 1e300;
+    for (int nc = 1; nc <= std::min(d, 16); ++nc) {
+        p.nc = nc;
+        if (fused3_lds_bytes(ctx, p) > (size_t)ctx->max_lds) break;
+        const long long S = (d + nc - 1) / nc;
+        const double rounds = (double)((bk * S + ctx->n_cu - 1) / std::max(ctx->n_cu, 1));
+        const double t_stream = 2.0 * std::min(nc, d) * n * n * 8.0 / bw_cu;
+        const int rt = (n + 15) / 16, ks = (n + 3) / 4;
+        const int g2ct = ctx->iso ? (d + 15) / 16 : (n + 15) / 16;
+        const int p2ct = ((2 + m) * nc + 15) / 16;
+        const double t_matrix = (double)((rt * (g2ct + p2ct) + 3) / 4) * ks * 64.0 / clk + 1.5e-6;
+        const double t = rounds * std::max(t_stream, t_matrix) + t_matrix;
+        if (t < best_t) {
+            best_t = t;
+            best = nc;
+        }
     }
     return best;
 }
@@ -1255,8 +1718,28 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     p.compact = compact ? 1 : 0;
     p.jac_per = compact ? jac_per_compact(ctx) : jac_per_full(ctx);
     const bool want_jac = jac != nullptr;
-    const bool v2 = ctx->opt_kernel == 2 && ctx->opt_use_mfma != 0;
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
+    if (want_jac && ctx->opt_kernel == 3 && ctx->opt_use_mfma != 0) {
+        p.nc = choose_cols_v3(ctx);
+        size_t lds3 = fused3_lds_bytes(ctx, p);
+        while (lds3 > (size_t)ctx->max_lds && p.nc > 1) {
+            --p.nc;
+            lds3 = fused3_lds_bytes(ctx, p);
+        }
+        if (lds3 > (size_t)ctx->max_lds) return fail(ctx, PCL_ESHAPE, "fused kernel needs %zu B of LDS (> %d)", lds3, ctx->max_lds);
+        p.S = (p.d + p.nc - 1) / p.nc;
+        const long long items = (long long)p.batch * p.K * p.S;
+        if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+        const bool reg = v3_reg_path(ctx, p.nc);
+        auto kern3 = reg ? pcl_fused_kernel_v3<true> : pcl_fused_kernel_v3<false>;
+        int rc = set_lds_attr(ctx, (const void *)kern3, reg ? 6 : 7, lds3);
+        if (rc != PCL_OK) return rc;
+        const long long g3 = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, items) : std::min<long long>(items, std::max(ctx->n_cu, 1));
+        hipLaunchKernelGGL(kern3, dim3((unsigned)g3), dim3(512), lds3, ctx->stream, p);
+        HIP_TRY(ctx, hipGetLastError());
+        return PCL_OK;
+    }
+    const bool v2 = ctx->opt_kernel >= 2 && ctx->opt_use_mfma != 0;
     p.nc = choose_cols_per_slice(ctx, want_jac);
     auto bytes = [&]() { return v2 ? fused2_lds_bytes(p, want_jac, p.ell_lds != 0) : fused_lds_bytes(p, want_jac); };
     size_t lds = bytes();
@@ -1438,7 +1921,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
     else if (!strcmp(key, "grid"))
         ctx->opt_grid = v;
     else if (!strcmp(key, "kernel_version")) {
-        if (v != 1 && v != 2) return fail(ctx, PCL_EINVAL, "kernel_version must be 1 or 2");
+        if (v < 1 || v > 3) return fail(ctx, PCL_EINVAL, "kernel_version must be 1, 2 or 3");
         ctx->opt_kernel = v;
     }
     else
@@ -1454,7 +1937,7 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
     else if (!strcmp(key, "nt_stores"))
         *v = ctx->opt_nt;
     else if (!strcmp(key, "effective_cols_per_slice"))
-        *v = choose_cols_per_slice(ctx, true);
+        *v = (ctx->opt_kernel == 3 && ctx->opt_use_mfma) ? choose_cols_v3(ctx) : choose_cols_per_slice(ctx, true);
     else if (!strcmp(key, "n_cu"))
         *v = ctx->n_cu;
     else if (!strcmp(key, "kernel_version"))

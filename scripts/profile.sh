@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-run() { name=$1; shift; rocprofv3 "$@" -d $OUT/$name -o $name -- python $ROOT/bench.py $ARGS > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
+run() { name=$1; shift; rocprofv3 "$@" --output-format csv -d $OUT/$name -o $name -- python $ROOT/bench.py $ARGS > $OUT/$name.log 2>&1; echo "$name rc=$?"; }
 run trace --kernel-trace --stats
 run pmc_fetch --pmc FETCH_SIZE
 run pmc_write --pmc WRITE_SIZE

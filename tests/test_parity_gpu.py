@@ -43,9 +43,10 @@ def make_ctx(lay, G0, Gj, **kw):
 
 
 # ---- committed golden vectors ----------------------------------------------------------------
-# kernel variants: (kernel_version, use_mfma).  (2,1) is the default wave-specialised MFMA kernel,
-# (1,1) the single-role MFMA kernel, (1,0) the plain-VALU kernel.
-VARIANTS = [(2, 1), (1, 1), (1, 0)]
+# kernel variants: (kernel_version, use_mfma).  (3,1) is the default: one persistent, wave-specialised,
+# software-pipelined workgroup per CU; (2,1) persistent without the cross-item pipeline; (1,1) the
+# single-role MFMA kernel, (1,0) the plain-VALU kernel.  pcl_eval (no Jacobian) runs v2/v1 code.
+VARIANTS = [(3, 1), (2, 1), (1, 1), (1, 0)]
 
 
 def set_variant(c, variant):
