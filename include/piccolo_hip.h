@@ -152,6 +152,9 @@ int pcl_jac_expand_dev(pcl_ctx *ctx, const double *compact_dev, double *vals_dev
 /* key: "cols_per_slice" (state columns per workgroup; 0 = heuristic), "use_mfma" (1/0), "nt_stores" (1/0). */
 int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t value);
 int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *value);
+/* Profiling aid: after pcl_set_option(ctx, "debug_timing", 1), up to 64 s_memtime stamps written by workgroup 0
+ * at its phase boundaries during the last launch. */
+int pcl_debug_timing(pcl_ctx *ctx, int64_t *out, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ EXPORTS = [
     "pcl_eval", "pcl_jac", "pcl_eval_jac", "pcl_hess",
     "pcl_set_stream", "pcl_reset_stream", "pcl_sync", "pcl_eval_dev", "pcl_eval_jac_dev", "pcl_hess_dev",
     "pcl_jac_compact_nnz", "pcl_eval_jac_compact_dev", "pcl_jac_expand_dev",
-    "pcl_set_option", "pcl_get_option",
+    "pcl_set_option", "pcl_get_option", "pcl_debug_timing",
 ]  # fmt: skip
 
 
@@ -119,5 +119,6 @@ def load():
     L.pcl_jac_expand_dev.argtypes = [vp, vp, vp]
     L.pcl_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     L.pcl_get_option.argtypes = [vp, ctypes.c_char_p, c_i64p]
+    L.pcl_debug_timing.argtypes = [vp, c_i64p, ctypes.c_int64]
     _lib = L
     return L

@@ -57,6 +57,11 @@ struct KParams {
     const unsigned char *uell_l;  // per union entry: up to uell_w (drive index, value) pairs, zero padded
     const double *uell_v;
     int uell_w;
+    int stagger;     // v2: s_memtime ticks by which the second resident workgroup of a CU delays its start
+    int n_cu;        // CUs on the device
+    long long *dbg;  // optional: cycle stamps of workgroup 0 / matrix wave 0 (option debug_timing)
+    int ncw;      // v3: state columns per matrix-wave chunk ((2+m)*ncw <= 16)
+    int tab_lds;  // v3: union / ELL tables staged in LDS
     int iso;               // 1: G0 and every G_l are exact iso(.) images -> G^2 needs only its first d columns
     long long z_batch_stride;   // doubles between trajectories (0 in MEMBERS mode)
     long long g0_batch_stride;  // n*n if per-member drift else 0
@@ -373,14 +378,73 @@ __device__ __forceinline__ void wave_rowgemm(const double *__restrict__ A, int l
     }
 }
 
-// Persistent form: the grid is (workgroups that fit on the chip); each workgroup walks the work
-// items (b, k, s) with stride gridDim.x.  What does not depend on the item lives in registers / LDS
-// for the whole launch: every thread keeps its elements of the drift tile G0 and the (drive, value)
-// pairs of the union pattern that touch them, and the ELL form of the drives is staged in LDS once.
-// Per item only u_k, dt_k and the slice's state columns are read from memory.
-#define PCL_NGE 8  // G elements per thread: n*n <= 64*64 = 8 * 512
+// Phase-2 product of the matrix waves for a narrow slice (ncols1 <= 32, 2*nc <= 16), one row tile per wave:
+//   acc0/acc1 = G * M1[:, tile 0/1],  acc2 = G2 * M1[:, tile 0]  (its columns nc..2nc-1 are G2 D).
+// Operands of k-step ks+1 are requested before the MFMAs of step ks issue.
+__device__ __forceinline__ void wave_phase2_fused(const double *G, const double *G2, const double *M1, double *W1,
+                                                  double *G2D, int LD, int n, int ncols1, int nc, bool want_g2, int wave,
+                                                  int lane) {
+    const int rt_n = (n + 15) >> 4;
+    const bool two = ncols1 > 16;
+    const int kfull = n >> 2, krem = n & 3;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int rt = wave; rt < rt_n; rt += 4) {
+        const double *Ap = G + rt * 16 + li + LD * lk;
+        const double *A2p = (want_g2 ? G2 : G) + rt * 16 + li + LD * lk;
+        const double *Bp0 = M1 + lk + LD * li;
+        const double *Bp1 = Bp0 + (two ? LD * 16 : 0);
+        double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+        double a = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0;
+        if (kfull > 0) {
+            a = Ap[0];
+            a2 = A2p[0];
+            b0 = Bp0[0];
+            b1 = Bp1[0];
+        }
+        for (int ks = 0; ks < kfull; ++ks) {
+            const double ca = a, ca2 = a2, cb0 = b0, cb1 = b1;
+            if (ks + 1 < kfull) {
+                a = Ap[LD * 4 * (ks + 1)];
+                a2 = A2p[LD * 4 * (ks + 1)];
+                b0 = Bp0[4 * (ks + 1)];
+                b1 = Bp1[4 * (ks + 1)];
+            }
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca, cb0, acc0, 0, 0, 0);
+            if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca, cb1, acc1, 0, 0, 0);
+            if (want_g2) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca2, cb0, acc2, 0, 0, 0);
+        }
+        if (krem) {
+            const bool ok = lk < krem;
+            const double ra = ok ? Ap[LD * 4 * kfull] : 0.0;
+            const double ra2 = ok ? A2p[LD * 4 * kfull] : 0.0;
+            const double rb0 = ok ? Bp0[4 * kfull] : 0.0;
+            const double rb1 = ok ? Bp1[4 * kfull] : 0.0;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra, rb0, acc0, 0, 0, 0);
+            if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra, rb1, acc1, 0, 0, 0);
+            if (want_g2) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra2, rb0, acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + lk + 4 * r;
+            if (row < n) {
+                if (li < ncols1) W1[row + LD * li] = acc0[r];
+                if (two && li + 16 < ncols1) W1[row + LD * (li + 16)] = acc1[r];
+                if (want_g2 && li >= nc && li < 2 * nc) G2D[row + LD * (li - nc)] = acc2[r];
+            }
+        }
+    }
+}
 
-template <bool JAC, int WU>  // WU: (drive,value) pairs per G element held in registers; -1: general (table in memory)
+// Persistent form: the grid is (workgroups that fit on the chip); each workgroup walks the work
+// items (b, k, s) with stride gridDim.x.  What does not depend on the item stays on chip for the
+// whole launch: the LDS tile G holds the drift everywhere except on the union pattern of the
+// drives, which is the only part rewritten per item (each thread keeps its pattern entries in
+// registers), and the ELL form of the drives is staged in LDS once.  Per item only u_k, dt_k and
+// the slice's state columns are read from memory, one item ahead.  Element-wise passes give every
+// thread a fixed row (tid % n) and walk columns: no integer division inside the item loop.
+#define PCL_NUE2 2  // union-pattern entries per thread held in registers (REG path: n_upos <= 1024)
+
+template <bool JAC, int WU>  // WU: (drive,value) pairs per pattern entry held in registers; -1: general (tables in memory)
 __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
     extern __shared__ double lds[];
     const int n = p.n, d = p.d, m = p.m, LD = p.LD, nc = p.nc;
@@ -388,6 +452,7 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
     const int wave = tid >> 6, lane = tid & 63;
     const bool matrix_wave = wave < 4;
     const int stid = tid - 256;  // index among the stream waves' threads
+    const int nn = n * n;
 
     const int ncols1 = JAC ? (2 + m) * nc : 2 * nc;
     const int n_ell = m * n * p.ell_w;
@@ -396,39 +461,50 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
     double *M1 = G2 + (JAC ? LD * n : 0);
     double *W1 = M1 + LD * ncols1;
     double *G2D = W1 + LD * ncols1;
-    double *ellv_l = G2D + LD * nc;
+    double *us = G2D + LD * nc;  // 2 x [u_k (m) | dt_k]: current / next item
+    double *ellv_l = us + 2 * (m + 1);
     unsigned short *ellc_l = reinterpret_cast<unsigned short *>(ellv_l + n_ell);
     const long long xd = (long long)n * d;
     const int ew = p.ell_w;
+    const bool fused_p2 = ncols1 <= 32 && 2 * nc <= 16;
 
-    // ---- launch-invariant per-thread state ----------------------------------------------------------
+    // ---- fixed thread coordinates ----------------------------------------------------------------------
+    const int ri = tid % n, rj0 = tid / n, rstep = 512 / n;  // all threads: row ri, columns rj0, rj0+rstep, ..
+    const bool ract = rj0 < rstep;
+    const int sstep = 256 / n;                               // stream waves as a 256-thread group: row si
+    const int si = matrix_wave ? 0 : stid % n, sj0 = matrix_wave ? 0 : stid / n;
+    const bool sact = !matrix_wave && sj0 < sstep;
+    const int hn = n >> 1;                                   // stream waves: row pair (pi, pi+1)
+    const int pi = matrix_wave ? 0 : 2 * (stid % hn), pj0 = matrix_wave ? 0 : stid / hn, pstep = max(256 / hn, 1);
+    const bool pact = !matrix_wave && pj0 < pstep;
+
+    // ---- launch-invariant state -------------------------------------------------------------------------
+    if (!p.g0_batch_stride)
+        for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = p.G0[e];
     constexpr int WUR = WU > 0 ? WU : 1;
-    double g0r[PCL_NGE];
-    int gidx[PCL_NGE];
-    int uq[PCL_NGE];  // WU == -1 only
-    unsigned char ul[PCL_NGE][WUR];
-    double uv[PCL_NGE][WUR];
+    int un_idx[PCL_NUE2];
+    double un_g0[PCL_NUE2];
+    unsigned char un_l[PCL_NUE2][WUR];
+    double un_v[PCL_NUE2][WUR];
+    if (WU > 0) {
 #pragma unroll
-    for (int r = 0; r < PCL_NGE; ++r) {
-        const int e = tid + 512 * r;
-        gidx[r] = -1;
-        g0r[r] = 0.0;
-        uq[r] = -1;
+        for (int r = 0; r < PCL_NUE2; ++r) {
+            const int q = tid + 512 * r;
+            un_idx[r] = -1;
+            un_g0[r] = 0.0;
 #pragma unroll
-        for (int w = 0; w < WUR; ++w) {
-            ul[r][w] = 0;
-            uv[r][w] = 0.0;
-        }
-        if (e < n * n) {
-            gidx[r] = (e % n) + LD * (e / n);
-            if (!p.g0_batch_stride) g0r[r] = p.G0[e];
-            const int q = (m > 0) ? p.umap[e] : -1;
-            uq[r] = q;
-            if (WU > 0 && q >= 0) {
+            for (int w = 0; w < WUR; ++w) {
+                un_l[r][w] = 0;
+                un_v[r][w] = 0.0;
+            }
+            if (q < p.n_upos) {
+                const int pos = p.upos[q];
+                un_idx[r] = (pos % n) + LD * (pos / n);
+                un_g0[r] = p.G0[pos];
 #pragma unroll
                 for (int w = 0; w < WUR; ++w) {
-                    ul[r][w] = p.uell_l[q * WUR + w];
-                    uv[r][w] = p.uell_v[q * WUR + w];
+                    un_l[r][w] = p.uell_l[q * WUR + w];
+                    un_v[r][w] = p.uell_v[q * WUR + w];
                 }
             }
         }
@@ -441,314 +517,9 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
         }
     }
 
+    // ---- per-item inputs, requested one item ahead -------------------------------------------------
     const int n_items = p.batch * p.K * p.S;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int s = item % p.S;
-        const int k = (item / p.S) % p.K;
-        const int b = item / (p.S * p.K);
-        const int c0 = s * nc;
-        const int nce = min(nc, d - c0);
-
-        const double *Zb = p.Z + (long long)b * p.z_batch_stride;
-        const double *zk = Zb + (long long)k * p.z_dim;
-        const double *zn = zk + p.z_dim;
-        const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-        const double h = zk[p.dt_off];
-        const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
-        const double *uk = zk + p.u_off;
-
-        // ---- phase 0: G(u_k), S, D -> LDS -------------------------------------------------------------
-        if (!(p.ablate & 8)) {
-            const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
-#pragma unroll
-            for (int r = 0; r < PCL_NGE; ++r) {
-                if (gidx[r] >= 0) {
-                    double g = p.g0_batch_stride ? G0b[tid + 512 * r] : g0r[r];
-                    if (WU > 0) {
-#pragma unroll
-                        for (int w = 0; w < WUR; ++w) g += uk[ul[r][w]] * uv[r][w];
-                    } else if (WU < 0 && uq[r] >= 0) {
-                        const double *cf = p.ucoef + (long long)uq[r] * m;
-                        for (int l = 0; l < m; ++l) g += uk[l] * cf[l];
-                    }
-                    G[gidx[r]] = g;
-                }
-            }
-        }
-        for (int e = tid; e < nc * n; e += 512) {
-            const int c = e / n, i = e % n;
-            double xs = 0.0, xdv = 0.0;
-            if (c < nce) {
-                const double xn = zn[x_off + (c0 + c) * n + i], xc = zk[x_off + (c0 + c) * n + i];
-                xs = xn + xc;
-                xdv = xn - xc;
-            }
-            M1[i + LD * c] = xs;
-            M1[i + LD * (nc + c)] = xdv;
-        }
-        __syncthreads();
-
-        // ---- phase 1 ------------------------------------------------------------------------------------
-        if (JAC) {
-            if (matrix_wave) {
-                if (!(p.ablate & 1)) {
-                    if (p.iso)
-                        wave_rowgemm<1>(G, LD, G, LD, G2, LD, n, d, n, wave, 4, lane, d);
-                    else
-                        wave_rowgemm<0>(G, LD, G, LD, G2, LD, n, n, n, wave, 4, lane, 0);
-                }
-            } else if (!(p.ablate & 16)) {
-                const double *Dm = M1 + LD * nc;
-                for (int e = stid; e < m * nc * n; e += 256) {
-                    const int i = e % n, c = (e / n) % nc, l = e / (n * nc);
-                    const int base = (l * n + i) * ew;
-                    double acc = 0.0;
-                    if (stage) {
-                        for (int q = 0; q < ew; ++q) acc += ellv_l[base + q] * Dm[ellc_l[base + q] + LD * c];
-                    } else {
-                        for (int q = 0; q < ew; ++q) acc += p.ell_val[base + q] * Dm[p.ell_col[base + q] + LD * c];
-                    }
-                    M1[i + LD * ((2 + l) * nc + c)] = acc;
-                }
-            }
-            __syncthreads();
-        }
-
-        // ---- phase 2 ------------------------------------------------------------------------------------
-        const long long bk = (long long)b * p.K + k;
-        double *jb = JAC ? p.jac + bk * p.jac_per : nullptr;
-        const long long blk = p.compact ? (long long)n * n : (long long)d * n * n;  // size of seg 0 / seg 1
-        if (matrix_wave) {
-            if (!(p.ablate & 1)) {
-                wave_rowgemm<0>(G, LD, M1, LD, W1, LD, n, ncols1, n, wave, 4, lane, 0);
-                if (JAC) wave_rowgemm<0>(G2, LD, M1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
-            }
-        } else if (JAC && !(p.ablate & 2)) {
-            // pair index q covers flat column-major positions 2q, 2q+1 (same column since n is even)
-            const int half = (n * n) >> 1;
-            int cbeg = c0, cend = c0 + nce;
-            if (p.compact) {  // unique blocks only: slice 0 writes the single copy
-                cbeg = 0;
-                cend = (s == 0) ? 1 : 0;
-            }
-            for (int q = stid; q < half; q += 256) {
-                const int pos = 2 * q;
-                const int i = pos % n, j = pos / n;
-                const double g0 = G[i + LD * j], g1 = G[i + 1 + LD * j];
-                const double h0 = G2[i + LD * j], h1 = G2[i + 1 + LD * j];
-                const double id0 = (i == j) ? 1.0 : 0.0, id1 = (i + 1 == j) ? 1.0 : 0.0;
-                const double e0 = id0 + c2 * h0, e1 = id1 + c2 * h1;
-                const double bp0 = -(e0 + c1 * g0), bp1 = -(e1 + c1 * g1);
-                const double bm0 = e0 - c1 * g0, bm1 = e1 - c1 * g1;
-                for (int c = cbeg; c < cend; ++c) {
-                    double *o0 = jb + (long long)c * n * n + pos;
-                    store2(o0, bp0, bp1, p.nt);
-                    store2(o0 + blk, bm0, bm1, p.nt);
-                }
-            }
-        }
-        __syncthreads();
-        if (!JAC) {  // eval only: delta needs G (G D), a second dependent product
-            if (matrix_wave && !(p.ablate & 1)) wave_rowgemm<0>(G, LD, W1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
-            __syncthreads();
-        }
-
-        // ---- phase 3: column outputs ---------------------------------------------------------------------
-        if (!(p.ablate & 4)) {
-            for (int e = tid; e < nce * n; e += 512) {
-                const int c = e / n, i = e % n;
-                const double gs = W1[i + LD * c], g2d = G2D[i + LD * c];
-                const long long r = (long long)(c0 + c) * n + i;
-                if (p.delta) p.delta[bk * xd + r] = M1[i + LD * (nc + c)] - c1 * gs + c2 * g2d;
-                if (JAC) jb[2 * blk + (long long)m * xd + r] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
-            }
-            if (JAC) {
-                const double *GDm = W1 + LD * nc;
-                for (int e = tid; e < m * nce * n; e += 512) {
-                    const int i = e % n, c = (e / n) % nce, l = e / (n * nce);
-                    const int base = (l * n + i) * ew;
-                    double acc = 0.0;
-                    if (stage) {
-                        for (int q = 0; q < ew; ++q) {
-                            const int col = ellc_l[base + q];
-                            acc += ellv_l[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
-                        }
-                    } else {
-                        for (int q = 0; q < ew; ++q) {
-                            const int col = p.ell_col[base + q];
-                            acc += p.ell_val[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
-                        }
-                    }
-                    jb[2 * blk + (long long)l * xd + (long long)(c0 + c) * n + i] = acc + c2 * W1[i + LD * ((2 + l) * nc + c)];
-                }
-            }
-        }
-        __syncthreads();  // LDS is rewritten by the next item's phase 0
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Fused residual + Jacobian kernel, version 3 (default): ONE persistent 8-wave workgroup per CU,
-// software-pipelined across its work items (b, k, s).  In iteration `it` every wave
-//   * issues a quarter of the replicated -B^+ / B^- block stores of item it-1 (held in registers,
-//     copied out of the LDS tiles G, G^2 at the top of the iteration) and then
-//   * runs its share of one phase of item it:
-//       S1 S,D -> LDS | S2 G(u_k), G_l D | S3 G^2 (MFMA) | S4 G*M1, G^2*D (MFMA) | S5 column outputs.
-// Stores are asynchronous, so each burst drains to HBM underneath the phase that follows it: the
-// iteration time tends to max(matrix path, store stream), and the store stream is the roofline term.
-// What does not depend on the item (drift tile, union pattern of the drives, ELL drives) is staged in
-// LDS once per launch; per item only u_k, dt_k and the slice's state columns are read, one item ahead.
-// LDS map: G0 [n*n] | G [LD*n] | G2 [LD*n] | M1 [LD*ncols1] | W1 [LD*ncols1] | G2D [LD*nc] | us [2(m+1)] |
-//          union values [n_upos*uw] | ELL values [n_ell] | umap u16 [n*n] | union drive ids u8 | ELL cols u16
-// ------------------------------------------------------------------------------------------
-// One 16x16 output tile C[rt, ct] = A[rt, :] * B[:, ct] on one wavefront; operands of k-step ks+1 are
-// requested before the MFMA of step ks issues.  MODE 1 additionally writes the iso mirror of G^2.
-template <int MODE>
-__device__ __forceinline__ void wave_tile(const double *__restrict__ A, int lda, const double *__restrict__ B, int ldb,
-                                          double *__restrict__ C, int ldc, int M, int Nc, int Kd, int rt, int ct,
-                                          int lane, int dmir) {
-    const int kfull = Kd >> 2, krem = Kd & 3;
-    const int li = lane & 15, lk = lane >> 4;
-    const double *Ap = A + rt * 16 + li + lda * lk;
-    const double *Bp = B + lk + ldb * (ct * 16 + li);
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    double an = 0.0, bn = 0.0;
-    if (kfull > 0) {
-        an = Ap[0];
-        bn = Bp[0];
-    }
-    for (int ks = 0; ks < kfull; ++ks) {
-        const double a = an, b = bn;
-        if (ks + 1 < kfull) {
-            an = Ap[lda * 4 * (ks + 1)];
-            bn = Bp[4 * (ks + 1)];
-        }
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    if (krem) {
-        const bool ok = lk < krem;
-        const double a = ok ? Ap[lda * 4 * kfull] : 0.0;
-        const double b = ok ? Bp[4 * kfull] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    const int col = ct * 16 + li;
-    if (col < Nc) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = rt * 16 + lk + 4 * r;
-            if (row < M) {
-                C[row + ldc * col] = acc[r];
-                if (MODE == 1) {
-                    if (row < dmir)
-                        C[row + dmir + ldc * (col + dmir)] = acc[r];
-                    else
-                        C[row - dmir + ldc * (col + dmir)] = -acc[r];
-                }
-            }
-        }
-    }
-}
-
-#define PCL_NSP 4  // B^{+-} value pairs per thread: (n*n/2) / 512 <= 4 for n <= 64
-#define PCL_NUE 4  // union-pattern entries per thread held in registers (REG path: n_upos <= 2048)
-#define PCL_NCI 4  // column steps of the element-wise passes held in registers (REG path)
-#define PCL_REGW 2 // (drive, value) pairs per union entry / ELL entries per row held in registers (REG path)
-
-// REG = true : the thread's union-pattern entries and ELL rows live in registers for the whole launch
-//              (needs union width <= 2, ELL width <= 2, n_upos <= 512*PCL_NUE, (1+m)*nc <= PCL_NCI*(512/n));
-// REG = false: general sizes, tables read from LDS / memory.
-template <bool REG>
-__global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
-    extern __shared__ double lds[];
-    const int n = p.n, d = p.d, m = p.m, LD = p.LD, nc = p.nc;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int nn = n * n;
-    const int ncols1 = (2 + m) * nc;
-    const int n_ell = m * n * p.ell_w, ew = p.ell_w;
-    const int uw = p.uell_w;
-    const long long xd = (long long)n * d;
-
-    double *G = lds;
-    double *G2 = G + LD * n;
-    double *M1 = G2 + LD * n;
-    double *W1 = M1 + LD * ncols1;
-    double *G2D = W1 + LD * ncols1;
-    double *us = G2D + LD * nc;
-    double *ellv = us + 2 * (m + 1);
-    unsigned short *ellc = reinterpret_cast<unsigned short *>(ellv + ((!REG && p.ell_lds) ? n_ell : 0));
-    const bool ell_lds = !REG && p.ell_lds;
-
-    // fixed thread coordinates: element-wise passes own row ri and walk columns; the block stream owns the
-    // row pair (pi, pi+1) and walks columns
-    const int ri = tid % n, rj0 = tid / n, rstep = 512 / n;
-    const bool ract = rj0 < rstep;
-    const int hn = n >> 1;
-    const int pi = 2 * (tid % hn), pj0 = tid / hn, pstep = max(512 / hn, 1);
-    const bool pact = pj0 < pstep;
     const bool pf_x = nc <= rstep;  // one state element per thread: prefetchable
-    const int rt_n = (n + 15) >> 4;
-    const int g2_ct = p.iso ? (d + 15) >> 4 : rt_n;
-    const int w1_ct = (ncols1 + 15) >> 4;
-
-    // ---- launch-invariant state -------------------------------------------------------------------------
-    // G holds the drift tile everywhere except on the union pattern of the drives, which every item rewrites.
-    if (!p.g0_batch_stride)
-        for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = p.G0[e];
-    int un_idx[PCL_NUE];
-    double un_g0[PCL_NUE];
-    unsigned char un_l[PCL_NUE][PCL_REGW];
-    double un_v[PCL_NUE][PCL_REGW];
-    unsigned short el_c[PCL_NCI][PCL_REGW];
-    double el_v[PCL_NCI][PCL_REGW];
-    if (REG) {
-#pragma unroll
-        for (int r = 0; r < PCL_NUE; ++r) {
-            const int q = tid + 512 * r;
-            un_idx[r] = -1;
-            un_g0[r] = 0.0;
-#pragma unroll
-            for (int w = 0; w < PCL_REGW; ++w) {
-                un_l[r][w] = 0;
-                un_v[r][w] = 0.0;
-            }
-            if (q < p.n_upos) {
-                const int pos = p.upos[q];
-                un_idx[r] = (pos % n) + LD * (pos / n);
-                un_g0[r] = p.G0[pos];
-#pragma unroll
-                for (int w = 0; w < PCL_REGW; ++w)
-                    if (w < uw) {
-                        un_l[r][w] = p.uell_l[q * uw + w];
-                        un_v[r][w] = p.uell_v[q * uw + w];
-                    }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < PCL_NCI; ++t) {
-            const int cl = rj0 + rstep * t;  // combined column: block lb = cl / nc (0: delta/dt, 1+l: drive l)
-            const int lb = cl / nc;
-#pragma unroll
-            for (int w = 0; w < PCL_REGW; ++w) {
-                el_c[t][w] = 0;
-                el_v[t][w] = 0.0;
-                if (ract && lb >= 1 && lb <= m && w < ew) {
-                    el_c[t][w] = (unsigned short)p.ell_col[((lb - 1) * n + ri) * ew + w];
-                    el_v[t][w] = p.ell_val[((lb - 1) * n + ri) * ew + w];
-                }
-            }
-        }
-    } else if (p.ell_lds) {
-        for (int e = tid; e < n_ell; e += 512) {
-            ellv[e] = p.ell_val[e];
-            ellc[e] = (unsigned short)p.ell_col[e];
-        }
-    }
-
-    const int n_items = p.batch * p.K * p.S;
-    const int n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    const long long blk = p.compact ? (long long)nn : (long long)d * nn;  // size of seg 0 / seg 1
-
     double pf_v = 0.0, pf_xn = 0.0, pf_xc = 0.0;
     auto request = [&](int item) {
         const int s = item % p.S;
@@ -765,117 +536,46 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
         }
     };
     int cur = 0;
-    if (n_my > 0) {
+    if ((int)blockIdx.x < n_items) {
         request(blockIdx.x);
         if (tid <= m) us[tid] = pf_v;
     }
-    __syncthreads();  // B0: G = G0, tables staged, us[0] valid
+    // Two workgroups share a CU.  Started together they would run their phases in lockstep (both in the
+    // compute phases, then both in the store phase); delaying the second one by about half an item makes
+    // one of them stream while the other computes.
+    if (p.stagger > 0 && (int)blockIdx.x >= p.n_cu) {
+        const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+        while ((long long)__builtin_amdgcn_s_memtime() - t0 < p.stagger) __builtin_amdgcn_s_sleep(32);
+    }
+    __syncthreads();  // G = drift, tables staged, us[0] valid
 
-    double bpr[PCL_NSP][2], bmr[PCL_NSP][2];
-    for (int it = 0; it <= n_my; ++it) {
-        // ---- item it (computed) ------------------------------------------------------------------------
-        const bool have = it < n_my;
-        const int item = blockIdx.x + it * gridDim.x;
-        const int s = have ? item % p.S : 0;
-        const int k = have ? (item / p.S) % p.K : 0;
-        const int b = have ? item / (p.S * p.K) : 0;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int s = item % p.S;
+        const int k = (item / p.S) % p.K;
+        const int b = item / (p.S * p.K);
         const int c0 = s * nc;
         const int nce = min(nc, d - c0);
         const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
+        const double *zn = zk + p.z_dim;
+        const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
         const double *usc = us + cur * (m + 1);
         const double h = usc[m];
         const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
-        // ---- item it-1 (streamed) ------------------------------------------------------------------------
-        const bool sthave = it >= 1 && pact && !(p.ablate & 2);
-        const int pitem = blockIdx.x + (it - 1) * gridDim.x;
-        const int ps = it >= 1 ? pitem % p.S : 0;
-        const int pk = it >= 1 ? (pitem / p.S) % p.K : 0;
-        const int pb = it >= 1 ? pitem / (p.S * p.K) : 0;
-        int cbeg = ps * nc, cend = ps * nc + min(nc, d - ps * nc);
-        if (p.compact) {  // unique blocks only: slice 0 writes the single copy
-            cbeg = 0;
-            cend = (ps == 0) ? 1 : 0;
-        }
-        const int ncopy = 2 * (cend - cbeg);     // -B^+ copies, then B^- copies
-        const int per_burst = (ncopy + 3) >> 2;  // four bursts, one per phase
-        double *sjb = p.jac + ((long long)pb * p.K + pk) * p.jac_per + (long long)cbeg * nn + pi;
-        auto burst = [&](int q0) {
-            if (!sthave) return;
-            const int q1 = min(ncopy, q0 + per_burst);
-            for (int q = q0; q < q1; ++q) {
-                const bool minus = q >= (ncopy >> 1);
-                double *o = sjb + (minus ? blk + (long long)(q - (ncopy >> 1)) * nn : (long long)q * nn);
-#pragma unroll
-                for (int r = 0; r < PCL_NSP; ++r) {
-                    const int j = pj0 + pstep * r;
-                    if (j < n) {
-                        if (minus)
-                            store2(o + n * j, bmr[r][0], bmr[r][1], p.nt);
-                        else
-                            store2(o + n * j, bpr[r][0], bpr[r][1], p.nt);
-                    }
-                }
-            }
-        };
 
-        // -- S1: -B^+, B^- of item it-1 -> registers ; S, D of item it -> M1 ------------------------------
-        if (sthave) {
-            const double hp = us[(cur ^ 1) * (m + 1) + m];  // dt of item it-1
-            const double d1 = 0.5 * hp, d2 = hp * hp * (1.0 / 12.0);
-#pragma unroll
-            for (int r = 0; r < PCL_NSP; ++r) {
-                const int j = pj0 + pstep * r;
-                if (j < n) {
-                    const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
-                    const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
-                    const double e0 = ((pi == j) ? 1.0 : 0.0) + d2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + d2 * h1;
-                    bpr[r][0] = -(e0 + d1 * g0);
-                    bpr[r][1] = -(e1 + d1 * g1);
-                    bmr[r][0] = e0 - d1 * g0;
-                    bmr[r][1] = e1 - d1 * g1;
-                }
-            }
-        }
-        if (have && ract) {
-            if (pf_x) {
-                if (rj0 < nc) {
-                    M1[ri + LD * rj0] = pf_xn + pf_xc;
-                    M1[ri + LD * (nc + rj0)] = pf_xn - pf_xc;
-                }
-            } else {
-                const double *zn = zk + p.z_dim;
-                const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-                for (int c = rj0; c < nc; c += rstep) {
-                    double xs = 0.0, xdv = 0.0;
-                    if (c < nce) {
-                        const double xn = zn[x_off + (c0 + c) * n + ri], xc = zk[x_off + (c0 + c) * n + ri];
-                        xs = xn + xc;
-                        xdv = xn - xc;
-                    }
-                    M1[ri + LD * c] = xs;
-                    M1[ri + LD * (nc + c)] = xdv;
-                }
-            }
-        }
-        __syncthreads();  // B1: G, G2 of item it-1 are in registers; D is in LDS
-
-        // -- S2: burst A ; G(u_k) on the union pattern ; G_l D ---------------------------------------------
-        burst(0);
-        if (!REG && p.g0_batch_stride) {  // per-member drift: the whole tile changes with b
-            if (have) {
-                const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
-                for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = G0b[e];
-            }
+        // ---- phase 0: G(u_k) on the union pattern, S, D -> LDS -----------------------------------------
+        if (WU < 0 && p.g0_batch_stride) {  // per-member drift: the whole tile changes with b
+            const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
+            for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = G0b[e];
             __syncthreads();  // the dense rewrite lands before the pattern update
         }
-        if (have) {
-            if (REG) {
+        if (!(p.ablate & 8)) {
+            if (WU > 0) {
 #pragma unroll
-                for (int r = 0; r < PCL_NUE; ++r)
+                for (int r = 0; r < PCL_NUE2; ++r)
                     if (un_idx[r] >= 0) {
                         double g = un_g0[r];
 #pragma unroll
-                        for (int w = 0; w < PCL_REGW; ++w) g += usc[un_l[r][w]] * un_v[r][w];
+                        for (int w = 0; w < WUR; ++w) g += usc[un_l[r][w]] * un_v[r][w];
                         G[un_idx[r]] = g;
                     }
             } else {
@@ -888,113 +588,580 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                     G[(pos % n) + LD * (pos / n)] = g;
                 }
             }
-            if (ract) {
-                const double *Dm = M1 + LD * nc;
-                if (REG) {
-#pragma unroll
-                    for (int t = 0; t < PCL_NCI; ++t) {
-                        const int cl = rj0 + rstep * t;
-                        if (cl >= nc && cl < (1 + m) * nc) {
-                            const int c = cl % nc;
-                            double acc = 0.0;
-#pragma unroll
-                            for (int w = 0; w < PCL_REGW; ++w) acc += el_v[t][w] * Dm[el_c[t][w] + LD * c];
-                            M1[ri + LD * (nc + cl)] = acc;  // column (2 + l) nc + c  ==  nc + cl
-                        }
-                    }
-                } else {
-                    for (int cl = nc + rj0; cl < (1 + m) * nc; cl += rstep) {
-                        const int l = cl / nc - 1, c = cl % nc;
-                        const int base = (l * n + ri) * ew;
-                        double acc = 0.0;
-                        if (ell_lds) {
-                            for (int q = 0; q < ew; ++q) acc += ellv[base + q] * Dm[ellc[base + q] + LD * c];
-                        } else {
-                            for (int q = 0; q < ew; ++q) acc += p.ell_val[base + q] * Dm[p.ell_col[base + q] + LD * c];
-                        }
-                        M1[ri + LD * (nc + cl)] = acc;
-                    }
+        }
+        if (pf_x) {
+            if (ract && rj0 < nc) {
+                M1[ri + LD * rj0] = pf_xn + pf_xc;
+                M1[ri + LD * (nc + rj0)] = pf_xn - pf_xc;
+            }
+        } else if (ract) {
+            for (int c = rj0; c < nc; c += rstep) {
+                double xs = 0.0, xdv = 0.0;
+                if (c < nce) {
+                    const double xn = zn[x_off + (c0 + c) * n + ri], xc = zk[x_off + (c0 + c) * n + ri];
+                    xs = xn + xc;
+                    xdv = xn - xc;
                 }
+                M1[ri + LD * c] = xs;
+                M1[ri + LD * (nc + c)] = xdv;
             }
         }
-        __syncthreads();  // B2: G, M1 complete
+        __syncthreads();
 
-        // -- S3: burst B ; G^2 ----------------------------------------------------------------------------------
-        burst(per_burst);
-        if (have && !(p.ablate & 1)) {
-            for (int t = wave; t < rt_n * g2_ct; t += 8) {
-                if (p.iso)
-                    wave_tile<1>(G, LD, G, LD, G2, LD, n, d, n, t % rt_n, t / rt_n, lane, d);
-                else
-                    wave_tile<0>(G, LD, G, LD, G2, LD, n, n, n, t % rt_n, t / rt_n, lane, 0);
-            }
-        }
-        __syncthreads();  // B3: G2 complete
-
-        // -- S4: burst C ; W1 = G M1 (MFMA) ; G2D = G^2 D (VALU) ; request the next item's inputs -------------
-        burst(2 * per_burst);
-        if (have && !(p.ablate & 1)) {
-            for (int t = wave; t < rt_n * w1_ct; t += 8)
-                wave_tile<0>(G, LD, M1, LD, W1, LD, n, ncols1, n, t % rt_n, t / rt_n, lane, 0);
-            if (ract) {
+        // ---- phase 1: matrix waves G^2 ; stream waves G_l D ---------------------------------------------
+        if (JAC) {
+            if (matrix_wave) {
+                if (!(p.ablate & 1)) {
+                    if (p.iso)
+                        wave_rowgemm<1>(G, LD, G, LD, G2, LD, n, d, n, wave, 4, lane, d);
+                    else
+                        wave_rowgemm<0>(G, LD, G, LD, G2, LD, n, n, n, wave, 4, lane, 0);
+                }
+            } else if (sact && !(p.ablate & 16)) {
                 const double *Dm = M1 + LD * nc;
-                for (int c = rj0; c < nc; c += rstep) {
+                for (int cl = sj0; cl < m * nc; cl += sstep) {
+                    const int l = cl / nc, c = cl - l * nc;
+                    const int base = (l * n + si) * ew;
                     double acc = 0.0;
-                    for (int kk = 0; kk < n; ++kk) acc = fma(G2[ri + LD * kk], Dm[kk + LD * c], acc);
-                    G2D[ri + LD * c] = acc;
+                    if (stage) {
+                        for (int q = 0; q < ew; ++q) acc += ellv_l[base + q] * Dm[ellc_l[base + q] + LD * c];
+                    } else {
+                        for (int q = 0; q < ew; ++q) acc += p.ell_val[base + q] * Dm[p.ell_col[base + q] + LD * c];
+                    }
+                    M1[si + LD * (2 * nc + cl)] = acc;
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- phase 2: matrix waves W1 = G M1, G2D = G^2 D ; stream waves the block copies -------------------
+        const long long bk = (long long)b * p.K + k;
+        double *jb = JAC ? p.jac + bk * p.jac_per : nullptr;
+        const long long blk = p.compact ? (long long)nn : (long long)d * nn;  // size of seg 0 / seg 1
+        if (matrix_wave) {
+            if (!(p.ablate & 1)) {
+                if (fused_p2) {
+                    wave_phase2_fused(G, G2, M1, W1, G2D, LD, n, ncols1, nc, JAC, wave, lane);
+                } else {
+                    wave_rowgemm<0>(G, LD, M1, LD, W1, LD, n, ncols1, n, wave, 4, lane, 0);
+                    if (JAC) wave_rowgemm<0>(G2, LD, M1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
+                }
+            }
+        } else if (JAC && pact && !(p.ablate & 2)) {
+            int cbeg = c0, cend = c0 + nce;
+            if (p.compact) {  // unique blocks only: slice 0 writes the single copy
+                cbeg = 0;
+                cend = (s == 0) ? 1 : 0;
+            }
+            for (int j = pj0; j < n; j += pstep) {
+                const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
+                const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
+                const double e0 = ((pi == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + c2 * h1;
+                const double bp0 = -(e0 + c1 * g0), bp1 = -(e1 + c1 * g1);
+                const double bm0 = e0 - c1 * g0, bm1 = e1 - c1 * g1;
+                double *o0 = jb + (long long)cbeg * nn + (pi + n * j);
+                for (int c = cbeg; c < cend; ++c, o0 += nn) {
+                    store2(o0, bp0, bp1, p.nt);
+                    store2(o0 + blk, bm0, bm1, p.nt);
                 }
             }
         }
-        if (it + 1 < n_my) request(item + gridDim.x);
-        __syncthreads();  // B4: W1, G2D complete
+        // inputs of this workgroup's next item: in flight during the rest of this one
+        if (item + (int)gridDim.x < n_items) request(item + gridDim.x);
+        __syncthreads();
+        if (!JAC) {  // eval only: delta needs G (G D), a second dependent product
+            if (matrix_wave && !(p.ablate & 1)) wave_rowgemm<0>(G, LD, W1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
+            __syncthreads();
+        }
 
-        // -- S5: burst D ; column outputs: block 0 -> delta and d/ddt, block 1+l -> d/du_l -----------------
-        burst(3 * per_burst);
-        if (have && ract && !(p.ablate & 4)) {
-            const long long bk = (long long)b * p.K + k;
-            double *jb = p.jac + bk * p.jac_per;
+        // ---- phase 3: column outputs: block 0 -> delta and d/ddt, block 1+l -> d/du_l ----------------------
+        if (ract && !(p.ablate & 4)) {
             const double *GDm = W1 + LD * nc;
-            auto emit = [&](int cl, int t) {
-                const int lb = cl / nc, c = cl % nc;
-                if (c >= nce) return;
+            const int ncl = JAC ? (1 + m) * nc : nc;
+            for (int cl = rj0; cl < ncl; cl += rstep) {
+                const int lb = cl / nc, c = cl - lb * nc;
+                if (c >= nce) continue;
                 const long long r = (long long)(c0 + c) * n + ri;
                 if (lb == 0) {
                     const double gs = W1[ri + LD * c], g2d = G2D[ri + LD * c];
                     if (p.delta) p.delta[bk * xd + r] = M1[ri + LD * (nc + c)] - c1 * gs + c2 * g2d;
-                    jb[2 * blk + (long long)m * xd + r] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
+                    if (JAC) jb[2 * blk + (long long)m * xd + r] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
                 } else {
                     const int l = lb - 1;
+                    const int base = (l * n + ri) * ew;
                     double acc = 0.0;
-                    if (REG) {
-#pragma unroll
-                        for (int w = 0; w < PCL_REGW; ++w) {
-                            const int col = el_c[t < PCL_NCI ? t : 0][w];
-                            acc += el_v[t < PCL_NCI ? t : 0][w] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
+                    if (stage) {
+                        for (int q = 0; q < ew; ++q) {
+                            const int col = ellc_l[base + q];
+                            acc += ellv_l[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
                         }
                     } else {
-                        const int base = (l * n + ri) * ew;
                         for (int q = 0; q < ew; ++q) {
-                            const int col = ell_lds ? (int)ellc[base + q] : p.ell_col[base + q];
-                            const double v = ell_lds ? ellv[base + q] : p.ell_val[base + q];
-                            acc += v * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
+                            const int col = p.ell_col[base + q];
+                            acc += p.ell_val[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
                         }
                     }
                     jb[2 * blk + (long long)l * xd + r] = acc + c2 * W1[ri + LD * (nc + cl)];
                 }
-            };
-            if (REG) {
-#pragma unroll
-                for (int t = 0; t < PCL_NCI; ++t) {
-                    const int cl = rj0 + rstep * t;
-                    if (cl < (1 + m) * nc) emit(cl, t);
-                }
-            } else {
-                for (int cl = rj0; cl < (1 + m) * nc; cl += rstep) emit(cl, 0);
             }
         }
-        if (tid <= m) us[(cur ^ 1) * (m + 1) + tid] = pf_v;
+        if (tid <= m) us[(cur ^ 1) * (m + 1) + tid] = pf_v;  // requested during phase 2
         cur ^= 1;
-        __syncthreads();  // B0: iteration boundary
+        __syncthreads();  // LDS is rewritten by the next item's phase 0
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused residual + Jacobian kernel, version 3 (default): ONE persistent workgroup per CU, four
+// "matrix" wavefronts + four "stream" wavefronts, ONE workgroup barrier per work item (b, k, s).
+//
+//   stream waves  copy the item's -B^+ / B^- values out of the LDS tiles G, G^2 into registers and
+//                 then do nothing but issue the replicated 16-byte block stores (the HBM-roofline
+//                 stream; they are the waves that sit in the store queue's back-pressure);
+//   matrix waves  meanwhile work wave-synchronously (no workgroup barrier among them):
+//                 (1) the item's state columns in chunks of ncw columns, one chunk per wave at a time:
+//                     M = [S | D | G_l D] -> G*M on the f64 matrix cores -> delta, d/ddt, d/du_l
+//                     straight from the accumulator layout to HBM;
+//                 (2) G(u) and G^2 of the workgroup's NEXT item into the other half of the
+//                     double-buffered G / G^2 tiles (every matrix wave rewrites the whole union
+//                     pattern of G itself - identical values - so no wave waits for another before
+//                     its G^2 tiles).
+// Item time = max(store stream, matrix work); with the matrix work a fraction of the stream the
+// kernel runs at the store stream's rate.
+// LDS map (doubles): G [2][LD*n] | G2 [2][LD*n] | per matrix wave: M [LD*CW] GD [LD*ncw] G2D [LD*ncw] |
+//                    us [3][m+1] | union values | ELL values | (u16) union LDS offsets, ELL columns | (u8) union drives
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync() {
+    // Lanes of one wave exchange data through LDS: wait for this wave's LDS traffic only (never vmcnt - the
+    // wave's global stores may sit in a saturated store queue for microseconds) and pin the compiler's order.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+#define PCL_NSP 8   // B^{+-} value pairs per stream thread: (n*n/2) / 256 <= 8 for n <= 64
+#define PCL_MAXRT 4 // 16-row tiles of an n <= 64 operand
+#define PCL_MREG 8  // drives whose ELL row is held in registers (EW > 0 variants)
+
+struct V3Tables {  // launch-invariant tables, in LDS when they fit (else in memory)
+    const double *unv;          // [n_upos*uw] drive coefficients of the union pattern
+    const unsigned char *unl;   // [n_upos*uw] drive index
+    const unsigned short *uni;  // [n_upos] LDS offset (row + LD*col) of the pattern entry
+    const double *ung0;         // [n_upos] drift value at the pattern entry (shared-drift case)
+    const double *ellv;         // [m*n*ew]
+    const unsigned short *ellc;
+};
+
+template <int EW>  // ELL width held in registers for m <= PCL_MREG drives (0: general, tables in LDS / memory)
+__global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
+    extern __shared__ double lds[];
+    const int n = p.n, d = p.d, m = p.m, LD = p.LD;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int nn = n * n;
+    const int ew = p.ell_w, uw = p.uell_w, n_ell = m * n * ew, n_un = p.n_upos;
+    const int ncw = p.ncw;             // state columns per chunk
+    const int colsw = (2 + m) * ncw;   // operand columns per chunk
+    const int CW = 16;                 // one 16-column operand tile per chunk (host guarantees colsw <= 16)
+    const long long xd = (long long)n * d;
+    const int tile = LD * n;
+
+    double *Gb = lds;
+    double *G2b = Gb + 2 * tile;
+    double *wbuf = G2b + 2 * tile;  // per matrix wave
+    const int wsz = LD * (CW + 3 * ncw);
+    double *us = wbuf + 4 * wsz;
+    double *t_unv = us + 3 * (m + 1);
+    double *t_ung0 = t_unv + (p.tab_lds ? n_un * uw : 0);
+    double *t_ellv = t_ung0 + (p.tab_lds ? n_un : 0);
+    unsigned short *t_uni = reinterpret_cast<unsigned short *>(t_ellv + (p.tab_lds ? n_ell : 0));
+    unsigned short *t_ellc = t_uni + (p.tab_lds ? n_un : 0);
+    unsigned char *t_unl = reinterpret_cast<unsigned char *>(t_ellc + (p.tab_lds ? n_ell : 0));
+
+    // ---- prologue: both G buffers = drift tile, tables -> LDS ----------------------------------------------
+    if (!p.g0_batch_stride)
+        for (int e = tid; e < nn; e += 512) {
+            const double g = p.G0[e];
+            const int o = (e % n) + LD * (e / n);
+            Gb[o] = g;
+            Gb[tile + o] = g;
+        }
+    if (p.tab_lds) {
+        for (int e = tid; e < n_un * uw; e += 512) {
+            t_unv[e] = p.uell_v[e];
+            t_unl[e] = p.uell_l[e];
+        }
+        for (int e = tid; e < n_un; e += 512) {
+            const int pos = p.upos[e];
+            t_uni[e] = (unsigned short)((pos % n) + LD * (pos / n));
+            t_ung0[e] = p.g0_batch_stride ? 0.0 : p.G0[pos];
+        }
+        for (int e = tid; e < n_ell; e += 512) {
+            t_ellv[e] = p.ell_val[e];
+            t_ellc[e] = (unsigned short)p.ell_col[e];
+        }
+    }
+    __syncthreads();
+
+    const int n_items = p.batch * p.K * p.S;
+    const int n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const long long blk = p.compact ? (long long)nn : (long long)d * nn;  // size of seg 0 / seg 1
+    const int nc = p.nc;
+    auto decode = [&](int it, int &s, int &k, int &b) {
+        const int item = blockIdx.x + it * gridDim.x;
+        s = item % p.S;
+        k = (item / p.S) % p.K;
+        b = item / (p.S * p.K);
+    };
+
+    if (wave < 4) {
+        // ======================================= matrix waves =========================================
+        double *Mw = wbuf + wave * wsz;  // [LD*CW]: S | D | G_l D
+        double *GDw = Mw + LD * CW;      // [LD*ncw]
+        double *G2Dw = GDw + LD * ncw;   // [LD*ncw]
+        double *GSw = G2Dw + LD * ncw;   // [LD*ncw]
+        const int li = lane & 15, lk = lane >> 4;
+        const int rt_n = (n + 15) >> 4;
+        const int kfull = n >> 2, krem = n & 3;
+        // ELL rows (drive l, row = lane) in registers
+        unsigned short er_c[PCL_MREG][EW > 0 ? EW : 1];
+        double er_v[PCL_MREG][EW > 0 ? EW : 1];
+        if (EW > 0) {
+#pragma unroll
+            for (int l = 0; l < PCL_MREG; ++l)
+#pragma unroll
+                for (int q = 0; q < (EW > 0 ? EW : 1); ++q) {
+                    er_c[l][q] = 0;
+                    er_v[l][q] = 0.0;
+                    if (l < m && lane < n) {
+                        er_c[l][q] = (unsigned short)p.ell_col[(l * n + lane) * ew + q];
+                        er_v[l][q] = p.ell_val[(l * n + lane) * ew + q];
+                    }
+                }
+        }
+
+        // G(u) on the union pattern + this wave's share of the G^2 tiles, for item `it`, into buffer `buf`
+        auto build = [&](int it, int buf) {
+            int s, k, b;
+            decode(it, s, k, b);
+            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
+            double *G = Gb + buf * tile, *G2 = G2b + buf * tile;
+            double *usn = us + (it % 3) * (m + 1);
+            if (lane <= m) usn[lane] = zk[lane < m ? p.u_off + lane : p.dt_off];  // every wave: identical values
+            wave_lds_sync();
+            const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
+            if (p.g0_batch_stride)  // per-member drift: the whole tile changes with b
+                for (int e = lane; e < nn; e += 64) G[(e % n) + LD * (e / n)] = G0b[e];
+            if (p.tab_lds) {
+                for (int q = lane; q < n_un; q += 64) {
+                    double g = p.g0_batch_stride ? G0b[p.upos[q]] : t_ung0[q];
+                    for (int w = 0; w < uw; ++w) g += usn[t_unl[q * uw + w]] * t_unv[q * uw + w];
+                    G[t_uni[q]] = g;
+                }
+            } else {
+                for (int q = lane; q < n_un; q += 64) {
+                    const int pos = p.upos[q];
+                    double g = G0b[pos];
+                    const double *cf = p.ucoef + (long long)q * m;
+                    for (int l = 0; l < m; ++l) g += usn[l] * cf[l];
+                    G[(pos % n) + LD * (pos / n)] = g;
+                }
+            }
+            wave_lds_sync();
+            if (p.ablate & 1) return;
+            // G^2: row tile rt = wave (+4..), all column tiles; with the iso structure only the first d columns
+            const int ct_n = p.iso ? (d + 15) >> 4 : rt_n;
+            const int Nc = p.iso ? d : n;
+            for (int rt = wave; rt < rt_n; rt += 4) {
+                const double *Ap = G + rt * 16 + li + LD * lk;
+                for (int ct = 0; ct < ct_n; ct += 2) {
+                    const bool two = ct + 1 < ct_n;
+                    const double *Bp0 = G + lk + LD * (ct * 16 + li);
+                    const double *Bp1 = Bp0 + (two ? LD * 16 : 0);
+                    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                    double an = 0.0, b0n = 0.0, b1n = 0.0;
+                    if (kfull > 0) {
+                        an = Ap[0];
+                        b0n = Bp0[0];
+                        b1n = Bp1[0];
+                    }
+                    for (int ks = 0; ks < kfull; ++ks) {
+                        const double a = an, b0 = b0n, b1 = b1n;
+                        if (ks + 1 < kfull) {
+                            an = Ap[LD * 4 * (ks + 1)];
+                            b0n = Bp0[4 * (ks + 1)];
+                            b1n = Bp1[4 * (ks + 1)];
+                        }
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
+                        if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+                    }
+                    if (krem) {
+                        const bool ok = lk < krem;
+                        const double a = ok ? Ap[LD * 4 * kfull] : 0.0;
+                        const double b0 = ok ? Bp0[4 * kfull] : 0.0;
+                        const double b1 = ok ? Bp1[4 * kfull] : 0.0;
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
+                        if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int col = (ct + t) * 16 + li;
+                        if ((t == 0 || two) && col < Nc) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = rt * 16 + lk + 4 * r;
+                                const double v = t ? acc1[r] : acc0[r];
+                                if (row < n) {
+                                    G2[row + LD * col] = v;
+                                    if (p.iso) {
+                                        if (row < d)
+                                            G2[row + d + LD * (col + d)] = v;
+                                        else
+                                            G2[row - d + LD * (col + d)] = -v;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        };
+
+        if (n_my > 0) build(0, 0);
+        __syncthreads();  // item 0's G, G^2 complete
+
+        for (int it = 0; it < n_my; ++it) {
+            const int cur = it & 1;
+            int s, k, b;
+            decode(it, s, k, b);
+            const int c0 = s * nc, nce = min(nc, d - c0);
+            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
+            const double *zn = zk + p.z_dim;
+            const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+            const double *G = Gb + cur * tile, *G2 = G2b + cur * tile;
+            const double h = us[(it % 3) * (m + 1) + m];
+            const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0), h6 = h * (1.0 / 6.0);
+            const long long bk = (long long)b * p.K + k;
+            double *jb = p.jac + bk * p.jac_per;
+            double *ju = jb + 2 * blk, *jh = ju + (long long)m * xd;
+
+            const int nchunk = (nce + ncw - 1) / ncw;
+            int stamp = 0;
+#define PCL_STAMP()                                                                                     \
+    do {                                                                                                \
+        if (p.dbg && blockIdx.x == 0 && wave == 0 && lane == 0 && it == 1 && stamp < 60) p.dbg[stamp++] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+            PCL_STAMP();
+            for (int ch = wave; ch < nchunk && !(p.ablate & 4); ch += 4) {
+                const int cc0 = c0 + ch * ncw;             // first state column of the chunk
+                const int ncc = min(ncw, c0 + nce - cc0);  // columns in this chunk
+                // ---- M = [S | D | G_l D]   (lane = row) -----------------------------------------------------
+                if (lane < n) {
+                    for (int c = 0; c < ncw; ++c) {
+                        double xs = 0.0, xdv = 0.0;
+                        if (c < ncc) {
+                            const long long o = x_off + (long long)(cc0 + c) * n + lane;
+                            const double xn = zn[o], xc = zk[o];
+                            xs = xn + xc;
+                            xdv = xn - xc;
+                        }
+                        Mw[lane + LD * c] = xs;
+                        Mw[lane + LD * (ncw + c)] = xdv;
+                    }
+                    for (int c = colsw; c < CW; ++c) Mw[lane + LD * c] = 0.0;
+                }
+                wave_lds_sync();
+                PCL_STAMP();  // S, D loaded
+                const double *Dm = Mw + LD * ncw;
+                if (lane < n) {
+                    if (EW > 0) {
+#pragma unroll
+                        for (int l = 0; l < PCL_MREG; ++l)
+                            if (l < m)
+                                for (int c = 0; c < ncw; ++c) {
+                                    double acc = 0.0;
+#pragma unroll
+                                    for (int q = 0; q < (EW > 0 ? EW : 1); ++q) acc += er_v[l][q] * Dm[er_c[l][q] + LD * c];
+                                    Mw[lane + LD * (2 * ncw + l * ncw + c)] = acc;
+                                }
+                    } else {
+                        for (int l = 0; l < m; ++l)
+                            for (int c = 0; c < ncw; ++c) {
+                                const int base = (l * n + lane) * ew;
+                                double acc = 0.0;
+                                for (int q = 0; q < ew; ++q) {
+                                    const int col = p.tab_lds ? (int)t_ellc[base + q] : p.ell_col[base + q];
+                                    const double ev = p.tab_lds ? t_ellv[base + q] : p.ell_val[base + q];
+                                    acc += ev * Dm[col + LD * c];
+                                }
+                                Mw[lane + LD * (2 * ncw + l * ncw + c)] = acc;
+                            }
+                    }
+                    PCL_STAMP();  // G_l D done
+                    // G2D = G^2 D on the VALU, 6 independent partial sums per column
+                    for (int c = 0; c < ncw; ++c) {
+                        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0;
+                        int kk = 0;
+                        for (; kk + 6 <= n; kk += 6) {
+                            s0 = fma(G2[lane + LD * kk], Dm[kk + LD * c], s0);
+                            s1 = fma(G2[lane + LD * (kk + 1)], Dm[kk + 1 + LD * c], s1);
+                            s2 = fma(G2[lane + LD * (kk + 2)], Dm[kk + 2 + LD * c], s2);
+                            s3 = fma(G2[lane + LD * (kk + 3)], Dm[kk + 3 + LD * c], s3);
+                            s4 = fma(G2[lane + LD * (kk + 4)], Dm[kk + 4 + LD * c], s4);
+                            s5 = fma(G2[lane + LD * (kk + 5)], Dm[kk + 5 + LD * c], s5);
+                        }
+                        for (; kk < n; ++kk) s0 = fma(G2[lane + LD * kk], Dm[kk + LD * c], s0);
+                        G2Dw[lane + LD * c] = ((s0 + s1) + (s2 + s3)) + (s4 + s5);
+                    }
+                }
+                wave_lds_sync();
+                PCL_STAMP();  // G2D done
+                // ---- W = G * M on the matrix cores: all row tiles at once (they share the b operand) ----------
+                {
+                    const double *Bp = Mw + lk + LD * li;
+                    const double *Ap[PCL_MAXRT];
+                    bool rok[PCL_MAXRT];
+#pragma unroll
+                    for (int t = 0; t < PCL_MAXRT; ++t) {
+                        rok[t] = t * 16 < n;
+                        Ap[t] = G + (rok[t] ? t * 16 : 0) + li + LD * lk;
+                    }
+                    double4_t acc[PCL_MAXRT];
+#pragma unroll
+                    for (int t = 0; t < PCL_MAXRT; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+                    if (!(p.ablate & 1)) {
+                        double an[PCL_MAXRT], bn = 0.0;
+#pragma unroll
+                        for (int t = 0; t < PCL_MAXRT; ++t) an[t] = kfull > 0 ? Ap[t][0] : 0.0;
+                        if (kfull > 0) bn = Bp[0];
+                        for (int ks = 0; ks < kfull; ++ks) {
+                            double a[PCL_MAXRT];
+                            const double bb = bn;
+#pragma unroll
+                            for (int t = 0; t < PCL_MAXRT; ++t) a[t] = an[t];
+                            if (ks + 1 < kfull) {
+#pragma unroll
+                                for (int t = 0; t < PCL_MAXRT; ++t) an[t] = Ap[t][LD * 4 * (ks + 1)];
+                                bn = Bp[4 * (ks + 1)];
+                            }
+#pragma unroll
+                            for (int t = 0; t < PCL_MAXRT; ++t)
+                                if (rok[t]) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bb, acc[t], 0, 0, 0);
+                        }
+                        if (krem) {
+                            const bool ok = lk < krem;
+                            const double bb = ok ? Bp[4 * kfull] : 0.0;
+#pragma unroll
+                            for (int t = 0; t < PCL_MAXRT; ++t)
+                                if (rok[t]) {
+                                    const double a = ok ? Ap[t][LD * 4 * kfull] : 0.0;
+                                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[t], 0, 0, 0);
+                                }
+                        }
+                    }
+                    // accumulator layout -> LDS: column li of [G S | G D | G (G_l D)]; the last group goes back into M's
+                    // own columns (their operand role is over)
+                    double *dst = li < ncw ? GSw + LD * li : (li < 2 * ncw ? GDw + LD * (li - ncw) : Mw + LD * li);
+#pragma unroll
+                    for (int t = 0; t < PCL_MAXRT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = t * 16 + lk + 4 * r;
+                            if (row < n && li < colsw) dst[row] = acc[t][r];
+                        }
+                }
+                wave_lds_sync();
+                PCL_STAMP();  // MFMA + accumulators -> LDS done
+                // ---- outputs (lane = row; consecutive lanes -> consecutive addresses) -------------------------------
+                if (lane < n) {
+                    for (int c = 0; c < ncc; ++c) {
+                        const long long rr = (long long)(cc0 + c) * n + lane;
+                        const double gs = GSw[lane + LD * c], g2d = G2Dw[lane + LD * c];
+                        if (p.delta) p.delta[bk * xd + rr] = Mw[lane + LD * (ncw + c)] - c1 * gs + c2 * g2d;
+                        jh[rr] = -0.5 * gs + h6 * g2d;
+                    }
+                    // d/du_l = G_l (-c1 S + c2 G D) + c2 G (G_l D)
+                    if (EW > 0) {
+#pragma unroll
+                        for (int l = 0; l < PCL_MREG; ++l)
+                            if (l < m)
+                                for (int c = 0; c < ncc; ++c) {
+                                    double acc = 0.0;
+#pragma unroll
+                                    for (int q = 0; q < (EW > 0 ? EW : 1); ++q)
+                                        acc += er_v[l][q] * (-c1 * Mw[er_c[l][q] + LD * c] + c2 * GDw[er_c[l][q] + LD * c]);
+                                    ju[(long long)l * xd + (long long)(cc0 + c) * n + lane] = acc + c2 * Mw[lane + LD * (2 * ncw + l * ncw + c)];
+                                }
+                    } else {
+                        for (int l = 0; l < m; ++l)
+                            for (int c = 0; c < ncc; ++c) {
+                                const int base = (l * n + lane) * ew;
+                                double acc = 0.0;
+                                for (int q = 0; q < ew; ++q) {
+                                    const int col = p.tab_lds ? (int)t_ellc[base + q] : p.ell_col[base + q];
+                                    const double ev = p.tab_lds ? t_ellv[base + q] : p.ell_val[base + q];
+                                    acc += ev * (-c1 * Mw[col + LD * c] + c2 * GDw[col + LD * c]);
+                                }
+                                ju[(long long)l * xd + (long long)(cc0 + c) * n + lane] = acc + c2 * Mw[lane + LD * (2 * ncw + l * ncw + c)];
+                            }
+                    }
+                }
+                wave_lds_sync();  // the chunk buffers are rewritten by this wave's next chunk
+                PCL_STAMP();  // outputs issued
+            }
+            // ---- next item's G(u), G^2 into the other buffer ----------------------------------------------------
+            if (it + 1 < n_my) build(it + 1, cur ^ 1);
+            PCL_STAMP();  // next G, G^2 built
+            __syncthreads();  // item boundary
+            PCL_STAMP();  // barrier passed
+        }
+    } else {
+        // ======================================= stream waves =========================================
+        const int stid = tid - 256;
+        const int hn = n >> 1;
+        const int pi = 2 * (stid % hn), pj0 = stid / hn, pstep = max(256 / hn, 1);
+        const bool pact = pj0 < pstep;
+        __syncthreads();  // item 0's G, G^2 complete
+        for (int it = 0; it < n_my; ++it) {
+            const int cur = it & 1;
+            int s, k, b;
+            decode(it, s, k, b);
+            const double *G = Gb + cur * tile, *G2 = G2b + cur * tile;
+            if (pact && !(p.ablate & 2)) {
+                const double h = us[(it % 3) * (m + 1) + m];
+                const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
+                double bpr[PCL_NSP][2], bmr[PCL_NSP][2];
+#pragma unroll
+                for (int r = 0; r < PCL_NSP; ++r) {
+                    const int j = pj0 + pstep * r;
+                    if (j < n) {
+                        const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
+                        const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
+                        const double e0 = ((pi == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + c2 * h1;
+                        bpr[r][0] = -(e0 + c1 * g0);
+                        bpr[r][1] = -(e1 + c1 * g1);
+                        bmr[r][0] = e0 - c1 * g0;
+                        bmr[r][1] = e1 - c1 * g1;
+                    }
+                }
+                int cbeg = s * nc, cend = s * nc + min(nc, d - s * nc);
+                if (p.compact) {  // unique blocks only: slice 0 writes the single copy
+                    cbeg = 0;
+                    cend = (s == 0) ? 1 : 0;
+                }
+                double *o = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn + pi;
+                for (int c = cbeg; c < cend; ++c, o += nn) {
+#pragma unroll
+                    for (int r = 0; r < PCL_NSP; ++r) {
+                        const int j = pj0 + pstep * r;
+                        if (j < n) {
+                            store2(o + n * j, bpr[r][0], bpr[r][1], p.nt);
+                            store2(o + blk + n * j, bmr[r][0], bmr[r][1], p.nt);
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // item boundary
+        }
     }
 }
 
@@ -1198,6 +1365,8 @@ struct pcl_ctx {
     double *dZ = nullptr, *dmu = nullptr, *ddelta = nullptr, *dvals = nullptr, *dhess = nullptr;
     // options
     int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_ablate = 0, opt_kernel = 2;
+    long long *ddbg = nullptr;
+    int64_t opt_stagger = 0;
     int64_t opt_grid = 0;  // 0: resident workgroups (persistent kernel)
     size_t lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // last MaxDynamicSharedMemorySize set per kernel variant
     int max_lds = 0;
@@ -1439,7 +1608,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     void *ptrs[] = {ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
-                    ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v};
+                    ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -1598,6 +1767,9 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.LD = lds_ld(D.d);
     p.nt = (int)ctx->opt_nt;
     p.ablate = (int)ctx->opt_ablate;
+    p.dbg = ctx->ddbg;
+    p.stagger = (int)ctx->opt_stagger;
+    p.n_cu = ctx->n_cu;
     p.hess_per = hess_per(ctx);
 }
 
@@ -1612,7 +1784,7 @@ static const size_t ELL_LDS_MAX_BYTES = 8192;
 static size_t fused2_lds_bytes(const KParams &p, bool jac, bool ell_lds) {  // version-2 kernel
     const size_t ncols1 = jac ? (size_t)(2 + p.m) * p.nc : 2 * (size_t)p.nc;
     const size_t n_ell = (size_t)p.m * p.n * p.ell_w;
-    size_t bytes = ((size_t)p.LD * p.n * (jac ? 2 : 1) + 2 * p.LD * ncols1 + (size_t)p.LD * p.nc) * sizeof(double);
+    size_t bytes = ((size_t)p.LD * p.n * (jac ? 2 : 1) + 2 * p.LD * ncols1 + (size_t)p.LD * p.nc + 2 * (p.m + 1)) * sizeof(double);
     if (jac && ell_lds) bytes += n_ell * sizeof(double) + (n_ell * sizeof(unsigned short) + 7) / 8 * 8;
     return bytes + 128;  // slack: operand tiles may be read past the last buffer's edge
 }
@@ -1652,47 +1824,38 @@ static int choose_cols_per_slice(const pcl_ctx *ctx, bool jac) {
     return best;
 }
 
-static bool v3_reg_path(const pcl_ctx *ctx, int nc) {
-    const int rstep = 512 / ctx->n;
-    return !ctx->desc.per_member_G0 && ctx->uell_w <= 2 && ctx->ell_w <= 2 && ctx->n_upos <= 512 * 4 &&
-           (1 + ctx->desc.n_drives) * nc <= 4 * rstep;
-}
+static bool v3_supported(const pcl_ctx *ctx) { return 2 + ctx->desc.n_drives <= 16; }
+static int v3_ncw(const pcl_ctx *ctx, int nc) { return std::max(1, std::min(nc, 16 / (2 + ctx->desc.n_drives))); }
 
-static size_t fused3_lds_bytes(const pcl_ctx *ctx, const KParams &p) {  // version-3 kernel
-    const size_t ncols1 = (size_t)(2 + p.m) * p.nc;
-    const size_t n_ell = (size_t)p.m * p.n * p.ell_w;
-    size_t dbl = 2 * (size_t)p.LD * p.n + 2 * p.LD * ncols1 + (size_t)p.LD * p.nc + 2 * (p.m + 1);
-    size_t bytes = dbl * sizeof(double);
-    if (!v3_reg_path(ctx, p.nc) && ell_fits_lds(ctx)) bytes += n_ell * (sizeof(double) + 2);
+static size_t fused3_lds_bytes(const pcl_ctx *ctx, const KParams &p, bool tab) {  // version-3 kernel
+    const size_t tile = (size_t)p.LD * p.n, wsz = (size_t)p.LD * (16 + 3 * p.ncw);
+    const size_t n_ell = (size_t)p.m * p.n * p.ell_w, n_un = (size_t)ctx->n_upos, uw = (size_t)ctx->uell_w;
+    size_t bytes = (4 * tile + 4 * wsz + 3 * (size_t)(p.m + 1)) * sizeof(double);
+    if (tab) bytes += (n_un * uw + n_un + n_ell) * sizeof(double) + (n_un + n_ell) * 2 + n_un * uw;
     return (bytes + 7) / 8 * 8 + 128;  // slack: operand tiles may be read past the last buffer's edge
 }
 
-// v3 cost model (one workgroup per CU, item time = max(store stream, matrix path)); picks the slice width.
+// v3 cost model (one workgroup per CU; item time = max(store stream, matrix work)): picks the slice width nc.
 static int choose_cols_v3(const pcl_ctx *ctx) {
     const int d = ctx->desc.d, n = ctx->n, m = ctx->desc.n_drives;
     if (ctx->opt_cols_per_slice > 0) return (int)std::min<int64_t>(ctx->opt_cols_per_slice, d);
-    KParams p;
-    memset(&p, 0, sizeof p);
-    p.n = n;
-    p.m = m;
-    p.LD = ((n + 3) & ~3) + 2;
-    p.ell_w = ctx->ell_w;
     const double bw_cu = 6.3e12 / std::max(ctx->n_cu, 1);  // achievable HBM bytes/s per CU when all CUs stream
     const double clk = 2.0e9;
     const long long bk = (long long)ctx->desc.batch * ctx->K;
-    int best = 1;
+    const int rt = (n + 15) / 16, ks = (n + 3) / 4;
+    const int g2ct = ctx->iso ? (d + 15) / 16 : (n + 15) / 16;
+    int best = d;
     double best_t = 1e300;
-    for (int nc = 1; nc <= std::min(d, 16); ++nc) {
-        p.nc = nc;
-        if (fused3_lds_bytes(ctx, p) > (size_t)ctx->max_lds) break;
+    for (int nc = 1; nc <= d; ++nc) {
+        const int ncw = v3_ncw(ctx, nc);
         const long long S = (d + nc - 1) / nc;
         const double rounds = (double)((bk * S + ctx->n_cu - 1) / std::max(ctx->n_cu, 1));
-        const double t_stream = 2.0 * std::min(nc, d) * n * n * 8.0 / bw_cu;
-        const int rt = (n + 15) / 16, ks = (n + 3) / 4;
-        const int g2ct = ctx->iso ? (d + 15) / 16 : (n + 15) / 16;
-        const int p2ct = ((2 + m) * nc + 15) / 16;
-        const double t_matrix = (double)((rt * (g2ct + p2ct) + 3) / 4) * ks * 64.0 / clk + 1.5e-6;
-        const double t = rounds * std::max(t_stream, t_matrix) + t_matrix;
+        const double t_stream = 2.0 * nc * n * n * 8.0 / bw_cu;
+        const int chunks_per_wave = ((nc + ncw - 1) / ncw + 3) / 4;
+        const double t_build = ((rt + 3) / 4) * (double)g2ct * ks * 72.0 / clk + 0.5e-6;
+        const double t_chunk = rt * ks * 72.0 / clk + 2.0e-6;
+        const double t_matrix = t_build + chunks_per_wave * t_chunk;
+        const double t = rounds * std::max(t_stream, t_matrix) + t_build + 1.0e-6;
         if (t < best_t) {
             best_t = t;
             best = nc;
@@ -1719,26 +1882,30 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     p.jac_per = compact ? jac_per_compact(ctx) : jac_per_full(ctx);
     const bool want_jac = jac != nullptr;
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
-    if (want_jac && ctx->opt_kernel == 3 && ctx->opt_use_mfma != 0) {
+    if (want_jac && ctx->opt_kernel == 3 && ctx->opt_use_mfma != 0 && v3_supported(ctx)) {
         p.nc = choose_cols_v3(ctx);
-        size_t lds3 = fused3_lds_bytes(ctx, p);
-        while (lds3 > (size_t)ctx->max_lds && p.nc > 1) {
-            --p.nc;
-            lds3 = fused3_lds_bytes(ctx, p);
+        p.ncw = v3_ncw(ctx, p.nc);
+        p.tab_lds = 1;
+        size_t lds3 = fused3_lds_bytes(ctx, p, true);
+        if (lds3 > (size_t)ctx->max_lds) {  // large union / ELL tables stay in memory
+            p.tab_lds = 0;
+            lds3 = fused3_lds_bytes(ctx, p, false);
         }
-        if (lds3 > (size_t)ctx->max_lds) return fail(ctx, PCL_ESHAPE, "fused kernel needs %zu B of LDS (> %d)", lds3, ctx->max_lds);
+        if (lds3 > (size_t)ctx->max_lds) goto not_v3;  // double-buffered tiles do not fit (n close to 64): kernel v2
         p.S = (p.d + p.nc - 1) / p.nc;
         const long long items = (long long)p.batch * p.K * p.S;
         if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
-        const bool reg = v3_reg_path(ctx, p.nc);
-        auto kern3 = reg ? pcl_fused_kernel_v3<true> : pcl_fused_kernel_v3<false>;
-        int rc = set_lds_attr(ctx, (const void *)kern3, reg ? 6 : 7, lds3);
+        typedef void (*kern3_t)(const KParams);
+        const int ewr = (p.m <= 8 && ctx->ell_w >= 1 && ctx->ell_w <= 2) ? ctx->ell_w : 0;
+        kern3_t kern3 = ewr == 1 ? (kern3_t)pcl_fused_kernel_v3<1> : ewr == 2 ? (kern3_t)pcl_fused_kernel_v3<2> : (kern3_t)pcl_fused_kernel_v3<0>;
+        int rc = set_lds_attr(ctx, (const void *)kern3, 6, lds3);
         if (rc != PCL_OK) return rc;
         const long long g3 = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, items) : std::min<long long>(items, std::max(ctx->n_cu, 1));
         hipLaunchKernelGGL(kern3, dim3((unsigned)g3), dim3(512), lds3, ctx->stream, p);
         HIP_TRY(ctx, hipGetLastError());
         return PCL_OK;
     }
+not_v3:
     const bool v2 = ctx->opt_kernel >= 2 && ctx->opt_use_mfma != 0;
     p.nc = choose_cols_per_slice(ctx, want_jac);
     auto bytes = [&]() { return v2 ? fused2_lds_bytes(p, want_jac, p.ell_lds != 0) : fused_lds_bytes(p, want_jac); };
@@ -1753,7 +1920,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "grid too large");
     if (v2) {
         typedef void (*kern_t)(const KParams);
-        const int wu = ctx->uell_w <= 2 ? ctx->uell_w : -1;
+        const int wu = (ctx->uell_w <= 2 && ctx->n_upos <= 1024 && !ctx->desc.per_member_G0) ? ctx->uell_w : -1;
         kern_t kern = want_jac ? (wu == 1 ? (kern_t)pcl_fused_kernel_v2<true, 1> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<true, 2> : (kern_t)pcl_fused_kernel_v2<true, -1>)
                                : (wu == 1 ? (kern_t)pcl_fused_kernel_v2<false, 1> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<false, 2> : (kern_t)pcl_fused_kernel_v2<false, -1>);
         int rc = set_lds_attr(ctx, (const void *)kern, want_jac ? 4 : 5, lds);  // wu is fixed per context
@@ -1920,6 +2087,17 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_ablate = v;
     else if (!strcmp(key, "grid"))
         ctx->opt_grid = v;
+    else if (!strcmp(key, "stagger"))
+        ctx->opt_stagger = v;
+    else if (!strcmp(key, "debug_timing")) {  // profiling aid: cycle stamps of workgroup 0 (pcl_debug_timing reads them)
+        if (v && !ctx->ddbg) {
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->ddbg, 64 * sizeof(long long)));
+            HIP_TRY(ctx, hipMemset(ctx->ddbg, 0, 64 * sizeof(long long)));
+        } else if (!v && ctx->ddbg) {
+            (void)hipFree(ctx->ddbg);
+            ctx->ddbg = nullptr;
+        }
+    }
     else if (!strcmp(key, "kernel_version")) {
         if (v < 1 || v > 3) return fail(ctx, PCL_EINVAL, "kernel_version must be 1, 2 or 3");
         ctx->opt_kernel = v;
@@ -1928,6 +2106,14 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         return fail(ctx, PCL_EINVAL, "unknown option '%s'", key);
     return PCL_OK;
 }
+extern "C" int pcl_debug_timing(pcl_ctx *ctx, int64_t *out, int64_t cap) {
+    if (!ctx || !out || cap < 0) return PCL_EINVAL;
+    if (!ctx->ddbg) return fail(ctx, PCL_EINVAL, "pcl_debug_timing: set option debug_timing first");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->ddbg, (size_t)std::min<int64_t>(cap, 64) * sizeof(long long), hipMemcpyDeviceToHost));
+    return PCL_OK;
+}
+
 extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
     if (!ctx || !key || !v) return PCL_EINVAL;
     if (!strcmp(key, "cols_per_slice"))
@@ -1937,7 +2123,7 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
     else if (!strcmp(key, "nt_stores"))
         *v = ctx->opt_nt;
     else if (!strcmp(key, "effective_cols_per_slice"))
-        *v = (ctx->opt_kernel == 3 && ctx->opt_use_mfma) ? choose_cols_v3(ctx) : choose_cols_per_slice(ctx, true);
+        *v = (ctx->opt_kernel == 3 && ctx->opt_use_mfma && v3_supported(ctx)) ? choose_cols_v3(ctx) : choose_cols_per_slice(ctx, true);
     else if (!strcmp(key, "n_cu"))
         *v = ctx->n_cu;
     else if (!strcmp(key, "kernel_version"))
