@@ -4,7 +4,7 @@ Piccolo.jl / DirectTrajOpt.jl (one hot path; see DESIGN.md and SURVEY.md section
 The directory name contains a dot, so it is imported through the loader shim
 ``piccolo_jl_amd.py`` at the repository root:  ``import piccolo_jl_amd as pa``.
 """
-from . import _lib, integrators, quantum, trajectory
+from . import _lib, distributed, integrators, quantum, synthetic, trajectory
 from ._lib import PclError, build_library
 from .integrators import (
     BilinearIntegrator,

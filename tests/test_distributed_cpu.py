@@ -1,0 +1,121 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: units are sharded round-robin over ranks, each rank
+evaluates only its own members, and ONE sum all_reduce of [merit | shared-control gradient] reproduces
+the unsharded result.  The evaluator is replaced by the CPU oracle here (no GPU in this container);
+the host logic under test is piccolo.jl_amd/distributed.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import piccolo_jl_amd as pa
+from oracle import pade_oracle as po
+from piccolo_jl_amd import distributed as pd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ensemble(M=5, N=7, seed=3):
+    """Config-4-style ensemble: M perturbed drifts, shared controls, layout [U1..UM, dt, t, u]."""
+    rng = np.random.default_rng(seed)
+    base = po.config_system(1)
+    d, m = base.levels, base.n_drives
+    xd = 2 * d * d
+    lay = po.Layout(d=d, m=m, N=N, z_dim=M * xd + 2 + m, x_off=0, u_off=M * xd + 2, dt_off=M * xd)
+    Z = 0.3 * rng.standard_normal((N, lay.z_dim))
+    Z[:, lay.dt_off] = 0.1 + 0.05 * rng.random(N)
+    systems = [po.quantum_system((1 + 0.05 * (i - M // 2)) * base.H_drift, base.H_drives, [1.0, 1.0]) for i in range(M)]
+    return systems, lay, Z, xd
+
+
+def _member_outputs(systems, lay, Z, xd, members):
+    dl, vl = [], []
+    for i in members:
+        s = systems[i]
+        G0, Gj = s.G_drift, np.array(s.G_drives)
+        dl.append(po.pade_residual(Z, lay, G0, Gj, 4, x_off=i * xd))
+        vl.append(po.pade_jacobian_values(Z, lay, G0, Gj, 4, x_off=i * xd))
+    return torch.from_numpy(np.stack(dl)).reshape(-1), torch.from_numpy(np.stack(vl)).reshape(-1)
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    d_ = pd.init_process_group("gloo")
+    systems, lay, Z, xd = _ensemble()
+    M = len(systems)
+    mine = pd.shard_indices(M, rank, world)
+    delta, vals = _member_outputs(systems, lay, Z, xd, mine)
+    w = torch.tensor([1.0 + 0.1 * i for i in mine], dtype=torch.float64)
+    phi, gu, gdt = pd.constraint_merit_and_shared_gradient(delta, vals, len(mine), lay.K, lay.d, lay.m, w)
+    phi, gu, gdt = pd.reduce_merit_and_gradient(phi, gu, gdt, d_)
+    per_unit = torch.tensor([float(i) for i in mine], dtype=torch.float64)
+    allv = pd.gather_per_unit(per_unit, M, rank, world, d_)
+    if rank == 0:
+        torch.save(dict(phi=phi, gu=gu, gdt=gdt, allv=allv), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_indices_cover_exactly_once():
+    for total, world in [(64, 8), (5, 2), (3, 4), (1, 1)]:
+        seen = sorted(i for r in range(world) for i in pd.shard_indices(total, r, world))
+        assert seen == list(range(total))
+    assert pd.shard_indices(64, 3, 8) == list(range(3, 64, 8))  # 8 members per GPU at config 4
+    with pytest.raises(ValueError):
+        pd.shard_indices(4, 4, 4)
+
+
+def test_jacobian_views_match_layout():
+    d, m, K, B = 2, 2, 3, 2
+    n, xd = 2 * d, 2 * d * d
+    per = 2 * d * n * n + xd * (m + 1)
+    vals = torch.arange(B * K * per, dtype=torch.float64)
+    ju, jh = pd.jacobian_views(vals, B, K, d, m)
+    assert ju.shape == (B, K, m, xd) and jh.shape == (B, K, xd)
+    assert ju[1, 2, 1, 3].item() == (1 * K + 2) * per + 2 * d * n * n + 1 * xd + 3
+    assert jh[0, 1, 5].item() == 1 * per + 2 * d * n * n + m * xd + 5
+
+
+def test_world2_gloo_reduce_equals_unsharded(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    systems, lay, Z, xd = _ensemble()
+    M = len(systems)
+    delta, vals = _member_outputs(systems, lay, Z, xd, range(M))
+    w = torch.tensor([1.0 + 0.1 * i for i in range(M)], dtype=torch.float64)
+    phi, gu, gdt = pd.constraint_merit_and_shared_gradient(delta, vals, M, lay.K, lay.d, lay.m, w)
+    assert torch.allclose(got["phi"], phi, rtol=1e-13, atol=0)
+    assert torch.allclose(got["gu"], gu, rtol=1e-12, atol=1e-14)
+    assert torch.allclose(got["gdt"], gdt, rtol=1e-12, atol=1e-14)
+    assert torch.equal(got["allv"], torch.arange(M, dtype=torch.float64))
+    # the reduced gradient is the gradient of the merit function w.r.t. the shared controls (finite differences)
+    def merit(Zp):
+        d_, _ = _member_outputs(systems, lay, Zp, xd, range(M))
+        return float(0.5 * (w[:, None] * d_.view(M, -1) ** 2).sum())
+    eps = 1e-6
+    for (k, l) in [(0, 0), (2, 1), (lay.K - 1, 0)]:
+        Zp, Zm = Z.copy(), Z.copy()
+        Zp[k, lay.u_off + l] += eps
+        Zm[k, lay.u_off + l] -= eps
+        assert abs((merit(Zp) - merit(Zm)) / (2 * eps) - float(gu[k, l])) < 1e-6
+    Zp, Zm = Z.copy(), Z.copy()
+    Zp[1, lay.dt_off] += eps
+    Zm[1, lay.dt_off] -= eps
+    assert abs((merit(Zp) - merit(Zm)) / (2 * eps) - float(gdt[1])) < 1e-6
+
+
+def test_single_process_reduce_is_identity():
+    phi, gu, gdt = torch.tensor(2.0, dtype=torch.float64), torch.ones(3, 2, dtype=torch.float64), torch.zeros(3, dtype=torch.float64)
+    a, b, c = pd.reduce_merit_and_gradient(phi, gu, gdt, None)
+    assert a.item() == 2.0 and torch.equal(b, gu) and torch.equal(c, gdt)
