@@ -380,3 +380,67 @@ def test_deterministic_bitwise_repeatability(config3_full):
     b = c.eval_jac(Z)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     c.close()
+
+
+def test_ensemble_merit_and_shared_gradient_on_device():
+    """Config-4 style: per-member drifts, shared controls; merit + shared-control gradient from the device
+    buffers (piccolo.jl_amd/distributed.py) against finite differences of the oracle's merit."""
+    import torch
+
+    from piccolo_jl_amd import distributed as pd
+
+    rng = np.random.default_rng(4)
+    base = po.config_system(2)
+    d, m, M, N = base.levels, base.n_drives, 3, 6
+    xd = 2 * d * d
+    lay = po.Layout(d=d, m=m, N=N, z_dim=M * xd + 2 + m, x_off=0, u_off=M * xd + 2, dt_off=M * xd)
+    Z = 0.2 * rng.standard_normal((N, lay.z_dim))
+    Z[:, lay.dt_off] = 0.1 + 0.05 * rng.random(N)
+    osys = [po.System(base.H_drift + 0.01 * i * np.diag(np.arange(d)).astype(complex), base.H_drives, base.drive_bounds) for i in range(M)]
+    psys = [pa.QuantumSystem(s.H_drift, s.H_drives, [b[1] for b in s.drive_bounds]) for s in osys]
+    traj = traj_from_Z(pa, Z, lay, n_members=M)
+    B = pa.BilinearIntegrator(psys, traj)
+    Zd = torch.from_numpy(traj.datavec).cuda()
+    dd = torch.empty(B.dim, dtype=torch.float64, device="cuda")
+    vd = torch.empty(B.ctx.jac_nnz, dtype=torch.float64, device="cuda")
+    B.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    B.ctx.eval_jac_dev(Zd, dd, vd)
+    phi, gu, gdt = pd.constraint_merit_and_shared_gradient(dd, vd, M, lay.K, d, m)
+    phi, gu, gdt = pd.reduce_merit_and_gradient(phi, gu, gdt, None)
+
+    def merit(Zp):
+        return sum(0.5 * (po.pade_residual(Zp, lay, s.G_drift, np.array(s.G_drives), 4, x_off=i * xd) ** 2).sum() for i, s in enumerate(osys))
+
+    assert abs(float(phi) - merit(Z)) < 1e-12 * max(1.0, merit(Z))
+    eps = 1e-6
+    for (k, l) in [(0, 0), (3, 2), (lay.K - 1, m - 1)]:
+        Zp, Zm = Z.copy(), Z.copy()
+        Zp[k, lay.u_off + l] += eps
+        Zm[k, lay.u_off + l] -= eps
+        assert abs((merit(Zp) - merit(Zm)) / (2 * eps) - float(gu[k, l])) < 1e-6
+    Zp, Zm = Z.copy(), Z.copy()
+    Zp[2, lay.dt_off] += eps
+    Zm[2, lay.dt_off] -= eps
+    assert abs((merit(Zp) - merit(Zm)) / (2 * eps) - float(gdt[2])) < 1e-6
+    B.close()
+
+
+def test_phase_timing_debug_hook():
+    """The profiling hook returns monotone cycle stamps and does not change results."""
+    import ctypes
+
+    so = po.config_system(3)
+    Z, lay = po.synthetic_trajectory(so, 12, seed=5)
+    c = make_ctx(lay, so.G_drift, np.array(so.G_drives))
+    ref = c.eval_jac(Z)
+    c.set_option("kernel_version", 3)
+    c.set_option("debug_timing", 1)
+    got = c.eval_jac(Z)
+    close(got[0], ref[0])
+    close(got[1], ref[1])
+    out = (ctypes.c_int64 * 64)()
+    c._chk(c._L.pcl_debug_timing(c._h, out, 64))
+    t = np.array(out[:])
+    t = t[t > 0]
+    assert (np.diff(t) > 0).all()
+    c.close()
