@@ -158,7 +158,7 @@ def main():
         "unit": "GB/s",
         "frac": abytes * B / kernel_s / 1e9 / HBM_PEAK_GBS,
         "traffic": None,
-        "kernel": "pcl_fused_kernel_v2<true,1> (persistent; 2 workgroups/CU; 4 MFMA waves + 4 store-stream waves each)",
+        "kernel": "pcl_fused_kernel_v2<true,1,27,6,3> (persistent; 2 workgroups/CU; 4 MFMA waves + 4 store-stream waves each)",
         "kernel_us": kernel_s * 1e6,
         "algorithmic_bytes_per_launch": abytes * B,
     }

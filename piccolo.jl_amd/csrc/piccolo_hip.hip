@@ -57,8 +57,6 @@ struct KParams {
     const unsigned char *uell_l;  // per union entry: up to uell_w (drive index, value) pairs, zero padded
     const double *uell_v;
     int uell_w;
-    int stagger;     // v2: s_memtime ticks by which the second resident workgroup of a CU delays its start
-    int n_cu;        // CUs on the device
     long long *dbg;  // optional: cycle stamps of workgroup 0 / matrix wave 0 (option debug_timing)
     int ncw;      // v3: state columns per matrix-wave chunk ((2+m)*ncw <= 16)
     int tab_lds;  // v3: union / ELL tables staged in LDS
@@ -444,10 +442,12 @@ __device__ __forceinline__ void wave_phase2_fused(const double *G, const double 
 // thread a fixed row (tid % n) and walk columns: no integer division inside the item loop.
 #define PCL_NUE2 2  // union-pattern entries per thread held in registers (REG path: n_upos <= 1024)
 
-template <bool JAC, int WU>  // WU: (drive,value) pairs per pattern entry held in registers; -1: general (tables in memory)
+// TD/TM/TNC: compile-time Hilbert dimension, drive count and slice width (0 = run-time values).  With the shape fixed
+// every LDS offset, trip count and divisor is a constant: the specialised instances need far fewer scalar registers.
+template <bool JAC, int WU, int TD, int TM, int TNC>  // WU: (drive,value) pairs per pattern entry in registers; -1: general
 __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
     extern __shared__ double lds[];
-    const int n = p.n, d = p.d, m = p.m, LD = p.LD, nc = p.nc;
+    const int d = TD ? TD : p.d, n = 2 * d, m = TD ? TM : p.m, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD, nc = TNC ? TNC : p.nc;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const bool matrix_wave = wave < 4;
@@ -539,13 +539,6 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
     if ((int)blockIdx.x < n_items) {
         request(blockIdx.x);
         if (tid <= m) us[tid] = pf_v;
-    }
-    // Two workgroups share a CU.  Started together they would run their phases in lockstep (both in the
-    // compute phases, then both in the store phase); delaying the second one by about half an item makes
-    // one of them stream while the other computes.
-    if (p.stagger > 0 && (int)blockIdx.x >= p.n_cu) {
-        const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-        while ((long long)__builtin_amdgcn_s_memtime() - t0 < p.stagger) __builtin_amdgcn_s_sleep(32);
     }
     __syncthreads();  // G = drift, tables staged, us[0] valid
 
@@ -741,6 +734,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 #define PCL_NSP 8   // B^{+-} value pairs per stream thread: (n*n/2) / 256 <= 8 for n <= 64
 #define PCL_MAXRT 4 // 16-row tiles of an n <= 64 operand
 #define PCL_MREG 8  // drives whose ELL row is held in registers (EW > 0 variants)
+#define PCL_PFC 4   // chunks per matrix wave whose state inputs are fetched at the top of the item (registers)
+#define PCL_PFW 2   // ... for chunk widths up to this many columns (wider chunks load at use)
 
 struct V3Tables {  // launch-invariant tables, in LDS when they fit (else in memory)
     const double *unv;          // [n_upos*uw] drive coefficients of the union pattern
@@ -751,15 +746,17 @@ struct V3Tables {  // launch-invariant tables, in LDS when they fit (else in mem
     const unsigned short *ellc;
 };
 
-template <int EW>  // ELL width held in registers for m <= PCL_MREG drives (0: general, tables in LDS / memory)
+// EW: ELL width held in registers for m <= PCL_MREG drives (0: general, tables in LDS / memory).
+// TD/TM/TNCW: compile-time Hilbert dimension, drive count, chunk width (0 = run-time values).
+template <int EW, int TD, int TM, int TNCW>
 __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     extern __shared__ double lds[];
-    const int n = p.n, d = p.d, m = p.m, LD = p.LD;
+    const int d = TD ? TD : p.d, n = 2 * d, m = TD ? TM : p.m, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int nn = n * n;
     const int ew = p.ell_w, uw = p.uell_w, n_ell = m * n * ew, n_un = p.n_upos;
-    const int ncw = p.ncw;             // state columns per chunk
+    const int ncw = TNCW ? TNCW : p.ncw;  // state columns per chunk
     const int colsw = (2 + m) * ncw;   // operand columns per chunk
     const int CW = 16;                 // one 16-column operand tile per chunk (host guarantees colsw <= 16)
     const long long xd = (long long)n * d;
@@ -840,13 +837,12 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
         }
 
         // G(u) on the union pattern + this wave's share of the G^2 tiles, for item `it`, into buffer `buf`
-        auto build = [&](int it, int buf) {
+        auto build = [&](int it, int buf, double u_lane) {
             int s, k, b;
             decode(it, s, k, b);
-            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
             double *G = Gb + buf * tile, *G2 = G2b + buf * tile;
             double *usn = us + (it % 3) * (m + 1);
-            if (lane <= m) usn[lane] = zk[lane < m ? p.u_off + lane : p.dt_off];  // every wave: identical values
+            if (lane <= m) usn[lane] = u_lane;  // every wave: identical values
             wave_lds_sync();
             const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
             if (p.g0_batch_stride)  // per-member drift: the whole tile changes with b
@@ -926,7 +922,12 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             }
         };
 
-        if (n_my > 0) build(0, 0);
+        if (n_my > 0) {
+            int s0, k0, b0;
+            decode(0, s0, k0, b0);
+            const double *z0 = p.Z + (long long)b0 * p.z_batch_stride + (long long)k0 * p.z_dim;
+            build(0, 0, lane <= m ? z0[lane < m ? p.u_off + lane : p.dt_off] : 0.0);
+        }
         __syncthreads();  // item 0's G, G^2 complete
 
         for (int it = 0; it < n_my; ++it) {
@@ -951,21 +952,60 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
         if (p.dbg && blockIdx.x == 0 && wave == 0 && lane == 0 && it == 1 && stamp < 60) p.dbg[stamp++] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
             PCL_STAMP();
-            for (int ch = wave; ch < nchunk && !(p.ablate & 4); ch += 4) {
+            // All global reads of this item are issued here, before the wave has any of the item's stores in flight:
+            // a later load would sit behind them in the CU's saturated memory pipeline (and vmcnt is in-order).
+            const bool pf = ncw <= PCL_PFW;
+            double pxn[PCL_PFC][PCL_PFW], pxc[PCL_PFC][PCL_PFW];
+            if (pf && lane < n && !(p.ablate & 4)) {
+#pragma unroll
+                for (int t = 0; t < PCL_PFC; ++t)
+#pragma unroll
+                    for (int c = 0; c < PCL_PFW; ++c) {
+                        const int col = c0 + (wave + 4 * t) * ncw + c;
+                        pxn[t][c] = pxc[t][c] = 0.0;
+                        if (c < ncw && col < c0 + nce) {
+                            const long long o = x_off + (long long)col * n + lane;
+                            pxn[t][c] = zn[o];
+                            pxc[t][c] = zk[o];
+                        }
+                    }
+            }
+            double pf_u = 0.0;  // next item's u_k / dt_k (consumed by build)
+            if (it + 1 < n_my && lane <= m) {
+                int s2, k2, b2;
+                decode(it + 1, s2, k2, b2);
+                const double *zk2 = p.Z + (long long)b2 * p.z_batch_stride + (long long)k2 * p.z_dim;
+                pf_u = zk2[lane < m ? p.u_off + lane : p.dt_off];
+            }
+            int tch = 0;
+            for (int ch = wave; ch < nchunk && !(p.ablate & 4); ch += 4, ++tch) {
                 const int cc0 = c0 + ch * ncw;             // first state column of the chunk
                 const int ncc = min(ncw, c0 + nce - cc0);  // columns in this chunk
                 // ---- M = [S | D | G_l D]   (lane = row) -----------------------------------------------------
                 if (lane < n) {
-                    for (int c = 0; c < ncw; ++c) {
-                        double xs = 0.0, xdv = 0.0;
-                        if (c < ncc) {
-                            const long long o = x_off + (long long)(cc0 + c) * n + lane;
-                            const double xn = zn[o], xc = zk[o];
-                            xs = xn + xc;
-                            xdv = xn - xc;
+                    if (pf && tch < PCL_PFC) {
+#pragma unroll
+                        for (int t = 0; t < PCL_PFC; ++t)
+                            if (t == tch) {
+#pragma unroll
+                                for (int c = 0; c < PCL_PFW; ++c)
+                                    if (c < ncw) {
+                                        Mw[lane + LD * c] = pxn[t][c] + pxc[t][c];
+                                        Mw[lane + LD * (ncw + c)] = pxn[t][c] - pxc[t][c];
+                                    }
+                            }
+                    } else {
+                        for (int c = 0; c < ncw; ++c) {
+                            double xs = 0.0, xdv = 0.0;
+                            if (c < ncc) {
+                                const long long o = x_off + (long long)(cc0 + c) * n + lane;
+                                const double xn = zn[o], xc = zk[o];
+                                xs = xn + xc;
+                                xdv = xn - xc;
+                            }
+                            Mw[lane + LD * c] = xs;
+                            Mw[lane + LD * (ncw + c)] = xdv;
                         }
-                        Mw[lane + LD * c] = xs;
-                        Mw[lane + LD * (ncw + c)] = xdv;
                     }
                     for (int c = colsw; c < CW; ++c) Mw[lane + LD * c] = 0.0;
                 }
@@ -1071,29 +1111,29 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                 }
                 wave_lds_sync();
                 PCL_STAMP();  // MFMA + accumulators -> LDS done
-                // ---- outputs (lane = row; consecutive lanes -> consecutive addresses) -------------------------------
+                // ---- outputs: finish in LDS (lane = row, in place), then 16-byte stores --------------------------------
+                // in place: delta -> D column, d/ddt -> GS column, d/du_l -> the G (G_l D) column
                 if (lane < n) {
-                    for (int c = 0; c < ncc; ++c) {
-                        const long long rr = (long long)(cc0 + c) * n + lane;
+                    for (int c = 0; c < ncw; ++c) {
                         const double gs = GSw[lane + LD * c], g2d = G2Dw[lane + LD * c];
-                        if (p.delta) p.delta[bk * xd + rr] = Mw[lane + LD * (ncw + c)] - c1 * gs + c2 * g2d;
-                        jh[rr] = -0.5 * gs + h6 * g2d;
+                        G2Dw[lane + LD * c] = Mw[lane + LD * (ncw + c)] - c1 * gs + c2 * g2d;  // delta
+                        GSw[lane + LD * c] = -0.5 * gs + h6 * g2d;                                // d/ddt
                     }
                     // d/du_l = G_l (-c1 S + c2 G D) + c2 G (G_l D)
                     if (EW > 0) {
 #pragma unroll
                         for (int l = 0; l < PCL_MREG; ++l)
                             if (l < m)
-                                for (int c = 0; c < ncc; ++c) {
+                                for (int c = 0; c < ncw; ++c) {
                                     double acc = 0.0;
 #pragma unroll
                                     for (int q = 0; q < (EW > 0 ? EW : 1); ++q)
                                         acc += er_v[l][q] * (-c1 * Mw[er_c[l][q] + LD * c] + c2 * GDw[er_c[l][q] + LD * c]);
-                                    ju[(long long)l * xd + (long long)(cc0 + c) * n + lane] = acc + c2 * Mw[lane + LD * (2 * ncw + l * ncw + c)];
+                                    Mw[lane + LD * (2 * ncw + l * ncw + c)] = acc + c2 * Mw[lane + LD * (2 * ncw + l * ncw + c)];
                                 }
                     } else {
                         for (int l = 0; l < m; ++l)
-                            for (int c = 0; c < ncc; ++c) {
+                            for (int c = 0; c < ncw; ++c) {
                                 const int base = (l * n + lane) * ew;
                                 double acc = 0.0;
                                 for (int q = 0; q < ew; ++q) {
@@ -1101,15 +1141,31 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                                     const double ev = p.tab_lds ? t_ellv[base + q] : p.ell_val[base + q];
                                     acc += ev * (-c1 * Mw[col + LD * c] + c2 * GDw[col + LD * c]);
                                 }
-                                ju[(long long)l * xd + (long long)(cc0 + c) * n + lane] = acc + c2 * Mw[lane + LD * (2 * ncw + l * ncw + c)];
+                                Mw[lane + LD * (2 * ncw + l * ncw + c)] = acc + c2 * Mw[lane + LD * (2 * ncw + l * ncw + c)];
                             }
+                    }
+                }
+                wave_lds_sync();
+                // the chunk's columns are contiguous in every output vector: element e = c*n + row, two per lane
+                {
+                    const int hn2 = n >> 1;
+                    const long long o0 = (long long)cc0 * n;
+                    for (int e2 = lane; e2 < ((p.ablate & 32) ? 0 : ncc * hn2); e2 += 64) {
+                        const int c = e2 / hn2, r0 = 2 * (e2 - c * hn2);
+                        const long long o = o0 + (long long)c * n + r0;
+                        if (p.delta) store2(p.delta + bk * xd + o, G2Dw[r0 + LD * c], G2Dw[r0 + 1 + LD * c], false);
+                        store2(jh + o, GSw[r0 + LD * c], GSw[r0 + 1 + LD * c], false);
+                        for (int l = 0; l < m; ++l) {
+                            const double *src = Mw + LD * (2 * ncw + l * ncw + c) + r0;
+                            store2(ju + (long long)l * xd + o, src[0], src[1], false);
+                        }
                     }
                 }
                 wave_lds_sync();  // the chunk buffers are rewritten by this wave's next chunk
                 PCL_STAMP();  // outputs issued
             }
             // ---- next item's G(u), G^2 into the other buffer ----------------------------------------------------
-            if (it + 1 < n_my) build(it + 1, cur ^ 1);
+            if (it + 1 < n_my) build(it + 1, cur ^ 1, pf_u);
             PCL_STAMP();  // next G, G^2 built
             __syncthreads();  // item boundary
             PCL_STAMP();  // barrier passed
@@ -1366,9 +1422,10 @@ struct pcl_ctx {
     // options
     int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_ablate = 0, opt_kernel = 2;
     long long *ddbg = nullptr;
-    int64_t opt_stagger = 0;
+    int64_t opt_specialize = 1;
     int64_t opt_grid = 0;  // 0: resident workgroups (persistent kernel)
-    size_t lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // last MaxDynamicSharedMemorySize set per kernel variant
+    size_t lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const void *lds_kern[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // last MaxDynamicSharedMemorySize set per kernel variant
     int max_lds = 0;
     int n_cu = 0;
     mutable std::string err;
@@ -1768,8 +1825,6 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.nt = (int)ctx->opt_nt;
     p.ablate = (int)ctx->opt_ablate;
     p.dbg = ctx->ddbg;
-    p.stagger = (int)ctx->opt_stagger;
-    p.n_cu = ctx->n_cu;
     p.hess_per = hess_per(ctx);
 }
 
@@ -1865,7 +1920,8 @@ static int choose_cols_v3(const pcl_ctx *ctx) {
 }
 
 static int set_lds_attr(pcl_ctx *ctx, const void *kern, int slot, size_t lds) {
-    if (ctx->lds_set[slot] == lds) return PCL_OK;
+    if (ctx->lds_set[slot] == lds && ctx->lds_kern[slot] == kern) return PCL_OK;
+    ctx->lds_kern[slot] = kern;
     HIP_TRY(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ctx->lds_set[slot] = lds;
     return PCL_OK;
@@ -1897,7 +1953,9 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
         typedef void (*kern3_t)(const KParams);
         const int ewr = (p.m <= 8 && ctx->ell_w >= 1 && ctx->ell_w <= 2) ? ctx->ell_w : 0;
-        kern3_t kern3 = ewr == 1 ? (kern3_t)pcl_fused_kernel_v3<1> : ewr == 2 ? (kern3_t)pcl_fused_kernel_v3<2> : (kern3_t)pcl_fused_kernel_v3<0>;
+        kern3_t kern3 = ewr == 1 ? (kern3_t)pcl_fused_kernel_v3<1, 0, 0, 0> : ewr == 2 ? (kern3_t)pcl_fused_kernel_v3<2, 0, 0, 0> : (kern3_t)pcl_fused_kernel_v3<0, 0, 0, 0>;
+        // shape-specialised instance (BASELINE config 3/4/5: d = 27, six drives with two entries per row, 2-column chunks)
+        if (ewr == 2 && p.d == 27 && p.m == 6 && p.ncw == 2 && ctx->opt_specialize) kern3 = (kern3_t)pcl_fused_kernel_v3<2, 27, 6, 2>;
         int rc = set_lds_attr(ctx, (const void *)kern3, 6, lds3);
         if (rc != PCL_OK) return rc;
         const long long g3 = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, items) : std::min<long long>(items, std::max(ctx->n_cu, 1));
@@ -1921,8 +1979,10 @@ not_v3:
     if (v2) {
         typedef void (*kern_t)(const KParams);
         const int wu = (ctx->uell_w <= 2 && ctx->n_upos <= 1024 && !ctx->desc.per_member_G0) ? ctx->uell_w : -1;
-        kern_t kern = want_jac ? (wu == 1 ? (kern_t)pcl_fused_kernel_v2<true, 1> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<true, 2> : (kern_t)pcl_fused_kernel_v2<true, -1>)
-                               : (wu == 1 ? (kern_t)pcl_fused_kernel_v2<false, 1> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<false, 2> : (kern_t)pcl_fused_kernel_v2<false, -1>);
+        kern_t kern = want_jac ? (wu == 1 ? (kern_t)pcl_fused_kernel_v2<true, 1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<true, 2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v2<true, -1, 0, 0, 0>)
+                               : (wu == 1 ? (kern_t)pcl_fused_kernel_v2<false, 1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<false, 2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v2<false, -1, 0, 0, 0>);
+        // shape-specialised instance (BASELINE config 3/4/5: three 3-level transmons, d = 27, six drives, 3-column slices)
+        if (want_jac && wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize) kern = (kern_t)pcl_fused_kernel_v2<true, 1, 27, 6, 3>;
         int rc = set_lds_attr(ctx, (const void *)kern, want_jac ? 4 : 5, lds);  // wu is fixed per context
         if (rc != PCL_OK) return rc;
         // persistent grid: as many workgroups as are resident at once
@@ -2087,8 +2147,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_ablate = v;
     else if (!strcmp(key, "grid"))
         ctx->opt_grid = v;
-    else if (!strcmp(key, "stagger"))
-        ctx->opt_stagger = v;
+    else if (!strcmp(key, "specialize"))  // 0: always the run-time-shape kernel instances
+        ctx->opt_specialize = v != 0;
     else if (!strcmp(key, "debug_timing")) {  // profiling aid: cycle stamps of workgroup 0 (pcl_debug_timing reads them)
         if (v && !ctx->ddbg) {
             HIP_TRY(ctx, hipMalloc((void **)&ctx->ddbg, 64 * sizeof(long long)));
@@ -2134,8 +2194,8 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         p.nc = choose_cols_per_slice(ctx, true);
         const size_t lds = fused2_lds_bytes(p, true, ell_fits_lds(ctx));
         int nb = 0;
-        (void)hipFuncSetAttribute((const void *)pcl_fused_kernel_v2<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pcl_fused_kernel_v2<true, 1>, 512, lds) != hipSuccess) nb = -1;
+        (void)hipFuncSetAttribute((const void *)pcl_fused_kernel_v2<true, 1, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pcl_fused_kernel_v2<true, 1, 0, 0, 0>, 512, lds) != hipSuccess) nb = -1;
         *v = nb * 1000000LL + (long long)lds;
     }
     else if (!strcmp(key, "iso_structured"))

@@ -13,7 +13,7 @@ system = synthetic.config_system(3)
 trajs = [synthetic.synthetic_trajectory(system, 100, seed=1000 + i) for i in range(B)]
 ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], B)
 c = ms.ctx
-c.set_option("cols_per_slice", nc); c.set_option("debug_timing", 1); c.set_option("debug_ablate", ab)
+c.set_option("kernel_version", 3); c.set_option("cols_per_slice", nc); c.set_option("debug_timing", 1); c.set_option("debug_ablate", ab)
 Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()
 dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda"); vd = torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")
 c.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -240,9 +240,11 @@ def test_config3_full_size_vs_c_oracle(config3_full):
     assert c.jac_per == 167670 and c.jac_nnz == 16599330 and c.hess_per == 20440
     for variant in VARIANTS:
         set_variant(c, variant)
-        delta, vals = c.eval_jac(Z)
-        close(delta, d_ref)
-        close(vals, j_ref)
+        for spec in (1, 0):  # shape-specialised (d=27, m=6) and run-time-shape instances of the same kernel
+            c.set_option("specialize", spec)
+            delta, vals = c.eval_jac(Z)
+            close(delta, d_ref)
+            close(vals, j_ref)
     mu = np.random.default_rng(9).standard_normal((lay.K, lay.x_dim))
     close(c.hess(Z, mu), ref_lib.hess(Z, mu, lay, G0, Gj), 1e-11)
     c.close()
