@@ -148,6 +148,19 @@ int pcl_jac_compact_nnz(const pcl_ctx *ctx, int64_t *nnz, int64_t *nnz_per_inter
 int pcl_eval_jac_compact_dev(pcl_ctx *ctx, const double *Z_dev, double *delta_dev, double *compact_dev);
 int pcl_jac_expand_dev(pcl_ctx *ctx, const double *compact_dev, double *vals_dev);
 
+/* DerivativeIntegrator / time-consistency rows sharing the context's trajectory layout ------
+ *   DerivativeIntegrator(x, dx):  x_{k+1} - x_k - dt_k dx_k = 0      src/control/templates/smooth_pulse_problem.jl:267-275
+ *   TimeConsistencyConstraint  :  t_{k+1} - t_k - dt_k      = 0      smooth_pulse_problem.jl:277   (pass dx_off = -1)
+ * x_off / dx_off: 0-based component offsets inside a knot, dim: component length.  rows = K*dim (x batch in TRAJ mode),
+ * row k*dim + r.  Values per interval: [d/dx_k = -1 (dim) | d/dx_{k+1} = +1 (dim) | d/ddx_k = -dt_k (dim; absent when
+ * dx_off < 0) | d/ddt_k = -dx_k[r] (dim)]; order reported by pcl_deriv_structure.  In MEMBERS mode the rows are those of
+ * the one shared trajectory (not replicated per member). */
+int pcl_deriv_nnz(const pcl_ctx *ctx, int32_t dx_off, int32_t dim, int64_t *n_rows, int64_t *nnz);
+int pcl_deriv_structure(const pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim, int64_t *rows, int64_t *cols);
+int pcl_deriv_eval_jac(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim, const double *Z, double *delta, double *vals);
+int pcl_deriv_eval_jac_dev(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim, const double *Z_dev, double *delta_dev,
+                           double *vals_dev);
+
 /* tuning / introspection ---------------------------------------------------- */
 /* key: "cols_per_slice" (state columns per workgroup; 0 = heuristic), "use_mfma" (1/0), "nt_stores" (1/0). */
 int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t value);

@@ -603,6 +603,33 @@ def derivative_residual(Z, off_x, off_dx, m, dt_off):
     return Z[1:, off_x : off_x + m] - Z[:-1, off_x : off_x + m] - Z[:-1, dt_off : dt_off + 1] * Z[:-1, off_dx : off_dx + m]
 
 
+def derivative_jacobian(Z, z_dim, off_x, off_dx, m, dt_off, index_base=0):
+    """Triplets of the rows above in the library's order: per interval [-1 | +1 | -dt_k | -dx_k]
+    (off_dx < 0: time consistency, dx == 1, segments [-1 | +1 | -1])."""
+    N = Z.shape[0]
+    rows, cols, vals = [], [], []
+    r = np.arange(m)
+    for k in range(N - 1):
+        r0, v0 = k * m + index_base, k * z_dim + index_base
+        rows += [r0 + r, r0 + r]
+        cols += [v0 + off_x + r, v0 + z_dim + off_x + r]
+        vals += [-np.ones(m), np.ones(m)]
+        if off_dx >= 0:
+            rows += [r0 + r, r0 + r]
+            cols += [v0 + off_dx + r, np.full(m, v0 + dt_off)]
+            vals += [np.full(m, -Z[k, dt_off]), -Z[k, off_dx : off_dx + m]]
+        else:
+            rows += [r0 + r]
+            cols += [np.full(m, v0 + dt_off)]
+            vals += [-np.ones(m)]
+    return np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+
+
+def time_consistency_residual(Z, t_off, dt_off):
+    """t_{k+1} - t_k - dt_k  [REF smooth_pulse_problem.jl:277]"""
+    return (Z[1:, t_off] - Z[:-1, t_off] - Z[:-1, dt_off])[:, None]
+
+
 # --------------------------------------------------------------------------- #
 # Synthetic benchmark inputs (SURVEY section 8(d))
 # --------------------------------------------------------------------------- #

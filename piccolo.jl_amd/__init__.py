@@ -8,6 +8,7 @@ from . import _lib, distributed, integrators, quantum, synthetic, trajectory
 from ._lib import PclError, build_library
 from .integrators import (
     BilinearIntegrator,
+    DerivativeIntegrator,
     HipPadeIntegrator,
     HipPadeMultistart,
     eval_hessian_of_lagrangian,

@@ -1396,6 +1396,38 @@ __global__ __launch_bounds__(256) void pcl_hess_kernel(const KParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// DerivativeIntegrator rows  x_{k+1} - x_k - dt_k * dx_k  and the time-consistency row  t_{k+1} - t_k - dt_k
+// (dx_off < 0: dx == 1).  Trivially sparse; one thread per (b, k, r).  Values per (b,k): [-1 (dim) | +1 (dim) |
+// -dt_k (dim, absent for time consistency) | -dx_k[r] (dim)].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pcl_deriv_kernel(const double *__restrict__ Z, double *__restrict__ delta,
+                                                        double *__restrict__ vals, int K, int z_dim, int x_off, int dx_off,
+                                                        int dim, int dt_off, long long z_batch_stride, long long total) {
+    const int nseg = dx_off >= 0 ? 4 : 3;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(e % dim);
+        const long long bk = e / dim;
+        const int k = (int)(bk % K);
+        const long long b = bk / K;
+        const double *zk = Z + b * z_batch_stride + (long long)k * z_dim;
+        const double h = zk[dt_off];
+        const double dx = dx_off >= 0 ? zk[dx_off + r] : 1.0;
+        if (delta) delta[e] = zk[z_dim + x_off + r] - zk[x_off + r] - h * dx;
+        if (vals) {
+            double *v = vals + bk * (long long)nseg * dim;
+            v[r] = -1.0;
+            v[dim + r] = 1.0;
+            if (dx_off >= 0) {
+                v[2 * dim + r] = -h;
+                v[3 * dim + r] = -dx;
+            } else {
+                v[2 * dim + r] = -1.0;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_create_error;
@@ -2131,6 +2163,80 @@ extern "C" int pcl_hess(pcl_ctx *ctx, const double *Z, const double *mu, double 
     HIP_TRY(ctx, hipMemcpyAsync(vals, ctx->dhess, nv * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PCL_OK;
+}
+
+// --- DerivativeIntegrator / time-consistency rows ---------------------------
+static int deriv_check(const pcl_ctx *ctx, int x_off, int dx_off, int dim) {
+    const int zd = ctx->desc.z_dim;
+    if (dim < 1 || x_off < 0 || x_off + dim > zd || (dx_off >= 0 && dx_off + dim > zd))
+        return fail(ctx, PCL_EINVAL, "derivative rows: components outside the knot (x_off=%d dx_off=%d dim=%d z_dim=%d)", x_off, dx_off, dim, zd);
+    return PCL_OK;
+}
+extern "C" int pcl_deriv_nnz(const pcl_ctx *ctx, int32_t dx_off, int32_t dim, int64_t *rows, int64_t *nnz) {
+    if (!ctx) return PCL_EINVAL;
+    const long long nb = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? ctx->desc.batch : 1;
+    if (rows) *rows = nb * ctx->K * dim;
+    if (nnz) *nnz = nb * ctx->K * dim * (dx_off >= 0 ? 4 : 3);
+    return PCL_OK;
+}
+extern "C" int pcl_deriv_structure(const pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim, int64_t *rows, int64_t *cols) {
+    if (!ctx) return PCL_EINVAL;
+    if (!rows || !cols) return fail(ctx, PCL_EINVAL, "pcl_deriv_structure: NULL output");
+    TRY(deriv_check(ctx, x_off, dx_off, dim));
+    const pcl_desc &D = ctx->desc;
+    const long long nb = D.batch_mode == PCL_BATCH_TRAJ ? D.batch : 1, zd = D.z_dim, base = D.index_base;
+    const int nseg = dx_off >= 0 ? 4 : 3;
+    long long p = 0;
+    for (long long b = 0; b < nb; ++b)
+        for (long long k = 0; k < ctx->K; ++k) {
+            const long long v0 = b * zd * D.N + k * zd + base, r0 = (b * ctx->K + k) * dim + base;
+            for (int seg = 0; seg < nseg; ++seg)
+                for (long long r = 0; r < dim; ++r, ++p) {
+                    rows[p] = r0 + r;
+                    cols[p] = seg == 0 ? v0 + x_off + r : seg == 1 ? v0 + zd + x_off + r : (seg == 2 && dx_off >= 0) ? v0 + dx_off + r : v0 + D.dt_off;
+                }
+        }
+    return PCL_OK;
+}
+extern "C" int pcl_deriv_eval_jac_dev(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim, const double *Z, double *delta,
+                                      double *vals) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || (!delta && !vals)) return fail(ctx, PCL_EINVAL, "pcl_deriv_eval_jac_dev: NULL pointer");
+    TRY(deriv_check(ctx, x_off, dx_off, dim));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const pcl_desc &D = ctx->desc;
+    const long long nb = D.batch_mode == PCL_BATCH_TRAJ ? D.batch : 1;
+    const long long total = nb * ctx->K * dim;
+    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(pcl_deriv_kernel, dim3(grid), dim3(256), 0, ctx->stream, Z, delta, vals, ctx->K, D.z_dim, x_off, dx_off, dim,
+                       D.dt_off, D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0LL, total);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCL_OK;
+}
+extern "C" int pcl_deriv_eval_jac(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim, const double *Z, double *delta, double *vals) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || (!delta && !vals)) return fail(ctx, PCL_EINVAL, "pcl_deriv_eval_jac: NULL pointer");
+    TRY(deriv_check(ctx, x_off, dx_off, dim));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int64_t nr = 0, nz = 0;
+    pcl_deriv_nnz(ctx, dx_off, dim, &nr, &nz);
+    double *dd = nullptr, *dv = nullptr;
+    TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
+    HIP_TRY(ctx, hipMalloc((void **)&dd, (size_t)nr * sizeof(double)));
+    if (hipMalloc((void **)&dv, (size_t)nz * sizeof(double)) != hipSuccess) {
+        (void)hipFree(dd);
+        return fail(ctx, PCL_ENOMEM, "pcl_deriv_eval_jac: device allocation failed");
+    }
+    int rc = PCL_OK;
+    if (hipMemcpyAsync(ctx->dZ, Z, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = PCL_EHIP;
+    if (rc == PCL_OK) rc = pcl_deriv_eval_jac_dev(ctx, x_off, dx_off, dim, ctx->dZ, dd, dv);
+    if (rc == PCL_OK && delta && hipMemcpyAsync(delta, dd, (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = PCL_EHIP;
+    if (rc == PCL_OK && vals && hipMemcpyAsync(vals, dv, (size_t)nz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = PCL_EHIP;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == PCL_OK) rc = PCL_EHIP;
+    (void)hipFree(dd);
+    (void)hipFree(dv);
+    if (rc == PCL_EHIP) return fail(ctx, PCL_EHIP, "pcl_deriv_eval_jac: HIP error %s", hipGetErrorString(hipGetLastError()));
+    return rc;
 }
 
 // --- options ---------------------------------------------------------------------------------

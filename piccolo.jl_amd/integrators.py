@@ -24,7 +24,7 @@ from ._lib import PCL_BATCH_MEMBERS, PCL_BATCH_TRAJ, PclError
 from .trajectory import STATE, TIMESTEP, NamedTrajectory
 
 __all__ = [
-    "HipPadeIntegrator", "HipPadeMultistart", "BilinearIntegrator", "evaluate_", "eval_jacobian",
+    "HipPadeIntegrator", "HipPadeMultistart", "DerivativeIntegrator", "BilinearIntegrator", "evaluate_", "eval_jacobian",
     "jacobian_structure", "hessian_structure", "eval_hessian_of_lagrangian", "PclError",
 ]  # fmt: skip
 
@@ -189,6 +189,29 @@ class _PclContext:
     def hess_dev(self, Z, mu, vals):
         self._chk(self._L.pcl_hess_dev(self._h, _ptr(Z), _ptr(mu), _ptr(vals)))
 
+    # -- DerivativeIntegrator / time-consistency rows on this context's trajectory layout -----------------
+    def deriv_dims(self, dx_off, dim):
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        self._chk(self._L.pcl_deriv_nnz(self._h, dx_off, dim, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def deriv_structure(self, x_off, dx_off, dim):
+        _, nnz = self.deriv_dims(dx_off, dim)
+        rows, cols = np.empty(nnz, np.int64), np.empty(nnz, np.int64)
+        p = ctypes.POINTER(ctypes.c_int64)
+        self._chk(self._L.pcl_deriv_structure(self._h, x_off, dx_off, dim, rows.ctypes.data_as(p), cols.ctypes.data_as(p)))
+        return rows, cols
+
+    def deriv_eval_jac(self, x_off, dx_off, dim, Z):
+        Z = self._z(Z)
+        nr, nnz = self.deriv_dims(dx_off, dim)
+        delta, vals = np.empty(nr), np.empty(nnz)
+        self._chk(self._L.pcl_deriv_eval_jac(self._h, x_off, dx_off, dim, _ptr(Z), _ptr(delta), _ptr(vals)))
+        return delta, vals
+
+    def deriv_eval_jac_dev(self, x_off, dx_off, dim, Z, delta, vals):
+        self._chk(self._L.pcl_deriv_eval_jac_dev(self._h, x_off, dx_off, dim, _ptr(Z), _ptr(delta), _ptr(vals)))
+
     def set_option(self, key, value):
         self._chk(self._L.pcl_set_option(self._h, key.encode(), int(value)))
 
@@ -293,6 +316,48 @@ class HipPadeMultistart:
 
     def close(self):
         self._ctx.close()
+
+
+class DerivativeIntegrator:
+    """``DerivativeIntegrator(x, dx, traj)``: rows ``x_{k+1} - x_k - dt_k dx_k`` of the problem templates' integrator
+    list ``[dynamics, DerivativeIntegrator(u, du), DerivativeIntegrator(du, ddu)]``
+    [REF src/control/templates/smooth_pulse_problem.jl:264-275].  ``dx_name=None`` gives the time-consistency rows
+    ``t_{k+1} - t_k - dt_k`` [REF :277].  Evaluated on the GPU through the dynamics integrator's context (same
+    trajectory layout, same stream)."""
+
+    def __init__(self, x_name, dx_name, traj, like):
+        self._ctx = like.ctx
+        self._sig = (traj.dim, traj.N)
+        self.x_name, self.dx_name = x_name, dx_name
+        self.x_off = traj.components[x_name].start
+        self.dx_off = -1 if dx_name is None else traj.components[dx_name].start
+        self.x_dim = len(traj.components[x_name])
+        if dx_name is not None and len(traj.components[dx_name]) != self.x_dim:
+            raise ValueError("components %r and %r differ in length" % (x_name, dx_name))
+        self.dim, self.nnz = self._ctx.deriv_dims(self.dx_off, self.x_dim)
+
+    @property
+    def ctx(self):
+        return self
+
+    def _check(self, traj):
+        if (traj.dim, traj.N) != self._sig:
+            raise ValueError("trajectory shape differs from the one this integrator was built for")
+
+    # the generic functions below dispatch on these three
+    def eval(self, Z, delta=None):
+        d, _ = self._ctx.deriv_eval_jac(self.x_off, self.dx_off, self.x_dim, Z)
+        if delta is not None:
+            delta[:] = d
+            return delta
+        return d
+
+    def jac(self, Z):
+        return self._ctx.deriv_eval_jac(self.x_off, self.dx_off, self.x_dim, Z)[1]
+
+    def jac_structure(self, dtype=np.int64):
+        r, c = self._ctx.deriv_structure(self.x_off, self.dx_off, self.x_dim)
+        return r.astype(dtype), c.astype(dtype)
 
 
 # ---------------------------------------------------------------------------

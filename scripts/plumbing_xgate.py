@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[0] ("plumbing"): single-qubit X gate, T=50 knots, 4th-order Pade collocation, solved with a
+CPU NLP solver whose constraint callbacks (residual, sparse Jacobian, Hessian of the Lagrangian) are served by the GPU
+evaluator -- the shape of `solve!(SmoothPulseProblem(qtraj, N))` [REF src/control/templates/smooth_pulse_problem.jl:
+240-295, src/control/problems.jl:409-429] with scipy's trust-constr standing in for Ipopt (no Ipopt in the image).
+Constraint list = prob.integrators order: [dynamics, DerivativeIntegrator(u,du), DerivativeIntegrator(du,ddu)] + time
+consistency [REF smooth_pulse_problem.jl:264-277]."""
+import os
+import sys
+
+import numpy as np
+import scipy.linalg
+import scipy.sparse as sp
+from scipy.optimize import BFGS, Bounds, NonlinearConstraint, minimize
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import piccolo_jl_amd as pa
+from piccolo_jl_amd.objectives import unitary_fidelity_loss, unitary_infidelity
+
+
+def solve(N=50, T=10.0, Q=100.0, R=1e-2, seed=0, max_iter=300, verbose=0):
+    system = pa.QuantumSystem(0.5 * pa.PAULIS["Z"], [pa.PAULIS["X"], pa.PAULIS["Y"]], [1.0, 1.0])  # first_gate.jl:42-48
+    U_goal = pa.GATES["X"]
+    rng = np.random.default_rng(seed)
+    times = np.linspace(0, T, N)
+    u0 = 0.1 * rng.standard_normal((2, N))
+    u0[:, 0] = u0[:, -1] = 0.0
+    # rollout for the initial states (piecewise-constant exact propagation)
+    states, U = [], np.eye(2, dtype=complex)
+    for k in range(N):
+        states.append(U)
+        if k + 1 < N:
+            U = scipy.linalg.expm(-1j * (times[k + 1] - times[k]) * system.H(u0[:, k])) @ U
+    traj = pa.unitary_trajectory(system, u0, times, U_goal, states=states)
+    B = pa.BilinearIntegrator(system, traj)
+    rows = [B, pa.DerivativeIntegrator("u", "du", traj, like=B), pa.DerivativeIntegrator("du", "ddu", traj, like=B),
+            pa.DerivativeIntegrator("t", None, traj, like=B)]  # fmt: skip
+    nv = traj.dim * traj.N
+    structs = [pa.jacobian_structure(r) for r in rows]
+    offs = np.cumsum([0] + [r.dim for r in rows])
+    comp = traj.components
+    xN = slice((N - 1) * traj.dim + comp["Ũ⃗"].start, (N - 1) * traj.dim + comp["Ũ⃗"].stop)
+    reg_idx = np.concatenate([np.arange(k * traj.dim + comp[c].start, k * traj.dim + comp[c].stop) for k in range(N) for c in ("u", "du", "ddu")])
+
+    def cons(z):
+        traj.update(z)
+        return np.concatenate([pa.evaluate_(np.zeros(r.dim), r, traj) for r in rows])
+
+    def cons_jac(z):
+        traj.update(z)
+        mats = []
+        for r, (rr, cc), o in zip(rows, structs, offs):
+            mats.append(sp.csr_matrix((r.ctx.jac(traj.datavec), (rr, cc)), shape=(r.dim, nv)))
+        return sp.vstack(mats).tocsr()
+
+    def cons_hess(z, v):
+        traj.update(z)
+        H = pa.eval_hessian_of_lagrangian(B, traj, v[: B.dim])
+        # derivative rows: d^2/(d dt_k d dx_k[r]) = -1
+        ii, jj, vv = [], [], []
+        for r, o in zip(rows[1:3], offs[1:3]):
+            mu = v[o : o + r.dim].reshape(N - 1, r.x_dim)
+            for k in range(N - 1):
+                a = k * traj.dim + comp["Δt"].start
+                b = k * traj.dim + r.dx_off + np.arange(r.x_dim)
+                ii += [np.full(r.x_dim, a), b]
+                jj += [b, np.full(r.x_dim, a)]
+                vv += [-mu[k], -mu[k]]
+        return H + sp.csr_matrix((np.concatenate(vv), (np.concatenate(ii), np.concatenate(jj))), shape=(nv, nv))
+
+    def obj(z):
+        f, g = unitary_infidelity(z[xN], U_goal, Q)
+        grad = np.zeros(nv)
+        grad[xN] = g
+        grad[reg_idx] = R * z[reg_idx]
+        return f + 0.5 * R * float(z[reg_idx] @ z[reg_idx]), grad
+
+    lb, ub = np.full(nv, -np.inf), np.full(nv, np.inf)
+    for k in range(N):
+        o = k * traj.dim
+        lb[o + comp["Ũ⃗"].start : o + comp["Ũ⃗"].stop], ub[o + comp["Ũ⃗"].start : o + comp["Ũ⃗"].stop] = -1.0, 1.0
+        lb[o + comp["u"].start : o + comp["u"].stop], ub[o + comp["u"].start : o + comp["u"].stop] = -1.0, 1.0
+        lb[o + comp["ddu"].start : o + comp["ddu"].stop], ub[o + comp["ddu"].start : o + comp["ddu"].stop] = -2.0, 2.0
+        lb[o + comp["Δt"].start] = ub[o + comp["Δt"].start] = traj.datavec[o + comp["Δt"].start]  # timesteps_all_equal
+    z0 = traj.datavec.copy()
+    x1 = slice(comp["Ũ⃗"].start, comp["Ũ⃗"].stop)
+    lb[x1] = ub[x1] = z0[x1]  # initial condition
+    for k in (0, N - 1):  # u(0) = u(T) = 0
+        s = slice(k * traj.dim + comp["u"].start, k * traj.dim + comp["u"].stop)
+        lb[s] = ub[s] = 0.0
+    z0 = np.clip(z0, lb, ub)
+    nc_rows = int(offs[-1])
+    res = minimize(obj, z0, jac=True, method="trust-constr", hess=BFGS(), bounds=Bounds(lb, ub, keep_feasible=False),
+                   constraints=[NonlinearConstraint(cons, np.zeros(nc_rows), np.zeros(nc_rows), jac=cons_jac, hess=cons_hess)],
+                   options=dict(maxiter=max_iter, gtol=1e-8, xtol=1e-12, verbose=verbose, sparse_jacobian=True))  # fmt: skip
+    traj.update(res.x)
+    viol = np.abs(cons(res.x)).max()
+    fid = unitary_fidelity_loss(res.x[xN], U_goal)
+    B.close()
+    return dict(fidelity=float(fid), max_violation=float(viol), iterations=int(res.nit), n_vars=nv, n_rows=nc_rows, traj=traj)
+
+
+if __name__ == "__main__":
+    r = solve(verbose=1)
+    print({k: v for k, v in r.items() if k != "traj"})

@@ -230,3 +230,20 @@ def test_structure_counts_match_survey_table():
         assert po.jac_nnz_per_interval(lay) == jn and po.hess_nnz_per_interval(lay) == hn
         assert ref_lib.lib().pade_ref_jac_nnz_per_interval(lay.d, lay.m) == jn
         assert ref_lib.lib().pade_ref_hess_nnz_per_interval(lay.d, lay.m) == hn
+
+
+def test_derivative_rows_jacobian_finite_differences():
+    rng = np.random.default_rng(8)
+    N, z_dim, m = 5, 12, 3
+    Z = rng.standard_normal((N, z_dim))
+    off_x, off_dx, dt_off = 2, 6, 0
+    r, c, v = po.derivative_jacobian(Z, z_dim, off_x, off_dx, m, dt_off)
+    J = np.zeros(((N - 1) * m, N * z_dim))
+    np.add.at(J, (r, c), v)
+    f = lambda z: po.derivative_residual(z.reshape(N, z_dim), off_x, off_dx, m, dt_off).reshape(-1)
+    assert np.abs(J - _fd_jac(f, Z.reshape(-1).copy())).max() < 1e-8
+    r, c, v = po.derivative_jacobian(Z, z_dim, 1, -1, 1, dt_off)  # time consistency on component 1
+    J = np.zeros((N - 1, N * z_dim))
+    np.add.at(J, (r, c), v)
+    f = lambda z: po.time_consistency_residual(z.reshape(N, z_dim), 1, dt_off).reshape(-1)
+    assert np.abs(J - _fd_jac(f, Z.reshape(-1).copy())).max() < 1e-8

@@ -446,3 +446,37 @@ def test_phase_timing_debug_hook():
     t = t[t > 0]
     assert (np.diff(t) > 0).all()
     c.close()
+
+
+def test_derivative_and_time_consistency_rows(golden, golden_meta):
+    """the other members of prob.integrators, on a trajectory solved by the reference
+    (residuals ~1e-7 there) and on random data, values + structure against the oracle."""
+    systems, lay, _ = ref_case("two_qubit_zoh", golden_meta)
+    Z = golden("ref_two_qubit_zoh")["Z"]
+    traj = traj_from_Z(pa, Z, lay)
+    B = pa.BilinearIntegrator(product_system(2), traj)
+    m = lay.m
+    for x, dx in (("u", "du"), ("du", "ddu")):
+        D = pa.DerivativeIntegrator(x, dx, traj, like=B)
+        assert D.dim == m * lay.K
+        delta = pa.evaluate_(np.zeros(D.dim), D, traj)
+        ox, odx = traj.components[x].start, traj.components[dx].start
+        close(delta, po.derivative_residual(Z, ox, odx, m, lay.dt_off))
+        assert np.abs(delta).max() < 1e-6  # the reference solved these rows
+        J = pa.eval_jacobian(D, traj)
+        r, c, v = po.derivative_jacobian(Z, lay.z_dim, ox, odx, m, lay.dt_off)
+        rr, cc = pa.jacobian_structure(D)
+        assert np.array_equal(rr, r) and np.array_equal(cc, c)
+        close(D.jac(traj.datavec), v)
+        assert J.shape == (D.dim, traj.dim * traj.N)
+    T = pa.DerivativeIntegrator("t", None, traj, like=B)
+    delta = pa.evaluate_(np.zeros(T.dim), T, traj)
+    close(delta, po.time_consistency_residual(Z, lay.dt_off + 1, lay.dt_off))
+    assert np.abs(delta).max() < 1e-12
+    r, c, v = po.derivative_jacobian(Z, lay.z_dim, lay.dt_off + 1, -1, 1, lay.dt_off)
+    rr, cc = pa.jacobian_structure(T)
+    assert np.array_equal(rr, r) and np.array_equal(cc, c)
+    close(T.jac(traj.datavec), v)
+    with pytest.raises(pa.PclError):
+        B.ctx.deriv_eval_jac(lay.z_dim - 1, -1, 4, traj.datavec)
+    B.close()
