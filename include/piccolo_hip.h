@@ -161,6 +161,17 @@ int pcl_deriv_eval_jac(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim,
 int pcl_deriv_eval_jac_dev(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim, const double *Z_dev, double *delta_dev,
                            double *vals_dev);
 
+/* multi-GPU: the one exchange of the path ------------------------------------------------------
+ * One context per GPU/process.  Rank 0 obtains an id, ships the 128 bytes to the other ranks by any means (MPI,
+ * sockets, a file), every rank calls pcl_comm_init; pcl_reduce_sum_dev is an in-place RCCL all-reduce(sum, f64) over
+ * xGMI on the context's stream -- used for [merit | d/du | d/ddt] of the shared controls (~5.6 KB: latency-bound).
+ * librccl is opened lazily (dlopen); single-GPU users never load it. */
+typedef struct pcl_comm_id { char bytes[128]; } pcl_comm_id;
+int pcl_comm_get_unique_id(pcl_comm_id *out);
+int pcl_comm_init(pcl_ctx *ctx, const pcl_comm_id *id, int32_t rank, int32_t nranks);
+int pcl_reduce_sum_dev(pcl_ctx *ctx, double *buf_dev, int64_t n);
+int pcl_comm_destroy(pcl_ctx *ctx);
+
 /* tuning / introspection ---------------------------------------------------- */
 /* key: "cols_per_slice" (state columns per workgroup; 0 = heuristic), "use_mfma" (1/0), "nt_stores" (1/0). */
 int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t value);

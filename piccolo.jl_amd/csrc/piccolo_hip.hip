@@ -24,6 +24,8 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "piccolo_hip.h"
 
 #define PCL_VERSION_STR "piccolo_hip 0.1.0 (gfx950, pade4)"
@@ -1454,6 +1456,7 @@ struct pcl_ctx {
     // options
     int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_ablate = 0, opt_kernel = 2;
     long long *ddbg = nullptr;
+    void *comm = nullptr;  // ncclComm_t
     int64_t opt_specialize = 1;
     int64_t opt_grid = 0;  // 0: resident workgroups (persistent kernel)
     size_t lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1692,9 +1695,11 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     return PCL_OK;
 }
 
+extern "C" int pcl_comm_destroy(pcl_ctx *ctx);
 extern "C" void pcl_destroy(pcl_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)pcl_comm_destroy(ctx);
     void *ptrs[] = {ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
                     ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg};
@@ -2237,6 +2242,75 @@ extern "C" int pcl_deriv_eval_jac(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, i
     (void)hipFree(dv);
     if (rc == PCL_EHIP) return fail(ctx, PCL_EHIP, "pcl_deriv_eval_jac: HIP error %s", hipGetErrorString(hipGetLastError()));
     return rc;
+}
+
+// --- RCCL sum-reduce of the shared-control payload -----------------------------
+// librccl is opened lazily with dlopen so that single-GPU users never load it.  ncclUniqueId is 128 opaque bytes;
+// ncclDataType_t ncclFloat64 = 8, ncclRedOp_t ncclSum = 0 (rccl.h of ROCm 7.x).
+namespace {
+struct RcclApi {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, pcl_comm_id, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+int rccl_load(const pcl_ctx *ctx) {
+    if (g_rccl.h) return PCL_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(ctx, PCL_ERCCL, "dlopen(librccl.so): %s", dlerror());
+    RcclApi a;
+    a.h = h;
+    a.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(void **, int, pcl_comm_id, int))dlsym(h, "ncclCommInitRank");
+    a.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
+    a.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    a.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy) return fail(ctx, PCL_ERCCL, "librccl lacks the expected symbols");
+    g_rccl = a;
+    return PCL_OK;
+}
+int rccl_fail(const pcl_ctx *ctx, const char *what, int rc) {
+    return fail(ctx, PCL_ERCCL, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
+}
+}  // namespace
+
+extern "C" int pcl_comm_get_unique_id(pcl_comm_id *out) {
+    if (!out) return fail(nullptr, PCL_EINVAL, "pcl_comm_get_unique_id: NULL");
+    int rc = rccl_load(nullptr);
+    if (rc != PCL_OK) return rc;
+    int nrc = g_rccl.GetUniqueId(out);
+    return nrc == 0 ? PCL_OK : rccl_fail(nullptr, "ncclGetUniqueId", nrc);
+}
+extern "C" int pcl_comm_init(pcl_ctx *ctx, const pcl_comm_id *id, int32_t rank, int32_t nranks) {
+    if (!ctx || !id) return PCL_EINVAL;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, PCL_EINVAL, "pcl_comm_init: rank %d of %d", rank, nranks);
+    if (ctx->comm) return fail(ctx, PCL_EINVAL, "pcl_comm_init: communicator already initialised");
+    TRY(rccl_load(ctx));
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int nrc = g_rccl.CommInitRank(&ctx->comm, nranks, *id, rank);
+    if (nrc != 0) {
+        ctx->comm = nullptr;
+        return rccl_fail(ctx, "ncclCommInitRank", nrc);
+    }
+    return PCL_OK;
+}
+extern "C" int pcl_reduce_sum_dev(pcl_ctx *ctx, double *buf_dev, int64_t n) {
+    if (!ctx) return PCL_EINVAL;
+    if (!buf_dev || n < 0) return fail(ctx, PCL_EINVAL, "pcl_reduce_sum_dev: bad buffer");
+    if (!ctx->comm) return fail(ctx, PCL_ERCCL, "pcl_reduce_sum_dev: call pcl_comm_init first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int nrc = g_rccl.AllReduce(buf_dev, buf_dev, (size_t)n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+    return nrc == 0 ? PCL_OK : rccl_fail(ctx, "ncclAllReduce", nrc);
+}
+extern "C" int pcl_comm_destroy(pcl_ctx *ctx) {
+    if (!ctx) return PCL_EINVAL;
+    if (ctx->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+    return PCL_OK;
 }
 
 // --- options ---------------------------------------------------------------------------------

@@ -212,6 +212,20 @@ class _PclContext:
     def deriv_eval_jac_dev(self, x_off, dx_off, dim, Z, delta, vals):
         self._chk(self._L.pcl_deriv_eval_jac_dev(self._h, x_off, dx_off, dim, _ptr(Z), _ptr(delta), _ptr(vals)))
 
+    # -- RCCL (C-ABI path; torch.distributed is the alternative plumbing, see distributed.py) ----------------
+    def comm_unique_id(self):
+        buf = ctypes.create_string_buffer(128)
+        rc = self._L.pcl_comm_get_unique_id(buf)
+        if rc != 0:
+            raise PclError(rc, (self._L.pcl_last_error(None) or b"").decode())
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, nranks):
+        self._chk(self._L.pcl_comm_init(self._h, ctypes.create_string_buffer(unique_id, 128), rank, nranks))
+
+    def reduce_sum_dev(self, buf):
+        self._chk(self._L.pcl_reduce_sum_dev(self._h, _ptr(buf), buf.numel()))
+
     def set_option(self, key, value):
         self._chk(self._L.pcl_set_option(self._h, key.encode(), int(value)))
 

@@ -480,3 +480,26 @@ def test_derivative_and_time_consistency_rows(golden, golden_meta):
     with pytest.raises(pa.PclError):
         B.ctx.deriv_eval_jac(lay.z_dim - 1, -1, 4, traj.datavec)
     B.close()
+
+
+def test_rccl_reduce_through_the_c_abi_single_rank():
+    """pcl_comm_* / pcl_reduce_sum_dev (RCCL, dlopen'ed lazily): with one rank the all-reduce is the identity; errors are loud."""
+    import torch
+
+    rng = np.random.default_rng(0)
+    lay, G0, Gj, Z = _random_case(2, 1, 3, rng)
+    c = make_ctx(lay, G0, Gj)
+    buf = torch.arange(700, dtype=torch.float64, device="cuda")
+    with pytest.raises(pa.PclError) as ei:
+        c.reduce_sum_dev(buf)
+    assert ei.value.code == pa._lib.PCL_ERCCL
+    uid = c.comm_unique_id()
+    assert len(uid) == 128
+    c.comm_init(uid, 0, 1)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.reduce_sum_dev(buf)
+    torch.cuda.synchronize()
+    assert torch.equal(buf.cpu(), torch.arange(700, dtype=torch.float64))
+    with pytest.raises(pa.PclError):
+        c.comm_init(uid, 0, 1)  # already initialised
+    c.close()
