@@ -115,11 +115,12 @@ def main():
         chk = float(dd.abs().max().item())
         assert np.isfinite(chk) and chk > 0
         nc = c.get_option("effective_cols_per_slice")
+        lk = c.get_option("last_kernel")
         ms.close()
         del Zd, dd, vd
-        return wall, dev, nc
+        return wall, dev, nc, lk
 
-    wall, dev, nc = run_case(B, args.steps, args.warmup)
+    wall, dev, nc, lk = run_case(B, args.steps, args.warmup)
     t = torch.tensor([wall, dev], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -158,7 +159,9 @@ def main():
         "unit": "GB/s",
         "frac": abytes * B / kernel_s / 1e9 / HBM_PEAK_GBS,
         "traffic": None,
-        "kernel": "pcl_fused_kernel_v2<true,1,27,6,3> (persistent; 2 workgroups/CU; 4 MFMA waves + 4 store-stream waves each)",
+        "kernel": {41: "pcl_fused_kernel_v4<1,27,6,3>", 40: "pcl_fused_kernel_v4<1,0,0,0>", 21: "pcl_fused_kernel_v2<true,1,27,6,3>",
+                   20: "pcl_fused_kernel_v2<true,1,0,0,0>"}.get(lk, "pcl_fused_kernel (id %d)" % lk)
+        + " (persistent; 2 workgroups/CU; 4 MFMA waves + 4 store-stream waves each)",
         "kernel_us": kernel_s * 1e6,
         "algorithmic_bytes_per_launch": abytes * B,
     }
@@ -172,13 +175,14 @@ def main():
             pass
 
     if rank == 0 and world == 1 and not args.no_single:
-        w1, d1, nc1 = run_case(1, max(args.steps, 200), args.warmup)
+        w1, d1, nc1, lk1 = run_case(1, max(args.steps, 200), args.warmup)
         st = max(args.steps, 200)
         out["single_trajectory"] = {
             "evals_per_s": st / w1,
             "us_per_eval_wall": w1 / st * 1e6,
             "us_per_eval_kernel": d1 / st * 1e6,
             "cols_per_slice": nc1,
+            "kernel_id": lk1,
             "hbm_GBps": abytes / (d1 / st) / 1e9,
         }
     if rank == 0 and world == 1:

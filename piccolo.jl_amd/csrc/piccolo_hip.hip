@@ -707,6 +707,324 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused residual + Jacobian kernel, version 4: version 2's frame (persistent, 2 workgroups per CU, 4 matrix + 4 stream
+// waves, 4 barriers per item) with the block stores of an item SPREAD over four phases instead of one:
+//   the stream waves copy the item's -B^+ / B^- values into registers as soon as G^2 exists (start of phase 2) and
+//   issue a quarter of the copies in each of  phase 2, phase 3 (this item), phase 0, phase 1 (next item);
+//   every other duty (union update of G, S/D, G_l D, MFMA products, column outputs) belongs to the matrix waves.
+// Per item the workgroup then spends  sum_j max(matrix phase j, store burst j)  instead of
+// (matrix phases 0,1,3) + max(matrix phase 2, all stores): the store queue of the CU is fed in every phase.
+// ------------------------------------------------------------------------------------------
+#define PCL_NUE4 4  // union-pattern entries per matrix-wave thread held in registers (REG path: n_upos <= 1024)
+
+template <int WU, int TD, int TM, int TNC>
+__global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v4(const KParams p) {
+    extern __shared__ double lds[];
+    const int d = TD ? TD : p.d, n = 2 * d, m = TD ? TM : p.m, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD, nc = TNC ? TNC : p.nc;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const bool matrix_wave = wave < 4;
+    const int nn = n * n;
+    const int ncols1 = (2 + m) * nc;
+    const int n_ell = m * n * p.ell_w;
+    double *G = lds;
+    double *G2 = G + LD * n;
+    double *M1 = G2 + LD * n;
+    double *W1 = M1 + LD * ncols1;
+    double *G2D = W1 + LD * ncols1;
+    double *us = G2D + LD * nc;  // 2 x [u_k (m) | dt_k]: current / next item
+    double *ellv_l = us + 2 * (m + 1);
+    unsigned short *ellc_l = reinterpret_cast<unsigned short *>(ellv_l + n_ell);
+    const long long xd = (long long)n * d;
+    const int ew = p.ell_w;
+    const bool fused_p2 = ncols1 <= 32 && 2 * nc <= 16;
+    const bool stage = p.ell_lds;
+    const int n_items = p.batch * p.K * p.S;
+    const long long blk = p.compact ? (long long)nn : (long long)d * nn;  // size of seg 0 / seg 1
+
+    if (!p.g0_batch_stride)
+        for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = p.G0[e];
+    if (stage)
+        for (int e = tid; e < n_ell; e += 512) {
+            ellv_l[e] = p.ell_val[e];
+            ellc_l[e] = (unsigned short)p.ell_col[e];
+        }
+
+    if (matrix_wave) {
+        // ===================================== matrix waves (256 threads) ======================================
+        const int ri = tid % n, rj0 = tid / n, rstep = 256 / n;  // row ri, columns rj0, rj0+rstep, ..
+        const bool ract = rj0 < rstep;
+        constexpr int WUR = WU > 0 ? WU : 1;
+        int un_idx[PCL_NUE4];
+        double un_g0[PCL_NUE4];
+        unsigned char un_l[PCL_NUE4][WUR];
+        double un_v[PCL_NUE4][WUR];
+        if (WU > 0) {
+#pragma unroll
+            for (int r = 0; r < PCL_NUE4; ++r) {
+                const int q = tid + 256 * r;
+                un_idx[r] = -1;
+                un_g0[r] = 0.0;
+#pragma unroll
+                for (int w = 0; w < WUR; ++w) {
+                    un_l[r][w] = 0;
+                    un_v[r][w] = 0.0;
+                }
+                if (q < p.n_upos) {
+                    const int pos = p.upos[q];
+                    un_idx[r] = (pos % n) + LD * (pos / n);
+                    un_g0[r] = p.G0[pos];
+#pragma unroll
+                    for (int w = 0; w < WUR; ++w) {
+                        un_l[r][w] = p.uell_l[q * WUR + w];
+                        un_v[r][w] = p.uell_v[q * WUR + w];
+                    }
+                }
+            }
+        }
+        const bool pf_x = nc <= rstep;  // one state element per thread: prefetchable
+        double pf_v = 0.0, pf_xn = 0.0, pf_xc = 0.0;
+        auto request = [&](int item) {
+            const int s = item % p.S;
+            const int k = (item / p.S) % p.K;
+            const int b = item / (p.S * p.K);
+            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
+            if (tid <= m) pf_v = zk[tid < m ? p.u_off + tid : p.dt_off];
+            pf_xn = pf_xc = 0.0;
+            if (pf_x && ract && rj0 < min(nc, d - s * nc)) {
+                const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+                const long long o = x_off + (long long)(s * nc + rj0) * n + ri;
+                pf_xc = zk[o];
+                pf_xn = zk[p.z_dim + o];
+            }
+        };
+        int cur = 0;
+        if ((int)blockIdx.x < n_items) {
+            request(blockIdx.x);
+            if (tid <= m) us[tid] = pf_v;
+        }
+        __syncthreads();  // G = drift, tables staged, us[0] valid
+
+        for (int item = blockIdx.x;; item += gridDim.x) {
+            const bool have = item < n_items;
+            const int s = have ? item % p.S : 0;
+            const int k = have ? (item / p.S) % p.K : 0;
+            const int b = have ? item / (p.S * p.K) : 0;
+            const int c0 = s * nc;
+            const int nce = min(nc, d - c0);
+            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
+            const double *zn = zk + p.z_dim;
+            const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+            const double *usc = us + cur * (m + 1);
+            const double h = usc[m];
+            const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
+
+            // ---- phase 0: G(u_k) on the union pattern, S, D -> LDS -------------------------------------------
+            if (WU < 0 && p.g0_batch_stride) {  // per-member drift: the whole tile changes with b
+                if (have) {
+                    const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
+                    for (int e = tid; e < nn; e += 256) G[(e % n) + LD * (e / n)] = G0b[e];
+                }
+                __syncthreads();  // (stream waves take part) the dense rewrite lands before the pattern update
+            }
+            if (have) {
+                if (WU > 0) {
+#pragma unroll
+                    for (int r = 0; r < PCL_NUE4; ++r)
+                        if (un_idx[r] >= 0) {
+                            double g = un_g0[r];
+#pragma unroll
+                            for (int w = 0; w < WUR; ++w) g += usc[un_l[r][w]] * un_v[r][w];
+                            G[un_idx[r]] = g;
+                        }
+                } else {
+                    const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
+                    for (int q = tid; q < p.n_upos; q += 256) {
+                        const int pos = p.upos[q];
+                        double g = G0b[pos];
+                        const double *cf = p.ucoef + (long long)q * m;
+                        for (int l = 0; l < m; ++l) g += usc[l] * cf[l];
+                        G[(pos % n) + LD * (pos / n)] = g;
+                    }
+                }
+                if (pf_x) {
+                    if (ract && rj0 < nc) {
+                        M1[ri + LD * rj0] = pf_xn + pf_xc;
+                        M1[ri + LD * (nc + rj0)] = pf_xn - pf_xc;
+                    }
+                } else if (ract) {
+                    for (int c = rj0; c < nc; c += rstep) {
+                        double xs = 0.0, xdv = 0.0;
+                        if (c < nce) {
+                            const double xn = zn[x_off + (c0 + c) * n + ri], xc = zk[x_off + (c0 + c) * n + ri];
+                            xs = xn + xc;
+                            xdv = xn - xc;
+                        }
+                        M1[ri + LD * c] = xs;
+                        M1[ri + LD * (nc + c)] = xdv;
+                    }
+                }
+            }
+            __syncthreads();  // B_a
+            if (!have) {
+                __syncthreads();  // B_b: the stream waves' last burst pair runs through phases 0 and 1 of this empty item
+                break;
+            }
+
+            // ---- phase 1: G_l D (VALU) then G^2 (MFMA) ----------------------------------------------------------
+            if (ract) {
+                const double *Dm = M1 + LD * nc;
+                for (int cl = rj0; cl < m * nc; cl += rstep) {
+                    const int l = cl / nc, c = cl - l * nc;
+                    const int base = (l * n + ri) * ew;
+                    double acc = 0.0;
+                    if (stage) {
+                        for (int q = 0; q < ew; ++q) acc += ellv_l[base + q] * Dm[ellc_l[base + q] + LD * c];
+                    } else {
+                        for (int q = 0; q < ew; ++q) acc += p.ell_val[base + q] * Dm[p.ell_col[base + q] + LD * c];
+                    }
+                    M1[ri + LD * (2 * nc + cl)] = acc;
+                }
+            }
+            if (!(p.ablate & 1)) {
+                if (p.iso)
+                    wave_rowgemm<1>(G, LD, G, LD, G2, LD, n, d, n, wave, 4, lane, d);
+                else
+                    wave_rowgemm<0>(G, LD, G, LD, G2, LD, n, n, n, wave, 4, lane, 0);
+            }
+            __syncthreads();  // B_b: G, G^2, M1 complete
+
+            // ---- phase 2: W1 = G M1, G2D = G^2 D ; request the next item's inputs -------------------------------
+            if (!(p.ablate & 1)) {
+                if (fused_p2) {
+                    wave_phase2_fused(G, G2, M1, W1, G2D, LD, n, ncols1, nc, true, wave, lane);
+                } else {
+                    wave_rowgemm<0>(G, LD, M1, LD, W1, LD, n, ncols1, n, wave, 4, lane, 0);
+                    wave_rowgemm<0>(G2, LD, M1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
+                }
+            }
+            if (item + (int)gridDim.x < n_items) request(item + gridDim.x);
+            __syncthreads();  // B_c
+
+            // ---- phase 3: column outputs: block 0 -> delta and d/ddt, block 1+l -> d/du_l -----------------------
+            if (ract && !(p.ablate & 4)) {
+                const long long bk = (long long)b * p.K + k;
+                double *jb = p.jac + bk * p.jac_per;
+                const double *GDm = W1 + LD * nc;
+                for (int cl = rj0; cl < (1 + m) * nc; cl += rstep) {
+                    const int lb = cl / nc, c = cl - lb * nc;
+                    if (c >= nce) continue;
+                    const long long r = (long long)(c0 + c) * n + ri;
+                    if (lb == 0) {
+                        const double gs = W1[ri + LD * c], g2d = G2D[ri + LD * c];
+                        if (p.delta) p.delta[bk * xd + r] = M1[ri + LD * (nc + c)] - c1 * gs + c2 * g2d;
+                        jb[2 * blk + (long long)m * xd + r] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
+                    } else {
+                        const int l = lb - 1;
+                        const int base = (l * n + ri) * ew;
+                        double acc = 0.0;
+                        if (stage) {
+                            for (int q = 0; q < ew; ++q) {
+                                const int col = ellc_l[base + q];
+                                acc += ellv_l[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
+                            }
+                        } else {
+                            for (int q = 0; q < ew; ++q) {
+                                const int col = p.ell_col[base + q];
+                                acc += p.ell_val[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
+                            }
+                        }
+                        jb[2 * blk + (long long)l * xd + r] = acc + c2 * W1[ri + LD * (nc + cl)];
+                    }
+                }
+            }
+            if (tid <= m) us[(cur ^ 1) * (m + 1) + tid] = pf_v;  // requested during phase 2
+            cur ^= 1;
+            __syncthreads();  // B_d
+        }
+    } else {
+        // ===================================== stream waves (256 threads) ======================================
+        const int stid = tid - 256;
+        const int hn = n >> 1;
+        const int pi = 2 * (stid % hn), pj0 = stid / hn, pstep = max(256 / hn, 1);
+        const bool pact = pj0 < pstep;
+        constexpr int NSP = TD ? (2 * TD + (256 / TD) - 1) / (256 / TD) : 8;  // column steps per thread (<= 8 for n <= 64)
+        double bpr[NSP][2], bmr[NSP][2];
+        double *sjb = nullptr;
+        int ncopy = 0;
+        // burst j in 0..3: copies q = (j>>1), (j>>1)+2, .. and the (j&1) half of this thread's column steps -> four equal
+        // quarters of the item's stores whatever the copy count
+        auto burst = [&](int jq) {
+            if (!pact || (p.ablate & 2)) return;
+            const int half = ncopy >> 1;
+            const int rlo = (jq & 1) ? NSP / 2 : 0, rhi = (jq & 1) ? NSP : NSP / 2;
+            for (int q = jq >> 1; q < ncopy; q += 2) {
+                const bool minus = q >= half;
+                double *o = sjb + (minus ? blk + (long long)(q - half) * nn : (long long)q * nn);
+                if (minus) {
+#pragma unroll
+                    for (int r = 0; r < NSP; ++r) {
+                        const int j = pj0 + pstep * r;
+                        if (r >= rlo && r < rhi && j < n) store2(o + n * j, bmr[r][0], bmr[r][1], p.nt);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NSP; ++r) {
+                        const int j = pj0 + pstep * r;
+                        if (r >= rlo && r < rhi && j < n) store2(o + n * j, bpr[r][0], bpr[r][1], p.nt);
+                    }
+                }
+            }
+        };
+        int cur = 0;
+        __syncthreads();  // prologue barrier
+        for (int item = blockIdx.x;; item += gridDim.x) {
+            const bool have = item < n_items;
+            if (WU < 0 && p.g0_batch_stride) __syncthreads();
+            burst(2);  // previous item, third quarter (phase 0)
+            __syncthreads();       // B_a
+            burst(3);  // previous item, last quarter (phase 1)
+            __syncthreads();       // B_b: this item's G, G^2 complete
+            if (!have) break;
+            {
+                const int s = item % p.S;
+                const int k = (item / p.S) % p.K;
+                const int b = item / (p.S * p.K);
+                const double h = us[cur * (m + 1) + m];
+                const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
+                if (pact) {
+#pragma unroll
+                    for (int r = 0; r < NSP; ++r) {
+                        const int j = pj0 + pstep * r;
+                        if (j < n) {
+                            const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
+                            const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
+                            const double e0 = ((pi == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + c2 * h1;
+                            bpr[r][0] = -(e0 + c1 * g0);
+                            bpr[r][1] = -(e1 + c1 * g1);
+                            bmr[r][0] = e0 - c1 * g0;
+                            bmr[r][1] = e1 - c1 * g1;
+                        }
+                    }
+                }
+                int cbeg = s * nc, cend = s * nc + min(nc, d - s * nc);
+                if (p.compact) {  // unique blocks only: slice 0 writes the single copy
+                    cbeg = 0;
+                    cend = (s == 0) ? 1 : 0;
+                }
+                ncopy = 2 * (cend - cbeg);  // -B^+ copies, then B^- copies
+                sjb = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn + pi;
+            }
+            burst(0);         // phase 2
+            __syncthreads();  // B_c
+            burst(1);         // phase 3
+            cur ^= 1;
+            __syncthreads();   // B_d
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Fused residual + Jacobian kernel, version 3 (default): ONE persistent workgroup per CU, four
 // "matrix" wavefronts + four "stream" wavefronts, ONE workgroup barrier per work item (b, k, s).
 //
@@ -1454,10 +1772,11 @@ struct pcl_ctx {
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dmu = nullptr, *ddelta = nullptr, *dvals = nullptr, *dhess = nullptr;
     // options
-    int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_ablate = 0, opt_kernel = 2;
+    int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_ablate = 0, opt_kernel = 0;  // 0 = auto (2 or 4 by work per workgroup)
     long long *ddbg = nullptr;
     void *comm = nullptr;  // ncclComm_t
     int64_t opt_specialize = 1;
+    int64_t last_kernel = 0;  // 10*version + (1 if shape-specialised) of the last fused launch
     int64_t opt_grid = 0;  // 0: resident workgroups (persistent kernel)
     size_t lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const void *lds_kern[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // last MaxDynamicSharedMemorySize set per kernel variant
@@ -1898,7 +2217,7 @@ static int choose_cols_per_slice(const pcl_ctx *ctx, bool jac) {
     p.m = ctx->desc.n_drives;
     p.LD = ((ctx->n + 3) & ~3) + 2;
     p.ell_w = ctx->ell_w;
-    const bool v2 = ctx->opt_kernel >= 2;
+    const bool v2 = ctx->opt_kernel == 0 || ctx->opt_kernel >= 2;
     const bool ell = ell_fits_lds(ctx);
     auto bytes = [&](int nc) {
         p.nc = nc;
@@ -1975,7 +2294,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     p.jac_per = compact ? jac_per_compact(ctx) : jac_per_full(ctx);
     const bool want_jac = jac != nullptr;
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
-    if (want_jac && ctx->opt_kernel == 3 && ctx->opt_use_mfma != 0 && v3_supported(ctx)) {
+    if (want_jac && ctx->opt_kernel == 3 && ctx->opt_use_mfma != 0 && v3_supported(ctx)) {  // (never chosen automatically)
         p.nc = choose_cols_v3(ctx);
         p.ncw = v3_ncw(ctx, p.nc);
         p.tab_lds = 1;
@@ -1993,6 +2312,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         kern3_t kern3 = ewr == 1 ? (kern3_t)pcl_fused_kernel_v3<1, 0, 0, 0> : ewr == 2 ? (kern3_t)pcl_fused_kernel_v3<2, 0, 0, 0> : (kern3_t)pcl_fused_kernel_v3<0, 0, 0, 0>;
         // shape-specialised instance (BASELINE config 3/4/5: d = 27, six drives with two entries per row, 2-column chunks)
         if (ewr == 2 && p.d == 27 && p.m == 6 && p.ncw == 2 && ctx->opt_specialize) kern3 = (kern3_t)pcl_fused_kernel_v3<2, 27, 6, 2>;
+        ctx->last_kernel = 30 + ((ewr == 2 && p.d == 27 && p.m == 6 && p.ncw == 2 && ctx->opt_specialize) ? 1 : 0);
         int rc = set_lds_attr(ctx, (const void *)kern3, 6, lds3);
         if (rc != PCL_OK) return rc;
         const long long g3 = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, items) : std::min<long long>(items, std::max(ctx->n_cu, 1));
@@ -2001,7 +2321,8 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         return PCL_OK;
     }
 not_v3:
-    const bool v2 = ctx->opt_kernel >= 2 && ctx->opt_use_mfma != 0;
+    const bool v2 = (ctx->opt_kernel == 0 || ctx->opt_kernel >= 2) && ctx->opt_use_mfma != 0;
+    bool v4 = v2 && ctx->opt_kernel == 4 && want_jac;
     p.nc = choose_cols_per_slice(ctx, want_jac);
     auto bytes = [&]() { return v2 ? fused2_lds_bytes(p, want_jac, p.ell_lds != 0) : fused_lds_bytes(p, want_jac); };
     size_t lds = bytes();
@@ -2015,11 +2336,19 @@ not_v3:
     if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "grid too large");
     if (v2) {
         typedef void (*kern_t)(const KParams);
+        const int per_cu_guess = std::max(1, std::min(2, (int)((size_t)ctx->max_lds / lds)));
         const int wu = (ctx->uell_w <= 2 && ctx->n_upos <= 1024 && !ctx->desc.per_member_G0) ? ctx->uell_w : -1;
         kern_t kern = want_jac ? (wu == 1 ? (kern_t)pcl_fused_kernel_v2<true, 1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<true, 2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v2<true, -1, 0, 0, 0>)
                                : (wu == 1 ? (kern_t)pcl_fused_kernel_v2<false, 1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<false, 2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v2<false, -1, 0, 0, 0>);
         // shape-specialised instance (BASELINE config 3/4/5: three 3-level transmons, d = 27, six drives, 3-column slices)
         if (want_jac && wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize) kern = (kern_t)pcl_fused_kernel_v2<true, 1, 27, 6, 3>;
+        // auto: spreading an item's stores into the next item's phases pays once a workgroup walks several items
+        if (ctx->opt_kernel == 0 && want_jac && grid >= 4 * (long long)per_cu_guess * std::max(ctx->n_cu, 1)) v4 = true;
+        if (v4) {
+            kern = wu == 1 ? (kern_t)pcl_fused_kernel_v4<1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v4<2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v4<-1, 0, 0, 0>;
+            if (wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize) kern = (kern_t)pcl_fused_kernel_v4<1, 27, 6, 3>;
+        }
+        ctx->last_kernel = (v4 ? 40 : 20) + ((wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize && want_jac) ? 1 : 0);
         int rc = set_lds_attr(ctx, (const void *)kern, want_jac ? 4 : 5, lds);  // wu is fixed per context
         if (rc != PCL_OK) return rc;
         // persistent grid: as many workgroups as are resident at once
@@ -2339,7 +2668,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         }
     }
     else if (!strcmp(key, "kernel_version")) {
-        if (v < 1 || v > 3) return fail(ctx, PCL_EINVAL, "kernel_version must be 1, 2 or 3");
+        if (v < 0 || v > 4) return fail(ctx, PCL_EINVAL, "kernel_version must be 0 (auto), 1, 2, 3 or 4");
         ctx->opt_kernel = v;
     }
     else
@@ -2368,6 +2697,8 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->n_cu;
     else if (!strcmp(key, "kernel_version"))
         *v = ctx->opt_kernel;
+    else if (!strcmp(key, "last_kernel"))
+        *v = ctx->last_kernel;
     else if (!strcmp(key, "occupancy_v2")) {
         KParams p;
         fill_params(ctx, p);
