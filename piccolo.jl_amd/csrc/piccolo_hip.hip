@@ -72,7 +72,10 @@ struct KParams {
     int nc;       // state columns per slice
     int S;        // slices per interval
     int LD;       // LDS leading dimension of every n-row tile
-    int compact;  // 1: write unique blocks only (jac_per is the compact size)
+    int compact;  // 1: write unique blocks only (jac_per is the compact size); 2: split mode - unique blocks go to
+                  //    `blocks` (2*n*n per (b,k)) and `flags[b*K+k]` is raised, everything else in the full layout
+    double *blocks;
+    unsigned int *flags;
     int nt;       // 1: nontemporal streaming stores
     int ablate;   // DEBUG ONLY (wrong results): bit0 skip matrix products, bit1 skip block streaming, bit2 skip column outputs
 };
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
         // ---- phase 2: matrix waves W1 = G M1, G2D = G^2 D ; stream waves the block copies -------------------
         const long long bk = (long long)b * p.K + k;
         double *jb = JAC ? p.jac + bk * p.jac_per : nullptr;
-        const long long blk = p.compact ? (long long)nn : (long long)d * nn;  // size of seg 0 / seg 1
+        const long long blk = p.compact == 1 ? (long long)nn : (long long)d * nn;  // size of seg 0 / seg 1 in `jac`
         if (matrix_wave) {
             if (!(p.ablate & 1)) {
                 if (fused_p2) {
@@ -648,22 +651,31 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
                 cbeg = 0;
                 cend = (s == 0) ? 1 : 0;
             }
+            double *ob = p.compact == 2 ? p.blocks + bk * 2 * nn : jb;  // split mode: blocks go to the scratch tiles
+            const long long oblk = p.compact == 2 ? (long long)nn : blk;
             for (int j = pj0; j < n; j += pstep) {
                 const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
                 const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
                 const double e0 = ((pi == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + c2 * h1;
                 const double bp0 = -(e0 + c1 * g0), bp1 = -(e1 + c1 * g1);
                 const double bm0 = e0 - c1 * g0, bm1 = e1 - c1 * g1;
-                double *o0 = jb + (long long)cbeg * nn + (pi + n * j);
+                double *o0 = ob + (long long)cbeg * nn + (pi + n * j);
                 for (int c = cbeg; c < cend; ++c, o0 += nn) {
                     store2(o0, bp0, bp1, p.nt);
-                    store2(o0 + blk, bm0, bm1, p.nt);
+                    store2(o0 + oblk, bm0, bm1, p.nt);
                 }
             }
+            if (p.compact == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's tile stores have left the CU
         }
         // inputs of this workgroup's next item: in flight during the rest of this one
         if (item + (int)gridDim.x < n_items) request(item + gridDim.x);
         __syncthreads();
+        if (JAC && p.compact == 2 && s == 0 && tid == 256) {
+            // publish the interval's tiles to the expander kernel (other CUs / XCDs): agent-scope release, then the flag
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(p.flags + bk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (!JAC) {  // eval only: delta needs G (G D), a second dependent product
             if (matrix_wave && !(p.ablate & 1)) wave_rowgemm<0>(G, LD, W1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
             __syncthreads();
@@ -1571,6 +1583,72 @@ __global__ __launch_bounds__(256) void pcl_expand_kernel(const double *__restric
 }
 
 // ------------------------------------------------------------------------------------------
+// Split mode, consumer side: persistent expander.  Work item = (b, k, piece): `cpp` of the 2d block copies of one
+// interval.  The workgroup waits until the producer kernel (running concurrently on another stream) has raised the
+// interval's flag, loads the unique -B^+ / B^- tile values it needs from the scratch tiles (L2) into registers and
+// streams the copies.  No LDS, no barrier inside the stream.  Hand-off protocol: producer = stores, s_waitcnt vmcnt(0),
+// __syncthreads, one lane: agent-scope release fence + relaxed agent-scope flag store; consumer = one lane polls the
+// flag (relaxed, agent scope), agent-scope acquire fence, __syncthreads, plain loads.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pcl_expand_stream_kernel(const double *blocks, const unsigned int *flags,
+                                                                double *__restrict__ jac, int d, int n, long long jac_per,
+                                                                long long n_bk, int pieces, int cpp, int nt) {
+    const int nn = n * n;
+    const int tid = threadIdx.x;
+    const int hn = n >> 1;
+    const int pi = 2 * (tid % hn), pj0 = tid / hn, pstep = max(256 / hn, 1);
+    const bool pact = pj0 < pstep;
+    const long long n_items = n_bk * pieces;
+    const long long blk = (long long)d * nn;
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const long long bk = item / pieces;
+        const int piece = (int)(item - bk * pieces);
+        if (tid == 0) {
+            // bounded spin (about a second): a producer that never shows up must not hang the device
+            int spins = 0;
+            while (__hip_atomic_load(flags + bk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && spins < (1 << 22)) {
+                __builtin_amdgcn_s_sleep(8);
+                ++spins;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (pact) {
+            const double *src = blocks + bk * 2 * nn + pi;
+            double2_t vp[8], vm[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int j = pj0 + pstep * r;
+                if (j < n) {
+                    vp[r] = *reinterpret_cast<const double2_t *>(src + n * j);
+                    vm[r] = *reinterpret_cast<const double2_t *>(src + nn + n * j);
+                }
+            }
+            // copies q in [piece*cpp, ..): q < d are -B^+ copies, q >= d are B^- copies
+            const int q0 = piece * cpp, q1 = min(2 * d, q0 + cpp);
+            double *dst = jac + bk * jac_per + pi;
+            for (int q = q0; q < q1; ++q) {
+                if (q < d) {
+                    double *o = dst + (long long)q * nn;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int j = pj0 + pstep * r;
+                        if (j < n) store2(o + n * j, vp[r][0], vp[r][1], nt);
+                    }
+                } else {
+                    double *o = dst + blk + (long long)(q - d) * nn;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int j = pj0 + pstep * r;
+                        if (j < n) store2(o + n * j, vm[r][0], vm[r][1], nt);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Hessian-of-Lagrangian kernel: one workgroup per (b, k); the d state columns are processed in
 // chunks of nc columns (columns are independent except for the (m+1)(m+2)/2 scalar entries,
 // whose per-chunk partial sums are accumulated in LDS in a fixed order -> deterministic).
@@ -1775,6 +1853,12 @@ struct pcl_ctx {
     int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_ablate = 0, opt_kernel = 0;  // 0 = auto (2 or 4 by work per workgroup)
     long long *ddbg = nullptr;
     void *comm = nullptr;  // ncclComm_t
+    // split mode (producer kernel + concurrent expander kernel)
+    double *dblocks = nullptr;
+    unsigned int *dflags = nullptr;
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int64_t opt_cpp = 6;  // block copies per expander work item
     int64_t opt_specialize = 1;
     int64_t last_kernel = 0;  // 10*version + (1 if shape-specialised) of the last fused launch
     int64_t opt_grid = 0;  // 0: resident workgroups (persistent kernel)
@@ -2024,6 +2108,11 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
                     ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    if (ctx->dblocks) (void)hipFree(ctx->dblocks);
+    if (ctx->dflags) (void)hipFree(ctx->dflags);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -2351,11 +2440,43 @@ not_v3:
         ctx->last_kernel = (v4 ? 40 : 20) + ((wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize && want_jac) ? 1 : 0);
         int rc = set_lds_attr(ctx, (const void *)kern, want_jac ? 4 : 5, lds);  // wu is fixed per context
         if (rc != PCL_OK) return rc;
+        const bool split = ctx->opt_kernel == 5 && want_jac && !compact;
+        if (split) {
+            const long long n_bk = (long long)p.batch * p.K;
+            if (!ctx->dblocks) {
+                HIP_TRY(ctx, hipMalloc((void **)&ctx->dblocks, (size_t)n_bk * 2 * p.n * p.n * sizeof(double)));
+                HIP_TRY(ctx, hipMalloc((void **)&ctx->dflags, (size_t)n_bk * sizeof(unsigned int)));
+                HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+                HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+            }
+            p.compact = 2;
+            p.blocks = ctx->dblocks;
+            p.flags = ctx->dflags;
+            kern = wu == 1 ? (kern_t)pcl_fused_kernel_v2<true, 1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<true, 2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v2<true, -1, 0, 0, 0>;
+            if (wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize) kern = (kern_t)pcl_fused_kernel_v2<true, 1, 27, 6, 3>;
+            ctx->last_kernel = 50;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dflags, (ctx->opt_ablate & 64) ? 0xFF : 0, (size_t)n_bk * sizeof(unsigned int), ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+        }
         // persistent grid: as many workgroups as are resident at once
         const int per_cu = std::max(1, std::min(2, (int)((size_t)ctx->max_lds / lds)));
         const long long resident = (long long)per_cu * std::max(ctx->n_cu, 1);
         const long long g2 = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, grid) : std::min(grid, resident);
-        hipLaunchKernelGGL(kern, dim3((unsigned)g2), dim3(512), lds, ctx->stream, p);
+        if (!(split && (ctx->opt_ablate & 64))) hipLaunchKernelGGL(kern, dim3((unsigned)g2), dim3(512), lds, ctx->stream, p);
+        if (split) {
+            // the expander leaves wave slots and all LDS to the producer: at most 4 x 256 threads per CU
+            const int cpp = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_cpp, 2 * p.d));
+            const int pieces = (2 * p.d + cpp - 1) / cpp;
+            const long long n_bk = (long long)p.batch * p.K;
+            const long long eg = std::min<long long>(n_bk * pieces, 4LL * std::max(ctx->n_cu, 1));
+            hipLaunchKernelGGL(pcl_expand_stream_kernel, dim3((unsigned)eg), dim3(256), 0, ctx->aux_stream, ctx->dblocks, ctx->dflags, jac,
+                               p.d, p.n, jac_per_full(ctx), n_bk, pieces, cpp, p.nt);
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
     } else {
         const bool mf = ctx->opt_use_mfma != 0;
         auto kern = want_jac ? (mf ? pcl_fused_kernel<true, true> : pcl_fused_kernel<true, false>)
@@ -2656,6 +2777,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_ablate = v;
     else if (!strcmp(key, "grid"))
         ctx->opt_grid = v;
+    else if (!strcmp(key, "copies_per_piece"))
+        ctx->opt_cpp = v;
     else if (!strcmp(key, "specialize"))  // 0: always the run-time-shape kernel instances
         ctx->opt_specialize = v != 0;
     else if (!strcmp(key, "debug_timing")) {  // profiling aid: cycle stamps of workgroup 0 (pcl_debug_timing reads them)
@@ -2668,7 +2791,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         }
     }
     else if (!strcmp(key, "kernel_version")) {
-        if (v < 0 || v > 4) return fail(ctx, PCL_EINVAL, "kernel_version must be 0 (auto), 1, 2, 3 or 4");
+        if (v < 0 || v > 5) return fail(ctx, PCL_EINVAL, "kernel_version must be 0 (auto), 1, 2, 3, 4 or 5 (split)");
         ctx->opt_kernel = v;
     }
     else

@@ -45,9 +45,10 @@ def make_ctx(lay, G0, Gj, **kw):
 # ---- committed golden vectors ----------------------------------------------------------------
 # kernel variants: (kernel_version, use_mfma).  (3,1) is the default: one persistent, wave-specialised,
 # software-pipelined workgroup per CU; (2,1) persistent, 2 workgroups per CU (default); (4,1) the same frame with
-# the block stores spread over four phases; (1,1) the
+# the block stores spread over four phases; (5,1) split mode: producer kernel + concurrent expander kernel on a second
+# stream, handed off through agent-scope flags; (1,1) the
 # single-role MFMA kernel, (1,0) the plain-VALU kernel.  pcl_eval (no Jacobian) runs v2/v1 code.
-VARIANTS = [(2, 1), (4, 1), (3, 1), (1, 1), (1, 0)]
+VARIANTS = [(2, 1), (4, 1), (3, 1), (5, 1), (1, 1), (1, 0)]
 
 
 def set_variant(c, variant):
@@ -82,7 +83,7 @@ def test_seeded_vs_oracle_all_slicings(cfg, N):
     G0, Gj = so.G_drift, np.array(so.G_drives)
     d_ref, j_ref = ref_lib.eval_jac(Z, lay, G0, Gj)
     c = make_ctx(lay, G0, Gj)
-    for variant in VARIANTS[:3]:
+    for variant in VARIANTS[:4]:
         set_variant(c, variant)
         for nc in sorted({0, 1, 2, 3, 5, lay.d}):
             if nc > lay.d:
