@@ -9,6 +9,7 @@
  * DirectTrajOpt.jl, known from Piccolo's call sites):
  *
  *   pcl_create            BilinearIntegrator(qtraj::UnitaryTrajectory, N)     src/control/integrators.jl:35-51
+ *                         BilinearIntegrator(qtraj::KetTrajectory, N)         src/control/integrators.jl:58-74  (state_cols = 1)
  *                         BilinearIntegrator(qtraj::SamplingTrajectory, N)    src/control/integrators.jl:134-162
  *                         (copies G_drift / G_drives of sys.G, quantum_systems.jl:225-226,
  *                          composite_quantum_systems.jl:124-132, and the component ranges of the
@@ -97,7 +98,8 @@ typedef struct pcl_desc {
     int32_t device_id;   /* HIP device ordinal */
     int32_t index_base;  /* 0 (C/Python) or 1 (Julia/MOI) for the emitted structure */
     int32_t per_member_G0; /* 0: one G0 for all members; 1: G0 holds batch matrices (per-member H_drift) */
-    int32_t reserved;
+    int32_t state_cols;  /* columns of the state matrix X (n x state_cols): 0 or d = unitary (Utilde, x_dim = 2 d^2),
+                            1 = ket (psitilde = [Re psi; Im psi], x_dim = 2d; KetTrajectory, integrators.jl:58-74) */
     int64_t global_dim;  /* traj.global_dim (trailing globals in the variable vector; only shifts nothing, kept for
                             the column count reported by pcl_constraint_dim) */
     const double *G0;      /* n x n column-major (x batch if per_member_G0) : G_drift = iso(-i H_drift) */
@@ -160,6 +162,14 @@ int pcl_deriv_structure(const pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32
 int pcl_deriv_eval_jac(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim, const double *Z, double *delta, double *vals);
 int pcl_deriv_eval_jac_dev(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim, const double *Z_dev, double *delta_dev,
                            double *vals_dev);
+
+/* terminal objective of the unitary problems ---------------------------------------------------
+ *   UnitaryInfidelityObjective: Q * |1 - |tr(U_goal' U_N)|^2 / d^2|             src/control/objectives.jl:330-356
+ * pcl_set_goal copies the goal's iso-vec (x_dim doubles, operator_to_iso_vec(U_goal)).  pcl_infidelity_dev writes one value
+ * per member / seed (value_dev[batch]) and the gradient w.r.t. that member's terminal state (grad_dev[batch*x_dim], iso-vec
+ * order); either output may be NULL.  Subspace (EmbeddedOperator) fidelity and the regularisers stay with the caller. */
+int pcl_set_goal(pcl_ctx *ctx, const double *goal_iso_vec);
+int pcl_infidelity_dev(pcl_ctx *ctx, const double *Z_dev, double Q, double *value_dev, double *grad_dev);
 
 /* multi-GPU: the one exchange of the path ------------------------------------------------------
  * One context per GPU/process.  Rank 0 obtains an id, ships the 128 bytes to the other ranks by any means (MPI,

@@ -320,14 +320,19 @@ class Layout:
     x_off: int
     u_off: int
     dt_off: int
+    cols: Optional[int] = None  # state columns: None/d = unitary (X is n x d), 1 = ket [REF integrators.jl:58-74]
 
     @property
     def n(self):
         return 2 * self.d
 
     @property
+    def C(self):
+        return self.d if self.cols is None else self.cols
+
+    @property
     def x_dim(self):
-        return 2 * self.d * self.d
+        return 2 * self.d * self.C
 
     @property
     def K(self):
@@ -342,7 +347,7 @@ class Layout:
     def X(self, Z, k, x_off=None):
         """n x d real matrix [Re U; Im U] of knot k (column c = iso-vec slice c)."""
         o = self.x_off if x_off is None else x_off
-        return Z[k, o : o + self.x_dim].reshape(self.d, self.n).T
+        return Z[k, o : o + self.x_dim].reshape(self.C, self.n).T
 
     def u(self, Z, k):
         return Z[k, self.u_off : self.u_off + self.m]
@@ -412,12 +417,12 @@ def pade_residual(Z, lay: Layout, G0, Gj, order=4, x_off=None):
 
 
 def jac_nnz_per_interval(lay: Layout):
-    return 2 * lay.d * lay.n * lay.n + lay.x_dim * (lay.m + 1)
+    return 2 * lay.C * lay.n * lay.n + lay.x_dim * (lay.m + 1)
 
 
 def jac_structure(lay: Layout, x_off=None, index_base=0):
     o = lay.x_off if x_off is None else x_off
-    d, n, m, xd, zd = lay.d, lay.n, lay.m, lay.x_dim, lay.z_dim
+    d, n, m, xd, zd = lay.C, lay.n, lay.m, lay.x_dim, lay.z_dim
     per = jac_nnz_per_interval(lay)
     rows = np.empty(lay.K * per, dtype=np.int64)
     cols = np.empty_like(rows)
@@ -447,7 +452,7 @@ def pade_jacobian_values(Z, lay: Layout, G0, Gj, order=4, x_off=None):
     """Jacobian values in the fixed triplet order above.  Returns [K, nnz_per_interval]."""
     c = pade_coeffs(order)
     q = order // 2
-    d, n, m, xd = lay.d, lay.n, lay.m, lay.x_dim
+    d, n, m, xd = lay.C, lay.n, lay.m, lay.x_dim
     per = jac_nnz_per_interval(lay)
     out = np.empty((lay.K, per))
     for k in range(lay.K):
@@ -547,7 +552,7 @@ def hess_structure(lay: Layout, x_off=None, index_base=0):
 def pade4_hessian_values(Z, mu, lay: Layout, G0, Gj, x_off=None):
     """Values of grad^2 (sum_k mu_k^T delta_k) in the order above.  ``mu`` is
     [K, x_dim].  Returns [K, hess_nnz_per_interval]."""
-    d, n, m, xd = lay.d, lay.n, lay.m, lay.x_dim
+    d, n, m, xd = lay.C, lay.n, lay.m, lay.x_dim
     per = hess_nnz_per_interval(lay)
     out = np.empty((lay.K, per))
     ip = lambda A, B: float(np.sum(A * B))

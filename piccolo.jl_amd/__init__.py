@@ -31,6 +31,6 @@ from .quantum import (
     lift_operator,
     operator_to_iso_vec,
 )
-from .trajectory import NamedTrajectory, add_control_derivatives, sampling_trajectory, unitary_trajectory
+from .trajectory import NamedTrajectory, add_control_derivatives, ket_trajectory, sampling_trajectory, unitary_trajectory
 
 __version__ = "0.1.0"

@@ -28,6 +28,7 @@ EXPORTS = [
     "pcl_set_stream", "pcl_reset_stream", "pcl_sync", "pcl_eval_dev", "pcl_eval_jac_dev", "pcl_hess_dev",
     "pcl_jac_compact_nnz", "pcl_eval_jac_compact_dev", "pcl_jac_expand_dev",
     "pcl_deriv_nnz", "pcl_deriv_structure", "pcl_deriv_eval_jac", "pcl_deriv_eval_jac_dev",
+    "pcl_set_goal", "pcl_infidelity_dev",
     "pcl_comm_get_unique_id", "pcl_comm_init", "pcl_reduce_sum_dev", "pcl_comm_destroy",
     "pcl_set_option", "pcl_get_option", "pcl_debug_timing",
 ]  # fmt: skip
@@ -54,7 +55,7 @@ class pcl_desc(ctypes.Structure):
         ("device_id", ctypes.c_int32),
         ("index_base", ctypes.c_int32),
         ("per_member_G0", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("state_cols", ctypes.c_int32),
         ("global_dim", ctypes.c_int64),
         ("G0", ctypes.POINTER(ctypes.c_double)),
         ("Gj", ctypes.POINTER(ctypes.c_double)),
@@ -123,6 +124,8 @@ def load():
     L.pcl_deriv_structure.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_i64p, c_i64p]
     L.pcl_deriv_eval_jac.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp]
     L.pcl_deriv_eval_jac_dev.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp]
+    L.pcl_set_goal.argtypes = [vp, vp]
+    L.pcl_infidelity_dev.argtypes = [vp, vp, ctypes.c_double, vp, vp]
     L.pcl_comm_get_unique_id.argtypes = [ctypes.c_char_p]
     L.pcl_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32]
     L.pcl_reduce_sum_dev.argtypes = [vp, vp, ctypes.c_int64]

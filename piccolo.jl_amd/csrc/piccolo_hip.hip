@@ -69,6 +69,7 @@ struct KParams {
     long long hess_per;
     int n_upos;
     int d, n, m, K, z_dim, u_off, dt_off, batch;
+    int cols;     // state columns: d for a unitary (X is n x d), 1 for a ket; x_dim = n * cols
     int nc;       // state columns per slice
     int S;        // slices per interval
     int LD;       // LDS leading dimension of every n-row tile
@@ -188,7 +189,7 @@ __device__ __forceinline__ void build_G(const KParams &p, const double *__restri
 template <bool JAC, bool MFMA>
 __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
     extern __shared__ double lds[];
-    const int n = p.n, d = p.d, m = p.m, LD = p.LD, nc = p.nc;
+    const int n = p.n, d = p.cols, m = p.m, LD = p.LD, nc = p.nc;  // d: state columns here (no iso shortcut in this kernel)
     const int tid = threadIdx.x, nth = blockDim.x;
 
     const int bid = blockIdx.x;
@@ -453,6 +454,7 @@ template <bool JAC, int WU, int TD, int TM, int TNC>  // WU: (drive,value) pairs
 __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
     extern __shared__ double lds[];
     const int d = TD ? TD : p.d, n = 2 * d, m = TD ? TM : p.m, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD, nc = TNC ? TNC : p.nc;
+    const int C = TD ? TD : p.cols;  // state columns (specialised instances are unitary: C = d)
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const bool matrix_wave = wave < 4;
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
     double *us = G2D + LD * nc;  // 2 x [u_k (m) | dt_k]: current / next item
     double *ellv_l = us + 2 * (m + 1);
     unsigned short *ellc_l = reinterpret_cast<unsigned short *>(ellv_l + n_ell);
-    const long long xd = (long long)n * d;
+    const long long xd = (long long)n * C;
     const int ew = p.ell_w;
     const bool fused_p2 = ncols1 <= 32 && 2 * nc <= 16;
 
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
         const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
         if (tid <= m) pf_v = zk[tid < m ? p.u_off + tid : p.dt_off];
         pf_xn = pf_xc = 0.0;
-        if (pf_x && ract && rj0 < min(nc, d - s * nc)) {
+        if (pf_x && ract && rj0 < min(nc, C - s * nc)) {
             const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
             const long long o = x_off + (long long)(s * nc + rj0) * n + ri;
             pf_xc = zk[o];
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
         const int k = (item / p.S) % p.K;
         const int b = item / (p.S * p.K);
         const int c0 = s * nc;
-        const int nce = min(nc, d - c0);
+        const int nce = min(nc, C - c0);
         const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
         const double *zn = zk + p.z_dim;
         const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
         // ---- phase 2: matrix waves W1 = G M1, G2D = G^2 D ; stream waves the block copies -------------------
         const long long bk = (long long)b * p.K + k;
         double *jb = JAC ? p.jac + bk * p.jac_per : nullptr;
-        const long long blk = p.compact == 1 ? (long long)nn : (long long)d * nn;  // size of seg 0 / seg 1 in `jac`
+        const long long blk = p.compact == 1 ? (long long)nn : (long long)C * nn;  // size of seg 0 / seg 1 in `jac`
         if (matrix_wave) {
             if (!(p.ablate & 1)) {
                 if (fused_p2) {
@@ -1664,7 +1666,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <bool MFMA>
 __global__ __launch_bounds__(256) void pcl_hess_kernel(const KParams p) {
     extern __shared__ double lds[];
-    const int n = p.n, d = p.d, m = p.m, LD = p.LD, nc = p.nc;
+    const int n = p.n, d = p.cols, m = p.m, LD = p.LD, nc = p.nc;  // d: state columns here
     const int tid = threadIdx.x, nth = blockDim.x;
     const int k = blockIdx.x % p.K, b = blockIdx.x / p.K;
     const long long xd = (long long)n * d;
@@ -1826,6 +1828,53 @@ __global__ __launch_bounds__(256) void pcl_deriv_kernel(const double *__restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// Terminal unitary infidelity  Q * |1 - |tr(U_goal' U_N)|^2 / d^2|  and its gradient w.r.t. the terminal iso-vec
+// (reference: src/control/objectives.jl:330-356).  One workgroup per member / seed.
+// With X = [Re U; Im U] (n x d, column c at x[c*n ..]) and the goal stored the same way:
+//   t = tr(Ug' U) = sum (gr*ur + gi*ui) + i sum (gr*ui - gi*ur);  F = |t|^2 / d^2
+//   dF/dur = 2 (tr*gr - ti*gi) / d^2 ,  dF/dui = 2 (tr*gi + ti*gr) / d^2
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pcl_infidelity_kernel(const double *__restrict__ Z, const double *__restrict__ goal,
+                                                             const int *__restrict__ x_offs, double *__restrict__ value,
+                                                             double *__restrict__ grad, double Q, int d, int N, int z_dim,
+                                                             long long z_batch_stride) {
+    __shared__ double red[2][8];
+    const int n = 2 * d, b = blockIdx.x, tid = threadIdx.x;
+    const double *x = Z + (long long)b * z_batch_stride + (long long)(N - 1) * z_dim + x_offs[z_batch_stride ? 0 : b];
+    double tr = 0.0, ti = 0.0;
+    for (int e = tid; e < d * d; e += 256) {
+        const int c = e / d, i = e - c * d;
+        const double ur = x[c * n + i], ui = x[c * n + d + i], gr = goal[c * n + i], gi = goal[c * n + d + i];
+        tr += gr * ur + gi * ui;
+        ti += gr * ui - gi * ur;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        tr += __shfl_down(tr, off, 64);
+        ti += __shfl_down(ti, off, 64);
+    }
+    if ((tid & 63) == 0) {
+        red[0][tid >> 6] = tr;
+        red[1][tid >> 6] = ti;
+    }
+    __syncthreads();
+    tr = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    ti = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double inv = 1.0 / ((double)d * d);
+    const double F = (tr * tr + ti * ti) * inv;
+    const double sgn = (1.0 - F >= 0.0) ? 1.0 : -1.0;
+    if (tid == 0 && value) value[b] = Q * fabs(1.0 - F);
+    if (grad) {
+        double *g = grad + (long long)b * n * d;
+        for (int e = tid; e < d * d; e += 256) {
+            const int c = e / d, i = e - c * d;
+            const double gr = goal[c * n + i], gi = goal[c * n + d + i];
+            g[c * n + i] = -sgn * Q * 2.0 * (tr * gr - ti * gi) * inv;
+            g[c * n + d + i] = -sgn * Q * 2.0 * (tr * gi + ti * gr) * inv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Host side
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_create_error;
@@ -1833,6 +1882,7 @@ static thread_local std::string g_create_error;
 struct pcl_ctx {
     pcl_desc desc;
     int n, K;
+    int cols;  // state columns (d for unitaries, 1 for kets)
     long long x_dim;
     std::vector<int32_t> x_offs;
     int device;
@@ -1853,6 +1903,7 @@ struct pcl_ctx {
     int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_ablate = 0, opt_kernel = 0;  // 0 = auto (2 or 4 by work per workgroup)
     long long *ddbg = nullptr;
     void *comm = nullptr;  // ncclComm_t
+    double *dgoal = nullptr;  // iso-vec of the goal unitary (pcl_set_goal)
     // split mode (producer kernel + concurrent expander kernel)
     double *dblocks = nullptr;
     unsigned int *dflags = nullptr;
@@ -1889,7 +1940,7 @@ static int fail(const pcl_ctx *ctx, int code, const char *fmt, ...) {
     } while (0)
 
 static long long jac_per_full(const pcl_ctx *c) {
-    return 2LL * c->desc.d * c->n * c->n + c->x_dim * (c->desc.n_drives + 1);
+    return 2LL * c->cols * c->n * c->n + c->x_dim * (c->desc.n_drives + 1);
 }
 static long long jac_per_compact(const pcl_ctx *c) { return 2LL * c->n * c->n + c->x_dim * (c->desc.n_drives + 1); }
 static long long hess_per(const pcl_ctx *c) {
@@ -1933,7 +1984,9 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     if (dsc->batch_mode != PCL_BATCH_MEMBERS && dsc->batch_mode != PCL_BATCH_TRAJ)
         return fail(nullptr, PCL_EINVAL, "pcl_create: unknown batch_mode %d", dsc->batch_mode);
     if (!dsc->G0 || (m > 0 && !dsc->Gj) || !dsc->x_offs) return fail(nullptr, PCL_EINVAL, "pcl_create: G0/Gj/x_offs must be non-NULL");
-    const long long x_dim = 2LL * d * d;
+    const int cols = dsc->state_cols > 0 ? dsc->state_cols : d;
+    if (cols > d) return fail(nullptr, PCL_EINVAL, "pcl_create: state_cols=%d exceeds d=%d", cols, d);
+    const long long x_dim = 2LL * d * cols;
     const int n_off = dsc->batch_mode == PCL_BATCH_MEMBERS ? dsc->batch : 1;
     for (int i = 0; i < n_off; ++i)
         if (dsc->x_offs[i] < 0 || dsc->x_offs[i] + x_dim > dsc->z_dim)
@@ -1954,6 +2007,7 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     ctx->n = n;
     ctx->K = dsc->N - 1;
     ctx->x_dim = x_dim;
+    ctx->cols = cols;
     ctx->x_offs.assign(dsc->x_offs, dsc->x_offs + n_off);
     ctx->desc.x_offs = nullptr;
     ctx->desc.G0 = ctx->desc.Gj = nullptr;
@@ -2108,6 +2162,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
                     ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    if (ctx->dgoal) (void)hipFree(ctx->dgoal);
     if (ctx->dblocks) (void)hipFree(ctx->dblocks);
     if (ctx->dflags) (void)hipFree(ctx->dflags);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -2148,7 +2203,7 @@ static int jac_structure_impl(const pcl_ctx *ctx, I *rows, I *cols) {
     if (!ctx) return PCL_EINVAL;
     if (!rows || !cols) return fail(ctx, PCL_EINVAL, "pcl_jac_structure: NULL output");
     const pcl_desc &D = ctx->desc;
-    const long long n = ctx->n, d = D.d, m = D.n_drives, xd = ctx->x_dim, zd = D.z_dim, base = D.index_base;
+    const long long n = ctx->n, d = ctx->cols, m = D.n_drives, xd = ctx->x_dim, zd = D.z_dim, base = D.index_base;
     const long long per = jac_per_full(ctx);
     for (long long b = 0; b < D.batch; ++b) {
         const long long xo = ctx->x_offs[D.batch_mode == PCL_BATCH_MEMBERS ? b : 0];
@@ -2259,6 +2314,7 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.z_batch_stride = D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0;
     p.g0_batch_stride = D.per_member_G0 ? (long long)ctx->n * ctx->n : 0;
     p.d = D.d;
+    p.cols = ctx->cols;
     p.n = ctx->n;
     p.m = D.n_drives;
     p.K = ctx->K;
@@ -2298,7 +2354,7 @@ static bool ell_fits_lds(const pcl_ctx *ctx) {
 // arithmetic; but (i) two workgroups must fit in one CU's LDS so that one streams while the other
 // computes, and (ii) the grid has to cover the chip a few times over.
 static int choose_cols_per_slice(const pcl_ctx *ctx, bool jac) {
-    const int d = ctx->desc.d;
+    const int d = ctx->cols;
     if (ctx->opt_cols_per_slice > 0) return (int)std::min<int64_t>(ctx->opt_cols_per_slice, d);
     KParams p;
     memset(&p, 0, sizeof p);
@@ -2383,7 +2439,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     p.jac_per = compact ? jac_per_compact(ctx) : jac_per_full(ctx);
     const bool want_jac = jac != nullptr;
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
-    if (want_jac && ctx->opt_kernel == 3 && ctx->opt_use_mfma != 0 && v3_supported(ctx)) {  // (never chosen automatically)
+    if (want_jac && ctx->opt_kernel == 3 && ctx->opt_use_mfma != 0 && v3_supported(ctx) && ctx->cols == ctx->desc.d) {  // (never chosen automatically)
         p.nc = choose_cols_v3(ctx);
         p.ncw = v3_ncw(ctx, p.nc);
         p.tab_lds = 1;
@@ -2411,7 +2467,8 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     }
 not_v3:
     const bool v2 = (ctx->opt_kernel == 0 || ctx->opt_kernel >= 2) && ctx->opt_use_mfma != 0;
-    bool v4 = v2 && ctx->opt_kernel == 4 && want_jac;
+    const bool unitary = ctx->cols == ctx->desc.d;  // kernels 3, 4, 5 and the specialised instances assume X is n x d
+    bool v4 = v2 && ctx->opt_kernel == 4 && want_jac && unitary;
     p.nc = choose_cols_per_slice(ctx, want_jac);
     auto bytes = [&]() { return v2 ? fused2_lds_bytes(p, want_jac, p.ell_lds != 0) : fused_lds_bytes(p, want_jac); };
     size_t lds = bytes();
@@ -2420,7 +2477,7 @@ not_v3:
         lds = bytes();
     }
     if (lds > (size_t)ctx->max_lds) return fail(ctx, PCL_ESHAPE, "fused kernel needs %zu B of LDS (> %d)", lds, ctx->max_lds);
-    p.S = (p.d + p.nc - 1) / p.nc;
+    p.S = (p.cols + p.nc - 1) / p.nc;
     const long long grid = (long long)p.batch * p.K * p.S;
     if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "grid too large");
     if (v2) {
@@ -2430,17 +2487,17 @@ not_v3:
         kern_t kern = want_jac ? (wu == 1 ? (kern_t)pcl_fused_kernel_v2<true, 1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<true, 2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v2<true, -1, 0, 0, 0>)
                                : (wu == 1 ? (kern_t)pcl_fused_kernel_v2<false, 1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<false, 2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v2<false, -1, 0, 0, 0>);
         // shape-specialised instance (BASELINE config 3/4/5: three 3-level transmons, d = 27, six drives, 3-column slices)
-        if (want_jac && wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize) kern = (kern_t)pcl_fused_kernel_v2<true, 1, 27, 6, 3>;
+        if (want_jac && unitary && wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize) kern = (kern_t)pcl_fused_kernel_v2<true, 1, 27, 6, 3>;
         // auto: spreading an item's stores into the next item's phases pays once a workgroup walks several items
-        if (ctx->opt_kernel == 0 && want_jac && grid >= 4 * (long long)per_cu_guess * std::max(ctx->n_cu, 1)) v4 = true;
+        if (ctx->opt_kernel == 0 && want_jac && unitary && grid >= 4 * (long long)per_cu_guess * std::max(ctx->n_cu, 1)) v4 = true;
         if (v4) {
             kern = wu == 1 ? (kern_t)pcl_fused_kernel_v4<1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v4<2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v4<-1, 0, 0, 0>;
             if (wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize) kern = (kern_t)pcl_fused_kernel_v4<1, 27, 6, 3>;
         }
-        ctx->last_kernel = (v4 ? 40 : 20) + ((wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize && want_jac) ? 1 : 0);
+        ctx->last_kernel = (v4 ? 40 : 20) + ((unitary && wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize && want_jac) ? 1 : 0);
         int rc = set_lds_attr(ctx, (const void *)kern, want_jac ? 4 : 5, lds);  // wu is fixed per context
         if (rc != PCL_OK) return rc;
-        const bool split = ctx->opt_kernel == 5 && want_jac && !compact;
+        const bool split = ctx->opt_kernel == 5 && want_jac && !compact && unitary;
         if (split) {
             const long long n_bk = (long long)p.batch * p.K;
             if (!ctx->dblocks) {
@@ -2502,7 +2559,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
     p.mu = mu;
     p.hess = hess;
     // column chunk: as many columns as fit in half the LDS (two workgroups per CU)
-    p.nc = p.d;
+    p.nc = p.cols;
     while (p.nc > 1 && hess_lds_bytes(p) > (size_t)ctx->max_lds / 2) p.nc = (p.nc + 1) / 2;
     const size_t lds = hess_lds_bytes(p);
     if (lds > (size_t)ctx->max_lds)
@@ -2552,8 +2609,8 @@ extern "C" int pcl_jac_expand_dev(pcl_ctx *ctx, const double *compact, double *v
     if (!compact || !vals) return fail(ctx, PCL_EINVAL, "pcl_jac_expand_dev: NULL pointer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long n_bk = (long long)ctx->desc.batch * ctx->K;
-    const long long grid = n_bk * ctx->desc.d;
-    hipLaunchKernelGGL(pcl_expand_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, compact, vals, ctx->desc.d, ctx->n,
+    const long long grid = n_bk * ctx->cols;
+    hipLaunchKernelGGL(pcl_expand_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, compact, vals, ctx->cols, ctx->n,
                        ctx->desc.n_drives, n_bk, (int)ctx->opt_nt);
     HIP_TRY(ctx, hipGetLastError());
     return PCL_OK;
@@ -2692,6 +2749,28 @@ extern "C" int pcl_deriv_eval_jac(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, i
     (void)hipFree(dv);
     if (rc == PCL_EHIP) return fail(ctx, PCL_EHIP, "pcl_deriv_eval_jac: HIP error %s", hipGetErrorString(hipGetLastError()));
     return rc;
+}
+
+// --- terminal infidelity objective ----------------------------------------------
+extern "C" int pcl_set_goal(pcl_ctx *ctx, const double *goal_iso_vec) {
+    if (!ctx) return PCL_EINVAL;
+    if (!goal_iso_vec) return fail(ctx, PCL_EINVAL, "pcl_set_goal: NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->dgoal) HIP_TRY(ctx, hipMalloc((void **)&ctx->dgoal, (size_t)ctx->x_dim * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(ctx->dgoal, goal_iso_vec, (size_t)ctx->x_dim * sizeof(double), hipMemcpyHostToDevice));
+    return PCL_OK;
+}
+extern "C" int pcl_infidelity_dev(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || (!value && !grad)) return fail(ctx, PCL_EINVAL, "pcl_infidelity_dev: NULL pointer");
+    if (!ctx->dgoal) return fail(ctx, PCL_EINVAL, "pcl_infidelity_dev: call pcl_set_goal first");
+    if (ctx->cols != ctx->desc.d) return fail(ctx, PCL_ENOTIMPL, "pcl_infidelity_dev: unitary (n x d) states only");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const pcl_desc &D = ctx->desc;
+    hipLaunchKernelGGL(pcl_infidelity_kernel, dim3((unsigned)D.batch), dim3(256), 0, ctx->stream, Z, ctx->dgoal, ctx->dxoffs, value, grad, Q,
+                       D.d, D.N, D.z_dim, D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0LL);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCL_OK;
 }
 
 // --- RCCL sum-reduce of the shared-control payload -----------------------------

@@ -54,7 +54,7 @@ class _PclContext:
     """Owns one ``pcl_ctx`` (one GPU, one stream)."""
 
     def __init__(self, *, d, m, N, z_dim, u_off, dt_off, x_offs, G0, Gj, batch, batch_mode, per_member_G0=False,
-                 global_dim=0, device=0, index_base=0, pade_order=4):  # fmt: skip
+                 global_dim=0, device=0, index_base=0, pade_order=4, state_cols=0):  # fmt: skip
         self._L = _lib.load()
         self._h = None
         n = 2 * d
@@ -68,7 +68,7 @@ class _PclContext:
         desc = _lib.pcl_desc(
             struct_size=ctypes.sizeof(_lib.pcl_desc), d=d, n_drives=m, N=N, z_dim=z_dim, u_off=u_off, dt_off=dt_off,
             batch=batch, batch_mode=batch_mode, pade_order=pade_order, device_id=device, index_base=index_base,
-            per_member_G0=int(bool(per_member_G0)), reserved=0, global_dim=global_dim,
+            per_member_G0=int(bool(per_member_G0)), state_cols=state_cols, global_dim=global_dim,
             G0=g0.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
             Gj=gj.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
             x_offs=xo.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
@@ -212,6 +212,16 @@ class _PclContext:
     def deriv_eval_jac_dev(self, x_off, dx_off, dim, Z, delta, vals):
         self._chk(self._L.pcl_deriv_eval_jac_dev(self._h, x_off, dx_off, dim, _ptr(Z), _ptr(delta), _ptr(vals)))
 
+    # -- terminal infidelity objective on device ----------------------------------------------------------------
+    def set_goal(self, goal_iso_vec):
+        g = np.ascontiguousarray(goal_iso_vec, dtype=np.float64).reshape(-1)
+        if g.size != self.x_dim:
+            raise ValueError("goal iso-vec has %d entries, expected %d" % (g.size, self.x_dim))
+        self._chk(self._L.pcl_set_goal(self._h, _ptr(g)))
+
+    def infidelity_dev(self, Z, Q, value=None, grad=None):
+        self._chk(self._L.pcl_infidelity_dev(self._h, _ptr(Z), float(Q), _ptr(value), _ptr(grad)))
+
     # -- RCCL (C-ABI path; torch.distributed is the alternative plumbing, see distributed.py) ----------------
     def comm_unique_id(self):
         buf = ctypes.create_string_buffer(128)
@@ -257,8 +267,11 @@ class HipPadeIntegrator:
         for nm in x_names:
             if nm not in traj.components:
                 raise KeyError("trajectory has no component %r" % (nm,))
-            if len(traj.components[nm]) != 2 * d * d:
-                raise ValueError("component %r has dim %d, expected 2 d^2 = %d" % (nm, len(traj.components[nm]), 2 * d * d))
+        xlen = len(traj.components[x_names[0]])
+        if xlen % n or not (1 <= xlen // n <= d) or any(len(traj.components[nm]) != xlen for nm in x_names):
+            raise ValueError("state components must all have dim n*C with n = %d, 1 <= C <= d (unitary: C = d = %d, ket: C = 1); got %d"
+                             % (n, d, xlen))  # fmt: skip
+        cols = xlen // n
         if m and len(traj.components[u_name]) < m:
             raise ValueError("drive component %r has dim %d < n_drives = %d" % (u_name, len(traj.components[u_name]), m))
         self.x_names = x_names
@@ -270,7 +283,7 @@ class HipPadeIntegrator:
             d=d, m=m, N=traj.N, z_dim=traj.dim, u_off=traj.components[u_name].start,
             dt_off=traj.components[traj.timestep].start, x_offs=[traj.components[nm].start for nm in x_names],
             G0=G_drift, Gj=self.G_drives, batch=len(x_names), batch_mode=PCL_BATCH_MEMBERS, per_member_G0=per_member,
-            global_dim=traj.global_dim, device=device, index_base=index_base, pade_order=pade_order,
+            global_dim=traj.global_dim, device=device, index_base=index_base, pade_order=pade_order, state_cols=cols,
         )  # fmt: skip
         self.x_dim = self._ctx.x_dim * len(x_names) if len(x_names) > 1 else self._ctx.x_dim
         self.dim = self._ctx.n_rows
@@ -294,7 +307,7 @@ class HipPadeIntegrator:
         if self._f_ctx is None:
             self._f_ctx = _PclContext(d=c.d, m=c.m, N=2, z_dim=c.x_dim + 1 + c.m, u_off=c.x_dim + 1, dt_off=c.x_dim,
                                       x_offs=[0], G0=self.G_drift, Gj=self.G_drives, batch=1,
-                                      batch_mode=PCL_BATCH_MEMBERS)  # fmt: skip
+                                      batch_mode=PCL_BATCH_MEMBERS, state_cols=c.x_dim // c.n)  # fmt: skip
         z = np.zeros((2, c.x_dim + 1 + c.m))
         z[0, : c.x_dim], z[0, c.x_dim], z[0, c.x_dim + 1 :] = x, dt, np.asarray(u)[: c.m]
         z[1, : c.x_dim] = x_next
@@ -315,10 +328,14 @@ class HipPadeMultistart:
         G_drives = np.asarray(G_drives, dtype=np.float64)
         n = np.asarray(G_drift).shape[-1]
         m = G_drives.shape[0] if G_drives.size else 0
+        xlen = len(traj.components[x_name])
+        if xlen % n or not (1 <= xlen // n <= n // 2):
+            raise ValueError("state component %r has dim %d, expected n*C with n = %d" % (x_name, xlen, n))
         self._ctx = _PclContext(
             d=n // 2, m=m, N=traj.N, z_dim=traj.dim, u_off=traj.components[u_name].start,
             dt_off=traj.components[traj.timestep].start, x_offs=[traj.components[x_name].start], G0=G_drift,
             Gj=G_drives.reshape(m, n, n), batch=batch, batch_mode=PCL_BATCH_TRAJ, device=device, index_base=index_base,
+            state_cols=xlen // n,
         )  # fmt: skip
         self.batch = batch
         self.x_dim = self._ctx.x_dim

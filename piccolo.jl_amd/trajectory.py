@@ -20,6 +20,7 @@ import numpy as np
 from .quantum import operator_to_iso_vec
 
 STATE = "Ũ⃗"  # :Ũ⃗  (state_name of a UnitaryTrajectory)
+KET = "ψ̃"  # :ψ̃  (state_name of a KetTrajectory)
 TIMESTEP = "Δt"
 
 
@@ -171,3 +172,23 @@ def sampling_trajectory(systems, controls, times, U_goal, states=None, state_nam
         initial={nm: operator_to_iso_vec(np.eye(d)) for nm in names},
         goal={nm: operator_to_iso_vec(U_goal) for nm in names},
     )
+
+
+def ket_trajectory(system, controls, times, psi_init, psi_goal, states=None, n_derivs=2, state_name=KET):
+    """``NamedTrajectory(qtraj::KetTrajectory, N)``: components ``[psitilde, dt, t, u, du, ddu]`` with
+    ``psitilde = [Re psi; Im psi]`` [REF src/quantum/primitives/isomorphisms.jl:55;
+    src/quantum/trajectories/named_trajectory_conversion.jl]."""
+    from .quantum import ket_to_iso
+
+    times = np.asarray(times, float)
+    N = times.size
+    u = np.asarray(controls, float).reshape(system.n_drives, N)
+    if states is None:
+        states = [np.asarray(psi_init, complex)] * N
+    X = np.stack([ket_to_iso(s_) for s_ in states], axis=1)
+    dts = np.diff(times)
+    dts = np.concatenate((dts, dts[-1:])) if N > 1 else np.ones(1)
+    comps = OrderedDict([(state_name, X), (TIMESTEP, dts[None, :]), ("t", times[None, :]), ("u", u)])
+    traj = NamedTrajectory(comps, controls=(TIMESTEP, "u"), timestep=TIMESTEP,
+                           initial={state_name: ket_to_iso(psi_init)}, goal={state_name: ket_to_iso(psi_goal)})  # fmt: skip
+    return add_control_derivatives(traj, n_derivs) if n_derivs else traj

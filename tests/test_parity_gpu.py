@@ -505,3 +505,84 @@ def test_rccl_reduce_through_the_c_abi_single_rank():
     with pytest.raises(pa.PclError):
         c.comm_init(uid, 0, 1)  # already initialised
     c.close()
+
+
+def test_terminal_infidelity_objective_on_device():
+    """Q |1 - |tr(Ug' U_N)|^2/d^2| and its gradient, per seed, against the host formula
+    (piccolo.jl_amd/objectives.py, itself checked by finite differences here)."""
+    import torch
+
+    from piccolo_jl_amd.objectives import unitary_fidelity_loss, unitary_infidelity
+
+    rng = np.random.default_rng(12)
+    so = po.config_system(2)
+    d, Bn, N = so.levels, 3, 5
+    Zs, lay = [], None
+    for s_ in range(Bn):
+        Z, lay = po.synthetic_trajectory(so, N, seed=50 + s_, noise=5e-2)
+        Zs.append(Z)
+    t = traj_from_Z(pa, Zs[0], lay)
+    ms = pa.HipPadeMultistart(so.G_drift, np.array(so.G_drives), t, Bn)
+    Ug = pa.GATES["CX"] @ np.diag(np.exp(1j * rng.random(d)))
+    ms.ctx.set_goal(pa.operator_to_iso_vec(Ug))
+    Zd = torch.from_numpy(np.stack(Zs)).cuda()
+    val = torch.zeros(Bn, dtype=torch.float64, device="cuda")
+    grad = torch.zeros(Bn * lay.x_dim, dtype=torch.float64, device="cuda")
+    ms.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ms.ctx.infidelity_dev(Zd, 100.0, val, grad)
+    torch.cuda.synchronize()
+    for s_ in range(Bn):
+        x = Zs[s_][N - 1, : lay.x_dim]
+        f, g = unitary_infidelity(x, Ug, 100.0)
+        assert abs(val[s_].item() - f) < 1e-12 * max(1.0, f)
+        close(grad[s_ * lay.x_dim : (s_ + 1) * lay.x_dim].cpu().numpy(), g)
+        assert abs(f - 100.0 * abs(1 - unitary_fidelity_loss(x, Ug))) < 1e-12
+        eps = 1e-6
+        for i in (0, 5, lay.x_dim - 1):
+            xp, xm = x.copy(), x.copy()
+            xp[i] += eps
+            xm[i] -= eps
+            assert abs((unitary_infidelity(xp, Ug, 100.0)[0] - unitary_infidelity(xm, Ug, 100.0)[0]) / (2 * eps) - g[i]) < 1e-6
+    with pytest.raises(ValueError):
+        ms.ctx.set_goal(np.zeros(3))
+    ms.close()
+
+
+@pytest.mark.parametrize("d,m,N", [(2, 2, 8), (5, 2, 6), (27, 6, 4)])
+def test_ket_variant(d, m, N):
+    """BilinearIntegrator(qtraj::KetTrajectory, N) [REF src/control/integrators.jl:58-74]: the generator acts on one
+    iso-ket column (x_dim = 2d), no I_d (x) replication; every output against the oracle with cols = 1."""
+    rng = np.random.default_rng(100 + d)
+    n = 2 * d
+    Hd = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+    Hd = Hd + Hd.conj().T
+    Hs = []
+    for _ in range(m):
+        A = (rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))) * (rng.random((d, d)) < 0.4)
+        Hs.append(A + A.conj().T)
+    so = po.quantum_system(0.3 * Hd, Hs, [1.0] * m)
+    xd = n
+    z_dim = xd + 2 + 3 * m
+    lay = po.Layout(d=d, m=m, N=N, z_dim=z_dim, x_off=0, u_off=xd + 2, dt_off=xd, cols=1)
+    Z = 0.5 * rng.standard_normal((N, z_dim))
+    Z[:, lay.dt_off] = 0.05 + 0.05 * rng.random(N)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    psys = pa.QuantumSystem(so.H_drift, so.H_drives, [1.0] * m)
+    comps = {"ψ̃": Z[:, :xd].T, "Δt": Z[:, xd][None], "t": Z[:, xd + 1][None], "u": Z[:, xd + 2 : xd + 2 + m].T,
+             "du": Z[:, xd + 2 + m : xd + 2 + 2 * m].T, "ddu": Z[:, xd + 2 + 2 * m :].T}  # fmt: skip
+    traj = pa.NamedTrajectory(comps, controls=("ddu", "Δt"), timestep="Δt")
+    assert np.array_equal(traj.datavec, Z.reshape(-1))
+    B = pa.BilinearIntegrator(psys, traj, x_name="ψ̃")
+    assert B.x_dim == n and B.dim == n * (N - 1) and B.ctx.jac_per == 2 * n * n + n * (m + 1)
+    delta = pa.evaluate_(np.zeros(B.dim), B, traj)
+    close(delta, po.pade_residual(Z, lay, G0, Gj, 4), 1e-11)
+    d2, vals = B.ctx.eval_jac(traj.datavec)
+    close(d2, po.pade_residual(Z, lay, G0, Gj, 4), 1e-11)
+    close(vals, po.pade_jacobian_values(Z, lay, G0, Gj, 4), 1e-11)
+    r, c = pa.jacobian_structure(B)
+    r0, c0 = po.jac_structure(lay)
+    assert np.array_equal(r, r0) and np.array_equal(c, c0)
+    mu = rng.standard_normal((lay.K, lay.x_dim))
+    close(B.ctx.hess(traj.datavec, mu), po.pade4_hessian_values(Z, mu, lay, G0, Gj), 1e-10)
+    close(B.f(Z[2, :xd], Z[1, :xd], Z[1, xd + 2 : xd + 2 + m], Z[1, xd]), delta[n : 2 * n], 1e-11)
+    B.close()
