@@ -159,9 +159,10 @@ def main():
         "unit": "GB/s",
         "frac": abytes * B / kernel_s / 1e9 / HBM_PEAK_GBS,
         "traffic": None,
-        "kernel": {41: "pcl_fused_kernel_v4<1,27,6,3>", 40: "pcl_fused_kernel_v4<1,0,0,0>", 21: "pcl_fused_kernel_v2<true,1,27,6,3>",
+        "kernel": {31: "pcl_fused_kernel_v3<2,27,6,2>", 30: "pcl_fused_kernel_v3<2,0,0,0>", 41: "pcl_fused_kernel_v4<1,27,6,3>", 40: "pcl_fused_kernel_v4<1,0,0,0>", 21: "pcl_fused_kernel_v2<true,1,27,6,3>",
                    20: "pcl_fused_kernel_v2<true,1,0,0,0>"}.get(lk, "pcl_fused_kernel (id %d)" % lk)
-        + " (persistent; 2 workgroups/CU; 4 MFMA waves + 4 store-stream waves each)",
+        + (" (persistent; 1 workgroup/CU; 4 MFMA waves + 4 store-stream waves; one barrier per item)" if lk // 10 == 3 else
+           " (persistent; 2 workgroups/CU; 4 MFMA waves + 4 store-stream waves each)"),
         "kernel_us": kernel_s * 1e6,
         "algorithmic_bytes_per_launch": abytes * B,
     }

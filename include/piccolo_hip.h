@@ -40,8 +40,9 @@
  * jac_nnz_per_interval = 2*d*n*n + x_dim*(m+1) doubles, blocks ordered b-major then k:
  *     seg 0  d delta/d X_k      for c<d, j<n, i<n : -B^+[i,j]   row c*n+i, col x_off + c*n+j     (knot k)
  *     seg 1  d delta/d X_{k+1}  same loop          :  B^-[i,j]                                    (knot k+1)
- *     seg 2  d delta/d u_l      for l<m, r<x_dim                col u_off + l                     (knot k)
- *     seg 3  d delta/d dt       for r<x_dim                     col dt_off                        (knot k)
+ *     tail   for c<cols (state column): for l<m, i<n : d delta[c*n+i]/d u_l   col u_off + l         (knot k)
+ *                                       then   i<n : d delta[c*n+i]/d dt    col dt_off
+ *            (column-major: the (m+1)*n doubles one state column produces are contiguous -- full-line stores)
  * Hessian-of-Lagrangian values per (b,k), hess_nnz_per_interval = (m+1)(m+2)/2 + 2*x_dim*(m+1):
  *     seg 0 (u_i,u_j) j<=i | seg 1 (dt,u_j) | seg 2 (dt,dt) | seg 3 (u_l, X_k[r]) | seg 4 (dt, X_k[r])
  *     seg 5 (X_{k+1}[r], u_l) | seg 6 (X_{k+1}[r], dt)   -- each pair once, as (max index, min index).

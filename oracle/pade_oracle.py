@@ -410,8 +410,9 @@ def pade_residual(Z, lay: Layout, G0, Gj, order=4, x_off=None):
 # (the C ABI reports it through pcl_jac_structure):
 #   seg 0  d delta / d X_k      : for c in 0..d-1, for j in 0..n-1, for i in 0..n-1 : -B^+[i,j]
 #   seg 1  d delta / d X_{k+1}  : same loop                                          :  B^-[i,j]
-#   seg 2  d delta / d u_l      : for l in 0..m-1, for r in 0..x_dim-1
-#   seg 3  d delta / d dt       : for r in 0..x_dim-1
+#   tail   for c in 0..C-1 (state column):  for l in 0..m-1, for i in 0..n-1 : d delta[c*n+i] / d u_l ;
+#                                           then for i in 0..n-1            : d delta[c*n+i] / d dt
+#          (column-major: everything one state column produces is contiguous, (m+1)*n doubles)
 # row(delta_k[r]) = k*x_dim + r ;  col(comp i of knot k) = k*z_dim + i   (0-based)
 # --------------------------------------------------------------------------- #
 
@@ -439,12 +440,11 @@ def jac_structure(lay: Layout, x_off=None, index_base=0):
         rows[p : p + nb] = k * xd + blk_r
         cols[p : p + nb] = (k + 1) * zd + o + blk_c
         p += nb
-        for l in range(m):
-            rows[p : p + xd] = k * xd + r_all
-            cols[p : p + xd] = k * zd + lay.u_off + l
-            p += xd
-        rows[p : p + xd] = k * xd + r_all
-        cols[p : p + xd] = k * zd + lay.dt_off
+        for cc in range(d):
+            for l in range(m + 1):
+                rows[p : p + n] = k * xd + cc * n + np.arange(n)
+                cols[p : p + n] = k * zd + (lay.u_off + l if l < m else lay.dt_off)
+                p += n
     return rows + index_base, cols + index_base
 
 
@@ -469,17 +469,18 @@ def pade_jacobian_values(Z, lay: Layout, G0, Gj, order=4, x_off=None):
         out[k, p : p + nb] = np.tile(Bm.T.reshape(-1), d)
         p += nb
         Y = [((-1) ** j) * Xn - Xc for j in range(q + 1)]
+        tail = np.empty((d, m + 1, n))  # [state column][drive l | dt][row]
         for l in range(m):
             R = np.zeros_like(Xc)
             for j in range(1, q + 1):
                 dGj = sum(P[a] @ Gj[l] @ P[j - 1 - a] for a in range(j))
                 R += c[j] * h**j * (dGj @ Y[j])
-            out[k, p : p + xd] = R.T.reshape(-1)
-            p += xd
+            tail[:, l, :] = R.T
         R = np.zeros_like(Xc)
         for j in range(1, q + 1):
             R += j * c[j] * h ** (j - 1) * (P[j] @ Y[j])
-        out[k, p : p + xd] = R.T.reshape(-1)
+        tail[:, m, :] = R.T
+        out[k, p:] = tail.reshape(-1)
     return out
 
 

@@ -176,16 +176,24 @@ int pade_ref_eval_jac(int d, int m, int N, int z_dim, int x_off, int u_off, int 
                     memcpy(J0 + (size_t)c * nn, J0, sizeof(double) * nn);
                     memcpy(J1 + (size_t)c * nn, J1, sizeof(double) * nn);
                 }
-                double *Ju = J + 2 * (size_t)d * nn;
+                /* tail, column-major: for state column c: [d/du_0 .. d/du_{m-1} | d/ddt], n doubles each */
+                double *Jt = J + 2 * (size_t)d * nn;
                 for (int l = 0; l < m; ++l) {
                     csc_mm(n, d, &S[l], Sm, T1); /* G_l S      */
                     csc_mm(n, d, &S[l], GD, T2); /* G_l (G D)  */
                     csc_mm(n, d, &S[l], D, T3);  /* G_l D      */
                     gemm_nn(n, d, G, T3, T4);    /* G (G_l D)  */
-                    for (size_t i = 0; i < xd; ++i) Ju[(size_t)l * xd + i] = -c1 * T1[i] + c2 * (T2[i] + T4[i]);
+                    for (int c = 0; c < d; ++c)
+                        for (int i = 0; i < n; ++i) {
+                            const size_t e = (size_t)c * n + i;
+                            Jt[((size_t)c * (m + 1) + l) * n + i] = -c1 * T1[e] + c2 * (T2[e] + T4[e]);
+                        }
                 }
-                double *Jh = Ju + (size_t)m * xd;
-                for (size_t i = 0; i < xd; ++i) Jh[i] = -0.5 * GS[i] + (h / 6.0) * G2D[i];
+                for (int c = 0; c < d; ++c)
+                    for (int i = 0; i < n; ++i) {
+                        const size_t e = (size_t)c * n + i;
+                        Jt[((size_t)c * (m + 1) + m) * n + i] = -0.5 * GS[e] + (h / 6.0) * G2D[e];
+                    }
             }
         }
         free(G);

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
         const double gs = W1[i + LD * c], g2d = G2D[i + LD * c];
         const long long r = (long long)(c0 + c) * n + i;
         if (p.delta) p.delta[bk * xd + r] = M1[i + LD * (nc + c)] - c1 * gs + c2 * g2d;
-        if (JAC) jb[2 * blk + (long long)m * xd + r] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
+        if (JAC) jb[2 * blk + ((long long)(c0 + c) * (m + 1) + m) * n + i] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
     }
     if (JAC) {
         for (int e = tid; e < ((p.ablate & 4) ? 0 : m * nce * n); e += nth) {
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
             const int *rp = p.csr_ptr + l * (n + 1);
             double acc = 0.0;
             for (int q = rp[i]; q < rp[i + 1]; ++q) acc += p.csr_val[q] * T[p.csr_col[q] + LD * c];
-            jb[2 * blk + (long long)l * xd + (long long)(c0 + c) * n + i] = acc + c2 * W1[i + LD * ((2 + l) * nc + c)];
+            jb[2 * blk + ((long long)(c0 + c) * (m + 1) + l) * n + i] = acc + c2 * W1[i + LD * ((2 + l) * nc + c)];
         }
 
         // ---- replicated diagonal blocks: stream -B^+ and B^- ---------------------------------
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
                 if (lb == 0) {
                     const double gs = W1[ri + LD * c], g2d = G2D[ri + LD * c];
                     if (p.delta) p.delta[bk * xd + r] = M1[ri + LD * (nc + c)] - c1 * gs + c2 * g2d;
-                    if (JAC) jb[2 * blk + (long long)m * xd + r] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
+                    if (JAC) jb[2 * blk + ((long long)(c0 + c) * (m + 1) + m) * n + ri] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
                 } else {
                     const int l = lb - 1;
                     const int base = (l * n + ri) * ew;
@@ -710,7 +711,7 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
                             acc += p.ell_val[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
                         }
                     }
-                    jb[2 * blk + (long long)l * xd + r] = acc + c2 * W1[ri + LD * (nc + cl)];
+                    jb[2 * blk + ((long long)(c0 + c) * (m + 1) + l) * n + ri] = acc + c2 * W1[ri + LD * (nc + cl)];
                 }
             }
         }
@@ -932,7 +933,7 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v4(const KParams p) {
                     if (lb == 0) {
                         const double gs = W1[ri + LD * c], g2d = G2D[ri + LD * c];
                         if (p.delta) p.delta[bk * xd + r] = M1[ri + LD * (nc + c)] - c1 * gs + c2 * g2d;
-                        jb[2 * blk + (long long)m * xd + r] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
+                        jb[2 * blk + ((long long)(c0 + c) * (m + 1) + m) * n + ri] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
                     } else {
                         const int l = lb - 1;
                         const int base = (l * n + ri) * ew;
@@ -948,7 +949,7 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v4(const KParams p) {
                                 acc += p.ell_val[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
                             }
                         }
-                        jb[2 * blk + (long long)l * xd + r] = acc + c2 * W1[ri + LD * (nc + cl)];
+                        jb[2 * blk + ((long long)(c0 + c) * (m + 1) + l) * n + ri] = acc + c2 * W1[ri + LD * (nc + cl)];
                     }
                 }
             }
@@ -1277,7 +1278,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0), h6 = h * (1.0 / 6.0);
             const long long bk = (long long)b * p.K + k;
             double *jb = p.jac + bk * p.jac_per;
-            double *ju = jb + 2 * blk, *jh = ju + (long long)m * xd;
+            double *jt = jb + 2 * blk;  // tail: for column c: [d/du_0 .. d/du_{m-1} | d/ddt], n doubles each
 
             const int nchunk = (nce + ncw - 1) / ncw;
             int stamp = 0;
@@ -1486,13 +1487,13 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                     const long long o0 = (long long)cc0 * n;
                     for (int e2 = lane; e2 < ((p.ablate & 32) ? 0 : ncc * hn2); e2 += 64) {
                         const int c = e2 / hn2, r0 = 2 * (e2 - c * hn2);
-                        const long long o = o0 + (long long)c * n + r0;
-                        if (p.delta) store2(p.delta + bk * xd + o, G2Dw[r0 + LD * c], G2Dw[r0 + 1 + LD * c], false);
-                        store2(jh + o, GSw[r0 + LD * c], GSw[r0 + 1 + LD * c], false);
+                        if (p.delta) store2(p.delta + bk * xd + o0 + (long long)c * n + r0, G2Dw[r0 + LD * c], G2Dw[r0 + 1 + LD * c], false);
+                        double *tc = jt + (long long)(cc0 + c) * (m + 1) * n + r0;  // this column's (m+1)*n tail block
                         for (int l = 0; l < m; ++l) {
                             const double *src = Mw + LD * (2 * ncw + l * ncw + c) + r0;
-                            store2(ju + (long long)l * xd + o, src[0], src[1], false);
+                            store2(tc + (long long)l * n, src[0], src[1], false);
                         }
+                        store2(tc + (long long)m * n, GSw[r0 + LD * c], GSw[r0 + 1 + LD * c], false);
                     }
                 }
                 wave_lds_sync();  // the chunk buffers are rewritten by this wave's next chunk
@@ -1900,7 +1901,7 @@ struct pcl_ctx {
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dmu = nullptr, *ddelta = nullptr, *dvals = nullptr, *dhess = nullptr;
     // options
-    int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_ablate = 0, opt_kernel = 0;  // 0 = auto (2 or 4 by work per workgroup)
+    int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_ablate = 0, opt_kernel = 0;  // 0 = auto: 3 when it applies, else 4 / 2 by work per workgroup
     long long *ddbg = nullptr;
     void *comm = nullptr;  // ncclComm_t
     double *dgoal = nullptr;  // iso-vec of the goal unitary (pcl_set_goal)
@@ -2221,13 +2222,14 @@ static int jac_structure_impl(const pcl_ctx *ctx, I *rows, I *cols) {
                             c[p] = (I)(cb + cc * n + j);
                         }
             }
-            for (long long l = 0; l <= m; ++l) {
-                const long long col = voff + k * zd + (l < m ? D.u_off + l : D.dt_off) + base;
-                for (long long q = 0; q < xd; ++q, ++p) {
-                    r[p] = (I)(r0 + q);
-                    c[p] = (I)col;
+            for (long long cc = 0; cc < d; ++cc)  // tail: per state column, the m drive blocks then the dt block
+                for (long long l = 0; l <= m; ++l) {
+                    const long long col = voff + k * zd + (l < m ? D.u_off + l : D.dt_off) + base;
+                    for (long long i = 0; i < n; ++i, ++p) {
+                        r[p] = (I)(r0 + cc * n + i);
+                        c[p] = (I)col;
+                    }
                 }
-            }
         }
     }
     return PCL_OK;
@@ -2391,16 +2393,19 @@ static size_t fused3_lds_bytes(const pcl_ctx *ctx, const KParams &p, bool tab) {
     return (bytes + 7) / 8 * 8 + 128;  // slack: operand tiles may be read past the last buffer's edge
 }
 
-// v3 cost model (one workgroup per CU; item time = max(store stream, matrix work)): picks the slice width nc.
+// v3 cost model: one workgroup per CU walks ceil(items / CUs) items; an item costs max(store stream, matrix work).
+// Constants are the measured config-3 phase times (scripts/phase_timing.py, with the stream running): ~7 us per
+// 2-column chunk, ~4 us for G(u) + G^2, stream at ~0.85 of the CU's fair HBM share; other shapes scale by MFMA count.
 static int choose_cols_v3(const pcl_ctx *ctx) {
     const int d = ctx->desc.d, n = ctx->n, m = ctx->desc.n_drives;
     if (ctx->opt_cols_per_slice > 0) return (int)std::min<int64_t>(ctx->opt_cols_per_slice, d);
-    const double bw_cu = 6.3e12 / std::max(ctx->n_cu, 1);  // achievable HBM bytes/s per CU when all CUs stream
-    const double clk = 2.0e9;
+    const double bw_cu = 0.85 * 6.3e12 / std::max(ctx->n_cu, 1);
     const long long bk = (long long)ctx->desc.batch * ctx->K;
     const int rt = (n + 15) / 16, ks = (n + 3) / 4;
     const int g2ct = ctx->iso ? (d + 15) / 16 : (n + 15) / 16;
-    int best = d;
+    const double t_chunk = 7.0e-6 * (rt * ks) / (4.0 * 14.0);
+    const double t_build = 4.0e-6 * (((rt + 3) / 4) * ((g2ct + 1) / 2) * ks) / 14.0;
+    std::vector<double> tt(d + 1, 1e300);
     double best_t = 1e300;
     for (int nc = 1; nc <= d; ++nc) {
         const int ncw = v3_ncw(ctx, nc);
@@ -2408,15 +2413,16 @@ static int choose_cols_v3(const pcl_ctx *ctx) {
         const double rounds = (double)((bk * S + ctx->n_cu - 1) / std::max(ctx->n_cu, 1));
         const double t_stream = 2.0 * nc * n * n * 8.0 / bw_cu;
         const int chunks_per_wave = ((nc + ncw - 1) / ncw + 3) / 4;
-        const double t_build = ((rt + 3) / 4) * (double)g2ct * ks * 72.0 / clk + 0.5e-6;
-        const double t_chunk = rt * ks * 72.0 / clk + 2.0e-6;
         const double t_matrix = t_build + chunks_per_wave * t_chunk;
-        const double t = rounds * std::max(t_stream, t_matrix) + t_build + 1.0e-6;
-        if (t < best_t) {
-            best_t = t;
-            best = nc;
-        }
+        // a ragged last slice (d % nc != 0) leaves workgroups with unequal items: charge the mean fill
+        const double fill = (double)d / (double)(S * nc);
+        tt[nc] = rounds * std::max(t_stream, t_matrix) / std::sqrt(std::max(fill, 0.25)) + 2.0 * t_build;
+        best_t = std::min(best_t, tt[nc]);
     }
+    // among near-ties take the narrowest slice (more, smaller items balance better across the CUs)
+    int best = d;
+    for (int nc = d; nc >= 1; --nc)
+        if (tt[nc] <= 1.06 * best_t) best = nc;
     return best;
 }
 
@@ -2439,7 +2445,8 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     p.jac_per = compact ? jac_per_compact(ctx) : jac_per_full(ctx);
     const bool want_jac = jac != nullptr;
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
-    if (want_jac && ctx->opt_kernel == 3 && ctx->opt_use_mfma != 0 && v3_supported(ctx) && ctx->cols == ctx->desc.d) {  // (never chosen automatically)
+    if (want_jac && !compact && (ctx->opt_kernel == 3 || ctx->opt_kernel == 0) && ctx->opt_use_mfma != 0 && v3_supported(ctx) &&
+        ctx->cols == ctx->desc.d) {  // the default whenever its LDS budget fits (else kernels 2 / 4 below)
         p.nc = choose_cols_v3(ctx);
         p.ncw = v3_ncw(ctx, p.nc);
         p.tab_lds = 1;
@@ -2894,7 +2901,8 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
     else if (!strcmp(key, "nt_stores"))
         *v = ctx->opt_nt;
     else if (!strcmp(key, "effective_cols_per_slice"))
-        *v = (ctx->opt_kernel == 3 && ctx->opt_use_mfma && v3_supported(ctx)) ? choose_cols_v3(ctx) : choose_cols_per_slice(ctx, true);
+        *v = ((ctx->opt_kernel == 3 || ctx->opt_kernel == 0) && ctx->opt_use_mfma && v3_supported(ctx) && ctx->cols == ctx->desc.d) ? choose_cols_v3(ctx)
+                                                                                                                                 : choose_cols_per_slice(ctx, true);
     else if (!strcmp(key, "n_cu"))
         *v = ctx->n_cu;
     else if (!strcmp(key, "kernel_version"))

@@ -39,28 +39,28 @@ def init_process_group(backend=None):
     return dist
 
 
-def jacobian_views(vals, batch, K, d, m):
-    """Views into the Jacobian value buffer (order: include/piccolo_hip.h): returns
-    (ju [batch, K, m, x_dim], jh [batch, K, x_dim]) without copying."""
-    n, xd = 2 * d, 2 * d * d
-    per = 2 * d * n * n + xd * (m + 1)
+def jacobian_views(vals, batch, K, d, m, cols=None):
+    """View into the Jacobian value buffer (order: include/piccolo_hip.h): the tail as
+    ``[batch, K, cols, m+1, n]`` (state column, drive l or dt at index m, row) without copying."""
+    C = d if cols is None else cols
+    n = 2 * d
+    per = 2 * C * n * n + n * C * (m + 1)
     v = vals.view(batch, K, per)
-    tail = v[:, :, 2 * d * n * n :]
-    return tail[:, :, : m * xd].reshape(batch, K, m, xd), tail[:, :, m * xd :]
+    return v[:, :, 2 * C * n * n :].reshape(batch, K, C, m + 1, n)
 
 
-def constraint_merit_and_shared_gradient(delta, vals, batch, K, d, m, weights=None):
+def constraint_merit_and_shared_gradient(delta, vals, batch, K, d, m, weights=None, cols=None):
     """phi = sum_i w_i/2 |delta_i|^2 over this rank's members and its gradient with respect to the
     shared variables: g_u[k, l] = sum_i w_i <d delta_ik / d u_l, delta_ik>, g_dt[k] likewise.
     Works on any device (torch ops on views of the evaluator's output buffers)."""
-    xd = 2 * d * d
-    dl = delta.view(batch, K, xd)
+    C = d if cols is None else cols
+    n = 2 * d
+    dl = delta.view(batch, K, C, n)
     w = torch.ones(batch, dtype=delta.dtype, device=delta.device) if weights is None else weights.to(delta)
-    ju, jh = jacobian_views(vals, batch, K, d, m)
-    phi = 0.5 * torch.einsum("b,bkr,bkr->", w, dl, dl)
-    g_u = torch.einsum("b,bklr,bkr->kl", w, ju, dl)
-    g_dt = torch.einsum("b,bkr,bkr->k", w, jh, dl)
-    return phi, g_u, g_dt
+    tail = jacobian_views(vals, batch, K, d, m, cols)
+    phi = 0.5 * torch.einsum("b,bkci,bkci->", w, dl, dl)
+    g = torch.einsum("b,bkcli,bkci->kl", w, tail, dl)  # [K, m+1]
+    return phi, g[:, :m].contiguous(), g[:, m].contiguous()
 
 
 def reduce_merit_and_gradient(phi, g_u, g_dt, dist=None):

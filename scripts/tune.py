@@ -13,7 +13,7 @@ ap.add_argument("--nc", type=int, nargs="+", default=[0])
 ap.add_argument("--nt", type=int, nargs="+", default=[0])
 ap.add_argument("--mfma", type=int, nargs="+", default=[1])
 ap.add_argument("--ablate", type=int, nargs="+", default=[0])
-ap.add_argument("--kernel", type=int, nargs="+", default=[3])
+ap.add_argument("--kernel", type=int, nargs="+", default=[0])
 ap.add_argument("--grid", type=int, nargs="+", default=[0])
 ap.add_argument("--specialize", type=int, nargs="+", default=[1])
 ap.add_argument("--cpp", type=int, nargs="+", default=[6])

@@ -80,10 +80,11 @@ def test_jacobian_views_match_layout():
     n, xd = 2 * d, 2 * d * d
     per = 2 * d * n * n + xd * (m + 1)
     vals = torch.arange(B * K * per, dtype=torch.float64)
-    ju, jh = pd.jacobian_views(vals, B, K, d, m)
-    assert ju.shape == (B, K, m, xd) and jh.shape == (B, K, xd)
-    assert ju[1, 2, 1, 3].item() == (1 * K + 2) * per + 2 * d * n * n + 1 * xd + 3
-    assert jh[0, 1, 5].item() == 1 * per + 2 * d * n * n + m * xd + 5
+    tail = pd.jacobian_views(vals, B, K, d, m)
+    assert tail.shape == (B, K, d, m + 1, n)
+    # (b=1, k=2, column c=1, drive l=1, row i=3) and the dt block (index m) of (b=0, k=1, c=0, i=2)
+    assert tail[1, 2, 1, 1, 3].item() == (1 * K + 2) * per + 2 * d * n * n + (1 * (m + 1) + 1) * n + 3
+    assert tail[0, 1, 0, m, 2].item() == 1 * per + 2 * d * n * n + (0 * (m + 1) + m) * n + 2
 
 
 def test_world2_gloo_reduce_equals_unsharded(tmp_path):

@@ -297,8 +297,15 @@ def test_compact_and_expand(config3_full):
     c.jac_expand_dev(cd, fd)
     torch.cuda.synchronize()
     assert c.compact_per == 2 * lay.n**2 + lay.x_dim * (lay.m + 1)
-    assert np.array_equal(dd.cpu().numpy(), delta)
-    assert np.array_equal(fd.cpu().numpy(), vals)
+    # the compact producer and the default fused kernel are different code paths: equal to rounding
+    close(dd.cpu().numpy(), delta)
+    close(fd.cpu().numpy(), vals)
+    # the expansion itself is exact replication of the unique tiles and a verbatim copy of the tail
+    nn, d, K = lay.n**2, lay.d, lay.K
+    F = fd.cpu().numpy().reshape(K, -1)
+    Cc = cd.cpu().numpy().reshape(K, -1)
+    assert np.array_equal(F[:, : 2 * d * nn].reshape(K, 2, d, nn), np.broadcast_to(Cc[:, : 2 * nn].reshape(K, 2, 1, nn), (K, 2, d, nn)))
+    assert np.array_equal(F[:, 2 * d * nn :], Cc[:, 2 * nn :])
     c.close()
 
 
