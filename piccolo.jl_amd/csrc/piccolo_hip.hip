@@ -2399,7 +2399,7 @@ static size_t fused3_lds_bytes(const pcl_ctx *ctx, const KParams &p, bool tab) {
 static int choose_cols_v3(const pcl_ctx *ctx) {
     const int d = ctx->desc.d, n = ctx->n, m = ctx->desc.n_drives;
     if (ctx->opt_cols_per_slice > 0) return (int)std::min<int64_t>(ctx->opt_cols_per_slice, d);
-    const double bw_cu = 0.85 * 6.3e12 / std::max(ctx->n_cu, 1);
+    const double hbm = 0.85 * 6.3e12;  // store-stream rate the kernel sustains chip-wide
     const long long bk = (long long)ctx->desc.batch * ctx->K;
     const int rt = (n + 15) / 16, ks = (n + 3) / 4;
     const int g2ct = ctx->iso ? (d + 15) / 16 : (n + 15) / 16;
@@ -2410,13 +2410,21 @@ static int choose_cols_v3(const pcl_ctx *ctx) {
     for (int nc = 1; nc <= d; ++nc) {
         const int ncw = v3_ncw(ctx, nc);
         const long long S = (d + nc - 1) / nc;
-        const double rounds = (double)((bk * S + ctx->n_cu - 1) / std::max(ctx->n_cu, 1));
-        const double t_stream = 2.0 * nc * n * n * 8.0 / bw_cu;
+        const long long items = bk * S, ncu = std::max(ctx->n_cu, 1);
         const int chunks_per_wave = ((nc + ncw - 1) / ncw + 3) / 4;
         const double t_matrix = t_build + chunks_per_wave * t_chunk;
+        const double item_bytes = 2.0 * nc * n * n * 8.0;
+        // rounds of up to n_cu items; the HBM rate is shared by the workgroups active in the round (a lone CU tops out
+        // at a few times its fair share)
+        double t = 0.0;
+        for (long long left = items; left > 0; left -= ncu) {
+            const double active = (double)std::min(left, ncu);
+            const double rate = std::min(hbm / active, 3.0 * hbm / (double)ncu);
+            t += std::max(item_bytes / rate, t_matrix);
+        }
         // a ragged last slice (d % nc != 0) leaves workgroups with unequal items: charge the mean fill
         const double fill = (double)d / (double)(S * nc);
-        tt[nc] = rounds * std::max(t_stream, t_matrix) / std::sqrt(std::max(fill, 0.25)) + 2.0 * t_build;
+        tt[nc] = t / std::sqrt(std::max(fill, 0.25)) + 2.0 * t_build;
         best_t = std::min(best_t, tt[nc]);
     }
     // among near-ties take the narrowest slice (more, smaller items balance better across the CUs)
