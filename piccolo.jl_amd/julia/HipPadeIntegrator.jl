@@ -27,7 +27,7 @@ const LIB = get(ENV, "PICCOLO_HIP_LIB", "libpiccolo_hip.so")
 struct PclDesc
     struct_size::Int32; d::Int32; n_drives::Int32; N::Int32; z_dim::Int32
     u_off::Int32; dt_off::Int32; batch::Int32; batch_mode::Int32; pade_order::Int32
-    device_id::Int32; index_base::Int32; per_member_G0::Int32; reserved::Int32
+    device_id::Int32; index_base::Int32; per_member_G0::Int32; state_cols::Int32
     global_dim::Int64
     G0::Ptr{Float64}; Gj::Ptr{Float64}; x_offs::Ptr{Int32}
 end
