@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the batch-1 (single trajectory) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the Hessian / compact / host-delivered / config-2 rates")
     args = ap.parse_args()
 
     import torch
@@ -186,6 +187,52 @@ def main():
             "kernel_id": lk1,
             "hbm_GBps": abytes / (d1 / st) / 1e9,
         }
+    if rank == 0 and world == 1 and not args.no_extras:
+        # the other rates of the same path, reported beside the headline (never as `value`)
+        ex = {}
+        st = max(20, min(args.steps, 100))
+        ms = pa.HipPadeMultistart(G0, Gj, t0, B, device=local)
+        c = ms.ctx
+        c.set_stream(stream.cuda_stream)
+        Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()
+        dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
+        mu = torch.randn(c.n_rows, dtype=torch.float64, device="cuda")
+        hv = torch.empty(c.hess_nnz, dtype=torch.float64, device="cuda")
+        w, dv = time_steps(lambda: c.hess_dev(Zd, mu, hv), st, 5, torch, None)
+        ex["hessian_of_lagrangian"] = {"evals_per_s": B * st / w, "us_per_eval_kernel": dv / st / B * 1e6, "batch": B,
+                                       "nnz_per_eval": c.hess_nnz // B}
+        cv = torch.empty(c.compact_nnz, dtype=torch.float64, device="cuda")
+        w, dv = time_steps(lambda: c.eval_jac_compact_dev(Zd, dd, cv), st, 5, torch, None)
+        ex["compact_jacobian"] = {"evals_per_s": B * st / w, "us_per_eval_kernel": dv / st / B * 1e6, "batch": B,
+                                  "values_per_eval": c.compact_nnz // B}
+        w, dv = time_steps(lambda: c.eval_dev(Zd, dd), st, 5, torch, None)
+        ex["residual_only"] = {"evals_per_s": B * st / w, "us_per_eval_kernel": dv / st / B * 1e6, "batch": B}
+        ms.close()
+        del Zd, dd, mu, hv, cv
+        # host-delivered: the host-pointer entry point (H2D of Z, kernel, D2H of delta + 132.8 MB of values), one trajectory
+        it = pa.HipPadeIntegrator(G0, Gj, t0, device=local)
+        hd = np.empty(it.ctx.n_rows)
+        hvals = np.empty(it.ctx.jac_nnz)
+        it.ctx.eval_jac(t0.datavec, hd, hvals)
+        th = time.perf_counter()
+        for _ in range(5):
+            it.ctx.eval_jac(t0.datavec, hd, hvals)
+        th = (time.perf_counter() - th) / 5
+        ex["host_delivered"] = {"evals_per_s": 1.0 / th, "ms_per_eval": th * 1e3, "GBps_over_pcie": hvals.nbytes / th / 1e9,
+                                "note": "pageable numpy buffers"}
+        it.close()
+        # BASELINE config 2 (CNOT, d=4, N=100): launch-bound, report us/eval
+        s2 = synthetic.config_system(2)
+        t2 = synthetic.synthetic_trajectory(s2, 100, seed=20260929 + 2)
+        i2 = pa.HipPadeIntegrator(s2.G_drift, s2.G_drives_array(), t2, device=local)
+        i2.ctx.set_stream(stream.cuda_stream)
+        Z2 = torch.from_numpy(t2.datavec).cuda()
+        d2 = torch.empty(i2.ctx.n_rows, dtype=torch.float64, device="cuda")
+        v2 = torch.empty(i2.ctx.jac_nnz, dtype=torch.float64, device="cuda")
+        w, dv = time_steps(lambda: i2.ctx.eval_jac_dev(Z2, d2, v2), 200, 20, torch, None)
+        ex["config2_cnot"] = {"evals_per_s": 200 / w, "us_per_eval_wall": w / 200 * 1e6, "us_per_eval_kernel": dv / 200 * 1e6}
+        i2.close()
+        out["other_rates"] = ex
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             from oracle import pade_oracle as po

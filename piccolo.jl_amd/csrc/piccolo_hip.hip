@@ -60,6 +60,12 @@ struct KParams {
     const unsigned char *uell_l;  // per union entry: up to uell_w (drive index, value) pairs, zero padded
     const double *uell_v;
     int uell_w;
+    const double *ellt_val;  // ELL form of the transposed drives G_l^T: [m][n][ellt_w]
+    const int *ellt_col;
+    int ellt_w;
+    const double *ug0;    // [n_upos] drift value at each union-pattern entry (first / shared drift)
+    double *hpart;        // Hessian v2: per (b,k,slice) partial scalar entries
+    unsigned int *hcnt;   // Hessian v2: per (b,k) arrival counter (self-resetting)
     long long *dbg;  // optional: cycle stamps of workgroup 0 / matrix wave 0 (option debug_timing)
     int ncw;      // v3: state columns per matrix-wave chunk ((2+m)*ncw <= 16)
     int tab_lds;  // v3: union / ELL tables staged in LDS
@@ -1797,6 +1803,395 @@ __global__ __launch_bounds__(256) void pcl_hess_kernel(const KParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Hessian-of-Lagrangian kernel, version 2 (default when every drive row / column has <= EW entries and m <= 6):
+// persistent workgroups (2 per CU, 4 wavefronts each) over work items (b, k, slice of <= 16 state columns).
+// Per item the four waves work wave-synchronously on chunks of NCW = 16/(m+1) columns:
+//     operand tile  [M | P_1 .. P_m],  P_l = G_l^T M  (ELL rows of G_l^T in registers, lane = row)
+//     one pass of the f64 matrix cores:  G^T [M | P_l] = [A1 | Q_l]
+//     R_l = G_l^T A1, E_l = G_l D (registers)  ->  the d2/du dX vectors straight to HBM
+//     the (m+1)(m+2)/2 - 1 scalar entries that involve u as per-lane partial sums in registers:
+//         <M,(G_i G_j + G_j G_i) D> = <P_i,E_j> + <P_j,E_i>,   <M,G_j S> = <P_j,S>,
+//         <M,(G_j G + G G_j) D> = <Q_j,D> + <A1,E_j>
+// then, once per item: A2 = G^T A1 for all the slice's columns in ONE matrix-core pass (wave w = row tile w),
+// the d2/dh dX vectors, <A2,D>, and a fixed-order reduction lane -> wave -> workgroup -> (slices of the interval,
+// summed by the last slice to arrive: partial sums in `hpart`, arrival counter in `hcnt`) -> deterministic.
+// No G^2, no G D product: every contraction with D is moved onto M's side.
+// LDS map (doubles): G [LD*n] | A1s [LD*16] | A2s [LD*16] | Ds [LD*16] | per wave Mw [LD*16] | wsum [4][NSC] | wsum2 [4] | flag
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a DPP row, the same bits in every lane of the row (xor 1, xor 2, half mirror, mirror)
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return v;
+}
+
+// TD: compile-time Hilbert dimension (0 = run-time).  ANTI: every G_l is exactly antisymmetric (G = iso(-iH) with H
+// Hermitian), so the rows of G_l^T are minus the rows of G_l and one ELL table serves both.
+template <int EW, int TM, int TD, bool ANTI>
+__global__ __launch_bounds__(256, 2) void pcl_hess_kernel_v2(const KParams p) {
+    extern __shared__ double lds[];
+    constexpr int m = TM;
+    constexpr int NCW = 16 / (TM + 1);
+    constexpr int NSC = (TM + 1) * (TM + 2) / 2;
+    constexpr int NPAIR = TM * (TM + 1) / 2;
+    constexpr int NACC = NPAIR + TM;
+    const int n = TD ? 2 * TD : p.n, d = p.cols, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nn = n * n;
+    const long long xd = (long long)n * d;
+    const int kfull = n >> 2, krem = n & 3;
+
+    double *G = lds;
+    double *A1s = G + LD * n;
+    double *A2s = A1s + LD * 16;
+    double *Ds = A2s + LD * 16;
+    double *Mw = Ds + LD * 16 + wave * (LD * 16);
+    double *wsum = Ds + LD * 16 + 4 * (LD * 16);
+    double *wsum2 = wsum + 4 * NSC;
+    int *lastflag = reinterpret_cast<int *>(wsum2 + 4);
+
+    // ELL rows of G_l (er) and of G_l^T (et) for row = lane
+    constexpr int TE = ANTI ? 1 : TM;  // the transposed table is only held when it differs from minus the plain one
+    unsigned short er_c[TM][EW], et_c_[TE][EW];
+    double er_v[TM][EW], et_v_[TE][EW];
+#pragma unroll
+    for (int l = 0; l < TM; ++l)
+#pragma unroll
+        for (int q = 0; q < EW; ++q) {
+            er_c[l][q] = 0;
+            er_v[l][q] = 0.0;
+            if (!ANTI) {
+                et_c_[ANTI ? 0 : l][q] = 0;
+                et_v_[ANTI ? 0 : l][q] = 0.0;
+            }
+            if (lane < n) {
+                if (q < p.ell_w) {
+                    er_c[l][q] = (unsigned short)p.ell_col[(l * n + lane) * p.ell_w + q];
+                    er_v[l][q] = p.ell_val[(l * n + lane) * p.ell_w + q];
+                }
+                if (!ANTI && q < p.ellt_w) {
+                    et_c_[ANTI ? 0 : l][q] = (unsigned short)p.ellt_col[(l * n + lane) * p.ellt_w + q];
+                    et_v_[ANTI ? 0 : l][q] = p.ellt_val[(l * n + lane) * p.ellt_w + q];
+                }
+            }
+        }
+#define ET_C(l, q) (ANTI ? er_c[l][q] : et_c_[ANTI ? 0 : (l)][q])
+#define ET_V(l, q) (ANTI ? er_v[l][q] : et_v_[ANTI ? 0 : (l)][q])  // ANTI: the caller negates the sum
+    if (!p.g0_batch_stride)
+        for (int e = tid; e < nn; e += 256) G[(e % n) + LD * (e / n)] = p.G0[e];
+
+    const int S = p.S, nc = p.nc;
+    const int n_items = p.batch * p.K * S;
+    int stamp = 0;
+#define PCL_HSTAMP()                                                                                  \
+    do {                                                                                             \
+        if (p.dbg && blockIdx.x == 0 && tid == 0 && stamp < 60) p.dbg[stamp++] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+    PCL_HSTAMP();  // prologue done
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int s = item % S, k = (item / S) % p.K, b = item / (S * p.K);
+        const int c0 = s * nc, nce = min(nc, d - c0);
+        const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
+        const double *zn = zk + p.z_dim;
+        const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+        const double h = zk[p.dt_off];
+        const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0), h6 = h * (1.0 / 6.0);
+        const long long bk = (long long)b * p.K + k;
+        const double *mu = p.mu + bk * xd;
+        double *H = p.hess + bk * p.hess_per;
+        double *H3 = H + NSC, *H4 = H3 + (long long)m * xd, *H5 = H4 + xd, *H6 = H5 + (long long)m * xd;
+
+        // inputs of this wave's first chunk: requested before G is built, consumed after
+        const int nchunk = (nce + NCW - 1) / NCW;
+        double pxn[NCW], pxc[NCW], pmu[NCW];
+#pragma unroll
+        for (int c = 0; c < NCW; ++c) {
+            pxn[c] = pxc[c] = pmu[c] = 0.0;
+            if (lane < n && wave < nchunk && wave * NCW + c < nce) {
+                const long long g = (long long)(c0 + wave * NCW + c) * n + lane;
+                pxn[c] = zn[x_off + g];
+                pxc[c] = zk[x_off + g];
+                pmu[c] = mu[g];
+            }
+        }
+        __syncthreads();  // the previous item of this workgroup is fully consumed
+        PCL_HSTAMP();  // item start
+        // ---- G(u_k): drift everywhere (per-member drift only), then the drives' union pattern ------------------
+        {
+            const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
+            if (p.g0_batch_stride)
+                for (int e = tid; e < nn; e += 256)
+                    if (p.umap[e] < 0) G[(e % n) + LD * (e / n)] = G0b[e];
+            double uu[TM];
+#pragma unroll
+            for (int l = 0; l < TM; ++l) uu[l] = zk[p.u_off + l];
+            for (int q = tid; q < p.n_upos; q += 256) {
+                const int pos = p.upos[q];
+                double g = p.g0_batch_stride ? G0b[pos] : p.ug0[q];
+                const double *cf = p.ucoef + (long long)q * m;
+#pragma unroll
+                for (int l = 0; l < TM; ++l) g += uu[l] * cf[l];
+                G[(pos % n) + LD * (pos / n)] = g;
+            }
+        }
+        __syncthreads();
+
+        PCL_HSTAMP();  // G built
+        double acc[NACC];
+#pragma unroll
+        for (int e = 0; e < NACC; ++e) acc[e] = 0.0;
+        for (int ch = wave; ch < nchunk; ch += 4) {
+            const int cl0 = ch * NCW;                // first column of the chunk inside the slice
+            const int ncc = min(NCW, nce - cl0);     // columns in this chunk
+            double Sv[NCW], Pv[TM][NCW];
+            if (lane < n) {
+#pragma unroll
+                for (int c = 0; c < NCW; ++c) {
+                    Sv[c] = 0.0;
+                    double mv = 0.0;
+                    if (c < ncc) {
+                        double xn = pxn[c], xc = pxc[c];
+                        mv = pmu[c];
+                        if (ch != wave) {  // further chunks of a wide slice load at use
+                            const long long g = (long long)(c0 + cl0 + c) * n + lane;
+                            xn = zn[x_off + g];
+                            xc = zk[x_off + g];
+                            mv = mu[g];
+                        }
+                        Sv[c] = xn + xc;
+                        Ds[lane + LD * (cl0 + c)] = xn - xc;
+                    }
+                    Mw[lane + LD * c] = mv;
+                }
+            }
+            wave_lds_sync();
+            PCL_HSTAMP();  // inputs loaded
+            if (lane < n) {
+#pragma unroll
+                for (int l = 0; l < TM; ++l)
+#pragma unroll
+                    for (int c = 0; c < NCW; ++c) {
+                        double pv = 0.0;
+                        if (c < ncc) {
+#pragma unroll
+                            for (int q = 0; q < EW; ++q) pv += ET_V(l, q) * Mw[ET_C(l, q) + LD * c];
+                            if (ANTI) pv = -pv;
+                        }
+                        Pv[l][c] = pv;
+                        Mw[lane + LD * (NCW + l * NCW + c)] = pv;
+                    }
+            }
+            wave_lds_sync();
+            PCL_HSTAMP();  // P, E done
+            // ---- [A1 | Q_l] = G^T [M | P_l]: all row tiles at once (they share the b operand) --------------------
+            double4_t ac[PCL_MAXRT];
+            {
+                const double *Bp = Mw + lk + LD * li;
+                const double *Ap[PCL_MAXRT];
+                bool rok[PCL_MAXRT];
+#pragma unroll
+                for (int t = 0; t < PCL_MAXRT; ++t) {
+                    rok[t] = t * 16 < n;
+                    Ap[t] = G + lk + LD * ((rok[t] ? t * 16 : 0) + li);
+                    ac[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+                }
+                double an[PCL_MAXRT], bn = 0.0;
+#pragma unroll
+                for (int t = 0; t < PCL_MAXRT; ++t) an[t] = kfull > 0 ? Ap[t][0] : 0.0;
+                if (kfull > 0) bn = Bp[0];
+                for (int ks = 0; ks < kfull; ++ks) {
+                    double a[PCL_MAXRT];
+                    const double bb = bn;
+#pragma unroll
+                    for (int t = 0; t < PCL_MAXRT; ++t) a[t] = an[t];
+                    if (ks + 1 < kfull) {
+#pragma unroll
+                        for (int t = 0; t < PCL_MAXRT; ++t) an[t] = Ap[t][4 * (ks + 1)];
+                        bn = Bp[4 * (ks + 1)];
+                    }
+#pragma unroll
+                    for (int t = 0; t < PCL_MAXRT; ++t)
+                        if (rok[t]) ac[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bb, ac[t], 0, 0, 0);
+                }
+                if (krem) {
+                    const bool ok = lk < krem;
+                    const double bb = ok ? Bp[4 * kfull] : 0.0;
+#pragma unroll
+                    for (int t = 0; t < PCL_MAXRT; ++t)
+                        if (rok[t]) {
+                            const double a = ok ? Ap[t][4 * kfull] : 0.0;
+                            ac[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, ac[t], 0, 0, 0);
+                        }
+                }
+            }
+            wave_lds_sync();  // every operand read of this wave is complete before the tile is overwritten
+            PCL_HSTAMP();  // MFMA done
+            if (li < (TM + 1) * NCW) {
+                double *a1 = (li < ncc) ? A1s + LD * (cl0 + li) : nullptr;
+#pragma unroll
+                for (int t = 0; t < PCL_MAXRT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = t * 16 + lk + 4 * r;
+                        if (row < n) {
+                            Mw[row + LD * li] = ac[t][r];
+                            if (a1) a1[row] = ac[t][r];
+                        }
+                    }
+            }
+            wave_lds_sync();
+            if (lane < n) {
+#pragma unroll
+                for (int c = 0; c < NCW; ++c)
+                    if (c < ncc) {
+                        const double a1v = Mw[lane + LD * c];
+                        const double *Dc = Ds + LD * (cl0 + c);
+                        const double dv = Dc[lane];
+                        const long long o = (long long)(c0 + cl0 + c) * n + lane;
+                        double Ev[TM];  // E_l = G_l D, this row and column
+#pragma unroll
+                        for (int l = 0; l < TM; ++l) {
+                            double ev = 0.0, r = 0.0;  // R_l = G_l^T A1
+#pragma unroll
+                            for (int q = 0; q < EW; ++q) {
+                                ev += er_v[l][q] * Dc[er_c[l][q]];
+                                r += ET_V(l, q) * Mw[ET_C(l, q) + LD * c];
+                            }
+                            if (ANTI) r = -r;
+                            Ev[l] = ev;
+                            const double qv = Mw[lane + LD * (NCW + l * NCW + c)];
+                            const double kt = c2 * (qv + r), pl = -c1 * Pv[l][c];
+                            if (!(p.ablate & 1)) {
+                                H3[(long long)l * xd + o] = pl - kt;
+                                H5[(long long)l * xd + o] = pl + kt;
+                            }
+                            acc[NPAIR + l] += -0.5 * Pv[l][c] * Sv[c] + h6 * (qv * dv + a1v * ev);
+                        }
+                        int e = 0;
+                        if (!(p.ablate & 2)) {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int j = 0; j <= i; ++j, ++e) acc[e] += Pv[i][c] * Ev[j] + Pv[j][c] * Ev[i];
+                        }
+                    }
+            }
+            wave_lds_sync();  // Mw is rewritten by this wave's next chunk / the reduction below
+            PCL_HSTAMP();  // chunk outputs + sums done
+        }
+        // ---- lane -> wave reduction of the per-lane partial sums on the matrix cores (fixed order) -----------------
+        // C += 1_e x v_e : with a = [li == e] and b = the lanes' partial sums of entry e, row e of C collects
+        // sum_k v_e[lane j + 16 k] in column j; four DPP steps then add the 16 columns of a row.
+        {
+            double4_t r0 = {0.0, 0.0, 0.0, 0.0}, r1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int e = 0; e < NACC; ++e) {
+                const double ind = (li == (e & 15)) ? 1.0 : 0.0;
+                if (e < 16)
+                    r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ind, acc[e], r0, 0, 0, 0);
+                else
+                    r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ind, acc[e], r1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double t0 = row16_sum(r0[r]);
+                const int e0 = lk + 4 * r;
+                if (li == 0 && e0 < NACC) wsum[wave * NSC + e0] = t0;
+                if (NACC > 16) {
+                    const double t1 = row16_sum(r1[r]);
+                    if (li == 0 && 16 + e0 < NACC) wsum[wave * NSC + 16 + e0] = t1;
+                }
+            }
+        }
+        PCL_HSTAMP();  // wave reduction done
+        __syncthreads();  // A1s, Ds and wsum complete
+        PCL_HSTAMP();
+        // ---- A2 = G^T A1 for the slice's columns: wave w = row tile w --------------------------------------------
+        if (wave * 16 < n) {
+            const double *Ap = G + lk + LD * (wave * 16 + li);
+            const double *Bp = A1s + lk + LD * li;
+            double4_t a2 = {0.0, 0.0, 0.0, 0.0};
+            for (int ks = 0; ks < kfull; ++ks) a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[4 * ks], Bp[4 * ks], a2, 0, 0, 0);
+            if (krem) {
+                const bool ok = lk < krem;
+                a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? Ap[4 * kfull] : 0.0, ok ? Bp[4 * kfull] : 0.0, a2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave * 16 + lk + 4 * r;
+                if (row < n) A2s[row + LD * li] = a2[r];
+            }
+        }
+        __syncthreads();
+        {
+            double v = 0.0;
+            for (int e = tid; e < nce * n; e += 256) {
+                const int c = e / n, i = e - c * n;
+                v += A2s[i + LD * c] * Ds[i + LD * c];
+            }
+            v = wave_sum(v);
+            if (lane == 0) wsum2[wave] = v;
+        }
+        __syncthreads();
+        PCL_HSTAMP();  // A2 done
+        if (tid < NSC) {
+            double tot;
+            if (tid < NACC) {
+                tot = ((wsum[tid] + wsum[NSC + tid]) + wsum[2 * NSC + tid]) + wsum[3 * NSC + tid];
+                if (tid < NPAIR) tot *= c2;
+            } else {
+                tot = (((wsum2[0] + wsum2[1]) + wsum2[2]) + wsum2[3]) * (1.0 / 6.0);
+            }
+            if (S == 1)
+                H[tid] = tot;
+            else {
+                // agent-scope (write-through) store of this slice's partial entry; it has left the CU before the arrival
+                // counter moves.  No release fence: that would write back this XCD's whole L2 (full of Hessian output).
+                __hip_atomic_store(p.hpart + (bk * S + s) * NSC + tid, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        unsigned int ticket = 0;
+        if (S > 1) {
+            __syncthreads();
+            if (tid == 0) ticket = __hip_atomic_fetch_add(p.hcnt + bk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // the d2/dh dX vectors go out while the counter's round trip is in flight
+        for (int e = tid; e < nce * n; e += 256) {
+            const int c = e / n, i = e - c * n;
+            const double a1 = A1s[i + LD * c], a2 = A2s[i + LD * c];
+            const long long o = (long long)(c0 + c) * n + i;
+            H4[o] = -0.5 * a1 - h6 * a2;
+            H6[o] = -0.5 * a1 + h6 * a2;
+        }
+        if (S > 1) {
+            if (tid == 0) {
+                const int last = ticket == (unsigned int)(S - 1);
+                if (last) __hip_atomic_store(p.hcnt + bk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                *lastflag = last;
+            }
+            __syncthreads();
+            if (*lastflag && tid < NSC) {  // the last slice of the interval to arrive sums the partials in slice order
+                double t = 0.0;  // agent-scope loads bypass this XCD's L2
+                for (int q = 0; q < S; ++q) t += __hip_atomic_load(p.hpart + (bk * S + q) * NSC + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                H[tid] = t;
+            }
+        }
+        PCL_HSTAMP();  // item done
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // DerivativeIntegrator rows  x_{k+1} - x_k - dt_k * dx_k  and the time-consistency row  t_{k+1} - t_k - dt_k
 // (dx_off < 0: dx == 1).  Trivially sparse; one thread per (b, k, r).  Values per (b,k): [-1 (dim) | +1 (dim) |
 // -dt_k (dim, absent for time consistency) | -dx_k[r] (dim)].
@@ -1898,6 +2293,15 @@ struct pcl_ctx {
     int ell_w = 0, iso = 0, uell_w = 0;
     unsigned char *duell_l = nullptr;
     double *duell_v = nullptr;
+    int *dellt_col = nullptr;  // ELL form of G_l^T (Hessian kernel v2)
+    double *dellt_val = nullptr;
+    int ellt_w = 0;
+    int drives_antisym = 0;  // every G_l == -G_l^T exactly
+    double *dug0 = nullptr;
+    double *dhpart = nullptr;  // Hessian v2 scratch: per (b,k,slice) partial scalar entries + per (b,k) arrival counters
+    unsigned int *dhcnt = nullptr;
+    long long hpart_cap = 0;
+    int64_t opt_hess_kernel = 0, last_hess_kernel = 0;  // 0 = auto
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dmu = nullptr, *ddelta = nullptr, *dvals = nullptr, *dhess = nullptr;
     // options
@@ -2117,6 +2521,31 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
             }
         }
     ctx->ell_w = ell_w;
+    int ellt_w = m > 0 ? 1 : 0;
+    for (int l = 0; l < m; ++l)
+        for (int i = 0; i < n; ++i) ellt_w = std::max(ellt_w, csc_ptr[(size_t)l * (n + 1) + i + 1] - csc_ptr[(size_t)l * (n + 1) + i]);
+    std::vector<int> ellt_col((size_t)m * n * ellt_w, 0);
+    std::vector<double> ellt_val((size_t)m * n * ellt_w, 0.0);
+    for (int l = 0; l < m; ++l)
+        for (int i = 0; i < n; ++i) {
+            const int beg = csc_ptr[(size_t)l * (n + 1) + i], end = csc_ptr[(size_t)l * (n + 1) + i + 1];
+            for (int q = beg; q < end; ++q) {
+                ellt_col[((size_t)l * n + i) * ellt_w + (q - beg)] = csc_row[q];
+                ellt_val[((size_t)l * n + i) * ellt_w + (q - beg)] = csc_val[q];
+            }
+        }
+    ctx->ellt_w = ellt_w;
+    {
+        bool anti = true;
+        for (int l = 0; l < m && anti; ++l)
+            for (int j = 0; j < n && anti; ++j)
+                for (int i = 0; i < n; ++i)
+                    if (dsc->Gj[(size_t)l * nn + i + (size_t)n * j] != -dsc->Gj[(size_t)l * nn + j + (size_t)n * i]) {
+                        anti = false;
+                        break;
+                    }
+        ctx->drives_antisym = anti ? 1 : 0;
+    }
     // exact iso structure  M = [[A, -B], [B, A]]  of the drift(s) and of every drive?
     auto is_iso = [&](const double *A) {
         for (int j = 0; j < d; ++j)
@@ -2145,6 +2574,13 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     CREATE_TRY(upload(ctx, &ctx->duell_v, uell_v));
     CREATE_TRY(upload(ctx, &ctx->dell_col, ell_col));
     CREATE_TRY(upload(ctx, &ctx->dell_val, ell_val));
+    CREATE_TRY(upload(ctx, &ctx->dellt_col, ellt_col));
+    CREATE_TRY(upload(ctx, &ctx->dellt_val, ellt_val));
+    {
+        std::vector<double> ug0(std::max<size_t>(upos.size(), 1), 0.0);
+        for (size_t q = 0; q < upos.size(); ++q) ug0[q] = dsc->G0[upos[q]];
+        CREATE_TRY(upload(ctx, &ctx->dug0, ug0));
+    }
     std::vector<int> xo(ctx->x_offs.begin(), ctx->x_offs.end());
     CREATE_TRY(upload(ctx, &ctx->dxoffs, xo));
 #undef CREATE_TRY
@@ -2160,7 +2596,8 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     (void)pcl_comm_destroy(ctx);
     void *ptrs[] = {ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
-                    ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg};
+                    ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg, ctx->dellt_col, ctx->dellt_val,
+                    ctx->dhpart, ctx->dhcnt, ctx->dug0};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (ctx->dgoal) (void)hipFree(ctx->dgoal);
@@ -2312,6 +2749,12 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.ell_val = ctx->dell_val;
     p.ell_col = ctx->dell_col;
     p.ell_w = ctx->ell_w;
+    p.ellt_val = ctx->dellt_val;
+    p.ellt_col = ctx->dellt_col;
+    p.ellt_w = ctx->ellt_w;
+    p.hpart = ctx->dhpart;
+    p.hcnt = ctx->dhcnt;
+    p.ug0 = ctx->dug0;
     p.iso = ctx->iso;
     p.z_batch_stride = D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0;
     p.g0_batch_stride = D.per_member_G0 ? (long long)ctx->n * ctx->n : 0;
@@ -2566,6 +3009,28 @@ static size_t hess_lds_bytes(const KParams &p) {
     return ((size_t)p.LD * p.n + (6 + 3 * (size_t)p.m) * p.LD * p.nc + 8 + p.m + 5 * nscal) * sizeof(double);
 }
 
+template <int EW, bool ANTI>
+static const void *hess_v2_kernel(int m) {
+    switch (m) {
+    case 1: return (const void *)pcl_hess_kernel_v2<EW, 1, 0, ANTI>;
+    case 2: return (const void *)pcl_hess_kernel_v2<EW, 2, 0, ANTI>;
+    case 3: return (const void *)pcl_hess_kernel_v2<EW, 3, 0, ANTI>;
+    case 4: return (const void *)pcl_hess_kernel_v2<EW, 4, 0, ANTI>;
+    case 5: return (const void *)pcl_hess_kernel_v2<EW, 5, 0, ANTI>;
+    case 6: return (const void *)pcl_hess_kernel_v2<EW, 6, 0, ANTI>;
+    }
+    return nullptr;
+}
+#define PCL_HESS_EW 2
+static bool hess_v2_supported(const pcl_ctx *ctx) {
+    const int m = ctx->desc.n_drives;
+    return m >= 1 && m <= 6 && ctx->ell_w <= PCL_HESS_EW && ctx->ellt_w <= PCL_HESS_EW;
+}
+static size_t hess2_lds_bytes(const KParams &p) {
+    const size_t nscal = (size_t)(p.m + 1) * (p.m + 2) / 2;
+    return ((size_t)p.LD * p.n + 7 * (size_t)p.LD * 16 + 4 * nscal + 4 + 2) * sizeof(double);
+}
+
 static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *hess) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     KParams p;
@@ -2573,6 +3038,48 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
     p.Z = Z;
     p.mu = mu;
     p.hess = hess;
+    const bool mf = ctx->opt_use_mfma != 0;
+    if (ctx->opt_hess_kernel == 2 && !hess_v2_supported(ctx))
+        return fail(ctx, PCL_ESHAPE, "hess_kernel=2 needs 1..6 drives with at most %d entries per row and column (have m=%d, widths %d/%d)",
+                    PCL_HESS_EW, p.m, ctx->ell_w, ctx->ellt_w);
+    if (mf && ctx->opt_hess_kernel != 1 && hess_v2_supported(ctx) && hess2_lds_bytes(p) <= (size_t)ctx->max_lds) {
+        // one chunk of 16/(m+1) columns per wave and item when the interval's columns allow it, never more than 16 per slice
+        const int ncw = 16 / (p.m + 1);
+        int S = (p.cols + 4 * ncw - 1) / (4 * ncw);
+        if (ctx->opt_cols_per_slice > 0) S = (p.cols + (int)std::min<int64_t>(ctx->opt_cols_per_slice, 16) - 1) / (int)std::min<int64_t>(ctx->opt_cols_per_slice, 16);
+        S = std::max(S, (p.cols + 15) / 16);
+        p.nc = (p.cols + S - 1) / S;
+        p.S = (p.cols + p.nc - 1) / p.nc;
+        const long long nbk = (long long)p.batch * p.K;
+        if (p.S > 1 && ctx->hpart_cap < nbk * p.S) {
+            const size_t nscal = (size_t)(p.m + 1) * (p.m + 2) / 2;
+            if (ctx->dhpart) (void)hipFree(ctx->dhpart);
+            if (ctx->dhcnt) (void)hipFree(ctx->dhcnt);
+            ctx->dhpart = nullptr;
+            ctx->dhcnt = nullptr;
+            ctx->hpart_cap = 0;
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->dhpart, (size_t)nbk * p.S * nscal * sizeof(double)));
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->dhcnt, (size_t)nbk * sizeof(unsigned int)));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dhcnt, 0, (size_t)nbk * sizeof(unsigned int), ctx->stream));
+            ctx->hpart_cap = nbk * p.S;
+        }
+        p.hpart = ctx->dhpart;
+        p.hcnt = ctx->dhcnt;
+        const size_t lds = hess2_lds_bytes(p);
+        const void *kern = ctx->drives_antisym ? hess_v2_kernel<PCL_HESS_EW, true>(p.m) : hess_v2_kernel<PCL_HESS_EW, false>(p.m);
+        if (ctx->opt_specialize && p.d == 27 && p.m == 6 && ctx->drives_antisym)
+            kern = (const void *)pcl_hess_kernel_v2<PCL_HESS_EW, 6, 27, true>;  // BASELINE config 3's shape
+        if (int rc = set_lds_attr(ctx, kern, 7, lds)) return rc;
+        const long long items = nbk * p.S;
+        const int per_cu = std::max(1, std::min(2, (int)((size_t)ctx->max_lds / lds)));
+        long long grid = std::min<long long>(items, (long long)per_cu * ctx->n_cu);
+        if (ctx->opt_grid > 0) grid = std::min<long long>(items, ctx->opt_grid);
+        void *args[] = {(void *)&p};
+        HIP_TRY(ctx, hipLaunchKernel(kern, dim3((unsigned)grid), dim3(256), args, lds, ctx->stream));
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->last_hess_kernel = 2;
+        return PCL_OK;
+    }
     // column chunk: as many columns as fit in half the LDS (two workgroups per CU)
     p.nc = p.cols;
     while (p.nc > 1 && hess_lds_bytes(p) > (size_t)ctx->max_lds / 2) p.nc = (p.nc + 1) / 2;
@@ -2580,11 +3087,11 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
     if (lds > (size_t)ctx->max_lds)
         return fail(ctx, PCL_ESHAPE, "Hessian kernel needs %zu B of LDS (> %d) for d=%d, m=%d", lds, ctx->max_lds, p.d, p.m);
     const long long grid = (long long)p.batch * p.K;
-    const bool mf = ctx->opt_use_mfma != 0;
     auto kern = mf ? pcl_hess_kernel<true> : pcl_hess_kernel<false>;
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
+    ctx->last_hess_kernel = 1;
     return PCL_OK;
 }
 
@@ -2875,6 +3382,10 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_cpp = v;
     else if (!strcmp(key, "specialize"))  // 0: always the run-time-shape kernel instances
         ctx->opt_specialize = v != 0;
+    else if (!strcmp(key, "hess_kernel")) {  // 0: auto, 1: one workgroup per interval, 2: persistent wave-synchronous kernel
+        if (v < 0 || v > 2) return fail(ctx, PCL_EINVAL, "hess_kernel must be 0, 1 or 2");
+        ctx->opt_hess_kernel = v;
+    }
     else if (!strcmp(key, "debug_timing")) {  // profiling aid: cycle stamps of workgroup 0 (pcl_debug_timing reads them)
         if (v && !ctx->ddbg) {
             HIP_TRY(ctx, hipMalloc((void **)&ctx->ddbg, 64 * sizeof(long long)));
@@ -2917,6 +3428,14 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->opt_kernel;
     else if (!strcmp(key, "last_kernel"))
         *v = ctx->last_kernel;
+    else if (!strcmp(key, "hess_kernel"))
+        *v = ctx->opt_hess_kernel;
+    else if (!strcmp(key, "last_hess_kernel"))
+        *v = ctx->last_hess_kernel;
+    else if (!strcmp(key, "ell_width_t"))
+        *v = ctx->ellt_w;
+    else if (!strcmp(key, "drives_antisymmetric"))
+        *v = ctx->drives_antisym;
     else if (!strcmp(key, "occupancy_v2")) {
         KParams p;
         fill_params(ctx, p);

@@ -593,3 +593,35 @@ def test_ket_variant(d, m, N):
     close(B.ctx.hess(traj.datavec, mu), po.pade4_hessian_values(Z, mu, lay, G0, Gj), 1e-10)
     close(B.f(Z[2, :xd], Z[1, :xd], Z[1, xd + 2 : xd + 2 + m], Z[1, xd]), delta[n : 2 * n], 1e-11)
     B.close()
+
+
+# ---- Hessian kernels ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,N,batch", [(1, 50, 1), (2, 100, 2), (3, 6, 1), (3, 5, 3)])
+def test_hessian_kernel_variants(cfg, N, batch):
+    """Both Hessian kernels (1: one workgroup per interval; 2: persistent, wave-synchronous, column slices whose scalar
+    entries are combined by the last slice to arrive) against the oracle, for every slicing of the state columns;
+    kernel 2 must be what `auto` runs for the sparse drives of the reference's systems, and it must be
+    bitwise repeatable (fixed-order sums)."""
+    so = po.config_system(cfg)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    Zs, lay = [], None
+    for s in range(batch):
+        Z, lay = po.synthetic_trajectory(so, N, seed=77 + s)
+        Zs.append(Z)
+    rng = np.random.default_rng(5 + cfg)
+    mus = [rng.standard_normal((lay.K, lay.x_dim)) for _ in range(batch)]
+    ref = np.concatenate([po.pade4_hessian_values(Z, mu, lay, G0, Gj).reshape(-1) for Z, mu in zip(Zs, mus)])
+    c = make_ctx(lay, G0, Gj, batch=batch, batch_mode=pa._lib.PCL_BATCH_TRAJ, x_offs=[lay.x_off])
+    Zb, mub = np.stack(Zs), np.concatenate([m_.reshape(-1) for m_ in mus])
+    h_auto = c.hess(Zb, mub)
+    assert c.get_option("last_hess_kernel") == 2
+    close(h_auto, ref, 1e-11)
+    for hk in (1, 2):
+        c.set_option("hess_kernel", hk)
+        for cps in (0, 1, 2, 3, 5, 16):
+            c.set_option("cols_per_slice", cps)
+            h = c.hess(Zb, mub)
+            assert c.get_option("last_hess_kernel") == hk
+            close(h, ref, 1e-11)
+            assert np.array_equal(h, c.hess(Zb, mub))
+    c.close()
