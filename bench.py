@@ -117,11 +117,12 @@ def main():
         assert np.isfinite(chk) and chk > 0
         nc = c.get_option("effective_cols_per_slice")
         lk = c.get_option("last_kernel")
+        ns = c.get_option("last_stream_workgroups")
         ms.close()
         del Zd, dd, vd
-        return wall, dev, nc, lk
+        return wall, dev, nc, lk, ns
 
-    wall, dev, nc, lk = run_case(B, args.steps, args.warmup)
+    wall, dev, nc, lk, ns = run_case(B, args.steps, args.warmup)
     t = torch.tensor([wall, dev], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -149,6 +150,7 @@ def main():
             "seeds_per_gpu": B,
             "total_seeds": B * world,
             "cols_per_slice": nc,
+            "stream_workgroups": ns,
             "parallelism": "seeds sharded over %d rank(s), no data-path collective" % world,
         },
     }
@@ -162,7 +164,9 @@ def main():
         "traffic": None,
         "kernel": {31: "pcl_fused_kernel_v3<2,27,6,2>", 30: "pcl_fused_kernel_v3<2,0,0,0>", 41: "pcl_fused_kernel_v4<1,27,6,3>", 40: "pcl_fused_kernel_v4<1,0,0,0>", 21: "pcl_fused_kernel_v2<true,1,27,6,3>",
                    20: "pcl_fused_kernel_v2<true,1,0,0,0>"}.get(lk, "pcl_fused_kernel (id %d)" % lk)
-        + (" (persistent; 1 workgroup/CU; 4 MFMA waves + 4 store-stream waves; one barrier per item)" if lk // 10 == 3 else
+        + ((" (persistent; 1 workgroup/CU; contiguous column ranges; %d workgroups stream the B+- blocks, the others do the column work "
+            "with 8 matrix waves)" % ns) if lk // 10 == 3 and ns > 0 else
+           " (persistent; 1 workgroup/CU; 4 MFMA waves + 4 store-stream waves; one barrier per item)" if lk // 10 == 3 else
            " (persistent; 2 workgroups/CU; 4 MFMA waves + 4 store-stream waves each)"),
         "kernel_us": kernel_s * 1e6,
         "algorithmic_bytes_per_launch": abytes * B,
@@ -177,7 +181,7 @@ def main():
             pass
 
     if rank == 0 and world == 1 and not args.no_single:
-        w1, d1, nc1, lk1 = run_case(1, max(args.steps, 200), args.warmup)
+        w1, d1, nc1, lk1, ns1 = run_case(1, max(args.steps, 200), args.warmup)
         st = max(args.steps, 200)
         out["single_trajectory"] = {
             "evals_per_s": st / w1,

@@ -69,6 +69,8 @@ struct KParams {
     long long *dbg;  // optional: cycle stamps of workgroup 0 / matrix wave 0 (option debug_timing)
     int ncw;      // v3: state columns per matrix-wave chunk ((2+m)*ncw <= 16)
     int tab_lds;  // v3: union / ELL tables staged in LDS
+    int contig;   // v3: 1 = contiguous column ranges per workgroup (see the kernel), 0 = items dealt round-robin
+    int n_stream; // v3, contig: > 0 = role split, this many stream-role workgroups (the rest do the column work)
     int iso;               // 1: G0 and every G_l are exact iso(.) images -> G^2 needs only its first d columns
     long long z_batch_stride;   // doubles between trajectories (0 in MEMBERS mode)
     long long g0_batch_stride;  // n*n if per-member drift else 0
@@ -1140,20 +1142,55 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     }
     __syncthreads();
 
-    const int n_items = p.batch * p.K * p.S;
-    const int n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    // Work split.  contig = 0: items (b, k, slice of nc columns) dealt round-robin to the workgroups.
+    // contig = 1: the batch*K*d state columns of the launch are cut into gridDim.x equal contiguous ranges (to within one
+    // column); a workgroup's items are the pieces of its range that lie in one interval (first and last piece partial),
+    // so G, G^2 are built once per interval touched and every CU streams the same number of bytes.
     const long long blk = p.compact ? (long long)nn : (long long)d * nn;  // size of seg 0 / seg 1
     const int nc = p.nc;
-    auto decode = [&](int it, int &s, int &k, int &b) {
-        const int item = blockIdx.x + it * gridDim.x;
-        s = item % p.S;
-        k = (item / p.S) % p.K;
-        b = item / (p.S * p.K);
+    int n_my;
+    long long g_lo = 0, g_hi = 0;
+    // Role split (contig only, n_stream > 0): workgroups [0, n_stream) stream the B^{+-} blocks of ALL columns (their
+    // matrix waves only build G, G^2), workgroups [n_stream, grid) do the column work of ALL columns (their stream waves
+    // idle).  The store stream is memory-side bound and half the CUs sustain it; on a CU of its own it is not slowed
+    // by the matrix waves' instructions and memory operations.
+    const bool stream_role = p.n_stream > 0 && (int)blockIdx.x < p.n_stream;
+    const bool matrix_role = p.n_stream > 0 && !stream_role;
+    if (p.contig) {
+        const long long tot = (long long)p.batch * p.K * d;
+        const long long widx = matrix_role ? (long long)blockIdx.x - p.n_stream : (long long)blockIdx.x;
+        const long long wcnt = p.n_stream > 0 ? (stream_role ? (long long)p.n_stream : (long long)gridDim.x - p.n_stream) : (long long)gridDim.x;
+        g_lo = tot * widx / wcnt;
+        g_hi = tot * (widx + 1) / wcnt;
+        n_my = g_hi > g_lo ? (int)((g_hi - 1) / d - g_lo / d) + 1 : 0;
+    } else {
+        const int n_items = p.batch * p.K * p.S;
+        n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    }
+    // item `it` of this workgroup: interval (b, k), state columns [c0, c0 + nce)
+    auto decode = [&](int it, int &c0, int &nce, int &k, int &b) {
+        if (p.contig) {
+            const long long bk = g_lo / d + it;
+            c0 = it == 0 ? (int)(g_lo - bk * d) : 0;
+            nce = (int)min((long long)d, g_hi - bk * d) - c0;
+            k = (int)(bk % p.K);
+            b = (int)(bk / p.K);
+        } else {
+            const int item = blockIdx.x + it * gridDim.x;
+            const int s = item % p.S;
+            c0 = s * nc;
+            nce = min(nc, d - c0);
+            k = (item / p.S) % p.K;
+            b = item / (p.S * p.K);
+        }
     };
 
-    if (wave < 4) {
+    if (wave < 4 || matrix_role) {
         // ======================================= matrix waves =========================================
-        double *Mw = wbuf + wave * wsz;  // [LD*CW]: S | D | G_l D
+        // matrix role: all eight waves work on chunks; G, G^2 are single-buffered there and the second halves of the
+        // double buffers hold the chunk buffers of waves 4..7 (the host checks 2*wsz <= tile)
+        const int nmw = matrix_role ? 8 : 4;
+        double *Mw = wave < 4 ? wbuf + wave * wsz : (wave < 6 ? Gb + tile + (wave - 4) * wsz : G2b + tile + (wave - 6) * wsz);  // [LD*CW]: S | D | G_l D
         double *GDw = Mw + LD * CW;      // [LD*ncw]
         double *G2Dw = GDw + LD * ncw;   // [LD*ncw]
         double *GSw = G2Dw + LD * ncw;   // [LD*ncw]
@@ -1179,8 +1216,8 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
 
         // G(u) on the union pattern + this wave's share of the G^2 tiles, for item `it`, into buffer `buf`
         auto build = [&](int it, int buf, double u_lane) {
-            int s, k, b;
-            decode(it, s, k, b);
+            int c0_, nce_, k, b;
+            decode(it, c0_, nce_, k, b);
             double *G = Gb + buf * tile, *G2 = G2b + buf * tile;
             double *usn = us + (it % 3) * (m + 1);
             if (lane <= m) usn[lane] = u_lane;  // every wave: identical values
@@ -1263,19 +1300,18 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             }
         };
 
-        if (n_my > 0) {
-            int s0, k0, b0;
-            decode(0, s0, k0, b0);
+        if (n_my > 0 && wave < 4) {
+            int c00, nce0, k0, b0;
+            decode(0, c00, nce0, k0, b0);
             const double *z0 = p.Z + (long long)b0 * p.z_batch_stride + (long long)k0 * p.z_dim;
             build(0, 0, lane <= m ? z0[lane < m ? p.u_off + lane : p.dt_off] : 0.0);
         }
         __syncthreads();  // item 0's G, G^2 complete
 
         for (int it = 0; it < n_my; ++it) {
-            const int cur = it & 1;
-            int s, k, b;
-            decode(it, s, k, b);
-            const int c0 = s * nc, nce = min(nc, d - c0);
+            const int cur = matrix_role ? 0 : (it & 1);
+            int c0, nce, k, b;
+            decode(it, c0, nce, k, b);
             const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
             const double *zn = zk + p.z_dim;
             const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
@@ -1297,29 +1333,34 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             // a later load would sit behind them in the CU's saturated memory pipeline (and vmcnt is in-order).
             const bool pf = ncw <= PCL_PFW;
             double pxn[PCL_PFC][PCL_PFW], pxc[PCL_PFC][PCL_PFW];
-            if (pf && lane < n && !(p.ablate & 4)) {
+            if (pf && lane < n && !(p.ablate & 4) && !stream_role) {
 #pragma unroll
                 for (int t = 0; t < PCL_PFC; ++t)
 #pragma unroll
                     for (int c = 0; c < PCL_PFW; ++c) {
-                        const int col = c0 + (wave + 4 * t) * ncw + c;
+                        const int col = c0 + (wave + nmw * t) * ncw + c;
                         pxn[t][c] = pxc[t][c] = 0.0;
                         if (c < ncw && col < c0 + nce) {
                             const long long o = x_off + (long long)col * n + lane;
-                            pxn[t][c] = zn[o];
-                            pxc[t][c] = zk[o];
+                            if (p.ablate & 8) {  // DEBUG: no state loads
+                                pxn[t][c] = 1e-3 * lane;
+                                pxc[t][c] = 1e-3 * col;
+                            } else {
+                                pxn[t][c] = zn[o];
+                                pxc[t][c] = zk[o];
+                            }
                         }
                     }
             }
             double pf_u = 0.0;  // next item's u_k / dt_k (consumed by build)
-            if (it + 1 < n_my && lane <= m) {
-                int s2, k2, b2;
-                decode(it + 1, s2, k2, b2);
+            if (it + 1 < n_my && lane <= m && wave < 4) {
+                int c02, nce2, k2, b2;
+                decode(it + 1, c02, nce2, k2, b2);
                 const double *zk2 = p.Z + (long long)b2 * p.z_batch_stride + (long long)k2 * p.z_dim;
                 pf_u = zk2[lane < m ? p.u_off + lane : p.dt_off];
             }
             int tch = 0;
-            for (int ch = wave; ch < nchunk && !(p.ablate & 4); ch += 4, ++tch) {
+            for (int ch = wave; ch < nchunk && !(p.ablate & 4) && !stream_role; ch += nmw, ++tch) {
                 const int cc0 = c0 + ch * ncw;             // first state column of the chunk
                 const int ncc = min(ncw, c0 + nce - cc0);  // columns in this chunk
                 // ---- M = [S | D | G_l D]   (lane = row) -----------------------------------------------------
@@ -1506,7 +1547,8 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                 PCL_STAMP();  // outputs issued
             }
             // ---- next item's G(u), G^2 into the other buffer ----------------------------------------------------
-            if (it + 1 < n_my) build(it + 1, cur ^ 1, pf_u);
+            if (matrix_role) __syncthreads();  // single-buffered G, G^2: every wave is done with this item's tiles
+            if (it + 1 < n_my && wave < 4) build(it + 1, matrix_role ? 0 : cur ^ 1, pf_u);
             PCL_STAMP();  // next G, G^2 built
             __syncthreads();  // item boundary
             PCL_STAMP();  // barrier passed
@@ -1520,10 +1562,10 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
         __syncthreads();  // item 0's G, G^2 complete
         for (int it = 0; it < n_my; ++it) {
             const int cur = it & 1;
-            int s, k, b;
-            decode(it, s, k, b);
+            int c0, nce, k, b;
+            decode(it, c0, nce, k, b);
             const double *G = Gb + cur * tile, *G2 = G2b + cur * tile;
-            if (pact && !(p.ablate & 2)) {
+            if (pact && !(p.ablate & 2) && !matrix_role) {
                 const double h = us[(it % 3) * (m + 1) + m];
                 const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
                 double bpr[PCL_NSP][2], bmr[PCL_NSP][2];
@@ -1540,10 +1582,10 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                         bmr[r][1] = e1 - c1 * g1;
                     }
                 }
-                int cbeg = s * nc, cend = s * nc + min(nc, d - s * nc);
+                int cbeg = c0, cend = c0 + nce;
                 if (p.compact) {  // unique blocks only: slice 0 writes the single copy
                     cbeg = 0;
-                    cend = (s == 0) ? 1 : 0;
+                    cend = (c0 == 0) ? 1 : 0;
                 }
                 double *o = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn + pi;
                 for (int c = cbeg; c < cend; ++c, o += nn) {
@@ -2316,6 +2358,9 @@ struct pcl_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int64_t opt_cpp = 6;  // block copies per expander work item
     int64_t opt_specialize = 1;
+    int64_t opt_contig = -1;     // v3: contiguous column ranges per workgroup (-1: auto by launch size)
+    int64_t opt_stream_wg = -1;  // v3, contiguous: stream-role workgroups (-1: auto = half, 0: every workgroup does both)
+    int64_t last_n_stream = 0;  // stream-role workgroups of the last kernel-3 launch (0: fused roles / round-robin)
     int64_t last_kernel = 0;  // 10*version + (1 if shape-specialised) of the last fused launch
     int64_t opt_grid = 0;  // 0: resident workgroups (persistent kernel)
     size_t lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2839,6 +2884,19 @@ static size_t fused3_lds_bytes(const pcl_ctx *ctx, const KParams &p, bool tab) {
 // v3 cost model: one workgroup per CU walks ceil(items / CUs) items; an item costs max(store stream, matrix work).
 // Constants are the measured config-3 phase times (scripts/phase_timing.py, with the stream running): ~7 us per
 // 2-column chunk, ~4 us for G(u) + G^2, stream at ~0.85 of the CU's fair HBM share; other shapes scale by MFMA count.
+// Role split needs the chunk buffers of matrix waves 4..7 inside the second halves of the G / G^2 double buffers.
+static bool v3_role_split_fits(const pcl_ctx *ctx) {
+    const int ncw = v3_ncw(ctx, ctx->desc.d), LD = lds_ld(ctx->desc.d);
+    return 2 * (size_t)LD * (16 + 3 * ncw) <= (size_t)LD * ctx->n;
+}
+// Work split of kernel 3: contiguous column ranges (+ role split) pay off once every CU has a few intervals' worth of
+// columns; below that the round-robin slices balance a short launch better (measured: batch >= 3 at config 3).
+static bool v3_contiguous(const pcl_ctx *ctx) {
+    if (ctx->opt_cols_per_slice > 0 || ctx->opt_contig == 0) return false;
+    if (ctx->opt_contig > 0) return true;
+    const long long cols = (long long)ctx->desc.batch * ctx->K * ctx->desc.d;
+    return v3_role_split_fits(ctx) && cols >= 28LL * std::max(ctx->n_cu, 1);
+}
 static int choose_cols_v3(const pcl_ctx *ctx) {
     const int d = ctx->desc.d, n = ctx->n, m = ctx->desc.n_drives;
     if (ctx->opt_cols_per_slice > 0) return (int)std::min<int64_t>(ctx->opt_cols_per_slice, d);
@@ -2898,7 +2956,10 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
     if (want_jac && !compact && (ctx->opt_kernel == 3 || ctx->opt_kernel == 0) && ctx->opt_use_mfma != 0 && v3_supported(ctx) &&
         ctx->cols == ctx->desc.d) {  // the default whenever its LDS budget fits (else kernels 2 / 4 below)
-        p.nc = choose_cols_v3(ctx);
+        // default: contiguous column ranges (one item per interval touched); an explicit cols_per_slice or
+        // contiguous = 0 selects the round-robin slices
+        p.contig = v3_contiguous(ctx) ? 1 : 0;
+        p.nc = p.contig ? p.d : choose_cols_v3(ctx);
         p.ncw = v3_ncw(ctx, p.nc);
         p.tab_lds = 1;
         size_t lds3 = fused3_lds_bytes(ctx, p, true);
@@ -2918,7 +2979,14 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         ctx->last_kernel = 30 + ((ewr == 2 && p.d == 27 && p.m == 6 && p.ncw == 2 && ctx->opt_specialize) ? 1 : 0);
         int rc = set_lds_attr(ctx, (const void *)kern3, 6, lds3);
         if (rc != PCL_OK) return rc;
-        const long long g3 = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, items) : std::min<long long>(items, std::max(ctx->n_cu, 1));
+        const long long units = p.contig ? (long long)p.batch * p.K * p.d : items;  // what the grid is cut into
+        const long long g3 = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, units) : std::min<long long>(units, std::max(ctx->n_cu, 1));
+        p.n_stream = 0;
+        if (p.contig && g3 >= 2 && v3_role_split_fits(ctx)) {
+            const long long want = ctx->opt_stream_wg < 0 ? g3 / 2 : ctx->opt_stream_wg;  // auto: half the workgroups stream
+            if (want > 0) p.n_stream = (int)std::min<long long>(want, g3 - 1);
+        }
+        ctx->last_n_stream = p.n_stream;
         hipLaunchKernelGGL(kern3, dim3((unsigned)g3), dim3(512), lds3, ctx->stream, p);
         HIP_TRY(ctx, hipGetLastError());
         return PCL_OK;
@@ -3382,6 +3450,10 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_cpp = v;
     else if (!strcmp(key, "specialize"))  // 0: always the run-time-shape kernel instances
         ctx->opt_specialize = v != 0;
+    else if (!strcmp(key, "stream_workgroups"))  // kernel 3, contiguous: > 0 = role split with this many stream-role workgroups
+        ctx->opt_stream_wg = v;
+    else if (!strcmp(key, "contiguous"))  // kernel 3: 1 = equal contiguous column ranges per workgroup (default), 0 = round-robin slices
+        ctx->opt_contig = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "hess_kernel")) {  // 0: auto, 1: one workgroup per interval, 2: persistent wave-synchronous kernel
         if (v < 0 || v > 2) return fail(ctx, PCL_EINVAL, "hess_kernel must be 0, 1 or 2");
         ctx->opt_hess_kernel = v;
@@ -3420,14 +3492,21 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
     else if (!strcmp(key, "nt_stores"))
         *v = ctx->opt_nt;
     else if (!strcmp(key, "effective_cols_per_slice"))
-        *v = ((ctx->opt_kernel == 3 || ctx->opt_kernel == 0) && ctx->opt_use_mfma && v3_supported(ctx) && ctx->cols == ctx->desc.d) ? choose_cols_v3(ctx)
-                                                                                                                                 : choose_cols_per_slice(ctx, true);
+        *v = ((ctx->opt_kernel == 3 || ctx->opt_kernel == 0) && ctx->opt_use_mfma && v3_supported(ctx) && ctx->cols == ctx->desc.d)
+                 ? (v3_contiguous(ctx) ? ctx->desc.d : choose_cols_v3(ctx))
+                 : choose_cols_per_slice(ctx, true);
     else if (!strcmp(key, "n_cu"))
         *v = ctx->n_cu;
     else if (!strcmp(key, "kernel_version"))
         *v = ctx->opt_kernel;
     else if (!strcmp(key, "last_kernel"))
         *v = ctx->last_kernel;
+    else if (!strcmp(key, "contiguous"))
+        *v = ctx->opt_contig;
+    else if (!strcmp(key, "stream_workgroups"))
+        *v = ctx->opt_stream_wg;
+    else if (!strcmp(key, "last_stream_workgroups"))
+        *v = ctx->last_n_stream;
     else if (!strcmp(key, "hess_kernel"))
         *v = ctx->opt_hess_kernel;
     else if (!strcmp(key, "last_hess_kernel"))

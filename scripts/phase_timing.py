@@ -7,7 +7,7 @@ import torch
 import piccolo_jl_amd as pa
 from piccolo_jl_amd import synthetic
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-nc = int(sys.argv[2]) if len(sys.argv) > 2 else 27
+nc = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0: contiguous column ranges
 ab = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 system = synthetic.config_system(3)
 trajs = [synthetic.synthetic_trajectory(system, 100, seed=1000 + i) for i in range(B)]

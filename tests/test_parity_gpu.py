@@ -625,3 +625,72 @@ def test_hessian_kernel_variants(cfg, N, batch):
             close(h, ref, 1e-11)
             assert np.array_equal(h, c.hess(Zb, mub))
     c.close()
+
+
+def test_contiguous_column_ranges_any_grid():
+    """Default work split of kernel 3: the batch*K*d state columns are cut into `grid` equal contiguous ranges, a
+    workgroup's items are the pieces of its range inside one interval.  Any grid (also ones that cut intervals at
+    odd places, one workgroup only, more workgroups than intervals) must give the oracle's values, bitwise equal to
+    the round-robin split."""
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    Bn, N = 2, 5
+    Zs, lay = [], None
+    for s in range(Bn):
+        Z, lay = po.synthetic_trajectory(so, N, seed=300 + s)
+        Zs.append(Z)
+    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn)
+    c = ms.ctx
+    refs = [ref_lib.eval_jac(Z, lay, G0, Gj) for Z in Zs]
+    d_ref = np.concatenate([r[0].reshape(-1) for r in refs])
+    j_ref = np.concatenate([r[1].reshape(-1) for r in refs])
+    c.set_option("kernel_version", 3)
+    c.set_option("contiguous", 0)
+    d_rr, j_rr = c.eval_jac(np.stack(Zs))
+    close(d_rr, d_ref)
+    close(j_rr, j_ref)
+    c.set_option("contiguous", 1)
+    c.set_option("stream_workgroups", 0)
+    assert c.get_option("effective_cols_per_slice") == lay.d
+    for grid in (0, 1, 2, 3, 7, 8, 13, 31, 100, 215, 216, 217, 256, 1000):
+        c.set_option("grid", grid)
+        delta, vals = c.eval_jac(np.stack(Zs))
+        assert c.get_option("last_kernel") // 10 == 3
+        close(delta, d_ref)
+        close(vals, j_ref)
+        assert np.array_equal(vals, j_rr) and np.array_equal(delta, d_rr), grid
+    # role split: `stream_workgroups` workgroups stream the blocks of all columns, the others (eight matrix waves each,
+    # single-buffered G) do the column work of all columns
+    for grid, ns in ((0, 128), (0, 1), (0, 255), (2, 1), (7, 3), (100, 37), (256, 100), (256, 200)):
+        c.set_option("grid", grid)
+        c.set_option("stream_workgroups", ns)
+        delta, vals = c.eval_jac(np.stack(Zs))
+        assert np.array_equal(vals, j_rr) and np.array_equal(delta, d_rr), (grid, ns)
+    ms.close()
+
+
+def test_config5_share_default_path():
+    """BASELINE config 5's per-GPU share at reduced batch (4 seeds of the full-size config-3 problem in one launch):
+    the path `auto` picks at this size - kernel 3, contiguous column ranges, half the workgroups streaming the blocks -
+    against the C oracle, and bitwise against the round-robin split."""
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    Bn, N = 4, 100
+    Zs, lay = [], None
+    for s in range(Bn):
+        Z, lay = po.synthetic_trajectory(so, N, seed=1000 + s)
+        Zs.append(Z)
+    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn)
+    c = ms.ctx
+    delta, vals = c.eval_jac(np.stack(Zs))
+    assert c.get_option("last_kernel") == 31 and c.get_option("last_stream_workgroups") == c.get_option("n_cu") // 2
+    per_d, per_j = lay.x_dim * lay.K, po.jac_nnz_per_interval(lay) * lay.K
+    for s in range(Bn):
+        d_ref, j_ref = ref_lib.eval_jac(Zs[s], lay, G0, Gj)
+        close(delta[s * per_d : (s + 1) * per_d], d_ref)
+        close(vals[s * per_j : (s + 1) * per_j], j_ref)
+    c.set_option("contiguous", 0)
+    d2, v2 = c.eval_jac(np.stack(Zs))
+    assert c.get_option("last_stream_workgroups") == 0
+    assert np.array_equal(d2, delta) and np.array_equal(v2, vals)
+    ms.close()
