@@ -1536,6 +1536,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                         const int c = e2 / hn2, r0 = 2 * (e2 - c * hn2);
                         if (p.delta) store2(p.delta + bk * xd + o0 + (long long)c * n + r0, G2Dw[r0 + LD * c], G2Dw[r0 + 1 + LD * c], false);
                         double *tc = jt + (long long)(cc0 + c) * (m + 1) * n + r0;  // this column's (m+1)*n tail block
+                        if (p.ablate & 64) tc = p.jac + (long long)blockIdx.x * 16384 + (wave * 1024 + c * 512) + r0;  // DEBUG: a cache-resident scratch target
                         for (int l = 0; l < m; ++l) {
                             const double *src = Mw + LD * (2 * ncw + l * ncw + c) + r0;
                             store2(tc + (long long)l * n, src[0], src[1], false);

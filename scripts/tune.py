@@ -17,8 +17,8 @@ ap.add_argument("--kernel", type=int, nargs="+", default=[0])
 ap.add_argument("--grid", type=int, nargs="+", default=[0])
 ap.add_argument("--specialize", type=int, nargs="+", default=[1])
 ap.add_argument("--cpp", type=int, nargs="+", default=[6])
-ap.add_argument("--contig", type=int, nargs="+", default=[1])
-ap.add_argument("--nstream", type=int, nargs="+", default=[0])
+ap.add_argument("--contig", type=int, nargs="+", default=[-1])
+ap.add_argument("--nstream", type=int, nargs="+", default=[-1])
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--knots", type=int, default=100)
 args = ap.parse_args()
