@@ -1117,31 +1117,6 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     unsigned short *t_ellc = t_uni + (p.tab_lds ? n_un : 0);
     unsigned char *t_unl = reinterpret_cast<unsigned char *>(t_ellc + (p.tab_lds ? n_ell : 0));
 
-    // ---- prologue: both G buffers = drift tile, tables -> LDS ----------------------------------------------
-    if (!p.g0_batch_stride)
-        for (int e = tid; e < nn; e += 512) {
-            const double g = p.G0[e];
-            const int o = (e % n) + LD * (e / n);
-            Gb[o] = g;
-            Gb[tile + o] = g;
-        }
-    if (p.tab_lds) {
-        for (int e = tid; e < n_un * uw; e += 512) {
-            t_unv[e] = p.uell_v[e];
-            t_unl[e] = p.uell_l[e];
-        }
-        for (int e = tid; e < n_un; e += 512) {
-            const int pos = p.upos[e];
-            t_uni[e] = (unsigned short)((pos % n) + LD * (pos / n));
-            t_ung0[e] = p.g0_batch_stride ? 0.0 : p.G0[pos];
-        }
-        for (int e = tid; e < n_ell; e += 512) {
-            t_ellv[e] = p.ell_val[e];
-            t_ellc[e] = (unsigned short)p.ell_col[e];
-        }
-    }
-    __syncthreads();
-
     // Work split.  contig = 0: items (b, k, slice of nc columns) dealt round-robin to the workgroups.
     // contig = 1: the batch*K*d state columns of the launch are cut into gridDim.x equal contiguous ranges (to within one
     // column); a workgroup's items are the pieces of its range that lie in one interval (first and last piece partial),
@@ -1184,6 +1159,40 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             b = item / (p.S * p.K);
         }
     };
+
+    // item 0's controls / time step: requested before the prologue's table loads so that the latencies overlap
+    double u0 = 0.0;
+    if (n_my > 0 && wave < 4 && lane <= m) {
+        int c00, nce0, k0, b0;
+        decode(0, c00, nce0, k0, b0);
+        const double *z0 = p.Z + (long long)b0 * p.z_batch_stride + (long long)k0 * p.z_dim;
+        u0 = z0[lane < m ? p.u_off + lane : p.dt_off];
+    }
+    // ---- prologue: both G buffers = drift tile, tables -> LDS ----------------------------------------------
+    if (!p.g0_batch_stride)
+        for (int e = tid; e < nn; e += 512) {
+            const double g = p.G0[e];
+            const int o = (e % n) + LD * (e / n);
+            Gb[o] = g;
+            Gb[tile + o] = g;
+        }
+    if (p.tab_lds) {
+        for (int e = tid; e < n_un * uw; e += 512) {
+            t_unv[e] = p.uell_v[e];
+            t_unl[e] = p.uell_l[e];
+        }
+        for (int e = tid; e < n_un; e += 512) {
+            const int pos = p.upos[e];
+            t_uni[e] = (unsigned short)((pos % n) + LD * (pos / n));
+            t_ung0[e] = p.g0_batch_stride ? 0.0 : p.ug0[e];  // (not G0[pos]: no dependent load in the prologue)
+        }
+        for (int e = tid; e < n_ell; e += 512) {
+            t_ellv[e] = p.ell_val[e];
+            t_ellc[e] = (unsigned short)p.ell_col[e];
+        }
+    }
+    __syncthreads();
+
 
     if (wave < 4 || matrix_role) {
         // ======================================= matrix waves =========================================
@@ -1300,12 +1309,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             }
         };
 
-        if (n_my > 0 && wave < 4) {
-            int c00, nce0, k0, b0;
-            decode(0, c00, nce0, k0, b0);
-            const double *z0 = p.Z + (long long)b0 * p.z_batch_stride + (long long)k0 * p.z_dim;
-            build(0, 0, lane <= m ? z0[lane < m ? p.u_off + lane : p.dt_off] : 0.0);
-        }
+        if (n_my > 0 && wave < 4) build(0, 0, u0);
         __syncthreads();  // item 0's G, G^2 complete
 
         for (int it = 0; it < n_my; ++it) {
