@@ -74,7 +74,7 @@ typedef enum pcl_status {
     PCL_EHIP = -3,    /* HIP runtime error (incl. "no GPU") */
     PCL_ERCCL = -4,   /* RCCL error */
     PCL_ESHAPE = -5,  /* shape outside what the kernels support (d > PCL_MAX_D, ...) */
-    PCL_ENOTIMPL = -6 /* valid request the library does not implement (e.g. pade_order != 4) */
+    PCL_ENOTIMPL = -6 /* valid request the library does not implement (e.g. an odd pade_order, the Hessian at order != 4) */
 } pcl_status;
 
 #define PCL_MAX_D 32 /* n = 2d <= 64: G(u_k), G^2 and the column tiles stay LDS-resident */
@@ -95,7 +95,7 @@ typedef struct pcl_desc {
     int32_t dt_off;      /* 0-based offset of the timestep component */
     int32_t batch;       /* number of members / seeds (>= 1) */
     int32_t batch_mode;  /* PCL_BATCH_MEMBERS or PCL_BATCH_TRAJ */
-    int32_t pade_order;  /* 4 */
+    int32_t pade_order;  /* diagonal Pade order p of B^{+-}_p: 2, 4 (the tuned path), 6, 8 or 10 */
     int32_t device_id;   /* HIP device ordinal */
     int32_t index_base;  /* 0 (C/Python) or 1 (Julia/MOI) for the emitted structure */
     int32_t per_member_G0; /* 0: one G0 for all members; 1: G0 holds batch matrices (per-member H_drift) */

@@ -29,7 +29,9 @@
 
 #include "piccolo_hip.h"
 
-#define PCL_VERSION_STR "piccolo_hip 0.1.0 (gfx950, pade4)"
+#define PCL_VERSION_STR "piccolo_hip 0.2.0 (gfx950, pade 2/4/6/8/10)"
+
+#define PCL_NSP 8   // B^{+-} value pairs per thread of a 256-thread group: (n*n/2) / 256 <= 8 for n <= 64
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -87,6 +89,8 @@ struct KParams {
     double *blocks;
     unsigned int *flags;
     int nt;       // 1: nontemporal streaming stores
+    int q;        // general-order kernel: p/2
+    double pc[6]; // general-order kernel: diagonal Pade coefficients c_0..c_q
     int ablate;   // DEBUG ONLY (wrong results): bit0 skip matrix products, bit1 skip block streaming, bit2 skip column outputs
 };
 
@@ -309,6 +313,197 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
                 store2(o0, bp0, bp1, p.nt);
                 store2(o0 + blk, bm0, bm1, p.nt);
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// General-order kernel: diagonal Pade orders p = 2q, q <= 5 (p = 2, 6, 8, 10; p = 4 only as a cross-check of the
+// specialised kernels).  One workgroup per (b, k, slice of nc columns); correctness first, no wave specialisation.
+// With Y_j = (-1)^j X_{k+1} - X_k (D for even j, -S for odd j) and c_j the Pade coefficients:
+//   residual (Horner)   W_q = c_q Y_q,  W_j = c_j Y_j + h G W_{j+1},  delta = W_0
+//   d/dh                V_q = q c_q Y_q, V_j = j c_j Y_j + h G V_{j+1} (j >= 1),  d delta/dh = G V_1
+//   d/du_l              dW_q = 0,  dW_j = h (G_l W_{j+1} + G dW_{j+1}),  d delta/du_l = dW_0
+//   blocks              B^{+-} = sum_j c_j (+-h)^j G^j, powers by repeated products, sums in registers
+// LDS map (doubles): G | Pa | Pb (JAC) | -S | D | W_0..W_q | V (2, JAC) | dWa, dWb (m each, JAC) | us      (column blocks LD*nc)
+// ------------------------------------------------------------------------------------------
+template <bool JAC>
+__global__ __launch_bounds__(256) void pcl_pade_kernel(const KParams p) {
+    extern __shared__ double lds[];
+    const int n = p.n, d = p.cols, m = p.m, LD = p.LD, nc = p.nc, q = p.q;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int bid = blockIdx.x;
+    const int s = bid % p.S;
+    const int k = (bid / p.S) % p.K;
+    const int b = bid / (p.S * p.K);
+    const int c0 = s * nc;
+    const int nce = min(nc, d - c0);
+    const int LDc = LD * nc;
+
+    double *G = lds;
+    double *Pa = G + LD * n;
+    double *Pb = Pa + (JAC ? LD * n : 0);
+    double *Sm = Pb + (JAC ? LD * n : 0);  // -S
+    double *Dm = Sm + LDc;
+    double *W = Dm + LDc;  // W_j at W + j*LDc
+    double *V = W + (q + 1) * LDc;
+    double *dWa = V + (JAC ? 2 * LDc : 0);
+    double *dWb = dWa + (JAC ? m * LDc : 0);
+    double *us = dWb + (JAC ? m * LDc : 0);
+
+    const double *Zb = p.Z + (long long)b * p.z_batch_stride;
+    const double *zk = Zb + (long long)k * p.z_dim;
+    const double *zn = zk + p.z_dim;
+    const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+    const double h = zk[p.dt_off];
+    const long long xd = (long long)n * d;
+
+    build_G(p, p.G0 + (long long)b * p.g0_batch_stride, zk, G, us);
+    for (int e = tid; e < nc * n; e += nth) {
+        const int c = e / n, i = e % n;
+        double xs = 0.0, xdv = 0.0;
+        if (c < nce) {
+            const double xn = zn[x_off + (c0 + c) * n + i], xc = zk[x_off + (c0 + c) * n + i];
+            xs = xn + xc;
+            xdv = xn - xc;
+        }
+        Sm[i + LD * c] = -xs;
+        Dm[i + LD * c] = xdv;
+    }
+    __syncthreads();
+    auto Y = [&](int j) { return (j & 1) ? Sm : Dm; };
+
+    // ---- residual: Horner in G ---------------------------------------------------------------------------------
+    for (int e = tid; e < nc * n; e += nth) {
+        const int idx = (e % n) + LD * (e / n);
+        W[q * LDc + idx] = p.pc[q] * Y(q)[idx];
+    }
+    __syncthreads();
+    for (int j = q - 1; j >= 0; --j) {
+        gemm_lds<true, false>(G, LD, W + (j + 1) * LDc, LD, W + j * LDc, LD, n, nc, n);
+        __syncthreads();
+        for (int e = tid; e < nc * n; e += nth) {
+            const int idx = (e % n) + LD * (e / n);
+            W[j * LDc + idx] = p.pc[j] * Y(j)[idx] + h * W[j * LDc + idx];
+        }
+        __syncthreads();
+    }
+    const long long bk = (long long)b * p.K + k;
+    if (p.delta)
+        for (int e = tid; e < nce * n; e += nth) p.delta[bk * xd + (long long)c0 * n + e] = W[(e % n) + LD * (e / n)];
+    if (!JAC) return;
+
+    double *jb = p.jac + bk * p.jac_per;
+    const long long blk = p.compact ? (long long)n * n : (long long)d * n * n;
+    double *jt = jb + 2 * blk;
+    // ---- d/dh ------------------------------------------------------------------------------------------------
+    {
+        double *cur = V, *oth = V + LDc;
+        for (int e = tid; e < nc * n; e += nth) {
+            const int idx = (e % n) + LD * (e / n);
+            cur[idx] = q * p.pc[q] * Y(q)[idx];
+        }
+        __syncthreads();
+        for (int j = q - 1; j >= 1; --j) {
+            gemm_lds<true, false>(G, LD, cur, LD, oth, LD, n, nc, n);
+            __syncthreads();
+            for (int e = tid; e < nc * n; e += nth) {
+                const int idx = (e % n) + LD * (e / n);
+                oth[idx] = j * p.pc[j] * Y(j)[idx] + h * oth[idx];
+            }
+            __syncthreads();
+            double *t = cur;
+            cur = oth;
+            oth = t;
+        }
+        gemm_lds<true, false>(G, LD, cur, LD, oth, LD, n, nc, n);
+        __syncthreads();
+        for (int e = tid; e < nce * n; e += nth) {
+            const int c = e / n, i = e % n;
+            jt[((long long)(c0 + c) * (m + 1) + m) * n + i] = oth[i + LD * c];
+        }
+    }
+    // ---- d/du_l ----------------------------------------------------------------------------------------------
+    if (m > 0) {
+        double *cur = dWa, *oth = dWb;
+        for (int e = tid; e < m * nc * n; e += nth) {
+            const int i = e % n, c = (e / n) % nc, l = e / (n * nc);
+            const int *rp = p.csr_ptr + l * (n + 1);
+            double a = 0.0;
+            for (int t = rp[i]; t < rp[i + 1]; ++t) a += p.csr_val[t] * W[q * LDc + p.csr_col[t] + LD * c];
+            cur[l * LDc + i + LD * c] = h * a;
+        }
+        __syncthreads();
+        for (int j = q - 2; j >= 0; --j) {
+            gemm_lds<true, false>(G, LD, cur, LD, oth, LD, n, m * nc, n);
+            __syncthreads();
+            for (int e = tid; e < m * nc * n; e += nth) {
+                const int i = e % n, c = (e / n) % nc, l = e / (n * nc);
+                const int *rp = p.csr_ptr + l * (n + 1);
+                double a = 0.0;
+                for (int t = rp[i]; t < rp[i + 1]; ++t) a += p.csr_val[t] * W[(j + 1) * LDc + p.csr_col[t] + LD * c];
+                oth[l * LDc + i + LD * c] = h * (oth[l * LDc + i + LD * c] + a);
+            }
+            __syncthreads();
+            double *t = cur;
+            cur = oth;
+            oth = t;
+        }
+        for (int e = tid; e < m * nce * n; e += nth) {
+            const int i = e % n, c = (e / n) % nce, l = e / (n * nce);
+            jt[((long long)(c0 + c) * (m + 1) + l) * n + i] = cur[l * LDc + i + LD * c];
+        }
+    }
+    // ---- blocks: B^{+-} = sum_j c_j (+-h)^j G^j ------------------------------------------------------------------
+    {
+        const int half = (n * n) >> 1;
+        double bp[PCL_NSP][2], bm[PCL_NSP][2];  // pairs (2q', 2q'+1), q' = tid + 256 r
+#pragma unroll
+        for (int r = 0; r < PCL_NSP; ++r) {
+            const int pos = 2 * (tid + 256 * r);
+            const int i = pos % n, jj = pos / n;
+            bp[r][0] = bm[r][0] = (i == jj) ? 1.0 : 0.0;
+            bp[r][1] = bm[r][1] = (i + 1 == jj) ? 1.0 : 0.0;
+        }
+        const double *Pc = G;
+        double hp = 1.0, hm = 1.0;
+        for (int j = 1; j <= q; ++j) {
+            hp *= h;
+            hm *= -h;
+#pragma unroll
+            for (int r = 0; r < PCL_NSP; ++r) {
+                const int qq = tid + 256 * r;
+                if (qq < half) {
+                    const int pos = 2 * qq;
+                    const int i = pos % n, jj = pos / n;
+                    const double v0 = Pc[i + LD * jj], v1 = Pc[i + 1 + LD * jj];
+                    bp[r][0] += p.pc[j] * hp * v0;
+                    bp[r][1] += p.pc[j] * hp * v1;
+                    bm[r][0] += p.pc[j] * hm * v0;
+                    bm[r][1] += p.pc[j] * hm * v1;
+                }
+            }
+            if (j < q) {
+                double *Pn = (Pc == Pa) ? Pb : Pa;
+                gemm_lds<true, false>(G, LD, Pc, LD, Pn, LD, n, n, n);
+                __syncthreads();
+                Pc = Pn;
+            }
+        }
+        int cbeg = c0, cend = c0 + nce;
+        if (p.compact) {
+            cbeg = 0;
+            cend = (s == 0) ? 1 : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < PCL_NSP; ++r) {
+            const int qq = tid + 256 * r;
+            if (qq < half)
+                for (int c = cbeg; c < cend; ++c) {
+                    double *o0 = jb + (long long)c * n * n + 2 * qq;
+                    store2(o0, -bp[r][0], -bp[r][1], p.nt);
+                    store2(o0 + blk, bm[r][0], bm[r][1], p.nt);
+                }
         }
     }
 }
@@ -1074,7 +1269,6 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-#define PCL_NSP 8   // B^{+-} value pairs per stream thread: (n*n/2) / 256 <= 8 for n <= 64
 #define PCL_MAXRT 4 // 16-row tiles of an n <= 64 operand
 #define PCL_MREG 8  // drives whose ELL row is held in registers (EW > 0 variants)
 #define PCL_PFC 4   // chunks per matrix wave whose state inputs are fetched at the top of the item (registers)
@@ -2363,6 +2557,7 @@ struct pcl_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int64_t opt_cpp = 6;  // block copies per expander work item
     int64_t opt_specialize = 1;
+    int64_t opt_general = 0;  // 1: run the general-order kernel also for pade_order 4 (cross-check)
     int64_t opt_contig = -1;     // v3: contiguous column ranges per workgroup (-1: auto by launch size)
     int64_t opt_stream_wg = -1;  // v3, contiguous: stream-role workgroups (-1: auto = half, 0: every workgroup does both)
     int64_t last_n_stream = 0;  // stream-role workgroups of the last kernel-3 launch (0: fused roles / round-robin)
@@ -2432,9 +2627,8 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
                     m, dsc->N, dsc->batch);
     if (d > PCL_MAX_D) return fail(nullptr, PCL_ESHAPE, "pcl_create: d=%d exceeds PCL_MAX_D=%d (LDS-resident tiles)", d, PCL_MAX_D);
     if (m > 24) return fail(nullptr, PCL_ESHAPE, "pcl_create: n_drives=%d exceeds 24", m);
-    if (dsc->pade_order != 4)
-        return fail(nullptr, PCL_ENOTIMPL, "pcl_create: pade_order=%d; only the order-4 (2,2) Pade residual is implemented",
-                    dsc->pade_order);
+    if (dsc->pade_order != 2 && dsc->pade_order != 4 && dsc->pade_order != 6 && dsc->pade_order != 8 && dsc->pade_order != 10)
+        return fail(nullptr, PCL_ENOTIMPL, "pcl_create: pade_order=%d; diagonal Pade orders 2, 4, 6, 8, 10 are implemented", dsc->pade_order);
     if (dsc->index_base != 0 && dsc->index_base != 1) return fail(nullptr, PCL_EINVAL, "pcl_create: index_base must be 0 or 1");
     if (dsc->batch_mode != PCL_BATCH_MEMBERS && dsc->batch_mode != PCL_BATCH_TRAJ)
         return fail(nullptr, PCL_EINVAL, "pcl_create: unknown batch_mode %d", dsc->batch_mode);
@@ -2948,6 +3142,36 @@ static int set_lds_attr(pcl_ctx *ctx, const void *kern, int slot, size_t lds) {
     return PCL_OK;
 }
 
+// General-order kernel (pade_order != 4, or option general_pade_kernel): slice width from the LDS budget.
+static size_t pade_lds_bytes(const KParams &p, bool jac) {
+    const size_t tiles = (jac ? 3 : 1) * (size_t)p.LD * p.n;
+    const size_t percol = (size_t)(p.q + 1) + 2 + (jac ? 2 + 2 * (size_t)p.m : 0);
+    return (tiles + percol * p.LD * p.nc + 8 + p.m) * sizeof(double);
+}
+static int launch_pade_general(pcl_ctx *ctx, KParams &p, bool want_jac) {
+    p.q = ctx->desc.pade_order / 2;
+    double f[16];
+    f[0] = 1.0;
+    for (int i = 1; i < 16; ++i) f[i] = f[i - 1] * i;
+    for (int j = 0; j <= p.q; ++j) p.pc[j] = f[2 * p.q - j] * f[p.q] / (f[2 * p.q] * f[j] * f[p.q - j]);
+    p.nc = ctx->opt_cols_per_slice > 0 ? (int)std::min<int64_t>(ctx->opt_cols_per_slice, p.cols) : p.cols;
+    while (p.nc > 1 && pade_lds_bytes(p, want_jac) > (size_t)ctx->max_lds) --p.nc;
+    const size_t lds = pade_lds_bytes(p, want_jac);
+    if (lds > (size_t)ctx->max_lds)
+        return fail(ctx, PCL_ESHAPE, "general-order kernel needs %zu B of LDS (> %d) for d=%d, m=%d, order %d", lds, ctx->max_lds, p.d, p.m, 2 * p.q);
+    p.S = (p.cols + p.nc - 1) / p.nc;
+    const long long grid = (long long)p.batch * p.K * p.S;
+    if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+    typedef void (*kern_t)(const KParams);
+    kern_t kern = want_jac ? (kern_t)pcl_pade_kernel<true> : (kern_t)pcl_pade_kernel<false>;
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->last_kernel = 90 + p.q;
+    ctx->last_n_stream = 0;
+    return PCL_OK;
+}
+
 static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *jac, bool compact) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     KParams p;
@@ -2958,6 +3182,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     p.compact = compact ? 1 : 0;
     p.jac_per = compact ? jac_per_compact(ctx) : jac_per_full(ctx);
     const bool want_jac = jac != nullptr;
+    if (ctx->desc.pade_order != 4 || ctx->opt_general) return launch_pade_general(ctx, p, want_jac);
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
     if (want_jac && !compact && (ctx->opt_kernel == 3 || ctx->opt_kernel == 0) && ctx->opt_use_mfma != 0 && v3_supported(ctx) &&
         ctx->cols == ctx->desc.d) {  // the default whenever its LDS budget fits (else kernels 2 / 4 below)
@@ -3112,6 +3337,8 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
     p.mu = mu;
     p.hess = hess;
     const bool mf = ctx->opt_use_mfma != 0;
+    if (ctx->desc.pade_order != 4)
+        return fail(ctx, PCL_ENOTIMPL, "the Hessian of the Lagrangian is implemented for pade_order 4 only (have %d)", ctx->desc.pade_order);
     if (ctx->opt_hess_kernel == 2 && !hess_v2_supported(ctx))
         return fail(ctx, PCL_ESHAPE, "hess_kernel=2 needs 1..6 drives with at most %d entries per row and column (have m=%d, widths %d/%d)",
                     PCL_HESS_EW, p.m, ctx->ell_w, ctx->ellt_w);
@@ -3455,6 +3682,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_cpp = v;
     else if (!strcmp(key, "specialize"))  // 0: always the run-time-shape kernel instances
         ctx->opt_specialize = v != 0;
+    else if (!strcmp(key, "general_pade_kernel"))  // 1: the general-order kernel also for pade_order 4
+        ctx->opt_general = v != 0;
     else if (!strcmp(key, "stream_workgroups"))  // kernel 3, contiguous: > 0 = role split with this many stream-role workgroups
         ctx->opt_stream_wg = v;
     else if (!strcmp(key, "contiguous"))  // kernel 3: 1 = equal contiguous column ranges per workgroup (default), 0 = round-robin slices

@@ -279,6 +279,7 @@ class HipPadeIntegrator:
         self.u_name = u_name
         self.G_drift, self.G_drives = G_drift, G_drives.reshape(m, n, n)
         self._sig = (traj.dim, traj.N)
+        self.pade_order = pade_order
         self._ctx = _PclContext(
             d=d, m=m, N=traj.N, z_dim=traj.dim, u_off=traj.components[u_name].start,
             dt_off=traj.components[traj.timestep].start, x_offs=[traj.components[nm].start for nm in x_names],
@@ -307,7 +308,7 @@ class HipPadeIntegrator:
         if self._f_ctx is None:
             self._f_ctx = _PclContext(d=c.d, m=c.m, N=2, z_dim=c.x_dim + 1 + c.m, u_off=c.x_dim + 1, dt_off=c.x_dim,
                                       x_offs=[0], G0=self.G_drift, Gj=self.G_drives, batch=1,
-                                      batch_mode=PCL_BATCH_MEMBERS, state_cols=c.x_dim // c.n)  # fmt: skip
+                                      batch_mode=PCL_BATCH_MEMBERS, state_cols=c.x_dim // c.n, pade_order=self.pade_order)  # fmt: skip
         z = np.zeros((2, c.x_dim + 1 + c.m))
         z[0, : c.x_dim], z[0, c.x_dim], z[0, c.x_dim + 1 :] = x, dt, np.asarray(u)[: c.m]
         z[1, : c.x_dim] = x_next

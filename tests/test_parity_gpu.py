@@ -373,9 +373,15 @@ def test_edge_shapes_general_dense_generators(d, m, N, x_off):
 def test_unsupported_requests_fail_loudly():
     rng = np.random.default_rng(0)
     lay, G0, Gj, Z = _random_case(2, 1, 3, rng)
-    with pytest.raises(pa.PclError) as ei:
-        make_ctx(lay, G0, Gj, pade_order=8)
+    for bad in (3, 5, 12, 0):
+        with pytest.raises(pa.PclError) as ei:
+            make_ctx(lay, G0, Gj, pade_order=bad)
+        assert ei.value.code == pa._lib.PCL_ENOTIMPL
+    c8 = make_ctx(lay, G0, Gj, pade_order=8)
+    with pytest.raises(pa.PclError) as ei:  # the Hessian exists at order 4 only: refused, not substituted
+        c8.hess(Z, np.zeros(c8.n_rows))
     assert ei.value.code == pa._lib.PCL_ENOTIMPL
+    c8.close()
     c = make_ctx(lay, G0, Gj)
     with pytest.raises(ValueError):
         c.eval(Z[:-1])
@@ -694,3 +700,94 @@ def test_config5_share_default_path():
     assert c.get_option("last_stream_workgroups") == 0
     assert np.array_equal(d2, delta) and np.array_equal(v2, vals)
     ms.close()
+
+
+# ---- higher Pade orders ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("order", [2, 4, 6, 8, 10])
+@pytest.mark.parametrize("cfg,N", [(1, 12), (2, 20), (3, 4)])
+def test_general_pade_orders_vs_oracle(order, cfg, N):
+    """delta and the Jacobian of the order-p residual B^-_p X_{k+1} - B^+_p X_k (general-order kernel; for p = 4 it is
+    forced with `general_pade_kernel` and must agree with the tuned kernels too), every slicing, compact form."""
+    so = po.config_system(cfg)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    Z, lay = po.synthetic_trajectory(so, N, seed=40 + cfg)
+    c = make_ctx(lay, G0, Gj, pade_order=order)
+    d_ref = po.pade_residual(Z, lay, G0, Gj, order)
+    j_ref = po.pade_jacobian_values(Z, lay, G0, Gj, order)
+    if order == 4:
+        d4, j4 = c.eval_jac(Z)
+        c.set_option("general_pade_kernel", 1)
+    for cps in (0, 1, 2, 5):
+        c.set_option("cols_per_slice", cps)
+        delta, vals = c.eval_jac(Z)
+        assert c.get_option("last_kernel") == 90 + order // 2
+        close(delta, d_ref, 1e-11)
+        close(vals, j_ref, 1e-11)
+        close(c.eval(Z), d_ref, 1e-11)
+    if order == 4:
+        close(delta, d4)
+        close(vals, j4)
+    c.close()
+
+
+def test_higher_orders_reach_the_reference_exp_floor(golden, golden_meta):
+    """The reference's constraint is x_{k+1} = expv(dt G) x_k.  On its own solved trajectory (two_qubit_zoh, exp-residual
+    6e-12) the GPU residual of order 4 sits at 1.5e-9 (Pade truncation), orders 6, 8, 10 at the reference's floor."""
+    systems, lay, _ = ref_case("two_qubit_zoh", golden_meta)
+    Z = golden("ref_two_qubit_zoh")["Z"]
+    so = systems[0]
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    r_exp = np.abs(po.exp_residual(Z, lay, G0, Gj)).max()
+    assert r_exp < 1e-11
+    got = {}
+    for order in (2, 4, 6, 8, 10):
+        c = make_ctx(lay, G0, Gj, pade_order=order)
+        delta = c.eval(Z)
+        close(delta, po.pade_residual(Z, lay, G0, Gj, order), 1e-12)
+        got[order] = np.abs(delta).max()
+        c.close()
+    assert got[2] > 1e-6 and 1e-9 < got[4] < 3e-9
+    for order in (6, 8, 10):
+        assert got[order] < 2e-11, got
+
+
+def test_general_order_ket_ensemble_and_integrator_interface():
+    """Order 8 through the plug-in interface: a ket integrator and a 3-member ensemble with per-member drift."""
+    rng = np.random.default_rng(8)
+    d, m, N = 3, 2, 6
+    n = 2 * d
+    Hd = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+    Hd = Hd + Hd.conj().T
+    Hs = []
+    for _ in range(m):
+        A = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+        Hs.append(A + A.conj().T)
+    so = po.quantum_system(0.3 * Hd, Hs, [1.0] * m)
+    z_dim = n + 2 + 3 * m
+    lay = po.Layout(d=d, m=m, N=N, z_dim=z_dim, x_off=0, u_off=n + 2, dt_off=n, cols=1)
+    Z = 0.5 * rng.standard_normal((N, z_dim))
+    Z[:, lay.dt_off] = 0.05 + 0.05 * rng.random(N)
+    comps = {"ψ̃": Z[:, :n].T, "Δt": Z[:, n][None], "t": Z[:, n + 1][None], "u": Z[:, n + 2 : n + 2 + m].T,
+             "du": Z[:, n + 2 + m : n + 2 + 2 * m].T, "ddu": Z[:, n + 2 + 2 * m :].T}  # fmt: skip
+    traj = pa.NamedTrajectory(comps, controls=("ddu", "Δt"), timestep="Δt")
+    B = pa.BilinearIntegrator(pa.QuantumSystem(so.H_drift, so.H_drives, [1.0] * m), traj, x_name="ψ̃", pade_order=8)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    d2, vals = B.ctx.eval_jac(traj.datavec)
+    close(d2, po.pade_residual(Z, lay, G0, Gj, 8), 1e-11)
+    close(vals, po.pade_jacobian_values(Z, lay, G0, Gj, 8), 1e-11)
+    close(B.f(Z[2, :n], Z[1, :n], Z[1, n + 2 : n + 2 + m], Z[1, n]), d2[n : 2 * n], 1e-11)
+    B.close()
+    # ensemble
+    systems = [po.quantum_system(s_ * 0.5 * po.PAULIS["Z"], [po.PAULIS["X"], po.PAULIS["Y"]], [1.0, 1.0]) for s_ in (1.0, 1.05, 0.95)]
+    M, dd, xd = 3, 2, 8
+    layE = po.Layout(d=dd, m=2, N=7, z_dim=M * xd + 2 + 2, x_off=0, u_off=M * xd + 2, dt_off=M * xd)
+    ZE = 0.3 * rng.standard_normal((7, layE.z_dim))
+    ZE[:, layE.dt_off] = 0.1 + 0.1 * rng.random(7)
+    trajE = traj_from_Z(pa, ZE, layE, n_members=M)
+    BE = pa.BilinearIntegrator([pa.QuantumSystem(s_.H_drift, s_.H_drives, [1.0, 1.0]) for s_ in systems], trajE, pade_order=6)
+    delta, vals = BE.ctx.eval_jac(trajE.datavec)
+    per_d, per_j = layE.x_dim * layE.K, po.jac_nnz_per_interval(layE) * layE.K
+    for i, s_ in enumerate(systems):
+        close(delta[i * per_d : (i + 1) * per_d], po.pade_residual(ZE, layE, s_.G_drift, np.array(s_.G_drives), 6, x_off=i * xd), 1e-11)
+        close(vals[i * per_j : (i + 1) * per_j], po.pade_jacobian_values(ZE, layE, s_.G_drift, np.array(s_.G_drives), 6, x_off=i * xd), 1e-11)
+    BE.close()
