@@ -50,7 +50,7 @@ mutable struct HipPadeIntegrator <: AbstractIntegrator
 end
 
 function _create(G0s::Vector{<:AbstractMatrix}, Gjs::Vector{<:AbstractMatrix}, traj::NamedTrajectory,
-                 x_names::Vector{Symbol}, u_name::Symbol; device::Integer = 0)
+                 x_names::Vector{Symbol}, u_name::Symbol; device::Integer = 0, pade_order::Integer = 4)
     n = size(G0s[1], 1); d = n ÷ 2; m = length(Gjs)
     G0 = reduce(vcat, [vec(Matrix{Float64}(G)) for G in G0s])          # column-major, one block per member
     Gj = m == 0 ? zeros(1) : reduce(vcat, [vec(Matrix{Float64}(G)) for G in Gjs])
@@ -59,7 +59,7 @@ function _create(G0s::Vector{<:AbstractMatrix}, Gjs::Vector{<:AbstractMatrix}, t
     GC.@preserve G0 Gj x_offs begin
         desc = PclDesc(sizeof(PclDesc), d, m, traj.N, traj.dim,
                        traj.components[u_name][1] - 1, traj.components[traj.timestep][1] - 1,
-                       length(x_names), 0 #= PCL_BATCH_MEMBERS =#, 4, device, 1 #= 1-based =#,
+                       length(x_names), 0 #= PCL_BATCH_MEMBERS =#, pade_order #= 2, 4, 6, 8 or 10 =#, device, 1 #= 1-based =#,
                        length(G0s) > 1 ? 1 : 0, 0, traj.global_dim,
                        pointer(G0), pointer(Gj), pointer(x_offs))
         rc = ccall((:pcl_create, LIB), Cint, (Ref{PclDesc}, Ref{Ptr{Cvoid}}), desc, ctx)
