@@ -172,6 +172,14 @@ int pcl_deriv_eval_jac_dev(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t 
 int pcl_set_goal(pcl_ctx *ctx, const double *goal_iso_vec);
 int pcl_infidelity_dev(pcl_ctx *ctx, const double *Z_dev, double Q, double *value_dev, double *grad_dev);
 
+/* rollout for validation ------------------------------------------------------------------------
+ *   unitary_rollout(traj, sys; interpolation = :constant)                       src/quantum/dynamics.jl:631-667
+ *   RolloutStates: "a GPU rollout overwrites `states` in place"                 src/quantum/trajectories/ensemble_trajectory.jl:56-71
+ * Exact piecewise-constant propagation X_{k+1} = exp(dt_k G(u_k)) X_k from the knot-0 state of every member / trajectory
+ * (scaling and squaring, to rounding).  X_out: [batch][N][x_dim] doubles, iso-vec per knot (knot 0 = the input state). */
+int pcl_rollout(pcl_ctx *ctx, const double *Z, double *X_out);
+int pcl_rollout_dev(pcl_ctx *ctx, const double *Z_dev, double *X_out_dev);
+
 /* multi-GPU: the one exchange of the path ------------------------------------------------------
  * One context per GPU/process.  Rank 0 obtains an id, ships the 128 bytes to the other ranks by any means (MPI,
  * sockets, a file), every rank calls pcl_comm_init; pcl_reduce_sum_dev is an in-place RCCL all-reduce(sum, f64) over

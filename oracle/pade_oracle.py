@@ -378,6 +378,22 @@ def exp_residual(Z, lay: Layout, G0, Gj, x_off=None):
     return out
 
 
+def exact_rollout(Z, lay: Layout, G0, Gj, x_off=None):
+    """X_{k+1} = expm(dt_k G(u_k)) X_k from the knot-0 state: what the reference's
+    unitary_rollout(...; interpolation = :constant) integrates [REF src/quantum/dynamics.jl:631-667].
+    Returns [N, x_dim] iso-vec rows."""
+    from scipy.linalg import expm
+
+    X = lay.X(Z, 0, x_off)
+    out = np.empty((lay.N, lay.x_dim))
+    out[0] = X.T.reshape(-1)
+    for k in range(lay.K):
+        G = G0 + np.tensordot(lay.u(Z, k), Gj, axes=1) if lay.m else G0
+        X = expm(lay.dt(Z, k) * G) @ X
+        out[k + 1] = X.T.reshape(-1)
+    return out
+
+
 def _powers(G, q):
     P = [np.eye(G.shape[0])]
     for _ in range(q):

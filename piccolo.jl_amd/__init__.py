@@ -16,6 +16,8 @@ from .integrators import (
     evaluate_,
     hessian_structure,
     jacobian_structure,
+    unitary_rollout,
+    unitary_rollout_fidelity,
 )
 from .quantum import (
     GATES,

@@ -89,6 +89,8 @@ struct KParams {
     double *blocks;
     unsigned int *flags;
     int nt;       // 1: nontemporal streaming stores
+    double *expm;  // rollout: per (b,k) propagator exp(dt_k G(u_k)), n*n col-major
+    double *xout;  // rollout: states at every knot, [batch][N][x_dim]
     int q;        // general-order kernel: p/2
     double pc[6]; // general-order kernel: diagonal Pade coefficients c_0..c_q
     int ablate;   // DEBUG ONLY (wrong results): bit0 skip matrix products, bit1 skip block streaming, bit2 skip column outputs
@@ -2433,6 +2435,95 @@ __global__ __launch_bounds__(256, 2) void pcl_hess_kernel_v2(const KParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Rollout: exact piecewise-constant propagation  X_{k+1} = exp(dt_k G(u_k)) X_k  from the knot-0 state
+// -- what the reference's unitary_rollout(...; interpolation = :constant) integrates with an ODE solver
+// [REF src/quantum/dynamics.jl:631-667] and the slot its RolloutStates reserves for "a GPU rollout"
+// [REF src/quantum/trajectories/ensemble_trajectory.jl:56-71].
+//   pcl_expm_kernel   one workgroup per (b, k): E = exp(h G) by scaling and squaring, Taylor degree 14 (Horner) at
+//                     |h| ||G||_1 / 2^s <= 1/4 (truncation < 1e-21), products on the matrix cores
+//   pcl_chain_kernel  one workgroup per member / trajectory: the K dependent n x n x cols products
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pcl_expm_kernel(const KParams p) {
+    extern __shared__ double lds[];
+    const int n = p.n, LD = p.LD;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int k = blockIdx.x % p.K, b = blockIdx.x / p.K;
+    double *A = lds, *T = A + LD * n, *T2 = T + LD * n, *us = T2 + LD * n, *red = us + 8 + p.m;
+    const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
+    const double h = zk[p.dt_off];
+    build_G(p, p.G0 + (long long)b * p.g0_batch_stride, zk, A, us);
+    __syncthreads();
+    if (tid < 64) {
+        double cs = 0.0;
+        if (tid < n)
+            for (int i = 0; i < n; ++i) cs += fabs(A[i + LD * tid]);
+        red[tid] = cs;
+    }
+    __syncthreads();
+    double nrm = 0.0;
+    for (int j = 0; j < n; ++j) nrm = fmax(nrm, red[j]);
+    double theta = fabs(h) * nrm;
+    int sq = 0;
+    while (theta > 0.25 && sq < 60) {
+        theta *= 0.5;
+        ++sq;
+    }
+    const double hs = ldexp(h, -sq);
+    for (int e = tid; e < n * n; e += nth) T[(e % n) + LD * (e / n)] = (e % n == e / n) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int j = 14; j >= 1; --j) {  // T <- I + (hs/j) A T
+        gemm_lds<true, false>(A, LD, T, LD, T2, LD, n, n, n);
+        __syncthreads();
+        const double f = hs / j;
+        for (int e = tid; e < n * n; e += nth) {
+            const int idx = (e % n) + LD * (e / n);
+            T[idx] = ((e % n == e / n) ? 1.0 : 0.0) + f * T2[idx];
+        }
+        __syncthreads();
+    }
+    double *cur = T, *oth = T2;
+    for (int i = 0; i < sq; ++i) {
+        gemm_lds<true, false>(cur, LD, cur, LD, oth, LD, n, n, n);
+        __syncthreads();
+        double *t = cur;
+        cur = oth;
+        oth = t;
+    }
+    double *E = p.expm + ((long long)b * p.K + k) * n * n;
+    for (int e = tid; e < n * n; e += nth) E[e] = cur[(e % n) + LD * (e / n)];
+}
+
+__global__ __launch_bounds__(256) void pcl_chain_kernel(const KParams p) {
+    extern __shared__ double lds[];
+    const int n = p.n, LD = p.LD, cols = p.cols;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int b = blockIdx.x;
+    const long long xd = (long long)n * cols;
+    double *E = lds, *Xa = E + LD * n, *Xb = Xa + LD * cols;
+    const double *z0 = p.Z + (long long)b * p.z_batch_stride;
+    const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+    double *out = p.xout + (long long)b * (p.K + 1) * xd;
+    for (int e = tid; e < xd; e += nth) {
+        const double v = z0[x_off + e];
+        Xa[(e % n) + LD * (e / n)] = v;
+        out[e] = v;
+    }
+    double *cur = Xa, *oth = Xb;
+    for (int k = 0; k < p.K; ++k) {
+        const double *Ek = p.expm + ((long long)b * p.K + k) * n * n;
+        __syncthreads();  // previous product complete (E and `oth` free)
+        for (int e = tid; e < n * n; e += nth) E[(e % n) + LD * (e / n)] = Ek[e];
+        __syncthreads();
+        gemm_lds<true, false>(E, LD, cur, LD, oth, LD, n, cols, n);
+        __syncthreads();
+        for (int e = tid; e < xd; e += nth) out[(long long)(k + 1) * xd + e] = oth[(e % n) + LD * (e / n)];
+        double *t = cur;
+        cur = oth;
+        oth = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // DerivativeIntegrator rows  x_{k+1} - x_k - dt_k * dx_k  and the time-consistency row  t_{k+1} - t_k - dt_k
 // (dx_off < 0: dx == 1).  Trivially sparse; one thread per (b, k, r).  Values per (b,k): [-1 (dim) | +1 (dim) |
 // -dt_k (dim, absent for time consistency) | -dx_k[r] (dim)].
@@ -2539,6 +2630,7 @@ struct pcl_ctx {
     int ellt_w = 0;
     int drives_antisym = 0;  // every G_l == -G_l^T exactly
     double *dug0 = nullptr;
+    double *dexpm = nullptr, *dxout = nullptr;  // rollout scratch: propagators, staged output of the host-pointer call
     double *dhpart = nullptr;  // Hessian v2 scratch: per (b,k,slice) partial scalar entries + per (b,k) arrival counters
     unsigned int *dhcnt = nullptr;
     long long hpart_cap = 0;
@@ -2841,7 +2933,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     void *ptrs[] = {ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
                     ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg, ctx->dellt_col, ctx->dellt_val,
-                    ctx->dhpart, ctx->dhcnt, ctx->dug0};
+                    ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (ctx->dgoal) (void)hipFree(ctx->dgoal);
@@ -3443,6 +3535,28 @@ extern "C" int pcl_hess_dev(pcl_ctx *ctx, const double *Z, const double *mu, dou
     return launch_hess(ctx, Z, mu, vals);
 }
 
+extern "C" int pcl_rollout_dev(pcl_ctx *ctx, const double *Z, double *X_out) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !X_out) return fail(ctx, PCL_EINVAL, "pcl_rollout_dev: NULL pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    KParams p;
+    fill_params(ctx, p);
+    p.Z = Z;
+    p.xout = X_out;
+    if (!ctx->dexpm) HIP_TRY(ctx, hipMalloc((void **)&ctx->dexpm, (size_t)p.batch * p.K * p.n * p.n * sizeof(double)));
+    p.expm = ctx->dexpm;
+    const size_t lds_a = (3 * (size_t)p.LD * p.n + 8 + p.m + 64) * sizeof(double);
+    const size_t lds_b = ((size_t)p.LD * p.n + 2 * (size_t)p.LD * p.cols) * sizeof(double);
+    if (lds_a > (size_t)ctx->max_lds || lds_b > (size_t)ctx->max_lds) return fail(ctx, PCL_ESHAPE, "pcl_rollout_dev: tiles exceed LDS");
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)pcl_expm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void *)pcl_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+    hipLaunchKernelGGL(pcl_expm_kernel, dim3((unsigned)((long long)p.batch * p.K)), dim3(256), lds_a, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(pcl_chain_kernel, dim3((unsigned)p.batch), dim3(256), lds_b, ctx->stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCL_OK;
+}
+
 // --- host-pointer API (staging buffers owned by the context) --------------------------------------
 static int ensure(pcl_ctx *ctx, double **buf, long long count) {
     if (*buf) return PCL_OK;
@@ -3495,6 +3609,20 @@ extern "C" int pcl_hess(pcl_ctx *ctx, const double *Z, const double *mu, double 
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dmu, mu, n_rows(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     TRY(launch_hess(ctx, ctx->dZ, ctx->dmu, ctx->dhess));
     HIP_TRY(ctx, hipMemcpyAsync(vals, ctx->dhess, nv * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+
+extern "C" int pcl_rollout(pcl_ctx *ctx, const double *Z, double *X_out) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !X_out) return fail(ctx, PCL_EINVAL, "pcl_rollout: NULL pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long nv = (long long)ctx->desc.batch * ctx->desc.N * ctx->x_dim;
+    TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
+    TRY(ensure(ctx, &ctx->dxout, nv));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dZ, Z, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    TRY(pcl_rollout_dev(ctx, ctx->dZ, ctx->dxout));
+    HIP_TRY(ctx, hipMemcpyAsync(X_out, ctx->dxout, nv * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PCL_OK;
 }

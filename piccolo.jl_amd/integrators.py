@@ -222,6 +222,17 @@ class _PclContext:
     def infidelity_dev(self, Z, Q, value=None, grad=None):
         self._chk(self._L.pcl_infidelity_dev(self._h, _ptr(Z), float(Q), _ptr(value), _ptr(grad)))
 
+    # -- rollout (exact piecewise-constant propagation from the knot-0 state) ----------------------------------------
+    def rollout(self, Z, out=None):
+        """[batch, N, x_dim] iso-vec states: X_{k+1} = exp(dt_k G(u_k)) X_k."""
+        Z = self._z(Z)
+        out = np.empty((self.batch, self.N, self.x_dim)) if out is None else out
+        self._chk(self._L.pcl_rollout(self._h, _ptr(Z), _ptr(out)))
+        return out
+
+    def rollout_dev(self, Z, out):
+        self._chk(self._L.pcl_rollout_dev(self._h, _ptr(Z), _ptr(out)))
+
     # -- RCCL (C-ABI path; torch.distributed is the alternative plumbing, see distributed.py) ----------------
     def comm_unique_id(self):
         buf = ctypes.create_string_buffer(128)
@@ -452,3 +463,28 @@ def eval_hessian_of_lagrangian(B, traj, mu):
     nv = traj.dim * traj.N + traj.global_dim
     L = sp.coo_matrix((vals, (rows, cols)), shape=(nv, nv)).tocsr()
     return L + sp.tril(L, -1).T
+
+
+def unitary_rollout(B, traj):
+    """``unitary_rollout(traj, sys; interpolation = :constant)`` [REF src/quantum/dynamics.jl:631-667]: the iso-vec
+    states at every knot, ``x_dim x N`` (a list of such arrays for an ensemble integrator), by exact propagation
+    ``exp(dt_k G(u_k))`` on the GPU instead of an ODE solve.  Starts from the trajectory's knot-0 state."""
+    B._check(traj)
+    X = B.ctx.rollout(traj.datavec)
+    outs = [X[i].T.copy() for i in range(X.shape[0])]
+    return outs[0] if len(outs) == 1 else outs
+
+
+def unitary_rollout_fidelity(B, traj, U_goal=None):
+    """``unitary_rollout_fidelity`` [REF src/quantum/dynamics.jl:594-629]: ``|tr(U_goal' U_N)|^2 / d^2`` of the rolled-out
+    terminal state(s); ``U_goal`` defaults to the trajectory's goal for the integrator's state."""
+    from .quantum import iso_vec_to_operator
+
+    X = unitary_rollout(B, traj)
+    Xs = X if isinstance(X, list) else [X]
+    fids = []
+    for name, Xi in zip(B.x_names, Xs):
+        Ug = np.asarray(U_goal) if U_goal is not None else iso_vec_to_operator(traj.goal[name])
+        Uf = iso_vec_to_operator(Xi[:, -1])
+        fids.append(abs(np.trace(Ug.conj().T @ Uf)) ** 2 / Ug.shape[0] ** 2)
+    return fids[0] if len(fids) == 1 else fids

@@ -247,3 +247,16 @@ def test_derivative_rows_jacobian_finite_differences():
     np.add.at(J, (r, c), v)
     f = lambda z: po.time_consistency_residual(z.reshape(N, z_dim), 1, dt_off).reshape(-1)
     assert np.abs(J - _fd_jac(f, Z.reshape(-1).copy())).max() < 1e-8
+
+
+def test_oracle_rollout_reproduces_reference_solved_states(golden, golden_meta):
+    """Pin of `exact_rollout` (the checker of the GPU rollout): propagating the reference's own converged trajectory from
+    its knot-0 state with exp(dt_k G(u_k)) must land on the reference's own states (it solved x_{k+1} = expv(dt G) x_k to
+    6e-12 per knot), at every knot."""
+    systems, lay, _ = ref_case("two_qubit_zoh", golden_meta)
+    Z = golden("ref_two_qubit_zoh")["Z"]
+    so = systems[0]
+    X = po.exact_rollout(Z, lay, so.G_drift, np.array(so.G_drives))
+    states = np.stack([lay.X(Z, k).T.reshape(-1) for k in range(lay.N)])
+    assert np.abs(X - states).max() < 1e-9
+    assert np.array_equal(X[0], states[0])

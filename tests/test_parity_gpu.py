@@ -791,3 +791,72 @@ def test_general_order_ket_ensemble_and_integrator_interface():
         close(delta[i * per_d : (i + 1) * per_d], po.pade_residual(ZE, layE, s_.G_drift, np.array(s_.G_drives), 6, x_off=i * xd), 1e-11)
         close(vals[i * per_j : (i + 1) * per_j], po.pade_jacobian_values(ZE, layE, s_.G_drift, np.array(s_.G_drives), 6, x_off=i * xd), 1e-11)
     BE.close()
+
+
+# ---- rollout ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["two_qubit_zoh", "multilevel_transmon", "first_gate"])
+def test_rollout_on_reference_solved_trajectories(name, golden, golden_meta):
+    """Exact piecewise-constant propagation on the GPU vs scipy expm, and vs the reference's own solved states: a
+    trajectory that satisfies x_{k+1} = expv(dt G) x_k to 1e-11 per knot IS its own rollout (to the accumulated
+    constraint residual)."""
+    systems, lay, _ = ref_case(name, golden_meta)
+    Z = golden("ref_" + name)["Z"]
+    so = systems[0]
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    c = make_ctx(lay, G0, Gj)
+    X = c.rollout(Z)[0]
+    close(X, po.exact_rollout(Z, lay, G0, Gj), 1e-11)
+    states = np.stack([lay.X(Z, k).T.reshape(-1) for k in range(lay.N)])
+    dev = np.abs(X - states).max()
+    res = np.abs(po.exp_residual(Z, lay, G0, Gj)).max()
+    assert dev <= 2 * lay.N * res + 1e-12, (dev, res)
+    if name == "two_qubit_zoh":
+        assert dev < 1e-9
+    # unitarity of the propagated state (G is skew: exp(hG) orthogonal)
+    Xk = X[-1].reshape(lay.d, lay.n).T
+    U = Xk[: lay.d] + 1j * Xk[lay.d :]
+    assert np.abs(U.conj().T @ U - np.eye(lay.d)).max() < 1e-11
+    c.close()
+
+
+def test_rollout_interface_ensemble_ket_and_large_steps():
+    """unitary_rollout / unitary_rollout_fidelity through the integrator objects: config 3 synthetic (d = 27), an ensemble
+    with per-member drift, a ket, and steps with ||dt G|| >> 1 (several squarings)."""
+    so = po.config_system(3)
+    Z, lay = po.synthetic_trajectory(so, 12, seed=5)
+    Z[:, lay.dt_off] *= np.linspace(1.0, 40.0, lay.N)  # up to ||dt G||_1 ~ 25
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    psys = product_system(3)
+    traj = traj_from_Z(pa, Z, lay)
+    B = pa.BilinearIntegrator(psys, traj)
+    X = pa.unitary_rollout(B, traj)
+    assert X.shape == (lay.x_dim, lay.N)
+    close(X.T, po.exact_rollout(Z, lay, G0, Gj), 1e-10)
+    Ug = pa.iso_vec_to_operator(X[:, -1])
+    assert abs(pa.unitary_rollout_fidelity(B, traj, Ug) - 1.0) < 1e-10
+    B.close()
+    # ensemble: members propagate under their own drift from their own knot-0 state
+    rng = np.random.default_rng(2)
+    systems = [po.quantum_system(s_ * 0.5 * po.PAULIS["Z"], [po.PAULIS["X"], po.PAULIS["Y"]], [1.0, 1.0]) for s_ in (1.0, 1.05, 0.95)]
+    M, xd = 3, 8
+    layE = po.Layout(d=2, m=2, N=9, z_dim=M * xd + 2 + 2, x_off=0, u_off=M * xd + 2, dt_off=M * xd)
+    ZE = 0.3 * rng.standard_normal((9, layE.z_dim))
+    ZE[:, layE.dt_off] = 0.1 + 0.1 * rng.random(9)
+    trajE = traj_from_Z(pa, ZE, layE, n_members=M)
+    BE = pa.BilinearIntegrator([pa.QuantumSystem(s_.H_drift, s_.H_drives, [1.0, 1.0]) for s_ in systems], trajE)
+    XE = pa.unitary_rollout(BE, trajE)
+    for i, s_ in enumerate(systems):
+        close(XE[i].T, po.exact_rollout(ZE, layE, s_.G_drift, np.array(s_.G_drives), x_off=i * xd), 1e-11)
+    BE.close()
+    # ket
+    d, m, N = 5, 2, 7
+    n = 2 * d
+    Hd = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+    Hs = [(lambda A: A + A.conj().T)(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))) for _ in range(m)]
+    sk = po.quantum_system(0.3 * (Hd + Hd.conj().T), Hs, [1.0] * m)
+    layK = po.Layout(d=d, m=m, N=N, z_dim=n + 2 + m, x_off=0, u_off=n + 2, dt_off=n, cols=1)
+    ZK = 0.5 * rng.standard_normal((N, layK.z_dim))
+    ZK[:, layK.dt_off] = 0.05 + 0.05 * rng.random(N)
+    ck = make_ctx(layK, sk.G_drift, np.array(sk.G_drives), state_cols=1)
+    close(ck.rollout(ZK)[0], po.exact_rollout(ZK, layK, sk.G_drift, np.array(sk.G_drives)), 1e-11)
+    ck.close()
