@@ -72,6 +72,7 @@ struct KParams {
     int ncw;      // v3: state columns per matrix-wave chunk ((2+m)*ncw <= 16)
     int tab_lds;  // v3: union / ELL tables staged in LDS
     int contig;   // v3: 1 = contiguous column ranges per workgroup (see the kernel), 0 = items dealt round-robin
+    int flat;     // v3: 1 = line-aligned flat block stream (values recomputed from LDS per store), 0 = per-block stores from registers
     int n_stream; // v3, contig: > 0 = role split, this many stream-role workgroups (the rest do the column work)
     int iso;               // 1: G0 and every G_l are exact iso(.) images -> G^2 needs only its first d columns
     long long z_batch_stride;   // doubles between trajectories (0 in MEMBERS mode)
@@ -1766,7 +1767,50 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             int c0, nce, k, b;
             decode(it, c0, nce, k, b);
             const double *G = Gb + cur * tile, *G2 = G2b + cur * tile;
-            if (pact && !(p.ablate & 2) && !matrix_role) {
+            if (p.flat && !(p.ablate & 2) && !matrix_role) {
+                // Optional line-aligned flat stream (option aligned_stream): the item's share of a segment (copies
+                // cbeg..cend-1 of one n x n block) is ONE contiguous run; after a partial head up to the next 128-byte line
+                // every wave-level store covers eight whole lines (1 KiB); values recomputed per store from the LDS tiles.
+                // A bare store kernel gains 30-40 % from this alignment (scripts/probes/wstream2.hip); this kernel, whose
+                // per-block stores are 1 KiB contiguous per instruction already, does not (28.0 vs 28.2 us/eval).
+                const double h = us[(it % 3) * (m + 1) + m];
+                const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
+                int cbeg = c0, cend = c0 + nce;
+                if (p.compact) {
+                    cbeg = 0;
+                    cend = (c0 == 0) ? 1 : 0;
+                }
+                const long long L = (long long)(cend - cbeg) * nn;  // doubles per run
+                double *jbk = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn;
+                const int di = 512 % n, dj = (512 / n) % n;
+                auto put = [&](double *A0, long long a, int i, int j, int sg) {
+                    const double g0 = G[i + LD * j], g1 = G[i + 1 + LD * j];
+                    const double h0 = G2[i + LD * j], h1 = G2[i + 1 + LD * j];
+                    const double e0 = ((i == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((i + 1 == j) ? 1.0 : 0.0) + c2 * h1;
+                    if (sg == 0)
+                        store2(A0 + a, -(e0 + c1 * g0), -(e1 + c1 * g1), p.nt);
+                    else
+                        store2(A0 + a, e0 - c1 * g0, e1 - c1 * g1, p.nt);
+                };
+#pragma unroll
+                for (int sg = 0; sg < 2; ++sg) {
+                    double *A0 = jbk + sg * blk;
+                    const int head = (int)(((128 - ((unsigned long long)A0 & 127)) & 127) >> 3);  // doubles (even)
+                    if (2 * stid < head && 2 * stid < L) put(A0, 2 * stid, (2 * stid) % n, ((2 * stid) / n) % n, sg);
+                    long long a = head + 2LL * stid;
+                    int i = (int)(a % n), j = (int)((a / n) % n);
+                    for (; a < L; a += 512) {
+                        put(A0, a, i, j, sg);
+                        i += di;
+                        if (i >= n) {
+                            i -= n;
+                            ++j;
+                        }
+                        j += dj;
+                        if (j >= n) j -= n;
+                    }
+                }
+            } else if (pact && !(p.ablate & 2) && !matrix_role) {
                 const double h = us[(it % 3) * (m + 1) + m];
                 const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
                 double bpr[PCL_NSP][2], bmr[PCL_NSP][2];
@@ -2649,6 +2693,7 @@ struct pcl_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int64_t opt_cpp = 6;  // block copies per expander work item
     int64_t opt_specialize = 1;
+    int64_t opt_flat = 0;     // v3: line-aligned flat block stream (measured: no gain over the per-block stores, slower for one trajectory)
     int64_t opt_general = 0;  // 1: run the general-order kernel also for pade_order 4 (cross-check)
     int64_t opt_contig = -1;     // v3: contiguous column ranges per workgroup (-1: auto by launch size)
     int64_t opt_stream_wg = -1;  // v3, contiguous: stream-role workgroups (-1: auto = half, 0: every workgroup does both)
@@ -3281,6 +3326,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         // default: contiguous column ranges (one item per interval touched); an explicit cols_per_slice or
         // contiguous = 0 selects the round-robin slices
         p.contig = v3_contiguous(ctx) ? 1 : 0;
+        p.flat = ctx->opt_flat ? 1 : 0;
         p.nc = p.contig ? p.d : choose_cols_v3(ctx);
         p.ncw = v3_ncw(ctx, p.nc);
         p.tab_lds = 1;
@@ -3810,6 +3856,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_cpp = v;
     else if (!strcmp(key, "specialize"))  // 0: always the run-time-shape kernel instances
         ctx->opt_specialize = v != 0;
+    else if (!strcmp(key, "aligned_stream"))  // kernel 3: 1 = line-aligned flat block stream, 0 = per-block stores from registers (default)
+        ctx->opt_flat = v != 0;
     else if (!strcmp(key, "general_pade_kernel"))  // 1: the general-order kernel also for pade_order 4
         ctx->opt_general = v != 0;
     else if (!strcmp(key, "stream_workgroups"))  // kernel 3, contiguous: > 0 = role split with this many stream-role workgroups

@@ -670,8 +670,10 @@ def test_contiguous_column_ranges_any_grid():
     for grid, ns in ((0, 128), (0, 1), (0, 255), (2, 1), (7, 3), (100, 37), (256, 100), (256, 200)):
         c.set_option("grid", grid)
         c.set_option("stream_workgroups", ns)
-        delta, vals = c.eval_jac(np.stack(Zs))
-        assert np.array_equal(vals, j_rr) and np.array_equal(delta, d_rr), (grid, ns)
+        for flat in (0, 1):  # 1: line-aligned flat block stream, values recomputed per store from the LDS tiles
+            c.set_option("aligned_stream", flat)
+            delta, vals = c.eval_jac(np.stack(Zs))
+            assert np.array_equal(vals, j_rr) and np.array_equal(delta, d_rr), (grid, ns, flat)
     ms.close()
 
 
