@@ -72,6 +72,7 @@ struct KParams {
     int ncw;      // v3: state columns per matrix-wave chunk ((2+m)*ncw <= 16)
     int tab_lds;  // v3: union / ELL tables staged in LDS
     int contig;   // v3: 1 = contiguous column ranges per workgroup (see the kernel), 0 = items dealt round-robin
+    int snc;      // v3, role split: > 0 = the stream workgroups take pieces of snc columns round-robin (0: contiguous ranges)
     int flat;     // v3: 1 = line-aligned flat block stream (values recomputed from LDS per store), 0 = per-block stores from registers
     int n_stream; // v3, contig: > 0 = role split, this many stream-role workgroups (the rest do the column work)
     int iso;               // 1: G0 and every G_l are exact iso(.) images -> G^2 needs only its first d columns
@@ -1328,32 +1329,40 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     // by the matrix waves' instructions and memory operations.
     const bool stream_role = p.n_stream > 0 && (int)blockIdx.x < p.n_stream;
     const bool matrix_role = p.n_stream > 0 && !stream_role;
-    if (p.contig) {
+    // stream role, optional: pieces of p.snc columns dealt round-robin to the stream workgroups (at any moment they then
+    // write one window of ~n_stream/S consecutive intervals instead of n_stream far-apart ranges)
+    const bool srr = stream_role && p.snc > 0;
+    const int sS = srr ? (d + p.snc - 1) / p.snc : 1;
+    if (p.contig && !srr) {
         const long long tot = (long long)p.batch * p.K * d;
         const long long widx = matrix_role ? (long long)blockIdx.x - p.n_stream : (long long)blockIdx.x;
         const long long wcnt = p.n_stream > 0 ? (stream_role ? (long long)p.n_stream : (long long)gridDim.x - p.n_stream) : (long long)gridDim.x;
         g_lo = tot * widx / wcnt;
         g_hi = tot * (widx + 1) / wcnt;
         n_my = g_hi > g_lo ? (int)((g_hi - 1) / d - g_lo / d) + 1 : 0;
+    } else if (srr) {
+        const int n_items = p.batch * p.K * sS;
+        n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + p.n_stream - 1) / p.n_stream : 0;
     } else {
         const int n_items = p.batch * p.K * p.S;
         n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     }
     // item `it` of this workgroup: interval (b, k), state columns [c0, c0 + nce)
     auto decode = [&](int it, int &c0, int &nce, int &k, int &b) {
-        if (p.contig) {
+        if (p.contig && !srr) {
             const long long bk = g_lo / d + it;
             c0 = it == 0 ? (int)(g_lo - bk * d) : 0;
             nce = (int)min((long long)d, g_hi - bk * d) - c0;
             k = (int)(bk % p.K);
             b = (int)(bk / p.K);
         } else {
-            const int item = blockIdx.x + it * gridDim.x;
-            const int s = item % p.S;
-            c0 = s * nc;
-            nce = min(nc, d - c0);
-            k = (item / p.S) % p.K;
-            b = item / (p.S * p.K);
+            const int S_ = srr ? sS : p.S, nc_ = srr ? p.snc : nc;
+            const int item = blockIdx.x + it * (srr ? p.n_stream : (int)gridDim.x);
+            const int s = item % S_;
+            c0 = s * nc_;
+            nce = min(nc_, d - c0);
+            k = (item / S_) % p.K;
+            b = item / (S_ * p.K);
         }
     };
 
@@ -2693,6 +2702,7 @@ struct pcl_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int64_t opt_cpp = 6;  // block copies per expander work item
     int64_t opt_specialize = 1;
+    int64_t opt_snc = 0;      // v3, role split: stream pieces of this many columns dealt round-robin (0: contiguous ranges)
     int64_t opt_flat = 0;     // v3: line-aligned flat block stream (measured: no gain over the per-block stores, slower for one trajectory)
     int64_t opt_general = 0;  // 1: run the general-order kernel also for pade_order 4 (cross-check)
     int64_t opt_contig = -1;     // v3: contiguous column ranges per workgroup (-1: auto by launch size)
@@ -3327,6 +3337,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         // contiguous = 0 selects the round-robin slices
         p.contig = v3_contiguous(ctx) ? 1 : 0;
         p.flat = ctx->opt_flat ? 1 : 0;
+        p.snc = (int)std::max<int64_t>(0, std::min<int64_t>(ctx->opt_snc, p.d));
         p.nc = p.contig ? p.d : choose_cols_v3(ctx);
         p.ncw = v3_ncw(ctx, p.nc);
         p.tab_lds = 1;
@@ -3856,6 +3867,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_cpp = v;
     else if (!strcmp(key, "specialize"))  // 0: always the run-time-shape kernel instances
         ctx->opt_specialize = v != 0;
+    else if (!strcmp(key, "stream_piece_cols"))  // kernel 3, role split: > 0 = stream pieces of this many columns, round-robin
+        ctx->opt_snc = v;
     else if (!strcmp(key, "aligned_stream"))  // kernel 3: 1 = line-aligned flat block stream, 0 = per-block stores from registers (default)
         ctx->opt_flat = v != 0;
     else if (!strcmp(key, "general_pade_kernel"))  // 1: the general-order kernel also for pade_order 4
