@@ -862,3 +862,42 @@ def test_rollout_interface_ensemble_ket_and_large_steps():
     ck = make_ctx(layK, sk.G_drift, np.array(sk.G_drives), state_cols=1)
     close(ck.rollout(ZK)[0], po.exact_rollout(ZK, layK, sk.G_drift, np.array(sk.G_drives)), 1e-11)
     ck.close()
+
+
+def test_multi_ket_integrator():
+    """BilinearIntegrator(qtraj::MultiKetTrajectory, N) [REF src/control/integrators.jl:98-117]: one ket integrator per
+    state component psi1..psiK, same system, shared controls; rows concatenated ket-major.  Here: one context, K members."""
+    rng = np.random.default_rng(21)
+    d, m, N, Kk = 4, 2, 8, 3
+    n = 2 * d
+    Hd = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+    Hs = [(lambda A: A + A.conj().T)(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))) for _ in range(m)]
+    so = po.quantum_system(0.3 * (Hd + Hd.conj().T), Hs, [1.0] * m)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    z_dim = Kk * n + 2 + m
+    lay = po.Layout(d=d, m=m, N=N, z_dim=z_dim, x_off=0, u_off=Kk * n + 2, dt_off=Kk * n, cols=1)
+    Z = 0.5 * rng.standard_normal((N, z_dim))
+    Z[:, lay.dt_off] = 0.05 + 0.05 * rng.random(N)
+    comps = {}
+    for i in range(Kk):
+        comps["ψ̃%d" % (i + 1)] = Z[:, i * n : (i + 1) * n].T
+    comps["Δt"], comps["t"], comps["u"] = Z[:, Kk * n][None], Z[:, Kk * n + 1][None], Z[:, Kk * n + 2 :].T
+    traj = pa.NamedTrajectory(comps, controls=("u", "Δt"), timestep="Δt")
+    assert np.array_equal(traj.datavec, Z.reshape(-1))
+    names = ["ψ̃%d" % (i + 1) for i in range(Kk)]
+    B = pa.HipPadeIntegrator(G0, Gj, traj, names)
+    assert B.dim == Kk * n * (N - 1)
+    delta, vals = B.ctx.eval_jac(traj.datavec)
+    rows, cols = pa.jacobian_structure(B)
+    per_d, per_j = n * lay.K, po.jac_nnz_per_interval(lay) * lay.K
+    for i in range(Kk):
+        close(delta[i * per_d : (i + 1) * per_d], po.pade_residual(Z, lay, G0, Gj, 4, x_off=i * n), 1e-11)
+        close(vals[i * per_j : (i + 1) * per_j], po.pade_jacobian_values(Z, lay, G0, Gj, 4, x_off=i * n), 1e-11)
+        r0, c0 = po.jac_structure(lay, x_off=i * n)
+        assert np.array_equal(rows[i * per_j : (i + 1) * per_j], r0 + i * per_d) and np.array_equal(cols[i * per_j : (i + 1) * per_j], c0)
+    mu = rng.standard_normal(B.dim)
+    hv = B.ctx.hess(traj.datavec, mu)
+    hper = po.hess_nnz_per_interval(lay) * lay.K
+    for i in range(Kk):
+        close(hv[i * hper : (i + 1) * hper], po.pade4_hessian_values(Z, mu[i * per_d : (i + 1) * per_d].reshape(lay.K, -1), lay, G0, Gj, x_off=i * n), 1e-10)
+    B.close()
