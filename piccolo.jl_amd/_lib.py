@@ -66,7 +66,8 @@ class pcl_desc(ctypes.Structure):
 def build_library(force=False, verbose=False):
     """Compile csrc/piccolo_hip.hip for gfx950 into csrc/libpiccolo_hip.so (in-tree)."""
     src = os.path.join(CSRC, "piccolo_hip.hip")
-    deps = [src, os.path.join(INCLUDE, "piccolo_hip.h")]
+    deps = [src, os.path.join(INCLUDE, "piccolo_hip.h")] + sorted(
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))  # the kernel families are headers of this one TU
     if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(p) for p in deps):
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,0 +1,604 @@
+// pcl_kernel_fused_v3.hpp -- the default fused residual + Jacobian kernel.
+#pragma once
+
+// ------------------------------------------------------------------------------------------
+// Fused residual + Jacobian kernel, version 3 (default): ONE persistent workgroup per CU, four
+// "matrix" wavefronts + four "stream" wavefronts, ONE workgroup barrier per work item (b, k, s).
+//
+//   stream waves  copy the item's -B^+ / B^- values out of the LDS tiles G, G^2 into registers and
+//                 then do nothing but issue the replicated 16-byte block stores (the HBM-roofline
+//                 stream; they are the waves that sit in the store queue's back-pressure);
+//   matrix waves  meanwhile work wave-synchronously (no workgroup barrier among them):
+//                 (1) the item's state columns in chunks of ncw columns, one chunk per wave at a time:
+//                     M = [S | D | G_l D] -> G*M on the f64 matrix cores -> delta, d/ddt, d/du_l
+//                     straight from the accumulator layout to HBM;
+//                 (2) G(u) and G^2 of the workgroup's NEXT item into the other half of the
+//                     double-buffered G / G^2 tiles (every matrix wave rewrites the whole union
+//                     pattern of G itself - identical values - so no wave waits for another before
+//                     its G^2 tiles).
+// Item time = max(store stream, matrix work); with the matrix work a fraction of the stream the
+// kernel runs at the store stream's rate.
+// LDS map (doubles): G [2][LD*n] | G2 [2][LD*n] | per matrix wave: M [LD*CW] GD [LD*ncw] G2D [LD*ncw] |
+//                    us [3][m+1] | union values | ELL values | (u16) union LDS offsets, ELL columns | (u8) union drives
+// ------------------------------------------------------------------------------------------
+
+
+struct V3Tables {  // launch-invariant tables, in LDS when they fit (else in memory)
+    const double *unv;          // [n_upos*uw] drive coefficients of the union pattern
+    const unsigned char *unl;   // [n_upos*uw] drive index
+    const unsigned short *uni;  // [n_upos] LDS offset (row + LD*col) of the pattern entry
+    const double *ung0;         // [n_upos] drift value at the pattern entry (shared-drift case)
+    const double *ellv;         // [m*n*ew]
+    const unsigned short *ellc;
+};
+
+// EW: ELL width held in registers for m <= PCL_MREG drives (0: general, tables in LDS / memory).
+// TD/TM/TNCW: compile-time Hilbert dimension, drive count, chunk width (0 = run-time values).
+template <int EW, int TD, int TM, int TNCW>
+__global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
+    extern __shared__ double lds[];
+    const int d = TD ? TD : p.d, n = 2 * d, m = TD ? TM : p.m, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int nn = n * n;
+    const int ew = p.ell_w, uw = p.uell_w, n_ell = m * n * ew, n_un = p.n_upos;
+    const int ncw = TNCW ? TNCW : p.ncw;  // state columns per chunk
+    const int colsw = (2 + m) * ncw;   // operand columns per chunk
+    const int CW = 16;                 // one 16-column operand tile per chunk (host guarantees colsw <= 16)
+    const long long xd = (long long)n * d;
+    const int tile = LD * n;
+
+    double *Gb = lds;
+    double *G2b = Gb + 2 * tile;
+    double *wbuf = G2b + 2 * tile;  // per matrix wave
+    const int wsz = LD * (CW + 3 * ncw);
+    double *us = wbuf + 4 * wsz;
+    double *t_unv = us + 3 * (m + 1);
+    double *t_ung0 = t_unv + (p.tab_lds ? n_un * uw : 0);
+    double *t_ellv = t_ung0 + (p.tab_lds ? n_un : 0);
+    unsigned short *t_uni = reinterpret_cast<unsigned short *>(t_ellv + (p.tab_lds ? n_ell : 0));
+    unsigned short *t_ellc = t_uni + (p.tab_lds ? n_un : 0);
+    unsigned char *t_unl = reinterpret_cast<unsigned char *>(t_ellc + (p.tab_lds ? n_ell : 0));
+
+    // Work split.  contig = 0: items (b, k, slice of nc columns) dealt round-robin to the workgroups.
+    // contig = 1: the batch*K*d state columns of the launch are cut into gridDim.x equal contiguous ranges (to within one
+    // column); a workgroup's items are the pieces of its range that lie in one interval (first and last piece partial),
+    // so G, G^2 are built once per interval touched and every CU streams the same number of bytes.
+    const long long blk = p.compact ? (long long)nn : (long long)d * nn;  // size of seg 0 / seg 1
+    const int nc = p.nc;
+    int n_my;
+    long long g_lo = 0, g_hi = 0;
+    // Role split (contig only, n_stream > 0): workgroups [0, n_stream) stream the B^{+-} blocks of ALL columns (their
+    // matrix waves only build G, G^2), workgroups [n_stream, grid) do the column work of ALL columns (their stream waves
+    // idle).  The store stream is memory-side bound and half the CUs sustain it; on a CU of its own it is not slowed
+    // by the matrix waves' instructions and memory operations.
+    const bool stream_role = p.n_stream > 0 && (int)blockIdx.x < p.n_stream;
+    const bool matrix_role = p.n_stream > 0 && !stream_role;
+    // stream role, optional: pieces of p.snc columns dealt round-robin to the stream workgroups (at any moment they then
+    // write one window of ~n_stream/S consecutive intervals instead of n_stream far-apart ranges)
+    const bool srr = stream_role && p.snc > 0;
+    const int sS = srr ? (d + p.snc - 1) / p.snc : 1;
+    if (p.contig && !srr) {
+        const long long tot = (long long)p.batch * p.K * d;
+        const long long widx = matrix_role ? (long long)blockIdx.x - p.n_stream : (long long)blockIdx.x;
+        const long long wcnt = p.n_stream > 0 ? (stream_role ? (long long)p.n_stream : (long long)gridDim.x - p.n_stream) : (long long)gridDim.x;
+        g_lo = tot * widx / wcnt;
+        g_hi = tot * (widx + 1) / wcnt;
+        n_my = g_hi > g_lo ? (int)((g_hi - 1) / d - g_lo / d) + 1 : 0;
+    } else if (srr) {
+        const int n_items = p.batch * p.K * sS;
+        n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + p.n_stream - 1) / p.n_stream : 0;
+    } else {
+        const int n_items = p.batch * p.K * p.S;
+        n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    }
+    // item `it` of this workgroup: interval (b, k), state columns [c0, c0 + nce)
+    auto decode = [&](int it, int &c0, int &nce, int &k, int &b) {
+        if (p.contig && !srr) {
+            const long long bk = g_lo / d + it;
+            c0 = it == 0 ? (int)(g_lo - bk * d) : 0;
+            nce = (int)min((long long)d, g_hi - bk * d) - c0;
+            k = (int)(bk % p.K);
+            b = (int)(bk / p.K);
+        } else {
+            const int S_ = srr ? sS : p.S, nc_ = srr ? p.snc : nc;
+            const int item = blockIdx.x + it * (srr ? p.n_stream : (int)gridDim.x);
+            const int s = item % S_;
+            c0 = s * nc_;
+            nce = min(nc_, d - c0);
+            k = (item / S_) % p.K;
+            b = item / (S_ * p.K);
+        }
+    };
+
+    // item 0's controls / time step: requested before the prologue's table loads so that the latencies overlap
+    double u0 = 0.0;
+    if (n_my > 0 && wave < 4 && lane <= m) {
+        int c00, nce0, k0, b0;
+        decode(0, c00, nce0, k0, b0);
+        const double *z0 = p.Z + (long long)b0 * p.z_batch_stride + (long long)k0 * p.z_dim;
+        u0 = z0[lane < m ? p.u_off + lane : p.dt_off];
+    }
+    // ---- prologue: both G buffers = drift tile, tables -> LDS ----------------------------------------------
+    if (!p.g0_batch_stride)
+        for (int e = tid; e < nn; e += 512) {
+            const double g = p.G0[e];
+            const int o = (e % n) + LD * (e / n);
+            Gb[o] = g;
+            Gb[tile + o] = g;
+        }
+    if (p.tab_lds) {
+        for (int e = tid; e < n_un * uw; e += 512) {
+            t_unv[e] = p.uell_v[e];
+            t_unl[e] = p.uell_l[e];
+        }
+        for (int e = tid; e < n_un; e += 512) {
+            const int pos = p.upos[e];
+            t_uni[e] = (unsigned short)((pos % n) + LD * (pos / n));
+            t_ung0[e] = p.g0_batch_stride ? 0.0 : p.ug0[e];  // (not G0[pos]: no dependent load in the prologue)
+        }
+        for (int e = tid; e < n_ell; e += 512) {
+            t_ellv[e] = p.ell_val[e];
+            t_ellc[e] = (unsigned short)p.ell_col[e];
+        }
+    }
+    __syncthreads();
+
+
+    if (wave < 4 || matrix_role) {
+        // ======================================= matrix waves =========================================
+        // matrix role: all eight waves work on chunks; G, G^2 are single-buffered there and the second halves of the
+        // double buffers hold the chunk buffers of waves 4..7 (the host checks 2*wsz <= tile)
+        const int nmw = matrix_role ? 8 : 4;
+        double *Mw = wave < 4 ? wbuf + wave * wsz : (wave < 6 ? Gb + tile + (wave - 4) * wsz : G2b + tile + (wave - 6) * wsz);  // [LD*CW]: S | D | G_l D
+        double *GDw = Mw + LD * CW;      // [LD*ncw]
+        double *G2Dw = GDw + LD * ncw;   // [LD*ncw]
+        double *GSw = G2Dw + LD * ncw;   // [LD*ncw]
+        const int li = lane & 15, lk = lane >> 4;
+        const int rt_n = (n + 15) >> 4;
+        const int kfull = n >> 2, krem = n & 3;
+        // ELL rows (drive l, row = lane) in registers
+        unsigned short er_c[PCL_MREG][EW > 0 ? EW : 1];
+        double er_v[PCL_MREG][EW > 0 ? EW : 1];
+        if (EW > 0) {
+#pragma unroll
+            for (int l = 0; l < PCL_MREG; ++l)
+#pragma unroll
+                for (int q = 0; q < (EW > 0 ? EW : 1); ++q) {
+                    er_c[l][q] = 0;
+                    er_v[l][q] = 0.0;
+                    if (l < m && lane < n) {
+                        er_c[l][q] = (unsigned short)p.ell_col[(l * n + lane) * ew + q];
+                        er_v[l][q] = p.ell_val[(l * n + lane) * ew + q];
+                    }
+                }
+        }
+
+        // G(u) on the union pattern + this wave's share of the G^2 tiles, for item `it`, into buffer `buf`
+        auto build = [&](int it, int buf, double u_lane) {
+            int c0_, nce_, k, b;
+            decode(it, c0_, nce_, k, b);
+            double *G = Gb + buf * tile, *G2 = G2b + buf * tile;
+            double *usn = us + (it % 3) * (m + 1);
+            if (lane <= m) usn[lane] = u_lane;  // every wave: identical values
+            wave_lds_sync();
+            const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
+            if (p.g0_batch_stride)  // per-member drift: the whole tile changes with b
+                for (int e = lane; e < nn; e += 64) G[(e % n) + LD * (e / n)] = G0b[e];
+            if (p.tab_lds) {
+                for (int q = lane; q < n_un; q += 64) {
+                    double g = p.g0_batch_stride ? G0b[p.upos[q]] : t_ung0[q];
+                    for (int w = 0; w < uw; ++w) g += usn[t_unl[q * uw + w]] * t_unv[q * uw + w];
+                    G[t_uni[q]] = g;
+                }
+            } else {
+                for (int q = lane; q < n_un; q += 64) {
+                    const int pos = p.upos[q];
+                    double g = G0b[pos];
+                    const double *cf = p.ucoef + (long long)q * m;
+                    for (int l = 0; l < m; ++l) g += usn[l] * cf[l];
+                    G[(pos % n) + LD * (pos / n)] = g;
+                }
+            }
+            wave_lds_sync();
+            if (p.ablate & 1) return;
+            // G^2: row tile rt = wave (+4..), all column tiles; with the iso structure only the first d columns
+            const int ct_n = p.iso ? (d + 15) >> 4 : rt_n;
+            const int Nc = p.iso ? d : n;
+            for (int rt = wave; rt < rt_n; rt += 4) {
+                const double *Ap = G + rt * 16 + li + LD * lk;
+                for (int ct = 0; ct < ct_n; ct += 2) {
+                    const bool two = ct + 1 < ct_n;
+                    const double *Bp0 = G + lk + LD * (ct * 16 + li);
+                    const double *Bp1 = Bp0 + (two ? LD * 16 : 0);
+                    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                    double an = 0.0, b0n = 0.0, b1n = 0.0;
+                    if (kfull > 0) {
+                        an = Ap[0];
+                        b0n = Bp0[0];
+                        b1n = Bp1[0];
+                    }
+                    for (int ks = 0; ks < kfull; ++ks) {
+                        const double a = an, b0 = b0n, b1 = b1n;
+                        if (ks + 1 < kfull) {
+                            an = Ap[LD * 4 * (ks + 1)];
+                            b0n = Bp0[4 * (ks + 1)];
+                            b1n = Bp1[4 * (ks + 1)];
+                        }
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
+                        if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+                    }
+                    if (krem) {
+                        const bool ok = lk < krem;
+                        const double a = ok ? Ap[LD * 4 * kfull] : 0.0;
+                        const double b0 = ok ? Bp0[4 * kfull] : 0.0;
+                        const double b1 = ok ? Bp1[4 * kfull] : 0.0;
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
+                        if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int col = (ct + t) * 16 + li;
+                        if ((t == 0 || two) && col < Nc) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = rt * 16 + lk + 4 * r;
+                                const double v = t ? acc1[r] : acc0[r];
+                                if (row < n) {
+                                    G2[row + LD * col] = v;
+                                    if (p.iso) {
+                                        if (row < d)
+                                            G2[row + d + LD * (col + d)] = v;
+                                        else
+                                            G2[row - d + LD * (col + d)] = -v;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        };
+
+        if (n_my > 0 && wave < 4) build(0, 0, u0);
+        __syncthreads();  // item 0's G, G^2 complete
+
+        for (int it = 0; it < n_my; ++it) {
+            const int cur = matrix_role ? 0 : (it & 1);
+            int c0, nce, k, b;
+            decode(it, c0, nce, k, b);
+            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
+            const double *zn = zk + p.z_dim;
+            const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+            const double *G = Gb + cur * tile, *G2 = G2b + cur * tile;
+            const double h = us[(it % 3) * (m + 1) + m];
+            const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0), h6 = h * (1.0 / 6.0);
+            const long long bk = (long long)b * p.K + k;
+            double *jb = p.jac + bk * p.jac_per;
+            double *jt = jb + 2 * blk;  // tail: for column c: [d/du_0 .. d/du_{m-1} | d/ddt], n doubles each
+
+            const int nchunk = (nce + ncw - 1) / ncw;
+            int stamp = 0;
+#define PCL_STAMP()                                                                                     \
+    do {                                                                                                \
+        if (p.dbg && blockIdx.x == 0 && wave == 0 && lane == 0 && it == 1 && stamp < 60) p.dbg[stamp++] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+            PCL_STAMP();
+            // All global reads of this item are issued here, before the wave has any of the item's stores in flight:
+            // a later load would sit behind them in the CU's saturated memory pipeline (and vmcnt is in-order).
+            const bool pf = ncw <= PCL_PFW;
+            double pxn[PCL_PFC][PCL_PFW], pxc[PCL_PFC][PCL_PFW];
+            if (pf && lane < n && !(p.ablate & 4) && !stream_role) {
+#pragma unroll
+                for (int t = 0; t < PCL_PFC; ++t)
+#pragma unroll
+                    for (int c = 0; c < PCL_PFW; ++c) {
+                        const int col = c0 + (wave + nmw * t) * ncw + c;
+                        pxn[t][c] = pxc[t][c] = 0.0;
+                        if (c < ncw && col < c0 + nce) {
+                            const long long o = x_off + (long long)col * n + lane;
+                            if (p.ablate & 8) {  // DEBUG: no state loads
+                                pxn[t][c] = 1e-3 * lane;
+                                pxc[t][c] = 1e-3 * col;
+                            } else {
+                                pxn[t][c] = zn[o];
+                                pxc[t][c] = zk[o];
+                            }
+                        }
+                    }
+            }
+            double pf_u = 0.0;  // next item's u_k / dt_k (consumed by build)
+            if (it + 1 < n_my && lane <= m && wave < 4) {
+                int c02, nce2, k2, b2;
+                decode(it + 1, c02, nce2, k2, b2);
+                const double *zk2 = p.Z + (long long)b2 * p.z_batch_stride + (long long)k2 * p.z_dim;
+                pf_u = zk2[lane < m ? p.u_off + lane : p.dt_off];
+            }
+            int tch = 0;
+            for (int ch = wave; ch < nchunk && !(p.ablate & 4) && !stream_role; ch += nmw, ++tch) {
+                const int cc0 = c0 + ch * ncw;             // first state column of the chunk
+                const int ncc = min(ncw, c0 + nce - cc0);  // columns in this chunk
+                // ---- M = [S | D | G_l D]   (lane = row) -----------------------------------------------------
+                if (lane < n) {
+                    if (pf && tch < PCL_PFC) {
+#pragma unroll
+                        for (int t = 0; t < PCL_PFC; ++t)
+                            if (t == tch) {
+#pragma unroll
+                                for (int c = 0; c < PCL_PFW; ++c)
+                                    if (c < ncw) {
+                                        Mw[lane + LD * c] = pxn[t][c] + pxc[t][c];
+                                        Mw[lane + LD * (ncw + c)] = pxn[t][c] - pxc[t][c];
+                                    }
+                            }
+                    } else {
+                        for (int c = 0; c < ncw; ++c) {
+                            double xs = 0.0, xdv = 0.0;
+                            if (c < ncc) {
+                                const long long o = x_off + (long long)(cc0 + c) * n + lane;
+                                const double xn = zn[o], xc = zk[o];
+                                xs = xn + xc;
+                                xdv = xn - xc;
+                            }
+                            Mw[lane + LD * c] = xs;
+                            Mw[lane + LD * (ncw + c)] = xdv;
+                        }
+                    }
+                    for (int c = colsw; c < CW; ++c) Mw[lane + LD * c] = 0.0;
+                }
+                wave_lds_sync();
+                PCL_STAMP();  // S, D loaded
+                const double *Dm = Mw + LD * ncw;
+                if (lane < n) {
+                    if (EW > 0) {
+#pragma unroll
+                        for (int l = 0; l < PCL_MREG; ++l)
+                            if (l < m)
+                                for (int c = 0; c < ncw; ++c) {
+                                    double acc = 0.0;
+#pragma unroll
+                                    for (int q = 0; q < (EW > 0 ? EW : 1); ++q) acc += er_v[l][q] * Dm[er_c[l][q] + LD * c];
+                                    Mw[lane + LD * (2 * ncw + l * ncw + c)] = acc;
+                                }
+                    } else {
+                        for (int l = 0; l < m; ++l)
+                            for (int c = 0; c < ncw; ++c) {
+                                const int base = (l * n + lane) * ew;
+                                double acc = 0.0;
+                                for (int q = 0; q < ew; ++q) {
+                                    const int col = p.tab_lds ? (int)t_ellc[base + q] : p.ell_col[base + q];
+                                    const double ev = p.tab_lds ? t_ellv[base + q] : p.ell_val[base + q];
+                                    acc += ev * Dm[col + LD * c];
+                                }
+                                Mw[lane + LD * (2 * ncw + l * ncw + c)] = acc;
+                            }
+                    }
+                    PCL_STAMP();  // G_l D done
+                    // G2D = G^2 D on the VALU, 6 independent partial sums per column
+                    for (int c = 0; c < ncw; ++c) {
+                        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0;
+                        int kk = 0;
+                        for (; kk + 6 <= n; kk += 6) {
+                            s0 = fma(G2[lane + LD * kk], Dm[kk + LD * c], s0);
+                            s1 = fma(G2[lane + LD * (kk + 1)], Dm[kk + 1 + LD * c], s1);
+                            s2 = fma(G2[lane + LD * (kk + 2)], Dm[kk + 2 + LD * c], s2);
+                            s3 = fma(G2[lane + LD * (kk + 3)], Dm[kk + 3 + LD * c], s3);
+                            s4 = fma(G2[lane + LD * (kk + 4)], Dm[kk + 4 + LD * c], s4);
+                            s5 = fma(G2[lane + LD * (kk + 5)], Dm[kk + 5 + LD * c], s5);
+                        }
+                        for (; kk < n; ++kk) s0 = fma(G2[lane + LD * kk], Dm[kk + LD * c], s0);
+                        G2Dw[lane + LD * c] = ((s0 + s1) + (s2 + s3)) + (s4 + s5);
+                    }
+                }
+                wave_lds_sync();
+                PCL_STAMP();  // G2D done
+                // ---- W = G * M on the matrix cores: all row tiles at once (they share the b operand) ----------
+                {
+                    const double *Bp = Mw + lk + LD * li;
+                    const double *Ap[PCL_MAXRT];
+                    bool rok[PCL_MAXRT];
+#pragma unroll
+                    for (int t = 0; t < PCL_MAXRT; ++t) {
+                        rok[t] = t * 16 < n;
+                        Ap[t] = G + (rok[t] ? t * 16 : 0) + li + LD * lk;
+                    }
+                    double4_t acc[PCL_MAXRT];
+#pragma unroll
+                    for (int t = 0; t < PCL_MAXRT; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+                    if (!(p.ablate & 1)) {
+                        double an[PCL_MAXRT], bn = 0.0;
+#pragma unroll
+                        for (int t = 0; t < PCL_MAXRT; ++t) an[t] = kfull > 0 ? Ap[t][0] : 0.0;
+                        if (kfull > 0) bn = Bp[0];
+                        for (int ks = 0; ks < kfull; ++ks) {
+                            double a[PCL_MAXRT];
+                            const double bb = bn;
+#pragma unroll
+                            for (int t = 0; t < PCL_MAXRT; ++t) a[t] = an[t];
+                            if (ks + 1 < kfull) {
+#pragma unroll
+                                for (int t = 0; t < PCL_MAXRT; ++t) an[t] = Ap[t][LD * 4 * (ks + 1)];
+                                bn = Bp[4 * (ks + 1)];
+                            }
+#pragma unroll
+                            for (int t = 0; t < PCL_MAXRT; ++t)
+                                if (rok[t]) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bb, acc[t], 0, 0, 0);
+                        }
+                        if (krem) {
+                            const bool ok = lk < krem;
+                            const double bb = ok ? Bp[4 * kfull] : 0.0;
+#pragma unroll
+                            for (int t = 0; t < PCL_MAXRT; ++t)
+                                if (rok[t]) {
+                                    const double a = ok ? Ap[t][LD * 4 * kfull] : 0.0;
+                                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[t], 0, 0, 0);
+                                }
+                        }
+                    }
+                    // accumulator layout -> LDS: column li of [G S | G D | G (G_l D)]; the last group goes back into M's
+                    // own columns (their operand role is over)
+                    double *dst = li < ncw ? GSw + LD * li : (li < 2 * ncw ? GDw + LD * (li - ncw) : Mw + LD * li);
+#pragma unroll
+                    for (int t = 0; t < PCL_MAXRT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = t * 16 + lk + 4 * r;
+                            if (row < n && li < colsw) dst[row] = acc[t][r];
+                        }
+                }
+                wave_lds_sync();
+                PCL_STAMP();  // MFMA + accumulators -> LDS done
+                // ---- outputs: finish in LDS (lane = row, in place), then 16-byte stores --------------------------------
+                // in place: delta -> D column, d/ddt -> GS column, d/du_l -> the G (G_l D) column
+                if (lane < n) {
+                    for (int c = 0; c < ncw; ++c) {
+                        const double gs = GSw[lane + LD * c], g2d = G2Dw[lane + LD * c];
+                        G2Dw[lane + LD * c] = Mw[lane + LD * (ncw + c)] - c1 * gs + c2 * g2d;  // delta
+                        GSw[lane + LD * c] = -0.5 * gs + h6 * g2d;                                // d/ddt
+                    }
+                    // d/du_l = G_l (-c1 S + c2 G D) + c2 G (G_l D)
+                    if (EW > 0) {
+#pragma unroll
+                        for (int l = 0; l < PCL_MREG; ++l)
+                            if (l < m)
+                                for (int c = 0; c < ncw; ++c) {
+                                    double acc = 0.0;
+#pragma unroll
+                                    for (int q = 0; q < (EW > 0 ? EW : 1); ++q)
+                                        acc += er_v[l][q] * (-c1 * Mw[er_c[l][q] + LD * c] + c2 * GDw[er_c[l][q] + LD * c]);
+                                    Mw[lane + LD * (2 * ncw + l * ncw + c)] = acc + c2 * Mw[lane + LD * (2 * ncw + l * ncw + c)];
+                                }
+                    } else {
+                        for (int l = 0; l < m; ++l)
+                            for (int c = 0; c < ncw; ++c) {
+                                const int base = (l * n + lane) * ew;
+                                double acc = 0.0;
+                                for (int q = 0; q < ew; ++q) {
+                                    const int col = p.tab_lds ? (int)t_ellc[base + q] : p.ell_col[base + q];
+                                    const double ev = p.tab_lds ? t_ellv[base + q] : p.ell_val[base + q];
+                                    acc += ev * (-c1 * Mw[col + LD * c] + c2 * GDw[col + LD * c]);
+                                }
+                                Mw[lane + LD * (2 * ncw + l * ncw + c)] = acc + c2 * Mw[lane + LD * (2 * ncw + l * ncw + c)];
+                            }
+                    }
+                }
+                wave_lds_sync();
+                // the chunk's columns are contiguous in every output vector: element e = c*n + row, two per lane
+                {
+                    const int hn2 = n >> 1;
+                    const long long o0 = (long long)cc0 * n;
+                    for (int e2 = lane; e2 < ((p.ablate & 32) ? 0 : ncc * hn2); e2 += 64) {
+                        const int c = e2 / hn2, r0 = 2 * (e2 - c * hn2);
+                        if (p.delta) store2(p.delta + bk * xd + o0 + (long long)c * n + r0, G2Dw[r0 + LD * c], G2Dw[r0 + 1 + LD * c], false);
+                        double *tc = jt + (long long)(cc0 + c) * (m + 1) * n + r0;  // this column's (m+1)*n tail block
+                        if (p.ablate & 64) tc = p.jac + (long long)blockIdx.x * 16384 + (wave * 1024 + c * 512) + r0;  // DEBUG: a cache-resident scratch target
+                        for (int l = 0; l < m; ++l) {
+                            const double *src = Mw + LD * (2 * ncw + l * ncw + c) + r0;
+                            store2(tc + (long long)l * n, src[0], src[1], false);
+                        }
+                        store2(tc + (long long)m * n, GSw[r0 + LD * c], GSw[r0 + 1 + LD * c], false);
+                    }
+                }
+                wave_lds_sync();  // the chunk buffers are rewritten by this wave's next chunk
+                PCL_STAMP();  // outputs issued
+            }
+            // ---- next item's G(u), G^2 into the other buffer ----------------------------------------------------
+            if (matrix_role) __syncthreads();  // single-buffered G, G^2: every wave is done with this item's tiles
+            if (it + 1 < n_my && wave < 4) build(it + 1, matrix_role ? 0 : cur ^ 1, pf_u);
+            PCL_STAMP();  // next G, G^2 built
+            __syncthreads();  // item boundary
+            PCL_STAMP();  // barrier passed
+        }
+    } else {
+        // ======================================= stream waves =========================================
+        const int stid = tid - 256;
+        const int hn = n >> 1;
+        const int pi = 2 * (stid % hn), pj0 = stid / hn, pstep = max(256 / hn, 1);
+        const bool pact = pj0 < pstep;
+        __syncthreads();  // item 0's G, G^2 complete
+        for (int it = 0; it < n_my; ++it) {
+            const int cur = it & 1;
+            int c0, nce, k, b;
+            decode(it, c0, nce, k, b);
+            const double *G = Gb + cur * tile, *G2 = G2b + cur * tile;
+            if (p.flat && !(p.ablate & 2) && !matrix_role) {
+                // Optional line-aligned flat stream (option aligned_stream): the item's share of a segment (copies
+                // cbeg..cend-1 of one n x n block) is ONE contiguous run; after a partial head up to the next 128-byte line
+                // every wave-level store covers eight whole lines (1 KiB); values recomputed per store from the LDS tiles.
+                // A bare store kernel gains 30-40 % from this alignment (scripts/probes/wstream2.hip); this kernel, whose
+                // per-block stores are 1 KiB contiguous per instruction already, does not (28.0 vs 28.2 us/eval).
+                const double h = us[(it % 3) * (m + 1) + m];
+                const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
+                int cbeg = c0, cend = c0 + nce;
+                if (p.compact) {
+                    cbeg = 0;
+                    cend = (c0 == 0) ? 1 : 0;
+                }
+                const long long L = (long long)(cend - cbeg) * nn;  // doubles per run
+                double *jbk = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn;
+                const int di = 512 % n, dj = (512 / n) % n;
+                auto put = [&](double *A0, long long a, int i, int j, int sg) {
+                    const double g0 = G[i + LD * j], g1 = G[i + 1 + LD * j];
+                    const double h0 = G2[i + LD * j], h1 = G2[i + 1 + LD * j];
+                    const double e0 = ((i == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((i + 1 == j) ? 1.0 : 0.0) + c2 * h1;
+                    if (sg == 0)
+                        store2(A0 + a, -(e0 + c1 * g0), -(e1 + c1 * g1), p.nt);
+                    else
+                        store2(A0 + a, e0 - c1 * g0, e1 - c1 * g1, p.nt);
+                };
+#pragma unroll
+                for (int sg = 0; sg < 2; ++sg) {
+                    double *A0 = jbk + sg * blk;
+                    const int head = (int)(((128 - ((unsigned long long)A0 & 127)) & 127) >> 3);  // doubles (even)
+                    if (2 * stid < head && 2 * stid < L) put(A0, 2 * stid, (2 * stid) % n, ((2 * stid) / n) % n, sg);
+                    long long a = head + 2LL * stid;
+                    int i = (int)(a % n), j = (int)((a / n) % n);
+                    for (; a < L; a += 512) {
+                        put(A0, a, i, j, sg);
+                        i += di;
+                        if (i >= n) {
+                            i -= n;
+                            ++j;
+                        }
+                        j += dj;
+                        if (j >= n) j -= n;
+                    }
+                }
+            } else if (pact && !(p.ablate & 2) && !matrix_role) {
+                const double h = us[(it % 3) * (m + 1) + m];
+                const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
+                double bpr[PCL_NSP][2], bmr[PCL_NSP][2];
+#pragma unroll
+                for (int r = 0; r < PCL_NSP; ++r) {
+                    const int j = pj0 + pstep * r;
+                    if (j < n) {
+                        const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
+                        const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
+                        const double e0 = ((pi == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + c2 * h1;
+                        bpr[r][0] = -(e0 + c1 * g0);
+                        bpr[r][1] = -(e1 + c1 * g1);
+                        bmr[r][0] = e0 - c1 * g0;
+                        bmr[r][1] = e1 - c1 * g1;
+                    }
+                }
+                int cbeg = c0, cend = c0 + nce;
+                if (p.compact) {  // unique blocks only: slice 0 writes the single copy
+                    cbeg = 0;
+                    cend = (c0 == 0) ? 1 : 0;
+                }
+                double *o = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn + pi;
+                for (int c = cbeg; c < cend; ++c, o += nn) {
+#pragma unroll
+                    for (int r = 0; r < PCL_NSP; ++r) {
+                        const int j = pj0 + pstep * r;
+                        if (j < n) {
+                            store2(o + n * j, bpr[r][0], bpr[r][1], p.nt);
+                            store2(o + blk + n * j, bmr[r][0], bmr[r][1], p.nt);
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // item boundary
+        }
+    }
+}

@@ -1,18 +1,12 @@
-// piccolo_hip.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI for the Pade-4 collocation
-// constraint evaluator.  ABI and the reference interfaces it replaces: include/piccolo_hip.h.
-//
-// Kernel design (DESIGN.md has the full account):
-//   one workgroup (4 wavefronts) per (member b, interval k, column slice s).
-//   * G(u_k) = G0 + sum_l u_l G_l is assembled in LDS from the dense drift tile and the
-//     union sparsity pattern of the drives;
-//   * G^2 and G * [S | D | G_l D] run on the f64 matrix cores (v_mfma_f64_16x16x4_f64),
-//     operands read straight from LDS tiles, one 16x16 output tile per wavefront at a time;
-//   * the slice's columns of delta, d/du_l, d/ddt are combined on the VALU and stored;
-//   * the slice's share of the d replicated diagonal blocks of I_d (x) B^{+-} is formed in
-//     registers from the LDS-resident G and G^2 and streamed to HBM with 16-byte coalesced
-//     stores (this stream is >98 % of the bytes: the kernel is HBM-write-bound).
-//
-// No CPU fallback exists in this file: every entry point needs a HIP device.
+// piccolo_hip.hip -- libpiccolo_hip.so: C ABI (include/piccolo_hip.h cites the reference interfaces it replaces) and host
+// side of the gfx950 (MI355X / CDNA4) Pade collocation constraint evaluator.  One translation unit; the kernels live in
+//   pcl_device_common.hpp      parameter block, MFMA tile GEMM on LDS operands, wave-level helpers
+//   pcl_kernel_fused_v3.hpp    default residual + Jacobian kernel: persistent, one workgroup per CU, stream / matrix roles
+//   pcl_kernels_fused_v2.hpp   fallbacks (two workgroups per CU); also pcl_eval, kets, compact Jacobian
+//   pcl_kernels_reference.hpp  single-role kernel (A/B reference) and the general-order kernel (Pade 2..10)
+//   pcl_kernels_hessian.hpp    Hessian of the Lagrangian
+//   pcl_kernels_misc.hpp       compact -> full expansion, rollout, derivative / time rows, terminal infidelity
+// DESIGN.md has the full account.  No CPU fallback exists: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -31,2629 +25,12 @@
 
 #define PCL_VERSION_STR "piccolo_hip 0.2.0 (gfx950, pade 2/4/6/8/10)"
 
-#define PCL_NSP 8   // B^{+-} value pairs per thread of a 256-thread group: (n*n/2) / 256 <= 8 for n <= 64
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef double double2_t __attribute__((ext_vector_type(2)));
-
-// ------------------------------------------------------------------------------------------
-// Kernel parameters
-// ------------------------------------------------------------------------------------------
-struct KParams {
-    const double *Z;       // trajectory buffer(s), knot-major
-    const double *mu;      // multipliers (Hessian kernel)
-    double *delta;         // may be null
-    double *jac;           // full or compact Jacobian values; may be null
-    double *hess;          // Hessian values
-    const double *G0;      // n*n col-major (x batch if per-member)
-    const int *upos;       // union pattern of the drives: flat col-major position
-    const double *ucoef;   // n_upos x m coefficients (row-major: [q*m + l])
-    const int *csr_ptr;    // m*(n+1): CSR row pointers of every G_l (rows of G_l)
-    const int *csr_col;
-    const double *csr_val;
-    const int *csc_ptr;    // m*(n+1): CSC (= CSR of G_l^T) for the Hessian kernel
-    const int *csc_row;
-    const double *csc_val;
-    const int *x_offs;     // per-member state offsets
-    const int *umap;       // n*n: index into the union-pattern coefficient table, or -1
-    const double *ell_val; // ELL form of the drives: [m][n][ell_w] (row-major), zero padded
-    const int *ell_col;
-    int ell_w, ell_lds;    // ELL width; 1 = stage the ELL arrays in LDS
-    const unsigned char *uell_l;  // per union entry: up to uell_w (drive index, value) pairs, zero padded
-    const double *uell_v;
-    int uell_w;
-    const double *ellt_val;  // ELL form of the transposed drives G_l^T: [m][n][ellt_w]
-    const int *ellt_col;
-    int ellt_w;
-    const double *ug0;    // [n_upos] drift value at each union-pattern entry (first / shared drift)
-    double *hpart;        // Hessian v2: per (b,k,slice) partial scalar entries
-    unsigned int *hcnt;   // Hessian v2: per (b,k) arrival counter (self-resetting)
-    long long *dbg;  // optional: cycle stamps of workgroup 0 / matrix wave 0 (option debug_timing)
-    int ncw;      // v3: state columns per matrix-wave chunk ((2+m)*ncw <= 16)
-    int tab_lds;  // v3: union / ELL tables staged in LDS
-    int contig;   // v3: 1 = contiguous column ranges per workgroup (see the kernel), 0 = items dealt round-robin
-    int snc;      // v3, role split: > 0 = the stream workgroups take pieces of snc columns round-robin (0: contiguous ranges)
-    int flat;     // v3: 1 = line-aligned flat block stream (values recomputed from LDS per store), 0 = per-block stores from registers
-    int n_stream; // v3, contig: > 0 = role split, this many stream-role workgroups (the rest do the column work)
-    int iso;               // 1: G0 and every G_l are exact iso(.) images -> G^2 needs only its first d columns
-    long long z_batch_stride;   // doubles between trajectories (0 in MEMBERS mode)
-    long long g0_batch_stride;  // n*n if per-member drift else 0
-    long long jac_per;          // doubles per (b,k) in `jac`
-    long long hess_per;
-    int n_upos;
-    int d, n, m, K, z_dim, u_off, dt_off, batch;
-    int cols;     // state columns: d for a unitary (X is n x d), 1 for a ket; x_dim = n * cols
-    int nc;       // state columns per slice
-    int S;        // slices per interval
-    int LD;       // LDS leading dimension of every n-row tile
-    int compact;  // 1: write unique blocks only (jac_per is the compact size); 2: split mode - unique blocks go to
-                  //    `blocks` (2*n*n per (b,k)) and `flags[b*K+k]` is raised, everything else in the full layout
-    double *blocks;
-    unsigned int *flags;
-    int nt;       // 1: nontemporal streaming stores
-    double *expm;  // rollout: per (b,k) propagator exp(dt_k G(u_k)), n*n col-major
-    double *xout;  // rollout: states at every knot, [batch][N][x_dim]
-    int q;        // general-order kernel: p/2
-    double pc[6]; // general-order kernel: diagonal Pade coefficients c_0..c_q
-    int ablate;   // DEBUG ONLY (wrong results): bit0 skip matrix products, bit1 skip block streaming, bit2 skip column outputs
-};
-
-// ------------------------------------------------------------------------------------------
-// MFMA tile GEMM on LDS operands:  C[0:M,0:Nc] = op(A)[0:M,0:Kd] * B[0:Kd,0:Nc]
-//   column-major everywhere; op(A) = A or A^T.  v_mfma_f64_16x16x4_f64 operand maps:
-//   a: lane l holds A[i = l&15][k = l>>4], b: B[k = l>>4][j = l&15],
-//   c/d: 4 doubles per lane, col = l&15, row = (l>>4) + 4*reg.
-//   Out-of-range rows/cols/k are fed as exact zeros, so no tile padding is needed in LDS.
-//   Two output tiles are processed together so each wave has two independent accumulators.
-// ------------------------------------------------------------------------------------------
-template <bool TRANS_A>
-__device__ __forceinline__ void mfma_gemm_lds(const double *__restrict__ A, int lda, const double *__restrict__ B,
-                                              int ldb, double *__restrict__ C, int ldc, int M, int Nc, int Kd,
-                                              int wave, int nwaves, int lane) {
-    const int rt_n = (M + 15) >> 4, ct_n = (Nc + 15) >> 4, ks_n = (Kd + 3) >> 2;
-    const int nt = rt_n * ct_n;
-    const int li = lane & 15, lk = lane >> 4;
-    for (int t0 = wave * 2; t0 < nt; t0 += nwaves * 2) {
-        const int t1 = t0 + 1;
-        const bool has1 = t1 < nt;
-        const int rt0 = t0 % rt_n, ct0 = t0 / rt_n;
-        const int rt1 = has1 ? t1 % rt_n : rt0, ct1 = has1 ? t1 / rt_n : ct0;
-        const int row0 = rt0 * 16 + li, col0 = ct0 * 16 + li;
-        const int row1 = rt1 * 16 + li, col1 = ct1 * 16 + li;
-        const bool r0 = row0 < M, c0 = col0 < Nc, r1 = has1 && row1 < M, c1 = has1 && col1 < Nc;
-        double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        for (int ks = 0; ks < ks_n; ++ks) {
-            const int k = ks * 4 + lk;
-            const bool kok = k < Kd;
-            double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
-            if (r0 && kok) a0 = TRANS_A ? A[k + lda * row0] : A[row0 + lda * k];
-            if (c0 && kok) b0 = B[k + ldb * col0];
-            if (r1 && kok) a1 = TRANS_A ? A[k + lda * row1] : A[row1 + lda * k];
-            if (c1 && kok) b1 = B[k + ldb * col1];
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
-        }
-        if (c0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = rt0 * 16 + lk + 4 * r;
-                if (rr < M) C[rr + ldc * col0] = acc0[r];
-            }
-        }
-        if (c1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = rt1 * 16 + lk + 4 * r;
-                if (rr < M) C[rr + ldc * col1] = acc1[r];
-            }
-        }
-    }
-}
-
-// Plain VALU version of the same contract (selected with option use_mfma = 0; used to A/B the
-// matrix-core path and as a second implementation in the parity tests).
-template <bool TRANS_A>
-__device__ __forceinline__ void valu_gemm_lds(const double *__restrict__ A, int lda, const double *__restrict__ B,
-                                              int ldb, double *__restrict__ C, int ldc, int M, int Nc, int Kd,
-                                              int tid, int nthreads) {
-    for (int e = tid; e < M * Nc; e += nthreads) {
-        const int i = e % M, j = e / M;
-        double s = 0.0;
-        for (int k = 0; k < Kd; ++k) s = fma(TRANS_A ? A[k + lda * i] : A[i + lda * k], B[k + ldb * j], s);
-        C[i + ldc * j] = s;
-    }
-}
-
-template <bool MFMA, bool TRANS_A>
-__device__ __forceinline__ void gemm_lds(const double *A, int lda, const double *B, int ldb, double *C, int ldc, int M,
-                                         int Nc, int Kd) {
-    if (MFMA)
-        mfma_gemm_lds<TRANS_A>(A, lda, B, ldb, C, ldc, M, Nc, Kd, threadIdx.x >> 6, blockDim.x >> 6,
-                               threadIdx.x & 63);
-    else
-        valu_gemm_lds<TRANS_A>(A, lda, B, ldb, C, ldc, M, Nc, Kd, threadIdx.x, blockDim.x);
-}
-
-__device__ __forceinline__ void store2(double *p, double a, double b, bool nt) {
-    double2_t v = {a, b};
-    if (nt)
-        __builtin_nontemporal_store(v, reinterpret_cast<double2_t *>(p));
-    else
-        *reinterpret_cast<double2_t *>(p) = v;
-}
-
-// Assemble G(u_k) into LDS (ld = LD):  G = G0 + sum_l u_l G_l, in drive order (deterministic).
-__device__ __forceinline__ void build_G(const KParams &p, const double *__restrict__ G0, const double *__restrict__ zk,
-                                        double *__restrict__ G, double *__restrict__ us) {
-    const int n = p.n, LD = p.LD;
-    for (int e = threadIdx.x; e < n * n; e += blockDim.x) G[(e % n) + LD * (e / n)] = G0[e];
-    if ((int)threadIdx.x < p.m) us[threadIdx.x] = zk[p.u_off + threadIdx.x];
-    __syncthreads();
-    for (int q = threadIdx.x; q < p.n_upos; q += blockDim.x) {
-        const int pos = p.upos[q];
-        const int idx = (pos % n) + LD * (pos / n);
-        double g = G[idx];
-        for (int l = 0; l < p.m; ++l) g += us[l] * p.ucoef[(long long)q * p.m + l];
-        G[idx] = g;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Fused residual + Jacobian kernel.
-// LDS map (doubles):  G [LD*n] | G2 [LD*n] | M1 [LD*(2+m)*nc] | W1 [LD*(2+m)*nc] | G2D [LD*nc] | T [LD*nc] | us[8+m]
-//   M1 = [S | D | G_1 D .. G_m D] (slice columns), W1 = G*M1 = [GS | GD | G(G_l D)].
-// ------------------------------------------------------------------------------------------
-template <bool JAC, bool MFMA>
-__global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
-    extern __shared__ double lds[];
-    const int n = p.n, d = p.cols, m = p.m, LD = p.LD, nc = p.nc;  // d: state columns here (no iso shortcut in this kernel)
-    const int tid = threadIdx.x, nth = blockDim.x;
-
-    const int bid = blockIdx.x;
-    const int s = bid % p.S;
-    const int k = (bid / p.S) % p.K;
-    const int b = bid / (p.S * p.K);
-    const int c0 = s * nc;
-    const int nce = min(nc, d - c0);  // columns actually owned by this slice
-
-    const int ncols1 = JAC ? (2 + m) * nc : 2 * nc;
-    double *G = lds;
-    double *G2 = G + LD * n;
-    double *M1 = G2 + (JAC ? LD * n : 0);
-    double *W1 = M1 + LD * ncols1;
-    double *G2D = W1 + LD * ncols1;
-    double *T = G2D + LD * nc;
-    double *us = T + LD * nc;
-
-    const double *Zb = p.Z + (long long)b * p.z_batch_stride;
-    const double *zk = Zb + (long long)k * p.z_dim;
-    const double *zn = zk + p.z_dim;
-    const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-    const double h = zk[p.dt_off];
-    const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
-    const long long xd = (long long)n * d;
-
-    build_G(p, p.G0 + (long long)b * p.g0_batch_stride, zk, G, us);
-
-    // S and D for the slice's columns (unused trailing columns are zero)
-    for (int e = tid; e < nc * n; e += nth) {
-        const int c = e / n, i = e % n;
-        double xs = 0.0, xdv = 0.0;
-        if (c < nce) {
-            const double xn = zn[x_off + (c0 + c) * n + i], xc = zk[x_off + (c0 + c) * n + i];
-            xs = xn + xc;
-            xdv = xn - xc;
-        }
-        M1[i + LD * c] = xs;
-        M1[i + LD * (nc + c)] = xdv;
-    }
-    __syncthreads();
-
-    if (JAC) {
-        // G_l D via the CSR rows of G_l
-        const double *Dm = M1 + LD * nc;
-        for (int e = tid; e < m * nc * n; e += nth) {
-            const int i = e % n, c = (e / n) % nc, l = e / (n * nc);
-            const int *rp = p.csr_ptr + l * (n + 1);
-            double acc = 0.0;
-            for (int q = rp[i]; q < rp[i + 1]; ++q) acc += p.csr_val[q] * Dm[p.csr_col[q] + LD * c];
-            M1[i + LD * ((2 + l) * nc + c)] = acc;
-        }
-        __syncthreads();
-        if (!(p.ablate & 1)) gemm_lds<MFMA, false>(G, LD, G, LD, G2, LD, n, n, n);
-    }
-    if (!(p.ablate & 1)) gemm_lds<MFMA, false>(G, LD, M1, LD, W1, LD, n, ncols1, n);
-    __syncthreads();
-
-    // pass 2: G2D = G * (G D);  T = -c1 S + c2 G D
-    if (!(p.ablate & 1)) gemm_lds<MFMA, false>(G, LD, W1 + LD * nc, LD, G2D, LD, n, nc, n);
-    if (JAC) {
-        for (int e = tid; e < nc * n; e += nth) {
-            const int c = e / n, i = e % n;
-            T[i + LD * c] = -c1 * M1[i + LD * c] + c2 * W1[i + LD * (nc + c)];
-        }
-    }
-    __syncthreads();
-
-    // ---- column outputs -------------------------------------------------------------------
-    const long long bk = (long long)b * p.K + k;
-    double *jb = JAC ? p.jac + bk * p.jac_per : nullptr;
-    const long long blk = p.compact ? (long long)n * n : (long long)d * n * n;  // size of seg 0 / seg 1
-    for (int e = tid; e < ((p.ablate & 4) ? 0 : nce * n); e += nth) {
-        const int c = e / n, i = e % n;
-        const double gs = W1[i + LD * c], g2d = G2D[i + LD * c];
-        const long long r = (long long)(c0 + c) * n + i;
-        if (p.delta) p.delta[bk * xd + r] = M1[i + LD * (nc + c)] - c1 * gs + c2 * g2d;
-        if (JAC) jb[2 * blk + ((long long)(c0 + c) * (m + 1) + m) * n + i] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
-    }
-    if (JAC) {
-        for (int e = tid; e < ((p.ablate & 4) ? 0 : m * nce * n); e += nth) {
-            const int i = e % n, c = (e / n) % nce, l = e / (n * nce);
-            const int *rp = p.csr_ptr + l * (n + 1);
-            double acc = 0.0;
-            for (int q = rp[i]; q < rp[i + 1]; ++q) acc += p.csr_val[q] * T[p.csr_col[q] + LD * c];
-            jb[2 * blk + ((long long)(c0 + c) * (m + 1) + l) * n + i] = acc + c2 * W1[i + LD * ((2 + l) * nc + c)];
-        }
-
-        // ---- replicated diagonal blocks: stream -B^+ and B^- ---------------------------------
-        // pair index q covers flat column-major positions 2q, 2q+1 (same column since n is even)
-        const int half = (n * n) >> 1;
-        int cbeg = c0, cend = c0 + nce;
-        if (p.compact) {  // unique blocks only: slice 0 writes the single copy
-            cbeg = 0;
-            cend = (s == 0) ? 1 : 0;
-        }
-        for (int q = tid; q < ((p.ablate & 2) ? 0 : half); q += nth) {
-            const int pos = 2 * q;
-            const int i = pos % n, j = pos / n;
-            const double g0 = G[i + LD * j], g1 = G[i + 1 + LD * j];
-            const double h0 = G2[i + LD * j], h1 = G2[i + 1 + LD * j];
-            const double id0 = (i == j) ? 1.0 : 0.0, id1 = (i + 1 == j) ? 1.0 : 0.0;
-            const double e0 = id0 + c2 * h0, e1 = id1 + c2 * h1;
-            const double bp0 = -(e0 + c1 * g0), bp1 = -(e1 + c1 * g1);
-            const double bm0 = e0 - c1 * g0, bm1 = e1 - c1 * g1;
-            for (int c = cbeg; c < cend; ++c) {
-                double *o0 = jb + (long long)c * n * n + pos;
-                store2(o0, bp0, bp1, p.nt);
-                store2(o0 + blk, bm0, bm1, p.nt);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// General-order kernel: diagonal Pade orders p = 2q, q <= 5 (p = 2, 6, 8, 10; p = 4 only as a cross-check of the
-// specialised kernels).  One workgroup per (b, k, slice of nc columns); correctness first, no wave specialisation.
-// With Y_j = (-1)^j X_{k+1} - X_k (D for even j, -S for odd j) and c_j the Pade coefficients:
-//   residual (Horner)   W_q = c_q Y_q,  W_j = c_j Y_j + h G W_{j+1},  delta = W_0
-//   d/dh                V_q = q c_q Y_q, V_j = j c_j Y_j + h G V_{j+1} (j >= 1),  d delta/dh = G V_1
-//   d/du_l              dW_q = 0,  dW_j = h (G_l W_{j+1} + G dW_{j+1}),  d delta/du_l = dW_0
-//   blocks              B^{+-} = sum_j c_j (+-h)^j G^j, powers by repeated products, sums in registers
-// LDS map (doubles): G | Pa | Pb (JAC) | -S | D | W_0..W_q | V (2, JAC) | dWa, dWb (m each, JAC) | us      (column blocks LD*nc)
-// ------------------------------------------------------------------------------------------
-template <bool JAC>
-__global__ __launch_bounds__(256) void pcl_pade_kernel(const KParams p) {
-    extern __shared__ double lds[];
-    const int n = p.n, d = p.cols, m = p.m, LD = p.LD, nc = p.nc, q = p.q;
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const int bid = blockIdx.x;
-    const int s = bid % p.S;
-    const int k = (bid / p.S) % p.K;
-    const int b = bid / (p.S * p.K);
-    const int c0 = s * nc;
-    const int nce = min(nc, d - c0);
-    const int LDc = LD * nc;
-
-    double *G = lds;
-    double *Pa = G + LD * n;
-    double *Pb = Pa + (JAC ? LD * n : 0);
-    double *Sm = Pb + (JAC ? LD * n : 0);  // -S
-    double *Dm = Sm + LDc;
-    double *W = Dm + LDc;  // W_j at W + j*LDc
-    double *V = W + (q + 1) * LDc;
-    double *dWa = V + (JAC ? 2 * LDc : 0);
-    double *dWb = dWa + (JAC ? m * LDc : 0);
-    double *us = dWb + (JAC ? m * LDc : 0);
-
-    const double *Zb = p.Z + (long long)b * p.z_batch_stride;
-    const double *zk = Zb + (long long)k * p.z_dim;
-    const double *zn = zk + p.z_dim;
-    const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-    const double h = zk[p.dt_off];
-    const long long xd = (long long)n * d;
-
-    build_G(p, p.G0 + (long long)b * p.g0_batch_stride, zk, G, us);
-    for (int e = tid; e < nc * n; e += nth) {
-        const int c = e / n, i = e % n;
-        double xs = 0.0, xdv = 0.0;
-        if (c < nce) {
-            const double xn = zn[x_off + (c0 + c) * n + i], xc = zk[x_off + (c0 + c) * n + i];
-            xs = xn + xc;
-            xdv = xn - xc;
-        }
-        Sm[i + LD * c] = -xs;
-        Dm[i + LD * c] = xdv;
-    }
-    __syncthreads();
-    auto Y = [&](int j) { return (j & 1) ? Sm : Dm; };
-
-    // ---- residual: Horner in G ---------------------------------------------------------------------------------
-    for (int e = tid; e < nc * n; e += nth) {
-        const int idx = (e % n) + LD * (e / n);
-        W[q * LDc + idx] = p.pc[q] * Y(q)[idx];
-    }
-    __syncthreads();
-    for (int j = q - 1; j >= 0; --j) {
-        gemm_lds<true, false>(G, LD, W + (j + 1) * LDc, LD, W + j * LDc, LD, n, nc, n);
-        __syncthreads();
-        for (int e = tid; e < nc * n; e += nth) {
-            const int idx = (e % n) + LD * (e / n);
-            W[j * LDc + idx] = p.pc[j] * Y(j)[idx] + h * W[j * LDc + idx];
-        }
-        __syncthreads();
-    }
-    const long long bk = (long long)b * p.K + k;
-    if (p.delta)
-        for (int e = tid; e < nce * n; e += nth) p.delta[bk * xd + (long long)c0 * n + e] = W[(e % n) + LD * (e / n)];
-    if (!JAC) return;
-
-    double *jb = p.jac + bk * p.jac_per;
-    const long long blk = p.compact ? (long long)n * n : (long long)d * n * n;
-    double *jt = jb + 2 * blk;
-    // ---- d/dh ------------------------------------------------------------------------------------------------
-    {
-        double *cur = V, *oth = V + LDc;
-        for (int e = tid; e < nc * n; e += nth) {
-            const int idx = (e % n) + LD * (e / n);
-            cur[idx] = q * p.pc[q] * Y(q)[idx];
-        }
-        __syncthreads();
-        for (int j = q - 1; j >= 1; --j) {
-            gemm_lds<true, false>(G, LD, cur, LD, oth, LD, n, nc, n);
-            __syncthreads();
-            for (int e = tid; e < nc * n; e += nth) {
-                const int idx = (e % n) + LD * (e / n);
-                oth[idx] = j * p.pc[j] * Y(j)[idx] + h * oth[idx];
-            }
-            __syncthreads();
-            double *t = cur;
-            cur = oth;
-            oth = t;
-        }
-        gemm_lds<true, false>(G, LD, cur, LD, oth, LD, n, nc, n);
-        __syncthreads();
-        for (int e = tid; e < nce * n; e += nth) {
-            const int c = e / n, i = e % n;
-            jt[((long long)(c0 + c) * (m + 1) + m) * n + i] = oth[i + LD * c];
-        }
-    }
-    // ---- d/du_l ----------------------------------------------------------------------------------------------
-    if (m > 0) {
-        double *cur = dWa, *oth = dWb;
-        for (int e = tid; e < m * nc * n; e += nth) {
-            const int i = e % n, c = (e / n) % nc, l = e / (n * nc);
-            const int *rp = p.csr_ptr + l * (n + 1);
-            double a = 0.0;
-            for (int t = rp[i]; t < rp[i + 1]; ++t) a += p.csr_val[t] * W[q * LDc + p.csr_col[t] + LD * c];
-            cur[l * LDc + i + LD * c] = h * a;
-        }
-        __syncthreads();
-        for (int j = q - 2; j >= 0; --j) {
-            gemm_lds<true, false>(G, LD, cur, LD, oth, LD, n, m * nc, n);
-            __syncthreads();
-            for (int e = tid; e < m * nc * n; e += nth) {
-                const int i = e % n, c = (e / n) % nc, l = e / (n * nc);
-                const int *rp = p.csr_ptr + l * (n + 1);
-                double a = 0.0;
-                for (int t = rp[i]; t < rp[i + 1]; ++t) a += p.csr_val[t] * W[(j + 1) * LDc + p.csr_col[t] + LD * c];
-                oth[l * LDc + i + LD * c] = h * (oth[l * LDc + i + LD * c] + a);
-            }
-            __syncthreads();
-            double *t = cur;
-            cur = oth;
-            oth = t;
-        }
-        for (int e = tid; e < m * nce * n; e += nth) {
-            const int i = e % n, c = (e / n) % nce, l = e / (n * nce);
-            jt[((long long)(c0 + c) * (m + 1) + l) * n + i] = cur[l * LDc + i + LD * c];
-        }
-    }
-    // ---- blocks: B^{+-} = sum_j c_j (+-h)^j G^j ------------------------------------------------------------------
-    {
-        const int half = (n * n) >> 1;
-        double bp[PCL_NSP][2], bm[PCL_NSP][2];  // pairs (2q', 2q'+1), q' = tid + 256 r
-#pragma unroll
-        for (int r = 0; r < PCL_NSP; ++r) {
-            const int pos = 2 * (tid + 256 * r);
-            const int i = pos % n, jj = pos / n;
-            bp[r][0] = bm[r][0] = (i == jj) ? 1.0 : 0.0;
-            bp[r][1] = bm[r][1] = (i + 1 == jj) ? 1.0 : 0.0;
-        }
-        const double *Pc = G;
-        double hp = 1.0, hm = 1.0;
-        for (int j = 1; j <= q; ++j) {
-            hp *= h;
-            hm *= -h;
-#pragma unroll
-            for (int r = 0; r < PCL_NSP; ++r) {
-                const int qq = tid + 256 * r;
-                if (qq < half) {
-                    const int pos = 2 * qq;
-                    const int i = pos % n, jj = pos / n;
-                    const double v0 = Pc[i + LD * jj], v1 = Pc[i + 1 + LD * jj];
-                    bp[r][0] += p.pc[j] * hp * v0;
-                    bp[r][1] += p.pc[j] * hp * v1;
-                    bm[r][0] += p.pc[j] * hm * v0;
-                    bm[r][1] += p.pc[j] * hm * v1;
-                }
-            }
-            if (j < q) {
-                double *Pn = (Pc == Pa) ? Pb : Pa;
-                gemm_lds<true, false>(G, LD, Pc, LD, Pn, LD, n, n, n);
-                __syncthreads();
-                Pc = Pn;
-            }
-        }
-        int cbeg = c0, cend = c0 + nce;
-        if (p.compact) {
-            cbeg = 0;
-            cend = (s == 0) ? 1 : 0;
-        }
-#pragma unroll
-        for (int r = 0; r < PCL_NSP; ++r) {
-            const int qq = tid + 256 * r;
-            if (qq < half)
-                for (int c = cbeg; c < cend; ++c) {
-                    double *o0 = jb + (long long)c * n * n + 2 * qq;
-                    store2(o0, -bp[r][0], -bp[r][1], p.nt);
-                    store2(o0 + blk, bm[r][0], bm[r][1], p.nt);
-                }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Fused residual + Jacobian kernel, version 2 (default): 8 wavefronts, wave-specialised.
-//   waves 0-3 ("matrix" waves) own one 16-row tile each and run every MFMA product;
-//   waves 4-7 ("stream" waves) apply the sparse drives (VALU) and then stream the slice's share of
-//   the replicated B^{+-} blocks to HBM while the matrix waves compute the slice's columns.
-// Phases (separated by one __syncthreads each):
-//   0  all   : G(u_k) -> LDS (one pass: drift tile + union-pattern map), S, D, ELL drives -> LDS
-//   1  matrix: G2 = G*G (first d columns + mirror if iso)      stream: M1[:, (2+l)nc..] = G_l D
-//   2  matrix: W1 = G*M1, G2D = G2*D                            stream: -B^+, B^- block copies -> HBM
-//   3  all   : delta, d/ddt, d/du_l columns -> HBM
-// LDS map (doubles): G [LD*n] | G2 [LD*n] | M1 [LD*ncols1] | W1 [LD*ncols1] | G2D [LD*nc] | ELL val/col | slack
-// MFMA operand loads are unconditional: a tile may read rows/columns past the matrix edge (the
-// neighbouring buffer); such lanes only feed output rows/columns that are never stored.
-// ------------------------------------------------------------------------------------------
-template <int MODE>  // 0: plain store; 1: store + iso mirror (C = G2 first d columns)
-__device__ __forceinline__ void wave_rowgemm(const double *__restrict__ A, int lda, const double *__restrict__ B,
-                                             int ldb, double *__restrict__ C, int ldc, int M, int Nc, int Kd, int wave,
-                                             int nwaves, int lane, int dmir) {
-    const int rt_n = (M + 15) >> 4, ct_n = (Nc + 15) >> 4;
-    const int kfull = Kd >> 2, krem = Kd & 3;
-    const int li = lane & 15, lk = lane >> 4;
-    for (int rt = wave; rt < rt_n; rt += nwaves) {
-        const double *Ap = A + rt * 16 + li + lda * lk;
-        for (int ct = 0; ct < ct_n; ct += 2) {
-            const bool two = ct + 1 < ct_n;
-            const double *Bp0 = B + lk + ldb * (ct * 16 + li);
-            const double *Bp1 = Bp0 + (two ? ldb * 16 : 0);
-            double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-            // operands of step ks+1 are requested before the MFMAs of step ks issue
-            double an = 0.0, b0n = 0.0, b1n = 0.0;
-            if (kfull > 0) {
-                an = Ap[0];
-                b0n = Bp0[0];
-                if (two) b1n = Bp1[0];
-            }
-            for (int ks = 0; ks < kfull; ++ks) {
-                const double a = an, b0 = b0n, b1 = b1n;
-                if (ks + 1 < kfull) {
-                    an = Ap[lda * 4 * (ks + 1)];
-                    b0n = Bp0[4 * (ks + 1)];
-                    if (two) b1n = Bp1[4 * (ks + 1)];
-                }
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
-                if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
-            }
-            if (krem) {
-                const bool ok = lk < krem;
-                const double a = ok ? Ap[lda * 4 * kfull] : 0.0;
-                const double b0 = ok ? Bp0[4 * kfull] : 0.0;
-                const double b1 = ok ? Bp1[4 * kfull] : 0.0;
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
-                if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (t == 1 && !two) break;
-                const int col = (ct + t) * 16 + li;
-                if (col < Nc) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = rt * 16 + lk + 4 * r;
-                        const double v = t ? acc1[r] : acc0[r];
-                        if (row < M) {
-                            C[row + ldc * col] = v;
-                            if (MODE == 1) {
-                                if (row < dmir)
-                                    C[row + dmir + ldc * (col + dmir)] = v;
-                                else
-                                    C[row - dmir + ldc * (col + dmir)] = -v;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-// Phase-2 product of the matrix waves for a narrow slice (ncols1 <= 32, 2*nc <= 16), one row tile per wave:
-//   acc0/acc1 = G * M1[:, tile 0/1],  acc2 = G2 * M1[:, tile 0]  (its columns nc..2nc-1 are G2 D).
-// Operands of k-step ks+1 are requested before the MFMAs of step ks issue.
-__device__ __forceinline__ void wave_phase2_fused(const double *G, const double *G2, const double *M1, double *W1,
-                                                  double *G2D, int LD, int n, int ncols1, int nc, bool want_g2, int wave,
-                                                  int lane) {
-    const int rt_n = (n + 15) >> 4;
-    const bool two = ncols1 > 16;
-    const int kfull = n >> 2, krem = n & 3;
-    const int li = lane & 15, lk = lane >> 4;
-    for (int rt = wave; rt < rt_n; rt += 4) {
-        const double *Ap = G + rt * 16 + li + LD * lk;
-        const double *A2p = (want_g2 ? G2 : G) + rt * 16 + li + LD * lk;
-        const double *Bp0 = M1 + lk + LD * li;
-        const double *Bp1 = Bp0 + (two ? LD * 16 : 0);
-        double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-        double a = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0;
-        if (kfull > 0) {
-            a = Ap[0];
-            a2 = A2p[0];
-            b0 = Bp0[0];
-            b1 = Bp1[0];
-        }
-        for (int ks = 0; ks < kfull; ++ks) {
-            const double ca = a, ca2 = a2, cb0 = b0, cb1 = b1;
-            if (ks + 1 < kfull) {
-                a = Ap[LD * 4 * (ks + 1)];
-                a2 = A2p[LD * 4 * (ks + 1)];
-                b0 = Bp0[4 * (ks + 1)];
-                b1 = Bp1[4 * (ks + 1)];
-            }
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca, cb0, acc0, 0, 0, 0);
-            if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca, cb1, acc1, 0, 0, 0);
-            if (want_g2) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca2, cb0, acc2, 0, 0, 0);
-        }
-        if (krem) {
-            const bool ok = lk < krem;
-            const double ra = ok ? Ap[LD * 4 * kfull] : 0.0;
-            const double ra2 = ok ? A2p[LD * 4 * kfull] : 0.0;
-            const double rb0 = ok ? Bp0[4 * kfull] : 0.0;
-            const double rb1 = ok ? Bp1[4 * kfull] : 0.0;
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra, rb0, acc0, 0, 0, 0);
-            if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra, rb1, acc1, 0, 0, 0);
-            if (want_g2) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ra2, rb0, acc2, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = rt * 16 + lk + 4 * r;
-            if (row < n) {
-                if (li < ncols1) W1[row + LD * li] = acc0[r];
-                if (two && li + 16 < ncols1) W1[row + LD * (li + 16)] = acc1[r];
-                if (want_g2 && li >= nc && li < 2 * nc) G2D[row + LD * (li - nc)] = acc2[r];
-            }
-        }
-    }
-}
-
-// Persistent form: the grid is (workgroups that fit on the chip); each workgroup walks the work
-// items (b, k, s) with stride gridDim.x.  What does not depend on the item stays on chip for the
-// whole launch: the LDS tile G holds the drift everywhere except on the union pattern of the
-// drives, which is the only part rewritten per item (each thread keeps its pattern entries in
-// registers), and the ELL form of the drives is staged in LDS once.  Per item only u_k, dt_k and
-// the slice's state columns are read from memory, one item ahead.  Element-wise passes give every
-// thread a fixed row (tid % n) and walk columns: no integer division inside the item loop.
-#define PCL_NUE2 2  // union-pattern entries per thread held in registers (REG path: n_upos <= 1024)
-
-// TD/TM/TNC: compile-time Hilbert dimension, drive count and slice width (0 = run-time values).  With the shape fixed
-// every LDS offset, trip count and divisor is a constant: the specialised instances need far fewer scalar registers.
-template <bool JAC, int WU, int TD, int TM, int TNC>  // WU: (drive,value) pairs per pattern entry in registers; -1: general
-__global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
-    extern __shared__ double lds[];
-    const int d = TD ? TD : p.d, n = 2 * d, m = TD ? TM : p.m, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD, nc = TNC ? TNC : p.nc;
-    const int C = TD ? TD : p.cols;  // state columns (specialised instances are unitary: C = d)
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const bool matrix_wave = wave < 4;
-    const int stid = tid - 256;  // index among the stream waves' threads
-    const int nn = n * n;
-
-    const int ncols1 = JAC ? (2 + m) * nc : 2 * nc;
-    const int n_ell = m * n * p.ell_w;
-    double *G = lds;
-    double *G2 = G + LD * n;
-    double *M1 = G2 + (JAC ? LD * n : 0);
-    double *W1 = M1 + LD * ncols1;
-    double *G2D = W1 + LD * ncols1;
-    double *us = G2D + LD * nc;  // 2 x [u_k (m) | dt_k]: current / next item
-    double *ellv_l = us + 2 * (m + 1);
-    unsigned short *ellc_l = reinterpret_cast<unsigned short *>(ellv_l + n_ell);
-    const long long xd = (long long)n * C;
-    const int ew = p.ell_w;
-    const bool fused_p2 = ncols1 <= 32 && 2 * nc <= 16;
-
-    // ---- fixed thread coordinates ----------------------------------------------------------------------
-    const int ri = tid % n, rj0 = tid / n, rstep = 512 / n;  // all threads: row ri, columns rj0, rj0+rstep, ..
-    const bool ract = rj0 < rstep;
-    const int sstep = 256 / n;                               // stream waves as a 256-thread group: row si
-    const int si = matrix_wave ? 0 : stid % n, sj0 = matrix_wave ? 0 : stid / n;
-    const bool sact = !matrix_wave && sj0 < sstep;
-    const int hn = n >> 1;                                   // stream waves: row pair (pi, pi+1)
-    const int pi = matrix_wave ? 0 : 2 * (stid % hn), pj0 = matrix_wave ? 0 : stid / hn, pstep = max(256 / hn, 1);
-    const bool pact = !matrix_wave && pj0 < pstep;
-
-    // ---- launch-invariant state -------------------------------------------------------------------------
-    if (!p.g0_batch_stride)
-        for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = p.G0[e];
-    constexpr int WUR = WU > 0 ? WU : 1;
-    int un_idx[PCL_NUE2];
-    double un_g0[PCL_NUE2];
-    unsigned char un_l[PCL_NUE2][WUR];
-    double un_v[PCL_NUE2][WUR];
-    if (WU > 0) {
-#pragma unroll
-        for (int r = 0; r < PCL_NUE2; ++r) {
-            const int q = tid + 512 * r;
-            un_idx[r] = -1;
-            un_g0[r] = 0.0;
-#pragma unroll
-            for (int w = 0; w < WUR; ++w) {
-                un_l[r][w] = 0;
-                un_v[r][w] = 0.0;
-            }
-            if (q < p.n_upos) {
-                const int pos = p.upos[q];
-                un_idx[r] = (pos % n) + LD * (pos / n);
-                un_g0[r] = p.G0[pos];
-#pragma unroll
-                for (int w = 0; w < WUR; ++w) {
-                    un_l[r][w] = p.uell_l[q * WUR + w];
-                    un_v[r][w] = p.uell_v[q * WUR + w];
-                }
-            }
-        }
-    }
-    const bool stage = JAC && p.ell_lds;
-    if (stage) {
-        for (int e = tid; e < n_ell; e += 512) {
-            ellv_l[e] = p.ell_val[e];
-            ellc_l[e] = (unsigned short)p.ell_col[e];
-        }
-    }
-
-    // ---- per-item inputs, requested one item ahead -------------------------------------------------
-    const int n_items = p.batch * p.K * p.S;
-    const bool pf_x = nc <= rstep;  // one state element per thread: prefetchable
-    double pf_v = 0.0, pf_xn = 0.0, pf_xc = 0.0;
-    auto request = [&](int item) {
-        const int s = item % p.S;
-        const int k = (item / p.S) % p.K;
-        const int b = item / (p.S * p.K);
-        const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
-        if (tid <= m) pf_v = zk[tid < m ? p.u_off + tid : p.dt_off];
-        pf_xn = pf_xc = 0.0;
-        if (pf_x && ract && rj0 < min(nc, C - s * nc)) {
-            const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-            const long long o = x_off + (long long)(s * nc + rj0) * n + ri;
-            pf_xc = zk[o];
-            pf_xn = zk[p.z_dim + o];
-        }
-    };
-    int cur = 0;
-    if ((int)blockIdx.x < n_items) {
-        request(blockIdx.x);
-        if (tid <= m) us[tid] = pf_v;
-    }
-    __syncthreads();  // G = drift, tables staged, us[0] valid
-
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int s = item % p.S;
-        const int k = (item / p.S) % p.K;
-        const int b = item / (p.S * p.K);
-        const int c0 = s * nc;
-        const int nce = min(nc, C - c0);
-        const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
-        const double *zn = zk + p.z_dim;
-        const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-        const double *usc = us + cur * (m + 1);
-        const double h = usc[m];
-        const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
-
-        // ---- phase 0: G(u_k) on the union pattern, S, D -> LDS -----------------------------------------
-        if (WU < 0 && p.g0_batch_stride) {  // per-member drift: the whole tile changes with b
-            const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
-            for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = G0b[e];
-            __syncthreads();  // the dense rewrite lands before the pattern update
-        }
-        if (!(p.ablate & 8)) {
-            if (WU > 0) {
-#pragma unroll
-                for (int r = 0; r < PCL_NUE2; ++r)
-                    if (un_idx[r] >= 0) {
-                        double g = un_g0[r];
-#pragma unroll
-                        for (int w = 0; w < WUR; ++w) g += usc[un_l[r][w]] * un_v[r][w];
-                        G[un_idx[r]] = g;
-                    }
-            } else {
-                const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
-                for (int q = tid; q < p.n_upos; q += 512) {
-                    const int pos = p.upos[q];
-                    double g = G0b[pos];
-                    const double *cf = p.ucoef + (long long)q * m;
-                    for (int l = 0; l < m; ++l) g += usc[l] * cf[l];
-                    G[(pos % n) + LD * (pos / n)] = g;
-                }
-            }
-        }
-        if (pf_x) {
-            if (ract && rj0 < nc) {
-                M1[ri + LD * rj0] = pf_xn + pf_xc;
-                M1[ri + LD * (nc + rj0)] = pf_xn - pf_xc;
-            }
-        } else if (ract) {
-            for (int c = rj0; c < nc; c += rstep) {
-                double xs = 0.0, xdv = 0.0;
-                if (c < nce) {
-                    const double xn = zn[x_off + (c0 + c) * n + ri], xc = zk[x_off + (c0 + c) * n + ri];
-                    xs = xn + xc;
-                    xdv = xn - xc;
-                }
-                M1[ri + LD * c] = xs;
-                M1[ri + LD * (nc + c)] = xdv;
-            }
-        }
-        __syncthreads();
-
-        // ---- phase 1: matrix waves G^2 ; stream waves G_l D ---------------------------------------------
-        if (JAC) {
-            if (matrix_wave) {
-                if (!(p.ablate & 1)) {
-                    if (p.iso)
-                        wave_rowgemm<1>(G, LD, G, LD, G2, LD, n, d, n, wave, 4, lane, d);
-                    else
-                        wave_rowgemm<0>(G, LD, G, LD, G2, LD, n, n, n, wave, 4, lane, 0);
-                }
-            } else if (sact && !(p.ablate & 16)) {
-                const double *Dm = M1 + LD * nc;
-                for (int cl = sj0; cl < m * nc; cl += sstep) {
-                    const int l = cl / nc, c = cl - l * nc;
-                    const int base = (l * n + si) * ew;
-                    double acc = 0.0;
-                    if (stage) {
-                        for (int q = 0; q < ew; ++q) acc += ellv_l[base + q] * Dm[ellc_l[base + q] + LD * c];
-                    } else {
-                        for (int q = 0; q < ew; ++q) acc += p.ell_val[base + q] * Dm[p.ell_col[base + q] + LD * c];
-                    }
-                    M1[si + LD * (2 * nc + cl)] = acc;
-                }
-            }
-            __syncthreads();
-        }
-
-        // ---- phase 2: matrix waves W1 = G M1, G2D = G^2 D ; stream waves the block copies -------------------
-        const long long bk = (long long)b * p.K + k;
-        double *jb = JAC ? p.jac + bk * p.jac_per : nullptr;
-        const long long blk = p.compact == 1 ? (long long)nn : (long long)C * nn;  // size of seg 0 / seg 1 in `jac`
-        if (matrix_wave) {
-            if (!(p.ablate & 1)) {
-                if (fused_p2) {
-                    wave_phase2_fused(G, G2, M1, W1, G2D, LD, n, ncols1, nc, JAC, wave, lane);
-                } else {
-                    wave_rowgemm<0>(G, LD, M1, LD, W1, LD, n, ncols1, n, wave, 4, lane, 0);
-                    if (JAC) wave_rowgemm<0>(G2, LD, M1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
-                }
-            }
-        } else if (JAC && pact && !(p.ablate & 2)) {
-            int cbeg = c0, cend = c0 + nce;
-            if (p.compact) {  // unique blocks only: slice 0 writes the single copy
-                cbeg = 0;
-                cend = (s == 0) ? 1 : 0;
-            }
-            double *ob = p.compact == 2 ? p.blocks + bk * 2 * nn : jb;  // split mode: blocks go to the scratch tiles
-            const long long oblk = p.compact == 2 ? (long long)nn : blk;
-            for (int j = pj0; j < n; j += pstep) {
-                const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
-                const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
-                const double e0 = ((pi == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + c2 * h1;
-                const double bp0 = -(e0 + c1 * g0), bp1 = -(e1 + c1 * g1);
-                const double bm0 = e0 - c1 * g0, bm1 = e1 - c1 * g1;
-                double *o0 = ob + (long long)cbeg * nn + (pi + n * j);
-                for (int c = cbeg; c < cend; ++c, o0 += nn) {
-                    store2(o0, bp0, bp1, p.nt);
-                    store2(o0 + oblk, bm0, bm1, p.nt);
-                }
-            }
-            if (p.compact == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's tile stores have left the CU
-        }
-        // inputs of this workgroup's next item: in flight during the rest of this one
-        if (item + (int)gridDim.x < n_items) request(item + gridDim.x);
-        __syncthreads();
-        if (JAC && p.compact == 2 && s == 0 && tid == 256) {
-            // publish the interval's tiles to the expander kernel (other CUs / XCDs): agent-scope release, then the flag
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(p.flags + bk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (!JAC) {  // eval only: delta needs G (G D), a second dependent product
-            if (matrix_wave && !(p.ablate & 1)) wave_rowgemm<0>(G, LD, W1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
-            __syncthreads();
-        }
-
-        // ---- phase 3: column outputs: block 0 -> delta and d/ddt, block 1+l -> d/du_l ----------------------
-        if (ract && !(p.ablate & 4)) {
-            const double *GDm = W1 + LD * nc;
-            const int ncl = JAC ? (1 + m) * nc : nc;
-            for (int cl = rj0; cl < ncl; cl += rstep) {
-                const int lb = cl / nc, c = cl - lb * nc;
-                if (c >= nce) continue;
-                const long long r = (long long)(c0 + c) * n + ri;
-                if (lb == 0) {
-                    const double gs = W1[ri + LD * c], g2d = G2D[ri + LD * c];
-                    if (p.delta) p.delta[bk * xd + r] = M1[ri + LD * (nc + c)] - c1 * gs + c2 * g2d;
-                    if (JAC) jb[2 * blk + ((long long)(c0 + c) * (m + 1) + m) * n + ri] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
-                } else {
-                    const int l = lb - 1;
-                    const int base = (l * n + ri) * ew;
-                    double acc = 0.0;
-                    if (stage) {
-                        for (int q = 0; q < ew; ++q) {
-                            const int col = ellc_l[base + q];
-                            acc += ellv_l[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
-                        }
-                    } else {
-                        for (int q = 0; q < ew; ++q) {
-                            const int col = p.ell_col[base + q];
-                            acc += p.ell_val[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
-                        }
-                    }
-                    jb[2 * blk + ((long long)(c0 + c) * (m + 1) + l) * n + ri] = acc + c2 * W1[ri + LD * (nc + cl)];
-                }
-            }
-        }
-        if (tid <= m) us[(cur ^ 1) * (m + 1) + tid] = pf_v;  // requested during phase 2
-        cur ^= 1;
-        __syncthreads();  // LDS is rewritten by the next item's phase 0
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Fused residual + Jacobian kernel, version 4: version 2's frame (persistent, 2 workgroups per CU, 4 matrix + 4 stream
-// waves, 4 barriers per item) with the block stores of an item SPREAD over four phases instead of one:
-//   the stream waves copy the item's -B^+ / B^- values into registers as soon as G^2 exists (start of phase 2) and
-//   issue a quarter of the copies in each of  phase 2, phase 3 (this item), phase 0, phase 1 (next item);
-//   every other duty (union update of G, S/D, G_l D, MFMA products, column outputs) belongs to the matrix waves.
-// Per item the workgroup then spends  sum_j max(matrix phase j, store burst j)  instead of
-// (matrix phases 0,1,3) + max(matrix phase 2, all stores): the store queue of the CU is fed in every phase.
-// ------------------------------------------------------------------------------------------
-#define PCL_NUE4 4  // union-pattern entries per matrix-wave thread held in registers (REG path: n_upos <= 1024)
-
-template <int WU, int TD, int TM, int TNC>
-__global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v4(const KParams p) {
-    extern __shared__ double lds[];
-    const int d = TD ? TD : p.d, n = 2 * d, m = TD ? TM : p.m, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD, nc = TNC ? TNC : p.nc;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const bool matrix_wave = wave < 4;
-    const int nn = n * n;
-    const int ncols1 = (2 + m) * nc;
-    const int n_ell = m * n * p.ell_w;
-    double *G = lds;
-    double *G2 = G + LD * n;
-    double *M1 = G2 + LD * n;
-    double *W1 = M1 + LD * ncols1;
-    double *G2D = W1 + LD * ncols1;
-    double *us = G2D + LD * nc;  // 2 x [u_k (m) | dt_k]: current / next item
-    double *ellv_l = us + 2 * (m + 1);
-    unsigned short *ellc_l = reinterpret_cast<unsigned short *>(ellv_l + n_ell);
-    const long long xd = (long long)n * d;
-    const int ew = p.ell_w;
-    const bool fused_p2 = ncols1 <= 32 && 2 * nc <= 16;
-    const bool stage = p.ell_lds;
-    const int n_items = p.batch * p.K * p.S;
-    const long long blk = p.compact ? (long long)nn : (long long)d * nn;  // size of seg 0 / seg 1
-
-    if (!p.g0_batch_stride)
-        for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = p.G0[e];
-    if (stage)
-        for (int e = tid; e < n_ell; e += 512) {
-            ellv_l[e] = p.ell_val[e];
-            ellc_l[e] = (unsigned short)p.ell_col[e];
-        }
-
-    if (matrix_wave) {
-        // ===================================== matrix waves (256 threads) ======================================
-        const int ri = tid % n, rj0 = tid / n, rstep = 256 / n;  // row ri, columns rj0, rj0+rstep, ..
-        const bool ract = rj0 < rstep;
-        constexpr int WUR = WU > 0 ? WU : 1;
-        int un_idx[PCL_NUE4];
-        double un_g0[PCL_NUE4];
-        unsigned char un_l[PCL_NUE4][WUR];
-        double un_v[PCL_NUE4][WUR];
-        if (WU > 0) {
-#pragma unroll
-            for (int r = 0; r < PCL_NUE4; ++r) {
-                const int q = tid + 256 * r;
-                un_idx[r] = -1;
-                un_g0[r] = 0.0;
-#pragma unroll
-                for (int w = 0; w < WUR; ++w) {
-                    un_l[r][w] = 0;
-                    un_v[r][w] = 0.0;
-                }
-                if (q < p.n_upos) {
-                    const int pos = p.upos[q];
-                    un_idx[r] = (pos % n) + LD * (pos / n);
-                    un_g0[r] = p.G0[pos];
-#pragma unroll
-                    for (int w = 0; w < WUR; ++w) {
-                        un_l[r][w] = p.uell_l[q * WUR + w];
-                        un_v[r][w] = p.uell_v[q * WUR + w];
-                    }
-                }
-            }
-        }
-        const bool pf_x = nc <= rstep;  // one state element per thread: prefetchable
-        double pf_v = 0.0, pf_xn = 0.0, pf_xc = 0.0;
-        auto request = [&](int item) {
-            const int s = item % p.S;
-            const int k = (item / p.S) % p.K;
-            const int b = item / (p.S * p.K);
-            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
-            if (tid <= m) pf_v = zk[tid < m ? p.u_off + tid : p.dt_off];
-            pf_xn = pf_xc = 0.0;
-            if (pf_x && ract && rj0 < min(nc, d - s * nc)) {
-                const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-                const long long o = x_off + (long long)(s * nc + rj0) * n + ri;
-                pf_xc = zk[o];
-                pf_xn = zk[p.z_dim + o];
-            }
-        };
-        int cur = 0;
-        if ((int)blockIdx.x < n_items) {
-            request(blockIdx.x);
-            if (tid <= m) us[tid] = pf_v;
-        }
-        __syncthreads();  // G = drift, tables staged, us[0] valid
-
-        for (int item = blockIdx.x;; item += gridDim.x) {
-            const bool have = item < n_items;
-            const int s = have ? item % p.S : 0;
-            const int k = have ? (item / p.S) % p.K : 0;
-            const int b = have ? item / (p.S * p.K) : 0;
-            const int c0 = s * nc;
-            const int nce = min(nc, d - c0);
-            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
-            const double *zn = zk + p.z_dim;
-            const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-            const double *usc = us + cur * (m + 1);
-            const double h = usc[m];
-            const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
-
-            // ---- phase 0: G(u_k) on the union pattern, S, D -> LDS -------------------------------------------
-            if (WU < 0 && p.g0_batch_stride) {  // per-member drift: the whole tile changes with b
-                if (have) {
-                    const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
-                    for (int e = tid; e < nn; e += 256) G[(e % n) + LD * (e / n)] = G0b[e];
-                }
-                __syncthreads();  // (stream waves take part) the dense rewrite lands before the pattern update
-            }
-            if (have) {
-                if (WU > 0) {
-#pragma unroll
-                    for (int r = 0; r < PCL_NUE4; ++r)
-                        if (un_idx[r] >= 0) {
-                            double g = un_g0[r];
-#pragma unroll
-                            for (int w = 0; w < WUR; ++w) g += usc[un_l[r][w]] * un_v[r][w];
-                            G[un_idx[r]] = g;
-                        }
-                } else {
-                    const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
-                    for (int q = tid; q < p.n_upos; q += 256) {
-                        const int pos = p.upos[q];
-                        double g = G0b[pos];
-                        const double *cf = p.ucoef + (long long)q * m;
-                        for (int l = 0; l < m; ++l) g += usc[l] * cf[l];
-                        G[(pos % n) + LD * (pos / n)] = g;
-                    }
-                }
-                if (pf_x) {
-                    if (ract && rj0 < nc) {
-                        M1[ri + LD * rj0] = pf_xn + pf_xc;
-                        M1[ri + LD * (nc + rj0)] = pf_xn - pf_xc;
-                    }
-                } else if (ract) {
-                    for (int c = rj0; c < nc; c += rstep) {
-                        double xs = 0.0, xdv = 0.0;
-                        if (c < nce) {
-                            const double xn = zn[x_off + (c0 + c) * n + ri], xc = zk[x_off + (c0 + c) * n + ri];
-                            xs = xn + xc;
-                            xdv = xn - xc;
-                        }
-                        M1[ri + LD * c] = xs;
-                        M1[ri + LD * (nc + c)] = xdv;
-                    }
-                }
-            }
-            __syncthreads();  // B_a
-            if (!have) {
-                __syncthreads();  // B_b: the stream waves' last burst pair runs through phases 0 and 1 of this empty item
-                break;
-            }
-
-            // ---- phase 1: G_l D (VALU) then G^2 (MFMA) ----------------------------------------------------------
-            if (ract) {
-                const double *Dm = M1 + LD * nc;
-                for (int cl = rj0; cl < m * nc; cl += rstep) {
-                    const int l = cl / nc, c = cl - l * nc;
-                    const int base = (l * n + ri) * ew;
-                    double acc = 0.0;
-                    if (stage) {
-                        for (int q = 0; q < ew; ++q) acc += ellv_l[base + q] * Dm[ellc_l[base + q] + LD * c];
-                    } else {
-                        for (int q = 0; q < ew; ++q) acc += p.ell_val[base + q] * Dm[p.ell_col[base + q] + LD * c];
-                    }
-                    M1[ri + LD * (2 * nc + cl)] = acc;
-                }
-            }
-            if (!(p.ablate & 1)) {
-                if (p.iso)
-                    wave_rowgemm<1>(G, LD, G, LD, G2, LD, n, d, n, wave, 4, lane, d);
-                else
-                    wave_rowgemm<0>(G, LD, G, LD, G2, LD, n, n, n, wave, 4, lane, 0);
-            }
-            __syncthreads();  // B_b: G, G^2, M1 complete
-
-            // ---- phase 2: W1 = G M1, G2D = G^2 D ; request the next item's inputs -------------------------------
-            if (!(p.ablate & 1)) {
-                if (fused_p2) {
-                    wave_phase2_fused(G, G2, M1, W1, G2D, LD, n, ncols1, nc, true, wave, lane);
-                } else {
-                    wave_rowgemm<0>(G, LD, M1, LD, W1, LD, n, ncols1, n, wave, 4, lane, 0);
-                    wave_rowgemm<0>(G2, LD, M1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
-                }
-            }
-            if (item + (int)gridDim.x < n_items) request(item + gridDim.x);
-            __syncthreads();  // B_c
-
-            // ---- phase 3: column outputs: block 0 -> delta and d/ddt, block 1+l -> d/du_l -----------------------
-            if (ract && !(p.ablate & 4)) {
-                const long long bk = (long long)b * p.K + k;
-                double *jb = p.jac + bk * p.jac_per;
-                const double *GDm = W1 + LD * nc;
-                for (int cl = rj0; cl < (1 + m) * nc; cl += rstep) {
-                    const int lb = cl / nc, c = cl - lb * nc;
-                    if (c >= nce) continue;
-                    const long long r = (long long)(c0 + c) * n + ri;
-                    if (lb == 0) {
-                        const double gs = W1[ri + LD * c], g2d = G2D[ri + LD * c];
-                        if (p.delta) p.delta[bk * xd + r] = M1[ri + LD * (nc + c)] - c1 * gs + c2 * g2d;
-                        jb[2 * blk + ((long long)(c0 + c) * (m + 1) + m) * n + ri] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
-                    } else {
-                        const int l = lb - 1;
-                        const int base = (l * n + ri) * ew;
-                        double acc = 0.0;
-                        if (stage) {
-                            for (int q = 0; q < ew; ++q) {
-                                const int col = ellc_l[base + q];
-                                acc += ellv_l[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
-                            }
-                        } else {
-                            for (int q = 0; q < ew; ++q) {
-                                const int col = p.ell_col[base + q];
-                                acc += p.ell_val[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
-                            }
-                        }
-                        jb[2 * blk + ((long long)(c0 + c) * (m + 1) + l) * n + ri] = acc + c2 * W1[ri + LD * (nc + cl)];
-                    }
-                }
-            }
-            if (tid <= m) us[(cur ^ 1) * (m + 1) + tid] = pf_v;  // requested during phase 2
-            cur ^= 1;
-            __syncthreads();  // B_d
-        }
-    } else {
-        // ===================================== stream waves (256 threads) ======================================
-        const int stid = tid - 256;
-        const int hn = n >> 1;
-        const int pi = 2 * (stid % hn), pj0 = stid / hn, pstep = max(256 / hn, 1);
-        const bool pact = pj0 < pstep;
-        constexpr int NSP = TD ? (2 * TD + (256 / TD) - 1) / (256 / TD) : 8;  // column steps per thread (<= 8 for n <= 64)
-        double bpr[NSP][2], bmr[NSP][2];
-        double *sjb = nullptr;
-        int ncopy = 0;
-        // burst j in 0..3: copies q = (j>>1), (j>>1)+2, .. and the (j&1) half of this thread's column steps -> four equal
-        // quarters of the item's stores whatever the copy count
-        auto burst = [&](int jq) {
-            if (!pact || (p.ablate & 2)) return;
-            const int half = ncopy >> 1;
-            const int rlo = (jq & 1) ? NSP / 2 : 0, rhi = (jq & 1) ? NSP : NSP / 2;
-            for (int q = jq >> 1; q < ncopy; q += 2) {
-                const bool minus = q >= half;
-                double *o = sjb + (minus ? blk + (long long)(q - half) * nn : (long long)q * nn);
-                if (minus) {
-#pragma unroll
-                    for (int r = 0; r < NSP; ++r) {
-                        const int j = pj0 + pstep * r;
-                        if (r >= rlo && r < rhi && j < n) store2(o + n * j, bmr[r][0], bmr[r][1], p.nt);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < NSP; ++r) {
-                        const int j = pj0 + pstep * r;
-                        if (r >= rlo && r < rhi && j < n) store2(o + n * j, bpr[r][0], bpr[r][1], p.nt);
-                    }
-                }
-            }
-        };
-        int cur = 0;
-        __syncthreads();  // prologue barrier
-        for (int item = blockIdx.x;; item += gridDim.x) {
-            const bool have = item < n_items;
-            if (WU < 0 && p.g0_batch_stride) __syncthreads();
-            burst(2);  // previous item, third quarter (phase 0)
-            __syncthreads();       // B_a
-            burst(3);  // previous item, last quarter (phase 1)
-            __syncthreads();       // B_b: this item's G, G^2 complete
-            if (!have) break;
-            {
-                const int s = item % p.S;
-                const int k = (item / p.S) % p.K;
-                const int b = item / (p.S * p.K);
-                const double h = us[cur * (m + 1) + m];
-                const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
-                if (pact) {
-#pragma unroll
-                    for (int r = 0; r < NSP; ++r) {
-                        const int j = pj0 + pstep * r;
-                        if (j < n) {
-                            const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
-                            const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
-                            const double e0 = ((pi == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + c2 * h1;
-                            bpr[r][0] = -(e0 + c1 * g0);
-                            bpr[r][1] = -(e1 + c1 * g1);
-                            bmr[r][0] = e0 - c1 * g0;
-                            bmr[r][1] = e1 - c1 * g1;
-                        }
-                    }
-                }
-                int cbeg = s * nc, cend = s * nc + min(nc, d - s * nc);
-                if (p.compact) {  // unique blocks only: slice 0 writes the single copy
-                    cbeg = 0;
-                    cend = (s == 0) ? 1 : 0;
-                }
-                ncopy = 2 * (cend - cbeg);  // -B^+ copies, then B^- copies
-                sjb = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn + pi;
-            }
-            burst(0);         // phase 2
-            __syncthreads();  // B_c
-            burst(1);         // phase 3
-            cur ^= 1;
-            __syncthreads();   // B_d
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Fused residual + Jacobian kernel, version 3 (default): ONE persistent workgroup per CU, four
-// "matrix" wavefronts + four "stream" wavefronts, ONE workgroup barrier per work item (b, k, s).
-//
-//   stream waves  copy the item's -B^+ / B^- values out of the LDS tiles G, G^2 into registers and
-//                 then do nothing but issue the replicated 16-byte block stores (the HBM-roofline
-//                 stream; they are the waves that sit in the store queue's back-pressure);
-//   matrix waves  meanwhile work wave-synchronously (no workgroup barrier among them):
-//                 (1) the item's state columns in chunks of ncw columns, one chunk per wave at a time:
-//                     M = [S | D | G_l D] -> G*M on the f64 matrix cores -> delta, d/ddt, d/du_l
-//                     straight from the accumulator layout to HBM;
-//                 (2) G(u) and G^2 of the workgroup's NEXT item into the other half of the
-//                     double-buffered G / G^2 tiles (every matrix wave rewrites the whole union
-//                     pattern of G itself - identical values - so no wave waits for another before
-//                     its G^2 tiles).
-// Item time = max(store stream, matrix work); with the matrix work a fraction of the stream the
-// kernel runs at the store stream's rate.
-// LDS map (doubles): G [2][LD*n] | G2 [2][LD*n] | per matrix wave: M [LD*CW] GD [LD*ncw] G2D [LD*ncw] |
-//                    us [3][m+1] | union values | ELL values | (u16) union LDS offsets, ELL columns | (u8) union drives
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_lds_sync() {
-    // Lanes of one wave exchange data through LDS: wait for this wave's LDS traffic only (never vmcnt - the
-    // wave's global stores may sit in a saturated store queue for microseconds) and pin the compiler's order.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-
-#define PCL_MAXRT 4 // 16-row tiles of an n <= 64 operand
-#define PCL_MREG 8  // drives whose ELL row is held in registers (EW > 0 variants)
-#define PCL_PFC 4   // chunks per matrix wave whose state inputs are fetched at the top of the item (registers)
-#define PCL_PFW 2   // ... for chunk widths up to this many columns (wider chunks load at use)
-
-struct V3Tables {  // launch-invariant tables, in LDS when they fit (else in memory)
-    const double *unv;          // [n_upos*uw] drive coefficients of the union pattern
-    const unsigned char *unl;   // [n_upos*uw] drive index
-    const unsigned short *uni;  // [n_upos] LDS offset (row + LD*col) of the pattern entry
-    const double *ung0;         // [n_upos] drift value at the pattern entry (shared-drift case)
-    const double *ellv;         // [m*n*ew]
-    const unsigned short *ellc;
-};
-
-// EW: ELL width held in registers for m <= PCL_MREG drives (0: general, tables in LDS / memory).
-// TD/TM/TNCW: compile-time Hilbert dimension, drive count, chunk width (0 = run-time values).
-template <int EW, int TD, int TM, int TNCW>
-__global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
-    extern __shared__ double lds[];
-    const int d = TD ? TD : p.d, n = 2 * d, m = TD ? TM : p.m, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int nn = n * n;
-    const int ew = p.ell_w, uw = p.uell_w, n_ell = m * n * ew, n_un = p.n_upos;
-    const int ncw = TNCW ? TNCW : p.ncw;  // state columns per chunk
-    const int colsw = (2 + m) * ncw;   // operand columns per chunk
-    const int CW = 16;                 // one 16-column operand tile per chunk (host guarantees colsw <= 16)
-    const long long xd = (long long)n * d;
-    const int tile = LD * n;
-
-    double *Gb = lds;
-    double *G2b = Gb + 2 * tile;
-    double *wbuf = G2b + 2 * tile;  // per matrix wave
-    const int wsz = LD * (CW + 3 * ncw);
-    double *us = wbuf + 4 * wsz;
-    double *t_unv = us + 3 * (m + 1);
-    double *t_ung0 = t_unv + (p.tab_lds ? n_un * uw : 0);
-    double *t_ellv = t_ung0 + (p.tab_lds ? n_un : 0);
-    unsigned short *t_uni = reinterpret_cast<unsigned short *>(t_ellv + (p.tab_lds ? n_ell : 0));
-    unsigned short *t_ellc = t_uni + (p.tab_lds ? n_un : 0);
-    unsigned char *t_unl = reinterpret_cast<unsigned char *>(t_ellc + (p.tab_lds ? n_ell : 0));
-
-    // Work split.  contig = 0: items (b, k, slice of nc columns) dealt round-robin to the workgroups.
-    // contig = 1: the batch*K*d state columns of the launch are cut into gridDim.x equal contiguous ranges (to within one
-    // column); a workgroup's items are the pieces of its range that lie in one interval (first and last piece partial),
-    // so G, G^2 are built once per interval touched and every CU streams the same number of bytes.
-    const long long blk = p.compact ? (long long)nn : (long long)d * nn;  // size of seg 0 / seg 1
-    const int nc = p.nc;
-    int n_my;
-    long long g_lo = 0, g_hi = 0;
-    // Role split (contig only, n_stream > 0): workgroups [0, n_stream) stream the B^{+-} blocks of ALL columns (their
-    // matrix waves only build G, G^2), workgroups [n_stream, grid) do the column work of ALL columns (their stream waves
-    // idle).  The store stream is memory-side bound and half the CUs sustain it; on a CU of its own it is not slowed
-    // by the matrix waves' instructions and memory operations.
-    const bool stream_role = p.n_stream > 0 && (int)blockIdx.x < p.n_stream;
-    const bool matrix_role = p.n_stream > 0 && !stream_role;
-    // stream role, optional: pieces of p.snc columns dealt round-robin to the stream workgroups (at any moment they then
-    // write one window of ~n_stream/S consecutive intervals instead of n_stream far-apart ranges)
-    const bool srr = stream_role && p.snc > 0;
-    const int sS = srr ? (d + p.snc - 1) / p.snc : 1;
-    if (p.contig && !srr) {
-        const long long tot = (long long)p.batch * p.K * d;
-        const long long widx = matrix_role ? (long long)blockIdx.x - p.n_stream : (long long)blockIdx.x;
-        const long long wcnt = p.n_stream > 0 ? (stream_role ? (long long)p.n_stream : (long long)gridDim.x - p.n_stream) : (long long)gridDim.x;
-        g_lo = tot * widx / wcnt;
-        g_hi = tot * (widx + 1) / wcnt;
-        n_my = g_hi > g_lo ? (int)((g_hi - 1) / d - g_lo / d) + 1 : 0;
-    } else if (srr) {
-        const int n_items = p.batch * p.K * sS;
-        n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + p.n_stream - 1) / p.n_stream : 0;
-    } else {
-        const int n_items = p.batch * p.K * p.S;
-        n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    }
-    // item `it` of this workgroup: interval (b, k), state columns [c0, c0 + nce)
-    auto decode = [&](int it, int &c0, int &nce, int &k, int &b) {
-        if (p.contig && !srr) {
-            const long long bk = g_lo / d + it;
-            c0 = it == 0 ? (int)(g_lo - bk * d) : 0;
-            nce = (int)min((long long)d, g_hi - bk * d) - c0;
-            k = (int)(bk % p.K);
-            b = (int)(bk / p.K);
-        } else {
-            const int S_ = srr ? sS : p.S, nc_ = srr ? p.snc : nc;
-            const int item = blockIdx.x + it * (srr ? p.n_stream : (int)gridDim.x);
-            const int s = item % S_;
-            c0 = s * nc_;
-            nce = min(nc_, d - c0);
-            k = (item / S_) % p.K;
-            b = item / (S_ * p.K);
-        }
-    };
-
-    // item 0's controls / time step: requested before the prologue's table loads so that the latencies overlap
-    double u0 = 0.0;
-    if (n_my > 0 && wave < 4 && lane <= m) {
-        int c00, nce0, k0, b0;
-        decode(0, c00, nce0, k0, b0);
-        const double *z0 = p.Z + (long long)b0 * p.z_batch_stride + (long long)k0 * p.z_dim;
-        u0 = z0[lane < m ? p.u_off + lane : p.dt_off];
-    }
-    // ---- prologue: both G buffers = drift tile, tables -> LDS ----------------------------------------------
-    if (!p.g0_batch_stride)
-        for (int e = tid; e < nn; e += 512) {
-            const double g = p.G0[e];
-            const int o = (e % n) + LD * (e / n);
-            Gb[o] = g;
-            Gb[tile + o] = g;
-        }
-    if (p.tab_lds) {
-        for (int e = tid; e < n_un * uw; e += 512) {
-            t_unv[e] = p.uell_v[e];
-            t_unl[e] = p.uell_l[e];
-        }
-        for (int e = tid; e < n_un; e += 512) {
-            const int pos = p.upos[e];
-            t_uni[e] = (unsigned short)((pos % n) + LD * (pos / n));
-            t_ung0[e] = p.g0_batch_stride ? 0.0 : p.ug0[e];  // (not G0[pos]: no dependent load in the prologue)
-        }
-        for (int e = tid; e < n_ell; e += 512) {
-            t_ellv[e] = p.ell_val[e];
-            t_ellc[e] = (unsigned short)p.ell_col[e];
-        }
-    }
-    __syncthreads();
-
-
-    if (wave < 4 || matrix_role) {
-        // ======================================= matrix waves =========================================
-        // matrix role: all eight waves work on chunks; G, G^2 are single-buffered there and the second halves of the
-        // double buffers hold the chunk buffers of waves 4..7 (the host checks 2*wsz <= tile)
-        const int nmw = matrix_role ? 8 : 4;
-        double *Mw = wave < 4 ? wbuf + wave * wsz : (wave < 6 ? Gb + tile + (wave - 4) * wsz : G2b + tile + (wave - 6) * wsz);  // [LD*CW]: S | D | G_l D
-        double *GDw = Mw + LD * CW;      // [LD*ncw]
-        double *G2Dw = GDw + LD * ncw;   // [LD*ncw]
-        double *GSw = G2Dw + LD * ncw;   // [LD*ncw]
-        const int li = lane & 15, lk = lane >> 4;
-        const int rt_n = (n + 15) >> 4;
-        const int kfull = n >> 2, krem = n & 3;
-        // ELL rows (drive l, row = lane) in registers
-        unsigned short er_c[PCL_MREG][EW > 0 ? EW : 1];
-        double er_v[PCL_MREG][EW > 0 ? EW : 1];
-        if (EW > 0) {
-#pragma unroll
-            for (int l = 0; l < PCL_MREG; ++l)
-#pragma unroll
-                for (int q = 0; q < (EW > 0 ? EW : 1); ++q) {
-                    er_c[l][q] = 0;
-                    er_v[l][q] = 0.0;
-                    if (l < m && lane < n) {
-                        er_c[l][q] = (unsigned short)p.ell_col[(l * n + lane) * ew + q];
-                        er_v[l][q] = p.ell_val[(l * n + lane) * ew + q];
-                    }
-                }
-        }
-
-        // G(u) on the union pattern + this wave's share of the G^2 tiles, for item `it`, into buffer `buf`
-        auto build = [&](int it, int buf, double u_lane) {
-            int c0_, nce_, k, b;
-            decode(it, c0_, nce_, k, b);
-            double *G = Gb + buf * tile, *G2 = G2b + buf * tile;
-            double *usn = us + (it % 3) * (m + 1);
-            if (lane <= m) usn[lane] = u_lane;  // every wave: identical values
-            wave_lds_sync();
-            const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
-            if (p.g0_batch_stride)  // per-member drift: the whole tile changes with b
-                for (int e = lane; e < nn; e += 64) G[(e % n) + LD * (e / n)] = G0b[e];
-            if (p.tab_lds) {
-                for (int q = lane; q < n_un; q += 64) {
-                    double g = p.g0_batch_stride ? G0b[p.upos[q]] : t_ung0[q];
-                    for (int w = 0; w < uw; ++w) g += usn[t_unl[q * uw + w]] * t_unv[q * uw + w];
-                    G[t_uni[q]] = g;
-                }
-            } else {
-                for (int q = lane; q < n_un; q += 64) {
-                    const int pos = p.upos[q];
-                    double g = G0b[pos];
-                    const double *cf = p.ucoef + (long long)q * m;
-                    for (int l = 0; l < m; ++l) g += usn[l] * cf[l];
-                    G[(pos % n) + LD * (pos / n)] = g;
-                }
-            }
-            wave_lds_sync();
-            if (p.ablate & 1) return;
-            // G^2: row tile rt = wave (+4..), all column tiles; with the iso structure only the first d columns
-            const int ct_n = p.iso ? (d + 15) >> 4 : rt_n;
-            const int Nc = p.iso ? d : n;
-            for (int rt = wave; rt < rt_n; rt += 4) {
-                const double *Ap = G + rt * 16 + li + LD * lk;
-                for (int ct = 0; ct < ct_n; ct += 2) {
-                    const bool two = ct + 1 < ct_n;
-                    const double *Bp0 = G + lk + LD * (ct * 16 + li);
-                    const double *Bp1 = Bp0 + (two ? LD * 16 : 0);
-                    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-                    double an = 0.0, b0n = 0.0, b1n = 0.0;
-                    if (kfull > 0) {
-                        an = Ap[0];
-                        b0n = Bp0[0];
-                        b1n = Bp1[0];
-                    }
-                    for (int ks = 0; ks < kfull; ++ks) {
-                        const double a = an, b0 = b0n, b1 = b1n;
-                        if (ks + 1 < kfull) {
-                            an = Ap[LD * 4 * (ks + 1)];
-                            b0n = Bp0[4 * (ks + 1)];
-                            b1n = Bp1[4 * (ks + 1)];
-                        }
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
-                        if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
-                    }
-                    if (krem) {
-                        const bool ok = lk < krem;
-                        const double a = ok ? Ap[LD * 4 * kfull] : 0.0;
-                        const double b0 = ok ? Bp0[4 * kfull] : 0.0;
-                        const double b1 = ok ? Bp1[4 * kfull] : 0.0;
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
-                        if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int col = (ct + t) * 16 + li;
-                        if ((t == 0 || two) && col < Nc) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = rt * 16 + lk + 4 * r;
-                                const double v = t ? acc1[r] : acc0[r];
-                                if (row < n) {
-                                    G2[row + LD * col] = v;
-                                    if (p.iso) {
-                                        if (row < d)
-                                            G2[row + d + LD * (col + d)] = v;
-                                        else
-                                            G2[row - d + LD * (col + d)] = -v;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        };
-
-        if (n_my > 0 && wave < 4) build(0, 0, u0);
-        __syncthreads();  // item 0's G, G^2 complete
-
-        for (int it = 0; it < n_my; ++it) {
-            const int cur = matrix_role ? 0 : (it & 1);
-            int c0, nce, k, b;
-            decode(it, c0, nce, k, b);
-            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
-            const double *zn = zk + p.z_dim;
-            const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-            const double *G = Gb + cur * tile, *G2 = G2b + cur * tile;
-            const double h = us[(it % 3) * (m + 1) + m];
-            const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0), h6 = h * (1.0 / 6.0);
-            const long long bk = (long long)b * p.K + k;
-            double *jb = p.jac + bk * p.jac_per;
-            double *jt = jb + 2 * blk;  // tail: for column c: [d/du_0 .. d/du_{m-1} | d/ddt], n doubles each
-
-            const int nchunk = (nce + ncw - 1) / ncw;
-            int stamp = 0;
-#define PCL_STAMP()                                                                                     \
-    do {                                                                                                \
-        if (p.dbg && blockIdx.x == 0 && wave == 0 && lane == 0 && it == 1 && stamp < 60) p.dbg[stamp++] = (long long)__builtin_amdgcn_s_memtime(); \
-    } while (0)
-            PCL_STAMP();
-            // All global reads of this item are issued here, before the wave has any of the item's stores in flight:
-            // a later load would sit behind them in the CU's saturated memory pipeline (and vmcnt is in-order).
-            const bool pf = ncw <= PCL_PFW;
-            double pxn[PCL_PFC][PCL_PFW], pxc[PCL_PFC][PCL_PFW];
-            if (pf && lane < n && !(p.ablate & 4) && !stream_role) {
-#pragma unroll
-                for (int t = 0; t < PCL_PFC; ++t)
-#pragma unroll
-                    for (int c = 0; c < PCL_PFW; ++c) {
-                        const int col = c0 + (wave + nmw * t) * ncw + c;
-                        pxn[t][c] = pxc[t][c] = 0.0;
-                        if (c < ncw && col < c0 + nce) {
-                            const long long o = x_off + (long long)col * n + lane;
-                            if (p.ablate & 8) {  // DEBUG: no state loads
-                                pxn[t][c] = 1e-3 * lane;
-                                pxc[t][c] = 1e-3 * col;
-                            } else {
-                                pxn[t][c] = zn[o];
-                                pxc[t][c] = zk[o];
-                            }
-                        }
-                    }
-            }
-            double pf_u = 0.0;  // next item's u_k / dt_k (consumed by build)
-            if (it + 1 < n_my && lane <= m && wave < 4) {
-                int c02, nce2, k2, b2;
-                decode(it + 1, c02, nce2, k2, b2);
-                const double *zk2 = p.Z + (long long)b2 * p.z_batch_stride + (long long)k2 * p.z_dim;
-                pf_u = zk2[lane < m ? p.u_off + lane : p.dt_off];
-            }
-            int tch = 0;
-            for (int ch = wave; ch < nchunk && !(p.ablate & 4) && !stream_role; ch += nmw, ++tch) {
-                const int cc0 = c0 + ch * ncw;             // first state column of the chunk
-                const int ncc = min(ncw, c0 + nce - cc0);  // columns in this chunk
-                // ---- M = [S | D | G_l D]   (lane = row) -----------------------------------------------------
-                if (lane < n) {
-                    if (pf && tch < PCL_PFC) {
-#pragma unroll
-                        for (int t = 0; t < PCL_PFC; ++t)
-                            if (t == tch) {
-#pragma unroll
-                                for (int c = 0; c < PCL_PFW; ++c)
-                                    if (c < ncw) {
-                                        Mw[lane + LD * c] = pxn[t][c] + pxc[t][c];
-                                        Mw[lane + LD * (ncw + c)] = pxn[t][c] - pxc[t][c];
-                                    }
-                            }
-                    } else {
-                        for (int c = 0; c < ncw; ++c) {
-                            double xs = 0.0, xdv = 0.0;
-                            if (c < ncc) {
-                                const long long o = x_off + (long long)(cc0 + c) * n + lane;
-                                const double xn = zn[o], xc = zk[o];
-                                xs = xn + xc;
-                                xdv = xn - xc;
-                            }
-                            Mw[lane + LD * c] = xs;
-                            Mw[lane + LD * (ncw + c)] = xdv;
-                        }
-                    }
-                    for (int c = colsw; c < CW; ++c) Mw[lane + LD * c] = 0.0;
-                }
-                wave_lds_sync();
-                PCL_STAMP();  // S, D loaded
-                const double *Dm = Mw + LD * ncw;
-                if (lane < n) {
-                    if (EW > 0) {
-#pragma unroll
-                        for (int l = 0; l < PCL_MREG; ++l)
-                            if (l < m)
-                                for (int c = 0; c < ncw; ++c) {
-                                    double acc = 0.0;
-#pragma unroll
-                                    for (int q = 0; q < (EW > 0 ? EW : 1); ++q) acc += er_v[l][q] * Dm[er_c[l][q] + LD * c];
-                                    Mw[lane + LD * (2 * ncw + l * ncw + c)] = acc;
-                                }
-                    } else {
-                        for (int l = 0; l < m; ++l)
-                            for (int c = 0; c < ncw; ++c) {
-                                const int base = (l * n + lane) * ew;
-                                double acc = 0.0;
-                                for (int q = 0; q < ew; ++q) {
-                                    const int col = p.tab_lds ? (int)t_ellc[base + q] : p.ell_col[base + q];
-                                    const double ev = p.tab_lds ? t_ellv[base + q] : p.ell_val[base + q];
-                                    acc += ev * Dm[col + LD * c];
-                                }
-                                Mw[lane + LD * (2 * ncw + l * ncw + c)] = acc;
-                            }
-                    }
-                    PCL_STAMP();  // G_l D done
-                    // G2D = G^2 D on the VALU, 6 independent partial sums per column
-                    for (int c = 0; c < ncw; ++c) {
-                        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0;
-                        int kk = 0;
-                        for (; kk + 6 <= n; kk += 6) {
-                            s0 = fma(G2[lane + LD * kk], Dm[kk + LD * c], s0);
-                            s1 = fma(G2[lane + LD * (kk + 1)], Dm[kk + 1 + LD * c], s1);
-                            s2 = fma(G2[lane + LD * (kk + 2)], Dm[kk + 2 + LD * c], s2);
-                            s3 = fma(G2[lane + LD * (kk + 3)], Dm[kk + 3 + LD * c], s3);
-                            s4 = fma(G2[lane + LD * (kk + 4)], Dm[kk + 4 + LD * c], s4);
-                            s5 = fma(G2[lane + LD * (kk + 5)], Dm[kk + 5 + LD * c], s5);
-                        }
-                        for (; kk < n; ++kk) s0 = fma(G2[lane + LD * kk], Dm[kk + LD * c], s0);
-                        G2Dw[lane + LD * c] = ((s0 + s1) + (s2 + s3)) + (s4 + s5);
-                    }
-                }
-                wave_lds_sync();
-                PCL_STAMP();  // G2D done
-                // ---- W = G * M on the matrix cores: all row tiles at once (they share the b operand) ----------
-                {
-                    const double *Bp = Mw + lk + LD * li;
-                    const double *Ap[PCL_MAXRT];
-                    bool rok[PCL_MAXRT];
-#pragma unroll
-                    for (int t = 0; t < PCL_MAXRT; ++t) {
-                        rok[t] = t * 16 < n;
-                        Ap[t] = G + (rok[t] ? t * 16 : 0) + li + LD * lk;
-                    }
-                    double4_t acc[PCL_MAXRT];
-#pragma unroll
-                    for (int t = 0; t < PCL_MAXRT; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-                    if (!(p.ablate & 1)) {
-                        double an[PCL_MAXRT], bn = 0.0;
-#pragma unroll
-                        for (int t = 0; t < PCL_MAXRT; ++t) an[t] = kfull > 0 ? Ap[t][0] : 0.0;
-                        if (kfull > 0) bn = Bp[0];
-                        for (int ks = 0; ks < kfull; ++ks) {
-                            double a[PCL_MAXRT];
-                            const double bb = bn;
-#pragma unroll
-                            for (int t = 0; t < PCL_MAXRT; ++t) a[t] = an[t];
-                            if (ks + 1 < kfull) {
-#pragma unroll
-                                for (int t = 0; t < PCL_MAXRT; ++t) an[t] = Ap[t][LD * 4 * (ks + 1)];
-                                bn = Bp[4 * (ks + 1)];
-                            }
-#pragma unroll
-                            for (int t = 0; t < PCL_MAXRT; ++t)
-                                if (rok[t]) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bb, acc[t], 0, 0, 0);
-                        }
-                        if (krem) {
-                            const bool ok = lk < krem;
-                            const double bb = ok ? Bp[4 * kfull] : 0.0;
-#pragma unroll
-                            for (int t = 0; t < PCL_MAXRT; ++t)
-                                if (rok[t]) {
-                                    const double a = ok ? Ap[t][LD * 4 * kfull] : 0.0;
-                                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[t], 0, 0, 0);
-                                }
-                        }
-                    }
-                    // accumulator layout -> LDS: column li of [G S | G D | G (G_l D)]; the last group goes back into M's
-                    // own columns (their operand role is over)
-                    double *dst = li < ncw ? GSw + LD * li : (li < 2 * ncw ? GDw + LD * (li - ncw) : Mw + LD * li);
-#pragma unroll
-                    for (int t = 0; t < PCL_MAXRT; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = t * 16 + lk + 4 * r;
-                            if (row < n && li < colsw) dst[row] = acc[t][r];
-                        }
-                }
-                wave_lds_sync();
-                PCL_STAMP();  // MFMA + accumulators -> LDS done
-                // ---- outputs: finish in LDS (lane = row, in place), then 16-byte stores --------------------------------
-                // in place: delta -> D column, d/ddt -> GS column, d/du_l -> the G (G_l D) column
-                if (lane < n) {
-                    for (int c = 0; c < ncw; ++c) {
-                        const double gs = GSw[lane + LD * c], g2d = G2Dw[lane + LD * c];
-                        G2Dw[lane + LD * c] = Mw[lane + LD * (ncw + c)] - c1 * gs + c2 * g2d;  // delta
-                        GSw[lane + LD * c] = -0.5 * gs + h6 * g2d;                                // d/ddt
-                    }
-                    // d/du_l = G_l (-c1 S + c2 G D) + c2 G (G_l D)
-                    if (EW > 0) {
-#pragma unroll
-                        for (int l = 0; l < PCL_MREG; ++l)
-                            if (l < m)
-                                for (int c = 0; c < ncw; ++c) {
-                                    double acc = 0.0;
-#pragma unroll
-                                    for (int q = 0; q < (EW > 0 ? EW : 1); ++q)
-                                        acc += er_v[l][q] * (-c1 * Mw[er_c[l][q] + LD * c] + c2 * GDw[er_c[l][q] + LD * c]);
-                                    Mw[lane + LD * (2 * ncw + l * ncw + c)] = acc + c2 * Mw[lane + LD * (2 * ncw + l * ncw + c)];
-                                }
-                    } else {
-                        for (int l = 0; l < m; ++l)
-                            for (int c = 0; c < ncw; ++c) {
-                                const int base = (l * n + lane) * ew;
-                                double acc = 0.0;
-                                for (int q = 0; q < ew; ++q) {
-                                    const int col = p.tab_lds ? (int)t_ellc[base + q] : p.ell_col[base + q];
-                                    const double ev = p.tab_lds ? t_ellv[base + q] : p.ell_val[base + q];
-                                    acc += ev * (-c1 * Mw[col + LD * c] + c2 * GDw[col + LD * c]);
-                                }
-                                Mw[lane + LD * (2 * ncw + l * ncw + c)] = acc + c2 * Mw[lane + LD * (2 * ncw + l * ncw + c)];
-                            }
-                    }
-                }
-                wave_lds_sync();
-                // the chunk's columns are contiguous in every output vector: element e = c*n + row, two per lane
-                {
-                    const int hn2 = n >> 1;
-                    const long long o0 = (long long)cc0 * n;
-                    for (int e2 = lane; e2 < ((p.ablate & 32) ? 0 : ncc * hn2); e2 += 64) {
-                        const int c = e2 / hn2, r0 = 2 * (e2 - c * hn2);
-                        if (p.delta) store2(p.delta + bk * xd + o0 + (long long)c * n + r0, G2Dw[r0 + LD * c], G2Dw[r0 + 1 + LD * c], false);
-                        double *tc = jt + (long long)(cc0 + c) * (m + 1) * n + r0;  // this column's (m+1)*n tail block
-                        if (p.ablate & 64) tc = p.jac + (long long)blockIdx.x * 16384 + (wave * 1024 + c * 512) + r0;  // DEBUG: a cache-resident scratch target
-                        for (int l = 0; l < m; ++l) {
-                            const double *src = Mw + LD * (2 * ncw + l * ncw + c) + r0;
-                            store2(tc + (long long)l * n, src[0], src[1], false);
-                        }
-                        store2(tc + (long long)m * n, GSw[r0 + LD * c], GSw[r0 + 1 + LD * c], false);
-                    }
-                }
-                wave_lds_sync();  // the chunk buffers are rewritten by this wave's next chunk
-                PCL_STAMP();  // outputs issued
-            }
-            // ---- next item's G(u), G^2 into the other buffer ----------------------------------------------------
-            if (matrix_role) __syncthreads();  // single-buffered G, G^2: every wave is done with this item's tiles
-            if (it + 1 < n_my && wave < 4) build(it + 1, matrix_role ? 0 : cur ^ 1, pf_u);
-            PCL_STAMP();  // next G, G^2 built
-            __syncthreads();  // item boundary
-            PCL_STAMP();  // barrier passed
-        }
-    } else {
-        // ======================================= stream waves =========================================
-        const int stid = tid - 256;
-        const int hn = n >> 1;
-        const int pi = 2 * (stid % hn), pj0 = stid / hn, pstep = max(256 / hn, 1);
-        const bool pact = pj0 < pstep;
-        __syncthreads();  // item 0's G, G^2 complete
-        for (int it = 0; it < n_my; ++it) {
-            const int cur = it & 1;
-            int c0, nce, k, b;
-            decode(it, c0, nce, k, b);
-            const double *G = Gb + cur * tile, *G2 = G2b + cur * tile;
-            if (p.flat && !(p.ablate & 2) && !matrix_role) {
-                // Optional line-aligned flat stream (option aligned_stream): the item's share of a segment (copies
-                // cbeg..cend-1 of one n x n block) is ONE contiguous run; after a partial head up to the next 128-byte line
-                // every wave-level store covers eight whole lines (1 KiB); values recomputed per store from the LDS tiles.
-                // A bare store kernel gains 30-40 % from this alignment (scripts/probes/wstream2.hip); this kernel, whose
-                // per-block stores are 1 KiB contiguous per instruction already, does not (28.0 vs 28.2 us/eval).
-                const double h = us[(it % 3) * (m + 1) + m];
-                const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
-                int cbeg = c0, cend = c0 + nce;
-                if (p.compact) {
-                    cbeg = 0;
-                    cend = (c0 == 0) ? 1 : 0;
-                }
-                const long long L = (long long)(cend - cbeg) * nn;  // doubles per run
-                double *jbk = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn;
-                const int di = 512 % n, dj = (512 / n) % n;
-                auto put = [&](double *A0, long long a, int i, int j, int sg) {
-                    const double g0 = G[i + LD * j], g1 = G[i + 1 + LD * j];
-                    const double h0 = G2[i + LD * j], h1 = G2[i + 1 + LD * j];
-                    const double e0 = ((i == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((i + 1 == j) ? 1.0 : 0.0) + c2 * h1;
-                    if (sg == 0)
-                        store2(A0 + a, -(e0 + c1 * g0), -(e1 + c1 * g1), p.nt);
-                    else
-                        store2(A0 + a, e0 - c1 * g0, e1 - c1 * g1, p.nt);
-                };
-#pragma unroll
-                for (int sg = 0; sg < 2; ++sg) {
-                    double *A0 = jbk + sg * blk;
-                    const int head = (int)(((128 - ((unsigned long long)A0 & 127)) & 127) >> 3);  // doubles (even)
-                    if (2 * stid < head && 2 * stid < L) put(A0, 2 * stid, (2 * stid) % n, ((2 * stid) / n) % n, sg);
-                    long long a = head + 2LL * stid;
-                    int i = (int)(a % n), j = (int)((a / n) % n);
-                    for (; a < L; a += 512) {
-                        put(A0, a, i, j, sg);
-                        i += di;
-                        if (i >= n) {
-                            i -= n;
-                            ++j;
-                        }
-                        j += dj;
-                        if (j >= n) j -= n;
-                    }
-                }
-            } else if (pact && !(p.ablate & 2) && !matrix_role) {
-                const double h = us[(it % 3) * (m + 1) + m];
-                const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
-                double bpr[PCL_NSP][2], bmr[PCL_NSP][2];
-#pragma unroll
-                for (int r = 0; r < PCL_NSP; ++r) {
-                    const int j = pj0 + pstep * r;
-                    if (j < n) {
-                        const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
-                        const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
-                        const double e0 = ((pi == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + c2 * h1;
-                        bpr[r][0] = -(e0 + c1 * g0);
-                        bpr[r][1] = -(e1 + c1 * g1);
-                        bmr[r][0] = e0 - c1 * g0;
-                        bmr[r][1] = e1 - c1 * g1;
-                    }
-                }
-                int cbeg = c0, cend = c0 + nce;
-                if (p.compact) {  // unique blocks only: slice 0 writes the single copy
-                    cbeg = 0;
-                    cend = (c0 == 0) ? 1 : 0;
-                }
-                double *o = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn + pi;
-                for (int c = cbeg; c < cend; ++c, o += nn) {
-#pragma unroll
-                    for (int r = 0; r < PCL_NSP; ++r) {
-                        const int j = pj0 + pstep * r;
-                        if (j < n) {
-                            store2(o + n * j, bpr[r][0], bpr[r][1], p.nt);
-                            store2(o + blk + n * j, bmr[r][0], bmr[r][1], p.nt);
-                        }
-                    }
-                }
-            }
-            __syncthreads();  // item boundary
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Expansion kernel: compact -> full triplet order (replicate the unique blocks d times).
-// grid.x = batch*K*d ; each block copies one (b,k,c) pair of n*n blocks; block c==0 also copies the tail.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pcl_expand_kernel(const double *__restrict__ compact, double *__restrict__ full,
-                                                         int d, int n, int m, long long n_bk, int nt) {
-    const long long nn = (long long)n * n, xd = (long long)n * d;
-    const long long cper = 2 * nn + xd * (m + 1), fper = 2 * d * nn + xd * (m + 1);
-    const long long bid = blockIdx.x;
-    const int c = (int)(bid % d);
-    const long long bk = bid / d;
-    if (bk >= n_bk) return;
-    const double *src = compact + bk * cper;
-    double *dst = full + bk * fper;
-    for (long long q = threadIdx.x; q < (nn >> 1); q += blockDim.x) {
-        const double2_t v0 = *reinterpret_cast<const double2_t *>(src + 2 * q);
-        const double2_t v1 = *reinterpret_cast<const double2_t *>(src + nn + 2 * q);
-        store2(dst + c * nn + 2 * q, v0[0], v0[1], nt);
-        store2(dst + (d + c) * nn + 2 * q, v1[0], v1[1], nt);
-    }
-    if (c == 0) {
-        const long long tail = xd * (m + 1);
-        for (long long q = threadIdx.x; q < (tail >> 1); q += blockDim.x) {
-            const double2_t v = *reinterpret_cast<const double2_t *>(src + 2 * nn + 2 * q);
-            store2(dst + 2 * d * nn + 2 * q, v[0], v[1], nt);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Split mode, consumer side: persistent expander.  Work item = (b, k, piece): `cpp` of the 2d block copies of one
-// interval.  The workgroup waits until the producer kernel (running concurrently on another stream) has raised the
-// interval's flag, loads the unique -B^+ / B^- tile values it needs from the scratch tiles (L2) into registers and
-// streams the copies.  No LDS, no barrier inside the stream.  Hand-off protocol: producer = stores, s_waitcnt vmcnt(0),
-// __syncthreads, one lane: agent-scope release fence + relaxed agent-scope flag store; consumer = one lane polls the
-// flag (relaxed, agent scope), agent-scope acquire fence, __syncthreads, plain loads.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pcl_expand_stream_kernel(const double *blocks, const unsigned int *flags,
-                                                                double *__restrict__ jac, int d, int n, long long jac_per,
-                                                                long long n_bk, int pieces, int cpp, int nt) {
-    const int nn = n * n;
-    const int tid = threadIdx.x;
-    const int hn = n >> 1;
-    const int pi = 2 * (tid % hn), pj0 = tid / hn, pstep = max(256 / hn, 1);
-    const bool pact = pj0 < pstep;
-    const long long n_items = n_bk * pieces;
-    const long long blk = (long long)d * nn;
-    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const long long bk = item / pieces;
-        const int piece = (int)(item - bk * pieces);
-        if (tid == 0) {
-            // bounded spin (about a second): a producer that never shows up must not hang the device
-            int spins = 0;
-            while (__hip_atomic_load(flags + bk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && spins < (1 << 22)) {
-                __builtin_amdgcn_s_sleep(8);
-                ++spins;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        if (pact) {
-            const double *src = blocks + bk * 2 * nn + pi;
-            double2_t vp[8], vm[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int j = pj0 + pstep * r;
-                if (j < n) {
-                    vp[r] = *reinterpret_cast<const double2_t *>(src + n * j);
-                    vm[r] = *reinterpret_cast<const double2_t *>(src + nn + n * j);
-                }
-            }
-            // copies q in [piece*cpp, ..): q < d are -B^+ copies, q >= d are B^- copies
-            const int q0 = piece * cpp, q1 = min(2 * d, q0 + cpp);
-            double *dst = jac + bk * jac_per + pi;
-            for (int q = q0; q < q1; ++q) {
-                if (q < d) {
-                    double *o = dst + (long long)q * nn;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const int j = pj0 + pstep * r;
-                        if (j < n) store2(o + n * j, vp[r][0], vp[r][1], nt);
-                    }
-                } else {
-                    double *o = dst + blk + (long long)(q - d) * nn;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const int j = pj0 + pstep * r;
-                        if (j < n) store2(o + n * j, vm[r][0], vm[r][1], nt);
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Hessian-of-Lagrangian kernel: one workgroup per (b, k); the d state columns are processed in
-// chunks of nc columns (columns are independent except for the (m+1)(m+2)/2 scalar entries,
-// whose per-chunk partial sums are accumulated in LDS in a fixed order -> deterministic).
-// With M = mu_k (n x d):  A1 = G^T M, A2 = G^T A1, P_l = G_l^T M, Q_l = G^T P_l, R_l = G_l^T A1,
-//                         GD = G D, E_l = G_l D.
-// LDS map: G [LD*n] | Mm | S | D | GD | A1 | A2 (each LD*nc) | P | Q | E (each m*LD*nc) | us | red | acc
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-template <bool MFMA>
-__global__ __launch_bounds__(256) void pcl_hess_kernel(const KParams p) {
-    extern __shared__ double lds[];
-    const int n = p.n, d = p.cols, m = p.m, LD = p.LD, nc = p.nc;  // d: state columns here
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const int k = blockIdx.x % p.K, b = blockIdx.x / p.K;
-    const long long xd = (long long)n * d;
-    const int LDc = LD * nc;
-    const int nscal = (m + 1) * (m + 2) / 2;
-    const int nw = nth >> 6, wv = tid >> 6, lane = tid & 63;
-
-    double *G = lds;
-    double *Mm = G + LD * n;
-    double *Sm = Mm + LDc;
-    double *Dm = Sm + LDc;
-    double *GD = Dm + LDc;
-    double *A1 = GD + LDc;
-    double *A2 = A1 + LDc;
-    double *P = A2 + LDc;
-    double *Q = P + m * LDc;
-    double *E = Q + m * LDc;
-    double *us = E + m * LDc;
-    double *red = us + 8 + m;       // nw * nscal
-    double *acc = red + nw * nscal;  // nscal
-
-    const double *Zb = p.Z + (long long)b * p.z_batch_stride;
-    const double *zk = Zb + (long long)k * p.z_dim;
-    const double *zn = zk + p.z_dim;
-    const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-    const double h = zk[p.dt_off];
-    const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0), h6 = h * (1.0 / 6.0);
-    const long long bk = (long long)b * p.K + k;
-    const double *mu = p.mu + bk * xd;
-    double *H = p.hess + bk * p.hess_per;
-    double *H3 = H + nscal, *H4 = H3 + (long long)m * xd, *H5 = H4 + xd, *H6 = H5 + (long long)m * xd;
-
-    build_G(p, p.G0 + (long long)b * p.g0_batch_stride, zk, G, us);
-    for (int e = tid; e < nscal; e += nth) acc[e] = 0.0;
-
-    for (int c0 = 0; c0 < d; c0 += nc) {
-        const int nce = min(nc, d - c0);
-        __syncthreads();  // previous chunk fully consumed (and G / acc initialised)
-        for (int e = tid; e < nce * n; e += nth) {
-            const int c = e / n, i = e % n;
-            const long long g = (long long)(c0 + c) * n + i;
-            const double xn = zn[x_off + g], xc = zk[x_off + g];
-            Sm[i + LD * c] = xn + xc;
-            Dm[i + LD * c] = xn - xc;
-            Mm[i + LD * c] = mu[g];
-        }
-        __syncthreads();
-        // sparse applications: P_l = G_l^T M (CSC columns of G_l), E_l = G_l D (CSR rows)
-        for (int e = tid; e < m * nce * n; e += nth) {
-            const int i = e % n, c = (e / n) % nce, l = e / (n * nce);
-            const int *cp = p.csc_ptr + l * (n + 1);
-            double a = 0.0;
-            for (int q = cp[i]; q < cp[i + 1]; ++q) a += p.csc_val[q] * Mm[p.csc_row[q] + LD * c];
-            P[l * LDc + i + LD * c] = a;
-            const int *rp = p.csr_ptr + l * (n + 1);
-            double a2 = 0.0;
-            for (int q = rp[i]; q < rp[i + 1]; ++q) a2 += p.csr_val[q] * Dm[p.csr_col[q] + LD * c];
-            E[l * LDc + i + LD * c] = a2;
-        }
-        __syncthreads();
-        gemm_lds<MFMA, false>(G, LD, Dm, LD, GD, LD, n, nce, n);
-        gemm_lds<MFMA, true>(G, LD, Mm, LD, A1, LD, n, nce, n);
-        for (int l = 0; l < m; ++l) gemm_lds<MFMA, true>(G, LD, P + l * LDc, LD, Q + l * LDc, LD, n, nce, n);
-        __syncthreads();
-        gemm_lds<MFMA, true>(G, LD, A1, LD, A2, LD, n, nce, n);
-
-        // ---- scalar segments 0..2: per-wave partial sums -> red[w][pidx] ----------------------
-        int pidx = 0;
-        for (int i = 0; i < m; ++i)
-            for (int j = 0; j <= i; ++j, ++pidx) {
-                double v = 0.0;
-                for (int e = tid; e < nce * n; e += nth) {
-                    const int idx = (e % n) + LD * (e / n);
-                    v += P[i * LDc + idx] * E[j * LDc + idx] + P[j * LDc + idx] * E[i * LDc + idx];
-                }
-                v = wave_sum(v);
-                if (lane == 0) red[wv * nscal + pidx] = c2 * v;
-            }
-        for (int j = 0; j < m; ++j, ++pidx) {
-            double v1 = 0.0, v2 = 0.0;
-            for (int e = tid; e < nce * n; e += nth) {
-                const int idx = (e % n) + LD * (e / n);
-                v1 += P[j * LDc + idx] * Sm[idx];
-                v2 += P[j * LDc + idx] * GD[idx] + A1[idx] * E[j * LDc + idx];
-            }
-            v1 = wave_sum(v1);
-            v2 = wave_sum(v2);
-            if (lane == 0) red[wv * nscal + pidx] = -0.5 * v1 + h6 * v2;
-        }
-        {
-            double v = 0.0;
-            for (int e = tid; e < nce * n; e += nth) {
-                const int idx = (e % n) + LD * (e / n);
-                v += A1[idx] * GD[idx];
-            }
-            v = wave_sum(v);
-            if (lane == 0) red[wv * nscal + pidx] = v * (1.0 / 6.0);
-        }
-        __syncthreads();  // red complete, A2 complete
-        for (int e = tid; e < nscal; e += nth) {
-            double t = acc[e];
-            for (int w = 0; w < nw; ++w) t += red[w * nscal + e];
-            acc[e] = t;
-        }
-        // ---- vector segments 3..6 for this chunk's columns --------------------------------------
-        for (int e = tid; e < m * nce * n; e += nth) {
-            const int i = e % n, c = (e / n) % nce, l = e / (n * nce);
-            const int *cp = p.csc_ptr + l * (n + 1);
-            double r = 0.0;  // R_l = G_l^T (G^T M)
-            for (int q = cp[i]; q < cp[i + 1]; ++q) r += p.csc_val[q] * A1[p.csc_row[q] + LD * c];
-            const int idx = i + LD * c;
-            const double kt = c2 * (Q[l * LDc + idx] + r);
-            const double pl = -c1 * P[l * LDc + idx];
-            const long long o = (long long)l * xd + (long long)(c0 + c) * n + i;
-            H3[o] = pl - kt;
-            H5[o] = pl + kt;
-        }
-        for (int e = tid; e < nce * n; e += nth) {
-            const int idx = (e % n) + LD * (e / n);
-            const long long o = (long long)c0 * n + e;
-            H4[o] = -0.5 * A1[idx] - h6 * A2[idx];
-            H6[o] = -0.5 * A1[idx] + h6 * A2[idx];
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < nscal; e += nth) H[e] = acc[e];
-}
-
-// ------------------------------------------------------------------------------------------
-// Hessian-of-Lagrangian kernel, version 2 (default when every drive row / column has <= EW entries and m <= 6):
-// persistent workgroups (2 per CU, 4 wavefronts each) over work items (b, k, slice of <= 16 state columns).
-// Per item the four waves work wave-synchronously on chunks of NCW = 16/(m+1) columns:
-//     operand tile  [M | P_1 .. P_m],  P_l = G_l^T M  (ELL rows of G_l^T in registers, lane = row)
-//     one pass of the f64 matrix cores:  G^T [M | P_l] = [A1 | Q_l]
-//     R_l = G_l^T A1, E_l = G_l D (registers)  ->  the d2/du dX vectors straight to HBM
-//     the (m+1)(m+2)/2 - 1 scalar entries that involve u as per-lane partial sums in registers:
-//         <M,(G_i G_j + G_j G_i) D> = <P_i,E_j> + <P_j,E_i>,   <M,G_j S> = <P_j,S>,
-//         <M,(G_j G + G G_j) D> = <Q_j,D> + <A1,E_j>
-// then, once per item: A2 = G^T A1 for all the slice's columns in ONE matrix-core pass (wave w = row tile w),
-// the d2/dh dX vectors, <A2,D>, and a fixed-order reduction lane -> wave -> workgroup -> (slices of the interval,
-// summed by the last slice to arrive: partial sums in `hpart`, arrival counter in `hcnt`) -> deterministic.
-// No G^2, no G D product: every contraction with D is moved onto M's side.
-// LDS map (doubles): G [LD*n] | A1s [LD*16] | A2s [LD*16] | Ds [LD*16] | per wave Mw [LD*16] | wsum [4][NSC] | wsum2 [4] | flag
-// ------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-// sum over the 16 lanes of a DPP row, the same bits in every lane of the row (xor 1, xor 2, half mirror, mirror)
-__device__ __forceinline__ double row16_sum(double v) {
-    v += dpp_f64<0xB1>(v);
-    v += dpp_f64<0x4E>(v);
-    v += dpp_f64<0x141>(v);
-    v += dpp_f64<0x140>(v);
-    return v;
-}
-
-// TD: compile-time Hilbert dimension (0 = run-time).  ANTI: every G_l is exactly antisymmetric (G = iso(-iH) with H
-// Hermitian), so the rows of G_l^T are minus the rows of G_l and one ELL table serves both.
-template <int EW, int TM, int TD, bool ANTI>
-__global__ __launch_bounds__(256, 2) void pcl_hess_kernel_v2(const KParams p) {
-    extern __shared__ double lds[];
-    constexpr int m = TM;
-    constexpr int NCW = 16 / (TM + 1);
-    constexpr int NSC = (TM + 1) * (TM + 2) / 2;
-    constexpr int NPAIR = TM * (TM + 1) / 2;
-    constexpr int NACC = NPAIR + TM;
-    const int n = TD ? 2 * TD : p.n, d = p.cols, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int li = lane & 15, lk = lane >> 4;
-    const int nn = n * n;
-    const long long xd = (long long)n * d;
-    const int kfull = n >> 2, krem = n & 3;
-
-    double *G = lds;
-    double *A1s = G + LD * n;
-    double *A2s = A1s + LD * 16;
-    double *Ds = A2s + LD * 16;
-    double *Mw = Ds + LD * 16 + wave * (LD * 16);
-    double *wsum = Ds + LD * 16 + 4 * (LD * 16);
-    double *wsum2 = wsum + 4 * NSC;
-    int *lastflag = reinterpret_cast<int *>(wsum2 + 4);
-
-    // ELL rows of G_l (er) and of G_l^T (et) for row = lane
-    constexpr int TE = ANTI ? 1 : TM;  // the transposed table is only held when it differs from minus the plain one
-    unsigned short er_c[TM][EW], et_c_[TE][EW];
-    double er_v[TM][EW], et_v_[TE][EW];
-#pragma unroll
-    for (int l = 0; l < TM; ++l)
-#pragma unroll
-        for (int q = 0; q < EW; ++q) {
-            er_c[l][q] = 0;
-            er_v[l][q] = 0.0;
-            if (!ANTI) {
-                et_c_[ANTI ? 0 : l][q] = 0;
-                et_v_[ANTI ? 0 : l][q] = 0.0;
-            }
-            if (lane < n) {
-                if (q < p.ell_w) {
-                    er_c[l][q] = (unsigned short)p.ell_col[(l * n + lane) * p.ell_w + q];
-                    er_v[l][q] = p.ell_val[(l * n + lane) * p.ell_w + q];
-                }
-                if (!ANTI && q < p.ellt_w) {
-                    et_c_[ANTI ? 0 : l][q] = (unsigned short)p.ellt_col[(l * n + lane) * p.ellt_w + q];
-                    et_v_[ANTI ? 0 : l][q] = p.ellt_val[(l * n + lane) * p.ellt_w + q];
-                }
-            }
-        }
-#define ET_C(l, q) (ANTI ? er_c[l][q] : et_c_[ANTI ? 0 : (l)][q])
-#define ET_V(l, q) (ANTI ? er_v[l][q] : et_v_[ANTI ? 0 : (l)][q])  // ANTI: the caller negates the sum
-    if (!p.g0_batch_stride)
-        for (int e = tid; e < nn; e += 256) G[(e % n) + LD * (e / n)] = p.G0[e];
-
-    const int S = p.S, nc = p.nc;
-    const int n_items = p.batch * p.K * S;
-    int stamp = 0;
-#define PCL_HSTAMP()                                                                                  \
-    do {                                                                                             \
-        if (p.dbg && blockIdx.x == 0 && tid == 0 && stamp < 60) p.dbg[stamp++] = (long long)__builtin_amdgcn_s_memtime(); \
-    } while (0)
-    PCL_HSTAMP();  // prologue done
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int s = item % S, k = (item / S) % p.K, b = item / (S * p.K);
-        const int c0 = s * nc, nce = min(nc, d - c0);
-        const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
-        const double *zn = zk + p.z_dim;
-        const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-        const double h = zk[p.dt_off];
-        const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0), h6 = h * (1.0 / 6.0);
-        const long long bk = (long long)b * p.K + k;
-        const double *mu = p.mu + bk * xd;
-        double *H = p.hess + bk * p.hess_per;
-        double *H3 = H + NSC, *H4 = H3 + (long long)m * xd, *H5 = H4 + xd, *H6 = H5 + (long long)m * xd;
-
-        // inputs of this wave's first chunk: requested before G is built, consumed after
-        const int nchunk = (nce + NCW - 1) / NCW;
-        double pxn[NCW], pxc[NCW], pmu[NCW];
-#pragma unroll
-        for (int c = 0; c < NCW; ++c) {
-            pxn[c] = pxc[c] = pmu[c] = 0.0;
-            if (lane < n && wave < nchunk && wave * NCW + c < nce) {
-                const long long g = (long long)(c0 + wave * NCW + c) * n + lane;
-                pxn[c] = zn[x_off + g];
-                pxc[c] = zk[x_off + g];
-                pmu[c] = mu[g];
-            }
-        }
-        __syncthreads();  // the previous item of this workgroup is fully consumed
-        PCL_HSTAMP();  // item start
-        // ---- G(u_k): drift everywhere (per-member drift only), then the drives' union pattern ------------------
-        {
-            const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
-            if (p.g0_batch_stride)
-                for (int e = tid; e < nn; e += 256)
-                    if (p.umap[e] < 0) G[(e % n) + LD * (e / n)] = G0b[e];
-            double uu[TM];
-#pragma unroll
-            for (int l = 0; l < TM; ++l) uu[l] = zk[p.u_off + l];
-            for (int q = tid; q < p.n_upos; q += 256) {
-                const int pos = p.upos[q];
-                double g = p.g0_batch_stride ? G0b[pos] : p.ug0[q];
-                const double *cf = p.ucoef + (long long)q * m;
-#pragma unroll
-                for (int l = 0; l < TM; ++l) g += uu[l] * cf[l];
-                G[(pos % n) + LD * (pos / n)] = g;
-            }
-        }
-        __syncthreads();
-
-        PCL_HSTAMP();  // G built
-        double acc[NACC];
-#pragma unroll
-        for (int e = 0; e < NACC; ++e) acc[e] = 0.0;
-        for (int ch = wave; ch < nchunk; ch += 4) {
-            const int cl0 = ch * NCW;                // first column of the chunk inside the slice
-            const int ncc = min(NCW, nce - cl0);     // columns in this chunk
-            double Sv[NCW], Pv[TM][NCW];
-            if (lane < n) {
-#pragma unroll
-                for (int c = 0; c < NCW; ++c) {
-                    Sv[c] = 0.0;
-                    double mv = 0.0;
-                    if (c < ncc) {
-                        double xn = pxn[c], xc = pxc[c];
-                        mv = pmu[c];
-                        if (ch != wave) {  // further chunks of a wide slice load at use
-                            const long long g = (long long)(c0 + cl0 + c) * n + lane;
-                            xn = zn[x_off + g];
-                            xc = zk[x_off + g];
-                            mv = mu[g];
-                        }
-                        Sv[c] = xn + xc;
-                        Ds[lane + LD * (cl0 + c)] = xn - xc;
-                    }
-                    Mw[lane + LD * c] = mv;
-                }
-            }
-            wave_lds_sync();
-            PCL_HSTAMP();  // inputs loaded
-            if (lane < n) {
-#pragma unroll
-                for (int l = 0; l < TM; ++l)
-#pragma unroll
-                    for (int c = 0; c < NCW; ++c) {
-                        double pv = 0.0;
-                        if (c < ncc) {
-#pragma unroll
-                            for (int q = 0; q < EW; ++q) pv += ET_V(l, q) * Mw[ET_C(l, q) + LD * c];
-                            if (ANTI) pv = -pv;
-                        }
-                        Pv[l][c] = pv;
-                        Mw[lane + LD * (NCW + l * NCW + c)] = pv;
-                    }
-            }
-            wave_lds_sync();
-            PCL_HSTAMP();  // P, E done
-            // ---- [A1 | Q_l] = G^T [M | P_l]: all row tiles at once (they share the b operand) --------------------
-            double4_t ac[PCL_MAXRT];
-            {
-                const double *Bp = Mw + lk + LD * li;
-                const double *Ap[PCL_MAXRT];
-                bool rok[PCL_MAXRT];
-#pragma unroll
-                for (int t = 0; t < PCL_MAXRT; ++t) {
-                    rok[t] = t * 16 < n;
-                    Ap[t] = G + lk + LD * ((rok[t] ? t * 16 : 0) + li);
-                    ac[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-                }
-                double an[PCL_MAXRT], bn = 0.0;
-#pragma unroll
-                for (int t = 0; t < PCL_MAXRT; ++t) an[t] = kfull > 0 ? Ap[t][0] : 0.0;
-                if (kfull > 0) bn = Bp[0];
-                for (int ks = 0; ks < kfull; ++ks) {
-                    double a[PCL_MAXRT];
-                    const double bb = bn;
-#pragma unroll
-                    for (int t = 0; t < PCL_MAXRT; ++t) a[t] = an[t];
-                    if (ks + 1 < kfull) {
-#pragma unroll
-                        for (int t = 0; t < PCL_MAXRT; ++t) an[t] = Ap[t][4 * (ks + 1)];
-                        bn = Bp[4 * (ks + 1)];
-                    }
-#pragma unroll
-                    for (int t = 0; t < PCL_MAXRT; ++t)
-                        if (rok[t]) ac[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bb, ac[t], 0, 0, 0);
-                }
-                if (krem) {
-                    const bool ok = lk < krem;
-                    const double bb = ok ? Bp[4 * kfull] : 0.0;
-#pragma unroll
-                    for (int t = 0; t < PCL_MAXRT; ++t)
-                        if (rok[t]) {
-                            const double a = ok ? Ap[t][4 * kfull] : 0.0;
-                            ac[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, ac[t], 0, 0, 0);
-                        }
-                }
-            }
-            wave_lds_sync();  // every operand read of this wave is complete before the tile is overwritten
-            PCL_HSTAMP();  // MFMA done
-            if (li < (TM + 1) * NCW) {
-                double *a1 = (li < ncc) ? A1s + LD * (cl0 + li) : nullptr;
-#pragma unroll
-                for (int t = 0; t < PCL_MAXRT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = t * 16 + lk + 4 * r;
-                        if (row < n) {
-                            Mw[row + LD * li] = ac[t][r];
-                            if (a1) a1[row] = ac[t][r];
-                        }
-                    }
-            }
-            wave_lds_sync();
-            if (lane < n) {
-#pragma unroll
-                for (int c = 0; c < NCW; ++c)
-                    if (c < ncc) {
-                        const double a1v = Mw[lane + LD * c];
-                        const double *Dc = Ds + LD * (cl0 + c);
-                        const double dv = Dc[lane];
-                        const long long o = (long long)(c0 + cl0 + c) * n + lane;
-                        double Ev[TM];  // E_l = G_l D, this row and column
-#pragma unroll
-                        for (int l = 0; l < TM; ++l) {
-                            double ev = 0.0, r = 0.0;  // R_l = G_l^T A1
-#pragma unroll
-                            for (int q = 0; q < EW; ++q) {
-                                ev += er_v[l][q] * Dc[er_c[l][q]];
-                                r += ET_V(l, q) * Mw[ET_C(l, q) + LD * c];
-                            }
-                            if (ANTI) r = -r;
-                            Ev[l] = ev;
-                            const double qv = Mw[lane + LD * (NCW + l * NCW + c)];
-                            const double kt = c2 * (qv + r), pl = -c1 * Pv[l][c];
-                            if (!(p.ablate & 1)) {
-                                H3[(long long)l * xd + o] = pl - kt;
-                                H5[(long long)l * xd + o] = pl + kt;
-                            }
-                            acc[NPAIR + l] += -0.5 * Pv[l][c] * Sv[c] + h6 * (qv * dv + a1v * ev);
-                        }
-                        int e = 0;
-                        if (!(p.ablate & 2)) {
-#pragma unroll
-                            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                                for (int j = 0; j <= i; ++j, ++e) acc[e] += Pv[i][c] * Ev[j] + Pv[j][c] * Ev[i];
-                        }
-                    }
-            }
-            wave_lds_sync();  // Mw is rewritten by this wave's next chunk / the reduction below
-            PCL_HSTAMP();  // chunk outputs + sums done
-        }
-        // ---- lane -> wave reduction of the per-lane partial sums on the matrix cores (fixed order) -----------------
-        // C += 1_e x v_e : with a = [li == e] and b = the lanes' partial sums of entry e, row e of C collects
-        // sum_k v_e[lane j + 16 k] in column j; four DPP steps then add the 16 columns of a row.
-        {
-            double4_t r0 = {0.0, 0.0, 0.0, 0.0}, r1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int e = 0; e < NACC; ++e) {
-                const double ind = (li == (e & 15)) ? 1.0 : 0.0;
-                if (e < 16)
-                    r0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ind, acc[e], r0, 0, 0, 0);
-                else
-                    r1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ind, acc[e], r1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double t0 = row16_sum(r0[r]);
-                const int e0 = lk + 4 * r;
-                if (li == 0 && e0 < NACC) wsum[wave * NSC + e0] = t0;
-                if (NACC > 16) {
-                    const double t1 = row16_sum(r1[r]);
-                    if (li == 0 && 16 + e0 < NACC) wsum[wave * NSC + 16 + e0] = t1;
-                }
-            }
-        }
-        PCL_HSTAMP();  // wave reduction done
-        __syncthreads();  // A1s, Ds and wsum complete
-        PCL_HSTAMP();
-        // ---- A2 = G^T A1 for the slice's columns: wave w = row tile w --------------------------------------------
-        if (wave * 16 < n) {
-            const double *Ap = G + lk + LD * (wave * 16 + li);
-            const double *Bp = A1s + lk + LD * li;
-            double4_t a2 = {0.0, 0.0, 0.0, 0.0};
-            for (int ks = 0; ks < kfull; ++ks) a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[4 * ks], Bp[4 * ks], a2, 0, 0, 0);
-            if (krem) {
-                const bool ok = lk < krem;
-                a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? Ap[4 * kfull] : 0.0, ok ? Bp[4 * kfull] : 0.0, a2, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wave * 16 + lk + 4 * r;
-                if (row < n) A2s[row + LD * li] = a2[r];
-            }
-        }
-        __syncthreads();
-        {
-            double v = 0.0;
-            for (int e = tid; e < nce * n; e += 256) {
-                const int c = e / n, i = e - c * n;
-                v += A2s[i + LD * c] * Ds[i + LD * c];
-            }
-            v = wave_sum(v);
-            if (lane == 0) wsum2[wave] = v;
-        }
-        __syncthreads();
-        PCL_HSTAMP();  // A2 done
-        if (tid < NSC) {
-            double tot;
-            if (tid < NACC) {
-                tot = ((wsum[tid] + wsum[NSC + tid]) + wsum[2 * NSC + tid]) + wsum[3 * NSC + tid];
-                if (tid < NPAIR) tot *= c2;
-            } else {
-                tot = (((wsum2[0] + wsum2[1]) + wsum2[2]) + wsum2[3]) * (1.0 / 6.0);
-            }
-            if (S == 1)
-                H[tid] = tot;
-            else {
-                // agent-scope (write-through) store of this slice's partial entry; it has left the CU before the arrival
-                // counter moves.  No release fence: that would write back this XCD's whole L2 (full of Hessian output).
-                __hip_atomic_store(p.hpart + (bk * S + s) * NSC + tid, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
-        unsigned int ticket = 0;
-        if (S > 1) {
-            __syncthreads();
-            if (tid == 0) ticket = __hip_atomic_fetch_add(p.hcnt + bk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // the d2/dh dX vectors go out while the counter's round trip is in flight
-        for (int e = tid; e < nce * n; e += 256) {
-            const int c = e / n, i = e - c * n;
-            const double a1 = A1s[i + LD * c], a2 = A2s[i + LD * c];
-            const long long o = (long long)(c0 + c) * n + i;
-            H4[o] = -0.5 * a1 - h6 * a2;
-            H6[o] = -0.5 * a1 + h6 * a2;
-        }
-        if (S > 1) {
-            if (tid == 0) {
-                const int last = ticket == (unsigned int)(S - 1);
-                if (last) __hip_atomic_store(p.hcnt + bk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-                *lastflag = last;
-            }
-            __syncthreads();
-            if (*lastflag && tid < NSC) {  // the last slice of the interval to arrive sums the partials in slice order
-                double t = 0.0;  // agent-scope loads bypass this XCD's L2
-                for (int q = 0; q < S; ++q) t += __hip_atomic_load(p.hpart + (bk * S + q) * NSC + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                H[tid] = t;
-            }
-        }
-        PCL_HSTAMP();  // item done
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Rollout: exact piecewise-constant propagation  X_{k+1} = exp(dt_k G(u_k)) X_k  from the knot-0 state
-// -- what the reference's unitary_rollout(...; interpolation = :constant) integrates with an ODE solver
-// [REF src/quantum/dynamics.jl:631-667] and the slot its RolloutStates reserves for "a GPU rollout"
-// [REF src/quantum/trajectories/ensemble_trajectory.jl:56-71].
-//   pcl_expm_kernel   one workgroup per (b, k): E = exp(h G) by scaling and squaring, Taylor degree 14 (Horner) at
-//                     |h| ||G||_1 / 2^s <= 1/4 (truncation < 1e-21), products on the matrix cores
-//   pcl_chain_kernel  one workgroup per member / trajectory: the K dependent n x n x cols products
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pcl_expm_kernel(const KParams p) {
-    extern __shared__ double lds[];
-    const int n = p.n, LD = p.LD;
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const int k = blockIdx.x % p.K, b = blockIdx.x / p.K;
-    double *A = lds, *T = A + LD * n, *T2 = T + LD * n, *us = T2 + LD * n, *red = us + 8 + p.m;
-    const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
-    const double h = zk[p.dt_off];
-    build_G(p, p.G0 + (long long)b * p.g0_batch_stride, zk, A, us);
-    __syncthreads();
-    if (tid < 64) {
-        double cs = 0.0;
-        if (tid < n)
-            for (int i = 0; i < n; ++i) cs += fabs(A[i + LD * tid]);
-        red[tid] = cs;
-    }
-    __syncthreads();
-    double nrm = 0.0;
-    for (int j = 0; j < n; ++j) nrm = fmax(nrm, red[j]);
-    double theta = fabs(h) * nrm;
-    int sq = 0;
-    while (theta > 0.25 && sq < 60) {
-        theta *= 0.5;
-        ++sq;
-    }
-    const double hs = ldexp(h, -sq);
-    for (int e = tid; e < n * n; e += nth) T[(e % n) + LD * (e / n)] = (e % n == e / n) ? 1.0 : 0.0;
-    __syncthreads();
-    for (int j = 14; j >= 1; --j) {  // T <- I + (hs/j) A T
-        gemm_lds<true, false>(A, LD, T, LD, T2, LD, n, n, n);
-        __syncthreads();
-        const double f = hs / j;
-        for (int e = tid; e < n * n; e += nth) {
-            const int idx = (e % n) + LD * (e / n);
-            T[idx] = ((e % n == e / n) ? 1.0 : 0.0) + f * T2[idx];
-        }
-        __syncthreads();
-    }
-    double *cur = T, *oth = T2;
-    for (int i = 0; i < sq; ++i) {
-        gemm_lds<true, false>(cur, LD, cur, LD, oth, LD, n, n, n);
-        __syncthreads();
-        double *t = cur;
-        cur = oth;
-        oth = t;
-    }
-    double *E = p.expm + ((long long)b * p.K + k) * n * n;
-    for (int e = tid; e < n * n; e += nth) E[e] = cur[(e % n) + LD * (e / n)];
-}
-
-__global__ __launch_bounds__(256) void pcl_chain_kernel(const KParams p) {
-    extern __shared__ double lds[];
-    const int n = p.n, LD = p.LD, cols = p.cols;
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const int b = blockIdx.x;
-    const long long xd = (long long)n * cols;
-    double *E = lds, *Xa = E + LD * n, *Xb = Xa + LD * cols;
-    const double *z0 = p.Z + (long long)b * p.z_batch_stride;
-    const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-    double *out = p.xout + (long long)b * (p.K + 1) * xd;
-    for (int e = tid; e < xd; e += nth) {
-        const double v = z0[x_off + e];
-        Xa[(e % n) + LD * (e / n)] = v;
-        out[e] = v;
-    }
-    double *cur = Xa, *oth = Xb;
-    for (int k = 0; k < p.K; ++k) {
-        const double *Ek = p.expm + ((long long)b * p.K + k) * n * n;
-        __syncthreads();  // previous product complete (E and `oth` free)
-        for (int e = tid; e < n * n; e += nth) E[(e % n) + LD * (e / n)] = Ek[e];
-        __syncthreads();
-        gemm_lds<true, false>(E, LD, cur, LD, oth, LD, n, cols, n);
-        __syncthreads();
-        for (int e = tid; e < xd; e += nth) out[(long long)(k + 1) * xd + e] = oth[(e % n) + LD * (e / n)];
-        double *t = cur;
-        cur = oth;
-        oth = t;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// DerivativeIntegrator rows  x_{k+1} - x_k - dt_k * dx_k  and the time-consistency row  t_{k+1} - t_k - dt_k
-// (dx_off < 0: dx == 1).  Trivially sparse; one thread per (b, k, r).  Values per (b,k): [-1 (dim) | +1 (dim) |
-// -dt_k (dim, absent for time consistency) | -dx_k[r] (dim)].
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pcl_deriv_kernel(const double *__restrict__ Z, double *__restrict__ delta,
-                                                        double *__restrict__ vals, int K, int z_dim, int x_off, int dx_off,
-                                                        int dim, int dt_off, long long z_batch_stride, long long total) {
-    const int nseg = dx_off >= 0 ? 4 : 3;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int r = (int)(e % dim);
-        const long long bk = e / dim;
-        const int k = (int)(bk % K);
-        const long long b = bk / K;
-        const double *zk = Z + b * z_batch_stride + (long long)k * z_dim;
-        const double h = zk[dt_off];
-        const double dx = dx_off >= 0 ? zk[dx_off + r] : 1.0;
-        if (delta) delta[e] = zk[z_dim + x_off + r] - zk[x_off + r] - h * dx;
-        if (vals) {
-            double *v = vals + bk * (long long)nseg * dim;
-            v[r] = -1.0;
-            v[dim + r] = 1.0;
-            if (dx_off >= 0) {
-                v[2 * dim + r] = -h;
-                v[3 * dim + r] = -dx;
-            } else {
-                v[2 * dim + r] = -1.0;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Terminal unitary infidelity  Q * |1 - |tr(U_goal' U_N)|^2 / d^2|  and its gradient w.r.t. the terminal iso-vec
-// (reference: src/control/objectives.jl:330-356).  One workgroup per member / seed.
-// With X = [Re U; Im U] (n x d, column c at x[c*n ..]) and the goal stored the same way:
-//   t = tr(Ug' U) = sum (gr*ur + gi*ui) + i sum (gr*ui - gi*ur);  F = |t|^2 / d^2
-//   dF/dur = 2 (tr*gr - ti*gi) / d^2 ,  dF/dui = 2 (tr*gi + ti*gr) / d^2
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pcl_infidelity_kernel(const double *__restrict__ Z, const double *__restrict__ goal,
-                                                             const int *__restrict__ x_offs, double *__restrict__ value,
-                                                             double *__restrict__ grad, double Q, int d, int N, int z_dim,
-                                                             long long z_batch_stride) {
-    __shared__ double red[2][8];
-    const int n = 2 * d, b = blockIdx.x, tid = threadIdx.x;
-    const double *x = Z + (long long)b * z_batch_stride + (long long)(N - 1) * z_dim + x_offs[z_batch_stride ? 0 : b];
-    double tr = 0.0, ti = 0.0;
-    for (int e = tid; e < d * d; e += 256) {
-        const int c = e / d, i = e - c * d;
-        const double ur = x[c * n + i], ui = x[c * n + d + i], gr = goal[c * n + i], gi = goal[c * n + d + i];
-        tr += gr * ur + gi * ui;
-        ti += gr * ui - gi * ur;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        tr += __shfl_down(tr, off, 64);
-        ti += __shfl_down(ti, off, 64);
-    }
-    if ((tid & 63) == 0) {
-        red[0][tid >> 6] = tr;
-        red[1][tid >> 6] = ti;
-    }
-    __syncthreads();
-    tr = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    ti = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    const double inv = 1.0 / ((double)d * d);
-    const double F = (tr * tr + ti * ti) * inv;
-    const double sgn = (1.0 - F >= 0.0) ? 1.0 : -1.0;
-    if (tid == 0 && value) value[b] = Q * fabs(1.0 - F);
-    if (grad) {
-        double *g = grad + (long long)b * n * d;
-        for (int e = tid; e < d * d; e += 256) {
-            const int c = e / d, i = e - c * d;
-            const double gr = goal[c * n + i], gi = goal[c * n + d + i];
-            g[c * n + i] = -sgn * Q * 2.0 * (tr * gr - ti * gi) * inv;
-            g[c * n + d + i] = -sgn * Q * 2.0 * (tr * gi + ti * gr) * inv;
-        }
-    }
-}
+#include "pcl_device_common.hpp"
+#include "pcl_kernels_reference.hpp"
+#include "pcl_kernels_fused_v2.hpp"
+#include "pcl_kernel_fused_v3.hpp"
+#include "pcl_kernels_hessian.hpp"
+#include "pcl_kernels_misc.hpp"
 
 // ------------------------------------------------------------------------------------------
 // Host side
