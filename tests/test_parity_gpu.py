@@ -901,3 +901,50 @@ def test_multi_ket_integrator():
     for i in range(Kk):
         close(hv[i * hper : (i + 1) * hper], po.pade4_hessian_values(Z, mu[i * per_d : (i + 1) * per_d].reshape(lay.K, -1), lay, G0, Gj, x_off=i * n), 1e-10)
     B.close()
+
+
+@pytest.mark.parametrize("d,m,sparse", [(26, 3, False), (23, 6, True), (12, 3, False), (32, 2, True), (27, 6, True)])
+def test_work_splits_on_general_shapes(d, m, sparse):
+    """The work splits of kernel 3 on shapes that take the run-time-shape instances (general real generators, dense-ish
+    or 2-per-row drives, per-trajectory batches, `specialize` off for config 3's shape): round-robin slices, contiguous
+    ranges with both roles per workgroup, role split (where the eight-wave matrix role fits LDS) -- all against the C
+    oracle and bitwise equal to each other."""
+    rng = np.random.default_rng(7 * d + m)
+    Bn, N = 2, 4
+    lay, G0, Gj, _ = _random_case(d, m, N, rng)
+    if sparse:  # two entries per row: the register-resident ELL path
+        n = 2 * d
+        Gj = np.zeros((m, n, n))
+        for l in range(m):
+            for i in range(n):
+                Gj[l, i, rng.choice(n, 2, replace=False)] = rng.standard_normal(2)
+    Zs = []
+    for _ in range(Bn):
+        Z = rng.standard_normal((N, lay.z_dim))
+        Z[:, lay.dt_off] = 0.05 + 0.1 * rng.random(N)
+        Zs.append(Z)
+    c = make_ctx(lay, G0, Gj, batch=Bn, batch_mode=pa._lib.PCL_BATCH_TRAJ)
+    refs = [ref_lib.eval_jac(Z, lay, G0, Gj) for Z in Zs]
+    d_ref = np.concatenate([r[0].reshape(-1) for r in refs])
+    j_ref = np.concatenate([r[1].reshape(-1) for r in refs])
+    c.set_option("kernel_version", 3)
+    c.set_option("specialize", 0)
+    c.set_option("contiguous", 0)
+    d0, v0 = c.eval_jac(np.stack(Zs))
+    if d == 32:
+        assert c.get_option("last_kernel") // 10 == 2  # double-buffered tiles of kernel 3 do not fit: fallback
+        c.close()
+        return
+    assert c.get_option("last_kernel") == 30
+    close(d0, d_ref, 1e-11)
+    close(v0, j_ref, 1e-11)
+    c.set_option("contiguous", 1)
+    for grid, ns in ((0, 0), (5, 0), (0, 128), (0, 100), (9, 4), (256, 255)):
+        c.set_option("grid", grid)
+        c.set_option("stream_workgroups", ns)
+        d1, v1 = c.eval_jac(np.stack(Zs))
+        assert c.get_option("last_kernel") == 30
+        fits = 2 * (16 + 3 * max(1, min(d, 16 // (2 + m)))) <= 2 * d
+        assert (c.get_option("last_stream_workgroups") > 0) == (ns > 0 and fits), (ns, fits)
+        assert np.array_equal(d1, d0) and np.array_equal(v1, v0), (grid, ns)
+    c.close()
