@@ -72,16 +72,19 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     // matrix waves only build G, G^2), workgroups [n_stream, grid) do the column work of ALL columns (their stream waves
     // idle).  The store stream is memory-side bound and half the CUs sustain it; on a CU of its own it is not slowed
     // by the matrix waves' instructions and memory operations.
-    const bool stream_role = p.n_stream > 0 && (int)blockIdx.x < p.n_stream;
-    const bool matrix_role = p.n_stream > 0 && !stream_role;
+    // all_matrix (compact Jacobian: one copy of the blocks per interval, nothing to stream): every workgroup takes the
+    // matrix role; the workgroup whose range holds an interval's column 0 also writes the interval's two unique blocks.
+    const bool stream_role = !p.all_matrix && p.n_stream > 0 && (int)blockIdx.x < p.n_stream;
+    const bool matrix_role = p.all_matrix || (p.n_stream > 0 && !stream_role);
     // stream role, optional: pieces of p.snc columns dealt round-robin to the stream workgroups (at any moment they then
     // write one window of ~n_stream/S consecutive intervals instead of n_stream far-apart ranges)
     const bool srr = stream_role && p.snc > 0;
     const int sS = srr ? (d + p.snc - 1) / p.snc : 1;
     if (p.contig && !srr) {
         const long long tot = (long long)p.batch * p.K * d;
-        const long long widx = matrix_role ? (long long)blockIdx.x - p.n_stream : (long long)blockIdx.x;
-        const long long wcnt = p.n_stream > 0 ? (stream_role ? (long long)p.n_stream : (long long)gridDim.x - p.n_stream) : (long long)gridDim.x;
+        const long long widx = (matrix_role && !p.all_matrix) ? (long long)blockIdx.x - p.n_stream : (long long)blockIdx.x;
+        const long long wcnt = (p.n_stream > 0 && !p.all_matrix) ? (stream_role ? (long long)p.n_stream : (long long)gridDim.x - p.n_stream)
+                                                                   : (long long)gridDim.x;
         g_lo = tot * widx / wcnt;
         g_hi = tot * (widx + 1) / wcnt;
         n_my = g_hi > g_lo ? (int)((g_hi - 1) / d - g_lo / d) + 1 : 0;
@@ -313,6 +316,17 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                 decode(it + 1, c02, nce2, k2, b2);
                 const double *zk2 = p.Z + (long long)b2 * p.z_batch_stride + (long long)k2 * p.z_dim;
                 pf_u = zk2[lane < m ? p.u_off + lane : p.dt_off];
+            }
+            if (p.all_matrix && p.compact && c0 == 0 && !(p.ablate & 2)) {  // the interval's unique -B^+ / B^- blocks
+                const int half = nn >> 1;
+                for (int q = tid; q < half; q += 512) {
+                    const int pos = 2 * q, i = pos % n, j = pos / n;
+                    const double g0 = G[i + LD * j], g1 = G[i + 1 + LD * j];
+                    const double h0 = G2[i + LD * j], h1 = G2[i + 1 + LD * j];
+                    const double e0 = ((i == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((i + 1 == j) ? 1.0 : 0.0) + c2 * h1;
+                    store2(jb + pos, -(e0 + c1 * g0), -(e1 + c1 * g1), p.nt);
+                    store2(jb + blk + pos, e0 - c1 * g0, e1 - c1 * g1, p.nt);
+                }
             }
             int tch = 0;
             for (int ch = wave; ch < nchunk && !(p.ablate & 4) && !stream_role; ch += nmw, ++tch) {

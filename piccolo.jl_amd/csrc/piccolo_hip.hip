@@ -708,11 +708,12 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     const bool want_jac = jac != nullptr;
     if (ctx->desc.pade_order != 4 || ctx->opt_general) return launch_pade_general(ctx, p, want_jac);
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
-    if (want_jac && !compact && (ctx->opt_kernel == 3 || ctx->opt_kernel == 0) && ctx->opt_use_mfma != 0 && v3_supported(ctx) &&
-        ctx->cols == ctx->desc.d) {  // the default whenever its LDS budget fits (else kernels 2 / 4 below)
+    if (want_jac && (!compact || v3_role_split_fits(ctx)) && (ctx->opt_kernel == 3 || ctx->opt_kernel == 0) && ctx->opt_use_mfma != 0 &&
+        v3_supported(ctx) && ctx->cols == ctx->desc.d) {  // the default whenever its LDS budget fits (else kernels 2 / 4 below)
         // default: contiguous column ranges (one item per interval touched); an explicit cols_per_slice or
         // contiguous = 0 selects the round-robin slices
-        p.contig = v3_contiguous(ctx) ? 1 : 0;
+        p.contig = (compact || v3_contiguous(ctx)) ? 1 : 0;  // compact: contiguous ranges, every workgroup in the matrix role
+        p.all_matrix = compact ? 1 : 0;
         p.flat = ctx->opt_flat ? 1 : 0;
         p.snc = (int)std::max<int64_t>(0, std::min<int64_t>(ctx->opt_snc, p.d));
         p.nc = p.contig ? p.d : choose_cols_v3(ctx);
@@ -738,7 +739,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         const long long units = p.contig ? (long long)p.batch * p.K * p.d : items;  // what the grid is cut into
         const long long g3 = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, units) : std::min<long long>(units, std::max(ctx->n_cu, 1));
         p.n_stream = 0;
-        if (p.contig && g3 >= 2 && v3_role_split_fits(ctx)) {
+        if (p.contig && !p.all_matrix && g3 >= 2 && v3_role_split_fits(ctx)) {
             const long long want = ctx->opt_stream_wg < 0 ? g3 / 2 : ctx->opt_stream_wg;  // auto: half the workgroups stream
             if (want > 0) p.n_stream = (int)std::min<long long>(want, g3 - 1);
         }
