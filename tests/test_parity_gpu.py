@@ -948,3 +948,50 @@ def test_work_splits_on_general_shapes(d, m, sparse):
         assert (c.get_option("last_stream_workgroups") > 0) == (ns > 0 and fits), (ns, fits)
         assert np.array_equal(d1, d0) and np.array_equal(v1, v0), (grid, ns)
     c.close()
+
+
+def test_config4_share_full_size_ensemble():
+    """BASELINE config 4's per-GPU share at reduced width: 4 of the 64 perturbed-drift members of the 3-transmon problem in
+    ONE trajectory buffer (layout [U1..U4, dt, t, u, du, ddu], SURVEY 8(d): H_drift_i = H_drift + eps_i sum_q a_q' a_q 2 pi,
+    eps_i ~ U(-1e-3, 1e-3), default_rng(2000 + i)), N = 100, through the path `auto` picks at this size (kernel 3, role split,
+    per-member drift tiles) against the C oracle per member."""
+    base = po.config_system(3)
+    d, m, M, N = base.levels, base.n_drives, 4, 100
+    xd = 2 * d * d
+    a = po.annihilate(3)
+    num = sum(po.lift_operator(a.conj().T @ a, q, [3, 3, 3]) for q in (1, 2, 3))
+    osys = []
+    for i in range(M):
+        eps = np.random.default_rng(2000 + i).uniform(-1e-3, 1e-3)
+        osys.append(po.System(base.H_drift + eps * 2 * np.pi * num, base.H_drives, base.drive_bounds))
+    Z1, lay1 = po.synthetic_trajectory(base, N, seed=20260929 + 4)
+    lay = po.Layout(d=d, m=m, N=N, z_dim=M * xd + 2 + 3 * m, x_off=0, u_off=M * xd + 2, dt_off=M * xd)
+    Z = np.zeros((N, lay.z_dim))
+    rng = np.random.default_rng(44)
+    for i in range(M):
+        Z[:, i * xd : (i + 1) * xd] = Z1[:, :xd] + 1e-3 * rng.standard_normal((N, xd))
+    Z[:, M * xd :] = Z1[:, xd:]
+    comps = {}
+    for i in range(M):
+        comps["Ũ⃗%d" % (i + 1)] = Z[:, i * xd : (i + 1) * xd].T
+    o = M * xd
+    comps["Δt"], comps["t"] = Z[:, o][None], Z[:, o + 1][None]
+    comps["u"], comps["du"], comps["ddu"] = Z[:, o + 2 : o + 2 + m].T, Z[:, o + 2 + m : o + 2 + 2 * m].T, Z[:, o + 2 + 2 * m :].T
+    traj = pa.NamedTrajectory(comps, controls=("ddu", "Δt"), timestep="Δt")
+    assert np.array_equal(traj.datavec, Z.reshape(-1))
+    psys = [pa.QuantumSystem(s.H_drift, s.H_drives, [b[1] for b in s.drive_bounds]) for s in osys]
+    B = pa.BilinearIntegrator(psys, traj)
+    delta, vals = B.ctx.eval_jac(traj.datavec)
+    assert B.ctx.get_option("last_kernel") == 31 and B.ctx.get_option("last_stream_workgroups") == B.ctx.get_option("n_cu") // 2
+    per_d, per_j = xd * lay.K, po.jac_nnz_per_interval(lay) * lay.K
+    for i, s in enumerate(osys):
+        d_ref, j_ref = ref_lib.eval_jac(Z, lay, s.G_drift, np.array(s.G_drives), x_off=i * xd)
+        close(delta[i * per_d : (i + 1) * per_d], d_ref)
+        close(vals[i * per_j : (i + 1) * per_j], j_ref)
+    mu = np.random.default_rng(5).standard_normal(B.dim)
+    hv = B.ctx.hess(traj.datavec, mu)
+    hper = po.hess_nnz_per_interval(lay) * lay.K
+    for i, s in enumerate(osys):
+        h_ref = ref_lib.hess(Z, mu[i * per_d : (i + 1) * per_d].reshape(lay.K, -1), lay, s.G_drift, np.array(s.G_drives), x_off=i * xd)
+        close(hv[i * hper : (i + 1) * hper], h_ref, 1e-10)
+    B.close()
