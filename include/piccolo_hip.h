@@ -82,6 +82,7 @@ typedef enum pcl_status {
 /* batch_mode */
 #define PCL_BATCH_MEMBERS 0 /* ONE trajectory buffer; member b owns state columns at x_offs[b]; shared u, dt
                                (SamplingTrajectory: sampling_trajectory.jl:207-237) */
+#define PCL_STATE_VECTOR (-1) /* pcl_desc.state_cols: see there */
 #define PCL_BATCH_TRAJ 1    /* batch independent trajectory buffers (multistart seeds), Z_b = Z + b*z_dim*N;
                                x_offs[0] is the state offset in each */
 
@@ -100,7 +101,11 @@ typedef struct pcl_desc {
     int32_t index_base;  /* 0 (C/Python) or 1 (Julia/MOI) for the emitted structure */
     int32_t per_member_G0; /* 0: one G0 for all members; 1: G0 holds batch matrices (per-member H_drift) */
     int32_t state_cols;  /* columns of the state matrix X (n x state_cols): 0 or d = unitary (Utilde, x_dim = 2 d^2),
-                            1 = ket (psitilde = [Re psi; Im psi], x_dim = 2d; KetTrajectory, integrators.jl:58-74) */
+                            1 = ket (psitilde = [Re psi; Im psi], x_dim = 2d; KetTrajectory, integrators.jl:58-74);
+                            PCL_STATE_VECTOR: the state is a real vector of length d acted on by a general real d x d
+                            generator (n = d, odd allowed, d <= 64) -- the compact density vector rhotilde with d = levels^2
+                            and the compact Lindbladian generators (DensityTrajectory, integrators.jl:82-95,
+                            open_quantum_systems.jl:541-588).  Runs the general-order kernel at every pade_order. */
     int64_t global_dim;  /* traj.global_dim (trailing globals in the variable vector; only shifts nothing, kept for
                             the column count reported by pcl_constraint_dim) */
     const double *G0;      /* n x n column-major (x batch if per_member_G0) : G_drift = iso(-i H_drift) */

@@ -153,6 +153,101 @@ def ad_vec(H, anti=False):
 
 
 # --------------------------------------------------------------------------- #
+# Open systems: compact density isomorphism and compact Lindbladian generators
+# [REF isomorphisms.jl:163-330,390-396; open_quantum_systems.jl:541-588]
+# --------------------------------------------------------------------------- #
+
+
+def density_to_iso_vec(rho):
+    """ket_to_iso(vec(rho)) [REF isomorphisms.jl:150-160]."""
+    return ket_to_iso(np.asarray(rho, complex).T.reshape(-1))
+
+
+def density_to_compact_iso(rho):
+    """n^2 reals of a Hermitian rho: Re of the upper triangle (column-major), then Im of the strict upper triangle
+    (column-major) [REF isomorphisms.jl:176-192]."""
+    rho = np.asarray(rho, complex)
+    n = rho.shape[0]
+    x = [rho[j, k].real for k in range(n) for j in range(k + 1)]
+    x += [rho[j, k].imag for k in range(1, n) for j in range(k)]
+    return np.array(x)
+
+
+def compact_iso_to_density(x):
+    """[REF isomorphisms.jl:201-222]"""
+    x = np.asarray(x, float)
+    n = int(round(np.sqrt(x.size)))
+    rho = np.zeros((n, n), complex)
+    idx = 0
+    for k in range(n):
+        for j in range(k + 1):
+            rho[j, k] = x[idx]
+            if j != k:
+                rho[k, j] = x[idx]
+            idx += 1
+    for k in range(1, n):
+        for j in range(k):
+            rho[j, k] += 1j * x[idx]
+            rho[k, j] -= 1j * x[idx]
+            idx += 1
+    return rho
+
+
+def density_lift_matrix(n):
+    """L (2n^2 x n^2): compact -> iso_vec [REF isomorphisms.jl:236-276]."""
+    L = np.zeros((2 * n * n, n * n))
+    col = 0
+    for k in range(n):
+        for j in range(k + 1):
+            L[k * n + j, col] = 1.0
+            if j != k:
+                L[j * n + k, col] = 1.0
+            col += 1
+    for k in range(1, n):
+        for j in range(k):
+            L[n * n + k * n + j, col] = 1.0
+            L[n * n + j * n + k, col] = -1.0
+            col += 1
+    return L
+
+
+def density_projection_matrix(n):
+    """P (n^2 x 2n^2): iso_vec -> compact, P L = I [REF isomorphisms.jl:294-324]."""
+    P = np.zeros((n * n, 2 * n * n))
+    row = 0
+    for k in range(n):
+        for j in range(k + 1):
+            P[row, k * n + j] = 1.0
+            row += 1
+    for k in range(1, n):
+        for j in range(k):
+            P[row, n * n + k * n + j] = 1.0
+            row += 1
+    return P
+
+
+def iso_D(Lop):
+    """iso(conj(L) (x) L - 1/2 ad_vec(L'L, anti)) [REF isomorphisms.jl:394-396]."""
+    Lop = np.asarray(Lop, complex)
+    return iso(np.kron(Lop.conj(), Lop) - 0.5 * ad_vec(Lop.conj().T @ Lop, anti=True))
+
+
+def compact_lindbladian_generators(H_drift, H_drives, dissipators=()):
+    """(Gc_drift, [Gc_drive_j]) with Gc = P G(ad_vec(H)) L (+ sum of P iso_D(L_j) L for constant-rate dissipators
+    folded into the drift) [REF open_quantum_systems.jl:541-588]: d/dt x = (Gc_drift + sum u_j Gc_j) x for the compact
+    density vector x."""
+    H_drift = np.asarray(H_drift, complex)
+    n = H_drift.shape[0]
+    P, L = density_projection_matrix(n), density_lift_matrix(n)
+    drift = P @ G_of_H(ad_vec(H_drift)) @ L
+    for Lop in dissipators:
+        drift = drift + P @ iso_D(Lop) @ L
+    drives = [P @ G_of_H(ad_vec(np.asarray(H, complex))) @ L for H in H_drives]
+    return drift, drives
+
+
+
+# --------------------------------------------------------------------------- #
 # Operators and systems
 # --------------------------------------------------------------------------- #
 
@@ -321,10 +416,12 @@ class Layout:
     u_off: int
     dt_off: int
     cols: Optional[int] = None  # state columns: None/d = unitary (X is n x d), 1 = ket [REF integrators.jl:58-74]
+    gen: Optional[int] = None  # generator dimension when it is not 2d: compact density vectors, gen = levels^2, one
+    #                            column [REF integrators.jl:82-95] (then `d` is not used)
 
     @property
     def n(self):
-        return 2 * self.d
+        return 2 * self.d if self.gen is None else self.gen
 
     @property
     def C(self):
@@ -332,7 +429,7 @@ class Layout:
 
     @property
     def x_dim(self):
-        return 2 * self.d * self.C
+        return self.n * self.C
 
     @property
     def K(self):

@@ -24,15 +24,18 @@ from .quantum import (
     PAULIS,
     CompositeQuantumSystem,
     MultiTransmonSystem,
+    OpenQuantumSystem,
     QuantumSystem,
     TransmonDipoleCoupling,
     TransmonSystem,
     annihilate,
+    compact_iso_to_density,
+    density_to_compact_iso,
     iso,
     iso_vec_to_operator,
     lift_operator,
     operator_to_iso_vec,
 )
-from .trajectory import NamedTrajectory, add_control_derivatives, ket_trajectory, sampling_trajectory, unitary_trajectory
+from .trajectory import NamedTrajectory, add_control_derivatives, density_trajectory, ket_trajectory, sampling_trajectory, unitary_trajectory
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

@@ -17,6 +17,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 PCL_OK = 0
 PCL_EINVAL, PCL_ENOMEM, PCL_EHIP, PCL_ERCCL, PCL_ESHAPE, PCL_ENOTIMPL = -1, -2, -3, -4, -5, -6
 PCL_BATCH_MEMBERS, PCL_BATCH_TRAJ = 0, 1
+PCL_STATE_VECTOR = -1  # pcl_desc.state_cols: general real d x d generator on one real column (compact density vectors)
 _STATUS_NAMES = {0: "PCL_OK", -1: "PCL_EINVAL", -2: "PCL_ENOMEM", -3: "PCL_EHIP", -4: "PCL_ERCCL", -5: "PCL_ESHAPE", -6: "PCL_ENOTIMPL"}
 
 # every symbol include/piccolo_hip.h declares (tests check the .so exports all of them)

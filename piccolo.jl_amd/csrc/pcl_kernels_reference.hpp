@@ -263,15 +263,28 @@ __global__ __launch_bounds__(256) void pcl_pade_kernel(const KParams p) {
         }
     }
     // ---- blocks: B^{+-} = sum_j c_j (+-h)^j G^j ------------------------------------------------------------------
+    // each thread owns the flat column-major positions (2q', 2q'+1), q' = tid + 256 r; for an odd n (compact density
+    // vectors) the two positions may lie in different columns and the stores are scalar (blocks are not 16-byte aligned)
     {
-        const int half = (n * n) >> 1;
-        double bp[PCL_NSP][2], bm[PCL_NSP][2];  // pairs (2q', 2q'+1), q' = tid + 256 r
+        const int nn_ = n * n, half = (nn_ + 1) >> 1;
+        const bool even = !(n & 1);
+        double bp[PCL_NSP][2], bm[PCL_NSP][2];
+        int o0_[PCL_NSP], o1_[PCL_NSP];  // LDS offsets of the two positions (-1: none)
 #pragma unroll
         for (int r = 0; r < PCL_NSP; ++r) {
             const int pos = 2 * (tid + 256 * r);
-            const int i = pos % n, jj = pos / n;
-            bp[r][0] = bm[r][0] = (i == jj) ? 1.0 : 0.0;
-            bp[r][1] = bm[r][1] = (i + 1 == jj) ? 1.0 : 0.0;
+            o0_[r] = o1_[r] = -1;
+            bp[r][0] = bm[r][0] = bp[r][1] = bm[r][1] = 0.0;
+            if (pos < nn_) {
+                const int i = pos % n, jj = pos / n;
+                o0_[r] = i + LD * jj;
+                bp[r][0] = bm[r][0] = (i == jj) ? 1.0 : 0.0;
+            }
+            if (pos + 1 < nn_) {
+                const int i = (pos + 1) % n, jj = (pos + 1) / n;
+                o1_[r] = i + LD * jj;
+                bp[r][1] = bm[r][1] = (i == jj) ? 1.0 : 0.0;
+            }
         }
         const double *Pc = G;
         double hp = 1.0, hm = 1.0;
@@ -280,16 +293,11 @@ __global__ __launch_bounds__(256) void pcl_pade_kernel(const KParams p) {
             hm *= -h;
 #pragma unroll
             for (int r = 0; r < PCL_NSP; ++r) {
-                const int qq = tid + 256 * r;
-                if (qq < half) {
-                    const int pos = 2 * qq;
-                    const int i = pos % n, jj = pos / n;
-                    const double v0 = Pc[i + LD * jj], v1 = Pc[i + 1 + LD * jj];
-                    bp[r][0] += p.pc[j] * hp * v0;
-                    bp[r][1] += p.pc[j] * hp * v1;
-                    bm[r][0] += p.pc[j] * hm * v0;
-                    bm[r][1] += p.pc[j] * hm * v1;
-                }
+                const double v0 = o0_[r] >= 0 ? Pc[o0_[r]] : 0.0, v1 = o1_[r] >= 0 ? Pc[o1_[r]] : 0.0;
+                bp[r][0] += p.pc[j] * hp * v0;
+                bp[r][1] += p.pc[j] * hp * v1;
+                bm[r][0] += p.pc[j] * hm * v0;
+                bm[r][1] += p.pc[j] * hm * v1;
             }
             if (j < q) {
                 double *Pn = (Pc == Pa) ? Pb : Pa;
@@ -308,9 +316,18 @@ __global__ __launch_bounds__(256) void pcl_pade_kernel(const KParams p) {
             const int qq = tid + 256 * r;
             if (qq < half)
                 for (int c = cbeg; c < cend; ++c) {
-                    double *o0 = jb + (long long)c * n * n + 2 * qq;
-                    store2(o0, -bp[r][0], -bp[r][1], p.nt);
-                    store2(o0 + blk, bm[r][0], bm[r][1], p.nt);
+                    double *o0 = jb + (long long)c * nn_ + 2 * qq;
+                    if (even) {
+                        store2(o0, -bp[r][0], -bp[r][1], p.nt);
+                        store2(o0 + blk, bm[r][0], bm[r][1], p.nt);
+                    } else {
+                        o0[0] = -bp[r][0];
+                        o0[blk] = bm[r][0];
+                        if (o1_[r] >= 0) {
+                            o0[1] = -bp[r][1];
+                            o0[blk + 1] = bm[r][1];
+                        }
+                    }
                 }
         }
     }

@@ -41,6 +41,7 @@ struct pcl_ctx {
     pcl_desc desc;
     int n, K;
     int cols;  // state columns (d for unitaries, 1 for kets)
+    int vec = 0;  // PCL_STATE_VECTOR: n = desc.d (general generator on one column; general-order kernel only)
     long long x_dim;
     std::vector<int32_t> x_offs;
     int device;
@@ -145,11 +146,13 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     if (dsc->struct_size != (int32_t)sizeof(pcl_desc))
         return fail(nullptr, PCL_EINVAL, "pcl_create: desc.struct_size=%d, library expects %zu (ABI mismatch)",
                     dsc->struct_size, sizeof(pcl_desc));
-    const int d = dsc->d, m = dsc->n_drives, n = 2 * d;
+    const bool vec = dsc->state_cols == PCL_STATE_VECTOR;  // general real d x d generator on one real column
+    const int d = dsc->d, m = dsc->n_drives, n = vec ? d : 2 * d;
     if (d < 1 || m < 0 || dsc->N < 2 || dsc->batch < 1)
         return fail(nullptr, PCL_EINVAL, "pcl_create: need d>=1, n_drives>=0, N>=2, batch>=1 (got d=%d m=%d N=%d batch=%d)", d,
                     m, dsc->N, dsc->batch);
-    if (d > PCL_MAX_D) return fail(nullptr, PCL_ESHAPE, "pcl_create: d=%d exceeds PCL_MAX_D=%d (LDS-resident tiles)", d, PCL_MAX_D);
+    if (n > 2 * PCL_MAX_D)
+        return fail(nullptr, PCL_ESHAPE, "pcl_create: generator dimension %d exceeds %d (LDS-resident tiles; d <= %d)", n, 2 * PCL_MAX_D, PCL_MAX_D);
     if (m > 24) return fail(nullptr, PCL_ESHAPE, "pcl_create: n_drives=%d exceeds 24", m);
     if (dsc->pade_order != 2 && dsc->pade_order != 4 && dsc->pade_order != 6 && dsc->pade_order != 8 && dsc->pade_order != 10)
         return fail(nullptr, PCL_ENOTIMPL, "pcl_create: pade_order=%d; diagonal Pade orders 2, 4, 6, 8, 10 are implemented", dsc->pade_order);
@@ -157,9 +160,10 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     if (dsc->batch_mode != PCL_BATCH_MEMBERS && dsc->batch_mode != PCL_BATCH_TRAJ)
         return fail(nullptr, PCL_EINVAL, "pcl_create: unknown batch_mode %d", dsc->batch_mode);
     if (!dsc->G0 || (m > 0 && !dsc->Gj) || !dsc->x_offs) return fail(nullptr, PCL_EINVAL, "pcl_create: G0/Gj/x_offs must be non-NULL");
-    const int cols = dsc->state_cols > 0 ? dsc->state_cols : d;
+    if (dsc->state_cols < 0 && !vec) return fail(nullptr, PCL_EINVAL, "pcl_create: state_cols=%d", dsc->state_cols);
+    const int cols = vec ? 1 : (dsc->state_cols > 0 ? dsc->state_cols : d);
     if (cols > d) return fail(nullptr, PCL_EINVAL, "pcl_create: state_cols=%d exceeds d=%d", cols, d);
-    const long long x_dim = 2LL * d * cols;
+    const long long x_dim = (long long)n * cols;
     const int n_off = dsc->batch_mode == PCL_BATCH_MEMBERS ? dsc->batch : 1;
     for (int i = 0; i < n_off; ++i)
         if (dsc->x_offs[i] < 0 || dsc->x_offs[i] + x_dim > dsc->z_dim)
@@ -181,6 +185,7 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     ctx->K = dsc->N - 1;
     ctx->x_dim = x_dim;
     ctx->cols = cols;
+    ctx->vec = vec ? 1 : 0;
     ctx->x_offs.assign(dsc->x_offs, dsc->x_offs + n_off);
     ctx->desc.x_offs = nullptr;
     ctx->desc.G0 = ctx->desc.Gj = nullptr;
@@ -323,9 +328,11 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
             }
         return true;
     };
-    bool iso = true;
-    for (int bb = 0; bb < (dsc->per_member_G0 ? dsc->batch : 1); ++bb) iso = iso && is_iso(dsc->G0 + bb * nn);
-    for (int l = 0; l < m; ++l) iso = iso && is_iso(dsc->Gj + l * nn);
+    bool iso = !vec;  // the iso(.) block structure only exists for n = 2d
+    if (iso)
+        for (int bb = 0; bb < (dsc->per_member_G0 ? dsc->batch : 1); ++bb) iso = iso && is_iso(dsc->G0 + bb * nn);
+    if (iso)
+        for (int l = 0; l < m; ++l) iso = iso && is_iso(dsc->Gj + l * nn);
     ctx->iso = iso ? 1 : 0;
     std::vector<double> g0(dsc->G0, dsc->G0 + nn * (dsc->per_member_G0 ? dsc->batch : 1));
     CREATE_TRY(upload(ctx, &ctx->dG0, g0));
@@ -494,7 +501,7 @@ extern "C" int pcl_hess_structure_i64(const pcl_ctx *ctx, int64_t *rows, int64_t
 // --- launch helpers -------------------------------------------------------------------------
 // LD = (n rounded up to 4) + 2  ==  2*odd: conflict-free ds_read_b64 of the MFMA b operand
 // (16 columns x 2 k-rows per half-wave land on 32 distinct 8-byte bank pairs).
-static int lds_ld(int d) { return ((2 * d + 3) & ~3) + 2; }
+static int lds_ld(int n) { return ((n + 3) & ~3) + 2; }  // n = generator dimension
 
 static void fill_params(const pcl_ctx *ctx, KParams &p) {
     memset(&p, 0, sizeof p);
@@ -535,7 +542,7 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.u_off = D.u_off;
     p.dt_off = D.dt_off;
     p.batch = D.batch;
-    p.LD = lds_ld(D.d);
+    p.LD = lds_ld(ctx->n);
     p.nt = (int)ctx->opt_nt;
     p.ablate = (int)ctx->opt_ablate;
     p.dbg = ctx->ddbg;
@@ -609,7 +616,7 @@ static size_t fused3_lds_bytes(const pcl_ctx *ctx, const KParams &p, bool tab) {
 // 2-column chunk, ~4 us for G(u) + G^2, stream at ~0.85 of the CU's fair HBM share; other shapes scale by MFMA count.
 // Role split needs the chunk buffers of matrix waves 4..7 inside the second halves of the G / G^2 double buffers.
 static bool v3_role_split_fits(const pcl_ctx *ctx) {
-    const int ncw = v3_ncw(ctx, ctx->desc.d), LD = lds_ld(ctx->desc.d);
+    const int ncw = v3_ncw(ctx, ctx->desc.d), LD = lds_ld(ctx->n);
     return 2 * (size_t)LD * (16 + 3 * ncw) <= (size_t)LD * ctx->n;
 }
 // Work split of kernel 3: contiguous column ranges (+ role split) pay off once every CU has a few intervals' worth of
@@ -706,10 +713,10 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     p.compact = compact ? 1 : 0;
     p.jac_per = compact ? jac_per_compact(ctx) : jac_per_full(ctx);
     const bool want_jac = jac != nullptr;
-    if (ctx->desc.pade_order != 4 || ctx->opt_general) return launch_pade_general(ctx, p, want_jac);
+    if (ctx->desc.pade_order != 4 || ctx->opt_general || ctx->vec) return launch_pade_general(ctx, p, want_jac);
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
     if (want_jac && (!compact || v3_role_split_fits(ctx)) && (ctx->opt_kernel == 3 || ctx->opt_kernel == 0) && ctx->opt_use_mfma != 0 &&
-        v3_supported(ctx) && ctx->cols == ctx->desc.d) {  // the default whenever its LDS budget fits (else kernels 2 / 4 below)
+        v3_supported(ctx) && !ctx->vec && ctx->cols == ctx->desc.d) {  // the default whenever its LDS budget fits (else kernels 2 / 4 below)
         // default: contiguous column ranges (one item per interval touched); an explicit cols_per_slice or
         // contiguous = 0 selects the round-robin slices
         p.contig = (compact || v3_contiguous(ctx)) ? 1 : 0;  // compact: contiguous ranges, every workgroup in the matrix role
@@ -750,7 +757,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     }
 not_v3:
     const bool v2 = (ctx->opt_kernel == 0 || ctx->opt_kernel >= 2) && ctx->opt_use_mfma != 0;
-    const bool unitary = ctx->cols == ctx->desc.d;  // kernels 3, 4, 5 and the specialised instances assume X is n x d
+    const bool unitary = !ctx->vec && ctx->cols == ctx->desc.d;  // kernels 3, 4, 5 and the specialised instances assume X is n x d
     bool v4 = v2 && ctx->opt_kernel == 4 && want_jac && unitary;
     p.nc = choose_cols_per_slice(ctx, want_jac);
     auto bytes = [&]() { return v2 ? fused2_lds_bytes(p, want_jac, p.ell_lds != 0) : fused_lds_bytes(p, want_jac); };
@@ -849,7 +856,7 @@ static const void *hess_v2_kernel(int m) {
 #define PCL_HESS_EW 2
 static bool hess_v2_supported(const pcl_ctx *ctx) {
     const int m = ctx->desc.n_drives;
-    return m >= 1 && m <= 6 && ctx->ell_w <= PCL_HESS_EW && ctx->ellt_w <= PCL_HESS_EW;
+    return !ctx->vec && m >= 1 && m <= 6 && ctx->ell_w <= PCL_HESS_EW && ctx->ellt_w <= PCL_HESS_EW;
 }
 static size_t hess2_lds_bytes(const KParams &p) {
     const size_t nscal = (size_t)(p.m + 1) * (p.m + 2) / 2;
@@ -1149,7 +1156,7 @@ extern "C" int pcl_infidelity_dev(pcl_ctx *ctx, const double *Z, double Q, doubl
     if (!ctx) return PCL_EINVAL;
     if (!Z || (!value && !grad)) return fail(ctx, PCL_EINVAL, "pcl_infidelity_dev: NULL pointer");
     if (!ctx->dgoal) return fail(ctx, PCL_EINVAL, "pcl_infidelity_dev: call pcl_set_goal first");
-    if (ctx->cols != ctx->desc.d) return fail(ctx, PCL_ENOTIMPL, "pcl_infidelity_dev: unitary (n x d) states only");
+    if (ctx->vec || ctx->cols != ctx->desc.d) return fail(ctx, PCL_ENOTIMPL, "pcl_infidelity_dev: unitary (n x d) states only");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const pcl_desc &D = ctx->desc;
     hipLaunchKernelGGL(pcl_infidelity_kernel, dim3((unsigned)D.batch), dim3(256), 0, ctx->stream, Z, ctx->dgoal, ctx->dxoffs, value, grad, Q,

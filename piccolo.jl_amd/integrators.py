@@ -57,7 +57,7 @@ class _PclContext:
                  global_dim=0, device=0, index_base=0, pade_order=4, state_cols=0):  # fmt: skip
         self._L = _lib.load()
         self._h = None
-        n = 2 * d
+        n = d if state_cols == _lib.PCL_STATE_VECTOR else 2 * d  # PCL_STATE_VECTOR: general d x d generator, one column
         g0 = _colmajor(G0)
         gj = _colmajor(Gj) if m else np.zeros(1)
         if g0.size != n * n * (batch if per_member_G0 else 1):
@@ -279,10 +279,16 @@ class HipPadeIntegrator:
             if nm not in traj.components:
                 raise KeyError("trajectory has no component %r" % (nm,))
         xlen = len(traj.components[x_names[0]])
-        if xlen % n or not (1 <= xlen // n <= d) or any(len(traj.components[nm]) != xlen for nm in x_names):
-            raise ValueError("state components must all have dim n*C with n = %d, 1 <= C <= d (unitary: C = d = %d, ket: C = 1); got %d"
-                             % (n, d, xlen))  # fmt: skip
-        cols = xlen // n
+        vec = n % 2 == 1  # odd generator dimension: a compact density vector (levels^2) under a compact Lindbladian
+        if vec:
+            if xlen != n or any(len(traj.components[nm]) != xlen for nm in x_names):
+                raise ValueError("an odd generator dimension (%d) takes state components of that length; got %d" % (n, xlen))
+            d, cols = n, 1
+        else:
+            if xlen % n or not (1 <= xlen // n <= d) or any(len(traj.components[nm]) != xlen for nm in x_names):
+                raise ValueError("state components must all have dim n*C with n = %d, 1 <= C <= d (unitary: C = d = %d, ket: C = 1); got %d"
+                                 % (n, d, xlen))  # fmt: skip
+            cols = xlen // n
         if m and len(traj.components[u_name]) < m:
             raise ValueError("drive component %r has dim %d < n_drives = %d" % (u_name, len(traj.components[u_name]), m))
         self.x_names = x_names
@@ -295,8 +301,10 @@ class HipPadeIntegrator:
             d=d, m=m, N=traj.N, z_dim=traj.dim, u_off=traj.components[u_name].start,
             dt_off=traj.components[traj.timestep].start, x_offs=[traj.components[nm].start for nm in x_names],
             G0=G_drift, Gj=self.G_drives, batch=len(x_names), batch_mode=PCL_BATCH_MEMBERS, per_member_G0=per_member,
-            global_dim=traj.global_dim, device=device, index_base=index_base, pade_order=pade_order, state_cols=cols,
+            global_dim=traj.global_dim, device=device, index_base=index_base, pade_order=pade_order,
+            state_cols=_lib.PCL_STATE_VECTOR if vec else cols,
         )  # fmt: skip
+        self._state_cols = _lib.PCL_STATE_VECTOR if vec else cols
         self.x_dim = self._ctx.x_dim * len(x_names) if len(x_names) > 1 else self._ctx.x_dim
         self.dim = self._ctx.n_rows
         self._f_ctx = None
@@ -319,7 +327,7 @@ class HipPadeIntegrator:
         if self._f_ctx is None:
             self._f_ctx = _PclContext(d=c.d, m=c.m, N=2, z_dim=c.x_dim + 1 + c.m, u_off=c.x_dim + 1, dt_off=c.x_dim,
                                       x_offs=[0], G0=self.G_drift, Gj=self.G_drives, batch=1,
-                                      batch_mode=PCL_BATCH_MEMBERS, state_cols=c.x_dim // c.n, pade_order=self.pade_order)  # fmt: skip
+                                      batch_mode=PCL_BATCH_MEMBERS, state_cols=self._state_cols, pade_order=self.pade_order)  # fmt: skip
         z = np.zeros((2, c.x_dim + 1 + c.m))
         z[0, : c.x_dim], z[0, c.x_dim], z[0, c.x_dim + 1 :] = x, dt, np.asarray(u)[: c.m]
         z[1, : c.x_dim] = x_next
@@ -422,6 +430,11 @@ def BilinearIntegrator(system, traj, x_name=None, u_name="u", **kw):
         return HipPadeIntegrator(np.array([s.G_drift for s in systems]), Gd[0], traj, names, u_name, **kw)
     if getattr(system, "time_dependent", False):
         raise NotImplementedError("time-dependent systems use TimeDependentBilinearIntegrator (out of scope)")
+    from .quantum import OpenQuantumSystem
+    from .trajectory import DENSITY
+
+    if isinstance(system, OpenQuantumSystem):  # BilinearIntegrator(qtraj::DensityTrajectory, N) [REF integrators.jl:82-95]
+        return HipPadeIntegrator(system.G_drift, system.G_drives_array(), traj, x_name or DENSITY, u_name, **kw)
     return HipPadeIntegrator(system.G_drift, system.G_drives_array(), traj, x_name or STATE, u_name, **kw)
 
 

@@ -222,3 +222,104 @@ def MultiTransmonSystem(omegas, deltas, gs, levels_per_transmon=3, drive_bounds=
         for j in range(i + 1, len(subs) + 1):
             Hc += TransmonDipoleCoupling(gs[i - 1, j - 1], (i, j), lv, lab_frame=lab_frame)
     return CompositeQuantumSystem(Hc, subs)
+
+
+# ---------------------------------------------------------------------------
+# open systems: compact density isomorphism + compact Lindbladian generators
+# ---------------------------------------------------------------------------
+def ad_vec(Hm, anti=False):
+    """I (x) H - (-1)^anti conj(H)' (x) I  [REF isomorphisms.jl:378-381]."""
+    Hm = np.asarray(Hm, _c)
+    Id = np.eye(Hm.shape[0])
+    return np.kron(Id, Hm) - (-1.0) ** int(anti) * np.kron(Hm.T, Id)
+
+
+def density_to_compact_iso(rho):
+    """n^2 reals of a Hermitian rho: Re upper triangle (column-major), then Im strict upper triangle
+    [REF isomorphisms.jl:176-192]."""
+    rho = np.asarray(rho, _c)
+    n = rho.shape[0]
+    return np.array([rho[j, k].real for k in range(n) for j in range(k + 1)] + [rho[j, k].imag for k in range(1, n) for j in range(k)])
+
+
+def compact_iso_to_density(x):
+    """[REF isomorphisms.jl:201-222]"""
+    x = np.asarray(x, float)
+    n = int(round(np.sqrt(x.size)))
+    rho = np.zeros((n, n), _c)
+    iu = [(j, k) for k in range(n) for j in range(k + 1)]
+    for (j, k), v in zip(iu, x[: len(iu)]):
+        rho[j, k] = v
+        rho[k, j] = v
+    for (j, k), v in zip([(j, k) for k in range(1, n) for j in range(k)], x[len(iu) :]):
+        rho[j, k] += 1j * v
+        rho[k, j] -= 1j * v
+    return rho
+
+
+def density_lift_matrix(n):
+    """L (2n^2 x n^2), compact -> iso_vec [REF isomorphisms.jl:236-276]."""
+    L = np.zeros((2 * n * n, n * n))
+    col = 0
+    for k in range(n):
+        for j in range(k + 1):
+            L[k * n + j, col] = 1.0
+            if j != k:
+                L[j * n + k, col] = 1.0
+            col += 1
+    for k in range(1, n):
+        for j in range(k):
+            L[n * n + k * n + j, col] = 1.0
+            L[n * n + j * n + k, col] = -1.0
+            col += 1
+    return L
+
+
+def density_projection_matrix(n):
+    """P (n^2 x 2n^2), iso_vec -> compact; P L = I [REF isomorphisms.jl:294-324]."""
+    P = np.zeros((n * n, 2 * n * n))
+    row = 0
+    for k in range(n):
+        for j in range(k + 1):
+            P[row, k * n + j] = 1.0
+            row += 1
+    for k in range(1, n):
+        for j in range(k):
+            P[row, n * n + k * n + j] = 1.0
+            row += 1
+    return P
+
+
+def iso_D(Lop):
+    """Isomorphic Lindblad dissipator [REF isomorphisms.jl:394-396]."""
+    Lop = np.asarray(Lop, _c)
+    return iso(np.kron(Lop.conj(), Lop) - 0.5 * ad_vec(Lop.conj().T @ Lop, anti=True))
+
+
+class OpenQuantumSystem:
+    """Linear drives, constant-rate dissipators.  ``G_drift`` / ``G_drives`` are the COMPACT Lindbladian generators
+    (levels^2 x levels^2, real): d/dt x = (G_drift + sum_j u_j G_drives[j]) x for x = density_to_compact_iso(rho)
+    [REF open_quantum_systems.jl:541-588 (compact_lindbladian_generators); integrators.jl:82-95]."""
+
+    time_dependent = False
+
+    def __init__(self, H_drift, H_drives=(), drive_bounds=None, dissipation_operators=()):
+        self.H_drift = np.asarray(H_drift, _c)
+        self.H_drives = [np.asarray(Hd, _c) for Hd in H_drives]
+        self.dissipation_operators = [np.asarray(Lo, _c) for Lo in dissipation_operators]
+        self.levels = self.H_drift.shape[0]
+        self.n_drives = len(self.H_drives)
+        self.drive_bounds = _normalize_bounds(drive_bounds if drive_bounds is not None else [1.0] * self.n_drives)
+        n = self.levels
+        P, L = density_projection_matrix(n), density_lift_matrix(n)
+        self.G_drift = P @ G(ad_vec(self.H_drift)) @ L
+        for Lo in self.dissipation_operators:
+            self.G_drift = self.G_drift + P @ iso_D(Lo) @ L
+        self.G_drives = [P @ G(ad_vec(Hd)) @ L for Hd in self.H_drives]
+
+    def G(self, u, t=0.0):
+        return self.G_drift + sum((uj * Gd for uj, Gd in zip(u, self.G_drives)), np.zeros_like(self.G_drift))
+
+    def G_drives_array(self):
+        n2 = self.levels**2
+        return np.array(self.G_drives).reshape(self.n_drives, n2, n2)

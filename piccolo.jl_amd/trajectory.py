@@ -21,6 +21,7 @@ from .quantum import operator_to_iso_vec
 
 STATE = "Ũ⃗"  # :Ũ⃗  (state_name of a UnitaryTrajectory)
 KET = "ψ̃"  # :ψ̃  (state_name of a KetTrajectory)
+DENSITY = "ρ⃗̃"  # :ρ⃗̃  (state_name of a DensityTrajectory: compact isomorphism, levels^2 reals)
 TIMESTEP = "Δt"
 
 
@@ -191,4 +192,23 @@ def ket_trajectory(system, controls, times, psi_init, psi_goal, states=None, n_d
     comps = OrderedDict([(state_name, X), (TIMESTEP, dts[None, :]), ("t", times[None, :]), ("u", u)])
     traj = NamedTrajectory(comps, controls=(TIMESTEP, "u"), timestep=TIMESTEP,
                            initial={state_name: ket_to_iso(psi_init)}, goal={state_name: ket_to_iso(psi_goal)})  # fmt: skip
+    return add_control_derivatives(traj, n_derivs) if n_derivs else traj
+
+
+def density_trajectory(system, controls, times, rho_init, rho_goal, states=None, n_derivs=2, state_name=DENSITY):
+    """``NamedTrajectory(qtraj::DensityTrajectory, N)``: components ``[rhotilde, dt, t, u, du, ddu]`` with
+    ``rhotilde = density_to_compact_iso(rho)`` (levels^2 reals) [REF named_trajectory_conversion.jl:540-600]."""
+    from .quantum import density_to_compact_iso
+
+    times = np.asarray(times, float)
+    N = times.size
+    u = np.asarray(controls, float).reshape(system.n_drives, N)
+    if states is None:
+        states = [np.asarray(rho_init, complex)] * N
+    X = np.stack([density_to_compact_iso(r) for r in states], axis=1)
+    dts = np.diff(times)
+    dts = np.concatenate((dts, dts[-1:])) if N > 1 else np.ones(1)
+    comps = OrderedDict([(state_name, X), (TIMESTEP, dts[None, :]), ("t", times[None, :]), ("u", u)])
+    traj = NamedTrajectory(comps, controls=(TIMESTEP, "u"), timestep=TIMESTEP,
+                           initial={state_name: density_to_compact_iso(rho_init)}, goal={state_name: density_to_compact_iso(rho_goal)})  # fmt: skip
     return add_control_derivatives(traj, n_derivs) if n_derivs else traj

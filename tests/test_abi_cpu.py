@@ -61,7 +61,7 @@ def _mk(**over):
     "over,code,msg",
     [
         (dict(pade_order=7), pa._lib.PCL_ENOTIMPL, "orders 2, 4, 6, 8, 10"),
-        (dict(d=33, G0=np.zeros((66, 66)), Gj=np.zeros((2, 66, 66)), z_dim=3000, x_offs=[0], u_off=2900, dt_off=2899), pa._lib.PCL_ESHAPE, "PCL_MAX_D"),
+        (dict(d=33, G0=np.zeros((66, 66)), Gj=np.zeros((2, 66, 66)), z_dim=3000, x_offs=[0], u_off=2900, dt_off=2899), pa._lib.PCL_ESHAPE, "generator dimension"),
         (dict(N=1), pa._lib.PCL_EINVAL, "N>=2"),
         (dict(x_offs=[12]), pa._lib.PCL_EINVAL, "does not fit"),
         (dict(u_off=15), pa._lib.PCL_EINVAL, "u_off"),

@@ -260,3 +260,57 @@ def test_oracle_rollout_reproduces_reference_solved_states(golden, golden_meta):
     states = np.stack([lay.X(Z, k).T.reshape(-1) for k in range(lay.N)])
     assert np.abs(X - states).max() < 1e-9
     assert np.array_equal(X[0], states[0])
+
+
+def test_compact_density_isomorphism_literals_and_lindblad_rhs():
+    """The reference's own checks of the compact density isomorphism [REF isomorphisms.jl:539-620]: the explicit 2x2
+    ordering literal, sizes / nnz of L and P, P L = I, L x = iso_vec; and the physics pin of the compact Lindbladian
+    [REF open_quantum_systems.jl:541-588]: Gc x == compact(-i[H, rho] + sum L rho L' - 1/2 {L'L, rho})."""
+    a, b, c, d = 0.6, 0.4, 0.2, 0.1
+    rho = np.array([[a, c + d * 1j], [c - d * 1j, b]])
+    assert np.allclose(po.density_to_compact_iso(rho), [a, c, b, d])
+    rng = np.random.default_rng(0)
+    for n in (2, 3, 4, 7):
+        L, P = po.density_lift_matrix(n), po.density_projection_matrix(n)
+        assert L.shape == (2 * n * n, n * n) and P.shape == (n * n, 2 * n * n)
+        assert np.count_nonzero(L) == n * (2 * n - 1) and np.count_nonzero(P) == n * n
+        assert np.allclose(P @ L, np.eye(n * n))
+        A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        r = (A + A.conj().T) / 2
+        assert np.allclose(L @ po.density_to_compact_iso(r), po.density_to_iso_vec(r))
+        assert np.allclose(P @ po.density_to_iso_vec(r), po.density_to_compact_iso(r))
+        assert np.allclose(po.compact_iso_to_density(po.density_to_compact_iso(r)), r)
+        LP = L @ P
+        assert np.allclose(LP @ LP, LP)
+    n = 3
+    H = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    H = H + H.conj().T
+    Ls = [rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)) for _ in range(2)]
+    A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    r = (A + A.conj().T) / 2
+    drift, drives = po.compact_lindbladian_generators(H, [H @ H], Ls)
+    rhs = -1j * (H @ r - r @ H) + sum(Lo @ r @ Lo.conj().T - 0.5 * (Lo.conj().T @ Lo @ r + r @ Lo.conj().T @ Lo) for Lo in Ls)
+    assert np.abs(drift @ po.density_to_compact_iso(r) - po.density_to_compact_iso(rhs)).max() < 1e-13
+    HH = H @ H
+    assert np.abs(drives[0] @ po.density_to_compact_iso(r) - po.density_to_compact_iso(-1j * (HH @ r - r @ HH))).max() < 1e-12
+
+
+def test_oracle_general_generator_dimension_finite_differences():
+    """Layout(gen=n): the oracle's residual / Jacobian / Hessian for a general real n x n generator on one column (odd n),
+    against finite differences."""
+    rng = np.random.default_rng(3)
+    n, m, N = 9, 2, 4
+    lay = po.Layout(d=0, m=m, N=N, z_dim=n + 2 + m, x_off=0, u_off=n + 2, dt_off=n, cols=1, gen=n)
+    G0 = rng.standard_normal((n, n))
+    Gj = rng.standard_normal((m, n, n))
+    Z = 0.3 * rng.standard_normal((N, lay.z_dim))
+    Z[:, lay.dt_off] = 0.1
+    assert lay.x_dim == n and po.jac_nnz_per_interval(lay) == 2 * n * n + n * (m + 1)
+    J = po.pade_jacobian_dense(Z, lay, G0, Gj, 4)
+    eps = 1e-6
+    for col in (0, n - 1, lay.dt_off, lay.u_off + 1, lay.z_dim + 3):
+        Zp, Zm = Z.reshape(-1).copy(), Z.reshape(-1).copy()
+        Zp[col] += eps
+        Zm[col] -= eps
+        fd = (po.pade_residual(Zp.reshape(N, -1), lay, G0, Gj, 4) - po.pade_residual(Zm.reshape(N, -1), lay, G0, Gj, 4)).reshape(-1) / (2 * eps)
+        assert np.abs(fd - J[:, col]).max() < 1e-7

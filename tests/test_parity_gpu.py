@@ -995,3 +995,55 @@ def test_config4_share_full_size_ensemble():
         h_ref = ref_lib.hess(Z, mu[i * per_d : (i + 1) * per_d].reshape(lay.K, -1), lay, s.G_drift, np.array(s.G_drives), x_off=i * xd)
         close(hv[i * hper : (i + 1) * hper], h_ref, 1e-10)
     B.close()
+
+
+# ---- compact-density variant ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("levels,order", [(2, 4), (3, 4), (3, 8), (4, 4), (5, 6)])
+def test_density_variant(levels, order):
+    """BilinearIntegrator(qtraj::DensityTrajectory, N) [REF src/control/integrators.jl:82-95]: compact density vector
+    (levels^2 reals) under the compact Lindbladian generators (general real, odd dimension for odd `levels`:
+    PCL_STATE_VECTOR).  delta / Jacobian / structure / Hessian (order 4) / rollout against the oracle; the rollout keeps
+    tr(rho) = 1 and rho Hermitian positive (a physical channel)."""
+    rng = np.random.default_rng(10 * levels + order)
+    n, m, N = levels, 2, 7
+    H = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    H = 0.5 * (H + H.conj().T)
+    Hs = [(lambda A: A + A.conj().T)(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) for _ in range(m)]
+    a = pa.annihilate(n)
+    Ls = [0.3 * a, 0.1 * np.diag(np.arange(n)).astype(complex)]
+    sys_ = pa.OpenQuantumSystem(H, Hs, [1.0] * m, Ls)
+    G0o, Gjo = po.compact_lindbladian_generators(H, Hs, Ls)
+    assert np.array_equal(sys_.G_drift, G0o)
+    n2 = n * n
+    psi = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    psi /= np.linalg.norm(psi)
+    rho0 = np.outer(psi, psi.conj())
+    times = np.cumsum(np.concatenate(([0.0], 0.05 + 0.05 * rng.random(N - 1))))
+    traj = pa.density_trajectory(sys_, 0.5 * rng.standard_normal((m, N)), times, rho0, rho0)
+    Z = traj.datavec.reshape(N, traj.dim).copy()
+    Z[1:, :n2] += 0.05 * rng.standard_normal((N - 1, n2))  # an infeasible iterate: non-trivial residuals
+    traj.update(Z.reshape(-1))
+    lay = po.Layout(d=0, m=m, N=N, z_dim=traj.dim, x_off=0, u_off=traj.components["u"].start, dt_off=traj.components["Δt"].start,
+                    cols=1, gen=n2)  # fmt: skip
+    B = pa.BilinearIntegrator(sys_, traj, pade_order=order)
+    assert B.x_name == "ρ⃗̃" and B.x_dim == n2 and B.dim == n2 * (N - 1)
+    Gj_arr = np.array(Gjo)
+    delta, vals = B.ctx.eval_jac(traj.datavec)
+    close(delta, po.pade_residual(Z, lay, G0o, Gj_arr, order), 1e-11)
+    close(vals, po.pade_jacobian_values(Z, lay, G0o, Gj_arr, order), 1e-11)
+    close(pa.evaluate_(np.zeros(B.dim), B, traj), delta, 1e-13)
+    r, c = pa.jacobian_structure(B)
+    r0, c0 = po.jac_structure(lay)
+    assert np.array_equal(r, r0) and np.array_equal(c, c0)
+    J = pa.eval_jacobian(B, traj).toarray()
+    close(J, po.pade_jacobian_dense(Z, lay, G0o, Gj_arr, order), 1e-11)
+    if order == 4:
+        mu = rng.standard_normal((lay.K, lay.x_dim))
+        close(B.ctx.hess(traj.datavec, mu), po.pade4_hessian_values(Z, mu, lay, G0o, Gj_arr), 1e-10)
+    X = pa.unitary_rollout(B, traj)  # exact propagation of the compact density vector
+    close(X.T, po.exact_rollout(Z, lay, G0o, Gj_arr), 1e-11)
+    for k in (1, N - 1):
+        rho = pa.compact_iso_to_density(X[:, k])
+        assert abs(np.trace(rho).real - 1.0) < 1e-12 and np.linalg.eigvalsh(rho).min() > -1e-12
+    close(B.f(Z[2, :n2], Z[1, :n2], Z[1, lay.u_off : lay.u_off + m], Z[1, lay.dt_off]), delta[n2 : 2 * n2], 1e-11)
+    B.close()
