@@ -50,8 +50,10 @@ mutable struct HipPadeIntegrator <: AbstractIntegrator
 end
 
 function _create(G0s::Vector{<:AbstractMatrix}, Gjs::Vector{<:AbstractMatrix}, traj::NamedTrajectory,
-                 x_names::Vector{Symbol}, u_name::Symbol; device::Integer = 0, pade_order::Integer = 4)
-    n = size(G0s[1], 1); d = n ÷ 2; m = length(Gjs)
+                 x_names::Vector{Symbol}, u_name::Symbol; device::Integer = 0, pade_order::Integer = 4,
+                 state_cols::Integer = 0)
+    # state_cols: 0 unitary (n = 2d), 1 ket, -1 = PCL_STATE_VECTOR (general n x n generator on one real column, d := n)
+    n = size(G0s[1], 1); d = state_cols == -1 ? n : n ÷ 2; m = length(Gjs)
     G0 = reduce(vcat, [vec(Matrix{Float64}(G)) for G in G0s])          # column-major, one block per member
     Gj = m == 0 ? zeros(1) : reduce(vcat, [vec(Matrix{Float64}(G)) for G in Gjs])
     x_offs = Int32[traj.components[nm][1] - 1 for nm in x_names]
@@ -60,7 +62,7 @@ function _create(G0s::Vector{<:AbstractMatrix}, Gjs::Vector{<:AbstractMatrix}, t
         desc = PclDesc(sizeof(PclDesc), d, m, traj.N, traj.dim,
                        traj.components[u_name][1] - 1, traj.components[traj.timestep][1] - 1,
                        length(x_names), 0 #= PCL_BATCH_MEMBERS =#, pade_order #= 2, 4, 6, 8 or 10 =#, device, 1 #= 1-based =#,
-                       length(G0s) > 1 ? 1 : 0, 0, traj.global_dim,
+                       length(G0s) > 1 ? 1 : 0, state_cols, traj.global_dim,
                        pointer(G0), pointer(Gj), pointer(x_offs))
         rc = ccall((:pcl_create, LIB), Cint, (Ref{PclDesc}, Ref{Ptr{Cvoid}}), desc, ctx)
         rc == 0 || error("pcl_create: ", unsafe_string(ccall((:pcl_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
@@ -99,6 +101,24 @@ function HipPadeIntegrator(qtraj::SamplingTrajectory, N::Int; kwargs...)
     G0s = [Matrix(s.G(zeros(m), 0.0)) for s in qtraj.systems]
     Gj = [Matrix(qtraj.systems[1].G(e(j), 0.0)) - G0s[1] for j in 1:m]
     return _create(G0s, Gj, traj, state_names(qtraj), drive_name(qtraj); kwargs...)
+end
+
+# BilinearIntegrator(qtraj::KetTrajectory, N) [REF integrators.jl:58-74]
+function HipPadeIntegrator(qtraj::KetTrajectory, N::Int; kwargs...)
+    sys = get_system(qtraj); traj = NamedTrajectory(qtraj, N); m = sys.n_drives
+    e(j) = (u = zeros(m); u[j] = 1.0; u)
+    G0 = Matrix(sys.G(zeros(m), 0.0))
+    Gj = [Matrix(sys.G(e(j), 0.0)) - G0 for j in 1:m]
+    return _create([G0], Gj, traj, [state_name(qtraj)], drive_name(qtraj); state_cols = 1, kwargs...)
+end
+
+# BilinearIntegrator(qtraj::DensityTrajectory, N) [REF integrators.jl:82-95]: compact Lindbladian generators, linear
+# drives and constant dissipation rates (compact_lindbladian_generators folds the dissipators into the drift)
+function HipPadeIntegrator(qtraj::DensityTrajectory, N::Int; kwargs...)
+    sys = get_system(qtraj); traj = NamedTrajectory(qtraj, N)
+    Gc_drift, Gc_drives = compact_lindbladian_generators(sys)
+    return _create([Matrix(Gc_drift)], [Matrix(G) for G in Gc_drives], traj, [state_name(qtraj)], drive_name(qtraj);
+                   state_cols = -1, kwargs...)
 end
 
 _z(traj::NamedTrajectory) = traj.datavec    # knot-major flat buffer, passed as is
