@@ -615,6 +615,10 @@ static size_t fused3_lds_bytes(const pcl_ctx *ctx, const KParams &p, bool tab) {
 // Constants are the measured config-3 phase times (scripts/phase_timing.py, with the stream running): ~7 us per
 // 2-column chunk, ~4 us for G(u) + G^2, stream at ~0.85 of the CU's fair HBM share; other shapes scale by MFMA count.
 // Role split needs the chunk buffers of matrix waves 4..7 inside the second halves of the G / G^2 double buffers.
+// the shape of BASELINE configs 3/4/5 (three 3-level transmons: d = 27, six drives with two entries per row)
+static bool v3_specialised(const pcl_ctx *ctx) {
+    return ctx->opt_specialize && ctx->desc.d == 27 && ctx->desc.n_drives == 6 && ctx->ell_w == 2;
+}
 static bool v3_role_split_fits(const pcl_ctx *ctx) {
     const int ncw = v3_ncw(ctx, ctx->desc.d), LD = lds_ld(ctx->n);
     return 2 * (size_t)LD * (16 + 3 * ncw) <= (size_t)LD * ctx->n;
@@ -715,8 +719,10 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     const bool want_jac = jac != nullptr;
     if (ctx->desc.pade_order != 4 || ctx->opt_general || ctx->vec) return launch_pade_general(ctx, p, want_jac);
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
-    if (want_jac && (!compact || v3_role_split_fits(ctx)) && (ctx->opt_kernel == 3 || ctx->opt_kernel == 0) && ctx->opt_use_mfma != 0 &&
-        v3_supported(ctx) && !ctx->vec && ctx->cols == ctx->desc.d) {  // the default whenever its LDS budget fits (else kernels 2 / 4 below)
+    // auto: kernel 3 where its shape-specialised instance applies (BASELINE configs 3/4/5); its run-time-shape instances
+    // lose to kernels 1 / 2 on every other shape measured (scripts/small_d_probe*.py: up to 3x), so they need kernel_version = 3
+    if (want_jac && (!compact || v3_role_split_fits(ctx)) && (ctx->opt_kernel == 3 || (ctx->opt_kernel == 0 && v3_specialised(ctx))) &&
+        ctx->opt_use_mfma != 0 && v3_supported(ctx) && !ctx->vec && ctx->cols == ctx->desc.d) {
         // default: contiguous column ranges (one item per interval touched); an explicit cols_per_slice or
         // contiguous = 0 selects the round-robin slices
         p.contig = (compact || v3_contiguous(ctx)) ? 1 : 0;  // compact: contiguous ranges, every workgroup in the matrix role
@@ -724,6 +730,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         p.flat = ctx->opt_flat ? 1 : 0;
         p.snc = (int)std::max<int64_t>(0, std::min<int64_t>(ctx->opt_snc, p.d));
         p.nc = p.contig ? p.d : choose_cols_v3(ctx);
+        if (!p.contig && ctx->opt_cols_per_slice <= 0 && p.nc < 2 && p.d >= 2) p.nc = 2;  // keep the 2-column chunks of the specialised instance
         p.ncw = v3_ncw(ctx, p.nc);
         p.tab_lds = 1;
         size_t lds3 = fused3_lds_bytes(ctx, p, true);
@@ -756,7 +763,10 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         return PCL_OK;
     }
 not_v3:
-    const bool v2 = (ctx->opt_kernel == 0 || ctx->opt_kernel >= 2) && ctx->opt_use_mfma != 0;
+    // auto: small Hilbert dimensions are launch- / latency-bound, one workgroup per item (kernel 1) beats the persistent
+    // kernels there (measured: d <= 8 always, d <= 16 while all items fit one round of workgroups)
+    const bool v1_auto = ctx->opt_kernel == 0 && (ctx->desc.d <= 8 || (ctx->desc.d <= 16 && (long long)ctx->desc.batch * ctx->K <= 512));
+    const bool v2 = !v1_auto && (ctx->opt_kernel == 0 || ctx->opt_kernel >= 2) && ctx->opt_use_mfma != 0;
     const bool unitary = !ctx->vec && ctx->cols == ctx->desc.d;  // kernels 3, 4, 5 and the specialised instances assume X is n x d
     bool v4 = v2 && ctx->opt_kernel == 4 && want_jac && unitary;
     p.nc = choose_cols_per_slice(ctx, want_jac);
@@ -784,6 +794,7 @@ not_v3:
             kern = wu == 1 ? (kern_t)pcl_fused_kernel_v4<1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v4<2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v4<-1, 0, 0, 0>;
             if (wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize) kern = (kern_t)pcl_fused_kernel_v4<1, 27, 6, 3>;
         }
+        ctx->last_n_stream = 0;
         ctx->last_kernel = (v4 ? 40 : 20) + ((unitary && wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize && want_jac) ? 1 : 0);
         int rc = set_lds_attr(ctx, (const void *)kern, want_jac ? 4 : 5, lds);  // wu is fixed per context
         if (rc != PCL_OK) return rc;
@@ -830,6 +841,8 @@ not_v3:
                              : (mf ? pcl_fused_kernel<false, true> : pcl_fused_kernel<false, false>);
         int rc = set_lds_attr(ctx, (const void *)kern, (want_jac ? 0 : 2) + (mf ? 0 : 1), lds);
         if (rc != PCL_OK) return rc;
+        ctx->last_kernel = 10;
+        ctx->last_n_stream = 0;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx->stream, p);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1300,7 +1313,7 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
     else if (!strcmp(key, "nt_stores"))
         *v = ctx->opt_nt;
     else if (!strcmp(key, "effective_cols_per_slice"))
-        *v = ((ctx->opt_kernel == 3 || ctx->opt_kernel == 0) && ctx->opt_use_mfma && v3_supported(ctx) && ctx->cols == ctx->desc.d)
+        *v = ((ctx->opt_kernel == 3 || (ctx->opt_kernel == 0 && v3_specialised(ctx))) && ctx->opt_use_mfma && v3_supported(ctx) && !ctx->vec && ctx->cols == ctx->desc.d)
                  ? (v3_contiguous(ctx) ? ctx->desc.d : choose_cols_v3(ctx))
                  : choose_cols_per_slice(ctx, true);
     else if (!strcmp(key, "n_cu"))

@@ -1085,3 +1085,28 @@ def test_device_entry_points_are_graph_capturable():
         assert all(torch.equal(a, b) for a, b in zip(ref, (dd, vd, hv)))
         close(dd.cpu().numpy(), po.pade_residual(Z, lay, so.G_drift, np.array(so.G_drives), 4))
     c.close()
+
+
+def test_auto_kernel_policy_by_shape():
+    """`auto` picks the kernel measured best per shape (scripts/small_d_probe*.py): one workgroup per item for small
+    Hilbert dimensions, the persistent two-workgroup kernels above, kernel 3 where its shape-specialised instance applies."""
+    expect = {1: 10, 2: 10, 3: 31}
+    for cfg, kid in expect.items():
+        so = po.config_system(cfg)
+        Z, lay = po.synthetic_trajectory(so, 8, seed=1)
+        c = make_ctx(lay, so.G_drift, np.array(so.G_drives))
+        delta, vals = c.eval_jac(Z)
+        assert c.get_option("last_kernel") == kid, (cfg, c.get_option("last_kernel"))
+        d_ref, j_ref = ref_lib.eval_jac(Z, lay, so.G_drift, np.array(so.G_drives))
+        close(delta, d_ref)
+        close(vals, j_ref)
+        c.close()
+    rng = np.random.default_rng(3)
+    lay, G0, Gj, Z = _random_case(20, 3, 4, rng)  # general real generators, d = 20: persistent two-workgroup kernel
+    c = make_ctx(lay, G0, Gj)
+    delta, vals = c.eval_jac(Z)
+    assert c.get_option("last_kernel") // 10 in (2, 4)
+    d_ref, j_ref = ref_lib.eval_jac(Z, lay, G0, Gj)
+    close(delta, d_ref, 1e-11)
+    close(vals, j_ref, 1e-11)
+    c.close()
