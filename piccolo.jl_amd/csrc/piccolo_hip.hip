@@ -616,8 +616,12 @@ static size_t fused3_lds_bytes(const pcl_ctx *ctx, const KParams &p, bool tab) {
 // 2-column chunk, ~4 us for G(u) + G^2, stream at ~0.85 of the CU's fair HBM share; other shapes scale by MFMA count.
 // Role split needs the chunk buffers of matrix waves 4..7 inside the second halves of the G / G^2 double buffers.
 // the shape of BASELINE configs 3/4/5 (three 3-level transmons: d = 27, six drives with two entries per row)
+// plus two 5-level transmons (d = 25, four drives) and, for launches of one round of workgroups, two 4-level transmons
 static bool v3_specialised(const pcl_ctx *ctx) {
-    return ctx->opt_specialize && ctx->desc.d == 27 && ctx->desc.n_drives == 6 && ctx->ell_w == 2;
+    if (!ctx->opt_specialize || ctx->ell_w != 2) return false;
+    const int d = ctx->desc.d, m = ctx->desc.n_drives;
+    if ((d == 27 && m == 6) || (d == 25 && m == 4)) return true;
+    return d == 16 && m == 4 && (long long)ctx->desc.batch * ctx->K <= 512;
 }
 static bool v3_role_split_fits(const pcl_ctx *ctx) {
     const int ncw = v3_ncw(ctx, ctx->desc.d), LD = lds_ld(ctx->n);
@@ -745,9 +749,17 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         typedef void (*kern3_t)(const KParams);
         const int ewr = (p.m <= 8 && ctx->ell_w >= 1 && ctx->ell_w <= 2) ? ctx->ell_w : 0;
         kern3_t kern3 = ewr == 1 ? (kern3_t)pcl_fused_kernel_v3<1, 0, 0, 0> : ewr == 2 ? (kern3_t)pcl_fused_kernel_v3<2, 0, 0, 0> : (kern3_t)pcl_fused_kernel_v3<0, 0, 0, 0>;
-        // shape-specialised instance (BASELINE config 3/4/5: d = 27, six drives with two entries per row, 2-column chunks)
-        if (ewr == 2 && p.d == 27 && p.m == 6 && p.ncw == 2 && ctx->opt_specialize) kern3 = (kern3_t)pcl_fused_kernel_v3<2, 27, 6, 2>;
-        ctx->last_kernel = 30 + ((ewr == 2 && p.d == 27 && p.m == 6 && p.ncw == 2 && ctx->opt_specialize) ? 1 : 0);
+        // shape-specialised instances (compile-time d, m, chunk width; two drive entries per row):
+        //   three 3-level transmons (BASELINE configs 3/4/5), two 5-level transmons, two 4-level transmons
+        bool spec3 = false;
+        if (ewr == 2 && p.ncw == 2 && ctx->opt_specialize) {
+            spec3 = true;
+            if (p.d == 27 && p.m == 6) kern3 = (kern3_t)pcl_fused_kernel_v3<2, 27, 6, 2>;
+            else if (p.d == 25 && p.m == 4) kern3 = (kern3_t)pcl_fused_kernel_v3<2, 25, 4, 2>;
+            else if (p.d == 16 && p.m == 4) kern3 = (kern3_t)pcl_fused_kernel_v3<2, 16, 4, 2>;
+            else spec3 = false;
+        }
+        ctx->last_kernel = 30 + (spec3 ? 1 : 0);
         int rc = set_lds_attr(ctx, (const void *)kern3, 6, lds3);
         if (rc != PCL_OK) return rc;
         const long long units = p.contig ? (long long)p.batch * p.K * p.d : items;  // what the grid is cut into
@@ -916,6 +928,8 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
         const void *kern = ctx->drives_antisym ? hess_v2_kernel<PCL_HESS_EW, true>(p.m) : hess_v2_kernel<PCL_HESS_EW, false>(p.m);
         if (ctx->opt_specialize && p.d == 27 && p.m == 6 && ctx->drives_antisym)
             kern = (const void *)pcl_hess_kernel_v2<PCL_HESS_EW, 6, 27, true>;  // BASELINE config 3's shape
+        else if (ctx->opt_specialize && p.d == 25 && p.m == 4 && ctx->drives_antisym)
+            kern = (const void *)pcl_hess_kernel_v2<PCL_HESS_EW, 4, 25, true>;  // two 5-level transmons
         if (int rc = set_lds_attr(ctx, kern, 7, lds)) return rc;
         const long long items = nbk * p.S;
         const int per_cu = std::max(1, std::min(2, (int)((size_t)ctx->max_lds / lds)));

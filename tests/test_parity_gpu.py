@@ -1110,3 +1110,29 @@ def test_auto_kernel_policy_by_shape():
     close(delta, d_ref, 1e-11)
     close(vals, j_ref, 1e-11)
     c.close()
+
+
+@pytest.mark.parametrize("levels,batch", [(5, 1), (5, 3), (4, 1)])
+def test_other_specialised_shapes(levels, batch):
+    """Two 5-level (d = 25) and two 4-level (d = 16) transmons with four drives: the shape-specialised instances of
+    kernel 3 (role split at d = 25 for the larger launch) and of the Hessian kernel, against the C oracle."""
+    so = po.multi_transmon_system([4.0, 4.1], [0.2, 0.2], [[0, 0.01], [0.01, 0]], levels_per_transmon=levels, drive_bounds=0.1)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    N = 100 if batch > 1 else 12
+    Zs, lay = [], None
+    for s in range(batch):
+        Z, lay = po.synthetic_trajectory(so, N, seed=60 + s)
+        Zs.append(Z)
+    c = make_ctx(lay, G0, Gj, batch=batch, batch_mode=pa._lib.PCL_BATCH_TRAJ)
+    delta, vals = c.eval_jac(np.stack(Zs))
+    assert c.get_option("last_kernel") == 31
+    if batch > 1:
+        assert c.get_option("last_stream_workgroups") > 0
+    refs = [ref_lib.eval_jac(Z, lay, G0, Gj) for Z in Zs]
+    close(delta, np.concatenate([r[0].reshape(-1) for r in refs]))
+    close(vals, np.concatenate([r[1].reshape(-1) for r in refs]))
+    mu = np.random.default_rng(1).standard_normal((batch, lay.K, lay.x_dim))
+    hv = c.hess(np.stack(Zs), mu.reshape(-1))
+    assert c.get_option("last_hess_kernel") == 2
+    close(hv, np.concatenate([ref_lib.hess(Z, mu[i], lay, G0, Gj).reshape(-1) for i, Z in enumerate(Zs)]), 1e-10)
+    c.close()
