@@ -206,11 +206,13 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *       "cols_per_slice"     state columns per work item (0 = heuristic; forces the round-robin split in kernel 3)
  *       "hess_kernel"        0 auto | 1 one workgroup per interval | 2 persistent wave-synchronous kernel
  *       "general_pade_kernel" 1: run the general-order kernel for pade_order 4 too (cross-check)
+ *       "jit"                1 (default): shapes outside the static instance table are compiled on first use with hiprtc
+ *                            (Hessian kernel 2 for d >= 12; fused kernel 3 when kernel_version = 3); 0: run-time-shape instances
  *       "use_mfma" (1/0: plain-VALU products in kernel 1), "nt_stores" (1/0), "specialize" (1/0: shape-specialised
  *       instances), "grid" (workgroups, 0 = one per CU), "copies_per_piece" (kernel 5), "debug_timing", "debug_ablate"
  *       (profiling only: results are WRONG when non-zero)
  * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised; 90 + q for the general-order
- *       kernel), "last_stream_workgroups", "last_hess_kernel", "n_cu", "iso_structured", "drives_antisymmetric",
+ *       kernel), "last_stream_workgroups", "last_hess_kernel" (3: compiled on first use), "jit_compiles", "n_cu", "iso_structured", "drives_antisymmetric",
  *       "ell_width", "ell_width_t", "union_width", "occupancy_v2".  Unknown keys return PCL_EINVAL. */
 int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t value);
 int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *value);

@@ -81,6 +81,7 @@ struct pcl_ctx {
     int64_t opt_cpp = 6;  // block copies per expander work item
     int64_t opt_specialize = 1;
     int64_t opt_snc = 0;      // v3, role split: stream pieces of this many columns dealt round-robin (0: contiguous ranges)
+    int64_t opt_jit = 1;      // compile shape-specialised instances on first use (hiprtc) for shapes outside the static table
     int64_t opt_flat = 0;     // v3: line-aligned flat block stream (measured: no gain over the per-block stores, slower for one trajectory)
     int64_t opt_general = 0;  // 1: run the general-order kernel also for pade_order 4 (cross-check)
     int64_t opt_contig = -1;     // v3: contiguous column ranges per workgroup (-1: auto by launch size)
@@ -498,6 +499,149 @@ extern "C" int pcl_hess_structure_i64(const pcl_ctx *ctx, int64_t *rows, int64_t
     return hess_structure_impl<int64_t>(ctx, rows, cols);
 }
 
+// --- run-time shape specialisation (hiprtc) -----------------------------------------------------------------------
+// The wave-synchronous kernels are 1.3-3x faster with compile-time Hilbert dimension / drive count (constant LDS strides,
+// no SGPR spills).  A few shapes are instantiated statically; any other shape is compiled on first use from the kernel
+// headers that sit next to this library (pcl_*.hpp, located with dladdr) -- about 1.5 s, cached for the process.
+// libhiprtc is opened lazily; when it or the headers are missing the run-time-shape instances are used (same results).
+#include <map>
+#include <mutex>
+namespace {
+struct JitKernels {
+    hipModule_t mod = nullptr;
+    hipFunction_t fused = nullptr, hess = nullptr;
+    bool failed = false;
+};
+struct HiprtcApi {
+    void *h = nullptr;
+    int (*CreateProgram)(void **, const char *, const char *, int, const char **, const char **) = nullptr;
+    int (*AddNameExpression)(void *, const char *) = nullptr;
+    int (*CompileProgram)(void *, int, const char **) = nullptr;
+    int (*GetLoweredName)(void *, const char *, const char **) = nullptr;
+    int (*GetCodeSize)(void *, size_t *) = nullptr;
+    int (*GetCode)(void *, char *) = nullptr;
+    int (*GetProgramLogSize)(void *, size_t *) = nullptr;
+    int (*GetProgramLog)(void *, char *) = nullptr;
+    int (*DestroyProgram)(void **) = nullptr;
+};
+std::mutex g_jit_mutex;
+std::map<std::string, JitKernels> g_jit;  // key: device | ew | d | m | ncw | anti
+HiprtcApi g_rtc;
+int64_t g_jit_compiles = 0;
+std::string g_jit_note;
+
+bool rtc_load() {
+    if (g_rtc.h) return true;
+    void *h = dlopen("libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libhiprtc.so.7", RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        g_jit_note = std::string("dlopen(libhiprtc.so): ") + dlerror();
+        return false;
+    }
+    HiprtcApi a;
+    a.h = h;
+#define RTC_SYM(field, name) a.field = (decltype(a.field))dlsym(h, name)
+    RTC_SYM(CreateProgram, "hiprtcCreateProgram");
+    RTC_SYM(AddNameExpression, "hiprtcAddNameExpression");
+    RTC_SYM(CompileProgram, "hiprtcCompileProgram");
+    RTC_SYM(GetLoweredName, "hiprtcGetLoweredName");
+    RTC_SYM(GetCodeSize, "hiprtcGetCodeSize");
+    RTC_SYM(GetCode, "hiprtcGetCode");
+    RTC_SYM(GetProgramLogSize, "hiprtcGetProgramLogSize");
+    RTC_SYM(GetProgramLog, "hiprtcGetProgramLog");
+    RTC_SYM(DestroyProgram, "hiprtcDestroyProgram");
+#undef RTC_SYM
+    if (!a.CreateProgram || !a.AddNameExpression || !a.CompileProgram || !a.GetLoweredName || !a.GetCodeSize || !a.GetCode || !a.DestroyProgram) {
+        g_jit_note = "libhiprtc lacks the expected symbols";
+        return false;
+    }
+    g_rtc = a;
+    return true;
+}
+
+bool slurp(const std::string &path, std::string &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[65536];
+    size_t n;
+    out.clear();
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    fclose(f);
+    return !out.empty();
+}
+
+// Compile (once per process and shape) the fused kernel 3 and the Hessian kernel 2 for compile-time (d, m).
+const JitKernels *jit_get(int device, int ew, int d, int m, int ncw, bool anti, bool want_hess) {
+    char key[96];
+    snprintf(key, sizeof key, "%d|%d|%d|%d|%d|%d|%d", device, ew, d, m, ncw, anti ? 1 : 0, want_hess ? 1 : 0);
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    auto it = g_jit.find(key);
+    if (it != g_jit.end()) return it->second.failed ? nullptr : &it->second;
+    JitKernels &jk = g_jit[key];
+    jk.failed = true;
+    if (!rtc_load()) return nullptr;
+    Dl_info info;
+    if (!dladdr((const void *)&pcl_version, &info) || !info.dli_fname) {
+        g_jit_note = "dladdr failed";
+        return nullptr;
+    }
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+    const char *names[] = {"pcl_device_common.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp"};
+    std::string hdr[3];
+    const char *hdrp[3];
+    for (int i = 0; i < 3; ++i) {
+        if (!slurp(dir + "/" + names[i], hdr[i])) {
+            g_jit_note = "kernel header not found next to the library: " + dir + "/" + names[i];
+            return nullptr;
+        }
+        hdrp[i] = hdr[i].c_str();
+    }
+    const char *src = "#include \"pcl_device_common.hpp\"\n#include \"pcl_kernel_fused_v3.hpp\"\n#include \"pcl_kernels_hessian.hpp\"\n";
+    void *prog = nullptr;
+    if (g_rtc.CreateProgram(&prog, src, "pcl_jit.hip", 3, hdrp, names) != 0) {
+        g_jit_note = "hiprtcCreateProgram failed";
+        return nullptr;
+    }
+    char nf[96], nh[96];
+    snprintf(nf, sizeof nf, "pcl_fused_kernel_v3<%d, %d, %d, %d>", ew, d, m, ncw);
+    snprintf(nh, sizeof nh, "pcl_hess_kernel_v2<2, %d, %d, %s>", m, d, anti ? "true" : "false");
+    g_rtc.AddNameExpression(prog, nf);
+    if (want_hess) g_rtc.AddNameExpression(prog, nh);
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+    const int rc = g_rtc.CompileProgram(prog, 3, opts);
+    if (rc != 0) {
+        size_t ls = 0;
+        g_jit_note = "hiprtcCompileProgram failed";
+        if (g_rtc.GetProgramLogSize && g_rtc.GetProgramLog && g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
+            std::string log(ls, '\0');
+            g_rtc.GetProgramLog(prog, &log[0]);
+            g_jit_note += ": " + log.substr(0, 400);
+        }
+        g_rtc.DestroyProgram(&prog);
+        return nullptr;
+    }
+    const char *lf = nullptr, *lh = nullptr;
+    size_t cs = 0;
+    g_rtc.GetLoweredName(prog, nf, &lf);
+    if (want_hess) g_rtc.GetLoweredName(prog, nh, &lh);
+    g_rtc.GetCodeSize(prog, &cs);
+    std::vector<char> code(cs);
+    g_rtc.GetCode(prog, code.data());
+    std::string slf = lf ? lf : "", slh = lh ? lh : "";
+    g_rtc.DestroyProgram(&prog);
+    if (hipModuleLoadData(&jk.mod, code.data()) != hipSuccess || slf.empty() || hipModuleGetFunction(&jk.fused, jk.mod, slf.c_str()) != hipSuccess) {
+        g_jit_note = "hipModuleLoadData / hipModuleGetFunction failed";
+        return nullptr;
+    }
+    if (want_hess && (slh.empty() || hipModuleGetFunction(&jk.hess, jk.mod, slh.c_str()) != hipSuccess)) jk.hess = nullptr;
+    jk.failed = false;
+    ++g_jit_compiles;
+    return &jk;
+}
+}  // namespace
+
 // --- launch helpers -------------------------------------------------------------------------
 // LD = (n rounded up to 4) + 2  ==  2*odd: conflict-free ds_read_b64 of the MFMA b operand
 // (16 columns x 2 k-rows per half-wave land on 32 distinct 8-byte bank pairs).
@@ -617,11 +761,16 @@ static size_t fused3_lds_bytes(const pcl_ctx *ctx, const KParams &p, bool tab) {
 // Role split needs the chunk buffers of matrix waves 4..7 inside the second halves of the G / G^2 double buffers.
 // the shape of BASELINE configs 3/4/5 (three 3-level transmons: d = 27, six drives with two entries per row)
 // plus two 5-level transmons (d = 25, four drives) and, for launches of one round of workgroups, two 4-level transmons
+static bool v3_role_split_fits(const pcl_ctx *ctx);
+static bool hess_v2_supported(const pcl_ctx *ctx);
 static bool v3_specialised(const pcl_ctx *ctx) {
-    if (!ctx->opt_specialize || ctx->ell_w != 2) return false;
+    if (!ctx->opt_specialize || ctx->ell_w < 1 || ctx->ell_w > 2) return false;
     const int d = ctx->desc.d, m = ctx->desc.n_drives;
-    if ((d == 27 && m == 6) || (d == 25 && m == 4)) return true;
-    return d == 16 && m == 4 && (long long)ctx->desc.batch * ctx->K <= 512;
+    if (ctx->ell_w == 2 && ((d == 27 && m == 6) || (d == 25 && m == 4))) return true;
+    if (ctx->ell_w == 2 && d == 16 && m == 4 && (long long)ctx->desc.batch * ctx->K <= 512) return true;
+    // Other shapes: `kernel_version = 3` compiles the shape on first use (hiprtc) instead of running the run-time-shape
+    // instance; measured on d = 22..30 it only ties the persistent two-workgroup kernels, so `auto` does not take it.
+    return false;
 }
 static bool v3_role_split_fits(const pcl_ctx *ctx) {
     const int ncw = v3_ncw(ctx, ctx->desc.d), LD = lds_ld(ctx->n);
@@ -759,9 +908,17 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
             else if (p.d == 16 && p.m == 4) kern3 = (kern3_t)pcl_fused_kernel_v3<2, 16, 4, 2>;
             else spec3 = false;
         }
-        ctx->last_kernel = 30 + (spec3 ? 1 : 0);
-        int rc = set_lds_attr(ctx, (const void *)kern3, 6, lds3);
-        if (rc != PCL_OK) return rc;
+        hipFunction_t jitf = nullptr;  // run-time compiled instance for this context's shape
+        if (!spec3 && ctx->opt_jit && ctx->opt_specialize && ewr >= 1) {
+            const JitKernels *jk = jit_get(ctx->device, ewr, p.d, p.m, p.ncw, ctx->drives_antisym != 0, hess_v2_supported(ctx));
+            if (jk) jitf = jk->fused;
+        }
+        if (!spec3 && !jitf && ctx->opt_kernel == 0) goto not_v3;  // auto never runs the run-time-shape instances
+        ctx->last_kernel = jitf ? 32 : 30 + (spec3 ? 1 : 0);
+        if (!jitf) {
+            int rc = set_lds_attr(ctx, (const void *)kern3, 6, lds3);
+            if (rc != PCL_OK) return rc;
+        }
         const long long units = p.contig ? (long long)p.batch * p.K * p.d : items;  // what the grid is cut into
         const long long g3 = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, units) : std::min<long long>(units, std::max(ctx->n_cu, 1));
         p.n_stream = 0;
@@ -770,6 +927,11 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
             if (want > 0) p.n_stream = (int)std::min<long long>(want, g3 - 1);
         }
         ctx->last_n_stream = p.n_stream;
+        if (jitf) {
+            void *args[] = {(void *)&p};
+            HIP_TRY(ctx, hipModuleLaunchKernel(jitf, (unsigned)g3, 1, 1, 512, 1, 1, (unsigned)lds3, ctx->stream, args, nullptr));
+            return PCL_OK;
+        }
         hipLaunchKernelGGL(kern3, dim3((unsigned)g3), dim3(512), lds3, ctx->stream, p);
         HIP_TRY(ctx, hipGetLastError());
         return PCL_OK;
@@ -925,20 +1087,30 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
         p.hpart = ctx->dhpart;
         p.hcnt = ctx->dhcnt;
         const size_t lds = hess2_lds_bytes(p);
+        hipFunction_t jith = nullptr;
+        const bool hess_static = ctx->opt_specialize && ctx->drives_antisym && ((p.d == 27 && p.m == 6) || (p.d == 25 && p.m == 4));
+        if (!hess_static && ctx->opt_jit && ctx->opt_specialize && ctx->cols == ctx->desc.d && ctx->ell_w >= 1 && p.d >= 12) {  // small d: launch-bound either way
+            const JitKernels *jk = jit_get(ctx->device, ctx->ell_w, p.d, p.m, v3_ncw(ctx, p.d), ctx->drives_antisym != 0, true);
+            if (jk) jith = jk->hess;
+        }
         const void *kern = ctx->drives_antisym ? hess_v2_kernel<PCL_HESS_EW, true>(p.m) : hess_v2_kernel<PCL_HESS_EW, false>(p.m);
         if (ctx->opt_specialize && p.d == 27 && p.m == 6 && ctx->drives_antisym)
             kern = (const void *)pcl_hess_kernel_v2<PCL_HESS_EW, 6, 27, true>;  // BASELINE config 3's shape
         else if (ctx->opt_specialize && p.d == 25 && p.m == 4 && ctx->drives_antisym)
             kern = (const void *)pcl_hess_kernel_v2<PCL_HESS_EW, 4, 25, true>;  // two 5-level transmons
-        if (int rc = set_lds_attr(ctx, kern, 7, lds)) return rc;
+        if (!jith)
+            if (int rc = set_lds_attr(ctx, kern, 7, lds)) return rc;
         const long long items = nbk * p.S;
         const int per_cu = std::max(1, std::min(2, (int)((size_t)ctx->max_lds / lds)));
         long long grid = std::min<long long>(items, (long long)per_cu * ctx->n_cu);
         if (ctx->opt_grid > 0) grid = std::min<long long>(items, ctx->opt_grid);
         void *args[] = {(void *)&p};
-        HIP_TRY(ctx, hipLaunchKernel(kern, dim3((unsigned)grid), dim3(256), args, lds, ctx->stream));
+        if (jith)
+            HIP_TRY(ctx, hipModuleLaunchKernel(jith, (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
+        else
+            HIP_TRY(ctx, hipLaunchKernel(kern, dim3((unsigned)grid), dim3(256), args, lds, ctx->stream));
         HIP_TRY(ctx, hipGetLastError());
-        ctx->last_hess_kernel = 2;
+        ctx->last_hess_kernel = jith ? 3 : 2;
         return PCL_OK;
     }
     // column chunk: as many columns as fit in half the LDS (two workgroups per CU)
@@ -1281,6 +1453,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_specialize = v != 0;
     else if (!strcmp(key, "stream_piece_cols"))  // kernel 3, role split: > 0 = stream pieces of this many columns, round-robin
         ctx->opt_snc = v;
+    else if (!strcmp(key, "jit"))  // 1 (default): compile the context's shape on first use when no static instance matches
+        ctx->opt_jit = v != 0;
     else if (!strcmp(key, "aligned_stream"))  // kernel 3: 1 = line-aligned flat block stream, 0 = per-block stores from registers (default)
         ctx->opt_flat = v != 0;
     else if (!strcmp(key, "general_pade_kernel"))  // 1: the general-order kernel also for pade_order 4
@@ -1338,6 +1512,12 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->last_kernel;
     else if (!strcmp(key, "contiguous"))
         *v = ctx->opt_contig;
+    else if (!strcmp(key, "jit"))
+        *v = ctx->opt_jit;
+    else if (!strcmp(key, "jit_compiles")) {
+        std::lock_guard<std::mutex> lock(g_jit_mutex);
+        *v = g_jit_compiles;
+    }
     else if (!strcmp(key, "stream_workgroups"))
         *v = ctx->opt_stream_wg;
     else if (!strcmp(key, "last_stream_workgroups"))

@@ -1149,6 +1149,56 @@ def test_other_specialised_shapes(levels, batch):
     close(vals, np.concatenate([r[1].reshape(-1) for r in refs]))
     mu = np.random.default_rng(1).standard_normal((batch, lay.K, lay.x_dim))
     hv = c.hess(np.stack(Zs), mu.reshape(-1))
-    assert c.get_option("last_hess_kernel") == 2
+    assert c.get_option("last_hess_kernel") == (2 if levels == 5 else 3)  # static instance at d = 25, compiled on first use at d = 16
     close(hv, np.concatenate([ref_lib.hess(Z, mu[i], lay, G0, Gj).reshape(-1) for i, Z in enumerate(Zs)]), 1e-10)
     c.close()
+
+
+def test_runtime_compiled_shape_instances():
+    """Shapes outside the static instance table are compiled on first use (hiprtc) with compile-time (d, m): fused
+    kernel 3 (role split) and Hessian kernel 2.  Same values as the run-time-shape kernels (`jit` = 0) and the C oracle."""
+    rng = np.random.default_rng(23)
+    d, m, Bn, N = 23, 5, 4, 100
+    lay, G0, _, _ = _random_case(d, m, N, rng)
+    n = 2 * d
+    Gj = np.zeros((m, n, n))
+    for l in range(m):  # two entries per row AND per column (circulant pattern), not antisymmetric
+        for i in range(n):
+            Gj[l, i, (i + l + 1) % n], Gj[l, i, (i - l - 1) % n] = rng.standard_normal(2)
+    Zs = []
+    for _ in range(Bn):
+        Z = 0.3 * rng.standard_normal((N, lay.z_dim))
+        Z[:, lay.dt_off] = 0.05 + 0.05 * rng.random(N)
+        Zs.append(Z)
+    c = make_ctx(lay, 0.2 * G0, Gj, batch=Bn, batch_mode=pa._lib.PCL_BATCH_TRAJ)
+    G0 = 0.2 * G0
+    n0 = c.get_option("jit_compiles")
+    c.set_option("kernel_version", 3)  # fused: the compiled instance replaces the run-time-shape instance of kernel 3
+    delta, vals = c.eval_jac(np.stack(Zs))
+    assert c.get_option("last_kernel") == 32 and c.get_option("last_stream_workgroups") > 0
+    assert c.get_option("jit_compiles") == n0 + 1
+    refs = [ref_lib.eval_jac(Z, lay, G0, Gj) for Z in Zs]
+    d_ref = np.concatenate([r[0].reshape(-1) for r in refs])
+    j_ref = np.concatenate([r[1].reshape(-1) for r in refs])
+    close(delta, d_ref, 1e-11)
+    close(vals, j_ref, 1e-11)
+    mu = rng.standard_normal((Bn, lay.K, lay.x_dim))
+    hv = c.hess(np.stack(Zs), mu.reshape(-1))
+    assert c.get_option("last_hess_kernel") == 3 and c.get_option("jit_compiles") == n0 + 1  # one module serves both
+    h_ref = np.concatenate([ref_lib.hess(Z, mu[i], lay, G0, Gj).reshape(-1) for i, Z in enumerate(Zs)])
+    close(hv, h_ref, 1e-10)
+    c.set_option("jit", 0)
+    c.set_option("kernel_version", 0)
+    d0, v0 = c.eval_jac(np.stack(Zs))
+    assert c.get_option("last_kernel") // 10 in (2, 4)
+    close(d0, d_ref, 1e-11)
+    close(v0, j_ref, 1e-11)
+    h0 = c.hess(np.stack(Zs), mu.reshape(-1))
+    assert c.get_option("last_hess_kernel") == 2
+    close(h0, h_ref, 1e-10)
+    c.close()
+    c2 = make_ctx(lay, G0, Gj, batch=Bn, batch_mode=pa._lib.PCL_BATCH_TRAJ)  # same shape again: served from the process cache
+    c2.set_option("kernel_version", 3)
+    c2.eval_jac(np.stack(Zs))
+    assert c2.get_option("last_kernel") == 32 and c2.get_option("jit_compiles") == n0 + 1
+    c2.close()
