@@ -507,9 +507,9 @@ extern "C" int pcl_hess_structure_i64(const pcl_ctx *ctx, int64_t *rows, int64_t
 #include <map>
 #include <mutex>
 namespace {
-struct JitKernels {
+struct JitKernel {
     hipModule_t mod = nullptr;
-    hipFunction_t fused = nullptr, hess = nullptr;
+    hipFunction_t fn = nullptr;
     bool failed = false;
 };
 struct HiprtcApi {
@@ -525,7 +525,7 @@ struct HiprtcApi {
     int (*DestroyProgram)(void **) = nullptr;
 };
 std::mutex g_jit_mutex;
-std::map<std::string, JitKernels> g_jit;  // key: device | ew | d | m | ncw | anti
+std::map<std::string, JitKernel> g_jit;  // key: device | template instance
 HiprtcApi g_rtc;
 int64_t g_jit_compiles = 0;
 std::string g_jit_note;
@@ -570,14 +570,13 @@ bool slurp(const std::string &path, std::string &out) {
     return !out.empty();
 }
 
-// Compile (once per process and shape) the fused kernel 3 and the Hessian kernel 2 for compile-time (d, m).
-const JitKernels *jit_get(int device, int ew, int d, int m, int ncw, bool anti, bool want_hess) {
-    char key[96];
-    snprintf(key, sizeof key, "%d|%d|%d|%d|%d|%d|%d", device, ew, d, m, ncw, anti ? 1 : 0, want_hess ? 1 : 0);
+// Compile (once per process, device and instance) one template instance, e.g. "pcl_hess_kernel_v2<2, 4, 24, true>".
+hipFunction_t jit_function(int device, const char *instance) {
+    const std::string key = std::to_string(device) + "|" + instance;
     std::lock_guard<std::mutex> lock(g_jit_mutex);
     auto it = g_jit.find(key);
-    if (it != g_jit.end()) return it->second.failed ? nullptr : &it->second;
-    JitKernels &jk = g_jit[key];
+    if (it != g_jit.end()) return it->second.failed ? nullptr : it->second.fn;
+    JitKernel &jk = g_jit[key];
     jk.failed = true;
     if (!rtc_load()) return nullptr;
     Dl_info info;
@@ -588,32 +587,28 @@ const JitKernels *jit_get(int device, int ew, int d, int m, int ncw, bool anti, 
     std::string dir(info.dli_fname);
     const size_t slash = dir.find_last_of('/');
     dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
-    const char *names[] = {"pcl_device_common.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp"};
-    std::string hdr[3];
-    const char *hdrp[3];
-    for (int i = 0; i < 3; ++i) {
+    const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp"};
+    std::string hdr[4];
+    const char *hdrp[4];
+    for (int i = 0; i < 4; ++i) {
         if (!slurp(dir + "/" + names[i], hdr[i])) {
             g_jit_note = "kernel header not found next to the library: " + dir + "/" + names[i];
             return nullptr;
         }
         hdrp[i] = hdr[i].c_str();
     }
-    const char *src = "#include \"pcl_device_common.hpp\"\n#include \"pcl_kernel_fused_v3.hpp\"\n#include \"pcl_kernels_hessian.hpp\"\n";
+    const char *src = "#include \"pcl_device_common.hpp\"\n#include \"pcl_kernels_fused_v2.hpp\"\n#include \"pcl_kernel_fused_v3.hpp\"\n"
+                      "#include \"pcl_kernels_hessian.hpp\"\n";
     void *prog = nullptr;
-    if (g_rtc.CreateProgram(&prog, src, "pcl_jit.hip", 3, hdrp, names) != 0) {
+    if (g_rtc.CreateProgram(&prog, src, "pcl_jit.hip", 4, hdrp, names) != 0) {
         g_jit_note = "hiprtcCreateProgram failed";
         return nullptr;
     }
-    char nf[96], nh[96];
-    snprintf(nf, sizeof nf, "pcl_fused_kernel_v3<%d, %d, %d, %d>", ew, d, m, ncw);
-    snprintf(nh, sizeof nh, "pcl_hess_kernel_v2<2, %d, %d, %s>", m, d, anti ? "true" : "false");
-    g_rtc.AddNameExpression(prog, nf);
-    if (want_hess) g_rtc.AddNameExpression(prog, nh);
+    g_rtc.AddNameExpression(prog, instance);
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    const int rc = g_rtc.CompileProgram(prog, 3, opts);
-    if (rc != 0) {
+    if (g_rtc.CompileProgram(prog, 3, opts) != 0) {
         size_t ls = 0;
-        g_jit_note = "hiprtcCompileProgram failed";
+        g_jit_note = std::string("hiprtcCompileProgram failed for ") + instance;
         if (g_rtc.GetProgramLogSize && g_rtc.GetProgramLog && g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
             std::string log(ls, '\0');
             g_rtc.GetProgramLog(prog, &log[0]);
@@ -622,23 +617,21 @@ const JitKernels *jit_get(int device, int ew, int d, int m, int ncw, bool anti, 
         g_rtc.DestroyProgram(&prog);
         return nullptr;
     }
-    const char *lf = nullptr, *lh = nullptr;
+    const char *lowered = nullptr;
     size_t cs = 0;
-    g_rtc.GetLoweredName(prog, nf, &lf);
-    if (want_hess) g_rtc.GetLoweredName(prog, nh, &lh);
+    g_rtc.GetLoweredName(prog, instance, &lowered);
     g_rtc.GetCodeSize(prog, &cs);
     std::vector<char> code(cs);
     g_rtc.GetCode(prog, code.data());
-    std::string slf = lf ? lf : "", slh = lh ? lh : "";
+    const std::string lname = lowered ? lowered : "";
     g_rtc.DestroyProgram(&prog);
-    if (hipModuleLoadData(&jk.mod, code.data()) != hipSuccess || slf.empty() || hipModuleGetFunction(&jk.fused, jk.mod, slf.c_str()) != hipSuccess) {
+    if (lname.empty() || hipModuleLoadData(&jk.mod, code.data()) != hipSuccess || hipModuleGetFunction(&jk.fn, jk.mod, lname.c_str()) != hipSuccess) {
         g_jit_note = "hipModuleLoadData / hipModuleGetFunction failed";
         return nullptr;
     }
-    if (want_hess && (slh.empty() || hipModuleGetFunction(&jk.hess, jk.mod, slh.c_str()) != hipSuccess)) jk.hess = nullptr;
     jk.failed = false;
     ++g_jit_compiles;
-    return &jk;
+    return jk.fn;
 }
 }  // namespace
 
@@ -910,8 +903,9 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         }
         hipFunction_t jitf = nullptr;  // run-time compiled instance for this context's shape
         if (!spec3 && ctx->opt_jit && ctx->opt_specialize && ewr >= 1) {
-            const JitKernels *jk = jit_get(ctx->device, ewr, p.d, p.m, p.ncw, ctx->drives_antisym != 0, hess_v2_supported(ctx));
-            if (jk) jitf = jk->fused;
+            char inst[96];
+            snprintf(inst, sizeof inst, "pcl_fused_kernel_v3<%d, %d, %d, %d>", ewr, p.d, p.m, p.ncw);
+            jitf = jit_function(ctx->device, inst);
         }
         if (!spec3 && !jitf && ctx->opt_kernel == 0) goto not_v3;  // auto never runs the run-time-shape instances
         ctx->last_kernel = jitf ? 32 : 30 + (spec3 ? 1 : 0);
@@ -968,10 +962,24 @@ not_v3:
             kern = wu == 1 ? (kern_t)pcl_fused_kernel_v4<1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v4<2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v4<-1, 0, 0, 0>;
             if (wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize) kern = (kern_t)pcl_fused_kernel_v4<1, 27, 6, 3>;
         }
+        // jit = 2 (experiment): compile-time (d, m, slice width) for kernels 2 / 4 too -- measured from -8 % to +30 % depending
+        // on the shape (scripts/jit_probe.py), so not part of the default
+        hipFunction_t jit2 = nullptr;
+        const bool static2 = unitary && wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize && want_jac;
+        if (!static2 && ctx->opt_jit >= 2 && ctx->opt_specialize && want_jac && unitary && wu >= 1 && p.d >= 12 && ctx->opt_kernel != 5) {
+            char inst[96];
+            if (v4)
+                snprintf(inst, sizeof inst, "pcl_fused_kernel_v4<%d, %d, %d, %d>", wu, p.d, p.m, p.nc);
+            else
+                snprintf(inst, sizeof inst, "pcl_fused_kernel_v2<true, %d, %d, %d, %d>", wu, p.d, p.m, p.nc);
+            jit2 = jit_function(ctx->device, inst);
+        }
         ctx->last_n_stream = 0;
-        ctx->last_kernel = (v4 ? 40 : 20) + ((unitary && wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize && want_jac) ? 1 : 0);
-        int rc = set_lds_attr(ctx, (const void *)kern, want_jac ? 4 : 5, lds);  // wu is fixed per context
-        if (rc != PCL_OK) return rc;
+        ctx->last_kernel = jit2 ? (v4 ? 42 : 22) : (v4 ? 40 : 20) + ((unitary && wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize && want_jac) ? 1 : 0);
+        if (!jit2) {
+            int rc = set_lds_attr(ctx, (const void *)kern, want_jac ? 4 : 5, lds);  // wu is fixed per context
+            if (rc != PCL_OK) return rc;
+        }
         const bool split = ctx->opt_kernel == 5 && want_jac && !compact && unitary;
         if (split) {
             const long long n_bk = (long long)p.batch * p.K;
@@ -996,7 +1004,11 @@ not_v3:
         const int per_cu = std::max(1, std::min(2, (int)((size_t)ctx->max_lds / lds)));
         const long long resident = (long long)per_cu * std::max(ctx->n_cu, 1);
         const long long g2 = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, grid) : std::min(grid, resident);
-        if (!(split && (ctx->opt_ablate & 64))) hipLaunchKernelGGL(kern, dim3((unsigned)g2), dim3(512), lds, ctx->stream, p);
+        if (jit2) {
+            void *args[] = {(void *)&p};
+            HIP_TRY(ctx, hipModuleLaunchKernel(jit2, (unsigned)g2, 1, 1, 512, 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
+        } else if (!(split && (ctx->opt_ablate & 64)))
+            hipLaunchKernelGGL(kern, dim3((unsigned)g2), dim3(512), lds, ctx->stream, p);
         if (split) {
             // the expander leaves wave slots and all LDS to the producer: at most 4 x 256 threads per CU
             const int cpp = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_cpp, 2 * p.d));
@@ -1090,8 +1102,9 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
         hipFunction_t jith = nullptr;
         const bool hess_static = ctx->opt_specialize && ctx->drives_antisym && ((p.d == 27 && p.m == 6) || (p.d == 25 && p.m == 4));
         if (!hess_static && ctx->opt_jit && ctx->opt_specialize && ctx->cols == ctx->desc.d && ctx->ell_w >= 1 && p.d >= 12) {  // small d: launch-bound either way
-            const JitKernels *jk = jit_get(ctx->device, ctx->ell_w, p.d, p.m, v3_ncw(ctx, p.d), ctx->drives_antisym != 0, true);
-            if (jk) jith = jk->hess;
+            char inst[96];
+            snprintf(inst, sizeof inst, "pcl_hess_kernel_v2<%d, %d, %d, %s>", PCL_HESS_EW, p.m, p.d, ctx->drives_antisym ? "true" : "false");
+            jith = jit_function(ctx->device, inst);
         }
         const void *kern = ctx->drives_antisym ? hess_v2_kernel<PCL_HESS_EW, true>(p.m) : hess_v2_kernel<PCL_HESS_EW, false>(p.m);
         if (ctx->opt_specialize && p.d == 27 && p.m == 6 && ctx->drives_antisym)
@@ -1453,8 +1466,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_specialize = v != 0;
     else if (!strcmp(key, "stream_piece_cols"))  // kernel 3, role split: > 0 = stream pieces of this many columns, round-robin
         ctx->opt_snc = v;
-    else if (!strcmp(key, "jit"))  // 1 (default): compile the context's shape on first use when no static instance matches
-        ctx->opt_jit = v != 0;
+    else if (!strcmp(key, "jit"))  // 1 (default): compile the context's shape on first use when no static instance matches; 2: also kernels 2 / 4
+        ctx->opt_jit = v < 0 ? 0 : (v > 2 ? 2 : v);
     else if (!strcmp(key, "aligned_stream"))  // kernel 3: 1 = line-aligned flat block stream, 0 = per-block stores from registers (default)
         ctx->opt_flat = v != 0;
     else if (!strcmp(key, "general_pade_kernel"))  // 1: the general-order kernel also for pade_order 4
