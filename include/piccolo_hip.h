@@ -194,6 +194,7 @@ typedef struct pcl_comm_id { char bytes[128]; } pcl_comm_id;
 int pcl_comm_get_unique_id(pcl_comm_id *out);
 int pcl_comm_init(pcl_ctx *ctx, const pcl_comm_id *id, int32_t rank, int32_t nranks);
 int pcl_reduce_sum_dev(pcl_ctx *ctx, double *buf_dev, int64_t n);
+int pcl_reduce_sum(pcl_ctx *ctx, double *buf_host, int64_t n); /* same for a host buffer (staged; returns after the sum) */
 int pcl_comm_destroy(pcl_ctx *ctx);
 
 /* tuning / introspection ---------------------------------------------------- */

@@ -30,7 +30,7 @@ EXPORTS = [
     "pcl_jac_compact_nnz", "pcl_eval_jac_compact_dev", "pcl_jac_expand_dev",
     "pcl_deriv_nnz", "pcl_deriv_structure", "pcl_deriv_eval_jac", "pcl_deriv_eval_jac_dev",
     "pcl_set_goal", "pcl_infidelity_dev", "pcl_rollout", "pcl_rollout_dev",
-    "pcl_comm_get_unique_id", "pcl_comm_init", "pcl_reduce_sum_dev", "pcl_comm_destroy",
+    "pcl_comm_get_unique_id", "pcl_comm_init", "pcl_reduce_sum_dev", "pcl_reduce_sum", "pcl_comm_destroy",
     "pcl_set_option", "pcl_get_option", "pcl_debug_timing",
 ]  # fmt: skip
 
@@ -133,6 +133,7 @@ def load():
     L.pcl_comm_get_unique_id.argtypes = [ctypes.c_char_p]
     L.pcl_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32]
     L.pcl_reduce_sum_dev.argtypes = [vp, vp, ctypes.c_int64]
+    L.pcl_reduce_sum.argtypes = [vp, vp, ctypes.c_int64]
     L.pcl_comm_destroy.argtypes = [vp]
     L.pcl_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     L.pcl_get_option.argtypes = [vp, ctypes.c_char_p, c_i64p]

@@ -61,6 +61,8 @@ struct pcl_ctx {
     int ellt_w = 0;
     int drives_antisym = 0;  // every G_l == -G_l^T exactly
     double *dug0 = nullptr;
+    double *dreduce = nullptr;  // staging of pcl_reduce_sum (host buffer)
+    int64_t reduce_cap = 0;
     double *dexpm = nullptr, *dxout = nullptr;  // rollout scratch: propagators, staged output of the host-pointer call
     double *dhpart = nullptr;  // Hessian v2 scratch: per (b,k,slice) partial scalar entries + per (b,k) arrival counters
     unsigned int *dhcnt = nullptr;
@@ -373,7 +375,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     void *ptrs[] = {ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
                     ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg, ctx->dellt_col, ctx->dellt_val,
-                    ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout};
+                    ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout, ctx->dreduce};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (ctx->dgoal) (void)hipFree(ctx->dgoal);
@@ -1438,6 +1440,25 @@ extern "C" int pcl_reduce_sum_dev(pcl_ctx *ctx, double *buf_dev, int64_t n) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int nrc = g_rccl.AllReduce(buf_dev, buf_dev, (size_t)n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
     return nrc == 0 ? PCL_OK : rccl_fail(ctx, "ncclAllReduce", nrc);
+}
+extern "C" int pcl_reduce_sum(pcl_ctx *ctx, double *buf, int64_t n) {  // host buffer, staged through device memory; synchronous
+    if (!ctx) return PCL_EINVAL;
+    if (!buf || n < 0) return fail(ctx, PCL_EINVAL, "pcl_reduce_sum: bad buffer");
+    if (!ctx->comm) return fail(ctx, PCL_ERCCL, "pcl_reduce_sum: call pcl_comm_init first");
+    if (n == 0) return PCL_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->reduce_cap < n) {
+        if (ctx->dreduce) (void)hipFree(ctx->dreduce);
+        ctx->dreduce = nullptr;
+        ctx->reduce_cap = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->dreduce, (size_t)n * sizeof(double)));
+        ctx->reduce_cap = n;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dreduce, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = pcl_reduce_sum_dev(ctx, ctx->dreduce, n)) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(buf, ctx->dreduce, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
 }
 extern "C" int pcl_comm_destroy(pcl_ctx *ctx) {
     if (!ctx) return PCL_EINVAL;

@@ -247,6 +247,11 @@ class _PclContext:
     def reduce_sum_dev(self, buf):
         self._chk(self._L.pcl_reduce_sum_dev(self._h, _ptr(buf), buf.numel()))
 
+    def reduce_sum(self, buf):
+        """In-place sum over the ranks of a host (numpy, float64, contiguous) buffer."""
+        self._chk(self._L.pcl_reduce_sum(self._h, _ptr(buf), buf.size))
+        return buf
+
     def set_option(self, key, value):
         self._chk(self._L.pcl_set_option(self._h, key.encode(), int(value)))
 

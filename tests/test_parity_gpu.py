@@ -515,6 +515,8 @@ def test_rccl_reduce_through_the_c_abi_single_rank():
     c.reduce_sum_dev(buf)
     torch.cuda.synchronize()
     assert torch.equal(buf.cpu(), torch.arange(700, dtype=torch.float64))
+    hb = np.arange(811, dtype=np.float64)  # host-buffer variant (what a Julia host holds): staged, synchronous
+    assert np.array_equal(c.reduce_sum(hb), np.arange(811, dtype=np.float64))
     with pytest.raises(pa.PclError):
         c.comm_init(uid, 0, 1)  # already initialised
     c.close()
