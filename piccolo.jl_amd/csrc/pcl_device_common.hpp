@@ -2,6 +2,10 @@
 // (included by piccolo_hip.hip only; gfx950).
 #pragma once
 
+// debug_timing buffer: 64 phase stamps of workgroup 0, then per-workgroup start / end times (s_memrealtime, 100 MHz) of kernel 3
+#define PCL_DBG_WG 1024
+#define PCL_DBG_WORDS (64 + 2 * PCL_DBG_WG)
+
 #define PCL_NSP 8   // B^{+-} value pairs per thread of a 256-thread group: (n*n/2) / 256 <= 8 for n <= 64
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -43,6 +47,8 @@ struct KParams {
     int ncw;      // v3: state columns per matrix-wave chunk ((2+m)*ncw <= 16)
     int tab_lds;  // v3: union / ELL tables staged in LDS
     int contig;   // v3: 1 = contiguous column ranges per workgroup (see the kernel), 0 = items dealt round-robin
+    int sdyn;     // v3, role split with snc > 0: 1 = the stream pieces are handed out by a launch-wide ticket counter
+    unsigned int *sctr;  // ... the counter (zero between launches)
     int snc;      // v3, role split: > 0 = the stream workgroups take pieces of snc columns round-robin (0: contiguous ranges)
     int flat;     // v3: 1 = line-aligned flat block stream (values recomputed from LDS per store), 0 = per-block stores from registers
     int all_matrix; // v3, contig: 1 = every workgroup takes the matrix role (compact Jacobian)

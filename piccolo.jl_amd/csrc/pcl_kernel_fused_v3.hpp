@@ -39,6 +39,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     extern __shared__ double lds[];
     const int d = TD ? TD : p.d, n = 2 * d, m = TD ? TM : p.m, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD;
     const int tid = threadIdx.x;
+    if (p.dbg && tid == 0 && blockIdx.x < PCL_DBG_WG) p.dbg[64 + blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
     const int wave = tid >> 6, lane = tid & 63;
     const int nn = n * n;
     const int ew = p.ell_w, uw = p.uell_w, n_ell = m * n * ew, n_un = p.n_upos;
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     double *wbuf = G2b + 2 * tile;  // per matrix wave
     const int wsz = LD * (CW + 3 * ncw);
     double *us = wbuf + 4 * wsz;
-    double *t_unv = us + 3 * (m + 1);
+    int *sitem = reinterpret_cast<int *>(us + 3 * (m + 1));  // dynamic stream pieces: tickets of items it, it+1, it+2 (mod 4)
+    double *t_unv = us + 3 * (m + 1) + 2;
     double *t_ung0 = t_unv + (p.tab_lds ? n_un * uw : 0);
     double *t_ellv = t_ung0 + (p.tab_lds ? n_un : 0);
     unsigned short *t_uni = reinterpret_cast<unsigned short *>(t_ellv + (p.tab_lds ? n_ell : 0));
@@ -80,6 +82,12 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     // write one window of ~n_stream/S consecutive intervals instead of n_stream far-apart ranges)
     const bool srr = stream_role && p.snc > 0;
     const int sS = srr ? (d + p.snc - 1) / p.snc : 1;
+    // ... or handed out dynamically (p.sdyn): equal byte shares do not finish together -- with every CU streaming the same
+    // number of bytes the slowest stream workgroup ends 15-20 % after the mean (scripts/wg_timeline.py) -- so a stream
+    // workgroup takes its next piece from a launch-wide ticket counter (self-resetting: the last ticket zeroes it)
+    const bool sdyn = srr && p.sdyn;
+    const int n_items_s = p.batch * p.K * sS;
+    auto alive = [&](int it) { return sdyn ? sitem[it & 3] < n_items_s : it < n_my; };
     if (p.contig && !srr) {
         const long long tot = (long long)p.batch * p.K * d;
         const long long widx = (matrix_role && !p.all_matrix) ? (long long)blockIdx.x - p.n_stream : (long long)blockIdx.x;
@@ -91,6 +99,13 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     } else if (srr) {
         const int n_items = p.batch * p.K * sS;
         n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + p.n_stream - 1) / p.n_stream : 0;
+        if (sdyn) {  // two tickets ahead: the matrix waves build item it+1 while item it streams
+            if (tid == 0) {
+                sitem[0] = (int)__hip_atomic_fetch_add(p.sctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sitem[1] = (int)__hip_atomic_fetch_add(p.sctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
     } else {
         const int n_items = p.batch * p.K * p.S;
         n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
@@ -105,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             b = (int)(bk / p.K);
         } else {
             const int S_ = srr ? sS : p.S, nc_ = srr ? p.snc : nc;
-            const int item = blockIdx.x + it * (srr ? p.n_stream : (int)gridDim.x);
+            const int item = sdyn ? sitem[it & 3] : blockIdx.x + it * (srr ? p.n_stream : (int)gridDim.x);
             const int s = item % S_;
             c0 = s * nc_;
             nce = min(nc_, d - c0);
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
 
     // item 0's controls / time step: requested before the prologue's table loads so that the latencies overlap
     double u0 = 0.0;
-    if (n_my > 0 && wave < 4 && lane <= m) {
+    if (alive(0) && wave < 4 && lane <= m) {
         int c00, nce0, k0, b0;
         decode(0, c00, nce0, k0, b0);
         const double *z0 = p.Z + (long long)b0 * p.z_batch_stride + (long long)k0 * p.z_dim;
@@ -263,10 +278,10 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             }
         };
 
-        if (n_my > 0 && wave < 4) build(0, 0, u0);
+        if (alive(0) && wave < 4) build(0, 0, u0);
         __syncthreads();  // item 0's G, G^2 complete
 
-        for (int it = 0; it < n_my; ++it) {
+        for (int it = 0; alive(it); ++it) {
             const int cur = matrix_role ? 0 : (it & 1);
             int c0, nce, k, b;
             decode(it, c0, nce, k, b);
@@ -311,7 +326,12 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                     }
             }
             double pf_u = 0.0;  // next item's u_k / dt_k (consumed by build)
-            if (it + 1 < n_my && lane <= m && wave < 4) {
+            if (sdyn && tid == 0) {  // ticket of item it+2 (visible to both wave groups after this item's barrier)
+                const unsigned int tk = __hip_atomic_fetch_add(p.sctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sitem[(it + 2) & 3] = (int)tk;
+                if (tk == (unsigned int)(n_items_s + 2 * p.n_stream - 1)) __hip_atomic_store(p.sctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (alive(it + 1) && lane <= m && wave < 4) {
                 int c02, nce2, k2, b2;
                 decode(it + 1, c02, nce2, k2, b2);
                 const double *zk2 = p.Z + (long long)b2 * p.z_batch_stride + (long long)k2 * p.z_dim;
@@ -518,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             }
             // ---- next item's G(u), G^2 into the other buffer ----------------------------------------------------
             if (matrix_role) __syncthreads();  // single-buffered G, G^2: every wave is done with this item's tiles
-            if (it + 1 < n_my && wave < 4) build(it + 1, matrix_role ? 0 : cur ^ 1, pf_u);
+            if (alive(it + 1) && wave < 4) build(it + 1, matrix_role ? 0 : cur ^ 1, pf_u);
             PCL_STAMP();  // next G, G^2 built
             __syncthreads();  // item boundary
             PCL_STAMP();  // barrier passed
@@ -530,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
         const int pi = 2 * (stid % hn), pj0 = stid / hn, pstep = max(256 / hn, 1);
         const bool pact = pj0 < pstep;
         __syncthreads();  // item 0's G, G^2 complete
-        for (int it = 0; it < n_my; ++it) {
+        for (int it = 0; alive(it); ++it) {
             const int cur = it & 1;
             int c0, nce, k, b;
             decode(it, c0, nce, k, b);
@@ -614,5 +634,9 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             }
             __syncthreads();  // item boundary
         }
+    }
+    if (p.dbg && tid == 256 && blockIdx.x < PCL_DBG_WG) {  // wave 4: a stream wave, or a matrix wave of a matrix-role workgroup
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // its stores have left the CU
+        p.dbg[64 + PCL_DBG_WG + blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 }

@@ -82,6 +82,8 @@ struct pcl_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int64_t opt_cpp = 6;  // block copies per expander work item
     int64_t opt_specialize = 1;
+    int64_t opt_sdyn = 1;     // v3, role split: stream pieces handed out dynamically (when opt_snc > 0)
+    unsigned int *dsctr = nullptr;
     int64_t opt_snc = 0;      // v3, role split: stream pieces of this many columns dealt round-robin (0: contiguous ranges)
     int64_t opt_jit = 1;      // compile shape-specialised instances on first use (hiprtc) for shapes outside the static table
     int64_t opt_flat = 0;     // v3: line-aligned flat block stream (measured: no gain over the per-block stores, slower for one trajectory)
@@ -375,7 +377,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     void *ptrs[] = {ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
                     ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg, ctx->dellt_col, ctx->dellt_val,
-                    ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout, ctx->dreduce};
+                    ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout, ctx->dreduce, ctx->dsctr};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (ctx->dgoal) (void)hipFree(ctx->dgoal);
@@ -745,7 +747,7 @@ static int v3_ncw(const pcl_ctx *ctx, int nc) { return std::max(1, std::min(nc, 
 static size_t fused3_lds_bytes(const pcl_ctx *ctx, const KParams &p, bool tab) {  // version-3 kernel
     const size_t tile = (size_t)p.LD * p.n, wsz = (size_t)p.LD * (16 + 3 * p.ncw);
     const size_t n_ell = (size_t)p.m * p.n * p.ell_w, n_un = (size_t)ctx->n_upos, uw = (size_t)ctx->uell_w;
-    size_t bytes = (4 * tile + 4 * wsz + 3 * (size_t)(p.m + 1)) * sizeof(double);
+    size_t bytes = (4 * tile + 4 * wsz + 3 * (size_t)(p.m + 1) + 2) * sizeof(double);
     if (tab) bytes += (n_un * uw + n_un + n_ell) * sizeof(double) + (n_un + n_ell) * 2 + n_un * uw;
     return (bytes + 7) / 8 * 8 + 128;  // slack: operand tiles may be read past the last buffer's edge
 }
@@ -877,6 +879,12 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         p.all_matrix = compact ? 1 : 0;
         p.flat = ctx->opt_flat ? 1 : 0;
         p.snc = (int)std::max<int64_t>(0, std::min<int64_t>(ctx->opt_snc, p.d));
+        p.sdyn = (p.snc > 0 && ctx->opt_sdyn) ? 1 : 0;
+        if (p.sdyn && !ctx->dsctr) {
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->dsctr, sizeof(unsigned int)));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dsctr, 0, sizeof(unsigned int), ctx->stream));
+        }
+        p.sctr = ctx->dsctr;
         p.nc = p.contig ? p.d : choose_cols_v3(ctx);
         if (!p.contig && ctx->opt_cols_per_slice <= 0 && p.nc < 2 && p.d >= 2) p.nc = 2;  // keep the 2-column chunks of the specialised instance
         p.ncw = v3_ncw(ctx, p.nc);
@@ -1485,6 +1493,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_cpp = v;
     else if (!strcmp(key, "specialize"))  // 0: always the run-time-shape kernel instances
         ctx->opt_specialize = v != 0;
+    else if (!strcmp(key, "stream_dynamic"))  // kernel 3, role split with stream_piece_cols > 0: 1 = ticket counter, 0 = round-robin
+        ctx->opt_sdyn = v != 0;
     else if (!strcmp(key, "stream_piece_cols"))  // kernel 3, role split: > 0 = stream pieces of this many columns, round-robin
         ctx->opt_snc = v;
     else if (!strcmp(key, "jit"))  // 1 (default): compile the context's shape on first use when no static instance matches; 2: also kernels 2 / 4
@@ -1503,8 +1513,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
     }
     else if (!strcmp(key, "debug_timing")) {  // profiling aid: cycle stamps of workgroup 0 (pcl_debug_timing reads them)
         if (v && !ctx->ddbg) {
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->ddbg, 64 * sizeof(long long)));
-            HIP_TRY(ctx, hipMemset(ctx->ddbg, 0, 64 * sizeof(long long)));
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->ddbg, PCL_DBG_WORDS * sizeof(long long)));
+            HIP_TRY(ctx, hipMemset(ctx->ddbg, 0, PCL_DBG_WORDS * sizeof(long long)));
         } else if (!v && ctx->ddbg) {
             (void)hipFree(ctx->ddbg);
             ctx->ddbg = nullptr;
@@ -1522,7 +1532,7 @@ extern "C" int pcl_debug_timing(pcl_ctx *ctx, int64_t *out, int64_t cap) {
     if (!ctx || !out || cap < 0) return PCL_EINVAL;
     if (!ctx->ddbg) return fail(ctx, PCL_EINVAL, "pcl_debug_timing: set option debug_timing first");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out, ctx->ddbg, (size_t)std::min<int64_t>(cap, 64) * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->ddbg, (size_t)std::min<int64_t>(cap, PCL_DBG_WORDS) * sizeof(long long), hipMemcpyDeviceToHost));
     return PCL_OK;
 }
 

@@ -676,6 +676,14 @@ def test_contiguous_column_ranges_any_grid():
             c.set_option("aligned_stream", flat)
             delta, vals = c.eval_jac(np.stack(Zs))
             assert np.array_equal(vals, j_rr) and np.array_equal(delta, d_rr), (grid, ns, flat)
+        c.set_option("aligned_stream", 0)
+        for snc, dyn in ((5, 0), (5, 1), (27, 1), (1, 1)):  # stream pieces: round-robin / handed out by a ticket counter
+            c.set_option("stream_piece_cols", snc)
+            c.set_option("stream_dynamic", dyn)
+            for _ in range(2):  # twice: the ticket counter resets itself
+                delta, vals = c.eval_jac(np.stack(Zs))
+                assert np.array_equal(vals, j_rr) and np.array_equal(delta, d_rr), (grid, ns, snc, dyn)
+        c.set_option("stream_piece_cols", 0)
     ms.close()
 
 
