@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void pcl_pade_kernel(const KParams p) {
     // ---- blocks: B^{+-} = sum_j c_j (+-h)^j G^j ------------------------------------------------------------------
     // each thread owns the flat column-major positions (2q', 2q'+1), q' = tid + 256 r; for an odd n (compact density
     // vectors) the two positions may lie in different columns and the stores are scalar (blocks are not 16-byte aligned)
-    {
+    if (!(p.compact && s != 0)) {  // compact layout: only slice 0 writes (and therefore forms) the blocks
         const int nn_ = n * n, half = (nn_ + 1) >> 1;
         const bool even = !(n & 1);
         double bp[PCL_NSP][2], bm[PCL_NSP][2];

@@ -61,6 +61,9 @@ struct pcl_ctx {
     int ellt_w = 0;
     int drives_antisym = 0;  // every G_l == -G_l^T exactly
     double *dug0 = nullptr;
+    double *dcompact = nullptr;  // general-order kernel: unique tiles before the expansion kernel replicates them
+    long long compact_cap = 0;
+    int64_t opt_general_two_step = 0;  // measured slower (the general-order kernel is compute-bound, not store-bound)
     double *dreduce = nullptr;  // staging of pcl_reduce_sum (host buffer)
     int64_t reduce_cap = 0;
     double *dexpm = nullptr, *dxout = nullptr;  // rollout scratch: propagators, staged output of the host-pointer call
@@ -377,7 +380,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     void *ptrs[] = {ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
                     ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg, ctx->dellt_col, ctx->dellt_val,
-                    ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout, ctx->dreduce, ctx->dsctr};
+                    ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout, ctx->dreduce, ctx->dsctr, ctx->dcompact};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (ctx->dgoal) (void)hipFree(ctx->dgoal);
@@ -850,8 +853,32 @@ static int launch_pade_general(pcl_ctx *ctx, KParams &p, bool want_jac) {
     typedef void (*kern_t)(const KParams);
     kern_t kern = want_jac ? (kern_t)pcl_pade_kernel<true> : (kern_t)pcl_pade_kernel<false>;
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // Option general_two_step (off: measured 7-50 % slower, the kernel is compute-bound): the kernel writes the unique tiles
+    // into a context scratch (compact layout: the powers of G are formed by slice 0 only) and the streaming expansion kernel
+    // replicates them
+    double *jac_full = nullptr;
+    if (want_jac && !p.compact && p.cols > 1 && ctx->opt_general_two_step) {
+        const long long need = (long long)p.batch * p.K * jac_per_compact(ctx);
+        if (ctx->compact_cap < need) {
+            if (ctx->dcompact) (void)hipFree(ctx->dcompact);
+            ctx->dcompact = nullptr;
+            ctx->compact_cap = 0;
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->dcompact, (size_t)need * sizeof(double)));
+            ctx->compact_cap = need;
+        }
+        jac_full = p.jac;
+        p.jac = ctx->dcompact;
+        p.compact = 1;
+        p.jac_per = jac_per_compact(ctx);
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
+    if (jac_full) {
+        const long long n_bk = (long long)p.batch * p.K;
+        hipLaunchKernelGGL(pcl_expand_kernel, dim3((unsigned)(n_bk * p.cols)), dim3(256), 0, ctx->stream, (const double *)ctx->dcompact, jac_full,
+                           p.cols, p.n, p.m, n_bk, (int)ctx->opt_nt);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     ctx->last_kernel = 90 + p.q;
     ctx->last_n_stream = 0;
     return PCL_OK;
@@ -1501,6 +1528,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_jit = v < 0 ? 0 : (v > 2 ? 2 : v);
     else if (!strcmp(key, "aligned_stream"))  // kernel 3: 1 = line-aligned flat block stream, 0 = per-block stores from registers (default)
         ctx->opt_flat = v != 0;
+    else if (!strcmp(key, "general_two_step"))  // general-order kernel: 1 = unique tiles + expansion kernel, 0 (default) = one kernel writes every copy
+        ctx->opt_general_two_step = v != 0;
     else if (!strcmp(key, "general_pade_kernel"))  // 1: the general-order kernel also for pade_order 4
         ctx->opt_general = v != 0;
     else if (!strcmp(key, "stream_workgroups"))  // kernel 3, contiguous: > 0 = role split with this many stream-role workgroups

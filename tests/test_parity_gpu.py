@@ -731,10 +731,12 @@ def test_general_pade_orders_vs_oracle(order, cfg, N):
         c.set_option("general_pade_kernel", 1)
     for cps in (0, 1, 2, 5):
         c.set_option("cols_per_slice", cps)
-        delta, vals = c.eval_jac(Z)
-        assert c.get_option("last_kernel") == 90 + order // 2
-        close(delta, d_ref, 1e-11)
-        close(vals, j_ref, 1e-11)
+        for two_step in (0, 1):  # one kernel writes every copy (default) / unique tiles + expansion kernel
+            c.set_option("general_two_step", two_step)
+            delta, vals = c.eval_jac(Z)
+            assert c.get_option("last_kernel") == 90 + order // 2
+            close(delta, d_ref, 1e-11)
+            close(vals, j_ref, 1e-11)
         close(c.eval(Z), d_ref, 1e-11)
     if order == 4:
         close(delta, d4)
