@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the batch-1 (single trajectory) measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even for one rank: exercises the multi-rank code path on one GPU")
     ap.add_argument("--no-extras", action="store_true", help="skip the Hessian / compact / host-delivered / config-2 rates")
     args = ap.parse_args()
 
@@ -87,7 +88,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the evaluator has no CPU path)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
