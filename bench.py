@@ -88,10 +88,16 @@ def main():
         raise SystemExit("bench.py needs a GPU (the evaluator has no CPU path)")
     torch.cuda.set_device(local)
     dist = None
+    saved_stdout = None
     if world > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL prints a version banner on stdout when the communicator comes up; the contract is ONE JSON line on stdout,
+        # so stdout (fd 1) points at stderr until the line is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     stream = torch.cuda.Stream()  # the launch stream; HIP events below are recorded on it
@@ -279,8 +285,12 @@ def main():
                 "intervals, gcc -O3 -march=x86-64-v3), outputs preallocated, best of thread counts up to %d available cores"
                 % (n, N, el, avail),
             }
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
