@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
 // LDS map (doubles): G | Pa | Pb (JAC) | -S | D | W_0..W_q | V (2, JAC) | dWa, dWb (m each, JAC) | us      (column blocks LD*nc)
 // ------------------------------------------------------------------------------------------
 template <bool JAC>
-__global__ __launch_bounds__(256) void pcl_pade_kernel(const KParams p) {
+__global__ __launch_bounds__(512) void pcl_pade_kernel(const KParams p) {  // 512 threads (256 with option general_threads; 1024 measured no better)
     extern __shared__ double lds[];
     const int n = p.n, d = p.cols, m = p.m, LD = p.LD, nc = p.nc, q = p.q;
     const int tid = threadIdx.x, nth = blockDim.x;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void pcl_pade_kernel(const KParams p) {
         }
     }
     // ---- blocks: B^{+-} = sum_j c_j (+-h)^j G^j ------------------------------------------------------------------
-    // each thread owns the flat column-major positions (2q', 2q'+1), q' = tid + 256 r; for an odd n (compact density
+    // each thread owns the flat column-major positions (2q', 2q'+1), q' = tid + blockDim.x r; for an odd n (compact density
     // vectors) the two positions may lie in different columns and the stores are scalar (blocks are not 16-byte aligned)
     if (!(p.compact && s != 0)) {  // compact layout: only slice 0 writes (and therefore forms) the blocks
         const int nn_ = n * n, half = (nn_ + 1) >> 1;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void pcl_pade_kernel(const KParams p) {
         int o0_[PCL_NSP], o1_[PCL_NSP];  // LDS offsets of the two positions (-1: none)
 #pragma unroll
         for (int r = 0; r < PCL_NSP; ++r) {
-            const int pos = 2 * (tid + 256 * r);
+            const int pos = 2 * (tid + nth * r);
             o0_[r] = o1_[r] = -1;
             bp[r][0] = bm[r][0] = bp[r][1] = bm[r][1] = 0.0;
             if (pos < nn_) {
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void pcl_pade_kernel(const KParams p) {
         }
 #pragma unroll
         for (int r = 0; r < PCL_NSP; ++r) {
-            const int qq = tid + 256 * r;
+            const int qq = tid + nth * r;
             if (qq < half)
                 for (int c = cbeg; c < cend; ++c) {
                     double *o0 = jb + (long long)c * nn_ + 2 * qq;

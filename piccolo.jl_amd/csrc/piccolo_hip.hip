@@ -63,6 +63,7 @@ struct pcl_ctx {
     double *dug0 = nullptr;
     double *dcompact = nullptr;  // general-order kernel: unique tiles before the expansion kernel replicates them
     long long compact_cap = 0;
+    int64_t opt_general_threads = 512;
     int64_t opt_general_two_step = 0;  // measured slower (the general-order kernel is compute-bound, not store-bound)
     double *dreduce = nullptr;  // staging of pcl_reduce_sum (host buffer)
     int64_t reduce_cap = 0;
@@ -871,7 +872,7 @@ static int launch_pade_general(pcl_ctx *ctx, KParams &p, bool want_jac) {
         p.compact = 1;
         p.jac_per = jac_per_compact(ctx);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx->stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)ctx->opt_general_threads), lds, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
     if (jac_full) {
         const long long n_bk = (long long)p.batch * p.K;
@@ -1528,6 +1529,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_jit = v < 0 ? 0 : (v > 2 ? 2 : v);
     else if (!strcmp(key, "aligned_stream"))  // kernel 3: 1 = line-aligned flat block stream, 0 = per-block stores from registers (default)
         ctx->opt_flat = v != 0;
+    else if (!strcmp(key, "general_threads"))  // general-order kernel: 256 or 512 (default) threads per workgroup
+        ctx->opt_general_threads = v == 256 ? 256 : 512;
     else if (!strcmp(key, "general_two_step"))  // general-order kernel: 1 = unique tiles + expansion kernel, 0 (default) = one kernel writes every copy
         ctx->opt_general_two_step = v != 0;
     else if (!strcmp(key, "general_pade_kernel"))  // 1: the general-order kernel also for pade_order 4

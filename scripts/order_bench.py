@@ -20,8 +20,9 @@ with torch.cuda.stream(stream):
         c.set_stream(stream.cuda_stream)
         dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
         vd = torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")
-        for gen in ((0, 1) if order == 4 else (0,)):
-            c.set_option("general_pade_kernel", gen)
+        for gen in ((0, 1, 2) if order == 4 else (1, 2)):
+            c.set_option("general_pade_kernel", 1 if gen else 0)
+            c.set_option("general_threads", {1: 512, 2: 256, 3: 1024}.get(gen, 512))
             for _ in range(3):
                 c.eval_jac_dev(Zd, dd, vd)
             stream.synchronize()
@@ -31,5 +32,5 @@ with torch.cuda.stream(stream):
                 c.eval_jac_dev(Zd, dd, vd)
             e1.record(stream)
             stream.synchronize()
-            print("order %2d%s: %.1f us/eval (kernel id %d)" % (order, " (general kernel)" if gen else "", e0.elapsed_time(e1) / 20 / B * 1e3, c.get_option("last_kernel")), flush=True)
+            print("order %2d%s: %.1f us/eval (kernel id %d)" % (order, (" (general kernel, %d threads)" % {1: 512, 2: 256, 3: 1024}[gen]) if gen else "", e0.elapsed_time(e1) / 20 / B * 1e3, c.get_option("last_kernel")), flush=True)
         c.close()
