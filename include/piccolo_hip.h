@@ -203,7 +203,7 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *                            workgroup per CU (default where it applies) | 5 producer + expander kernels on two streams
  *       "contiguous"         kernel 3: -1 auto by launch size | 0 round-robin column slices | 1 equal contiguous column ranges
  *       "stream_workgroups"  kernel 3, contiguous: -1 auto (half) | 0 both roles in every workgroup | n stream-role workgroups
- *       "stream_piece_cols", "stream_dynamic", "aligned_stream"   kernel 3 experiments (measured no better; off by default)
+ *       "stream_piece_cols", "stream_dynamic", "stream_xcds", "aligned_stream"   kernel 3 experiments (measured no better; off by default)
  *       "cols_per_slice"     state columns per work item (0 = heuristic; forces the round-robin split in kernel 3)
  *       "hess_kernel"        0 auto | 1 one workgroup per interval | 2 persistent wave-synchronous kernel
  *       "general_pade_kernel" 1: run the general-order kernel for pade_order 4 too (cross-check)

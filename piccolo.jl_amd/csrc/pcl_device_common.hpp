@@ -52,6 +52,7 @@ struct KParams {
     int snc;      // v3, role split: > 0 = the stream workgroups take pieces of snc columns round-robin (0: contiguous ranges)
     int flat;     // v3: 1 = line-aligned flat block stream (values recomputed from LDS per store), 0 = per-block stores from registers
     int all_matrix; // v3, contig: 1 = every workgroup takes the matrix role (compact Jacobian)
+    int sxcd;     // v3, role split: > 0 = the stream role goes to the workgroups of XCDs 0..sxcd-1 (n_stream = grid/8 * sxcd)
     int n_stream; // v3, contig: > 0 = role split, this many stream-role workgroups (the rest do the column work)
     int iso;               // 1: G0 and every G_l are exact iso(.) images -> G^2 needs only its first d columns
     long long z_batch_stride;   // doubles between trajectories (0 in MEMBERS mode)

@@ -76,7 +76,15 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     // by the matrix waves' instructions and memory operations.
     // all_matrix (compact Jacobian: one copy of the blocks per interval, nothing to stream): every workgroup takes the
     // matrix role; the workgroup whose range holds an interval's column 0 also writes the interval's two unique blocks.
-    const bool stream_role = !p.all_matrix && p.n_stream > 0 && (int)blockIdx.x < p.n_stream;
+    // Workgroup index used by the work split.  Workgroups are dispatched round-robin over the 8 XCDs (XCD = blockIdx % 8);
+    // with p.sxcd = k > 0 the stream role goes to the workgroups of XCDs 0..k-1 (each XCD's L2 then serves one kind of
+    // traffic) instead of to the first n_stream workgroups (every XCD half / half).
+    int bx = (int)blockIdx.x;
+    if (p.sxcd > 0 && (gridDim.x & 7) == 0) {
+        const int g8 = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        bx = xcd < p.sxcd ? slot * p.sxcd + xcd : g8 * p.sxcd + slot * (8 - p.sxcd) + (xcd - p.sxcd);
+    }
+    const bool stream_role = !p.all_matrix && p.n_stream > 0 && bx < p.n_stream;
     const bool matrix_role = p.all_matrix || (p.n_stream > 0 && !stream_role);
     // stream role, optional: pieces of p.snc columns dealt round-robin to the stream workgroups (at any moment they then
     // write one window of ~n_stream/S consecutive intervals instead of n_stream far-apart ranges)
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     auto alive = [&](int it) { return sdyn ? sitem[it & 3] < n_items_s : it < n_my; };
     if (p.contig && !srr) {
         const long long tot = (long long)p.batch * p.K * d;
-        const long long widx = (matrix_role && !p.all_matrix) ? (long long)blockIdx.x - p.n_stream : (long long)blockIdx.x;
+        const long long widx = (matrix_role && !p.all_matrix) ? (long long)bx - p.n_stream : (long long)bx;
         const long long wcnt = (p.n_stream > 0 && !p.all_matrix) ? (stream_role ? (long long)p.n_stream : (long long)gridDim.x - p.n_stream)
                                                                    : (long long)gridDim.x;
         g_lo = tot * widx / wcnt;
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
         n_my = g_hi > g_lo ? (int)((g_hi - 1) / d - g_lo / d) + 1 : 0;
     } else if (srr) {
         const int n_items = p.batch * p.K * sS;
-        n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + p.n_stream - 1) / p.n_stream : 0;
+        n_my = n_items > bx ? (n_items - bx + p.n_stream - 1) / p.n_stream : 0;
         if (sdyn) {  // two tickets ahead: the matrix waves build item it+1 while item it streams
             if (tid == 0) {
                 sitem[0] = (int)__hip_atomic_fetch_add(p.sctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
         }
     } else {
         const int n_items = p.batch * p.K * p.S;
-        n_my = n_items > (int)blockIdx.x ? (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+        n_my = n_items > bx ? (n_items - bx + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     }
     // item `it` of this workgroup: interval (b, k), state columns [c0, c0 + nce)
     auto decode = [&](int it, int &c0, int &nce, int &k, int &b) {
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             b = (int)(bk / p.K);
         } else {
             const int S_ = srr ? sS : p.S, nc_ = srr ? p.snc : nc;
-            const int item = sdyn ? sitem[it & 3] : blockIdx.x + it * (srr ? p.n_stream : (int)gridDim.x);
+            const int item = sdyn ? sitem[it & 3] : bx + it * (srr ? p.n_stream : (int)gridDim.x);
             const int s = item % S_;
             c0 = s * nc_;
             nce = min(nc_, d - c0);

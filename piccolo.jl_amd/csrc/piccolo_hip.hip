@@ -86,6 +86,7 @@ struct pcl_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int64_t opt_cpp = 6;  // block copies per expander work item
     int64_t opt_specialize = 1;
+    int64_t opt_sxcd = 0;     // v3, role split: stream role on whole XCDs (0: interleaved on every XCD)
     int64_t opt_sdyn = 1;     // v3, role split: stream pieces handed out dynamically (when opt_snc > 0)
     unsigned int *dsctr = nullptr;
     int64_t opt_snc = 0;      // v3, role split: stream pieces of this many columns dealt round-robin (0: contiguous ranges)
@@ -957,6 +958,10 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         if (p.contig && !p.all_matrix && g3 >= 2 && v3_role_split_fits(ctx)) {
             const long long want = ctx->opt_stream_wg < 0 ? g3 / 2 : ctx->opt_stream_wg;  // auto: half the workgroups stream
             if (want > 0) p.n_stream = (int)std::min<long long>(want, g3 - 1);
+            if (ctx->opt_sxcd > 0 && ctx->opt_sxcd < 8 && (g3 & 7) == 0) {  // whole XCDs per role
+                p.sxcd = (int)ctx->opt_sxcd;
+                p.n_stream = (int)(g3 / 8 * ctx->opt_sxcd);
+            }
         }
         ctx->last_n_stream = p.n_stream;
         if (jitf) {
@@ -1521,6 +1526,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_cpp = v;
     else if (!strcmp(key, "specialize"))  // 0: always the run-time-shape kernel instances
         ctx->opt_specialize = v != 0;
+    else if (!strcmp(key, "stream_xcds"))  // kernel 3, role split: k > 0 = the workgroups of XCDs 0..k-1 stream, the others do the column work
+        ctx->opt_sxcd = v;
     else if (!strcmp(key, "stream_dynamic"))  // kernel 3, role split with stream_piece_cols > 0: 1 = ticket counter, 0 = round-robin
         ctx->opt_sdyn = v != 0;
     else if (!strcmp(key, "stream_piece_cols"))  // kernel 3, role split: > 0 = stream pieces of this many columns, round-robin

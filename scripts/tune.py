@@ -22,6 +22,7 @@ ap.add_argument("--nstream", type=int, nargs="+", default=[-1])
 ap.add_argument("--flat", type=int, nargs="+", default=[0])
 ap.add_argument("--snc", type=int, nargs="+", default=[0])
 ap.add_argument("--sdyn", type=int, nargs="+", default=[1])
+ap.add_argument("--sxcd", type=int, nargs="+", default=[0])
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--knots", type=int, default=100)
 args = ap.parse_args()
@@ -41,9 +42,9 @@ with torch.cuda.stream(stream):
         dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
         vd = torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")
         print("occupancy_v2 (blocks*1e6 + lds bytes):", c.get_option("occupancy_v2"), flush=True)
-        for kv, gr, sp, cp, nc, nt, mf, ab, cg, ns, fl, sn, sy in itertools.product(args.kernel, args.grid, args.specialize, args.cpp, args.nc, args.nt, args.mfma, args.ablate, args.contig, args.nstream, args.flat, args.snc, args.sdyn):
+        for kv, gr, sp, cp, nc, nt, mf, ab, cg, ns, fl, sn, sy, sx in itertools.product(args.kernel, args.grid, args.specialize, args.cpp, args.nc, args.nt, args.mfma, args.ablate, args.contig, args.nstream, args.flat, args.snc, args.sdyn, args.sxcd):
             c.set_option("kernel_version", kv); c.set_option("grid", gr); c.set_option("specialize", sp); c.set_option("copies_per_piece", cp)
-            c.set_option("cols_per_slice", nc); c.set_option("contiguous", cg); c.set_option("stream_workgroups", ns); c.set_option("aligned_stream", fl); c.set_option("stream_piece_cols", sn); c.set_option("stream_dynamic", sy); c.set_option("nt_stores", nt); c.set_option("use_mfma", mf); c.set_option("debug_ablate", ab)
+            c.set_option("cols_per_slice", nc); c.set_option("contiguous", cg); c.set_option("stream_workgroups", ns); c.set_option("aligned_stream", fl); c.set_option("stream_piece_cols", sn); c.set_option("stream_dynamic", sy); c.set_option("stream_xcds", sx); c.set_option("nt_stores", nt); c.set_option("use_mfma", mf); c.set_option("debug_ablate", ab)
             for _ in range(10):
                 c.eval_jac_dev(Zd, dd, vd)
             stream.synchronize()
@@ -56,6 +57,6 @@ with torch.cuda.stream(stream):
                 e1.record(stream)
                 stream.synchronize()
                 best = min(best, e0.elapsed_time(e1) / args.steps * 1e3)
-            print(json.dumps(dict(batch=B, sdyn=sy, snc=sn, flat=fl, contig=cg, nstream=ns, kernel=kv, grid=gr, spec=sp, cpp=cp, nc=nc, eff_nc=c.get_option("effective_cols_per_slice"), nt=nt, mfma=mf, ablate=ab,
+            print(json.dumps(dict(batch=B, sxcd=sx, sdyn=sy, snc=sn, flat=fl, contig=cg, nstream=ns, kernel=kv, grid=gr, spec=sp, cpp=cp, nc=nc, eff_nc=c.get_option("effective_cols_per_slice"), nt=nt, mfma=mf, ablate=ab,
                                   us_per_launch=round(best, 2), us_per_eval=round(best / B, 2), GBps=round(abytes * B / best / 1e3, 1))), flush=True)
         ms.close()

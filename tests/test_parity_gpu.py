@@ -684,6 +684,14 @@ def test_contiguous_column_ranges_any_grid():
                 delta, vals = c.eval_jac(np.stack(Zs))
                 assert np.array_equal(vals, j_rr) and np.array_equal(delta, d_rr), (grid, ns, snc, dyn)
         c.set_option("stream_piece_cols", 0)
+    for k in (3, 4):  # stream role on whole XCDs (grid a multiple of 8)
+        c.set_option("grid", 256)
+        c.set_option("stream_workgroups", -1)
+        c.set_option("stream_xcds", k)
+        delta, vals = c.eval_jac(np.stack(Zs))
+        assert c.get_option("last_stream_workgroups") == 32 * k
+        assert np.array_equal(vals, j_rr) and np.array_equal(delta, d_rr), k
+    c.set_option("stream_xcds", 0)
     ms.close()
 
 
