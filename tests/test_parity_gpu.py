@@ -689,7 +689,7 @@ def test_contiguous_column_ranges_any_grid():
         c.set_option("stream_workgroups", -1)
         c.set_option("stream_xcds", k)
         delta, vals = c.eval_jac(np.stack(Zs))
-        assert c.get_option("last_stream_workgroups") == 32 * k
+        assert c.get_option("last_stream_workgroups") == (Bn * lay.K * lay.d) // 8 * k  # 216 columns -> 216 workgroups
         assert np.array_equal(vals, j_rr) and np.array_equal(delta, d_rr), k
     c.set_option("stream_xcds", 0)
     ms.close()
