@@ -197,28 +197,31 @@ int pcl_reduce_sum_dev(pcl_ctx *ctx, double *buf_dev, int64_t n);
 int pcl_reduce_sum(pcl_ctx *ctx, double *buf_host, int64_t n); /* same for a host buffer (staged; returns after the sum) */
 int pcl_comm_destroy(pcl_ctx *ctx);
 
-/* tuning / introspection ---------------------------------------------------- */
-/* Defaults are what the benchmark runs; every other setting is for A/B measurements and the parity tests.
- * set:  "kernel_version"     0 auto | 1 one workgroup per item | 2, 4 persistent, two workgroups per CU | 3 persistent, one
- *                            workgroup per CU (default where it applies) | 5 producer + expander kernels on two streams
+/* tuning / introspection ----------------------------------------------------
+ * Defaults are what the benchmark runs; the other settings exist for A/B measurements and for the parity tests (every
+ * setting produces the same results).  Experiments of earlier rounds (stream pieces, per-XCD roles, split producer /
+ * expander kernels, ablation switches) are not part of the library any more.
+ * set:  "kernel_version"     0 auto | 1 one workgroup per item | 2 persistent, two workgroups per CU | 3 persistent, one
+ *                            workgroup per CU with stream / matrix roles (default where its specialised instance applies)
  *       "contiguous"         kernel 3: -1 auto by launch size | 0 round-robin column slices | 1 equal contiguous column ranges
  *       "stream_workgroups"  kernel 3, contiguous: -1 auto (half) | 0 both roles in every workgroup | n stream-role workgroups
- *       "stream_piece_cols", "stream_dynamic", "stream_xcds", "aligned_stream"   kernel 3 experiments (measured no better; off by default)
  *       "cols_per_slice"     state columns per work item (0 = heuristic; forces the round-robin split in kernel 3)
  *       "hess_kernel"        0 auto | 1 one workgroup per interval | 2 persistent wave-synchronous kernel
  *       "general_pade_kernel" 1: run the general-order kernel for pade_order 4 too (cross-check)
+ *       "general_threads" (256 / 512), "general_two_step" (1: unique tiles + expansion kernel)   general-order kernel
  *       "jit"                1 (default): shapes outside the static instance table are compiled on first use with hiprtc
  *                            (Hessian kernel 2 for d >= 12; fused kernel 3 when kernel_version = 3); 0: run-time-shape instances
  *       "use_mfma" (1/0: plain-VALU products in kernel 1), "nt_stores" (1/0), "specialize" (1/0: shape-specialised
- *       instances), "grid" (workgroups, 0 = one per CU), "copies_per_piece" (kernel 5), "debug_timing", "debug_ablate"
- *       (profiling only: results are WRONG when non-zero)
+ *       instances), "grid" (workgroups, 0 = one per CU), "host_threads" (host-pointer entry points: threads that expand the
+ *       compact values into the caller's array, 0 = auto), "host_path" (0 auto | 1 full values over PCIe | 2 compact + host expansion),
+ *       "debug_timing" (PCL_ENOTIMPL unless the library was built with -DPCL_PROFILE)
  * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised; 90 + q for the general-order
  *       kernel), "last_stream_workgroups", "last_hess_kernel" (3: compiled on first use), "jit_compiles", "n_cu", "iso_structured", "drives_antisymmetric",
  *       "ell_width", "ell_width_t", "union_width", "occupancy_v2".  Unknown keys return PCL_EINVAL. */
 int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t value);
 int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *value);
-/* Profiling aid: after pcl_set_option(ctx, "debug_timing", 1), up to 64 s_memtime stamps written by workgroup 0
- * at its phase boundaries during the last launch. */
+/* Profiling aid (libraries built with -DPCL_PROFILE only): after pcl_set_option(ctx, "debug_timing", 1), up to 64
+ * s_memtime stamps written by workgroup 0 at its phase boundaries during the last launch. */
 int pcl_debug_timing(pcl_ctx *ctx, int64_t *out, int64_t cap);
 
 #ifdef __cplusplus

@@ -64,18 +64,42 @@ class pcl_desc(ctypes.Structure):
     ]
 
 
-def build_library(force=False, verbose=False):
-    """Compile csrc/piccolo_hip.hip for gfx950 into csrc/libpiccolo_hip.so (in-tree)."""
+def _source_digest(paths, flags):
+    import hashlib
+
+    h = hashlib.sha256(" ".join(flags).encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def build_library(force=False, verbose=False, profile=False):
+    """Compile csrc/piccolo_hip.hip for gfx950 into csrc/libpiccolo_hip.so (in-tree).
+
+    The library is rebuilt whenever the digest of its sources and flags differs from the one recorded next to the
+    shared object (``libpiccolo_hip.so.digest``) -- modification times play no part, so a stale binary is never
+    reused after an edit, a checkout or a copy to another box.  ``profile=True`` adds ``-DPCL_PROFILE`` (cycle stamps
+    inside the kernels for scripts/probes; never the shipped build)."""
     src = os.path.join(CSRC, "piccolo_hip.hip")
     deps = [src, os.path.join(INCLUDE, "piccolo_hip.h")] + sorted(
         os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))  # the kernel families are headers of this one TU
-    if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(p) for p in deps):
-        return SO_PATH
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread"] + (["-DPCL_PROFILE"] if profile else [])
+    digest = _source_digest(deps, flags)
+    stamp = SO_PATH + ".digest"
+    if not force and os.path.exists(SO_PATH) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == digest:
+                return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-o", SO_PATH, src]
+    if not os.path.exists(hipcc):
+        raise FileNotFoundError("%s not found and %s is stale or missing (sources changed since it was built)" % (hipcc, SO_PATH))
+    cmd = [hipcc] + flags + ["-I", INCLUDE, "-o", SO_PATH, src]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
     return SO_PATH
 
 

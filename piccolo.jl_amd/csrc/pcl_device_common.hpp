@@ -43,16 +43,11 @@ struct KParams {
     const double *ug0;    // [n_upos] drift value at each union-pattern entry (first / shared drift)
     double *hpart;        // Hessian v2: per (b,k,slice) partial scalar entries
     unsigned int *hcnt;   // Hessian v2: per (b,k) arrival counter (self-resetting)
-    long long *dbg;  // optional: cycle stamps of workgroup 0 / matrix wave 0 (option debug_timing)
+    long long *dbg;  // cycle stamps of workgroup 0 / matrix wave 0 (builds with -DPCL_PROFILE only; NULL otherwise)
     int ncw;      // v3: state columns per matrix-wave chunk ((2+m)*ncw <= 16)
     int tab_lds;  // v3: union / ELL tables staged in LDS
     int contig;   // v3: 1 = contiguous column ranges per workgroup (see the kernel), 0 = items dealt round-robin
-    int sdyn;     // v3, role split with snc > 0: 1 = the stream pieces are handed out by a launch-wide ticket counter
-    unsigned int *sctr;  // ... the counter (zero between launches)
-    int snc;      // v3, role split: > 0 = the stream workgroups take pieces of snc columns round-robin (0: contiguous ranges)
-    int flat;     // v3: 1 = line-aligned flat block stream (values recomputed from LDS per store), 0 = per-block stores from registers
     int all_matrix; // v3, contig: 1 = every workgroup takes the matrix role (compact Jacobian)
-    int sxcd;     // v3, role split: > 0 = the stream role goes to the workgroups of XCDs 0..sxcd-1 (n_stream = grid/8 * sxcd)
     int n_stream; // v3, contig: > 0 = role split, this many stream-role workgroups (the rest do the column work)
     int iso;               // 1: G0 and every G_l are exact iso(.) images -> G^2 needs only its first d columns
     long long z_batch_stride;   // doubles between trajectories (0 in MEMBERS mode)
@@ -65,16 +60,12 @@ struct KParams {
     int nc;       // state columns per slice
     int S;        // slices per interval
     int LD;       // LDS leading dimension of every n-row tile
-    int compact;  // 1: write unique blocks only (jac_per is the compact size); 2: split mode - unique blocks go to
-                  //    `blocks` (2*n*n per (b,k)) and `flags[b*K+k]` is raised, everything else in the full layout
-    double *blocks;
-    unsigned int *flags;
+    int compact;  // 1: write unique blocks only (jac_per is the compact size)
     int nt;       // 1: nontemporal streaming stores
     double *expm;  // rollout: per (b,k) propagator exp(dt_k G(u_k)), n*n col-major
     double *xout;  // rollout: states at every knot, [batch][N][x_dim]
     int q;        // general-order kernel: p/2
     double pc[6]; // general-order kernel: diagonal Pade coefficients c_0..c_q
-    int ablate;   // DEBUG ONLY (wrong results): bit0 skip matrix products, bit1 skip block streaming, bit2 skip column outputs
 };
 
 // ------------------------------------------------------------------------------------------

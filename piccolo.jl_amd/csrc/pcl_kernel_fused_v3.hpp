@@ -39,7 +39,9 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     extern __shared__ double lds[];
     const int d = TD ? TD : p.d, n = 2 * d, m = TD ? TM : p.m, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD;
     const int tid = threadIdx.x;
+#ifdef PCL_PROFILE
     if (p.dbg && tid == 0 && blockIdx.x < PCL_DBG_WG) p.dbg[64 + blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     const int wave = tid >> 6, lane = tid & 63;
     const int nn = n * n;
     const int ew = p.ell_w, uw = p.uell_w, n_ell = m * n * ew, n_un = p.n_upos;
@@ -54,7 +56,6 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     double *wbuf = G2b + 2 * tile;  // per matrix wave
     const int wsz = LD * (CW + 3 * ncw);
     double *us = wbuf + 4 * wsz;
-    int *sitem = reinterpret_cast<int *>(us + 3 * (m + 1));  // dynamic stream pieces: tickets of items it, it+1, it+2 (mod 4)
     double *t_unv = us + 3 * (m + 1) + 2;
     double *t_ung0 = t_unv + (p.tab_lds ? n_un * uw : 0);
     double *t_ellv = t_ung0 + (p.tab_lds ? n_un : 0);
@@ -76,27 +77,11 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     // by the matrix waves' instructions and memory operations.
     // all_matrix (compact Jacobian: one copy of the blocks per interval, nothing to stream): every workgroup takes the
     // matrix role; the workgroup whose range holds an interval's column 0 also writes the interval's two unique blocks.
-    // Workgroup index used by the work split.  Workgroups are dispatched round-robin over the 8 XCDs (XCD = blockIdx % 8);
-    // with p.sxcd = k > 0 the stream role goes to the workgroups of XCDs 0..k-1 (each XCD's L2 then serves one kind of
-    // traffic) instead of to the first n_stream workgroups (every XCD half / half).
-    int bx = (int)blockIdx.x;
-    if (p.sxcd > 0 && (gridDim.x & 7) == 0) {
-        const int g8 = (int)gridDim.x >> 3, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-        bx = xcd < p.sxcd ? slot * p.sxcd + xcd : g8 * p.sxcd + slot * (8 - p.sxcd) + (xcd - p.sxcd);
-    }
+    const int bx = (int)blockIdx.x;  // dispatched round-robin over the 8 XCDs: both roles land on every XCD
     const bool stream_role = !p.all_matrix && p.n_stream > 0 && bx < p.n_stream;
     const bool matrix_role = p.all_matrix || (p.n_stream > 0 && !stream_role);
-    // stream role, optional: pieces of p.snc columns dealt round-robin to the stream workgroups (at any moment they then
-    // write one window of ~n_stream/S consecutive intervals instead of n_stream far-apart ranges)
-    const bool srr = stream_role && p.snc > 0;
-    const int sS = srr ? (d + p.snc - 1) / p.snc : 1;
-    // ... or handed out dynamically (p.sdyn): equal byte shares do not finish together -- with every CU streaming the same
-    // number of bytes the slowest stream workgroup ends 15-20 % after the mean (scripts/wg_timeline.py) -- so a stream
-    // workgroup takes its next piece from a launch-wide ticket counter (self-resetting: the last ticket zeroes it)
-    const bool sdyn = srr && p.sdyn;
-    const int n_items_s = p.batch * p.K * sS;
-    auto alive = [&](int it) { return sdyn ? sitem[it & 3] < n_items_s : it < n_my; };
-    if (p.contig && !srr) {
+    auto alive = [&](int it) { return it < n_my; };
+    if (p.contig) {
         const long long tot = (long long)p.batch * p.K * d;
         const long long widx = (matrix_role && !p.all_matrix) ? (long long)bx - p.n_stream : (long long)bx;
         const long long wcnt = (p.n_stream > 0 && !p.all_matrix) ? (stream_role ? (long long)p.n_stream : (long long)gridDim.x - p.n_stream)
@@ -104,36 +89,25 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
         g_lo = tot * widx / wcnt;
         g_hi = tot * (widx + 1) / wcnt;
         n_my = g_hi > g_lo ? (int)((g_hi - 1) / d - g_lo / d) + 1 : 0;
-    } else if (srr) {
-        const int n_items = p.batch * p.K * sS;
-        n_my = n_items > bx ? (n_items - bx + p.n_stream - 1) / p.n_stream : 0;
-        if (sdyn) {  // two tickets ahead: the matrix waves build item it+1 while item it streams
-            if (tid == 0) {
-                sitem[0] = (int)__hip_atomic_fetch_add(p.sctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sitem[1] = (int)__hip_atomic_fetch_add(p.sctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-        }
     } else {
         const int n_items = p.batch * p.K * p.S;
         n_my = n_items > bx ? (n_items - bx + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     }
     // item `it` of this workgroup: interval (b, k), state columns [c0, c0 + nce)
     auto decode = [&](int it, int &c0, int &nce, int &k, int &b) {
-        if (p.contig && !srr) {
+        if (p.contig) {
             const long long bk = g_lo / d + it;
             c0 = it == 0 ? (int)(g_lo - bk * d) : 0;
             nce = (int)min((long long)d, g_hi - bk * d) - c0;
             k = (int)(bk % p.K);
             b = (int)(bk / p.K);
         } else {
-            const int S_ = srr ? sS : p.S, nc_ = srr ? p.snc : nc;
-            const int item = sdyn ? sitem[it & 3] : bx + it * (srr ? p.n_stream : (int)gridDim.x);
-            const int s = item % S_;
-            c0 = s * nc_;
-            nce = min(nc_, d - c0);
-            k = (item / S_) % p.K;
-            b = item / (S_ * p.K);
+            const int item = bx + it * (int)gridDim.x;
+            const int s = item % p.S;
+            c0 = s * nc;
+            nce = min(nc, d - c0);
+            k = (item / p.S) % p.K;
+            b = item / (p.S * p.K);
         }
     };
 
@@ -209,8 +183,12 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             if (lane <= m) usn[lane] = u_lane;  // every wave: identical values
             wave_lds_sync();
             const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
-            if (p.g0_batch_stride)  // per-member drift: the whole tile changes with b
-                for (int e = lane; e < nn; e += 64) G[(e % n) + LD * (e / n)] = G0b[e];
+            if (p.g0_batch_stride)  // per-member drift: the whole tile changes with b.  Union positions are skipped: every
+                                    // position only ever receives its final value, so the four building waves (which write
+                                    // identical data and then read all of G for their G^2 tiles without a workgroup barrier)
+                                    // cannot observe each other's intermediate state
+                for (int e = lane; e < nn; e += 64)
+                    if (p.umap[e] < 0) G[(e % n) + LD * (e / n)] = G0b[e];
             if (p.tab_lds) {
                 for (int q = lane; q < n_un; q += 64) {
                     double g = p.g0_batch_stride ? G0b[p.upos[q]] : t_ung0[q];
@@ -227,7 +205,6 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                 }
             }
             wave_lds_sync();
-            if (p.ablate & 1) return;
             // G^2: row tile rt = wave (+4..), all column tiles; with the iso structure only the first d columns
             const int ct_n = p.iso ? (d + 15) >> 4 : rt_n;
             const int Nc = p.iso ? d : n;
@@ -304,17 +281,21 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             double *jt = jb + 2 * blk;  // tail: for column c: [d/du_0 .. d/du_{m-1} | d/ddt], n doubles each
 
             const int nchunk = (nce + ncw - 1) / ncw;
+#ifdef PCL_PROFILE
             int stamp = 0;
 #define PCL_STAMP()                                                                                     \
     do {                                                                                                \
         if (p.dbg && blockIdx.x == 0 && wave == 0 && lane == 0 && it == 1 && stamp < 60) p.dbg[stamp++] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
+#else
+#define PCL_STAMP() do { } while (0)
+#endif
             PCL_STAMP();
             // All global reads of this item are issued here, before the wave has any of the item's stores in flight:
             // a later load would sit behind them in the CU's saturated memory pipeline (and vmcnt is in-order).
             const bool pf = ncw <= PCL_PFW;
             double pxn[PCL_PFC][PCL_PFW], pxc[PCL_PFC][PCL_PFW];
-            if (pf && lane < n && !(p.ablate & 4) && !stream_role) {
+            if (pf && lane < n && !stream_role) {
 #pragma unroll
                 for (int t = 0; t < PCL_PFC; ++t)
 #pragma unroll
@@ -323,29 +304,19 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                         pxn[t][c] = pxc[t][c] = 0.0;
                         if (c < ncw && col < c0 + nce) {
                             const long long o = x_off + (long long)col * n + lane;
-                            if (p.ablate & 8) {  // DEBUG: no state loads
-                                pxn[t][c] = 1e-3 * lane;
-                                pxc[t][c] = 1e-3 * col;
-                            } else {
-                                pxn[t][c] = zn[o];
-                                pxc[t][c] = zk[o];
-                            }
+                            pxn[t][c] = zn[o];
+                            pxc[t][c] = zk[o];
                         }
                     }
             }
             double pf_u = 0.0;  // next item's u_k / dt_k (consumed by build)
-            if (sdyn && tid == 0) {  // ticket of item it+2 (visible to both wave groups after this item's barrier)
-                const unsigned int tk = __hip_atomic_fetch_add(p.sctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sitem[(it + 2) & 3] = (int)tk;
-                if (tk == (unsigned int)(n_items_s + 2 * p.n_stream - 1)) __hip_atomic_store(p.sctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             if (alive(it + 1) && lane <= m && wave < 4) {
                 int c02, nce2, k2, b2;
                 decode(it + 1, c02, nce2, k2, b2);
                 const double *zk2 = p.Z + (long long)b2 * p.z_batch_stride + (long long)k2 * p.z_dim;
                 pf_u = zk2[lane < m ? p.u_off + lane : p.dt_off];
             }
-            if (p.all_matrix && p.compact && c0 == 0 && !(p.ablate & 2)) {  // the interval's unique -B^+ / B^- blocks
+            if (p.all_matrix && p.compact && c0 == 0) {  // the interval's unique -B^+ / B^- blocks
                 const int half = nn >> 1;
                 for (int q = tid; q < half; q += 512) {
                     const int pos = 2 * q, i = pos % n, j = pos / n;
@@ -357,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                 }
             }
             int tch = 0;
-            for (int ch = wave; ch < nchunk && !(p.ablate & 4) && !stream_role; ch += nmw, ++tch) {
+            for (int ch = wave; ch < nchunk && !stream_role; ch += nmw, ++tch) {
                 const int cc0 = c0 + ch * ncw;             // first state column of the chunk
                 const int ncc = min(ncw, c0 + nce - cc0);  // columns in this chunk
                 // ---- M = [S | D | G_l D]   (lane = row) -----------------------------------------------------
@@ -447,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                     double4_t acc[PCL_MAXRT];
 #pragma unroll
                     for (int t = 0; t < PCL_MAXRT; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-                    if (!(p.ablate & 1)) {
+                    {
                         double an[PCL_MAXRT], bn = 0.0;
 #pragma unroll
                         for (int t = 0; t < PCL_MAXRT; ++t) an[t] = kfull > 0 ? Ap[t][0] : 0.0;
@@ -529,11 +500,10 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                 {
                     const int hn2 = n >> 1;
                     const long long o0 = (long long)cc0 * n;
-                    for (int e2 = lane; e2 < ((p.ablate & 32) ? 0 : ncc * hn2); e2 += 64) {
+                    for (int e2 = lane; e2 < ncc * hn2; e2 += 64) {
                         const int c = e2 / hn2, r0 = 2 * (e2 - c * hn2);
                         if (p.delta) store2(p.delta + bk * xd + o0 + (long long)c * n + r0, G2Dw[r0 + LD * c], G2Dw[r0 + 1 + LD * c], false);
                         double *tc = jt + (long long)(cc0 + c) * (m + 1) * n + r0;  // this column's (m+1)*n tail block
-                        if (p.ablate & 64) tc = p.jac + (long long)blockIdx.x * 16384 + (wave * 1024 + c * 512) + r0;  // DEBUG: a cache-resident scratch target
                         for (int l = 0; l < m; ++l) {
                             const double *src = Mw + LD * (2 * ncw + l * ncw + c) + r0;
                             store2(tc + (long long)l * n, src[0], src[1], false);
@@ -563,50 +533,7 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             int c0, nce, k, b;
             decode(it, c0, nce, k, b);
             const double *G = Gb + cur * tile, *G2 = G2b + cur * tile;
-            if (p.flat && !(p.ablate & 2) && !matrix_role) {
-                // Optional line-aligned flat stream (option aligned_stream): the item's share of a segment (copies
-                // cbeg..cend-1 of one n x n block) is ONE contiguous run; after a partial head up to the next 128-byte line
-                // every wave-level store covers eight whole lines (1 KiB); values recomputed per store from the LDS tiles.
-                // A bare store kernel gains 30-40 % from this alignment (scripts/probes/wstream2.hip); this kernel, whose
-                // per-block stores are 1 KiB contiguous per instruction already, does not (28.0 vs 28.2 us/eval).
-                const double h = us[(it % 3) * (m + 1) + m];
-                const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
-                int cbeg = c0, cend = c0 + nce;
-                if (p.compact) {
-                    cbeg = 0;
-                    cend = (c0 == 0) ? 1 : 0;
-                }
-                const long long L = (long long)(cend - cbeg) * nn;  // doubles per run
-                double *jbk = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn;
-                const int di = 512 % n, dj = (512 / n) % n;
-                auto put = [&](double *A0, long long a, int i, int j, int sg) {
-                    const double g0 = G[i + LD * j], g1 = G[i + 1 + LD * j];
-                    const double h0 = G2[i + LD * j], h1 = G2[i + 1 + LD * j];
-                    const double e0 = ((i == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((i + 1 == j) ? 1.0 : 0.0) + c2 * h1;
-                    if (sg == 0)
-                        store2(A0 + a, -(e0 + c1 * g0), -(e1 + c1 * g1), p.nt);
-                    else
-                        store2(A0 + a, e0 - c1 * g0, e1 - c1 * g1, p.nt);
-                };
-#pragma unroll
-                for (int sg = 0; sg < 2; ++sg) {
-                    double *A0 = jbk + sg * blk;
-                    const int head = (int)(((128 - ((unsigned long long)A0 & 127)) & 127) >> 3);  // doubles (even)
-                    if (2 * stid < head && 2 * stid < L) put(A0, 2 * stid, (2 * stid) % n, ((2 * stid) / n) % n, sg);
-                    long long a = head + 2LL * stid;
-                    int i = (int)(a % n), j = (int)((a / n) % n);
-                    for (; a < L; a += 512) {
-                        put(A0, a, i, j, sg);
-                        i += di;
-                        if (i >= n) {
-                            i -= n;
-                            ++j;
-                        }
-                        j += dj;
-                        if (j >= n) j -= n;
-                    }
-                }
-            } else if (pact && !(p.ablate & 2) && !matrix_role) {
+            if (pact && !matrix_role) {
                 const double h = us[(it % 3) * (m + 1) + m];
                 const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
                 double bpr[PCL_NSP][2], bmr[PCL_NSP][2];
@@ -643,8 +570,10 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             __syncthreads();  // item boundary
         }
     }
+#ifdef PCL_PROFILE
     if (p.dbg && tid == 256 && blockIdx.x < PCL_DBG_WG) {  // wave 4: a stream wave, or a matrix wave of a matrix-role workgroup
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // its stores have left the CU
         p.dbg[64 + PCL_DBG_WG + blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
     }
+#endif
 }

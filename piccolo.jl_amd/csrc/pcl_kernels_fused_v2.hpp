@@ -1,5 +1,5 @@
-// pcl_kernels_fused_v2.hpp -- persistent wave-specialised kernels with two workgroups per CU: versions 2 and 4 (fallbacks of
-// version 3; version 2 also serves pcl_eval, kets and the compact mode).
+// pcl_kernels_fused_v2.hpp -- persistent wave-specialised kernel with two workgroups per CU (version 2): the fallback of
+// version 3 for shapes whose double-buffered tiles do not fit LDS, for kets and for the compact mode at such shapes.
 #pragma once
 
 // ------------------------------------------------------------------------------------------
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
             for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = G0b[e];
             __syncthreads();  // the dense rewrite lands before the pattern update
         }
-        if (!(p.ablate & 8)) {
+        {
             if (WU > 0) {
 #pragma unroll
                 for (int r = 0; r < PCL_NUE2; ++r)
@@ -309,13 +309,11 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
         // ---- phase 1: matrix waves G^2 ; stream waves G_l D ---------------------------------------------
         if (JAC) {
             if (matrix_wave) {
-                if (!(p.ablate & 1)) {
-                    if (p.iso)
-                        wave_rowgemm<1>(G, LD, G, LD, G2, LD, n, d, n, wave, 4, lane, d);
-                    else
-                        wave_rowgemm<0>(G, LD, G, LD, G2, LD, n, n, n, wave, 4, lane, 0);
-                }
-            } else if (sact && !(p.ablate & 16)) {
+                if (p.iso)
+                    wave_rowgemm<1>(G, LD, G, LD, G2, LD, n, d, n, wave, 4, lane, d);
+                else
+                    wave_rowgemm<0>(G, LD, G, LD, G2, LD, n, n, n, wave, 4, lane, 0);
+            } else if (sact) {
                 const double *Dm = M1 + LD * nc;
                 for (int cl = sj0; cl < m * nc; cl += sstep) {
                     const int l = cl / nc, c = cl - l * nc;
@@ -335,54 +333,43 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
         // ---- phase 2: matrix waves W1 = G M1, G2D = G^2 D ; stream waves the block copies -------------------
         const long long bk = (long long)b * p.K + k;
         double *jb = JAC ? p.jac + bk * p.jac_per : nullptr;
-        const long long blk = p.compact == 1 ? (long long)nn : (long long)C * nn;  // size of seg 0 / seg 1 in `jac`
+        const long long blk = p.compact ? (long long)nn : (long long)C * nn;  // size of seg 0 / seg 1 in `jac`
         if (matrix_wave) {
-            if (!(p.ablate & 1)) {
-                if (fused_p2) {
-                    wave_phase2_fused(G, G2, M1, W1, G2D, LD, n, ncols1, nc, JAC, wave, lane);
-                } else {
-                    wave_rowgemm<0>(G, LD, M1, LD, W1, LD, n, ncols1, n, wave, 4, lane, 0);
-                    if (JAC) wave_rowgemm<0>(G2, LD, M1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
-                }
+            if (fused_p2) {
+                wave_phase2_fused(G, G2, M1, W1, G2D, LD, n, ncols1, nc, JAC, wave, lane);
+            } else {
+                wave_rowgemm<0>(G, LD, M1, LD, W1, LD, n, ncols1, n, wave, 4, lane, 0);
+                if (JAC) wave_rowgemm<0>(G2, LD, M1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
             }
-        } else if (JAC && pact && !(p.ablate & 2)) {
+        } else if (JAC && pact) {
             int cbeg = c0, cend = c0 + nce;
             if (p.compact) {  // unique blocks only: slice 0 writes the single copy
                 cbeg = 0;
                 cend = (s == 0) ? 1 : 0;
             }
-            double *ob = p.compact == 2 ? p.blocks + bk * 2 * nn : jb;  // split mode: blocks go to the scratch tiles
-            const long long oblk = p.compact == 2 ? (long long)nn : blk;
             for (int j = pj0; j < n; j += pstep) {
                 const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
                 const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
                 const double e0 = ((pi == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + c2 * h1;
                 const double bp0 = -(e0 + c1 * g0), bp1 = -(e1 + c1 * g1);
                 const double bm0 = e0 - c1 * g0, bm1 = e1 - c1 * g1;
-                double *o0 = ob + (long long)cbeg * nn + (pi + n * j);
+                double *o0 = jb + (long long)cbeg * nn + (pi + n * j);
                 for (int c = cbeg; c < cend; ++c, o0 += nn) {
                     store2(o0, bp0, bp1, p.nt);
-                    store2(o0 + oblk, bm0, bm1, p.nt);
+                    store2(o0 + blk, bm0, bm1, p.nt);
                 }
             }
-            if (p.compact == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's tile stores have left the CU
         }
         // inputs of this workgroup's next item: in flight during the rest of this one
         if (item + (int)gridDim.x < n_items) request(item + gridDim.x);
         __syncthreads();
-        if (JAC && p.compact == 2 && s == 0 && tid == 256) {
-            // publish the interval's tiles to the expander kernel (other CUs / XCDs): agent-scope release, then the flag
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(p.flags + bk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         if (!JAC) {  // eval only: delta needs G (G D), a second dependent product
-            if (matrix_wave && !(p.ablate & 1)) wave_rowgemm<0>(G, LD, W1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
+            if (matrix_wave) wave_rowgemm<0>(G, LD, W1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
             __syncthreads();
         }
 
         // ---- phase 3: column outputs: block 0 -> delta and d/ddt, block 1+l -> d/du_l ----------------------
-        if (ract && !(p.ablate & 4)) {
+        if (ract) {
             const double *GDm = W1 + LD * nc;
             const int ncl = JAC ? (1 + m) * nc : nc;
             for (int cl = rj0; cl < ncl; cl += rstep) {
@@ -415,323 +402,5 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
         if (tid <= m) us[(cur ^ 1) * (m + 1) + tid] = pf_v;  // requested during phase 2
         cur ^= 1;
         __syncthreads();  // LDS is rewritten by the next item's phase 0
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Fused residual + Jacobian kernel, version 4: version 2's frame (persistent, 2 workgroups per CU, 4 matrix + 4 stream
-// waves, 4 barriers per item) with the block stores of an item SPREAD over four phases instead of one:
-//   the stream waves copy the item's -B^+ / B^- values into registers as soon as G^2 exists (start of phase 2) and
-//   issue a quarter of the copies in each of  phase 2, phase 3 (this item), phase 0, phase 1 (next item);
-//   every other duty (union update of G, S/D, G_l D, MFMA products, column outputs) belongs to the matrix waves.
-// Per item the workgroup then spends  sum_j max(matrix phase j, store burst j)  instead of
-// (matrix phases 0,1,3) + max(matrix phase 2, all stores): the store queue of the CU is fed in every phase.
-// ------------------------------------------------------------------------------------------
-#define PCL_NUE4 4  // union-pattern entries per matrix-wave thread held in registers (REG path: n_upos <= 1024)
-
-template <int WU, int TD, int TM, int TNC>
-__global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v4(const KParams p) {
-    extern __shared__ double lds[];
-    const int d = TD ? TD : p.d, n = 2 * d, m = TD ? TM : p.m, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD, nc = TNC ? TNC : p.nc;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const bool matrix_wave = wave < 4;
-    const int nn = n * n;
-    const int ncols1 = (2 + m) * nc;
-    const int n_ell = m * n * p.ell_w;
-    double *G = lds;
-    double *G2 = G + LD * n;
-    double *M1 = G2 + LD * n;
-    double *W1 = M1 + LD * ncols1;
-    double *G2D = W1 + LD * ncols1;
-    double *us = G2D + LD * nc;  // 2 x [u_k (m) | dt_k]: current / next item
-    double *ellv_l = us + 2 * (m + 1);
-    unsigned short *ellc_l = reinterpret_cast<unsigned short *>(ellv_l + n_ell);
-    const long long xd = (long long)n * d;
-    const int ew = p.ell_w;
-    const bool fused_p2 = ncols1 <= 32 && 2 * nc <= 16;
-    const bool stage = p.ell_lds;
-    const int n_items = p.batch * p.K * p.S;
-    const long long blk = p.compact ? (long long)nn : (long long)d * nn;  // size of seg 0 / seg 1
-
-    if (!p.g0_batch_stride)
-        for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = p.G0[e];
-    if (stage)
-        for (int e = tid; e < n_ell; e += 512) {
-            ellv_l[e] = p.ell_val[e];
-            ellc_l[e] = (unsigned short)p.ell_col[e];
-        }
-
-    if (matrix_wave) {
-        // ===================================== matrix waves (256 threads) ======================================
-        const int ri = tid % n, rj0 = tid / n, rstep = 256 / n;  // row ri, columns rj0, rj0+rstep, ..
-        const bool ract = rj0 < rstep;
-        constexpr int WUR = WU > 0 ? WU : 1;
-        int un_idx[PCL_NUE4];
-        double un_g0[PCL_NUE4];
-        unsigned char un_l[PCL_NUE4][WUR];
-        double un_v[PCL_NUE4][WUR];
-        if (WU > 0) {
-#pragma unroll
-            for (int r = 0; r < PCL_NUE4; ++r) {
-                const int q = tid + 256 * r;
-                un_idx[r] = -1;
-                un_g0[r] = 0.0;
-#pragma unroll
-                for (int w = 0; w < WUR; ++w) {
-                    un_l[r][w] = 0;
-                    un_v[r][w] = 0.0;
-                }
-                if (q < p.n_upos) {
-                    const int pos = p.upos[q];
-                    un_idx[r] = (pos % n) + LD * (pos / n);
-                    un_g0[r] = p.G0[pos];
-#pragma unroll
-                    for (int w = 0; w < WUR; ++w) {
-                        un_l[r][w] = p.uell_l[q * WUR + w];
-                        un_v[r][w] = p.uell_v[q * WUR + w];
-                    }
-                }
-            }
-        }
-        const bool pf_x = nc <= rstep;  // one state element per thread: prefetchable
-        double pf_v = 0.0, pf_xn = 0.0, pf_xc = 0.0;
-        auto request = [&](int item) {
-            const int s = item % p.S;
-            const int k = (item / p.S) % p.K;
-            const int b = item / (p.S * p.K);
-            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
-            if (tid <= m) pf_v = zk[tid < m ? p.u_off + tid : p.dt_off];
-            pf_xn = pf_xc = 0.0;
-            if (pf_x && ract && rj0 < min(nc, d - s * nc)) {
-                const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-                const long long o = x_off + (long long)(s * nc + rj0) * n + ri;
-                pf_xc = zk[o];
-                pf_xn = zk[p.z_dim + o];
-            }
-        };
-        int cur = 0;
-        if ((int)blockIdx.x < n_items) {
-            request(blockIdx.x);
-            if (tid <= m) us[tid] = pf_v;
-        }
-        __syncthreads();  // G = drift, tables staged, us[0] valid
-
-        for (int item = blockIdx.x;; item += gridDim.x) {
-            const bool have = item < n_items;
-            const int s = have ? item % p.S : 0;
-            const int k = have ? (item / p.S) % p.K : 0;
-            const int b = have ? item / (p.S * p.K) : 0;
-            const int c0 = s * nc;
-            const int nce = min(nc, d - c0);
-            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
-            const double *zn = zk + p.z_dim;
-            const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
-            const double *usc = us + cur * (m + 1);
-            const double h = usc[m];
-            const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
-
-            // ---- phase 0: G(u_k) on the union pattern, S, D -> LDS -------------------------------------------
-            if (WU < 0 && p.g0_batch_stride) {  // per-member drift: the whole tile changes with b
-                if (have) {
-                    const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
-                    for (int e = tid; e < nn; e += 256) G[(e % n) + LD * (e / n)] = G0b[e];
-                }
-                __syncthreads();  // (stream waves take part) the dense rewrite lands before the pattern update
-            }
-            if (have) {
-                if (WU > 0) {
-#pragma unroll
-                    for (int r = 0; r < PCL_NUE4; ++r)
-                        if (un_idx[r] >= 0) {
-                            double g = un_g0[r];
-#pragma unroll
-                            for (int w = 0; w < WUR; ++w) g += usc[un_l[r][w]] * un_v[r][w];
-                            G[un_idx[r]] = g;
-                        }
-                } else {
-                    const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
-                    for (int q = tid; q < p.n_upos; q += 256) {
-                        const int pos = p.upos[q];
-                        double g = G0b[pos];
-                        const double *cf = p.ucoef + (long long)q * m;
-                        for (int l = 0; l < m; ++l) g += usc[l] * cf[l];
-                        G[(pos % n) + LD * (pos / n)] = g;
-                    }
-                }
-                if (pf_x) {
-                    if (ract && rj0 < nc) {
-                        M1[ri + LD * rj0] = pf_xn + pf_xc;
-                        M1[ri + LD * (nc + rj0)] = pf_xn - pf_xc;
-                    }
-                } else if (ract) {
-                    for (int c = rj0; c < nc; c += rstep) {
-                        double xs = 0.0, xdv = 0.0;
-                        if (c < nce) {
-                            const double xn = zn[x_off + (c0 + c) * n + ri], xc = zk[x_off + (c0 + c) * n + ri];
-                            xs = xn + xc;
-                            xdv = xn - xc;
-                        }
-                        M1[ri + LD * c] = xs;
-                        M1[ri + LD * (nc + c)] = xdv;
-                    }
-                }
-            }
-            __syncthreads();  // B_a
-            if (!have) {
-                __syncthreads();  // B_b: the stream waves' last burst pair runs through phases 0 and 1 of this empty item
-                break;
-            }
-
-            // ---- phase 1: G_l D (VALU) then G^2 (MFMA) ----------------------------------------------------------
-            if (ract) {
-                const double *Dm = M1 + LD * nc;
-                for (int cl = rj0; cl < m * nc; cl += rstep) {
-                    const int l = cl / nc, c = cl - l * nc;
-                    const int base = (l * n + ri) * ew;
-                    double acc = 0.0;
-                    if (stage) {
-                        for (int q = 0; q < ew; ++q) acc += ellv_l[base + q] * Dm[ellc_l[base + q] + LD * c];
-                    } else {
-                        for (int q = 0; q < ew; ++q) acc += p.ell_val[base + q] * Dm[p.ell_col[base + q] + LD * c];
-                    }
-                    M1[ri + LD * (2 * nc + cl)] = acc;
-                }
-            }
-            if (!(p.ablate & 1)) {
-                if (p.iso)
-                    wave_rowgemm<1>(G, LD, G, LD, G2, LD, n, d, n, wave, 4, lane, d);
-                else
-                    wave_rowgemm<0>(G, LD, G, LD, G2, LD, n, n, n, wave, 4, lane, 0);
-            }
-            __syncthreads();  // B_b: G, G^2, M1 complete
-
-            // ---- phase 2: W1 = G M1, G2D = G^2 D ; request the next item's inputs -------------------------------
-            if (!(p.ablate & 1)) {
-                if (fused_p2) {
-                    wave_phase2_fused(G, G2, M1, W1, G2D, LD, n, ncols1, nc, true, wave, lane);
-                } else {
-                    wave_rowgemm<0>(G, LD, M1, LD, W1, LD, n, ncols1, n, wave, 4, lane, 0);
-                    wave_rowgemm<0>(G2, LD, M1 + LD * nc, LD, G2D, LD, n, nc, n, wave, 4, lane, 0);
-                }
-            }
-            if (item + (int)gridDim.x < n_items) request(item + gridDim.x);
-            __syncthreads();  // B_c
-
-            // ---- phase 3: column outputs: block 0 -> delta and d/ddt, block 1+l -> d/du_l -----------------------
-            if (ract && !(p.ablate & 4)) {
-                const long long bk = (long long)b * p.K + k;
-                double *jb = p.jac + bk * p.jac_per;
-                const double *GDm = W1 + LD * nc;
-                for (int cl = rj0; cl < (1 + m) * nc; cl += rstep) {
-                    const int lb = cl / nc, c = cl - lb * nc;
-                    if (c >= nce) continue;
-                    const long long r = (long long)(c0 + c) * n + ri;
-                    if (lb == 0) {
-                        const double gs = W1[ri + LD * c], g2d = G2D[ri + LD * c];
-                        if (p.delta) p.delta[bk * xd + r] = M1[ri + LD * (nc + c)] - c1 * gs + c2 * g2d;
-                        jb[2 * blk + ((long long)(c0 + c) * (m + 1) + m) * n + ri] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
-                    } else {
-                        const int l = lb - 1;
-                        const int base = (l * n + ri) * ew;
-                        double acc = 0.0;
-                        if (stage) {
-                            for (int q = 0; q < ew; ++q) {
-                                const int col = ellc_l[base + q];
-                                acc += ellv_l[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
-                            }
-                        } else {
-                            for (int q = 0; q < ew; ++q) {
-                                const int col = p.ell_col[base + q];
-                                acc += p.ell_val[base + q] * (-c1 * M1[col + LD * c] + c2 * GDm[col + LD * c]);
-                            }
-                        }
-                        jb[2 * blk + ((long long)(c0 + c) * (m + 1) + l) * n + ri] = acc + c2 * W1[ri + LD * (nc + cl)];
-                    }
-                }
-            }
-            if (tid <= m) us[(cur ^ 1) * (m + 1) + tid] = pf_v;  // requested during phase 2
-            cur ^= 1;
-            __syncthreads();  // B_d
-        }
-    } else {
-        // ===================================== stream waves (256 threads) ======================================
-        const int stid = tid - 256;
-        const int hn = n >> 1;
-        const int pi = 2 * (stid % hn), pj0 = stid / hn, pstep = max(256 / hn, 1);
-        const bool pact = pj0 < pstep;
-        constexpr int NSP = TD ? (2 * TD + (256 / TD) - 1) / (256 / TD) : 8;  // column steps per thread (<= 8 for n <= 64)
-        double bpr[NSP][2], bmr[NSP][2];
-        double *sjb = nullptr;
-        int ncopy = 0;
-        // burst j in 0..3: copies q = (j>>1), (j>>1)+2, .. and the (j&1) half of this thread's column steps -> four equal
-        // quarters of the item's stores whatever the copy count
-        auto burst = [&](int jq) {
-            if (!pact || (p.ablate & 2)) return;
-            const int half = ncopy >> 1;
-            const int rlo = (jq & 1) ? NSP / 2 : 0, rhi = (jq & 1) ? NSP : NSP / 2;
-            for (int q = jq >> 1; q < ncopy; q += 2) {
-                const bool minus = q >= half;
-                double *o = sjb + (minus ? blk + (long long)(q - half) * nn : (long long)q * nn);
-                if (minus) {
-#pragma unroll
-                    for (int r = 0; r < NSP; ++r) {
-                        const int j = pj0 + pstep * r;
-                        if (r >= rlo && r < rhi && j < n) store2(o + n * j, bmr[r][0], bmr[r][1], p.nt);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < NSP; ++r) {
-                        const int j = pj0 + pstep * r;
-                        if (r >= rlo && r < rhi && j < n) store2(o + n * j, bpr[r][0], bpr[r][1], p.nt);
-                    }
-                }
-            }
-        };
-        int cur = 0;
-        __syncthreads();  // prologue barrier
-        for (int item = blockIdx.x;; item += gridDim.x) {
-            const bool have = item < n_items;
-            if (WU < 0 && p.g0_batch_stride) __syncthreads();
-            burst(2);  // previous item, third quarter (phase 0)
-            __syncthreads();       // B_a
-            burst(3);  // previous item, last quarter (phase 1)
-            __syncthreads();       // B_b: this item's G, G^2 complete
-            if (!have) break;
-            {
-                const int s = item % p.S;
-                const int k = (item / p.S) % p.K;
-                const int b = item / (p.S * p.K);
-                const double h = us[cur * (m + 1) + m];
-                const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
-                if (pact) {
-#pragma unroll
-                    for (int r = 0; r < NSP; ++r) {
-                        const int j = pj0 + pstep * r;
-                        if (j < n) {
-                            const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
-                            const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
-                            const double e0 = ((pi == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + c2 * h1;
-                            bpr[r][0] = -(e0 + c1 * g0);
-                            bpr[r][1] = -(e1 + c1 * g1);
-                            bmr[r][0] = e0 - c1 * g0;
-                            bmr[r][1] = e1 - c1 * g1;
-                        }
-                    }
-                }
-                int cbeg = s * nc, cend = s * nc + min(nc, d - s * nc);
-                if (p.compact) {  // unique blocks only: slice 0 writes the single copy
-                    cbeg = 0;
-                    cend = (s == 0) ? 1 : 0;
-                }
-                ncopy = 2 * (cend - cbeg);  // -B^+ copies, then B^- copies
-                sjb = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn + pi;
-            }
-            burst(0);         // phase 2
-            __syncthreads();  // B_c
-            burst(1);         // phase 3
-            cur ^= 1;
-            __syncthreads();   // B_d
-        }
     }
 }

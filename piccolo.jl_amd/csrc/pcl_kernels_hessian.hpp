@@ -217,11 +217,15 @@ __global__ __launch_bounds__(256, 2) void pcl_hess_kernel_v2(const KParams p) {
 
     const int S = p.S, nc = p.nc;
     const int n_items = p.batch * p.K * S;
+#ifdef PCL_PROFILE
     int stamp = 0;
 #define PCL_HSTAMP()                                                                                  \
     do {                                                                                             \
         if (p.dbg && blockIdx.x == 0 && tid == 0 && stamp < 60) p.dbg[stamp++] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
+#else
+#define PCL_HSTAMP() do { } while (0)
+#endif
     PCL_HSTAMP();  // prologue done
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int s = item % S, k = (item / S) % p.K, b = item / (S * p.K);
@@ -396,19 +400,15 @@ __global__ __launch_bounds__(256, 2) void pcl_hess_kernel_v2(const KParams p) {
                             Ev[l] = ev;
                             const double qv = Mw[lane + LD * (NCW + l * NCW + c)];
                             const double kt = c2 * (qv + r), pl = -c1 * Pv[l][c];
-                            if (!(p.ablate & 1)) {
-                                H3[(long long)l * xd + o] = pl - kt;
-                                H5[(long long)l * xd + o] = pl + kt;
-                            }
+                            H3[(long long)l * xd + o] = pl - kt;
+                            H5[(long long)l * xd + o] = pl + kt;
                             acc[NPAIR + l] += -0.5 * Pv[l][c] * Sv[c] + h6 * (qv * dv + a1v * ev);
                         }
                         int e = 0;
-                        if (!(p.ablate & 2)) {
 #pragma unroll
-                            for (int i = 0; i < TM; ++i)
+                        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                                for (int j = 0; j <= i; ++j, ++e) acc[e] += Pv[i][c] * Ev[j] + Pv[j][c] * Ev[i];
-                        }
+                            for (int j = 0; j <= i; ++j, ++e) acc[e] += Pv[i][c] * Ev[j] + Pv[j][c] * Ev[i];
                     }
             }
             wave_lds_sync();  // Mw is rewritten by this wave's next chunk / the reduction below

@@ -32,72 +32,6 @@ __global__ __launch_bounds__(256) void pcl_expand_kernel(const double *__restric
 }
 
 // ------------------------------------------------------------------------------------------
-// Split mode, consumer side: persistent expander.  Work item = (b, k, piece): `cpp` of the 2d block copies of one
-// interval.  The workgroup waits until the producer kernel (running concurrently on another stream) has raised the
-// interval's flag, loads the unique -B^+ / B^- tile values it needs from the scratch tiles (L2) into registers and
-// streams the copies.  No LDS, no barrier inside the stream.  Hand-off protocol: producer = stores, s_waitcnt vmcnt(0),
-// __syncthreads, one lane: agent-scope release fence + relaxed agent-scope flag store; consumer = one lane polls the
-// flag (relaxed, agent scope), agent-scope acquire fence, __syncthreads, plain loads.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pcl_expand_stream_kernel(const double *blocks, const unsigned int *flags,
-                                                                double *__restrict__ jac, int d, int n, long long jac_per,
-                                                                long long n_bk, int pieces, int cpp, int nt) {
-    const int nn = n * n;
-    const int tid = threadIdx.x;
-    const int hn = n >> 1;
-    const int pi = 2 * (tid % hn), pj0 = tid / hn, pstep = max(256 / hn, 1);
-    const bool pact = pj0 < pstep;
-    const long long n_items = n_bk * pieces;
-    const long long blk = (long long)d * nn;
-    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const long long bk = item / pieces;
-        const int piece = (int)(item - bk * pieces);
-        if (tid == 0) {
-            // bounded spin (about a second): a producer that never shows up must not hang the device
-            int spins = 0;
-            while (__hip_atomic_load(flags + bk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && spins < (1 << 22)) {
-                __builtin_amdgcn_s_sleep(8);
-                ++spins;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        if (pact) {
-            const double *src = blocks + bk * 2 * nn + pi;
-            double2_t vp[8], vm[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int j = pj0 + pstep * r;
-                if (j < n) {
-                    vp[r] = *reinterpret_cast<const double2_t *>(src + n * j);
-                    vm[r] = *reinterpret_cast<const double2_t *>(src + nn + n * j);
-                }
-            }
-            // copies q in [piece*cpp, ..): q < d are -B^+ copies, q >= d are B^- copies
-            const int q0 = piece * cpp, q1 = min(2 * d, q0 + cpp);
-            double *dst = jac + bk * jac_per + pi;
-            for (int q = q0; q < q1; ++q) {
-                if (q < d) {
-                    double *o = dst + (long long)q * nn;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const int j = pj0 + pstep * r;
-                        if (j < n) store2(o + n * j, vp[r][0], vp[r][1], nt);
-                    }
-                } else {
-                    double *o = dst + blk + (long long)(q - d) * nn;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const int j = pj0 + pstep * r;
-                        if (j < n) store2(o + n * j, vm[r][0], vm[r][1], nt);
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Rollout: exact piecewise-constant propagation  X_{k+1} = exp(dt_k G(u_k)) X_k  from the knot-0 state
 // -- what the reference's unitary_rollout(...; interpolation = :constant) integrates with an ODE solver
 // [REF src/quantum/dynamics.jl:631-667] and the slot its RolloutStates reserves for "a GPU rollout"

@@ -64,13 +64,13 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
             M1[i + LD * ((2 + l) * nc + c)] = acc;
         }
         __syncthreads();
-        if (!(p.ablate & 1)) gemm_lds<MFMA, false>(G, LD, G, LD, G2, LD, n, n, n);
+        gemm_lds<MFMA, false>(G, LD, G, LD, G2, LD, n, n, n);
     }
-    if (!(p.ablate & 1)) gemm_lds<MFMA, false>(G, LD, M1, LD, W1, LD, n, ncols1, n);
+    gemm_lds<MFMA, false>(G, LD, M1, LD, W1, LD, n, ncols1, n);
     __syncthreads();
 
     // pass 2: G2D = G * (G D);  T = -c1 S + c2 G D
-    if (!(p.ablate & 1)) gemm_lds<MFMA, false>(G, LD, W1 + LD * nc, LD, G2D, LD, n, nc, n);
+    gemm_lds<MFMA, false>(G, LD, W1 + LD * nc, LD, G2D, LD, n, nc, n);
     if (JAC) {
         for (int e = tid; e < nc * n; e += nth) {
             const int c = e / n, i = e % n;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
     const long long bk = (long long)b * p.K + k;
     double *jb = JAC ? p.jac + bk * p.jac_per : nullptr;
     const long long blk = p.compact ? (long long)n * n : (long long)d * n * n;  // size of seg 0 / seg 1
-    for (int e = tid; e < ((p.ablate & 4) ? 0 : nce * n); e += nth) {
+    for (int e = tid; e < nce * n; e += nth) {
         const int c = e / n, i = e % n;
         const double gs = W1[i + LD * c], g2d = G2D[i + LD * c];
         const long long r = (long long)(c0 + c) * n + i;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
         if (JAC) jb[2 * blk + ((long long)(c0 + c) * (m + 1) + m) * n + i] = -0.5 * gs + (h * (1.0 / 6.0)) * g2d;
     }
     if (JAC) {
-        for (int e = tid; e < ((p.ablate & 4) ? 0 : m * nce * n); e += nth) {
+        for (int e = tid; e < m * nce * n; e += nth) {
             const int i = e % n, c = (e / n) % nce, l = e / (n * nce);
             const int *rp = p.csr_ptr + l * (n + 1);
             double acc = 0.0;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
             cbeg = 0;
             cend = (s == 0) ? 1 : 0;
         }
-        for (int q = tid; q < ((p.ablate & 2) ? 0 : half); q += nth) {
+        for (int q = tid; q < half; q += nth) {
             const int pos = 2 * q;
             const int i = pos % n, j = pos / n;
             const double g0 = G[i + LD * j], g1 = G[i + 1 + LD * j];

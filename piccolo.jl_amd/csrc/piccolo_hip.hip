@@ -2,7 +2,7 @@
 // side of the gfx950 (MI355X / CDNA4) Pade collocation constraint evaluator.  One translation unit; the kernels live in
 //   pcl_device_common.hpp      parameter block, MFMA tile GEMM on LDS operands, wave-level helpers
 //   pcl_kernel_fused_v3.hpp    default residual + Jacobian kernel: persistent, one workgroup per CU, stream / matrix roles
-//   pcl_kernels_fused_v2.hpp   fallbacks (two workgroups per CU); also pcl_eval, kets, compact Jacobian
+//   pcl_kernels_fused_v2.hpp   fallback (two workgroups per CU); also kets and the compact Jacobian at large n
 //   pcl_kernels_reference.hpp  single-role kernel (A/B reference) and the general-order kernel (Pade 2..10)
 //   pcl_kernels_hessian.hpp    Hessian of the Lagrangian
 //   pcl_kernels_misc.hpp       compact -> full expansion, rollout, derivative / time rows, terminal infidelity
@@ -75,23 +75,12 @@ struct pcl_ctx {
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dmu = nullptr, *ddelta = nullptr, *dvals = nullptr, *dhess = nullptr;
     // options
-    int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_ablate = 0, opt_kernel = 0;  // 0 = auto: 3 when it applies, else 4 / 2 by work per workgroup
+    int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_kernel = 0;  // 0 = auto: 3 where its specialised instance applies, else 1 / 2 by shape
     long long *ddbg = nullptr;
     void *comm = nullptr;  // ncclComm_t
     double *dgoal = nullptr;  // iso-vec of the goal unitary (pcl_set_goal)
-    // split mode (producer kernel + concurrent expander kernel)
-    double *dblocks = nullptr;
-    unsigned int *dflags = nullptr;
-    hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int64_t opt_cpp = 6;  // block copies per expander work item
     int64_t opt_specialize = 1;
-    int64_t opt_sxcd = 0;     // v3, role split: stream role on whole XCDs (0: interleaved on every XCD)
-    int64_t opt_sdyn = 1;     // v3, role split: stream pieces handed out dynamically (when opt_snc > 0)
-    unsigned int *dsctr = nullptr;
-    int64_t opt_snc = 0;      // v3, role split: stream pieces of this many columns dealt round-robin (0: contiguous ranges)
     int64_t opt_jit = 1;      // compile shape-specialised instances on first use (hiprtc) for shapes outside the static table
-    int64_t opt_flat = 0;     // v3: line-aligned flat block stream (measured: no gain over the per-block stores, slower for one trajectory)
     int64_t opt_general = 0;  // 1: run the general-order kernel also for pade_order 4 (cross-check)
     int64_t opt_contig = -1;     // v3: contiguous column ranges per workgroup (-1: auto by launch size)
     int64_t opt_stream_wg = -1;  // v3, contiguous: stream-role workgroups (-1: auto = half, 0: every workgroup does both)
@@ -123,6 +112,28 @@ static int fail(const pcl_ctx *ctx, int code, const char *fmt, ...) {
         hipError_t e_ = (expr);                                                                 \
         if (e_ != hipSuccess) return fail(ctx, PCL_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// Every entry point runs on the context's device and leaves the caller's current device as it found it.
+namespace {
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            changed = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+}  // namespace
+#define ON_DEVICE(ctx)                                                                                         \
+    DeviceGuard dev_guard_((ctx)->device);                                                                     \
+    if (dev_guard_.err != hipSuccess) return fail(ctx, PCL_EHIP, "hipSetDevice(%d): %s", (ctx)->device, hipGetErrorString(dev_guard_.err))
 
 static long long jac_per_full(const pcl_ctx *c) {
     return 2LL * c->cols * c->n * c->n + c->x_dim * (c->desc.n_drives + 1);
@@ -220,7 +231,8 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
         }                                                                                              \
     } while (0)
 
-    CREATE_HIP(hipSetDevice(ctx->device));
+    DeviceGuard dev_guard_(ctx->device);
+    CREATE_HIP(dev_guard_.err);
     hipDeviceProp_t prop;
     CREATE_HIP(hipGetDeviceProperties(&prop, ctx->device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -377,20 +389,15 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
 extern "C" int pcl_comm_destroy(pcl_ctx *ctx);
 extern "C" void pcl_destroy(pcl_ctx *ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard dev_guard_(ctx->device);
     (void)pcl_comm_destroy(ctx);
     void *ptrs[] = {ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
                     ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg, ctx->dellt_col, ctx->dellt_val,
-                    ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout, ctx->dreduce, ctx->dsctr, ctx->dcompact};
+                    ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout, ctx->dreduce, ctx->dcompact};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (ctx->dgoal) (void)hipFree(ctx->dgoal);
-    if (ctx->dblocks) (void)hipFree(ctx->dblocks);
-    if (ctx->dflags) (void)hipFree(ctx->dflags);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -614,8 +621,12 @@ hipFunction_t jit_function(int device, const char *instance) {
         return nullptr;
     }
     g_rtc.AddNameExpression(prog, instance);
+#ifdef PCL_PROFILE
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-DPCL_PROFILE"};
+#else
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    if (g_rtc.CompileProgram(prog, 3, opts) != 0) {
+#endif
+    if (g_rtc.CompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts) != 0) {
         size_t ls = 0;
         g_jit_note = std::string("hiprtcCompileProgram failed for ") + instance;
         if (g_rtc.GetProgramLogSize && g_rtc.GetProgramLog && g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
@@ -690,7 +701,6 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.batch = D.batch;
     p.LD = lds_ld(ctx->n);
     p.nt = (int)ctx->opt_nt;
-    p.ablate = (int)ctx->opt_ablate;
     p.dbg = ctx->ddbg;
     p.hess_per = hess_per(ctx);
 }
@@ -887,7 +897,7 @@ static int launch_pade_general(pcl_ctx *ctx, KParams &p, bool want_jac) {
 }
 
 static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *jac, bool compact) {
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     KParams p;
     fill_params(ctx, p);
     p.Z = Z;
@@ -906,14 +916,6 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         // contiguous = 0 selects the round-robin slices
         p.contig = (compact || v3_contiguous(ctx)) ? 1 : 0;  // compact: contiguous ranges, every workgroup in the matrix role
         p.all_matrix = compact ? 1 : 0;
-        p.flat = ctx->opt_flat ? 1 : 0;
-        p.snc = (int)std::max<int64_t>(0, std::min<int64_t>(ctx->opt_snc, p.d));
-        p.sdyn = (p.snc > 0 && ctx->opt_sdyn) ? 1 : 0;
-        if (p.sdyn && !ctx->dsctr) {
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->dsctr, sizeof(unsigned int)));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->dsctr, 0, sizeof(unsigned int), ctx->stream));
-        }
-        p.sctr = ctx->dsctr;
         p.nc = p.contig ? p.d : choose_cols_v3(ctx);
         if (!p.contig && ctx->opt_cols_per_slice <= 0 && p.nc < 2 && p.d >= 2) p.nc = 2;  // keep the 2-column chunks of the specialised instance
         p.ncw = v3_ncw(ctx, p.nc);
@@ -958,10 +960,6 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         if (p.contig && !p.all_matrix && g3 >= 2 && v3_role_split_fits(ctx)) {
             const long long want = ctx->opt_stream_wg < 0 ? g3 / 2 : ctx->opt_stream_wg;  // auto: half the workgroups stream
             if (want > 0) p.n_stream = (int)std::min<long long>(want, g3 - 1);
-            if (ctx->opt_sxcd > 0 && ctx->opt_sxcd < 8 && (g3 & 7) == 0) {  // whole XCDs per role
-                p.sxcd = (int)ctx->opt_sxcd;
-                p.n_stream = (int)(g3 / 8 * ctx->opt_sxcd);
-            }
         }
         ctx->last_n_stream = p.n_stream;
         if (jitf) {
@@ -978,8 +976,7 @@ not_v3:
     // kernels there (measured: d <= 8 always, d <= 16 while all items fit one round of workgroups)
     const bool v1_auto = ctx->opt_kernel == 0 && (ctx->desc.d <= 8 || (ctx->desc.d <= 16 && (long long)ctx->desc.batch * ctx->K <= 512));
     const bool v2 = !v1_auto && (ctx->opt_kernel == 0 || ctx->opt_kernel >= 2) && ctx->opt_use_mfma != 0;
-    const bool unitary = !ctx->vec && ctx->cols == ctx->desc.d;  // kernels 3, 4, 5 and the specialised instances assume X is n x d
-    bool v4 = v2 && ctx->opt_kernel == 4 && want_jac && unitary;
+    const bool unitary = !ctx->vec && ctx->cols == ctx->desc.d;  // kernel 3 and the specialised instances assume X is n x d
     p.nc = choose_cols_per_slice(ctx, want_jac);
     auto bytes = [&]() { return v2 ? fused2_lds_bytes(p, want_jac, p.ell_lds != 0) : fused_lds_bytes(p, want_jac); };
     size_t lds = bytes();
@@ -993,77 +990,22 @@ not_v3:
     if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "grid too large");
     if (v2) {
         typedef void (*kern_t)(const KParams);
-        const int per_cu_guess = std::max(1, std::min(2, (int)((size_t)ctx->max_lds / lds)));
         const int wu = (ctx->uell_w <= 2 && ctx->n_upos <= 1024 && !ctx->desc.per_member_G0) ? ctx->uell_w : -1;
         kern_t kern = want_jac ? (wu == 1 ? (kern_t)pcl_fused_kernel_v2<true, 1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<true, 2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v2<true, -1, 0, 0, 0>)
                                : (wu == 1 ? (kern_t)pcl_fused_kernel_v2<false, 1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<false, 2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v2<false, -1, 0, 0, 0>);
         // shape-specialised instance (BASELINE config 3/4/5: three 3-level transmons, d = 27, six drives, 3-column slices)
         if (want_jac && unitary && wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize) kern = (kern_t)pcl_fused_kernel_v2<true, 1, 27, 6, 3>;
-        // auto: spreading an item's stores into the next item's phases pays once a workgroup walks several items
-        if (ctx->opt_kernel == 0 && want_jac && unitary && grid >= 4 * (long long)per_cu_guess * std::max(ctx->n_cu, 1)) v4 = true;
-        if (v4) {
-            kern = wu == 1 ? (kern_t)pcl_fused_kernel_v4<1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v4<2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v4<-1, 0, 0, 0>;
-            if (wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize) kern = (kern_t)pcl_fused_kernel_v4<1, 27, 6, 3>;
-        }
-        // jit = 2 (experiment): compile-time (d, m, slice width) for kernels 2 / 4 too -- measured from -8 % to +30 % depending
-        // on the shape (scripts/jit_probe.py), so not part of the default
-        hipFunction_t jit2 = nullptr;
-        const bool static2 = unitary && wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize && want_jac;
-        if (!static2 && ctx->opt_jit >= 2 && ctx->opt_specialize && want_jac && unitary && wu >= 1 && p.d >= 12 && ctx->opt_kernel != 5) {
-            char inst[96];
-            if (v4)
-                snprintf(inst, sizeof inst, "pcl_fused_kernel_v4<%d, %d, %d, %d>", wu, p.d, p.m, p.nc);
-            else
-                snprintf(inst, sizeof inst, "pcl_fused_kernel_v2<true, %d, %d, %d, %d>", wu, p.d, p.m, p.nc);
-            jit2 = jit_function(ctx->device, inst);
-        }
         ctx->last_n_stream = 0;
-        ctx->last_kernel = jit2 ? (v4 ? 42 : 22) : (v4 ? 40 : 20) + ((unitary && wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize && want_jac) ? 1 : 0);
-        if (!jit2) {
+        ctx->last_kernel = 20 + ((unitary && wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize && want_jac) ? 1 : 0);
+        {
             int rc = set_lds_attr(ctx, (const void *)kern, want_jac ? 4 : 5, lds);  // wu is fixed per context
             if (rc != PCL_OK) return rc;
-        }
-        const bool split = ctx->opt_kernel == 5 && want_jac && !compact && unitary;
-        if (split) {
-            const long long n_bk = (long long)p.batch * p.K;
-            if (!ctx->dblocks) {
-                HIP_TRY(ctx, hipMalloc((void **)&ctx->dblocks, (size_t)n_bk * 2 * p.n * p.n * sizeof(double)));
-                HIP_TRY(ctx, hipMalloc((void **)&ctx->dflags, (size_t)n_bk * sizeof(unsigned int)));
-                HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-                HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-                HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-            }
-            p.compact = 2;
-            p.blocks = ctx->dblocks;
-            p.flags = ctx->dflags;
-            kern = wu == 1 ? (kern_t)pcl_fused_kernel_v2<true, 1, 0, 0, 0> : wu == 2 ? (kern_t)pcl_fused_kernel_v2<true, 2, 0, 0, 0> : (kern_t)pcl_fused_kernel_v2<true, -1, 0, 0, 0>;
-            if (wu == 1 && p.d == 27 && p.m == 6 && p.nc == 3 && ctx->opt_specialize) kern = (kern_t)pcl_fused_kernel_v2<true, 1, 27, 6, 3>;
-            ctx->last_kernel = 50;
-            HIP_TRY(ctx, hipMemsetAsync(ctx->dflags, (ctx->opt_ablate & 64) ? 0xFF : 0, (size_t)n_bk * sizeof(unsigned int), ctx->stream));
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
         }
         // persistent grid: as many workgroups as are resident at once
         const int per_cu = std::max(1, std::min(2, (int)((size_t)ctx->max_lds / lds)));
         const long long resident = (long long)per_cu * std::max(ctx->n_cu, 1);
         const long long g2 = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, grid) : std::min(grid, resident);
-        if (jit2) {
-            void *args[] = {(void *)&p};
-            HIP_TRY(ctx, hipModuleLaunchKernel(jit2, (unsigned)g2, 1, 1, 512, 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
-        } else if (!(split && (ctx->opt_ablate & 64)))
-            hipLaunchKernelGGL(kern, dim3((unsigned)g2), dim3(512), lds, ctx->stream, p);
-        if (split) {
-            // the expander leaves wave slots and all LDS to the producer: at most 4 x 256 threads per CU
-            const int cpp = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_cpp, 2 * p.d));
-            const int pieces = (2 * p.d + cpp - 1) / cpp;
-            const long long n_bk = (long long)p.batch * p.K;
-            const long long eg = std::min<long long>(n_bk * pieces, 4LL * std::max(ctx->n_cu, 1));
-            hipLaunchKernelGGL(pcl_expand_stream_kernel, dim3((unsigned)eg), dim3(256), 0, ctx->aux_stream, ctx->dblocks, ctx->dflags, jac,
-                               p.d, p.n, jac_per_full(ctx), n_bk, pieces, cpp, p.nt);
-            HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)g2), dim3(512), lds, ctx->stream, p);
     } else {
         const bool mf = ctx->opt_use_mfma != 0;
         auto kern = want_jac ? (mf ? pcl_fused_kernel<true, true> : pcl_fused_kernel<true, false>)
@@ -1106,7 +1048,7 @@ static size_t hess2_lds_bytes(const KParams &p) {
 }
 
 static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *hess) {
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     KParams p;
     fill_params(ctx, p);
     p.Z = Z;
@@ -1136,9 +1078,10 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             ctx->hpart_cap = 0;
             HIP_TRY(ctx, hipMalloc((void **)&ctx->dhpart, (size_t)nbk * p.S * nscal * sizeof(double)));
             HIP_TRY(ctx, hipMalloc((void **)&ctx->dhcnt, (size_t)nbk * sizeof(unsigned int)));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->dhcnt, 0, (size_t)nbk * sizeof(unsigned int), ctx->stream));
             ctx->hpart_cap = nbk * p.S;
         }
+        // arrival counters start from zero in every launch (a launch that faulted must not poison the next one)
+        if (p.S > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->dhcnt, 0, (size_t)nbk * sizeof(unsigned int), ctx->stream));
         p.hpart = ctx->dhpart;
         p.hcnt = ctx->dhcnt;
         const size_t lds = hess2_lds_bytes(p);
@@ -1218,9 +1161,14 @@ extern "C" int pcl_eval_jac_compact_dev(pcl_ctx *ctx, const double *Z, double *d
 extern "C" int pcl_jac_expand_dev(pcl_ctx *ctx, const double *compact, double *vals) {
     if (!ctx) return PCL_EINVAL;
     if (!compact || !vals) return fail(ctx, PCL_EINVAL, "pcl_jac_expand_dev: NULL pointer");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     const long long n_bk = (long long)ctx->desc.batch * ctx->K;
     const long long grid = n_bk * ctx->cols;
+    if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "pcl_jac_expand_dev: %lld work items exceed the grid limit", grid);
+    if (ctx->cols == 1) {  // one state column (kets, compact density vectors): the compact layout IS the full layout
+        HIP_TRY(ctx, hipMemcpyAsync(vals, compact, (size_t)(n_bk * jac_per_full(ctx)) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        return PCL_OK;
+    }
     hipLaunchKernelGGL(pcl_expand_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, compact, vals, ctx->cols, ctx->n,
                        ctx->desc.n_drives, n_bk, (int)ctx->opt_nt);
     HIP_TRY(ctx, hipGetLastError());
@@ -1235,7 +1183,7 @@ extern "C" int pcl_hess_dev(pcl_ctx *ctx, const double *Z, const double *mu, dou
 extern "C" int pcl_rollout_dev(pcl_ctx *ctx, const double *Z, double *X_out) {
     if (!ctx) return PCL_EINVAL;
     if (!Z || !X_out) return fail(ctx, PCL_EINVAL, "pcl_rollout_dev: NULL pointer");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     KParams p;
     fill_params(ctx, p);
     p.Z = Z;
@@ -1270,7 +1218,7 @@ static int ensure(pcl_ctx *ctx, double **buf, long long count) {
 static int host_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *vals) {
     if (!ctx) return PCL_EINVAL;
     if (!Z || (!delta && !vals)) return fail(ctx, PCL_EINVAL, "NULL pointer");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     const long long nv = jac_per_full(ctx) * ctx->desc.batch * ctx->K;
     TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
     TRY(ensure(ctx, &ctx->ddelta, n_rows(ctx)));
@@ -1297,7 +1245,7 @@ extern "C" int pcl_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double
 extern "C" int pcl_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *vals) {
     if (!ctx) return PCL_EINVAL;
     if (!Z || !mu || !vals) return fail(ctx, PCL_EINVAL, "pcl_hess: NULL pointer");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     const long long nv = hess_per(ctx) * ctx->desc.batch * ctx->K;
     TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
     TRY(ensure(ctx, &ctx->dmu, n_rows(ctx)));
@@ -1313,7 +1261,7 @@ extern "C" int pcl_hess(pcl_ctx *ctx, const double *Z, const double *mu, double 
 extern "C" int pcl_rollout(pcl_ctx *ctx, const double *Z, double *X_out) {
     if (!ctx) return PCL_EINVAL;
     if (!Z || !X_out) return fail(ctx, PCL_EINVAL, "pcl_rollout: NULL pointer");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     const long long nv = (long long)ctx->desc.batch * ctx->desc.N * ctx->x_dim;
     TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
     TRY(ensure(ctx, &ctx->dxout, nv));
@@ -1362,7 +1310,7 @@ extern "C" int pcl_deriv_eval_jac_dev(pcl_ctx *ctx, int32_t x_off, int32_t dx_of
     if (!ctx) return PCL_EINVAL;
     if (!Z || (!delta && !vals)) return fail(ctx, PCL_EINVAL, "pcl_deriv_eval_jac_dev: NULL pointer");
     TRY(deriv_check(ctx, x_off, dx_off, dim));
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     const pcl_desc &D = ctx->desc;
     const long long nb = D.batch_mode == PCL_BATCH_TRAJ ? D.batch : 1;
     const long long total = nb * ctx->K * dim;
@@ -1376,7 +1324,7 @@ extern "C" int pcl_deriv_eval_jac(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, i
     if (!ctx) return PCL_EINVAL;
     if (!Z || (!delta && !vals)) return fail(ctx, PCL_EINVAL, "pcl_deriv_eval_jac: NULL pointer");
     TRY(deriv_check(ctx, x_off, dx_off, dim));
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     int64_t nr = 0, nz = 0;
     pcl_deriv_nnz(ctx, dx_off, dim, &nr, &nz);
     double *dd = nullptr, *dv = nullptr;
@@ -1402,7 +1350,7 @@ extern "C" int pcl_deriv_eval_jac(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, i
 extern "C" int pcl_set_goal(pcl_ctx *ctx, const double *goal_iso_vec) {
     if (!ctx) return PCL_EINVAL;
     if (!goal_iso_vec) return fail(ctx, PCL_EINVAL, "pcl_set_goal: NULL");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     if (!ctx->dgoal) HIP_TRY(ctx, hipMalloc((void **)&ctx->dgoal, (size_t)ctx->x_dim * sizeof(double)));
     HIP_TRY(ctx, hipMemcpy(ctx->dgoal, goal_iso_vec, (size_t)ctx->x_dim * sizeof(double), hipMemcpyHostToDevice));
     return PCL_OK;
@@ -1412,7 +1360,7 @@ extern "C" int pcl_infidelity_dev(pcl_ctx *ctx, const double *Z, double Q, doubl
     if (!Z || (!value && !grad)) return fail(ctx, PCL_EINVAL, "pcl_infidelity_dev: NULL pointer");
     if (!ctx->dgoal) return fail(ctx, PCL_EINVAL, "pcl_infidelity_dev: call pcl_set_goal first");
     if (ctx->vec || ctx->cols != ctx->desc.d) return fail(ctx, PCL_ENOTIMPL, "pcl_infidelity_dev: unitary (n x d) states only");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     const pcl_desc &D = ctx->desc;
     hipLaunchKernelGGL(pcl_infidelity_kernel, dim3((unsigned)D.batch), dim3(256), 0, ctx->stream, Z, ctx->dgoal, ctx->dxoffs, value, grad, Q,
                        D.d, D.N, D.z_dim, D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0LL);
@@ -1466,7 +1414,7 @@ extern "C" int pcl_comm_init(pcl_ctx *ctx, const pcl_comm_id *id, int32_t rank, 
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, PCL_EINVAL, "pcl_comm_init: rank %d of %d", rank, nranks);
     if (ctx->comm) return fail(ctx, PCL_EINVAL, "pcl_comm_init: communicator already initialised");
     TRY(rccl_load(ctx));
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     int nrc = g_rccl.CommInitRank(&ctx->comm, nranks, *id, rank);
     if (nrc != 0) {
         ctx->comm = nullptr;
@@ -1478,7 +1426,7 @@ extern "C" int pcl_reduce_sum_dev(pcl_ctx *ctx, double *buf_dev, int64_t n) {
     if (!ctx) return PCL_EINVAL;
     if (!buf_dev || n < 0) return fail(ctx, PCL_EINVAL, "pcl_reduce_sum_dev: bad buffer");
     if (!ctx->comm) return fail(ctx, PCL_ERCCL, "pcl_reduce_sum_dev: call pcl_comm_init first");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     int nrc = g_rccl.AllReduce(buf_dev, buf_dev, (size_t)n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
     return nrc == 0 ? PCL_OK : rccl_fail(ctx, "ncclAllReduce", nrc);
 }
@@ -1487,7 +1435,7 @@ extern "C" int pcl_reduce_sum(pcl_ctx *ctx, double *buf, int64_t n) {  // host b
     if (!buf || n < 0) return fail(ctx, PCL_EINVAL, "pcl_reduce_sum: bad buffer");
     if (!ctx->comm) return fail(ctx, PCL_ERCCL, "pcl_reduce_sum: call pcl_comm_init first");
     if (n == 0) return PCL_OK;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ON_DEVICE(ctx);
     if (ctx->reduce_cap < n) {
         if (ctx->dreduce) (void)hipFree(ctx->dreduce);
         ctx->dreduce = nullptr;
@@ -1518,24 +1466,12 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_use_mfma = v != 0;
     else if (!strcmp(key, "nt_stores"))
         ctx->opt_nt = v != 0;
-    else if (!strcmp(key, "debug_ablate"))  // profiling aid: results are WRONG when non-zero
-        ctx->opt_ablate = v;
     else if (!strcmp(key, "grid"))
         ctx->opt_grid = v;
-    else if (!strcmp(key, "copies_per_piece"))
-        ctx->opt_cpp = v;
     else if (!strcmp(key, "specialize"))  // 0: always the run-time-shape kernel instances
         ctx->opt_specialize = v != 0;
-    else if (!strcmp(key, "stream_xcds"))  // kernel 3, role split: k > 0 = the workgroups of XCDs 0..k-1 stream, the others do the column work
-        ctx->opt_sxcd = v;
-    else if (!strcmp(key, "stream_dynamic"))  // kernel 3, role split with stream_piece_cols > 0: 1 = ticket counter, 0 = round-robin
-        ctx->opt_sdyn = v != 0;
-    else if (!strcmp(key, "stream_piece_cols"))  // kernel 3, role split: > 0 = stream pieces of this many columns, round-robin
-        ctx->opt_snc = v;
-    else if (!strcmp(key, "jit"))  // 1 (default): compile the context's shape on first use when no static instance matches; 2: also kernels 2 / 4
-        ctx->opt_jit = v < 0 ? 0 : (v > 2 ? 2 : v);
-    else if (!strcmp(key, "aligned_stream"))  // kernel 3: 1 = line-aligned flat block stream, 0 = per-block stores from registers (default)
-        ctx->opt_flat = v != 0;
+    else if (!strcmp(key, "jit"))  // 1 (default): compile the context's shape on first use when no static instance matches
+        ctx->opt_jit = v != 0;
     else if (!strcmp(key, "general_threads"))  // general-order kernel: 256 or 512 (default) threads per workgroup
         ctx->opt_general_threads = v == 256 ? 256 : 512;
     else if (!strcmp(key, "general_two_step"))  // general-order kernel: 1 = unique tiles + expansion kernel, 0 (default) = one kernel writes every copy
@@ -1551,6 +1487,9 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_hess_kernel = v;
     }
     else if (!strcmp(key, "debug_timing")) {  // profiling aid: cycle stamps of workgroup 0 (pcl_debug_timing reads them)
+#ifndef PCL_PROFILE
+        if (v) return fail(ctx, PCL_ENOTIMPL, "debug_timing needs a library built with -DPCL_PROFILE (the shipped kernels carry no stamps)");
+#endif
         if (v && !ctx->ddbg) {
             HIP_TRY(ctx, hipMalloc((void **)&ctx->ddbg, PCL_DBG_WORDS * sizeof(long long)));
             HIP_TRY(ctx, hipMemset(ctx->ddbg, 0, PCL_DBG_WORDS * sizeof(long long)));
@@ -1560,7 +1499,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         }
     }
     else if (!strcmp(key, "kernel_version")) {
-        if (v < 0 || v > 5) return fail(ctx, PCL_EINVAL, "kernel_version must be 0 (auto), 1, 2, 3, 4 or 5 (split)");
+        if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "kernel_version must be 0 (auto), 1, 2 or 3");
         ctx->opt_kernel = v;
     }
     else
