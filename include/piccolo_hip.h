@@ -147,7 +147,16 @@ int pcl_reset_stream(pcl_ctx *ctx); /* back to the context's own non-blocking st
 int pcl_sync(pcl_ctx *ctx);
 int pcl_eval_dev(pcl_ctx *ctx, const double *Z_dev, double *delta_dev);
 int pcl_eval_jac_dev(pcl_ctx *ctx, const double *Z_dev, double *delta_dev, double *vals_dev);
+int pcl_jac_dev(pcl_ctx *ctx, const double *Z_dev, double *vals_dev); /* eval_jacobian alone (integrators.jl:780) */
 int pcl_hess_dev(pcl_ctx *ctx, const double *Z_dev, const double *mu_dev, double *vals_dev);
+
+/* Member window: restrict the evaluator entry points (pcl_eval*, pcl_jac*, pcl_hess*, pcl_rollout*, their nnz / structure
+ * queries and pcl_constraint_dim's row count) to members / seeds [first, first+count) of the context.  Inputs stay the full
+ * buffers (Z of every member; TRAJ mode: of every seed); outputs, multipliers and structure rows are those of the window,
+ * numbered from 0.  This is what one member of the reference's Vector{BilinearIntegrator} evaluates
+ * (src/control/integrators.jl:134-146: one integrator per ensemble member, rows of each numbered on their own).
+ * The objective / merit entry points always cover every member.  Default: all members. */
+int pcl_set_member_window(pcl_ctx *ctx, int32_t first, int32_t count);
 
 /* Compact Jacobian: the d diagonal copies of I_d (x) B^{+-} are identical, so per (b,k) only
  * [-B^+ (n*n) | B^- (n*n) | d/du (m*x_dim) | d/ddt (x_dim)] = 2 n^2 + x_dim (m+1) doubles are unique.
@@ -169,13 +178,38 @@ int pcl_deriv_eval_jac(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim,
 int pcl_deriv_eval_jac_dev(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim, const double *Z_dev, double *delta_dev,
                            double *vals_dev);
 
-/* terminal objective of the unitary problems ---------------------------------------------------
- *   UnitaryInfidelityObjective: Q * |1 - |tr(U_goal' U_N)|^2 / d^2|             src/control/objectives.jl:330-356
- * pcl_set_goal copies the goal's iso-vec (x_dim doubles, operator_to_iso_vec(U_goal)).  pcl_infidelity_dev writes one value
- * per member / seed (value_dev[batch]) and the gradient w.r.t. that member's terminal state (grad_dev[batch*x_dim], iso-vec
- * order); either output may be NULL.  Subspace (EmbeddedOperator) fidelity and the regularisers stay with the caller. */
+/* objective of the unitary problems -------------------------------------------------------------
+ *   UnitaryInfidelityObjective: Q * |1 - F(U_N)|,  F = |tr(U_goal' U_N)|^2 / d^2          src/control/objectives.jl:330-337,347-356
+ *   ... with an EmbeddedOperator goal: F = (tr(M'M) + |tr M|^2) / (ns (ns+1)),
+ *       M = U_goal[sub,sub]' U_N[sub,sub]                                                   src/control/objectives.jl:339-345
+ *   SamplingProblem: sum_i (w_i Q) |1 - F_i| + shared regularisers                          src/control/templates/sampling_problem.jl:381-387
+ *   QuadraticRegularizer(name, traj, R) x3 [EXT DirectTrajOpt]                              src/control/templates/smooth_pulse_problem.jl:249-251
+ * pcl_set_goal copies the goal's iso-vec (x_dim doubles, operator_to_iso_vec(U_goal)); pcl_set_goal_subspace the iso-vec of
+ * the ns x ns block unembed(op) (2 ns^2 doubles) and its ns 0-based subspace indices (op.subspace - 1); the later call wins.
+ * pcl_set_weights: per member / seed weights w (batch doubles, NULL = ones).
+ * pcl_infidelity_dev writes one value per member / seed (value_dev[batch]) and the gradient w.r.t. that member's terminal
+ * state (grad_dev[batch*x_dim], iso-vec order); either output may be NULL.
+ * Regularisers: J_r = 1/2 sum_k dt_k^p sum_i R_i Z[k, off+i]^2 with p = dt_power in {0, 1, 2}.  DirectTrajOpt is not vendored
+ * with the reference and nothing in the reference pins the value; p = 2 (r_k = dt_k v_k, J += r_k' R r_k / 2) is the form of
+ * its QuantumCollocation lineage, p = 0 the plain knot-point form -- the binding chooses.
+ * pcl_objective[_dev]: the whole objective and its gradient w.r.t. the variable vector.  MEMBERS mode: value[1] = sum over
+ * members + regularisers, grad[z_dim*N].  TRAJ mode: value[batch], grad[batch][z_dim*N] (one NLP per seed).  grad may be NULL. */
 int pcl_set_goal(pcl_ctx *ctx, const double *goal_iso_vec);
+int pcl_set_goal_subspace(pcl_ctx *ctx, const double *goal_sub_iso_vec, const int32_t *subspace, int32_t ns);
+int pcl_set_weights(pcl_ctx *ctx, const double *weights);
 int pcl_infidelity_dev(pcl_ctx *ctx, const double *Z_dev, double Q, double *value_dev, double *grad_dev);
+int pcl_add_regularizer(pcl_ctx *ctx, int32_t off, int32_t dim, const double *R, int32_t dt_power);
+int pcl_clear_regularizers(pcl_ctx *ctx);
+int pcl_objective_dev(pcl_ctx *ctx, const double *Z_dev, double Q, double *value_dev, double *grad_dev);
+int pcl_objective(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad);
+
+/* what a sharded ensemble exchanges: out = [phi | g_u (K x m, interval-major) | g_dt (K)] with
+ *   phi = sum_b w_b <lam_b, delta_b>  (lam_dev == NULL: lam = delta and phi = 1/2 sum_b w_b |delta_b|^2, the constraint merit),
+ *   g = J^T (w lam) restricted to the SHARED variables u_k, dt_k -- the only part of the Lagrangian gradient to which other
+ * ranks' members contribute (member states are rank-private).  MEMBERS mode: one set of pcl_merit_grad_len doubles, to be
+ * summed over ranks with pcl_reduce_sum_dev; TRAJ mode: `sets` = batch sets (nothing is shared between seeds). */
+int pcl_merit_grad_len(const pcl_ctx *ctx, int64_t *len, int64_t *sets);
+int pcl_merit_grad_dev(pcl_ctx *ctx, const double *delta_dev, const double *lam_dev, const double *vals_dev, double *out_dev);
 
 /* rollout for validation ------------------------------------------------------------------------
  *   unitary_rollout(traj, sys; interpolation = :constant)                       src/quantum/dynamics.jl:631-667

@@ -38,6 +38,7 @@ Pade formulas (diagonal Pade approximant of exp):
 from __future__ import annotations
 
 import dataclasses
+import itertools
 import struct
 from typing import List, Optional, Sequence
 
@@ -604,6 +605,188 @@ def pade_jacobian_dense(Z, lay: Layout, G0, Gj, order=4, x_off=None):
     J = np.zeros((lay.x_dim * lay.K, lay.z_dim * lay.N))
     np.add.at(J, (rows, cols), vals)
     return J
+
+
+def exp_jacobian_values(Z, lay: Layout, G0, Gj, x_off=None):
+    """Jacobian of the REFERENCE's constraint  delta_k = x_{k+1} - exp(dt_k Ghat(u_k)) x_k
+    [REF docs/src/concepts/index.md:21; integrators.jl:48] in the SAME triplet order as ``pade_jacobian_values``:
+    d/dX_k = -(I_d (x) E), d/dX_{k+1} = I, d/du_l = -L(hG; h G_l) X_k (L = Frechet derivative of expm,
+    scipy.linalg.expm_frechet, Al-Mohy & Higham), d/dh = -G E X_k.  The reference itself obtains these numbers by
+    ForwardDiff through expv [REF integrators.jl:282-285]; this is what the Pade Jacobian is pinned against."""
+    d, n, m = lay.C, lay.n, lay.m
+    per = jac_nnz_per_interval(lay)
+    out = np.empty((lay.K, per))
+    for k in range(lay.K):
+        G = G0 + np.tensordot(lay.u(Z, k), Gj, axes=1) if m else G0
+        h = lay.dt(Z, k)
+        Xc = lay.X(Z, k, x_off)
+        E = scipy.linalg.expm(h * G)
+        nb = d * n * n
+        out[k, :nb] = np.tile((-E).T.reshape(-1), d)
+        out[k, nb : 2 * nb] = np.tile(np.eye(n).T.reshape(-1), d)
+        tail = np.empty((d, m + 1, n))
+        for l in range(m):
+            L = scipy.linalg.expm_frechet(h * G, h * Gj[l], compute_expm=False)
+            tail[:, l, :] = (-(L @ Xc)).T
+        tail[:, m, :] = (-(G @ E @ Xc)).T
+        out[k, 2 * nb :] = tail.reshape(-1)
+    return out
+
+
+def pade_jacobian_in_exp_form(Z, lay: Layout, G0, Gj, order, x_off=None):
+    """The Pade-p Jacobian premultiplied by (B^-_p)^{-1} per interval:  delta^P = B^- (X_{k+1} - R_p X_k) with
+    R_p = (B^-)^{-1} B^+ the (p/2, p/2) Pade approximant of exp, so (B^-)^{-1} J^P is the Jacobian of
+    X_{k+1} - R_p X_k up to terms proportional to the residual itself.  On a trajectory that satisfies the constraint
+    this equals ``exp_jacobian_values`` to the truncation order of R_p.  Same triplet order."""
+    c = pade_coeffs(order)
+    q = order // 2
+    d, n, m = lay.C, lay.n, lay.m
+    V = pade_jacobian_values(Z, lay, G0, Gj, order, x_off)
+    out = np.empty_like(V)
+    nb = d * n * n
+    for k in range(lay.K):
+        G = G0 + np.tensordot(lay.u(Z, k), Gj, axes=1) if m else G0
+        h = lay.dt(Z, k)
+        P = _powers(G, q)
+        Bm = sum(c[j] * (-h) ** j * P[j] for j in range(q + 1))
+        Bi = np.linalg.inv(Bm)
+        for seg in range(2):
+            blocks = V[k, seg * nb : (seg + 1) * nb].reshape(d, n, n)  # [copy][col j][row i]
+            out[k, seg * nb : (seg + 1) * nb] = np.stack([(Bi @ b.T).T for b in blocks]).reshape(-1)
+        tail = V[k, 2 * nb :].reshape(d, m + 1, n)
+        out[k, 2 * nb :] = np.einsum("ij,clj->cli", Bi, tail).reshape(-1)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# Objectives of the unitary problems (SURVEY 8(f) row 1).
+#   unitary_fidelity_loss(Utilde, U_goal)                [REF src/control/objectives.jl:330-337]
+#   unitary_fidelity_loss(Utilde, op::EmbeddedOperator)   [REF src/control/objectives.jl:339-345]
+#   UnitaryInfidelityObjective = TerminalObjective(|1 - F|; Q)   [REF :347-356]  (Q * l(x_N), DirectTrajOpt [EXT])
+#   embed / unembed / get_subspace_indices                [REF src/quantum/operators/embedded_operators.jl:24-40,116-131,345-369]
+#   weighted ensemble sum  sum_i w_i Q l_i + regularisers  [REF src/control/templates/sampling_problem.jl:381-387]
+#   QuadraticRegularizer(name, traj, R)                   [EXT DirectTrajOpt; used at smooth_pulse_problem.jl:249-251]
+# --------------------------------------------------------------------------- #
+
+
+def get_subspace_indices(subspaces, subsystem_levels):
+    """0-based indices of the product basis states whose every subsystem level lies in that subsystem's subspace
+    (``subspaces`` 0-based level lists).  [REF embedded_operators.jl:352-364; literal [1:2,1:2],[3,3] -> [1,2,4,5] (1-based) :629]"""
+    idx = []
+    for flat, lv in enumerate(itertools.product(*[range(L) for L in subsystem_levels])):
+        if all(l in sub for l, sub in zip(lv, subspaces)):
+            idx.append(flat)
+    return idx
+
+
+def embed(op, subspace, levels):
+    """Place the subspace operator into a levels x levels zero matrix.  [REF embedded_operators.jl:24-32]"""
+    out = np.zeros((levels, levels), dtype=complex)
+    out[np.ix_(subspace, subspace)] = np.asarray(op)
+    return out
+
+
+def unembed(op_embedded, subspace):
+    """[REF embedded_operators.jl:34-40]"""
+    return np.asarray(op_embedded)[np.ix_(subspace, subspace)]
+
+
+def unitary_fidelity_loss(Uvec, U_goal, subspace=None):
+    """F: |tr(U_goal' U)|^2 / n^2 for a matrix goal; for an embedded goal (``subspace`` given, ``U_goal`` the embedded
+    levels x levels operator) the reference's subspace formula (tr(M'M) + |tr M|^2) / (n (n+1)), M = U_goal_sub' U_sub."""
+    U = iso_vec_to_operator(np.asarray(Uvec, dtype=float))
+    Ug = np.asarray(U_goal, dtype=complex)
+    if subspace is None:
+        n = U.shape[0]
+        return abs(np.trace(Ug.conj().T @ U)) ** 2 / n**2
+    Ugs = unembed(Ug, subspace)
+    Us = U[np.ix_(subspace, subspace)]
+    n = len(subspace)
+    M = Ugs.conj().T @ Us
+    return (abs(np.trace(M.conj().T @ M)) + abs(np.trace(M)) ** 2) / (n * (n + 1))
+
+
+def unitary_infidelity(Uvec, U_goal, Q=100.0, subspace=None):
+    """Q * |1 - F|  (UnitaryInfidelityObjective's terminal term)."""
+    return Q * abs(1.0 - unitary_fidelity_loss(Uvec, U_goal, subspace))
+
+
+def unitary_infidelity_gradient(Uvec, U_goal, Q=100.0, subspace=None):
+    """Gradient of ``unitary_infidelity`` w.r.t. the iso-vec (analytic; the reference differentiates with ForwardDiff)."""
+    U = iso_vec_to_operator(np.asarray(Uvec, dtype=float))
+    Ug = np.asarray(U_goal, dtype=complex)
+    lv = U.shape[0]
+    dF = np.zeros((lv, lv), dtype=complex)  # dF/dRe(U) + i dF/dIm(U)
+    if subspace is None:
+        t = np.trace(Ug.conj().T @ U)
+        dF = 2.0 * t * Ug / lv**2  # t = sum conj(g) u:  dF/dRe(u) = 2 Re(t g), dF/dIm(u) = 2 Im(t g)
+        F = abs(t) ** 2 / lv**2
+    else:
+        Ugs = unembed(Ug, subspace)
+        Us = U[np.ix_(subspace, subspace)]
+        n = len(subspace)
+        M = Ugs.conj().T @ Us
+        t = np.trace(M)
+        W = Ugs @ M  # d tr(M'M) / d conj(U_s)
+        dsub = (2.0 * W + 2.0 * t * Ugs) / (n * (n + 1))
+        dF[np.ix_(subspace, subspace)] = dsub
+        F = (abs(np.trace(M.conj().T @ M)) + abs(t) ** 2) / (n * (n + 1))
+    sgn = 1.0 if 1.0 - F >= 0.0 else -1.0
+    g = -sgn * Q * dF
+    return operator_to_iso_vec_parts(g.real, g.imag)
+
+
+def operator_to_iso_vec_parts(re, im):
+    """iso-vec layout (column c = [Re U[:,c]; Im U[:,c]]) from separate real / imaginary parts."""
+    lv = re.shape[0]
+    out = np.empty(2 * lv * lv)
+    for c in range(lv):
+        out[c * 2 * lv : c * 2 * lv + lv] = re[:, c]
+        out[c * 2 * lv + lv : (c + 1) * 2 * lv] = im[:, c]
+    return out
+
+
+def quadratic_regularizer(Z, off, dim, R, dt_off, dt_power=2):
+    """DirectTrajOpt's QuadraticRegularizer(name, traj, R) [EXT; un-vendored -- the QuantumCollocation-lineage form]:
+        J = 1/2 sum_k (dt_k^p) * sum_i R_i v_{k,i}^2 ,   v = Z[k, off:off+dim]
+    with p = dt_power = 2 (r_k = dt_k v_k, J += r_k' R r_k / 2); p = 0 drops the time-step weighting (knot-point form).
+    Nothing in the reference pins the value (its tests only check the term exists and is zero for R = 0,
+    [REF spline_pulse_problem.jl:1570-1578]); ``dt_power`` is a parameter of the C ABI for that reason."""
+    Z = np.asarray(Z)
+    R = np.broadcast_to(np.asarray(R, dtype=float), (dim,))
+    v = Z[:, off : off + dim]
+    w = Z[:, dt_off] ** dt_power if dt_power else np.ones(Z.shape[0])
+    return 0.5 * float(np.sum(w[:, None] * R[None, :] * v * v))
+
+
+def quadratic_regularizer_gradient(Z, off, dim, R, dt_off, dt_power=2):
+    """Gradient of ``quadratic_regularizer`` w.r.t. the whole knot array (same shape as Z)."""
+    Z = np.asarray(Z)
+    R = np.broadcast_to(np.asarray(R, dtype=float), (dim,))
+    g = np.zeros_like(Z)
+    v = Z[:, off : off + dim]
+    h = Z[:, dt_off]
+    w = h**dt_power if dt_power else np.ones(Z.shape[0])
+    g[:, off : off + dim] += w[:, None] * R[None, :] * v
+    if dt_power:
+        g[:, dt_off] += 0.5 * dt_power * h ** (dt_power - 1) * np.sum(R[None, :] * v * v, axis=1)
+    return g
+
+
+def sampling_objective(Z, lay: Layout, x_offs, goal, weights, Q, regs=(), subspace=None):
+    """SamplingProblem objective  sum_i (w_i Q) |1 - F_i(x_N^{(i)})| + sum regs  [REF sampling_problem.jl:381-387]
+    (regs: tuples (off, dim, R, dt_power)); returns (value, gradient [N, z_dim])."""
+    Z = np.asarray(Z)
+    J = 0.0
+    g = np.zeros_like(Z)
+    for xo, w in zip(x_offs, weights):
+        xN = Z[-1, xo : xo + lay.x_dim]
+        J += unitary_infidelity(xN, goal, w * Q, subspace)
+        g[-1, xo : xo + lay.x_dim] += unitary_infidelity_gradient(xN, goal, w * Q, subspace)
+    for off, dim, R, pw in regs:
+        J += quadratic_regularizer(Z, off, dim, R, lay.dt_off, pw)
+        g += quadratic_regularizer_gradient(Z, off, dim, R, lay.dt_off, pw)
+    return J, g
 
 
 # --------------------------------------------------------------------------- #

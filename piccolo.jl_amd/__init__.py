@@ -4,12 +4,13 @@ Piccolo.jl / DirectTrajOpt.jl (one hot path; see DESIGN.md and SURVEY.md section
 The directory name contains a dot, so it is imported through the loader shim
 ``piccolo_jl_amd.py`` at the repository root:  ``import piccolo_jl_amd as pa``.
 """
-from . import _lib, distributed, integrators, quantum, synthetic, trajectory
+from . import _lib, distributed, integrators, objectives, quantum, synthetic, trajectory
 from ._lib import PclError, build_library
 from .integrators import (
     BilinearIntegrator,
     DerivativeIntegrator,
     HipPadeIntegrator,
+    HipPadeMemberIntegrator,
     HipPadeMultistart,
     eval_hessian_of_lagrangian,
     eval_jacobian,
@@ -19,6 +20,7 @@ from .integrators import (
     unitary_rollout,
     unitary_rollout_fidelity,
 )
+from .objectives import EmbeddedOperator, Objective, QuadraticRegularizer, UnitaryInfidelityObjective, get_subspace_indices
 from .quantum import (
     GATES,
     PAULIS,

@@ -153,48 +153,245 @@ __global__ __launch_bounds__(256) void pcl_deriv_kernel(const double *__restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// Terminal unitary infidelity  Q * |1 - |tr(U_goal' U_N)|^2 / d^2|  and its gradient w.r.t. the terminal iso-vec
-// (reference: src/control/objectives.jl:330-356).  One workgroup per member / seed.
+// Terminal unitary infidelity  w_b Q * |1 - F|  and its gradient w.r.t. the terminal iso-vec.
+// One workgroup per member / seed.  Two fidelities, as in the reference:
+//   matrix goal      F = |tr(U_goal' U_N)|^2 / d^2                                    src/control/objectives.jl:330-337
+//   EmbeddedOperator F = (tr(M'M) + |tr M|^2) / (ns (ns+1)),  M = Ug_sub' U_N[sub,sub]  src/control/objectives.jl:339-345
 // With X = [Re U; Im U] (n x d, column c at x[c*n ..]) and the goal stored the same way:
-//   t = tr(Ug' U) = sum (gr*ur + gi*ui) + i sum (gr*ui - gi*ur);  F = |t|^2 / d^2
-//   dF/dur = 2 (tr*gr - ti*gi) / d^2 ,  dF/dui = 2 (tr*gi + ti*gr) / d^2
+//   t = tr(Ug' U) = sum conj(g) u;  d|t|^2/dRe(u) = 2 Re(t g),  d|t|^2/dIm(u) = 2 Im(t g);
+//   d tr(M'M)/d(Re, Im)(U_sub) = 2 (Re, Im)(Ug_sub M).
+// `accumulate`: add the gradient into grad (which then is the full-trajectory gradient buffer, terminal knot slot of
+// this member) instead of overwriting a per-member x_dim slot.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pcl_infidelity_kernel(const double *__restrict__ Z, const double *__restrict__ goal,
-                                                             const int *__restrict__ x_offs, double *__restrict__ value,
-                                                             double *__restrict__ grad, double Q, int d, int N, int z_dim,
-                                                             long long z_batch_stride) {
-    __shared__ double red[2][8];
-    const int n = 2 * d, b = blockIdx.x, tid = threadIdx.x;
-    const double *x = Z + (long long)b * z_batch_stride + (long long)(N - 1) * z_dim + x_offs[z_batch_stride ? 0 : b];
-    double tr = 0.0, ti = 0.0;
-    for (int e = tid; e < d * d; e += 256) {
-        const int c = e / d, i = e - c * d;
-        const double ur = x[c * n + i], ui = x[c * n + d + i], gr = goal[c * n + i], gi = goal[c * n + d + i];
-        tr += gr * ur + gi * ui;
-        ti += gr * ui - gi * ur;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        tr += __shfl_down(tr, off, 64);
-        ti += __shfl_down(ti, off, 64);
-    }
-    if ((tid & 63) == 0) {
-        red[0][tid >> 6] = tr;
-        red[1][tid >> 6] = ti;
-    }
+__device__ __forceinline__ double block_sum_256(double v, double *red) {  // fixed order; red: 8 doubles of LDS
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     __syncthreads();
-    tr = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    ti = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    const double inv = 1.0 / ((double)d * d);
-    const double F = (tr * tr + ti * ti) * inv;
-    const double sgn = (1.0 - F >= 0.0) ? 1.0 : -1.0;
-    if (tid == 0 && value) value[b] = Q * fabs(1.0 - F);
-    if (grad) {
-        double *g = grad + (long long)b * n * d;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__global__ __launch_bounds__(256) void pcl_infidelity_kernel(const double *__restrict__ Z, const double *__restrict__ goal,
+                                                             const int *__restrict__ sub, int ns,
+                                                             const int *__restrict__ x_offs, const double *__restrict__ weights,
+                                                             double *__restrict__ value, double *__restrict__ grad,
+                                                             long long grad_stride, int accumulate, double Q, int d, int N,
+                                                             int z_dim, long long z_batch_stride) {
+    extern __shared__ double lds[];
+    __shared__ double red[8];
+    const int n = 2 * d, b = blockIdx.x, tid = threadIdx.x;
+    const int xo = x_offs[z_batch_stride ? 0 : b];
+    const double *x = Z + (long long)b * z_batch_stride + (long long)(N - 1) * z_dim + xo;
+    const double Qw = Q * (weights ? weights[b] : 1.0);
+    double *g = grad ? grad + (long long)b * grad_stride + (accumulate ? (long long)(N - 1) * z_dim + xo : 0) : nullptr;
+    if (ns <= 0) {
+        double tr = 0.0, ti = 0.0;
         for (int e = tid; e < d * d; e += 256) {
             const int c = e / d, i = e - c * d;
-            const double gr = goal[c * n + i], gi = goal[c * n + d + i];
-            g[c * n + i] = -sgn * Q * 2.0 * (tr * gr - ti * gi) * inv;
-            g[c * n + d + i] = -sgn * Q * 2.0 * (tr * gi + ti * gr) * inv;
+            const double ur = x[c * n + i], ui = x[c * n + d + i], gr = goal[c * n + i], gi = goal[c * n + d + i];
+            tr += gr * ur + gi * ui;
+            ti += gr * ui - gi * ur;
         }
+        tr = block_sum_256(tr, red);
+        ti = block_sum_256(ti, red);
+        const double inv = 1.0 / ((double)d * d);
+        const double F = (tr * tr + ti * ti) * inv;
+        const double sgn = (1.0 - F >= 0.0) ? 1.0 : -1.0;
+        if (tid == 0 && value) value[b] = Qw * fabs(1.0 - F);
+        if (g) {
+            for (int e = tid; e < d * d; e += 256) {
+                const int c = e / d, i = e - c * d;
+                const double gr = goal[c * n + i], gi = goal[c * n + d + i];
+                const double v0 = -sgn * Qw * 2.0 * (tr * gr - ti * gi) * inv, v1 = -sgn * Qw * 2.0 * (tr * gi + ti * gr) * inv;
+                if (accumulate) {
+                    g[c * n + i] += v0;
+                    g[c * n + d + i] += v1;
+                } else {
+                    g[c * n + i] = v0;
+                    g[c * n + d + i] = v1;
+                }
+            }
+        }
+        return;
+    }
+    // ---- subspace (EmbeddedOperator) fidelity: ns x ns complex blocks in LDS: Us | Ug | M | W (re, im planes) ----
+    const int nn = ns * ns;
+    double *Ur = lds, *Ui = Ur + nn, *Gr = Ui + nn, *Gi = Gr + nn, *Mr = Gi + nn, *Mi = Mr + nn;
+    const int n2 = 2 * ns;
+    for (int e = tid; e < nn; e += 256) {
+        const int c = e / ns, i = e - c * ns;  // column-major [i + ns*c]
+        Ur[e] = x[sub[c] * n + sub[i]];
+        Ui[e] = x[sub[c] * n + d + sub[i]];
+        Gr[e] = goal[c * n2 + i];
+        Gi[e] = goal[c * n2 + ns + i];
+    }
+    __syncthreads();
+    double tr = 0.0, ti = 0.0, fro = 0.0;
+    for (int e = tid; e < nn; e += 256) {  // M = Ug' Us
+        const int c = e / ns, i = e - c * ns;
+        double mr = 0.0, mi = 0.0;
+        for (int k = 0; k < ns; ++k) {
+            const double ar = Gr[k + ns * i], ai = -Gi[k + ns * i];  // conj(Ug[k,i])
+            const double br = Ur[k + ns * c], bi = Ui[k + ns * c];
+            mr += ar * br - ai * bi;
+            mi += ar * bi + ai * br;
+        }
+        Mr[e] = mr;
+        Mi[e] = mi;
+        fro += mr * mr + mi * mi;
+        if (i == c) {
+            tr += mr;
+            ti += mi;
+        }
+    }
+    tr = block_sum_256(tr, red);
+    ti = block_sum_256(ti, red);
+    fro = block_sum_256(fro, red);  // (its leading barrier also completes M)
+    const double inv = 1.0 / ((double)ns * (ns + 1));
+    const double F = (fabs(fro) + tr * tr + ti * ti) * inv;
+    const double sgn = (1.0 - F >= 0.0) ? 1.0 : -1.0;
+    if (tid == 0 && value) value[b] = Qw * fabs(1.0 - F);
+    if (g) {
+        if (!accumulate)
+            for (int e = tid; e < n * d; e += 256) g[e] = 0.0;
+        __syncthreads();
+        for (int e = tid; e < nn; e += 256) {  // W = Ug M ; dF = (2 W + 2 t Ug) / (ns (ns+1))
+            const int c = e / ns, i = e - c * ns;
+            double wr = 0.0, wi = 0.0;
+            for (int k = 0; k < ns; ++k) {
+                const double ar = Gr[i + ns * k], ai = Gi[i + ns * k];
+                const double br = Mr[k + ns * c], bi = Mi[k + ns * c];
+                wr += ar * br - ai * bi;
+                wi += ar * bi + ai * br;
+            }
+            const double gr = Gr[e], gi = Gi[e];
+            const double dr = (2.0 * wr + 2.0 * (tr * gr - ti * gi)) * inv, di = (2.0 * wi + 2.0 * (tr * gi + ti * gr)) * inv;
+            g[sub[c] * n + sub[i]] += -sgn * Qw * dr;
+            g[sub[c] * n + d + sub[i]] += -sgn * Qw * di;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Quadratic regularisers  J_r = 1/2 sum_k dt_k^p sum_i R_i v_{k,i}^2  (DirectTrajOpt's QuadraticRegularizer [EXT], used by
+// every problem template: src/control/templates/smooth_pulse_problem.jl:249-251).  One workgroup per (knot, trajectory
+// buffer): writes the knot's whole gradient row (zeros where no term applies), the knot's value into regval.
+// reg table (device): per regulariser {off, dim, dt_power, R offset}; R values concatenated.
+// ------------------------------------------------------------------------------------------
+struct PclReg {
+    int off, dim, pw, r0;
+};
+#define PCL_MAX_REGS 8
+
+__global__ __launch_bounds__(256) void pcl_regularizer_kernel(const double *__restrict__ Z, const PclReg *__restrict__ regs, int n_regs,
+                                                              const double *__restrict__ Rv, double *__restrict__ grad,
+                                                              double *__restrict__ regval, int N, int z_dim, int dt_off,
+                                                              long long z_batch_stride) {
+    __shared__ double red[8];
+    __shared__ double sr[PCL_MAX_REGS];
+    const int k = blockIdx.x, tb = blockIdx.y, tid = threadIdx.x;
+    const double *z = Z + (long long)tb * z_batch_stride + (long long)k * z_dim;
+    double *g = grad ? grad + (long long)tb * (long long)z_dim * N + (long long)k * z_dim : nullptr;
+    const double h = z[dt_off];
+    double val = 0.0, gdt = 0.0;
+    for (int r = 0; r < n_regs; ++r) {
+        const PclReg R = regs[r];
+        double s = 0.0;
+        for (int i = tid; i < R.dim; i += 256) {
+            const double v = z[R.off + i];
+            s += Rv[R.r0 + i] * v * v;
+        }
+        s = block_sum_256(s, red);
+        const double w = R.pw == 0 ? 1.0 : (R.pw == 1 ? h : h * h);
+        val += 0.5 * w * s;
+        gdt += R.pw == 0 ? 0.0 : (R.pw == 1 ? 0.5 * s : h * s);
+        if (tid == 0) sr[r] = w;
+    }
+    __syncthreads();
+    if (g) {
+        for (int i = tid; i < z_dim; i += 256) {
+            double gi = 0.0;
+            for (int r = 0; r < n_regs; ++r) {
+                const PclReg R = regs[r];
+                if (i >= R.off && i < R.off + R.dim) gi += sr[r] * Rv[R.r0 + i - R.off] * z[i];
+            }
+            if (i == dt_off) gi += gdt;
+            g[i] = gi;
+        }
+    }
+    if (tid == 0) regval[(long long)tb * N + k] = val;
+}
+
+// value[0] = sum_b member[b] + sum_k regval[k]   (MEMBERS), value[b] = member[b] + sum_k regval[b][k]   (TRAJ): fixed order
+__global__ void pcl_objective_sum_kernel(const double *__restrict__ member, const double *__restrict__ regval, double *__restrict__ value,
+                                         int batch, int N, int traj_mode) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (traj_mode) {
+        for (int b = 0; b < batch; ++b) {
+            double s = member[b];
+            for (int k = 0; k < N; ++k) s += regval[(long long)b * N + k];
+            value[b] = s;
+        }
+    } else {
+        double s = 0.0;
+        for (int b = 0; b < batch; ++b) s += member[b];
+        for (int k = 0; k < N; ++k) s += regval[k];
+        value[0] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The reduce payload of a sharded ensemble: for multipliers lam (NULL: lam = delta, i.e. the merit
+// phi = 1/2 sum w |delta|^2 and its gradient) over this context's members b:
+//     phi_k  = sum_b w_b c <lam_bk, delta_bk>           (c = 1/2 when lam = delta)
+//     g[k,l] = sum_b w_b <d delta_bk / d u_l, lam_bk>,  g[k,m] = sum_b w_b <d delta_bk / d dt, lam_bk>
+// i.e. J^T lam restricted to the SHARED variables (the only part of the Lagrangian gradient that needs other ranks).
+// One workgroup per interval (x trajectory in TRAJ mode, where nothing is shared and the sums run over one b);
+// wave w owns drive indices l = w, w+4, ..: a dot product over the member's tail block, summed over b in order.
+// out: [phi | g_u (K*m, k-major) | g_dt (K)] per output set; phi_k goes to scratch and is summed by pcl_merit_sum_kernel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pcl_merit_grad_kernel(const double *__restrict__ delta, const double *__restrict__ lam,
+                                                             const double *__restrict__ vals, const double *__restrict__ weights,
+                                                             double *__restrict__ out, double *__restrict__ phik, int batch, int K,
+                                                             int cols, int n, int m, long long jac_per, long long tail_off,
+                                                             int traj_mode) {
+    const int k = blockIdx.x, set = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long xd = (long long)n * cols;
+    const int b_lo = traj_mode ? set : 0, b_hi = traj_mode ? set + 1 : batch;
+    double *o = out + (long long)set * (1 + (long long)K * m + K);
+    for (int l = wave; l <= m + 1; l += 4) {  // l == m+1: the phi_k job
+        double tot = 0.0;
+        for (int b = b_lo; b < b_hi; ++b) {
+            const long long bk = (long long)b * K + k;
+            const double *dl = delta + bk * xd;
+            const double *lm = lam ? lam + bk * xd : dl;
+            const double *tail = vals + bk * jac_per + tail_off;
+            double s = 0.0;
+            if (l <= m) {
+                for (int c = 0; c < cols; ++c)
+                    for (int i = lane; i < n; i += 64) s += tail[((long long)c * (m + 1) + l) * n + i] * lm[c * n + i];
+            } else {
+                for (long long e = lane; e < xd; e += 64) s += lm[e] * dl[e];
+                s *= lam ? 1.0 : 0.5;
+            }
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            tot += (weights ? weights[b] : 1.0) * s;
+        }
+        if (lane == 0) {
+            if (l < m)
+                o[1 + (long long)k * m + l] = tot;
+            else if (l == m)
+                o[1 + (long long)K * m + k] = tot;
+            else
+                phik[(long long)set * K + k] = tot;
+        }
+    }
+}
+__global__ void pcl_merit_sum_kernel(const double *__restrict__ phik, double *__restrict__ out, int K, int m, int sets) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int s = 0; s < sets; ++s) {
+        double t = 0.0;
+        for (int k = 0; k < K; ++k) t += phik[(long long)s * K + k];
+        out[(long long)s * (1 + (long long)K * m + K)] = t;
     }
 }

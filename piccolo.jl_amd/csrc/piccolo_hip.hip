@@ -75,10 +75,22 @@ struct pcl_ctx {
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dmu = nullptr, *ddelta = nullptr, *dvals = nullptr, *dhess = nullptr;
     // options
+    int win_first = 0, win_count = 0;  // member window (pcl_set_member_window): the members / seeds the evaluator entry points cover
     int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_kernel = 0;  // 0 = auto: 3 where its specialised instance applies, else 1 / 2 by shape
     long long *ddbg = nullptr;
     void *comm = nullptr;  // ncclComm_t
-    double *dgoal = nullptr;  // iso-vec of the goal unitary (pcl_set_goal)
+    double *dgoal = nullptr;  // iso-vec of the goal unitary (pcl_set_goal) or of its subspace block (pcl_set_goal_subspace)
+    int *dsub = nullptr;      // subspace indices of an embedded goal
+    int n_sub = 0;            // 0: full-space fidelity
+    double *dweights = nullptr;  // per member / seed weights of the objective (NULL: ones)
+    std::vector<PclReg> regs;    // quadratic regularisers (pcl_add_regularizer)
+    std::vector<double> reg_R;
+    PclReg *dregs = nullptr;
+    double *dreg_R = nullptr;
+    bool regs_dirty = false;
+    double *dobj = nullptr;      // objective scratch: per-member values | per-knot regulariser values
+    double *dphik = nullptr;     // merit scratch: per-interval partial sums
+    double *dgrad = nullptr, *dval = nullptr;  // staging of the host-pointer objective call
     int64_t opt_specialize = 1;
     int64_t opt_jit = 1;      // compile shape-specialised instances on first use (hiprtc) for shapes outside the static table
     int64_t opt_general = 0;  // 1: run the general-order kernel also for pade_order 4 (cross-check)
@@ -146,7 +158,8 @@ static long long hess_per(const pcl_ctx *c) {
 static long long z_len(const pcl_ctx *c) {
     return (long long)c->desc.z_dim * c->desc.N * (c->desc.batch_mode == PCL_BATCH_TRAJ ? c->desc.batch : 1);
 }
-static long long n_rows(const pcl_ctx *c) { return (long long)c->desc.batch * c->x_dim * c->K; }
+static long long n_rows(const pcl_ctx *c) { return (long long)c->win_count * c->x_dim * c->K; }        // of the member window
+static long long n_rows_all(const pcl_ctx *c) { return (long long)c->desc.batch * c->x_dim * c->K; }  // of every member (allocation sizes)
 
 extern "C" const char *pcl_version(void) { return PCL_VERSION_STR; }
 
@@ -211,6 +224,8 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     ctx->desc.x_offs = nullptr;
     ctx->desc.G0 = ctx->desc.Gj = nullptr;
     ctx->device = dsc->device_id;
+    ctx->win_first = 0;
+    ctx->win_count = dsc->batch;
 
 #define CREATE_TRY(expr)                                                  \
     do {                                                                  \
@@ -398,6 +413,9 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (ctx->dgoal) (void)hipFree(ctx->dgoal);
+    for (void *q : {(void *)ctx->dsub, (void *)ctx->dweights, (void *)ctx->dregs, (void *)ctx->dreg_R, (void *)ctx->dobj, (void *)ctx->dphik,
+                    (void *)ctx->dgrad, (void *)ctx->dval})
+        if (q) (void)hipFree(q);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -412,19 +430,27 @@ extern "C" int pcl_constraint_dim(const pcl_ctx *ctx, int64_t *x_dim, int64_t *r
 extern "C" int pcl_jac_nnz(const pcl_ctx *ctx, int64_t *nnz, int64_t *per) {
     if (!ctx) return PCL_EINVAL;
     if (per) *per = jac_per_full(ctx);
-    if (nnz) *nnz = jac_per_full(ctx) * ctx->desc.batch * ctx->K;
+    if (nnz) *nnz = jac_per_full(ctx) * ctx->win_count * ctx->K;
+    return PCL_OK;
+}
+extern "C" int pcl_set_member_window(pcl_ctx *ctx, int32_t first, int32_t count) {
+    if (!ctx) return PCL_EINVAL;
+    if (first < 0 || count < 1 || (long long)first + count > ctx->desc.batch)
+        return fail(ctx, PCL_EINVAL, "pcl_set_member_window: [%d, %d) outside the %d members of this context", first, first + count, ctx->desc.batch);
+    ctx->win_first = first;
+    ctx->win_count = count;
     return PCL_OK;
 }
 extern "C" int pcl_jac_compact_nnz(const pcl_ctx *ctx, int64_t *nnz, int64_t *per) {
     if (!ctx) return PCL_EINVAL;
     if (per) *per = jac_per_compact(ctx);
-    if (nnz) *nnz = jac_per_compact(ctx) * ctx->desc.batch * ctx->K;
+    if (nnz) *nnz = jac_per_compact(ctx) * ctx->win_count * ctx->K;
     return PCL_OK;
 }
 extern "C" int pcl_hess_nnz(const pcl_ctx *ctx, int64_t *nnz, int64_t *per) {
     if (!ctx) return PCL_EINVAL;
     if (per) *per = hess_per(ctx);
-    if (nnz) *nnz = hess_per(ctx) * ctx->desc.batch * ctx->K;
+    if (nnz) *nnz = hess_per(ctx) * ctx->win_count * ctx->K;
     return PCL_OK;
 }
 
@@ -435,9 +461,10 @@ static int jac_structure_impl(const pcl_ctx *ctx, I *rows, I *cols) {
     const pcl_desc &D = ctx->desc;
     const long long n = ctx->n, d = ctx->cols, m = D.n_drives, xd = ctx->x_dim, zd = D.z_dim, base = D.index_base;
     const long long per = jac_per_full(ctx);
-    for (long long b = 0; b < D.batch; ++b) {
-        const long long xo = ctx->x_offs[D.batch_mode == PCL_BATCH_MEMBERS ? b : 0];
-        const long long voff = D.batch_mode == PCL_BATCH_TRAJ ? b * zd * D.N : 0;
+    for (long long b = 0; b < ctx->win_count; ++b) {  // b: member inside the window, bg: member of the context
+        const long long bg = ctx->win_first + b;
+        const long long xo = ctx->x_offs[D.batch_mode == PCL_BATCH_MEMBERS ? bg : 0];
+        const long long voff = D.batch_mode == PCL_BATCH_TRAJ ? bg * zd * D.N : 0;
         for (long long k = 0; k < ctx->K; ++k) {
             I *r = rows + (b * ctx->K + k) * per, *c = cols + (b * ctx->K + k) * per;
             const long long r0 = b * xd * ctx->K + k * xd + base;
@@ -479,9 +506,10 @@ static int hess_structure_impl(const pcl_ctx *ctx, I *rows, I *cols) {
     const pcl_desc &D = ctx->desc;
     const long long m = D.n_drives, xd = ctx->x_dim, zd = D.z_dim, base = D.index_base;
     const long long per = hess_per(ctx);
-    for (long long b = 0; b < D.batch; ++b) {
-        const long long xo = ctx->x_offs[D.batch_mode == PCL_BATCH_MEMBERS ? b : 0];
-        const long long voff = D.batch_mode == PCL_BATCH_TRAJ ? b * zd * D.N : 0;
+    for (long long b = 0; b < ctx->win_count; ++b) {
+        const long long bg = ctx->win_first + b;
+        const long long xo = ctx->x_offs[D.batch_mode == PCL_BATCH_MEMBERS ? bg : 0];
+        const long long voff = D.batch_mode == PCL_BATCH_TRAJ ? bg * zd * D.N : 0;
         for (long long k = 0; k < ctx->K; ++k) {
             I *r = rows + (b * ctx->K + k) * per, *c = cols + (b * ctx->K + k) * per;
             const long long uk = voff + k * zd + D.u_off, hk = voff + k * zd + D.dt_off;
@@ -663,7 +691,7 @@ static int lds_ld(int n) { return ((n + 3) & ~3) + 2; }  // n = generator dimens
 static void fill_params(const pcl_ctx *ctx, KParams &p) {
     memset(&p, 0, sizeof p);
     const pcl_desc &D = ctx->desc;
-    p.G0 = ctx->dG0;
+    p.G0 = ctx->dG0 + (D.per_member_G0 ? (long long)ctx->win_first * ctx->n * ctx->n : 0);  // member window: offsets, not kernel logic
     p.upos = ctx->dupos;
     p.ucoef = ctx->ducoef;
     p.n_upos = ctx->n_upos;
@@ -673,7 +701,7 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.csc_ptr = ctx->dcsc_ptr;
     p.csc_row = ctx->dcsc_row;
     p.csc_val = ctx->dcsc_val;
-    p.x_offs = ctx->dxoffs;
+    p.x_offs = ctx->dxoffs + (D.batch_mode == PCL_BATCH_MEMBERS ? ctx->win_first : 0);
     p.umap = ctx->dumap;
     p.uell_l = ctx->duell_l;
     p.uell_v = ctx->duell_v;
@@ -698,7 +726,7 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.z_dim = D.z_dim;
     p.u_off = D.u_off;
     p.dt_off = D.dt_off;
-    p.batch = D.batch;
+    p.batch = ctx->win_count;
     p.LD = lds_ld(ctx->n);
     p.nt = (int)ctx->opt_nt;
     p.dbg = ctx->ddbg;
@@ -744,7 +772,7 @@ static int choose_cols_per_slice(const pcl_ctx *ctx, bool jac) {
         p.nc = nc;
         return v2 ? fused2_lds_bytes(p, jac, ell) : fused_lds_bytes(p, jac);
     };
-    const long long bk = (long long)ctx->desc.batch * ctx->K;
+    const long long bk = (long long)ctx->win_count * ctx->K;
     const long long want = 3LL * std::max(ctx->n_cu, 1);
     int best = 1;
     for (int nc = d; nc >= 1; --nc) {
@@ -779,7 +807,7 @@ static bool v3_specialised(const pcl_ctx *ctx) {
     if (!ctx->opt_specialize || ctx->ell_w < 1 || ctx->ell_w > 2) return false;
     const int d = ctx->desc.d, m = ctx->desc.n_drives;
     if (ctx->ell_w == 2 && ((d == 27 && m == 6) || (d == 25 && m == 4))) return true;
-    if (ctx->ell_w == 2 && d == 16 && m == 4 && (long long)ctx->desc.batch * ctx->K <= 512) return true;
+    if (ctx->ell_w == 2 && d == 16 && m == 4 && (long long)ctx->win_count * ctx->K <= 512) return true;
     // Other shapes: `kernel_version = 3` compiles the shape on first use (hiprtc) instead of running the run-time-shape
     // instance; measured on d = 22..30 it only ties the persistent two-workgroup kernels, so `auto` does not take it.
     return false;
@@ -793,14 +821,14 @@ static bool v3_role_split_fits(const pcl_ctx *ctx) {
 static bool v3_contiguous(const pcl_ctx *ctx) {
     if (ctx->opt_cols_per_slice > 0 || ctx->opt_contig == 0) return false;
     if (ctx->opt_contig > 0) return true;
-    const long long cols = (long long)ctx->desc.batch * ctx->K * ctx->desc.d;
+    const long long cols = (long long)ctx->win_count * ctx->K * ctx->desc.d;
     return v3_role_split_fits(ctx) && cols >= 28LL * std::max(ctx->n_cu, 1);
 }
 static int choose_cols_v3(const pcl_ctx *ctx) {
     const int d = ctx->desc.d, n = ctx->n, m = ctx->desc.n_drives;
     if (ctx->opt_cols_per_slice > 0) return (int)std::min<int64_t>(ctx->opt_cols_per_slice, d);
     const double hbm = 0.85 * 6.3e12;  // store-stream rate the kernel sustains chip-wide
-    const long long bk = (long long)ctx->desc.batch * ctx->K;
+    const long long bk = (long long)ctx->win_count * ctx->K;
     const int rt = (n + 15) / 16, ks = (n + 3) / 4;
     const int g2ct = ctx->iso ? (d + 15) / 16 : (n + 15) / 16;
     const double t_chunk = 7.0e-6 * (rt * ks) / (4.0 * 14.0);
@@ -900,7 +928,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     ON_DEVICE(ctx);
     KParams p;
     fill_params(ctx, p);
-    p.Z = Z;
+    p.Z = Z + (ctx->desc.batch_mode == PCL_BATCH_TRAJ ? (long long)ctx->win_first * ctx->desc.z_dim * ctx->desc.N : 0);
     p.delta = delta;
     p.jac = jac;
     p.compact = compact ? 1 : 0;
@@ -974,7 +1002,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
 not_v3:
     // auto: small Hilbert dimensions are launch- / latency-bound, one workgroup per item (kernel 1) beats the persistent
     // kernels there (measured: d <= 8 always, d <= 16 while all items fit one round of workgroups)
-    const bool v1_auto = ctx->opt_kernel == 0 && (ctx->desc.d <= 8 || (ctx->desc.d <= 16 && (long long)ctx->desc.batch * ctx->K <= 512));
+    const bool v1_auto = ctx->opt_kernel == 0 && (ctx->desc.d <= 8 || (ctx->desc.d <= 16 && (long long)ctx->win_count * ctx->K <= 512));
     const bool v2 = !v1_auto && (ctx->opt_kernel == 0 || ctx->opt_kernel >= 2) && ctx->opt_use_mfma != 0;
     const bool unitary = !ctx->vec && ctx->cols == ctx->desc.d;  // kernel 3 and the specialised instances assume X is n x d
     p.nc = choose_cols_per_slice(ctx, want_jac);
@@ -1051,7 +1079,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
     ON_DEVICE(ctx);
     KParams p;
     fill_params(ctx, p);
-    p.Z = Z;
+    p.Z = Z + (ctx->desc.batch_mode == PCL_BATCH_TRAJ ? (long long)ctx->win_first * ctx->desc.z_dim * ctx->desc.N : 0);
     p.mu = mu;
     p.hess = hess;
     const bool mf = ctx->opt_use_mfma != 0;
@@ -1069,16 +1097,15 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
         p.nc = (p.cols + S - 1) / S;
         p.S = (p.cols + p.nc - 1) / p.nc;
         const long long nbk = (long long)p.batch * p.K;
-        if (p.S > 1 && ctx->hpart_cap < nbk * p.S) {
+        const long long nbk_all = (long long)ctx->desc.batch * p.K;  // scratch is sized for every member, whatever the window
+        if (p.S > 1 && !ctx->dhcnt) HIP_TRY(ctx, hipMalloc((void **)&ctx->dhcnt, (size_t)nbk_all * sizeof(unsigned int)));
+        if (p.S > 1 && ctx->hpart_cap < nbk_all * p.S) {
             const size_t nscal = (size_t)(p.m + 1) * (p.m + 2) / 2;
             if (ctx->dhpart) (void)hipFree(ctx->dhpart);
-            if (ctx->dhcnt) (void)hipFree(ctx->dhcnt);
             ctx->dhpart = nullptr;
-            ctx->dhcnt = nullptr;
             ctx->hpart_cap = 0;
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->dhpart, (size_t)nbk * p.S * nscal * sizeof(double)));
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->dhcnt, (size_t)nbk * sizeof(unsigned int)));
-            ctx->hpart_cap = nbk * p.S;
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->dhpart, (size_t)nbk_all * p.S * nscal * sizeof(double)));
+            ctx->hpart_cap = nbk_all * p.S;
         }
         // arrival counters start from zero in every launch (a launch that faulted must not poison the next one)
         if (p.S > 1) HIP_TRY(ctx, hipMemsetAsync(ctx->dhcnt, 0, (size_t)nbk * sizeof(unsigned int), ctx->stream));
@@ -1153,6 +1180,11 @@ extern "C" int pcl_eval_jac_dev(pcl_ctx *ctx, const double *Z, double *delta, do
     if (!Z || !vals) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_dev: NULL pointer");
     return launch_fused(ctx, Z, delta, vals, false);
 }
+extern "C" int pcl_jac_dev(pcl_ctx *ctx, const double *Z, double *vals) {  // eval_jacobian alone: no residual is written
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !vals) return fail(ctx, PCL_EINVAL, "pcl_jac_dev: NULL pointer");
+    return launch_fused(ctx, Z, nullptr, vals, false);
+}
 extern "C" int pcl_eval_jac_compact_dev(pcl_ctx *ctx, const double *Z, double *delta, double *compact) {
     if (!ctx) return PCL_EINVAL;
     if (!Z || !compact) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_compact_dev: NULL pointer");
@@ -1162,7 +1194,7 @@ extern "C" int pcl_jac_expand_dev(pcl_ctx *ctx, const double *compact, double *v
     if (!ctx) return PCL_EINVAL;
     if (!compact || !vals) return fail(ctx, PCL_EINVAL, "pcl_jac_expand_dev: NULL pointer");
     ON_DEVICE(ctx);
-    const long long n_bk = (long long)ctx->desc.batch * ctx->K;
+    const long long n_bk = (long long)ctx->win_count * ctx->K;
     const long long grid = n_bk * ctx->cols;
     if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "pcl_jac_expand_dev: %lld work items exceed the grid limit", grid);
     if (ctx->cols == 1) {  // one state column (kets, compact density vectors): the compact layout IS the full layout
@@ -1186,9 +1218,9 @@ extern "C" int pcl_rollout_dev(pcl_ctx *ctx, const double *Z, double *X_out) {
     ON_DEVICE(ctx);
     KParams p;
     fill_params(ctx, p);
-    p.Z = Z;
+    p.Z = Z + (ctx->desc.batch_mode == PCL_BATCH_TRAJ ? (long long)ctx->win_first * ctx->desc.z_dim * ctx->desc.N : 0);
     p.xout = X_out;
-    if (!ctx->dexpm) HIP_TRY(ctx, hipMalloc((void **)&ctx->dexpm, (size_t)p.batch * p.K * p.n * p.n * sizeof(double)));
+    if (!ctx->dexpm) HIP_TRY(ctx, hipMalloc((void **)&ctx->dexpm, (size_t)ctx->desc.batch * p.K * p.n * p.n * sizeof(double)));
     p.expm = ctx->dexpm;
     const size_t lds_a = (3 * (size_t)p.LD * p.n + 8 + p.m + 64) * sizeof(double);
     const size_t lds_b = ((size_t)p.LD * p.n + 2 * (size_t)p.LD * p.cols) * sizeof(double);
@@ -1219,10 +1251,10 @@ static int host_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *v
     if (!ctx) return PCL_EINVAL;
     if (!Z || (!delta && !vals)) return fail(ctx, PCL_EINVAL, "NULL pointer");
     ON_DEVICE(ctx);
-    const long long nv = jac_per_full(ctx) * ctx->desc.batch * ctx->K;
+    const long long nv = jac_per_full(ctx) * ctx->win_count * ctx->K;
     TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
-    TRY(ensure(ctx, &ctx->ddelta, n_rows(ctx)));
-    if (vals) TRY(ensure(ctx, &ctx->dvals, nv));
+    TRY(ensure(ctx, &ctx->ddelta, n_rows_all(ctx)));
+    if (vals) TRY(ensure(ctx, &ctx->dvals, jac_per_full(ctx) * ctx->desc.batch * ctx->K));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dZ, Z, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     TRY(launch_fused(ctx, ctx->dZ, ctx->ddelta, vals ? ctx->dvals : nullptr, false));
     if (delta) HIP_TRY(ctx, hipMemcpyAsync(delta, ctx->ddelta, n_rows(ctx) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1246,10 +1278,10 @@ extern "C" int pcl_hess(pcl_ctx *ctx, const double *Z, const double *mu, double 
     if (!ctx) return PCL_EINVAL;
     if (!Z || !mu || !vals) return fail(ctx, PCL_EINVAL, "pcl_hess: NULL pointer");
     ON_DEVICE(ctx);
-    const long long nv = hess_per(ctx) * ctx->desc.batch * ctx->K;
+    const long long nv = hess_per(ctx) * ctx->win_count * ctx->K;
     TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
-    TRY(ensure(ctx, &ctx->dmu, n_rows(ctx)));
-    TRY(ensure(ctx, &ctx->dhess, nv));
+    TRY(ensure(ctx, &ctx->dmu, n_rows_all(ctx)));
+    TRY(ensure(ctx, &ctx->dhess, hess_per(ctx) * ctx->desc.batch * ctx->K));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dZ, Z, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dmu, mu, n_rows(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     TRY(launch_hess(ctx, ctx->dZ, ctx->dmu, ctx->dhess));
@@ -1262,9 +1294,9 @@ extern "C" int pcl_rollout(pcl_ctx *ctx, const double *Z, double *X_out) {
     if (!ctx) return PCL_EINVAL;
     if (!Z || !X_out) return fail(ctx, PCL_EINVAL, "pcl_rollout: NULL pointer");
     ON_DEVICE(ctx);
-    const long long nv = (long long)ctx->desc.batch * ctx->desc.N * ctx->x_dim;
+    const long long nv = (long long)ctx->win_count * ctx->desc.N * ctx->x_dim;
     TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
-    TRY(ensure(ctx, &ctx->dxout, nv));
+    TRY(ensure(ctx, &ctx->dxout, (long long)ctx->desc.batch * ctx->desc.N * ctx->x_dim));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dZ, Z, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     TRY(pcl_rollout_dev(ctx, ctx->dZ, ctx->dxout));
     HIP_TRY(ctx, hipMemcpyAsync(X_out, ctx->dxout, nv * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1347,24 +1379,172 @@ extern "C" int pcl_deriv_eval_jac(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, i
 }
 
 // --- terminal infidelity objective ----------------------------------------------
+static int objective_unitary_only(const pcl_ctx *ctx, const char *who) {
+    if (ctx->vec || ctx->cols != ctx->desc.d) return fail(ctx, PCL_ENOTIMPL, "%s: unitary (n x d) states only", who);
+    return PCL_OK;
+}
 extern "C" int pcl_set_goal(pcl_ctx *ctx, const double *goal_iso_vec) {
     if (!ctx) return PCL_EINVAL;
     if (!goal_iso_vec) return fail(ctx, PCL_EINVAL, "pcl_set_goal: NULL");
+    TRY(objective_unitary_only(ctx, "pcl_set_goal"));
     ON_DEVICE(ctx);
-    if (!ctx->dgoal) HIP_TRY(ctx, hipMalloc((void **)&ctx->dgoal, (size_t)ctx->x_dim * sizeof(double)));
+    if (ctx->dgoal) (void)hipFree(ctx->dgoal);
+    ctx->dgoal = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->dgoal, (size_t)ctx->x_dim * sizeof(double)));
     HIP_TRY(ctx, hipMemcpy(ctx->dgoal, goal_iso_vec, (size_t)ctx->x_dim * sizeof(double), hipMemcpyHostToDevice));
+    ctx->n_sub = 0;
     return PCL_OK;
 }
+extern "C" int pcl_set_goal_subspace(pcl_ctx *ctx, const double *goal_sub_iso_vec, const int32_t *subspace, int32_t ns) {
+    if (!ctx) return PCL_EINVAL;
+    if (!goal_sub_iso_vec || !subspace) return fail(ctx, PCL_EINVAL, "pcl_set_goal_subspace: NULL");
+    TRY(objective_unitary_only(ctx, "pcl_set_goal_subspace"));
+    if (ns < 1 || ns > ctx->desc.d) return fail(ctx, PCL_EINVAL, "pcl_set_goal_subspace: ns=%d outside 1..d=%d", ns, ctx->desc.d);
+    for (int i = 0; i < ns; ++i) {
+        if (subspace[i] < 0 || subspace[i] >= ctx->desc.d) return fail(ctx, PCL_EINVAL, "pcl_set_goal_subspace: index %d outside 0..d-1", subspace[i]);
+        for (int j = 0; j < i; ++j)
+            if (subspace[j] == subspace[i]) return fail(ctx, PCL_EINVAL, "pcl_set_goal_subspace: index %d repeated", subspace[i]);
+    }
+    ON_DEVICE(ctx);
+    if (ctx->dgoal) (void)hipFree(ctx->dgoal);
+    if (ctx->dsub) (void)hipFree(ctx->dsub);
+    ctx->dgoal = nullptr;
+    ctx->dsub = nullptr;
+    ctx->n_sub = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->dgoal, (size_t)2 * ns * ns * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->dsub, (size_t)ns * sizeof(int)));
+    HIP_TRY(ctx, hipMemcpy(ctx->dgoal, goal_sub_iso_vec, (size_t)2 * ns * ns * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->dsub, subspace, (size_t)ns * sizeof(int), hipMemcpyHostToDevice));
+    ctx->n_sub = ns;
+    return PCL_OK;
+}
+extern "C" int pcl_set_weights(pcl_ctx *ctx, const double *w) {
+    if (!ctx) return PCL_EINVAL;
+    ON_DEVICE(ctx);
+    if (!w) {
+        if (ctx->dweights) (void)hipFree(ctx->dweights);
+        ctx->dweights = nullptr;
+        return PCL_OK;
+    }
+    if (!ctx->dweights) HIP_TRY(ctx, hipMalloc((void **)&ctx->dweights, (size_t)ctx->desc.batch * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(ctx->dweights, w, (size_t)ctx->desc.batch * sizeof(double), hipMemcpyHostToDevice));
+    return PCL_OK;
+}
+extern "C" int pcl_add_regularizer(pcl_ctx *ctx, int32_t off, int32_t dim, const double *R, int32_t dt_power) {
+    if (!ctx) return PCL_EINVAL;
+    if (!R || dim < 1 || off < 0 || off + dim > ctx->desc.z_dim) return fail(ctx, PCL_EINVAL, "pcl_add_regularizer: component [%d, %d) outside the knot (z_dim=%d)", off, off + dim, ctx->desc.z_dim);
+    if (dt_power < 0 || dt_power > 2) return fail(ctx, PCL_EINVAL, "pcl_add_regularizer: dt_power must be 0, 1 or 2");
+    if ((int)ctx->regs.size() >= PCL_MAX_REGS) return fail(ctx, PCL_ESHAPE, "pcl_add_regularizer: at most %d regularisers", PCL_MAX_REGS);
+    PclReg r{off, dim, dt_power, (int)ctx->reg_R.size()};
+    ctx->regs.push_back(r);
+    ctx->reg_R.insert(ctx->reg_R.end(), R, R + dim);
+    ctx->regs_dirty = true;
+    return PCL_OK;
+}
+extern "C" int pcl_clear_regularizers(pcl_ctx *ctx) {
+    if (!ctx) return PCL_EINVAL;
+    ctx->regs.clear();
+    ctx->reg_R.clear();
+    ctx->regs_dirty = true;
+    return PCL_OK;
+}
+static unsigned infidelity_lds(const pcl_ctx *ctx) { return (unsigned)(6 * (size_t)ctx->n_sub * ctx->n_sub * sizeof(double)); }
 extern "C" int pcl_infidelity_dev(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad) {
     if (!ctx) return PCL_EINVAL;
     if (!Z || (!value && !grad)) return fail(ctx, PCL_EINVAL, "pcl_infidelity_dev: NULL pointer");
     if (!ctx->dgoal) return fail(ctx, PCL_EINVAL, "pcl_infidelity_dev: call pcl_set_goal first");
-    if (ctx->vec || ctx->cols != ctx->desc.d) return fail(ctx, PCL_ENOTIMPL, "pcl_infidelity_dev: unitary (n x d) states only");
+    TRY(objective_unitary_only(ctx, "pcl_infidelity_dev"));
     ON_DEVICE(ctx);
     const pcl_desc &D = ctx->desc;
-    hipLaunchKernelGGL(pcl_infidelity_kernel, dim3((unsigned)D.batch), dim3(256), 0, ctx->stream, Z, ctx->dgoal, ctx->dxoffs, value, grad, Q,
-                       D.d, D.N, D.z_dim, D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0LL);
+    hipLaunchKernelGGL(pcl_infidelity_kernel, dim3((unsigned)D.batch), dim3(256), infidelity_lds(ctx), ctx->stream, Z, ctx->dgoal, ctx->dsub,
+                       ctx->n_sub, ctx->dxoffs, ctx->dweights, value, grad, (long long)ctx->x_dim, 0, Q, D.d, D.N, D.z_dim,
+                       D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0LL);
     HIP_TRY(ctx, hipGetLastError());
+    return PCL_OK;
+}
+// Whole objective of the unitary templates: sum_b w_b Q |1 - F_b| + quadratic regularisers, value + full gradient.
+extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !value) return fail(ctx, PCL_EINVAL, "pcl_objective_dev: NULL pointer");
+    if (!ctx->dgoal && ctx->regs.empty()) return fail(ctx, PCL_EINVAL, "pcl_objective_dev: no goal and no regulariser set");
+    if (ctx->dgoal) TRY(objective_unitary_only(ctx, "pcl_objective_dev"));
+    ON_DEVICE(ctx);
+    const pcl_desc &D = ctx->desc;
+    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
+    const int nbuf = traj ? D.batch : 1;
+    const long long zs = traj ? (long long)D.z_dim * D.N : 0LL;
+    if (!ctx->dobj) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->dobj, ((size_t)D.batch + (size_t)nbuf * D.N) * sizeof(double)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dobj, 0, ((size_t)D.batch + (size_t)nbuf * D.N) * sizeof(double), ctx->stream));
+    }
+    if (ctx->regs_dirty) {  // (re)upload the table; rare
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->dregs) (void)hipFree(ctx->dregs);
+        if (ctx->dreg_R) (void)hipFree(ctx->dreg_R);
+        ctx->dregs = nullptr;
+        ctx->dreg_R = nullptr;
+        if (!ctx->regs.empty()) {
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->dregs, ctx->regs.size() * sizeof(PclReg)));
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->dreg_R, ctx->reg_R.size() * sizeof(double)));
+            HIP_TRY(ctx, hipMemcpy(ctx->dregs, ctx->regs.data(), ctx->regs.size() * sizeof(PclReg), hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpy(ctx->dreg_R, ctx->reg_R.data(), ctx->reg_R.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        ctx->regs_dirty = false;
+    }
+    double *member = ctx->dobj, *regval = ctx->dobj + D.batch;
+    // the regulariser kernel writes every gradient row (zeros included) and the per-knot values (zeros without terms)
+    hipLaunchKernelGGL(pcl_regularizer_kernel, dim3((unsigned)D.N, (unsigned)nbuf), dim3(256), 0, ctx->stream, Z, (const PclReg *)ctx->dregs,
+                       (int)ctx->regs.size(), (const double *)ctx->dreg_R, grad, regval, D.N, D.z_dim, D.dt_off, zs);
+    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->dgoal) {
+        hipLaunchKernelGGL(pcl_infidelity_kernel, dim3((unsigned)D.batch), dim3(256), infidelity_lds(ctx), ctx->stream, Z, ctx->dgoal,
+                           ctx->dsub, ctx->n_sub, ctx->dxoffs, ctx->dweights, member, grad, traj ? (long long)D.z_dim * D.N : 0LL, 1, Q, D.d,
+                           D.N, D.z_dim, zs);
+        HIP_TRY(ctx, hipGetLastError());
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(member, 0, (size_t)D.batch * sizeof(double), ctx->stream));
+    }
+    hipLaunchKernelGGL(pcl_objective_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)member, (const double *)regval, value,
+                       D.batch, D.N, traj ? 1 : 0);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCL_OK;
+}
+extern "C" int pcl_objective(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !value) return fail(ctx, PCL_EINVAL, "pcl_objective: NULL pointer");
+    ON_DEVICE(ctx);
+    const int nval = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? ctx->desc.batch : 1;
+    TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
+    TRY(ensure(ctx, &ctx->dgrad, z_len(ctx)));
+    TRY(ensure(ctx, &ctx->dval, nval));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dZ, Z, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    TRY(pcl_objective_dev(ctx, ctx->dZ, Q, ctx->dval, ctx->dgrad));
+    HIP_TRY(ctx, hipMemcpyAsync(value, ctx->dval, (size_t)nval * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (grad) HIP_TRY(ctx, hipMemcpyAsync(grad, ctx->dgrad, z_len(ctx) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+// [phi | J^T lam on the shared controls and time steps]: the payload of the one collective (pcl_reduce_sum_dev)
+extern "C" int pcl_merit_grad_dev(pcl_ctx *ctx, const double *delta, const double *lam, const double *vals, double *out) {
+    if (!ctx) return PCL_EINVAL;
+    if (!delta || !vals || !out) return fail(ctx, PCL_EINVAL, "pcl_merit_grad_dev: NULL pointer");
+    ON_DEVICE(ctx);
+    const pcl_desc &D = ctx->desc;
+    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
+    const int sets = traj ? D.batch : 1;
+    if (!ctx->dphik) HIP_TRY(ctx, hipMalloc((void **)&ctx->dphik, (size_t)sets * ctx->K * sizeof(double)));
+    hipLaunchKernelGGL(pcl_merit_grad_kernel, dim3((unsigned)ctx->K, (unsigned)sets), dim3(256), 0, ctx->stream, delta, lam, vals,
+                       (const double *)ctx->dweights, out, ctx->dphik, D.batch, ctx->K, ctx->cols, ctx->n, D.n_drives, jac_per_full(ctx),
+                       2LL * ctx->cols * ctx->n * ctx->n, traj ? 1 : 0);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(pcl_merit_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)ctx->dphik, out, ctx->K, D.n_drives, sets);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCL_OK;
+}
+extern "C" int pcl_merit_grad_len(const pcl_ctx *ctx, int64_t *len, int64_t *sets) {
+    if (!ctx) return PCL_EINVAL;
+    if (len) *len = 1 + (int64_t)ctx->K * ctx->desc.n_drives + ctx->K;
+    if (sets) *sets = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? ctx->desc.batch : 1;
     return PCL_OK;
 }
 

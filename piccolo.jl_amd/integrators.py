@@ -24,7 +24,7 @@ from ._lib import PCL_BATCH_MEMBERS, PCL_BATCH_TRAJ, PclError
 from .trajectory import STATE, TIMESTEP, NamedTrajectory
 
 __all__ = [
-    "HipPadeIntegrator", "HipPadeMultistart", "DerivativeIntegrator", "BilinearIntegrator", "evaluate_", "eval_jacobian",
+    "HipPadeIntegrator", "HipPadeMemberIntegrator", "HipPadeMultistart", "DerivativeIntegrator", "BilinearIntegrator", "evaluate_", "eval_jacobian",
     "jacobian_structure", "hessian_structure", "eval_hessian_of_lagrangian", "PclError",
 ]  # fmt: skip
 
@@ -90,6 +90,7 @@ class _PclContext:
         self._chk(self._L.pcl_jac_compact_nnz(h, ctypes.byref(a), ctypes.byref(b)))
         self.compact_nnz, self.compact_per = a.value, b.value
         self.z_len = z_dim * N * (batch if batch_mode == PCL_BATCH_TRAJ else 1)
+        self.window = (0, batch)
 
     def _chk(self, rc):
         if rc != 0:
@@ -189,6 +190,24 @@ class _PclContext:
     def hess_dev(self, Z, mu, vals):
         self._chk(self._L.pcl_hess_dev(self._h, _ptr(Z), _ptr(mu), _ptr(vals)))
 
+    def jac_dev(self, Z, vals):
+        self._chk(self._L.pcl_jac_dev(self._h, _ptr(Z), _ptr(vals)))
+
+    # -- member window: the evaluator calls cover members [first, first+count) (one member of the reference's integrator vector)
+    def set_member_window(self, first=0, count=None):
+        count = self.batch - first if count is None else count
+        self._chk(self._L.pcl_set_member_window(self._h, int(first), int(count)))
+        self.window = (int(first), int(count))
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self._chk(self._L.pcl_constraint_dim(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        self.n_rows = b.value
+        self._chk(self._L.pcl_jac_nnz(self._h, ctypes.byref(a), ctypes.byref(b)))
+        self.jac_nnz = a.value
+        self._chk(self._L.pcl_hess_nnz(self._h, ctypes.byref(a), ctypes.byref(b)))
+        self.hess_nnz = a.value
+        self._chk(self._L.pcl_jac_compact_nnz(self._h, ctypes.byref(a), ctypes.byref(b)))
+        self.compact_nnz = a.value
+
     # -- DerivativeIntegrator / time-consistency rows on this context's trajectory layout -----------------
     def deriv_dims(self, dx_off, dim):
         a, b = ctypes.c_int64(), ctypes.c_int64()
@@ -219,14 +238,58 @@ class _PclContext:
             raise ValueError("goal iso-vec has %d entries, expected %d" % (g.size, self.x_dim))
         self._chk(self._L.pcl_set_goal(self._h, _ptr(g)))
 
+    def set_goal_subspace(self, goal_sub_iso_vec, subspace):
+        """Embedded goal: iso-vec of the ns x ns block ``unembed(op)`` and its 0-based subspace indices."""
+        sub = np.ascontiguousarray(subspace, dtype=np.int32).reshape(-1)
+        g = np.ascontiguousarray(goal_sub_iso_vec, dtype=np.float64).reshape(-1)
+        if g.size != 2 * sub.size * sub.size:
+            raise ValueError("subspace goal iso-vec has %d entries, expected %d" % (g.size, 2 * sub.size * sub.size))
+        self._chk(self._L.pcl_set_goal_subspace(self._h, _ptr(g), sub.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), sub.size))
+
+    def set_weights(self, weights):
+        if weights is None:
+            self._chk(self._L.pcl_set_weights(self._h, None))
+            return
+        w = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1)
+        if w.size != self.batch:
+            raise ValueError("expected %d weights, got %d" % (self.batch, w.size))
+        self._chk(self._L.pcl_set_weights(self._h, _ptr(w)))
+
     def infidelity_dev(self, Z, Q, value=None, grad=None):
         self._chk(self._L.pcl_infidelity_dev(self._h, _ptr(Z), float(Q), _ptr(value), _ptr(grad)))
+
+    def add_regularizer(self, off, dim, R, dt_power=2):
+        R = np.ascontiguousarray(np.broadcast_to(np.asarray(R, dtype=np.float64), (dim,)))
+        self._chk(self._L.pcl_add_regularizer(self._h, int(off), int(dim), _ptr(R), int(dt_power)))
+
+    def clear_regularizers(self):
+        self._chk(self._L.pcl_clear_regularizers(self._h))
+
+    def objective_dev(self, Z, Q, value, grad=None):
+        self._chk(self._L.pcl_objective_dev(self._h, _ptr(Z), float(Q), _ptr(value), _ptr(grad)))
+
+    def objective(self, Z, Q, want_grad=True):
+        """(value [1 or batch], gradient [z_len] or None) of the whole objective, host buffers."""
+        Z = self._z(Z)
+        value = np.empty(self.batch if self.batch_mode == PCL_BATCH_TRAJ else 1)
+        grad = np.empty(self.z_len) if want_grad else None
+        self._chk(self._L.pcl_objective(self._h, _ptr(Z), float(Q), _ptr(value), _ptr(grad)))
+        return value, grad
+
+    def merit_grad_len(self):
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        self._chk(self._L.pcl_merit_grad_len(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def merit_grad_dev(self, delta, lam, vals, out):
+        """out <- [phi | J^T lam on the shared u_k | ... on dt_k] (lam None: lam = delta, phi = the constraint merit)."""
+        self._chk(self._L.pcl_merit_grad_dev(self._h, _ptr(delta), _ptr(lam), _ptr(vals), _ptr(out)))
 
     # -- rollout (exact piecewise-constant propagation from the knot-0 state) ----------------------------------------
     def rollout(self, Z, out=None):
         """[batch, N, x_dim] iso-vec states: X_{k+1} = exp(dt_k G(u_k)) X_k."""
         Z = self._z(Z)
-        out = np.empty((self.batch, self.N, self.x_dim)) if out is None else out
+        out = np.empty((self.window[1], self.N, self.x_dim)) if out is None else out
         self._chk(self._L.pcl_rollout(self._h, _ptr(Z), _ptr(out)))
         return out
 
@@ -344,6 +407,149 @@ class HipPadeIntegrator:
             self._f_ctx.close()
 
 
+class _EnsembleCore:
+    """What the M per-member integrators of a SamplingTrajectory share: ONE batched ``pcl_ctx`` (all members, per-member
+    drift tiles, one launch) and the results of the last fused evaluation.
+
+    The reference evaluates its integrators one after the other on the same trajectory
+    (``evaluate!(delta_i, B_i, traj)`` for i = 1..M [REF src/control/integrators.jl:316-317]); here the first member asked
+    about a trajectory launches the fused kernel for ALL members and the others slice their rows out of the cached
+    result.  The cache key is the trajectory buffer itself (byte comparison with the copy the results were computed from),
+    so a stale result can never be served.  Hessian calls carry a per-member multiplier slice and run on a one-member
+    window of the same context (``pcl_set_member_window``)."""
+
+    def __init__(self, fused, n_members):
+        self.fused = fused  # HipPadeIntegrator over all members
+        self.ctx = fused.ctx
+        self.M = n_members
+        self.per_rows = self.ctx.x_dim * self.ctx.K
+        self.per_jac = self.ctx.jac_per * self.ctx.K
+        self.per_hess = self.ctx.hess_per * self.ctx.K
+        self._Z = None
+        self._delta = None
+        self._vals = None
+        self.launches = 0  # fused launches so far (tests check the sharing)
+
+    def _fresh(self, Z):
+        Z = np.ascontiguousarray(Z, dtype=np.float64).reshape(-1)
+        if self._Z is None or self._Z.shape != Z.shape or not np.array_equal(self._Z, Z):
+            self._Z = Z.copy()
+            self._delta = self._vals = None
+        return self._Z
+
+    def delta(self, Z):
+        Z = self._fresh(Z)
+        if self._delta is None:
+            self.ctx.set_member_window(0, self.M)
+            self._delta = self.ctx.eval(Z)
+            self.launches += 1
+        return self._delta
+
+    def delta_and_vals(self, Z):
+        Z = self._fresh(Z)
+        if self._vals is None:
+            self.ctx.set_member_window(0, self.M)
+            self._delta, self._vals = self.ctx.eval_jac(Z)
+            self.launches += 1
+        return self._delta, self._vals
+
+    def close(self):
+        self.fused.close()
+
+
+class _MemberView:
+    """The ``ctx``-like object of one member integrator: the generic functions (``evaluate_``, ``eval_jacobian`` ...) call
+    ``eval / jac / hess / *_structure`` on it exactly as on a whole context; rows are numbered inside the member's block
+    (the reference's integrators are separate objects; the problem adds each block's row offset)."""
+
+    def __init__(self, core, i):
+        self._core, self._i = core, i
+        c = core.ctx
+        self.x_dim, self.K, self.N, self.z_dim, self.z_len = c.x_dim, c.K, c.N, c.z_dim, c.z_len
+        self.n_rows, self.jac_nnz, self.hess_nnz = core.per_rows, core.per_jac, core.per_hess
+
+    def eval(self, Z, delta=None):
+        i, r = self._i, self._core.per_rows
+        d = self._core.delta(Z)[i * r : (i + 1) * r]
+        if delta is not None:
+            delta[:] = d
+            return delta
+        return d.copy()
+
+    def jac(self, Z, vals=None):
+        i, r = self._i, self._core.per_jac
+        v = self._core.delta_and_vals(Z)[1][i * r : (i + 1) * r]
+        if vals is not None:
+            vals[:] = v
+            return vals
+        return v.copy()
+
+    def eval_jac(self, Z, delta=None, vals=None):
+        return self.eval(Z, delta), self.jac(Z, vals)
+
+    def _windowed(self, fn):
+        c = self._core.ctx
+        c.set_member_window(self._i, 1)
+        try:
+            return fn(c)
+        finally:
+            c.set_member_window(0, self._core.M)
+
+    def jac_structure(self, dtype=np.int64):
+        return self._windowed(lambda c: c.jac_structure(dtype))
+
+    def hess_structure(self, dtype=np.int64):
+        return self._windowed(lambda c: c.hess_structure(dtype))
+
+    def hess(self, Z, mu, vals=None):
+        return self._windowed(lambda c: c.hess(Z, mu, vals))
+
+    def rollout(self, Z):
+        return self._windowed(lambda c: c.rollout(Z))
+
+
+class HipPadeMemberIntegrator:
+    """One element of ``BilinearIntegrator(qtraj::SamplingTrajectory, N)``'s ``Vector{BilinearIntegrator}``
+    [REF src/control/integrators.jl:134-162]: the dynamics rows of ONE ensemble member (state component ``x_name``, the
+    member's own system), with the reference's properties ``dim == x_dim*(N-1)``, ``x_dim``, ``x_name``, ``f``.  All members
+    of one vector evaluate through a shared batched context (``ensemble``)."""
+
+    def __init__(self, core, i, x_name, G_drift, G_drives, u_name, sig, pade_order):
+        self.ensemble, self.member = core, i
+        self.x_name, self.x_names, self.u_name = x_name, [x_name], u_name
+        self.G_drift, self.G_drives = G_drift, G_drives
+        self._sig, self.pade_order = sig, pade_order
+        self._view = _MemberView(core, i)
+        self.x_dim = core.ctx.x_dim
+        self.dim = core.per_rows
+        self._f_ctx = None
+
+    @property
+    def ctx(self):
+        return self._view
+
+    _check = HipPadeIntegrator._check
+
+    def f(self, x_next, x, u, dt):
+        """``B.f(x_next, x, u, dt)`` of this member's system [REF integrators.jl:518-525]."""
+        c = self.ensemble.ctx
+        if self._f_ctx is None:
+            self._f_ctx = _PclContext(d=c.d, m=c.m, N=2, z_dim=c.x_dim + 1 + c.m, u_off=c.x_dim + 1, dt_off=c.x_dim, x_offs=[0],
+                                      G0=self.G_drift, Gj=self.G_drives, batch=1, batch_mode=PCL_BATCH_MEMBERS,
+                                      state_cols=self.ensemble.fused._state_cols, pade_order=self.pade_order)  # fmt: skip
+        z = np.zeros((2, c.x_dim + 1 + c.m))
+        z[0, : c.x_dim], z[0, c.x_dim], z[0, c.x_dim + 1 :] = x, dt, np.asarray(u)[: c.m]
+        z[1, : c.x_dim] = x_next
+        return self._f_ctx.eval(z)
+
+    def close(self):
+        if self._f_ctx is not None:
+            self._f_ctx.close()
+            self._f_ctx = None
+        if self.member == 0:
+            self.ensemble.close()
+
+
 class HipPadeMultistart:
     """B independent trajectories of identical shape evaluated in one launch (multistart
     seeds; BASELINE.json config 5).  Not a reference type: the reference has no multistart
@@ -422,17 +628,27 @@ class DerivativeIntegrator:
 def BilinearIntegrator(system, traj, x_name=None, u_name="u", **kw):
     """``BilinearIntegrator(qtraj, N)`` for the time-independent unitary path.
 
-    ``system`` is one system (UnitaryTrajectory) or a list of systems sharing the
-    drives (SamplingTrajectory: one member state ``Utilde<i>`` per system)."""
+    ``system`` is one system (UnitaryTrajectory) -> one integrator, or a list of systems
+    (``BilinearIntegrator(qtraj::SamplingTrajectory, N)`` [REF integrators.jl:134-146]) -> a LIST with one integrator per
+    member, in member order, as the reference returns and as ``SamplingProblem`` requires
+    [REF src/control/templates/sampling_problem.jl:190-223].  Members that share the drive generators (per-member
+    ``H_drift`` only -- BASELINE config 4) evaluate through one batched context; an ensemble whose members differ in
+    their drive generators too (each member uses its full ``sys.G`` [REF integrators.jl:149-162]) gets one context per
+    member."""
     if isinstance(system, (list, tuple)):
         systems = list(system)
         if any(getattr(s, "time_dependent", False) for s in systems):
             raise NotImplementedError("time-dependent systems use TimeDependentBilinearIntegrator (out of scope)")
         names = x_name or ["%s%d" % (STATE, i) for i in range(1, len(systems) + 1)]
-        Gd = np.array([s.G_drives_array() for s in systems])
+        if len(names) != len(systems):
+            raise ValueError("%d state names for %d systems" % (len(names), len(systems)))
+        Gd = [s.G_drives_array() for s in systems]
         if not all(np.array_equal(Gd[0], g) for g in Gd[1:]):
-            raise NotImplementedError("ensemble members must share the drive generators (per-member G_drift only)")
-        return HipPadeIntegrator(np.array([s.G_drift for s in systems]), Gd[0], traj, names, u_name, **kw)
+            return [HipPadeIntegrator(s.G_drift, g, traj, nm, u_name, **kw) for s, g, nm in zip(systems, Gd, names)]
+        fused = HipPadeIntegrator(np.array([s.G_drift for s in systems]), Gd[0], traj, names, u_name, **kw)
+        core = _EnsembleCore(fused, len(systems))
+        return [HipPadeMemberIntegrator(core, i, nm, systems[i].G_drift, fused.G_drives, u_name, fused._sig, fused.pade_order)
+                for i, nm in enumerate(names)]  # fmt: skip
     if getattr(system, "time_dependent", False):
         raise NotImplementedError("time-dependent systems use TimeDependentBilinearIntegrator (out of scope)")
     from .quantum import OpenQuantumSystem

@@ -1,27 +1,121 @@
-"""Host-side (numpy) terminal objective used by the plumbing solve: the reference's unitary infidelity
-``Q * |1 - |tr(U_goal' U_N)|^2 / n^2|`` [REF src/control/objectives.jl:330-356] and its gradient with respect to
-the terminal iso-vec.  SURVEY.md section 8(f) lists the on-device version as the next row after the constraint
-path; this small host function exists so that a whole NLP can be driven through the GPU evaluator's callbacks."""
+"""Host-side mirror of the objective terms of the reference's unitary problem templates, evaluated ON THE GPU through
+the C ABI (``pcl_set_goal[_subspace]``, ``pcl_set_weights``, ``pcl_add_regularizer``, ``pcl_objective[_dev]``):
+
+  UnitaryInfidelityObjective(U_goal, name, traj; Q)        src/control/objectives.jl:347-356   (Q * |1 - F(U_N)|)
+  ... with an EmbeddedOperator goal (subspace fidelity)     src/control/objectives.jl:339-345
+  QuadraticRegularizer(name, traj, R) [EXT DirectTrajOpt]   src/control/templates/smooth_pulse_problem.jl:249-251
+  sum_i (w_i Q) l_i + regularisers (SamplingProblem)        src/control/templates/sampling_problem.jl:381-387
+
+Terms are small records combined with ``+`` (as the reference combines ``AbstractObjective``s); ``bind`` attaches the sum
+to an integrator's context, after which ``value_and_gradient(traj)`` is one call into the library.  Nothing here computes
+an objective on the host.
+"""
 import numpy as np
 
-from .quantum import iso_vec_to_operator
+from .quantum import operator_to_iso_vec
+
+__all__ = ["EmbeddedOperator", "UnitaryInfidelityObjective", "QuadraticRegularizer", "Objective", "get_subspace_indices"]
 
 
-def unitary_fidelity_loss(x, U_goal):
-    """|tr(U_goal' U)|^2 / n^2 (the reference calls this the *fidelity loss*; it is the fidelity)."""
-    U = iso_vec_to_operator(x)
-    n = U.shape[0]
-    return abs(np.trace(np.asarray(U_goal).conj().T @ U)) ** 2 / n**2
+def get_subspace_indices(subspaces, subsystem_levels):
+    """0-based indices of the product-basis states whose every subsystem level lies in that subsystem's subspace
+    (``subspaces``: one 0-based level list per subsystem) [REF src/quantum/operators/embedded_operators.jl:352-364]."""
+    import itertools
+
+    return [flat for flat, lv in enumerate(itertools.product(*[range(L) for L in subsystem_levels]))
+            if all(l in sub for l, sub in zip(lv, subspaces))]  # fmt: skip
 
 
-def unitary_infidelity(x, U_goal, Q=100.0):
-    """(value, gradient w.r.t. the iso-vec x) of Q * |1 - F(x)|."""
-    Ug = np.asarray(U_goal, dtype=complex)
-    U = iso_vec_to_operator(x)
-    n = U.shape[0]
-    t = np.trace(Ug.conj().T @ U)
-    F = abs(t) ** 2 / n**2
-    W = np.conj(t) * np.conj(Ug)  # d|t|^2/dRe U = 2 Re W ; d|t|^2/dIm U = -2 Im W
-    gU = np.vstack((2 * W.real, -2 * W.imag)) / n**2  # [Re; Im] blocks, n x ... -> (2n, n)
-    sign = 1.0 if 1 - F >= 0 else -1.0
-    return Q * abs(1 - F), (-sign * Q) * gU.T.reshape(-1)
+class EmbeddedOperator:
+    """``EmbeddedOperator(subspace_operator, subspace, subsystem_levels)`` [REF embedded_operators.jl:70-89]; ``subspace``
+    holds 0-based indices here."""
+
+    def __init__(self, subspace_operator, subspace, subsystem_levels):
+        levels = [subsystem_levels] if np.isscalar(subsystem_levels) else list(subsystem_levels)
+        self.subspace = [int(i) for i in subspace]
+        self.subsystem_levels = levels
+        n = int(np.prod(levels))
+        op = np.asarray(subspace_operator, dtype=complex)
+        if op.shape != (len(self.subspace),) * 2:
+            raise ValueError("subspace operator is %r, subspace has %d indices" % (op.shape, len(self.subspace)))
+        self.operator = np.zeros((n, n), dtype=complex)
+        self.operator[np.ix_(self.subspace, self.subspace)] = op
+
+    def unembed(self):
+        return self.operator[np.ix_(self.subspace, self.subspace)]
+
+
+class _Term:
+    def __add__(self, other):
+        return Objective(_terms(self) + _terms(other))
+
+    __radd__ = lambda self, other: self if other == 0 else NotImplemented
+
+
+def _terms(x):
+    return list(x.terms) if isinstance(x, Objective) else [x]
+
+
+class UnitaryInfidelityObjective(_Term):
+    """``Q * |1 - F|`` on the terminal state(s) ``names`` (one name, or the member states of an ensemble with optional
+    ``weights`` -- the SamplingProblem sum)."""
+
+    def __init__(self, U_goal, names, traj=None, Q=100.0, weights=None):
+        self.goal, self.Q = U_goal, float(Q)
+        self.names = [names] if isinstance(names, str) else list(names)
+        self.weights = None if weights is None else np.asarray(weights, dtype=np.float64)
+
+
+class QuadraticRegularizer(_Term):
+    """``1/2 sum_k dt_k^p sum_i R_i v_{k,i}^2`` on component ``name``; ``R`` a scalar or one weight per entry.
+    ``dt_power`` = 2 is the DirectTrajOpt / QuantumCollocation form (r = dt v), 0 the plain knot-point form."""
+
+    def __init__(self, name, traj, R, dt_power=2):
+        self.name, self.dt_power = name, int(dt_power)
+        self.off, self.dim = traj.components[name].start, len(traj.components[name])
+        self.R = np.broadcast_to(np.asarray(R, dtype=np.float64), (self.dim,)).copy()
+
+
+class Objective:
+    def __init__(self, terms):
+        self.terms = list(terms)
+        self._ctx = None
+        self._Q = 0.0
+
+    def __add__(self, other):
+        return Objective(self.terms + _terms(other))
+
+    def bind(self, B):
+        """Attach to the context of integrator ``B`` (a single integrator, a fused ensemble integrator, or any member of
+        an integrator list -- its shared batched context is used)."""
+        B = B[0] if isinstance(B, (list, tuple)) else B
+        ctx = B.ensemble.ctx if hasattr(B, "ensemble") else B.ctx
+        inf = [t for t in self.terms if isinstance(t, UnitaryInfidelityObjective)]
+        if len(inf) > 1:
+            raise NotImplementedError("one terminal infidelity term per problem")
+        ctx.clear_regularizers()
+        for t in self.terms:
+            if isinstance(t, QuadraticRegularizer):
+                ctx.add_regularizer(t.off, t.dim, t.R, t.dt_power)
+        self._Q = 0.0
+        if inf:
+            t = inf[0]
+            if isinstance(t.goal, EmbeddedOperator):
+                ctx.set_goal_subspace(operator_to_iso_vec(t.goal.unembed()), t.goal.subspace)
+            else:
+                ctx.set_goal(operator_to_iso_vec(np.asarray(t.goal, dtype=complex)))
+            ctx.set_weights(t.weights)
+            self._Q = t.Q
+        self._ctx = ctx
+        return self
+
+    def value_and_gradient(self, traj_or_Z, want_grad=True):
+        """(J, dJ/dz) for the trajectory's variable vector (host buffers; one value per seed for a multistart context)."""
+        if self._ctx is None:
+            raise RuntimeError("bind the objective to an integrator first")
+        Z = traj_or_Z.datavec if hasattr(traj_or_Z, "datavec") else traj_or_Z
+        v, g = self._ctx.objective(Z, self._Q, want_grad)
+        return (float(v[0]) if v.size == 1 else v), g
+
+    def value_and_gradient_dev(self, Z_dev, value_dev, grad_dev=None):
+        self._ctx.objective_dev(Z_dev, self._Q, value_dev, grad_dev)

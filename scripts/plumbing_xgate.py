@@ -15,7 +15,6 @@ from scipy.optimize import BFGS, Bounds, NonlinearConstraint, minimize
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import piccolo_jl_amd as pa
-from piccolo_jl_amd.objectives import unitary_fidelity_loss, unitary_infidelity
 
 
 def solve(N=50, T=10.0, Q=100.0, R=1e-2, seed=0, max_iter=300, verbose=0):
@@ -39,8 +38,6 @@ def solve(N=50, T=10.0, Q=100.0, R=1e-2, seed=0, max_iter=300, verbose=0):
     structs = [pa.jacobian_structure(r) for r in rows]
     offs = np.cumsum([0] + [r.dim for r in rows])
     comp = traj.components
-    xN = slice((N - 1) * traj.dim + comp["Ũ⃗"].start, (N - 1) * traj.dim + comp["Ũ⃗"].stop)
-    reg_idx = np.concatenate([np.arange(k * traj.dim + comp[c].start, k * traj.dim + comp[c].stop) for k in range(N) for c in ("u", "du", "ddu")])
 
     def cons(z):
         traj.update(z)
@@ -68,12 +65,14 @@ def solve(N=50, T=10.0, Q=100.0, R=1e-2, seed=0, max_iter=300, verbose=0):
                 vv += [-mu[k], -mu[k]]
         return H + sp.csr_matrix((np.concatenate(vv), (np.concatenate(ii), np.concatenate(jj))), shape=(nv, nv))
 
+    # objective on the GPU: UnitaryInfidelityObjective + 3 x QuadraticRegularizer [REF smooth_pulse_problem.jl:240-251]
+    J = pa.UnitaryInfidelityObjective(U_goal, "Ũ⃗", traj, Q=Q)
+    for c_ in ("u", "du", "ddu"):
+        J = J + pa.QuadraticRegularizer(c_, traj, R, dt_power=0)
+    J.bind(B)
+
     def obj(z):
-        f, g = unitary_infidelity(z[xN], U_goal, Q)
-        grad = np.zeros(nv)
-        grad[xN] = g
-        grad[reg_idx] = R * z[reg_idx]
-        return f + 0.5 * R * float(z[reg_idx] @ z[reg_idx]), grad
+        return J.value_and_gradient(z)
 
     lb, ub = np.full(nv, -np.inf), np.full(nv, np.inf)
     for k in range(N):
@@ -95,7 +94,7 @@ def solve(N=50, T=10.0, Q=100.0, R=1e-2, seed=0, max_iter=300, verbose=0):
                    options=dict(maxiter=max_iter, gtol=1e-8, xtol=1e-12, verbose=verbose, sparse_jacobian=True))  # fmt: skip
     traj.update(res.x)
     viol = np.abs(cons(res.x)).max()
-    fid = unitary_fidelity_loss(res.x[xN], U_goal)
+    fid = 1.0 - pa.Objective([pa.UnitaryInfidelityObjective(U_goal, "Ũ⃗", traj, Q=1.0)]).bind(B).value_and_gradient(res.x, want_grad=False)[0]
     B.close()
     return dict(fidelity=float(fid), max_violation=float(viol), iterations=int(res.nit), n_vars=nv, n_rows=nc_rows, traj=traj)
 

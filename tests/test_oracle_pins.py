@@ -314,3 +314,119 @@ def test_oracle_general_generator_dimension_finite_differences():
         Zm[col] -= eps
         fd = (po.pade_residual(Zp.reshape(N, -1), lay, G0, Gj, 4) - po.pade_residual(Zm.reshape(N, -1), lay, G0, Gj, 4)).reshape(-1) / (2 * eps)
         assert np.abs(fd - J[:, col]).max() < 1e-7
+
+
+# ---- the Pade Jacobian pinned against the reference's OWN constraint function ---------------------------------
+@pytest.mark.parametrize(
+    "name,orders",
+    [
+        ("two_qubit_zoh", {4: (1e-11, 2e-7), 6: (0, 1e-9), 8: (0, 1e-9), 10: (0, 1e-9)}),
+        ("multilevel_transmon", {10: (0, 1e-6)}),  # large steps (Pade-10 residual 1e-7 there, see above): looser band
+    ],
+)
+def test_pade_jacobian_vs_frechet_derivative_of_the_exp_constraint(name, orders, golden, golden_meta):
+    """The reference's constraint is x_{k+1} - exp(dt G(u_k)) x_k and its Jacobian is the Frechet derivative of expm
+    (it gets it by ForwardDiff through expv).  On trajectories SOLVED BY THE REFERENCE (residual ~1e-11) the oracle's
+    analytic Pade-p Jacobian, premultiplied by (B^-_p)^{-1}, must equal that Jacobian: to 1e-9 at orders 6..10 (the
+    high orders are the exp constraint's own Jacobian to rounding), and at order 4 to its known truncation order
+    (||dt G|| <= 0.076: x^5/720-sized terms, i.e. nonzero but below 2e-7).  This pins every Jacobian segment -- the B^{+-}
+    blocks, d/du_l, d/ddt, their signs, the (u_k, dt_k) index convention and the triplet order -- on numbers the
+    reference's constraint function defines, not on finite differences of the oracle itself."""
+    systems, lay, _ = ref_case(name, golden_meta)
+    Z = golden("ref_" + name)["Z"]
+    s = systems[0]
+    G0, Gj = s.G_drift, np.array(s.G_drives)
+    if lay.K > 60:  # every interval is an independent check; a spread subset keeps the CPU suite fast
+        keep = np.unique(np.linspace(0, lay.K - 1, 40).astype(int))
+    else:
+        keep = np.arange(lay.K)
+    Je = po.exp_jacobian_values(Z, lay, G0, Gj)[keep]
+    scale = np.abs(Je).max()
+    for order, (lo, hi) in orders.items():
+        Jp = po.pade_jacobian_in_exp_form(Z, lay, G0, Gj, order)[keep]
+        err = np.abs(Jp - Je).max() / scale
+        assert lo <= err < hi, (order, err)
+    # tripwire: the same comparison with the drive of the NEXT knot (the wrong index convention) is far off
+    Zs = Z.copy()
+    Zs[:-1, lay.u_off : lay.u_off + lay.m] = Z[1:, lay.u_off : lay.u_off + lay.m]
+    order = max(orders)
+    bad = np.abs(po.pade_jacobian_in_exp_form(Zs, lay, G0, Gj, order)[keep] - Je).max() / scale
+    assert bad > 1e-4, bad
+
+
+def test_exp_jacobian_finite_differences(golden, golden_meta):
+    """The Frechet-derivative Jacobian above really is the Jacobian of the oracle's exp residual (central differences)."""
+    systems, lay, _ = ref_case("two_qubit_zoh", golden_meta)
+    Z = golden("ref_two_qubit_zoh")["Z"][:4].copy()
+    lay = po.Layout(d=lay.d, m=lay.m, N=4, z_dim=lay.z_dim, x_off=lay.x_off, u_off=lay.u_off, dt_off=lay.dt_off)
+    s = systems[0]
+    G0, Gj = s.G_drift, np.array(s.G_drives)
+    rows, cols = po.jac_structure(lay)
+    J = np.zeros((lay.x_dim * lay.K, lay.z_dim * lay.N))
+    np.add.at(J, (rows, cols), po.exp_jacobian_values(Z, lay, G0, Gj).reshape(-1))
+    f = lambda z: po.exp_residual(z.reshape(lay.N, lay.z_dim), lay, G0, Gj).reshape(-1)
+    Jfd = _fd_jac(f, Z.reshape(-1))
+    assert np.abs(J - Jfd).max() < 1e-8
+
+
+# ---- objectives: known answers of the reference's own tests, then finite differences ---------------------------------
+def test_fidelity_literals_of_the_reference():
+    """[REF src/quantum/dynamics.jl:1305-1315] unitary_fidelity(X, X) = 1, (X, Z) = 0, the subspace restriction;
+    [REF src/quantum/operators/embedded_operators.jl:627-633] get_subspace_indices literals (1-based there)."""
+    X, Zp, I2 = po.PAULIS["X"], po.PAULIS["Z"], np.eye(2)
+    xv = po.operator_to_iso_vec(X)
+    assert abs(po.unitary_fidelity_loss(xv, X) - 1.0) < 1e-15
+    assert abs(po.unitary_fidelity_loss(xv, Zp)) < 1e-15
+    # global-phase invariance, F(U, U) = 1 for a random unitary, 0 <= F <= 1
+    rng = np.random.default_rng(1)
+    for lv in (2, 3, 4, 9):
+        U = np.linalg.qr(rng.standard_normal((lv, lv)) + 1j * rng.standard_normal((lv, lv)))[0]
+        V = np.linalg.qr(rng.standard_normal((lv, lv)) + 1j * rng.standard_normal((lv, lv)))[0]
+        uv = po.operator_to_iso_vec(U)
+        assert abs(po.unitary_fidelity_loss(uv, U) - 1.0) < 1e-13
+        assert abs(po.unitary_fidelity_loss(po.operator_to_iso_vec(np.exp(0.7j) * U), U) - 1.0) < 1e-13
+        F = po.unitary_fidelity_loss(uv, V)
+        assert 0.0 <= F <= 1.0
+        assert abs(F - abs(np.trace(V.conj().T @ U)) ** 2 / lv**2) < 1e-14
+    # hand-computed 2x2: U = diag(1, i), goal = I: tr = 1 + i, |tr|^2 = 2, F = 2/4
+    assert abs(po.unitary_fidelity_loss(po.operator_to_iso_vec(np.diag([1, 1j])), I2) - 0.5) < 1e-15
+    # subspace literals
+    assert [i + 1 for i in po.get_subspace_indices([[0, 1], [0, 1]], [3, 3])] == [1, 2, 4, 5]
+    assert [i + 1 for i in po.get_subspace_indices([[1], [1]], [3, 3])] == [5]
+    assert [i + 1 for i in po.get_subspace_indices([[1], [0, 1]], [3, 3])] == [4, 5]
+    # a 3-level embedding of X scored on the qubit subspace: the embedded-goal formula gives 1 for the goal itself,
+    # whatever the leakage block holds, and reduces to (n + |tr M|^2) / (n (n + 1)) for a unitary subspace block
+    U3 = np.zeros((3, 3), dtype=complex)
+    U3[:2, :2] = X
+    U3[2, 2] = np.exp(0.3j)
+    goal = po.embed(X, [0, 1], 3)
+    assert np.array_equal(po.unembed(goal, [0, 1]), X.astype(complex))
+    assert abs(po.unitary_fidelity_loss(po.operator_to_iso_vec(U3), goal, [0, 1]) - 1.0) < 1e-15
+    U3b = np.zeros((3, 3), dtype=complex)
+    U3b[:2, :2] = np.diag([1, 1j])  # M = X' diag(1, i): tr M = 0, tr M'M = 2 -> F = 2 / 6
+    U3b[2, 2] = 1.0
+    assert abs(po.unitary_fidelity_loss(po.operator_to_iso_vec(U3b), goal, [0, 1]) - 1.0 / 3.0) < 1e-15
+
+
+@pytest.mark.parametrize("sub", [None, [0, 1, 3, 4]])
+def test_objective_gradients_finite_differences(sub):
+    rng = np.random.default_rng(7)
+    lv = 9 if sub else 4
+    U = np.linalg.qr(rng.standard_normal((lv, lv)) + 1j * rng.standard_normal((lv, lv)))[0]
+    U = U + 0.05 * (rng.standard_normal((lv, lv)) + 1j * rng.standard_normal((lv, lv)))
+    ns = len(sub) if sub else lv
+    Gs = np.linalg.qr(rng.standard_normal((ns, ns)) + 1j * rng.standard_normal((ns, ns)))[0]
+    goal = po.embed(Gs, sub, lv) if sub else Gs
+    x = po.operator_to_iso_vec(U)
+    g = po.unitary_infidelity_gradient(x, goal, 3.0, sub)
+    fd = np.array([(po.unitary_infidelity(x + e, goal, 3.0, sub) - po.unitary_infidelity(x - e, goal, 3.0, sub)) / 2e-6 for e in 1e-6 * np.eye(x.size)])
+    assert np.abs(g - fd).max() < 1e-8
+    # regulariser + weighted ensemble sum
+    Z = rng.standard_normal((5, 12))
+    Z[:, 3] = 0.1 + 0.1 * rng.random(5)
+    for pw in (0, 1, 2):
+        gz = po.quadratic_regularizer_gradient(Z, 5, 4, [1.0, 2.0, 0.5, 0.0], 3, pw)
+        f = lambda z: po.quadratic_regularizer(z.reshape(5, 12), 5, 4, [1.0, 2.0, 0.5, 0.0], 3, pw)
+        fdz = np.array([(f(Z.reshape(-1) + e) - f(Z.reshape(-1) - e)) / 2e-6 for e in 1e-6 * np.eye(60)])
+        assert np.abs(gz.reshape(-1) - fdz).max() < 1e-8
+    assert po.quadratic_regularizer(Z, 5, 4, 0.0, 3) == 0.0  # [REF spline_pulse_problem.jl:1570-1578]: R = 0 -> exactly zero

@@ -196,32 +196,86 @@ def test_reference_solved_trajectories(name, golden, golden_meta):
 
 @pytest.mark.parametrize("name", ["sampling_robust", "robust_sampling"])
 def test_reference_solved_ensembles(name, golden, golden_meta):
-    """SamplingTrajectory layout [U1..UM, dt, t, u], per-member drift, shared controls, free dt."""
+    """SamplingTrajectory layout [U1..UM, dt, t, u], per-member drift, shared controls, free dt, on the reference's own
+    solved ensembles -- through the boundary the reference defines: ``BilinearIntegrator(qtraj::SamplingTrajectory, N)``
+    returns ONE INTEGRATOR PER MEMBER [REF src/control/integrators.jl:134-146] (``SamplingProblem`` rejects anything else,
+    [REF sampling_problem.jl:195-223]); each has dim = x_dim (N-1), its own x_name and rows numbered inside its block, and
+    the problem concatenates them in member order [REF integrators.jl:316-317]."""
     systems, lay, x_offs = ref_case(name, golden_meta)
     Z = golden("ref_" + name)["Z"]
     M = len(systems)
     psys = [pa.QuantumSystem(s.H_drift, s.H_drives, [1.0, 1.0]) for s in systems]
     traj = traj_from_Z(pa, Z, lay, n_members=M)
-    B = pa.BilinearIntegrator(psys, traj)
-    assert B.dim == M * lay.x_dim * lay.K and B.x_names == ["Ũ⃗%d" % (i + 1) for i in range(M)]
-    delta = pa.evaluate_(np.zeros(B.dim), B, traj)
-    vals = B.ctx.jac(traj.datavec)
-    rows, cols = pa.jacobian_structure(B)
-    for i, (s, xo) in enumerate(zip(systems, x_offs)):
-        G0, Gj = s.G_drift, np.array(s.G_drives)
-        close(delta[i * lay.x_dim * lay.K : (i + 1) * lay.x_dim * lay.K], po.pade_residual(Z, lay, G0, Gj, 4, x_off=xo))
-        per = po.jac_nnz_per_interval(lay) * lay.K
-        close(vals[i * per : (i + 1) * per], po.pade_jacobian_values(Z, lay, G0, Gj, 4, x_off=xo))
-        r0, c0 = po.jac_structure(lay, x_off=xo)
-        assert np.array_equal(rows[i * per : (i + 1) * per], r0 + i * lay.x_dim * lay.K)
-        assert np.array_equal(cols[i * per : (i + 1) * per], c0)
-    mu = np.random.default_rng(3).standard_normal(B.dim)
-    hv = B.ctx.hess(traj.datavec, mu)
+    Bs = pa.BilinearIntegrator(psys, traj)
+    assert isinstance(Bs, list) and len(Bs) == M
+    core = Bs[0].ensemble
+    per_d, per = lay.x_dim * lay.K, po.jac_nnz_per_interval(lay) * lay.K
     hper = po.hess_nnz_per_interval(lay) * lay.K
-    for i, (s, xo) in enumerate(zip(systems, x_offs)):
-        h0 = po.pade4_hessian_values(Z, mu[i * lay.x_dim * lay.K : (i + 1) * lay.x_dim * lay.K].reshape(lay.K, -1), lay, s.G_drift, np.array(s.G_drives), x_off=xo)
-        close(hv[i * hper : (i + 1) * hper], h0, 1e-11)
-    B.close()
+    mu = np.random.default_rng(3).standard_normal(M * per_d)
+    deltas, jvals = [], []
+    for i, (B, s, xo) in enumerate(zip(Bs, systems, x_offs)):
+        G0, Gj = s.G_drift, np.array(s.G_drives)
+        assert B.dim == per_d and B.x_dim == lay.x_dim and B.x_name == "Ũ⃗%d" % (i + 1) and B.ensemble is core
+        delta = pa.evaluate_(np.zeros(B.dim), B, traj)
+        close(delta, po.pade_residual(Z, lay, G0, Gj, 4, x_off=xo))
+        J = pa.eval_jacobian(B, traj)
+        assert J.shape == (B.dim, traj.dim * traj.N + traj.global_dim)  # [REF integrators.jl:780-783]
+        vals = B.ctx.jac(traj.datavec)
+        close(vals, po.pade_jacobian_values(Z, lay, G0, Gj, 4, x_off=xo))
+        rows, cols = pa.jacobian_structure(B)
+        r0, c0 = po.jac_structure(lay, x_off=xo)
+        assert np.array_equal(rows, r0) and np.array_equal(cols, c0)  # rows inside the member's own block
+        h0 = po.pade4_hessian_values(Z, mu[i * per_d : (i + 1) * per_d].reshape(lay.K, -1), lay, G0, Gj, x_off=xo)
+        close(B.ctx.hess(traj.datavec, mu[i * per_d : (i + 1) * per_d]), h0, 1e-11)
+        hr, hc = pa.hessian_structure(B)
+        hr0, hc0 = po.hess_structure(lay, x_off=xo)
+        assert np.array_equal(hr, hr0) and np.array_equal(hc, hc0)
+        # B.f: the scalar one-interval form of THIS member's system [REF integrators.jl:518-525]
+        k = 3
+        fk = B.f(Z[k + 1, xo : xo + lay.x_dim], Z[k, xo : xo + lay.x_dim], Z[k, lay.u_off : lay.u_off + lay.m], Z[k, lay.dt_off])
+        close(fk, delta[k * lay.x_dim : (k + 1) * lay.x_dim])
+        deltas.append(delta)
+        jvals.append(vals)
+    assert core.launches == 2  # ONE fused residual launch and ONE fused residual+Jacobian launch served all M members
+    # a changed trajectory invalidates the cache
+    Z2 = Z.copy()
+    Z2[:, lay.u_off] += 1e-3
+    traj2 = traj_from_Z(pa, Z2, lay, n_members=M)
+    d2 = pa.evaluate_(np.zeros(per_d), Bs[-1], traj2)
+    close(d2, po.pade_residual(Z2, lay, systems[-1].G_drift, np.array(systems[-1].G_drives), 4, x_off=x_offs[-1]))
+    assert core.launches == 3
+    # the members' blocks in order are the fused context's output (what the device-resident path hands to the solver)
+    fd, fv = core.ctx.eval_jac(traj.datavec)
+    assert np.array_equal(fd, np.concatenate(deltas)) and np.array_equal(fv, np.concatenate(jvals))
+    # member windows through the C ABI give the same numbers as the slices
+    core.ctx.set_member_window(1, M - 1)
+    wd, wv = core.ctx.eval_jac(traj.datavec)
+    assert np.array_equal(wd, fd[per_d:]) and np.array_equal(wv, fv[per:])
+    core.ctx.set_member_window(0, M)
+    with pytest.raises(pa.PclError):
+        core.ctx.set_member_window(1, M)
+    for B in Bs:
+        B.close()
+
+
+def test_ensemble_with_per_member_drive_generators():
+    """Members that differ in their DRIVE generators too (each member uses its full sys.G, [REF integrators.jl:149-162]):
+    one integrator per member, each with its own context."""
+    rng = np.random.default_rng(8)
+    M, N, xd = 3, 6, 8
+    lay = po.Layout(d=2, m=2, N=N, z_dim=M * xd + 2 + 2, x_off=0, u_off=M * xd + 2, dt_off=M * xd)
+    Z = 0.3 * rng.standard_normal((N, lay.z_dim))
+    Z[:, lay.dt_off] = 0.1 + 0.1 * rng.random(N)
+    osys = [po.quantum_system(0.5 * po.PAULIS["Z"], [(1 + 0.02 * i) * po.PAULIS["X"], po.PAULIS["Y"]], [1.0, 1.0]) for i in range(M)]
+    psys = [pa.QuantumSystem(s.H_drift, s.H_drives, [1.0, 1.0]) for s in osys]
+    traj = traj_from_Z(pa, Z, lay, n_members=M)
+    Bs = pa.BilinearIntegrator(psys, traj)
+    assert isinstance(Bs, list) and len(Bs) == M
+    for i, (B, s) in enumerate(zip(Bs, osys)):
+        assert B.x_name == "Ũ⃗%d" % (i + 1) and B.dim == lay.x_dim * lay.K
+        close(pa.evaluate_(np.zeros(B.dim), B, traj), po.pade_residual(Z, lay, s.G_drift, np.array(s.G_drives), 4, x_off=i * xd))
+        close(B.ctx.jac(traj.datavec), po.pade_jacobian_values(Z, lay, s.G_drift, np.array(s.G_drives), 4, x_off=i * xd))
+        B.close()
 
 
 # ---- BASELINE.json's full sizes ---------------------------------------------------------------------------
@@ -414,14 +468,44 @@ def test_ensemble_merit_and_shared_gradient_on_device():
     osys = [po.System(base.H_drift + 0.01 * i * np.diag(np.arange(d)).astype(complex), base.H_drives, base.drive_bounds) for i in range(M)]
     psys = [pa.QuantumSystem(s.H_drift, s.H_drives, [b[1] for b in s.drive_bounds]) for s in osys]
     traj = traj_from_Z(pa, Z, lay, n_members=M)
-    B = pa.BilinearIntegrator(psys, traj)
+    B = pa.BilinearIntegrator(psys, traj)[0].ensemble.fused  # the batched context the per-member integrators share
     Zd = torch.from_numpy(traj.datavec).cuda()
     dd = torch.empty(B.dim, dtype=torch.float64, device="cuda")
     vd = torch.empty(B.ctx.jac_nnz, dtype=torch.float64, device="cuda")
     B.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     B.ctx.eval_jac_dev(Zd, dd, vd)
-    phi, gu, gdt = pd.constraint_merit_and_shared_gradient(dd, vd, M, lay.K, d, m)
-    phi, gu, gdt = pd.reduce_merit_and_gradient(phi, gu, gdt, None)
+    # the payload kernel of the C ABI (pcl_merit_grad_dev) ...
+    ln, sets = B.ctx.merit_grad_len()
+    assert (ln, sets) == (1 + lay.K * m + lay.K, 1)
+    out = torch.empty(ln, dtype=torch.float64, device="cuda")
+    B.ctx.merit_grad_dev(dd, None, vd, out)
+    torch.cuda.synchronize()
+    phi, gu, gdt = out[0], out[1 : 1 + lay.K * m].view(lay.K, m), out[1 + lay.K * m :]
+    # ... equals the torch restatement of distributed.py (used by the gloo tests on CPU)
+    phi_t, gu_t, gdt_t = pd.constraint_merit_and_shared_gradient(dd, vd, M, lay.K, d, m)
+    assert abs(float(phi) - float(phi_t)) < 1e-12 * max(1.0, float(phi_t))
+    close(gu.cpu().numpy(), gu_t.cpu().numpy())
+    close(gdt.cpu().numpy(), gdt_t.cpu().numpy())
+    # J^T lam for arbitrary multipliers and weights against the oracle's dense Jacobian
+    lam = torch.from_numpy(rng.standard_normal(B.dim)).cuda()
+    w = 1.0 + 0.1 * np.arange(M)
+    B.ctx.set_weights(w)
+    out2 = torch.empty(ln, dtype=torch.float64, device="cuda")
+    B.ctx.merit_grad_dev(dd, lam, vd, out2)
+    torch.cuda.synchronize()
+    B.ctx.set_weights(None)
+    g_ref = np.zeros(lay.z_dim * lay.N)
+    phi_ref = 0.0
+    for i, s in enumerate(osys):
+        Ji = po.pade_jacobian_dense(Z, lay, s.G_drift, np.array(s.G_drives), 4, x_off=i * xd)
+        li = lam[i * lay.x_dim * lay.K : (i + 1) * lay.x_dim * lay.K].cpu().numpy()
+        g_ref += w[i] * (Ji.T @ li)
+        phi_ref += w[i] * float(li @ po.pade_residual(Z, lay, s.G_drift, np.array(s.G_drives), 4, x_off=i * xd).reshape(-1))
+    g_ref = g_ref.reshape(lay.N, lay.z_dim)
+    o2 = out2.cpu().numpy()
+    assert abs(o2[0] - phi_ref) < 1e-12 * max(1.0, abs(phi_ref))
+    close(o2[1 : 1 + lay.K * m].reshape(lay.K, m), g_ref[: lay.K, lay.u_off : lay.u_off + m], 1e-11)
+    close(o2[1 + lay.K * m :], g_ref[: lay.K, lay.dt_off], 1e-11)
 
     def merit(Zp):
         return sum(0.5 * (po.pade_residual(Zp, lay, s.G_drift, np.array(s.G_drives), 4, x_off=i * xd) ** 2).sum() for i, s in enumerate(osys))
@@ -519,11 +603,9 @@ def test_rccl_reduce_through_the_c_abi_single_rank():
 
 
 def test_terminal_infidelity_objective_on_device():
-    """Q |1 - |tr(Ug' U_N)|^2/d^2| and its gradient, per seed, against the host formula
-    (piccolo.jl_amd/objectives.py, itself checked by finite differences here)."""
+    """Q |1 - |tr(Ug' U_N)|^2/d^2| and its gradient, per seed, against the ORACLE's restatement of
+    [REF src/control/objectives.jl:330-337,347-356] (pinned on the reference's literals in tests/test_oracle_pins.py)."""
     import torch
-
-    from piccolo_jl_amd.objectives import unitary_fidelity_loss, unitary_infidelity
 
     rng = np.random.default_rng(12)
     so = po.config_system(2)
@@ -534,8 +616,10 @@ def test_terminal_infidelity_objective_on_device():
         Zs.append(Z)
     t = traj_from_Z(pa, Zs[0], lay)
     ms = pa.HipPadeMultistart(so.G_drift, np.array(so.G_drives), t, Bn)
-    Ug = pa.GATES["CX"] @ np.diag(np.exp(1j * rng.random(d)))
-    ms.ctx.set_goal(pa.operator_to_iso_vec(Ug))
+    Ug = po.PAULIS["X"]
+    Ug = np.kron(np.diag([1, 0]), np.eye(2)) + np.kron(np.diag([0, 1]), Ug)  # CX
+    Ug = Ug @ np.diag(np.exp(1j * rng.random(d)))
+    ms.ctx.set_goal(po.operator_to_iso_vec(Ug))
     Zd = torch.from_numpy(np.stack(Zs)).cuda()
     val = torch.zeros(Bn, dtype=torch.float64, device="cuda")
     grad = torch.zeros(Bn * lay.x_dim, dtype=torch.float64, device="cuda")
@@ -544,19 +628,81 @@ def test_terminal_infidelity_objective_on_device():
     torch.cuda.synchronize()
     for s_ in range(Bn):
         x = Zs[s_][N - 1, : lay.x_dim]
-        f, g = unitary_infidelity(x, Ug, 100.0)
+        f = po.unitary_infidelity(x, Ug, 100.0)
         assert abs(val[s_].item() - f) < 1e-12 * max(1.0, f)
-        close(grad[s_ * lay.x_dim : (s_ + 1) * lay.x_dim].cpu().numpy(), g)
-        assert abs(f - 100.0 * abs(1 - unitary_fidelity_loss(x, Ug))) < 1e-12
-        eps = 1e-6
-        for i in (0, 5, lay.x_dim - 1):
-            xp, xm = x.copy(), x.copy()
-            xp[i] += eps
-            xm[i] -= eps
-            assert abs((unitary_infidelity(xp, Ug, 100.0)[0] - unitary_infidelity(xm, Ug, 100.0)[0]) / (2 * eps) - g[i]) < 1e-6
+        close(grad[s_ * lay.x_dim : (s_ + 1) * lay.x_dim].cpu().numpy(), po.unitary_infidelity_gradient(x, Ug, 100.0))
     with pytest.raises(ValueError):
         ms.ctx.set_goal(np.zeros(3))
     ms.close()
+
+
+def test_subspace_fidelity_regularisers_and_weighted_ensemble_objective():
+    """The rest of SURVEY 8(f) row 1: the EmbeddedOperator (subspace) fidelity a multilevel-transmon gate uses
+    [REF objectives.jl:339-345], the three quadratic regularisers [REF smooth_pulse_problem.jl:249-251] and the weighted
+    ensemble sum [REF sampling_problem.jl:381-387] -- value and full gradient on the device against the oracle."""
+    rng = np.random.default_rng(21)
+    # two 3-level transmons, CZ-like goal on the qubit subspace, three perturbed-drift members with weights
+    base = po.multi_transmon_system([4.0, 4.1], [0.2, 0.2], [[0, 0.05], [0.05, 0]], levels_per_transmon=3, drive_bounds=0.1)
+    d, m, M, N = base.levels, base.n_drives, 3, 6
+    assert d == 9
+    xd = 2 * d * d
+    sub = po.get_subspace_indices([[0, 1], [0, 1]], [3, 3])
+    assert sub == [0, 1, 3, 4] and pa.get_subspace_indices([[0, 1], [0, 1]], [3, 3]) == sub
+    Gs = np.diag([1, 1, 1, -1]).astype(complex) @ np.diag(np.exp(1j * rng.random(4)))
+    goal = po.embed(Gs, sub, d)
+    lay = po.Layout(d=d, m=m, N=N, z_dim=M * xd + 2 + 3 * m, x_off=0, u_off=M * xd + 2, dt_off=M * xd)
+    Z = 0.2 * rng.standard_normal((N, lay.z_dim))
+    Z[:, lay.dt_off] = 0.1 + 0.05 * rng.random(N)
+    for i in range(M):  # terminal states near a unitary, so that F is in the interesting range
+        U = np.linalg.qr(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d)))[0]
+        Z[-1, i * xd : (i + 1) * xd] = po.operator_to_iso_vec(U) + 0.02 * rng.standard_normal(xd)
+    osys = [po.System(base.H_drift + 0.01 * i * np.diag(np.arange(d)).astype(complex), base.H_drives, base.drive_bounds) for i in range(M)]
+    psys = [pa.QuantumSystem(s.H_drift, s.H_drives, [b[1] for b in s.drive_bounds]) for s in osys]
+    comps = {"Ũ⃗%d" % (i + 1): Z[:, i * xd : (i + 1) * xd].T for i in range(M)}
+    o = M * xd
+    comps["Δt"], comps["t"] = Z[:, o][None], Z[:, o + 1][None]
+    comps["u"], comps["du"], comps["ddu"] = Z[:, o + 2 : o + 2 + m].T, Z[:, o + 2 + m : o + 2 + 2 * m].T, Z[:, o + 2 + 2 * m :].T
+    traj = pa.NamedTrajectory(comps, controls=("ddu", "Δt"), timestep="Δt")
+    assert np.array_equal(traj.datavec, Z.reshape(-1))
+    Bs = pa.BilinearIntegrator(psys, traj)
+    w = np.array([0.5, 0.3, 0.2])
+    Q = 100.0
+    Ru, Rdu, Rddu = 1e-2, np.linspace(0.5, 2.0, m), 3.0
+    names = [B.x_name for B in Bs]
+    for pw in (2, 0, 1):
+        J = pa.UnitaryInfidelityObjective(pa.EmbeddedOperator(Gs, sub, [3, 3]), names, traj, Q=Q, weights=w)
+        J = J + pa.QuadraticRegularizer("u", traj, Ru, pw) + pa.QuadraticRegularizer("du", traj, Rdu, pw) + pa.QuadraticRegularizer("ddu", traj, Rddu, pw)
+        val, grad = J.bind(Bs).value_and_gradient(traj)
+        regs = [(lay.u_off, m, Ru, pw), (lay.u_off + m, m, Rdu, pw), (lay.u_off + 2 * m, m, Rddu, pw)]
+        v_ref, g_ref = po.sampling_objective(Z, lay, [i * xd for i in range(M)], goal, w, Q, regs, subspace=sub)
+        assert abs(val - v_ref) < 1e-12 * max(1.0, abs(v_ref)), (pw, val, v_ref)
+        close(grad, g_ref.reshape(-1), 1e-11)
+    # plain (full-space) goal through the same entry point, unit weights; repeated calls are bitwise identical
+    Ufull = np.linalg.qr(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d)))[0]
+    J = pa.Objective([pa.UnitaryInfidelityObjective(Ufull, names, traj, Q=Q)]).bind(Bs)
+    val, grad = J.value_and_gradient(traj)
+    v_ref, g_ref = po.sampling_objective(Z, lay, [i * xd for i in range(M)], Ufull, np.ones(M), Q)
+    assert abs(val - v_ref) < 1e-12 * max(1.0, abs(v_ref))
+    close(grad, g_ref.reshape(-1), 1e-11)
+    val2, grad2 = J.value_and_gradient(traj)
+    assert val2 == val and np.array_equal(grad2, grad)
+    # multistart context: one objective value and one gradient per seed
+    Zs = [Z[:, : xd + 2 + 3 * m].copy() for _ in range(2)]
+    for q, Zq in enumerate(Zs):
+        Zq[:, xd:] = Z[:, M * xd :]
+        Zq[:, :xd] = Z[:, q * xd : (q + 1) * xd]
+    lay1 = po.Layout.smooth_pulse(d, m, N)
+    t1 = traj_from_Z(pa, Zs[0], lay1)
+    ms = pa.HipPadeMultistart(osys[0].G_drift, np.array(osys[0].G_drives), t1, 2)
+    J1 = (pa.UnitaryInfidelityObjective(pa.EmbeddedOperator(Gs, sub, [3, 3]), "Ũ⃗", t1, Q=Q) + pa.QuadraticRegularizer("u", t1, Ru)).bind(ms)
+    vals, grads = J1.value_and_gradient(np.stack(Zs))
+    for q, Zq in enumerate(Zs):
+        v_ref, g_ref = po.sampling_objective(Zq, lay1, [0], goal, [1.0], Q, [(lay1.u_off, m, Ru, 2)], subspace=sub)
+        assert abs(vals[q] - v_ref) < 1e-12 * max(1.0, abs(v_ref))
+        close(grads[q * lay1.z_dim * N : (q + 1) * lay1.z_dim * N], g_ref.reshape(-1), 1e-11)
+    ms.close()
+    for B in Bs:
+        B.close()
 
 
 @pytest.mark.parametrize("d,m,N", [(2, 2, 8), (5, 2, 6), (27, 6, 4)])
@@ -800,7 +946,8 @@ def test_general_order_ket_ensemble_and_integrator_interface():
     ZE = 0.3 * rng.standard_normal((7, layE.z_dim))
     ZE[:, layE.dt_off] = 0.1 + 0.1 * rng.random(7)
     trajE = traj_from_Z(pa, ZE, layE, n_members=M)
-    BE = pa.BilinearIntegrator([pa.QuantumSystem(s_.H_drift, s_.H_drives, [1.0, 1.0]) for s_ in systems], trajE, pade_order=6)
+    BEs = pa.BilinearIntegrator([pa.QuantumSystem(s_.H_drift, s_.H_drives, [1.0, 1.0]) for s_ in systems], trajE, pade_order=6)
+    BE = BEs[0].ensemble.fused
     delta, vals = BE.ctx.eval_jac(trajE.datavec)
     per_d, per_j = layE.x_dim * layE.K, po.jac_nnz_per_interval(layE) * layE.K
     for i, s_ in enumerate(systems):
@@ -859,11 +1006,13 @@ def test_rollout_interface_ensemble_ket_and_large_steps():
     ZE = 0.3 * rng.standard_normal((9, layE.z_dim))
     ZE[:, layE.dt_off] = 0.1 + 0.1 * rng.random(9)
     trajE = traj_from_Z(pa, ZE, layE, n_members=M)
-    BE = pa.BilinearIntegrator([pa.QuantumSystem(s_.H_drift, s_.H_drives, [1.0, 1.0]) for s_ in systems], trajE)
-    XE = pa.unitary_rollout(BE, trajE)
+    BEs = pa.BilinearIntegrator([pa.QuantumSystem(s_.H_drift, s_.H_drives, [1.0, 1.0]) for s_ in systems], trajE)
+    XE = pa.unitary_rollout(BEs[0].ensemble.fused, trajE)
     for i, s_ in enumerate(systems):
         close(XE[i].T, po.exact_rollout(ZE, layE, s_.G_drift, np.array(s_.G_drives), x_off=i * xd), 1e-11)
-    BE.close()
+        close(pa.unitary_rollout(BEs[i], trajE).T, po.exact_rollout(ZE, layE, s_.G_drift, np.array(s_.G_drives), x_off=i * xd), 1e-11)
+    for B_ in BEs:
+        B_.close()
     # ket
     d, m, N = 5, 2, 7
     n = 2 * d
