@@ -346,52 +346,68 @@ __global__ void pcl_objective_sum_kernel(const double *__restrict__ member, cons
 //     phi_k  = sum_b w_b c <lam_bk, delta_bk>           (c = 1/2 when lam = delta)
 //     g[k,l] = sum_b w_b <d delta_bk / d u_l, lam_bk>,  g[k,m] = sum_b w_b <d delta_bk / d dt, lam_bk>
 // i.e. J^T lam restricted to the SHARED variables (the only part of the Lagrangian gradient that needs other ranks).
-// One workgroup per interval (x trajectory in TRAJ mode, where nothing is shared and the sums run over one b);
-// wave w owns drive indices l = w, w+4, ..: a dot product over the member's tail block, summed over b in order.
-// out: [phi | g_u (K*m, k-major) | g_dt (K)] per output set; phi_k goes to scratch and is summed by pcl_merit_sum_kernel.
+// Two launches, fixed summation order (bitwise repeatable):
+//   pcl_merit_part_kernel  one workgroup per (interval, member); wave w owns the jobs l = w, w+8, .. (l < m: d/du_l, l = m:
+//                          d/ddt, l = m+1: <lam, delta>): one dot product over the member's tail block, 16-byte loads
+//   pcl_merit_sum_kernel   sums the members in order with their weights, then phi over the intervals in order
+// out: [phi | g_u (K*m, k-major) | g_dt (K)] per output set (one set; TRAJ mode: one per trajectory, nothing is shared).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pcl_merit_grad_kernel(const double *__restrict__ delta, const double *__restrict__ lam,
-                                                             const double *__restrict__ vals, const double *__restrict__ weights,
-                                                             double *__restrict__ out, double *__restrict__ phik, int batch, int K,
-                                                             int cols, int n, int m, long long jac_per, long long tail_off,
-                                                             int traj_mode) {
-    const int k = blockIdx.x, set = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const long long xd = (long long)n * cols;
-    const int b_lo = traj_mode ? set : 0, b_hi = traj_mode ? set + 1 : batch;
-    double *o = out + (long long)set * (1 + (long long)K * m + K);
-    for (int l = wave; l <= m + 1; l += 4) {  // l == m+1: the phi_k job
-        double tot = 0.0;
-        for (int b = b_lo; b < b_hi; ++b) {
-            const long long bk = (long long)b * K + k;
-            const double *dl = delta + bk * xd;
-            const double *lm = lam ? lam + bk * xd : dl;
-            const double *tail = vals + bk * jac_per + tail_off;
-            double s = 0.0;
-            if (l <= m) {
-                for (int c = 0; c < cols; ++c)
-                    for (int i = lane; i < n; i += 64) s += tail[((long long)c * (m + 1) + l) * n + i] * lm[c * n + i];
+__global__ __launch_bounds__(512) void pcl_merit_part_kernel(const double *__restrict__ delta, const double *__restrict__ lam,
+                                                             const double *__restrict__ vals, double *__restrict__ part, int K,
+                                                             int cols, int n, int m, long long jac_per, long long tail_off) {
+    const int k = blockIdx.x, b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long xd = (long long)n * cols, bk = (long long)b * K + k;
+    const double *dl = delta + bk * xd;
+    const double *lm = lam ? lam + bk * xd : dl;
+    const double *tail = vals + bk * jac_per + tail_off;
+    const bool pairs = (n & 1) == 0;  // 16-byte loads when every run of n doubles starts 16-byte aligned (n even)
+    for (int l = wave; l <= m + 1; l += 8) {
+        double s = 0.0;
+        if (l <= m) {
+            if (pairs) {
+                const int hn = n >> 1;
+                for (int e = lane; e < cols * hn; e += 64) {
+                    const int c = e / hn, i = 2 * (e - c * hn);
+                    const double2_t t = *reinterpret_cast<const double2_t *>(tail + ((long long)c * (m + 1) + l) * n + i);
+                    const double2_t v = *reinterpret_cast<const double2_t *>(lm + c * n + i);
+                    s += t[0] * v[0] + t[1] * v[1];
+                }
             } else {
-                for (long long e = lane; e < xd; e += 64) s += lm[e] * dl[e];
-                s *= lam ? 1.0 : 0.5;
+                for (int e = lane; e < cols * n; e += 64) {
+                    const int c = e / n, i = e - c * n;
+                    s += tail[((long long)c * (m + 1) + l) * n + i] * lm[c * n + i];
+                }
             }
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-            tot += (weights ? weights[b] : 1.0) * s;
+        } else {
+            for (long long e = lane; e < xd; e += 64) s += lm[e] * dl[e];
+            s *= lam ? 1.0 : 0.5;
         }
-        if (lane == 0) {
-            if (l < m)
-                o[1 + (long long)k * m + l] = tot;
-            else if (l == m)
-                o[1 + (long long)K * m + k] = tot;
-            else
-                phik[(long long)set * K + k] = tot;
-        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) part[bk * (m + 2) + l] = s;
     }
 }
-__global__ void pcl_merit_sum_kernel(const double *__restrict__ phik, double *__restrict__ out, int K, int m, int sets) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int s = 0; s < sets; ++s) {
+__global__ __launch_bounds__(256) void pcl_merit_sum_kernel(const double *__restrict__ part, const double *__restrict__ weights,
+                                                            double *__restrict__ out, double *__restrict__ phik, int batch, int K, int m,
+                                                            int traj_mode) {
+    const int set = blockIdx.x;  // TRAJ mode: one output set per trajectory; MEMBERS mode: one set, summed over the members
+    const int b_lo = traj_mode ? set : 0, b_hi = traj_mode ? set + 1 : batch;
+    double *o = out + (long long)set * (1 + (long long)K * m + K);
+    double *ph = phik + (long long)set * K;
+    for (int e = threadIdx.x; e < K * (m + 2); e += 256) {
+        const int k = e / (m + 2), l = e - k * (m + 2);
         double t = 0.0;
-        for (int k = 0; k < K; ++k) t += phik[(long long)s * K + k];
-        out[(long long)s * (1 + (long long)K * m + K)] = t;
+        for (int b = b_lo; b < b_hi; ++b) t += (weights ? weights[b] : 1.0) * part[((long long)b * K + k) * (m + 2) + l];
+        if (l < m)
+            o[1 + (long long)k * m + l] = t;
+        else if (l == m)
+            o[1 + (long long)K * m + k] = t;
+        else
+            ph[k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < K; ++k) t += ph[k];
+        o[0] = t;
     }
 }

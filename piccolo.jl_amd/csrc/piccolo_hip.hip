@@ -31,6 +31,7 @@
 #include "pcl_kernel_fused_v3.hpp"
 #include "pcl_kernels_hessian.hpp"
 #include "pcl_kernels_misc.hpp"
+#include "pcl_host_expand.hpp"
 
 // ------------------------------------------------------------------------------------------
 // Host side
@@ -75,6 +76,12 @@ struct pcl_ctx {
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dmu = nullptr, *ddelta = nullptr, *dvals = nullptr, *dhess = nullptr;
     // options
+    // host-pointer entry points: pinned staging + compact D2H + threaded expansion into the caller's array
+    pcl_host::Pool *pool = nullptr;
+    double *hZ = nullptr, *hcompact = nullptr, *hdelta = nullptr;  // pinned (hipHostMalloc)
+    double *dcomp_host = nullptr;                                    // device buffer of the compact values
+    hipEvent_t ev_chunk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t opt_host_threads = 0, opt_host_path = 0, opt_host_chunks = 4;
     int win_first = 0, win_count = 0;  // member window (pcl_set_member_window): the members / seeds the evaluator entry points cover
     int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_kernel = 0;  // 0 = auto: 3 where its specialised instance applies, else 1 / 2 by shape
     long long *ddbg = nullptr;
@@ -413,6 +420,13 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (ctx->dgoal) (void)hipFree(ctx->dgoal);
+    delete ctx->pool;
+    ctx->pool = nullptr;
+    for (double *q : {ctx->hZ, ctx->hcompact, ctx->hdelta})
+        if (q) (void)hipHostFree(q);
+    if (ctx->dcomp_host) (void)hipFree(ctx->dcomp_host);
+    for (hipEvent_t e : ctx->ev_chunk)
+        if (e) (void)hipEventDestroy(e);
     for (void *q : {(void *)ctx->dsub, (void *)ctx->dweights, (void *)ctx->dregs, (void *)ctx->dreg_R, (void *)ctx->dobj, (void *)ctx->dphik,
                     (void *)ctx->dgrad, (void *)ctx->dval})
         if (q) (void)hipFree(q);
@@ -1247,19 +1261,80 @@ static int ensure(pcl_ctx *ctx, double **buf, long long count) {
         if (rc_ != PCL_OK) return rc_; \
     } while (0)
 
+static int ensure_pinned(pcl_ctx *ctx, double **buf, long long count) {
+    if (*buf) return PCL_OK;
+    hipError_t e = hipHostMalloc((void **)buf, (size_t)count * sizeof(double), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx, PCL_ENOMEM, "hipHostMalloc(%lld doubles): %s", count, hipGetErrorString(e));
+    return PCL_OK;
+}
+static int host_threads(const pcl_ctx *ctx) {
+    if (ctx->opt_host_threads > 0) return (int)std::min<int64_t>(ctx->opt_host_threads, 256);
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hw ? hw / 2 : 8u, 48u));  // memory-write-bound: a fraction of the cores saturates it
+}
+
+// Host-pointer evaluation.  Two ways to deliver the Jacobian values into the caller's (pageable) array:
+//   full    the kernel writes the full triplet-order values in HBM and 132.8 MB (config 3) cross PCIe;
+//   compact the kernel writes only the unique tiles (12.7 MB), they cross PCIe into pinned staging in chunks of intervals,
+//           and the host's threads replicate them into the caller's array with streaming stores while the next chunk is
+//           in flight -- bound by host memory write bandwidth instead of by PCIe.  Default whenever blocks are replicated.
 static int host_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *vals) {
     if (!ctx) return PCL_EINVAL;
     if (!Z || (!delta && !vals)) return fail(ctx, PCL_EINVAL, "NULL pointer");
     ON_DEVICE(ctx);
-    const long long nv = jac_per_full(ctx) * ctx->win_count * ctx->K;
+    const long long nbk = (long long)ctx->win_count * ctx->K, nbk_all = (long long)ctx->desc.batch * ctx->K;
+    const long long nv = jac_per_full(ctx) * nbk;
+    const bool compact_path = vals && ctx->cols > 1 && ctx->opt_host_path != 1;
     TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
     TRY(ensure(ctx, &ctx->ddelta, n_rows_all(ctx)));
-    if (vals) TRY(ensure(ctx, &ctx->dvals, jac_per_full(ctx) * ctx->desc.batch * ctx->K));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dZ, Z, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    TRY(launch_fused(ctx, ctx->dZ, ctx->ddelta, vals ? ctx->dvals : nullptr, false));
-    if (delta) HIP_TRY(ctx, hipMemcpyAsync(delta, ctx->ddelta, n_rows(ctx) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (vals) HIP_TRY(ctx, hipMemcpyAsync(vals, ctx->dvals, nv * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    TRY(ensure_pinned(ctx, &ctx->hZ, z_len(ctx)));
+    memcpy(ctx->hZ, Z, (size_t)z_len(ctx) * sizeof(double));  // pinned source: the H2D copy is one asynchronous DMA
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dZ, ctx->hZ, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (!compact_path) {
+        if (vals) TRY(ensure(ctx, &ctx->dvals, jac_per_full(ctx) * nbk_all));
+        TRY(launch_fused(ctx, ctx->dZ, ctx->ddelta, vals ? ctx->dvals : nullptr, false));
+        if (delta) HIP_TRY(ctx, hipMemcpyAsync(delta, ctx->ddelta, n_rows(ctx) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (vals) HIP_TRY(ctx, hipMemcpyAsync(vals, ctx->dvals, nv * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return PCL_OK;
+    }
+    const long long cper = jac_per_compact(ctx), fper = jac_per_full(ctx);
+    TRY(ensure(ctx, &ctx->dcomp_host, cper * nbk_all));
+    TRY(ensure_pinned(ctx, &ctx->hcompact, cper * nbk_all));
+    TRY(ensure_pinned(ctx, &ctx->hdelta, n_rows_all(ctx)));
+    const int n_chunks = (int)std::max<long long>(1, std::min<long long>(std::min<int64_t>(ctx->opt_host_chunks, 8), nbk));
+    for (int c = 0; c < n_chunks; ++c)
+        if (!ctx->ev_chunk[c]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_chunk[c], hipEventDisableTiming));
+    TRY(launch_fused(ctx, ctx->dZ, ctx->ddelta, ctx->dcomp_host, true));
+    for (int c = 0; c < n_chunks; ++c) {
+        const long long lo = nbk * c / n_chunks, hi = nbk * (c + 1) / n_chunks;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->hcompact + lo * cper, ctx->dcomp_host + lo * cper, (size_t)((hi - lo) * cper) * sizeof(double),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[c], ctx->stream));
+    }
+    if (delta) HIP_TRY(ctx, hipMemcpyAsync(ctx->hdelta, ctx->ddelta, n_rows(ctx) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    const int want_threads = host_threads(ctx);
+    if (!ctx->pool || ctx->pool->size() != want_threads - 1) {
+        delete ctx->pool;
+        ctx->pool = new (std::nothrow) pcl_host::Pool(want_threads - 1);  // the calling thread is the last worker
+        if (!ctx->pool) return fail(ctx, PCL_ENOMEM, "thread pool");
+    }
+    const int cols = ctx->cols;
+    const long long nn = (long long)ctx->n * ctx->n, tail = ctx->x_dim * (ctx->desc.n_drives + 1);
+    const double *hc = ctx->hcompact;
+    ctx->pool->begin(2 * nbk, [=](long long job) {
+        const long long bk = job >> 1;
+        pcl_host::expand_interval(vals + bk * fper, hc + bk * cper, cols, nn, tail, (int)(job & 1));
+    });
+    int rc = PCL_OK;
+    for (int c = 0; c < n_chunks; ++c) {
+        if (rc == PCL_OK && hipEventSynchronize(ctx->ev_chunk[c]) != hipSuccess) rc = PCL_EHIP;
+        ctx->pool->publish(2 * (nbk * (c + 1) / n_chunks));  // (on an error the workers still run to completion, on stale bytes)
+    }
+    ctx->pool->wait();
+    if (rc != PCL_OK) return fail(ctx, PCL_EHIP, "hipEventSynchronize: %s", hipGetErrorString(hipGetLastError()));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (delta) memcpy(delta, ctx->hdelta, (size_t)n_rows(ctx) * sizeof(double));
     return PCL_OK;
 }
 extern "C" int pcl_eval(pcl_ctx *ctx, const double *Z, double *delta) {
@@ -1532,12 +1607,14 @@ extern "C" int pcl_merit_grad_dev(pcl_ctx *ctx, const double *delta, const doubl
     const pcl_desc &D = ctx->desc;
     const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
     const int sets = traj ? D.batch : 1;
-    if (!ctx->dphik) HIP_TRY(ctx, hipMalloc((void **)&ctx->dphik, (size_t)sets * ctx->K * sizeof(double)));
-    hipLaunchKernelGGL(pcl_merit_grad_kernel, dim3((unsigned)ctx->K, (unsigned)sets), dim3(256), 0, ctx->stream, delta, lam, vals,
-                       (const double *)ctx->dweights, out, ctx->dphik, D.batch, ctx->K, ctx->cols, ctx->n, D.n_drives, jac_per_full(ctx),
-                       2LL * ctx->cols * ctx->n * ctx->n, traj ? 1 : 0);
+    const int m = D.n_drives;
+    if (!ctx->dphik) HIP_TRY(ctx, hipMalloc((void **)&ctx->dphik, ((size_t)D.batch * ctx->K * (m + 2) + (size_t)sets * ctx->K) * sizeof(double)));
+    double *part = ctx->dphik, *phik = ctx->dphik + (size_t)D.batch * ctx->K * (m + 2);
+    hipLaunchKernelGGL(pcl_merit_part_kernel, dim3((unsigned)ctx->K, (unsigned)D.batch), dim3(512), 0, ctx->stream, delta, lam, vals, part,
+                       ctx->K, ctx->cols, ctx->n, m, jac_per_full(ctx), 2LL * ctx->cols * ctx->n * ctx->n);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(pcl_merit_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)ctx->dphik, out, ctx->K, D.n_drives, sets);
+    hipLaunchKernelGGL(pcl_merit_sum_kernel, dim3((unsigned)sets), dim3(256), 0, ctx->stream, (const double *)part,
+                       (const double *)ctx->dweights, out, phik, D.batch, ctx->K, m, traj ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
     return PCL_OK;
 }
@@ -1648,6 +1725,12 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_nt = v != 0;
     else if (!strcmp(key, "grid"))
         ctx->opt_grid = v;
+    else if (!strcmp(key, "host_threads"))  // host-pointer entry points: threads expanding the compact values (0 = auto)
+        ctx->opt_host_threads = v < 0 ? 0 : v;
+    else if (!strcmp(key, "host_path"))  // 0 auto | 1 full values over PCIe | 2 compact values + host expansion
+        ctx->opt_host_path = v < 0 || v > 2 ? 0 : v;
+    else if (!strcmp(key, "host_chunks"))  // interval chunks of the compact D2H copy that overlap with the expansion (1..8)
+        ctx->opt_host_chunks = v < 1 ? 1 : (v > 8 ? 8 : v);
     else if (!strcmp(key, "specialize"))  // 0: always the run-time-shape kernel instances
         ctx->opt_specialize = v != 0;
     else if (!strcmp(key, "jit"))  // 1 (default): compile the context's shape on first use when no static instance matches
@@ -1708,6 +1791,12 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
                  : choose_cols_per_slice(ctx, true);
     else if (!strcmp(key, "n_cu"))
         *v = ctx->n_cu;
+    else if (!strcmp(key, "host_threads"))
+        *v = host_threads(ctx);
+    else if (!strcmp(key, "host_path"))
+        *v = ctx->opt_host_path;
+    else if (!strcmp(key, "host_chunks"))
+        *v = ctx->opt_host_chunks;
     else if (!strcmp(key, "kernel_version"))
         *v = ctx->opt_kernel;
     else if (!strcmp(key, "last_kernel"))

@@ -1,15 +1,17 @@
-# HipPadeIntegrator.jl -- Julia-side glue of the drop-in: a `DirectTrajOpt.AbstractIntegrator`
-# whose arithmetic runs in libpiccolo_hip.so (HIP kernels on an MI355X) through `ccall`.
+# HipPadeIntegrator.jl -- Julia-side glue of the drop-in: `DirectTrajOpt.AbstractIntegrator`s whose arithmetic runs in
+# libpiccolo_hip.so (HIP kernels on an MI355X) through `ccall`.
 #
-# STATUS: written against the interface Piccolo.jl v2.0.2 *uses* (call sites cited below); the
-# abstract type and the generic functions live in the un-vendored DirectTrajOpt.jl (compat 0.9.5 / 0.10)
-# and there is no Julia in the build container, so this file has NOT been executed.  All logic is in
-# the C library (include/piccolo_hip.h); this file only marshals arguments.  See INTEGRATION.md.
+# STATUS: written against the interface Piccolo.jl v2.0.2 *uses* (call sites cited below).  The abstract type and the
+# generic functions live in the un-vendored DirectTrajOpt.jl (compat 0.9.5 / 0.10) and there is no Julia in the build
+# container, so this file has NOT been executed.  `selftest.jl` (next to this file) is the script a maintainer runs first:
+# it checks this glue against DirectTrajOpt's own `test_integrator` and against `BilinearIntegrator`, and lists the
+# DirectTrajOpt method names the glue had to guess (section "names to be matched" below).  All arithmetic is in the C
+# library (include/piccolo_hip.h); this file only marshals arguments.  See INTEGRATION.md.
 #
 #   plug-in points in the reference:
 #     SmoothPulseProblem(qtraj, N; integrator = HipPadeIntegrator(qtraj, N))
 #         src/control/templates/smooth_pulse_problem.jl:123,213-233
-#     SamplingProblem(qcp, systems; integrator = (sq, N) -> HipPadeIntegrator(sq, N))
+#     SamplingProblem(qcp, systems; integrator = (sq, N) -> HipPadeIntegrator(sq, N))     # returns a Vector, one per member
 #         src/control/templates/sampling_problem.jl:190-237,292
 #     Specs.register_integrator!(:hip_pade, RegistryEntry(factory = (qtraj, N; alg) -> HipPadeIntegrator(qtraj, N)))
 #         src/specs/registries.jl:82-86,112,119 ; src/specs/materialize.jl:216-222
@@ -19,7 +21,9 @@ using LinearAlgebra, SparseArrays
 using NamedTrajectories
 using DirectTrajOpt
 import DirectTrajOpt: AbstractIntegrator
-using Piccolo: get_system, state_name, state_names, drive_name, UnitaryTrajectory, SamplingTrajectory
+using Piccolo: get_system, state_name, state_names, drive_name, sampling_member_states,
+               UnitaryTrajectory, KetTrajectory, MultiKetTrajectory, DensityTrajectory, SamplingTrajectory,
+               compact_lindbladian_generators
 
 const LIB = get(ENV, "PICCOLO_HIP_LIB", "libpiccolo_hip.so")
 
@@ -32,132 +36,266 @@ struct PclDesc
     G0::Ptr{Float64}; Gj::Ptr{Float64}; x_offs::Ptr{Int32}
 end
 
-check(ctx, rc) = rc == 0 || error("libpiccolo_hip: ",
-    unsafe_string(ccall((:pcl_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx)), " (code $rc)")
+_lasterr(ctx) = unsafe_string(ccall((:pcl_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))
+check(ctx, rc) = rc == 0 || error("libpiccolo_hip: ", _lasterr(ctx), " (code $rc)")
+
+# One `pcl_ctx` (one GPU, one stream).  A SamplingTrajectory's M member integrators share ONE batched context: the first
+# member asked about a trajectory launches the fused kernels for ALL members, the others slice their rows out of the
+# cached result (the cache key is the trajectory buffer itself, compared by value, so a stale result is never served).
+mutable struct PclCore
+    ctx::Ptr{Cvoid}
+    n_members::Int
+    x_dim::Int                      # per member
+    rows_per::Int                   # x_dim * (N-1)
+    jac_per::Int                    # Jacobian values per member
+    hess_per::Int
+    z::Vector{Float64}              # trajectory buffer the cached results belong to
+    δ::Vector{Float64}              # all members, member-major
+    vals::Vector{Float64}
+    have_δ::Bool
+    have_vals::Bool
+    launches::Int
+end
+
+function _destroy!(c::PclCore)
+    c.ctx == C_NULL || ccall((:pcl_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.ctx)
+    c.ctx = C_NULL
+    return nothing
+end
 
 mutable struct HipPadeIntegrator <: AbstractIntegrator
-    ctx::Ptr{Cvoid}
-    x_name::Symbol            # first (or only) state component
+    core::PclCore
+    member::Int               # 1-based member of the core's ensemble (1 for a single-state integrator)
+    x_name::Symbol
     x_names::Vector{Symbol}
     u_name::Symbol
     x_dim::Int
-    dim::Int                  # == x_dim * (N - 1) * length(x_names)        [REF integrators.jl:309]
-    jac_rows::Vector{Int32}   # 1-based, in value order (never assumed, always queried)
+    dim::Int                  # == x_dim * (N - 1)                                    [REF integrators.jl:307-309]
+    jac_rows::Vector{Int32}   # 1-based, in value order, numbered inside this integrator's block (never assumed, always queried)
     jac_cols::Vector{Int32}
     hess_rows::Vector{Int32}
     hess_cols::Vector{Int32}
     n_vars::Int
+    G0::Matrix{Float64}       # this member's generators (for `f`)
+    Gj::Vector{Matrix{Float64}}
+    state_cols::Int
+    pade_order::Int
+    fcore::Union{Nothing,PclCore}   # lazily created 2-knot context behind `B.f`
 end
 
-function _create(G0s::Vector{<:AbstractMatrix}, Gjs::Vector{<:AbstractMatrix}, traj::NamedTrajectory,
-                 x_names::Vector{Symbol}, u_name::Symbol; device::Integer = 0, pade_order::Integer = 4,
-                 state_cols::Integer = 0)
+function _create_core(G0s::Vector{Matrix{Float64}}, Gjs::Vector{Matrix{Float64}}, N::Int, z_dim::Int, u_off::Int, dt_off::Int,
+                      x_offs::Vector{Int32}, global_dim::Int; device::Integer = 0, pade_order::Integer = 4, state_cols::Integer = 0)
     # state_cols: 0 unitary (n = 2d), 1 ket, -1 = PCL_STATE_VECTOR (general n x n generator on one real column, d := n)
     n = size(G0s[1], 1); d = state_cols == -1 ? n : n ÷ 2; m = length(Gjs)
-    G0 = reduce(vcat, [vec(Matrix{Float64}(G)) for G in G0s])          # column-major, one block per member
-    Gj = m == 0 ? zeros(1) : reduce(vcat, [vec(Matrix{Float64}(G)) for G in Gjs])
-    x_offs = Int32[traj.components[nm][1] - 1 for nm in x_names]
+    G0 = reduce(vcat, [vec(G) for G in G0s])                       # column-major, one block per member
+    Gj = m == 0 ? zeros(1) : reduce(vcat, [vec(G) for G in Gjs])
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve G0 Gj x_offs begin
-        desc = PclDesc(sizeof(PclDesc), d, m, traj.N, traj.dim,
-                       traj.components[u_name][1] - 1, traj.components[traj.timestep][1] - 1,
-                       length(x_names), 0 #= PCL_BATCH_MEMBERS =#, pade_order #= 2, 4, 6, 8 or 10 =#, device, 1 #= 1-based =#,
-                       length(G0s) > 1 ? 1 : 0, state_cols, traj.global_dim,
+        desc = PclDesc(sizeof(PclDesc), d, m, N, z_dim, u_off, dt_off,
+                       length(x_offs), 0 #= PCL_BATCH_MEMBERS =#, pade_order #= 2, 4, 6, 8 or 10 =#, device, 1 #= 1-based =#,
+                       length(G0s) > 1 ? 1 : 0, state_cols, global_dim,
                        pointer(G0), pointer(Gj), pointer(x_offs))
         rc = ccall((:pcl_create, LIB), Cint, (Ref{PclDesc}, Ref{Ptr{Cvoid}}), desc, ctx)
-        rc == 0 || error("pcl_create: ", unsafe_string(ccall((:pcl_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+        rc == 0 || error("pcl_create: ", _lasterr(C_NULL))
     end
     c = ctx[]
-    nnz = Ref{Int64}(0); per = Ref{Int64}(0); xd = Ref{Int64}(0); nr = Ref{Int64}(0); ncol = Ref{Int64}(0)
+    xd = Ref{Int64}(0); nr = Ref{Int64}(0); ncol = Ref{Int64}(0); nnz = Ref{Int64}(0); per = Ref{Int64}(0)
     check(c, ccall((:pcl_constraint_dim, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}), c, xd, nr, ncol))
+    M = length(x_offs)
     check(c, ccall((:pcl_jac_nnz, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), c, nnz, per))
-    jr = Vector{Int32}(undef, nnz[]); jc = similar(jr)
-    check(c, ccall((:pcl_jac_structure, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}), c, jr, jc))
+    jac_per = Int(nnz[]) ÷ M
     check(c, ccall((:pcl_hess_nnz, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), c, nnz, per))
-    hr = Vector{Int32}(undef, nnz[]); hc = similar(hr)
-    check(c, ccall((:pcl_hess_structure, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}), c, hr, hc))
-    B = HipPadeIntegrator(c, x_names[1], x_names, u_name, Int(xd[]) * length(x_names), Int(nr[]), jr, jc, hr, hc, Int(ncol[]))
-    finalizer(b -> (b.ctx == C_NULL || ccall((:pcl_destroy, LIB), Cvoid, (Ptr{Cvoid},), b.ctx); b.ctx = C_NULL), B)
-    return B
+    core = PclCore(c, M, Int(xd[]), Int(nr[]) ÷ M, jac_per, Int(nnz[]) ÷ M, Float64[], Float64[], Float64[], false, false, 0)
+    finalizer(_destroy!, core)
+    return core, Int(ncol[])
+end
+
+_window!(core::PclCore, first0::Integer, count::Integer) =
+    check(core.ctx, ccall((:pcl_set_member_window, LIB), Cint, (Ptr{Cvoid}, Int32, Int32), core.ctx, first0, count))
+
+# structure of ONE member (rows numbered inside the member's block, columns = global variable indices), 1-based
+function _member_structure(core::PclCore, member::Int)
+    _window!(core, member - 1, 1)
+    jr = Vector{Int32}(undef, core.jac_per); jc = similar(jr)
+    check(core.ctx, ccall((:pcl_jac_structure, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}), core.ctx, jr, jc))
+    hr = Vector{Int32}(undef, core.hess_per); hc = similar(hr)
+    check(core.ctx, ccall((:pcl_hess_structure, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}), core.ctx, hr, hc))
+    _window!(core, 0, core.n_members)
+    return jr, jc, hr, hc
+end
+
+function _generators(sys)
+    sys.time_dependent && error("HipPadeIntegrator: time-dependent systems use TimeDependentBilinearIntegrator")
+    m = sys.n_drives
+    e(j) = (u = zeros(m); u[j] = 1.0; u)
+    G0 = Matrix{Float64}(sys.G(zeros(m), 0.0))
+    Gj = [Matrix{Float64}(sys.G(e(j), 0.0)) - G0 for j in 1:m]      # linear drives: G(u) = G0 + sum u_j G_j
+    return G0, Gj
+end
+
+function _integrators(G0s, Gj, traj::NamedTrajectory, names::Vector{Symbol}, u_name::Symbol;
+                      state_cols::Integer = 0, pade_order::Integer = 4, kwargs...)
+    x_offs = Int32[traj.components[nm][1] - 1 for nm in names]
+    core, n_vars = _create_core(G0s, Gj, traj.N, traj.dim, traj.components[u_name][1] - 1,
+                                traj.components[traj.timestep][1] - 1, x_offs, traj.global_dim;
+                                state_cols = state_cols, pade_order = pade_order, kwargs...)
+    Bs = HipPadeIntegrator[]
+    for (i, nm) in enumerate(names)
+        jr, jc, hr, hc = _member_structure(core, i)
+        push!(Bs, HipPadeIntegrator(core, i, nm, [nm], u_name, core.x_dim, core.rows_per, jr, jc, hr, hc, n_vars,
+                                    G0s[length(G0s) > 1 ? i : 1], Gj, state_cols, pade_order, nothing))
+    end
+    return Bs
 end
 
 # BilinearIntegrator(qtraj::UnitaryTrajectory, N)                              [REF src/control/integrators.jl:35-51]
 function HipPadeIntegrator(qtraj::UnitaryTrajectory, N::Int; kwargs...)
-    sys = get_system(qtraj)
-    sys.time_dependent && error("HipPadeIntegrator: time-dependent systems use TimeDependentBilinearIntegrator")
-    traj = NamedTrajectory(qtraj, N)
-    m = sys.n_drives
-    e(j) = (u = zeros(m); u[j] = 1.0; u)
-    G0 = Matrix(sys.G(zeros(m), 0.0))
-    Gj = [Matrix(sys.G(e(j), 0.0)) - G0 for j in 1:m]          # linear drives: G(u) = G0 + sum u_j G_j
-    return _create([G0], Gj, traj, [state_name(qtraj)], drive_name(qtraj); kwargs...)
-end
-
-# BilinearIntegrator(qtraj::SamplingTrajectory, N): one member per system, shared controls [REF integrators.jl:134-162]
-function HipPadeIntegrator(qtraj::SamplingTrajectory, N::Int; kwargs...)
-    traj = NamedTrajectory(qtraj, N)
-    m = qtraj.systems[1].n_drives
-    e(j) = (u = zeros(m); u[j] = 1.0; u)
-    G0s = [Matrix(s.G(zeros(m), 0.0)) for s in qtraj.systems]
-    Gj = [Matrix(qtraj.systems[1].G(e(j), 0.0)) - G0s[1] for j in 1:m]
-    return _create(G0s, Gj, traj, state_names(qtraj), drive_name(qtraj); kwargs...)
+    G0, Gj = _generators(get_system(qtraj))
+    return only(_integrators([G0], Gj, NamedTrajectory(qtraj, N), [state_name(qtraj)], drive_name(qtraj); kwargs...))
 end
 
 # BilinearIntegrator(qtraj::KetTrajectory, N) [REF integrators.jl:58-74]
 function HipPadeIntegrator(qtraj::KetTrajectory, N::Int; kwargs...)
-    sys = get_system(qtraj); traj = NamedTrajectory(qtraj, N); m = sys.n_drives
-    e(j) = (u = zeros(m); u[j] = 1.0; u)
-    G0 = Matrix(sys.G(zeros(m), 0.0))
-    Gj = [Matrix(sys.G(e(j), 0.0)) - G0 for j in 1:m]
-    return _create([G0], Gj, traj, [state_name(qtraj)], drive_name(qtraj); state_cols = 1, kwargs...)
+    G0, Gj = _generators(get_system(qtraj))
+    return only(_integrators([G0], Gj, NamedTrajectory(qtraj, N), [state_name(qtraj)], drive_name(qtraj); state_cols = 1, kwargs...))
+end
+
+# BilinearIntegrator(qtraj::MultiKetTrajectory, N) -> Vector, one per ket, all under the same system [REF integrators.jl:103-117]
+function HipPadeIntegrator(qtraj::MultiKetTrajectory, N::Int; kwargs...)
+    G0, Gj = _generators(get_system(qtraj))
+    return _integrators([G0], Gj, NamedTrajectory(qtraj, N), collect(state_names(qtraj)), drive_name(qtraj); state_cols = 1, kwargs...)
 end
 
 # BilinearIntegrator(qtraj::DensityTrajectory, N) [REF integrators.jl:82-95]: compact Lindbladian generators, linear
 # drives and constant dissipation rates (compact_lindbladian_generators folds the dissipators into the drift)
 function HipPadeIntegrator(qtraj::DensityTrajectory, N::Int; kwargs...)
-    sys = get_system(qtraj); traj = NamedTrajectory(qtraj, N)
-    Gc_drift, Gc_drives = compact_lindbladian_generators(sys)
-    return _create([Matrix(Gc_drift)], [Matrix(G) for G in Gc_drives], traj, [state_name(qtraj)], drive_name(qtraj);
-                   state_cols = -1, kwargs...)
+    Gc_drift, Gc_drives = compact_lindbladian_generators(get_system(qtraj))
+    return only(_integrators([Matrix{Float64}(Gc_drift)], [Matrix{Float64}(G) for G in Gc_drives], NamedTrajectory(qtraj, N),
+                             [state_name(qtraj)], drive_name(qtraj); state_cols = -1, kwargs...))
 end
 
-_z(traj::NamedTrajectory) = traj.datavec    # knot-major flat buffer, passed as is
+# BilinearIntegrator(qtraj::SamplingTrajectory, N) -> Vector{<:AbstractIntegrator}, ONE PER MEMBER, in member order
+# [REF integrators.jl:134-146]; SamplingProblem rejects anything else [REF sampling_problem.jl:195-223].
+# Members that share the drive generators (perturbed drifts: the robust-control use) evaluate through one batched
+# context; members whose drive generators differ too (each member uses its full sys.G, [REF integrators.jl:149-162])
+# get a context each.
+function HipPadeIntegrator(qtraj::SamplingTrajectory, N::Int; kwargs...)
+    base = qtraj.base_trajectory
+    base isa UnitaryTrajectory || base isa KetTrajectory ||
+        error("HipPadeIntegrator(::SamplingTrajectory): unitary and ket bases are implemented (got $(typeof(base)))")
+    sc = base isa KetTrajectory ? 1 : 0
+    traj = NamedTrajectory(qtraj, N)
+    names = collect(Symbol, sampling_member_states(qtraj))
+    gens = [_generators(s) for s in qtraj.systems]
+    G0s = [g[1] for g in gens]
+    u = drive_name(qtraj)
+    if all(g -> g[2] == gens[1][2], gens)       # exact equality: the same drive Hamiltonians in every member
+        return _integrators(G0s, gens[1][2], traj, names, u; state_cols = sc, kwargs...)
+    end
+    return [only(_integrators([G0s[i]], gens[i][2], traj, [names[i]], u; state_cols = sc, kwargs...)) for i in eachindex(names)]
+end
+
+# ---- cached fused evaluation -------------------------------------------------------------------------------------
+function _fresh!(core::PclCore, z::AbstractVector{Float64})
+    if length(core.z) != length(z) || core.z != z
+        core.z = copy(z)
+        core.have_δ = core.have_vals = false
+    end
+    return core.z
+end
+
+function _all_δ!(core::PclCore, z)
+    zc = _fresh!(core, z)
+    if !core.have_δ
+        length(core.δ) == core.rows_per * core.n_members || (core.δ = Vector{Float64}(undef, core.rows_per * core.n_members))
+        δ = core.δ
+        GC.@preserve zc δ check(core.ctx, ccall((:pcl_eval, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), core.ctx, zc, δ))
+        core.have_δ = true; core.launches += 1
+    end
+    return core.δ
+end
+
+function _all_vals!(core::PclCore, z)
+    zc = _fresh!(core, z)
+    if !core.have_vals
+        length(core.δ) == core.rows_per * core.n_members || (core.δ = Vector{Float64}(undef, core.rows_per * core.n_members))
+        length(core.vals) == core.jac_per * core.n_members || (core.vals = Vector{Float64}(undef, core.jac_per * core.n_members))
+        δ = core.δ; v = core.vals
+        GC.@preserve zc δ v check(core.ctx, ccall((:pcl_eval_jac, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), core.ctx, zc, δ, v))
+        core.have_δ = core.have_vals = true; core.launches += 1
+    end
+    return core.vals
+end
+
+_core(B::HipPadeIntegrator) = getfield(B, :core)
+_rows(B::HipPadeIntegrator) = ((getfield(B, :member) - 1) * _core(B).rows_per + 1):(getfield(B, :member) * _core(B).rows_per)
+_jrng(B::HipPadeIntegrator) = ((getfield(B, :member) - 1) * _core(B).jac_per + 1):(getfield(B, :member) * _core(B).jac_per)
 
 # evaluate!(delta, B, traj)                                                   [REF integrators.jl:311,777]
 function DirectTrajOpt.evaluate!(δ::AbstractVector{Float64}, B::HipPadeIntegrator, traj::NamedTrajectory)
-    length(δ) == B.dim || throw(DimensionMismatch("δ has length $(length(δ)), integrator dim is $(B.dim)"))
-    z = _z(traj)
-    GC.@preserve z δ check(B.ctx, ccall((:pcl_eval, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), B.ctx, z, δ))
+    length(δ) == getfield(B, :dim) || throw(DimensionMismatch("δ has length $(length(δ)), integrator dim is $(getfield(B, :dim))"))
+    copyto!(δ, view(_all_δ!(_core(B), traj.datavec), _rows(B)))
     return δ
 end
 
 # eval_jacobian(B, traj) -> sparse (B.dim, traj.dim*traj.N + traj.global_dim)  [REF integrators.jl:780-783]
 function DirectTrajOpt.eval_jacobian(B::HipPadeIntegrator, traj::NamedTrajectory)
-    vals = Vector{Float64}(undef, length(B.jac_rows)); z = _z(traj)
-    GC.@preserve z vals check(B.ctx, ccall((:pcl_jac, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), B.ctx, z, vals))
-    return sparse(B.jac_rows, B.jac_cols, vals, B.dim, B.n_vars)
+    vals = _all_vals!(_core(B), traj.datavec)[_jrng(B)]
+    return sparse(getfield(B, :jac_rows), getfield(B, :jac_cols), vals, getfield(B, :dim), getfield(B, :n_vars))
 end
 
-# what DirectTrajOpt's MOI evaluator needs per IPM iteration (names to be matched to the installed DTO version):
-jacobian_structure(B::HipPadeIntegrator) = collect(zip(Int.(B.jac_rows), Int.(B.jac_cols)))
-hessian_structure(B::HipPadeIntegrator) = collect(zip(Int.(B.hess_rows), Int.(B.hess_cols)))
+# ---- names to be matched to the installed DirectTrajOpt version (selftest.jl prints the candidates) ------------------
+# What DirectTrajOpt's MOI evaluator needs per IPM iteration, in the shapes this library produces them: triplet
+# structure queried once, values in that order.
+jacobian_structure(B::HipPadeIntegrator) = collect(zip(Int.(getfield(B, :jac_rows)), Int.(getfield(B, :jac_cols))))
+hessian_structure(B::HipPadeIntegrator) = collect(zip(Int.(getfield(B, :hess_rows)), Int.(getfield(B, :hess_cols))))
 
-function eval_constraint_and_jacobian!(δ::Vector{Float64}, vals::Vector{Float64}, B::HipPadeIntegrator, z::Vector{Float64})
-    GC.@preserve z δ vals check(B.ctx, ccall((:pcl_eval_jac, LIB), Cint,
-        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), B.ctx, z, δ, vals))
+function eval_constraint_and_jacobian!(δ::AbstractVector{Float64}, vals::AbstractVector{Float64}, B::HipPadeIntegrator, z::Vector{Float64})
+    v = _all_vals!(_core(B), z)
+    copyto!(vals, view(v, _jrng(B)))
+    copyto!(δ, view(_core(B).δ, _rows(B)))
     return nothing
 end
 
+# Hessian of the Lagrangian of THIS integrator's rows: μ is the block's multiplier slice (length B.dim); runs on a
+# one-member window of the shared context (Pade order 4)
 function eval_hessian_of_lagrangian!(vals::Vector{Float64}, B::HipPadeIntegrator, z::Vector{Float64}, μ::Vector{Float64})
-    GC.@preserve z μ vals check(B.ctx, ccall((:pcl_hess, LIB), Cint,
-        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), B.ctx, z, μ, vals))
+    core = _core(B)
+    length(μ) == getfield(B, :dim) || throw(DimensionMismatch("μ has length $(length(μ)), integrator dim is $(getfield(B, :dim))"))
+    length(vals) == core.hess_per || throw(DimensionMismatch("vals has length $(length(vals)), expected $(core.hess_per)"))
+    _window!(core, getfield(B, :member) - 1, 1)
+    try
+        GC.@preserve z μ vals check(core.ctx, ccall((:pcl_hess, LIB), Cint,
+            (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), core.ctx, z, μ, vals))
+    finally
+        _window!(core, 0, core.n_members)
+    end
     return nothing
 end
 
-# B.f(x_next, x, u, Δt): scalar form used by the reference's cross-integrator test [REF integrators.jl:518-525]
+# ---- B.f(x_next, x, u, Δt): the scalar one-interval form the reference reads [REF integrators.jl:518-525,552;
+#      src/control/display/inspect.jl:630-636] -- a cached 2-knot context with layout [x | Δt | u] -----------------------
+function _f(B::HipPadeIntegrator, x_next::AbstractVector, x::AbstractVector, u::AbstractVector, Δt::Real)
+    xd = getfield(B, :x_dim); Gj = getfield(B, :Gj); m = length(Gj)
+    fc = getfield(B, :fcore)
+    if fc === nothing
+        fc, _ = _create_core([getfield(B, :G0)], Gj, 2, xd + 1 + m, xd + 1, xd, Int32[0], 0;
+                             state_cols = getfield(B, :state_cols), pade_order = getfield(B, :pade_order))
+        setfield!(B, :fcore, fc)
+    end
+    z = zeros(2 * (xd + 1 + m))
+    z[1:xd] .= x; z[xd+1] = Δt; z[(xd+2):(xd+1+m)] .= u[1:m]
+    z[(xd+1+m+1):(xd+1+m+xd)] .= x_next
+    δ = Vector{Float64}(undef, xd)
+    GC.@preserve z δ check(fc.ctx, ccall((:pcl_eval, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), fc.ctx, z, δ))
+    return δ
+end
+
 function Base.getproperty(B::HipPadeIntegrator, s::Symbol)
-    s === :f || return getfield(B, s)
-    return (x_next, x, u, Δt) -> error("HipPadeIntegrator.f: build a 2-knot trajectory and call evaluate! (see INTEGRATION.md)")
+    s === :f && return (x_next, x, u, Δt) -> _f(B, x_next, x, u, Δt)
+    s === :ctx && return getfield(B, :core).ctx
+    return getfield(B, s)
 end
 
 export HipPadeIntegrator

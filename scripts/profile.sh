@@ -4,7 +4,7 @@
 # Usage: scripts/profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:-"--steps 30 --warmup 5 --no-cpu-baseline --no-single --no-extras"}
+ARGS=${@:-"--steps 30 --warmup 5 --no-cpu-baseline --no-shares --no-extras"}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -1395,3 +1395,38 @@ def test_runtime_compiled_shape_instances():
     c2.eval_jac(np.stack(Zs))
     assert c2.get_option("last_kernel") == 32 and c2.get_option("jit_compiles") == n0 + 2
     c2.close()
+
+
+def test_host_delivery_paths_agree_bitwise():
+    """pcl_eval_jac / pcl_jac on host buffers: the compact-over-PCIe + threaded host expansion path (default) and the
+    full-values-over-PCIe path deliver bit-identical arrays, for any thread count / chunk count, single trajectory,
+    multistart batch and a member window; odd interval counts make half the destination blocks 16-byte (not 32-byte)
+    aligned, which exercises the streaming-store head/tail handling."""
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    Bn, N = 3, 6
+    Zs = []
+    for s in range(Bn):
+        Z, lay = po.synthetic_trajectory(so, N, seed=900 + s)
+        Zs.append(Z)
+    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn)
+    c = ms.ctx
+    c.set_option("host_path", 1)
+    d_full, v_full = c.eval_jac(np.stack(Zs))
+    refs = [ref_lib.eval_jac(Z, lay, G0, Gj) for Z in Zs]
+    close(v_full, np.concatenate([r[1].reshape(-1) for r in refs]))
+    for threads, chunks in ((0, 4), (1, 1), (2, 8), (3, 3), (7, 2), (64, 8)):
+        c.set_option("host_path", 2)
+        c.set_option("host_threads", threads)
+        c.set_option("host_chunks", chunks)
+        for rep in range(3):
+            v = np.full(c.jac_nnz + 3, np.nan)[1:-2]  # deliberately 8-byte (not 32-byte) aligned destination
+            d = np.empty(c.n_rows)
+            c.eval_jac(np.stack(Zs), d, v)
+            assert np.array_equal(v, v_full) and np.array_equal(d, d_full), (threads, chunks, rep)
+        assert np.array_equal(c.jac(np.stack(Zs)), v_full)
+    c.set_member_window(1, 2)
+    per = c.jac_per * lay.K
+    assert np.array_equal(c.jac(np.stack(Zs)), v_full[per:])
+    c.set_member_window(0, Bn)
+    ms.close()
