@@ -43,6 +43,7 @@ struct KParams {
     const double *ug0;    // [n_upos] drift value at each union-pattern entry (first / shared drift)
     double *hpart;        // Hessian v2: per (b,k,slice) partial scalar entries
     unsigned int *hcnt;   // Hessian v2: per (b,k) arrival counter (self-resetting)
+    int prof;        // builds with -DPCL_PROFILE only: experiment flags (option profile_flags); 0 otherwise
     long long *dbg;  // cycle stamps of workgroup 0 / matrix wave 0 (builds with -DPCL_PROFILE only; NULL otherwise)
     int ncw;      // v3: state columns per matrix-wave chunk ((2+m)*ncw <= 16)
     int tab_lds;  // v3: union / ELL tables staged in LDS

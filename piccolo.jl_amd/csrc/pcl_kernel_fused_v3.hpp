@@ -174,6 +174,10 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                 }
         }
 
+        // per-member drift: which member's drift the two G buffers (off the union pattern) and the union table t_ung0 hold.
+        // A workgroup's consecutive items almost always belong to the same member (contiguous column ranges), so the
+        // drift tile is rewritten -- from memory, by every building wave -- only when the member changes.
+        int drift_in_buf0 = -1, drift_in_buf1 = -1, drift_in_tab = -1;
         // G(u) on the union pattern + this wave's share of the G^2 tiles, for item `it`, into buffer `buf`
         auto build = [&](int it, int buf, double u_lane) {
             int c0_, nce_, k, b;
@@ -183,15 +187,48 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             if (lane <= m) usn[lane] = u_lane;  // every wave: identical values
             wave_lds_sync();
             const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
-            if (p.g0_batch_stride)  // per-member drift: the whole tile changes with b.  Union positions are skipped: every
-                                    // position only ever receives its final value, so the four building waves (which write
-                                    // identical data and then read all of G for their G^2 tiles without a workgroup barrier)
-                                    // cannot observe each other's intermediate state
-                for (int e = lane; e < nn; e += 64)
-                    if (p.umap[e] < 0) G[(e % n) + LD * (e / n)] = G0b[e];
+            if (p.g0_batch_stride) {
+                // per-member drift: the whole tile changes with b.  Union positions are skipped: every position only ever
+                // receives its final value, so the four building waves (which write identical data and then read all of G
+                // for their G^2 tiles without a workgroup barrier) cannot observe each other's intermediate state
+                int &have = buf ? drift_in_buf1 : drift_in_buf0;
+                if (have != b) {  // eight independent loads in flight per lane (the loop is latency-, not bandwidth-bound)
+                    for (int e0 = lane; e0 < nn; e0 += 64 * 8) {
+                        double v[8];
+                        int um[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int e = e0 + 64 * j;
+                            um[j] = e < nn ? p.umap[e] : 0;
+                            v[j] = e < nn ? G0b[e] : 0.0;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int e = e0 + 64 * j;
+                            if (um[j] < 0) G[(e % n) + LD * (e / n)] = v[j];
+                        }
+                    }
+                    have = b;
+                }
+                if (p.tab_lds && drift_in_tab != b) {  // (every building wave writes the same values)
+                    for (int q0 = lane; q0 < n_un; q0 += 64 * 4) {
+                        int ps[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ps[j] = q0 + 64 * j < n_un ? p.upos[q0 + 64 * j] : 0;
+                        double v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = G0b[ps[j]];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (q0 + 64 * j < n_un) t_ung0[q0 + 64 * j] = v[j];
+                    }
+                    drift_in_tab = b;
+                    wave_lds_sync();
+                }
+            }
             if (p.tab_lds) {
                 for (int q = lane; q < n_un; q += 64) {
-                    double g = p.g0_batch_stride ? G0b[p.upos[q]] : t_ung0[q];
+                    double g = t_ung0[q];
                     for (int w = 0; w < uw; ++w) g += usn[t_unl[q * uw + w]] * t_unv[q * uw + w];
                     G[t_uni[q]] = g;
                 }

@@ -322,21 +322,23 @@ __global__ __launch_bounds__(256) void pcl_regularizer_kernel(const double *__re
     if (tid == 0) regval[(long long)tb * N + k] = val;
 }
 
-// value[0] = sum_b member[b] + sum_k regval[k]   (MEMBERS), value[b] = member[b] + sum_k regval[b][k]   (TRAJ): fixed order
-__global__ void pcl_objective_sum_kernel(const double *__restrict__ member, const double *__restrict__ regval, double *__restrict__ value,
-                                         int batch, int N, int traj_mode) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// value[0] = sum_b member[b] + sum_k regval[k]   (MEMBERS), value[b] = member[b] + sum_k regval[b][k]   (TRAJ).
+// One wave per output; fixed summation order (lane-strided partial sums, then a shuffle tree): bitwise repeatable.
+__device__ __forceinline__ double wave_sum_strided(const double *__restrict__ v, int count) {
+    double s = 0.0;
+    for (int i = threadIdx.x & 63; i < count; i += 64) s += v[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    return s;  // valid in lane 0
+}
+__global__ __launch_bounds__(64) void pcl_objective_sum_kernel(const double *__restrict__ member, const double *__restrict__ regval,
+                                                               double *__restrict__ value, int batch, int N, int traj_mode) {
     if (traj_mode) {
-        for (int b = 0; b < batch; ++b) {
-            double s = member[b];
-            for (int k = 0; k < N; ++k) s += regval[(long long)b * N + k];
-            value[b] = s;
-        }
+        const int b = blockIdx.x;
+        const double s = wave_sum_strided(regval + (long long)b * N, N);
+        if (threadIdx.x == 0) value[b] = member[b] + s;
     } else {
-        double s = 0.0;
-        for (int b = 0; b < batch; ++b) s += member[b];
-        for (int k = 0; k < N; ++k) s += regval[k];
-        value[0] = s;
+        const double sm = wave_sum_strided(member, batch), sr = wave_sum_strided(regval, N);
+        if (threadIdx.x == 0) value[0] = sm + sr;
     }
 }
 
@@ -405,9 +407,8 @@ __global__ __launch_bounds__(256) void pcl_merit_sum_kernel(const double *__rest
             ph[k] = t;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int k = 0; k < K; ++k) t += ph[k];
-        o[0] = t;
+    if (threadIdx.x < 64) {
+        const double t = wave_sum_strided(ph, K);
+        if (threadIdx.x == 0) o[0] = t;
     }
 }

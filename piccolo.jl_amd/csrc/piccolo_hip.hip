@@ -4,7 +4,9 @@
 //   pcl_kernel_fused_v3.hpp    default residual + Jacobian kernel: persistent, one workgroup per CU, stream / matrix roles
 //   pcl_kernels_fused_v2.hpp   fallback (two workgroups per CU); also kets and the compact Jacobian at large n
 //   pcl_kernels_reference.hpp  single-role kernel (A/B reference) and the general-order kernel (Pade 2..10)
-//   pcl_kernels_hessian.hpp    Hessian of the Lagrangian
+//   pcl_kernel_eval.hpp        residual only (pcl_eval): persistent, three barriers per interval
+//   pcl_kernels_hessian.hpp    Hessian of the Lagrangian: versions 1 (one workgroup per interval) and 2 (column chunks, fallback)
+//   pcl_kernel_hessian_v3.hpp  Hessian of the Lagrangian, default: one workgroup per interval, jobs split by drive
 //   pcl_kernels_misc.hpp       compact -> full expansion, rollout, derivative / time rows, terminal infidelity
 // DESIGN.md has the full account.  No CPU fallback exists: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
@@ -29,7 +31,9 @@
 #include "pcl_kernels_reference.hpp"
 #include "pcl_kernels_fused_v2.hpp"
 #include "pcl_kernel_fused_v3.hpp"
+#include "pcl_kernel_eval.hpp"
 #include "pcl_kernels_hessian.hpp"
+#include "pcl_kernel_hessian_v3.hpp"
 #include "pcl_kernels_misc.hpp"
 #include "pcl_host_expand.hpp"
 
@@ -81,6 +85,7 @@ struct pcl_ctx {
     double *hZ = nullptr, *hcompact = nullptr, *hdelta = nullptr;  // pinned (hipHostMalloc)
     double *dcomp_host = nullptr;                                    // device buffer of the compact values
     hipEvent_t ev_chunk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t opt_prof = 0;  // -DPCL_PROFILE builds only
     int64_t opt_host_threads = 0, opt_host_path = 0, opt_host_chunks = 4;
     int win_first = 0, win_count = 0;  // member window (pcl_set_member_window): the members / seeds the evaluator entry points cover
     int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_kernel = 0;  // 0 = auto: 3 where its specialised instance applies, else 1 / 2 by shape
@@ -233,6 +238,10 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     ctx->device = dsc->device_id;
     ctx->win_first = 0;
     ctx->win_count = dsc->batch;
+    if (const char *hp = getenv("PCL_HOST_PATH")) {  // default of option "host_path" (1: full values over PCIe, 2: compact + host expansion)
+        const long v = strtol(hp, nullptr, 10);
+        if (v >= 0 && v <= 2) ctx->opt_host_path = v;
+    }
 
 #define CREATE_TRY(expr)                                                  \
     do {                                                                  \
@@ -645,10 +654,11 @@ hipFunction_t jit_function(int device, const char *instance) {
     std::string dir(info.dli_fname);
     const size_t slash = dir.find_last_of('/');
     dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
-    const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp"};
-    std::string hdr[4];
-    const char *hdrp[4];
-    for (int i = 0; i < 4; ++i) {
+    const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp",
+                           "pcl_kernel_hessian_v3.hpp"};
+    std::string hdr[5];
+    const char *hdrp[5];
+    for (int i = 0; i < 5; ++i) {
         if (!slurp(dir + "/" + names[i], hdr[i])) {
             g_jit_note = "kernel header not found next to the library: " + dir + "/" + names[i];
             return nullptr;
@@ -656,9 +666,9 @@ hipFunction_t jit_function(int device, const char *instance) {
         hdrp[i] = hdr[i].c_str();
     }
     const char *src = "#include \"pcl_device_common.hpp\"\n#include \"pcl_kernels_fused_v2.hpp\"\n#include \"pcl_kernel_fused_v3.hpp\"\n"
-                      "#include \"pcl_kernels_hessian.hpp\"\n";
+                      "#include \"pcl_kernels_hessian.hpp\"\n#include \"pcl_kernel_hessian_v3.hpp\"\n";
     void *prog = nullptr;
-    if (g_rtc.CreateProgram(&prog, src, "pcl_jit.hip", 4, hdrp, names) != 0) {
+    if (g_rtc.CreateProgram(&prog, src, "pcl_jit.hip", 5, hdrp, names) != 0) {
         g_jit_note = "hiprtcCreateProgram failed";
         return nullptr;
     }
@@ -744,6 +754,7 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.LD = lds_ld(ctx->n);
     p.nt = (int)ctx->opt_nt;
     p.dbg = ctx->ddbg;
+    p.prof = (int)ctx->opt_prof;
     p.hess_per = hess_per(ctx);
 }
 
@@ -1014,6 +1025,32 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         return PCL_OK;
     }
 not_v3:
+    // residual only (what the solver calls in every line-search trial): the dedicated kernel for unitary states
+    if (!want_jac && ctx->opt_use_mfma != 0 && !ctx->vec && ctx->cols == ctx->desc.d && ctx->desc.d >= 9 && (ctx->opt_kernel == 0 || ctx->opt_kernel == 3)) {
+        typedef void (*kerne_t)(const KParams);
+        const int wu = (ctx->uell_w <= 2 && ctx->n_upos <= 256 * PCL_NUE_EV) ? ctx->uell_w : -1;
+        const bool spec = ctx->opt_specialize && p.d == 27;
+        kerne_t ke = wu == 1 ? (spec ? (kerne_t)pcl_eval_kernel<1, 27> : (kerne_t)pcl_eval_kernel<1, 0>)
+                   : wu == 2 ? (spec ? (kerne_t)pcl_eval_kernel<2, 27> : (kerne_t)pcl_eval_kernel<2, 0>)
+                             : (kerne_t)pcl_eval_kernel<-1, 0>;
+        const size_t lde = (p.d & 1) ? (size_t)p.n : (size_t)p.LD;  // the kernel's leading dimension (2*odd)
+        const size_t ldse = (lde * p.n + 4 * lde * 16 + 2 * (size_t)(p.m + 1) + 2) * sizeof(double) + 128;
+        if (ldse <= (size_t)ctx->max_lds) {
+            if (int rc = set_lds_attr(ctx, (const void *)ke, 5, ldse)) return rc;
+            const long long items = (long long)p.batch * p.K;
+            if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+            // two resident workgroups per CU measured best (three: 28 us per 8 trajectories, two: 21.5); every workgroup walks the
+            // same number of intervals: grid = items / rounds
+            const int per_cu = std::max(1, std::min(2, (int)((size_t)ctx->max_lds / ldse)));
+            const long long slots = (long long)per_cu * std::max(ctx->n_cu, 1), rounds = (items + slots - 1) / slots;
+            const long long ge = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, items) : (items + rounds - 1) / rounds;
+            ctx->last_kernel = 60 + ((spec && wu > 0) ? 1 : 0);
+            ctx->last_n_stream = 0;
+            hipLaunchKernelGGL(ke, dim3((unsigned)ge), dim3(256), ldse, ctx->stream, p);
+            HIP_TRY(ctx, hipGetLastError());
+            return PCL_OK;
+        }
+    }
     // auto: small Hilbert dimensions are launch- / latency-bound, one workgroup per item (kernel 1) beats the persistent
     // kernels there (measured: d <= 8 always, d <= 16 while all items fit one round of workgroups)
     const bool v1_auto = ctx->opt_kernel == 0 && (ctx->desc.d <= 8 || (ctx->desc.d <= 16 && (long long)ctx->win_count * ctx->K <= 512));
@@ -1099,6 +1136,43 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
     const bool mf = ctx->opt_use_mfma != 0;
     if (ctx->desc.pade_order != 4)
         return fail(ctx, PCL_ENOTIMPL, "the Hessian of the Lagrangian is implemented for pade_order 4 only (have %d)", ctx->desc.pade_order);
+    // version 3 (default where its tiles fit LDS): one workgroup per interval, jobs split by drive
+    if (mf && (ctx->opt_hess_kernel == 0 || ctx->opt_hess_kernel == 3) && hess_v2_supported(ctx) && ctx->cols == ctx->desc.d && ctx->uell_w <= 2 &&
+        ctx->n_upos <= 512 * PCL_NUE_H3 && (ctx->opt_hess_kernel == 3 || ctx->desc.d >= 12)) {
+        const size_t lde = (p.d & 1) ? (size_t)p.n : (size_t)p.LD;
+        const size_t nsc = (size_t)(p.m + 1) * (p.m + 2) / 2;
+        const size_t lds3 = (lde * p.n + (8 + 2 * (size_t)p.m) * lde * 16 + 2 * (size_t)(p.m + 1) + 8 * nsc + 8) * sizeof(double) + 64;
+        const bool st27 = ctx->opt_specialize && ctx->drives_antisym && p.d == 27 && p.m == 6;
+        const bool st25 = ctx->opt_specialize && ctx->drives_antisym && p.d == 25 && p.m == 4;
+        if (lds3 <= (size_t)ctx->max_lds) {
+            const void *k3 = st27 ? (const void *)pcl_hess_kernel_v3<PCL_HESS_EW, 6, 27, true>
+                           : st25 ? (const void *)pcl_hess_kernel_v3<PCL_HESS_EW, 4, 25, true> : nullptr;
+            hipFunction_t j3 = nullptr;
+            if (!k3 && ctx->opt_jit && ctx->opt_specialize) {  // any other shape: compiled on first use
+                char inst[96];
+                snprintf(inst, sizeof inst, "pcl_hess_kernel_v3<%d, %d, %d, %s>", PCL_HESS_EW, p.m, p.d, ctx->drives_antisym ? "true" : "false");
+                j3 = jit_function(ctx->device, inst);
+            }
+            if (k3 || j3) {
+                if (k3)
+                    if (int rc = set_lds_attr(ctx, k3, 7, lds3)) return rc;
+                const long long items = (long long)p.batch * p.K;
+                if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+                const long long slots = std::max(ctx->n_cu, 1), rounds = (items + slots - 1) / slots;
+                long long grid = (items + rounds - 1) / rounds;  // every workgroup walks the same number of intervals
+                if (ctx->opt_grid > 0) grid = std::min<long long>(items, ctx->opt_grid);
+                void *args[] = {(void *)&p};
+                if (j3)
+                    HIP_TRY(ctx, hipModuleLaunchKernel(j3, (unsigned)grid, 1, 1, 512, 1, 1, (unsigned)lds3, ctx->stream, args, nullptr));
+                else
+                    HIP_TRY(ctx, hipLaunchKernel(k3, dim3((unsigned)grid), dim3(512), args, lds3, ctx->stream));
+                HIP_TRY(ctx, hipGetLastError());
+                ctx->last_hess_kernel = j3 ? 5 : 4;  // 4: version 3 (static instance), 5: version 3 compiled on first use
+                return PCL_OK;
+            }
+        }
+        if (ctx->opt_hess_kernel == 3) return fail(ctx, PCL_ESHAPE, "hess_kernel=3: no instance for this shape (tiles need %zu B of LDS, jit=%d)", lds3, (int)ctx->opt_jit);
+    }
     if (ctx->opt_hess_kernel == 2 && !hess_v2_supported(ctx))
         return fail(ctx, PCL_ESHAPE, "hess_kernel=2 needs 1..6 drives with at most %d entries per row and column (have m=%d, widths %d/%d)",
                     PCL_HESS_EW, p.m, ctx->ell_w, ctx->ellt_w);
@@ -1579,7 +1653,7 @@ extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double
     } else {
         HIP_TRY(ctx, hipMemsetAsync(member, 0, (size_t)D.batch * sizeof(double), ctx->stream));
     }
-    hipLaunchKernelGGL(pcl_objective_sum_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)member, (const double *)regval, value,
+    hipLaunchKernelGGL(pcl_objective_sum_kernel, dim3(traj ? (unsigned)D.batch : 1u), dim3(64), 0, ctx->stream, (const double *)member, (const double *)regval, value,
                        D.batch, D.N, traj ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
     return PCL_OK;
@@ -1725,6 +1799,10 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_nt = v != 0;
     else if (!strcmp(key, "grid"))
         ctx->opt_grid = v;
+#ifdef PCL_PROFILE
+    else if (!strcmp(key, "profile_flags"))  // profiling experiments (results may be WRONG); not present in the shipped library
+        ctx->opt_prof = v;
+#endif
     else if (!strcmp(key, "host_threads"))  // host-pointer entry points: threads expanding the compact values (0 = auto)
         ctx->opt_host_threads = v < 0 ? 0 : v;
     else if (!strcmp(key, "host_path"))  // 0 auto | 1 full values over PCIe | 2 compact values + host expansion
@@ -1746,7 +1824,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
     else if (!strcmp(key, "contiguous"))  // kernel 3: 1 = equal contiguous column ranges per workgroup (default), 0 = round-robin slices
         ctx->opt_contig = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "hess_kernel")) {  // 0: auto, 1: one workgroup per interval, 2: persistent wave-synchronous kernel
-        if (v < 0 || v > 2) return fail(ctx, PCL_EINVAL, "hess_kernel must be 0, 1 or 2");
+        if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "hess_kernel must be 0, 1, 2 or 3");
         ctx->opt_hess_kernel = v;
     }
     else if (!strcmp(key, "debug_timing")) {  // profiling aid: cycle stamps of workgroup 0 (pcl_debug_timing reads them)

@@ -26,10 +26,10 @@ def main():
         Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()
         mu = torch.randn(c.n_rows, dtype=torch.float64, device="cuda")
         hv = torch.empty(c.hess_nnz, dtype=torch.float64, device="cuda")
-        for hk in (1, 2):
+        for hk in (1, 2, 3):
             c.set_option("hess_kernel", hk)
-            for grid in ((0,) if hk == 1 else ABL):
-                c.set_option("debug_ablate", grid)
+            for grid in ((0,) if hk != 3 else (0, 128, 198, 256, 396)):
+                c.set_option("grid", grid)
                 for _ in range(5):
                     c.hess_dev(Zd, mu, hv)
                 torch.cuda.synchronize()
@@ -40,8 +40,8 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / 50 / batch
-                print("batch %d hess_kernel %d ablate %d: %.2f us/eval  (%.0f GB/s of output)" % (batch, hk, grid, us, c.hess_nnz / batch * 8 / us / 1e3), flush=True)
-        c.set_option("debug_ablate", 0)
+                print("batch %d hess_kernel %d grid %d: %.2f us/eval  (%.0f GB/s of output)" % (batch, hk, grid, us, c.hess_nnz / batch * 8 / us / 1e3), flush=True)
+        c.set_option("grid", 0)
         ms.close()
 
 

@@ -9,6 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The parity tests drive the work-split options of the FULL-values kernels through the host-pointer entry points, so those
+# deliver the full values over PCIe here; the default delivery (compact values + host expansion) is compared bitwise with
+# it, shape by shape, in test_host_delivery_paths_agree_bitwise.
+os.environ.setdefault("PCL_HOST_PATH", "1")
 
 
 def pytest_configure(config):

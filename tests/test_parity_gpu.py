@@ -748,10 +748,10 @@ def test_ket_variant(d, m, N):
 # ---- Hessian kernels ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cfg,N,batch", [(1, 50, 1), (2, 100, 2), (3, 6, 1), (3, 5, 3)])
 def test_hessian_kernel_variants(cfg, N, batch):
-    """Both Hessian kernels (1: one workgroup per interval; 2: persistent, wave-synchronous, column slices whose scalar
-    entries are combined by the last slice to arrive) against the oracle, for every slicing of the state columns;
-    kernel 2 must be what `auto` runs for the sparse drives of the reference's systems, and it must be
-    bitwise repeatable (fixed-order sums)."""
+    """The Hessian kernels (1: one workgroup per interval; 2: persistent, wave-synchronous, column slices whose scalar
+    entries are combined by the last slice to arrive; 3: one workgroup per interval, jobs split by drive, no
+    cross-workgroup step) against the oracle, for every slicing of the state columns / any grid; `auto` runs kernel 3 for
+    d >= 12 (static instance at BASELINE config 3's shape) and kernel 2 below; all are bitwise repeatable."""
     so = po.config_system(cfg)
     G0, Gj = so.G_drift, np.array(so.G_drives)
     Zs, lay = [], None
@@ -764,7 +764,7 @@ def test_hessian_kernel_variants(cfg, N, batch):
     c = make_ctx(lay, G0, Gj, batch=batch, batch_mode=pa._lib.PCL_BATCH_TRAJ, x_offs=[lay.x_off])
     Zb, mub = np.stack(Zs), np.concatenate([m_.reshape(-1) for m_ in mus])
     h_auto = c.hess(Zb, mub)
-    assert c.get_option("last_hess_kernel") == 2
+    assert c.get_option("last_hess_kernel") == (4 if cfg == 3 else 2)
     close(h_auto, ref, 1e-11)
     for hk in (1, 2):
         c.set_option("hess_kernel", hk)
@@ -774,6 +774,14 @@ def test_hessian_kernel_variants(cfg, N, batch):
             assert c.get_option("last_hess_kernel") == hk
             close(h, ref, 1e-11)
             assert np.array_equal(h, c.hess(Zb, mub))
+    c.set_option("cols_per_slice", 0)
+    c.set_option("hess_kernel", 3)
+    for grid in (0, 1, 2, 3, 7, 1000):
+        c.set_option("grid", grid)
+        h = c.hess(Zb, mub)
+        assert c.get_option("last_hess_kernel") == (4 if cfg == 3 else 5)  # 5: the shape's instance was compiled on first use
+        close(h, ref, 1e-11)
+        assert np.array_equal(h, c.hess(Zb, mub))
     c.close()
 
 
@@ -1342,7 +1350,7 @@ def test_other_specialised_shapes(levels, batch):
     close(vals, np.concatenate([r[1].reshape(-1) for r in refs]))
     mu = np.random.default_rng(1).standard_normal((batch, lay.K, lay.x_dim))
     hv = c.hess(np.stack(Zs), mu.reshape(-1))
-    assert c.get_option("last_hess_kernel") == (2 if levels == 5 else 3)  # static instance at d = 25, compiled on first use at d = 16
+    assert c.get_option("last_hess_kernel") == (4 if levels == 5 else 5)  # kernel 3: static instance at d = 25, compiled on first use at d = 16
     close(hv, np.concatenate([ref_lib.hess(Z, mu[i], lay, G0, Gj).reshape(-1) for i, Z in enumerate(Zs)]), 1e-10)
     c.close()
 
@@ -1377,7 +1385,7 @@ def test_runtime_compiled_shape_instances():
     close(vals, j_ref, 1e-11)
     mu = rng.standard_normal((Bn, lay.K, lay.x_dim))
     hv = c.hess(np.stack(Zs), mu.reshape(-1))
-    assert c.get_option("last_hess_kernel") == 3 and c.get_option("jit_compiles") == n0 + 2  # one compile per template instance
+    assert c.get_option("last_hess_kernel") == 5 and c.get_option("jit_compiles") == n0 + 2  # one compile per template instance
     h_ref = np.concatenate([ref_lib.hess(Z, mu[i], lay, G0, Gj).reshape(-1) for i, Z in enumerate(Zs)])
     close(hv, h_ref, 1e-10)
     c.set_option("jit", 0)
@@ -1430,3 +1438,79 @@ def test_host_delivery_paths_agree_bitwise():
     assert np.array_equal(c.jac(np.stack(Zs)), v_full[per:])
     c.set_member_window(0, Bn)
     ms.close()
+    # every kernel family behind the compact mode: small d (kernel 1), general dense generators (kernel 2), higher Pade
+    # order (general-order kernel), an ensemble with per-member drift, kets (one column: nothing to expand)
+    rng = np.random.default_rng(77)
+    cases = []
+    for cfg in (1, 2):
+        so_ = po.config_system(cfg)
+        Zc, layc = po.synthetic_trajectory(so_, 9, seed=cfg)
+        cases.append((make_ctx(layc, so_.G_drift, np.array(so_.G_drives)), Zc))
+    lay2, G02, Gj2, Z2 = _random_case(20, 3, 4, rng)
+    cases.append((make_ctx(lay2, G02, Gj2), Z2))
+    lay3, G03, Gj3, Z3 = _random_case(12, 2, 5, rng)
+    cases.append((make_ctx(lay3, G03, Gj3, pade_order=6), Z3))
+    layk = po.Layout(d=5, m=2, N=6, z_dim=10 + 2 + 2, x_off=0, u_off=12, dt_off=10, cols=1)
+    Zk = 0.5 * rng.standard_normal((6, layk.z_dim))
+    Zk[:, layk.dt_off] = 0.05 + 0.05 * rng.random(6)
+    Gk0, Gkj = rng.standard_normal((10, 10)), rng.standard_normal((2, 10, 10))
+    cases.append((make_ctx(layk, Gk0, Gkj, state_cols=1), Zk))
+    osys, psys, layE, ZE, trajE = _config4_share(2, 5)
+    BE = _fused_ensemble(psys, trajE)
+    cases.append((BE.ctx, ZE))
+    for cc, Zc in cases:
+        cc.set_option("host_path", 1)
+        d1, v1 = cc.eval_jac(Zc)
+        cc.set_option("host_path", 2)
+        cc.set_option("host_threads", 5)
+        d2, v2 = cc.eval_jac(Zc)
+        assert np.array_equal(d1, d2) and np.array_equal(v1, v2)
+        cc.close()
+
+
+def test_residual_only_kernel():
+    """pcl_eval[_dev] runs its own kernel for unitary states with d >= 9 (Ipopt calls eval_constraint alone in every
+    line-search trial): every instance (specialised d = 27, run-time shapes, drives with 1 / 2 / many entries per union
+    position, per-member drift), any grid, against the oracle and bitwise equal to the residual the fused kernel writes."""
+    rng = np.random.default_rng(31)
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    Bn, N = 3, 7
+    Zs = []
+    for s in range(Bn):
+        Z, lay = po.synthetic_trajectory(so, N, seed=400 + s)
+        Z[:, lay.dt_off] = 0.08 + 0.04 * rng.random(N)
+        Zs.append(Z)
+    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn)
+    c = ms.ctx
+    ref = np.concatenate([po.pade_residual(Z, lay, G0, Gj, 4).reshape(-1) for Z in Zs])
+    for spec in (1, 0):
+        c.set_option("specialize", spec)
+        for grid in (0, 1, 2, 5, 17, 1000):
+            c.set_option("grid", grid)
+            d = c.eval(np.stack(Zs))
+            assert c.get_option("last_kernel") == 60 + spec
+            close(d, ref)
+    c.set_option("grid", 0)
+    c.set_option("specialize", 1)
+    d_fused, _ = c.eval_jac(np.stack(Zs))
+    close(c.eval(np.stack(Zs)), d_fused, 1e-13)
+    ms.close()
+    # general real generators (dense drives: the union tables are read from memory), odd d, d = 32 (n = 64: the largest tile)
+    for d_, m_ in ((9, 2), (20, 3), (32, 2)):
+        lay2, G02, Gj2, Z2 = _random_case(d_, m_, 5, rng)
+        c2 = make_ctx(lay2, G02, Gj2)
+        close(c2.eval(Z2), po.pade_residual(Z2, lay2, G02, Gj2, 4).reshape(-1), 1e-11)
+        assert c2.get_option("last_kernel") == 60
+        c2.close()
+    # per-member drift tiles (ensemble), windows
+    osys, psys, layE, ZE, trajE = _config4_share(3, 6)
+    B = _fused_ensemble(psys, trajE)
+    dE = B.ctx.eval(trajE.datavec)
+    assert B.ctx.get_option("last_kernel") == 61
+    per = layE.x_dim * layE.K
+    for i, s in enumerate(osys):
+        close(dE[i * per : (i + 1) * per], po.pade_residual(ZE, layE, s.G_drift, np.array(s.G_drives), 4, x_off=i * layE.x_dim).reshape(-1))
+    B.ctx.set_member_window(2, 1)
+    assert np.array_equal(B.ctx.eval(trajE.datavec), dE[2 * per :])
+    B.close()
