@@ -153,6 +153,24 @@ __device__ __forceinline__ void store2(double *p, double a, double b, bool nt) {
         *reinterpret_cast<double2_t *>(p) = v;
 }
 
+// Column-major n x n matrix in memory -> LDS tile with leading dimension LD, by NT threads.  All global loads of a block of
+// eight iterations are issued before the first LDS write (written as load -> store per iteration, the compiler waits for every
+// load in turn: one dependent round trip to L2 / HBM per iteration).
+template <int NT>
+__device__ __forceinline__ void load_tile(const double *__restrict__ src, double *__restrict__ dst, int n, int LD, int tid) {
+    const int nn = n * n;
+    for (int e0 = tid; e0 < nn; e0 += NT * 8) {
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = e0 + NT * j < nn ? src[e0 + NT * j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = e0 + NT * j;
+            if (e < nn) dst[(e % n) + LD * (e / n)] = v[j];
+        }
+    }
+}
+
 // Assemble G(u_k) into LDS (ld = LD):  G = G0 + sum_l u_l G_l, in drive order (deterministic).
 __device__ __forceinline__ void build_G(const KParams &p, const double *__restrict__ G0, const double *__restrict__ zk,
                                         double *__restrict__ G, double *__restrict__ us) {

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
 
     // ---- launch-invariant state: drift tile, this thread's union-pattern entries ---------------------------------------
     if (!p.g0_batch_stride)
-        for (int e = tid; e < nn; e += 256) G[(e % n) + LD * (e / n)] = p.G0[e];
+        load_tile<256>(p.G0, G, n, LD, tid);
     constexpr int WUR = WU > 0 ? WU : 1;
     int un_idx[PCL_NUE_EV];
     double un_g0[PCL_NUE_EV];

@@ -41,7 +41,14 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     const int tid = threadIdx.x;
 #ifdef PCL_PROFILE
     if (p.dbg && tid == 0 && blockIdx.x < PCL_DBG_WG) p.dbg[64 + blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+#define PCL_S(i)                                                                                                            \
+    do {                                                                                                                    \
+        if (p.dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (p.prof & 2)) p.dbg[i] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PCL_S(i) do { } while (0)
 #endif
+    if (tid == 0) PCL_S(40);  // kernel entry
     const int wave = tid >> 6, lane = tid & 63;
     const int nn = n * n;
     const int ew = p.ell_w, uw = p.uell_w, n_ell = m * n * ew, n_un = p.n_upos;
@@ -113,37 +120,186 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
 
     // item 0's controls / time step: requested before the prologue's table loads so that the latencies overlap
     double u0 = 0.0;
-    if (alive(0) && wave < 4 && lane <= m) {
+    if (alive(0) && lane <= m) {  // (every wave: all eight take part in the first build)
         int c00, nce0, k0, b0;
         decode(0, c00, nce0, k0, b0);
         const double *z0 = p.Z + (long long)b0 * p.z_batch_stride + (long long)k0 * p.z_dim;
         u0 = z0[lane < m ? p.u_off + lane : p.dt_off];
     }
+    unsigned short er_c[PCL_MREG][EW > 0 ? EW : 1];  // ELL rows (drive l, row = lane) of the matrix waves, in registers
+    double er_v[PCL_MREG][EW > 0 ? EW : 1];
     // ---- prologue: both G buffers = drift tile, tables -> LDS ----------------------------------------------
-    if (!p.g0_batch_stride)
-        for (int e = tid; e < nn; e += 512) {
-            const double g = p.G0[e];
-            const int o = (e % n) + LD * (e / n);
-            Gb[o] = g;
-            Gb[tile + o] = g;
+    // Every loop issues ALL its global loads before the first LDS write: written as one load -> one store per iteration the
+    // compiler waits for each load in turn (s_waitcnt vmcnt(0) per iteration), ~15 dependent round trips to L2 / HBM --
+    // most of what an empty launch of this kernel used to cost.
+    // ONE gather phase: every global load of the prologue is issued before the first LDS write.  The tables live in
+    // separate small allocations and each dependent group of loads pays its own address-translation / L2 round trip at
+    // kernel start (~3k cycles measured per group): issued together they cost one.  (Sizes: nn <= 4096, n_un * uw <= 2048
+    // when staged, n_un <= 1024 -- checked by the host when it sets tab_lds.)
+    {
+        double vg[8], vu[4], g0v[2], ve[2];
+        unsigned char lb[4];
+        int ps[2], ce[2];
+        const bool tabs = p.tab_lds && n_un * uw <= 2048 && n_un <= 1024 && n_ell <= 1024;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vg[j] = (!p.g0_batch_stride && tid + 512 * j < nn) ? p.G0[tid + 512 * j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = tabs && tid + 512 * j < n_un * uw;
+            vu[j] = ok ? p.uell_v[tid + 512 * j] : 0.0;
+            lb[j] = ok ? p.uell_l[tid + 512 * j] : 0;
         }
-    if (p.tab_lds) {
-        for (int e = tid; e < n_un * uw; e += 512) {
-            t_unv[e] = p.uell_v[e];
-            t_unl[e] = p.uell_l[e];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = tabs && tid + 512 * j < n_un;
+            ps[j] = ok ? p.upos[tid + 512 * j] : 0;
+            g0v[j] = (ok && !p.g0_batch_stride) ? p.ug0[tid + 512 * j] : 0.0;  // (not G0[pos]: no dependent load in the prologue)
         }
-        for (int e = tid; e < n_un; e += 512) {
-            const int pos = p.upos[e];
-            t_uni[e] = (unsigned short)((pos % n) + LD * (pos / n));
-            t_ung0[e] = p.g0_batch_stride ? 0.0 : p.ug0[e];  // (not G0[pos]: no dependent load in the prologue)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = tabs && tid + 512 * j < n_ell;
+            ve[j] = ok ? p.ell_val[tid + 512 * j] : 0.0;
+            ce[j] = ok ? p.ell_col[tid + 512 * j] : 0;
         }
-        for (int e = tid; e < n_ell; e += 512) {
-            t_ellv[e] = p.ell_val[e];
-            t_ellc[e] = (unsigned short)p.ell_col[e];
+        if (!p.g0_batch_stride) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = tid + 512 * j;
+                if (e < nn) {
+                    const int o = (e % n) + LD * (e / n);
+                    Gb[o] = vg[j];
+                    Gb[tile + o] = vg[j];
+                }
+            }
+        }
+        if (tabs) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (tid + 512 * j < n_un * uw) {
+                    t_unv[tid + 512 * j] = vu[j];
+                    t_unl[tid + 512 * j] = lb[j];
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (tid + 512 * j < n_un) {
+                    t_uni[tid + 512 * j] = (unsigned short)((ps[j] % n) + LD * (ps[j] / n));
+                    t_ung0[tid + 512 * j] = g0v[j];
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (tid + 512 * j < n_ell) {
+                    t_ellv[tid + 512 * j] = ve[j];
+                    t_ellc[tid + 512 * j] = (unsigned short)ce[j];
+                }
+        } else if (p.tab_lds) {  // larger tables: plain loops
+            for (int e = tid; e < n_ell; e += 512) {
+                t_ellv[e] = p.ell_val[e];
+                t_ellc[e] = (unsigned short)p.ell_col[e];
+            }
+            for (int e = tid; e < n_un * uw; e += 512) {
+                t_unv[e] = p.uell_v[e];
+                t_unl[e] = p.uell_l[e];
+            }
+            for (int e = tid; e < n_un; e += 512) {
+                const int pos = p.upos[e];
+                t_uni[e] = (unsigned short)((pos % n) + LD * (pos / n));
+                t_ung0[e] = p.g0_batch_stride ? 0.0 : p.ug0[e];
+            }
+        }
+    }
+    if (tid == 0) PCL_S(41);  // prologue loads written
+    __syncthreads();
+    if (tid == 0) PCL_S(42);  // prologue barrier passed
+
+    // ---- first item's G(u), G^2 by ALL eight waves (the stream waves have nothing to write yet): the union pattern is
+    //      split over the 512 threads, then one barrier, then one G^2 tile job per wave (4 row tiles x 2 column tiles at
+    //      d = 27).  Every element is accumulated in the same order as in `build` below: identical bits. -----------------------
+    int first_b = -1;
+    if (alive(0)) {
+        int c0_, nce_, k0_, b0_;
+        decode(0, c0_, nce_, k0_, b0_);
+        first_b = b0_;
+        double *usn = us;  // slot of item 0
+        if (lane <= m) usn[lane] = u0;  // every wave: identical values
+        wave_lds_sync();
+        if (tid == 0) PCL_S(49);  // controls arrived
+        const double *G0b = p.G0 + (long long)b0_ * p.g0_batch_stride;
+        if (p.g0_batch_stride) {
+            for (int e = tid; e < nn; e += 512)
+                if (p.umap[e] < 0) Gb[(e % n) + LD * (e / n)] = G0b[e];
+            if (p.tab_lds)
+                for (int q = tid; q < n_un; q += 512) t_ung0[q] = G0b[p.upos[q]];
+            __syncthreads();
+        }
+        if (p.tab_lds) {
+            for (int q = tid; q < n_un; q += 512) {
+                double g = t_ung0[q];
+                for (int w = 0; w < uw; ++w) g += usn[t_unl[q * uw + w]] * t_unv[q * uw + w];
+                Gb[t_uni[q]] = g;
+            }
+        } else {
+            for (int q = tid; q < n_un; q += 512) {
+                const int pos = p.upos[q];
+                double g = G0b[pos];
+                const double *cf = p.ucoef + (long long)q * m;
+                for (int l = 0; l < m; ++l) g += usn[l] * cf[l];
+                Gb[(pos % n) + LD * (pos / n)] = g;
+            }
         }
     }
     __syncthreads();
+    if (tid == 0) PCL_S(50);  // G(u) complete
+    if (alive(0)) {
+        const int li = lane & 15, lk = lane >> 4;
+        const int rt_n = (n + 15) >> 4, kfull = n >> 2, krem = n & 3;
+        const int ct_n = p.iso ? (d + 15) >> 4 : rt_n, Nc = p.iso ? d : n;
+        const double *G = Gb;
+        double *G2 = G2b;
+        for (int job = wave; job < rt_n * ct_n; job += 8) {
+            const int rt = job % rt_n, ct = job / rt_n;
+            const double *Ap = G + rt * 16 + li + LD * lk;
+            const double *Bp = G + lk + LD * (ct * 16 + li);
+            // k-step ks into accumulator ks mod 4, G^2 = ((s0 + remainder step) + s2) + (s1 + s3): the order of `build` below
+            double4_t qa[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qa[j] = double4_t{0.0, 0.0, 0.0, 0.0};
+            double a[16], bb[16];  // every operand of the tile job is requested before the first MFMA (kfull <= 16)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool ok = j < kfull;
+                a[j] = ok ? Ap[LD * 4 * j] : 0.0;
+                bb[j] = ok ? Bp[4 * j] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < kfull) qa[j & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], bb[j], qa[j & 3], 0, 0, 0);
+            if (krem) {
+                const bool ok = lk < krem;
+                qa[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? Ap[LD * 4 * kfull] : 0.0, ok ? Bp[4 * kfull] : 0.0, qa[0], 0, 0, 0);
+            }
+            const double4_t acc = (qa[0] + qa[2]) + (qa[1] + qa[3]);
 
+            const int col = ct * 16 + li;
+            if (col < Nc) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rt * 16 + lk + 4 * r;
+                    if (row < n) {
+                        G2[row + LD * col] = acc[r];
+                        if (p.iso) {
+                            if (row < d)
+                                G2[row + d + LD * (col + d)] = acc[r];
+                            else
+                                G2[row - d + LD * (col + d)] = -acc[r];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (tid == 0) PCL_S(44);  // first G, G^2 built
+    __syncthreads();  // item 0's G, G^2 complete
+    if (tid == 0) PCL_S(45);
 
     if (wave < 4 || matrix_role) {
         // ======================================= matrix waves =========================================
@@ -157,27 +313,10 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
         const int li = lane & 15, lk = lane >> 4;
         const int rt_n = (n + 15) >> 4;
         const int kfull = n >> 2, krem = n & 3;
-        // ELL rows (drive l, row = lane) in registers
-        unsigned short er_c[PCL_MREG][EW > 0 ? EW : 1];
-        double er_v[PCL_MREG][EW > 0 ? EW : 1];
-        if (EW > 0) {
-#pragma unroll
-            for (int l = 0; l < PCL_MREG; ++l)
-#pragma unroll
-                for (int q = 0; q < (EW > 0 ? EW : 1); ++q) {
-                    er_c[l][q] = 0;
-                    er_v[l][q] = 0.0;
-                    if (l < m && lane < n) {
-                        er_c[l][q] = (unsigned short)p.ell_col[(l * n + lane) * ew + q];
-                        er_v[l][q] = p.ell_val[(l * n + lane) * ew + q];
-                    }
-                }
-        }
-
         // per-member drift: which member's drift the two G buffers (off the union pattern) and the union table t_ung0 hold.
         // A workgroup's consecutive items almost always belong to the same member (contiguous column ranges), so the
         // drift tile is rewritten -- from memory, by every building wave -- only when the member changes.
-        int drift_in_buf0 = -1, drift_in_buf1 = -1, drift_in_tab = -1;
+        int drift_in_buf0 = first_b, drift_in_buf1 = -1, drift_in_tab = first_b;  // (the first build above loaded buffer 0 and the table)
         // G(u) on the union pattern + this wave's share of the G^2 tiles, for item `it`, into buffer `buf`
         auto build = [&](int it, int buf, double u_lane) {
             int c0_, nce_, k, b;
@@ -226,7 +365,40 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                     wave_lds_sync();
                 }
             }
-            if (p.tab_lds) {
+            if (p.tab_lds && uw <= 2) {
+                // four pattern entries per lane and pass: every table read of the pass is issued before the first use (the
+                // one-entry-at-a-time form costs three dependent LDS round trips per entry)
+                for (int q0 = lane; q0 < n_un; q0 += 64 * 4) {
+                    double g0v[4], cv[4][2];
+                    int dl[4][2], oi[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = min(q0 + 64 * j, n_un - 1);
+                        g0v[j] = t_ung0[q];
+                        oi[j] = t_uni[q];
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            const bool ok = w < uw;
+                            dl[j][w] = ok ? t_unl[q * uw + w] : 0;
+                            cv[j][w] = ok ? t_unv[q * uw + w] : 0.0;
+                        }
+                    }
+                    double uv[4][2];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) uv[j][w] = usn[dl[j][w]];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (q0 + 64 * j < n_un) {
+                            double g = g0v[j];
+#pragma unroll
+                            for (int w = 0; w < 2; ++w)
+                                if (w < uw) g += uv[j][w] * cv[j][w];
+                            G[oi[j]] = g;
+                        }
+                }
+            } else if (p.tab_lds) {
                 for (int q = lane; q < n_un; q += 64) {
                     double g = t_ung0[q];
                     for (int w = 0; w < uw; ++w) g += usn[t_unl[q * uw + w]] * t_unv[q * uw + w];
@@ -251,31 +423,38 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                     const bool two = ct + 1 < ct_n;
                     const double *Bp0 = G + lk + LD * (ct * 16 + li);
                     const double *Bp1 = Bp0 + (two ? LD * 16 : 0);
-                    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-                    double an = 0.0, b0n = 0.0, b1n = 0.0;
-                    if (kfull > 0) {
-                        an = Ap[0];
-                        b0n = Bp0[0];
-                        b1n = Bp1[0];
-                    }
-                    for (int ks = 0; ks < kfull; ++ks) {
-                        const double a = an, b0 = b0n, b1 = b1n;
-                        if (ks + 1 < kfull) {
-                            an = Ap[LD * 4 * (ks + 1)];
-                            b0n = Bp0[4 * (ks + 1)];
-                            b1n = Bp1[4 * (ks + 1)];
+                    // Four accumulators per tile, k-step ks into accumulator ks mod 4 (a dependent f64 MFMA waits ~235 cycles
+                    // for its accumulator; four independent chains keep the pipe issuing):
+                    //     G^2 = ((s0 + remainder step) + s2) + (s1 + s3)   -- the first build above adds in exactly this order.
+                    double4_t q0[4], q1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q0[j] = q1[j] = double4_t{0.0, 0.0, 0.0, 0.0};
+                    for (int ks0 = 0; ks0 < kfull; ks0 += 4) {
+                        double a[4], b0[4], b1[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {  // the four steps' operands are requested together
+                            const bool ok = ks0 + j < kfull;
+                            a[j] = ok ? Ap[LD * 4 * (ks0 + j)] : 0.0;
+                            b0[j] = ok ? Bp0[4 * (ks0 + j)] : 0.0;
+                            b1[j] = ok ? Bp1[4 * (ks0 + j)] : 0.0;
                         }
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
-                        if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (ks0 + j < kfull) {
+                                q0[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], b0[j], q0[j], 0, 0, 0);
+                                if (two) q1[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], b1[j], q1[j], 0, 0, 0);
+                            }
                     }
                     if (krem) {
                         const bool ok = lk < krem;
                         const double a = ok ? Ap[LD * 4 * kfull] : 0.0;
                         const double b0 = ok ? Bp0[4 * kfull] : 0.0;
                         const double b1 = ok ? Bp1[4 * kfull] : 0.0;
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
-                        if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+                        q0[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, q0[0], 0, 0, 0);
+                        if (two) q1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, q1[0], 0, 0, 0);
                     }
+                    const double4_t acc0 = (q0[0] + q0[2]) + (q0[1] + q0[3]), acc1 = (q1[0] + q1[2]) + (q1[1] + q1[3]);
+
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const int col = (ct + t) * 16 + li;
@@ -300,8 +479,21 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             }
         };
 
-        if (alive(0) && wave < 4) build(0, 0, u0);
-        __syncthreads();  // item 0's G, G^2 complete
+        // the ELL rows are needed by the column work only: requested now, while the stream waves already write
+        if (EW > 0) {
+#pragma unroll
+            for (int l = 0; l < PCL_MREG; ++l)
+#pragma unroll
+                for (int q = 0; q < (EW > 0 ? EW : 1); ++q) {
+                    er_c[l][q] = 0;
+                    er_v[l][q] = 0.0;
+                    if (l < m && lane < n) {
+                        const int ie = (l * n + lane) * ew + q;
+                        er_c[l][q] = p.tab_lds ? t_ellc[ie] : (unsigned short)p.ell_col[ie];
+                        er_v[l][q] = p.tab_lds ? t_ellv[ie] : p.ell_val[ie];
+                    }
+                }
+        }
 
         for (int it = 0; alive(it); ++it) {
             const int cur = matrix_role ? 0 : (it & 1);
@@ -564,7 +756,6 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
         const int hn = n >> 1;
         const int pi = 2 * (stid % hn), pj0 = stid / hn, pstep = max(256 / hn, 1);
         const bool pact = pj0 < pstep;
-        __syncthreads();  // item 0's G, G^2 complete
         for (int it = 0; alive(it); ++it) {
             const int cur = it & 1;
             int c0, nce, k, b;
@@ -604,9 +795,15 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                     }
                 }
             }
+            if (tid == 256 && it == 0) {
+                PCL_S(46);  // first item's stores issued
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PCL_S(47);  // ... and gone
+            }
             __syncthreads();  // item boundary
         }
     }
+    if (tid == 0) PCL_S(48);  // matrix wave 0 done
 #ifdef PCL_PROFILE
     if (p.dbg && tid == 256 && blockIdx.x < PCL_DBG_WG) {  // wave 4: a stream wave, or a matrix wave of a matrix-role workgroup
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // its stores have left the CU

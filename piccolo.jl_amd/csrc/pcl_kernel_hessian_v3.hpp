@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void pcl_hess_kernel_v3(const KParams p) {
         }
     }
     if (!p.g0_batch_stride)
-        for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = p.G0[e];
+        load_tile<512>(p.G0, G, n, LD, tid);
     for (int e = tid; e < 8 * tile; e += 512) Ms[e] = 0.0;  // Ms, Ds, Ss, A1s: columns beyond d stay zero (they are MFMA operands)
 
     // ---- work: a contiguous range of intervals per workgroup (consecutive items share the ensemble member) ------------------

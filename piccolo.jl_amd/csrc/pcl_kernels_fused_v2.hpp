@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
 
     // ---- launch-invariant state -------------------------------------------------------------------------
     if (!p.g0_batch_stride)
-        for (int e = tid; e < nn; e += 512) G[(e % n) + LD * (e / n)] = p.G0[e];
+        load_tile<512>(p.G0, G, n, LD, tid);
     constexpr int WUR = WU > 0 ? WU : 1;
     int un_idx[PCL_NUE2];
     double un_g0[PCL_NUE2];

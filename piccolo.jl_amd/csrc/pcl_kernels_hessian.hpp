@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void pcl_hess_kernel_v2(const KParams p) {
 #define ET_C(l, q) (ANTI ? er_c[l][q] : et_c_[ANTI ? 0 : (l)][q])
 #define ET_V(l, q) (ANTI ? er_v[l][q] : et_v_[ANTI ? 0 : (l)][q])  // ANTI: the caller negates the sum
     if (!p.g0_batch_stride)
-        for (int e = tid; e < nn; e += 256) G[(e % n) + LD * (e / n)] = p.G0[e];
+        load_tile<256>(p.G0, G, n, LD, tid);
 
     const int S = p.S, nc = p.nc;
     const int n_items = p.batch * p.K * S;
