@@ -48,9 +48,13 @@ def algorithmic_bytes_per_eval(d, m, N, z_dim):
 
 
 def time_steps(launch, steps, warmup, torch, dist):
+    import gc
+
     for _ in range(warmup):
         launch()
     torch.cuda.synchronize()
+    gc.collect()  # a generation-2 collection inside the timed loop (tens of ms over torch's object graph) is host noise, not path time
+    gc.disable()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -65,6 +69,7 @@ def time_steps(launch, steps, warmup, torch, dist):
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    gc.enable()
     return wall, ev0.elapsed_time(ev1) * 1e-3
 
 
@@ -247,10 +252,10 @@ def main():
         "note": "kernel_us is the HIP-event time of one step" + (" (fused kernel + objective + payload kernels + all-reduce)" if workload == "ensemble" else " = one launch of the fused kernel"),
     }
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):  # HBM bytes per launch from the rocprofv3 --pmc passes (scripts/profile.sh), same workload only
+    if os.path.exists(pmc):  # HBM bytes per launch from the rocprofv3 --pmc passes (scripts/profile.sh), per workload
         try:
-            tr = json.load(open(pmc))
-            if tr.get("batch") == units and tr.get("knots") == N and tr.get("workload", "multistart" if units > 1 else "single") == workload:
+            tr = json.load(open(pmc)).get(workload)
+            if tr and tr.get("batch") == units and tr.get("knots") == N:
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -261,7 +266,6 @@ def main():
         out["multistart_share"] = {"evals_per_s": B * st / w8, "us_per_launch_kernel": d8 / st * 1e6, "seeds_per_launch": B,
                                    "hbm_GBps": abytes * B / (d8 / st) / 1e9, "frac_of_hbm_peak": abytes * B / (d8 / st) / 1e9 / HBM_PEAK_GBS,
                                    "kernel": describe(i8["kernel_id"], i8["stream_workgroups"])}  # fmt: skip
-        run_ensemble(B, 20, 5, False)  # (the first pass over a fresh 1 GB value buffer carries one-off host-side latency: not timed)
         we, de, ie, ub = run_ensemble(B, st, 20, False)
         out["ensemble_share"] = {"evals_per_s": B * st / we, "us_per_step_kernel": de / st * 1e6, "members_per_step": B,
                                  "hbm_GBps": ub * B / (de / st) / 1e9, "payload_bytes": ie["payload_bytes"], "all_reduce": ie["all_reduce"],

@@ -308,15 +308,36 @@ __global__ __launch_bounds__(256) void pcl_regularizer_kernel(const double *__re
         if (tid == 0) sr[r] = w;
     }
     __syncthreads();
-    if (g) {
-        for (int i = tid; i < z_dim; i += 256) {
-            double gi = 0.0;
+    if (g) {  // the gradient buffer was zeroed (memset) before this launch: only entries that carry a term are written; terms
+              // that overlap are added in regulariser order by the same thread (a thread owns entry i of every regulariser)
+        for (int r = 0; r < n_regs; ++r) {
+            const PclReg R = regs[r];
+            for (int i = tid; i < R.dim; i += 256)
+                if (R.off + i != dt_off) {
+                    double gi = 0.0;
+                    for (int r2 = 0; r2 < n_regs; ++r2) {  // every regulariser covering this entry (normally just r)
+                        const PclReg R2 = regs[r2];
+                        const int j = R.off + i - R2.off;
+                        if (j >= 0 && j < R2.dim) {
+                            if (r2 < r) {  // an earlier regulariser already wrote the complete sum for this entry
+                                gi = 0.0;
+                                goto next_entry;
+                            }
+                            gi += sr[r2] * Rv[R2.r0 + j] * z[R.off + i];
+                        }
+                    }
+                    g[R.off + i] = gi;
+                next_entry:;
+                }
+        }
+        if (tid == 0) {
+            double gi = gdt;
             for (int r = 0; r < n_regs; ++r) {
                 const PclReg R = regs[r];
-                if (i >= R.off && i < R.off + R.dim) gi += sr[r] * Rv[R.r0 + i - R.off] * z[i];
+                const int j = dt_off - R.off;
+                if (j >= 0 && j < R.dim) gi += sr[r] * Rv[R.r0 + j] * z[dt_off];
             }
-            if (i == dt_off) gi += gdt;
-            g[i] = gi;
+            g[dt_off] = gi;
         }
     }
     if (tid == 0) regval[(long long)tb * N + k] = val;
@@ -388,17 +409,24 @@ __global__ __launch_bounds__(512) void pcl_merit_part_kernel(const double *__res
         if (lane == 0) part[bk * (m + 2) + l] = s;
     }
 }
-__global__ __launch_bounds__(256) void pcl_merit_sum_kernel(const double *__restrict__ part, const double *__restrict__ weights,
+__global__ __launch_bounds__(1024) void pcl_merit_sum_kernel(const double *__restrict__ part, const double *__restrict__ weights,
                                                             double *__restrict__ out, double *__restrict__ phik, int batch, int K, int m,
                                                             int traj_mode) {
     const int set = blockIdx.x;  // TRAJ mode: one output set per trajectory; MEMBERS mode: one set, summed over the members
     const int b_lo = traj_mode ? set : 0, b_hi = traj_mode ? set + 1 : batch;
     double *o = out + (long long)set * (1 + (long long)K * m + K);
     double *ph = phik + (long long)set * K;
-    for (int e = threadIdx.x; e < K * (m + 2); e += 256) {
+    for (int e = threadIdx.x; e < K * (m + 2); e += 1024) {
         const int k = e / (m + 2), l = e - k * (m + 2);
         double t = 0.0;
-        for (int b = b_lo; b < b_hi; ++b) t += (weights ? weights[b] : 1.0) * part[((long long)b * K + k) * (m + 2) + l];
+        for (int b0 = b_lo; b0 < b_hi; b0 += 8) {  // eight members' partials in flight, added in member order
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = b0 + j < b_hi ? (weights ? weights[b0 + j] : 1.0) * part[((long long)(b0 + j) * K + k) * (m + 2) + l] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (b0 + j < b_hi) t += v[j];
+        }
         if (l < m)
             o[1 + (long long)k * m + l] = t;
         else if (l == m)

@@ -1641,7 +1641,9 @@ extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double
         ctx->regs_dirty = false;
     }
     double *member = ctx->dobj, *regval = ctx->dobj + D.batch;
-    // the regulariser kernel writes every gradient row (zeros included) and the per-knot values (zeros without terms)
+    // gradient: zeroed by a memset; the regulariser kernel writes the entries that carry a term (and the per-knot values),
+    // the infidelity kernel adds the terminal-state block
+    if (grad) HIP_TRY(ctx, hipMemsetAsync(grad, 0, (size_t)z_len(ctx) * sizeof(double), ctx->stream));
     hipLaunchKernelGGL(pcl_regularizer_kernel, dim3((unsigned)D.N, (unsigned)nbuf), dim3(256), 0, ctx->stream, Z, (const PclReg *)ctx->dregs,
                        (int)ctx->regs.size(), (const double *)ctx->dreg_R, grad, regval, D.N, D.z_dim, D.dt_off, zs);
     HIP_TRY(ctx, hipGetLastError());
@@ -1687,7 +1689,7 @@ extern "C" int pcl_merit_grad_dev(pcl_ctx *ctx, const double *delta, const doubl
     hipLaunchKernelGGL(pcl_merit_part_kernel, dim3((unsigned)ctx->K, (unsigned)D.batch), dim3(512), 0, ctx->stream, delta, lam, vals, part,
                        ctx->K, ctx->cols, ctx->n, m, jac_per_full(ctx), 2LL * ctx->cols * ctx->n * ctx->n);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(pcl_merit_sum_kernel, dim3((unsigned)sets), dim3(256), 0, ctx->stream, (const double *)part,
+    hipLaunchKernelGGL(pcl_merit_sum_kernel, dim3((unsigned)sets), dim3(1024), 0, ctx->stream, (const double *)part,
                        (const double *)ctx->dweights, out, phik, D.batch, ctx->K, m, traj ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
     return PCL_OK;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output (kernel-trace stats + PMC passes) into small committed summaries."""
+"""Condense rocprofv3 output of scripts/profile.sh (one kernel-trace run + separate PMC runs) into small committed summaries:
+<tag>_kernel_stats.csv, <tag>_summary.json, pmc_traffic.json (HBM bytes per launch of the fused kernel, per bench workload)."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -7,59 +8,61 @@ src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
 summary = {"tag": tag}
 
-def find(pat):
-    return sorted(glob.glob(os.path.join(src, "**", pat), recursive=True))
 
-# kernel stats
-for f in find("*kernel_stats.csv"):
-    rows = list(csv.DictReader(open(f)))
-    summary["kernel_stats"] = rows[:12]
+def find(run, pat):
+    return sorted(glob.glob(os.path.join(src, run, "**", pat), recursive=True))
+
+
+def short(name):
+    return name.split("(")[0][:90]
+
+
+for f in find("trace", "*kernel_stats.csv"):
     with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as o:
         o.write(open(f).read())
-# kernel trace: per-kernel durations (ns)
-for f in find("*kernel_trace.csv"):
-    dur = defaultdict(list)
-    meta = {}
+for f in find("trace", "*kernel_trace.csv"):
+    dur, meta = defaultdict(list), {}
     for r in csv.DictReader(open(f)):
-        name = r.get("Kernel_Name", "?")
-        dur[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-        meta[name] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
-    summary["kernel_trace"] = {k: dict(calls=len(v), avg_us=sum(v) / len(v) / 1e3, min_us=min(v) / 1e3, max_us=max(v) / 1e3, **meta[k]) for k, v in dur.items()}
-# PMC passes
+        name = short(r.get("Kernel_Name", "?"))
+        key = "%s | grid %s" % (name, r.get("Grid_Size_X", r.get("Grid_Size")))
+        dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        meta[key] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size_X", "Grid_Size_X")}
+    summary["kernel_trace"] = {k: dict(calls=len(v), avg_us=sum(v) / len(v) / 1e3, min_us=min(v) / 1e3, max_us=max(v) / 1e3, **meta[k])
+                               for k, v in dur.items() if "pcl_" in k}
 pmc = {}
-for f in find("*counter_collection.csv"):
-    acc = defaultdict(lambda: defaultdict(list))
-    for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for kname, cs in acc.items():
-        for cname, vals in cs.items():
-            pmc.setdefault(kname, {})[cname] = dict(n=len(vals), avg=sum(vals) / len(vals), min=min(vals), max=max(vals))
+for run in sorted(os.listdir(src)):
+    if not os.path.isdir(os.path.join(src, run)) or run == "trace":
+        continue
+    for f in find(run, "*counter_collection.csv"):
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            if "pcl_" not in r["Kernel_Name"]:
+                continue
+            acc["%s | grid %s" % (short(r["Kernel_Name"]), r.get("Grid_Size"))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for kname, cs in acc.items():
+            for cname, vals in cs.items():
+                pmc.setdefault(run, {}).setdefault(kname, {})[cname] = dict(n=len(vals), avg=sum(vals) / len(vals), min=min(vals), max=max(vals))
 summary["pmc_per_dispatch"] = pmc
-# HBM traffic of the dominant kernel (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB and come from
-# separate --pmc passes; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x -> doubled before use.
-main = None
-for kname, v in summary.get("kernel_trace", {}).items():
-    if "pcl_fused_kernel" in kname and (main is None or v["avg_us"] * v["calls"] > summary["kernel_trace"][main]["avg_us"] * summary["kernel_trace"][main]["calls"]):
-        main = kname
-if main and main in pmc and "WRITE_SIZE" in pmc[main] and "FETCH_SIZE" in pmc[main]:
-    wr, rd = pmc[main]["WRITE_SIZE"]["avg"] * 1024.0, pmc[main]["FETCH_SIZE"]["avg"] * 1024.0
-    summary["hbm_traffic"] = dict(kernel=main, write_bytes_per_launch=wr, fetch_bytes_per_launch_raw=rd,
-                                  fetch_bytes_per_launch_corrected=2.0 * rd, hbm_bytes_per_launch=wr + 2.0 * rd,
-                                  avg_kernel_us=summary["kernel_trace"][main]["avg_us"])
-    bench_line = None
-    for f in find("trace.log") + glob.glob(os.path.join(src, "trace.log")):
-        for line in open(f, errors="ignore"):
-            if line.startswith('{"metric"'):
-                bench_line = json.loads(line)
-    if bench_line:
-        summary["bench_line_under_profiler"] = bench_line
-        json.dump(dict(batch=bench_line["config"]["seeds_per_gpu"], knots=100, hbm_bytes_per_launch=wr + 2.0 * rd,
-                       write_bytes=wr, fetch_bytes_corrected=2.0 * rd, source="rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes), " + tag),
-                  open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+# HBM traffic of the fused kernel per workload (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE in KiB from separate
+# --pmc passes; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x -> doubled before use.
+traffic = {}
+for wl, units in (("single", 1), ("multistart", 8)):
+    w, r = pmc.get(wl + "_write", {}), pmc.get(wl + "_fetch", {})
+    kw = [k for k in w if "pcl_fused_kernel_v3" in k and "WRITE_SIZE" in w[k]]
+    kr = [k for k in r if "pcl_fused_kernel_v3" in k and "FETCH_SIZE" in r[k]]
+    if kw and kr:
+        wr, rd = w[kw[0]]["WRITE_SIZE"]["avg"] * 1024.0, r[kr[0]]["FETCH_SIZE"]["avg"] * 1024.0
+        traffic[wl] = dict(workload=wl, batch=units, knots=100, kernel=kw[0], write_bytes=wr, fetch_bytes_raw=rd, fetch_bytes_corrected=2.0 * rd,
+                           hbm_bytes_per_launch=wr + 2.0 * rd, source="rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes), " + tag)
+summary["hbm_traffic"] = traffic
+if traffic:
+    json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+for f in glob.glob(os.path.join(src, "trace.log")):
+    for line in open(f, errors="ignore"):
+        if line.startswith('{"metric"'):
+            summary["bench_line_under_profiler"] = json.loads(line)
 json.dump(summary, open(os.path.join(dst, "%s_summary.json" % tag), "w"), indent=1)
-for k, v in summary.get("kernel_trace", {}).items():
-    print("%-60s calls=%d avg=%.2f us" % (k[:60], v["calls"], v["avg_us"]))
-for k, cs in pmc.items():
-    print(k[:80])
-    for c, v in sorted(cs.items()):
-        print("    %-34s avg=%.4g (n=%d)" % (c, v["avg"], v["n"]))
+for k, v in sorted(summary.get("kernel_trace", {}).items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["calls"]):
+    print("%-100s calls=%4d avg=%9.2f us (min %.2f max %.2f)" % (k[:100], v["calls"], v["avg_us"], v["min_us"], v["max_us"]))
+for wl, t in traffic.items():
+    print(wl, "HBM bytes per launch %.4g (write %.4g, fetch corrected %.4g)" % (t["hbm_bytes_per_launch"], t["write_bytes"], t["fetch_bytes_corrected"]))
