@@ -92,6 +92,7 @@ def main():
     import torch
 
     import piccolo_jl_amd as pa
+    from piccolo_jl_amd import distributed as pd
     from piccolo_jl_amd import synthetic
 
     rank = int(os.environ.get("RANK", "0"))
@@ -184,7 +185,7 @@ def main():
             J.value_and_gradient_dev(Zd, payload[:1], grad)
             c.merit_grad_dev(dd, None, vd, payload[1:])
             if reduce_:
-                dist.all_reduce(payload, op=dist.ReduceOp.SUM)  # RCCL over xGMI, on this stream: the one collective of the path
+                pd.reduce_payload(payload, dist)  # ONE sum all-reduce (RCCL over xGMI, on this stream): the one collective of the path
 
         wall, dev = time_steps(step, steps, warmup, torch, dist if use_dist else None)
         chk = payload.cpu().numpy()

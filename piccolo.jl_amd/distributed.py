@@ -72,6 +72,15 @@ def reduce_merit_and_gradient(phi, g_u, g_dt, dist=None):
     return buf[0], buf[1 : 1 + K * m].view(K, m), buf[1 + K * m :]
 
 
+def reduce_payload(payload, dist=None):
+    """The all-reduce of a sharded ensemble step: ``payload`` = ``[objective | merit | J^T lam on u | on dt]`` as filled on
+    the device by ``pcl_objective_dev`` + ``pcl_merit_grad_dev`` (each rank: its own members, weights w_i of the WHOLE
+    ensemble; the shared regularisers are bound on rank 0 only, or with R / world everywhere).  In place; one sum."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(payload, op=dist.ReduceOp.SUM)
+    return payload
+
+
 def gather_per_unit(values, total, rank, world, dist=None):
     """Multistart (config 5): collect one scalar per seed from every rank into seed order."""
     out = torch.zeros(total, dtype=values.dtype, device=values.device)

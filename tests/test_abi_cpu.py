@@ -148,3 +148,41 @@ def test_quantum_system_validation():
         pa.QuantumSystem(pa.PAULIS["Z"], [np.array([[0, 1], [0, 0]])], [1.0])
     with pytest.raises(ValueError):
         pa.lift_operator(pa.PAULIS["X"], 1, [3, 2])
+
+
+def test_objective_terms_and_subspace_helpers_host_side():
+    """Host-side records of the objective mirror (no GPU): term composition, EmbeddedOperator, subspace indices
+    [REF src/quantum/operators/embedded_operators.jl:627-633 literals, 1-based there]."""
+    assert [i + 1 for i in pa.get_subspace_indices([[0, 1], [0, 1]], [3, 3])] == [1, 2, 4, 5]
+    assert [i + 1 for i in pa.get_subspace_indices([[1], [0, 1]], [3, 3])] == [4, 5]
+    X = pa.PAULIS["X"]
+    op = pa.EmbeddedOperator(X, [0, 1], 3)
+    assert op.operator.shape == (3, 3) and np.array_equal(op.unembed(), X.astype(complex)) and op.operator[2, 2] == 0
+    with pytest.raises(ValueError):
+        pa.EmbeddedOperator(X, [0, 1, 2], 3)
+    s = pa.QuantumSystem(0.5 * pa.PAULIS["Z"], [pa.PAULIS["X"], pa.PAULIS["Y"]], [1.0, 1.0])
+    t = pa.unitary_trajectory(s, np.zeros((2, 6)), np.linspace(0, 1, 6), pa.GATES["X"])
+    J = pa.UnitaryInfidelityObjective(pa.GATES["X"], "Ũ⃗", t, Q=50.0) + pa.QuadraticRegularizer("u", t, 1e-2) + pa.QuadraticRegularizer("du", t, [1.0, 2.0], 0)
+    assert isinstance(J, pa.Objective) and len(J.terms) == 3
+    assert J.terms[1].off == t.components["u"].start and J.terms[2].dt_power == 0 and np.array_equal(J.terms[2].R, [1.0, 2.0])
+    with pytest.raises(RuntimeError):
+        J.value_and_gradient(t)  # not bound to a context: nothing is ever computed on the host
+
+
+def test_config4_synthetic_members_match_the_oracle_definition():
+    """piccolo.jl_amd/synthetic.py (product side, used by bench.py) against SURVEY 8(d)'s definition restated with the oracle:
+    H_drift_i = H_drift + eps_i 2 pi sum_q a_q' a_q, eps_i ~ U(-1e-3, 1e-3), default_rng(2000 + i)."""
+    from oracle import pade_oracle as po
+    from piccolo_jl_amd import synthetic
+
+    base = po.config_system(3)
+    a = po.annihilate(3)
+    num = sum(po.lift_operator(a.conj().T @ a, q, [3, 3, 3]) for q in (1, 2, 3))
+    members = synthetic.config4_members(5, 3)
+    for j, s in enumerate(members):
+        eps = np.random.default_rng(2000 + 5 + j).uniform(-1e-3, 1e-3)
+        ref = po.System(base.H_drift + eps * 2 * np.pi * num, base.H_drives, base.drive_bounds)
+        assert np.allclose(s.G_drift, ref.G_drift, rtol=0, atol=1e-13)
+        assert np.allclose(s.G_drives_array(), np.array(ref.G_drives), rtol=0, atol=1e-13)
+    tr = synthetic.synthetic_ensemble(members[:2], 4, seed=1)
+    assert list(tr.components)[:3] == ["Ũ⃗1", "Ũ⃗2", "Δt"] and tr.dim == 2 * 1458 + 2 + 18

@@ -57,11 +57,19 @@ def _worker(rank, world, port, out):
     delta, vals = _member_outputs(systems, lay, Z, xd, mine)
     w = torch.tensor([1.0 + 0.1 * i for i in mine], dtype=torch.float64)
     phi, gu, gdt = pd.constraint_merit_and_shared_gradient(delta, vals, len(mine), lay.K, lay.d, lay.m, w)
+    # the objective part of the payload: every rank sums ITS members with the weights of the whole ensemble; the shared
+    # regularisers enter on rank 0 only
+    wall = np.array([1.0 + 0.1 * i for i in range(M)]) / M
+    goal = po.PAULIS["X"]
+    regs = [(lay.u_off, lay.m, 0.3, 2)] if rank == 0 else []
+    Jr, _ = po.sampling_objective(Z, lay, [i * xd for i in mine], goal, wall[mine], 100.0, regs)
+    payload = torch.cat([torch.tensor([Jr], dtype=torch.float64), phi.reshape(1), gu.reshape(-1), gdt.reshape(-1)])
+    pd.reduce_payload(payload, d_)
     phi, gu, gdt = pd.reduce_merit_and_gradient(phi, gu, gdt, d_)
     per_unit = torch.tensor([float(i) for i in mine], dtype=torch.float64)
     allv = pd.gather_per_unit(per_unit, M, rank, world, d_)
     if rank == 0:
-        torch.save(dict(phi=phi, gu=gu, gdt=gdt, allv=allv), out)
+        torch.save(dict(phi=phi, gu=gu, gdt=gdt, allv=allv, payload=payload), out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,6 +108,12 @@ def test_world2_gloo_reduce_equals_unsharded(tmp_path):
     assert torch.allclose(got["gu"], gu, rtol=1e-12, atol=1e-14)
     assert torch.allclose(got["gdt"], gdt, rtol=1e-12, atol=1e-14)
     assert torch.equal(got["allv"], torch.arange(M, dtype=torch.float64))
+    # objective of the whole ensemble = sum of the ranks' shares (weights of the whole ensemble, regularisers once)
+    wall = np.array([1.0 + 0.1 * i for i in range(M)]) / M
+    J_all, _ = po.sampling_objective(Z, lay, [i * xd for i in range(M)], po.PAULIS["X"], wall, 100.0, [(lay.u_off, lay.m, 0.3, 2)])
+    assert abs(float(got["payload"][0]) - J_all) < 1e-12 * max(1.0, abs(J_all))
+    assert got["payload"].numel() == 2 + lay.K * lay.m + lay.K
+    assert torch.allclose(got["payload"][1], phi, rtol=1e-13, atol=0) and torch.allclose(got["payload"][2 : 2 + lay.K * lay.m].view(lay.K, lay.m), gu, rtol=1e-12, atol=1e-14)
     # the reduced gradient is the gradient of the merit function w.r.t. the shared controls (finite differences)
     def merit(Zp):
         d_, _ = _member_outputs(systems, lay, Zp, xd, range(M))
