@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
             if (q < p.n_upos) {
                 const int pos = p.upos[q];
                 un_idx[r] = (pos % n) + LD * (pos / n);
-                un_g0[r] = p.G0[pos];
+                un_g0[r] = p.ug0[q];  // drift at the pattern entry (table: no load that depends on upos); per-member drifts are read per member
 #pragma unroll
                 for (int w = 0; w < WUR; ++w) {
                     un_l[r][w] = p.uell_l[q * WUR + w];
@@ -119,11 +119,29 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
         // ---- phase 0: G(u_k) on the union pattern; this wave's [S | D] ---------------------------------------------------
         if (p.g0_batch_stride && drift_b != b) {  // per-member drift: the tile (off the union pattern) changes with the member
             const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
-            for (int e = tid; e < nn; e += 256)
-                if (p.umap[e] < 0) G[(e % n) + LD * (e / n)] = G0b[e];
+            for (int e0 = tid; e0 < nn; e0 += 256 * 8) {  // eight independent loads in flight per thread
+                double v[8];
+                int um[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = e0 + 256 * j;
+                    um[j] = e < nn ? p.umap[e] : 0;
+                    v[j] = e < nn ? G0b[e] : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int e = e0 + 256 * j;
+                    if (um[j] < 0) G[(e % n) + LD * (e / n)] = v[j];
+                }
+            }
+            if (WU > 0) {
+#pragma unroll
+                for (int r = 0; r < PCL_NUE_EV; ++r)
+                    if (un_idx[r] >= 0) un_g0[r] = G0b[p.upos[tid + 256 * r]];
+            }
             drift_b = b;
         }
-        if (WU > 0 && !p.g0_batch_stride) {
+        if (WU > 0) {
 #pragma unroll
             for (int r = 0; r < PCL_NUE_EV; ++r)
                 if (un_idx[r] >= 0) {
@@ -216,29 +234,32 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
         // ---- phase 2: row tile `wave` of G (G D), all column tiles; delta = P + c2 G (G D) in place ---------------------------
         if (wave * 16 < n) {
             const double *Ap = G + wave * 16 + li + LD * lk;
-            double4_t a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
-            double an = 0.0, b0n = 0.0, b1n = 0.0;
-            if (kfull > 0) {
-                an = Ap[0];
-                b0n = Bp2[0][0];
-                b1n = Bp2[1][0];
-            }
-            for (int ks = 0; ks < kfull; ++ks) {
-                const double a = an, b0 = b0n, b1 = b1n;
-                if (ks + 1 < kfull) {
-                    an = Ap[LD * 4 * (ks + 1)];
-                    b0n = Bp2[0][4 * (ks + 1)];
-                    b1n = Bp2[1][4 * (ks + 1)];
+            // k-step ks into accumulator ks mod 2 of each column tile: four independent chains (a dependent f64 MFMA waits
+            // ~235 cycles for its accumulator, four in flight keep the pipe issuing every 64)
+            double4_t q0[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, q1[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+            for (int ks0 = 0; ks0 < kfull; ks0 += 2) {
+                double a[2], b0[2], b1[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bool ok = ks0 + j < kfull;
+                    a[j] = ok ? Ap[LD * 4 * (ks0 + j)] : 0.0;
+                    b0[j] = ok ? Bp2[0][4 * (ks0 + j)] : 0.0;
+                    b1[j] = ok ? Bp2[1][4 * (ks0 + j)] : 0.0;
                 }
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, a0, 0, 0, 0);
-                if (ct_n > 1) a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, a1, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (ks0 + j < kfull) {
+                        q0[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], b0[j], q0[j], 0, 0, 0);
+                        if (ct_n > 1) q1[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], b1[j], q1[j], 0, 0, 0);
+                    }
             }
             if (krem) {
                 const bool ok = lk < krem;
                 const double a = ok ? Ap[LD * 4 * kfull] : 0.0;
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ok ? Bp2[0][4 * kfull] : 0.0, a0, 0, 0, 0);
-                if (ct_n > 1) a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ok ? Bp2[1][4 * kfull] : 0.0, a1, 0, 0, 0);
+                q0[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ok ? Bp2[0][4 * kfull] : 0.0, q0[0], 0, 0, 0);
+                if (ct_n > 1) q1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ok ? Bp2[1][4 * kfull] : 0.0, q1[0], 0, 0, 0);
             }
+            const double4_t a0 = q0[0] + q0[1], a1 = q1[0] + q1[1];
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct)
                 if (b2ok[ct]) {

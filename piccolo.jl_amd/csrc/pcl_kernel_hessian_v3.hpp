@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512, 2) void pcl_hess_kernel_v3(const KParams p) {
         if (q < p.n_upos) {
             const int pos = p.upos[q];
             un_idx[r] = (pos % n) + LD * (pos / n);
-            un_g0[r] = p.G0[pos];  // (shared drift; a per-member drift is read per member below)
+            un_g0[r] = p.ug0[q];  // drift at the pattern entry (table: no load that depends on upos); per-member drifts are read per member
             for (int w = 0; w < p.uell_w; ++w) {  // host guarantees uell_w <= 2
                 un_l[r][w] = p.uell_l[q * p.uell_w + w];
                 un_v[r][w] = p.uell_v[q * p.uell_w + w];

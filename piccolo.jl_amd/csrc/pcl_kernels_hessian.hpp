@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void pcl_hess_kernel(const KParams p) {
 //         <M,(G_j G + G G_j) D> = <Q_j,D> + <A1,E_j>
 // then, once per item: A2 = G^T A1 for all the slice's columns in ONE matrix-core pass (wave w = row tile w),
 // the d2/dh dX vectors, <A2,D>, and a fixed-order reduction lane -> wave -> workgroup -> (slices of the interval,
-// summed by the last slice to arrive: partial sums in `hpart`, arrival counter in `hcnt`) -> deterministic.
+// summed by the last slice to arrive: partial sums in `hpart`, acquire-release arrival counter in `hcnt`) -> deterministic.
 // No G^2, no G D product: every contraction with D is moved onto M's side.
 // LDS map (doubles): G [LD*n] | A1s [LD*16] | A2s [LD*16] | Ds [LD*16] | per wave Mw [LD*16] | wsum [4][NSC] | wsum2 [4] | flag
 // ------------------------------------------------------------------------------------------
@@ -480,8 +480,8 @@ __global__ __launch_bounds__(256, 2) void pcl_hess_kernel_v2(const KParams p) {
             if (S == 1)
                 H[tid] = tot;
             else {
-                // agent-scope (write-through) store of this slice's partial entry; it has left the CU before the arrival
-                // counter moves.  No release fence: that would write back this XCD's whole L2 (full of Hessian output).
+                // agent-scope (write-through) store of this slice's partial entry; drained before the barrier below, so it
+                // has left the CU before the arrival counter moves
                 __hip_atomic_store(p.hpart + (bk * S + s) * NSC + tid, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -489,7 +489,11 @@ __global__ __launch_bounds__(256, 2) void pcl_hess_kernel_v2(const KParams p) {
         unsigned int ticket = 0;
         if (S > 1) {
             __syncthreads();
-            if (tid == 0) ticket = __hip_atomic_fetch_add(p.hcnt + bk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // release (this slice's partials, ordered before by the barrier) / acquire (the other slices' partials, for the
+            // last arriver) on the arrival counter: the pairing the HIP memory model asks for.  This kernel is the fallback
+            // of kernel 3 now (shapes without an instance; S > 1 only for d > 16), so the price of the release -- a
+            // write-back of this XCD's dirty L2 lines per item -- no longer sits on the benchmarked path.
+            if (tid == 0) ticket = __hip_atomic_fetch_add(p.hcnt + bk, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         }
         // the d2/dh dX vectors go out while the counter's round trip is in flight
         for (int e = tid; e < nce * n; e += 256) {
