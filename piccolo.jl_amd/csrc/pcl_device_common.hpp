@@ -156,7 +156,7 @@ __device__ __forceinline__ void store2(double *p, double a, double b, bool nt) {
 // Column-major n x n matrix in memory -> LDS tile with leading dimension LD, by NT threads.  All global loads of a block of
 // eight iterations are issued before the first LDS write (written as load -> store per iteration, the compiler waits for every
 // load in turn: one dependent round trip to L2 / HBM per iteration).
-template <int NT>
+template <int NT, bool TRANSPOSE = false>  // TRANSPOSE: dst[col + LD*row] (the row-contiguous layout of a conflict-free MFMA a operand)
 __device__ __forceinline__ void load_tile(const double *__restrict__ src, double *__restrict__ dst, int n, int LD, int tid) {
     const int nn = n * n;
     for (int e0 = tid; e0 < nn; e0 += NT * 8) {
@@ -166,7 +166,7 @@ __device__ __forceinline__ void load_tile(const double *__restrict__ src, double
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int e = e0 + NT * j;
-            if (e < nn) dst[(e % n) + LD * (e / n)] = v[j];
+            if (e < nn) dst[TRANSPOSE ? (e / n) + LD * (e % n) : (e % n) + LD * (e / n)] = v[j];
         }
     }
 }

@@ -15,7 +15,8 @@
 //                     delta = P + (h^2/12) G (G D), in place
 //   phase 3  wave w : its chunk's columns of delta are contiguous in memory: 16-byte stores
 // Matrix-core work per interval: 4 x 14 x 4 + 4 x 14 x 2 = 336 MFMAs at d = 27 (the minimum for 16-wide tiles).
-// LDS map (doubles): G [LD*n] | per wave M [LD*16] | us [2][m+1]
+// LDS map (doubles): G^T [LD*n] (G stored row-contiguous: G[i][k] at k + LD*i, the conflict-free layout of the MFMA a
+// operand -- the column-major layout costs a 2-way bank conflict on 6-10 of every 16 lanes) | per wave M [LD*16] | us [2][m+1]
 // ------------------------------------------------------------------------------------------
 #define PCL_NUE_EV 4  // union-pattern entries per thread in registers (256 threads: n_upos <= 1024)
 
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
 
     // ---- launch-invariant state: drift tile, this thread's union-pattern entries ---------------------------------------
     if (!p.g0_batch_stride)
-        load_tile<256>(p.G0, G, n, LD, tid);
+        load_tile<256, true>(p.G0, G, n, LD, tid);
     constexpr int WUR = WU > 0 ? WU : 1;
     int un_idx[PCL_NUE_EV];
     double un_g0[PCL_NUE_EV];
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
             }
             if (q < p.n_upos) {
                 const int pos = p.upos[q];
-                un_idx[r] = (pos % n) + LD * (pos / n);
+                un_idx[r] = (pos / n) + LD * (pos % n);
                 un_g0[r] = p.ug0[q];  // drift at the pattern entry (table: no load that depends on upos); per-member drifts are read per member
 #pragma unroll
                 for (int w = 0; w < WUR; ++w) {
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int e = e0 + 256 * j;
-                    if (um[j] < 0) G[(e % n) + LD * (e / n)] = v[j];
+                    if (um[j] < 0) G[(e / n) + LD * (e % n)] = v[j];
                 }
             }
             if (WU > 0) {
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
                 double g = G0b[pos];
                 const double *cf = p.ucoef + (long long)q * m;
                 for (int l = 0; l < m; ++l) g += usc[l] * cf[l];
-                G[(pos % n) + LD * (pos / n)] = g;
+                G[(pos / n) + LD * (pos % n)] = g;
             }
         }
         if (lane < n) {
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
 #pragma unroll
             for (int t = 0; t < PCL_MAXRT; ++t) {
                 rok[t] = t * 16 < n;
-                Ap[t] = G + (rok[t] ? t * 16 : 0) + li + LD * lk;
+                Ap[t] = G + lk + LD * ((rok[t] ? t * 16 : 0) + li);
                 acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
             }
             double an[PCL_MAXRT], bn = 0.0;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
                 for (int t = 0; t < PCL_MAXRT; ++t) a[t] = an[t];
                 if (ks + 1 < kfull) {
 #pragma unroll
-                    for (int t = 0; t < PCL_MAXRT; ++t) an[t] = Ap[t][LD * 4 * (ks + 1)];
+                    for (int t = 0; t < PCL_MAXRT; ++t) an[t] = Ap[t][4 * (ks + 1)];
                     bn = Bp[4 * (ks + 1)];
                 }
 #pragma unroll
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
 #pragma unroll
                 for (int t = 0; t < PCL_MAXRT; ++t)
                     if (rok[t]) {
-                        const double a = ok ? Ap[t][LD * 4 * kfull] : 0.0;
+                        const double a = ok ? Ap[t][4 * kfull] : 0.0;
                         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[t], 0, 0, 0);
                     }
             }
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
         __syncthreads();
         // ---- phase 2: row tile `wave` of G (G D), all column tiles; delta = P + c2 G (G D) in place ---------------------------
         if (wave * 16 < n) {
-            const double *Ap = G + wave * 16 + li + LD * lk;
+            const double *Ap = G + lk + LD * (wave * 16 + li);
             // k-step ks into accumulator ks mod 2 of each column tile: four independent chains (a dependent f64 MFMA waits
             // ~235 cycles for its accumulator, four in flight keep the pipe issuing every 64)
             double4_t q0[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, q1[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const bool ok = ks0 + j < kfull;
-                    a[j] = ok ? Ap[LD * 4 * (ks0 + j)] : 0.0;
+                    a[j] = ok ? Ap[4 * (ks0 + j)] : 0.0;
                     b0[j] = ok ? Bp2[0][4 * (ks0 + j)] : 0.0;
                     b1[j] = ok ? Bp2[1][4 * (ks0 + j)] : 0.0;
                 }
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256, 3) void pcl_eval_kernel(const KParams p) {
             }
             if (krem) {
                 const bool ok = lk < krem;
-                const double a = ok ? Ap[LD * 4 * kfull] : 0.0;
+                const double a = ok ? Ap[4 * kfull] : 0.0;
                 q0[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ok ? Bp2[0][4 * kfull] : 0.0, q0[0], 0, 0, 0);
                 if (ct_n > 1) q1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ok ? Bp2[1][4 * kfull] : 0.0, q1[0], 0, 0, 0);
             }
