@@ -74,7 +74,7 @@ typedef enum pcl_status {
     PCL_EHIP = -3,    /* HIP runtime error (incl. "no GPU") */
     PCL_ERCCL = -4,   /* RCCL error */
     PCL_ESHAPE = -5,  /* shape outside what the kernels support (d > PCL_MAX_D, ...) */
-    PCL_ENOTIMPL = -6 /* valid request the library does not implement (e.g. an odd pade_order, the Hessian at order != 4) */
+    PCL_ENOTIMPL = -6 /* valid request the library does not implement (e.g. an odd pade_order) */
 } pcl_status;
 
 #define PCL_MAX_D 32 /* n = 2d <= 64: G(u_k), G^2 and the column tiles stay LDS-resident */
@@ -240,7 +240,8 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *       "contiguous"         kernel 3: -1 auto by launch size | 0 round-robin column slices | 1 equal contiguous column ranges
  *       "stream_workgroups"  kernel 3, contiguous: -1 auto (half) | 0 both roles in every workgroup | n stream-role workgroups
  *       "cols_per_slice"     state columns per work item (0 = heuristic; forces the round-robin split in kernel 3)
- *       "hess_kernel"        0 auto | 1 one workgroup per interval | 2 persistent wave-synchronous kernel
+ *       "hess_kernel"        0 auto | 1 one workgroup per interval | 2 persistent, column chunks (fallback) | 3 one workgroup per
+ *                            interval, jobs split by drive (default for d >= 12); Pade orders other than 4 always run the general-order Hessian kernel
  *       "general_pade_kernel" 1: run the general-order kernel for pade_order 4 too (cross-check)
  *       "general_threads" (256 / 512), "general_two_step" (1: unique tiles + expansion kernel)   general-order kernel
  *       "jit"                1 (default): shapes outside the static instance table are compiled on first use with hiprtc

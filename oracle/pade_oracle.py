@@ -887,6 +887,64 @@ def pade4_hessian_values(Z, mu, lay: Layout, G0, Gj, x_off=None):
     return out
 
 
+def pade_hessian_values(Z, mu, lay: Layout, G0, Gj, order=4, x_off=None):
+    """grad^2 (sum_k mu_k^T delta_k) for ANY diagonal Pade order p = 2q, same value order as ``pade4_hessian_values``.
+    With T_j = c_j h^j, T'_j = j c_j h^(j-1), T''_j = j (j-1) c_j h^(j-2), Y_j = (-1)^j X_{k+1} - X_k and M = mu_k (n x d):
+        W_0 = M,  W_j = G^T W_{j-1}                                         ((G^j)^T M)
+        V_{l,0} = 0,  V_{l,j} = G^T V_{l,j-1} + G_l^T W_{j-1}               ((d_l G^j)^T M)
+        U_{il,j} = G^T U_{il,j-1} + G_l^T V_{i,j-1} + G_i^T V_{l,j-1}       ((d_i d_l G^j)^T M;  0 for j < 2)
+        (u_i,u_l): sum_j T_j <U_{il,j}, Y_j>     (h,u_l): sum_j T'_j <V_{l,j}, Y_j>     (h,h): sum_j T''_j <W_j, Y_j>
+        d2/du_l dX_{k+1} = sum_j T_j (-1)^j V_{l,j},  d2/du_l dX_k = -sum_j T_j V_{l,j}
+        d2/dh dX_{k+1}   = sum_j T'_j (-1)^j W_j,      d2/dh dX_k   = -sum_j T'_j W_j
+    (delta is linear in X: no X-X block).  Order 4 reproduces ``pade4_hessian_values`` (tests/test_oracle_pins.py)."""
+    c = pade_coeffs(order)
+    q = order // 2
+    d, n, m, xd = lay.C, lay.n, lay.m, lay.x_dim
+    per = hess_nnz_per_interval(lay)
+    out = np.empty((lay.K, per))
+    ip = lambda A, B: float(np.sum(A * B))
+    for k in range(lay.K):
+        G = G0 + np.tensordot(lay.u(Z, k), Gj, axes=1) if m else G0
+        h = lay.dt(Z, k)
+        Xn, Xc = lay.X(Z, k + 1, x_off), lay.X(Z, k, x_off)
+        M = mu[k].reshape(d, n).T
+        Y = [((-1) ** j) * Xn - Xc for j in range(q + 1)]
+        T = [c[j] * h**j for j in range(q + 1)]
+        T1 = [j * c[j] * h ** (j - 1) if j >= 1 else 0.0 for j in range(q + 1)]
+        T2 = [j * (j - 1) * c[j] * h ** (j - 2) if j >= 2 else 0.0 for j in range(q + 1)]
+        W = [M]
+        V = [[np.zeros_like(M) for _ in range(m)]]
+        U = [{(i, l): np.zeros_like(M) for i in range(m) for l in range(i + 1)}]
+        for j in range(1, q + 1):
+            W.append(G.T @ W[j - 1])
+            V.append([G.T @ V[j - 1][l] + Gj[l].T @ W[j - 1] for l in range(m)])
+            U.append({(i, l): G.T @ U[j - 1][(i, l)] + Gj[l].T @ V[j - 1][i] + Gj[i].T @ V[j - 1][l] for i in range(m) for l in range(i + 1)})
+        p = 0
+        for i in range(m):
+            for l in range(i + 1):
+                out[k, p] = sum(T[j] * ip(U[j][(i, l)], Y[j]) for j in range(2, q + 1))
+                p += 1
+        for l in range(m):
+            out[k, p] = sum(T1[j] * ip(V[j][l], Y[j]) for j in range(1, q + 1))
+            p += 1
+        out[k, p] = sum(T2[j] * ip(W[j], Y[j]) for j in range(2, q + 1))
+        p += 1
+        for l in range(m):
+            A = -sum(T[j] * V[j][l] for j in range(1, q + 1))
+            out[k, p : p + xd] = A.T.reshape(-1)
+            p += xd
+        A = -sum(T1[j] * W[j] for j in range(1, q + 1))
+        out[k, p : p + xd] = A.T.reshape(-1)
+        p += xd
+        for l in range(m):
+            A = sum(T[j] * (-1) ** j * V[j][l] for j in range(1, q + 1))
+            out[k, p : p + xd] = A.T.reshape(-1)
+            p += xd
+        A = sum(T1[j] * (-1) ** j * W[j] for j in range(1, q + 1))
+        out[k, p : p + xd] = A.T.reshape(-1)
+    return out
+
+
 def hessian_dense(vals, lay: Layout, x_off=None):
     rows, cols = hess_structure(lay, x_off)
     nv = lay.z_dim * lay.N

@@ -143,6 +143,164 @@ __global__ __launch_bounds__(256) void pcl_hess_kernel(const KParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Hessian of the Lagrangian at ANY diagonal Pade order p = 2q <= 10 (correctness first: one workgroup per (b, k), column
+// chunks, every product through gemm_lds).  With T_j = c_j h^j, T'_j = j c_j h^(j-1), T''_j = j (j-1) c_j h^(j-2),
+// Y_j = (-1)^j X_{k+1} - X_k, M = mu_k:
+//     W_j = G^T W_{j-1} (W_0 = M),   V_{l,j} = G^T V_{l,j-1} + G_l^T W_{j-1},   U_{il,j} = G^T U_{il,j-1} + G_l^T V_{i,j-1} + G_i^T V_{l,j-1}
+//     (u_i,u_l): sum_j T_j <U_{il,j},Y_j>   (h,u_l): sum_j T'_j <V_{l,j},Y_j>   (h,h): sum_j T''_j <W_j,Y_j>
+//     d2/du_l dX_{k+1} = sum_j T_j (-1)^j V_{l,j},  d2/du_l dX_k = -sum_j T_j V_{l,j},  d2/dh dX_{k+1} = sum_j T'_j (-1)^j W_j,  d2/dh dX_k = -sum_j T'_j W_j
+// Levels j = 1..q are walked with rolling buffers (previous / current level); the scalar entries are accumulated per wave and
+// level (wave sums, one row of `red` per wave) and added over the waves in order at the end: deterministic.
+// LDS map (doubles, LDc = LD*nc): G | Xn | Xc | Wa | Wb | H4a | H6a | Va[m] | Vb[m] | H3a[m] | H5a[m] | Ua[np] | Ub[np] | us | red[nw][nscal]
+// ------------------------------------------------------------------------------------------
+template <bool MFMA>
+__global__ __launch_bounds__(256) void pcl_hess_general_kernel(const KParams p) {
+    extern __shared__ double lds[];
+    const int n = p.n, d = p.cols, m = p.m, LD = p.LD, nc = p.nc, q = p.q;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int k = blockIdx.x % p.K, b = blockIdx.x / p.K;
+    const long long xd = (long long)n * d;
+    const int LDc = LD * nc;
+    const int npair = m * (m + 1) / 2, nscal = (m + 1) * (m + 2) / 2;
+    const int nw = nth >> 6, wv = tid >> 6, lane = tid & 63;
+
+    double *G = lds;
+    double *Xn = G + LD * n, *Xc = Xn + LDc, *Wa = Xc + LDc, *Wb = Wa + LDc, *H4a = Wb + LDc, *H6a = H4a + LDc;
+    double *Va = H6a + LDc, *Vb = Va + m * LDc, *H3a = Vb + m * LDc, *H5a = H3a + m * LDc;
+    double *Ua = H5a + m * LDc, *Ub = Ua + npair * LDc;
+    double *us = Ub + npair * LDc;
+    double *red = us + 8 + m;  // [nw][nscal]
+
+    const double *Zb = p.Z + (long long)b * p.z_batch_stride;
+    const double *zk = Zb + (long long)k * p.z_dim;
+    const double *zn = zk + p.z_dim;
+    const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+    const double h = zk[p.dt_off];
+    const long long bk = (long long)b * p.K + k;
+    const double *mu = p.mu + bk * xd;
+    double *H = p.hess + bk * p.hess_per;
+    double *H3 = H + nscal, *H4 = H3 + (long long)m * xd, *H5 = H4 + xd, *H6 = H5 + (long long)m * xd;
+
+    build_G(p, p.G0 + (long long)b * p.g0_batch_stride, zk, G, us);
+    for (int e = tid; e < nw * nscal; e += nth) red[e] = 0.0;
+
+    for (int c0 = 0; c0 < d; c0 += nc) {
+        const int nce = min(nc, d - c0);
+        const int ne = nce * n;  // elements of a chunk array: e -> (row e % n, column e / n)
+        __syncthreads();  // previous chunk fully consumed (and G / red initialised)
+        for (int e = tid; e < ne; e += nth) {
+            const int c = e / n, i = e % n, idx = i + LD * c;
+            const long long g = (long long)(c0 + c) * n + i;
+            Xn[idx] = zn[x_off + g];
+            Xc[idx] = zk[x_off + g];
+            Wa[idx] = mu[g];  // W_0 = M
+            H4a[idx] = H6a[idx] = 0.0;
+        }
+        for (int e = tid; e < m * ne; e += nth) {
+            const int a = e / ne, r = e - a * ne, idx = a * LDc + (r % n) + LD * (r / n);
+            Va[idx] = 0.0;  // V_{l,0} = 0
+            H3a[idx] = H5a[idx] = 0.0;
+        }
+        for (int e = tid; e < npair * ne; e += nth) {
+            const int a = e / ne, r = e - a * ne;
+            Ua[a * LDc + (r % n) + LD * (r / n)] = 0.0;  // U_{il,0} = 0
+        }
+        double *Wp = Wa, *Wc = Wb, *Vp = Va, *Vc = Vb, *Up = Ua, *Uc = Ub;
+        double hj1 = 1.0, hj2 = 0.0;  // h^(j-1), h^(j-2)
+        for (int j = 1; j <= q; ++j) {
+            __syncthreads();
+            // dense parts of level j: G^T times level j-1 (arrays of one family are consecutive column blocks)
+            gemm_lds<MFMA, true>(G, LD, Wp, LD, Wc, LD, n, nc, n);
+            if (m > 0) gemm_lds<MFMA, true>(G, LD, Vp, LD, Vc, LD, n, m * nc, n);
+            if (npair > 0 && j >= 2) gemm_lds<MFMA, true>(G, LD, Up, LD, Uc, LD, n, npair * nc, n);
+            __syncthreads();
+            // sparse parts (CSC columns of G_l = rows of G_l^T): V_{l,j} += G_l^T W_{j-1};  U_{il,j} (+)= G_l^T V_{i,j-1} + G_i^T V_{l,j-1}
+            for (int e = tid; e < m * ne; e += nth) {
+                const int l = e / ne, r = e - l * ne, i = r % n, c = r / n;
+                const int *cp = p.csc_ptr + l * (n + 1);
+                double a = 0.0;
+                for (int t = cp[i]; t < cp[i + 1]; ++t) a += p.csc_val[t] * Wp[p.csc_row[t] + LD * c];
+                Vc[l * LDc + i + LD * c] += a;
+            }
+            for (int e = tid; e < npair * ne; e += nth) {
+                const int pr = e / ne, r = e - pr * ne, i = r % n, c = r / n;
+                int pi = 0;
+                while ((pi + 1) * (pi + 2) / 2 <= pr) ++pi;  // pair index pr = pi (pi + 1) / 2 + pl, pl <= pi
+                const int pl = pr - pi * (pi + 1) / 2;
+                const int *ci = p.csc_ptr + pi * (n + 1), *cl = p.csc_ptr + pl * (n + 1);
+                double a = 0.0;
+                for (int t = cl[i]; t < cl[i + 1]; ++t) a += p.csc_val[t] * Vp[pi * LDc + p.csc_row[t] + LD * c];
+                for (int t = ci[i]; t < ci[i + 1]; ++t) a += p.csc_val[t] * Vp[pl * LDc + p.csc_row[t] + LD * c];
+                double *u = Uc + pr * LDc + i + LD * c;
+                *u = (j >= 2 ? *u : 0.0) + a;
+            }
+            __syncthreads();
+            // contributions of level j
+            const double cj = p.pc[j], Tj = cj * hj1 * h, T1 = j * cj * hj1, T2 = j >= 2 ? j * (j - 1) * cj * hj2 : 0.0;
+            const double sg = (j & 1) ? -1.0 : 1.0;
+            for (int e = tid; e < ne; e += nth) {
+                const int idx = (e % n) + LD * (e / n);
+                H4a[idx] += T1 * Wc[idx];
+                H6a[idx] += T1 * sg * Wc[idx];
+            }
+            for (int e = tid; e < m * ne; e += nth) {
+                const int l = e / ne, r = e - l * ne, idx = l * LDc + (r % n) + LD * (r / n);
+                H3a[idx] += Tj * Vc[idx];
+                H5a[idx] += Tj * sg * Vc[idx];
+            }
+            // scalars: entry -> sum over the chunk's elements of (family array) * Y_j, Y_j = sg Xn - Xc
+            for (int en = 0; en < nscal; ++en) {
+                const double *A;
+                double coef;
+                if (en < npair) {
+                    A = Uc + en * LDc;
+                    coef = j >= 2 ? Tj : 0.0;
+                } else if (en < npair + m) {
+                    A = Vc + (en - npair) * LDc;
+                    coef = T1;
+                } else {
+                    A = Wc;
+                    coef = T2;
+                }
+                double v = 0.0;
+                if (coef != 0.0)
+                    for (int e = tid; e < ne; e += nth) {
+                        const int idx = (e % n) + LD * (e / n);
+                        v += A[idx] * (sg * Xn[idx] - Xc[idx]);
+                    }
+                v = wave_sum(v);
+                if (lane == 0) red[wv * nscal + en] += coef * v;
+            }
+            hj2 = hj1;
+            hj1 *= h;
+            double *t;
+            t = Wp, Wp = Wc, Wc = t;
+            t = Vp, Vp = Vc, Vc = t;
+            t = Up, Up = Uc, Uc = t;
+        }
+        __syncthreads();
+        for (int e = tid; e < m * ne; e += nth) {
+            const int l = e / ne, r = e - l * ne, idx = l * LDc + (r % n) + LD * (r / n);
+            const long long o = (long long)l * xd + (long long)c0 * n + r;
+            H3[o] = -H3a[idx];
+            H5[o] = H5a[idx];
+        }
+        for (int e = tid; e < ne; e += nth) {
+            const int idx = (e % n) + LD * (e / n);
+            const long long o = (long long)c0 * n + e;
+            H4[o] = -H4a[idx];
+            H6[o] = H6a[idx];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < nscal; e += nth) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += red[w * nscal + e];
+        H[e] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Hessian-of-Lagrangian kernel, version 2 (default when every drive row / column has <= EW entries and m <= 6):
 // persistent workgroups (2 per CU, 4 wavefronts each) over work items (b, k, slice of <= 16 state columns).
 // Per item the four waves work wave-synchronously on chunks of NCW = 16/(m+1) columns:

@@ -1134,8 +1134,29 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
     p.mu = mu;
     p.hess = hess;
     const bool mf = ctx->opt_use_mfma != 0;
-    if (ctx->desc.pade_order != 4)
-        return fail(ctx, PCL_ENOTIMPL, "the Hessian of the Lagrangian is implemented for pade_order 4 only (have %d)", ctx->desc.pade_order);
+    if (ctx->desc.pade_order != 4 || ctx->opt_general) {
+        // any diagonal Pade order (and the cross-check of the order-4 kernels): the general-order kernel, correctness first
+        p.q = ctx->desc.pade_order / 2;
+        double f[16];
+        f[0] = 1.0;
+        for (int i = 1; i < 16; ++i) f[i] = f[i - 1] * i;
+        for (int j = 0; j <= p.q; ++j) p.pc[j] = f[2 * p.q - j] * f[p.q] / (f[2 * p.q] * f[j] * f[p.q - j]);
+        const size_t npair = (size_t)p.m * (p.m + 1) / 2, nsc = (size_t)(p.m + 1) * (p.m + 2) / 2;
+        auto bytes = [&](int nc) { return ((size_t)p.LD * p.n + (6 + 4 * (size_t)p.m + 2 * npair) * p.LD * nc + 8 + p.m + 4 * nsc) * sizeof(double); };
+        p.nc = p.cols;
+        while (p.nc > 1 && bytes(p.nc) > (size_t)ctx->max_lds) p.nc = (p.nc + 1) / 2;
+        const size_t ldsg = bytes(p.nc);
+        if (ldsg > (size_t)ctx->max_lds)
+            return fail(ctx, PCL_ESHAPE, "general-order Hessian kernel needs %zu B of LDS (> %d) for d=%d, m=%d", ldsg, ctx->max_lds, p.d, p.m);
+        const long long gridg = (long long)p.batch * p.K;
+        if (gridg > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+        auto kg = mf ? pcl_hess_general_kernel<true> : pcl_hess_general_kernel<false>;
+        HIP_TRY(ctx, hipFuncSetAttribute((const void *)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
+        hipLaunchKernelGGL(kg, dim3((unsigned)gridg), dim3(256), ldsg, ctx->stream, p);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->last_hess_kernel = 90 + p.q;
+        return PCL_OK;
+    }
     // version 3 (default where its tiles fit LDS): one workgroup per interval, jobs split by drive
     if (mf && (ctx->opt_hess_kernel == 0 || ctx->opt_hess_kernel == 3) && hess_v2_supported(ctx) && ctx->cols == ctx->desc.d && ctx->uell_w <= 2 &&
         ctx->n_upos <= 512 * PCL_NUE_H3 && (ctx->opt_hess_kernel == 3 || ctx->desc.d >= 12)) {

@@ -430,3 +430,22 @@ def test_objective_gradients_finite_differences(sub):
         fdz = np.array([(f(Z.reshape(-1) + e) - f(Z.reshape(-1) - e)) / 2e-6 for e in 1e-6 * np.eye(60)])
         assert np.abs(gz.reshape(-1) - fdz).max() < 1e-8
     assert po.quadratic_regularizer(Z, 5, 4, 0.0, 3) == 0.0  # [REF spline_pulse_problem.jl:1570-1578]: R = 0 -> exactly zero
+
+
+@pytest.mark.parametrize("order", [2, 4, 6, 8, 10])
+def test_oracle_general_order_hessian(order):
+    """The general-order Hessian of the Lagrangian: equal to the order-4 closed form at p = 4, symmetric, and equal to central
+    differences of J^T mu of the (Frechet-pinned) analytic Jacobian at every order."""
+    s = po.config_system(1)
+    Z, lay = po.synthetic_trajectory(s, 4, seed=4, noise=1e-2)
+    Z[:, lay.dt_off] = 0.3 + 0.2 * np.random.default_rng(1).random(4)  # large steps: the high-order terms matter
+    G0, Gj = s.G_drift, np.array(s.G_drives)
+    mu = np.random.default_rng(2).standard_normal((lay.K, lay.x_dim))
+    vals = po.pade_hessian_values(Z, mu, lay, G0, Gj, order)
+    if order == 4:
+        assert np.abs(vals - po.pade4_hessian_values(Z, mu, lay, G0, Gj)).max() < 1e-13
+    Hd = po.hessian_dense(vals, lay)
+    g = lambda z: po.pade_jacobian_dense(z.reshape(Z.shape), lay, G0, Gj, order).T @ mu.reshape(-1)
+    Hfd = _fd_jac(g, Z.reshape(-1).copy())
+    assert np.abs(Hd - Hfd).max() < 2e-7
+    assert np.abs(Hd - Hd.T).max() == 0

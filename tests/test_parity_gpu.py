@@ -429,11 +429,6 @@ def test_unsupported_requests_fail_loudly():
         with pytest.raises(pa.PclError) as ei:
             make_ctx(lay, G0, Gj, pade_order=bad)
         assert ei.value.code == pa._lib.PCL_ENOTIMPL
-    c8 = make_ctx(lay, G0, Gj, pade_order=8)
-    with pytest.raises(pa.PclError) as ei:  # the Hessian exists at order 4 only: refused, not substituted
-        c8.hess(Z, np.zeros(c8.n_rows))
-    assert ei.value.code == pa._lib.PCL_ENOTIMPL
-    c8.close()
     c = make_ctx(lay, G0, Gj)
     with pytest.raises(ValueError):
         c.eval(Z[:-1])
@@ -1514,3 +1509,53 @@ def test_residual_only_kernel():
     B.ctx.set_member_window(2, 1)
     assert np.array_equal(B.ctx.eval(trajE.datavec), dE[2 * per :])
     B.close()
+
+
+@pytest.mark.parametrize("order", [2, 4, 6, 8, 10])
+def test_hessian_of_the_lagrangian_at_every_pade_order(order):
+    """The general-order Hessian kernel (every diagonal Pade order; at order 4 selected with `general_pade_kernel` as a
+    cross-check of the tuned kernels) against the oracle's general-order formulas (pinned by finite differences of the
+    Frechet-pinned Jacobian): config 2 (sparse iso drives), a dense random case with an odd state offset, a two-member
+    ensemble with per-member drift, the compact-density variant, and several column chunk widths."""
+    rng = np.random.default_rng(40 + order)
+    so = po.config_system(2)
+    Z, lay = po.synthetic_trajectory(so, 6, seed=9, noise=1e-2)
+    Z[:, lay.dt_off] = 0.2 + 0.2 * rng.random(6)  # large steps: the high-order terms matter
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    mu = rng.standard_normal((lay.K, lay.x_dim))
+    ref = po.pade_hessian_values(Z, mu, lay, G0, Gj, order).reshape(-1)
+    c = make_ctx(lay, G0, Gj, pade_order=order)
+    if order == 4:
+        tuned = c.hess(Z, mu.reshape(-1))
+        c.set_option("general_pade_kernel", 1)
+    h = c.hess(Z, mu.reshape(-1))
+    assert c.get_option("last_hess_kernel") == 90 + order // 2
+    close(h, ref, 1e-11)
+    if order == 4:
+        close(h, tuned, 1e-11)
+    assert np.array_equal(h, c.hess(Z, mu.reshape(-1)))  # fixed-order sums
+    hs, hc = c.hess_structure()
+    r0, c0 = po.hess_structure(lay)
+    assert np.array_equal(hs, r0) and np.array_equal(hc, c0)
+    c.close()
+    lay2, G02, Gj2, Z2 = _random_case(5, 3, 4, rng, x_off=3)
+    G02, Gj2 = 0.5 * G02, 0.5 * Gj2
+    mu2 = rng.standard_normal((lay2.K, lay2.x_dim))
+    c2 = make_ctx(lay2, G02, Gj2, pade_order=order)
+    if order == 4:
+        c2.set_option("general_pade_kernel", 1)
+    close(c2.hess(Z2, mu2.reshape(-1)), po.pade_hessian_values(Z2, mu2, lay2, G02, Gj2, order).reshape(-1), 1e-10)
+    c2.close()
+    # ensemble with per-member drift (member-major rows) and d = 27 (several column chunks)
+    osys, psys, layE, ZE, trajE = _config4_share(2, 3)
+    ZE = ZE.copy()
+    names = ["Ũ⃗1", "Ũ⃗2"]
+    BE = pa.HipPadeIntegrator(np.array([s.G_drift for s in psys]), psys[0].G_drives_array(), trajE, names, pade_order=order)
+    if order == 4:
+        BE.ctx.set_option("general_pade_kernel", 1)
+    muE = rng.standard_normal((2, layE.K, layE.x_dim))
+    hE = BE.ctx.hess(trajE.datavec, muE.reshape(-1))
+    per = po.hess_nnz_per_interval(layE) * layE.K
+    for i, s in enumerate(osys):
+        close(hE[i * per : (i + 1) * per], po.pade_hessian_values(ZE, muE[i], layE, s.G_drift, np.array(s.G_drives), order, x_off=i * layE.x_dim).reshape(-1), 1e-10)
+    BE.close()
