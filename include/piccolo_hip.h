@@ -241,7 +241,10 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *       "stream_workgroups"  kernel 3, contiguous: -1 auto (half) | 0 both roles in every workgroup | n stream-role workgroups
  *       "cols_per_slice"     state columns per work item (0 = heuristic; forces the round-robin split in kernel 3)
  *       "hess_kernel"        0 auto | 1 one workgroup per interval | 2 persistent, column chunks (fallback) | 3 one workgroup per
- *                            interval, jobs split by drive (default for d >= 12); Pade orders other than 4 always run the general-order Hessian kernel
+ *                            interval, jobs split by drive (matrix cores; default for d >= 12 where kernel 4 does not apply) | 4 the
+ *                            pattern-compiled kernel: source generated from the sparsity pattern of the generators and compiled
+ *                            on first use (default for sparse exact-iso generators, odd 9 <= d <= 32, m <= 6; PCL_ESHAPE when
+ *                            forced elsewhere); Pade orders other than 4 always run the general-order Hessian kernel
  *       "general_pade_kernel" 1: run the general-order kernel for pade_order 4 too (cross-check)
  *       "general_threads" (256 / 512), "general_two_step" (1: unique tiles + expansion kernel)   general-order kernel
  *       "jit"                1 (default): shapes outside the static instance table are compiled on first use with hiprtc
@@ -251,13 +254,18 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *       compact values into the caller's array, 0 = auto), "host_path" (0 auto | 1 full values over PCIe | 2 compact + host expansion),
  *       "debug_timing" (PCL_ENOTIMPL unless the library was built with -DPCL_PROFILE)
  * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised; 90 + q for the general-order
- *       kernel), "last_stream_workgroups", "last_hess_kernel" (3: compiled on first use), "jit_compiles", "n_cu", "iso_structured", "drives_antisymmetric",
+ *       kernel), "last_stream_workgroups", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3 static / compiled | 6: pattern-compiled | 90 + q), "jit_compiles", "n_cu", "iso_structured", "drives_antisymmetric",
  *       "ell_width", "ell_width_t", "union_width", "occupancy_v2".  Unknown keys return PCL_EINVAL. */
 int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t value);
 int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *value);
 /* Profiling aid (libraries built with -DPCL_PROFILE only): after pcl_set_option(ctx, "debug_timing", 1), up to 64
  * s_memtime stamps written by workgroup 0 at its phase boundaries during the last launch. */
 int pcl_debug_timing(pcl_ctx *ctx, int64_t *out, int64_t cap);
+
+/* Inspection hook (needs no device): the HIP source the library generates and compiles on first use for the
+ * pattern-compiled kernels of a system with Hilbert dimension d <= 32 and m <= 6 drives whose generators are exact iso(.)
+ * images (G0: n*n column-major, Gj: m such blocks).  *needed = bytes including the terminator; buf may be NULL. */
+int pcl_codegen_source(int d, int m, const double *G0, const double *Gj, char *buf, int64_t cap, int64_t *needed);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,7 @@ EXPORTS = [
     "pcl_clear_regularizers", "pcl_objective_dev", "pcl_objective", "pcl_merit_grad_len", "pcl_merit_grad_dev",
     "pcl_rollout", "pcl_rollout_dev",
     "pcl_comm_get_unique_id", "pcl_comm_init", "pcl_reduce_sum_dev", "pcl_reduce_sum", "pcl_comm_destroy",
-    "pcl_set_option", "pcl_get_option", "pcl_debug_timing",
+    "pcl_set_option", "pcl_get_option", "pcl_debug_timing", "pcl_codegen_source",
 ]  # fmt: skip
 
 
@@ -174,5 +174,6 @@ def load():
     L.pcl_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     L.pcl_get_option.argtypes = [vp, ctypes.c_char_p, c_i64p]
     L.pcl_debug_timing.argtypes = [vp, c_i64p, ctypes.c_int64]
+    L.pcl_codegen_source.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int64, c_i64p]
     _lib = L
     return L

@@ -1,0 +1,317 @@
+// pcl_codegen.hpp -- host-only: source generator for the PATTERN-COMPILED kernels.
+//
+// The generators of the reference's systems are sparse (multilevel transmons, config 3: 614 of 2916 entries) and exact
+// iso(.) images  T = [[A, -B], [B, A]].  Every product of the Hessian of the Lagrangian acts on the state columns from the
+// left, so one state column never needs another one: a lane can own one column, keep it in REGISTERS and apply G(u)^T as a
+// straight line of fused multiply-adds whose register indices are the sparsity pattern and whose coefficients are scalar
+// registers (s_load from a per-interval value table).  No LDS operand traffic, no matrix-core padding (a 54 x 54 x 27
+// product costs 112 MFMAs = 7168 cycles of one SIMD; 307 FMAs = 1228 cycles).  The iso structure halves the code: the
+// lower half of the wave holds the column multiplied by -i, runs the SAME instructions and obtains the bottom rows.
+//
+// The pattern is data, so the kernel source is generated per system and compiled on first use (hiprtc).
+#pragma once
+
+#include <algorithm>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace pcl_codegen {
+
+struct SpPlan {
+    int d = 0, m = 0, n = 0;
+    int nz = 0, nzp = 0;          // union entries of the left column block [A; B] of G(u); padded to a multiple of 16
+    std::vector<int> row, col;    // entry k (in the emission order of sp_gt): G[row][col], row < n, col < d
+    std::vector<int> pos;         // row + n*col (column-major position in G0 / G_l)
+    std::vector<double> coef;     // [nz][m]: G_l at pos
+    std::vector<int> doff;        // [m+1]: offsets of the drives' entries
+    std::vector<int> drow, dcol;  // entries of the left column block of every G_l
+    std::vector<int> dmagi;       // ... index of |value| in `mags`
+    std::vector<char> dneg;       // ... value < 0
+    std::vector<double> mags;     // distinct magnitudes of the drives' entries (the device table; they live in SGPRs for the whole launch)
+    bool ok = false;
+};
+
+constexpr int kMaxMags = 8;  // distinct magnitudes of the drives' entries the kernels keep in scalar registers
+constexpr int kGroup = 9;  // outputs accumulated together by the long product (independent dependency chains per wave)
+
+namespace detail {
+struct Term {
+    int out, in;   // output index, input index (< d: a[in], >= d: b[in - d])
+    int src;       // caller's entry index; after ordering: the coefficient's table index
+    bool neg;
+    int mag = -1;  // >= 0: the coefficient is the resident magnitude mg.m<mag> instead of a table entry
+};
+// Emission order: the outputs in groups of `group`, round-robin inside a group (consecutive instructions belong to different
+// dependency chains; a finished group is handed to the caller, so at most `group` accumulators are live).
+static inline std::vector<Term> emission_order(const std::vector<Term> &terms, int d, int group) {
+    std::vector<std::vector<Term>> by(d);
+    for (const Term &t : terms) by[t.out].push_back(t);
+    std::vector<Term> out;
+    for (int g0 = 0; g0 < d; g0 += group) {
+        size_t longest = 0;
+        for (int o = g0; o < std::min(d, g0 + group); ++o) longest = std::max(longest, by[o].size());
+        for (size_t t = 0; t < longest; ++t)
+            for (int o = g0; o < std::min(d, g0 + group); ++o)
+                if (t < by[o].size()) out.push_back(by[o][t]);
+    }
+    return out;
+}
+// top rows of T^T x = A^T a + B^T b:  o[c] += T[rho][c] * (rho < d ? a[rho] : b[rho - d])
+static inline Term term_t(int row, int col, int d, int src) { return {col, row, src, false}; }
+// top rows of T x = A a - B b:  rho < d: o[rho] += T[rho][c] a[c];  rho >= d: o[rho - d] -= T[rho][c] b[c]
+static inline Term term_n(int row, int col, int d, int src) { return {row < d ? row : row - d, row < d ? col : d + col, src, row >= d}; }
+
+// Coefficient i of the table: element (i - base) % 8 of chunk (i - base) / 8.  A chunk is ONE s_load_dwordx16 issued by a
+// volatile asm statement at the point of first use (with its wait): left to the compiler, the loads of a whole product -- or
+// of several products that share a table -- are hoisted to the top of the interval and hundreds of SGPRs are spilled to VGPR
+// lanes.  Volatile asm statements keep their order, so they also keep the phases of a role apart.
+struct Chunks {
+    std::string &s;
+    const char *tab;
+    int base, n;
+    std::vector<char> state;  // 0: untouched, 1: load issued (prefetch), 2: waited for
+    Chunks(std::string &s_, const char *tab_, int base_, int n_) : s(s_), tab(tab_), base(base_), n((n_ + 15) / 16), state((n_ + 15) / 16 + 1, 0) {}
+    void declare() {
+        char buf[64];
+        for (int c = 0; c < std::max(n, 1); ++c) {
+            snprintf(buf, sizeof buf, "%ssp_v8d k%d, k%dh", c ? "; " : "    ", c, c);
+            s += buf;
+        }
+        s += ";\n";
+    }
+    void issue(int c) {
+        char buf[320];
+        snprintf(buf, sizeof buf, "        asm volatile(\"s_load_dwordx16 %%0, %%2, %d\\n\\ts_load_dwordx16 %%1, %%2, %d\" : \"=&s\"(k%d), \"=&s\"(k%dh) : \"s\"(%s) : \"memory\");\n",
+                 (base + 16 * c) * 8, (base + 16 * c + 8) * 8, c, c, tab);
+        s += buf;
+        state[c] = 1;
+    }
+    // 16 coefficients per chunk (two s_load_dwordx16).  The loads of chunk c + 1 are issued when chunk c is first used and
+    // waited for -- by a statement that passes the registers through, so that their uses stay behind it -- when chunk c + 1 is
+    // first used: one chunk of multiply-adds covers the scalar-cache latency.
+    std::string coef(int i) {
+        const int c = (i - base) / 16, e = (i - base) % 16;
+        char buf[320];
+        if (state[c] != 2) {
+            if (state[c] == 0) issue(c);
+            snprintf(buf, sizeof buf, "        asm volatile(\"s_waitcnt lgkmcnt(0)\" : \"+s\"(k%d), \"+s\"(k%dh));\n", c, c);
+            s += buf;
+            state[c] = 2;
+            if (c + 1 < n && state[c + 1] == 0) issue(c + 1);
+        }
+        snprintf(buf, sizeof buf, "k%d%s[%d]", c, e >= 8 ? "h" : "", e % 8);
+        return buf;
+    }
+};
+
+// Body of  template <class F> void f(a, b, tab, F out):  `ordered` is in emission order with consecutive table indices
+// starting at `base`; every output (also the ones without a term) is passed to out(index, value) once, group by group.
+static inline void emit_groups(std::string &s, const std::vector<Term> &ordered, int d, int group, const char *tab, int base) {
+    char buf[256];
+    Chunks ch(s, tab, base, (int)ordered.size());
+    ch.declare();
+    size_t i = 0;
+    for (int g0 = 0; g0 < d; g0 += group) {
+        const int g1 = std::min(d, g0 + group);
+        s += "    {\n";
+        std::vector<char> seen(d, 0);
+        for (int o = g0; o < g1; ++o) {
+            snprintf(buf, sizeof buf, "        double o%d = 0.0;\n", o);
+            s += buf;
+        }
+        // one volatile asm statement per multiply-add: the instruction order is the emission order (the compiler allocates the
+        // registers; left to schedule, it floats the arithmetic away from the loads and spills)
+        for (; i < ordered.size() && ordered[i].out < g1 && ordered[i].out >= g0; ++i) {
+            const Term &q = ordered[i];
+            const char *src = q.in < d ? "a" : "b";
+            const int idx = q.in < d ? q.in : q.in - d;
+            char mg[24];
+            snprintf(mg, sizeof mg, "mg.m%d", q.mag);
+            const std::string cf = q.mag >= 0 ? std::string(mg) : ch.coef(q.src);
+            if (!seen[q.out])
+                snprintf(buf, sizeof buf, "        asm volatile(\"v_mul_f64 %%0, %s%%1, %%2\" : \"=v\"(o%d) : \"s\"(%s), \"v\"(%s[%d]));\n", q.neg ? "-" : "", q.out, cf.c_str(), src, idx);
+            else if (!q.neg)
+                snprintf(buf, sizeof buf, "        asm volatile(\"v_fmac_f64 %%0, %%1, %%2\" : \"+v\"(o%d) : \"s\"(%s), \"v\"(%s[%d]));\n", q.out, cf.c_str(), src, idx);
+            else
+                snprintf(buf, sizeof buf, "        asm volatile(\"v_fma_f64 %%0, -%%1, %%2, %%0\" : \"+v\"(o%d) : \"s\"(%s), \"v\"(%s[%d]));\n", q.out, cf.c_str(), src, idx);
+            seen[q.out] = 1;
+            s += buf;
+        }
+        for (int o = g0; o < g1; ++o) {
+            snprintf(buf, sizeof buf, "        out(%d, o%d);\n", o, o);
+            s += buf;
+        }
+        // a scheduling-region boundary: what the caller does with the group (LDS stores, dot products) is scheduled here, not
+        // sunk to the end of the interval with every operand live until then
+        s += "        __builtin_amdgcn_sched_barrier(0);\n    }\n";
+    }
+}
+// Body of  double f(a, b, dq, mg):  <T^T x, dq> = sum_g m_g sum_k (+-) x[in_k] dq[out_k]  -- one multiply-add per entry, no
+// coefficient inside the sums (two dependency chains per magnitude)
+static inline void emit_dot(std::string &s, const std::vector<Term> &terms, int d, int n_mags) {
+    char buf[256];
+    std::vector<int> cnt(n_mags, 0);
+    for (int g = 0; g < n_mags; ++g) {
+        bool any = false;
+        for (const Term &q : terms) any |= q.mag == g;
+        if (!any) continue;
+        snprintf(buf, sizeof buf, "    double e%d_0 = 0.0, e%d_1 = 0.0;\n", g, g);
+        s += buf;
+    }
+    for (const Term &q : terms) {
+        const char *src = q.in < d ? "a" : "b";
+        const int idx = q.in < d ? q.in : q.in - d;
+        const int ch = cnt[q.mag]++ & 1;
+        if (!q.neg)
+            snprintf(buf, sizeof buf, "    asm volatile(\"v_fmac_f64 %%0, %%1, %%2\" : \"+v\"(e%d_%d) : \"v\"(%s[%d]), \"v\"(dq[%d]));\n", q.mag, ch, src, idx, q.out);
+        else
+            snprintf(buf, sizeof buf, "    asm volatile(\"v_fma_f64 %%0, -%%1, %%2, %%0\" : \"+v\"(e%d_%d) : \"v\"(%s[%d]), \"v\"(dq[%d]));\n", q.mag, ch, src, idx, q.out);
+        s += buf;
+    }
+    s += "    double r = 0.0;\n";
+    for (int g = 0; g < n_mags; ++g)
+        if (cnt[g]) {
+            snprintf(buf, sizeof buf, "    r = __builtin_fma(mg.m%d, e%d_0 + e%d_1, r);\n", g, g, g);
+            s += buf;
+        }
+    s += "    return r;\n";
+}
+}  // namespace detail
+
+// G0: n_g0 drifts (n*n column-major each), Gj: m drives.  The caller has verified the exact iso structure.
+static inline SpPlan make_plan(int d, int m, const double *G0, int n_g0, const double *Gj) {
+    using detail::Term;
+    SpPlan P;
+    P.d = d;
+    P.m = m;
+    P.n = 2 * d;
+    const int n = P.n;
+    const size_t nn = (size_t)n * n;
+    std::vector<Term> terms;
+    std::vector<int> rows, cols;
+    for (int c = 0; c < d; ++c)
+        for (int r = 0; r < n; ++r) {
+            const size_t pz = (size_t)r + (size_t)n * c;
+            bool any = false;
+            for (int b = 0; b < n_g0; ++b) any |= G0[b * nn + pz] != 0.0;
+            for (int l = 0; l < m; ++l) any |= Gj[l * nn + pz] != 0.0;
+            if (!any) continue;
+            terms.push_back(detail::term_t(r, c, d, (int)rows.size()));
+            rows.push_back(r);
+            cols.push_back(c);
+        }
+    for (const Term &t : detail::emission_order(terms, d, kGroup)) {  // table order = emission order of sp_gt: the scalar loads walk it front to back
+        const int r = rows[t.src], c = cols[t.src];
+        P.row.push_back(r);
+        P.col.push_back(c);
+        P.pos.push_back(r + n * c);
+        for (int l = 0; l < m; ++l) P.coef.push_back(Gj[l * nn + (size_t)r + (size_t)n * c]);
+    }
+    P.nz = (int)P.row.size();
+    P.nzp = (P.nz + 15) & ~15;
+    // drives: the entries of the left column block; their distinct magnitudes (a handful for the reference's systems: ladder
+    // operators) stay in scalar registers for the whole launch, the signs are instruction modifiers
+    P.doff.assign(m + 1, 0);
+    for (int l = 0; l < m; ++l) {
+        P.doff[l] = (int)P.drow.size();
+        for (int c = 0; c < d; ++c)
+            for (int r = 0; r < n; ++r) {
+                const double v = Gj[l * nn + (size_t)r + (size_t)n * c];
+                if (v == 0.0) continue;
+                const double mag = v < 0 ? -v : v;
+                int gi = -1;
+                for (size_t g = 0; g < P.mags.size(); ++g)
+                    if (P.mags[g] == mag) gi = (int)g;
+                if (gi < 0) {
+                    gi = (int)P.mags.size();
+                    P.mags.push_back(mag);
+                }
+                P.drow.push_back(r);
+                P.dcol.push_back(c);
+                P.dmagi.push_back(gi);
+                P.dneg.push_back(v < 0);
+            }
+    }
+    P.doff[m] = (int)P.drow.size();
+    P.ok = P.mags.size() <= (size_t)kMaxMags;
+    return P;
+}
+
+// Device functions shared by the pattern-compiled kernels (x = (a | b) is a column in the lane's convention; out(i, value)
+// receives every top row of the result once, in groups of kGroup):
+//   sp_gt(a, b, g, out)        G(u)^T x     (coefficients: the per-interval value table g)
+//   sp_glt_<l>(a, b, mg, out)  G_l^T x      (coefficients: the resident magnitudes mg, signs as instruction modifiers)
+//   sp_gltdot<l>(a, b, dq, mg) <G_l^T x, dq> over this half's rows
+static inline std::string apply_functions(const SpPlan &P) {
+    using detail::Term;
+    const int d = P.d;
+    std::string s;
+    char buf[320];
+    snprintf(buf, sizeof buf,
+             "#define SPD %d\n#define SPM %d\n#define SPN %d\n#define SPNZ %d\n#define SPNZP %d\n"
+             "typedef const double __attribute__((address_space(4))) *sp_cptr;\n"
+             "typedef double sp_v8d __attribute__((ext_vector_type(8)));\n",
+             d, P.m, P.n, P.nz, P.nzp);
+    s += buf;
+    {
+        std::vector<Term> t;  // the plan's entries ARE in emission order
+        for (int k = 0; k < P.nz; ++k) t.push_back(detail::term_t(P.row[k], P.col[k], d, k));
+        s += "template <class F> static __device__ __forceinline__ void sp_gt(const double (&a)[SPD], const double (&b)[SPD], sp_cptr g, F out) {\n";
+        detail::emit_groups(s, t, d, kGroup, "g", 0);
+        s += "}\n";
+    }
+    s += "struct sp_mags { double m0";
+    for (size_t g = 1; g < std::max<size_t>(P.mags.size(), 1); ++g) {
+        snprintf(buf, sizeof buf, ", m%zu", g);
+        s += buf;
+    }
+    s += "; };\n#define SP_LOAD_MAGS(mg, tab) do {";
+    for (size_t g = 0; g < std::max<size_t>(P.mags.size(), 1); ++g) {
+        snprintf(buf, sizeof buf, " (mg).m%zu = (tab)[%zu];", g, g);
+        s += buf;
+    }
+    s += " } while (0)\n";
+    s += "template <int V> struct sp_ic { static constexpr int value = V; };\n";
+    for (int l = 0; l < P.m; ++l) {
+        std::vector<Term> tt;
+        for (int k = P.doff[l]; k < P.doff[l + 1]; ++k) {
+            Term q = detail::term_t(P.drow[k], P.dcol[k], d, k);
+            q.neg = P.dneg[k] != 0;
+            q.mag = P.dmagi[k];
+            tt.push_back(q);
+        }
+        snprintf(buf, sizeof buf, "template <class F> static __device__ __forceinline__ void sp_glt_%d(const double (&a)[SPD], const double (&b)[SPD], const sp_mags &mg, F out) {\n", l);
+        s += buf;
+        detail::emit_groups(s, detail::emission_order(tt, d, kGroup), d, kGroup, "mg", 0);
+        s += "}\n";
+        snprintf(buf, sizeof buf, "static __device__ __forceinline__ double sp_gltdot_%d(const double (&a)[SPD], const double (&b)[SPD], const double (&dq)[SPD], const sp_mags &mg) {\n", l);
+        s += buf;
+        detail::emit_dot(s, tt, d, (int)P.mags.size());
+        s += "}\n";
+    }
+    s += "template <int L> static __device__ __forceinline__ double sp_gltdot(const double (&a)[SPD], const double (&b)[SPD], const double (&dq)[SPD], const sp_mags &mg) {\n";
+    for (int l = 0; l < P.m; ++l) {
+        snprintf(buf, sizeof buf, "    if constexpr (L == %d) return sp_gltdot_%d(a, b, dq, mg);\n", l, l);
+        s += buf;
+    }
+    s += "    return 0.0;\n}\n";
+    // the loader wave touches the next interval's value table (one 64-byte line per scalar load) so that the other waves' loads hit
+    s += "#define SP_PREFETCH_G(ptr) do { sp_v8d pf_; asm volatile(\"";
+    for (int c = 0; c * 8 < P.nzp; ++c) {
+        snprintf(buf, sizeof buf, "s_load_dwordx16 %%0, %%1, %d\\n\\t", c * 64);
+        s += buf;
+    }
+    s += "s_waitcnt lgkmcnt(0)\" : \"=&s\"(pf_) : \"s\"(ptr) : \"memory\"); } while (0)\n";
+    // run-time (wave-uniform) dispatch for the two small drive-specific products of a drive wave; the cases exchange data with
+    // the rest of the role through LDS only, so no register webs are merged behind the switch
+    s += "#define SP_GLT_SWITCH(l, a, b, mg, out) switch (l) {";
+    for (int l = 0; l < P.m; ++l) {
+        snprintf(buf, sizeof buf, " case %d: sp_glt_%d(a, b, mg, out); break;", l, l);
+        s += buf;
+    }
+    s += " default: break; }\n";
+    return s;
+}
+
+}  // namespace pcl_codegen

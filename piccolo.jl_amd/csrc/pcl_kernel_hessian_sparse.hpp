@@ -1,0 +1,360 @@
+// pcl_kernel_hessian_sparse.hpp -- Hessian of the Lagrangian, PATTERN-COMPILED version.
+// Included by generated source only (pcl_codegen.hpp): SPD (Hilbert dimension d <= 32), SPM (drives <= 6), SPN = 2 SPD,
+// SPNZ / SPNZP and the straight-line functions sp_gt / sp_glt / sp_glt_acc / sp_gl are defined before this file.
+//
+// Every product of the Hessian acts on a state column from the left, so a lane owns ONE column and keeps it in registers:
+//     lane = (half, c):  half 0 holds x = (a | b) = (top rows | bottom rows) of column c and produces the top rows of T x,
+//                        half 1 holds -i x = (b | -a), runs the same instructions and produces the bottom rows
+// (T = [[A, -B], [B, A]]: every generator is an exact iso(.) image).  A result that feeds another product is completed with
+// the other half's rows by one cross-half exchange.  Coefficients of G(u_k) come from a per-interval value table through
+// scalar loads (constant address space), the drives' from a launch-invariant table.
+// Roles (one workgroup of SPM + 2 waves per interval, a contiguous range of intervals per workgroup):
+//     wave 0      A1 = G^T M -> LDS tile (flag: ready), A2 = G^T A1, outputs d2/dh dX, <A2, D>
+//     wave 1      loader: the next interval's mu, x_k, x_{k+1} travel in its registers during the interval
+//     wave 2 + l  P_l = G_l^T M, <P_l, G_j D> for every j, Q_l = G^T P_l, Q_l += G_l^T A1, <P_l, S>, <Q_l + R_l, D>, outputs d2/du_l dX
+// Outputs leave through one LDS tile per wave (column layout -> flat) as runs of 64 consecutive doubles.
+// Two barriers per interval; the 28 scalar entries are wave sums (fixed shuffle tree) added in a fixed order: repeatable bits.
+#pragma once
+
+#define SPXD (SPN * SPD)
+#define SPTILE SPXD  // tiles are flat [column][row]: lane stride SPN doubles = 4 SPD banks -> conflict-free for odd SPD
+#define SPNL ((SPXD + 63) / 64)
+#define SPNSC ((SPM + 1) * (SPM + 2) / 2)
+#define SPNPAIR (SPM * (SPM + 1) / 2)
+
+// acc += x y, pinned where it is written: the compiler sinks plain dot-product arithmetic to the end of the interval (where the
+// sums are used) and keeps every operand alive -- in scratch -- until then.
+static __device__ __forceinline__ void sp_fmac(double &acc, double x, double y) { asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(acc) : "v"(x), "v"(y)); }
+template <int J, int N, class F>
+static __device__ __forceinline__ void sp_static_for(F f) {
+    if constexpr (J < N) {
+        f(sp_ic<J>{});
+        sp_static_for<J + 1, N>(f);
+    }
+}
+// The coefficient table is read through the constant address space (scalar loads).  Two products with the same table would
+// share ONE set of loads (every coefficient live between them: hundreds of SGPRs spilled to VGPR lanes); an opaque copy of the
+// pointer per product keeps each product's loads next to its multiply-adds.
+static __device__ __forceinline__ sp_cptr sp_opaque(sp_cptr q) {
+    asm volatile("" : "+s"(q));
+    return q;
+}
+// Phase fence.  The compiler schedules the whole interval as one block, starts the next phase's LDS reads and exchanges early
+// and runs out of registers (hundreds of scratch accesses per interval).  Volatile asm statements keep their order: passing
+// the values that live across a phase boundary, and the LDS offset the next phase reads with, through empty ones pins
+// everything that produces them before the boundary and everything that uses them after it.
+template <int N>
+static __device__ __forceinline__ void sp_fence(double (&v)[N]) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) asm volatile("" : "+v"(v[r]));
+}
+static __device__ __forceinline__ int sp_fence(int off) {
+    asm volatile("" : "+v"(off));
+    return off;
+}
+
+extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_kernel(const KParams p, const double *__restrict__ gvals_, const double *__restrict__ glv_) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the role branches are uniform
+    const int half = lane >> 5, c = lane & 31;
+    const bool act = c < SPD;
+    const int cc = act ? c : 0;
+    const double sgn = half ? -1.0 : 1.0;
+    const int own = cc * SPN + half * SPD, oth = cc * SPN + (1 - half) * SPD;
+    double *Mt = lds, *Dt = Mt + SPTILE, *St = Dt + SPTILE, *A1t = St + SPTILE, *Stg = A1t + SPTILE;  // Stg: SPM + 1 staging tiles
+    double *scal = Stg + (SPM + 1) * SPTILE;  // [SPM][SPM + 2][4] drive-wave sums per 16-lane row | [1][4] <A2, D>
+    int *flag = (int *)(scal + (SPM * (SPM + 2) + 1) * 4);
+    sp_cptr glv = (sp_cptr)glv_;
+
+    const int n_items = p.batch * p.K;
+    const int item_lo = (int)((long long)n_items * blockIdx.x / gridDim.x), item_hi = (int)((long long)n_items * (blockIdx.x + 1) / gridDim.x);
+    if (item_lo >= item_hi) return;
+
+    auto step_of = [&](int item) {
+        const int k = item % p.K, b = item / p.K;
+        return p.Z[(long long)b * p.z_batch_stride + (long long)k * p.z_dim + p.dt_off];
+    };
+    if (tid == 0) __hip_atomic_store(flag, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef PCL_PROFILE
+    int stamp_ = 0;  // cycle stamps of workgroup 0: 16 slots per wave (dbg[16 wave + i])
+#define SP_STAMP()                                                                                                        \
+    do {                                                                                                                  \
+        if (p.dbg && blockIdx.x == 0 && lane == 0 && wave < 4 && stamp_ < 16) p.dbg[16 * wave + stamp_++] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+    if (p.dbg && tid == 0 && blockIdx.x < PCL_DBG_WG) p.dbg[64 + 2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+#define SP_END()                                                                                                                         \
+    do {                                                                                                                                 \
+        if (p.dbg && lane == 0 && wave == 0 && blockIdx.x < PCL_DBG_WG) p.dbg[64 + 2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define SP_STAMP() do { } while (0)
+#define SP_END() do { } while (0)
+#endif
+    // flat tile -> global, 64 consecutive doubles per instruction.  Addresses are one per-lane base plus immediates (written
+    // with `lane + 64 i` indices, the compiler hoists 23 index registers per tile out of the interval loop and spills)
+    auto flush = [&](const double *T, double *out) {
+        wave_lds_sync();
+        const double *Tl = T + lane;
+        double *ol = out + lane;
+#pragma unroll
+        for (int i = 0; i < SPNL; ++i) {
+            if (i < SPXD / 64 || lane < SPXD % 64) {
+                if (p.nt)
+                    __builtin_nontemporal_store(Tl[64 * i], ol + 64 * i);
+                else
+                    ol[64 * i] = Tl[64 * i];
+            }
+        }
+        wave_lds_sync();
+    };
+    // The three roles run their own loops (the register allocation of one role does not carry the other roles' live values);
+    // every loop passes the same two workgroup barriers per interval.
+    if (wave == 1) {
+        // ---- loader ---------------------------------------------------------------------------------------------------------
+        double pm[SPNL], pxn[SPNL], pxc[SPNL];
+        auto request = [&](int item) {
+            const int k = item % p.K, b = item / p.K;
+            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + p.x_offs[p.z_batch_stride ? 0 : b];
+            const double *mu = p.mu + ((long long)b * p.K + k) * SPXD;
+            const double *mul = mu + lane, *zl = zk + lane, *zn = zk + p.z_dim + lane;
+#pragma unroll
+            for (int i = 0; i < SPNL; ++i) {
+                pm[i] = pxn[i] = pxc[i] = 0.0;
+                if (i < SPXD / 64 || lane < SPXD % 64) {
+                    pm[i] = mul[64 * i];
+                    pxc[i] = zl[64 * i];
+                    pxn[i] = zn[64 * i];
+                }
+            }
+        };
+        request(item_lo);
+        SP_PREFETCH_G((sp_cptr)(gvals_ + (long long)item_lo * SPNZP));
+        for (int item = item_lo; item < item_hi; ++item) {
+            double *Ml = Mt + lane, *Dl = Dt + lane, *Sl = St + lane;
+#pragma unroll
+            for (int i = 0; i < SPNL; ++i) {
+                if (i < SPXD / 64 || lane < SPXD % 64) {
+                    Ml[64 * i] = pm[i];
+                    Dl[64 * i] = pxn[i] - pxc[i];
+                    Sl[64 * i] = pxn[i] + pxc[i];
+                }
+            }
+            SP_STAMP();
+            __syncthreads();  // alpha: the interval's inputs are in LDS
+            SP_STAMP();
+            if (item + 1 < item_hi) {
+                request(item + 1);
+                SP_PREFETCH_G((sp_cptr)(gvals_ + (long long)(item + 1) * SPNZP));  // the scalar cache is warm when the other waves arrive
+            }
+            __syncthreads();  // gamma
+            SP_STAMP();
+        }
+    } else if (wave == 0) {
+        // ---- state wave -----------------------------------------------------------------------------------------------------
+        double hn = step_of(item_lo);
+        double *T = Stg + SPM * SPTILE;
+        __builtin_amdgcn_s_setprio(2);  // two dependent long products: the longest chain of the interval
+        for (int item = item_lo; item < item_hi; ++item) {
+            const int seq = item - item_lo;
+            const long long bk = item;  // = b K + k
+            const double h = hn;
+            const double c2 = h * h * (1.0 / 12.0), h6 = h * (1.0 / 6.0);
+            double *H = p.hess + bk * p.hess_per;
+            double *H4 = H + SPNSC + (long long)SPM * SPXD, *H6 = H4 + SPXD + (long long)SPM * SPXD;
+            sp_cptr g = (sp_cptr)(gvals_ + bk * SPNZP);
+            __syncthreads();  // alpha
+            SP_STAMP();
+            if (item + 1 < item_hi) hn = step_of(item + 1);
+            {  // A1 = G^T M -> the A1 tile (inactive lanes repeat column 0: the same values to the same addresses)
+                double a[SPD], bq[SPD];
+#pragma unroll
+                for (int r = 0; r < SPD; ++r) {
+                    a[r] = Mt[own + r];
+                    bq[r] = sgn * Mt[oth + r];
+                }
+                sp_gt(a, bq, g, [&](int c, double v) { A1t[own + c] = v; });
+            }
+            wave_lds_sync();
+            if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            SP_STAMP();
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+            {  // A2 = G^T A1 (the other half's rows come back from the tile) -> staging tile, <A2, D>
+                double a[SPD], bq[SPD], dq[SPD];  // (D in registers: a load next to each use is a full LDS round trip per output row)
+#pragma unroll
+                for (int r = 0; r < SPD; ++r) {
+                    a[r] = A1t[own + r];
+                    bq[r] = sgn * A1t[oth + r];
+                    dq[r] = Dt[own + r];
+                }
+                sp_gt(a, bq, sp_opaque(g), [&](int c, double v) {
+                    T[own + c] = v;
+                    if (c % 3 == 0)
+                        sp_fmac(s0, v, dq[c]);
+                    else if (c % 3 == 1)
+                        sp_fmac(s1, v, dq[c]);
+                    else
+                        sp_fmac(s2, v, dq[c]);
+                });
+            }
+            SP_STAMP();
+            {
+                const double s = row16_sum(act ? (s0 + s1) + s2 : 0.0);
+                if ((lane & 15) == 0) scal[(SPM * (SPM + 2)) * 4 + (lane >> 4)] = s;
+            }
+            {
+                double o6[SPD];
+#pragma unroll
+                for (int r = 0; r < SPD; ++r) {
+                    const double x = -0.5 * A1t[own + r], y = h6 * T[own + r];
+                    T[own + r] = x - y;
+                    o6[r] = x + y;
+                }
+                flush(T, H4);
+#pragma unroll
+                for (int r = 0; r < SPD; ++r) T[own + r] = o6[r];
+                flush(T, H6);
+            }
+            SP_STAMP();
+            __syncthreads();  // gamma: every tile has been read, the wave sums are in LDS
+            SP_STAMP();
+            if (lane < SPNSC) {
+                auto rows4 = [&](int e) { return ((scal[4 * e] + scal[4 * e + 1]) + scal[4 * e + 2]) + scal[4 * e + 3]; };
+                double v;
+                if (lane < SPNPAIR) {
+                    int i = 0;
+                    while ((i + 1) * (i + 2) / 2 <= lane) ++i;
+                    const int j = lane - i * (i + 1) / 2;
+                    v = c2 * (rows4(i * (SPM + 2) + j) + rows4(j * (SPM + 2) + i));
+                } else if (lane < SPNPAIR + SPM) {
+                    const int j = lane - SPNPAIR;
+                    v = __builtin_fma(h6, rows4(j * (SPM + 2) + SPM + 1), -0.5 * rows4(j * (SPM + 2) + SPM));
+                } else {
+                    v = rows4(SPM * (SPM + 2)) * (1.0 / 6.0);
+                }
+                H[lane] = v;
+            }
+        }
+        SP_END();
+    } else {
+        // ---- drive wave l ---------------------------------------------------------------------------------------------------
+        // One copy of the role for all drive waves (the instruction cache holds 64 KB): the two small products with G_l^T sit in
+        // a wave-uniform switch whose cases read and write LDS only, so no register webs are merged behind it.
+        const int l = wave - 2;
+        sp_mags mg;  // the distinct magnitudes of the drives' entries: scalar registers for the whole launch
+        SP_LOAD_MAGS(mg, glv);
+        double hn = step_of(item_lo);
+        double *T = Stg + l * SPTILE;
+        for (int item = item_lo; item < item_hi; ++item) {
+            const int seq = item - item_lo;
+            const long long bk = item;
+            const double h = hn;
+            const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
+            double *H = p.hess + bk * p.hess_per;
+            double *H3 = H + SPNSC + (long long)l * SPXD, *H5 = H3 + (long long)(SPM + 1) * SPXD;
+            sp_cptr g = (sp_cptr)(gvals_ + bk * SPNZP);
+            __syncthreads();  // alpha
+            SP_STAMP();
+            if (item + 1 < item_hi) hn = step_of(item + 1);
+            double t[SPM + 2];
+            {  // P_l = G_l^T M -> the wave's tile (results leave the switch through LDS: register webs merged behind a switch spill)
+                double a[SPD], bq[SPD];
+#pragma unroll
+                for (int r = 0; r < SPD; ++r) {
+                    a[r] = Mt[own + r];
+                    bq[r] = sgn * Mt[oth + r];
+                }
+                SP_GLT_SWITCH(l, a, bq, mg, [&](int c, double v) { T[own + c] = v; })
+            }
+            wave_lds_sync();
+            SP_STAMP();
+            double P[SPD], pb[SPD];
+#pragma unroll
+            for (int r = 0; r < SPD; ++r) {
+                P[r] = T[own + r];
+                pb[r] = sgn * T[oth + r];
+            }
+            {  // <P_l, S>
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int r = 0; r < SPD; r += 3) {
+                    sp_fmac(s0, P[r], St[own + r]);
+                    if (r + 1 < SPD) sp_fmac(s1, P[r + 1], St[own + r + 1]);
+                    if (r + 2 < SPD) sp_fmac(s2, P[r + 2], St[own + r + 2]);
+                }
+                t[SPM] = (s0 + s1) + s2;
+            }
+            SP_STAMP();
+            // R_l = G_l^T A1 -> the wave's tile (its copy of P_l has been read; A1 is ready by now, or almost)
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(1);
+            {
+                double a[SPD], bq[SPD];
+#pragma unroll
+                for (int r = 0; r < SPD; ++r) {
+                    a[r] = A1t[own + r];
+                    bq[r] = sgn * A1t[oth + r];
+                }
+                SP_GLT_SWITCH(l, a, bq, mg, [&](int c, double v) { T[own + c] = v; })
+            }
+            SP_STAMP();
+            {  // <P_l, G_j D> = <G_j^T P_l, D> (this half's rows of D in registers for the six products)
+                double dq[SPD];
+#pragma unroll
+                for (int r = 0; r < SPD; ++r) dq[r] = Dt[own + r];
+                sp_static_for<0, SPM>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    t[j] = sp_gltdot<j>(P, pb, dq, mg);
+                });
+            }
+            SP_STAMP();
+            // Q_l = G^T P_l in registers
+            double Q[SPD];
+            sp_gt(P, pb, g, [&](int c, double v) { Q[c] = v; });
+            SP_STAMP();
+            {  // outputs and <Q_l + R_l, D>
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int r = 0; r < SPD; ++r) {
+                    const double q = Q[r] + T[own + r], dv = Dt[own + r];
+                    if (r % 3 == 0)
+                        sp_fmac(s0, q, dv);
+                    else if (r % 3 == 1)
+                        sp_fmac(s1, q, dv);
+                    else
+                        sp_fmac(s2, q, dv);
+                    const double pl = -c1 * P[r], kt = c2 * q;
+                    T[own + r] = pl - kt;
+                    Q[r] = pl + kt;
+                }
+                t[SPM + 1] = (s0 + s1) + s2;
+                flush(T, H3);
+#pragma unroll
+                for (int r = 0; r < SPD; ++r) T[own + r] = Q[r];
+                flush(T, H5);
+            }
+#pragma unroll
+            for (int j = 0; j < SPM + 2; ++j) {
+                const double s = row16_sum(act ? t[j] : 0.0);
+                if ((lane & 15) == 0) scal[(l * (SPM + 2) + j) * 4 + (lane >> 4)] = s;
+            }
+            SP_STAMP();
+            __syncthreads();  // gamma
+        }
+    }
+}
+
+// Per-interval value table of G(u_k) on the union pattern:  gvals[(b K + k) SPNZP + q] = G0_b[pos_q] + sum_l u_l G_l[pos_q]
+extern "C" __global__ __launch_bounds__(256) void pcl_sparse_values_kernel(const KParams p, const int *__restrict__ pos, const double *__restrict__ coef, double *__restrict__ gvals) {
+    const int item = blockIdx.x, k = item % p.K, b = item / p.K;
+    const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
+    const double *G0b = p.G0 + (long long)b * p.g0_batch_stride;
+    for (int q = threadIdx.x; q < SPNZP; q += 256) {
+        double v = 0.0;
+        if (q < SPNZ) {
+            v = G0b[pos[q]];
+#pragma unroll
+            for (int l = 0; l < SPM; ++l) v = __builtin_fma(zk[p.u_off + l], coef[q * SPM + l], v);
+        }
+        gvals[(long long)item * SPNZP + q] = v;
+    }
+}

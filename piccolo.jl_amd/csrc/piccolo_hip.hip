@@ -24,6 +24,7 @@
 #include <dlfcn.h>
 
 #include "piccolo_hip.h"
+#include "pcl_codegen.hpp"
 
 #define PCL_VERSION_STR "piccolo_hip 0.2.0 (gfx950, pade 2/4/6/8/10)"
 
@@ -77,6 +78,13 @@ struct pcl_ctx {
     unsigned int *dhcnt = nullptr;
     long long hpart_cap = 0;
     int64_t opt_hess_kernel = 0, last_hess_kernel = 0;  // 0 = auto
+    // pattern-compiled kernels (pcl_codegen.hpp): plan, device tables, per-interval value table of G(u_k)
+    pcl_codegen::SpPlan *sp_plan = nullptr;
+    int *dsp_pos = nullptr;
+    double *dsp_coef = nullptr, *dsp_glv = nullptr, *dsp_gvals = nullptr;
+    long long sp_gvals_cap = 0;  // intervals the value table holds
+    int sp_failed = 0;           // the source did not compile: the other kernels serve the context
+    hipFunction_t sp_fval = nullptr, sp_fhess = nullptr;  // compiled on first use, kept for the context's lifetime
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dmu = nullptr, *ddelta = nullptr, *dvals = nullptr, *dhess = nullptr;
     // options
@@ -387,6 +395,11 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     if (iso)
         for (int l = 0; l < m; ++l) iso = iso && is_iso(dsc->Gj + l * nn);
     ctx->iso = iso ? 1 : 0;
+    // pattern-compiled kernels: sparse iso generators of a unitary problem, one state column per lane (d <= 32), m + 2 waves
+    if (iso && cols == d && d >= 9 && d <= 32 && (d & 1) && m >= 1 && m <= 6) {  // odd d: the flat [column][row] tiles are conflict-free
+        pcl_codegen::SpPlan plan = pcl_codegen::make_plan(d, m, dsc->G0, dsc->per_member_G0 ? dsc->batch : 1, dsc->Gj);
+        if (plan.ok && plan.nz <= 640 && (double)plan.nz <= 0.45 * 2.0 * d * d) ctx->sp_plan = new pcl_codegen::SpPlan(std::move(plan));
+    }
     std::vector<double> g0(dsc->G0, dsc->G0 + nn * (dsc->per_member_G0 ? dsc->batch : 1));
     CREATE_TRY(upload(ctx, &ctx->dG0, g0));
     CREATE_TRY(upload(ctx, &ctx->dupos, upos));
@@ -411,6 +424,14 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     }
     std::vector<int> xo(ctx->x_offs.begin(), ctx->x_offs.end());
     CREATE_TRY(upload(ctx, &ctx->dxoffs, xo));
+    if (ctx->sp_plan) {
+        const pcl_codegen::SpPlan &sp = *ctx->sp_plan;
+        std::vector<double> glv(sp.mags);  // the distinct magnitudes of the drives' entries
+        glv.resize(std::max<size_t>(glv.size(), 1) + 16, 0.0);
+        CREATE_TRY(upload(ctx, &ctx->dsp_pos, sp.pos));
+        CREATE_TRY(upload(ctx, &ctx->dsp_coef, sp.coef));
+        CREATE_TRY(upload(ctx, &ctx->dsp_glv, glv));
+    }
 #undef CREATE_TRY
 #undef CREATE_HIP
     *out = ctx;
@@ -439,6 +460,9 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     for (void *q : {(void *)ctx->dsub, (void *)ctx->dweights, (void *)ctx->dregs, (void *)ctx->dreg_R, (void *)ctx->dobj, (void *)ctx->dphik,
                     (void *)ctx->dgrad, (void *)ctx->dval})
         if (q) (void)hipFree(q);
+    for (void *q : {(void *)ctx->dsp_pos, (void *)ctx->dsp_coef, (void *)ctx->dsp_glv, (void *)ctx->dsp_gvals})
+        if (q) (void)hipFree(q);
+    delete ctx->sp_plan;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -571,6 +595,7 @@ extern "C" int pcl_hess_structure_i64(const pcl_ctx *ctx, int64_t *rows, int64_t
 // no SGPR spills).  A few shapes are instantiated statically; any other shape is compiled on first use from the kernel
 // headers that sit next to this library (pcl_*.hpp, located with dladdr) -- about 1.5 s, cached for the process.
 // libhiprtc is opened lazily; when it or the headers are missing the run-time-shape instances are used (same results).
+#include <functional>
 #include <map>
 #include <mutex>
 namespace {
@@ -637,12 +662,18 @@ bool slurp(const std::string &path, std::string &out) {
     return !out.empty();
 }
 
-// Compile (once per process, device and instance) one template instance, e.g. "pcl_hess_kernel_v2<2, 4, 24, true>".
-hipFunction_t jit_function(int device, const char *instance) {
-    const std::string key = std::to_string(device) + "|" + instance;
+// Compile (once per process, device and key) `source` against the kernel headers next to the library and return the kernel
+// `name_expr` names (a template instance such as "pcl_hess_kernel_v2<2, 4, 24, true>", or an extern "C" kernel of the source).
+hipFunction_t jit_compile(int device, const std::string &key_, const std::string &source, const char *name_expr, bool plain_name) {
+    const std::string key = std::to_string(device) + "|" + key_;
     std::lock_guard<std::mutex> lock(g_jit_mutex);
     auto it = g_jit.find(key);
-    if (it != g_jit.end()) return it->second.failed ? nullptr : it->second.fn;
+    if (it != g_jit.end()) {
+        if (it->second.failed) return nullptr;
+        if (!plain_name) return it->second.fn;
+        hipFunction_t f = nullptr;  // several kernels of one generated module
+        return hipModuleGetFunction(&f, it->second.mod, name_expr) == hipSuccess ? f : nullptr;
+    }
     JitKernel &jk = g_jit[key];
     jk.failed = true;
     if (!rtc_load()) return nullptr;
@@ -655,24 +686,23 @@ hipFunction_t jit_function(int device, const char *instance) {
     const size_t slash = dir.find_last_of('/');
     dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
     const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp",
-                           "pcl_kernel_hessian_v3.hpp"};
-    std::string hdr[5];
-    const char *hdrp[5];
-    for (int i = 0; i < 5; ++i) {
+                           "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp"};
+    constexpr int NH = 6;
+    std::string hdr[NH];
+    const char *hdrp[NH];
+    for (int i = 0; i < NH; ++i) {
         if (!slurp(dir + "/" + names[i], hdr[i])) {
             g_jit_note = "kernel header not found next to the library: " + dir + "/" + names[i];
             return nullptr;
         }
         hdrp[i] = hdr[i].c_str();
     }
-    const char *src = "#include \"pcl_device_common.hpp\"\n#include \"pcl_kernels_fused_v2.hpp\"\n#include \"pcl_kernel_fused_v3.hpp\"\n"
-                      "#include \"pcl_kernels_hessian.hpp\"\n#include \"pcl_kernel_hessian_v3.hpp\"\n";
     void *prog = nullptr;
-    if (g_rtc.CreateProgram(&prog, src, "pcl_jit.hip", 5, hdrp, names) != 0) {
+    if (g_rtc.CreateProgram(&prog, source.c_str(), "pcl_jit.hip", NH, hdrp, names) != 0) {
         g_jit_note = "hiprtcCreateProgram failed";
         return nullptr;
     }
-    g_rtc.AddNameExpression(prog, instance);
+    if (!plain_name) g_rtc.AddNameExpression(prog, name_expr);
 #ifdef PCL_PROFILE
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-DPCL_PROFILE"};
 #else
@@ -680,7 +710,7 @@ hipFunction_t jit_function(int device, const char *instance) {
 #endif
     if (g_rtc.CompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts) != 0) {
         size_t ls = 0;
-        g_jit_note = std::string("hiprtcCompileProgram failed for ") + instance;
+        g_jit_note = std::string("hiprtcCompileProgram failed for ") + key_;
         if (g_rtc.GetProgramLogSize && g_rtc.GetProgramLog && g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
             std::string log(ls, '\0');
             g_rtc.GetProgramLog(prog, &log[0]);
@@ -691,11 +721,11 @@ hipFunction_t jit_function(int device, const char *instance) {
     }
     const char *lowered = nullptr;
     size_t cs = 0;
-    g_rtc.GetLoweredName(prog, instance, &lowered);
+    if (!plain_name) g_rtc.GetLoweredName(prog, name_expr, &lowered);
     g_rtc.GetCodeSize(prog, &cs);
     std::vector<char> code(cs);
     g_rtc.GetCode(prog, code.data());
-    const std::string lname = lowered ? lowered : "";
+    const std::string lname = plain_name ? std::string(name_expr) : (lowered ? lowered : "");
     g_rtc.DestroyProgram(&prog);
     if (lname.empty() || hipModuleLoadData(&jk.mod, code.data()) != hipSuccess || hipModuleGetFunction(&jk.fn, jk.mod, lname.c_str()) != hipSuccess) {
         g_jit_note = "hipModuleLoadData / hipModuleGetFunction failed";
@@ -705,7 +735,30 @@ hipFunction_t jit_function(int device, const char *instance) {
     ++g_jit_compiles;
     return jk.fn;
 }
+hipFunction_t jit_function(int device, const char *instance) {
+    static const std::string src = "#include \"pcl_device_common.hpp\"\n#include \"pcl_kernels_fused_v2.hpp\"\n#include \"pcl_kernel_fused_v3.hpp\"\n"
+                                   "#include \"pcl_kernels_hessian.hpp\"\n#include \"pcl_kernel_hessian_v3.hpp\"\n";
+    return jit_compile(device, instance, src, instance, false);
+}
+// Source of the pattern-compiled kernels of one system (pcl_codegen.hpp)
+std::string sparse_source(const pcl_codegen::SpPlan &plan) {
+    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::apply_functions(plan) + "#include \"pcl_kernel_hessian_sparse.hpp\"\n";
+}
 }  // namespace
+
+// Inspection hook: the generated source of the pattern-compiled kernels for a system (needs no device).
+extern "C" int pcl_codegen_source(int d, int m, const double *G0, const double *Gj, char *buf, int64_t cap, int64_t *needed) {
+    if (d < 1 || d > 32 || m < 0 || m > 6 || !G0 || (m > 0 && !Gj) || !needed) return PCL_EINVAL;
+    const pcl_codegen::SpPlan plan = pcl_codegen::make_plan(d, m, G0, 1, Gj);
+    const std::string src = sparse_source(plan);
+    *needed = (int64_t)src.size() + 1;
+    if (buf && cap > 0) {
+        const size_t nb = std::min<size_t>((size_t)cap - 1, src.size());
+        memcpy(buf, src.data(), nb);
+        buf[nb] = '\0';
+    }
+    return PCL_OK;
+}
 
 // --- launch helpers -------------------------------------------------------------------------
 // LD = (n rounded up to 4) + 2  ==  2*odd: conflict-free ds_read_b64 of the MFMA b operand
@@ -1156,6 +1209,44 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
         HIP_TRY(ctx, hipGetLastError());
         ctx->last_hess_kernel = 90 + p.q;
         return PCL_OK;
+    }
+    // version 4 (default where it applies): the pattern-compiled kernel -- sparse iso generators, one state column per lane
+    if ((ctx->opt_hess_kernel == 0 || ctx->opt_hess_kernel == 4) && ctx->sp_plan && !ctx->sp_failed && ctx->opt_jit && ctx->desc.d == p.d) {
+        const pcl_codegen::SpPlan &sp = *ctx->sp_plan;
+        const long long items = (long long)p.batch * p.K;
+        if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+        const size_t ldsp = ((size_t)(5 + sp.m) * sp.n * sp.d + ((size_t)sp.m * (sp.m + 2) + 1) * 4) * sizeof(double) + 64;
+        if (!ctx->sp_fhess && ldsp <= (size_t)ctx->max_lds) {  // (the source is generated once per context)
+            const std::string src = sparse_source(sp);
+            const std::string key = "sparse:" + std::to_string(std::hash<std::string>{}(src));
+            ctx->sp_fhess = jit_compile(ctx->device, key, src, "pcl_hess_sparse_kernel", true);
+            if (ctx->sp_fhess) ctx->sp_fval = jit_compile(ctx->device, key, src, "pcl_sparse_values_kernel", true);
+        }
+        hipFunction_t fval = ctx->sp_fval, fmain = ctx->sp_fhess;
+        if (fmain && fval) {
+            if (ctx->sp_gvals_cap < (long long)ctx->desc.batch * p.K) {
+                if (ctx->dsp_gvals) (void)hipFree(ctx->dsp_gvals);
+                ctx->dsp_gvals = nullptr;
+                ctx->sp_gvals_cap = 0;
+                HIP_TRY(ctx, hipMalloc((void **)&ctx->dsp_gvals, ((size_t)ctx->desc.batch * p.K * sp.nzp + 32) * sizeof(double)));
+                ctx->sp_gvals_cap = (long long)ctx->desc.batch * p.K;
+            }
+            {
+                void *args[] = {(void *)&p, (void *)&ctx->dsp_pos, (void *)&ctx->dsp_coef, (void *)&ctx->dsp_gvals};
+                HIP_TRY(ctx, hipModuleLaunchKernel(fval, (unsigned)items, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+            }
+            const long long slots = std::max(ctx->n_cu, 1), rounds = (items + slots - 1) / slots;
+            long long grid = (items + rounds - 1) / rounds;  // every workgroup walks the same number of intervals
+            if (ctx->opt_grid > 0) grid = std::min<long long>(items, ctx->opt_grid);
+            void *args[] = {(void *)&p, (void *)&ctx->dsp_gvals, (void *)&ctx->dsp_glv};
+            HIP_TRY(ctx, hipModuleLaunchKernel(fmain, (unsigned)grid, 1, 1, 64 * (sp.m + 2), 1, 1, (unsigned)ldsp, ctx->stream, args, nullptr));
+            ctx->last_hess_kernel = 6;  // the pattern-compiled kernel
+            return PCL_OK;
+        }
+        ctx->sp_failed = 1;
+        if (ctx->opt_hess_kernel == 4) return fail(ctx, PCL_ESHAPE, "hess_kernel=4: the pattern-compiled kernel is not available (%s)", g_jit_note.c_str());
+    } else if (ctx->opt_hess_kernel == 4) {
+        return fail(ctx, PCL_ESHAPE, "hess_kernel=4 needs sparse iso generators (at most %d distinct drive magnitudes), a unitary problem with odd 9 <= d <= 32, 1..6 drives and jit=1", pcl_codegen::kMaxMags);
     }
     // version 3 (default where its tiles fit LDS): one workgroup per interval, jobs split by drive
     if (mf && (ctx->opt_hess_kernel == 0 || ctx->opt_hess_kernel == 3) && hess_v2_supported(ctx) && ctx->cols == ctx->desc.d && ctx->uell_w <= 2 &&
@@ -1847,7 +1938,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
     else if (!strcmp(key, "contiguous"))  // kernel 3: 1 = equal contiguous column ranges per workgroup (default), 0 = round-robin slices
         ctx->opt_contig = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "hess_kernel")) {  // 0: auto, 1: one workgroup per interval, 2: persistent wave-synchronous kernel
-        if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "hess_kernel must be 0, 1, 2 or 3");
+        if (v < 0 || v > 4) return fail(ctx, PCL_EINVAL, "hess_kernel must be 0 .. 4");
         ctx->opt_hess_kernel = v;
     }
     else if (!strcmp(key, "debug_timing")) {  // profiling aid: cycle stamps of workgroup 0 (pcl_debug_timing reads them)

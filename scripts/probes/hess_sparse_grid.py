@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Pattern-compiled Hessian kernel: launch time against the grid (items per workgroup) and the batch."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import piccolo_jl_amd as pa
+from piccolo_jl_amd import synthetic
+system = synthetic.config_system(3)
+def tm(c, Zd, mu, hv, reps=20):
+    for _ in range(3): c.hess_dev(Zd, mu, hv)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): c.hess_dev(Zd, mu, hv)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+for batch in (1, 8, 12, 16):
+    trajs = [synthetic.synthetic_trajectory(system, 100, seed=1000 + i) for i in range(batch)]
+    ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], batch)
+    c = ms.ctx
+    Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()
+    mu = torch.randn(c.n_rows, dtype=torch.float64, device="cuda")
+    hv = torch.empty(c.hess_nnz, dtype=torch.float64, device="cuda")
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    c.set_option("hess_kernel", 4)
+    items = batch * 99
+    line = "batch %2d items %4d:" % (batch, items)
+    for g in (0, items, 256, 198, 128, 99, 64, 32, 8, 1):
+        if g <= items:
+            c.set_option("grid", g)
+            line += " g%d %.0f" % (g, tm(c, Zd, mu, hv, 10 if g > 8 else 3))
+    c.set_option("grid", 0)
+    print(line, flush=True)
+    ms.close()

@@ -186,3 +186,49 @@ def test_config4_synthetic_members_match_the_oracle_definition():
         assert np.allclose(s.G_drives_array(), np.array(ref.G_drives), rtol=0, atol=1e-13)
     tr = synthetic.synthetic_ensemble(members[:2], 4, seed=1)
     assert list(tr.components)[:3] == ["Ũ⃗1", "Ũ⃗2", "Δt"] and tr.dim == 2 * 1458 + 2 + 18
+
+
+def _generated_source(lib, G0, Gj):
+    import ctypes
+    n = G0.shape[0]
+    g0 = np.ascontiguousarray(G0.T).ravel()  # column-major
+    gj = np.ascontiguousarray(np.stack([g.T for g in Gj])).ravel()
+    need = ctypes.c_int64()
+    assert lib.pcl_codegen_source(n // 2, len(Gj), g0.ctypes.data, gj.ctypes.data, None, 0, ctypes.byref(need)) == 0
+    buf = ctypes.create_string_buffer(need.value)
+    assert lib.pcl_codegen_source(n // 2, len(Gj), g0.ctypes.data, gj.ctypes.data, buf, need.value, ctypes.byref(need)) == 0
+    return buf.value.decode()
+
+
+def test_pattern_compiled_kernel_source(lib, tmp_path):
+    """The source the library generates for BASELINE config 3 (and compiles with hiprtc on first use): deterministic, one
+    multiply-add statement per entry of the union pattern of G(u) in the big product, and it compiles for gfx950 with the
+    toolchain of this image (no GPU needed) into a kernel that fits the register file without scratch traffic worth noting."""
+    import re, shutil, subprocess
+    from piccolo_jl_amd import synthetic
+    s3 = synthetic.config_system(3)
+    Gj = s3.G_drives_array()
+    src = _generated_source(lib, s3.G_drift, Gj)
+    assert src == _generated_source(lib, s3.G_drift, Gj)
+    assert "pcl_kernel_hessian_sparse.hpp" in src and "#define SPD 27" in src and "#define SPM 6" in src
+    n, d = 54, 27
+    union = s3.G_drift[:, :d] != 0
+    for g in Gj:
+        union |= g[:, :d] != 0
+    nz = int(union.sum())
+    assert "#define SPNZ %d\n" % nz in src
+    body = src[src.index("void sp_gt("):src.index("struct sp_mags")]
+    assert len(re.findall(r"v_(?:mul|fmac|fma)_f64", body)) == nz  # one instruction per entry: no padding, no dense tiles
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    f = tmp_path / "sp.hip"
+    f.write_text(src)
+    csrc = os.path.join(os.path.dirname(pa.__file__), "csrc") if os.path.isdir(os.path.join(os.path.dirname(pa.__file__), "csrc")) else None
+    assert csrc is not None
+    out = tmp_path / "sp.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-include", "hip/hip_runtime.h", "-I", csrc, "-S",
+                        "--cuda-device-only", "-o", str(out), str(f)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    assert "pcl_hess_sparse_kernel" in asm and "pcl_sparse_values_kernel" in asm
+    scratch = [int(x) for x in re.findall(r"; ScratchSize: (\d+)", asm)]
+    assert max(scratch) <= 256  # a few loop-invariant integers, not operand arrays

@@ -759,8 +759,21 @@ def test_hessian_kernel_variants(cfg, N, batch):
     c = make_ctx(lay, G0, Gj, batch=batch, batch_mode=pa._lib.PCL_BATCH_TRAJ, x_offs=[lay.x_off])
     Zb, mub = np.stack(Zs), np.concatenate([m_.reshape(-1) for m_ in mus])
     h_auto = c.hess(Zb, mub)
-    assert c.get_option("last_hess_kernel") == (4 if cfg == 3 else 2)
+    assert c.get_option("last_hess_kernel") == (6 if cfg == 3 else 2)  # 6: the pattern-compiled kernel (sparse iso generators, odd d >= 9)
     close(h_auto, ref, 1e-11)
+    if cfg == 3:
+        c.set_option("hess_kernel", 4)
+        for grid in (0, 1, 2, 3, 7, 1000):
+            c.set_option("grid", grid)
+            h = c.hess(Zb, mub)
+            assert c.get_option("last_hess_kernel") == 6
+            close(h, ref, 1e-11)
+            assert np.array_equal(h, c.hess(Zb, mub))
+        c.set_option("grid", 0)
+    else:
+        c.set_option("hess_kernel", 4)  # not a sparse iso system of odd d >= 9: loud failure, no silent substitute
+        with pytest.raises(pa.PclError):
+            c.hess(Zb, mub)
     for hk in (1, 2):
         c.set_option("hess_kernel", hk)
         for cps in (0, 1, 2, 3, 5, 16):
@@ -1344,9 +1357,14 @@ def test_other_specialised_shapes(levels, batch):
     close(delta, np.concatenate([r[0].reshape(-1) for r in refs]))
     close(vals, np.concatenate([r[1].reshape(-1) for r in refs]))
     mu = np.random.default_rng(1).standard_normal((batch, lay.K, lay.x_dim))
+    h_ref = np.concatenate([ref_lib.hess(Z, mu[i], lay, G0, Gj).reshape(-1) for i, Z in enumerate(Zs)])
     hv = c.hess(np.stack(Zs), mu.reshape(-1))
-    assert c.get_option("last_hess_kernel") == (4 if levels == 5 else 5)  # kernel 3: static instance at d = 25, compiled on first use at d = 16
-    close(hv, np.concatenate([ref_lib.hess(Z, mu[i], lay, G0, Gj).reshape(-1) for i, Z in enumerate(Zs)]), 1e-10)
+    assert c.get_option("last_hess_kernel") == (6 if levels == 5 else 5)  # d = 25: the pattern-compiled kernel; d = 16 (even): kernel 3, compiled on first use
+    close(hv, h_ref, 1e-10)
+    c.set_option("hess_kernel", 3)
+    hv = c.hess(np.stack(Zs), mu.reshape(-1))
+    assert c.get_option("last_hess_kernel") == (4 if levels == 5 else 5)  # kernel 3: static instance at d = 25
+    close(hv, h_ref, 1e-10)
     c.close()
 
 
