@@ -5,8 +5,10 @@
 // left, so one state column never needs another one: a lane can own one column, keep it in REGISTERS and apply G(u)^T as a
 // straight line of fused multiply-adds whose register indices are the sparsity pattern and whose coefficients are scalar
 // registers (s_load from a per-interval value table).  No LDS operand traffic, no matrix-core padding (a 54 x 54 x 27
-// product costs 112 MFMAs = 7168 cycles of one SIMD; 307 FMAs = 1228 cycles).  The iso structure halves the code: the
-// lower half of the wave holds the column multiplied by -i, runs the SAME instructions and obtains the bottom rows.
+// product costs 112 MFMAs = 7168 cycles of one SIMD; 307 FMAs = 1228 cycles).  The iso structure halves the code and the
+// registers: lane (half, c) holds only ITS half x of column c (half 0: top rows a, half 1: bottom rows b), both halves run
+// the SAME instructions  U = A^T x, V = B^T x  and one cross-half swap (v_permlane32_swap, no LDS) completes
+//     top = A^T a + B^T b = U(half 0) + V(half 1),      bottom = -B^T a + A^T b = U(half 1) - V(half 0).
 //
 // The pattern is data, so the kernel source is generated per system and compiled on first use (hiprtc).
 #pragma once
@@ -105,8 +107,10 @@ struct Chunks {
     }
 };
 
-// Body of  template <class F> void f(a, b, tab, F out):  `ordered` is in emission order with consecutive table indices
-// starting at `base`; every output (also the ones without a term) is passed to out(index, value) once, group by group.
+// Body of  template <class F> void f(x, tab, sgn, half, out):  `ordered` is in emission order with consecutive table indices
+// starting at `base` (or resident magnitudes).  Entries of the A block (in < d) accumulate U[out] += coef x[in], entries of
+// the B block V[out] += coef x[in - d]; a finished group of outputs is completed with the other half's V and passed to
+// out(index, value).
 static inline void emit_groups(std::string &s, const std::vector<Term> &ordered, int d, int group, const char *tab, int base) {
     char buf[256];
     Chunks ch(s, tab, base, (int)ordered.size());
@@ -115,31 +119,36 @@ static inline void emit_groups(std::string &s, const std::vector<Term> &ordered,
     for (int g0 = 0; g0 < d; g0 += group) {
         const int g1 = std::min(d, g0 + group);
         s += "    {\n";
-        std::vector<char> seen(d, 0);
+        std::vector<char> seen(2 * d, 0);
         for (int o = g0; o < g1; ++o) {
-            snprintf(buf, sizeof buf, "        double o%d = 0.0;\n", o);
+            snprintf(buf, sizeof buf, "        double u%d = 0.0, v%d = 0.0;\n", o, o);
             s += buf;
         }
         // one volatile asm statement per multiply-add: the instruction order is the emission order (the compiler allocates the
         // registers; left to schedule, it floats the arithmetic away from the loads and spills)
         for (; i < ordered.size() && ordered[i].out < g1 && ordered[i].out >= g0; ++i) {
             const Term &q = ordered[i];
-            const char *src = q.in < d ? "a" : "b";
-            const int idx = q.in < d ? q.in : q.in - d;
-            char mg[24];
+            const bool isv = q.in >= d;
+            const int idx = isv ? q.in - d : q.in;
+            char acc[16], mg[24];
+            snprintf(acc, sizeof acc, "%c%d", isv ? 'v' : 'u', q.out);
             snprintf(mg, sizeof mg, "mg.m%d", q.mag);
             const std::string cf = q.mag >= 0 ? std::string(mg) : ch.coef(q.src);
-            if (!seen[q.out])
-                snprintf(buf, sizeof buf, "        asm volatile(\"v_mul_f64 %%0, %s%%1, %%2\" : \"=v\"(o%d) : \"s\"(%s), \"v\"(%s[%d]));\n", q.neg ? "-" : "", q.out, cf.c_str(), src, idx);
+            char &sn = seen[(isv ? d : 0) + q.out];
+            if (!sn)
+                snprintf(buf, sizeof buf, "        asm volatile(\"v_mul_f64 %%0, %s%%1, %%2\" : \"=v\"(%s) : \"s\"(%s), \"v\"(x[%d]));\n", q.neg ? "-" : "", acc, cf.c_str(), idx);
             else if (!q.neg)
-                snprintf(buf, sizeof buf, "        asm volatile(\"v_fmac_f64 %%0, %%1, %%2\" : \"+v\"(o%d) : \"s\"(%s), \"v\"(%s[%d]));\n", q.out, cf.c_str(), src, idx);
+                snprintf(buf, sizeof buf, "        asm volatile(\"v_fmac_f64 %%0, %%1, %%2\" : \"+v\"(%s) : \"s\"(%s), \"v\"(x[%d]));\n", acc, cf.c_str(), idx);
             else
-                snprintf(buf, sizeof buf, "        asm volatile(\"v_fma_f64 %%0, -%%1, %%2, %%0\" : \"+v\"(o%d) : \"s\"(%s), \"v\"(%s[%d]));\n", q.out, cf.c_str(), src, idx);
-            seen[q.out] = 1;
+                snprintf(buf, sizeof buf, "        asm volatile(\"v_fma_f64 %%0, -%%1, %%2, %%0\" : \"+v\"(%s) : \"s\"(%s), \"v\"(x[%d]));\n", acc, cf.c_str(), idx);
+            sn = 1;
             s += buf;
         }
         for (int o = g0; o < g1; ++o) {
-            snprintf(buf, sizeof buf, "        out(%d, o%d);\n", o, o);
+            if (seen[d + o])  // (both halves run this code: an output without B entries has V = 0 in both)
+                snprintf(buf, sizeof buf, "        out(%d, sp_complete(u%d, v%d, sgn, half));\n", o, o, o);
+            else
+                snprintf(buf, sizeof buf, "        out(%d, u%d);\n", o, o);
             s += buf;
         }
         // a scheduling-region boundary: what the caller does with the group (LDS stores, dot products) is scheduled here, not
@@ -147,34 +156,44 @@ static inline void emit_groups(std::string &s, const std::vector<Term> &ordered,
         s += "        __builtin_amdgcn_sched_barrier(0);\n    }\n";
     }
 }
-// Body of  double f(a, b, dq, mg):  <T^T x, dq> = sum_g m_g sum_k (+-) x[in_k] dq[out_k]  -- one multiply-add per entry, no
-// coefficient inside the sums (two dependency chains per magnitude)
+// Body of  double f(x, down, doth, mg, sgn):  this lane's part of <T^T x, D> = U . D_own - sgn V . D_other
+//   = sum_g m_g (sum_{A entries} (+-) x[in] down[out] - sgn sum_{B entries} (+-) x[in] doth[out])
+// -- one multiply-add per entry, no coefficient inside the sums
 static inline void emit_dot(std::string &s, const std::vector<Term> &terms, int d, int n_mags) {
     char buf[256];
-    std::vector<int> cnt(n_mags, 0);
+    std::vector<int> cu(n_mags, 0), cv(n_mags, 0);
+    for (const Term &q : terms) (q.in >= d ? cv : cu)[q.mag]++;
     for (int g = 0; g < n_mags; ++g) {
-        bool any = false;
-        for (const Term &q : terms) any |= q.mag == g;
-        if (!any) continue;
-        snprintf(buf, sizeof buf, "    double e%d_0 = 0.0, e%d_1 = 0.0;\n", g, g);
-        s += buf;
+        if (cu[g]) {
+            snprintf(buf, sizeof buf, "    double eu%d = 0.0;\n", g);
+            s += buf;
+        }
+        if (cv[g]) {
+            snprintf(buf, sizeof buf, "    double ev%d = 0.0;\n", g);
+            s += buf;
+        }
     }
     for (const Term &q : terms) {
-        const char *src = q.in < d ? "a" : "b";
-        const int idx = q.in < d ? q.in : q.in - d;
-        const int ch = cnt[q.mag]++ & 1;
+        const bool isv = q.in >= d;
+        const int idx = isv ? q.in - d : q.in;
         if (!q.neg)
-            snprintf(buf, sizeof buf, "    asm volatile(\"v_fmac_f64 %%0, %%1, %%2\" : \"+v\"(e%d_%d) : \"v\"(%s[%d]), \"v\"(dq[%d]));\n", q.mag, ch, src, idx, q.out);
+            snprintf(buf, sizeof buf, "    asm volatile(\"v_fmac_f64 %%0, %%1, %%2\" : \"+v\"(e%c%d) : \"v\"(x[%d]), \"v\"(%s[%d]));\n", isv ? 'v' : 'u', q.mag, idx, isv ? "doth" : "down", q.out);
         else
-            snprintf(buf, sizeof buf, "    asm volatile(\"v_fma_f64 %%0, -%%1, %%2, %%0\" : \"+v\"(e%d_%d) : \"v\"(%s[%d]), \"v\"(dq[%d]));\n", q.mag, ch, src, idx, q.out);
+            snprintf(buf, sizeof buf, "    asm volatile(\"v_fma_f64 %%0, -%%1, %%2, %%0\" : \"+v\"(e%c%d) : \"v\"(x[%d]), \"v\"(%s[%d]));\n", isv ? 'v' : 'u', q.mag, idx, isv ? "doth" : "down", q.out);
         s += buf;
     }
     s += "    double r = 0.0;\n";
-    for (int g = 0; g < n_mags; ++g)
-        if (cnt[g]) {
-            snprintf(buf, sizeof buf, "    r = __builtin_fma(mg.m%d, e%d_0 + e%d_1, r);\n", g, g, g);
-            s += buf;
-        }
+    for (int g = 0; g < n_mags; ++g) {
+        if (cu[g] && cv[g])
+            snprintf(buf, sizeof buf, "    r = __builtin_fma(mg.m%d, __builtin_fma(-sgn, ev%d, eu%d), r);\n", g, g, g);
+        else if (cu[g])
+            snprintf(buf, sizeof buf, "    r = __builtin_fma(mg.m%d, eu%d, r);\n", g, g);
+        else if (cv[g])
+            snprintf(buf, sizeof buf, "    r = __builtin_fma(mg.m%d, -sgn * ev%d, r);\n", g, g);
+        else
+            continue;
+        s += buf;
+    }
     s += "    return r;\n";
 }
 }  // namespace detail
@@ -247,17 +266,24 @@ static inline std::string apply_functions(const SpPlan &P) {
     using detail::Term;
     const int d = P.d;
     std::string s;
-    char buf[320];
+    char buf[1600];
     snprintf(buf, sizeof buf,
              "#define SPD %d\n#define SPM %d\n#define SPN %d\n#define SPNZ %d\n#define SPNZP %d\n"
              "typedef const double __attribute__((address_space(4))) *sp_cptr;\n"
-             "typedef double sp_v8d __attribute__((ext_vector_type(8)));\n",
+             "typedef double sp_v8d __attribute__((ext_vector_type(8)));\n"
+             "// u + sgn * (the v of the lane 32 positions away): v_permlane32_swap, VALU only\n"
+             "static __device__ __forceinline__ double sp_complete(double u, double v, double sgn, int half) {\n"
+             "    const int lo = __double2loint(v), hi = __double2hiint(v);\n"
+             "    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);\n"
+             "    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);\n"
+             "    return __builtin_fma(sgn, __hiloint2double(half ? rh[0] : rh[1], half ? rl[0] : rl[1]), u);\n"
+             "}\n",
              d, P.m, P.n, P.nz, P.nzp);
     s += buf;
     {
         std::vector<Term> t;  // the plan's entries ARE in emission order
         for (int k = 0; k < P.nz; ++k) t.push_back(detail::term_t(P.row[k], P.col[k], d, k));
-        s += "template <class F> static __device__ __forceinline__ void sp_gt(const double (&a)[SPD], const double (&b)[SPD], sp_cptr g, F out) {\n";
+        s += "template <class F> static __device__ __forceinline__ void sp_gt(const double (&x)[SPD], sp_cptr g, double sgn, int half, F out) {\n";
         detail::emit_groups(s, t, d, kGroup, "g", 0);
         s += "}\n";
     }
@@ -281,18 +307,18 @@ static inline std::string apply_functions(const SpPlan &P) {
             q.mag = P.dmagi[k];
             tt.push_back(q);
         }
-        snprintf(buf, sizeof buf, "template <class F> static __device__ __forceinline__ void sp_glt_%d(const double (&a)[SPD], const double (&b)[SPD], const sp_mags &mg, F out) {\n", l);
+        snprintf(buf, sizeof buf, "template <class F> static __device__ __forceinline__ void sp_glt_%d(const double (&x)[SPD], const sp_mags &mg, double sgn, int half, F out) {\n", l);
         s += buf;
         detail::emit_groups(s, detail::emission_order(tt, d, kGroup), d, kGroup, "mg", 0);
         s += "}\n";
-        snprintf(buf, sizeof buf, "static __device__ __forceinline__ double sp_gltdot_%d(const double (&a)[SPD], const double (&b)[SPD], const double (&dq)[SPD], const sp_mags &mg) {\n", l);
+        snprintf(buf, sizeof buf, "static __device__ __forceinline__ double sp_gltdot_%d(const double (&x)[SPD], const double (&down)[SPD], const double (&doth)[SPD], const sp_mags &mg, double sgn) {\n", l);
         s += buf;
         detail::emit_dot(s, tt, d, (int)P.mags.size());
         s += "}\n";
     }
-    s += "template <int L> static __device__ __forceinline__ double sp_gltdot(const double (&a)[SPD], const double (&b)[SPD], const double (&dq)[SPD], const sp_mags &mg) {\n";
+    s += "template <int L> static __device__ __forceinline__ double sp_gltdot(const double (&x)[SPD], const double (&down)[SPD], const double (&doth)[SPD], const sp_mags &mg, double sgn) {\n";
     for (int l = 0; l < P.m; ++l) {
-        snprintf(buf, sizeof buf, "    if constexpr (L == %d) return sp_gltdot_%d(a, b, dq, mg);\n", l, l);
+        snprintf(buf, sizeof buf, "    if constexpr (L == %d) return sp_gltdot_%d(x, down, doth, mg, sgn);\n", l, l);
         s += buf;
     }
     s += "    return 0.0;\n}\n";
@@ -305,9 +331,9 @@ static inline std::string apply_functions(const SpPlan &P) {
     s += "s_waitcnt lgkmcnt(0)\" : \"=&s\"(pf_) : \"s\"(ptr) : \"memory\"); } while (0)\n";
     // run-time (wave-uniform) dispatch for the two small drive-specific products of a drive wave; the cases exchange data with
     // the rest of the role through LDS only, so no register webs are merged behind the switch
-    s += "#define SP_GLT_SWITCH(l, a, b, mg, out) switch (l) {";
+    s += "#define SP_GLT_SWITCH(l, x, mg, sgn, half, out) switch (l) {";
     for (int l = 0; l < P.m; ++l) {
-        snprintf(buf, sizeof buf, " case %d: sp_glt_%d(a, b, mg, out); break;", l, l);
+        snprintf(buf, sizeof buf, " case %d: sp_glt_%d(x, mg, sgn, half, out); break;", l, l);
         s += buf;
     }
     s += " default: break; }\n";

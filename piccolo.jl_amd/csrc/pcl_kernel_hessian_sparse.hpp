@@ -3,21 +3,25 @@
 // SPNZ / SPNZP and the straight-line functions sp_gt / sp_glt / sp_glt_acc / sp_gl are defined before this file.
 //
 // Every product of the Hessian acts on a state column from the left, so a lane owns ONE column and keeps it in registers:
-//     lane = (half, c):  half 0 holds x = (a | b) = (top rows | bottom rows) of column c and produces the top rows of T x,
-//                        half 1 holds -i x = (b | -a), runs the same instructions and produces the bottom rows
-// (T = [[A, -B], [B, A]]: every generator is an exact iso(.) image).  A result that feeds another product is completed with
-// the other half's rows by one cross-half exchange.  Coefficients of G(u_k) come from a per-interval value table through
-// scalar loads (constant address space), the drives' from a launch-invariant table.
+//     lane = (half, c): half 0 holds the top rows a of column c, half 1 the bottom rows b; both run the same instructions
+//     U = A^T x, V = B^T x on their half x and complete  top = U(0) + V(1), bottom = U(1) - V(0)  with one cross-half swap
+// (T = [[A, -B], [B, A]]: every generator is an exact iso(.) image).  Coefficients of G(u_k) come from a per-interval value
+// table through scalar loads (constant address space); the drives' distinct magnitudes live in scalar registers.
 // Roles (one workgroup of SPM + 2 waves per interval, a contiguous range of intervals per workgroup):
-//     wave 0      A1 = G^T M -> LDS tile (flag: ready), A2 = G^T A1, outputs d2/dh dX, <A2, D>
-//     wave 1      loader: the next interval's mu, x_k, x_{k+1} travel in its registers during the interval
-//     wave 2 + l  P_l = G_l^T M, <P_l, G_j D> for every j, Q_l = G^T P_l, Q_l += G_l^T A1, <P_l, S>, <Q_l + R_l, D>, outputs d2/du_l dX
-// Outputs leave through one LDS tile per wave (column layout -> flat) as runs of 64 consecutive doubles.
-// Two barriers per interval; the 28 scalar entries are wave sums (fixed shuffle tree) added in a fixed order: repeatable bits.
+//     wave 0      A1 = G^T M -> registers and LDS tile (flag: ready), A2 = G^T A1, outputs d2/dh dX, <A2, D>
+//     wave 1      loader: the next interval's mu, x_k, x_{k+1} travel in its registers during the interval; it also touches
+//                 the next interval's value table so that the other waves' scalar loads hit
+//     wave 2 + l  P_l = G_l^T M, <P_l, S>, R_l = G_l^T A1, <P_l, G_j D> for every j, Q_l = G^T P_l consumed row by row:
+//                 <Q_l + R_l, D> and the two output vectors d2/du_l dX
+// Outputs leave through one LDS tile per wave (lane = column -> lane = row): one column of SPN consecutive doubles per store.
+// Two barriers per interval; the 28 scalar entries are 16-lane row sums (DPP) added in a fixed order: repeatable bits.
 #pragma once
 
 #define SPXD (SPN * SPD)
-#define SPTILE SPXD  // tiles are flat [column][row]: lane stride SPN doubles = 4 SPD banks -> conflict-free for odd SPD
+// LDS tiles are [column][row] with an ODD column stride (SPN + 1 doubles): the lanes of a half wave, one column each, hit 32
+// different 8-byte bank pairs (with stride SPN -- even -- half of all LDS cycles of the kernel were bank conflicts)
+#define SPCS (SPN + 1)
+#define SPTILE (SPCS * SPD)
 #define SPNL ((SPXD + 63) / 64)
 #define SPNSC ((SPM + 1) * (SPM + 2) / 2)
 #define SPNPAIR (SPM * (SPM + 1) / 2)
@@ -61,7 +65,7 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
     const bool act = c < SPD;
     const int cc = act ? c : 0;
     const double sgn = half ? -1.0 : 1.0;
-    const int own = cc * SPN + half * SPD, oth = cc * SPN + (1 - half) * SPD;
+    const int own = cc * SPCS + half * SPD, oth = cc * SPCS + (1 - half) * SPD;
     double *Mt = lds, *Dt = Mt + SPTILE, *St = Dt + SPTILE, *A1t = St + SPTILE, *Stg = A1t + SPTILE;  // Stg: SPM + 1 staging tiles
     double *scal = Stg + (SPM + 1) * SPTILE;  // [SPM][SPM + 2][4] drive-wave sums per 16-lane row | [1][4] <A2, D>
     int *flag = (int *)(scal + (SPM * (SPM + 2) + 1) * 4);
@@ -91,19 +95,19 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
 #define SP_STAMP() do { } while (0)
 #define SP_END() do { } while (0)
 #endif
-    // flat tile -> global, 64 consecutive doubles per instruction.  Addresses are one per-lane base plus immediates (written
-    // with `lane + 64 i` indices, the compiler hoists 23 index registers per tile out of the interval loop and spills)
+    // tile -> global: lane = row, one column (SPN consecutive doubles) per instruction; every address is a per-lane base plus an
+    // immediate (index arithmetic on `lane + 64 i` gets hoisted out of the interval loop: 23 registers per tile, spilled)
     auto flush = [&](const double *T, double *out) {
         wave_lds_sync();
-        const double *Tl = T + lane;
-        double *ol = out + lane;
+        if (lane < SPN) {
+            const double *Tl = T + lane;
+            double *ol = out + lane;
 #pragma unroll
-        for (int i = 0; i < SPNL; ++i) {
-            if (i < SPXD / 64 || lane < SPXD % 64) {
+            for (int q = 0; q < SPD; ++q) {
                 if (p.nt)
-                    __builtin_nontemporal_store(Tl[64 * i], ol + 64 * i);
+                    __builtin_nontemporal_store(Tl[SPCS * q], ol + SPN * q);
                 else
-                    ol[64 * i] = Tl[64 * i];
+                    ol[SPN * q] = Tl[SPCS * q];
             }
         }
         wave_lds_sync();
@@ -112,32 +116,32 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
     // every loop passes the same two workgroup barriers per interval.
     if (wave == 1) {
         // ---- loader ---------------------------------------------------------------------------------------------------------
-        double pm[SPNL], pxn[SPNL], pxc[SPNL];
+        double pm[SPD], pxn[SPD], pxc[SPD];  // lane = row, one column per register
         auto request = [&](int item) {
             const int k = item % p.K, b = item / p.K;
             const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + p.x_offs[p.z_batch_stride ? 0 : b];
             const double *mu = p.mu + ((long long)b * p.K + k) * SPXD;
             const double *mul = mu + lane, *zl = zk + lane, *zn = zk + p.z_dim + lane;
 #pragma unroll
-            for (int i = 0; i < SPNL; ++i) {
-                pm[i] = pxn[i] = pxc[i] = 0.0;
-                if (i < SPXD / 64 || lane < SPXD % 64) {
-                    pm[i] = mul[64 * i];
-                    pxc[i] = zl[64 * i];
-                    pxn[i] = zn[64 * i];
+            for (int q = 0; q < SPD; ++q) {
+                pm[q] = pxn[q] = pxc[q] = 0.0;
+                if (lane < SPN) {
+                    pm[q] = mul[SPN * q];
+                    pxc[q] = zl[SPN * q];
+                    pxn[q] = zn[SPN * q];
                 }
             }
         };
         request(item_lo);
         SP_PREFETCH_G((sp_cptr)(gvals_ + (long long)item_lo * SPNZP));
         for (int item = item_lo; item < item_hi; ++item) {
-            double *Ml = Mt + lane, *Dl = Dt + lane, *Sl = St + lane;
+            if (lane < SPN) {
+                double *Ml = Mt + lane, *Dl = Dt + lane, *Sl = St + lane;
 #pragma unroll
-            for (int i = 0; i < SPNL; ++i) {
-                if (i < SPXD / 64 || lane < SPXD % 64) {
-                    Ml[64 * i] = pm[i];
-                    Dl[64 * i] = pxn[i] - pxc[i];
-                    Sl[64 * i] = pxn[i] + pxc[i];
+                for (int q = 0; q < SPD; ++q) {
+                    Ml[SPCS * q] = pm[q];
+                    Dl[SPCS * q] = pxn[q] - pxc[q];
+                    Sl[SPCS * q] = pxn[q] + pxc[q];
                 }
             }
             SP_STAMP();
@@ -166,35 +170,34 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
             __syncthreads();  // alpha
             SP_STAMP();
             if (item + 1 < item_hi) hn = step_of(item + 1);
-            {  // A1 = G^T M -> the A1 tile (inactive lanes repeat column 0: the same values to the same addresses)
-                double a[SPD], bq[SPD];
+            double A1[SPD];
+            {  // A1 = G^T M: registers (input of the second product, outputs) and the A1 tile (the drive waves' R_l)
+                double x[SPD];
 #pragma unroll
-                for (int r = 0; r < SPD; ++r) {
-                    a[r] = Mt[own + r];
-                    bq[r] = sgn * Mt[oth + r];
-                }
-                sp_gt(a, bq, g, [&](int c, double v) { A1t[own + c] = v; });
+                for (int r = 0; r < SPD; ++r) x[r] = Mt[own + r];
+                sp_gt(x, g, sgn, half, [&](int c, double v) {
+                    A1[c] = v;
+                    A1t[own + c] = v;  // (inactive lanes repeat column 0: the same values to the same addresses)
+                });
             }
             wave_lds_sync();
             if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             SP_STAMP();
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-            {  // A2 = G^T A1 (the other half's rows come back from the tile) -> staging tile, <A2, D>
-                double a[SPD], bq[SPD], dq[SPD];  // (D in registers: a load next to each use is a full LDS round trip per output row)
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, o6[SPD];
+            {  // A2 = G^T A1, consumed row by row: <A2, D>, d2/dh dX_k -> staging tile, d2/dh dX_{k+1} -> registers
+                double dq[SPD];
 #pragma unroll
-                for (int r = 0; r < SPD; ++r) {
-                    a[r] = A1t[own + r];
-                    bq[r] = sgn * A1t[oth + r];
-                    dq[r] = Dt[own + r];
-                }
-                sp_gt(a, bq, sp_opaque(g), [&](int c, double v) {
-                    T[own + c] = v;
+                for (int r = 0; r < SPD; ++r) dq[r] = Dt[own + r];
+                sp_gt(A1, sp_opaque(g), sgn, half, [&](int c, double v) {
                     if (c % 3 == 0)
                         sp_fmac(s0, v, dq[c]);
                     else if (c % 3 == 1)
                         sp_fmac(s1, v, dq[c]);
                     else
                         sp_fmac(s2, v, dq[c]);
+                    const double x = -0.5 * A1[c], y = h6 * v;
+                    T[own + c] = x - y;
+                    o6[c] = x + y;
                 });
             }
             SP_STAMP();
@@ -202,19 +205,10 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
                 const double s = row16_sum(act ? (s0 + s1) + s2 : 0.0);
                 if ((lane & 15) == 0) scal[(SPM * (SPM + 2)) * 4 + (lane >> 4)] = s;
             }
-            {
-                double o6[SPD];
+            flush(T, H4);
 #pragma unroll
-                for (int r = 0; r < SPD; ++r) {
-                    const double x = -0.5 * A1t[own + r], y = h6 * T[own + r];
-                    T[own + r] = x - y;
-                    o6[r] = x + y;
-                }
-                flush(T, H4);
-#pragma unroll
-                for (int r = 0; r < SPD; ++r) T[own + r] = o6[r];
-                flush(T, H6);
-            }
+            for (int r = 0; r < SPD; ++r) T[own + r] = o6[r];
+            flush(T, H6);
             SP_STAMP();
             __syncthreads();  // gamma: every tile has been read, the wave sums are in LDS
             SP_STAMP();
@@ -255,25 +249,25 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
             sp_cptr g = (sp_cptr)(gvals_ + bk * SPNZP);
             __syncthreads();  // alpha
             SP_STAMP();
+#ifdef PCL_PROFILE
+            if (((p.prof & 2) && wave >= 6) || ((p.prof & 4) && wave >= 4)) {  // experiments: fewer drive waves (wrong results)
+                __syncthreads();
+                continue;
+            }
+#endif
             if (item + 1 < item_hi) hn = step_of(item + 1);
             double t[SPM + 2];
-            {  // P_l = G_l^T M -> the wave's tile (results leave the switch through LDS: register webs merged behind a switch spill)
-                double a[SPD], bq[SPD];
+            double P[SPD], R[SPD];
+            {  // P_l = G_l^T M (this half's rows)
+                double x[SPD];
 #pragma unroll
-                for (int r = 0; r < SPD; ++r) {
-                    a[r] = Mt[own + r];
-                    bq[r] = sgn * Mt[oth + r];
-                }
-                SP_GLT_SWITCH(l, a, bq, mg, [&](int c, double v) { T[own + c] = v; })
+                for (int r = 0; r < SPD; ++r) x[r] = Mt[own + r];
+                // (the results leave the switch through the wave's tile: register webs merged behind a switch are spilled)
+                SP_GLT_SWITCH(l, x, mg, sgn, half, [&](int c, double v) { T[own + c] = v; })
             }
-            wave_lds_sync();
+#pragma unroll
+            for (int r = 0; r < SPD; ++r) P[r] = T[own + r];
             SP_STAMP();
-            double P[SPD], pb[SPD];
-#pragma unroll
-            for (int r = 0; r < SPD; ++r) {
-                P[r] = T[own + r];
-                pb[r] = sgn * T[oth + r];
-            }
             {  // <P_l, S>
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -285,53 +279,51 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
                 t[SPM] = (s0 + s1) + s2;
             }
             SP_STAMP();
-            // R_l = G_l^T A1 -> the wave's tile (its copy of P_l has been read; A1 is ready by now, or almost)
+            // R_l = G_l^T A1 (A1 is ready by now, or almost)
             while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(1);
             {
-                double a[SPD], bq[SPD];
+                double x[SPD];
 #pragma unroll
-                for (int r = 0; r < SPD; ++r) {
-                    a[r] = A1t[own + r];
-                    bq[r] = sgn * A1t[oth + r];
-                }
-                SP_GLT_SWITCH(l, a, bq, mg, [&](int c, double v) { T[own + c] = v; })
+                for (int r = 0; r < SPD; ++r) x[r] = A1t[own + r];
+                SP_GLT_SWITCH(l, x, mg, sgn, half, [&](int c, double v) { T[own + c] = v; })
             }
-            SP_STAMP();
-            {  // <P_l, G_j D> = <G_j^T P_l, D> (this half's rows of D in registers for the six products)
-                double dq[SPD];
 #pragma unroll
-                for (int r = 0; r < SPD; ++r) dq[r] = Dt[own + r];
+            for (int r = 0; r < SPD; ++r) R[r] = T[own + r];
+            SP_STAMP();
+            double down[SPD];
+#pragma unroll
+            for (int r = 0; r < SPD; ++r) down[r] = Dt[own + r];
+            {  // <P_l, G_j D> = <G_j^T P_l, D>: this lane's part is U . D_own - sgn V . D_other
+                double doth[SPD];
+#pragma unroll
+                for (int r = 0; r < SPD; ++r) doth[r] = Dt[oth + r];
                 sp_static_for<0, SPM>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
-                    t[j] = sp_gltdot<j>(P, pb, dq, mg);
+                    t[j] = sp_gltdot<j>(P, down, doth, mg, sgn);
                 });
             }
             SP_STAMP();
-            // Q_l = G^T P_l in registers
-            double Q[SPD];
-            sp_gt(P, pb, g, [&](int c, double v) { Q[c] = v; });
-            SP_STAMP();
-            {  // outputs and <Q_l + R_l, D>
+            {  // Q_l = G^T P_l, consumed row by row: <Q_l + R_l, D>, d2/du_l dX_k -> the wave's tile, d2/du_l dX_{k+1} -> R's registers
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-                for (int r = 0; r < SPD; ++r) {
-                    const double q = Q[r] + T[own + r], dv = Dt[own + r];
-                    if (r % 3 == 0)
-                        sp_fmac(s0, q, dv);
-                    else if (r % 3 == 1)
-                        sp_fmac(s1, q, dv);
+                sp_gt(P, g, sgn, half, [&](int c, double v) {
+                    const double q = v + R[c];
+                    if (c % 3 == 0)
+                        sp_fmac(s0, q, down[c]);
+                    else if (c % 3 == 1)
+                        sp_fmac(s1, q, down[c]);
                     else
-                        sp_fmac(s2, q, dv);
-                    const double pl = -c1 * P[r], kt = c2 * q;
-                    T[own + r] = pl - kt;
-                    Q[r] = pl + kt;
-                }
+                        sp_fmac(s2, q, down[c]);
+                    const double pl = -c1 * P[c], kt = c2 * q;
+                    T[own + c] = pl - kt;
+                    R[c] = pl + kt;
+                });
                 t[SPM + 1] = (s0 + s1) + s2;
-                flush(T, H3);
-#pragma unroll
-                for (int r = 0; r < SPD; ++r) T[own + r] = Q[r];
-                flush(T, H5);
             }
+            SP_STAMP();
+            flush(T, H3);
+#pragma unroll
+            for (int r = 0; r < SPD; ++r) T[own + r] = R[r];
+            flush(T, H5);
 #pragma unroll
             for (int j = 0; j < SPM + 2; ++j) {
                 const double s = row16_sum(act ? t[j] : 0.0);

@@ -396,7 +396,7 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
         for (int l = 0; l < m; ++l) iso = iso && is_iso(dsc->Gj + l * nn);
     ctx->iso = iso ? 1 : 0;
     // pattern-compiled kernels: sparse iso generators of a unitary problem, one state column per lane (d <= 32), m + 2 waves
-    if (iso && cols == d && d >= 9 && d <= 32 && (d & 1) && m >= 1 && m <= 6) {  // odd d: the flat [column][row] tiles are conflict-free
+    if (iso && cols == d && d >= 9 && d <= 32 && m >= 1 && m <= 6) {
         pcl_codegen::SpPlan plan = pcl_codegen::make_plan(d, m, dsc->G0, dsc->per_member_G0 ? dsc->batch : 1, dsc->Gj);
         if (plan.ok && plan.nz <= 640 && (double)plan.nz <= 0.45 * 2.0 * d * d) ctx->sp_plan = new pcl_codegen::SpPlan(std::move(plan));
     }
@@ -1215,7 +1215,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
         const pcl_codegen::SpPlan &sp = *ctx->sp_plan;
         const long long items = (long long)p.batch * p.K;
         if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
-        const size_t ldsp = ((size_t)(5 + sp.m) * sp.n * sp.d + ((size_t)sp.m * (sp.m + 2) + 1) * 4) * sizeof(double) + 64;
+        const size_t ldsp = ((size_t)(5 + sp.m) * (sp.n + 1) * sp.d + ((size_t)sp.m * (sp.m + 2) + 1) * 4) * sizeof(double) + 64;  // tiles: odd column stride n + 1
         if (!ctx->sp_fhess && ldsp <= (size_t)ctx->max_lds) {  // (the source is generated once per context)
             const std::string src = sparse_source(sp);
             const std::string key = "sparse:" + std::to_string(std::hash<std::string>{}(src));
@@ -1246,7 +1246,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
         ctx->sp_failed = 1;
         if (ctx->opt_hess_kernel == 4) return fail(ctx, PCL_ESHAPE, "hess_kernel=4: the pattern-compiled kernel is not available (%s)", g_jit_note.c_str());
     } else if (ctx->opt_hess_kernel == 4) {
-        return fail(ctx, PCL_ESHAPE, "hess_kernel=4 needs sparse iso generators (at most %d distinct drive magnitudes), a unitary problem with odd 9 <= d <= 32, 1..6 drives and jit=1", pcl_codegen::kMaxMags);
+        return fail(ctx, PCL_ESHAPE, "hess_kernel=4 needs sparse iso generators (at most %d distinct drive magnitudes), a unitary problem with 9 <= d <= 32, 1..6 drives and jit=1", pcl_codegen::kMaxMags);
     }
     // version 3 (default where its tiles fit LDS): one workgroup per interval, jobs split by drive
     if (mf && (ctx->opt_hess_kernel == 0 || ctx->opt_hess_kernel == 3) && hess_v2_supported(ctx) && ctx->cols == ctx->desc.d && ctx->uell_w <= 2 &&

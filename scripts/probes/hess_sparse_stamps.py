@@ -17,6 +17,7 @@ try:
     hv = torch.empty(c.hess_nnz, dtype=torch.float64, device="cuda")
     c.set_stream(torch.cuda.current_stream().cuda_stream)
     c.set_option("hess_kernel", 4)
+    if len(sys.argv) > 1: c.set_option("profile_flags", int(sys.argv[1]))
     for _ in range(3): c.hess_dev(Zd, mu, hv)
     c.sync()
     c.set_option("debug_timing", 1)
