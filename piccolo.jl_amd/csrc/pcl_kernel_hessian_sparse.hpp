@@ -57,6 +57,23 @@ static __device__ __forceinline__ int sp_fence(int off) {
     return off;
 }
 
+// Point-to-point synchronisation inside the workgroup: monotonic LDS counters (workgroup-scope release / acquire).  No workgroup
+// barrier in the interval loop: a wave starts the next interval as soon as ITS inputs are there, so the waves drift apart and
+// the LDS-heavy phases of some overlap the arithmetic of others (behind two barriers per interval all seven chains ran in
+// lock-step: every resource below 50 %).  Dependencies only point backwards (earlier stage, same or earlier interval).
+#define SP_SYNC_WORDS 16
+enum { SP_IN_READY = 0, SP_RD_DONE, SP_A1_READY, SP_A1_DONE, SP_COMB_DONE, SP_FIN = 8 /* one word per drive wave: intervals finished */ };
+static __device__ __forceinline__ void sp_wait(int *w, int target) {
+    // (bounded: a logic error must not hang the device)
+    for (int it = 0; __hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target && it < (1 << 22); ++it) __builtin_amdgcn_s_sleep(1);
+}
+static __device__ __forceinline__ void sp_post(int *w, int value, int lane) {  // after wave_lds_sync(): this wave's LDS traffic is complete
+    if (lane == 0) __hip_atomic_store(w, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __device__ __forceinline__ void sp_arrive(int *w, int lane) {
+    if (lane == 0) __hip_atomic_fetch_add(w, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_kernel(const KParams p, const double *__restrict__ gvals_, const double *__restrict__ glv_) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -67,8 +84,9 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
     const double sgn = half ? -1.0 : 1.0;
     const int own = cc * SPCS + half * SPD, oth = cc * SPCS + (1 - half) * SPD;
     double *Mt = lds, *Dt = Mt + SPTILE, *St = Dt + SPTILE, *A1t = St + SPTILE, *Stg = A1t + SPTILE;  // Stg: SPM + 1 staging tiles
-    double *scal = Stg + (SPM + 1) * SPTILE;  // [SPM][SPM + 2][4] drive-wave sums per 16-lane row | [1][4] <A2, D>
-    int *flag = (int *)(scal + (SPM * (SPM + 2) + 1) * 4);
+    constexpr int NSUM = (SPM * (SPM + 2) + 1) * 4;  // [SPM][SPM + 2][4] drive-wave sums per 16-lane row | [1][4] <A2, D>
+    double *scal = Stg + (SPM + 1) * SPTILE;         // two copies (interval parity)
+    int *sync = (int *)(scal + 2 * NSUM);
     sp_cptr glv = (sp_cptr)glv_;
 
     const int n_items = p.batch * p.K;
@@ -79,7 +97,8 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
         const int k = item % p.K, b = item / p.K;
         return p.Z[(long long)b * p.z_batch_stride + (long long)k * p.z_dim + p.dt_off];
     };
-    if (tid == 0) __hip_atomic_store(flag, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (tid < SP_SYNC_WORDS) sync[tid] = 0;
+    __syncthreads();  // the only workgroup barrier
 #ifdef PCL_PROFILE
     int stamp_ = 0;  // cycle stamps of workgroup 0: 16 slots per wave (dbg[16 wave + i])
 #define SP_STAMP()                                                                                                        \
@@ -112,8 +131,7 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
         }
         wave_lds_sync();
     };
-    // The three roles run their own loops (the register allocation of one role does not carry the other roles' live values);
-    // every loop passes the same two workgroup barriers per interval.
+    // The three roles run their own loops (the register allocation of one role does not carry the other roles' live values).
     if (wave == 1) {
         // ---- loader ---------------------------------------------------------------------------------------------------------
         double pm[SPD], pxn[SPD], pxc[SPD];  // lane = row, one column per register
@@ -133,8 +151,11 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
             }
         };
         request(item_lo);
-        SP_PREFETCH_G((sp_cptr)(gvals_ + (long long)item_lo * SPNZP));
         for (int item = item_lo; item < item_hi; ++item) {
+            const int seq = item - item_lo;
+            SP_PREFETCH_G((sp_cptr)(gvals_ + (long long)item * SPNZP));  // the scalar cache is warm when the other waves arrive
+            sp_wait(sync + SP_RD_DONE, (SPM + 1) * seq);                   // every reader is done with the previous interval's inputs
+            SP_STAMP();
             if (lane < SPN) {
                 double *Ml = Mt + lane, *Dl = Dt + lane, *Sl = St + lane;
 #pragma unroll
@@ -144,76 +165,28 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
                     Sl[SPCS * q] = pxn[q] + pxc[q];
                 }
             }
+            wave_lds_sync();
+            sp_post(sync + SP_IN_READY, seq + 1, lane);
             SP_STAMP();
-            __syncthreads();  // alpha: the interval's inputs are in LDS
-            SP_STAMP();
-            if (item + 1 < item_hi) {
-                request(item + 1);
-                SP_PREFETCH_G((sp_cptr)(gvals_ + (long long)(item + 1) * SPNZP));  // the scalar cache is warm when the other waves arrive
-            }
-            __syncthreads();  // gamma
-            SP_STAMP();
+            if (item + 1 < item_hi) request(item + 1);
         }
     } else if (wave == 0) {
         // ---- state wave -----------------------------------------------------------------------------------------------------
         double hn = step_of(item_lo);
         double *T = Stg + SPM * SPTILE;
         __builtin_amdgcn_s_setprio(2);  // two dependent long products: the longest chain of the interval
-        for (int item = item_lo; item < item_hi; ++item) {
-            const int seq = item - item_lo;
-            const long long bk = item;  // = b K + k
-            const double h = hn;
-            const double c2 = h * h * (1.0 / 12.0), h6 = h * (1.0 / 6.0);
-            double *H = p.hess + bk * p.hess_per;
-            double *H4 = H + SPNSC + (long long)SPM * SPXD, *H6 = H4 + SPXD + (long long)SPM * SPXD;
-            sp_cptr g = (sp_cptr)(gvals_ + bk * SPNZP);
-            __syncthreads();  // alpha
-            SP_STAMP();
-            if (item + 1 < item_hi) hn = step_of(item + 1);
-            double A1[SPD];
-            {  // A1 = G^T M: registers (input of the second product, outputs) and the A1 tile (the drive waves' R_l)
-                double x[SPD];
+        double hp = 0.0;
+        auto combine = [&](int sq, double hh) {  // the 28 scalar entries of interval sq: row sums added in a fixed order
+            const double c2 = hh * hh * (1.0 / 12.0), h6 = hh * (1.0 / 6.0);
+            const double *sc = scal + (sq & 1) * NSUM;
+            double *H = p.hess + (long long)(item_lo + sq) * p.hess_per;
+            // the drive waves' sums of that interval are in LDS (one progress word per drive wave: nothing stops a fast wave from
+            // finishing the next interval before a slow one finishes this one, so a shared arrival counter would lie)
 #pragma unroll
-                for (int r = 0; r < SPD; ++r) x[r] = Mt[own + r];
-                sp_gt(x, g, sgn, half, [&](int c, double v) {
-                    A1[c] = v;
-                    A1t[own + c] = v;  // (inactive lanes repeat column 0: the same values to the same addresses)
-                });
-            }
+            for (int j = 0; j < SPM; ++j) sp_wait(sync + SP_FIN + j, sq + 1);
             wave_lds_sync();
-            if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            SP_STAMP();
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, o6[SPD];
-            {  // A2 = G^T A1, consumed row by row: <A2, D>, d2/dh dX_k -> staging tile, d2/dh dX_{k+1} -> registers
-                double dq[SPD];
-#pragma unroll
-                for (int r = 0; r < SPD; ++r) dq[r] = Dt[own + r];
-                sp_gt(A1, sp_opaque(g), sgn, half, [&](int c, double v) {
-                    if (c % 3 == 0)
-                        sp_fmac(s0, v, dq[c]);
-                    else if (c % 3 == 1)
-                        sp_fmac(s1, v, dq[c]);
-                    else
-                        sp_fmac(s2, v, dq[c]);
-                    const double x = -0.5 * A1[c], y = h6 * v;
-                    T[own + c] = x - y;
-                    o6[c] = x + y;
-                });
-            }
-            SP_STAMP();
-            {
-                const double s = row16_sum(act ? (s0 + s1) + s2 : 0.0);
-                if ((lane & 15) == 0) scal[(SPM * (SPM + 2)) * 4 + (lane >> 4)] = s;
-            }
-            flush(T, H4);
-#pragma unroll
-            for (int r = 0; r < SPD; ++r) T[own + r] = o6[r];
-            flush(T, H6);
-            SP_STAMP();
-            __syncthreads();  // gamma: every tile has been read, the wave sums are in LDS
-            SP_STAMP();
             if (lane < SPNSC) {
-                auto rows4 = [&](int e) { return ((scal[4 * e] + scal[4 * e + 1]) + scal[4 * e + 2]) + scal[4 * e + 3]; };
+                auto rows4 = [&](int e) { return ((sc[4 * e] + sc[4 * e + 1]) + sc[4 * e + 2]) + sc[4 * e + 3]; };
                 double v;
                 if (lane < SPNPAIR) {
                     int i = 0;
@@ -228,7 +201,70 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
                 }
                 H[lane] = v;
             }
+            wave_lds_sync();
+            sp_post(sync + SP_COMB_DONE, sq + 1, lane);  // this copy of the sums may be rewritten (interval sq + 2)
+        };
+        for (int item = item_lo; item < item_hi; ++item) {
+            const int seq = item - item_lo;
+            const long long bk = item;  // = b K + k
+            const double h = hn;
+            const double c2 = h * h * (1.0 / 12.0), h6 = h * (1.0 / 6.0);
+            double *H = p.hess + bk * p.hess_per;
+            double *H4 = H + SPNSC + (long long)SPM * SPXD, *H6 = H4 + SPXD + (long long)SPM * SPXD;
+            double *sc = scal + (seq & 1) * NSUM;
+            sp_cptr g = (sp_cptr)(gvals_ + bk * SPNZP);
+            sp_wait(sync + SP_IN_READY, seq + 1);
+            SP_STAMP();
+            if (item + 1 < item_hi) hn = step_of(item + 1);
+            double A1[SPD];
+            {  // A1 = G^T M: registers (input of the second product, outputs) and the A1 tile (the drive waves' R_l)
+                double x[SPD];
+#pragma unroll
+                for (int r = 0; r < SPD; ++r) x[r] = Mt[own + r];
+                sp_wait(sync + SP_A1_DONE, SPM * seq);  // the drive waves have read the previous interval's A1
+                sp_gt(x, g, sgn, half, [&](int c, double v) {
+                    A1[c] = v;
+                    A1t[own + c] = v;  // (inactive lanes repeat column 0: the same values to the same addresses)
+                });
+            }
+            wave_lds_sync();
+            sp_post(sync + SP_A1_READY, seq + 1, lane);
+            SP_STAMP();
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, o6[SPD];
+            {  // A2 = G^T A1, consumed row by row: <A2, D>, d2/dh dX_k -> staging tile, d2/dh dX_{k+1} -> registers
+                double dq[SPD];
+#pragma unroll
+                for (int r = 0; r < SPD; ++r) dq[r] = Dt[own + r];
+                wave_lds_sync();
+                sp_arrive(sync + SP_RD_DONE, lane);  // this wave's reads of the interval's inputs are complete
+                sp_gt(A1, sp_opaque(g), sgn, half, [&](int c, double v) {
+                    if (c % 3 == 0)
+                        sp_fmac(s0, v, dq[c]);
+                    else if (c % 3 == 1)
+                        sp_fmac(s1, v, dq[c]);
+                    else
+                        sp_fmac(s2, v, dq[c]);
+                    const double x = -0.5 * A1[c], y = h6 * v;
+                    T[own + c] = x - y;
+                    o6[c] = x + y;
+                });
+            }
+            SP_STAMP();
+            flush(T, H4);
+#pragma unroll
+            for (int r = 0; r < SPD; ++r) T[own + r] = o6[r];
+            flush(T, H6);
+            SP_STAMP();
+            {
+                const double s = row16_sum(act ? (s0 + s1) + s2 : 0.0);
+                if ((lane & 15) == 0) sc[(SPM * (SPM + 2)) * 4 + (lane >> 4)] = s;
+            }
+            // the scalar entries of the PREVIOUS interval (its drive waves finished long ago: no wait on the critical path)
+            if (seq > 0) combine(seq - 1, hp);
+            hp = h;
+            SP_STAMP();
         }
+        combine(item_hi - 1 - item_lo, hp);
         SP_END();
     } else {
         // ---- drive wave l ---------------------------------------------------------------------------------------------------
@@ -246,12 +282,15 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
             const double c1 = 0.5 * h, c2 = h * h * (1.0 / 12.0);
             double *H = p.hess + bk * p.hess_per;
             double *H3 = H + SPNSC + (long long)l * SPXD, *H5 = H3 + (long long)(SPM + 1) * SPXD;
+            double *sc = scal + (seq & 1) * NSUM;
             sp_cptr g = (sp_cptr)(gvals_ + bk * SPNZP);
-            __syncthreads();  // alpha
+            sp_wait(sync + SP_IN_READY, seq + 1);
             SP_STAMP();
 #ifdef PCL_PROFILE
             if (((p.prof & 2) && wave >= 6) || ((p.prof & 4) && wave >= 4)) {  // experiments: fewer drive waves (wrong results)
-                __syncthreads();
+                sp_arrive(sync + SP_RD_DONE, lane);
+                sp_arrive(sync + SP_A1_DONE, lane);
+                sp_post(sync + SP_FIN + l, seq + 1, lane);
                 continue;
             }
 #endif
@@ -280,11 +319,13 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
             }
             SP_STAMP();
             // R_l = G_l^T A1 (A1 is ready by now, or almost)
-            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(1);
+            sp_wait(sync + SP_A1_READY, seq + 1);
             {
                 double x[SPD];
 #pragma unroll
                 for (int r = 0; r < SPD; ++r) x[r] = A1t[own + r];
+                wave_lds_sync();
+                sp_arrive(sync + SP_A1_DONE, lane);
                 SP_GLT_SWITCH(l, x, mg, sgn, half, [&](int c, double v) { T[own + c] = v; })
             }
 #pragma unroll
@@ -297,6 +338,8 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
                 double doth[SPD];
 #pragma unroll
                 for (int r = 0; r < SPD; ++r) doth[r] = Dt[oth + r];
+                wave_lds_sync();
+                sp_arrive(sync + SP_RD_DONE, lane);  // this wave's reads of the interval's inputs are complete
                 sp_static_for<0, SPM>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     t[j] = sp_gltdot<j>(P, down, doth, mg, sgn);
@@ -324,13 +367,15 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
 #pragma unroll
             for (int r = 0; r < SPD; ++r) T[own + r] = R[r];
             flush(T, H5);
+            sp_wait(sync + SP_COMB_DONE, seq - 1);  // the sums of interval seq - 2 (same copy) have been combined
 #pragma unroll
             for (int j = 0; j < SPM + 2; ++j) {
                 const double s = row16_sum(act ? t[j] : 0.0);
-                if ((lane & 15) == 0) scal[(l * (SPM + 2) + j) * 4 + (lane >> 4)] = s;
+                if ((lane & 15) == 0) sc[(l * (SPM + 2) + j) * 4 + (lane >> 4)] = s;
             }
+            wave_lds_sync();
+            sp_post(sync + SP_FIN + l, seq + 1, lane);
             SP_STAMP();
-            __syncthreads();  // gamma
         }
     }
 }

@@ -1215,7 +1215,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
         const pcl_codegen::SpPlan &sp = *ctx->sp_plan;
         const long long items = (long long)p.batch * p.K;
         if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
-        const size_t ldsp = ((size_t)(5 + sp.m) * (sp.n + 1) * sp.d + ((size_t)sp.m * (sp.m + 2) + 1) * 4) * sizeof(double) + 64;  // tiles: odd column stride n + 1
+        const size_t ldsp = ((size_t)(5 + sp.m) * (sp.n + 1) * sp.d + 2 * ((size_t)sp.m * (sp.m + 2) + 1) * 4) * sizeof(double) + 64;  // tiles (odd column stride n + 1), two copies of the sums, counters
         if (!ctx->sp_fhess && ldsp <= (size_t)ctx->max_lds) {  // (the source is generated once per context)
             const std::string src = sparse_source(sp);
             const std::string key = "sparse:" + std::to_string(std::hash<std::string>{}(src));

@@ -759,7 +759,7 @@ def test_hessian_kernel_variants(cfg, N, batch):
     c = make_ctx(lay, G0, Gj, batch=batch, batch_mode=pa._lib.PCL_BATCH_TRAJ, x_offs=[lay.x_off])
     Zb, mub = np.stack(Zs), np.concatenate([m_.reshape(-1) for m_ in mus])
     h_auto = c.hess(Zb, mub)
-    assert c.get_option("last_hess_kernel") == (6 if cfg == 3 else 2)  # 6: the pattern-compiled kernel (sparse iso generators, odd d >= 9)
+    assert c.get_option("last_hess_kernel") == (6 if cfg == 3 else 2)  # 6: the pattern-compiled kernel (sparse iso generators, 9 <= d <= 32)
     close(h_auto, ref, 1e-11)
     if cfg == 3:
         c.set_option("hess_kernel", 4)
@@ -771,7 +771,7 @@ def test_hessian_kernel_variants(cfg, N, batch):
             assert np.array_equal(h, c.hess(Zb, mub))
         c.set_option("grid", 0)
     else:
-        c.set_option("hess_kernel", 4)  # not a sparse iso system of odd d >= 9: loud failure, no silent substitute
+        c.set_option("hess_kernel", 4)  # not a sparse iso system with 9 <= d <= 32: loud failure, no silent substitute
         with pytest.raises(pa.PclError):
             c.hess(Zb, mub)
     for hk in (1, 2):
@@ -1359,7 +1359,7 @@ def test_other_specialised_shapes(levels, batch):
     mu = np.random.default_rng(1).standard_normal((batch, lay.K, lay.x_dim))
     h_ref = np.concatenate([ref_lib.hess(Z, mu[i], lay, G0, Gj).reshape(-1) for i, Z in enumerate(Zs)])
     hv = c.hess(np.stack(Zs), mu.reshape(-1))
-    assert c.get_option("last_hess_kernel") == (6 if levels == 5 else 5)  # d = 25: the pattern-compiled kernel; d = 16 (even): kernel 3, compiled on first use
+    assert c.get_option("last_hess_kernel") == 6  # the pattern-compiled kernel (sparse iso generators, 9 <= d <= 32)
     close(hv, h_ref, 1e-10)
     c.set_option("hess_kernel", 3)
     hv = c.hess(np.stack(Zs), mu.reshape(-1))
