@@ -111,7 +111,9 @@ struct Chunks {
 // starting at `base` (or resident magnitudes).  Entries of the A block (in < d) accumulate U[out] += coef x[in], entries of
 // the B block V[out] += coef x[in - d]; a finished group of outputs is completed with the other half's V and passed to
 // out(index, value).
-static inline void emit_groups(std::string &s, const std::vector<Term> &ordered, int d, int group, const char *tab, int base) {
+// lds_exchange: the results go to an LDS tile anyway (Tl = the lane's slots, To = the other half's): U is written, the other
+// half's slot receives -sgn V by an LDS atomic add (a wave's LDS operations complete in order), no cross-lane VALU work.
+static inline void emit_groups(std::string &s, const std::vector<Term> &ordered, int d, int group, const char *tab, int base, bool lds_exchange = false) {
     char buf[256];
     Chunks ch(s, tab, base, (int)ordered.size());
     ch.declare();
@@ -145,6 +147,15 @@ static inline void emit_groups(std::string &s, const std::vector<Term> &ordered,
             s += buf;
         }
         for (int o = g0; o < g1; ++o) {
+            if (lds_exchange) {
+                snprintf(buf, sizeof buf, "        Tl[%d] = u%d;\n", o, o);
+                s += buf;
+                if (seen[d + o]) {
+                    snprintf(buf, sizeof buf, "        __hip_atomic_fetch_add(To + %d, -sgn * v%d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n", o, o);
+                    s += buf;
+                }
+                continue;
+            }
             if (seen[d + o])  // (both halves run this code: an output without B entries has V = 0 in both)
                 snprintf(buf, sizeof buf, "        out(%d, sp_complete(u%d, v%d, sgn, half));\n", o, o, o);
             else
@@ -307,9 +318,10 @@ static inline std::string apply_functions(const SpPlan &P) {
             q.mag = P.dmagi[k];
             tt.push_back(q);
         }
-        snprintf(buf, sizeof buf, "template <class F> static __device__ __forceinline__ void sp_glt_%d(const double (&x)[SPD], const sp_mags &mg, double sgn, int half, F out) {\n", l);
+        // G_l^T x -> the wave's LDS tile (Tl: this lane's rows, To: the other half's rows of the same column)
+        snprintf(buf, sizeof buf, "static __device__ __forceinline__ void sp_glt_%d(const double (&x)[SPD], const sp_mags &mg, double sgn, double *Tl, double *To) {\n", l);
         s += buf;
-        detail::emit_groups(s, detail::emission_order(tt, d, kGroup), d, kGroup, "mg", 0);
+        detail::emit_groups(s, detail::emission_order(tt, d, kGroup), d, kGroup, "mg", 0, true);
         s += "}\n";
         snprintf(buf, sizeof buf, "static __device__ __forceinline__ double sp_gltdot_%d(const double (&x)[SPD], const double (&down)[SPD], const double (&doth)[SPD], const sp_mags &mg, double sgn) {\n", l);
         s += buf;
@@ -331,9 +343,9 @@ static inline std::string apply_functions(const SpPlan &P) {
     s += "s_waitcnt lgkmcnt(0)\" : \"=&s\"(pf_) : \"s\"(ptr) : \"memory\"); } while (0)\n";
     // run-time (wave-uniform) dispatch for the two small drive-specific products of a drive wave; the cases exchange data with
     // the rest of the role through LDS only, so no register webs are merged behind the switch
-    s += "#define SP_GLT_SWITCH(l, x, mg, sgn, half, out) switch (l) {";
+    s += "#define SP_GLT_SWITCH(l, x, mg, sgn, Tl, To) switch (l) {";
     for (int l = 0; l < P.m; ++l) {
-        snprintf(buf, sizeof buf, " case %d: sp_glt_%d(x, mg, sgn, half, out); break;", l, l);
+        snprintf(buf, sizeof buf, " case %d: sp_glt_%d(x, mg, sgn, Tl, To); break;", l, l);
         s += buf;
     }
     s += " default: break; }\n";

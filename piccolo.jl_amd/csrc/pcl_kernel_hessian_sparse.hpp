@@ -22,7 +22,6 @@
 // different 8-byte bank pairs (with stride SPN -- even -- half of all LDS cycles of the kernel were bank conflicts)
 #define SPCS (SPN + 1)
 #define SPTILE (SPCS * SPD)
-#define SPNL ((SPXD + 63) / 64)
 #define SPNSC ((SPM + 1) * (SPM + 2) / 2)
 #define SPNPAIR (SPM * (SPM + 1) / 2)
 
@@ -43,20 +42,6 @@ static __device__ __forceinline__ sp_cptr sp_opaque(sp_cptr q) {
     asm volatile("" : "+s"(q));
     return q;
 }
-// Phase fence.  The compiler schedules the whole interval as one block, starts the next phase's LDS reads and exchanges early
-// and runs out of registers (hundreds of scratch accesses per interval).  Volatile asm statements keep their order: passing
-// the values that live across a phase boundary, and the LDS offset the next phase reads with, through empty ones pins
-// everything that produces them before the boundary and everything that uses them after it.
-template <int N>
-static __device__ __forceinline__ void sp_fence(double (&v)[N]) {
-#pragma unroll
-    for (int r = 0; r < N; ++r) asm volatile("" : "+v"(v[r]));
-}
-static __device__ __forceinline__ int sp_fence(int off) {
-    asm volatile("" : "+v"(off));
-    return off;
-}
-
 // Point-to-point synchronisation inside the workgroup: monotonic LDS counters (workgroup-scope release / acquire).  No workgroup
 // barrier in the interval loop: a wave starts the next interval as soon as ITS inputs are there, so the waves drift apart and
 // the LDS-heavy phases of some overlap the arithmetic of others (behind two barriers per interval all seven chains ran in
@@ -301,19 +286,26 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
                 double x[SPD];
 #pragma unroll
                 for (int r = 0; r < SPD; ++r) x[r] = Mt[own + r];
-                // (the results leave the switch through the wave's tile: register webs merged behind a switch are spilled)
-                SP_GLT_SWITCH(l, x, mg, sgn, half, [&](int c, double v) { T[own + c] = v; })
+                // (the results leave the switch through the wave's tile -- register webs merged behind a switch are spilled -- and
+                //  the halves are completed there: U is written, the other half adds -sgn V to it with an LDS atomic)
+                if (act) {  // (the lanes beyond column d - 1 repeat column 0: harmless for stores, not for atomic adds)
+                    SP_GLT_SWITCH(l, x, mg, sgn, T + own, T + oth)
+                }
             }
+            wave_lds_sync();
 #pragma unroll
             for (int r = 0; r < SPD; ++r) P[r] = T[own + r];
             SP_STAMP();
-            {  // <P_l, S>
+            {  // <P_l, S>  (operands first: a load next to each pinned multiply-add is one LDS round trip per row)
+                double sv[SPD];
+#pragma unroll
+                for (int r = 0; r < SPD; ++r) sv[r] = St[own + r];
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
                 for (int r = 0; r < SPD; r += 3) {
-                    sp_fmac(s0, P[r], St[own + r]);
-                    if (r + 1 < SPD) sp_fmac(s1, P[r + 1], St[own + r + 1]);
-                    if (r + 2 < SPD) sp_fmac(s2, P[r + 2], St[own + r + 2]);
+                    sp_fmac(s0, P[r], sv[r]);
+                    if (r + 1 < SPD) sp_fmac(s1, P[r + 1], sv[r + 1]);
+                    if (r + 2 < SPD) sp_fmac(s2, P[r + 2], sv[r + 2]);
                 }
                 t[SPM] = (s0 + s1) + s2;
             }
@@ -326,8 +318,11 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
                 for (int r = 0; r < SPD; ++r) x[r] = A1t[own + r];
                 wave_lds_sync();
                 sp_arrive(sync + SP_A1_DONE, lane);
-                SP_GLT_SWITCH(l, x, mg, sgn, half, [&](int c, double v) { T[own + c] = v; })
+                if (act) {
+                    SP_GLT_SWITCH(l, x, mg, sgn, T + own, T + oth)
+                }
             }
+            wave_lds_sync();
 #pragma unroll
             for (int r = 0; r < SPD; ++r) R[r] = T[own + r];
             SP_STAMP();
