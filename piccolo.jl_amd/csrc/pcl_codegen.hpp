@@ -146,16 +146,23 @@ static inline void emit_groups(std::string &s, const std::vector<Term> &ordered,
             sn = 1;
             s += buf;
         }
-        for (int o = g0; o < g1; ++o) {
-            if (lds_exchange) {
+        if (lds_exchange) {
+            // every U of the group is stored before any V is added: the slot a lane adds to is ANOTHER lane's store target, which
+            // the compiler cannot see (per thread the two pointers never alias) -- the empty asm pins the order, the LDS pipeline
+            // executes a wave's operations in it
+            for (int o = g0; o < g1; ++o) {
                 snprintf(buf, sizeof buf, "        Tl[%d] = u%d;\n", o, o);
                 s += buf;
+            }
+            s += "        asm volatile(\"\" ::: \"memory\");\n";
+            for (int o = g0; o < g1; ++o)
                 if (seen[d + o]) {
                     snprintf(buf, sizeof buf, "        __hip_atomic_fetch_add(To + %d, -sgn * v%d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n", o, o);
                     s += buf;
                 }
-                continue;
-            }
+            s += "        asm volatile(\"\" ::: \"memory\");\n";
+        }
+        for (int o = g0; o < g1 && !lds_exchange; ++o) {
             if (seen[d + o])  // (both halves run this code: an output without B entries has V = 0 in both)
                 snprintf(buf, sizeof buf, "        out(%d, sp_complete(u%d, v%d, sgn, half));\n", o, o, o);
             else
