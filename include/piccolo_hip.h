@@ -245,6 +245,8 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *                            pattern-compiled kernel: source generated from the sparsity pattern of the generators and compiled
  *                            on first use (default for sparse exact-iso generators, odd 9 <= d <= 32, m <= 6; PCL_ESHAPE when
  *                            forced elsewhere); Pade orders other than 4 always run the general-order Hessian kernel
+ *       "eval_kernel"        residual only: 0 auto | 1 the matrix-core residual kernel | 2 the pattern-compiled kernel (one wave per
+ *                            interval; same applicability as hess_kernel 4; auto for launches with more intervals than CUs)
  *       "general_pade_kernel" 1: run the general-order kernel for pade_order 4 too (cross-check)
  *       "general_threads" (256 / 512), "general_two_step" (1: unique tiles + expansion kernel)   general-order kernel
  *       "jit"                1 (default): shapes outside the static instance table are compiled on first use with hiprtc
@@ -253,8 +255,8 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *       instances), "grid" (workgroups, 0 = one per CU), "host_threads" (host-pointer entry points: threads that expand the
  *       compact values into the caller's array, 0 = auto), "host_path" (0 auto | 1 full values over PCIe | 2 compact + host expansion),
  *       "debug_timing" (PCL_ENOTIMPL unless the library was built with -DPCL_PROFILE)
- * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised; 90 + q for the general-order
- *       kernel), "last_stream_workgroups", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3 static / compiled | 6: pattern-compiled | 90 + q), "jit_compiles", "n_cu", "iso_structured", "drives_antisymmetric",
+ * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised; 60 / 61 matrix-core residual kernel, 70 pattern-compiled residual kernel; 90 + q for the
+ *       general-order kernel), "last_stream_workgroups", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3 static / compiled | 6: pattern-compiled | 90 + q), "jit_compiles", "n_cu", "iso_structured", "drives_antisymmetric",
  *       "ell_width", "ell_width_t", "union_width", "occupancy_v2".  Unknown keys return PCL_EINVAL. */
 int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t value);
 int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *value);

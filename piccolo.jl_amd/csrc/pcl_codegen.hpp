@@ -26,6 +26,8 @@ struct SpPlan {
     std::vector<int> row, col;    // entry k (in the emission order of sp_gt): G[row][col], row < n, col < d
     std::vector<int> pos;         // row + n*col (column-major position in G0 / G_l)
     std::vector<double> coef;     // [nz][m]: G_l at pos
+    std::vector<int> row_n, col_n, pos_n;  // the same entries in the emission order of sp_g (G(u) x: outputs by row)
+    std::vector<double> coef_n;
     std::vector<int> doff;        // [m+1]: offsets of the drives' entries
     std::vector<int> drow, dcol;  // entries of the left column block of every G_l
     std::vector<int> dmagi;       // ... index of |value| in `mags`
@@ -61,8 +63,9 @@ static inline std::vector<Term> emission_order(const std::vector<Term> &terms, i
 }
 // top rows of T^T x = A^T a + B^T b:  o[c] += T[rho][c] * (rho < d ? a[rho] : b[rho - d])
 static inline Term term_t(int row, int col, int d, int src) { return {col, row, src, false}; }
-// top rows of T x = A a - B b:  rho < d: o[rho] += T[rho][c] a[c];  rho >= d: o[rho - d] -= T[rho][c] b[c]
-static inline Term term_n(int row, int col, int d, int src) { return {row < d ? row : row - d, row < d ? col : d + col, src, row >= d}; }
+// T x on this half's x:  A block (rho < d): U[rho] += T[rho][c] x[c];  B block: V[rho - d] += T[rho][c] x[c]
+// (top = U(0) - V(1), bottom = U(1) + V(0): the caller completes with -sgn)
+static inline Term term_n(int row, int col, int d, int src) { return {row < d ? row : row - d, row < d ? col : d + col, src, false}; }
 
 // Coefficient i of the table: element (i - base) % 8 of chunk (i - base) / 8.  A chunk is ONE s_load_dwordx16 issued by a
 // volatile asm statement at the point of first use (with its wait): left to the compiler, the loads of a whole product -- or
@@ -247,6 +250,17 @@ static inline SpPlan make_plan(int d, int m, const double *G0, int n_g0, const d
     }
     P.nz = (int)P.row.size();
     P.nzp = (P.nz + 15) & ~15;
+    {
+        std::vector<Term> tn;
+        for (size_t k = 0; k < rows.size(); ++k) tn.push_back(detail::term_n(rows[k], cols[k], d, (int)k));
+        for (const Term &t : detail::emission_order(tn, d, kGroup)) {
+            const int r = rows[t.src], c = cols[t.src];
+            P.row_n.push_back(r);
+            P.col_n.push_back(c);
+            P.pos_n.push_back(r + n * c);
+            for (int l = 0; l < m; ++l) P.coef_n.push_back(Gj[l * nn + (size_t)r + (size_t)n * c]);
+        }
+    }
     // drives: the entries of the left column block; their distinct magnitudes (a handful for the reference's systems: ladder
     // operators) stay in scalar registers for the whole launch, the signs are instruction modifiers
     P.doff.assign(m + 1, 0);
@@ -277,7 +291,8 @@ static inline SpPlan make_plan(int d, int m, const double *G0, int n_g0, const d
 
 // Device functions shared by the pattern-compiled kernels (x = (a | b) is a column in the lane's convention; out(i, value)
 // receives every top row of the result once, in groups of kGroup):
-//   sp_gt(a, b, g, out)        G(u)^T x     (coefficients: the per-interval value table g)
+//   sp_gt(x, g, sgn, half, out)   G(u)^T x   (coefficients: the per-interval value table g, in ITS emission order)
+//   sp_g(x, g, -sgn, half, out)   G(u) x     (its own table order: pos_n / coef_n)
 //   sp_glt_<l>(a, b, mg, out)  G_l^T x      (coefficients: the resident magnitudes mg, signs as instruction modifiers)
 //   sp_gltdot<l>(a, b, dq, mg) <G_l^T x, dq> over this half's rows
 static inline std::string apply_functions(const SpPlan &P) {
@@ -302,6 +317,13 @@ static inline std::string apply_functions(const SpPlan &P) {
         std::vector<Term> t;  // the plan's entries ARE in emission order
         for (int k = 0; k < P.nz; ++k) t.push_back(detail::term_t(P.row[k], P.col[k], d, k));
         s += "template <class F> static __device__ __forceinline__ void sp_gt(const double (&x)[SPD], sp_cptr g, double sgn, int half, F out) {\n";
+        detail::emit_groups(s, t, d, kGroup, "g", 0);
+        s += "}\n";
+    }
+    {
+        std::vector<Term> t;
+        for (int k = 0; k < P.nz; ++k) t.push_back(detail::term_n(P.row_n[k], P.col_n[k], d, k));
+        s += "template <class F> static __device__ __forceinline__ void sp_g(const double (&x)[SPD], sp_cptr g, double sgn, int half, F out) {\n";
         detail::emit_groups(s, t, d, kGroup, "g", 0);
         s += "}\n";
     }

@@ -84,7 +84,10 @@ struct pcl_ctx {
     double *dsp_coef = nullptr, *dsp_glv = nullptr, *dsp_gvals = nullptr;
     long long sp_gvals_cap = 0;  // intervals the value table holds
     int sp_failed = 0;           // the source did not compile: the other kernels serve the context
-    hipFunction_t sp_fval = nullptr, sp_fhess = nullptr;  // compiled on first use, kept for the context's lifetime
+    hipFunction_t sp_fval = nullptr, sp_fhess = nullptr, sp_feval = nullptr;  // compiled on first use, kept for the context's lifetime
+    int *dsp_pos_n = nullptr;       // the same tables in the emission order of the residual kernel's products
+    double *dsp_coef_n = nullptr;
+    int64_t opt_eval_kernel = 0;    // 0 auto | 1 matrix-core residual kernel | 2 pattern-compiled
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dmu = nullptr, *ddelta = nullptr, *dvals = nullptr, *dhess = nullptr;
     // options
@@ -431,6 +434,8 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
         CREATE_TRY(upload(ctx, &ctx->dsp_pos, sp.pos));
         CREATE_TRY(upload(ctx, &ctx->dsp_coef, sp.coef));
         CREATE_TRY(upload(ctx, &ctx->dsp_glv, glv));
+        CREATE_TRY(upload(ctx, &ctx->dsp_pos_n, sp.pos_n));
+        CREATE_TRY(upload(ctx, &ctx->dsp_coef_n, sp.coef_n));
     }
 #undef CREATE_TRY
 #undef CREATE_HIP
@@ -460,7 +465,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     for (void *q : {(void *)ctx->dsub, (void *)ctx->dweights, (void *)ctx->dregs, (void *)ctx->dreg_R, (void *)ctx->dobj, (void *)ctx->dphik,
                     (void *)ctx->dgrad, (void *)ctx->dval})
         if (q) (void)hipFree(q);
-    for (void *q : {(void *)ctx->dsp_pos, (void *)ctx->dsp_coef, (void *)ctx->dsp_glv, (void *)ctx->dsp_gvals})
+    for (void *q : {(void *)ctx->dsp_pos, (void *)ctx->dsp_coef, (void *)ctx->dsp_glv, (void *)ctx->dsp_gvals, (void *)ctx->dsp_pos_n, (void *)ctx->dsp_coef_n})
         if (q) (void)hipFree(q);
     delete ctx->sp_plan;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -686,8 +691,8 @@ hipFunction_t jit_compile(int device, const std::string &key_, const std::string
     const size_t slash = dir.find_last_of('/');
     dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
     const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp",
-                           "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp"};
-    constexpr int NH = 6;
+                           "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp", "pcl_kernel_eval_sparse.hpp"};
+    constexpr int NH = 7;
     std::string hdr[NH];
     const char *hdrp[NH];
     for (int i = 0; i < NH; ++i) {
@@ -742,7 +747,7 @@ hipFunction_t jit_function(int device, const char *instance) {
 }
 // Source of the pattern-compiled kernels of one system (pcl_codegen.hpp)
 std::string sparse_source(const pcl_codegen::SpPlan &plan) {
-    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::apply_functions(plan) + "#include \"pcl_kernel_hessian_sparse.hpp\"\n";
+    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::apply_functions(plan) + "#include \"pcl_kernel_hessian_sparse.hpp\"\n#include \"pcl_kernel_eval_sparse.hpp\"\n";
 }
 }  // namespace
 
@@ -1078,7 +1083,44 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         return PCL_OK;
     }
 not_v3:
-    // residual only (what the solver calls in every line-search trial): the dedicated kernel for unitary states
+    // residual only (what the solver calls in every line-search trial), sparse iso generators: the pattern-compiled kernel
+    // (auto: launches with more intervals than CUs -- below that one wave per interval is a longer chain than the matrix-core kernel's)
+    if (!want_jac && (ctx->opt_eval_kernel == 2 || (ctx->opt_eval_kernel == 0 && (long long)p.batch * p.K > ctx->n_cu)) && ctx->sp_plan && !ctx->sp_failed && ctx->opt_jit &&
+        (ctx->opt_kernel == 0 || ctx->opt_kernel == 3)) {
+        const pcl_codegen::SpPlan &sp = *ctx->sp_plan;
+        const long long items = (long long)p.batch * p.K;
+        if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+        if (!ctx->sp_feval) {
+            const std::string src = sparse_source(sp);
+            const std::string key = "sparse:" + std::to_string(std::hash<std::string>{}(src));
+            ctx->sp_feval = jit_compile(ctx->device, key, src, "pcl_eval_sparse_kernel", true);
+            if (!ctx->sp_feval) ctx->sp_failed = 1;
+        }
+        if (ctx->sp_feval) {
+            if (ctx->sp_gvals_cap < (long long)ctx->desc.batch * p.K) {
+                if (ctx->dsp_gvals) (void)hipFree(ctx->dsp_gvals);
+                ctx->dsp_gvals = nullptr;
+                ctx->sp_gvals_cap = 0;
+                HIP_TRY(ctx, hipMalloc((void **)&ctx->dsp_gvals, ((size_t)ctx->desc.batch * p.K * sp.nzp + 32) * sizeof(double)));
+                ctx->sp_gvals_cap = (long long)ctx->desc.batch * p.K;
+            }
+            // one wave per interval; the intervals are spread over the CUs first, then over the waves of a workgroup (<= 8)
+            const long long ncu = std::max(ctx->n_cu, 1);
+            int nw = (int)std::min<long long>(8, std::max<long long>(1, (items + ncu - 1) / ncu));
+            long long grid = std::min<long long>((items + nw - 1) / nw, ncu);
+            if (ctx->opt_grid > 0) grid = std::min<long long>(ctx->opt_grid, (items + nw - 1) / nw);
+            const size_t ldse = (size_t)nw * (sp.n + 1) * sp.d * sizeof(double);
+            void *args[] = {(void *)&p, (void *)&ctx->dsp_gvals, (void *)&ctx->dsp_pos_n, (void *)&ctx->dsp_coef_n};
+            HIP_TRY(ctx, hipModuleLaunchKernel(ctx->sp_feval, (unsigned)grid, 1, 1, 64 * nw, 1, 1, (unsigned)ldse, ctx->stream, args, nullptr));
+            ctx->last_kernel = 70;  // the pattern-compiled residual kernel
+            ctx->last_n_stream = 0;
+            return PCL_OK;
+        }
+        if (ctx->opt_eval_kernel == 2) return fail(ctx, PCL_ESHAPE, "eval_kernel=2: the pattern-compiled kernel is not available (%s)", g_jit_note.c_str());
+    } else if (!want_jac && ctx->opt_eval_kernel == 2) {
+        return fail(ctx, PCL_ESHAPE, "eval_kernel=2 needs sparse iso generators, a unitary problem with 9 <= d <= 32, 1..6 drives and jit=1");
+    }
+    // residual only, any generators: the dedicated matrix-core kernel for unitary states
     if (!want_jac && ctx->opt_use_mfma != 0 && !ctx->vec && ctx->cols == ctx->desc.d && ctx->desc.d >= 9 && (ctx->opt_kernel == 0 || ctx->opt_kernel == 3)) {
         typedef void (*kerne_t)(const KParams);
         const int wu = (ctx->uell_w <= 2 && ctx->n_upos <= 256 * PCL_NUE_EV) ? ctx->uell_w : -1;
@@ -1937,6 +1979,10 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_stream_wg = v;
     else if (!strcmp(key, "contiguous"))  // kernel 3: 1 = equal contiguous column ranges per workgroup (default), 0 = round-robin slices
         ctx->opt_contig = v < 0 ? -1 : (v != 0);
+    else if (!strcmp(key, "eval_kernel")) {  // residual only: 0 auto, 1 matrix-core kernel, 2 pattern-compiled kernel
+        if (v < 0 || v > 2) return fail(ctx, PCL_EINVAL, "eval_kernel must be 0, 1 or 2");
+        ctx->opt_eval_kernel = v;
+    }
     else if (!strcmp(key, "hess_kernel")) {  // 0: auto, 1: one workgroup per interval, 2: persistent wave-synchronous kernel
         if (v < 0 || v > 4) return fail(ctx, PCL_EINVAL, "hess_kernel must be 0 .. 4");
         ctx->opt_hess_kernel = v;
@@ -2007,6 +2053,8 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->last_n_stream;
     else if (!strcmp(key, "hess_kernel"))
         *v = ctx->opt_hess_kernel;
+    else if (!strcmp(key, "eval_kernel"))
+        *v = ctx->opt_eval_kernel;
     else if (!strcmp(key, "last_hess_kernel"))
         *v = ctx->last_hess_kernel;
     else if (!strcmp(key, "ell_width_t"))

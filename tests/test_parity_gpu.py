@@ -1508,7 +1508,25 @@ def test_residual_only_kernel():
     c.set_option("specialize", 1)
     d_fused, _ = c.eval_jac(np.stack(Zs))
     close(c.eval(np.stack(Zs)), d_fused, 1e-13)
+    # the pattern-compiled residual kernel (sparse iso generators; auto for launches with more intervals than CUs): one wave per
+    # interval, any grid, the oracle's values, bitwise repeatable
+    c.set_option("eval_kernel", 2)
+    for grid in (0, 1, 2, 5, 1000):
+        c.set_option("grid", grid)
+        d = c.eval(np.stack(Zs))
+        assert c.get_option("last_kernel") == 70
+        close(d, ref)
+        assert np.array_equal(d, c.eval(np.stack(Zs)))
+    c.set_option("grid", 0)
+    c.set_option("eval_kernel", 0)
     ms.close()
+    big = [po.synthetic_trajectory(so, 100, seed=500 + s)[0] for s in range(3)]  # 297 intervals > 256 CUs: auto picks it
+    layb = po.synthetic_trajectory(so, 100, seed=500)[1]
+    msb = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, big[0], layb), 3)
+    db = msb.ctx.eval(np.stack(big))
+    assert msb.ctx.get_option("last_kernel") == 70
+    close(db, np.concatenate([po.pade_residual(Z, layb, G0, Gj, 4).reshape(-1) for Z in big]))
+    msb.close()
     # general real generators (dense drives: the union tables are read from memory), odd d, d = 32 (n = 64: the largest tile)
     for d_, m_ in ((9, 2), (20, 3), (32, 2)):
         lay2, G02, Gj2, Z2 = _random_case(d_, m_, 5, rng)
@@ -1526,6 +1544,13 @@ def test_residual_only_kernel():
         close(dE[i * per : (i + 1) * per], po.pade_residual(ZE, layE, s.G_drift, np.array(s.G_drives), 4, x_off=i * layE.x_dim).reshape(-1))
     B.ctx.set_member_window(2, 1)
     assert np.array_equal(B.ctx.eval(trajE.datavec), dE[2 * per :])
+    B.ctx.set_member_window(0, 3)
+    B.ctx.set_option("eval_kernel", 2)  # per-member drifts (union pattern over the members), windows
+    d2 = B.ctx.eval(trajE.datavec)
+    assert B.ctx.get_option("last_kernel") == 70
+    close(d2, dE, 1e-12)
+    B.ctx.set_member_window(1, 2)
+    assert np.array_equal(B.ctx.eval(trajE.datavec), d2[per:])
     B.close()
 
 
