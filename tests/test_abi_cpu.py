@@ -217,8 +217,9 @@ def test_pattern_compiled_kernel_source(lib, tmp_path):
         union |= g[:, :d] != 0
     nz = int(union.sum())
     assert "#define SPNZ %d\n" % nz in src
-    body = src[src.index("void sp_gt("):src.index("struct sp_mags")]
-    assert len(re.findall(r"v_(?:mul|fmac|fma)_f64", body)) == nz  # one instruction per entry: no padding, no dense tiles
+    for fn, end in (("void sp_gt(", "void sp_g("), ("void sp_g(", "struct sp_mags")):  # G(u)^T x and G(u) x
+        body = src[src.index(fn):src.index(end)]
+        assert len(re.findall(r"v_(?:mul|fmac|fma)_f64", body)) == nz  # one instruction per entry: no padding, no dense tiles
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     f = tmp_path / "sp.hip"
     f.write_text(src)
@@ -229,6 +230,6 @@ def test_pattern_compiled_kernel_source(lib, tmp_path):
                         "--cuda-device-only", "-o", str(out), str(f)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     asm = out.read_text()
-    assert "pcl_hess_sparse_kernel" in asm and "pcl_sparse_values_kernel" in asm
+    assert "pcl_hess_sparse_kernel" in asm and "pcl_sparse_values_kernel" in asm and "pcl_eval_sparse_kernel" in asm
     scratch = [int(x) for x in re.findall(r"; ScratchSize: (\d+)", asm)]
     assert max(scratch) <= 256  # a few loop-invariant integers, not operand arrays
