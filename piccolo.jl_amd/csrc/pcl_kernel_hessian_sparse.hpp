@@ -99,19 +99,22 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
 #define SP_STAMP() do { } while (0)
 #define SP_END() do { } while (0)
 #endif
-    // tile -> global: lane = row, one column (SPN consecutive doubles) per instruction; every address is a per-lane base plus an
-    // immediate (index arithmetic on `lane + 64 i` gets hoisted out of the interval loop: 23 registers per tile, spilled)
+    // tile -> global: lane = a PAIR of rows, one column (SPN consecutive doubles) per 16-byte store instruction -- the CU's one
+    // vector-memory pipeline serves all seven waves' 14 x 27 stores per interval; with 8-byte lanes it was busy twice as long.
+    // Every address is a per-lane base plus an immediate (index arithmetic on `lane + 64 i` gets hoisted out of the interval
+    // loop: 23 registers per tile, spilled).
     auto flush = [&](const double *T, double *out) {
         wave_lds_sync();
-        if (lane < SPN) {
-            const double *Tl = T + lane;
-            double *ol = out + lane;
+        if (lane < SPD) {  // SPN / 2 row pairs
+            const double *Tl = T + 2 * lane;
+            double *ol = out + 2 * lane;
 #pragma unroll
             for (int q = 0; q < SPD; ++q) {
+                const double2_t v = {Tl[SPCS * q], Tl[SPCS * q + 1]};
                 if (p.nt)
-                    __builtin_nontemporal_store(Tl[SPCS * q], ol + SPN * q);
+                    __builtin_nontemporal_store(v, reinterpret_cast<double2_t *>(ol + SPN * q));
                 else
-                    ol[SPN * q] = Tl[SPCS * q];
+                    *reinterpret_cast<double2_t *>(ol + SPN * q) = v;
             }
         }
         wave_lds_sync();
