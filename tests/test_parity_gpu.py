@@ -1602,3 +1602,73 @@ def test_hessian_of_the_lagrangian_at_every_pade_order(order):
     for i, s in enumerate(osys):
         close(hE[i * per : (i + 1) * per], po.pade_hessian_values(ZE, muE[i], layE, s.G_drift, np.array(s.G_drives), order, x_off=i * layE.x_dim).reshape(-1), 1e-10)
     BE.close()
+
+
+def _random_sparse_iso_system(d, m, rng, n_mags=3):
+    """Sparse Hermitian drift and drives (complex entries: the A and the B block of iso(-iH) are both populated), drive
+    entries drawn from a few magnitudes with random signs / phases in {1, i}: what the pattern-compiled kernels specialise on."""
+    def herm(mask_density, vals):
+        H = np.zeros((d, d), dtype=complex)
+        for i in range(d):
+            for j in range(i, d):
+                if rng.random() < mask_density:
+                    v = vals()
+                    if i == j:
+                        H[i, i] = v.real if v.real != 0 else abs(v)
+                    else:
+                        H[i, j] = v
+                        H[j, i] = np.conj(v)
+        return H
+    density = min(0.18, 2.5 / d)  # (a few hundred entries in the union pattern at every size)
+    H0 = herm(density, lambda: complex(rng.standard_normal(), rng.standard_normal()))
+    H0 += np.diag(rng.standard_normal(d))
+    mags = [1.0, np.sqrt(2.0), 0.37][:n_mags]
+    Hd = [herm(density * 0.5, lambda: rng.choice(mags) * rng.choice([1.0, -1.0]) * rng.choice([1.0, 1j])) for _ in range(m)]
+    for H in Hd:  # every drive has entries in both blocks
+        i, j = rng.choice(d, 2, replace=False)
+        H[i, j] += 1j * mags[0]
+        H[j, i] -= 1j * mags[0]
+        H[i, i] += mags[0]
+    return po.G_of_H(H0), np.array([po.G_of_H(H) for H in Hd])
+
+
+@pytest.mark.parametrize("d,m,Bn,N", [(9, 1, 2, 4), (12, 2, 1, 5), (13, 6, 2, 3), (20, 3, 3, 4), (31, 5, 1, 3), (32, 4, 2, 3)])
+def test_pattern_compiled_kernels_random_sparse_systems(d, m, Bn, N):
+    """The pattern-compiled Hessian and residual kernels (source generated per system, hiprtc) on random sparse iso systems:
+    odd and even d up to 32 (every lane of a half wave in use), 1..6 drives (3..8 waves per workgroup, odd and even counts of
+    scalar entries), entries in both blocks of iso(-iH), several magnitudes and signs, more workgroups than intervals and fewer;
+    against the oracle, forced and as the `auto` choice, bitwise repeatable."""
+    rng = np.random.default_rng(100 * d + m)
+    G0, Gj = _random_sparse_iso_system(d, m, rng)
+    n, xd = 2 * d, 2 * d * d
+    lay = po.Layout(d=d, m=m, N=N, z_dim=xd + 2 + m, x_off=0, u_off=xd + 1, dt_off=xd)
+    Zs = []
+    for _ in range(Bn):
+        Z = 0.4 * rng.standard_normal((N, lay.z_dim))
+        Z[:, lay.dt_off] = 0.05 + 0.1 * rng.random(N)
+        Zs.append(Z)
+    c = make_ctx(lay, G0, Gj, batch=Bn, batch_mode=pa._lib.PCL_BATCH_TRAJ)
+    assert c.get_option("iso_structured") == 1
+    mu = rng.standard_normal((Bn, lay.K, lay.x_dim))
+    h_ref = np.concatenate([po.pade4_hessian_values(Z, mu[i], lay, G0, Gj).reshape(-1) for i, Z in enumerate(Zs)])
+    d_ref = np.concatenate([po.pade_residual(Z, lay, G0, Gj, 4).reshape(-1) for Z in Zs])
+    Zb = np.stack(Zs)
+    h = c.hess(Zb, mu.reshape(-1))
+    assert c.get_option("last_hess_kernel") == 6  # auto
+    close(h, h_ref, 1e-11)
+    c.set_option("hess_kernel", 4)
+    c.set_option("eval_kernel", 2)
+    for grid in (0, 1, 3, 1000):
+        c.set_option("grid", grid)
+        h2 = c.hess(Zb, mu.reshape(-1))
+        assert c.get_option("last_hess_kernel") == 6
+        close(h2, h_ref, 1e-11)
+        assert np.array_equal(h2, c.hess(Zb, mu.reshape(-1)))
+        dl = c.eval(Zb)
+        assert c.get_option("last_kernel") == 70
+        close(dl, d_ref, 1e-12)
+        assert np.array_equal(dl, c.eval(Zb))
+    c.set_option("grid", 0)
+    c.set_option("hess_kernel", 3)  # the matrix-core kernel on the same system
+    close(c.hess(Zb, mu.reshape(-1)), h_ref, 1e-11)
+    c.close()
