@@ -47,10 +47,18 @@ static __device__ __forceinline__ sp_cptr sp_opaque(sp_cptr q) {
 // the LDS-heavy phases of some overlap the arithmetic of others (behind two barriers per interval all seven chains ran in
 // lock-step: every resource below 50 %).  Dependencies only point backwards (earlier stage, same or earlier interval).
 #define SP_SYNC_WORDS 16
-enum { SP_IN_READY = 0, SP_RD_DONE, SP_A1_READY, SP_A1_DONE, SP_COMB_DONE, SP_FIN = 8 /* one word per drive wave: intervals finished */ };
-static __device__ __forceinline__ void sp_wait(int *w, int target) {
-    // (bounded: a logic error must not hang the device)
-    for (int it = 0; __hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target && it < (1 << 22); ++it) __builtin_amdgcn_s_sleep(1);
+enum { SP_IN_READY = 0, SP_RD_DONE, SP_A1_READY, SP_A1_DONE, SP_COMB_DONE, SP_ERR, SP_FIN = 8 /* one word per drive wave: intervals finished */ };
+static __device__ __forceinline__ void sp_wait(int *sync, int word, int target) {
+    // Bounded: a logic error must not hang the device.  A wait that gives up poisons the workgroup's scalar entries (NaN), so the
+    // failure is visible in the values instead of silent.
+    int it = 0;
+    while (__hip_atomic_load(sync + word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++it > (1 << 22)) {
+            __hip_atomic_store(sync + SP_ERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
+    }
 }
 static __device__ __forceinline__ void sp_post(int *w, int value, int lane) {  // after wave_lds_sync(): this wave's LDS traffic is complete
     if (lane == 0) __hip_atomic_store(w, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -142,7 +150,7 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
         for (int item = item_lo; item < item_hi; ++item) {
             const int seq = item - item_lo;
             SP_PREFETCH_G((sp_cptr)(gvals_ + (long long)item * SPNZP));  // the scalar cache is warm when the other waves arrive
-            sp_wait(sync + SP_RD_DONE, (SPM + 1) * seq);                   // every reader is done with the previous interval's inputs
+            sp_wait(sync, SP_RD_DONE, (SPM + 1) * seq);                   // every reader is done with the previous interval's inputs
             SP_STAMP();
             if (lane < SPN) {
                 double *Ml = Mt + lane, *Dl = Dt + lane, *Sl = St + lane;
@@ -171,7 +179,7 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
             // the drive waves' sums of that interval are in LDS (one progress word per drive wave: nothing stops a fast wave from
             // finishing the next interval before a slow one finishes this one, so a shared arrival counter would lie)
 #pragma unroll
-            for (int j = 0; j < SPM; ++j) sp_wait(sync + SP_FIN + j, sq + 1);
+            for (int j = 0; j < SPM; ++j) sp_wait(sync, SP_FIN + j, sq + 1);
             wave_lds_sync();
             if (lane < SPNSC) {
                 auto rows4 = [&](int e) { return ((sc[4 * e] + sc[4 * e + 1]) + sc[4 * e + 2]) + sc[4 * e + 3]; };
@@ -187,6 +195,7 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
                 } else {
                     v = rows4(SPM * (SPM + 2)) * (1.0 / 6.0);
                 }
+                if (__hip_atomic_load(sync + SP_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) v = __builtin_nan("");
                 H[lane] = v;
             }
             wave_lds_sync();
@@ -201,7 +210,7 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
             double *H4 = H + SPNSC + (long long)SPM * SPXD, *H6 = H4 + SPXD + (long long)SPM * SPXD;
             double *sc = scal + (seq & 1) * NSUM;
             sp_cptr g = (sp_cptr)(gvals_ + bk * SPNZP);
-            sp_wait(sync + SP_IN_READY, seq + 1);
+            sp_wait(sync, SP_IN_READY, seq + 1);
             SP_STAMP();
             if (item + 1 < item_hi) hn = step_of(item + 1);
             double A1[SPD];
@@ -209,7 +218,7 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
                 double x[SPD];
 #pragma unroll
                 for (int r = 0; r < SPD; ++r) x[r] = Mt[own + r];
-                sp_wait(sync + SP_A1_DONE, SPM * seq);  // the drive waves have read the previous interval's A1
+                sp_wait(sync, SP_A1_DONE, SPM * seq);  // the drive waves have read the previous interval's A1
                 sp_gt(x, g, sgn, half, [&](int c, double v) {
                     A1[c] = v;
                     A1t[own + c] = v;  // (inactive lanes repeat column 0: the same values to the same addresses)
@@ -272,7 +281,7 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
             double *H3 = H + SPNSC + (long long)l * SPXD, *H5 = H3 + (long long)(SPM + 1) * SPXD;
             double *sc = scal + (seq & 1) * NSUM;
             sp_cptr g = (sp_cptr)(gvals_ + bk * SPNZP);
-            sp_wait(sync + SP_IN_READY, seq + 1);
+            sp_wait(sync, SP_IN_READY, seq + 1);
             SP_STAMP();
 #ifdef PCL_PROFILE
             if (((p.prof & 2) && wave >= 6) || ((p.prof & 4) && wave >= 4)) {  // experiments: fewer drive waves (wrong results)
@@ -314,7 +323,7 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
             }
             SP_STAMP();
             // R_l = G_l^T A1 (A1 is ready by now, or almost)
-            sp_wait(sync + SP_A1_READY, seq + 1);
+            sp_wait(sync, SP_A1_READY, seq + 1);
             {
                 double x[SPD];
 #pragma unroll
@@ -365,7 +374,7 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
 #pragma unroll
             for (int r = 0; r < SPD; ++r) T[own + r] = R[r];
             flush(T, H5);
-            sp_wait(sync + SP_COMB_DONE, seq - 1);  // the sums of interval seq - 2 (same copy) have been combined
+            sp_wait(sync, SP_COMB_DONE, seq - 1);  // the sums of interval seq - 2 (same copy) have been combined
 #pragma unroll
             for (int j = 0; j < SPM + 2; ++j) {
                 const double s = row16_sum(act ? t[j] : 0.0);
