@@ -283,14 +283,18 @@ def main():
         mu = torch.randn(c.n_rows, dtype=torch.float64, device="cuda")
         hv = torch.empty(c.hess_nnz, dtype=torch.float64, device="cuda")
         w, dv = time_steps(lambda: c.hess_dev(Zd, mu, hv), st, 5, torch, None)
+        hk = c.get_option("last_hess_kernel")
         ex["hessian_of_lagrangian"] = {"evals_per_s": B * st / w, "us_per_eval_kernel": dv / st / B * 1e6, "batch": B,
-                                       "nnz_per_eval": c.hess_nnz // B}
+                                       "nnz_per_eval": c.hess_nnz // B, "kernel_id": hk,
+                                       "kernel": "pcl_hess_sparse_kernel (pattern-compiled, generated per system; + value-table launch)" if hk == 6 else "pcl_hess_kernel_v%d" % (3 if hk in (4, 5) else hk)}
         cv = torch.empty(c.compact_nnz, dtype=torch.float64, device="cuda")
         w, dv = time_steps(lambda: c.eval_jac_compact_dev(Zd, dd, cv), st, 5, torch, None)
         ex["compact_jacobian"] = {"evals_per_s": B * st / w, "us_per_eval_kernel": dv / st / B * 1e6, "batch": B,
                                   "values_per_eval": c.compact_nnz // B}
         w, dv = time_steps(lambda: c.eval_dev(Zd, dd), st, 5, torch, None)
-        ex["residual_only"] = {"evals_per_s": B * st / w, "us_per_eval_kernel": dv / st / B * 1e6, "batch": B}
+        ek = c.get_option("last_kernel")
+        ex["residual_only"] = {"evals_per_s": B * st / w, "us_per_eval_kernel": dv / st / B * 1e6, "batch": B, "kernel_id": ek,
+                               "kernel": "pcl_eval_sparse_kernel (pattern-compiled, one wave per interval)" if ek == 70 else "pcl_eval_kernel (matrix cores)"}
         ms.close()
         del Zd, dd, mu, hv, cv
         # host-delivered: the host-pointer entry point the Julia glue calls (pcl_eval_jac: H2D of Z, kernel, delta + values
