@@ -36,6 +36,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Host-side completion waits poll instead of sleeping on an interrupt: the timed region ends with a synchronize, and with K = 20
+# steps of 27 us an interrupt wake-up is a visible share of it (measured: 32.3 -> 31.8 us per step).  Must be set before HIP starts.
+os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s achievable
 
@@ -50,11 +53,11 @@ def algorithmic_bytes_per_eval(d, m, N, z_dim):
 def time_steps(launch, steps, warmup, torch, dist):
     import gc
 
+    gc.collect()  # a generation-2 collection inside the timed loop (tens of ms over torch's object graph) is host noise, not path time
+    gc.disable()  # (before the warmup: the collection takes tens of ms, the GPU would idle and clock down right before the timed region)
     for _ in range(warmup):
         launch()
     torch.cuda.synchronize()
-    gc.collect()  # a generation-2 collection inside the timed loop (tens of ms over torch's object graph) is host noise, not path time
-    gc.disable()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
