@@ -76,11 +76,18 @@ def _source_digest(paths, flags):
     return h.hexdigest()
 
 
+def _file_digest(path):
+    import hashlib
+
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def build_library(force=False, verbose=False, profile=False):
     """Compile csrc/piccolo_hip.hip for gfx950 into csrc/libpiccolo_hip.so (in-tree).
 
     The library is rebuilt whenever the digest of its sources and flags differs from the one recorded next to the
-    shared object (``libpiccolo_hip.so.digest``) -- modification times play no part, so a stale binary is never
+    shared object (``libpiccolo_hip.so.digest``: source digest + digest of the binary) -- modification times play no part, so a stale binary is never
     reused after an edit, a checkout or a copy to another box.  ``profile=True`` adds ``-DPCL_PROFILE`` (cycle stamps
     inside the kernels for scripts/probes; never the shipped build)."""
     src = os.path.join(CSRC, "piccolo_hip.hip")
@@ -91,8 +98,11 @@ def build_library(force=False, verbose=False, profile=False):
     stamp = SO_PATH + ".digest"
     if not force and os.path.exists(SO_PATH) and os.path.exists(stamp):
         with open(stamp) as f:
-            if f.read().strip() == digest:
-                return SO_PATH
+            rec = f.read().split()
+        # the record names the sources AND the binary built from them: a stamp restored by a checkout next to a binary built
+        # from other sources (it happened: an experiment survived its revert) does not pass
+        if len(rec) == 2 and rec[0] == digest and rec[1] == _file_digest(SO_PATH):
+            return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         raise FileNotFoundError("%s not found and %s is stale or missing (sources changed since it was built)" % (hipcc, SO_PATH))
@@ -101,7 +111,7 @@ def build_library(force=False, verbose=False, profile=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     with open(stamp, "w") as f:
-        f.write(digest + "\n")
+        f.write(digest + " " + _file_digest(SO_PATH) + "\n")
     return SO_PATH
 
 
