@@ -1,6 +1,6 @@
 // pcl_kernel_hessian_sparse.hpp -- Hessian of the Lagrangian, PATTERN-COMPILED version.
 // Included by generated source only (pcl_codegen.hpp): SPD (Hilbert dimension d <= 32), SPM (drives <= 6), SPN = 2 SPD,
-// SPNZ / SPNZP and the straight-line functions sp_gt / sp_glt / sp_glt_acc / sp_gl are defined before this file.
+// SPNZ / SPNZP and the straight-line functions sp_gt / sp_g / sp_glt_<l> / sp_gltdot<l> are defined before this file.
 //
 // Every product of the Hessian acts on a state column from the left, so a lane owns ONE column and keeps it in registers:
 //     lane = (half, c): half 0 holds the top rows a of column c, half 1 the bottom rows b; both run the same instructions
@@ -8,13 +8,14 @@
 // (T = [[A, -B], [B, A]]: every generator is an exact iso(.) image).  Coefficients of G(u_k) come from a per-interval value
 // table through scalar loads (constant address space); the drives' distinct magnitudes live in scalar registers.
 // Roles (one workgroup of SPM + 2 waves per interval, a contiguous range of intervals per workgroup):
-//     wave 0      A1 = G^T M -> registers and LDS tile (flag: ready), A2 = G^T A1, outputs d2/dh dX, <A2, D>
+//     wave 0      A1 = G^T M -> registers and LDS tile (counter: ready), A2 = G^T A1, outputs d2/dh dX, <A2, D>, the scalar entries
 //     wave 1      loader: the next interval's mu, x_k, x_{k+1} travel in its registers during the interval; it also touches
 //                 the next interval's value table so that the other waves' scalar loads hit
 //     wave 2 + l  P_l = G_l^T M, <P_l, S>, R_l = G_l^T A1, <P_l, G_j D> for every j, Q_l = G^T P_l consumed row by row:
 //                 <Q_l + R_l, D> and the two output vectors d2/du_l dX
 // Outputs leave through one LDS tile per wave (lane = column -> lane = row): one column of SPN consecutive doubles per store.
-// Two barriers per interval; the 28 scalar entries are 16-lane row sums (DPP) added in a fixed order: repeatable bits.
+// No workgroup barrier in the interval loop (point-to-point LDS counters, below); the 28 scalar entries are 16-lane row sums
+// (DPP) added in a fixed order one interval later: repeatable bits.
 #pragma once
 
 #define SPXD (SPN * SPD)
