@@ -251,7 +251,7 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *       "general_threads" (256 / 512), "general_two_step" (1: unique tiles + expansion kernel)   general-order kernel
  *       "jit"                1 (default): shapes outside the static instance table are compiled on first use with hiprtc
  *                            (Hessian kernel 2 for d >= 12; fused kernel 3 when kernel_version = 3); 0: run-time-shape instances
- *       "use_mfma" (1/0: plain-VALU products in kernel 1), "nt_stores" (1/0), "specialize" (1/0: shape-specialised
+ *       "use_mfma" (1/0: plain-VALU products in kernel 1), "nt_stores" (streaming stores of the Jacobian blocks: -1 auto by launch size | 0 plain | 1 nontemporal | 2 write-through), "specialize" (1/0: shape-specialised
  *       instances), "grid" (workgroups, 0 = one per CU), "host_threads" (host-pointer entry points: threads that expand the
  *       compact values into the caller's array, 0 = auto), "host_path" (0 auto | 1 full values over PCIe | 2 compact + host expansion),
  *       "debug_timing" (PCL_ENOTIMPL unless the library was built with -DPCL_PROFILE)

@@ -62,7 +62,7 @@ struct KParams {
     int S;        // slices per interval
     int LD;       // LDS leading dimension of every n-row tile
     int compact;  // 1: write unique blocks only (jac_per is the compact size)
-    int nt;       // 1: nontemporal streaming stores
+    int nt;       // streaming stores: 0 plain | 1 nontemporal | 2 write-through (sc0 sc1)
     double *expm;  // rollout: per (b,k) propagator exp(dt_k G(u_k)), n*n col-major
     double *xout;  // rollout: states at every knot, [batch][N][x_dim]
     int q;        // general-order kernel: p/2
@@ -145,12 +145,26 @@ __device__ __forceinline__ void gemm_lds(const double *A, int lda, const double 
         valu_gemm_lds<TRANS_A>(A, lda, B, ldb, C, ldc, M, Nc, Kd, threadIdx.x, blockDim.x);
 }
 
-__device__ __forceinline__ void store2(double *p, double a, double b, bool nt) {
+// nt: 0 plain | 1 nontemporal | 2 write-through at system scope (sc0 sc1).  Write-through halves the rate of launches whose
+// output exceeds the 256 MB infinity cache (1.08 GB: 191 -> 379 us) but is 0.7 us faster for one trajectory (135 MB, 27.3 ->
+// 26.6 us): the host picks it by launch size.
+__device__ __forceinline__ void store2(double *p, double a, double b, int nt) {
     double2_t v = {a, b};
-    if (nt)
+    if (nt == 2)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    else if (nt)
         __builtin_nontemporal_store(v, reinterpret_cast<double2_t *>(p));
     else
         *reinterpret_cast<double2_t *>(p) = v;
+}
+
+// One entry of -B^+ = -(I + (h/2) G + (h^2/12) G^2) and of B^- = I - (h/2) G + (h^2/12) G^2, with the roundings pinned (explicit
+// fused multiply-adds): the four kernels that form these blocks are compared bit for bit, and what the compiler contracts on its
+// own changes with the surrounding code.  id = the entry of I, c1 = h/2, c2 = h^2/12, g / h2 = the entries of G and G^2.
+__device__ __forceinline__ void bpm_entry(double id, double c1, double c2, double g, double h2, double &mbp, double &bm) {
+    const double e = __builtin_fma(c2, h2, id);
+    mbp = -__builtin_fma(c1, g, e);
+    bm = __builtin_fma(-c1, g, e);
 }
 
 // Column-major n x n matrix in memory -> LDS tile with leading dimension LD, by NT threads.  All global loads of a block of

@@ -551,9 +551,11 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                     const int pos = 2 * q, i = pos % n, j = pos / n;
                     const double g0 = G[i + LD * j], g1 = G[i + 1 + LD * j];
                     const double h0 = G2[i + LD * j], h1 = G2[i + 1 + LD * j];
-                    const double e0 = ((i == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((i + 1 == j) ? 1.0 : 0.0) + c2 * h1;
-                    store2(jb + pos, -(e0 + c1 * g0), -(e1 + c1 * g1), p.nt);
-                    store2(jb + blk + pos, e0 - c1 * g0, e1 - c1 * g1, p.nt);
+                    double bp0, bp1, bm0, bm1;
+                    bpm_entry((i == j) ? 1.0 : 0.0, c1, c2, g0, h0, bp0, bm0);
+                    bpm_entry((i + 1 == j) ? 1.0 : 0.0, c1, c2, g1, h1, bp1, bm1);
+                    store2(jb + pos, bp0, bp1, p.nt);
+                    store2(jb + blk + pos, bm0, bm1, p.nt);
                 }
             }
             int tch = 0;
@@ -771,11 +773,8 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                     if (j < n) {
                         const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
                         const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
-                        const double e0 = ((pi == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + c2 * h1;
-                        bpr[r][0] = -(e0 + c1 * g0);
-                        bpr[r][1] = -(e1 + c1 * g1);
-                        bmr[r][0] = e0 - c1 * g0;
-                        bmr[r][1] = e1 - c1 * g1;
+                        bpm_entry((pi == j) ? 1.0 : 0.0, c1, c2, g0, h0, bpr[r][0], bmr[r][0]);
+                        bpm_entry((pi + 1 == j) ? 1.0 : 0.0, c1, c2, g1, h1, bpr[r][1], bmr[r][1]);
                     }
                 }
                 int cbeg = c0, cend = c0 + nce;

@@ -350,9 +350,9 @@ __global__ __launch_bounds__(512, 4) void pcl_fused_kernel_v2(const KParams p) {
             for (int j = pj0; j < n; j += pstep) {
                 const double g0 = G[pi + LD * j], g1 = G[pi + 1 + LD * j];
                 const double h0 = G2[pi + LD * j], h1 = G2[pi + 1 + LD * j];
-                const double e0 = ((pi == j) ? 1.0 : 0.0) + c2 * h0, e1 = ((pi + 1 == j) ? 1.0 : 0.0) + c2 * h1;
-                const double bp0 = -(e0 + c1 * g0), bp1 = -(e1 + c1 * g1);
-                const double bm0 = e0 - c1 * g0, bm1 = e1 - c1 * g1;
+                double bp0, bp1, bm0, bm1;
+                bpm_entry((pi == j) ? 1.0 : 0.0, c1, c2, g0, h0, bp0, bm0);
+                bpm_entry((pi + 1 == j) ? 1.0 : 0.0, c1, c2, g1, h1, bp1, bm1);
                 double *o0 = jb + (long long)cbeg * nn + (pi + n * j);
                 for (int c = cbeg; c < cend; ++c, o0 += nn) {
                     store2(o0, bp0, bp1, p.nt);

@@ -113,9 +113,9 @@ __global__ __launch_bounds__(256) void pcl_fused_kernel(const KParams p) {
             const double g0 = G[i + LD * j], g1 = G[i + 1 + LD * j];
             const double h0 = G2[i + LD * j], h1 = G2[i + 1 + LD * j];
             const double id0 = (i == j) ? 1.0 : 0.0, id1 = (i + 1 == j) ? 1.0 : 0.0;
-            const double e0 = id0 + c2 * h0, e1 = id1 + c2 * h1;
-            const double bp0 = -(e0 + c1 * g0), bp1 = -(e1 + c1 * g1);
-            const double bm0 = e0 - c1 * g0, bm1 = e1 - c1 * g1;
+            double bp0, bp1, bm0, bm1;
+            bpm_entry(id0, c1, c2, g0, h0, bp0, bm0);
+            bpm_entry(id1, c1, c2, g1, h1, bp1, bm1);
             for (int c = cbeg; c < cend; ++c) {
                 double *o0 = jb + (long long)c * n * n + pos;
                 store2(o0, bp0, bp1, p.nt);

@@ -99,7 +99,7 @@ struct pcl_ctx {
     int64_t opt_prof = 0;  // -DPCL_PROFILE builds only
     int64_t opt_host_threads = 0, opt_host_path = 0, opt_host_chunks = 4;
     int win_first = 0, win_count = 0;  // member window (pcl_set_member_window): the members / seeds the evaluator entry points cover
-    int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = 0, opt_kernel = 0;  // 0 = auto: 3 where its specialised instance applies, else 1 / 2 by shape
+    int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = -1 /* auto by launch size */, opt_kernel = 0;  // 0 = auto: 3 where its specialised instance applies, else 1 / 2 by shape
     long long *ddbg = nullptr;
     void *comm = nullptr;  // ncclComm_t
     double *dgoal = nullptr;  // iso-vec of the goal unitary (pcl_set_goal) or of its subspace block (pcl_set_goal_subspace)
@@ -810,7 +810,7 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.dt_off = D.dt_off;
     p.batch = ctx->win_count;
     p.LD = lds_ld(ctx->n);
-    p.nt = (int)ctx->opt_nt;
+    p.nt = ctx->opt_nt > 0 ? (int)ctx->opt_nt : 0;  // (auto: the fused launch decides by its size)
     p.dbg = ctx->ddbg;
     p.prof = (int)ctx->opt_prof;
     p.hess_per = hess_per(ctx);
@@ -999,7 +999,7 @@ static int launch_pade_general(pcl_ctx *ctx, KParams &p, bool want_jac) {
     if (jac_full) {
         const long long n_bk = (long long)p.batch * p.K;
         hipLaunchKernelGGL(pcl_expand_kernel, dim3((unsigned)(n_bk * p.cols)), dim3(256), 0, ctx->stream, (const double *)ctx->dcompact, jac_full,
-                           p.cols, p.n, p.m, n_bk, (int)ctx->opt_nt);
+                           p.cols, p.n, p.m, n_bk, ctx->opt_nt == 1 ? 1 : 0);
         HIP_TRY(ctx, hipGetLastError());
     }
     ctx->last_kernel = 90 + p.q;
@@ -1017,6 +1017,9 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     p.compact = compact ? 1 : 0;
     p.jac_per = compact ? jac_per_compact(ctx) : jac_per_full(ctx);
     const bool want_jac = jac != nullptr;
+    // streaming stores of the Jacobian blocks (auto): write-through while the launch's values fit the infinity cache with room to
+    // spare (one trajectory of config 3: 133 MB), plain write-back above (see store2)
+    if (ctx->opt_nt < 0 && want_jac && !compact && (long long)ctx->win_count * ctx->K * jac_per_full(ctx) * 8 <= (192LL << 20)) p.nt = 2;
     if (ctx->desc.pade_order != 4 || ctx->opt_general || ctx->vec) return launch_pade_general(ctx, p, want_jac);
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
     // auto: kernel 3 where its shape-specialised instance applies (BASELINE configs 3/4/5); its run-time-shape instances
@@ -1444,7 +1447,7 @@ extern "C" int pcl_jac_expand_dev(pcl_ctx *ctx, const double *compact, double *v
         return PCL_OK;
     }
     hipLaunchKernelGGL(pcl_expand_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, compact, vals, ctx->cols, ctx->n,
-                       ctx->desc.n_drives, n_bk, (int)ctx->opt_nt);
+                       ctx->desc.n_drives, n_bk, ctx->opt_nt == 1 ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
     return PCL_OK;
 }
@@ -1951,8 +1954,10 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_cols_per_slice = v;
     } else if (!strcmp(key, "use_mfma"))
         ctx->opt_use_mfma = v != 0;
-    else if (!strcmp(key, "nt_stores"))
-        ctx->opt_nt = v != 0;
+    else if (!strcmp(key, "nt_stores")) {  // -1 auto (by launch size) | 0 plain | 1 nontemporal | 2 write-through
+        if (v < -1 || v > 2) return fail(ctx, PCL_EINVAL, "nt_stores must be -1, 0, 1 or 2");
+        ctx->opt_nt = v;
+    }
     else if (!strcmp(key, "grid"))
         ctx->opt_grid = v;
 #ifdef PCL_PROFILE

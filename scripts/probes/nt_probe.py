@@ -22,7 +22,7 @@ for batch in (8, 1):
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / n
     for rep in range(3):
-        for nt in (0, 1):
+        for nt in (0, -1, 2) if batch == 1 else (0, -1):
             c.set_option("nt_stores", nt)
             print("batch %d nt %d: %.2f us/launch" % (batch, nt, tm()), flush=True)
     c.set_option("nt_stores", 0)
