@@ -48,18 +48,13 @@ static __device__ __forceinline__ sp_cptr sp_opaque(sp_cptr q) {
 // the LDS-heavy phases of some overlap the arithmetic of others (behind two barriers per interval all seven chains ran in
 // lock-step: every resource below 50 %).  Dependencies only point backwards (earlier stage, same or earlier interval).
 #define SP_SYNC_WORDS 16
-enum { SP_IN_READY = 0, SP_RD_DONE, SP_A1_READY, SP_A1_DONE, SP_COMB_DONE, SP_ERR, SP_FIN = 8 /* one word per drive wave: intervals finished */ };
-static __device__ __forceinline__ void sp_wait(int *sync, int word, int target) {
-    // Bounded: a logic error must not hang the device.  A wait that gives up poisons the workgroup's scalar entries (NaN), so the
-    // failure is visible in the values instead of silent.
+enum { SP_IN_READY = 0, SP_RD_DONE, SP_A1_READY, SP_A1_DONE, SP_COMB_DONE, SP_FIN = 8 /* one word per drive wave: intervals finished */ };
+static __device__ __forceinline__ bool sp_wait(int *sync, int word, int target) {
+    // Bounded: a logic error must not hang the device.  Returns true when it gave up; the state wave turns that into NaN scalar
+    // entries (the drive waves' progress words are the last link of every dependency chain), so the failure shows in the values.
     int it = 0;
-    while (__hip_atomic_load(sync + word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++it > (1 << 22)) {
-            __hip_atomic_store(sync + SP_ERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            break;
-        }
-    }
+    for (; __hip_atomic_load(sync + word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target && it < (1 << 22); ++it) __builtin_amdgcn_s_sleep(1);
+    return it >= (1 << 22);
 }
 static __device__ __forceinline__ void sp_post(int *w, int value, int lane) {  // after wave_lds_sync(): this wave's LDS traffic is complete
     if (lane == 0) __hip_atomic_store(w, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -108,22 +103,20 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
 #define SP_STAMP() do { } while (0)
 #define SP_END() do { } while (0)
 #endif
-    // tile -> global: lane = a PAIR of rows, one column (SPN consecutive doubles) per 16-byte store instruction -- the CU's one
-    // vector-memory pipeline serves all seven waves' 14 x 27 stores per interval; with 8-byte lanes it was busy twice as long.
-    // Every address is a per-lane base plus an immediate (index arithmetic on `lane + 64 i` gets hoisted out of the interval
-    // loop: 23 registers per tile, spilled).
+    // tile -> global: lane = row, one column (SPN consecutive doubles) per store instruction; every address is a per-lane base plus an
+    // immediate (index arithmetic on `lane + 64 i` gets hoisted out of the interval loop: 23 registers per tile, spilled).  Row pairs
+    // with 16-byte stores measured 5 % slower (A/B on one box, scripts/probes/hess_ab.py).
     auto flush = [&](const double *T, double *out) {
         wave_lds_sync();
-        if (lane < SPD) {  // SPN / 2 row pairs
-            const double *Tl = T + 2 * lane;
-            double *ol = out + 2 * lane;
+        if (lane < SPN) {
+            const double *Tl = T + lane;
+            double *ol = out + lane;
 #pragma unroll
             for (int q = 0; q < SPD; ++q) {
-                const double2_t v = {Tl[SPCS * q], Tl[SPCS * q + 1]};
                 if (p.nt)
-                    __builtin_nontemporal_store(v, reinterpret_cast<double2_t *>(ol + SPN * q));
+                    __builtin_nontemporal_store(Tl[SPCS * q], ol + SPN * q);
                 else
-                    *reinterpret_cast<double2_t *>(ol + SPN * q) = v;
+                    ol[SPN * q] = Tl[SPCS * q];
             }
         }
         wave_lds_sync();
@@ -171,7 +164,6 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
         // ---- state wave -----------------------------------------------------------------------------------------------------
         double hn = step_of(item_lo);
         double *T = Stg + SPM * SPTILE;
-        __builtin_amdgcn_s_setprio(2);  // two dependent long products: the longest chain of the interval
         double hp = 0.0;
         auto combine = [&](int sq, double hh) {  // the 28 scalar entries of interval sq: row sums added in a fixed order
             const double c2 = hh * hh * (1.0 / 12.0), h6 = hh * (1.0 / 6.0);
@@ -179,8 +171,9 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
             double *H = p.hess + (long long)(item_lo + sq) * p.hess_per;
             // the drive waves' sums of that interval are in LDS (one progress word per drive wave: nothing stops a fast wave from
             // finishing the next interval before a slow one finishes this one, so a shared arrival counter would lie)
+            bool gave_up = false;
 #pragma unroll
-            for (int j = 0; j < SPM; ++j) sp_wait(sync, SP_FIN + j, sq + 1);
+            for (int j = 0; j < SPM; ++j) gave_up |= sp_wait(sync, SP_FIN + j, sq + 1);
             wave_lds_sync();
             if (lane < SPNSC) {
                 auto rows4 = [&](int e) { return ((sc[4 * e] + sc[4 * e + 1]) + sc[4 * e + 2]) + sc[4 * e + 3]; };
@@ -196,7 +189,7 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
                 } else {
                     v = rows4(SPM * (SPM + 2)) * (1.0 / 6.0);
                 }
-                if (__hip_atomic_load(sync + SP_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) v = __builtin_nan("");
+                if (gave_up) v = __builtin_nan("");
                 H[lane] = v;
             }
             wave_lds_sync();
