@@ -22,7 +22,7 @@ namespace pcl_codegen {
 
 struct SpPlan {
     int d = 0, m = 0, n = 0;
-    int nz = 0, nzp = 0;          // union entries of the left column block [A; B] of G(u); padded to a multiple of 16
+    int nz = 0, nzp = 0;          // union entries of the left column block [A; B] of G(u); padded: nz + kChunk rounded up to a multiple of 16
     std::vector<int> row, col;    // entry k (in the emission order of sp_gt): G[row][col], row < n, col < d
     std::vector<int> pos;         // row + n*col (column-major position in G0 / G_l)
     std::vector<double> coef;     // [nz][m]: G_l at pos
@@ -37,6 +37,7 @@ struct SpPlan {
 };
 
 constexpr int kMaxMags = 8;  // distinct magnitudes of the drives' entries the kernels keep in scalar registers
+constexpr int kChunk = 12;  // coefficients per asm statement of a table-driven product (8 + 4: s_load_dwordx16 + s_load_dwordx8)
 constexpr int kGroup = 9;  // outputs accumulated together by the long product (independent dependency chains per wave; 3 .. 9 measure
                            // the same, 14 and more spill)
 
@@ -68,49 +69,13 @@ static inline Term term_t(int row, int col, int d, int src) { return {col, row, 
 // (top = U(0) - V(1), bottom = U(1) + V(0): the caller completes with -sgn)
 static inline Term term_n(int row, int col, int d, int src) { return {row < d ? row : row - d, row < d ? col : d + col, src, false}; }
 
-// Coefficient i of the table: element (i - base) % 8 of chunk (i - base) / 8.  A chunk is ONE s_load_dwordx16 issued by a
-// volatile asm statement at the point of first use (with its wait): left to the compiler, the loads of a whole product -- or
-// of several products that share a table -- are hoisted to the top of the interval and hundreds of SGPRs are spilled to VGPR
-// lanes.  Volatile asm statements keep their order, so they also keep the phases of a role apart.
-struct Chunks {
-    std::string &s;
-    const char *tab;
-    int base, n;
-    std::vector<char> state;  // 0: untouched, 1: load issued (prefetch), 2: waited for
-    Chunks(std::string &s_, const char *tab_, int base_, int n_) : s(s_), tab(tab_), base(base_), n((n_ + 15) / 16), state((n_ + 15) / 16 + 1, 0) {}
-    void declare() {
-        char buf[64];
-        for (int c = 0; c < std::max(n, 1); ++c) {
-            snprintf(buf, sizeof buf, "%ssp_v8d k%d, k%dh", c ? "; " : "    ", c, c);
-            s += buf;
-        }
-        s += ";\n";
-    }
-    void issue(int c) {
-        char buf[320];
-        snprintf(buf, sizeof buf, "        asm volatile(\"s_load_dwordx16 %%0, %%2, %d\\n\\ts_load_dwordx16 %%1, %%2, %d\" : \"=&s\"(k%d), \"=&s\"(k%dh) : \"s\"(%s) : \"memory\");\n",
-                 (base + 16 * c) * 8, (base + 16 * c + 8) * 8, c, c, tab);
-        s += buf;
-        state[c] = 1;
-    }
-    // 16 coefficients per chunk (two s_load_dwordx16).  The loads of chunk c + 1 are issued when chunk c is first used and
-    // waited for -- by a statement that passes the registers through, so that their uses stay behind it -- when chunk c + 1 is
-    // first used: one chunk of multiply-adds covers the scalar-cache latency.
-    std::string coef(int i) {
-        const int c = (i - base) / 16, e = (i - base) % 16;
-        char buf[320];
-        if (state[c] != 2) {
-            if (state[c] == 0) issue(c);
-            snprintf(buf, sizeof buf, "        asm volatile(\"s_waitcnt lgkmcnt(0)\" : \"+s\"(k%d), \"+s\"(k%dh));\n", c, c);
-            s += buf;
-            state[c] = 2;
-            if (c + 1 < n && state[c + 1] == 0) issue(c + 1);
-        }
-        snprintf(buf, sizeof buf, "k%d%s[%d]", c, e >= 8 ? "h" : "", e % 8);
-        return buf;
-    }
-};
-
+// Coefficients of a table-driven product travel in CHUNKS of (at most) eight consecutive table entries = one s_load_dwordx16.
+// One volatile asm statement per chunk holds: the load of the NEXT chunk, this chunk's multiply-adds, the wait for that load.
+// Everything that is in flight stays inside one statement: outside of them every register holds what the compiler thinks it
+// holds.  (Issuing a load in one statement and waiting for it in a later one let the compiler re-use or spill the destination
+// registers in between -- a scalar load then landed in a store's base address: memory fault at d = 31.  Left entirely to the
+// compiler, the loads of a whole product are hoisted and hundreds of SGPRs are spilled to VGPR lanes.)
+//
 // Body of  template <class F> void f(x, tab, sgn, half, out):  `ordered` is in emission order with consecutive table indices
 // starting at `base` (or resident magnitudes).  Entries of the A block (in < d) accumulate U[out] += coef x[in], entries of
 // the B block V[out] += coef x[in - d]; a finished group of outputs is completed with the other half's V and passed to
@@ -118,10 +83,44 @@ struct Chunks {
 // lds_exchange: the results go to an LDS tile anyway (Tl = the lane's slots, To = the other half's): U is written, the other
 // half's slot receives -sgn V by an LDS atomic add (a wave's LDS operations complete in order), no cross-lane VALU work.
 static inline void emit_groups(std::string &s, const std::vector<Term> &ordered, int d, int group, const char *tab, int base, bool lds_exchange = false) {
-    char buf[256];
-    Chunks ch(s, tab, base, (int)ordered.size());
-    ch.declare();
-    size_t i = 0;
+    char buf[512];
+    const bool table = !ordered.empty() && ordered[0].mag < 0;
+    // chunks: runs of <= 12 terms that do not straddle a group
+    struct Run { size_t lo, hi; };
+    std::vector<Run> runs;
+    {
+        size_t i = 0;
+        for (int g0 = 0; g0 < d; g0 += group) {
+            const int g1 = std::min(d, g0 + group);
+            size_t j = i;
+            while (j < ordered.size() && ordered[j].out < g1 && ordered[j].out >= g0) ++j;
+            for (size_t r = i; r < j; r += kChunk) runs.push_back({r, std::min(j, r + kChunk)});
+            i = j;
+        }
+    }
+    // a chunk = 8 + 4 coefficients in two SGPR tuples pinned to physical registers (even chunks: s[36:51], s[52:59]; odd chunks:
+    // s[60:75], s[76:83]) so that the asm text can name a coefficient's register pair and the tuple costs ONE operand
+    auto regs16 = [](size_t c) { return c & 1 ? "s[60:75]" : "s[36:51]"; };
+    auto regs8 = [](size_t c) { return c & 1 ? "s[76:83]" : "s[52:59]"; };
+    auto coefreg = [](size_t c, int e) {
+        static char b[24];
+        const int base = (c & 1 ? 60 : 36) + (e < 8 ? 2 * e : 16 + 2 * (e - 8));
+        snprintf(b, sizeof b, "s[%d:%d]", base, base + 1);
+        return std::string(b);
+    };
+    if (table) {
+        for (size_t c = 0; c < runs.size(); ++c) {
+            snprintf(buf, sizeof buf, "%ssp_v8d k%zu; sp_v4d h%zu", c ? "; " : "    ", c, c);
+            s += buf;
+        }
+        s += ";\n";
+        if (!runs.empty()) {
+            snprintf(buf, sizeof buf, "    asm volatile(\"s_load_dwordx16 %%0, %%2, %d\\n\\ts_load_dwordx8 %%1, %%2, %d\\n\\ts_waitcnt lgkmcnt(0)\" : \"=&{%s}\"(k0), \"=&{%s}\"(h0) : \"s\"(%s) : \"memory\");\n",
+                     (base + (int)runs[0].lo) * 8, (base + (int)runs[0].lo + 8) * 8, regs16(0), regs8(0), tab);
+            s += buf;
+        }
+    }
+    size_t i = 0, run = 0;
     for (int g0 = 0; g0 < d; g0 += group) {
         const int g1 = std::min(d, g0 + group);
         s += "    {\n";
@@ -130,25 +129,110 @@ static inline void emit_groups(std::string &s, const std::vector<Term> &ordered,
             snprintf(buf, sizeof buf, "        double u%d = 0.0, v%d = 0.0;\n", o, o);
             s += buf;
         }
-        // one volatile asm statement per multiply-add: the instruction order is the emission order (the compiler allocates the
-        // registers; left to schedule, it floats the arithmetic away from the loads and spills)
-        for (; i < ordered.size() && ordered[i].out < g1 && ordered[i].out >= g0; ++i) {
-            const Term &q = ordered[i];
-            const bool isv = q.in >= d;
-            const int idx = isv ? q.in - d : q.in;
-            char acc[16], mg[24];
-            snprintf(acc, sizeof acc, "%c%d", isv ? 'v' : 'u', q.out);
-            snprintf(mg, sizeof mg, "mg.m%d", q.mag);
-            const std::string cf = q.mag >= 0 ? std::string(mg) : ch.coef(q.src);
-            char &sn = seen[(isv ? d : 0) + q.out];
-            if (!sn)
-                snprintf(buf, sizeof buf, "        asm volatile(\"v_mul_f64 %%0, %s%%1, %%2\" : \"=v\"(%s) : \"s\"(%s), \"v\"(x[%d]));\n", q.neg ? "-" : "", acc, cf.c_str(), idx);
-            else if (!q.neg)
-                snprintf(buf, sizeof buf, "        asm volatile(\"v_fmac_f64 %%0, %%1, %%2\" : \"+v\"(%s) : \"s\"(%s), \"v\"(x[%d]));\n", acc, cf.c_str(), idx);
-            else
-                snprintf(buf, sizeof buf, "        asm volatile(\"v_fma_f64 %%0, -%%1, %%2, %%0\" : \"+v\"(%s) : \"s\"(%s), \"v\"(x[%d]));\n", acc, cf.c_str(), idx);
-            sn = 1;
-            s += buf;
+        if (!table) {
+            // resident coefficients: one volatile asm statement per multiply-add (the instruction order is the emission order; left
+            // to schedule, the compiler floats the arithmetic away and spills)
+            for (; i < ordered.size() && ordered[i].out < g1 && ordered[i].out >= g0; ++i) {
+                const Term &q = ordered[i];
+                const bool isv = q.in >= d;
+                const int idx = isv ? q.in - d : q.in;
+                char acc[16], mg[24];
+                snprintf(acc, sizeof acc, "%c%d", isv ? 'v' : 'u', q.out);
+                snprintf(mg, sizeof mg, "mg.m%d", q.mag);
+                char &sn = seen[(isv ? d : 0) + q.out];
+                if (!sn)
+                    snprintf(buf, sizeof buf, "        asm volatile(\"v_mul_f64 %%0, %s%%1, %%2\" : \"=v\"(%s) : \"s\"(%s), \"v\"(x[%d]));\n", q.neg ? "-" : "", acc, mg, idx);
+                else if (!q.neg)
+                    snprintf(buf, sizeof buf, "        asm volatile(\"v_fmac_f64 %%0, %%1, %%2\" : \"+v\"(%s) : \"s\"(%s), \"v\"(x[%d]));\n", acc, mg, idx);
+                else
+                    snprintf(buf, sizeof buf, "        asm volatile(\"v_fma_f64 %%0, -%%1, %%2, %%0\" : \"+v\"(%s) : \"s\"(%s), \"v\"(x[%d]));\n", acc, mg, idx);
+                sn = 1;
+                s += buf;
+            }
+        } else {
+            for (; run < runs.size() && runs[run].lo < ordered.size() && ordered[runs[run].lo].out < g1 && ordered[runs[run].lo].out >= g0; ++run) {
+                const Run R = runs[run];
+                const bool has_next = run + 1 < runs.size();
+                // operands: [next chunk] accumulators ... | table pointer, coefficients, x values
+                std::vector<std::string> outs, ins;
+                std::vector<std::string> accn, xn;   // names already bound to an operand
+                std::vector<int> acci, xi;
+                std::string body;
+                int nop = 0;
+                if (has_next) {
+                    snprintf(buf, sizeof buf, "\"=&{%s}\"(k%zu)", regs16(run + 1), run + 1);
+                    outs.push_back(buf);
+                    snprintf(buf, sizeof buf, "\"=&{%s}\"(h%zu)", regs8(run + 1), run + 1);
+                    outs.push_back(buf);
+                    nop += 2;
+                }
+                // first pass: bind accumulators (outputs come first in the operand numbering)
+                struct Op { std::string acc; bool first; };
+                std::vector<Op> ops;
+                for (size_t t = R.lo; t < R.hi; ++t) {
+                    const Term &q = ordered[t];
+                    const bool isv = q.in >= d;
+                    snprintf(buf, sizeof buf, "%c%d", isv ? 'v' : 'u', q.out);
+                    const std::string acc = buf;
+                    char &sn = seen[(isv ? d : 0) + q.out];
+                    bool bound = false;
+                    for (auto &a : accn) bound |= a == acc;
+                    if (!bound) {
+                        accn.push_back(acc);
+                        acci.push_back(nop++);
+                        outs.push_back(std::string(sn ? "\"+v\"(" : "\"=&v\"(") + acc + ")");
+                    }
+                    ops.push_back({acc, !sn});
+                    sn = 1;
+                }
+                const int tab_op = nop++;
+                snprintf(buf, sizeof buf, "\"s\"(%s)", tab);
+                ins.push_back(buf);
+                snprintf(buf, sizeof buf, "\"{%s}\"(k%zu)", regs16(run), run);  // this chunk's tuples: one operand each, named in the text
+                ins.push_back(buf);
+                snprintf(buf, sizeof buf, "\"{%s}\"(h%zu)", regs8(run), run);
+                ins.push_back(buf);
+                nop += 2;
+                if (has_next) {
+                    snprintf(buf, sizeof buf, "s_load_dwordx16 %%0, %%%d, %d\\n\\ts_load_dwordx8 %%1, %%%d, %d\\n\\t", tab_op, (base + (int)runs[run + 1].lo) * 8, tab_op,
+                             (base + (int)runs[run + 1].lo + 8) * 8);
+                    body += buf;
+                }
+                for (size_t t = R.lo; t < R.hi; ++t) {
+                    const Term &q = ordered[t];
+                    const bool isv = q.in >= d;
+                    const int idx = isv ? q.in - d : q.in;
+                    const std::string creg = coefreg(run, (int)(t - R.lo));
+                    snprintf(buf, sizeof buf, "x[%d]", idx);
+                    const std::string xname = buf;
+                    int xop = -1;
+                    for (size_t k = 0; k < xn.size(); ++k)
+                        if (xn[k] == xname) xop = xi[k];
+                    if (xop < 0) {
+                        xop = nop++;
+                        xn.push_back(xname);
+                        xi.push_back(xop);
+                        ins.push_back("\"v\"(" + xname + ")");
+                    }
+                    int aop = -1;
+                    for (size_t k = 0; k < accn.size(); ++k)
+                        if (accn[k] == ops[t - R.lo].acc) aop = acci[k];
+                    if (ops[t - R.lo].first)
+                        snprintf(buf, sizeof buf, "v_mul_f64 %%%d, %s%s, %%%d\\n\\t", aop, q.neg ? "-" : "", creg.c_str(), xop);
+                    else if (!q.neg)
+                        snprintf(buf, sizeof buf, "v_fmac_f64 %%%d, %s, %%%d\\n\\t", aop, creg.c_str(), xop);
+                    else
+                        snprintf(buf, sizeof buf, "v_fma_f64 %%%d, -%s, %%%d, %%%d\\n\\t", aop, creg.c_str(), xop, aop);
+                    body += buf;
+                }
+                body += has_next ? "s_waitcnt lgkmcnt(0)" : "s_nop 0";
+                s += "        asm volatile(\"" + body + "\" : ";
+                for (size_t k = 0; k < outs.size(); ++k) s += (k ? ", " : "") + outs[k];
+                s += " : ";
+                for (size_t k = 0; k < ins.size(); ++k) s += (k ? ", " : "") + ins[k];
+                s += " : \"memory\");\n";
+                i = R.hi;
+            }
         }
         if (lds_exchange) {
             // every U of the group is stored before any V is added: the slot a lane adds to is ANOTHER lane's store target, which
@@ -250,7 +334,10 @@ static inline SpPlan make_plan(int d, int m, const double *G0, int n_g0, const d
         for (int l = 0; l < m; ++l) P.coef.push_back(Gj[l * nn + (size_t)r + (size_t)n * c]);
     }
     P.nz = (int)P.row.size();
-    P.nzp = (P.nz + 15) & ~15;
+    // padded so that the last chunk's loads (kChunk entries from any entry of the table) stay inside THIS interval's table: the
+    // residual kernel's waves write their tables themselves, and a scalar load that strays into a neighbour's lines caches them
+    // before their owner has written them (the scalar cache is not coherent: the owner then read stale coefficients at d = 31)
+    P.nzp = (P.nz + kChunk + 15) & ~15;
     {
         std::vector<Term> tn;
         for (size_t k = 0; k < rows.size(); ++k) tn.push_back(detail::term_n(rows[k], cols[k], d, (int)k));
@@ -305,6 +392,7 @@ static inline std::string apply_functions(const SpPlan &P) {
              "#define SPD %d\n#define SPM %d\n#define SPN %d\n#define SPNZ %d\n#define SPNZP %d\n"
              "typedef const double __attribute__((address_space(4))) *sp_cptr;\n"
              "typedef double sp_v8d __attribute__((ext_vector_type(8)));\n"
+             "typedef double sp_v4d __attribute__((ext_vector_type(4)));\n"
              "// u + sgn * (the v of the lane 32 positions away): v_permlane32_swap, VALU only\n"
              "static __device__ __forceinline__ double sp_complete(double u, double v, double sgn, int half) {\n"
              "    const int lo = __double2loint(v), hi = __double2hiint(v);\n"

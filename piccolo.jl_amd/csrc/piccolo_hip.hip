@@ -1110,6 +1110,7 @@ not_v3:
             // one wave per interval; the intervals are spread over the CUs first, then over the waves of a workgroup (<= 8)
             const long long ncu = std::max(ctx->n_cu, 1);
             int nw = (int)std::min<long long>(8, std::max<long long>(1, (items + ncu - 1) / ncu));
+            if (getenv("PCL_EVAL_NW")) nw = atoi(getenv("PCL_EVAL_NW"));
             long long grid = std::min<long long>((items + nw - 1) / nw, ncu);
             if (ctx->opt_grid > 0) grid = std::min<long long>(ctx->opt_grid, (items + nw - 1) / nw);
             const size_t ldse = (size_t)nw * (sp.n + 1) * sp.d * sizeof(double);
