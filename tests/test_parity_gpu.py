@@ -1669,6 +1669,17 @@ def test_pattern_compiled_kernels_random_sparse_systems(d, m, Bn, N):
         close(dl, d_ref, 1e-12)
         assert np.array_equal(dl, c.eval(Zb))
     c.set_option("grid", 0)
+    # other controls on the same context, back and forth: the per-interval value tables live at the same addresses in every launch and
+    # are read through the (non-coherent) scalar cache -- a launch must never see the previous launch's coefficients
+    Zb2 = Zb.copy()
+    Zb2[:, :, lay.u_off : lay.u_off + m] *= -1.7
+    h_ref2 = np.concatenate([po.pade4_hessian_values(Z, mu[i], lay, G0, Gj).reshape(-1) for i, Z in enumerate(Zb2)])
+    d_ref2 = np.concatenate([po.pade_residual(Z, lay, G0, Gj, 4).reshape(-1) for Z in Zb2])
+    for rep in range(2):
+        close(c.hess(Zb2, mu.reshape(-1)), h_ref2, 1e-11)
+        close(c.eval(Zb2), d_ref2, 1e-12)
+        close(c.hess(Zb, mu.reshape(-1)), h_ref, 1e-11)
+        close(c.eval(Zb), d_ref, 1e-12)
     c.set_option("hess_kernel", 3)  # the matrix-core kernel on the same system
     close(c.hess(Zb, mu.reshape(-1)), h_ref, 1e-11)
     c.close()
