@@ -84,6 +84,7 @@ struct pcl_ctx {
     double *dsp_coef = nullptr, *dsp_glv = nullptr, *dsp_gvals = nullptr;
     long long sp_gvals_cap = 0;  // intervals the value table holds
     int sp_failed = 0;           // the source did not compile: the other kernels serve the context
+    int sp_hess_unfit = 0;       // the Hessian kernel's tiles do not fit LDS (d = 32 with 5 or 6 drives)
     hipFunction_t sp_fval = nullptr, sp_fhess = nullptr, sp_feval = nullptr;  // compiled on first use, kept for the context's lifetime
     int *dsp_pos_n = nullptr;       // the same tables in the emission order of the residual kernel's products
     double *dsp_coef_n = nullptr;
@@ -1257,7 +1258,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
         return PCL_OK;
     }
     // version 4 (default where it applies): the pattern-compiled kernel -- sparse iso generators, one state column per lane
-    if ((ctx->opt_hess_kernel == 0 || ctx->opt_hess_kernel == 4) && ctx->sp_plan && !ctx->sp_failed && ctx->opt_jit && ctx->desc.d == p.d) {
+    if ((ctx->opt_hess_kernel == 0 || ctx->opt_hess_kernel == 4) && ctx->sp_plan && !ctx->sp_failed && !ctx->sp_hess_unfit && ctx->opt_jit && ctx->desc.d == p.d) {
         const pcl_codegen::SpPlan &sp = *ctx->sp_plan;
         const long long items = (long long)p.batch * p.K;
         if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
@@ -1289,8 +1290,13 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             ctx->last_hess_kernel = 6;  // the pattern-compiled kernel
             return PCL_OK;
         }
-        ctx->sp_failed = 1;
-        if (ctx->opt_hess_kernel == 4) return fail(ctx, PCL_ESHAPE, "hess_kernel=4: the pattern-compiled kernel is not available (%s)", g_jit_note.c_str());
+        if (ldsp > (size_t)ctx->max_lds)
+            ctx->sp_hess_unfit = 1;  // (the residual kernel of the same source needs one tile per wave and stays available)
+        else
+            ctx->sp_failed = 1;
+        if (ctx->opt_hess_kernel == 4)
+            return fail(ctx, PCL_ESHAPE, "hess_kernel=4: the pattern-compiled kernel is not available (%zu B of LDS needed, %d available; %s)", ldsp, ctx->max_lds,
+                        g_jit_note.c_str());
     } else if (ctx->opt_hess_kernel == 4) {
         return fail(ctx, PCL_ESHAPE, "hess_kernel=4 needs sparse iso generators (at most %d distinct drive magnitudes), a unitary problem with 9 <= d <= 32, 1..6 drives and jit=1", pcl_codegen::kMaxMags);
     }
