@@ -1683,3 +1683,30 @@ def test_pattern_compiled_kernels_random_sparse_systems(d, m, Bn, N):
     c.set_option("hess_kernel", 3)  # the matrix-core kernel on the same system
     close(c.hess(Zb, mu.reshape(-1)), h_ref, 1e-11)
     c.close()
+
+
+def test_pattern_compiled_kernels_largest_shape_falls_back():
+    """d = 32 with 6 drives: the pattern-compiled Hessian kernel's 11 tiles do not fit the 160 KB of LDS -- `auto` runs the
+    a matrix-core kernel (same values), forcing kernel 4 fails loudly, and the residual kernel of the same generated source (one tile
+    per wave) still runs."""
+    d, m, N = 32, 6, 3
+    rng = np.random.default_rng(3206)
+    G0, Gj = _random_sparse_iso_system(d, m, rng)
+    xd = 2 * d * d
+    lay = po.Layout(d=d, m=m, N=N, z_dim=xd + 2 + m, x_off=0, u_off=xd + 1, dt_off=xd)
+    Z = 0.4 * rng.standard_normal((N, lay.z_dim))
+    Z[:, lay.dt_off] = 0.05 + 0.1 * rng.random(N)
+    c = make_ctx(lay, G0, Gj)
+    mu = rng.standard_normal((lay.K, lay.x_dim))
+    h_ref = po.pade4_hessian_values(Z, mu, lay, G0, Gj).reshape(-1)
+    close(c.hess(Z, mu.reshape(-1)), h_ref, 1e-11)
+    assert c.get_option("last_hess_kernel") != 6  # a matrix-core kernel (the tiles of kernel 3 do not fit either: kernel 2 / 1)
+    c.set_option("hess_kernel", 4)
+    with pytest.raises(pa.PclError):
+        c.hess(Z, mu.reshape(-1))
+    c.set_option("hess_kernel", 0)
+    c.set_option("eval_kernel", 2)
+    close(c.eval(Z), po.pade_residual(Z, lay, G0, Gj, 4).reshape(-1), 1e-12)
+    assert c.get_option("last_kernel") == 70
+    close(c.hess(Z, mu.reshape(-1)), h_ref, 1e-11)
+    c.close()
