@@ -30,6 +30,7 @@
 
 #include "pcl_device_common.hpp"
 #include "pcl_kernels_reference.hpp"
+#include "pcl_kernel_pade_v2.hpp"
 #include "pcl_kernels_fused_v2.hpp"
 #include "pcl_kernel_fused_v3.hpp"
 #include "pcl_kernel_eval.hpp"
@@ -70,6 +71,8 @@ struct pcl_ctx {
     double *dcompact = nullptr;  // general-order kernel: unique tiles before the expansion kernel replicates them
     long long compact_cap = 0;
     int64_t opt_general_threads = 512;
+    int64_t opt_general_version = 0;   // 0 auto (the lock-step kernel where it fits) | 1 reference formulation | 2 lock-step kernel or error
+    int64_t opt_general_slices = 0;    // lock-step kernel: slices per interval (0 auto)
     int64_t opt_general_two_step = 0;  // measured slower (the general-order kernel is compute-bound, not store-bound)
     double *dreduce = nullptr;  // staging of pcl_reduce_sum (host buffer)
     int64_t reduce_cap = 0;
@@ -960,12 +963,66 @@ static size_t pade_lds_bytes(const KParams &p, bool jac) {
     const size_t percol = (size_t)(p.q + 1) + 2 + (jac ? 2 + 2 * (size_t)p.m : 0);
     return (tiles + percol * p.LD * p.nc + 8 + p.m) * sizeof(double);
 }
+// Lock-step general-order kernel (pcl_kernel_pade_v2.hpp).  PCL_ENOTIMPL (no error text): the shape is not taken, the caller
+// falls back to the reference formulation.
+static int launch_pade_v2(pcl_ctx *ctx, KParams &p) {
+    const int n = p.n, m = p.m, cols = p.cols;
+    if ((n & 1) || n > 64 || n < 2 || !p.jac) return PCL_ENOTIMPL;
+    const int LD = n | 1, rt_n = (n + 15) >> 4, wpr = 16 / rt_n;
+    auto lds_of = [&](int nc) { return ((size_t)std::max((5 + m) * nc + n, 3 * n) * LD + m + 8) * sizeof(double); };
+    auto fits = [&](int nc) { return lds_of(nc) <= (size_t)ctx->max_lds && (((2 + m) * nc + 15) / 16 + wpr - 1) / wpr <= PV2_MAXT; };
+    const long long items = (long long)p.batch * p.K;
+    int S = 1;
+    while (S < cols && !fits((cols + S - 1) / S)) ++S;
+    if (!fits((cols + S - 1) / S)) return PCL_ENOTIMPL;
+    if (ctx->opt_general_slices > 0)
+        S = (int)std::max<int64_t>(S, std::min<int64_t>(ctx->opt_general_slices, cols));
+    else  // few intervals: more, narrower slices until the grid covers the CUs (the blocks role is short)
+        S = std::max(S, (int)std::min<long long>(cols, (long long)(1.2 * ctx->n_cu) / std::max(items, 1LL) - 1));
+    p.LD = LD;
+    p.S = S;
+    p.nc = (cols + S - 1) / S;
+    p.S = (cols + p.nc - 1) / p.nc;
+    const size_t lds = lds_of(p.nc);
+    const long long grid = items * (p.S + 1);
+    if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+    double *scratch = nullptr;
+    if (!p.compact && cols > 1) {
+        const long long need = items * 2 * n * n;
+        if (ctx->compact_cap < need) {
+            if (ctx->dcompact) (void)hipFree(ctx->dcompact);
+            ctx->dcompact = nullptr;
+            ctx->compact_cap = 0;
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->dcompact, (size_t)need * sizeof(double)));
+            ctx->compact_cap = need;
+        }
+        scratch = ctx->dcompact;
+    }
+    int rc = set_lds_attr(ctx, (const void *)pcl_pade_v2_kernel, 7, lds);
+    if (rc != PCL_OK) return rc;
+    hipLaunchKernelGGL(pcl_pade_v2_kernel, dim3((unsigned)grid), dim3(1024), lds, ctx->stream, p, scratch);
+    HIP_TRY(ctx, hipGetLastError());
+    if (scratch) {
+        hipLaunchKernelGGL(pcl_replicate_kernel, dim3((unsigned)(items * cols)), dim3(256), 0, ctx->stream, (const double *)scratch, p.jac, cols, n,
+                           (long long)p.jac_per, items, ctx->opt_nt == 1 ? 1 : 0);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    ctx->last_kernel = 190 + p.q;
+    ctx->last_n_stream = 0;
+    return PCL_OK;
+}
+
 static int launch_pade_general(pcl_ctx *ctx, KParams &p, bool want_jac) {
     p.q = ctx->desc.pade_order / 2;
     double f[16];
     f[0] = 1.0;
     for (int i = 1; i < 16; ++i) f[i] = f[i - 1] * i;
     for (int j = 0; j <= p.q; ++j) p.pc[j] = f[2 * p.q - j] * f[p.q] / (f[2 * p.q] * f[j] * f[p.q - j]);
+    if (want_jac && ctx->opt_general_version != 1) {
+        const int rc = launch_pade_v2(ctx, p);
+        if (rc != PCL_ENOTIMPL) return rc;
+        if (ctx->opt_general_version == 2) return fail(ctx, PCL_ESHAPE, "the lock-step general-order kernel does not take this shape (n = %d, %d columns, m = %d)", p.n, p.cols, p.m);
+    }
     p.nc = ctx->opt_cols_per_slice > 0 ? (int)std::min<int64_t>(ctx->opt_cols_per_slice, p.cols) : p.cols;
     while (p.nc > 1 && pade_lds_bytes(p, want_jac) > (size_t)ctx->max_lds) --p.nc;
     const size_t lds = pade_lds_bytes(p, want_jac);
@@ -1983,6 +2040,10 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_jit = v != 0;
     else if (!strcmp(key, "general_threads"))  // general-order kernel: 256 or 512 (default) threads per workgroup
         ctx->opt_general_threads = v == 256 ? 256 : 512;
+    else if (!strcmp(key, "general_kernel_version"))  // general-order residual+Jacobian: 0 auto | 1 reference formulation | 2 lock-step kernel (error where it does not fit)
+        ctx->opt_general_version = v < 0 || v > 2 ? 0 : v;
+    else if (!strcmp(key, "general_slices"))  // lock-step kernel: slices of state columns per interval (0 auto)
+        ctx->opt_general_slices = v < 0 ? 0 : v;
     else if (!strcmp(key, "general_two_step"))  // general-order kernel: 1 = unique tiles + expansion kernel, 0 (default) = one kernel writes every copy
         ctx->opt_general_two_step = v != 0;
     else if (!strcmp(key, "general_pade_kernel"))  // 1: the general-order kernel also for pade_order 4

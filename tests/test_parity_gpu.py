@@ -877,6 +877,7 @@ def test_general_pade_orders_vs_oracle(order, cfg, N):
     if order == 4:
         d4, j4 = c.eval_jac(Z)
         c.set_option("general_pade_kernel", 1)
+    c.set_option("general_kernel_version", 1)  # the reference formulation: three Horner chains, one workgroup per slice
     for cps in (0, 1, 2, 5):
         c.set_option("cols_per_slice", cps)
         for two_step in (0, 1):  # one kernel writes every copy (default) / unique tiles + expansion kernel
@@ -889,6 +890,33 @@ def test_general_pade_orders_vs_oracle(order, cfg, N):
     if order == 4:
         close(delta, d4)
         close(vals, j4)
+    # the lock-step kernel (default where the shape fits): every slicing, full and compact layout
+    c.set_option("general_kernel_version", 2)
+    delta1 = vals1 = None
+    for slices in (0, 1, 2, 3, lay.d):
+        c.set_option("general_slices", slices)
+        delta, vals = c.eval_jac(Z)
+        assert c.get_option("last_kernel") == 190 + order // 2
+        close(delta, d_ref, 1e-11)
+        close(vals, j_ref, 1e-11)
+        if delta1 is None:
+            delta1, vals1 = delta, vals
+        assert np.array_equal(delta, delta1) and np.array_equal(vals, vals1)  # the slicing does not change the arithmetic
+    c.set_option("general_kernel_version", 0)
+    c.set_option("general_slices", 0)
+    delta, vals = c.eval_jac(Z)
+    assert c.get_option("last_kernel") == 190 + order // 2 and np.array_equal(vals, vals1)
+    import torch
+
+    Zd = torch.from_numpy(np.ascontiguousarray(Z).reshape(-1)).cuda()
+    dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
+    cv = torch.empty(c.compact_nnz, dtype=torch.float64, device="cuda")
+    fv = torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")
+    c.eval_jac_compact_dev(Zd, dd, cv)
+    assert c.get_option("last_kernel") == 190 + order // 2
+    c.jac_expand_dev(cv, fv)
+    c.sync()
+    assert np.array_equal(fv.cpu().numpy(), vals1) and np.array_equal(dd.cpu().numpy(), delta1)
     c.close()
 
 
