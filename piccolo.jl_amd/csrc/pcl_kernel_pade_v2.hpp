@@ -7,9 +7,8 @@
 //     level q:            W = c_q Y_q            V = q c_q Y_q               dW_l = 0
 //     level j = q-1..1:   W <- c_j Y_j + h G W   V <- j c_j Y_j + h G V      dW_l <- h (G_l W_old + G dW_l)
 //     level 0:            delta = D + h G W      d delta/dh = G V            d delta/du_l = h (G_l W_old + G dW_l)
-// i.e. per level ONE product  G [W | V | dW_0 .. dW_{m-1}]  (n x (2+m) nc columns) on the matrix cores, accumulators held in
-// registers across the workgroup barrier that ends the reads, then written in place (W alone is double-buffered: the drives'
-// sparse term G_l W_old is added by the lane that owns the element, reading the old W while the new one is written).
+// i.e. per level ONE product  G [W | V | dW_0 .. dW_{m-1}]  (n x (2+m) nc columns) on the matrix cores, from one LDS buffer into the
+// other (one workgroup barrier per level; the drives' sparse term G_l W_old is added by the lane that owns the element).
 // The A operand (G, fixed for the interval) stays in registers over all levels.
 //
 // Workgroup roles (1024 threads, one role per workgroup):
@@ -19,15 +18,17 @@
 //                                                            writes the ONE copy of -B^+ and B^- (compact layout: in place;
 //                                                            full layout: into a scratch that pcl_replicate_kernel streams
 //                                                            into the d replicated positions at HBM rate)
-// LDS (doubles), columns role: G | -S | D | Wa | Wb | V | dW (m) | us      blocks role: G | Pa | Pb        (LD odd: conflict-free
-// b operand)
+// LDS (doubles), columns role: G | -S | D | X (2+m) | X' (2+m) | us | drives' ELL rows      blocks role: G | Pa | Pb
+// (LD odd: conflict-free b operand)
 #pragma once
 
 #define PV2_KS 16   // k-steps of 4 (n <= 64)
-#define PV2_MAXT 4  // output tiles per wave and level
+#define PV2_NT 1024  // threads per workgroup
+#define PV2_NP 2    // B^{+-} value pairs per thread: n n / 2 / PV2_NT <= 2 for n <= 64
 
-// one 16 x 16 tile of G * B: a[] = this wave's rows of G, Bp = this lane's column of B in LDS (nullptr: zero column)
-__device__ __forceinline__ double4_t pv2_tile(const double (&a)[PV2_KS], const double *__restrict__ Bp, int n, int lk, int ks_n) {
+// one 16 x 16 tile of G * B: a[] = this wave's rows of G, Bp = this lane's column of B in LDS (nullptr: zero column), kmask = the
+// k-steps to take (wave-uniform)
+__device__ __forceinline__ double4_t pv2_tile(const double (&a)[PV2_KS], const double *__restrict__ Bp, int n, int lk, unsigned kmask) {
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
     double b[PV2_KS];
 #pragma unroll
@@ -37,11 +38,11 @@ __device__ __forceinline__ double4_t pv2_tile(const double (&a)[PV2_KS], const d
     }
 #pragma unroll
     for (int ks = 0; ks < PV2_KS; ++ks)
-        if (ks < ks_n) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+        if (kmask & (1u << ks)) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
     return acc;
 }
 
-__global__ __launch_bounds__(1024) void pcl_pade_v2_kernel(const KParams p, double *__restrict__ blocks) {
+__global__ __launch_bounds__(PV2_NT) void pcl_pade_v2_kernel(const KParams p, double *__restrict__ blocks) {
     extern __shared__ double lds[];
     const int n = p.n, d = p.cols, m = p.m, LD = p.LD, nc = p.nc, q = p.q, S = p.S;
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(1024) void pcl_pade_v2_kernel(const KParams p, doub
     const int k = (int)(item % p.K), b = (int)(item / p.K);
     const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
     const double h = zk[p.dt_off];
-    const int rt_n = (n + 15) >> 4, ks_n = (n + 3) >> 2;
+    const int rt_n = (n + 15) >> 4;
     const int wpr = nw / rt_n;                // waves per row tile
     const int rt = wave % rt_n, cw = wave / rt_n;  // this wave's row tile and its first column tile
     const bool idle = cw >= wpr;
@@ -72,11 +73,16 @@ __global__ __launch_bounds__(1024) void pcl_pade_v2_kernel(const KParams p, doub
             const int row = rt * 16 + li, kk = 4 * ks + lk;
             a[ks] = (row < n && kk < n) ? G[row + LD * kk] : 0.0;
         }
-        // each thread owns the flat column-major positions 2 (tid + nth r), +1 (n is even: same column)
-        double bp[2][2], bm[2][2];
-        int o_[2];
+        unsigned kmask = 0;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int ks = 0; ks < PV2_KS; ++ks)
+            if (__ballot(a[ks] != 0.0)) kmask |= 1u << ks;
+        kmask = __builtin_amdgcn_readfirstlane(kmask);
+        // each thread owns the flat column-major positions 2 (tid + nth r), +1 (n is even: same column)
+        double bp[PV2_NP][2], bm[PV2_NP][2];
+        int o_[PV2_NP];
+#pragma unroll
+        for (int r = 0; r < PV2_NP; ++r) {
             const int pos = 2 * (tid + nth * r);
             o_[r] = -1;
             bp[r][0] = bm[r][0] = bp[r][1] = bm[r][1] = 0.0;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(1024) void pcl_pade_v2_kernel(const KParams p, doub
             hp *= h;
             hm *= -h;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < PV2_NP; ++r) {
                 const double v0 = o_[r] >= 0 ? Pc[o_[r]] : 0.0, v1 = o_[r] >= 0 ? Pc[o_[r] + 1] : 0.0;
                 bp[r][0] += p.pc[j] * hp * v0;
                 bp[r][1] += p.pc[j] * hp * v1;
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(1024) void pcl_pade_v2_kernel(const KParams p, doub
                 if (!idle)
                     for (int ct = cw; ct < rt_n; ct += wpr) {
                         const int col = ct * 16 + li;
-                        const double4_t acc = pv2_tile(a, col < n ? Pc + LD * col : nullptr, n, lk, ks_n);
+                        const double4_t acc = pv2_tile(a, col < n ? Pc + LD * col : nullptr, n, lk, kmask);
                         if (col < n) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(1024) void pcl_pade_v2_kernel(const KParams p, doub
         }
         double *dst = (p.compact || !blocks) ? jb : blocks + item * 2 * nn;  // (one state column: the full layout IS the compact one)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < PV2_NP; ++r) {
             const int pos = 2 * (tid + nth * r);
             if (pos < nn) {
                 store2(dst + pos, -bp[r][0], -bp[r][1], 0);
@@ -132,11 +138,25 @@ __global__ __launch_bounds__(1024) void pcl_pade_v2_kernel(const KParams p, doub
 
     // ---- columns role ---------------------------------------------------------------------------------------------------
     const int s = (int)(bid % S);
-    const int c0 = s * nc, nce = min(nc, d - c0), LDc = LD * nc;
-    double *Sm = G + LD * n, *Dm = Sm + LDc, *Wc = Dm + LDc, *Wn = Wc + LDc, *X = Wn + LDc;  // X: V | dW_0 .. dW_{m-1}
-    double *us = X + (1 + m) * LDc;
+    const int c0 = s * nc, nce = min(nc, d - c0), LDc = LD * nc, T = 2 + m;
+    double *Sm = G + LD * n, *Dm = Sm + LDc, *Xc = Dm + LDc, *Xn = Xc + T * LDc;  // X: W | V | dW_0 .. dW_{m-1}
+    double *us = Xn + T * LDc;
     const double *zn = zk + p.z_dim;
     const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
+    // the drives' rows in ELL form (fixed width, zero padded): staged in LDS where the host found room, else read from memory
+    const int ew = p.ell_w;
+    const double *ev = p.ell_val;
+    const int *ec = p.ell_col;
+    if (p.ell_lds) {
+        double *evl = us + ((m + 2) & ~1);
+        int *ecl = reinterpret_cast<int *>(evl + m * n * ew);
+        for (int e = tid; e < m * n * ew; e += nth) {
+            evl[e] = p.ell_val[e];
+            ecl[e] = p.ell_col[e];
+        }
+        ev = evl;
+        ec = ecl;
+    }
     build_G(p, p.G0 + (long long)b * p.g0_batch_stride, zk, G, us);
     const double cq = p.pc[q];
     for (int e = tid; e < nc * n; e += nth) {
@@ -151,9 +171,9 @@ __global__ __launch_bounds__(1024) void pcl_pade_v2_kernel(const KParams p, doub
         Sm[idx] = -xs;
         Dm[idx] = xdv;
         const double yq = (q & 1) ? -xs : xdv;
-        Wc[idx] = cq * yq;
-        X[idx] = q * cq * yq;
-        for (int l = 0; l < m; ++l) X[(1 + l) * LDc + idx] = 0.0;
+        Xc[idx] = cq * yq;
+        Xc[LDc + idx] = q * cq * yq;
+        for (int l = 0; l < m; ++l) Xc[(2 + l) * LDc + idx] = 0.0;
     }
     __syncthreads();
     double a[PV2_KS];
@@ -162,64 +182,70 @@ __global__ __launch_bounds__(1024) void pcl_pade_v2_kernel(const KParams p, doub
         const int row = rt * 16 + li, kk = 4 * ks + lk;
         a[ks] = (row < n && kk < n) ? G[row + LD * kk] : 0.0;
     }
-    const int ctot = (2 + m) * nc, ct_n = (ctot + 15) >> 4;
+    // 16 x 4 blocks of G without a nonzero (the generators are sparse: at BASELINE config 3 G has 21 % nonzeros) are skipped:
+    // adding their exact-zero products changes nothing (but the sign of a zero sum)
+    unsigned kmask = 0;
+#pragma unroll
+    for (int ks = 0; ks < PV2_KS; ++ks)
+        if (__ballot(a[ks] != 0.0)) kmask |= 1u << ks;
+    kmask = __builtin_amdgcn_readfirstlane(kmask);
+    const int ctot = T * nc, ct_n = (ctot + 15) >> 4;
     for (int j = q - 1; j >= 0; --j) {
-        double4_t acc[PV2_MAXT];
-        if (!idle) {
+        const double *Yj = (j & 1) ? Sm : Dm;
+        const double cj = p.pc[j];
+        if (!idle)
+            for (int ct = cw; ct < ct_n; ct += wpr) {
+                const int vc = ct * 16 + li, bl = vc / nc, c = vc - bl * nc;
+                const bool on = vc < ctot;
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
+                if (!(j == q - 1 && ct * 16 >= 2 * nc))  // (dW is zero at the first level)
+                    acc = pv2_tile(a, on ? Xc + bl * LDc + LD * c : nullptr, n, lk, kmask);
+                if (on) {
+                    // the additive term of each element: c_j Y_j, j c_j Y_j, or the drives' sparse product with the old W
+                    double y[4];
 #pragma unroll
-            for (int t = 0; t < PV2_MAXT; ++t) {
-                const int ct = cw + t * wpr;
-                acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
-                if (ct < ct_n && !(j == q - 1 && ct * 16 >= 2 * nc)) {  // (dW is zero at the first level)
-                    const int vc = ct * 16 + li, bl = vc / nc, c = vc - bl * nc;
-                    const double *Bp = vc < ctot ? (bl == 0 ? Wc : X + (bl - 1) * LDc) + LD * c : nullptr;
-                    acc[t] = pv2_tile(a, Bp, n, lk, ks_n);
-                }
-            }
-        }
-        __syncthreads();  // every read of V / dW of the previous level is complete: written in place below
-        if (!idle) {
-            const double *Yj = (j & 1) ? Sm : Dm;
-            const double cj = p.pc[j];
-#pragma unroll
-            for (int t = 0; t < PV2_MAXT; ++t) {
-                const int ct = cw + t * wpr;
-                const int vc = ct * 16 + li;
-                if (ct < ct_n && vc < ctot) {
-                    const int bl = vc / nc, c = vc - bl * nc;
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = rt * 16 + lk + 4 * r;
+                        double v = 0.0;
+                        if (rr < n) {
+                            if (bl <= 1) {
+                                v = Yj[rr + LD * c];
+                            } else {
+                                const int eb = ((bl - 2) * n + rr) * ew;
+                                for (int e = 0; e < ew; ++e) v += ev[eb + e] * Xc[ec[eb + e] + LD * c];
+                            }
+                        }
+                        y[r] = v;
+                    }
+                    double *dst = Xn + bl * LDc + LD * c;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int rr = rt * 16 + lk + 4 * r;
                         if (rr < n) {
-                            const int idx = rr + LD * c;
-                            if (bl == 0) {
-                                Wn[idx] = cj * Yj[idx] + h * acc[t][r];
-                            } else if (bl == 1) {
-                                X[idx] = j ? j * cj * Yj[idx] + h * acc[t][r] : acc[t][r];
-                            } else {
-                                const int l = bl - 2;
-                                const int *rp = p.csr_ptr + l * (n + 1) + rr;
-                                double sa = 0.0;
-                                for (int e = rp[0]; e < rp[1]; ++e) sa += p.csr_val[e] * Wc[p.csr_col[e] + LD * c];
-                                X[(1 + l) * LDc + idx] = h * (acc[t][r] + sa);
-                            }
+                            double o;
+                            if (bl == 0)
+                                o = cj * y[r] + h * acc[r];
+                            else if (bl == 1)
+                                o = j ? j * cj * y[r] + h * acc[r] : acc[r];
+                            else
+                                o = h * (acc[r] + y[r]);
+                            dst[rr] = o;
                         }
                     }
                 }
             }
-        }
-        __syncthreads();
-        double *t_ = Wc;
-        Wc = Wn;
-        Wn = t_;
+        __syncthreads();  // level j is complete in Xn; nothing reads Xc any more
+        double *t_ = Xc;
+        Xc = Xn;
+        Xn = t_;
     }
     const long long xd = (long long)n * d;
     if (p.delta)
-        for (int e = tid; e < nce * n; e += nth) p.delta[item * xd + (long long)c0 * n + e] = Wc[(e % n) + LD * (e / n)];
+        for (int e = tid; e < nce * n; e += nth) p.delta[item * xd + (long long)c0 * n + e] = Xc[(e % n) + LD * (e / n)];
     double *jt = jb + 2 * blk + (long long)c0 * (m + 1) * n;
     for (int e = tid; e < (m + 1) * nce * n; e += nth) {
         const int i = e % n, l = (e / n) % (m + 1), c = e / (n * (m + 1));
-        jt[e] = X[(l < m ? (1 + l) * LDc : 0) + i + LD * c];
+        jt[e] = Xc[(l < m ? (2 + l) * LDc : LDc) + i + LD * c];
     }
 }
 

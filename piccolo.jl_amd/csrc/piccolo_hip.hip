@@ -968,9 +968,9 @@ static size_t pade_lds_bytes(const KParams &p, bool jac) {
 static int launch_pade_v2(pcl_ctx *ctx, KParams &p) {
     const int n = p.n, m = p.m, cols = p.cols;
     if ((n & 1) || n > 64 || n < 2 || !p.jac) return PCL_ENOTIMPL;
-    const int LD = n | 1, rt_n = (n + 15) >> 4, wpr = 16 / rt_n;
-    auto lds_of = [&](int nc) { return ((size_t)std::max((5 + m) * nc + n, 3 * n) * LD + m + 8) * sizeof(double); };
-    auto fits = [&](int nc) { return lds_of(nc) <= (size_t)ctx->max_lds && (((2 + m) * nc + 15) / 16 + wpr - 1) / wpr <= PV2_MAXT; };
+    const int LD = n | 1;
+    auto lds_of = [&](int nc) { return ((size_t)std::max((2 + 2 * (2 + m)) * nc + n, 3 * n) * LD + m + 8) * sizeof(double); };
+    auto fits = [&](int nc) { return lds_of(nc) <= (size_t)ctx->max_lds; };
     const long long items = (long long)p.batch * p.K;
     int S = 1;
     while (S < cols && !fits((cols + S - 1) / S)) ++S;
@@ -983,7 +983,10 @@ static int launch_pade_v2(pcl_ctx *ctx, KParams &p) {
     p.S = S;
     p.nc = (cols + S - 1) / S;
     p.S = (cols + p.nc - 1) / p.nc;
-    const size_t lds = lds_of(p.nc);
+    size_t lds = lds_of(p.nc);
+    const size_t ell_bytes = (size_t)m * n * p.ell_w * (sizeof(double) + sizeof(int)) + 16;
+    p.ell_lds = m > 0 && lds + ell_bytes <= (size_t)ctx->max_lds;
+    if (p.ell_lds) lds += ell_bytes;
     const long long grid = items * (p.S + 1);
     if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
     double *scratch = nullptr;
@@ -1000,7 +1003,7 @@ static int launch_pade_v2(pcl_ctx *ctx, KParams &p) {
     }
     int rc = set_lds_attr(ctx, (const void *)pcl_pade_v2_kernel, 7, lds);
     if (rc != PCL_OK) return rc;
-    hipLaunchKernelGGL(pcl_pade_v2_kernel, dim3((unsigned)grid), dim3(1024), lds, ctx->stream, p, scratch);
+    hipLaunchKernelGGL(pcl_pade_v2_kernel, dim3((unsigned)grid), dim3(PV2_NT), lds, ctx->stream, p, scratch);
     HIP_TRY(ctx, hipGetLastError());
     if (scratch) {
         hipLaunchKernelGGL(pcl_replicate_kernel, dim3((unsigned)(items * cols)), dim3(256), 0, ctx->stream, (const double *)scratch, p.jac, cols, n,
