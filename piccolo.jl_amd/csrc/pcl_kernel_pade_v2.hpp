@@ -2,24 +2,21 @@
 // not cover.  Same outputs as pcl_pade_kernel<true> (pcl_kernels_reference.hpp, which stays as the second implementation and
 // as the fallback for shapes this one does not take: odd n, slices too narrow for the LDS budget).
 //
-// The three Horner recursions of the reference formulation run in LOCK STEP, one matrix product per level instead of three
-// dependent chains (with Y_j = D for even j, -S for odd j; c_j the Pade coefficients; h the step):
-//     level q:            W = c_q Y_q            V = q c_q Y_q               dW_l = 0
-//     level j = q-1..1:   W <- c_j Y_j + h G W   V <- j c_j Y_j + h G V      dW_l <- h (G_l W_old + G dW_l)
+// The three Horner recursions of the reference formulation AND the powers of G run in LOCK STEP, one matrix product per level
+// instead of four dependent chains (with Y_j = D for even j, -S for odd j; c_j the Pade coefficients; h the step):
+//     level q:            W = c_q Y_q            V = q c_q Y_q               dW_l = 0                          P = G
+//     level j = q-1..1:   W <- c_j Y_j + h G W   V <- j c_j Y_j + h G V      dW_l <- h (G_l W_old + G dW_l)    P <- G P
 //     level 0:            delta = D + h G W      d delta/dh = G V            d delta/du_l = h (G_l W_old + G dW_l)
-// i.e. per level ONE product  G [W | V | dW_0 .. dW_{m-1}]  (n x (2+m) nc columns) on the matrix cores, from one LDS buffer into the
-// other (one workgroup barrier per level; the drives' sparse term G_l W_old is added by the lane that owns the element).
-// The A operand (G, fixed for the interval) stays in registers over all levels.
+// i.e. per level ONE product  G [W | V | dW_0 .. dW_{m-1} | P]  on the matrix cores, from one LDS buffer into the other (one
+// workgroup barrier per level; the drives' sparse term G_l W_old is added by the lane that owns the element).  The A operand
+// (G, fixed for the interval) stays in registers over all levels; its 16 x 4 blocks without a nonzero are skipped.
+// B^{+-} = sum_j c_j (+-h)^j G^j accumulates in registers as the powers appear and is written to its d replicated positions
+// by the workgroup that formed it.
 //
-// Workgroup roles (1024 threads, one role per workgroup):
-//   columns role (items * S workgroups, first in the grid)   slice s of an interval's state columns: the recursion above,
-//                                                            writes delta and the u / dt columns of the Jacobian
-//   blocks role  (items workgroups, last in the grid)        powers of G by repeated products, B^{+-} = sum_j c_j (+-h)^j G^j,
-//                                                            writes the ONE copy of -B^+ and B^- (compact layout: in place;
-//                                                            full layout: into a scratch that pcl_replicate_kernel streams
-//                                                            into the d replicated positions at HBM rate)
-// LDS (doubles), columns role: G | -S | D | X (2+m) | X' (2+m) | us | drives' ELL rows      blocks role: G | Pa | Pb
-// (LD odd: conflict-free b operand)
+// One workgroup (1024 threads) per (interval, slice): slice s takes nc of the state columns (W, V, dW) and npc of the n columns
+// of the powers, so every workgroup of the grid does the same work.
+// LDS (doubles): G | -S | D | X (2+m) | X' (2+m) | P' | us | drives' ELL rows      (P starts as the slice's columns of G in place;
+// LD odd: conflict-free b operand)
 #pragma once
 
 #define PV2_KS 16   // k-steps of 4 (n <= 64)
@@ -42,15 +39,14 @@ __device__ __forceinline__ double4_t pv2_tile(const double (&a)[PV2_KS], const d
     return acc;
 }
 
-__global__ __launch_bounds__(PV2_NT) void pcl_pade_v2_kernel(const KParams p, double *__restrict__ blocks) {
+__global__ __launch_bounds__(PV2_NT) void pcl_pade_v2_kernel(const KParams p) {
     extern __shared__ double lds[];
     const int n = p.n, d = p.cols, m = p.m, LD = p.LD, nc = p.nc, q = p.q, S = p.S;
     const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const long long items = (long long)p.batch * p.K;
     const long long bid = blockIdx.x;
-    const bool blocks_role = bid >= items * S;
-    const long long item = blocks_role ? bid - items * S : bid / S;
+    const long long item = bid / S;
+    const int s = (int)(bid % S);
     const int k = (int)(item % p.K), b = (int)(item / p.K);
     const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
     const double h = zk[p.dt_off];
@@ -61,86 +57,12 @@ __global__ __launch_bounds__(PV2_NT) void pcl_pade_v2_kernel(const KParams p, do
     const long long nn = (long long)n * n;
     double *jb = p.jac + item * p.jac_per;
     const long long blk = p.compact ? nn : (long long)d * nn;
-
+    const int npc = (n + S - 1) / S, pc0 = s * npc, npce = max(0, min(npc, n - pc0));  // this slice's columns of the powers
+    const int c0 = s * nc, nce = max(0, min(nc, d - c0)), LDc = LD * nc, T = 2 + m;
     double *G = lds;
-    if (blocks_role) {
-        double *Pa = G + LD * n, *Pb = Pa + LD * n;
-        build_G(p, p.G0 + (long long)b * p.g0_batch_stride, zk, G, Pb);  // (Pb: scratch for the controls)
-        __syncthreads();
-        double a[PV2_KS];
-#pragma unroll
-        for (int ks = 0; ks < PV2_KS; ++ks) {
-            const int row = rt * 16 + li, kk = 4 * ks + lk;
-            a[ks] = (row < n && kk < n) ? G[row + LD * kk] : 0.0;
-        }
-        unsigned kmask = 0;
-#pragma unroll
-        for (int ks = 0; ks < PV2_KS; ++ks)
-            if (__ballot(a[ks] != 0.0)) kmask |= 1u << ks;
-        kmask = __builtin_amdgcn_readfirstlane(kmask);
-        // each thread owns the flat column-major positions 2 (tid + nth r), +1 (n is even: same column)
-        double bp[PV2_NP][2], bm[PV2_NP][2];
-        int o_[PV2_NP];
-#pragma unroll
-        for (int r = 0; r < PV2_NP; ++r) {
-            const int pos = 2 * (tid + nth * r);
-            o_[r] = -1;
-            bp[r][0] = bm[r][0] = bp[r][1] = bm[r][1] = 0.0;
-            if (pos < nn) {
-                const int i = pos % n, jj = pos / n;
-                o_[r] = i + LD * jj;
-                bp[r][0] = bm[r][0] = (i == jj) ? 1.0 : 0.0;
-                bp[r][1] = bm[r][1] = (i + 1 == jj) ? 1.0 : 0.0;
-            }
-        }
-        const double *Pc = G;
-        double hp = 1.0, hm = 1.0;
-        for (int j = 1; j <= q; ++j) {
-            hp *= h;
-            hm *= -h;
-#pragma unroll
-            for (int r = 0; r < PV2_NP; ++r) {
-                const double v0 = o_[r] >= 0 ? Pc[o_[r]] : 0.0, v1 = o_[r] >= 0 ? Pc[o_[r] + 1] : 0.0;
-                bp[r][0] += p.pc[j] * hp * v0;
-                bp[r][1] += p.pc[j] * hp * v1;
-                bm[r][0] += p.pc[j] * hm * v0;
-                bm[r][1] += p.pc[j] * hm * v1;
-            }
-            if (j < q) {
-                double *Pn = (Pc == Pa) ? Pb : Pa;
-                if (!idle)
-                    for (int ct = cw; ct < rt_n; ct += wpr) {
-                        const int col = ct * 16 + li;
-                        const double4_t acc = pv2_tile(a, col < n ? Pc + LD * col : nullptr, n, lk, kmask);
-                        if (col < n) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int rr = rt * 16 + lk + 4 * r;
-                                if (rr < n) Pn[rr + LD * col] = acc[r];
-                            }
-                        }
-                    }
-                __syncthreads();
-                Pc = Pn;
-            }
-        }
-        double *dst = (p.compact || !blocks) ? jb : blocks + item * 2 * nn;  // (one state column: the full layout IS the compact one)
-#pragma unroll
-        for (int r = 0; r < PV2_NP; ++r) {
-            const int pos = 2 * (tid + nth * r);
-            if (pos < nn) {
-                store2(dst + pos, -bp[r][0], -bp[r][1], 0);
-                store2(dst + nn + pos, bm[r][0], bm[r][1], 0);
-            }
-        }
-        return;
-    }
-
-    // ---- columns role ---------------------------------------------------------------------------------------------------
-    const int s = (int)(bid % S);
-    const int c0 = s * nc, nce = min(nc, d - c0), LDc = LD * nc, T = 2 + m;
     double *Sm = G + LD * n, *Dm = Sm + LDc, *Xc = Dm + LDc, *Xn = Xc + T * LDc;  // X: W | V | dW_0 .. dW_{m-1}
-    double *us = Xn + T * LDc;
+    double *Pn = Xn + T * LDc, *Pc = G + LD * pc0;
+    double *us = Pn + LD * npc;
     const double *zn = zk + p.z_dim;
     const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
     // the drives' rows in ELL form (fixed width, zero padded): staged in LDS where the host found room, else read from memory
@@ -189,17 +111,42 @@ __global__ __launch_bounds__(PV2_NT) void pcl_pade_v2_kernel(const KParams p, do
     for (int ks = 0; ks < PV2_KS; ++ks)
         if (__ballot(a[ks] != 0.0)) kmask |= 1u << ks;
     kmask = __builtin_amdgcn_readfirstlane(kmask);
-    const int ctot = T * nc, ct_n = (ctot + 15) >> 4;
+    // B^{+-}: each thread owns the positions (2 pi, 2 pi + 1), pi = tid + nth r, of the slice's n x npce block of columns (n is
+    // even: both in one column); first term c_1 (+-h) G
+    double bp[PV2_NP][2], bm[PV2_NP][2];
+    int o_[PV2_NP];
+    double hp = h, hm = -h;
+#pragma unroll
+    for (int r = 0; r < PV2_NP; ++r) {
+        const int pos = 2 * (tid + nth * r);
+        o_[r] = -1;
+        bp[r][0] = bm[r][0] = bp[r][1] = bm[r][1] = 0.0;
+        if (pos < n * npce) {
+            const int i = pos % n, jj = pc0 + pos / n;
+            o_[r] = i + LD * (pos / n);
+            bp[r][0] = bm[r][0] = (i == jj) ? 1.0 : 0.0;
+            bp[r][1] = bm[r][1] = (i + 1 == jj) ? 1.0 : 0.0;
+            const double v0 = Pc[o_[r]], v1 = Pc[o_[r] + 1];
+            bp[r][0] += p.pc[1] * hp * v0;
+            bp[r][1] += p.pc[1] * hp * v1;
+            bm[r][0] += p.pc[1] * hm * v0;
+            bm[r][1] += p.pc[1] * hm * v1;
+        }
+    }
+    const int cx = T * nc, ctot = cx + npc, ct_n = (ctot + 15) >> 4;
     for (int j = q - 1; j >= 0; --j) {
         const double *Yj = (j & 1) ? Sm : Dm;
         const double cj = p.pc[j];
         if (!idle)
             for (int ct = cw; ct < ct_n; ct += wpr) {
-                const int vc = ct * 16 + li, bl = vc / nc, c = vc - bl * nc;
-                const bool on = vc < ctot;
+                const int vc = ct * 16 + li;
+                const bool isp = vc >= cx;                       // a column of the powers
+                const int bl = isp ? T : vc / nc, c = isp ? vc - cx : vc - bl * nc;
+                const bool on = isp ? (j > 0 && c < npce) : true;
+                // (dW is zero at the first level; the last level forms no power)
+                const bool skip = (j == q - 1 && ct * 16 >= 2 * nc && ct * 16 + 15 < cx) || (j == 0 && ct * 16 >= cx);
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
-                if (!(j == q - 1 && ct * 16 >= 2 * nc))  // (dW is zero at the first level)
-                    acc = pv2_tile(a, on ? Xc + bl * LDc + LD * c : nullptr, n, lk, kmask);
+                if (!skip) acc = pv2_tile(a, on ? (isp ? Pc : Xc + bl * LDc) + LD * c : nullptr, n, lk, kmask);
                 if (on) {
                     // the additive term of each element: c_j Y_j, j c_j Y_j, or the drives' sparse product with the old W
                     double y[4];
@@ -210,14 +157,14 @@ __global__ __launch_bounds__(PV2_NT) void pcl_pade_v2_kernel(const KParams p, do
                         if (rr < n) {
                             if (bl <= 1) {
                                 v = Yj[rr + LD * c];
-                            } else {
+                            } else if (!isp) {
                                 const int eb = ((bl - 2) * n + rr) * ew;
                                 for (int e = 0; e < ew; ++e) v += ev[eb + e] * Xc[ec[eb + e] + LD * c];
                             }
                         }
                         y[r] = v;
                     }
-                    double *dst = Xn + bl * LDc + LD * c;
+                    double *dst = (isp ? Pn : Xn + bl * LDc) + LD * c;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int rr = rt * 16 + lk + 4 * r;
@@ -227,17 +174,36 @@ __global__ __launch_bounds__(PV2_NT) void pcl_pade_v2_kernel(const KParams p, do
                                 o = cj * y[r] + h * acc[r];
                             else if (bl == 1)
                                 o = j ? j * cj * y[r] + h * acc[r] : acc[r];
-                            else
+                            else if (!isp)
                                 o = h * (acc[r] + y[r]);
+                            else
+                                o = acc[r];
                             dst[rr] = o;
                         }
                     }
                 }
             }
-        __syncthreads();  // level j is complete in Xn; nothing reads Xc any more
+        __syncthreads();  // level j is complete in X' / P'; nothing reads X / P any more
         double *t_ = Xc;
         Xc = Xn;
         Xn = t_;
+        if (j > 0) {  // the next power: its term of B^{+-}
+            t_ = Pc;
+            Pc = Pn;
+            Pn = t_;
+            const int pw = q + 1 - j;
+            hp *= h;
+            hm *= -h;
+#pragma unroll
+            for (int r = 0; r < PV2_NP; ++r)
+                if (o_[r] >= 0) {
+                    const double v0 = Pc[o_[r]], v1 = Pc[o_[r] + 1];
+                    bp[r][0] += p.pc[pw] * hp * v0;
+                    bp[r][1] += p.pc[pw] * hp * v1;
+                    bm[r][0] += p.pc[pw] * hm * v0;
+                    bm[r][1] += p.pc[pw] * hm * v1;
+                }
+        }
     }
     const long long xd = (long long)n * d;
     if (p.delta)
@@ -247,22 +213,15 @@ __global__ __launch_bounds__(PV2_NT) void pcl_pade_v2_kernel(const KParams p, do
         const int i = e % n, l = (e / n) % (m + 1), c = e / (n * (m + 1));
         jt[e] = Xc[(l < m ? (2 + l) * LDc : LDc) + i + LD * c];
     }
-}
-
-// the single copy of -B^+ / B^- per interval (blocks[item][2][n n]) -> the d replicated positions of the full Jacobian layout
-__global__ __launch_bounds__(256) void pcl_replicate_kernel(const double *__restrict__ blocks, double *__restrict__ full, int d, int n,
-                                                            long long fper, long long n_bk, int nt) {
-    const long long nn = (long long)n * n;
-    const long long bid = blockIdx.x;
-    const int c = (int)(bid % d);
-    const long long bk = bid / d;
-    if (bk >= n_bk) return;
-    const double *src = blocks + bk * 2 * nn;
-    double *dst = full + bk * fper;
-    for (long long q = threadIdx.x; q < (nn >> 1); q += blockDim.x) {
-        const double2_t v0 = *reinterpret_cast<const double2_t *>(src + 2 * q);
-        const double2_t v1 = *reinterpret_cast<const double2_t *>(src + nn + 2 * q);
-        store2(dst + c * nn + 2 * q, v0[0], v0[1], nt);
-        store2(dst + (d + c) * nn + 2 * q, v1[0], v1[1], nt);
-    }
+    // -B^+ and B^-: this slice's columns, into every replicated position (compact layout: the one copy)
+    const int copies = p.compact ? 1 : d;
+#pragma unroll
+    for (int r = 0; r < PV2_NP; ++r)
+        if (o_[r] >= 0) {
+            double *o0 = jb + (long long)pc0 * n + 2 * (tid + nth * r);
+            for (int c = 0; c < copies; ++c) {
+                store2(o0 + c * nn, -bp[r][0], -bp[r][1], p.nt);
+                store2(o0 + blk + c * nn, bm[r][0], bm[r][1], p.nt);
+            }
+        }
 }

@@ -969,47 +969,32 @@ static int launch_pade_v2(pcl_ctx *ctx, KParams &p) {
     const int n = p.n, m = p.m, cols = p.cols;
     if ((n & 1) || n > 64 || n < 2 || !p.jac) return PCL_ENOTIMPL;
     const int LD = n | 1;
-    auto lds_of = [&](int nc) { return ((size_t)std::max((2 + 2 * (2 + m)) * nc + n, 3 * n) * LD + m + 8) * sizeof(double); };
-    auto fits = [&](int nc) { return lds_of(nc) <= (size_t)ctx->max_lds; };
+    auto lds_of = [&](int S) {
+        const int nc = (cols + S - 1) / S, npc = (n + S - 1) / S;
+        return ((size_t)((2 + 2 * (2 + m)) * nc + n + npc) * LD + m + 8) * sizeof(double);
+    };
     const long long items = (long long)p.batch * p.K;
+    const int s_max = std::max(cols, 1);
     int S = 1;
-    while (S < cols && !fits((cols + S - 1) / S)) ++S;
-    if (!fits((cols + S - 1) / S)) return PCL_ENOTIMPL;
+    while (S < s_max && lds_of(S) > (size_t)ctx->max_lds) ++S;
+    if (lds_of(S) > (size_t)ctx->max_lds) return PCL_ENOTIMPL;
     if (ctx->opt_general_slices > 0)
-        S = (int)std::max<int64_t>(S, std::min<int64_t>(ctx->opt_general_slices, cols));
-    else  // few intervals: more, narrower slices until the grid covers the CUs (the blocks role is short)
-        S = std::max(S, (int)std::min<long long>(cols, (long long)(1.2 * ctx->n_cu) / std::max(items, 1LL) - 1));
+        S = (int)std::max<int64_t>(S, std::min<int64_t>(ctx->opt_general_slices, s_max));
+    else  // few intervals: more, narrower slices while the grid still fits the CUs in one round
+        S = std::max(S, (int)std::min<long long>(s_max, ctx->n_cu / std::max(items, 1LL)));
     p.LD = LD;
-    p.S = S;
     p.nc = (cols + S - 1) / S;
-    p.S = (cols + p.nc - 1) / p.nc;
-    size_t lds = lds_of(p.nc);
+    p.S = S;  // (slices beyond the last state column still carry their columns of the powers)
+    size_t lds = lds_of(S);
     const size_t ell_bytes = (size_t)m * n * p.ell_w * (sizeof(double) + sizeof(int)) + 16;
     p.ell_lds = m > 0 && lds + ell_bytes <= (size_t)ctx->max_lds;
     if (p.ell_lds) lds += ell_bytes;
-    const long long grid = items * (p.S + 1);
+    const long long grid = items * p.S;
     if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
-    double *scratch = nullptr;
-    if (!p.compact && cols > 1) {
-        const long long need = items * 2 * n * n;
-        if (ctx->compact_cap < need) {
-            if (ctx->dcompact) (void)hipFree(ctx->dcompact);
-            ctx->dcompact = nullptr;
-            ctx->compact_cap = 0;
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->dcompact, (size_t)need * sizeof(double)));
-            ctx->compact_cap = need;
-        }
-        scratch = ctx->dcompact;
-    }
     int rc = set_lds_attr(ctx, (const void *)pcl_pade_v2_kernel, 7, lds);
     if (rc != PCL_OK) return rc;
-    hipLaunchKernelGGL(pcl_pade_v2_kernel, dim3((unsigned)grid), dim3(PV2_NT), lds, ctx->stream, p, scratch);
+    hipLaunchKernelGGL(pcl_pade_v2_kernel, dim3((unsigned)grid), dim3(PV2_NT), lds, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
-    if (scratch) {
-        hipLaunchKernelGGL(pcl_replicate_kernel, dim3((unsigned)(items * cols)), dim3(256), 0, ctx->stream, (const double *)scratch, p.jac, cols, n,
-                           (long long)p.jac_per, items, ctx->opt_nt == 1 ? 1 : 0);
-        HIP_TRY(ctx, hipGetLastError());
-    }
     ctx->last_kernel = 190 + p.q;
     ctx->last_n_stream = 0;
     return PCL_OK;
