@@ -66,6 +66,7 @@ struct KParams {
     double *expm;  // rollout: per (b,k) propagator exp(dt_k G(u_k)), n*n col-major
     double *xout;  // rollout: states at every knot, [batch][N][x_dim]
     int q;        // general-order kernel: p/2
+    int lds_doubles;  // lock-step general-order kernel: doubles of LDS to zero-fill at the start
     double pc[6]; // general-order kernel: diagonal Pade coefficients c_0..c_q
 };
 

@@ -15,7 +15,7 @@
 //
 // One workgroup (1024 threads) per (interval, slice): slice s takes nc of the state columns (W, V, dW) and npc of the n columns
 // of the powers, so every workgroup of the grid does the same work.
-// LDS (doubles): G | -S | D | X (2+m) | X' (2+m) | P' | us | drives' ELL rows      (P starts as the slice's columns of G in place;
+// LDS (doubles): G | -S | D | X (2+m) | X' (2+m) | P' | zeros | us | drives' ELL rows      (P starts as the slice's columns of G in place;
 // LD odd: conflict-free b operand)
 #pragma once
 
@@ -23,16 +23,14 @@
 #define PV2_NT 1024  // threads per workgroup
 #define PV2_NP 2    // B^{+-} value pairs per thread: n n / 2 / PV2_NT <= 2 for n <= 64
 
-// one 16 x 16 tile of G * B: a[] = this wave's rows of G, Bp = this lane's column of B in LDS (nullptr: zero column), kmask = the
-// k-steps to take (wave-uniform)
-__device__ __forceinline__ double4_t pv2_tile(const double (&a)[PV2_KS], const double *__restrict__ Bp, int n, int lk, unsigned kmask) {
+// one 16 x 16 tile of G * B: a[] = this wave's rows of G, Bp = this lane's column of B in LDS + (lane >> 4), kmask = the k-steps
+// to take (wave-uniform).  The 16 operand loads are unconditional, base + immediate: rows beyond n meet a = 0, and every
+// double of the workgroup's LDS is finite (zero-filled at the start; a column of zeros stands in for columns beyond the last)
+__device__ __forceinline__ double4_t pv2_tile(const double (&a)[PV2_KS], const double *__restrict__ Bp, unsigned kmask) {
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
     double b[PV2_KS];
 #pragma unroll
-    for (int ks = 0; ks < PV2_KS; ++ks) {
-        const int kk = 4 * ks + lk;
-        b[ks] = (Bp && kk < n) ? Bp[kk] : 0.0;
-    }
+    for (int ks = 0; ks < PV2_KS; ++ks) b[ks] = Bp[4 * ks];
 #pragma unroll
     for (int ks = 0; ks < PV2_KS; ++ks)
         if (kmask & (1u << ks)) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
@@ -62,7 +60,10 @@ __global__ __launch_bounds__(PV2_NT) void pcl_pade_v2_kernel(const KParams p) {
     double *G = lds;
     double *Sm = G + LD * n, *Dm = Sm + LDc, *Xc = Dm + LDc, *Xn = Xc + T * LDc;  // X: W | V | dW_0 .. dW_{m-1}
     double *Pn = Xn + T * LDc, *Pc = G + LD * pc0;
-    double *us = Pn + LD * npc;
+    double *zcol = Pn + LD * npc;  // 64 zeros (+ 16 of slack behind the last tile: operand loads run up to row 63 of a column)
+    double *us = zcol + 80;
+    for (int e = tid; e < p.lds_doubles; e += nth) lds[e] = 0.0;
+    __syncthreads();
     const double *zn = zk + p.z_dim;
     const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
     // the drives' rows in ELL form (fixed width, zero padded): staged in LDS where the host found room, else read from memory
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(PV2_NT) void pcl_pade_v2_kernel(const KParams p) {
         }
     }
     const int cx = T * nc, ctot = cx + npc, ct_n = (ctot + 15) >> 4;
+    const unsigned inv_nc = (65536u + nc - 1) / nc;  // vc / nc = (vc inv_nc) >> 16 for vc < 2048
     for (int j = q - 1; j >= 0; --j) {
         const double *Yj = (j & 1) ? Sm : Dm;
         const double cj = p.pc[j];
@@ -141,12 +143,12 @@ __global__ __launch_bounds__(PV2_NT) void pcl_pade_v2_kernel(const KParams p) {
             for (int ct = cw; ct < ct_n; ct += wpr) {
                 const int vc = ct * 16 + li;
                 const bool isp = vc >= cx;                       // a column of the powers
-                const int bl = isp ? T : vc / nc, c = isp ? vc - cx : vc - bl * nc;
+                const int bl = isp ? T : (int)((vc * inv_nc) >> 16), c = isp ? vc - cx : vc - bl * nc;
                 const bool on = isp ? (j > 0 && c < npce) : true;
                 // (dW is zero at the first level; the last level forms no power)
                 const bool skip = (j == q - 1 && ct * 16 >= 2 * nc && ct * 16 + 15 < cx) || (j == 0 && ct * 16 >= cx);
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
-                if (!skip) acc = pv2_tile(a, on ? (isp ? Pc : Xc + bl * LDc) + LD * c : nullptr, n, lk, kmask);
+                if (!skip) acc = pv2_tile(a, (on ? (isp ? Pc : Xc + bl * LDc) + LD * c : zcol) + lk, kmask);
                 if (on) {
                     // the additive term of each element: c_j Y_j, j c_j Y_j, or the drives' sparse product with the old W
                     double y[4];

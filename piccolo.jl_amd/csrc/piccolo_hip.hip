@@ -971,7 +971,7 @@ static int launch_pade_v2(pcl_ctx *ctx, KParams &p) {
     const int LD = n | 1;
     auto lds_of = [&](int S) {
         const int nc = (cols + S - 1) / S, npc = (n + S - 1) / S;
-        return ((size_t)((2 + 2 * (2 + m)) * nc + n + npc) * LD + m + 8) * sizeof(double);
+        return ((size_t)((2 + 2 * (2 + m)) * nc + n + npc) * LD + 80 + m + 8) * sizeof(double);
     };
     const long long items = (long long)p.batch * p.K;
     const int s_max = std::max(cols, 1);
@@ -989,6 +989,7 @@ static int launch_pade_v2(pcl_ctx *ctx, KParams &p) {
     const size_t ell_bytes = (size_t)m * n * p.ell_w * (sizeof(double) + sizeof(int)) + 16;
     p.ell_lds = m > 0 && lds + ell_bytes <= (size_t)ctx->max_lds;
     if (p.ell_lds) lds += ell_bytes;
+    p.lds_doubles = (int)(lds / sizeof(double));
     const long long grid = items * p.S;
     if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
     int rc = set_lds_attr(ctx, (const void *)pcl_pade_v2_kernel, 7, lds);
