@@ -68,18 +68,13 @@ __global__ __launch_bounds__(PV2_NT) void pcl_pade_v2_kernel(const KParams p) {
     const int x_off = p.x_offs[p.z_batch_stride ? 0 : b];
     // the drives' rows in ELL form (fixed width, zero padded): staged in LDS where the host found room, else read from memory
     const int ew = p.ell_w;
-    const double *ev = p.ell_val;
-    const int *ec = p.ell_col;
-    if (p.ell_lds) {
-        double *evl = us + ((m + 2) & ~1);
-        int *ecl = reinterpret_cast<int *>(evl + m * n * ew);
+    double *evl = us + ((m + 2) & ~1);
+    int *ecl = reinterpret_cast<int *>(evl + m * n * ew);
+    if (p.ell_lds)
         for (int e = tid; e < m * n * ew; e += nth) {
             evl[e] = p.ell_val[e];
             ecl[e] = p.ell_col[e];
         }
-        ev = evl;
-        ec = ecl;
-    }
     build_G(p, p.G0 + (long long)b * p.g0_batch_stride, zk, G, us);
     const double cq = p.pc[q];
     for (int e = tid; e < nc * n; e += nth) {
@@ -150,38 +145,59 @@ __global__ __launch_bounds__(PV2_NT) void pcl_pade_v2_kernel(const KParams p) {
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
                 if (!skip) acc = pv2_tile(a, (on ? (isp ? Pc : Xc + bl * LDc) + LD * c : zcol) + lk, kmask);
                 if (on) {
-                    // the additive term of each element: c_j Y_j, j c_j Y_j, or the drives' sparse product with the old W
-                    double y[4];
+                    // the additive term of each element: c_j Y_j, j c_j Y_j, or the drives' sparse product with the old W.  Loads
+                    // are unconditional (rows beyond n - 1 read finite padding; the stores below are predicated)
+                    const int r0 = rt * 16 + lk;
+                    double y[4] = {0.0, 0.0, 0.0, 0.0};
+                    if (bl <= 1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int rr = rt * 16 + lk + 4 * r;
-                        double v = 0.0;
-                        if (rr < n) {
-                            if (bl <= 1) {
-                                v = Yj[rr + LD * c];
-                            } else if (!isp) {
-                                const int eb = ((bl - 2) * n + rr) * ew;
-                                for (int e = 0; e < ew; ++e) v += ev[eb + e] * Xc[ec[eb + e] + LD * c];
+                        for (int r = 0; r < 4; ++r) y[r] = Yj[r0 + 4 * r + LD * c];
+                    } else if (!isp) {
+                        const double *wc = Xc + LD * c;
+                        // (two code paths, one per address space of the ELL rows: a pointer that may be either is a FLAT load)
+                        auto sparse = [&](const auto *evp, const auto *ecp) {
+                            if (ew == 2) {  // the common width: all loads of the four rows in flight together
+                                double v_[4][2];
+                                int c_[4][2];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int eb = ((bl - 2) * n + min(r0 + 4 * r, n - 1)) * 2;
+                                    v_[r][0] = evp[eb];
+                                    v_[r][1] = evp[eb + 1];
+                                    c_[r][0] = ecp[eb];
+                                    c_[r][1] = ecp[eb + 1];
+                                }
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) y[r] = v_[r][0] * wc[c_[r][0]] + v_[r][1] * wc[c_[r][1]];
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int eb = ((bl - 2) * n + min(r0 + 4 * r, n - 1)) * ew;
+                                    double v = 0.0;
+                                    for (int e = 0; e < ew; ++e) v += evp[eb + e] * wc[ecp[eb + e]];
+                                    y[r] = v;
+                                }
                             }
-                        }
-                        y[r] = v;
+                        };
+                        if (p.ell_lds)
+                            sparse(evl, ecl);
+                        else
+                            sparse(p.ell_val, p.ell_col);
                     }
                     double *dst = (isp ? Pn : Xn + bl * LDc) + LD * c;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int rr = rt * 16 + lk + 4 * r;
-                        if (rr < n) {
-                            double o;
-                            if (bl == 0)
-                                o = cj * y[r] + h * acc[r];
-                            else if (bl == 1)
-                                o = j ? j * cj * y[r] + h * acc[r] : acc[r];
-                            else if (!isp)
-                                o = h * (acc[r] + y[r]);
-                            else
-                                o = acc[r];
-                            dst[rr] = o;
-                        }
+                        const int rr = r0 + 4 * r;
+                        double o;
+                        if (bl == 0)
+                            o = cj * y[r] + h * acc[r];
+                        else if (bl == 1)
+                            o = j ? j * cj * y[r] + h * acc[r] : acc[r];
+                        else if (!isp)
+                            o = h * (acc[r] + y[r]);
+                        else
+                            o = acc[r];
+                        if (rr < n) dst[rr] = o;
                     }
                 }
             }
