@@ -248,7 +248,10 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *       "eval_kernel"        residual only: 0 auto | 1 the matrix-core residual kernel | 2 the pattern-compiled kernel (one wave per
  *                            interval; same applicability as hess_kernel 4; auto for launches with more intervals than CUs)
  *       "general_pade_kernel" 1: run the general-order kernel for pade_order 4 too (cross-check)
- *       "general_threads" (256 / 512), "general_two_step" (1: unique tiles + expansion kernel)   general-order kernel
+ *       "general_kernel_version" residual+Jacobian at pade_order != 4: 0 auto (the lock-step kernel where the shape fits: even
+ *                             n <= 64 and LDS), 1 the reference formulation, 2 the lock-step kernel or PCL_ESHAPE
+ *       "general_slices"      lock-step kernel: slices of state columns per interval (0 auto)
+ *       "general_threads" (256 / 512), "general_two_step" (1: unique tiles + expansion kernel)   reference formulation
  *       "jit"                1 (default): shapes outside the static instance table are compiled on first use with hiprtc
  *                            (Hessian kernel 2 for d >= 12; fused kernel 3 when kernel_version = 3); 0: run-time-shape instances
  *       "use_mfma" (1/0: plain-VALU products in kernel 1), "nt_stores" (streaming stores of the Jacobian blocks: -1 auto by launch size | 0 plain | 1 nontemporal | 2 write-through), "specialize" (1/0: shape-specialised
@@ -256,7 +259,7 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *       compact values into the caller's array, 0 = auto), "host_path" (0 auto | 1 full values over PCIe | 2 compact + host expansion),
  *       "debug_timing" (PCL_ENOTIMPL unless the library was built with -DPCL_PROFILE)
  * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised; 60 / 61 matrix-core residual kernel, 70 pattern-compiled residual kernel; 90 + q for the
- *       general-order kernel), "last_stream_workgroups", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3 static / compiled | 6: pattern-compiled | 90 + q), "jit_compiles", "n_cu", "iso_structured", "drives_antisymmetric",
+ *       general-order kernel in the reference formulation, 190 + q for the lock-step general-order kernel), "last_stream_workgroups", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3 static / compiled | 6: pattern-compiled | 90 + q), "jit_compiles", "n_cu", "iso_structured", "drives_antisymmetric",
  *       "ell_width", "ell_width_t", "union_width", "occupancy_v2".  Unknown keys return PCL_EINVAL. */
 int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t value);
 int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *value);
