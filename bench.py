@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--no-shares", action="store_true", help="auto on 1 GPU: skip the multistart / ensemble share measurements")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even for one rank: exercises the multi-rank code path on one GPU")
+    ap.add_argument("--separate-payload", action="store_true", help="ensemble step: pcl_eval_jac_dev + pcl_merit_grad_dev instead of the fused pcl_eval_jac_merit_dev")
     ap.add_argument("--no-extras", action="store_true", help="skip the Hessian / compact / residual-only / host-delivered / config-2 rates")
     args = ap.parse_args()
 
@@ -184,9 +185,12 @@ def main():
         reduce_ = dist is not None and use_dist
 
         def step():
-            c.eval_jac_dev(Zd, dd, vd)
             J.value_and_gradient_dev(Zd, payload[:1], grad)
-            c.merit_grad_dev(dd, None, vd, payload[1:])
+            if args.separate_payload:  # A/B: the payload kernels read the tails back from HBM
+                c.eval_jac_dev(Zd, dd, vd)
+                c.merit_grad_dev(dd, None, vd, payload[1:])
+            else:  # the fused kernel's matrix waves form the payload's dot products while a column is in LDS
+                c.eval_jac_merit_dev(Zd, None, dd, vd, payload[1:])
             if reduce_:
                 pd.reduce_payload(payload, dist)  # ONE sum all-reduce (RCCL over xGMI, on this stream): the one collective of the path
 
@@ -195,6 +199,7 @@ def main():
         assert np.isfinite(chk).all() and chk[1] > 0
         info = dict(kernel_id=c.get_option("last_kernel"), stream_workgroups=c.get_option("last_stream_workgroups"),
                     payload_bytes=int(payload.numel() * 8), all_reduce=bool(reduce_), z_dim=int(traj.dim),
+                    payload_fused=bool(c.get_option("last_merit_fused")) and not args.separate_payload,
                     objective=float(chk[0]), merit=float(chk[1]))  # fmt: skip
         for b in Bs:
             b.close()
@@ -273,6 +278,7 @@ def main():
         we, de, ie, ub = run_ensemble(B, st, 20, False)
         out["ensemble_share"] = {"evals_per_s": B * st / we, "us_per_step_kernel": de / st * 1e6, "members_per_step": B,
                                  "hbm_GBps": ub * B / (de / st) / 1e9, "payload_bytes": ie["payload_bytes"], "all_reduce": ie["all_reduce"],
+                                 "payload_fused": ie["payload_fused"],
                                  "note": "config 4 share on one GPU: the step of the N > 1 default workload without the all-reduce"}  # fmt: skip
     if rank == 0 and world == 1 and not args.no_extras:
         # the other rates of the same path, reported beside the headline (never as `value`)

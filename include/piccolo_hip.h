@@ -210,6 +210,12 @@ int pcl_objective(pcl_ctx *ctx, const double *Z, double Q, double *value, double
  * summed over ranks with pcl_reduce_sum_dev; TRAJ mode: `sets` = batch sets (nothing is shared between seeds). */
 int pcl_merit_grad_len(const pcl_ctx *ctx, int64_t *len, int64_t *sets);
 int pcl_merit_grad_dev(pcl_ctx *ctx, const double *delta_dev, const double *lam_dev, const double *vals_dev, double *out_dev);
+/* pcl_eval_jac_dev + pcl_merit_grad_dev in one pass: the fused kernel forms the payload's dot products per state column while the
+ * column's vectors are still in LDS (the 1.7 % of the Jacobian values that pcl_merit_grad_dev reads back from HBM are never
+ * re-read); delta_dev and vals_dev are written exactly as by pcl_eval_jac_dev.  Launches that do not take fused kernel 3 (other
+ * shapes, Pade orders other than 4, a member window) run the two calls one after the other: same outputs, same layout.
+ * get_option "last_merit_fused" tells which. */
+int pcl_eval_jac_merit_dev(pcl_ctx *ctx, const double *Z_dev, const double *lam_dev, double *delta_dev, double *vals_dev, double *out_dev);
 
 /* rollout for validation ------------------------------------------------------------------------
  *   unitary_rollout(traj, sys; interpolation = :constant)                       src/quantum/dynamics.jl:631-667

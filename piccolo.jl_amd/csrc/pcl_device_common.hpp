@@ -68,6 +68,8 @@ struct KParams {
     int q;        // general-order kernel: p/2
     int lds_doubles;  // lock-step general-order kernel: doubles of LDS to zero-fill at the start
     double pc[6]; // general-order kernel: diagonal Pade coefficients c_0..c_q
+    double *mpart;       // v3, optional: per state column (b, k, c) the m + 2 dot products of the reduce payload (pcl_eval_jac_merit_dev)
+    const double *mlam;  // ... against these multipliers (NULL: lam = delta, the constraint merit)
 };
 
 // ------------------------------------------------------------------------------------------

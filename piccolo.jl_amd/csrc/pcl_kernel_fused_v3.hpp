@@ -34,7 +34,9 @@ struct V3Tables {  // launch-invariant tables, in LDS when they fit (else in mem
 
 // EW: ELL width held in registers for m <= PCL_MREG drives (0: general, tables in LDS / memory).
 // TD/TM/TNCW: compile-time Hilbert dimension, drive count, chunk width (0 = run-time values).
-template <int EW, int TD, int TM, int TNCW>
+// MERIT: the instance that also forms the reduce payload's dot products per state column (pcl_eval_jac_merit_dev); a separate
+// instance because the extra live values cost the plain one registers (246 -> 256 VGPRs and a spill at <2,27,6,2>).
+template <int EW, int TD, int TM, int TNCW, bool MERIT = false>
 __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
     extern __shared__ double lds[];
     const int d = TD ? TD : p.d, n = 2 * d, m = TD ? TM : p.m, LD = TD ? ((2 * TD + 3) & ~3) + 2 : p.LD;
@@ -562,6 +564,10 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
             for (int ch = wave; ch < nchunk && !stream_role; ch += nmw, ++tch) {
                 const int cc0 = c0 + ch * ncw;             // first state column of the chunk
                 const int ncc = min(ncw, c0 + nce - cc0);  // columns in this chunk
+                const bool pf_lam = MERIT && p.mpart && p.mlam && ncw <= PCL_PFW;  // multipliers of the chunk: requested now, used after the outputs are formed
+                double lamr[PCL_PFW];
+#pragma unroll
+                for (int c = 0; c < PCL_PFW; ++c) lamr[c] = (pf_lam && c < ncc && lane < n) ? p.mlam[bk * xd + (long long)(cc0 + c) * n + lane] : 0.0;
                 // ---- M = [S | D | G_l D]   (lane = row) -----------------------------------------------------
                 if (lane < n) {
                     if (pf && tch < PCL_PFC) {
@@ -727,6 +733,35 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                     }
                 }
                 wave_lds_sync();
+                // ---- optional: the chunk's share of the reduce payload (pcl_eval_jac_merit_dev), while the vectors are still in
+                //      LDS: per column <d delta/d u_l, lam>, <d delta/d dt, lam>, <delta, lam>.  Lane (s = lane & 15, q = lane >> 4)
+                //      adds the rows q, q + 4, .. of product s = c*(m+2) + l in row order, then the four parts in a fixed tree:
+                //      bitwise repeatable, and the 74 MB of tails are never read back from HBM.
+                if (MERIT && p.mpart) {
+                    if (p.mlam) {  // the multipliers take the place of S (dead since the epilogue above)
+                        if (lane < n) {
+                            if (pf_lam) {
+#pragma unroll
+                                for (int c = 0; c < PCL_PFW; ++c)
+                                    if (c < ncw) Mw[lane + LD * c] = lamr[c];
+                            } else {
+                                for (int c = 0; c < ncw; ++c) Mw[lane + LD * c] = c < ncc ? p.mlam[bk * xd + (long long)(cc0 + c) * n + lane] : 0.0;
+                            }
+                        }
+                        wave_lds_sync();
+                    }
+                    const int s = lane & 15, q = lane >> 4, c = s / (m + 2), l = s - c * (m + 2);
+                    double acc = 0.0;
+                    if (s < (m + 2) * ncw && c < ncc) {
+                        const double *av = l < m ? Mw + LD * (2 * ncw + l * ncw + c) : (l == m ? GSw + LD * c : G2Dw + LD * c);
+                        const double *lv = p.mlam ? Mw + LD * c : G2Dw + LD * c;
+                        for (int r = q; r < n; r += 4) acc = fma(av[r], lv[r], acc);
+                    }
+                    acc += __shfl_xor(acc, 16, 64);
+                    acc += __shfl_xor(acc, 32, 64);
+                    if (q == 0 && s < (m + 2) * ncw && c < ncc)
+                        p.mpart[(bk * d + cc0 + c) * (m + 2) + l] = (l == m + 1 && !p.mlam) ? 0.5 * acc : acc;
+                }
                 // the chunk's columns are contiguous in every output vector: element e = c*n + row, two per lane
                 {
                     const int hn2 = n >> 1;

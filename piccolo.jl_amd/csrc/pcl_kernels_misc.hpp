@@ -420,6 +420,19 @@ __global__ __launch_bounds__(512) void pcl_merit_part_kernel(const double *__res
         if (lane == 0) part[bk * (m + 2) + l] = s;
     }
 }
+// Fused variant (pcl_eval_jac_merit_dev): the fused kernel's matrix waves leave the m + 2 dot products per state column
+// (pcol[((b*K + k)*cols + c)*(m+2) + l], formed while the column's vectors were in LDS); this adds the columns of an interval
+// in a fixed order (lane-strided, then a shuffle tree) into the same part[] layout pcl_merit_part_kernel writes.
+__global__ __launch_bounds__(64) void pcl_merit_cols_kernel(const double *__restrict__ pcol, double *__restrict__ part, int K, int cols, int m) {
+    const long long bk = (long long)blockIdx.y * K + blockIdx.x;
+    const double *src = pcol + bk * cols * (m + 2);
+    for (int l = 0; l <= m + 1; ++l) {
+        double s = 0.0;
+        for (int c = threadIdx.x; c < cols; c += 64) s += src[(long long)c * (m + 2) + l];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (threadIdx.x == 0) part[bk * (m + 2) + l] = s;
+    }
+}
 __global__ __launch_bounds__(1024) void pcl_merit_sum_kernel(const double *__restrict__ part, const double *__restrict__ weights,
                                                             double *__restrict__ out, double *__restrict__ phik, int batch, int K, int m,
                                                             int traj_mode) {

@@ -117,6 +117,9 @@ struct pcl_ctx {
     bool regs_dirty = false;
     double *dobj = nullptr;      // objective scratch: per-member values | per-knot regulariser values
     double *dphik = nullptr;     // merit scratch: per-interval partial sums
+    double *dmcols = nullptr;    // fused merit: per-column partial dot products written by fused kernel 3
+    const double *merit_lam = nullptr;  // set for the duration of pcl_eval_jac_merit_dev
+    int merit_want = 0, merit_fused = 0;
     double *dgrad = nullptr, *dval = nullptr;  // staging of the host-pointer objective call
     int64_t opt_specialize = 1;
     int64_t opt_jit = 1;      // compile shape-specialised instances on first use (hiprtc) for shapes outside the static table
@@ -126,8 +129,8 @@ struct pcl_ctx {
     int64_t last_n_stream = 0;  // stream-role workgroups of the last kernel-3 launch (0: fused roles / round-robin)
     int64_t last_kernel = 0;  // 10*version + (1 if shape-specialised) of the last fused launch
     int64_t opt_grid = 0;  // 0: resident workgroups (persistent kernel)
-    size_t lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const void *lds_kern[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // last MaxDynamicSharedMemorySize set per kernel variant
+    size_t lds_set[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const void *lds_kern[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // last MaxDynamicSharedMemorySize set per kernel variant
     int max_lds = 0;
     int n_cu = 0;
     mutable std::string err;
@@ -466,7 +469,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     if (ctx->dcomp_host) (void)hipFree(ctx->dcomp_host);
     for (hipEvent_t e : ctx->ev_chunk)
         if (e) (void)hipEventDestroy(e);
-    for (void *q : {(void *)ctx->dsub, (void *)ctx->dweights, (void *)ctx->dregs, (void *)ctx->dreg_R, (void *)ctx->dobj, (void *)ctx->dphik,
+    for (void *q : {(void *)ctx->dsub, (void *)ctx->dweights, (void *)ctx->dregs, (void *)ctx->dreg_R, (void *)ctx->dobj, (void *)ctx->dphik, (void *)ctx->dmcols,
                     (void *)ctx->dgrad, (void *)ctx->dval})
         if (q) (void)hipFree(q);
     for (void *q : {(void *)ctx->dsp_pos, (void *)ctx->dsp_coef, (void *)ctx->dsp_glv, (void *)ctx->dsp_gvals, (void *)ctx->dsp_pos_n, (void *)ctx->dsp_coef_n})
@@ -1096,23 +1099,25 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         // shape-specialised instances (compile-time d, m, chunk width; two drive entries per row):
         //   three 3-level transmons (BASELINE configs 3/4/5), two 5-level transmons, two 4-level transmons
         bool spec3 = false;
+        // pcl_eval_jac_merit_dev: the MERIT instances (built in for config 3's shape, compiled on first use for other shapes)
+        bool want_merit = ctx->merit_want && !compact && delta && ctx->win_first == 0 && ctx->win_count == ctx->desc.batch;
         if (ewr == 2 && p.ncw == 2 && ctx->opt_specialize) {
             spec3 = true;
-            if (p.d == 27 && p.m == 6) kern3 = (kern3_t)pcl_fused_kernel_v3<2, 27, 6, 2>;
-            else if (p.d == 25 && p.m == 4) kern3 = (kern3_t)pcl_fused_kernel_v3<2, 25, 4, 2>;
-            else if (p.d == 16 && p.m == 4) kern3 = (kern3_t)pcl_fused_kernel_v3<2, 16, 4, 2>;
+            if (p.d == 27 && p.m == 6) kern3 = want_merit ? (kern3_t)pcl_fused_kernel_v3<2, 27, 6, 2, true> : (kern3_t)pcl_fused_kernel_v3<2, 27, 6, 2>;
+            else if (p.d == 25 && p.m == 4 && !want_merit) kern3 = (kern3_t)pcl_fused_kernel_v3<2, 25, 4, 2>;  // (merit: compiled on first use)
+            else if (p.d == 16 && p.m == 4 && !want_merit) kern3 = (kern3_t)pcl_fused_kernel_v3<2, 16, 4, 2>;
             else spec3 = false;
         }
         hipFunction_t jitf = nullptr;  // run-time compiled instance for this context's shape
         if (!spec3 && ctx->opt_jit && ctx->opt_specialize && ewr >= 1) {
             char inst[96];
-            snprintf(inst, sizeof inst, "pcl_fused_kernel_v3<%d, %d, %d, %d>", ewr, p.d, p.m, p.ncw);
+            snprintf(inst, sizeof inst, want_merit ? "pcl_fused_kernel_v3<%d, %d, %d, %d, true>" : "pcl_fused_kernel_v3<%d, %d, %d, %d>", ewr, p.d, p.m, p.ncw);
             jitf = jit_function(ctx->device, inst);
         }
         if (!spec3 && !jitf && ctx->opt_kernel == 0) goto not_v3;  // auto never runs the run-time-shape instances
         ctx->last_kernel = jitf ? 32 : 30 + (spec3 ? 1 : 0);
         if (!jitf) {
-            int rc = set_lds_attr(ctx, (const void *)kern3, 6, lds3);
+            int rc = set_lds_attr(ctx, (const void *)kern3, (want_merit && spec3) ? 8 : 6, lds3);
             if (rc != PCL_OK) return rc;
         }
         const long long units = p.contig ? (long long)p.batch * p.K * p.d : items;  // what the grid is cut into
@@ -1123,6 +1128,13 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
             if (want > 0) p.n_stream = (int)std::min<long long>(want, g3 - 1);
         }
         ctx->last_n_stream = p.n_stream;
+        if (want_merit && (spec3 || jitf)) {
+            // pcl_eval_jac_merit_dev: the matrix waves also leave the reduce payload's dot products per state column
+            if (!ctx->dmcols) HIP_TRY(ctx, hipMalloc((void **)&ctx->dmcols, (size_t)ctx->desc.batch * p.K * p.d * (p.m + 2) * sizeof(double)));
+            p.mpart = ctx->dmcols;
+            p.mlam = ctx->merit_lam;
+            ctx->merit_fused = 1;
+        }
         if (jitf) {
             void *args[] = {(void *)&p};
             HIP_TRY(ctx, hipModuleLaunchKernel(jitf, (unsigned)g3, 1, 1, 512, 1, 1, (unsigned)lds3, ctx->stream, args, nullptr));
@@ -1904,6 +1916,33 @@ extern "C" int pcl_merit_grad_dev(pcl_ctx *ctx, const double *delta, const doubl
     HIP_TRY(ctx, hipGetLastError());
     return PCL_OK;
 }
+// fused residual + Jacobian + reduce payload: one pass over the state columns (the tails are not read back from HBM)
+extern "C" int pcl_eval_jac_merit_dev(pcl_ctx *ctx, const double *Z, const double *lam, double *delta, double *vals, double *out) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !delta || !vals || !out) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_merit_dev: NULL pointer");
+    ctx->merit_want = 1;
+    ctx->merit_fused = 0;
+    ctx->merit_lam = lam;
+    const int rc = launch_fused(ctx, Z, delta, vals, false);
+    ctx->merit_want = 0;
+    ctx->merit_lam = nullptr;
+    if (rc != PCL_OK) return rc;
+    if (!ctx->merit_fused) return pcl_merit_grad_dev(ctx, delta, lam, vals, out);  // other kernels / member windows: the separate payload kernels
+    ON_DEVICE(ctx);
+    const pcl_desc &D = ctx->desc;
+    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
+    const int sets = traj ? D.batch : 1;
+    const int m = D.n_drives;
+    if (!ctx->dphik) HIP_TRY(ctx, hipMalloc((void **)&ctx->dphik, ((size_t)D.batch * ctx->K * (m + 2) + (size_t)sets * ctx->K) * sizeof(double)));
+    double *part = ctx->dphik, *phik = ctx->dphik + (size_t)D.batch * ctx->K * (m + 2);
+    hipLaunchKernelGGL(pcl_merit_cols_kernel, dim3((unsigned)ctx->K, (unsigned)D.batch), dim3(64), 0, ctx->stream, (const double *)ctx->dmcols, part,
+                       ctx->K, ctx->cols, m);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(pcl_merit_sum_kernel, dim3((unsigned)sets), dim3(1024), 0, ctx->stream, (const double *)part,
+                       (const double *)ctx->dweights, out, phik, D.batch, ctx->K, m, traj ? 1 : 0);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCL_OK;
+}
 extern "C" int pcl_merit_grad_len(const pcl_ctx *ctx, int64_t *len, int64_t *sets) {
     if (!ctx) return PCL_EINVAL;
     if (len) *len = 1 + (int64_t)ctx->K * ctx->desc.n_drives + ctx->K;
@@ -2101,6 +2140,8 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->opt_kernel;
     else if (!strcmp(key, "last_kernel"))
         *v = ctx->last_kernel;
+    else if (!strcmp(key, "last_merit_fused"))
+        *v = ctx->merit_fused;
     else if (!strcmp(key, "contiguous"))
         *v = ctx->opt_contig;
     else if (!strcmp(key, "jit"))

@@ -285,6 +285,11 @@ class _PclContext:
         """out <- [phi | J^T lam on the shared u_k | ... on dt_k] (lam None: lam = delta, phi = the constraint merit)."""
         self._chk(self._L.pcl_merit_grad_dev(self._h, _ptr(delta), _ptr(lam), _ptr(vals), _ptr(out)))
 
+    def eval_jac_merit_dev(self, Z, lam, delta, vals, out):
+        """``eval_jac_dev`` + ``merit_grad_dev`` in one pass over the state columns (pcl_eval_jac_merit_dev): the fused kernel
+        forms the payload's dot products while a column's vectors are in LDS; same outputs as the two calls."""
+        self._chk(self._L.pcl_eval_jac_merit_dev(self._h, _ptr(Z), _ptr(lam), _ptr(delta), _ptr(vals), _ptr(out)))
+
     # -- rollout (exact piecewise-constant propagation from the knot-0 state) ----------------------------------------
     def rollout(self, Z, out=None):
         """[batch, N, x_dim] iso-vec states: X_{k+1} = exp(dt_k G(u_k)) X_k."""

@@ -1250,6 +1250,111 @@ def test_per_member_drift_fused_roles_is_race_free():
     B.close()
 
 
+@pytest.mark.parametrize("M,N", [(8, 100), (2, 7), (1, 100)])
+def test_fused_reduce_payload_equals_the_separate_kernels(M, N):
+    """pcl_eval_jac_merit_dev: the fused kernel's matrix waves form the payload's dot products per state column while the
+    column is in LDS.  delta / Jacobian values must be bit-identical to pcl_eval_jac_dev's, the payload equal to
+    pcl_merit_grad_dev's (which the oracle's dense J^T lam pins in test_ensemble_merit_and_shared_gradient_on_device)
+    to summation-order rounding, for lam = delta and for given multipliers with weights; every work split of kernel 3
+    (role split at the shipped 8-member share, round-robin slices, contiguous ranges) gives the same bits; and the payload
+    itself against the C oracle's tails (J^T lam restricted to u_k, dt_k)."""
+    import torch
+
+    osys, psys, lay, Z, traj = _config4_share(M, N)
+    B = _fused_ensemble(psys, traj)
+    c = B.ctx
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    m, K, xd, d, n = lay.m, lay.K, lay.x_dim, lay.d, 2 * lay.d
+    Zd = torch.from_numpy(traj.datavec).cuda()
+    dd, vd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda"), torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")
+    dd2, vd2 = torch.empty_like(dd), torch.empty_like(vd)
+    ln, sets = c.merit_grad_len()
+    assert sets == 1
+    rng = np.random.default_rng(11)
+    lam = torch.from_numpy(rng.standard_normal(c.n_rows)).cuda()
+    w = 1.0 + 0.25 * np.arange(M)
+    c.eval_jac_dev(Zd, dd, vd)
+    for lam_d, weights in ((None, None), (lam, w)):
+        c.set_weights(weights)
+        ref = torch.empty(ln, dtype=torch.float64, device="cuda")
+        c.merit_grad_dev(dd, lam_d, vd, ref)
+        outs = []
+        splits = ((-1, -1, 0, 0),) if M == 8 else ((-1, -1, 0, 0), (0, -1, 0, 0), (0, -1, 5, 14), (1, 0, 7, 0), (1, 3, 9, 0))
+        for contig, sw, grid, cps in splits:
+            c.set_option("contiguous", contig)
+            c.set_option("stream_workgroups", sw)
+            c.set_option("grid", grid)
+            c.set_option("cols_per_slice", cps)
+            dd2.zero_(), vd2.zero_()
+            out = torch.full((ln,), float("nan"), dtype=torch.float64, device="cuda")
+            c.eval_jac_merit_dev(Zd, lam_d, dd2, vd2, out)
+            torch.cuda.synchronize()
+            assert c.get_option("last_kernel") == 31 and c.get_option("last_merit_fused") == 1
+            assert torch.equal(dd2, dd) and torch.equal(vd2, vd)
+            outs.append(out.cpu().numpy())
+        for o in outs:
+            assert np.array_equal(o, outs[0])  # per-column partials, added in a fixed order: independent of the work split
+        r = ref.cpu().numpy()
+        scale = max(1.0, float(np.abs(r).max()))
+        assert np.abs(outs[0] - r).max() <= 1e-12 * scale, np.abs(outs[0] - r).max()
+        # ... and against the C oracle: tails of the oracle's Jacobian dotted with the multipliers
+        per_d, per_j = xd * K, po.jac_nnz_per_interval(lay) * K
+        g = np.zeros((K, m + 1))
+        phi = 0.0
+        lam_h = None if lam_d is None else lam_d.cpu().numpy()
+        for i, s in enumerate(osys):
+            d_ref, j_ref = ref_lib.eval_jac(Z, lay, s.G_drift, np.array(s.G_drives), x_off=i * xd)
+            d_ref = np.asarray(d_ref).reshape(K, d, n)
+            li = d_ref if lam_h is None else lam_h[i * per_d : (i + 1) * per_d].reshape(K, d, n)
+            tails = np.asarray(j_ref).reshape(K, -1)[:, 2 * d * n * n :].reshape(K, d, m + 1, n)
+            wi = 1.0 if weights is None else weights[i]
+            g += wi * np.einsum("kcln,kcn->kl", tails, li)
+            phi += wi * (0.5 if lam_h is None else 1.0) * float((li * d_ref).sum())
+        o = outs[0]
+        assert abs(o[0] - phi) <= 1e-12 * max(1.0, abs(phi))
+        close(o[1 : 1 + K * m].reshape(K, m), g[:, :m], 1e-11)
+        close(o[1 + K * m :], g[:, m], 1e-11)
+    c.set_weights(None)
+    # a member window is not fused: the two separate calls run, same payload layout
+    if M > 1:
+        for k_, v_ in (("contiguous", -1), ("stream_workgroups", -1), ("grid", 0), ("cols_per_slice", 0)):
+            c.set_option(k_, v_)
+    B.close()
+
+
+def test_fused_reduce_payload_other_shapes():
+    """Shapes without a built-in MERIT instance: `auto` takes another kernel and pcl_eval_jac_merit_dev runs the two separate
+    calls (same outputs); with kernel_version = 3 the MERIT instance of the shape is compiled on first use."""
+    import torch
+
+    two3 = po.multi_transmon_system([4.0, 4.1], [0.2, 0.21], [[0, 0.01], [0.01, 0]], levels_per_transmon=3, drive_bounds=0.1)  # d = 9
+    for so, N, seed, Bn in ((po.config_system(2), 9, 3, 1), (two3, 8, 4, 3)):
+        Zs = [po.synthetic_trajectory(so, N, seed=seed + 10 * i) for i in range(Bn)]
+        lay = Zs[0][1]
+        c = make_ctx(lay, so.G_drift, np.array(so.G_drives), batch=Bn, batch_mode=pa._lib.PCL_BATCH_TRAJ if Bn > 1 else pa._lib.PCL_BATCH_MEMBERS)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        Zd = torch.from_numpy(np.ascontiguousarray(np.stack([z for z, _ in Zs]))).cuda()
+        dd, vd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda"), torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")
+        dd2, vd2 = torch.empty_like(dd), torch.empty_like(vd)
+        ln, sets = c.merit_grad_len()
+        ln *= sets
+        lam = torch.from_numpy(np.random.default_rng(seed).standard_normal(c.n_rows)).cuda()
+        for kv in (0, 3):
+            c.set_option("kernel_version", kv)
+            for lam_d in (None, lam):
+                ref, out = torch.empty(ln, dtype=torch.float64, device="cuda"), torch.empty(ln, dtype=torch.float64, device="cuda")
+                c.eval_jac_dev(Zd, dd, vd)
+                c.merit_grad_dev(dd, lam_d, vd, ref)
+                c.eval_jac_merit_dev(Zd, lam_d, dd2, vd2, out)
+                torch.cuda.synchronize()
+                fused = c.get_option("last_merit_fused")
+                assert fused == (1 if c.get_option("last_kernel") == 32 else 0)
+                assert torch.equal(dd2, dd) and torch.equal(vd2, vd)
+                r, o = ref.cpu().numpy(), out.cpu().numpy()
+                assert np.abs(o - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max()))
+        c.close()
+
+
 # ---- compact-density variant (SURVEY 8(f) row 3) ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("levels,order", [(2, 4), (3, 4), (3, 8), (4, 4), (5, 6)])
 def test_density_variant(levels, order):
