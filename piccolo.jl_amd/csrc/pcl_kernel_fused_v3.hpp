@@ -752,10 +752,25 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                     }
                     const int s = lane & 15, q = lane >> 4, c = s / (m + 2), l = s - c * (m + 2);
                     double acc = 0.0;
-                    if (s < (m + 2) * ncw && c < ncc) {
-                        const double *av = l < m ? Mw + LD * (2 * ncw + l * ncw + c) : (l == m ? GSw + LD * c : G2Dw + LD * c);
-                        const double *lv = p.mlam ? Mw + LD * c : G2Dw + LD * c;
-                        for (int r = q; r < n; r += 4) acc = fma(av[r], lv[r], acc);
+                    {
+                        // every operand of a batch is requested before its first use (a rolled loop is one LDS round trip per row)
+                        const bool on = s < (m + 2) * ncw && c < ncc;
+                        const double *av = !on ? Mw : (l < m ? Mw + LD * (2 * ncw + l * ncw + c) : (l == m ? GSw + LD * c : G2Dw + LD * c));
+                        const double *lv = !on ? Mw : (p.mlam ? Mw + LD * c : G2Dw + LD * c);
+                        constexpr int JN = TD ? (2 * TD + 3) / 4 : 16, JB = (JN + 1) / 2;
+#pragma unroll
+                        for (int j0 = 0; j0 < JN; j0 += JB) {
+                            double a[JB], bq[JB];
+#pragma unroll
+                            for (int j = 0; j < JB; ++j) {
+                                const int r = q + 4 * (j0 + j);
+                                const bool ok = on && j0 + j < JN && r < n;
+                                a[j] = ok ? av[r] : 0.0;
+                                bq[j] = ok ? lv[r] : 0.0;
+                            }
+#pragma unroll
+                            for (int j = 0; j < JB; ++j) acc = fma(a[j], bq[j], acc);
+                        }
                     }
                     acc += __shfl_xor(acc, 16, 64);
                     acc += __shfl_xor(acc, 32, 64);

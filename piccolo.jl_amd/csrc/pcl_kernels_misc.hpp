@@ -171,12 +171,55 @@ __device__ __forceinline__ double block_sum_256(double v, double *red) {  // fix
     return ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+// The objective's final sums inside the infidelity launch (pcl_objective_dev): the workgroup that arrives last at an agent-scope
+// ticket (acquire-release) adds the members' terms and the knots' regulariser values in the fixed order of
+// pcl_objective_sum_kernel -- same bits, one launch less.  `out` NULL: no fused sum (pcl_infidelity_dev).
+struct PclObjSum {
+    double *out;            // value[1] (MEMBERS) or value[batch] (TRAJ)
+    const double *regval;   // [nbuf][N] per-knot regulariser values (written by the previous launch)
+    unsigned int *ticket;   // zero between launches (the last arriver resets it)
+    int batch, N, traj_mode;
+};
+__device__ __forceinline__ double wave_sum_strided_fwd(const double *__restrict__ v, int count) {
+    double s = 0.0;
+    for (int i = threadIdx.x & 63; i < count; i += 64) s += v[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    return s;  // valid in lane 0
+}
+__device__ __forceinline__ void objective_finish(const PclObjSum &fin, const double *member, double *red) {
+    if (!fin.out) return;
+    __syncthreads();  // this workgroup's member[b] (thread 0) is written
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == (unsigned)fin.batch - 1u);
+    }
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(fin.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (threadIdx.x < 64) {
+        if (fin.traj_mode) {
+            for (int b = 0; b < fin.batch; ++b) {
+                const double s = wave_sum_strided_fwd(fin.regval + (long long)b * fin.N, fin.N);
+                if (threadIdx.x == 0) fin.out[b] = __hip_atomic_load(member + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + s;
+            }
+        } else {
+            double sm = 0.0;
+            for (int i = threadIdx.x; i < fin.batch; i += 64) sm += __hip_atomic_load(member + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int off = 32; off > 0; off >>= 1) sm += __shfl_down(sm, off, 64);
+            const double sr = wave_sum_strided_fwd(fin.regval, fin.N);
+            if (threadIdx.x == 0) fin.out[0] = sm + sr;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pcl_infidelity_kernel(const double *__restrict__ Z, const double *__restrict__ goal,
                                                              const int *__restrict__ sub, int ns,
                                                              const int *__restrict__ x_offs, const double *__restrict__ weights,
                                                              double *__restrict__ value, double *__restrict__ grad,
                                                              long long grad_stride, int accumulate, double Q, int d, int N,
-                                                             int z_dim, long long z_batch_stride) {
+                                                             int z_dim, long long z_batch_stride, PclObjSum fin) {
     extern __shared__ double lds[];
     __shared__ double red[8];
     const int n = 2 * d, b = blockIdx.x, tid = threadIdx.x;
@@ -212,6 +255,7 @@ __global__ __launch_bounds__(256) void pcl_infidelity_kernel(const double *__res
                 }
             }
         }
+        objective_finish(fin, value, red);
         return;
     }
     // ---- subspace (EmbeddedOperator) fidelity: ns x ns complex blocks in LDS: Us | Ug | M | W (re, im planes) ----
@@ -270,6 +314,7 @@ __global__ __launch_bounds__(256) void pcl_infidelity_kernel(const double *__res
             g[sub[c] * n + d + sub[i]] += -sgn * Qw * di;
         }
     }
+    objective_finish(fin, value, red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -308,8 +353,19 @@ __global__ __launch_bounds__(256) void pcl_regularizer_kernel(const double *__re
         if (tid == 0) sr[r] = w;
     }
     __syncthreads();
-    if (g) {  // the gradient buffer was zeroed (memset) before this launch: only entries that carry a term are written; terms
+    if (g) {  // the knot's whole row: zeros first (no memset launch before this kernel), then the entries that carry a term; terms
               // that overlap are added in regulariser order by the same thread (a thread owns entry i of every regulariser)
+        {
+            const bool al = ((reinterpret_cast<unsigned long long>(g) & 15) == 0);
+            int i0 = 0;
+            if (al) {
+                double2_t *g2 = reinterpret_cast<double2_t *>(g);
+                for (int i = tid; i < (z_dim >> 1); i += 256) g2[i] = double2_t{0.0, 0.0};
+                i0 = z_dim & ~1;
+            }
+            for (int i = i0 + tid; i < z_dim; i += 256) g[i] = 0.0;
+        }
+        __syncthreads();
         for (int r = 0; r < n_regs; ++r) {
             const PclReg R = regs[r];
             for (int i = tid; i < R.dim; i += 256)
@@ -421,16 +477,71 @@ __global__ __launch_bounds__(512) void pcl_merit_part_kernel(const double *__res
     }
 }
 // Fused variant (pcl_eval_jac_merit_dev): the fused kernel's matrix waves leave the m + 2 dot products per state column
-// (pcol[((b*K + k)*cols + c)*(m+2) + l], formed while the column's vectors were in LDS); this adds the columns of an interval
-// in a fixed order (lane-strided, then a shuffle tree) into the same part[] layout pcl_merit_part_kernel writes.
-__global__ __launch_bounds__(64) void pcl_merit_cols_kernel(const double *__restrict__ pcol, double *__restrict__ part, int K, int cols, int m) {
-    const long long bk = (long long)blockIdx.y * K + blockIdx.x;
-    const double *src = pcol + bk * cols * (m + 2);
-    for (int l = 0; l <= m + 1; ++l) {
+// (pcol[((b*K + k)*cols + c)*(m+2) + l], formed while the column's vectors were in LDS).  ONE launch finishes the payload, every
+// sum in a fixed order (bitwise repeatable): workgroup k adds the columns of interval k per (member, l) in column order, then
+// the members with their weights in member order (same arithmetic as pcl_merit_sum_kernel) -> g_u[k,:], g_dt[k], phi_k; the
+// workgroup that arrives last at the agent-scope ticket (acquire-release) adds phi_k over the intervals.
+__global__ __launch_bounds__(256) void pcl_merit_finish_kernel(const double *__restrict__ pcol, const double *__restrict__ weights,
+                                                              double *__restrict__ out, double *__restrict__ phik, unsigned int *ticket,
+                                                              int batch, int K, int cols, int m, int traj_mode) {
+    extern __shared__ double part[];  // [batch][m + 2]
+    __shared__ int last;
+    const int k = blockIdx.x, tid = threadIdx.x, m2 = m + 2;
+    const long long set_len = 1 + (long long)K * m + K;
+    for (int e = tid; e < batch * m2; e += 256) {
+        const int b = e / m2, l = e - b * m2;
+        const double *src = pcol + ((long long)b * K + k) * cols * m2 + l;
         double s = 0.0;
-        for (int c = threadIdx.x; c < cols; c += 64) s += src[(long long)c * (m + 2) + l];
+        for (int c0 = 0; c0 < cols; c0 += 8) {  // eight columns in flight, added in column order
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = c0 + j < cols ? src[(long long)(c0 + j) * m2] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (c0 + j < cols) s += v[j];
+        }
+        part[e] = s;
+    }
+    __syncthreads();
+    if (traj_mode) {
+        for (int e = tid; e < batch * m2; e += 256) {
+            const int b = e / m2, l = e - b * m2;
+            double *o = out + (long long)b * set_len;
+            const double t = 0.0 + (weights ? weights[b] : 1.0) * part[e];
+            if (l < m)
+                o[1 + (long long)k * m + l] = t;
+            else if (l == m)
+                o[1 + (long long)K * m + k] = t;
+            else
+                __hip_atomic_store(phik + (long long)b * K + k, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (tid < m2) {
+        const int l = tid;
+        double t = 0.0;
+        for (int b = 0; b < batch; ++b) t += (weights ? weights[b] : 1.0) * part[b * m2 + l];
+        if (l < m)
+            out[1 + (long long)k * m + l] = t;
+        else if (l == m)
+            out[1 + (long long)K * m + k] = t;
+        else
+            __hip_atomic_store(phik + k, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == (unsigned)K - 1u);
+    }
+    __syncthreads();
+    if (!last) return;
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int sets = traj_mode ? batch : 1;
+    for (int set = tid >> 6; set < sets; set += 4) {  // one wave per output set: lane-strided partial sums, then a shuffle tree
+        const double *ph = phik + (long long)set * K;
+        double s = 0.0;
+        for (int i = tid & 63; i < K; i += 64) s += __hip_atomic_load(ph + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (threadIdx.x == 0) part[bk * (m + 2) + l] = s;
+        if ((tid & 63) == 0) out[(long long)set * set_len] = s;
     }
 }
 __global__ __launch_bounds__(1024) void pcl_merit_sum_kernel(const double *__restrict__ part, const double *__restrict__ weights,

@@ -118,6 +118,7 @@ struct pcl_ctx {
     double *dobj = nullptr;      // objective scratch: per-member values | per-knot regulariser values
     double *dphik = nullptr;     // merit scratch: per-interval partial sums
     double *dmcols = nullptr;    // fused merit: per-column partial dot products written by fused kernel 3
+    unsigned int *dmticket = nullptr;  // ... arrival ticket of pcl_merit_finish_kernel (zero between launches)
     const double *merit_lam = nullptr;  // set for the duration of pcl_eval_jac_merit_dev
     int merit_want = 0, merit_fused = 0;
     double *dgrad = nullptr, *dval = nullptr;  // staging of the host-pointer objective call
@@ -469,7 +470,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     if (ctx->dcomp_host) (void)hipFree(ctx->dcomp_host);
     for (hipEvent_t e : ctx->ev_chunk)
         if (e) (void)hipEventDestroy(e);
-    for (void *q : {(void *)ctx->dsub, (void *)ctx->dweights, (void *)ctx->dregs, (void *)ctx->dreg_R, (void *)ctx->dobj, (void *)ctx->dphik, (void *)ctx->dmcols,
+    for (void *q : {(void *)ctx->dsub, (void *)ctx->dweights, (void *)ctx->dregs, (void *)ctx->dreg_R, (void *)ctx->dobj, (void *)ctx->dphik, (void *)ctx->dmcols, (void *)ctx->dmticket,
                     (void *)ctx->dgrad, (void *)ctx->dval})
         if (q) (void)hipFree(q);
     for (void *q : {(void *)ctx->dsp_pos, (void *)ctx->dsp_coef, (void *)ctx->dsp_glv, (void *)ctx->dsp_gvals, (void *)ctx->dsp_pos_n, (void *)ctx->dsp_coef_n})
@@ -1829,7 +1830,7 @@ extern "C" int pcl_infidelity_dev(pcl_ctx *ctx, const double *Z, double Q, doubl
     const pcl_desc &D = ctx->desc;
     hipLaunchKernelGGL(pcl_infidelity_kernel, dim3((unsigned)D.batch), dim3(256), infidelity_lds(ctx), ctx->stream, Z, ctx->dgoal, ctx->dsub,
                        ctx->n_sub, ctx->dxoffs, ctx->dweights, value, grad, (long long)ctx->x_dim, 0, Q, D.d, D.N, D.z_dim,
-                       D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0LL);
+                       D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0LL, PclObjSum{nullptr, nullptr, nullptr, 0, 0, 0});
     HIP_TRY(ctx, hipGetLastError());
     return PCL_OK;
 }
@@ -1844,9 +1845,9 @@ extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double
     const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
     const int nbuf = traj ? D.batch : 1;
     const long long zs = traj ? (long long)D.z_dim * D.N : 0LL;
-    if (!ctx->dobj) {
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->dobj, ((size_t)D.batch + (size_t)nbuf * D.N) * sizeof(double)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->dobj, 0, ((size_t)D.batch + (size_t)nbuf * D.N) * sizeof(double), ctx->stream));
+    if (!ctx->dobj) {  // [member terms | per-knot regulariser values | arrival ticket of the fused final sum]
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->dobj, ((size_t)D.batch + (size_t)nbuf * D.N + 1) * sizeof(double)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dobj, 0, ((size_t)D.batch + (size_t)nbuf * D.N + 1) * sizeof(double), ctx->stream));
     }
     if (ctx->regs_dirty) {  // (re)upload the table; rare
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1863,20 +1864,20 @@ extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double
         ctx->regs_dirty = false;
     }
     double *member = ctx->dobj, *regval = ctx->dobj + D.batch;
-    // gradient: zeroed by a memset; the regulariser kernel writes the entries that carry a term (and the per-knot values),
-    // the infidelity kernel adds the terminal-state block
-    if (grad) HIP_TRY(ctx, hipMemsetAsync(grad, 0, (size_t)z_len(ctx) * sizeof(double), ctx->stream));
+    // Two launches: the regulariser kernel writes every knot's whole gradient row (zeros where no term applies) and the per-knot
+    // values; the infidelity kernel adds the terminal-state blocks and its last-arriving workgroup forms the final sum(s).
     hipLaunchKernelGGL(pcl_regularizer_kernel, dim3((unsigned)D.N, (unsigned)nbuf), dim3(256), 0, ctx->stream, Z, (const PclReg *)ctx->dregs,
                        (int)ctx->regs.size(), (const double *)ctx->dreg_R, grad, regval, D.N, D.z_dim, D.dt_off, zs);
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->dgoal) {
         hipLaunchKernelGGL(pcl_infidelity_kernel, dim3((unsigned)D.batch), dim3(256), infidelity_lds(ctx), ctx->stream, Z, ctx->dgoal,
                            ctx->dsub, ctx->n_sub, ctx->dxoffs, ctx->dweights, member, grad, traj ? (long long)D.z_dim * D.N : 0LL, 1, Q, D.d,
-                           D.N, D.z_dim, zs);
+                           D.N, D.z_dim, zs,
+                           PclObjSum{value, regval, reinterpret_cast<unsigned int *>(ctx->dobj + D.batch + (size_t)nbuf * D.N), D.batch, D.N, traj ? 1 : 0});
         HIP_TRY(ctx, hipGetLastError());
-    } else {
-        HIP_TRY(ctx, hipMemsetAsync(member, 0, (size_t)D.batch * sizeof(double), ctx->stream));
+        return PCL_OK;
     }
+    HIP_TRY(ctx, hipMemsetAsync(member, 0, (size_t)D.batch * sizeof(double), ctx->stream));  // regularisers only
     hipLaunchKernelGGL(pcl_objective_sum_kernel, dim3(traj ? (unsigned)D.batch : 1u), dim3(64), 0, ctx->stream, (const double *)member, (const double *)regval, value,
                        D.batch, D.N, traj ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
@@ -1934,12 +1935,15 @@ extern "C" int pcl_eval_jac_merit_dev(pcl_ctx *ctx, const double *Z, const doubl
     const int sets = traj ? D.batch : 1;
     const int m = D.n_drives;
     if (!ctx->dphik) HIP_TRY(ctx, hipMalloc((void **)&ctx->dphik, ((size_t)D.batch * ctx->K * (m + 2) + (size_t)sets * ctx->K) * sizeof(double)));
-    double *part = ctx->dphik, *phik = ctx->dphik + (size_t)D.batch * ctx->K * (m + 2);
-    hipLaunchKernelGGL(pcl_merit_cols_kernel, dim3((unsigned)ctx->K, (unsigned)D.batch), dim3(64), 0, ctx->stream, (const double *)ctx->dmcols, part,
-                       ctx->K, ctx->cols, m);
-    HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(pcl_merit_sum_kernel, dim3((unsigned)sets), dim3(1024), 0, ctx->stream, (const double *)part,
-                       (const double *)ctx->dweights, out, phik, D.batch, ctx->K, m, traj ? 1 : 0);
+    double *phik = ctx->dphik + (size_t)D.batch * ctx->K * (m + 2);
+    if (!ctx->dmticket) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->dmticket, 64));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dmticket, 0, 64, ctx->stream));
+    }
+    // ONE launch: a workgroup per interval adds the columns, then the members (weights, member order); the workgroup that
+    // arrives last adds phi over the intervals
+    hipLaunchKernelGGL(pcl_merit_finish_kernel, dim3((unsigned)ctx->K), dim3(256), (size_t)D.batch * (m + 2) * sizeof(double), ctx->stream,
+                       (const double *)ctx->dmcols, (const double *)ctx->dweights, out, phik, ctx->dmticket, D.batch, ctx->K, ctx->cols, m, traj ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
     return PCL_OK;
 }
