@@ -600,7 +600,34 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                 PCL_STAMP();  // S, D loaded
                 const double *Dm = Mw + LD * ncw;
                 if (lane < n) {
-                    if (EW > 0) {
+                    if (EW > 0 && TNCW > 0) {
+                        // Gathers and results live in the same LDS array: written as load -> multiply -> store per (l, c) the
+                        // compiler must wait for every store before the next gather (it cannot prove they do not alias) -- one
+                        // LDS round trip per entry.  Three drives' gathers are requested together, then their results stored.
+                        constexpr int NCW = TNCW > 0 ? TNCW : 1, EWn = EW > 0 ? EW : 1;
+#pragma unroll
+                        for (int l0 = 0; l0 < PCL_MREG; l0 += 3) {
+                            double dv[3][NCW][EWn];
+#pragma unroll
+                            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                                for (int c = 0; c < NCW; ++c)
+#pragma unroll
+                                    for (int q = 0; q < EWn; ++q) dv[j][c][q] = (l0 + j < m) ? Dm[er_c[(l0 + j) % PCL_MREG][q] + LD * c] : 0.0;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j)
+                                if (l0 + j < m) {
+                                    const int l = (l0 + j) % PCL_MREG;
+#pragma unroll
+                                    for (int c = 0; c < NCW; ++c) {
+                                        double acc = 0.0;
+#pragma unroll
+                                        for (int q = 0; q < EWn; ++q) acc = __builtin_fma(er_v[l][q], dv[j][c][q], acc);
+                                        Mw[lane + LD * (2 * ncw + l * ncw + c)] = acc;
+                                    }
+                                }
+                        }
+                    } else if (EW > 0) {
 #pragma unroll
                         for (int l = 0; l < PCL_MREG; ++l)
                             if (l < m)
@@ -625,6 +652,33 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                     }
                     PCL_STAMP();  // G_l D done
                     // G2D = G^2 D on the VALU, 6 independent partial sums per column
+                    if (TNCW > 0) {
+                        // all columns of the chunk in one sweep over G^2's row: every G^2 entry is read once (not once per column) and
+                        // the operand column entries as neighbouring pairs; per column the same partial sums in the same order
+                        constexpr int NCW = TNCW > 0 ? TNCW : 1;
+                        double sa[6][NCW];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j)
+#pragma unroll
+                            for (int c = 0; c < NCW; ++c) sa[j][c] = 0.0;
+                        int kk = 0;
+#pragma unroll 3
+                        for (; kk + 6 <= n; kk += 6) {
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) {
+                                const double g = G2[lane + LD * (kk + j)];
+#pragma unroll
+                                for (int c = 0; c < NCW; ++c) sa[j][c] = fma(g, Dm[kk + j + LD * c], sa[j][c]);
+                            }
+                        }
+                        for (; kk < n; ++kk) {
+                            const double g = G2[lane + LD * kk];
+#pragma unroll
+                            for (int c = 0; c < NCW; ++c) sa[0][c] = fma(g, Dm[kk + LD * c], sa[0][c]);
+                        }
+#pragma unroll
+                        for (int c = 0; c < NCW; ++c) G2Dw[lane + LD * c] = ((sa[0][c] + sa[1][c]) + (sa[2][c] + sa[3][c])) + (sa[4][c] + sa[5][c]);
+                    } else
                     for (int c = 0; c < ncw; ++c) {
                         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0;
                         int kk = 0;
@@ -700,7 +754,56 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                 PCL_STAMP();  // MFMA + accumulators -> LDS done
                 // ---- outputs: finish in LDS (lane = row, in place), then 16-byte stores --------------------------------
                 // in place: delta -> D column, d/ddt -> GS column, d/du_l -> the G (G_l D) column
-                if (lane < n) {
+                if (EW > 0 && TNCW > 0) {
+                    // Same values as the general form below, with every LDS read of a step requested before its first store (see
+                    // the G_l D step above): Y = -c1 S + c2 G D takes the place of S, then d/du_l = G_l Y + c2 G (G_l D).
+                    constexpr int NCW = TNCW > 0 ? TNCW : 1, EWn = EW > 0 ? EW : 1;
+                    if (lane < n) {
+                        double gs[NCW], g2d[NCW], dd[NCW], ss[NCW], gd[NCW];
+#pragma unroll
+                        for (int c = 0; c < NCW; ++c) {
+                            gs[c] = GSw[lane + LD * c];
+                            g2d[c] = G2Dw[lane + LD * c];
+                            dd[c] = Mw[lane + LD * (ncw + c)];
+                            ss[c] = Mw[lane + LD * c];
+                            gd[c] = GDw[lane + LD * c];
+                        }
+#pragma unroll
+                        for (int c = 0; c < NCW; ++c) {
+                            G2Dw[lane + LD * c] = dd[c] - c1 * gs[c] + c2 * g2d[c];  // delta
+                            GSw[lane + LD * c] = -0.5 * gs[c] + h6 * g2d[c];        // d/ddt
+                            Mw[lane + LD * c] = __builtin_fma(c2, gd[c], -(c1 * ss[c]));  // Y (S is dead from here on)
+                        }
+                    }
+                    wave_lds_sync();
+                    if (lane < n) {
+#pragma unroll
+                        for (int l0 = 0; l0 < PCL_MREG; l0 += 3) {
+                            double yv[3][NCW][EWn], gv[3][NCW];
+#pragma unroll
+                            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                                for (int c = 0; c < NCW; ++c) {
+                                    const int l = (l0 + j) % PCL_MREG;
+#pragma unroll
+                                    for (int q = 0; q < EWn; ++q) yv[j][c][q] = (l0 + j < m) ? Mw[er_c[l][q] + LD * c] : 0.0;
+                                    gv[j][c] = (l0 + j < m) ? Mw[lane + LD * (2 * ncw + l * ncw + c)] : 0.0;
+                                }
+#pragma unroll
+                            for (int j = 0; j < 3; ++j)
+                                if (l0 + j < m) {
+                                    const int l = (l0 + j) % PCL_MREG;
+#pragma unroll
+                                    for (int c = 0; c < NCW; ++c) {
+                                        double acc = 0.0;
+#pragma unroll
+                                        for (int q = 0; q < EWn; ++q) acc = __builtin_fma(er_v[l][q], yv[j][c][q], acc);
+                                        Mw[lane + LD * (2 * ncw + l * ncw + c)] = __builtin_fma(c2, gv[j][c], acc);
+                                    }
+                                }
+                        }
+                    }
+                } else if (lane < n) {
                     for (int c = 0; c < ncw; ++c) {
                         const double gs = GSw[lane + LD * c], g2d = G2Dw[lane + LD * c];
                         G2Dw[lane + LD * c] = Mw[lane + LD * (ncw + c)] - c1 * gs + c2 * g2d;  // delta
