@@ -898,6 +898,9 @@ __global__ __launch_bounds__(512, 2) void pcl_fused_kernel_v3(const KParams p) {
                 wave_lds_sync();  // the chunk buffers are rewritten by this wave's next chunk
                 PCL_STAMP();  // outputs issued
             }
+#ifdef PCL_PROFILE
+            if (p.dbg && blockIdx.x == 0 && lane == 0 && it == 1) p.dbg[52 + wave] = (long long)__builtin_amdgcn_s_memtime();  // this wave's chunks done
+#endif
             // ---- next item's G(u), G^2 into the other buffer ----------------------------------------------------
             if (matrix_role) __syncthreads();  // single-buffered G, G^2: every wave is done with this item's tiles
             if (alive(it + 1) && wave < 4) build(it + 1, matrix_role ? 0 : cur ^ 1, pf_u);

@@ -28,6 +28,8 @@ try:
     wg = wg[wg[:, 0] > 0]
     w0 = wg[:, 0].min()
     print("last_kernel", c.get_option("last_kernel"), "workgroups", len(wg), "start max %.1f us | end min %.1f max %.1f us (100 MHz clock)" % ((wg[:, 0].max() - w0) / 100.0, (wg[:, 1].min() - w0) / 100.0, (wg[:, 1].max() - w0) / 100.0))
+    w = np.array(out[52:60])
+    print("chunks done per wave (cycles after wave 0's item top):", (w - out[0]).tolist())
     t = np.array(out[:40]); t = t[t > 0]
     print("stamps (s_memtime, 100 MHz ticks) deltas:", np.diff(t).tolist(), "total", int(t[-1] - t[0]))
     ms.close()
