@@ -230,6 +230,6 @@ def test_pattern_compiled_kernel_source(lib, tmp_path):
                         "--cuda-device-only", "-o", str(out), str(f)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     asm = out.read_text()
-    assert "pcl_hess_sparse_kernel" in asm and "pcl_sparse_values_kernel" in asm and "pcl_eval_sparse_kernel" in asm
+    assert "pcl_hess_sparse_kernel" in asm and "pcl_sparse_values_kernel" in asm and "pcl_eval_sparse_kernel" in asm and "pcl_jac_sparse_kernel" in asm
     scratch = [int(x) for x in re.findall(r"; ScratchSize: (\d+)", asm)]
     assert max(scratch) <= 256  # a few loop-invariant integers, not operand arrays
