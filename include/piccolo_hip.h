@@ -263,9 +263,11 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *       "use_mfma" (1/0: plain-VALU products in kernel 1), "nt_stores" (streaming stores of the Jacobian blocks: -1 auto by launch size | 0 plain | 1 nontemporal | 2 write-through), "specialize" (1/0: shape-specialised
  *       instances), "grid" (workgroups, 0 = one per CU), "host_threads" (host-pointer entry points: threads that expand the
  *       compact values into the caller's array, 0 = auto), "host_path" (0 auto | 1 full values over PCIe | 2 compact + host expansion),
+ *       "column_kernel" (fused residual + Jacobian, the column work: 1 kernel 3's matrix role, default | 2 EXPERIMENTAL pattern-compiled
+ *       column kernel + kernel 3 with every workgroup streaming: same values, not faster yet; needs sparse iso generators, contiguous ranges),
  *       "debug_timing" (PCL_ENOTIMPL unless the library was built with -DPCL_PROFILE)
- * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised; 60 / 61 matrix-core residual kernel, 70 pattern-compiled residual kernel; 90 + q for the
- *       general-order kernel in the reference formulation, 190 + q for the lock-step general-order kernel), "last_stream_workgroups", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3 static / compiled | 6: pattern-compiled | 90 + q), "jit_compiles", "n_cu", "iso_structured", "drives_antisymmetric",
+ * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised; 33 pattern-compiled columns + stream-only kernel 3; 60 / 61 matrix-core residual kernel, 70 pattern-compiled residual kernel; 90 + q for the
+ *       general-order kernel in the reference formulation, 190 + q for the lock-step general-order kernel), "last_stream_workgroups", "last_merit_fused", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3 static / compiled | 6: pattern-compiled | 90 + q), "jit_compiles", "n_cu", "iso_structured", "drives_antisymmetric",
  *       "ell_width", "ell_width_t", "union_width", "occupancy_v2".  Unknown keys return PCL_EINVAL. */
 int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t value);
 int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *value);
