@@ -57,11 +57,15 @@ def time_steps(launch, steps, warmup, torch, dist):
     gc.disable()  # (before the warmup: the collection takes tens of ms, the GPU would idle and clock down right before the timed region)
     for _ in range(warmup):
         launch()
+    # torch creates the underlying hipEvent at an event's FIRST record: recorded once here, the two events exist before the timed
+    # region (created inside it they cost 1-2 us per step of a 20-step region: scripts/probes/bench_fixed_latency.py)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    ev1.record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for _ in range(steps):
