@@ -279,6 +279,12 @@ int pcl_debug_timing(pcl_ctx *ctx, int64_t *out, int64_t cap);
  * pattern-compiled kernels of a system with Hilbert dimension d <= 32 and m <= 6 drives whose generators are exact iso(.)
  * images (G0: n*n column-major, Gj: m such blocks).  *needed = bytes including the terminator; buf may be NULL. */
 int pcl_codegen_source(int d, int m, const double *G0, const double *Gj, char *buf, int64_t cap, int64_t *needed);
+/* The same for the pattern-compiled FUSED residual + Jacobian kernel (kernel_version 4) at diagonal Pade order 2q, q = 1..5
+ * (n_g0 drifts G0[b] span the union pattern: an ensemble's members); PCL_ESHAPE when the drives need more resident
+ * coefficients than the kernel keeps.  pcl_codegen_apply_v4 applies the generator's term tables on the host to one column:
+ * y = (G0[0] + sum_l u_l G_l) x, x and y of length n = 2d -- what the generated product computes, checkable without a GPU. */
+int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, const double *Gj, int q, char *buf, int64_t cap, int64_t *needed);
+int pcl_codegen_apply_v4(int d, int m, const double *G0, int n_g0, const double *Gj, const double *u, const double *x, double *y);
 
 #ifdef __cplusplus
 }

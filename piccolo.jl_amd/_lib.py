@@ -34,6 +34,7 @@ EXPORTS = [
     "pcl_rollout", "pcl_rollout_dev",
     "pcl_comm_get_unique_id", "pcl_comm_init", "pcl_reduce_sum_dev", "pcl_reduce_sum", "pcl_comm_destroy",
     "pcl_set_option", "pcl_get_option", "pcl_debug_timing", "pcl_codegen_source",
+    "pcl_codegen_source_v4", "pcl_codegen_apply_v4",
 ]  # fmt: skip
 
 
@@ -186,5 +187,7 @@ def load():
     L.pcl_get_option.argtypes = [vp, ctypes.c_char_p, c_i64p]
     L.pcl_debug_timing.argtypes = [vp, c_i64p, ctypes.c_int64]
     L.pcl_codegen_source.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int64, c_i64p]
+    L.pcl_codegen_source_v4.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, c_i64p]
+    L.pcl_codegen_apply_v4.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp]
     _lib = L
     return L

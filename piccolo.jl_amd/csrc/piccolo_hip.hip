@@ -25,6 +25,7 @@
 
 #include "piccolo_hip.h"
 #include "pcl_codegen.hpp"
+#include "pcl_codegen_v4.hpp"
 
 #define PCL_VERSION_STR "piccolo_hip 0.2.0 (gfx950, pade 2/4/6/8/10)"
 
@@ -93,6 +94,11 @@ struct pcl_ctx {
     hipFunction_t sp_fval = nullptr, sp_fhess = nullptr, sp_feval = nullptr;  // compiled on first use, kept for the context's lifetime
     int *dsp_pos_n = nullptr;       // the same tables in the emission order of the residual kernel's products
     double *dsp_coef_n = nullptr;
+    // pattern-compiled FUSED residual + Jacobian kernel (pcl_codegen_v4.hpp, any Pade order): plan, drift tables, magnitudes
+    pcl_codegen::V4Plan *v4_plan = nullptr;
+    double *dv4_tab = nullptr, *dv4_mags = nullptr;
+    hipFunction_t v4_f = nullptr;
+    int v4_failed = 0;
     int64_t opt_eval_kernel = 0;    // 0 auto | 1 matrix-core residual kernel | 2 pattern-compiled
     int64_t opt_column_kernel = 1;  // fused residual + Jacobian, column work: 1 matrix cores (kernel 3's matrix role; default) | 2 pattern-compiled column kernel + stream-only kernel 3 (experimental: correct, not faster yet -- DESIGN 4.8)
     // staging for the host-pointer entry points
@@ -414,6 +420,11 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
         pcl_codegen::SpPlan plan = pcl_codegen::make_plan(d, m, dsc->G0, dsc->per_member_G0 ? dsc->batch : 1, dsc->Gj);
         if (plan.ok && plan.nz <= 640 && (double)plan.nz <= 0.45 * 2.0 * d * d) ctx->sp_plan = new pcl_codegen::SpPlan(std::move(plan));
     }
+    if (ctx->sp_plan) {  // the fused kernel of the same family: one LDS tile per chain (m + 7 tiles of d (n + 1) doubles)
+        pcl_codegen::V4Plan v4 = pcl_codegen::make_v4_plan(d, m, dsc->G0, dsc->per_member_G0 ? dsc->batch : 1, dsc->Gj);
+        const size_t lds4 = ((size_t)(m + 7) * d * (n + 1) + 16) * sizeof(double);
+        if (v4.ok && lds4 <= (size_t)ctx->max_lds) ctx->v4_plan = new pcl_codegen::V4Plan(std::move(v4));
+    }
     std::vector<double> g0(dsc->G0, dsc->G0 + nn * (dsc->per_member_G0 ? dsc->batch : 1));
     CREATE_TRY(upload(ctx, &ctx->dG0, g0));
     CREATE_TRY(upload(ctx, &ctx->dupos, upos));
@@ -448,6 +459,17 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
         CREATE_TRY(upload(ctx, &ctx->dsp_pos_n, sp.pos_n));
         CREATE_TRY(upload(ctx, &ctx->dsp_coef_n, sp.coef_n));
     }
+    if (ctx->v4_plan) {
+        const pcl_codegen::V4Plan &v4 = *ctx->v4_plan;
+        const int nb = dsc->per_member_G0 ? dsc->batch : 1;
+        std::vector<double> tab((size_t)nb * v4.n_drift_pad, 0.0);
+        for (int bb = 0; bb < nb; ++bb)
+            for (size_t q = 0; q < v4.drift_pos.size(); ++q) tab[(size_t)bb * v4.n_drift_pad + q] = dsc->G0[(size_t)bb * nn + v4.drift_pos[q]];
+        std::vector<double> mg(v4.mags);
+        mg.resize(std::max<size_t>(mg.size(), 1) + 16, 0.0);
+        CREATE_TRY(upload(ctx, &ctx->dv4_tab, tab));
+        CREATE_TRY(upload(ctx, &ctx->dv4_mags, mg));
+    }
 #undef CREATE_TRY
 #undef CREATE_HIP
     *out = ctx;
@@ -479,6 +501,9 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     for (void *q : {(void *)ctx->dsp_pos, (void *)ctx->dsp_coef, (void *)ctx->dsp_glv, (void *)ctx->dsp_gvals, (void *)ctx->dsp_pos_n, (void *)ctx->dsp_coef_n})
         if (q) (void)hipFree(q);
     delete ctx->sp_plan;
+    for (void *q : {(void *)ctx->dv4_tab, (void *)ctx->dv4_mags})
+        if (q) (void)hipFree(q);
+    delete ctx->v4_plan;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -702,8 +727,9 @@ hipFunction_t jit_compile(int device, const std::string &key_, const std::string
     const size_t slash = dir.find_last_of('/');
     dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
     const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp",
-                           "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp", "pcl_kernel_eval_sparse.hpp", "pcl_kernel_jac_sparse.hpp"};
-    constexpr int NH = 8;
+                           "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp", "pcl_kernel_eval_sparse.hpp", "pcl_kernel_jac_sparse.hpp",
+                           "pcl_kernel_fused_sparse.hpp"};
+    constexpr int NH = 9;
     std::string hdr[NH];
     const char *hdrp[NH];
     for (int i = 0; i < NH; ++i) {
@@ -763,7 +789,34 @@ std::string sparse_source(const pcl_codegen::SpPlan &plan, bool with_columns = f
     return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::apply_functions(plan) + "#include \"pcl_kernel_hessian_sparse.hpp\"\n#include \"pcl_kernel_eval_sparse.hpp\"\n" +
            (with_columns ? "#include \"pcl_kernel_jac_sparse.hpp\"\n" : "");
 }
+// Source of the pattern-compiled fused residual + Jacobian kernel of one system at Pade order 2q (pcl_codegen_v4.hpp)
+std::string v4_source(const pcl_codegen::V4Plan &plan, int q) {
+    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q) + "#include \"pcl_kernel_fused_sparse.hpp\"\n";
+}
 }  // namespace
+
+// Inspection hooks of the fused pattern-compiled kernel (no device needed): its generated source, and the generator's term
+// tables applied on the host to one column (y = G(u) x; n_g0 drifts span the union pattern, the first one is applied).
+extern "C" int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, const double *Gj, int q, char *buf, int64_t cap, int64_t *needed) {
+    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || !G0 || (m > 0 && !Gj) || !needed) return PCL_EINVAL;
+    const pcl_codegen::V4Plan plan = pcl_codegen::make_v4_plan(d, m, G0, n_g0, Gj);
+    if (!plan.ok) return PCL_ESHAPE;
+    const std::string src = v4_source(plan, q);
+    *needed = (int64_t)src.size() + 1;
+    if (buf && cap > 0) {
+        const size_t nb = std::min<size_t>((size_t)cap - 1, src.size());
+        memcpy(buf, src.data(), nb);
+        buf[nb] = '\0';
+    }
+    return PCL_OK;
+}
+extern "C" int pcl_codegen_apply_v4(int d, int m, const double *G0, int n_g0, const double *Gj, const double *u, const double *x, double *y) {
+    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || !G0 || (m > 0 && (!Gj || !u)) || !x || !y) return PCL_EINVAL;
+    const pcl_codegen::V4Plan plan = pcl_codegen::make_v4_plan(d, m, G0, n_g0, Gj);
+    if (!plan.ok) return PCL_ESHAPE;
+    pcl_codegen::v4_reference_apply(plan, G0, Gj, u, x, y);
+    return PCL_OK;
+}
 
 // Inspection hook: the generated source of the pattern-compiled kernels for a system (needs no device).
 extern "C" int pcl_codegen_source(int d, int m, const double *G0, const double *Gj, char *buf, int64_t cap, int64_t *needed) {
@@ -1011,12 +1064,63 @@ static int launch_pade_v2(pcl_ctx *ctx, KParams &p) {
     return PCL_OK;
 }
 
-static int launch_pade_general(pcl_ctx *ctx, KParams &p, bool want_jac) {
-    p.q = ctx->desc.pade_order / 2;
+// diagonal Pade coefficients of exp at order 2q: c_j = (2q - j)! q! / ((2q)! j! (q - j)!)
+static void fill_pade(KParams &p, int order) {
+    p.q = order / 2;
     double f[16];
     f[0] = 1.0;
     for (int i = 1; i < 16; ++i) f[i] = f[i - 1] * i;
     for (int j = 0; j <= p.q; ++j) p.pc[j] = f[2 * p.q - j] * f[p.q] / (f[2 * p.q] * f[j] * f[p.q - j]);
+}
+
+// Pattern-compiled fused residual + Jacobian kernel (pcl_kernel_fused_sparse.hpp; any Pade order): sparse exact-iso generators of
+// a unitary problem whose m + 7 chain tiles fit LDS.  PCL_ENOTIMPL (no error text): not taken, the caller goes on to the others.
+static bool v4_available(const pcl_ctx *ctx) {
+    return ctx->v4_plan && !ctx->v4_failed && ctx->opt_jit && !ctx->vec && ctx->cols == ctx->desc.d;
+}
+static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact) {
+    if (!v4_available(ctx) || !p.jac) return PCL_ENOTIMPL;
+    const pcl_codegen::V4Plan &v4 = *ctx->v4_plan;
+    fill_pade(p, ctx->desc.pade_order);
+    if (!ctx->v4_f) {
+        const std::string src = v4_source(v4, p.q);
+        const std::string key = "fused-sparse:" + std::to_string(p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
+        ctx->v4_f = jit_compile(ctx->device, key, src, "pcl_fused_sparse_kernel", true);
+        if (!ctx->v4_f) {
+            ctx->v4_failed = 1;
+            return PCL_ENOTIMPL;
+        }
+    }
+    const int d = p.d, m = p.m;
+    const long long bk = (long long)p.batch * p.K, ncu = std::max(ctx->n_cu, 1);
+    // contiguous column ranges once every CU has about an interval's worth of columns; below that round-robin slices of the
+    // intervals (an explicit cols_per_slice or contiguous = 0 / 1 decides otherwise)
+    p.contig = ctx->opt_cols_per_slice > 0 ? 0 : (ctx->opt_contig >= 0 ? (int)ctx->opt_contig : (compact || bk * d >= 28 * ncu ? 1 : 0));
+    if (p.contig)
+        p.nc = d;
+    else if (ctx->opt_cols_per_slice > 0)
+        p.nc = (int)std::min<int64_t>(ctx->opt_cols_per_slice, d);
+    else {
+        const long long S = std::max<long long>(1, std::min<long long>(d, ncu / std::max<long long>(bk, 1)));
+        p.nc = (int)((d + S - 1) / S);
+    }
+    p.S = (d + p.nc - 1) / p.nc;
+    p.all_matrix = 0;
+    p.n_stream = 0;
+    const long long units = p.contig ? bk * d : bk * p.S;
+    if (units > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+    const long long g = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, units) : std::min<long long>(units, ncu);
+    const size_t lds = ((size_t)(m + 7) * d * (p.n + 1) + 16) * sizeof(double);
+    const double *tab = ctx->dv4_tab + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_drift_pad : 0);
+    void *args[] = {(void *)&p, (void *)&tab, (void *)&ctx->dv4_mags};
+    HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_f, (unsigned)g, 1, 1, 64 * (m + 8), 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
+    ctx->last_kernel = 40 + p.q;
+    ctx->last_n_stream = 0;
+    return PCL_OK;
+}
+
+static int launch_pade_general(pcl_ctx *ctx, KParams &p, bool want_jac) {
+    fill_pade(p, ctx->desc.pade_order);
     if (want_jac && ctx->opt_general_version != 1) {
         const int rc = launch_pade_v2(ctx, p);
         if (rc != PCL_ENOTIMPL) return rc;
@@ -1077,6 +1181,13 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     // streaming stores of the Jacobian blocks (auto): write-through while the launch's values fit the infinity cache with room to
     // spare (one trajectory of config 3: 133 MB), plain write-back above (see store2)
     if (ctx->opt_nt < 0 && want_jac && !compact && (long long)ctx->win_count * ctx->K * jac_per_full(ctx) * 8 <= (192LL << 20)) p.nt = 2;
+    // kernel_version 4: the pattern-compiled fused kernel (sparse iso generators, any order)
+    if (want_jac && ctx->opt_kernel == 4) {
+        const bool want_merit = ctx->merit_want && !compact && delta && ctx->win_first == 0 && ctx->win_count == ctx->desc.batch;
+        const int rc = want_merit ? PCL_ENOTIMPL : launch_fused_v4(ctx, p, compact);
+        if (rc != PCL_ENOTIMPL) return rc;
+        if (!want_merit) return fail(ctx, PCL_ESHAPE, "kernel_version=4 needs sparse exact-iso generators of a unitary problem (9 <= d, tiles within LDS), 1..6 drives and jit=1 (%s)", g_jit_note.c_str());
+    }
     if (ctx->desc.pade_order != 4 || ctx->opt_general || ctx->vec) return launch_pade_general(ctx, p, want_jac);
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
     // auto: kernel 3 where its shape-specialised instance applies (BASELINE configs 3/4/5); its run-time-shape instances
@@ -1204,7 +1315,7 @@ not_v3:
     // residual only (what the solver calls in every line-search trial), sparse iso generators: the pattern-compiled kernel
     // (auto: launches with more intervals than CUs -- below that one wave per interval is a longer chain than the matrix-core kernel's)
     if (!want_jac && (ctx->opt_eval_kernel == 2 || (ctx->opt_eval_kernel == 0 && (long long)p.batch * p.K > ctx->n_cu)) && ctx->sp_plan && !ctx->sp_failed && ctx->opt_jit &&
-        (ctx->opt_kernel == 0 || ctx->opt_kernel == 3)) {
+        (ctx->opt_kernel == 0 || ctx->opt_kernel >= 3)) {
         const pcl_codegen::SpPlan &sp = *ctx->sp_plan;
         const long long items = (long long)p.batch * p.K;
         if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
@@ -1240,7 +1351,7 @@ not_v3:
         return fail(ctx, PCL_ESHAPE, "eval_kernel=2 needs sparse iso generators, a unitary problem with 9 <= d <= 32, 1..6 drives and jit=1");
     }
     // residual only, any generators: the dedicated matrix-core kernel for unitary states
-    if (!want_jac && ctx->opt_use_mfma != 0 && !ctx->vec && ctx->cols == ctx->desc.d && ctx->desc.d >= 9 && (ctx->opt_kernel == 0 || ctx->opt_kernel == 3)) {
+    if (!want_jac && ctx->opt_use_mfma != 0 && !ctx->vec && ctx->cols == ctx->desc.d && ctx->desc.d >= 9 && (ctx->opt_kernel == 0 || ctx->opt_kernel >= 3)) {
         typedef void (*kerne_t)(const KParams);
         const int wu = (ctx->uell_w <= 2 && ctx->n_upos <= 256 * PCL_NUE_EV) ? ctx->uell_w : -1;
         const bool spec = ctx->opt_specialize && p.d == 27;
@@ -2164,7 +2275,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         }
     }
     else if (!strcmp(key, "kernel_version")) {
-        if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "kernel_version must be 0 (auto), 1, 2 or 3");
+        if (v < 0 || v > 4) return fail(ctx, PCL_EINVAL, "kernel_version must be 0 (auto), 1, 2, 3 or 4");
         ctx->opt_kernel = v;
     }
     else

@@ -80,33 +80,64 @@ class Objective:
     def __init__(self, terms):
         self.terms = list(terms)
         self._ctx = None
+        self._bound = []
         self._Q = 0.0
 
     def __add__(self, other):
         return Objective(self.terms + _terms(other))
 
     def bind(self, B):
-        """Attach to the context of integrator ``B`` (a single integrator, a fused ensemble integrator, or any member of
-        an integrator list -- its shared batched context is used)."""
-        B = B[0] if isinstance(B, (list, tuple)) else B
-        ctx = B.ensemble.ctx if hasattr(B, "ensemble") else B.ctx
+        """Attach to the context(s) of integrator ``B``: a single integrator, or the integrator list of an ensemble.
+
+        A list whose members share ONE batched context (per-member drifts only) binds that context: the weighted
+        SamplingProblem sum is formed on the device.  A list of independent contexts (members that differ in their drive
+        generators too) binds every member's context with its own weight and sums on the host; the regularisers -- terms
+        of the shared controls -- are registered once, on the first member."""
+        members = list(B) if isinstance(B, (list, tuple)) else [B]
         inf = [t for t in self.terms if isinstance(t, UnitaryInfidelityObjective)]
         if len(inf) > 1:
             raise NotImplementedError("one terminal infidelity term per problem")
-        ctx.clear_regularizers()
-        for t in self.terms:
-            if isinstance(t, QuadraticRegularizer):
-                ctx.add_regularizer(t.off, t.dim, t.R, t.dt_power)
-        self._Q = 0.0
+        cores = {id(b.ensemble) for b in members if hasattr(b, "ensemble")}
+        shared = len(cores) == 1 and all(hasattr(b, "ensemble") for b in members)
+        if len(members) > 1 and not shared and any(hasattr(b, "ensemble") for b in members):
+            raise ValueError("the integrator list mixes members of different ensembles")
+        if shared:
+            core = members[0].ensemble
+            if len(members) != core.M:
+                raise ValueError("%d integrators of an ensemble of %d members" % (len(members), core.M))
+            ctxs = [core.ctx]
+        else:
+            ctxs = [b.ctx for b in members]
         if inf:
             t = inf[0]
-            if isinstance(t.goal, EmbeddedOperator):
-                ctx.set_goal_subspace(operator_to_iso_vec(t.goal.unembed()), t.goal.subspace)
-            else:
-                ctx.set_goal(operator_to_iso_vec(np.asarray(t.goal, dtype=complex)))
-            ctx.set_weights(t.weights)
-            self._Q = t.Q
-        self._ctx = ctx
+            have = [nm for b in members for nm in (b.x_names if not hasattr(b, "ensemble") else [b.x_name])]
+            if list(t.names) != have:
+                raise ValueError("the infidelity term names the states %r, the integrators evaluate %r" % (list(t.names), have))
+            if t.weights is not None and t.weights.size != len(have):
+                raise ValueError("expected %d weights, got %d" % (len(have), t.weights.size))
+        self._bound = []
+        self._Q = 0.0
+        for i, ctx in enumerate(ctxs):
+            ctx.clear_regularizers()
+            if i == 0:
+                for t in self.terms:
+                    if isinstance(t, QuadraticRegularizer):
+                        ctx.add_regularizer(t.off, t.dim, t.R, t.dt_power)
+            w_host = 1.0
+            if inf:
+                t = inf[0]
+                if isinstance(t.goal, EmbeddedOperator):
+                    ctx.set_goal_subspace(operator_to_iso_vec(t.goal.unembed()), t.goal.subspace)
+                else:
+                    ctx.set_goal(operator_to_iso_vec(np.asarray(t.goal, dtype=complex)))
+                if len(ctxs) == 1:
+                    ctx.set_weights(t.weights)
+                else:  # one member per context: its weight multiplies the member's infidelity on the host
+                    ctx.set_weights(None)
+                    w_host = 1.0 if t.weights is None else float(t.weights[i])
+                self._Q = t.Q
+            self._bound.append((ctx, w_host))
+        self._ctx = ctxs[0]
         return self
 
     def value_and_gradient(self, traj_or_Z, want_grad=True):
@@ -114,8 +145,19 @@ class Objective:
         if self._ctx is None:
             raise RuntimeError("bind the objective to an integrator first")
         Z = traj_or_Z.datavec if hasattr(traj_or_Z, "datavec") else traj_or_Z
-        v, g = self._ctx.objective(Z, self._Q, want_grad)
-        return (float(v[0]) if v.size == 1 else v), g
+        if len(self._bound) == 1:
+            v, g = self._ctx.objective(Z, self._Q, want_grad)
+            return (float(v[0]) if v.size == 1 else v), g
+        # independent contexts: member i contributes w_i Q |1 - F_i| (+ the regularisers, registered on member 0 only)
+        total, grad = 0.0, None
+        for i, (ctx, w) in enumerate(self._bound):
+            v, g = ctx.objective(Z, self._Q * w, want_grad)
+            total += float(v[0])
+            if want_grad:
+                grad = g.copy() if grad is None else grad + g
+        return total, grad
 
     def value_and_gradient_dev(self, Z_dev, value_dev, grad_dev=None):
+        if len(self._bound) != 1:
+            raise NotImplementedError("device-resident objective of an ensemble whose members have their own contexts: use value_and_gradient")
         self._ctx.objective_dev(Z_dev, self._Q, value_dev, grad_dev)
