@@ -14,7 +14,11 @@ Workloads (`--workload`, default `auto`):
               and its gradient + the merit and J^T delta on the shared controls (pcl_merit_grad_dev), then ONE sum
               all-reduce of that 5.6 KB payload over the ranks (RCCL) -- all inside the timed region.  One eval = one member.
   auto        1 GPU: `single` is timed as `value`; the multistart and ensemble shares are measured as well and reported
-              in `multistart_share` / `ensemble_share` of the same line.  N > 1 GPUs: `ensemble` (the workload with the collective).
+              in `multistart_share` / `ensemble_share` of the same line (+ `multistart_64`: config 5's 64 seeds on this one GPU,
+              the reference point of the scaling curve).  N > 1 GPUs: BOTH sharded workloads are timed, each in its own
+              barrier-bracketed region: `value` = config 5, the 64-seed multistart with 64 / N seeds per GPU in one launch
+              (STRONG scaling: the total is fixed at 64; no data-path collective), and `ensemble_share` = config 4's 64 members
+              with 64 / N per GPU, whose step contains the ONE RCCL all-reduce (`rccl_ranks`, `all_reduce_us` alone beside it).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -86,7 +90,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["auto", "single", "multistart", "ensemble"], default="auto")
-    ap.add_argument("--batch", type=int, default=8, help="seeds (multistart) or members (ensemble) per GPU: 64 / 8 GPUs")
+    ap.add_argument("--batch", type=int, default=0, help="seeds (multistart) or members (ensemble) per GPU; default: 8 on one GPU (the 8-GPU share), 64 // N on N > 1 GPUs")
+    ap.add_argument("--total-units", type=int, default=64, help="BASELINE configs 4 / 5: members / seeds of the whole job")
     ap.add_argument("--knots", type=int, default=100)
     ap.add_argument("--cols-per-slice", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,14 +134,18 @@ def main():
     stream = torch.cuda.Stream()  # the launch stream; HIP events below are recorded on it
     torch.cuda.set_stream(stream)
     system = synthetic.config_system(3)
-    N, B = args.knots, args.batch
+    N = args.knots
+    B = args.batch if args.batch > 0 else (8 if world == 1 else max(1, args.total_units // world))
     d, m = system.levels, system.n_drives
     G0, Gj = system.G_drift, system.G_drives_array()
-    workload = args.workload if args.workload != "auto" else ("single" if world == 1 else "ensemble")
+    workload = args.workload if args.workload != "auto" else ("single" if world == 1 else "multistart")
     KNAMES = {31: "pcl_fused_kernel_v3<2,27,6,2>", 30: "pcl_fused_kernel_v3<2,0,0,0>", 32: "pcl_fused_kernel_v3 (compiled for the shape)",
               21: "pcl_fused_kernel_v2<true,1,27,6,3>", 20: "pcl_fused_kernel_v2<true,1,0,0,0>"}  # fmt: skip
 
     def describe(lk, ns):
+        if 41 <= lk <= 45:
+            return ("pcl_fused_sparse_kernel (pattern-compiled per system, Pade order %d; persistent, 1 workgroup/CU: one wave per chain -- powers of G, "
+                    "W, V, dW_l -- + loader + writer + 4 store-stream waves; no workgroup barrier)" % (2 * (lk - 40)))
         return KNAMES.get(lk, "pcl_fused_kernel (id %d)" % lk) + (
             (" (persistent; 1 workgroup/CU; contiguous column ranges; %d workgroups stream the B+- blocks, the others do the column "
              "work with 8 matrix waves)" % ns) if lk // 10 == 3 and ns > 0 else
@@ -145,12 +154,15 @@ def main():
 
     # multistart seeds s = 0..: default_rng(1000 + s)  (SURVEY 8(d)); this rank owns seeds rank*B .. rank*B+B-1
     seeds = [synthetic.synthetic_trajectory(system, N, seed=1000 + rank * B + i) for i in range(B if (workload == "multistart" or world == 1) else 1)]
+    strong = world > 1 and workload in ("multistart", "ensemble") and args.batch <= 0  # the job's total is fixed (64): strong scaling
     t0 = seeds[0]
     abytes = algorithmic_bytes_per_eval(d, m, N, t0.dim)
 
-    def run_multistart(batch, steps, warmup, use_dist):
+    def run_multistart(batch, steps, warmup, use_dist, order=4):
         """`batch` independent trajectories in one launch per step (batch 1 = BASELINE config 3 strictly)."""
-        ms = pa.HipPadeMultistart(G0, Gj, t0, batch, device=local)
+        while len(seeds) < batch:
+            seeds.append(synthetic.synthetic_trajectory(system, N, seed=1000 + rank * batch + len(seeds)))
+        ms = pa.HipPadeMultistart(G0, Gj, t0, batch, device=local, pade_order=order)
         c = ms.ctx
         if args.cols_per_slice:
             c.set_option("cols_per_slice", args.cols_per_slice)
@@ -177,8 +189,8 @@ def main():
         c.set_stream(stream.cuda_stream)
         U_goal = np.eye(d, dtype=complex)
         J = pa.UnitaryInfidelityObjective(U_goal, [b.x_name for b in Bs], traj, Q=100.0, weights=np.full(M, 1.0 / (M * world)))
-        for nm, R in (("u", 1e-2), ("du", 1e-2), ("ddu", 1e-2)):
-            J = J + pa.QuadraticRegularizer(nm, traj, R)
+        for nm, R in (("u", 1e-2), ("du", 1e-2), ("ddu", 1e-2)):  # terms of the SHARED controls: R / world on every rank, so the all-reduced sum counts them once
+            J = J + pa.QuadraticRegularizer(nm, traj, R / world)
         J.bind(Bs)
         Zd = torch.from_numpy(traj.datavec).cuda()
         dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
@@ -205,6 +217,10 @@ def main():
                     payload_bytes=int(payload.numel() * 8), all_reduce=bool(reduce_), z_dim=int(traj.dim),
                     payload_fused=bool(c.get_option("last_merit_fused")) and not args.separate_payload,
                     objective=float(chk[0]), merit=float(chk[1]))  # fmt: skip
+        if reduce_:  # the collective alone (same payload, same stream), barrier-bracketed like the step
+            wr, dr = time_steps(lambda: pd.reduce_payload(payload, dist), steps, min(warmup, 5), torch, dist)
+            info["all_reduce_us"] = dr / steps * 1e6
+            info["rccl_ranks"] = int(dist.get_world_size())
         for b in Bs:
             b.close()
         del Zd, dd, vd, grad
@@ -223,7 +239,7 @@ def main():
     evals = world * units * args.steps
     wl_text = {
         "single": "ONE trajectory per launch (BASELINE config 3 strictly)" + ("; %d independent replicas (a single NLP does not shard)" % world if world > 1 else ""),
-        "multistart": "%d multistart seeds per GPU in one launch (BASELINE config 5 share: 64 seeds / 8 GPUs), no data-path collective" % B,
+        "multistart": "%d multistart seeds per GPU in one launch (BASELINE config 5: %d seeds over %d GPU(s)), no data-path collective" % (B, B * world, world),
         "ensemble": "%d perturbed-drift ensemble members per GPU with shared controls in one trajectory buffer (BASELINE config 4 share: 64 / 8 GPUs); "
         "step = fused residual+Jacobian + weighted infidelity/regulariser objective and gradient + merit and J^T delta on the shared controls + "
         "ONE %s of that %d-byte payload" % (B, "RCCL sum all-reduce" if info.get("all_reduce") else "(single rank: no) all-reduce", info.get("payload_bytes", 0)),
@@ -237,7 +253,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -247,10 +263,29 @@ def main():
             "workload_id": workload,
             "units_per_gpu": units,
             "total_units": units * world,
+            "units_total": units * world,
             "parallelism": "units sharded over %d rank(s)" % world,
         },
     }
     out["config"].update({k: v for k, v in info.items()})
+    pve = os.path.join(ROOT, "profiles", "pade_vs_exp.json")
+    if os.path.exists(pve):  # deviation of the Pade-p constraint from the reference's exp constraint, per config (scripts/pade_vs_exp.py)
+        try:
+            out["config"]["pade_order"] = 4
+            out["config"]["pade_vs_exp"] = {k: {kk: vv for kk, vv in v.items() if kk.startswith("order_") or kk == "max_norm_dtG"}
+                                            for k, v in json.load(open(pve))["configs"].items()}
+        except Exception:
+            pass
+    if world > 1 and workload == "multistart" and args.workload == "auto":
+        # config 4 beside it: 64 / N members per rank, the step that holds the one collective
+        we, de, ie, ub = run_ensemble(B, args.steps, args.warmup, True)
+        te = torch.tensor([we, de], dtype=torch.float64, device="cuda")
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        we, de = float(te[0]), float(te[1])
+        out["ensemble_share"] = {"evals_per_s": world * B * args.steps / we, "us_per_step_kernel": de / args.steps * 1e6, "members_per_gpu": B,
+                                 "members_total": B * world, "payload_bytes": ie["payload_bytes"], "all_reduce": ie["all_reduce"],
+                                 "rccl_ranks": ie.get("rccl_ranks"), "all_reduce_us": ie.get("all_reduce_us"), "payload_fused": ie["payload_fused"],
+                                 "note": "config 4: fused residual+Jacobian of this rank's members + objective + payload, then ONE RCCL sum all-reduce; max over ranks"}  # fmt: skip
     kernel_s = dev / args.steps  # HIP events on the launch stream around the K back-to-back steps
     out["roofline"] = {
         "bound": "hbm",
@@ -259,6 +294,7 @@ def main():
         "unit": "GB/s",
         "frac": ubytes * units / kernel_s / 1e9 / HBM_PEAK_GBS,
         "traffic": None,
+        "traffic_source": None,
         "kernel": describe(info["kernel_id"], info["stream_workgroups"]),
         "kernel_us": kernel_s * 1e6,
         "algorithmic_bytes_per_launch": ubytes * units,
@@ -270,6 +306,7 @@ def main():
             tr = json.load(open(pmc)).get(workload)
             if tr and tr.get("batch") == units and tr.get("knots") == N:
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (committed rocprofv3 --pmc pass of this workload; not measured in this run)"
         except Exception:
             pass
 
@@ -284,10 +321,26 @@ def main():
                                  "hbm_GBps": ub * B / (de / st) / 1e9, "payload_bytes": ie["payload_bytes"], "all_reduce": ie["all_reduce"],
                                  "payload_fused": ie["payload_fused"],
                                  "note": "config 4 share on one GPU: the step of the N > 1 default workload without the all-reduce"}  # fmt: skip
+    if rank == 0 and world == 1 and args.workload == "auto" and not args.no_shares:
+        # config 5 whole (64 seeds) on this one GPU in one launch: the N = 1 point of the multistart scaling curve
+        T = args.total_units
+        w64, d64, i64 = run_multistart(T, 10, 3, False)
+        out["multistart_64"] = {"evals_per_s": T * 10 / w64, "us_per_launch_kernel": d64 / 10 * 1e6, "seeds_per_launch": T,
+                                "frac_of_hbm_peak": abytes * T / (d64 / 10) / 1e9 / HBM_PEAK_GBS,
+                                "note": "the value an N-GPU run of this script reports is the same 64 seeds with 64 / N per GPU"}
     if rank == 0 and world == 1 and not args.no_extras:
         # the other rates of the same path, reported beside the headline (never as `value`)
         ex = {}
         st = max(20, min(args.steps, 100))
+        # the orders that reach the reference's exp constraint at this config (pade_vs_exp): same launch shapes as the headline
+        for order in (8, 10):
+            w1, d1, i1 = run_multistart(1, st, 10, False, order)
+            w8, d8, i8 = run_multistart(B, st, 10, False, order)
+            ex["order%d" % order] = {"single": {"evals_per_s": st / w1, "us_per_launch_kernel": d1 / st * 1e6, "frac_of_hbm_peak": abytes / (d1 / st) / 1e9 / HBM_PEAK_GBS,
+                                                "kernel_id": i1["kernel_id"]},
+                                     "batch8": {"evals_per_s": B * st / w8, "us_per_launch_kernel": d8 / st * 1e6,
+                                                "frac_of_hbm_peak": abytes * B / (d8 / st) / 1e9 / HBM_PEAK_GBS, "kernel_id": i8["kernel_id"]},
+                                     "kernel": describe(i1["kernel_id"], 0)}
         ms = pa.HipPadeMultistart(G0, Gj, t0, B, device=local)
         c = ms.ctx
         c.set_stream(stream.cuda_stream)

@@ -568,7 +568,8 @@ def pade_jacobian_values(Z, lay: Layout, G0, Gj, order=4, x_off=None):
     q = order // 2
     d, n, m, xd = lay.C, lay.n, lay.m, lay.x_dim
     per = jac_nnz_per_interval(lay)
-    out = np.empty((lay.K, per))
+    dt_ = np.result_type(np.asarray(Z).dtype, np.float64)  # complex Z: the complex-step derivative of this function pins the Hessian
+    out = np.empty((lay.K, per), dtype=dt_)
     for k in range(lay.K):
         G = G0 + np.tensordot(lay.u(Z, k), Gj, axes=1) if m else G0
         h = lay.dt(Z, k)
@@ -583,7 +584,7 @@ def pade_jacobian_values(Z, lay: Layout, G0, Gj, order=4, x_off=None):
         out[k, p : p + nb] = np.tile(Bm.T.reshape(-1), d)
         p += nb
         Y = [((-1) ** j) * Xn - Xc for j in range(q + 1)]
-        tail = np.empty((d, m + 1, n))  # [state column][drive l | dt][row]
+        tail = np.empty((d, m + 1, n), dtype=dt_)  # [state column][drive l | dt][row]
         for l in range(m):
             R = np.zeros_like(Xc)
             for j in range(1, q + 1):
@@ -602,7 +603,7 @@ def pade_jacobian_dense(Z, lay: Layout, G0, Gj, order=4, x_off=None):
     """Dense (x_dim*K) x (z_dim*N) Jacobian assembled from the triplets (small cases)."""
     rows, cols = jac_structure(lay, x_off)
     vals = pade_jacobian_values(Z, lay, G0, Gj, order, x_off).reshape(-1)
-    J = np.zeros((lay.x_dim * lay.K, lay.z_dim * lay.N))
+    J = np.zeros((lay.x_dim * lay.K, lay.z_dim * lay.N), dtype=vals.dtype)
     np.add.at(J, (rows, cols), vals)
     return J
 

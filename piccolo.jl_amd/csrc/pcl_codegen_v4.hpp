@@ -17,16 +17,18 @@
 
 namespace pcl_codegen {
 
-constexpr int kV4Group = 4;    // output rows accumulated together (2 * kV4Group independent chains; the product is ONE asm statement of
+constexpr int kV4Group = 3;    // output rows accumulated together (2 * kV4Group independent chains; the product is ONE asm statement of
                                // 54 + 7 kV4Group + ~13 vector registers next to whatever the role keeps live: 128 per lane at 14 waves per CU)
 constexpr int kV4Chunk = 8;    // drift coefficients per scalar-load chunk (one s_load_dwordx16; two chunks of scalar registers in rotation)
 constexpr int kV4MaxCf = 16;   // resident drive coefficients (drive, magnitude) the product keeps in scalar registers
+constexpr int kV4MaxRes = 28;  // resident coefficients in all (scalar register pairs): the drives' first, then the drift's value classes by use
+constexpr int kV4MaxResStreamed = 16;  // ... when some drift classes do not fit and the rest is streamed (the chunks take 32 scalar registers)
 
 struct V4Term {
     int row;    // output row inside the half (0 .. d-1)
     bool isV;   // B block (accumulates V: completed by the OTHER half) or A block (U)
     int in;     // input index (state row of this half's x)
-    int kind;   // 0: drift table entry `idx` (emission order) | 1: resident coefficient `idx`
+    int kind;   // 0: drift table entry `idx` (emission order) | 1: resident drive coefficient `idx` | 2: resident drift class `idx`
     int idx;
     bool neg;
 };
@@ -43,6 +45,11 @@ struct V4Plan {
     int n_drift_pad = 0;             // table length per member (padded: a chunk's loads never leave the member's table)
     std::vector<int> cf_l, cf_g;     // resident coefficient k = u[cf_l[k]] * mags[cf_g[k]]
     std::vector<double> mags;
+    // The drift's entries fall into a few VALUE CLASSES (15 distinct magnitudes among the 91 entries of BASELINE config 3; 27 for
+    // its perturbed ensemble members, the same classes in every member): the most used classes are resident too -- one table of
+    // class values per member, read once per item -- and only the rest of the entries is streamed.
+    int n_dcf = 0, n_dcf_pad = 0;    // resident drift classes; table stride per member
+    std::vector<double> dcf_vals;    // [n_g0][n_dcf_pad]
     std::vector<char> hasU, hasV;    // per output row: any A / B entry
     std::vector<std::vector<V4GEnt>> gl;  // per drive
     bool ok = false;
@@ -73,14 +80,67 @@ static inline V4Plan make_v4_plan(int d, int m, const double *G0, int n_g0, cons
         return (int)P.cf_l.size() - 1;
     };
     std::vector<std::vector<V4Term>> by(d);
+    // drift: value classes over the members (key = the entry's values in every member, sign-normalised by the first nonzero one)
+    std::vector<std::vector<double>> ckey;
+    std::vector<int> ccount;
+    std::vector<int> pos_class(nn, -1);
+    std::vector<char> pos_neg(nn, 0);
     for (int c = 0; c < d; ++c)
         for (int r = 0; r < n; ++r) {
             const size_t pz = (size_t)r + (size_t)n * c;
-            bool drift = false;
-            for (int b = 0; b < n_g0; ++b) drift |= G0[b * nn + pz] != 0.0;
+            std::vector<double> key(n_g0);
+            double sg = 0.0;
+            for (int b = 0; b < n_g0; ++b) {
+                key[b] = G0[b * nn + pz];
+                if (sg == 0.0 && key[b] != 0.0) sg = key[b] < 0 ? -1.0 : 1.0;
+            }
+            if (sg == 0.0) continue;
+            for (double &v : key) v *= sg;
+            int id = -1;
+            for (size_t k = 0; k < ckey.size() && id < 0; ++k)
+                if (ckey[k] == key) id = (int)k;
+            if (id < 0) {
+                id = (int)ckey.size();
+                ckey.push_back(key);
+                ccount.push_back(0);
+            }
+            ++ccount[id];
+            pos_class[pz] = id;
+            pos_neg[pz] = sg < 0;
+        }
+    for (int c = 0; c < d; ++c)  // the drives' coefficients first: they decide how many drift classes fit beside them
+        for (int r = 0; r < n; ++r)
+            for (int l = 0; l < m; ++l) {
+                const double v = Gj[l * nn + (size_t)r + (size_t)n * c];
+                if (v != 0.0) (void)cf_index(l, mag_index(v));
+            }
+    std::vector<int> class_res(ckey.size(), -1);
+    {
+        std::vector<int> order(ckey.size());
+        for (size_t k = 0; k < order.size(); ++k) order[k] = (int)k;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ccount[a] > ccount[b]; });
+        // everything resident when it fits (no scalar load inside the product); otherwise a smaller resident set beside the chunk registers
+        const bool all_fit = (int)order.size() + (int)P.cf_l.size() <= kV4MaxRes;
+        const int room = std::max(0, (all_fit ? kV4MaxRes : kV4MaxResStreamed) - (int)P.cf_l.size());
+        for (int k = 0; k < (int)order.size() && k < room; ++k) class_res[order[k]] = k;
+        P.n_dcf = std::min<int>((int)order.size(), room);
+        P.n_dcf_pad = (P.n_dcf + 8 + 7) & ~7;
+        P.dcf_vals.assign((size_t)n_g0 * P.n_dcf_pad, 0.0);
+        for (size_t k = 0; k < ckey.size(); ++k)
+            if (class_res[k] >= 0)
+                for (int b = 0; b < n_g0; ++b) P.dcf_vals[(size_t)b * P.n_dcf_pad + class_res[k]] = ckey[k][b];
+    }
+    for (int c = 0; c < d; ++c)
+        for (int r = 0; r < n; ++r) {
+            const size_t pz = (size_t)r + (size_t)n * c;
             const int row = r < d ? r : r - d;
             const bool isV = r >= d;
-            if (drift) by[row].push_back({row, isV, c, 0, (int)pz, false});  // idx: the position, replaced by the table index below
+            if (pos_class[pz] >= 0) {
+                if (class_res[pos_class[pz]] >= 0)
+                    by[row].push_back({row, isV, c, 2, class_res[pos_class[pz]], pos_neg[pz] != 0});
+                else
+                    by[row].push_back({row, isV, c, 0, (int)pz, false});  // idx: the position, replaced by the table index below
+            }
             for (int l = 0; l < m; ++l) {
                 const double v = Gj[l * nn + pz];
                 if (v == 0.0) continue;
@@ -118,7 +178,7 @@ static inline void v4_reference_apply(const V4Plan &P, const double *G0, const d
     const int d = P.d;
     std::vector<double> U0(d, 0.0), V0(d, 0.0), U1(d, 0.0), V1(d, 0.0);
     for (const V4Term &t : P.terms) {
-        double c = t.kind == 0 ? G0[P.drift_pos[t.idx]] : u[P.cf_l[t.idx]] * P.mags[P.cf_g[t.idx]];
+        double c = t.kind == 0 ? G0[P.drift_pos[t.idx]] : (t.kind == 1 ? u[P.cf_l[t.idx]] * P.mags[P.cf_g[t.idx]] : P.dcf_vals[t.idx]);
         if (t.neg) c = -c;
         (t.isV ? V0 : U0)[t.row] += c * x[t.in];      // half 0 holds the top rows a
         (t.isV ? V1 : U1)[t.row] += c * x[d + t.in];  // half 1 the bottom rows b
@@ -144,15 +204,18 @@ static inline void v4_emit_chunk_loads(std::string &s, int chunk) {
 }  // namespace detail
 
 // The generated definitions: shape macros, the resident-coefficient struct, the product, the drives' gathers.
-static inline std::string v4_functions(const V4Plan &P, int q) {
+// np: LDS tiles the powers of G rotate through (>= 2 for q >= 2; q when they fit)
+// variant: timing experiments of the product (WRONG results unless 0): 1 no ds_add_f64 | 2 no LDS operation in the epilogues | 3 one
+// accumulator chain per output row group only half as deep (kV4Group rows -> plain v_mul of every term: no dependent chains)
+static inline std::string v4_functions(const V4Plan &P, int q, int np, int variant = 0) {
     using detail::v4_chunk_reg;
     const int d = P.d, G = kV4Group;
     std::string s;
     char buf[512];
     snprintf(buf, sizeof buf,
-             "#define SPD %d\n#define SPM %d\n#define SPN %d\n#define SP4Q %d\n#define SP4NCF %d\n#define SP4NMAG %d\n#define SP4NDRIFT %d\n"
+             "#define SPD %d\n#define SPM %d\n#define SPN %d\n#define SP4Q %d\n#define SP4NP %d\n#define SP4NCF %d\n#define SP4NMAG %d\n#define SP4NDRIFT %d\n#define SP4NDCF %d\n#define SP4NDCFP %d\n"
              "typedef const double __attribute__((address_space(4))) *sp_cptr;\n",
-             d, P.m, P.n, q, (int)std::max<size_t>(P.cf_l.size(), 1), (int)std::max<size_t>(P.mags.size(), 1), P.n_drift_pad);
+             d, P.m, P.n, q, np, (int)std::max<size_t>(P.cf_l.size(), 1), (int)std::max<size_t>(P.mags.size(), 1), P.n_drift_pad, P.n_dcf, P.n_dcf_pad);
     s += buf;
     // resident coefficients.  (The products are VALU results in every lane; an "s" asm operand fed from a vector register sends
     // this compiler into an endless loop, so the value is moved to scalar registers explicitly.)
@@ -163,7 +226,17 @@ static inline std::string v4_functions(const V4Plan &P, int q) {
         snprintf(buf, sizeof buf, ", c%zu", k);
         s += buf;
     }
+    for (int k = 0; k < P.n_dcf; ++k) {
+        snprintf(buf, sizeof buf, ", g%d", k);
+        s += buf;
+    }
     s += "; };\n";
+    s += "#define SP4_SET_DCF(cf, tab) do {";  // the member's drift class values (scalar loads)
+    for (int k = 0; k < P.n_dcf; ++k) {
+        snprintf(buf, sizeof buf, " (cf).g%d = (tab)[%d];", k, k);
+        s += buf;
+    }
+    s += " } while (0)\n";
     s += "#define SP4_SET_CF(cf, u, mg) do {";
     for (size_t k = 0; k < P.cf_l.size(); ++k) {
         snprintf(buf, sizeof buf, " (cf).c%zu = sp4_uniform((u)[%d] * (mg)[%d]);", k, P.cf_l[k], P.cf_g[k]);
@@ -172,121 +245,175 @@ static inline std::string v4_functions(const V4Plan &P, int q) {
     if (P.cf_l.empty()) s += " (cf).c0 = 0.0;";
     s += " } while (0)\n";
 
-    // ---- the product: O = alpha Y + beta G(u) x -----------------------------------------------------------------------------
-    s += "// O[own] = alpha Y[own] + beta U,  O[other half] += betas V  (betas = -beta in half 1: top = A a - B b, bottom = A b + B a)\n";
-    s += "static __device__ __forceinline__ void sp4_product(const double (&x)[SPD], unsigned vY, unsigned vO, unsigned vOo, double alpha, double beta, double betas, sp_cptr tab, const sp4_cf &cf) {\n";
-    s += "    double";
-    for (int g = 0; g < G; ++g) {
-        snprintf(buf, sizeof buf, "%s aU%d, aV%d, yv%d", g ? "," : "", g, g, g);
-        s += buf;
-    }
-    s += ", t0, t1;\n";
-    s += "    asm volatile(\n";
+    // ---- the product: O = alpha Y + beta G(u) x;  the variant without Y (alpha = 0: the powers of G) reads nothing in its
+    //      epilogues and never waits for LDS ------------------------------------------------------------------------------------
     const int n_drift = (int)P.drift_pos.size();
     const int n_chunks = (n_drift + kV4Chunk - 1) / kV4Chunk;
-    if (n_chunks > 0) detail::v4_emit_chunk_loads(s, 0);
-    size_t ti = 0;
-    int tsel = 0;
-    for (int g0 = 0; g0 < d; g0 += G) {
-        const int g1 = std::min(d, g0 + G);
-        // this group's Y values
-        for (int o = g0; o < g1; ++o) {
-            snprintf(buf, sizeof buf, "        \"ds_read_b64 %%[yv%d], %%[vY] offset:%d\\n\\t\"\n", o - g0, 8 * o);
-            s += buf;
-        }
-        std::vector<char> seenU(G, 0), seenV(G, 0);
-        for (; ti < P.terms.size() && P.terms[ti].row >= g0 && P.terms[ti].row < g1; ++ti) {
-            const V4Term &t = P.terms[ti];
-            std::string coef;
-            if (t.kind == 0) {
-                const int chunk = t.idx / kV4Chunk, e = t.idx % kV4Chunk;
-                if (e == 0) {  // first use of a chunk: it has landed (requested one chunk ago); request the next one
-                    s += "        \"s_waitcnt lgkmcnt(0)\\n\\t\"\n";
-                    if (chunk + 1 < n_chunks) detail::v4_emit_chunk_loads(s, chunk + 1);
-                }
-                coef = v4_chunk_reg(chunk, e);
-            } else {
-                snprintf(buf, sizeof buf, "%%[cf%d]", t.idx);
-                coef = buf;
-            }
-            char acc[24];
-            snprintf(acc, sizeof acc, "%%[a%c%d]", t.isV ? 'V' : 'U', t.row - g0);
-            char &sn = (t.isV ? seenV : seenU)[t.row - g0];
-            if (!sn)
-                snprintf(buf, sizeof buf, "        \"v_mul_f64 %s, %s%s, %%[x%d]\\n\\t\"\n", acc, t.neg ? "-" : "", coef.c_str(), t.in);
-            else if (!t.neg)
-                snprintf(buf, sizeof buf, "        \"v_fmac_f64 %s, %s, %%[x%d]\\n\\t\"\n", acc, coef.c_str(), t.in);
-            else
-                snprintf(buf, sizeof buf, "        \"v_fma_f64 %s, -%s, %%[x%d], %s\\n\\t\"\n", acc, coef.c_str(), t.in, acc);
-            sn = 1;
-            s += buf;
-        }
-        // epilogue of the group: the Y values (and whatever else this wave has in flight) have landed
-        s += "        \"s_waitcnt lgkmcnt(0)\\n\\t\"\n";
-        for (int o = g0; o < g1; ++o) {
-            const int gi = o - g0;
-            const char *ta = "t0", *tb = "t1";
-            (void)tsel;
-            if (seenU[gi])
-                snprintf(buf, sizeof buf, "        \"v_mul_f64 %%[%s], %%[beta], %%[aU%d]\\n\\t\"\n        \"v_fmac_f64 %%[%s], %%[alpha], %%[yv%d]\\n\\t\"\n", ta, gi, ta, gi);
-            else
-                snprintf(buf, sizeof buf, "        \"v_mul_f64 %%[%s], %%[alpha], %%[yv%d]\\n\\t\"\n", ta, gi);
-            s += buf;
-            snprintf(buf, sizeof buf, "        \"ds_write_b64 %%[vO], %%[%s] offset:%d\\n\\t\"\n", ta, 8 * o);
-            s += buf;
-            if (seenV[gi]) {
-                snprintf(buf, sizeof buf, "        \"v_mul_f64 %%[%s], %%[betas], %%[aV%d]\\n\\t\"\n        \"ds_add_f64 %%[vOo], %%[%s] offset:%d\\n\\t\"\n", tb, gi, tb, 8 * o);
+    auto emit_product = [&](const char *name, bool with_y) {
+        // Accumulators in two sets (group parity): a finished group is scaled in place (own value alpha Y + beta U in the U
+        // register, betas V in the V register) and its LDS operations are issued BETWEEN the multiply-adds of the next group --
+        // back to back behind their v_mul they cost a lone wave 20-27 cycles each (a third of the product).
+        s += "// O[own] = alpha Y[own] + beta U,  O[other half] += betas V  (betas = -beta in half 1: top = A a - B b, bottom = A b + B a)\n";
+        snprintf(buf, sizeof buf, "static __device__ __forceinline__ void %s(const double (&x)[SPD], unsigned vY, unsigned vO, unsigned vOo, double alpha, double beta, double betas, sp_cptr tab, const sp4_cf &cf) {\n", name);
+        s += buf;
+        s += "    double";
+        for (int st = 0; st < 2; ++st)
+            for (int g = 0; g < G; ++g) {
+                snprintf(buf, sizeof buf, "%s aU%d_%d, aV%d_%d", (st || g) ? "," : "", st, g, st, g);
                 s += buf;
             }
+        if (with_y)
+            for (int g = 0; g < G; ++g) {
+                snprintf(buf, sizeof buf, ", yv%d", g);
+                s += buf;
+            }
+        s += ";\n";
+        if (!with_y) s += "    (void)vY;\n    (void)alpha;\n";
+        s += "    asm volatile(\n";
+        if (n_chunks > 0) detail::v4_emit_chunk_loads(s, 0);
+        size_t ti = 0;
+        std::vector<std::string> pending;  // LDS operations of the previous group
+        size_t pend_i = 0;
+        int ngroup = 0;
+        for (int g0 = 0; g0 < d; g0 += G, ++ngroup) {
+            const int g1 = std::min(d, g0 + G), st = ngroup & 1;
+            if (with_y)  // this group's Y values
+                for (int o = g0; o < g1; ++o) {
+                    snprintf(buf, sizeof buf, "        \"ds_read_b64 %%[yv%d], %%[vY] offset:%d\\n\\t\"\n", o - g0, 8 * o);
+                    s += buf;
+                }
+            size_t nterm = 0;
+            for (size_t t = ti; t < P.terms.size() && P.terms[t].row >= g0 && P.terms[t].row < g1; ++t) ++nterm;
+            const size_t npend = pending.size() - pend_i;
+            const size_t every = npend ? std::max<size_t>(1, nterm / (npend + 1)) : 0;
+            std::vector<char> seenU(G, 0), seenV(G, 0);
+            size_t k = 0;
+            for (; ti < P.terms.size() && P.terms[ti].row >= g0 && P.terms[ti].row < g1; ++ti, ++k) {
+                const V4Term &t = P.terms[ti];
+                if (every && k && k % every == 0 && pend_i < pending.size()) s += pending[pend_i++];
+                std::string coef;
+                if (t.kind == 0) {
+                    const int chunk = t.idx / kV4Chunk, e = t.idx % kV4Chunk;
+                    if (e == 0) {  // first use of a chunk: it has landed (requested one chunk ago); request the next one
+                        s += "        \"s_waitcnt lgkmcnt(0)\\n\\t\"\n";
+                        if (chunk + 1 < n_chunks) detail::v4_emit_chunk_loads(s, chunk + 1);
+                    }
+                    coef = v4_chunk_reg(chunk, e);
+                } else {
+                    snprintf(buf, sizeof buf, t.kind == 1 ? "%%[cf%d]" : "%%[dg%d]", t.idx);
+                    coef = buf;
+                }
+                char acc[24];
+                snprintf(acc, sizeof acc, "%%[a%c%d_%d]", t.isV ? 'V' : 'U', st, t.row - g0);
+                char &sn = (t.isV ? seenV : seenU)[t.row - g0];
+                if (!sn || variant == 3)
+                    snprintf(buf, sizeof buf, "        \"v_mul_f64 %s, %s%s, %%[x%d]\\n\\t\"\n", acc, t.neg ? "-" : "", coef.c_str(), t.in);
+                else if (!t.neg)
+                    snprintf(buf, sizeof buf, "        \"v_fmac_f64 %s, %s, %%[x%d]\\n\\t\"\n", acc, coef.c_str(), t.in);
+                else
+                    snprintf(buf, sizeof buf, "        \"v_fma_f64 %s, -%s, %%[x%d], %s\\n\\t\"\n", acc, coef.c_str(), t.in, acc);
+                sn = 1;
+                s += buf;
+            }
+            while (pend_i < pending.size()) s += pending[pend_i++];
+            pending.clear();
+            pend_i = 0;
+            // finish the group in place (with Y: its values -- and whatever else this wave has in flight -- have landed)
+            if (with_y) s += "        \"s_waitcnt lgkmcnt(0)\\n\\t\"\n";
+            for (int o = g0; o < g1; ++o) {
+                const int gi = o - g0;
+                if (seenU[gi]) {
+                    snprintf(buf, sizeof buf, "        \"v_mul_f64 %%[aU%d_%d], %%[beta], %%[aU%d_%d]\\n\\t\"\n", st, gi, st, gi);
+                    s += buf;
+                    if (with_y) {
+                        snprintf(buf, sizeof buf, "        \"v_fmac_f64 %%[aU%d_%d], %%[alpha], %%[yv%d]\\n\\t\"\n", st, gi, gi);
+                        s += buf;
+                    }
+                } else {
+                    if (with_y)
+                        snprintf(buf, sizeof buf, "        \"v_mul_f64 %%[aU%d_%d], %%[alpha], %%[yv%d]\\n\\t\"\n", st, gi, gi);
+                    else
+                        snprintf(buf, sizeof buf, "        \"v_mov_b64 %%[aU%d_%d], 0\\n\\t\"\n", st, gi);
+                    s += buf;
+                }
+                snprintf(buf, sizeof buf, "        \"ds_write_b64 %%[vO], %%[aU%d_%d] offset:%d\\n\\t\"\n", st, gi, 8 * o);
+                if (variant != 2) pending.push_back(buf);
+                if (seenV[gi]) {
+                    snprintf(buf, sizeof buf, "        \"v_mul_f64 %%[aV%d_%d], %%[betas], %%[aV%d_%d]\\n\\t\"\n", st, gi, st, gi);
+                    s += buf;
+                    snprintf(buf, sizeof buf, "        \"ds_add_f64 %%[vOo], %%[aV%d_%d] offset:%d\\n\\t\"\n", st, gi, 8 * o);
+                    if (variant != 1 && variant != 2) pending.push_back(buf);
+                }
+            }
         }
-    }
-    s += "        \"s_waitcnt lgkmcnt(0)\"\n        : ";
-    for (int g = 0; g < G; ++g) {
-        snprintf(buf, sizeof buf, "%s[aU%d] \"=&v\"(aU%d), [aV%d] \"=&v\"(aV%d), [yv%d] \"=&v\"(yv%d)", g ? ", " : "", g, g, g, g, g, g);
-        s += buf;
-    }
-    s += ", [t0] \"=&v\"(t0), [t1] \"=&v\"(t1)\n        : ";
-    for (int i = 0; i < d; ++i) {
-        snprintf(buf, sizeof buf, "%s[x%d] \"v\"(x[%d])", i ? ", " : "", i, i);
-        s += buf;
-    }
-    s += ", [vY] \"v\"(vY), [vO] \"v\"(vO), [vOo] \"v\"(vOo), [alpha] \"v\"(alpha), [beta] \"v\"(beta), [betas] \"v\"(betas), [tab] \"s\"(tab)";
-    for (size_t k = 0; k < std::max<size_t>(P.cf_l.size(), 1); ++k) {
-        snprintf(buf, sizeof buf, ", [cf%zu] \"s\"(cf.c%zu)", k, k);
-        s += buf;
-    }
-    s += "\n        : \"memory\"";
-    for (int r = 36; r < 68; ++r) {
-        snprintf(buf, sizeof buf, ", \"s%d\"", r);
-        s += buf;
-    }
-    s += ");\n}\n";
+        for (const std::string &q_ : pending) s += q_;
+        s += "        \"s_waitcnt lgkmcnt(0)\"\n        : ";
+        for (int st = 0; st < 2; ++st)
+            for (int g = 0; g < G; ++g) {
+                snprintf(buf, sizeof buf, "%s[aU%d_%d] \"=&v\"(aU%d_%d), [aV%d_%d] \"=&v\"(aV%d_%d)", (st || g) ? ", " : "", st, g, st, g, st, g, st, g);
+                s += buf;
+            }
+        if (with_y)
+            for (int g = 0; g < G; ++g) {
+                snprintf(buf, sizeof buf, ", [yv%d] \"=&v\"(yv%d)", g, g);
+                s += buf;
+            }
+        s += "\n        : ";
+        for (int i = 0; i < d; ++i) {
+            snprintf(buf, sizeof buf, "%s[x%d] \"v\"(x[%d])", i ? ", " : "", i, i);
+            s += buf;
+        }
+        if (with_y) s += ", [vY] \"v\"(vY), [alpha] \"s\"(alpha)";
+        s += ", [vO] \"v\"(vO), [vOo] \"v\"(vOo), [beta] \"s\"(beta), [betas] \"v\"(betas), [tab] \"s\"(tab)";
+        for (size_t k = 0; k < std::max<size_t>(P.cf_l.size(), 1); ++k) {
+            snprintf(buf, sizeof buf, ", [cf%zu] \"s\"(cf.c%zu)", k, k);
+            s += buf;
+        }
+        for (int k = 0; k < P.n_dcf; ++k) {
+            snprintf(buf, sizeof buf, ", [dg%d] \"s\"(cf.g%d)", k, k);
+            s += buf;
+        }
+        s += "\n        : \"memory\"";
+        for (int r = 36; r < 68 && n_chunks > 0; ++r) {  // the chunk registers of the streamed entries
+            snprintf(buf, sizeof buf, ", \"s%d\"", r);
+            s += buf;
+        }
+        s += ");\n}\n";
+    };
+    emit_product("sp4_product", true);
+    emit_product("sp4_product0", false);
 
     // ---- the drives' gathers: X[own + i] = hs * (G_l w)_i for this lane's half-rows; Wo / Wx = this lane's own / other half of
     //      column c of w in LDS; sb = -1 in half 0, +1 in half 1 (top = A a - B b, bottom = A b + B a) ----------------------------
     for (int l = 0; l < P.m; ++l) {
         snprintf(buf, sizeof buf, "static __device__ __forceinline__ void sp4_gather_%d(const double *__restrict__ Wo, const double *__restrict__ Wx, double *__restrict__ X, double hs, double sb, const double (&mg)[SP4NMAG]) {\n", l);
         s += buf;
-        s += "    double t_[SPD];\n";
-        for (int i = 0; i < d; ++i) {
-            std::string ea, eb;
-            for (const V4GEnt &e : P.gl[l])
-                if (e.row == i) {
-                    std::string &dst = e.isB ? eb : ea;
-                    snprintf(buf, sizeof buf, "%smg[%d] * %s[%d]", dst.empty() ? (e.neg ? "-" : "") : (e.neg ? " - " : " + "), e.mag, e.isB ? "Wx" : "Wo", e.col);
-                    dst += buf;
-                }
-            if (ea.empty() && eb.empty())
-                snprintf(buf, sizeof buf, "    t_[%d] = 0.0;\n", i);
-            else if (eb.empty())
-                snprintf(buf, sizeof buf, "    t_[%d] = hs * (%s);\n", i, ea.c_str());
-            else if (ea.empty())
-                snprintf(buf, sizeof buf, "    t_[%d] = hs * (sb * (%s));\n", i, eb.c_str());
-            else
-                snprintf(buf, sizeof buf, "    t_[%d] = hs * ((%s) + sb * (%s));\n", i, ea.c_str(), eb.c_str());
+        // nine rows at a time: every read of a batch before its writes (the compiler cannot prove the tiles distinct), and never more
+        // than nine results in registers next to the 27 of x the caller holds
+        for (int i0 = 0; i0 < d; i0 += 9) {
+            const int i1 = std::min(d, i0 + 9);
+            s += "    {\n        double t_[9];\n";
+            for (int i = i0; i < i1; ++i) {
+                std::string ea, eb;
+                for (const V4GEnt &e : P.gl[l])
+                    if (e.row == i) {
+                        std::string &dst = e.isB ? eb : ea;
+                        snprintf(buf, sizeof buf, "%smg[%d] * %s[%d]", dst.empty() ? (e.neg ? "-" : "") : (e.neg ? " - " : " + "), e.mag, e.isB ? "Wx" : "Wo", e.col);
+                        dst += buf;
+                    }
+                if (ea.empty() && eb.empty())
+                    snprintf(buf, sizeof buf, "        t_[%d] = 0.0;\n", i - i0);
+                else if (eb.empty())
+                    snprintf(buf, sizeof buf, "        t_[%d] = hs * (%s);\n", i - i0, ea.c_str());
+                else if (ea.empty())
+                    snprintf(buf, sizeof buf, "        t_[%d] = hs * (sb * (%s));\n", i - i0, eb.c_str());
+                else
+                    snprintf(buf, sizeof buf, "        t_[%d] = hs * ((%s) + sb * (%s));\n", i - i0, ea.c_str(), eb.c_str());
+                s += buf;
+            }
+            snprintf(buf, sizeof buf, "#pragma unroll\n        for (int i = 0; i < %d; ++i) X[%d + i] = t_[i];\n    }\n", i1 - i0, i0);
             s += buf;
         }
-        s += "#pragma unroll\n    for (int i = 0; i < SPD; ++i) X[i] = t_[i];\n";
         s += "}\n";
     }
     s += "#define SP4_GATHER_SWITCH(l, Wo, Wx, X, hs, sb, mg) switch (l) {";

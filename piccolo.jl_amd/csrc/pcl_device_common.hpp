@@ -70,6 +70,7 @@ struct KParams {
     double pc[6]; // general-order kernel: diagonal Pade coefficients c_0..c_q
     double *mpart;       // v3, optional: per state column (b, k, c) the m + 2 dot products of the reduce payload (pcl_eval_jac_merit_dev)
     const double *mlam;  // ... against these multipliers (NULL: lam = delta, the constraint merit)
+    int tail_mode;       // pattern-compiled fused kernel: who stores delta and the tails (option v4_tail_mode)
 };
 
 // ------------------------------------------------------------------------------------------

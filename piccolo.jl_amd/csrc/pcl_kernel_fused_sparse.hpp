@@ -1,6 +1,7 @@
 // pcl_kernel_fused_sparse.hpp -- fused residual + Jacobian, PATTERN-COMPILED, any diagonal Pade order 2q.
-// Included by generated source only (pcl_codegen_v4.hpp): SPD (Hilbert dimension), SPM (drives), SPN = 2 SPD, SP4Q (q), the
-// resident-coefficient struct sp4_cf, the product sp4_product and the drives' gathers sp4_gather_<l> are defined before this file.
+// Included by generated source only (pcl_codegen_v4.hpp): SPD (Hilbert dimension), SPM (drives), SPN = 2 SPD, SP4Q (q), SP4NP
+// (tiles of the powers of G), the resident-coefficient struct sp4_cf, the products sp4_product / sp4_product0 and the drives'
+// gathers sp4_gather_<l> are defined before this file.
 //
 // With Y_j = D (j even) or -S (j odd), D = X_{k+1} - X_k, S = X_{k+1} + X_k, c_j the Pade coefficients, h the step:
 //     level q:           W = c_q Y_q          V = q c_q Y_q            dW_l = 0                            P = I
@@ -9,11 +10,13 @@
 // Every chain acts on the state columns from the left: lane (half, c) owns its half of column c, G(u) x is the straight-line
 // product sp4_product (coefficients in scalar registers, no LDS operand traffic, no matrix-core padding: 307 multiply-adds
 // instead of 112 MFMAs per 27 columns at BASELINE config 3).  ONE persistent workgroup per CU, one WAVE per chain:
-//     wave 0            P: the powers of G (first d columns: the generators are exact iso(.) images), B^+ / B^- accumulated in two tiles
+//     wave 0            P: the powers of G (first d columns: the generators are exact iso(.) images) into a ring of SP4NP tiles
 //     wave 1, 2         W, V
 //     wave 3 + l        dW_l
 //     wave 3 + m        loader: D, S of the next item (lane = row, coalesced) -> tiles [column][row]
-//     wave 4 + m .. +3  stream: copy the item's -B^+ / B^- values into registers, then only issue the replicated 16-byte stores
+//     wave 4 + m        writer: delta and the tail block of a finished item, tiles -> memory as ONE contiguous run per item
+//     wave 5 + m .. +3  stream: fold every power into the item's -B^+ / B^- values in registers as it appears, then only issue the
+//                       replicated 16-byte stores
 // No workgroup barrier after the start: point-to-point monotonic LDS counters (dependencies only point backwards; bounded waits).
 // Work items as in kernel 3: contiguous column ranges per workgroup (pieces of one interval), or round-robin slices.
 #pragma once
@@ -21,20 +24,36 @@
 #define SP4CS (SPN + 1)           // odd column stride: the lanes of a half wave, one column each, hit distinct banks
 #define SP4TILE (SP4CS * SPD)
 #define SP4_WLOAD (SPM + 3)
-#define SP4_WSTREAM (SPM + 4)
+#define SP4_WWRITE (SPM + 4)
+#define SP4_WSTREAM (SPM + 5)
 #define SP4_NSTREAM 4
-#define SP4_NWAVES (SPM + 8)
-#define SP4_NTILES (SPM + 7)      // D, S, W, V, dW[m], P, B+, B-
+#define SP4_NWAVES (SPM + 9)
+#define SP4_NOUT (SPM + 2)        // output chains: W (delta), V (d/dh), dW_l (d/du_l)
+#define SP4_NTILES (SPM + 4 + SP4NP)  // D, S, W, V, dW[m], P[SP4NP]
 #define SP4_SYNC_WORDS 32
-enum { SP4_F_IN = 0, SP4_F_DW, SP4_F_DV, SP4_F_W, SP4_F_B, SP4_F_C, SP4_F_G = 8 /* one word per drive wave */ };
+// monotonic counters: IN items whose D, S are in LDS | DW, DV items whose D, S the W / V wave has finished with | W levels of W
+// published | B powers published (all items) | C + w powers folded by stream wave w | OC items the writer has taken out of the tiles |
+// G + l levels of W the drive wave l has gathered | O + w items whose output chain w is complete
+// (one word per arriver wherever arrivers can run ahead of each other: a shared arrival count lies -- a fast wave's extra arrival
+//  stands in for a slow wave's missing one)
+enum { SP4_F_IN = 0, SP4_F_DW, SP4_F_DV, SP4_F_W, SP4_F_B, SP4_F_OC, SP4_F_G = 8, SP4_F_O = 16, SP4_F_C = 24 /* per stream wave */, SP4_F_TS = 28 /* per stream wave: items whose tails it has stored */ };
 
 static __device__ __forceinline__ bool sp4_wait(int *sync, int word, int target, bool gave_up = false) {
     // Bounded: a logic error must not hang the device (the caller poisons the output instead; once a wave has given up it
     // does not wait again).
     if (gave_up) return true;
+    // back-off: a level-scale wait is answered within a few short polls; an item-scale wait (the chains run several times faster than
+    // the store stream) must not keep ten waves polling next to it -- every poll takes an issue slot and an LDS cycle from the CU
     int it = 0;
-    for (; __hip_atomic_load(sync + word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target && it < (1 << 20); ++it) __builtin_amdgcn_s_sleep(1);
-    return it >= (1 << 20);
+    for (; __hip_atomic_load(sync + word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target && it < (1 << 18); ++it) {
+        if (it < 16)
+            __builtin_amdgcn_s_sleep(1);
+        else if (it < 32)
+            __builtin_amdgcn_s_sleep(16);
+        else
+            __builtin_amdgcn_s_sleep(127);
+    }
+    return it >= (1 << 18);
 }
 static __device__ __forceinline__ void sp4_post(int *w, int value, int lane) {  // after wave_lds_sync(): this wave's LDS traffic is complete
     if (lane == 0) __hip_atomic_store(w, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -46,14 +65,14 @@ static __device__ __forceinline__ unsigned sp4_lds_off(const double *q) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const double *)q;
 }
 
-extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_kernel(const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ mags_) {
+extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_kernel(const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ mags_, const double *__restrict__ dcf_tab) {
     extern __shared__ double lds[];
     constexpr int d = SPD, n = SPN, m = SPM, q = SP4Q, nn = SPN * SPN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the role branches are uniform
     double *Dt = lds, *St = Dt + SP4TILE, *Wt = St + SP4TILE, *Vt = Wt + SP4TILE, *dWt = Vt + SP4TILE;
-    double *Pt = dWt + m * SP4TILE, *Bpt = Pt + SP4TILE, *Bmt = Bpt + SP4TILE;
-    int *sync = (int *)(Bmt + SP4TILE);
+    double *Pt = dWt + m * SP4TILE;  // SP4NP tiles: power j of item `it` lives in tile (it q + j - 1) mod SP4NP
+    int *sync = (int *)(Pt + SP4NP * SP4TILE);
     for (int e = tid; e < SP4_NTILES * SP4TILE + SP4_SYNC_WORDS / 2; e += 64 * SP4_NWAVES) lds[e] = 0.0;  // (finite everywhere; counters zero)
     __syncthreads();  // the only workgroup barrier
 
@@ -89,6 +108,51 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
         }
     };
     bool gave_up = false;
+    // delta and the tail block of a finished item, tiles -> memory: the item's nce n residuals and its nce (m + 1) n tail values
+    // are ONE contiguous run each, 1 KiB per instruction; `part` of `nparts` waves takes every nparts-th instruction.
+    // tail_mode: 0 the writer wave, plain stores | 1 nontemporal | 2 write-through | 3 the stream waves, behind the item's blocks
+    auto store_outputs = [&](int c0, int nce, long long bk, int part, int nparts, int nt) {
+        int l0 = lane + 64 * part;
+        asm volatile("" : "+v"(l0));
+        if (p.delta) {
+            double *dst = p.delta + bk * xd + (long long)c0 * n;
+            for (int e2 = l0; e2 < nce * d; e2 += 64 * nparts) {
+                const int cl = e2 / d, r0 = 2 * (e2 - cl * d);
+                const double *src = Wt + cl * SP4CS + r0;
+                store2(dst + 2 * e2, src[0], src[1], nt);
+            }
+        }
+        double *dst = p.jac + bk * p.jac_per + 2 * blk + (long long)c0 * (m + 1) * n;
+        // element pair e2 of the run: column cl, vector v (drives 0 .. m-1, then d/dh), row pair r0
+        for (int e2 = l0; e2 < nce * (m + 1) * d; e2 += 64 * nparts) {
+            const int cv = e2 / d, r0 = 2 * (e2 - cv * d);
+            const int cl = cv / (m + 1), v = cv - cl * (m + 1);
+            const double *src = (v < m ? dWt + v * SP4TILE : Vt) + cl * SP4CS + r0;
+            store2(dst + 2 * e2, src[0], src[1], nt);
+        }
+    };
+    const bool tails_by_stream = p.tail_mode == 3;
+    // the chains may rewrite their tiles once item it - 1 has left them
+    auto outputs_taken = [&](int it) {
+        if (!tails_by_stream) {
+            gave_up = sp4_wait(sync, SP4_F_OC, it, gave_up);
+        } else {
+            for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_TS + w, it, gave_up);
+        }
+    };
+#ifdef PCL_PROFILE
+    // cycle stamps of workgroup 0: the first 32 per wave (dbg[32 wave + i]); experiment flags (results WRONG): prof & 2 no block
+    // stores, prof & 4 no column chains (P and the stream only), prof & 8 no tail / delta stores
+    int stamp_ = 0;
+#define SP4_STAMP()                                                                                                          \
+    do {                                                                                                                     \
+        if (p.dbg && blockIdx.x == 0 && lane == 0 && stamp_ < 32) p.dbg[32 * wave + stamp_++] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+    const bool no_blocks = p.prof & 2, no_chains = p.prof & 4, no_tails = p.prof & 8;
+#else
+#define SP4_STAMP() do { } while (0)
+    constexpr bool no_blocks = false, no_chains = false, no_tails = false;
+#endif
 
     if (wave < SP4_WLOAD) {
         // ================================== column waves: one chain each ====================================================
@@ -112,80 +176,66 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             for (int l = 0; l < SPM; ++l) u[l] = zc[p.u_off + l];
             h = zc[p.dt_off];
             SP4_SET_CF(cf, u, mg);
+            SP4_SET_DCF(cf, (sp_cptr)(dcf_tab + (p.g0_batch_stride ? (long long)b * SP4NDCFP : 0)));
             tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
         };
-        // tile -> global, lane = row pair: column cl of the tile is a run of n consecutive doubles at dst + cl * colstride
-        auto store_tile = [&](const double *T, double *dst, long long colstride, int ncols) {
-            int l0 = lane;
-            asm volatile("" : "+v"(l0));
-            for (int e2 = l0; e2 < ncols * d; e2 += 64) {
-                const int cl = e2 / d, r0 = 2 * (e2 - cl * d);
-                const double *src = T + cl * SP4CS + r0;
-                store2(dst + (long long)cl * colstride + r0, src[0], src[1], 0);
-            }
-        };
         if (wave == 0) {
-            // ---- P: powers of G(u_k) and the blocks' values ------------------------------------------------------------------
+            // ---- P: powers of G(u_k), one tile of the ring per power -----------------------------------------------------------
+            __builtin_amdgcn_s_setprio(2);  // the stream waits for this chain
             for (int it = 0; it < n_my; ++it) {
                 int c0, nce, k, b;
                 decode(it, c0, nce, k, b);
                 SP4_LANEPOS();
                 const bool act = c < d;
-                const unsigned oP = sp4_lds_off(Pt + own), oPx = sp4_lds_off(Pt + oth);
                 double h;
                 sp4_cf cf;
                 sp_cptr tab;
+                SP4_STAMP();
                 scalars(k, b, h, cf, tab);
-                gave_up = sp4_wait(sync, SP4_F_C, SP4_NSTREAM * it, gave_up);  // the stream waves hold the previous item's values in registers
-                if (act) {  // P = B^+ = B^- = I (first d columns: this lane's rows of column c)
-#pragma unroll
-                    for (int i = 0; i < SPD; ++i) {
-                        const double e = (half == 0 && i == c) ? 1.0 : 0.0;
-                        Pt[own + i] = e;
-                        Bpt[own + i] = e;
-                        Bmt[own + i] = e;
-                    }
-                }
-                double hp = 1.0, hm = 1.0;
-#pragma unroll 1
-                for (int s = 0; s < q; ++s) {
+                SP4_STAMP();
+                const double bs = half ? -1.0 : 1.0;
+                {  // P_1 = G I: the unit vectors never touch LDS
+                    const int L = it * q;
+                    double *Po = Pt + (L % SP4NP) * SP4TILE;
                     double x[SPD];
+#pragma unroll
+                    for (int i = 0; i < SPD; ++i) x[i] = (half == 0 && i == c) ? 1.0 : 0.0;
+                    for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_C + w, L - SP4NP + 1, gave_up);  // the stream has folded the power this tile held
+                    if (act) sp4_product0(x, 0u, sp4_lds_off(Po + own), sp4_lds_off(Po + oth), 0.0, 1.0, bs, tab, cf);
+                    sp4_post(sync + SP4_F_B, L + 1, lane);
+                    SP4_STAMP();
+                }
+#pragma unroll 1
+                for (int j = 2; j <= q; ++j) {
+                    const int L = it * q + j - 1;
+                    const double *Pi = Pt + ((L - 1) % SP4NP) * SP4TILE;
+                    double *Po = Pt + (L % SP4NP) * SP4TILE;
+                    for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_C + w, L - SP4NP + 1, gave_up);
+                    double x[SPD];  // (read right before the product: 54 registers that nothing else should have to live beside)
                     if (act) {
 #pragma unroll
-                        for (int i = 0; i < SPD; ++i) x[i] = Pt[own + i];
+                        for (int i = 0; i < SPD; ++i) x[i] = Pi[own + i];
                     }
-                    if (act) sp4_product(x, oP, oP, oPx, 0.0, 1.0, half ? -1.0 : 1.0, tab, cf);
-                    hp *= h;
-                    hm *= -h;
-                    const double cp = p.pc[s + 1] * hp, cm = p.pc[s + 1] * hm;
-                    if (act) {  // B^+ += c_j h^j P, B^- += c_j (-h)^j P: this lane's rows, nine at a time (all reads of a batch before its writes)
-#pragma unroll
-                        for (int i0 = 0; i0 < SPD; i0 += 9) {
-                            double pv[9], bp[9], bm[9];
-#pragma unroll
-                            for (int i = 0; i < 9; ++i)
-                                if (i0 + i < SPD) {
-                                    pv[i] = Pt[own + i0 + i];
-                                    bp[i] = Bpt[own + i0 + i];
-                                    bm[i] = Bmt[own + i0 + i];
-                                }
-#pragma unroll
-                            for (int i = 0; i < 9; ++i)
-                                if (i0 + i < SPD) {
-                                    Bpt[own + i0 + i] = __builtin_fma(cp, pv[i], bp[i]);
-                                    Bmt[own + i0 + i] = __builtin_fma(cm, pv[i], bm[i]);
-                                }
-                        }
+#ifdef PCL_PROFILE
+                    SP4_STAMP();
+                    const int reps = (p.prof & 32) ? 17 : 1;  // the product's warm rate: sixteen more of it (same result)
+                    for (int rep = 0; rep < reps; ++rep) {
+                        if (act) sp4_product0(x, 0u, sp4_lds_off(Po + own), sp4_lds_off(Po + oth), 0.0, 1.0, bs, tab, cf);
+                        if (rep == 0) SP4_STAMP();
                     }
+                    SP4_STAMP();
+#else
+                    if (act) sp4_product0(x, 0u, sp4_lds_off(Po + own), sp4_lds_off(Po + oth), 0.0, 1.0, bs, tab, cf);
+#endif
+                    sp4_post(sync + SP4_F_B, L + 1, lane);
+                    SP4_STAMP();
                 }
-                wave_lds_sync();
-                sp4_post(sync + SP4_F_B, it + 1, lane);
             }
         } else if (wave <= 2) {
             // ---- W (delta) and V (d delta / dh) --------------------------------------------------------------------------------
             const bool isW = wave == 1;
             double *Xt = isW ? Wt : Vt;
-            for (int it = 0; it < n_my; ++it) {
+            for (int it = 0; it < n_my && !no_chains; ++it) {
                 int c0, nce, k, b;
                 decode(it, c0, nce, k, b);
                 SP4_LANEPOS();
@@ -195,8 +245,11 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 double h;
                 sp4_cf cf;
                 sp_cptr tab;
+                SP4_STAMP();
                 scalars(k, b, h, cf, tab);
                 gave_up = sp4_wait(sync, SP4_F_IN, it + 1, gave_up);
+                outputs_taken(it);  // the previous item has left this tile
+                SP4_STAMP();
                 {  // level q
                     const double *Yq = (q & 1) ? St : Dt;
                     const double aq = ((q & 1) ? -1.0 : 1.0) * p.pc[q] * (isW ? 1.0 : (double)q);
@@ -213,40 +266,34 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
 #pragma unroll 1
                 for (int s = 0; s < q; ++s) {
                     const int j = q - 1 - s;
-                    double x[SPD];
+                    if (isW) {  // every drive wave has gathered the level this product overwrites
+                        for (int l = 0; l < SPM; ++l) gave_up = sp4_wait(sync, SP4_F_G + l, it * q + s + 1, gave_up);
+                    }
+                    const double alpha = sp4_uniform(((j & 1) ? -1.0 : 1.0) * p.pc[j] * (isW ? 1.0 : (double)j));
+                    const double beta = sp4_uniform((!isW && j == 0) ? 1.0 : h);
+                    SP4_STAMP();
+                    double x[SPD];  // (read right before the product: 54 registers that nothing else should have to live beside)
                     if (act) {
 #pragma unroll
                         for (int i = 0; i < SPD; ++i) x[i] = Xt[own + i];
                     }
-                    if (isW) {  // every drive wave has gathered the level this product overwrites
-                        for (int l = 0; l < SPM; ++l) gave_up = sp4_wait(sync, SP4_F_G + l, it * q + s + 1, gave_up);
-                    }
-                    const double alpha = ((j & 1) ? -1.0 : 1.0) * p.pc[j] * (isW ? 1.0 : (double)j);
-                    const double beta = (!isW && j == 0) ? 1.0 : h;
                     if (act) sp4_product(x, (j & 1) ? oS : oD, oX, oXx, alpha, beta, half ? -beta : beta, tab, cf);
-                    if (isW && j >= 1) {
-                        wave_lds_sync();
-                        sp4_post(sync + SP4_F_W, it * q + s + 2, lane);
-                    }
+                    SP4_STAMP();
+                    if (isW && j >= 1) sp4_post(sync + SP4_F_W, it * q + s + 2, lane);
                 }
-                wave_lds_sync();
                 sp4_post(sync + (isW ? SP4_F_DW : SP4_F_DV), it + 1, lane);  // this wave's reads of D, S are complete
-                const long long bk = (long long)b * p.K + k;
-                if (isW) {
-                    if (p.delta) store_tile(Xt, p.delta + bk * xd + (long long)c0 * n, n, nce);
-                } else {
-                    store_tile(Xt, p.jac + bk * p.jac_per + 2 * blk + ((long long)c0 * (m + 1) + m) * n, (long long)(m + 1) * n, nce);
-                }
-                wave_lds_sync();  // (the tile is rewritten by the next item's level q)
+                sp4_post(sync + SP4_F_O + (isW ? 0 : 1), it + 1, lane);       // ... and its output vector
+                SP4_STAMP();
             }
         } else {
             // ---- dW_l (d delta / du_l) ----------------------------------------------------------------------------------------
             const int l = wave - 3;
             double *Xt = dWt + l * SP4TILE;
-            for (int it = 0; it < n_my; ++it) {
+            for (int it = 0; it < n_my && !no_chains; ++it) {
                 int c0, nce, k, b;
                 decode(it, c0, nce, k, b);
                 SP4_LANEPOS();
+                SP4_STAMP();
                 const unsigned oX = sp4_lds_off(Xt + own), oXx = sp4_lds_off(Xt + oth);
                 const double sb = half ? 1.0 : -1.0;
                 const bool act = c < nce;
@@ -256,38 +303,42 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 scalars(k, b, h, cf, tab);
                 // level q - 1: dW = h G_l W_q
                 gave_up = sp4_wait(sync, SP4_F_W, it * q + 1, gave_up);
+                outputs_taken(it);  // the previous item has left this tile
                 if (act) {
                     SP4_GATHER_SWITCH(l, Wt + own, Wt + oth, Xt + own, h, sb, mg)
                 }
                 wave_lds_sync();
                 sp4_post(sync + SP4_F_G + l, it * q + 1, lane);
+                const double hu = sp4_uniform(h);
 #pragma unroll 1
                 for (int s = 1; s < q; ++s) {
+                    gave_up = sp4_wait(sync, SP4_F_W, it * q + s + 1, gave_up);
                     double x[SPD];
                     if (act) {
 #pragma unroll
                         for (int i = 0; i < SPD; ++i) x[i] = Xt[own + i];
                     }
-                    gave_up = sp4_wait(sync, SP4_F_W, it * q + s + 1, gave_up);
                     wave_lds_sync();  // (x is in registers before the gather rewrites the tile)
                     if (act) {
                         SP4_GATHER_SWITCH(l, Wt + own, Wt + oth, Xt + own, h, sb, mg)
                     }
                     wave_lds_sync();
                     sp4_post(sync + SP4_F_G + l, it * q + s + 1, lane);
-                    if (act) sp4_product(x, oX, oX, oXx, 1.0, h, half ? -h : h, tab, cf);  // tile = h G_l W_old + h G dW_old
+                    SP4_STAMP();
+                    if (act) sp4_product(x, oX, oX, oXx, 1.0, hu, half ? -hu : hu, tab, cf);  // tile = h G_l W_old + h G dW_old
+                    SP4_STAMP();
                 }
-                const long long bk = (long long)b * p.K + k;
-                store_tile(Xt, p.jac + bk * p.jac_per + 2 * blk + ((long long)c0 * (m + 1) + l) * n, (long long)(m + 1) * n, nce);
-                wave_lds_sync();
+                sp4_post(sync + SP4_F_O + 2 + l, it + 1, lane);
+                SP4_STAMP();
             }
         }
     } else if (wave == SP4_WLOAD) {
         // ================================== loader: D, S of every item (lane = row) ============================================
         constexpr int NB = 9;  // columns per batch of loads
-        for (int it = 0; it < n_my; ++it) {
+        for (int it = 0; it < n_my && !no_chains; ++it) {
             int c0, nce, k, b;
             decode(it, c0, nce, k, b);
+            SP4_STAMP();
             const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + p.x_offs[p.z_batch_stride ? 0 : b] + (long long)c0 * n + (lane < n ? lane : 0);
             const double *zn = zk + p.z_dim;
             bool first = true;
@@ -317,26 +368,49 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             }
             wave_lds_sync();
             sp4_post(sync + SP4_F_IN, it + 1, lane);
+            SP4_STAMP();
+        }
+    } else if (wave == SP4_WWRITE) {
+        // ================================== writer: a finished item's delta and tail block, tiles -> memory ====================
+        // One wave stores the item's nce (m + 1) n tail values (and its nce n residuals) as ONE contiguous run, 1 KiB per
+        // instruction: written by the chains themselves, every store covered pieces of three 432-byte runs and neighbouring
+        // runs came from different waves at different times (1.7 % of the bytes cost 10 % of the launch).
+        for (int it = 0; it < n_my && !no_chains && !tails_by_stream; ++it) {
+            int c0, nce, k, b;
+            decode(it, c0, nce, k, b);
+            const long long bk = (long long)b * p.K + k;
+            for (int w = 0; w < SP4_NOUT; ++w) gave_up = sp4_wait(sync, SP4_F_O + w, it + 1, gave_up);
+            SP4_STAMP();
+            if (!no_tails) store_outputs(c0, nce, bk, 0, 1, p.tail_mode);
+            wave_lds_sync();
+            sp4_post(sync + SP4_F_OC, it + 1, lane);  // the chains may rewrite their tiles
+            SP4_STAMP();
         }
     } else {
         // ================================== stream waves ========================================================================
+        __builtin_amdgcn_s_setprio(3);  // few instructions, each of them keeps the memory system busy
         constexpr int hn = n >> 1;
         constexpr int pstep = (64 * SP4_NSTREAM) / hn > 0 ? (64 * SP4_NSTREAM) / hn : 1;
+        constexpr int NSP = (n + pstep - 1) / pstep;  // column positions per thread
         for (int it = 0; it < n_my; ++it) {
             int c0, nce, k, b;
             decode(it, c0, nce, k, b);
-            // (an opaque copy per item: derived from `tid` directly, the 24 tile addresses below are hoisted out of the item loop
+            // (an opaque copy per item: derived from `tid` directly, the tile addresses below are hoisted out of the item loop
             //  and spilled)
             int stid = tid - 64 * SP4_WSTREAM;
             asm volatile("" : "+v"(stid));
             const int pi = 2 * (stid % hn), pj0 = stid / hn;
             const bool pact = pj0 < pstep;
-            gave_up = sp4_wait(sync, SP4_F_B, it + 1, gave_up);
-            // entry (i, j) of the n x n iso matrix [[A, -B], [B, A]] whose first d columns are a tile: j >= d mirrors into column
-            // j - d, rows i < d from row i + d with the sign flipped, rows i >= d from row i - d
-            double bpr[PCL_NSP][2], bmr[PCL_NSP][2];
+            const double h = ((sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim))[p.dt_off];
+            SP4_STAMP();
+            // -B^+ and B^- of this thread's positions, folded power by power as the P wave publishes them.  Entry (i, j) of the
+            // n x n iso matrix [[A, -B], [B, A]] whose first d columns are a tile: j >= d mirrors into column j - d, rows i < d
+            // from row i + d with the sign flipped, rows i >= d from row i - d.
+            double bpr[NSP][2], bmr[NSP][2];
+            int toff[NSP][2];
+            unsigned flip = 0;  // bit 2 r + e: the mirrored entry changes sign
 #pragma unroll
-            for (int r = 0; r < PCL_NSP; ++r) {
+            for (int r = 0; r < NSP; ++r) {
                 const int j = min(pj0 + pstep * r, n - 1);
                 const bool mir = j >= d;
                 const int jj = mir ? j - d : j;
@@ -344,14 +418,58 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 for (int e = 0; e < 2; ++e) {
                     const int i = pi + e;
                     const int ii = mir ? (i < d ? i + d : i - d) : i;
-                    const double sg = (mir && i < d) ? -1.0 : 1.0;
-                    bpr[r][e] = -sg * Bpt[jj * SP4CS + ii];
-                    bmr[r][e] = sg * Bmt[jj * SP4CS + ii];
+                    toff[r][e] = jj * SP4CS + ii;
+                    flip |= (mir && i < d) ? 1u << (2 * r + e) : 0u;
+                    const double id = i == j ? 1.0 : 0.0;
+                    bpr[r][e] = -id;
+                    bmr[r][e] = id;
                 }
             }
-            wave_lds_sync();
-            sp4_arrive(sync + SP4_F_C, lane);  // the P wave may form the next item's values
-            if (pact) {
+            double hp = 1.0, hm = 1.0;
+#pragma unroll 1
+            for (int j = 1; j <= q; ++j) {
+                const int L = it * q + j - 1;
+                const double *T = Pt + (L % SP4NP) * SP4TILE;
+                hp *= h;
+                hm *= -h;
+                const double cp = p.pc[j] * hp, cm = p.pc[j] * hm;
+                gave_up = sp4_wait(sync, SP4_F_B, L + 1, gave_up);
+                double v[NSP][2];
+#pragma unroll
+                for (int r = 0; r < NSP; ++r)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) v[r][e] = T[toff[r][e]];
+#pragma unroll
+                for (int r = 0; r < NSP; ++r)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const double g = (flip >> (2 * r + e)) & 1u ? -v[r][e] : v[r][e];
+                        bpr[r][e] = __builtin_fma(-cp, g, bpr[r][e]);
+                        bmr[r][e] = __builtin_fma(cm, g, bmr[r][e]);
+                    }
+                wave_lds_sync();
+                sp4_post(sync + SP4_F_C + (wave - SP4_WSTREAM), L + 1, lane);  // the P wave may rewrite this tile
+            }
+            SP4_STAMP();
+            // tail_mode 3: this wave's share of the item's residuals and tails goes into its own store stream as soon as every chain
+            // has finished the item -- checked between two columns of blocks, never waited for before the last block is out (the
+            // chains run several times faster than the stream; behind the last block the stores would lengthen a one-item launch)
+            bool tails_out = !(tails_by_stream && !no_chains);
+            auto try_tails = [&](bool wait) {
+                if (tails_out) return;
+                if (wait) {
+                    for (int w = 0; w < SP4_NOUT; ++w) gave_up = sp4_wait(sync, SP4_F_O + w, it + 1, gave_up);
+                } else {
+                    bool ready = true;
+                    for (int w = 0; w < SP4_NOUT; ++w) ready = ready && __hip_atomic_load(sync + SP4_F_O + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= it + 1;
+                    if (!ready) return;
+                }
+                if (!no_tails) store_outputs(c0, nce, (long long)b * p.K + k, wave - SP4_WSTREAM, SP4_NSTREAM, 0);
+                wave_lds_sync();
+                sp4_post(sync + SP4_F_TS + (wave - SP4_WSTREAM), it + 1, lane);
+                tails_out = true;
+            };
+            {
                 int cbeg = c0, cend = c0 + nce;
                 if (p.compact) {  // unique blocks only: the piece that holds column 0 writes the single copy
                     cbeg = 0;
@@ -359,16 +477,27 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 }
                 double *o = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn + pi;
                 for (int cq = cbeg; cq < cend; ++cq, o += nn) {
+                    if (pact && !no_blocks) {
 #pragma unroll
-                    for (int r = 0; r < PCL_NSP; ++r) {
-                        const int j = pj0 + pstep * r;
-                        if (j < n) {
-                            store2(o + n * j, bpr[r][0], bpr[r][1], p.nt);
-                            store2(o + blk + n * j, bmr[r][0], bmr[r][1], p.nt);
+                        for (int r = 0; r < NSP; ++r) {
+                            const int j = pj0 + pstep * r;
+                            if (j < n) {
+                                store2(o + n * j, bpr[r][0], bpr[r][1], p.nt);
+                                store2(o + blk + n * j, bmr[r][0], bmr[r][1], p.nt);
+                            }
                         }
                     }
+                    try_tails(false);
                 }
             }
+            try_tails(true);
+            SP4_STAMP();
+#ifdef PCL_PROFILE
+            if (p.prof & 16) {  // ... and gone
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SP4_STAMP();
+            }
+#endif
         }
     }
     if (gave_up && lane == 0) p.jac[0] = __builtin_nan("");  // a wait gave up: visible in the values instead of a hung device

@@ -96,9 +96,11 @@ struct pcl_ctx {
     double *dsp_coef_n = nullptr;
     // pattern-compiled FUSED residual + Jacobian kernel (pcl_codegen_v4.hpp, any Pade order): plan, drift tables, magnitudes
     pcl_codegen::V4Plan *v4_plan = nullptr;
-    double *dv4_tab = nullptr, *dv4_mags = nullptr;
+    double *dv4_tab = nullptr, *dv4_mags = nullptr, *dv4_dcf = nullptr;
     hipFunction_t v4_f = nullptr;
     int v4_failed = 0;
+    int64_t opt_v4_variant = 0;     // PCL_PROFILE builds: timing variants of the generated product (wrong results)
+    int64_t opt_v4_tail_mode = 3;   // kernel 4: who stores delta and the tails: 0 the writer wave | 1 ... nontemporal | 2 ... write-through | 3 the stream waves (default)
     int64_t opt_eval_kernel = 0;    // 0 auto | 1 matrix-core residual kernel | 2 pattern-compiled
     int64_t opt_column_kernel = 1;  // fused residual + Jacobian, column work: 1 matrix cores (kernel 3's matrix role; default) | 2 pattern-compiled column kernel + stream-only kernel 3 (experimental: correct, not faster yet -- DESIGN 4.8)
     // staging for the host-pointer entry points
@@ -128,6 +130,8 @@ struct pcl_ctx {
     double *dphik = nullptr;     // merit scratch: per-interval partial sums
     double *dmcols = nullptr;    // fused merit: per-column partial dot products written by fused kernel 3
     unsigned int *dmticket = nullptr;  // ... arrival ticket of pcl_merit_finish_kernel (zero between launches)
+    bool tickets_dirty = true;   // the arrival tickets (objective sum, merit finish) are re-zeroed on the stream before their next use:
+                                 // set at allocation and whenever the stream changes (the last-arriving workgroup resets them otherwise)
     const double *merit_lam = nullptr;  // set for the duration of pcl_eval_jac_merit_dev
     int merit_want = 0, merit_fused = 0;
     double *dgrad = nullptr, *dval = nullptr;  // staging of the host-pointer objective call
@@ -186,6 +190,15 @@ struct DeviceGuard {
 #define ON_DEVICE(ctx)                                                                                         \
     DeviceGuard dev_guard_((ctx)->device);                                                                     \
     if (dev_guard_.err != hipSuccess) return fail(ctx, PCL_EHIP, "hipSetDevice(%d): %s", (ctx)->device, hipGetErrorString(dev_guard_.err))
+
+// LDS of the fused pattern-compiled kernel: m + 4 chain tiles (D, S, W, V, dW_l) + np tiles of the powers of G + counters
+static size_t v4_lds_bytes(int d, int m, int np) { return ((size_t)(m + 4 + np) * d * (2 * d + 1) + 16) * sizeof(double); }
+// tiles for the powers of G: all q when they fit (the stream never waits for the P wave), else as many as fit (>= 2)
+static int v4_power_tiles(int d, int m, int q, size_t max_lds) {
+    int np = q;
+    while (np > 2 && v4_lds_bytes(d, m, np) > max_lds) --np;
+    return v4_lds_bytes(d, m, np) <= max_lds ? np : 0;
+}
 
 static long long jac_per_full(const pcl_ctx *c) {
     return 2LL * c->cols * c->n * c->n + c->x_dim * (c->desc.n_drives + 1);
@@ -422,8 +435,7 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     }
     if (ctx->sp_plan) {  // the fused kernel of the same family: one LDS tile per chain (m + 7 tiles of d (n + 1) doubles)
         pcl_codegen::V4Plan v4 = pcl_codegen::make_v4_plan(d, m, dsc->G0, dsc->per_member_G0 ? dsc->batch : 1, dsc->Gj);
-        const size_t lds4 = ((size_t)(m + 7) * d * (n + 1) + 16) * sizeof(double);
-        if (v4.ok && lds4 <= (size_t)ctx->max_lds) ctx->v4_plan = new pcl_codegen::V4Plan(std::move(v4));
+        if (v4.ok && v4_power_tiles(d, m, dsc->pade_order / 2, (size_t)ctx->max_lds) > 0) ctx->v4_plan = new pcl_codegen::V4Plan(std::move(v4));
     }
     std::vector<double> g0(dsc->G0, dsc->G0 + nn * (dsc->per_member_G0 ? dsc->batch : 1));
     CREATE_TRY(upload(ctx, &ctx->dG0, g0));
@@ -469,6 +481,7 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
         mg.resize(std::max<size_t>(mg.size(), 1) + 16, 0.0);
         CREATE_TRY(upload(ctx, &ctx->dv4_tab, tab));
         CREATE_TRY(upload(ctx, &ctx->dv4_mags, mg));
+        CREATE_TRY(upload(ctx, &ctx->dv4_dcf, v4.dcf_vals));
     }
 #undef CREATE_TRY
 #undef CREATE_HIP
@@ -501,7 +514,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     for (void *q : {(void *)ctx->dsp_pos, (void *)ctx->dsp_coef, (void *)ctx->dsp_glv, (void *)ctx->dsp_gvals, (void *)ctx->dsp_pos_n, (void *)ctx->dsp_coef_n})
         if (q) (void)hipFree(q);
     delete ctx->sp_plan;
-    for (void *q : {(void *)ctx->dv4_tab, (void *)ctx->dv4_mags})
+    for (void *q : {(void *)ctx->dv4_tab, (void *)ctx->dv4_mags, (void *)ctx->dv4_dcf})
         if (q) (void)hipFree(q);
     delete ctx->v4_plan;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -790,9 +803,11 @@ std::string sparse_source(const pcl_codegen::SpPlan &plan, bool with_columns = f
            (with_columns ? "#include \"pcl_kernel_jac_sparse.hpp\"\n" : "");
 }
 // Source of the pattern-compiled fused residual + Jacobian kernel of one system at Pade order 2q (pcl_codegen_v4.hpp)
-std::string v4_source(const pcl_codegen::V4Plan &plan, int q) {
-    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q) + "#include \"pcl_kernel_fused_sparse.hpp\"\n";
+// (np: tiles of the powers of G -- v4_power_tiles)
+std::string v4_source(const pcl_codegen::V4Plan &plan, int q, int np, int variant = 0) {
+    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q, np, variant) + "#include \"pcl_kernel_fused_sparse.hpp\"\n";
 }
+
 }  // namespace
 
 // Inspection hooks of the fused pattern-compiled kernel (no device needed): its generated source, and the generator's term
@@ -801,7 +816,9 @@ extern "C" int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, c
     if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || !G0 || (m > 0 && !Gj) || !needed) return PCL_EINVAL;
     const pcl_codegen::V4Plan plan = pcl_codegen::make_v4_plan(d, m, G0, n_g0, Gj);
     if (!plan.ok) return PCL_ESHAPE;
-    const std::string src = v4_source(plan, q);
+    const int np = v4_power_tiles(d, m, q, 160 * 1024);
+    if (!np) return PCL_ESHAPE;
+    const std::string src = v4_source(plan, q, np);
     *needed = (int64_t)src.size() + 1;
     if (buf && cap > 0) {
         const size_t nb = std::min<size_t>((size_t)cap - 1, src.size());
@@ -1082,8 +1099,10 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact) {
     if (!v4_available(ctx) || !p.jac) return PCL_ENOTIMPL;
     const pcl_codegen::V4Plan &v4 = *ctx->v4_plan;
     fill_pade(p, ctx->desc.pade_order);
+    const int np = v4_power_tiles(p.d, p.m, p.q, (size_t)ctx->max_lds);
+    if (!np) return PCL_ENOTIMPL;
     if (!ctx->v4_f) {
-        const std::string src = v4_source(v4, p.q);
+        const std::string src = v4_source(v4, p.q, np, (int)ctx->opt_v4_variant);
         const std::string key = "fused-sparse:" + std::to_string(p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
         ctx->v4_f = jit_compile(ctx->device, key, src, "pcl_fused_sparse_kernel", true);
         if (!ctx->v4_f) {
@@ -1107,13 +1126,15 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact) {
     p.S = (d + p.nc - 1) / p.nc;
     p.all_matrix = 0;
     p.n_stream = 0;
+    p.tail_mode = (int)ctx->opt_v4_tail_mode;
     const long long units = p.contig ? bk * d : bk * p.S;
     if (units > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
     const long long g = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, units) : std::min<long long>(units, ncu);
-    const size_t lds = ((size_t)(m + 7) * d * (p.n + 1) + 16) * sizeof(double);
+    const size_t lds = v4_lds_bytes(d, m, np);
     const double *tab = ctx->dv4_tab + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_drift_pad : 0);
-    void *args[] = {(void *)&p, (void *)&tab, (void *)&ctx->dv4_mags};
-    HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_f, (unsigned)g, 1, 1, 64 * (m + 8), 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
+    const double *dcf = ctx->dv4_dcf + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_dcf_pad : 0);
+    void *args[] = {(void *)&p, (void *)&tab, (void *)&ctx->dv4_mags, (void *)&dcf};
+    HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_f, (unsigned)g, 1, 1, 64 * (m + 9), 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
     ctx->last_kernel = 40 + p.q;
     ctx->last_n_stream = 0;
     return PCL_OK;
@@ -1181,12 +1202,14 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     // streaming stores of the Jacobian blocks (auto): write-through while the launch's values fit the infinity cache with room to
     // spare (one trajectory of config 3: 133 MB), plain write-back above (see store2)
     if (ctx->opt_nt < 0 && want_jac && !compact && (long long)ctx->win_count * ctx->K * jac_per_full(ctx) * 8 <= (192LL << 20)) p.nt = 2;
-    // kernel_version 4: the pattern-compiled fused kernel (sparse iso generators, any order)
-    if (want_jac && ctx->opt_kernel == 4) {
+    // kernel_version 4: the pattern-compiled fused kernel (sparse iso generators, any order).  auto: every order but 4 (where
+    // the matrix-core kernel 3 measures the same or better: both run at the store stream's rate)
+    const bool v4_auto = ctx->opt_kernel == 0 && ctx->desc.pade_order != 4 && !ctx->opt_general && ctx->opt_general_version == 0;
+    if (want_jac && (ctx->opt_kernel == 4 || v4_auto)) {
         const bool want_merit = ctx->merit_want && !compact && delta && ctx->win_first == 0 && ctx->win_count == ctx->desc.batch;
         const int rc = want_merit ? PCL_ENOTIMPL : launch_fused_v4(ctx, p, compact);
         if (rc != PCL_ENOTIMPL) return rc;
-        if (!want_merit) return fail(ctx, PCL_ESHAPE, "kernel_version=4 needs sparse exact-iso generators of a unitary problem (9 <= d, tiles within LDS), 1..6 drives and jit=1 (%s)", g_jit_note.c_str());
+        if (!want_merit && ctx->opt_kernel == 4) return fail(ctx, PCL_ESHAPE, "kernel_version=4 needs sparse exact-iso generators of a unitary problem (9 <= d, tiles within LDS), 1..6 drives and jit=1 (%s)", g_jit_note.c_str());
     }
     if (ctx->desc.pade_order != 4 || ctx->opt_general || ctx->vec) return launch_pade_general(ctx, p, want_jac);
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
@@ -1336,7 +1359,6 @@ not_v3:
             // one wave per interval; the intervals are spread over the CUs first, then over the waves of a workgroup (<= 8)
             const long long ncu = std::max(ctx->n_cu, 1);
             int nw = (int)std::min<long long>(8, std::max<long long>(1, (items + ncu - 1) / ncu));
-            if (getenv("PCL_EVAL_NW")) nw = atoi(getenv("PCL_EVAL_NW"));
             long long grid = std::min<long long>((items + nw - 1) / nw, ncu);
             if (ctx->opt_grid > 0) grid = std::min<long long>(ctx->opt_grid, (items + nw - 1) / nw);
             const size_t ldse = (size_t)nw * (sp.n + 1) * sp.d * sizeof(double);
@@ -1635,11 +1657,13 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
 extern "C" int pcl_set_stream(pcl_ctx *ctx, void *s) {
     if (!ctx) return PCL_EINVAL;
     ctx->stream = (hipStream_t)s;  // NULL is HIP's legacy default stream
+    ctx->tickets_dirty = true;
     return PCL_OK;
 }
 extern "C" int pcl_reset_stream(pcl_ctx *ctx) {
     if (!ctx) return PCL_EINVAL;
     ctx->stream = ctx->own_stream;
+    ctx->tickets_dirty = true;
     return PCL_OK;
 }
 extern "C" int pcl_sync(pcl_ctx *ctx) {
@@ -1926,10 +1950,12 @@ extern "C" int pcl_set_goal(pcl_ctx *ctx, const double *goal_iso_vec) {
     if (!goal_iso_vec) return fail(ctx, PCL_EINVAL, "pcl_set_goal: NULL");
     TRY(objective_unitary_only(ctx, "pcl_set_goal"));
     ON_DEVICE(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the context's stream is non-blocking: nothing else orders a launch in flight)
     if (ctx->dgoal) (void)hipFree(ctx->dgoal);
     ctx->dgoal = nullptr;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->dgoal, (size_t)ctx->x_dim * sizeof(double)));
-    HIP_TRY(ctx, hipMemcpy(ctx->dgoal, goal_iso_vec, (size_t)ctx->x_dim * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dgoal, goal_iso_vec, (size_t)ctx->x_dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_sub = 0;
     return PCL_OK;
 }
@@ -1944,6 +1970,7 @@ extern "C" int pcl_set_goal_subspace(pcl_ctx *ctx, const double *goal_sub_iso_ve
             if (subspace[j] == subspace[i]) return fail(ctx, PCL_EINVAL, "pcl_set_goal_subspace: index %d repeated", subspace[i]);
     }
     ON_DEVICE(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->dgoal) (void)hipFree(ctx->dgoal);
     if (ctx->dsub) (void)hipFree(ctx->dsub);
     ctx->dgoal = nullptr;
@@ -1951,21 +1978,24 @@ extern "C" int pcl_set_goal_subspace(pcl_ctx *ctx, const double *goal_sub_iso_ve
     ctx->n_sub = 0;
     HIP_TRY(ctx, hipMalloc((void **)&ctx->dgoal, (size_t)2 * ns * ns * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void **)&ctx->dsub, (size_t)ns * sizeof(int)));
-    HIP_TRY(ctx, hipMemcpy(ctx->dgoal, goal_sub_iso_vec, (size_t)2 * ns * ns * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMemcpy(ctx->dsub, subspace, (size_t)ns * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dgoal, goal_sub_iso_vec, (size_t)2 * ns * ns * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dsub, subspace, (size_t)ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_sub = ns;
     return PCL_OK;
 }
 extern "C" int pcl_set_weights(pcl_ctx *ctx, const double *w) {
     if (!ctx) return PCL_EINVAL;
     ON_DEVICE(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!w) {
         if (ctx->dweights) (void)hipFree(ctx->dweights);
         ctx->dweights = nullptr;
         return PCL_OK;
     }
     if (!ctx->dweights) HIP_TRY(ctx, hipMalloc((void **)&ctx->dweights, (size_t)ctx->desc.batch * sizeof(double)));
-    HIP_TRY(ctx, hipMemcpy(ctx->dweights, w, (size_t)ctx->desc.batch * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dweights, w, (size_t)ctx->desc.batch * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PCL_OK;
 }
 extern "C" int pcl_add_regularizer(pcl_ctx *ctx, int32_t off, int32_t dim, const double *R, int32_t dt_power) {
@@ -2014,6 +2044,11 @@ extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double
     if (!ctx->dobj) {  // [member terms | per-knot regulariser values | arrival ticket of the fused final sum]
         HIP_TRY(ctx, hipMalloc((void **)&ctx->dobj, ((size_t)D.batch + (size_t)nbuf * D.N + 1) * sizeof(double)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->dobj, 0, ((size_t)D.batch + (size_t)nbuf * D.N + 1) * sizeof(double), ctx->stream));
+    }
+    if (ctx->tickets_dirty) {  // (a switch of streams may have left the initial memset pending on the old one)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dobj + D.batch + (size_t)nbuf * D.N, 0, sizeof(double), ctx->stream));
+        if (ctx->dmticket) HIP_TRY(ctx, hipMemsetAsync(ctx->dmticket, 0, 64, ctx->stream));
+        ctx->tickets_dirty = false;
     }
     if (ctx->regs_dirty) {  // (re)upload the table; rare
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2105,6 +2140,13 @@ extern "C" int pcl_eval_jac_merit_dev(pcl_ctx *ctx, const double *Z, const doubl
     if (!ctx->dmticket) {
         HIP_TRY(ctx, hipMalloc((void **)&ctx->dmticket, 64));
         HIP_TRY(ctx, hipMemsetAsync(ctx->dmticket, 0, 64, ctx->stream));
+    } else if (ctx->tickets_dirty) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dmticket, 0, 64, ctx->stream));
+        if (ctx->dobj) {
+            const int nbuf_ = traj ? D.batch : 1;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dobj + D.batch + (size_t)nbuf_ * D.N, 0, sizeof(double), ctx->stream));
+        }
+        ctx->tickets_dirty = false;
     }
     // ONE launch: a workgroup per interval adds the columns, then the members (weights, member order); the workgroup that
     // arrives last adds phi over the intervals
@@ -2225,6 +2267,10 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
 #ifdef PCL_PROFILE
     else if (!strcmp(key, "profile_flags"))  // profiling experiments (results may be WRONG); not present in the shipped library
         ctx->opt_prof = v;
+    else if (!strcmp(key, "v4_variant")) {  // timing variants of kernel 4's generated product (WRONG results); recompiles
+        ctx->opt_v4_variant = v;
+        ctx->v4_f = nullptr;
+    }
 #endif
     else if (!strcmp(key, "host_threads"))  // host-pointer entry points: threads expanding the compact values (0 = auto)
         ctx->opt_host_threads = v < 0 ? 0 : v;
@@ -2253,6 +2299,10 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
     else if (!strcmp(key, "column_kernel")) {  // fused residual + Jacobian, column work: 1 kernel 3's matrix role (default), 2 pattern-compiled kernel + stream-only kernel 3 (experimental)
         if (v < 1 || v > 2) return fail(ctx, PCL_EINVAL, "column_kernel must be 1 or 2");
         ctx->opt_column_kernel = v;
+    }
+    else if (!strcmp(key, "v4_tail_mode")) {  // kernel 4: 0 writer wave, plain stores | 1 nontemporal | 2 write-through | 3 the stream waves store the tails
+        if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "v4_tail_mode must be 0 .. 3");
+        ctx->opt_v4_tail_mode = v;
     }
     else if (!strcmp(key, "eval_kernel")) {  // residual only: 0 auto, 1 matrix-core kernel, 2 pattern-compiled kernel
         if (v < 0 || v > 2) return fail(ctx, PCL_EINVAL, "eval_kernel must be 0, 1 or 2");

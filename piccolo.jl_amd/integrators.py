@@ -560,7 +560,7 @@ class HipPadeMultistart:
     seeds; BASELINE.json config 5).  Not a reference type: the reference has no multistart
     facility; each seed is its own NLP and owns rows/columns ``b``-major."""
 
-    def __init__(self, G_drift, G_drives, traj, batch, x_name=STATE, u_name="u", *, device=0, index_base=0):
+    def __init__(self, G_drift, G_drives, traj, batch, x_name=STATE, u_name="u", *, device=0, index_base=0, pade_order=4):
         G_drives = np.asarray(G_drives, dtype=np.float64)
         n = np.asarray(G_drift).shape[-1]
         m = G_drives.shape[0] if G_drives.size else 0
@@ -571,9 +571,10 @@ class HipPadeMultistart:
             d=n // 2, m=m, N=traj.N, z_dim=traj.dim, u_off=traj.components[u_name].start,
             dt_off=traj.components[traj.timestep].start, x_offs=[traj.components[x_name].start], G0=G_drift,
             Gj=G_drives.reshape(m, n, n), batch=batch, batch_mode=PCL_BATCH_TRAJ, device=device, index_base=index_base,
-            state_cols=xlen // n,
+            state_cols=xlen // n, pade_order=pade_order,
         )  # fmt: skip
         self.batch = batch
+        self.x_name = x_name
         self.x_dim = self._ctx.x_dim
         self.dim = self._ctx.n_rows
 
@@ -641,19 +642,38 @@ def BilinearIntegrator(system, traj, x_name=None, u_name="u", **kw):
     their drive generators too (each member uses its full ``sys.G`` [REF integrators.jl:149-162]) gets one context per
     member."""
     if isinstance(system, (list, tuple)):
+        from .quantum import OpenQuantumSystem
+        from .trajectory import DENSITY
+
         systems = list(system)
         if any(getattr(s, "time_dependent", False) for s in systems):
             raise NotImplementedError("time-dependent systems use TimeDependentBilinearIntegrator (out of scope)")
-        names = x_name or ["%s%d" % (STATE, i) for i in range(1, len(systems) + 1)]
+        # Every base the reference samples [REF integrators.jl:149-226 (_sampling_integrator)]: unitary and ket members carry one
+        # state each, MultiKet / MultiDensity members a LIST of sub-states (one integrator per sub-state, all on the member's
+        # system), density members their compact Lindbladian generators.  `x_name`: one entry per member, a name or a list of
+        # sub-state names; the result is flat, member-major, sub-states in order -- what the reference's reduce(vcat, ...) returns.
+        default = DENSITY if isinstance(systems[0], OpenQuantumSystem) else STATE
+        names = x_name or ["%s%d" % (default, i) for i in range(1, len(systems) + 1)]
         if len(names) != len(systems):
             raise ValueError("%d state names for %d systems" % (len(names), len(systems)))
+        per = [[nm] if isinstance(nm, str) else list(nm) for nm in names]
+        flat = [nm for p_ in per for nm in p_]
+        owner = [i for i, p_ in enumerate(per) for _ in p_]
         Gd = [s.G_drives_array() for s in systems]
-        if not all(np.array_equal(Gd[0], g) for g in Gd[1:]):
-            return [HipPadeIntegrator(s.G_drift, g, traj, nm, u_name, **kw) for s, g, nm in zip(systems, Gd, names)]
-        fused = HipPadeIntegrator(np.array([s.G_drift for s in systems]), Gd[0], traj, names, u_name, **kw)
-        core = _EnsembleCore(fused, len(systems))
-        return [HipPadeMemberIntegrator(core, i, nm, systems[i].G_drift, fused.G_drives, u_name, fused._sig, fused.pade_order)
-                for i, nm in enumerate(names)]  # fmt: skip
+
+        def fused_members(idx):  # one batched context over the (member, sub-state) pairs `idx` that share drive generators
+            fused = HipPadeIntegrator(np.array([systems[owner[j]].G_drift for j in idx]), Gd[owner[idx[0]]], traj, [flat[j] for j in idx], u_name, **kw)
+            core = _EnsembleCore(fused, len(idx))
+            return [HipPadeMemberIntegrator(core, a, flat[j], systems[owner[j]].G_drift, fused.G_drives, u_name, fused._sig, fused.pade_order)
+                    for a, j in enumerate(idx)]  # fmt: skip
+
+        if all(np.array_equal(Gd[0], g) for g in Gd[1:]):
+            return fused_members(list(range(len(flat))))
+        out = []  # members that differ in their drive generators too: a context per member (shared by its sub-states)
+        for i, s in enumerate(systems):
+            idx = [j for j in range(len(flat)) if owner[j] == i]
+            out += [HipPadeIntegrator(s.G_drift, Gd[i], traj, flat[idx[0]], u_name, **kw)] if len(idx) == 1 else fused_members(idx)
+        return out
     if getattr(system, "time_dependent", False):
         raise NotImplementedError("time-dependent systems use TimeDependentBilinearIntegrator (out of scope)")
     from .quantum import OpenQuantumSystem

@@ -5,7 +5,7 @@
 # generic functions live in the un-vendored DirectTrajOpt.jl (compat 0.9.5 / 0.10) and there is no Julia in the build
 # container, so this file has NOT been executed.  `selftest.jl` (next to this file) is the script a maintainer runs first:
 # it checks this glue against DirectTrajOpt's own `test_integrator` and against `BilinearIntegrator`, and lists the
-# DirectTrajOpt method names the glue had to guess (section "names to be matched" below).  All arithmetic is in the C
+# DirectTrajOpt generics the glue bound itself to at load time (`HipPade.BOUND_GENERICS`, section "adaptive binding" below).  All arithmetic is in the C
 # library (include/piccolo_hip.h); this file only marshals arguments.  See INTEGRATION.md.
 #
 #   plug-in points in the reference:
@@ -22,7 +22,7 @@ using NamedTrajectories
 using DirectTrajOpt
 import DirectTrajOpt: AbstractIntegrator
 using Piccolo: get_system, state_name, state_names, drive_name, sampling_member_states,
-               UnitaryTrajectory, KetTrajectory, MultiKetTrajectory, DensityTrajectory, SamplingTrajectory,
+               UnitaryTrajectory, KetTrajectory, MultiKetTrajectory, DensityTrajectory, MultiDensityTrajectory, SamplingTrajectory,
                compact_lindbladian_generators
 
 const LIB = get(ENV, "PICCOLO_HIP_LIB", "libpiccolo_hip.so")
@@ -180,19 +180,31 @@ end
 # context; members whose drive generators differ too (each member uses its full sys.G, [REF integrators.jl:149-162])
 # get a context each.
 function HipPadeIntegrator(qtraj::SamplingTrajectory, N::Int; kwargs...)
+    # Every base the reference samples [REF src/control/integrators.jl:149-226 (_sampling_integrator)]:
+    #   Unitary / Ket       one state per member                     -> one integrator per member
+    #   MultiKet            a Vector of ket names per member         -> one integrator per ket, all on the member's system
+    #   Density             compact Lindbladian of the member        -> one integrator per member (state vector of length levels^2)
+    #   MultiDensity        a Vector of density names per member     -> one integrator per density sub-state
+    # The result is flat, member-major, sub-states in order: the reference's `reduce(vcat, ...)`.
     base = qtraj.base_trajectory
-    base isa UnitaryTrajectory || base isa KetTrajectory ||
-        error("HipPadeIntegrator(::SamplingTrajectory): unitary and ket bases are implemented (got $(typeof(base)))")
-    sc = base isa KetTrajectory ? 1 : 0
+    dens = base isa DensityTrajectory || base isa MultiDensityTrajectory
+    base isa UnitaryTrajectory || base isa KetTrajectory || base isa MultiKetTrajectory || dens ||
+        error("HipPadeIntegrator(::SamplingTrajectory): unsupported base trajectory $(typeof(base))")
+    sc = base isa UnitaryTrajectory ? 0 : (dens ? -1 : 1)
     traj = NamedTrajectory(qtraj, N)
-    names = collect(Symbol, sampling_member_states(qtraj))
-    gens = [_generators(s) for s in qtraj.systems]
-    G0s = [g[1] for g in gens]
     u = drive_name(qtraj)
-    if all(g -> g[2] == gens[1][2], gens)       # exact equality: the same drive Hamiltonians in every member
-        return _integrators(G0s, gens[1][2], traj, names, u; state_cols = sc, kwargs...)
+    per = [s isa AbstractVector ? collect(Symbol, s) : Symbol[s] for s in sampling_member_states(qtraj)]   # sub-state names per member
+    gens = dens ? [begin
+                       Gd, Gs = compact_lindbladian_generators(sys)
+                       (Matrix{Float64}(Gd), [Matrix{Float64}(G) for G in Gs])
+                   end for sys in qtraj.systems] : [_generators(sys) for sys in qtraj.systems]
+    flat = reduce(vcat, per)
+    owner = reduce(vcat, [fill(i, length(p)) for (i, p) in enumerate(per)])
+    if all(g -> g[2] == gens[1][2], gens)       # exact equality: the same drive generators in every member -> ONE batched context
+        return _integrators([gens[i][1] for i in owner], gens[1][2], traj, flat, u; state_cols = sc, kwargs...)
     end
-    return [only(_integrators([G0s[i]], gens[i][2], traj, [names[i]], u; state_cols = sc, kwargs...)) for i in eachindex(names)]
+    # members that differ in their drive generators too: a context per member, shared by the member's sub-states
+    return reduce(vcat, [_integrators(fill(gens[i][1], length(per[i])), gens[i][2], traj, per[i], u; state_cols = sc, kwargs...) for i in eachindex(per)])
 end
 
 # ---- cached fused evaluation -------------------------------------------------------------------------------------
@@ -245,9 +257,11 @@ function DirectTrajOpt.eval_jacobian(B::HipPadeIntegrator, traj::NamedTrajectory
     return sparse(getfield(B, :jac_rows), getfield(B, :jac_cols), vals, getfield(B, :dim), getfield(B, :n_vars))
 end
 
-# ---- names to be matched to the installed DirectTrajOpt version (selftest.jl prints the candidates) ------------------
-# What DirectTrajOpt's MOI evaluator needs per IPM iteration, in the shapes this library produces them: triplet
-# structure queried once, values in that order.
+# ---- what DirectTrajOpt's MOI evaluator needs per IPM iteration, in the shapes this library produces them: triplet structure
+#      queried once, values in that order.  DirectTrajOpt is not vendored with Piccolo and its generic names differ between
+#      the 0.9 and 0.10 lines, so the methods are defined under this module's own names AND -- at load time -- as methods of
+#      whichever of the candidate generics the INSTALLED DirectTrajOpt defines (`_bind_to_directtrajopt!` below); selftest.jl
+#      prints what was bound.
 jacobian_structure(B::HipPadeIntegrator) = collect(zip(Int.(getfield(B, :jac_rows)), Int.(getfield(B, :jac_cols))))
 hessian_structure(B::HipPadeIntegrator) = collect(zip(Int.(getfield(B, :hess_rows)), Int.(getfield(B, :hess_cols))))
 
@@ -258,8 +272,14 @@ function eval_constraint_and_jacobian!(δ::AbstractVector{Float64}, vals::Abstra
     return nothing
 end
 
+# Jacobian values alone, in structure order (the in-place filler shape)
+function eval_jacobian_values!(vals::AbstractVector{Float64}, B::HipPadeIntegrator, z::AbstractVector{Float64})
+    copyto!(vals, view(_all_vals!(_core(B), z), _jrng(B)))
+    return vals
+end
+
 # Hessian of the Lagrangian of THIS integrator's rows: μ is the block's multiplier slice (length B.dim); runs on a
-# one-member window of the shared context (Pade order 4)
+# one-member window of the shared context (every Pade order)
 function eval_hessian_of_lagrangian!(vals::Vector{Float64}, B::HipPadeIntegrator, z::Vector{Float64}, μ::Vector{Float64})
     core = _core(B)
     length(μ) == getfield(B, :dim) || throw(DimensionMismatch("μ has length $(length(μ)), integrator dim is $(getfield(B, :dim))"))
@@ -273,6 +293,50 @@ function eval_hessian_of_lagrangian!(vals::Vector{Float64}, B::HipPadeIntegrator
     end
     return nothing
 end
+
+# Adaptive binding.  For every candidate generic the installed DirectTrajOpt defines, a method for HipPadeIntegrator is added
+# that forwards to the functions above; the argument shapes tried are the ones DirectTrajOpt's own BilinearIntegrator methods
+# use in the 0.9 / 0.10 lines (structure: (B) or (B, traj); in-place values: (vals, B, traj) / (B, traj) -> values;
+# Hessian of the Lagrangian: (vals, B, traj, μ) / (B, traj, μ)).  Names the installed version does not define are skipped --
+# the module-local functions stay available either way.  Returns the list of names bound (selftest.jl prints it).
+const BOUND_GENERICS = Symbol[]
+function _bind_to_directtrajopt!()
+    empty!(BOUND_GENERICS)
+    z_of(traj) = traj isa NamedTrajectory ? traj.datavec : traj
+    for nm in (:jacobian_structure, :get_jacobian_structure)
+        isdefined(DirectTrajOpt, nm) || continue
+        @eval DirectTrajOpt.$nm(B::HipPadeIntegrator, args...) = jacobian_structure(B)
+        push!(BOUND_GENERICS, nm)
+    end
+    for nm in (:hessian_structure, :hessian_of_lagrangian_structure, :get_hessian_structure)
+        isdefined(DirectTrajOpt, nm) || continue
+        @eval DirectTrajOpt.$nm(B::HipPadeIntegrator, args...) = hessian_structure(B)
+        push!(BOUND_GENERICS, nm)
+    end
+    for nm in (:jacobian!, :eval_jacobian!, :jacobian_values!)
+        isdefined(DirectTrajOpt, nm) || continue
+        @eval DirectTrajOpt.$nm(vals::AbstractVector{Float64}, B::HipPadeIntegrator, traj, args...) =
+            eval_jacobian_values!(vals, B, $z_of(traj))
+        push!(BOUND_GENERICS, nm)
+    end
+    for nm in (:hessian_of_lagrangian!, :eval_hessian_of_lagrangian!, :hessian_of_lagrangian_values!)
+        isdefined(DirectTrajOpt, nm) || continue
+        @eval DirectTrajOpt.$nm(vals::AbstractVector{Float64}, B::HipPadeIntegrator, traj, μ::AbstractVector{Float64}, args...) =
+            eval_hessian_of_lagrangian!(vals isa Vector{Float64} ? vals : (vals .= vals; vals), B, Vector{Float64}($z_of(traj)), Vector{Float64}(μ))
+        push!(BOUND_GENERICS, nm)
+    end
+    for nm in (:hessian_of_lagrangian, :eval_hessian_of_lagrangian)
+        isdefined(DirectTrajOpt, nm) || continue
+        @eval function DirectTrajOpt.$nm(B::HipPadeIntegrator, traj, μ::AbstractVector{Float64}, args...)
+            vals = Vector{Float64}(undef, _core(B).hess_per)
+            eval_hessian_of_lagrangian!(vals, B, Vector{Float64}($z_of(traj)), Vector{Float64}(μ))
+            return sparse(Int.(getfield(B, :hess_rows)), Int.(getfield(B, :hess_cols)), vals, getfield(B, :n_vars), getfield(B, :n_vars))
+        end
+        push!(BOUND_GENERICS, nm)
+    end
+    return BOUND_GENERICS
+end
+__init__() = _bind_to_directtrajopt!()
 
 # ---- B.f(x_next, x, u, Δt): the scalar one-interval form the reference reads [REF integrators.jl:518-525,552;
 #      src/control/display/inspect.jl:630-636] -- a cached 2-knot context with layout [x | Δt | u] -----------------------

@@ -108,7 +108,7 @@ class Objective:
             ctxs = [core.ctx]
         else:
             ctxs = [b.ctx for b in members]
-        if inf:
+        if inf and all(hasattr(b, "x_names") for b in members):  # (a multistart context carries one state name for all its seeds)
             t = inf[0]
             have = [nm for b in members for nm in (b.x_names if not hasattr(b, "ensemble") else [b.x_name])]
             if list(t.names) != have:

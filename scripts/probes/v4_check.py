@@ -34,9 +34,10 @@ for N in ((5,) if quick else (5, 100)):
         c = ctx(lay, order)
         c.set_option("kernel_version", 4)
         first = None
-        for contig, cps, hp in ((-1, 0, 1), (0, 0, 1), (1, 0, 1), (0, 5, 1), (0, 27, 1), (0, 1, 1), (-1, 0, 2)):
+        for contig, cps, hp, tm in ((-1, 0, 1, 0), (0, 0, 1, 0), (1, 0, 1, 0), (0, 5, 1, 0), (0, 27, 1, 0), (0, 1, 1, 0), (-1, 0, 2, 0), (1, 0, 1, 3), (0, 5, 1, 3), (0, 0, 1, 2), (1, 0, 1, 1)):
             c.set_option("contiguous", contig)
             c.set_option("cols_per_slice", cps)
+            c.set_option("v4_tail_mode", tm)
             c.set_option("host_path", hp)  # 1: full values (the streamed blocks), 2: compact values + host expansion
             t0 = time.time()
             delta, vals = c.eval_jac(Z)
@@ -52,9 +53,40 @@ for N in ((5,) if quick else (5, 100)):
                 first = (delta, vals)
             good = ed < 1e-11 and ej < 1e-11 and same and c.get_option("last_kernel") == 40 + order // 2
             ok &= good
-            print("N=%3d order %2d contig %2d cps %2d host_path %d: delta %.1e blocks %.1e tails %.1e bitwise-equal-splits %s kernel %d (%.2f s) %s" % (
-                N, order, contig, cps, hp, ed, eb, et, same, c.get_option("last_kernel"), dt, "ok" if good else "FAIL"), flush=True)
+            print("N=%3d order %2d contig %2d cps %2d host_path %d tail_mode %d: delta %.1e blocks %.1e tails %.1e bitwise-equal-splits %s kernel %d (%.2f s) %s" % (
+                N, order, contig, cps, hp, tm, ed, eb, et, same, c.get_option("last_kernel"), dt, "ok" if good else "FAIL"), flush=True)
         c.close()
+# ensemble: per-member drifts (config 4's members: 27 drift classes, some of them streamed), members of one trajectory buffer
+from oracle import ref_lib
+for M, N in ((3, 6), (8, 100)):
+    psys = synthetic.config4_members(0, M)
+    osys = [po.System(s.H_drift, s.H_drives, s.drive_bounds) for s in psys]
+    traj = synthetic.synthetic_ensemble(psys, N, seed=20260929 + 4)
+    xd = 2 * 27 * 27
+    lay = po.Layout(d=27, m=6, N=N, z_dim=traj.dim, x_off=0, u_off=traj.components["u"].start, dt_off=traj.components["Δt"].start)
+    Z = traj.datavec.reshape(N, traj.dim)
+    names = ["Ũ⃗%d" % (i + 1) for i in range(M)]
+    Bi = pa.HipPadeIntegrator(np.array([s.G_drift for s in psys]), psys[0].G_drives_array(), traj, names)
+    c = Bi.ctx
+    c.set_option("host_path", 1)
+    per_d, per_j = xd * lay.K, po.jac_nnz_per_interval(lay) * lay.K
+    refs = [ref_lib.eval_jac(Z, lay, s.G_drift, np.array(s.G_drives), x_off=i * xd) for i, s in enumerate(osys)]
+    d_ref = np.concatenate([r[0].reshape(-1) for r in refs])
+    j_ref = np.concatenate([r[1].reshape(-1) for r in refs])
+    c.set_option("kernel_version", 4)
+    for contig, tm in ((-1, 0), (1, 3), (0, 3)):
+        c.set_option("contiguous", contig)
+        c.set_option("v4_tail_mode", tm)
+        delta, vals = c.eval_jac(traj.datavec)
+        good = err(delta, d_ref) < 1e-12 and err(vals, j_ref) < 1e-12 and c.get_option("last_kernel") == 42
+        ok &= good
+        print("ensemble M=%d N=%d contig %d tail_mode %d: delta %.1e jac %.1e kernel %d %s" % (M, N, contig, tm, err(delta, d_ref), err(vals, j_ref), c.get_option("last_kernel"), "ok" if good else "FAIL"), flush=True)
+    c.set_member_window(1, 1)  # one member of the ensemble (what a per-member Hessian / Jacobian call runs on)
+    delta, vals = c.eval_jac(traj.datavec)
+    good = err(delta, d_ref[per_d:2 * per_d]) < 1e-12 and err(vals, j_ref[per_j:2 * per_j]) < 1e-12
+    ok &= good
+    print("ensemble M=%d member window 1: delta %.1e jac %.1e %s" % (M, err(delta, d_ref[per_d:2 * per_d]), err(vals, j_ref[per_j:2 * per_j]), "ok" if good else "FAIL"), flush=True)
+    Bi.close()
 print("PARITY", "OK" if ok else "FAILED", flush=True)
 
 # ---- rates ----------------------------------------------------------------------------------------------------------------
@@ -72,11 +104,12 @@ with torch.cuda.stream(stream):
             c.set_stream(stream.cuda_stream)
             dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
             vd = torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")
-            for kv, contig in ((0, -1), (4, -1), (4, 1), (4, 0)):
-                if B == 8 and contig == 0:
+            for kv, contig, tm in ((0, -1, 0), (4, -1, 0), (4, -1, 1), (4, -1, 2), (4, -1, 3), (4, 1, 0), (4, 1, 3)):
+                if (B == 8 and contig == 1) or (order == 10 and tm in (1, 2)):
                     continue
                 c.set_option("kernel_version", kv)
                 c.set_option("contiguous", contig)
+                c.set_option("v4_tail_mode", tm)
                 for _ in range(5):
                     c.eval_jac_dev(Zd, dd, vd)
                 stream.synchronize()
@@ -88,6 +121,6 @@ with torch.cuda.stream(stream):
                 e1.record(stream)
                 stream.synchronize()
                 us = e0.elapsed_time(e1) / reps * 1e3
-                print("B=%d order %2d kernel_version %d contig %2d: %.1f us/launch (%.2f TB/s algorithmic) kernel id %d" % (
-                    B, order, kv, contig, us, B * 135119952 / us / 1e6, c.get_option("last_kernel")), flush=True)
+                print("B=%d order %2d kernel_version %d contig %2d tail_mode %d: %.1f us/launch (%.2f TB/s algorithmic) kernel id %d" % (
+                    B, order, kv, contig, tm, us, B * 135119952 / us / 1e6, c.get_option("last_kernel")), flush=True)
             c.close()

@@ -9,10 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-# The parity tests drive the work-split options of the FULL-values kernels through the host-pointer entry points, so those
-# deliver the full values over PCIe here; the default delivery (compact values + host expansion) is compared bitwise with
-# it, shape by shape, in test_host_delivery_paths_agree_bitwise.
-os.environ.setdefault("PCL_HOST_PATH", "1")
+# The library's default host delivery (compact values + threaded host expansion) stays the default here: every test that goes
+# through the reference-style objects (BilinearIntegrator, member integrators, multistart) runs it.  Tests that drive the
+# work-split options of the FULL-values kernels through the host-pointer entry points ask for `host_path` 1 explicitly
+# (tests/test_parity_gpu.py: make_ctx), and the core vectors run both.
 
 
 def pytest_configure(config):

@@ -193,6 +193,38 @@ def test_oracle_hessian_finite_differences():
     assert np.abs(Hd - Hd.T).max() == 0
 
 
+@pytest.mark.parametrize("cfg,order", [(1, 4), (2, 4), (2, 8), (1, 10)])
+def test_oracle_hessian_complex_step_of_the_pinned_jacobian(cfg, order):
+    """The tightest pin the Hessian of the Lagrangian can have here: the COMPLEX-STEP derivative of the Jacobian the tests above pin on
+    the Frechet derivative of the reference's exp constraint.  g(z) = J(z)^T mu is a polynomial in (X, u, h) evaluated by the
+    same oracle code on complex input, so H[:, j] = Im g(z + i eps e_j) / eps is exact to rounding (no step-size error:
+    eps = 1e-30), 1e-12 instead of the 1e-7 of central differences -- for order 4 (both restatements) and one higher order."""
+    s = po.config_system(cfg)
+    N = 3
+    Z, lay = po.synthetic_trajectory(s, N, seed=40 + cfg, noise=1e-2)
+    Z[:, lay.dt_off] = 0.1 + 0.05 * np.random.default_rng(1).random(N)
+    G0, Gj = s.G_drift, np.array(s.G_drives)
+    mu = np.random.default_rng(2).standard_normal((lay.K, lay.x_dim))
+    Hd = po.hessian_dense(po.pade_hessian_values(Z, mu, lay, G0, Gj, order), lay)
+    if order == 4:
+        assert np.abs(Hd - po.hessian_dense(po.pade4_hessian_values(Z, mu, lay, G0, Gj), lay)).max() < 1e-12 * max(1.0, np.abs(Hd).max())
+    nv, eps = Z.size, 1e-30
+    Hcs = np.empty((nv, nv))
+    z0 = Z.reshape(-1).astype(complex)
+    for j in range(nv):
+        z = z0.copy()
+        z[j] += 1j * eps
+        Hcs[:, j] = (po.pade_jacobian_dense(z.reshape(Z.shape), lay, G0, Gj, order).T @ mu.reshape(-1)).imag / eps
+    scale = max(1.0, np.abs(Hcs).max())
+    assert np.abs(Hd - Hcs).max() < 1e-12 * scale, np.abs(Hd - Hcs).max() / scale
+    assert np.abs(Hcs - Hcs.T).max() < 1e-12 * scale
+    # tripwire: a wrong index convention (u_{k+1} instead of u_k) is caught at this tolerance
+    Zs = Z.copy()
+    Zs[:-1, lay.u_off : lay.u_off + lay.m] = Z[1:, lay.u_off : lay.u_off + lay.m]
+    Hs = po.hessian_dense(po.pade_hessian_values(Zs, mu, lay, G0, Gj, order), lay)
+    assert np.abs(Hs - Hcs).max() > 1e-6 * scale
+
+
 @pytest.mark.parametrize("cfg,N", [(1, 9), (2, 10), (3, 4)])
 def test_c_restatement_matches_numpy(cfg, N):
     s = po.config_system(cfg)

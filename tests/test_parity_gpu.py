@@ -38,8 +38,11 @@ def product_system(cfg):
 def make_ctx(lay, G0, Gj, **kw):
     args = dict(d=lay.d, m=lay.m, N=lay.N, z_dim=lay.z_dim, u_off=lay.u_off, dt_off=lay.dt_off, x_offs=[lay.x_off], G0=G0,
                 Gj=Gj, batch=1, batch_mode=pa._lib.PCL_BATCH_MEMBERS)  # fmt: skip
+    host_path = kw.pop("host_path", 1)  # 1: full values over PCIe (the launch under test writes every replicated block)
     args.update(kw)
-    return pa.integrators._PclContext(**args)
+    c = pa.integrators._PclContext(**args)
+    c.set_option("host_path", host_path)
+    return c
 
 
 # ---- committed golden vectors ----------------------------------------------------------------
@@ -56,11 +59,12 @@ def set_variant(c, variant):
 
 @pytest.mark.parametrize("name", ["config1", "config2", "config3"])
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_golden_vectors(name, variant, golden, golden_meta):
+@pytest.mark.parametrize("host_path", [1, 2])  # full values over PCIe | the default: compact values + host expansion
+def test_golden_vectors(name, variant, host_path, golden, golden_meta):
     v = golden("vec_" + name)
     m = golden_meta["oracle_vectors"][name]
     lay = po.Layout(d=m["d"], m=m["m"], N=m["N"], z_dim=m["z_dim"], x_off=m["x_off"], u_off=m["u_off"], dt_off=m["dt_off"])
-    c = make_ctx(lay, v["G0"], v["Gj"])
+    c = make_ctx(lay, v["G0"], v["Gj"], host_path=host_path)
     set_variant(c, variant)
     assert c.get_option("iso_structured") == 1
     delta, vals = c.eval_jac(v["Z"])
@@ -532,7 +536,7 @@ def test_profiling_hooks_are_not_in_the_shipped_library():
         with pytest.raises(pa.PclError) as e:
             c.set_option(key, 1)
         assert e.value.code == pa._lib.PCL_EINVAL
-    for v in (4, 5):
+    for v in (5, 6):
         with pytest.raises(pa.PclError):
             c.set_option("kernel_version", v)
     c.close()
@@ -835,19 +839,21 @@ def test_contiguous_column_ranges_any_grid():
     ms.close()
 
 
-def test_config5_share_default_path():
-    """BASELINE config 5's per-GPU share at reduced batch (4 seeds of the full-size config-3 problem in one launch):
+@pytest.mark.parametrize("Bn", [4, 8])
+def test_config5_share_default_path(Bn):
+    """BASELINE config 5's per-GPU share (8 seeds of the full-size config-3 problem in one launch: the shipped share; 4: a narrower one):
     the path `auto` picks at this size - kernel 3, contiguous column ranges, half the workgroups streaming the blocks -
     against the C oracle, and bitwise against the round-robin split."""
     so = po.config_system(3)
     G0, Gj = so.G_drift, np.array(so.G_drives)
-    Bn, N = 4, 100
+    N = 100
     Zs, lay = [], None
     for s in range(Bn):
         Z, lay = po.synthetic_trajectory(so, N, seed=1000 + s)
         Zs.append(Z)
     ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn)
     c = ms.ctx
+    c.set_option("host_path", 1)  # the full-values launch (the default host delivery launches the compact kernel)
     delta, vals = c.eval_jac(np.stack(Zs))
     assert c.get_option("last_kernel") == 31 and c.get_option("last_stream_workgroups") == c.get_option("n_cu") // 2
     per_d, per_j = lay.x_dim * lay.K, po.jac_nnz_per_interval(lay) * lay.K
@@ -860,6 +866,94 @@ def test_config5_share_default_path():
     assert c.get_option("last_stream_workgroups") == 0
     assert np.array_equal(d2, delta) and np.array_equal(v2, vals)
     ms.close()
+
+
+# ---- the pattern-compiled fused kernel (kernel_version 4; auto for every Pade order but 4) ------------------------------------
+@pytest.mark.parametrize("order", [2, 4, 6, 8, 10])
+def test_pattern_compiled_fused_kernel(order):
+    """pcl_fused_sparse_kernel (generated per system and order): residual + Jacobian at BASELINE config 3 against the oracle, every
+    work split (round-robin slices, contiguous ranges, explicit slice widths, odd grids), both tail-store modes, the compact
+    layout, full size -- and bitwise equal across all of them: a lane's arithmetic depends on its state column only."""
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    for N in (5, 100):
+        Z, lay = po.synthetic_trajectory(so, N, seed=77)
+        Z[:, lay.dt_off] = 0.1 + 0.05 * np.random.default_rng(3).random(N)
+        d_ref = po.pade_residual(Z, lay, G0, Gj, order)
+        j_ref = po.pade_jacobian_values(Z, lay, G0, Gj, order)
+        c = make_ctx(lay, G0, Gj, pade_order=order)
+        c.set_option("kernel_version", 4)
+        first = None
+        splits = ((-1, 0, 0, 1, 3), (0, 0, 0, 1, 3), (1, 0, 0, 1, 3), (0, 5, 0, 1, 3), (0, 27, 7, 1, 3), (0, 1, 0, 1, 3), (1, 0, 5, 1, 0), (0, 5, 0, 1, 0),
+                  (0, 0, 0, 1, 2), (-1, 0, 0, 2, 3))
+        if N == 100:  # full size: the default split, contiguous ranges (several items per workgroup), the writer wave
+            splits = (splits[0], splits[2], splits[7]) if order in (4, 8) else (splits[0],)
+        for contig, cps, grid, hp, tm in splits:
+            c.set_option("contiguous", contig)
+            c.set_option("cols_per_slice", cps)
+            c.set_option("grid", grid)
+            c.set_option("v4_tail_mode", tm)
+            c.set_option("host_path", hp)
+            delta, vals = c.eval_jac(Z)
+            assert c.get_option("last_kernel") == 40 + order // 2
+            close(delta, d_ref, 1e-12)
+            close(vals, j_ref, 1e-12)
+            if first is None:
+                first = (delta, vals)
+            assert np.array_equal(delta, first[0]) and np.array_equal(vals, first[1])
+        close(c.jac(Z), j_ref, 1e-12)  # eval_jacobian alone: no residual is written
+        c.close()
+
+
+def test_pattern_compiled_fused_kernel_ensemble_and_shapes():
+    """Kernel 4 on per-member drifts (BASELINE config 4's members: 27 drift value classes, the less used ones streamed through the
+    chunk registers), on a member window, on TRAJ batches, and on other sparse shapes (two 5-level transmons, d = 25, m = 4)."""
+    osys, psys, lay, Z, traj = _config4_share(3, 9)
+    xd = lay.x_dim
+    B = _fused_ensemble(psys, traj)
+    c = B.ctx
+    c.set_option("host_path", 1)
+    per_d, per_j = xd * lay.K, po.jac_nnz_per_interval(lay) * lay.K
+    refs = [ref_lib.eval_jac(Z, lay, s.G_drift, np.array(s.G_drives), x_off=i * xd) for i, s in enumerate(osys)]
+    d_ref = np.concatenate([r[0].reshape(-1) for r in refs])
+    j_ref = np.concatenate([r[1].reshape(-1) for r in refs])
+    c.set_option("kernel_version", 4)
+    for contig, grid in ((-1, 0), (1, 0), (0, 3), (1, 7)):
+        c.set_option("contiguous", contig)
+        c.set_option("grid", grid)
+        delta, vals = c.eval_jac(traj.datavec)
+        assert c.get_option("last_kernel") == 42
+        close(delta, d_ref)
+        close(vals, j_ref)
+    c.set_option("grid", 0)
+    c.set_member_window(1, 2)
+    delta, vals = c.eval_jac(traj.datavec)
+    close(delta, d_ref[per_d:])
+    close(vals, j_ref[per_j:])
+    B.close()
+    # multistart batch (TRAJ mode), order 8
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    Zs = [po.synthetic_trajectory(so, 6, seed=500 + i)[0] for i in range(3)]
+    lay3 = po.Layout.smooth_pulse(so.levels, so.n_drives, 6)
+    c = make_ctx(lay3, G0, Gj, batch=3, batch_mode=pa._lib.PCL_BATCH_TRAJ, pade_order=8)
+    delta, vals = c.eval_jac(np.stack(Zs))
+    assert c.get_option("last_kernel") == 44  # auto at order 8
+    close(delta, np.concatenate([po.pade_residual(z, lay3, G0, Gj, 8).reshape(-1) for z in Zs]), 1e-12)
+    close(vals, np.concatenate([po.pade_jacobian_values(z, lay3, G0, Gj, 8).reshape(-1) for z in Zs]), 1e-12)
+    c.close()
+    # another sparse shape: two 5-level transmons
+    s2 = po.multi_transmon_system([4.0, 4.1], [0.2, 0.21], [[0, 0.02], [0.02, 0]], levels_per_transmon=5, drive_bounds=0.1)
+    G0, Gj = s2.G_drift, np.array(s2.G_drives)
+    Z, lay = po.synthetic_trajectory(s2, 7, seed=3)
+    for order in (4, 6):
+        c = make_ctx(lay, G0, Gj, pade_order=order)
+        c.set_option("kernel_version", 4)
+        delta, vals = c.eval_jac(Z)
+        assert c.get_option("last_kernel") == 40 + order // 2
+        close(delta, po.pade_residual(Z, lay, G0, Gj, order), 1e-12)
+        close(vals, po.pade_jacobian_values(Z, lay, G0, Gj, order), 1e-12)
+        c.close()
 
 
 # ---- higher Pade orders (SURVEY 8 a3) ---------------------------------------------------------------------------------
@@ -905,7 +999,13 @@ def test_general_pade_orders_vs_oracle(order, cfg, N):
     c.set_option("general_kernel_version", 0)
     c.set_option("general_slices", 0)
     delta, vals = c.eval_jac(Z)
-    assert c.get_option("last_kernel") == 190 + order // 2 and np.array_equal(vals, vals1)
+    if cfg == 3 and order != 4:  # auto: the pattern-compiled fused kernel (sparse iso generators; test_pattern_compiled_fused_kernel)
+        assert c.get_option("last_kernel") == 40 + order // 2
+        close(delta, d_ref, 1e-11)
+        close(vals, j_ref, 1e-11)
+    else:
+        assert c.get_option("last_kernel") == 190 + order // 2 and np.array_equal(vals, vals1)
+    c.set_option("general_kernel_version", 2)  # (the device-pointer checks below: the lock-step kernel)
     import torch
 
     Zd = torch.from_numpy(np.ascontiguousarray(Z).reshape(-1)).cuda()
@@ -1110,6 +1210,73 @@ def test_multi_ket_integrator():
     B.close()
 
 
+@pytest.mark.parametrize("base", ["density", "multiket", "multidensity"])
+def test_sampling_over_density_and_multi_state_bases(base):
+    """BilinearIntegrator(qtraj::SamplingTrajectory, N) for the bases beside unitaries and kets [REF src/control/integrators.jl:181-226]:
+    density members evaluate under their compact Lindbladian, MultiKet / MultiDensity members carry a list of sub-states and yield one
+    integrator per sub-state (member-major, sub-states in order -- the reference's reduce(vcat, ...)).  Members differ in their
+    drift (the robust-control use), so all of them share one batched context; every integrator against the oracle with ITS
+    member's generators."""
+    rng = np.random.default_rng({"density": 31, "multiket": 32, "multidensity": 33}[base])
+    levels, m, N, M = 3, 2, 6, 3
+    Hd = rng.standard_normal((levels, levels)) + 1j * rng.standard_normal((levels, levels))
+    Hd = 0.3 * (Hd + Hd.conj().T)
+    Hs = [(lambda A: A + A.conj().T)(rng.standard_normal((levels, levels)) + 1j * rng.standard_normal((levels, levels))) for _ in range(m)]
+    scales = [1.0, 1.05, 0.95]
+    dens = base != "multiket"
+    subs = 1 if base == "density" else 2
+    if dens:
+        a = pa.annihilate(levels)
+        Ls = [0.3 * a, 0.1 * np.diag(np.arange(levels)).astype(complex)]
+        systems = [pa.OpenQuantumSystem(sc * Hd, Hs, [1.0] * m, Ls) for sc in scales]
+        gens = [po.compact_lindbladian_generators(sc * Hd, Hs, Ls) for sc in scales]
+        xl = levels * levels
+        lay_kw = dict(d=0, cols=1, gen=xl)
+        stem = "ρ⃗̃"
+    else:
+        systems = [pa.QuantumSystem(sc * Hd, Hs, [1.0] * m) for sc in scales]
+        gens = [(o.G_drift, o.G_drives) for o in (po.quantum_system(sc * Hd, Hs, [1.0] * m) for sc in scales)]
+        xl = 2 * levels
+        lay_kw = dict(d=levels, cols=1)
+        stem = "ψ̃"
+    n_states = M * subs
+    z_dim = n_states * xl + 2 + m
+    Z = 0.5 * rng.standard_normal((N, z_dim))
+    Z[:, n_states * xl] = 0.05 + 0.05 * rng.random(N)
+    comps, names = {}, []
+    for i in range(M):
+        mine = []
+        for j in range(subs):
+            nm = "%s%d_%d" % (stem, j + 1, i + 1) if subs > 1 else "%s%d" % (stem, i + 1)
+            q = i * subs + j
+            comps[nm] = Z[:, q * xl : (q + 1) * xl].T
+            mine.append(nm)
+        names.append(mine if subs > 1 else mine[0])
+    o = n_states * xl
+    comps["Δt"], comps["t"], comps["u"] = Z[:, o][None], Z[:, o + 1][None], Z[:, o + 2 :].T
+    traj = pa.NamedTrajectory(comps, controls=("u", "Δt"), timestep="Δt")
+    assert np.array_equal(traj.datavec, Z.reshape(-1))
+    lay = po.Layout(m=m, N=N, z_dim=z_dim, x_off=0, u_off=o + 2, dt_off=o, **lay_kw)
+    Bs = pa.BilinearIntegrator(systems, traj, x_name=names if subs > 1 or dens else names)
+    assert len(Bs) == n_states and len({id(b.ensemble) for b in Bs}) == 1
+    flat = [nm for p_ in names for nm in ([p_] if isinstance(p_, str) else p_)]
+    for q, B in enumerate(Bs):
+        i = q // subs
+        G0, Gj = gens[i][0], np.array(gens[i][1])
+        assert B.x_name == flat[q] and B.x_dim == xl and B.dim == xl * (N - 1)
+        delta = pa.evaluate_(np.zeros(B.dim), B, traj)
+        close(delta, po.pade_residual(Z, lay, G0, Gj, 4, x_off=q * xl), 1e-11)
+        J = pa.eval_jacobian(B, traj).toarray()
+        rows, cols = po.jac_structure(lay, x_off=q * xl)
+        Jo = np.zeros_like(J)
+        np.add.at(Jo, (rows, cols), po.pade_jacobian_values(Z, lay, G0, Gj, 4, x_off=q * xl).reshape(-1))
+        close(J, Jo, 1e-11)
+        close(B.f(Z[2, q * xl : (q + 1) * xl], Z[1, q * xl : (q + 1) * xl], Z[1, lay.u_off : lay.u_off + m], Z[1, lay.dt_off]), delta[xl : 2 * xl], 1e-11)
+    assert Bs[0].ensemble.launches <= 2  # one fused launch serves every member (residual, then residual + Jacobian)
+    for b in Bs:
+        b.close()
+
+
 @pytest.mark.parametrize("d,m,sparse", [(26, 3, False), (23, 6, True), (12, 3, False), (32, 2, True), (27, 6, True)])
 def test_work_splits_on_general_shapes(d, m, sparse):
     """The work splits of kernel 3 on shapes that take the run-time-shape instances (general real generators, dense-ish
@@ -1202,6 +1369,7 @@ def test_config4_share_full_size_ensemble(M):
     osys, psys, lay, Z, traj = _config4_share(M, 100)
     xd = lay.x_dim
     B = _fused_ensemble(psys, traj)
+    B.ctx.set_option("host_path", 1)  # the full-values launch (the default host delivery launches the compact kernel)
     delta, vals = B.ctx.eval_jac(traj.datavec)
     assert B.ctx.get_option("last_kernel") == 31 and B.ctx.get_option("last_stream_workgroups") == B.ctx.get_option("n_cu") // 2
     per_d, per_j = xd * lay.K, po.jac_nnz_per_interval(lay) * lay.K
