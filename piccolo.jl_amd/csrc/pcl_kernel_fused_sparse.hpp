@@ -502,3 +502,101 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     }
     if (gave_up && lane == 0) p.jac[0] = __builtin_nan("");  // a wait gave up: visible in the values instead of a hung device
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Residual only (what the solver calls in every line-search trial), any order: delta = W_0 of the recursion above, q products.
+// One WAVE per interval and no cooperation between waves (SP4E_NW independent waves per workgroup, three tiles each: D, S, W):
+// every coefficient of the product is resident (or streamed from the launch-invariant drift table), so there is no per-interval
+// value table to write, flush and read back -- the round-2 kernel of this role spent most of an interval on exactly that.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define SP4E_NW 4
+extern "C" __global__ __launch_bounds__(64 * SP4E_NW) void pcl_eval_sparse4_kernel(const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ mags_, const double *__restrict__ dcf_tab) {
+    extern __shared__ double lds[];
+    constexpr int d = SPD, n = SPN, q = SP4Q;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *Dt = lds + wave * 3 * SP4TILE, *St = Dt + SP4TILE, *Xt = St + SP4TILE;
+    sp_cptr magc = (sp_cptr)mags_;
+    double mg[SP4NMAG];
+#pragma unroll
+    for (int g = 0; g < SP4NMAG; ++g) mg[g] = magc[g];
+    const int n_items = p.batch * p.K;
+    const long long xd = (long long)n * d;
+    for (int item = blockIdx.x * SP4E_NW + wave; item < n_items; item += gridDim.x * SP4E_NW) {
+        const int k = item % p.K, b = item / p.K;
+        int ln_ = lane;
+        asm volatile("" : "+v"(ln_));
+        const int half = ln_ >> 5, c = ln_ & 31;
+        const bool act = c < d;
+        const int own = (act ? c : 0) * SP4CS + half * d, oth = (act ? c : 0) * SP4CS + (1 - half) * d;
+        sp_cptr zc = (sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim);
+        double u[SPM > 0 ? SPM : 1];
+#pragma unroll
+        for (int l = 0; l < SPM; ++l) u[l] = zc[p.u_off + l];
+        const double h = zc[p.dt_off];
+        sp4_cf cf;
+        SP4_SET_CF(cf, u, mg);
+        SP4_SET_DCF(cf, (sp_cptr)(dcf_tab + (p.g0_batch_stride ? (long long)b * SP4NDCFP : 0)));
+        sp_cptr tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
+        // the interval's states, lane = row (coalesced), nine columns per batch of loads -> D, S tiles [column][row]
+        {
+            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + p.x_offs[p.z_batch_stride ? 0 : b] + (ln_ < n ? ln_ : 0);
+            const double *zn = zk + p.z_dim;
+            constexpr int NB = 9;
+#pragma unroll
+            for (int cb = 0; cb < SPD; cb += NB) {
+                double xc[NB], xn[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    if (cb + j < SPD) {
+                        xc[j] = zk[(cb + j) * n];
+                        xn[j] = zn[(cb + j) * n];
+                    }
+                if (ln_ < n) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        if (cb + j < SPD) {
+                            Dt[(cb + j) * SP4CS + ln_] = xn[j] - xc[j];
+                            St[(cb + j) * SP4CS + ln_] = xn[j] + xc[j];
+                        }
+                }
+            }
+        }
+        wave_lds_sync();
+        {  // level q
+            const double *Yq = (q & 1) ? St : Dt;
+            const double aq = ((q & 1) ? -1.0 : 1.0) * p.pc[q];
+            if (act) {
+                double y[SPD];
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) y[i] = Yq[own + i];
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) Xt[own + i] = aq * y[i];
+            }
+            wave_lds_sync();
+        }
+        const unsigned oX = sp4_lds_off(Xt + own), oXx = sp4_lds_off(Xt + oth), oD = sp4_lds_off(Dt + own), oS = sp4_lds_off(St + own);
+        const double hu = sp4_uniform(h);
+#pragma unroll 1
+        for (int s = 0; s < q; ++s) {
+            const int j = q - 1 - s;
+            const double alpha = sp4_uniform(((j & 1) ? -1.0 : 1.0) * p.pc[j]);
+            double x[SPD];
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) x[i] = Xt[own + i];
+            }
+            if (act) sp4_product(x, (j & 1) ? oS : oD, oX, oXx, alpha, hu, half ? -hu : hu, tab, cf);
+        }
+        wave_lds_sync();
+        {  // tile -> memory: the interval's n d residuals are one contiguous run, two rows per lane
+            double *dst = p.delta + (long long)item * xd;
+            for (int e2 = ln_; e2 < d * d; e2 += 64) {
+                const int cl = e2 / d, r0 = 2 * (e2 - cl * d);
+                const double *src = Xt + cl * SP4CS + r0;
+                store2(dst + 2 * e2, src[0], src[1], 0);
+            }
+        }
+        wave_lds_sync();  // (the tiles are rewritten by this wave's next interval)
+    }
+}
