@@ -538,11 +538,11 @@ extern "C" __global__ __launch_bounds__(64 * SP4E_NW) void pcl_eval_sparse4_kern
         SP4_SET_CF(cf, u, mg);
         SP4_SET_DCF(cf, (sp_cptr)(dcf_tab + (p.g0_batch_stride ? (long long)b * SP4NDCFP : 0)));
         sp_cptr tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
-        // the interval's states, lane = row (coalesced), nine columns per batch of loads -> D, S tiles [column][row]
+        // the interval's states, lane = row (coalesced), every load in flight at once (one memory round trip) -> D, S tiles [column][row]
         {
             const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + p.x_offs[p.z_batch_stride ? 0 : b] + (ln_ < n ? ln_ : 0);
             const double *zn = zk + p.z_dim;
-            constexpr int NB = 9;
+            constexpr int NB = SPD;
 #pragma unroll
             for (int cb = 0; cb < SPD; cb += NB) {
                 double xc[NB], xn[NB];

@@ -97,7 +97,7 @@ struct pcl_ctx {
     // pattern-compiled FUSED residual + Jacobian kernel (pcl_codegen_v4.hpp, any Pade order): plan, drift tables, magnitudes
     pcl_codegen::V4Plan *v4_plan = nullptr;
     double *dv4_tab = nullptr, *dv4_mags = nullptr, *dv4_dcf = nullptr;
-    hipFunction_t v4_f = nullptr;
+    hipFunction_t v4_f = nullptr, v4_feval = nullptr;
     int v4_failed = 0;
     int64_t opt_v4_variant = 0;     // PCL_PROFILE builds: timing variants of the generated product (wrong results)
     int64_t opt_v4_tail_mode = 3;   // kernel 4: who stores delta and the tails: 0 the writer wave | 1 ... nontemporal | 2 ... write-through | 3 the stream waves (default)
@@ -1095,21 +1095,51 @@ static void fill_pade(KParams &p, int order) {
 static bool v4_available(const pcl_ctx *ctx) {
     return ctx->v4_plan && !ctx->v4_failed && ctx->opt_jit && !ctx->vec && ctx->cols == ctx->desc.d;
 }
+// the generated module of the context's system and order (both kernels), compiled on first use
+static int v4_module(pcl_ctx *ctx, int q, int np) {
+    if (ctx->v4_f && ctx->v4_feval) return PCL_OK;
+    const std::string src = v4_source(*ctx->v4_plan, q, np, (int)ctx->opt_v4_variant);
+    const std::string key = "fused-sparse:" + std::to_string(q) + ":" + std::to_string(std::hash<std::string>{}(src));
+    ctx->v4_f = jit_compile(ctx->device, key, src, "pcl_fused_sparse_kernel", true);
+    ctx->v4_feval = ctx->v4_f ? jit_compile(ctx->device, key, src, "pcl_eval_sparse4_kernel", true) : nullptr;
+    if (!ctx->v4_f || !ctx->v4_feval) {
+        ctx->v4_f = ctx->v4_feval = nullptr;
+        ctx->v4_failed = 1;
+        return PCL_ENOTIMPL;
+    }
+    return PCL_OK;
+}
+// Residual only on the same products: one wave per interval, 4 waves per workgroup (three tiles each)
+static int launch_eval_v4(pcl_ctx *ctx, KParams &p) {
+    if (!v4_available(ctx) || !p.delta) return PCL_ENOTIMPL;
+    const pcl_codegen::V4Plan &v4 = *ctx->v4_plan;
+    fill_pade(p, ctx->desc.pade_order);
+    const int np = v4_power_tiles(p.d, p.m, p.q, (size_t)ctx->max_lds);
+    if (!np) return PCL_ENOTIMPL;
+    if (v4_module(ctx, p.q, np) != PCL_OK) return PCL_ENOTIMPL;
+    const long long items = (long long)p.batch * p.K;
+    if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+    const int nw = 4;
+    const size_t lds = (size_t)nw * 3 * p.d * (p.n + 1) * sizeof(double);
+    const int per_cu = std::max(1, (int)((size_t)ctx->max_lds / lds));
+    const long long slots = (long long)per_cu * std::max(ctx->n_cu, 1);
+    long long grid = std::min<long long>((items + nw - 1) / nw, slots);
+    if (ctx->opt_grid > 0) grid = std::min<long long>(ctx->opt_grid, (items + nw - 1) / nw);
+    const double *tab = ctx->dv4_tab + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_drift_pad : 0);
+    const double *dcf = ctx->dv4_dcf + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_dcf_pad : 0);
+    void *args[] = {(void *)&p, (void *)&tab, (void *)&ctx->dv4_mags, (void *)&dcf};
+    HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_feval, (unsigned)grid, 1, 1, 64 * nw, 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
+    ctx->last_kernel = 80 + p.q;
+    ctx->last_n_stream = 0;
+    return PCL_OK;
+}
 static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact) {
     if (!v4_available(ctx) || !p.jac) return PCL_ENOTIMPL;
     const pcl_codegen::V4Plan &v4 = *ctx->v4_plan;
     fill_pade(p, ctx->desc.pade_order);
     const int np = v4_power_tiles(p.d, p.m, p.q, (size_t)ctx->max_lds);
     if (!np) return PCL_ENOTIMPL;
-    if (!ctx->v4_f) {
-        const std::string src = v4_source(v4, p.q, np, (int)ctx->opt_v4_variant);
-        const std::string key = "fused-sparse:" + std::to_string(p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
-        ctx->v4_f = jit_compile(ctx->device, key, src, "pcl_fused_sparse_kernel", true);
-        if (!ctx->v4_f) {
-            ctx->v4_failed = 1;
-            return PCL_ENOTIMPL;
-        }
-    }
+    if (v4_module(ctx, p.q, np) != PCL_OK) return PCL_ENOTIMPL;
     const int d = p.d, m = p.m;
     const long long bk = (long long)p.batch * p.K, ncu = std::max(ctx->n_cu, 1);
     // contiguous column ranges once every CU has about an interval's worth of columns; below that round-robin slices of the
@@ -1210,6 +1240,12 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         const int rc = want_merit ? PCL_ENOTIMPL : launch_fused_v4(ctx, p, compact);
         if (rc != PCL_ENOTIMPL) return rc;
         if (!want_merit && ctx->opt_kernel == 4) return fail(ctx, PCL_ESHAPE, "kernel_version=4 needs sparse exact-iso generators of a unitary problem (9 <= d, tiles within LDS), 1..6 drives and jit=1 (%s)", g_jit_note.c_str());
+    }
+    // residual only on the same products (eval_kernel 3; auto: every order -- measured against the other residual kernels)
+    if (!want_jac && (ctx->opt_eval_kernel == 3 || (ctx->opt_eval_kernel == 0 && ctx->opt_kernel == 0 && !ctx->opt_general && ctx->opt_general_version == 0))) {
+        const int rc = launch_eval_v4(ctx, p);
+        if (rc != PCL_ENOTIMPL) return rc;
+        if (ctx->opt_eval_kernel == 3) return fail(ctx, PCL_ESHAPE, "eval_kernel=3 needs sparse exact-iso generators of a unitary problem (9 <= d, tiles within LDS), 1..6 drives and jit=1 (%s)", g_jit_note.c_str());
     }
     if (ctx->desc.pade_order != 4 || ctx->opt_general || ctx->vec) return launch_pade_general(ctx, p, want_jac);
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
@@ -2269,7 +2305,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_prof = v;
     else if (!strcmp(key, "v4_variant")) {  // timing variants of kernel 4's generated product (WRONG results); recompiles
         ctx->opt_v4_variant = v;
-        ctx->v4_f = nullptr;
+        ctx->v4_f = ctx->v4_feval = nullptr;
     }
 #endif
     else if (!strcmp(key, "host_threads"))  // host-pointer entry points: threads expanding the compact values (0 = auto)
@@ -2305,7 +2341,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_v4_tail_mode = v;
     }
     else if (!strcmp(key, "eval_kernel")) {  // residual only: 0 auto, 1 matrix-core kernel, 2 pattern-compiled kernel
-        if (v < 0 || v > 2) return fail(ctx, PCL_EINVAL, "eval_kernel must be 0, 1 or 2");
+        if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "eval_kernel must be 0 .. 3");
         ctx->opt_eval_kernel = v;
     }
     else if (!strcmp(key, "hess_kernel")) {  // 0: auto, 1: one workgroup per interval, 2: persistent wave-synchronous kernel

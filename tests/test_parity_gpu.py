@@ -1852,6 +1852,7 @@ def test_residual_only_kernel():
     ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn)
     c = ms.ctx
     ref = np.concatenate([po.pade_residual(Z, lay, G0, Gj, 4).reshape(-1) for Z in Zs])
+    c.set_option("eval_kernel", 1)  # the matrix-core residual kernel (any generators)
     for spec in (1, 0):
         c.set_option("specialize", spec)
         for grid in (0, 1, 2, 5, 17, 1000):
@@ -1872,14 +1873,23 @@ def test_residual_only_kernel():
         assert c.get_option("last_kernel") == 70
         close(d, ref)
         assert np.array_equal(d, c.eval(np.stack(Zs)))
+    # the residual kernel on the products of kernel 4 (resident coefficients, no per-interval table; auto for sparse iso generators)
+    for ek in (3, 0):
+        c.set_option("eval_kernel", ek)
+        for grid in (0, 1, 2, 5, 1000):
+            c.set_option("grid", grid)
+            d = c.eval(np.stack(Zs))
+            assert c.get_option("last_kernel") == 82
+            close(d, ref)
+            assert np.array_equal(d, c.eval(np.stack(Zs)))
     c.set_option("grid", 0)
     c.set_option("eval_kernel", 0)
     ms.close()
-    big = [po.synthetic_trajectory(so, 100, seed=500 + s)[0] for s in range(3)]  # 297 intervals > 256 CUs: auto picks it
+    big = [po.synthetic_trajectory(so, 100, seed=500 + s)[0] for s in range(3)]  # full size, auto
     layb = po.synthetic_trajectory(so, 100, seed=500)[1]
     msb = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, big[0], layb), 3)
     db = msb.ctx.eval(np.stack(big))
-    assert msb.ctx.get_option("last_kernel") == 70
+    assert msb.ctx.get_option("last_kernel") == 82
     close(db, np.concatenate([po.pade_residual(Z, layb, G0, Gj, 4).reshape(-1) for Z in big]))
     msb.close()
     # general real generators (dense drives: the union tables are read from memory), odd d, d = 32 (n = 64: the largest tile)
@@ -1892,6 +1902,7 @@ def test_residual_only_kernel():
     # per-member drift tiles (ensemble), windows
     osys, psys, layE, ZE, trajE = _config4_share(3, 6)
     B = _fused_ensemble(psys, trajE)
+    B.ctx.set_option("eval_kernel", 1)
     dE = B.ctx.eval(trajE.datavec)
     assert B.ctx.get_option("last_kernel") == 61
     per = layE.x_dim * layE.K
@@ -1906,6 +1917,13 @@ def test_residual_only_kernel():
     close(d2, dE, 1e-12)
     B.ctx.set_member_window(1, 2)
     assert np.array_equal(B.ctx.eval(trajE.datavec), d2[per:])
+    B.ctx.set_member_window(0, 3)
+    B.ctx.set_option("eval_kernel", 0)  # auto: the kernel-4 products (the members' drift value classes, some of them streamed)
+    d3 = B.ctx.eval(trajE.datavec)
+    assert B.ctx.get_option("last_kernel") == 82
+    close(d3, dE, 1e-12)
+    B.ctx.set_member_window(1, 2)
+    assert np.array_equal(B.ctx.eval(trajE.datavec), d3[per:])
     B.close()
 
 
