@@ -283,8 +283,9 @@ int pcl_codegen_source(int d, int m, const double *G0, const double *Gj, char *b
  * (n_g0 drifts G0[b] span the union pattern: an ensemble's members); PCL_ESHAPE when the drives need more resident
  * coefficients than the kernel keeps.  pcl_codegen_apply_v4 applies the generator's term tables on the host to one column:
  * y = (G0[0] + sum_l u_l G_l) x, x and y of length n = 2d -- what the generated product computes, checkable without a GPU. */
-int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, const double *Gj, int q, char *buf, int64_t cap, int64_t *needed);
-int pcl_codegen_apply_v4(int d, int m, const double *G0, int n_g0, const double *Gj, const double *u, const double *x, double *y);
+int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what /* 0 fused residual + Jacobian (+ residual only), 1 Hessian of the Lagrangian */,
+                          char *buf, int64_t cap, int64_t *needed);
+int pcl_codegen_apply_v4(int d, int m, const double *G0, int n_g0, const double *Gj, const double *u, const double *x, double *y, int transposed /* 1: y = G(u)^T x */);
 
 #ifdef __cplusplus
 }

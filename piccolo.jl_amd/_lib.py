@@ -187,7 +187,7 @@ def load():
     L.pcl_get_option.argtypes = [vp, ctypes.c_char_p, c_i64p]
     L.pcl_debug_timing.argtypes = [vp, c_i64p, ctypes.c_int64]
     L.pcl_codegen_source.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int64, c_i64p]
-    L.pcl_codegen_source_v4.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, c_i64p]
-    L.pcl_codegen_apply_v4.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp]
+    L.pcl_codegen_source_v4.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, c_i64p]
+    L.pcl_codegen_apply_v4.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int]
     _lib = L
     return L

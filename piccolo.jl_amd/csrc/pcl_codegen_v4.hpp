@@ -43,6 +43,8 @@ struct V4Plan {
     std::vector<V4Term> terms;       // emission order
     std::vector<int> drift_pos;      // table order: column-major position r + n c in G0
     int n_drift_pad = 0;             // table length per member (padded: a chunk's loads never leave the member's table)
+    std::vector<V4Term> terms_t;     // the same entries for G(u)^T x (the Hessian kernel): outputs by COLUMN of the left block
+    std::vector<int> drift_pos_t;    // ... and the order its streamed drift entries are read in (a table of its own, same stride)
     std::vector<int> cf_l, cf_g;     // resident coefficient k = u[cf_l[k]] * mags[cf_g[k]]
     std::vector<double> mags;
     // The drift's entries fall into a few VALUE CLASSES (15 distinct magnitudes among the 91 entries of BASELINE config 3; 27 for
@@ -149,22 +151,31 @@ static inline V4Plan make_v4_plan(int d, int m, const double *G0, int n_g0, cons
                 P.gl[l].push_back({row, c, isV, g, v < 0});
             }
         }
-    for (int g0 = 0; g0 < d; g0 += kV4Group) {
-        const int g1 = std::min(d, g0 + kV4Group);
-        size_t longest = 0;
-        for (int o = g0; o < g1; ++o) longest = std::max(longest, by[o].size());
-        for (size_t t = 0; t < longest; ++t)
-            for (int o = g0; o < g1; ++o)
-                if (t < by[o].size()) {
-                    V4Term q = by[o][t];
-                    if (q.kind == 0) {
-                        P.drift_pos.push_back(q.idx);
-                        q.idx = (int)P.drift_pos.size() - 1;
+    // G(u)^T x: entry (r, c) of the left block feeds output row c from input row r (mod d); A block -> U, B block -> V
+    // (top = U(0) + V(1), bottom = U(1) - V(0): the caller passes betas = -beta in half 0)
+    std::vector<std::vector<V4Term>> by_t(d);
+    for (int o = 0; o < d; ++o)
+        for (const V4Term &t : by[o]) by_t[t.in].push_back({t.in, t.isV, t.row, t.kind, t.idx, t.neg});
+    auto order_terms = [&](std::vector<std::vector<V4Term>> &lists, std::vector<V4Term> &out, std::vector<int> &dpos, bool mark) {
+        for (int g0 = 0; g0 < d; g0 += kV4Group) {
+            const int g1 = std::min(d, g0 + kV4Group);
+            size_t longest = 0;
+            for (int o = g0; o < g1; ++o) longest = std::max(longest, lists[o].size());
+            for (size_t t = 0; t < longest; ++t)
+                for (int o = g0; o < g1; ++o)
+                    if (t < lists[o].size()) {
+                        V4Term q = lists[o][t];
+                        if (q.kind == 0) {
+                            dpos.push_back(q.idx);
+                            q.idx = (int)dpos.size() - 1;
+                        }
+                        if (mark) (q.isV ? P.hasV : P.hasU)[q.row] = 1;
+                        out.push_back(q);
                     }
-                    (q.isV ? P.hasV : P.hasU)[q.row] = 1;
-                    P.terms.push_back(q);
-                }
-    }
+        }
+    };
+    order_terms(by, P.terms, P.drift_pos, true);
+    order_terms(by_t, P.terms_t, P.drift_pos_t, false);
     P.n_drift_pad = (((int)P.drift_pos.size() + kV4Chunk - 1) / kV4Chunk + 1) * kV4Chunk + 4;
     P.n_drift_pad = (P.n_drift_pad + 7) & ~7;
     P.ok = (int)P.cf_l.size() <= kV4MaxCf && P.mags.size() <= (size_t)kMaxMags;
@@ -189,6 +200,22 @@ static inline void v4_reference_apply(const V4Plan &P, const double *G0, const d
     }
 }
 
+// ... and of the transposed product y = G(u)^T x (the Hessian kernel's)
+static inline void v4_reference_apply_t(const V4Plan &P, const double *G0, const double *u, const double *x, double *y) {
+    const int d = P.d;
+    std::vector<double> U0(d, 0.0), V0(d, 0.0), U1(d, 0.0), V1(d, 0.0);
+    for (const V4Term &t : P.terms_t) {
+        double c = t.kind == 0 ? G0[P.drift_pos_t[t.idx]] : (t.kind == 1 ? u[P.cf_l[t.idx]] * P.mags[P.cf_g[t.idx]] : P.dcf_vals[t.idx]);
+        if (t.neg) c = -c;
+        (t.isV ? V0 : U0)[t.row] += c * x[t.in];
+        (t.isV ? V1 : U1)[t.row] += c * x[d + t.in];
+    }
+    for (int i = 0; i < d; ++i) {
+        y[i] = U0[i] + V1[i];      // top = A^T a + B^T b
+        y[d + i] = U1[i] - V0[i];  // bottom = A^T b - B^T a
+    }
+}
+
 namespace detail {
 static inline std::string v4_chunk_reg(int chunk, int e) {
     char b[32];
@@ -207,7 +234,7 @@ static inline void v4_emit_chunk_loads(std::string &s, int chunk) {
 // np: LDS tiles the powers of G rotate through (>= 2 for q >= 2; q when they fit)
 // variant: timing experiments of the product (WRONG results unless 0): 1 no ds_add_f64 | 2 no LDS operation in the epilogues | 3 one
 // accumulator chain per output row group only half as deep (kV4Group rows -> plain v_mul of every term: no dependent chains)
-static inline std::string v4_functions(const V4Plan &P, int q, int np, int variant = 0) {
+static inline std::string v4_functions(const V4Plan &P, int q, int np, int variant = 0, bool with_hessian = false) {
     using detail::v4_chunk_reg;
     const int d = P.d, G = kV4Group;
     std::string s;
@@ -249,7 +276,8 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
     //      epilogues and never waits for LDS ------------------------------------------------------------------------------------
     const int n_drift = (int)P.drift_pos.size();
     const int n_chunks = (n_drift + kV4Chunk - 1) / kV4Chunk;
-    auto emit_product = [&](const char *name, bool with_y) {
+    auto emit_product = [&](const char *name, bool with_y, bool transposed = false) {
+        const std::vector<V4Term> &terms = transposed ? P.terms_t : P.terms;
         // Accumulators in two sets (group parity): a finished group is scaled in place (own value alpha Y + beta U in the U
         // register, betas V in the V register) and its LDS operations are issued BETWEEN the multiply-adds of the next group --
         // back to back behind their v_mul they cost a lone wave 20-27 cycles each (a third of the product).
@@ -283,13 +311,13 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
                     s += buf;
                 }
             size_t nterm = 0;
-            for (size_t t = ti; t < P.terms.size() && P.terms[t].row >= g0 && P.terms[t].row < g1; ++t) ++nterm;
+            for (size_t t = ti; t < terms.size() && terms[t].row >= g0 && terms[t].row < g1; ++t) ++nterm;
             const size_t npend = pending.size() - pend_i;
             const size_t every = npend ? std::max<size_t>(1, nterm / (npend + 1)) : 0;
             std::vector<char> seenU(G, 0), seenV(G, 0);
             size_t k = 0;
-            for (; ti < P.terms.size() && P.terms[ti].row >= g0 && P.terms[ti].row < g1; ++ti, ++k) {
-                const V4Term &t = P.terms[ti];
+            for (; ti < terms.size() && terms[ti].row >= g0 && terms[ti].row < g1; ++ti, ++k) {
+                const V4Term &t = terms[ti];
                 if (every && k && k % every == 0 && pend_i < pending.size()) s += pending[pend_i++];
                 std::string coef;
                 if (t.kind == 0) {
@@ -382,6 +410,10 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
     };
     emit_product("sp4_product", true);
     emit_product("sp4_product0", false);
+    if (with_hessian) {  // G(u)^T x for the Hessian of the Lagrangian: same statement shape, the transposed term tables
+        emit_product("sp4_product_t", true, true);
+        emit_product("sp4_product0_t", false, true);
+    }
 
     // ---- the drives' gathers: X[own + i] = hs * (G_l w)_i for this lane's half-rows; Wo / Wx = this lane's own / other half of
     //      column c of w in LDS; sb = -1 in half 0, +1 in half 1 (top = A a - B b, bottom = A b + B a) ----------------------------
@@ -415,6 +447,123 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
             s += buf;
         }
         s += "}\n";
+    }
+    if (with_hessian) {
+        // X[own + c] = hs (G_l^T w)_c for this lane's half-rows: top = A^T a + B^T b, bottom = A^T b - B^T a (sb = +1 in half 0, -1 in half 1)
+        for (int l = 0; l < P.m; ++l) {
+            snprintf(buf, sizeof buf, "static __device__ __forceinline__ void sp4_gather_t_%d(const double *__restrict__ Wo, const double *__restrict__ Wx, double *__restrict__ X, double hs, double sb, const double (&mg)[SP4NMAG]) {\n", l);
+            s += buf;
+            for (int i0 = 0; i0 < d; i0 += 9) {
+                const int i1 = std::min(d, i0 + 9);
+                s += "    {\n        double t_[9];\n";
+                for (int i = i0; i < i1; ++i) {
+                    std::string ea, eb;
+                    for (const V4GEnt &e : P.gl[l])
+                        if (e.col == i) {  // transposed: output row = the entry's column, input = its row
+                            std::string &dst = e.isB ? eb : ea;
+                            snprintf(buf, sizeof buf, "%smg[%d] * %s[%d]", dst.empty() ? (e.neg ? "-" : "") : (e.neg ? " - " : " + "), e.mag, e.isB ? "Wx" : "Wo", e.row);
+                            dst += buf;
+                        }
+                    if (ea.empty() && eb.empty())
+                        snprintf(buf, sizeof buf, "        t_[%d] = 0.0;\n", i - i0);
+                    else if (eb.empty())
+                        snprintf(buf, sizeof buf, "        t_[%d] = hs * (%s);\n", i - i0, ea.c_str());
+                    else if (ea.empty())
+                        snprintf(buf, sizeof buf, "        t_[%d] = hs * (sb * (%s));\n", i - i0, eb.c_str());
+                    else
+                        snprintf(buf, sizeof buf, "        t_[%d] = hs * ((%s) + sb * (%s));\n", i - i0, ea.c_str(), eb.c_str());
+                    s += buf;
+                }
+                snprintf(buf, sizeof buf, "#pragma unroll\n        for (int i = 0; i < %d; ++i) X[%d + i] = t_[i];\n    }\n", i1 - i0, i0);
+                s += buf;
+            }
+            s += "}\n";
+        }
+        s += "#define SP4_GATHER_T_SWITCH(l, Wo, Wx, X, hs, sb, mg) switch (l) {";
+        for (int l = 0; l < P.m; ++l) {
+            snprintf(buf, sizeof buf, " case %d: sp4_gather_t_%d(Wo, Wx, X, hs, sb, mg); break;", l, l);
+            s += buf;
+        }
+        s += " default: break; }\n";
+        // <v, G_l z> = <G_l^T v, z>: this lane's part is  sum_j pa[j] zo[j] + sum_j pb[j] zx[j]  with pa = A_l^T v, pb = sb B_l^T v over its
+        // half-rows (z: this lane's own / other half of column c in LDS; sb = -1 in half 0, +1 in half 1 as in sp4_gather_<l>).
+        // sp4_gtv_<l> forms the parts a drive has (register arithmetic only, once per level); sp4_pdot_<l> is one dot product per
+        // power-chain level b -- one LDS read per multiply-add, none of them shared with another drive.
+        for (int l = 0; l < P.m; ++l) {
+            bool hasA = false, hasB = false;
+            for (const V4GEnt &e : P.gl[l]) (e.isB ? hasB : hasA) = true;
+            // nine rows of G_l^T v at a time (part = 0, 1, 2): the whole vector next to v and the two output vectors does not fit
+            snprintf(buf, sizeof buf, "template <int PART> static __device__ __forceinline__ void sp4_gtv_%d(const double (&v)[SPD], double sb, const double (&mg)[SP4NMAG], double (&pa)[9], double (&pb)[9]) {\n", l);
+            s += buf;
+            for (int part9 = 0; part9 * 9 < d; ++part9) {
+                snprintf(buf, sizeof buf, "    if constexpr (PART == %d) {\n", part9);
+                s += buf;
+                for (int part = 0; part < 2; ++part) {
+                    if (!(part ? hasB : hasA)) continue;
+                    for (int j = part9 * 9; j < std::min(d, part9 * 9 + 9); ++j) {  // (G_l^T v)_j over the entries of column j
+                        std::string ex;
+                        for (const V4GEnt &e : P.gl[l])
+                            if (e.col == j && e.isB == (part == 1)) {
+                                snprintf(buf, sizeof buf, "%smg[%d] * v[%d]", ex.empty() ? (e.neg ? "-" : "") : (e.neg ? " - " : " + "), e.mag, e.row);
+                                ex += buf;
+                            }
+                        if (ex.empty()) ex = "0.0";
+                        snprintf(buf, sizeof buf, part ? "        pb[%d] = sb * (%s);\n" : "        pa[%d] = %s;\n", j - part9 * 9, ex.c_str());
+                        s += buf;
+                    }
+                }
+                s += "    }\n";
+            }
+            s += "    (void)pa; (void)pb; (void)sb; (void)v; (void)mg;\n}\n";
+            snprintf(buf, sizeof buf, "template <int NR> static __device__ __forceinline__ double sp4_pdot_%d(const double (&pa)[9], const double (&pb)[9], const double *__restrict__ Zo, const double *__restrict__ Zx) {\n    double r0 = 0.0, r1 = 0.0;\n", l);
+            s += buf;
+            if (hasA) s += "#pragma unroll\n    for (int j = 0; j < NR; ++j) r0 = __builtin_fma(pa[j], Zo[j], r0);\n";
+            if (hasB) s += "#pragma unroll\n    for (int j = 0; j < NR; ++j) r1 = __builtin_fma(pb[j], Zx[j], r1);\n";
+            s += "    (void)pa; (void)pb; (void)Zo; (void)Zx;\n    return r0 + r1;\n}\n";
+        }
+    }
+    if (with_hessian) {
+        // this lane's part of <v, G_l z>: sum_i v[i] (G_l z)_i over its half-rows (z: this lane's own / other half of column c in LDS;
+        // sb = -1 in half 0, +1 in half 1 as in sp4_gather_<l>)
+        for (int l = 0; l < P.m; ++l) {
+            snprintf(buf, sizeof buf, "static __device__ __forceinline__ double sp4_gdot_%d(const double *__restrict__ Zo, const double *__restrict__ Zx, const double (&v)[SPD], double sb, const double (&mg)[SP4NMAG]) {\n    double r0 = 0.0, r1 = 0.0;\n", l);
+            s += buf;
+            int alt = 0;
+            for (int i = 0; i < d; ++i) {
+                std::string ea, eb;
+                for (const V4GEnt &e : P.gl[l])
+                    if (e.row == i) {
+                        std::string &dst = e.isB ? eb : ea;
+                        snprintf(buf, sizeof buf, "%smg[%d] * %s[%d]", dst.empty() ? (e.neg ? "-" : "") : (e.neg ? " - " : " + "), e.mag, e.isB ? "Zx" : "Zo", e.col);
+                        dst += buf;
+                    }
+                if (ea.empty() && eb.empty()) continue;
+                std::string g = eb.empty() ? "(" + ea + ")" : (ea.empty() ? "(sb * (" + eb + "))" : "((" + ea + ") + sb * (" + eb + "))");
+                snprintf(buf, sizeof buf, "    r%d = __builtin_fma(v[%d], %s, r%d);\n", alt, i, g.c_str(), alt);
+                s += buf;
+                alt ^= 1;
+            }
+            s += "    return r0 + r1;\n}\n";
+        }
+        s += "#define SP4_GDOT_SWITCH(res, l, Zo, Zx, v, sb, mg) switch (l) {";
+        for (int l = 0; l < P.m; ++l) {
+            snprintf(buf, sizeof buf, " case %d: res = sp4_gdot_%d(Zo, Zx, v, sb, mg); break;", l, l);
+            s += buf;
+        }
+        s += " default: res = 0.0; break; }\n";
+    }
+    if (with_hessian) {
+        s += "template <int L, int PART> static __device__ __forceinline__ void sp4_gtv(const double (&v)[SPD], double sb, const double (&mg)[SP4NMAG], double (&pa)[9], double (&pb)[9]) {\n";
+        for (int l = 0; l < P.m; ++l) {
+            snprintf(buf, sizeof buf, "    if constexpr (L == %d) sp4_gtv_%d<PART>(v, sb, mg, pa, pb);\n", l, l);
+            s += buf;
+        }
+        s += "}\ntemplate <int L, int NR> static __device__ __forceinline__ double sp4_pdot(const double (&pa)[9], const double (&pb)[9], const double *Zo, const double *Zx) {\n";
+        for (int l = 0; l < P.m; ++l) {
+            snprintf(buf, sizeof buf, "    if constexpr (L == %d) return sp4_pdot_%d<NR>(pa, pb, Zo, Zx);\n", l, l);
+            s += buf;
+        }
+        s += "    return 0.0;\n}\n";
     }
     s += "#define SP4_GATHER_SWITCH(l, Wo, Wx, X, hs, sb, mg) switch (l) {";
     for (int l = 0; l < P.m; ++l) {

@@ -96,8 +96,9 @@ struct pcl_ctx {
     double *dsp_coef_n = nullptr;
     // pattern-compiled FUSED residual + Jacobian kernel (pcl_codegen_v4.hpp, any Pade order): plan, drift tables, magnitudes
     pcl_codegen::V4Plan *v4_plan = nullptr;
-    double *dv4_tab = nullptr, *dv4_mags = nullptr, *dv4_dcf = nullptr;
-    hipFunction_t v4_f = nullptr, v4_feval = nullptr;
+    double *dv4_tab = nullptr, *dv4_tab_t = nullptr, *dv4_mags = nullptr, *dv4_dcf = nullptr;
+    hipFunction_t v4_f = nullptr, v4_feval = nullptr, v4_fhess = nullptr;
+    int v4_hess_failed = 0;
     int v4_failed = 0;
     int64_t opt_v4_variant = 0;     // PCL_PROFILE builds: timing variants of the generated product (wrong results)
     int64_t opt_v4_tail_mode = 3;   // kernel 4: who stores delta and the tails: 0 the writer wave | 1 ... nontemporal | 2 ... write-through | 3 the stream waves (default)
@@ -479,7 +480,11 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
             for (size_t q = 0; q < v4.drift_pos.size(); ++q) tab[(size_t)bb * v4.n_drift_pad + q] = dsc->G0[(size_t)bb * nn + v4.drift_pos[q]];
         std::vector<double> mg(v4.mags);
         mg.resize(std::max<size_t>(mg.size(), 1) + 16, 0.0);
+        std::vector<double> tab_t((size_t)nb * v4.n_drift_pad, 0.0);  // the order G(u)^T x reads the streamed drift entries in
+        for (int bb = 0; bb < nb; ++bb)
+            for (size_t q = 0; q < v4.drift_pos_t.size(); ++q) tab_t[(size_t)bb * v4.n_drift_pad + q] = dsc->G0[(size_t)bb * nn + v4.drift_pos_t[q]];
         CREATE_TRY(upload(ctx, &ctx->dv4_tab, tab));
+        CREATE_TRY(upload(ctx, &ctx->dv4_tab_t, tab_t));
         CREATE_TRY(upload(ctx, &ctx->dv4_mags, mg));
         CREATE_TRY(upload(ctx, &ctx->dv4_dcf, v4.dcf_vals));
     }
@@ -514,7 +519,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     for (void *q : {(void *)ctx->dsp_pos, (void *)ctx->dsp_coef, (void *)ctx->dsp_glv, (void *)ctx->dsp_gvals, (void *)ctx->dsp_pos_n, (void *)ctx->dsp_coef_n})
         if (q) (void)hipFree(q);
     delete ctx->sp_plan;
-    for (void *q : {(void *)ctx->dv4_tab, (void *)ctx->dv4_mags, (void *)ctx->dv4_dcf})
+    for (void *q : {(void *)ctx->dv4_tab, (void *)ctx->dv4_tab_t, (void *)ctx->dv4_mags, (void *)ctx->dv4_dcf})
         if (q) (void)hipFree(q);
     delete ctx->v4_plan;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -741,8 +746,8 @@ hipFunction_t jit_compile(int device, const std::string &key_, const std::string
     dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
     const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp",
                            "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp", "pcl_kernel_eval_sparse.hpp", "pcl_kernel_jac_sparse.hpp",
-                           "pcl_kernel_fused_sparse.hpp"};
-    constexpr int NH = 9;
+                           "pcl_kernel_fused_sparse.hpp", "pcl_kernel_hess_sparse4.hpp"};
+    constexpr int NH = 10;
     std::string hdr[NH];
     const char *hdrp[NH];
     for (int i = 0; i < NH; ++i) {
@@ -808,17 +813,21 @@ std::string v4_source(const pcl_codegen::V4Plan &plan, int q, int np, int varian
     return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q, np, variant) + "#include \"pcl_kernel_fused_sparse.hpp\"\n";
 }
 
+// ... and of the Hessian-of-the-Lagrangian kernel of the same family (pcl_kernel_hess_sparse4.hpp; any order)
+std::string v4_hess_source(const pcl_codegen::V4Plan &plan, int q) {
+    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q, 1, 0, true) + "#include \"pcl_kernel_hess_sparse4.hpp\"\n";
+}
 }  // namespace
 
 // Inspection hooks of the fused pattern-compiled kernel (no device needed): its generated source, and the generator's term
 // tables applied on the host to one column (y = G(u) x; n_g0 drifts span the union pattern, the first one is applied).
-extern "C" int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, const double *Gj, int q, char *buf, int64_t cap, int64_t *needed) {
-    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || !G0 || (m > 0 && !Gj) || !needed) return PCL_EINVAL;
+extern "C" int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what, char *buf, int64_t cap, int64_t *needed) {
+    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || what < 0 || what > 1 || !G0 || (m > 0 && !Gj) || !needed) return PCL_EINVAL;
     const pcl_codegen::V4Plan plan = pcl_codegen::make_v4_plan(d, m, G0, n_g0, Gj);
     if (!plan.ok) return PCL_ESHAPE;
     const int np = v4_power_tiles(d, m, q, 160 * 1024);
     if (!np) return PCL_ESHAPE;
-    const std::string src = v4_source(plan, q, np);
+    const std::string src = what == 1 ? v4_hess_source(plan, q) : v4_source(plan, q, np);
     *needed = (int64_t)src.size() + 1;
     if (buf && cap > 0) {
         const size_t nb = std::min<size_t>((size_t)cap - 1, src.size());
@@ -827,11 +836,14 @@ extern "C" int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, c
     }
     return PCL_OK;
 }
-extern "C" int pcl_codegen_apply_v4(int d, int m, const double *G0, int n_g0, const double *Gj, const double *u, const double *x, double *y) {
+extern "C" int pcl_codegen_apply_v4(int d, int m, const double *G0, int n_g0, const double *Gj, const double *u, const double *x, double *y, int transposed) {
     if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || !G0 || (m > 0 && (!Gj || !u)) || !x || !y) return PCL_EINVAL;
     const pcl_codegen::V4Plan plan = pcl_codegen::make_v4_plan(d, m, G0, n_g0, Gj);
     if (!plan.ok) return PCL_ESHAPE;
-    pcl_codegen::v4_reference_apply(plan, G0, Gj, u, x, y);
+    if (transposed)
+        pcl_codegen::v4_reference_apply_t(plan, G0, u, x, y);
+    else
+        pcl_codegen::v4_reference_apply(plan, G0, Gj, u, x, y);
     return PCL_OK;
 }
 
@@ -1517,6 +1529,39 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
     p.mu = mu;
     p.hess = hess;
     const bool mf = ctx->opt_use_mfma != 0;
+    // hess_kernel 7 (auto at every order but 4): the pattern-compiled kernel on the products of fused kernel 4 -- any order,
+    // one workgroup of m + 1 waves per interval (column slices where the m + 3 + 2 (q - 2) tiles do not fit LDS)
+    if ((ctx->opt_hess_kernel == 7 || (ctx->opt_hess_kernel == 0 && ctx->desc.pade_order != 4 && !ctx->opt_general)) && v4_available(ctx) && !ctx->v4_hess_failed) {
+        const pcl_codegen::V4Plan &v4 = *ctx->v4_plan;
+        fill_pade(p, ctx->desc.pade_order);
+        const int nz = p.q > 2 ? p.q - 2 : 0, ntile = p.m + 3 + 2 * nz;
+        auto bytes = [&](int nc) { return ((size_t)ntile * nc * (p.n + 1) + (size_t)(p.m + 1) * (p.m + 2) + 8) * sizeof(double); };
+        p.nc = p.d;
+        while (p.nc > 1 && bytes(p.nc) > (size_t)ctx->max_lds) p.nc = (p.nc + 1) / 2;
+        if (ctx->opt_cols_per_slice > 0) p.nc = (int)std::min<int64_t>(p.nc, ctx->opt_cols_per_slice);
+        if (!ctx->v4_fhess) {
+            const std::string src = v4_hess_source(v4, p.q);
+            const std::string key = "hess-sparse4:" + std::to_string(p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
+            ctx->v4_fhess = jit_compile(ctx->device, key, src, "pcl_hess_sparse4_kernel", true);
+            if (!ctx->v4_fhess) ctx->v4_hess_failed = 1;
+        }
+        if (ctx->v4_fhess && bytes(p.nc) <= (size_t)ctx->max_lds) {
+            const long long items = (long long)p.batch * p.K;
+            if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+            const long long slots = std::max(ctx->n_cu, 1), rounds = (items + slots - 1) / slots;
+            long long grid = (items + rounds - 1) / rounds;  // every workgroup walks the same number of intervals
+            if (ctx->opt_grid > 0) grid = std::min<long long>(items, ctx->opt_grid);
+            const long long wo = ctx->desc.per_member_G0 ? (long long)ctx->win_first : 0;
+            const double *tab = ctx->dv4_tab + wo * v4.n_drift_pad, *tab_t = ctx->dv4_tab_t + wo * v4.n_drift_pad, *dcf = ctx->dv4_dcf + wo * v4.n_dcf_pad;
+            void *args[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf};
+            HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhess, (unsigned)grid, 1, 1, 64 * (1 + p.m), 1, 1, (unsigned)bytes(p.nc), ctx->stream, args, nullptr));
+            ctx->last_hess_kernel = 70 + p.q;
+            return PCL_OK;
+        }
+        if (ctx->opt_hess_kernel == 7) return fail(ctx, PCL_ESHAPE, "hess_kernel=7: the pattern-compiled general-order kernel is not available (%s)", g_jit_note.c_str());
+    } else if (ctx->opt_hess_kernel == 7) {
+        return fail(ctx, PCL_ESHAPE, "hess_kernel=7 needs sparse exact-iso generators of a unitary problem (9 <= d <= 32), 1..6 drives and jit=1");
+    }
     if (ctx->desc.pade_order != 4 || ctx->opt_general) {
         // any diagonal Pade order (and the cross-check of the order-4 kernels): the general-order kernel, correctness first
         p.q = ctx->desc.pade_order / 2;
@@ -2345,7 +2390,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_eval_kernel = v;
     }
     else if (!strcmp(key, "hess_kernel")) {  // 0: auto, 1: one workgroup per interval, 2: persistent wave-synchronous kernel
-        if (v < 0 || v > 4) return fail(ctx, PCL_EINVAL, "hess_kernel must be 0 .. 4");
+        if ((v < 0 || v > 4) && v != 7) return fail(ctx, PCL_EINVAL, "hess_kernel must be 0 .. 4 or 7");
         ctx->opt_hess_kernel = v;
     }
     else if (!strcmp(key, "debug_timing")) {  // profiling aid: cycle stamps of workgroup 0 (pcl_debug_timing reads them)

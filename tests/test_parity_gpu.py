@@ -1977,6 +1977,48 @@ def test_hessian_of_the_lagrangian_at_every_pade_order(order):
     BE.close()
 
 
+@pytest.mark.parametrize("order", [2, 4, 6, 8, 10])
+def test_pattern_compiled_general_order_hessian(order):
+    """pcl_hess_sparse4_kernel (hess_kernel 7; auto at every order but 4): the Hessian of the Lagrangian at BASELINE config 3 against
+    the oracle's general-order formulas (pinned by the complex-step derivative of the Frechet-pinned Jacobian), every column
+    slicing and grid (the 28 scalar entries are summed over the slices in registers), repeatable bits, full size at order 8,
+    and per-member drifts on a member window."""
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    for N in ((4, 100) if order == 8 else (4,)):
+        Z, lay = po.synthetic_trajectory(so, N, seed=79)
+        Z[:, lay.dt_off] = 0.1 + 0.05 * np.random.default_rng(3).random(N)
+        mu = np.random.default_rng(5).standard_normal((lay.K, lay.x_dim))
+        ref = po.pade_hessian_values(Z, mu, lay, G0, Gj, order).reshape(-1)
+        c = make_ctx(lay, G0, Gj, pade_order=order)
+        c.set_option("hess_kernel", 7)
+        for cps, grid in (((0, 0), (9, 0), (5, 3), (0, 1)) if N == 4 else ((0, 0),)):
+            c.set_option("cols_per_slice", cps)
+            c.set_option("grid", grid)
+            h = c.hess(Z, mu.reshape(-1))
+            assert c.get_option("last_hess_kernel") == 70 + order // 2
+            close(h, ref, 1e-11)
+            assert np.array_equal(h, c.hess(Z, mu.reshape(-1)))
+        if order != 4:  # auto
+            c.set_option("hess_kernel", 0)
+            c.set_option("cols_per_slice", 0)
+            c.set_option("grid", 0)
+            close(c.hess(Z, mu.reshape(-1)), ref, 1e-11)
+            assert c.get_option("last_hess_kernel") == 70 + order // 2
+        c.close()
+    osys, psys, layE, ZE, trajE = _config4_share(3, 4)
+    BE = pa.HipPadeIntegrator(np.array([s.G_drift for s in psys]), psys[0].G_drives_array(), trajE, ["Ũ⃗1", "Ũ⃗2", "Ũ⃗3"], pade_order=order)
+    BE.ctx.set_option("hess_kernel", 7)
+    muE = np.random.default_rng(6).standard_normal((3, layE.K, layE.x_dim))
+    hE = BE.ctx.hess(trajE.datavec, muE.reshape(-1))
+    per = po.hess_nnz_per_interval(layE) * layE.K
+    for i, s in enumerate(osys):
+        close(hE[i * per : (i + 1) * per], po.pade_hessian_values(ZE, muE[i], layE, s.G_drift, np.array(s.G_drives), order, x_off=i * layE.x_dim).reshape(-1), 1e-11)
+    BE.ctx.set_member_window(1, 1)
+    assert np.array_equal(BE.ctx.hess(trajE.datavec, muE[1].reshape(-1)), hE[per : 2 * per])
+    BE.close()
+
+
 def _random_sparse_iso_system(d, m, rng, n_mags=3):
     """Sparse Hermitian drift and drives (complex entries: the A and the B block of iso(-iH) are both populated), drive
     entries drawn from a few magnitudes with random signs / phases in {1, i}: what the pattern-compiled kernels specialise on."""
