@@ -336,7 +336,22 @@ def main():
         for order in (8, 10):
             w1, d1, i1 = run_multistart(1, st, 10, False, order)
             w8, d8, i8 = run_multistart(B, st, 10, False, order)
-            ex["order%d" % order] = {"single": {"evals_per_s": st / w1, "us_per_launch_kernel": d1 / st * 1e6, "frac_of_hbm_peak": abytes / (d1 / st) / 1e9 / HBM_PEAK_GBS,
+            mso = pa.HipPadeMultistart(G0, Gj, t0, B, device=local, pade_order=order)
+            co = mso.ctx
+            co.set_stream(stream.cuda_stream)
+            Zo = torch.from_numpy(np.stack([t.datavec for t in seeds[:B]])).cuda()
+            do_ = torch.empty(co.n_rows, dtype=torch.float64, device="cuda")
+            muo = torch.randn(co.n_rows, dtype=torch.float64, device="cuda")
+            ho = torch.empty(co.hess_nnz, dtype=torch.float64, device="cuda")
+            wh, dh = time_steps(lambda: co.hess_dev(Zo, muo, ho), 20, 3, torch, None)
+            we, de_ = time_steps(lambda: co.eval_dev(Zo, do_), st, 5, torch, None)
+            hko, eko = co.get_option("last_hess_kernel"), co.get_option("last_kernel")
+            mso.close()
+            del Zo, do_, muo, ho
+            ex["order%d" % order] = {"hessian_of_lagrangian": {"us_per_eval_kernel": dh / 20 / B * 1e6, "batch": B, "kernel_id": hko,
+                                                               "kernel": "pcl_hess_sparse4_kernel (pattern-compiled, any order)" if hko // 10 == 7 else "general-order kernel"},
+                                     "residual_only": {"us_per_eval_kernel": de_ / st / B * 1e6, "batch": B, "kernel_id": eko},
+                                     "single": {"evals_per_s": st / w1, "us_per_launch_kernel": d1 / st * 1e6, "frac_of_hbm_peak": abytes / (d1 / st) / 1e9 / HBM_PEAK_GBS,
                                                 "kernel_id": i1["kernel_id"]},
                                      "batch8": {"evals_per_s": B * st / w8, "us_per_launch_kernel": d8 / st * 1e6,
                                                 "frac_of_hbm_peak": abytes * B / (d8 / st) / 1e9 / HBM_PEAK_GBS, "kernel_id": i8["kernel_id"]},
@@ -360,7 +375,8 @@ def main():
         w, dv = time_steps(lambda: c.eval_dev(Zd, dd), st, 5, torch, None)
         ek = c.get_option("last_kernel")
         ex["residual_only"] = {"evals_per_s": B * st / w, "us_per_eval_kernel": dv / st / B * 1e6, "batch": B, "kernel_id": ek,
-                               "kernel": "pcl_eval_sparse_kernel (pattern-compiled, one wave per interval)" if ek == 70 else "pcl_eval_kernel (matrix cores)"}
+                               "kernel": "pcl_eval_sparse4_kernel (pattern-compiled products with resident coefficients, one wave per interval)" if ek // 10 == 8 else
+                               "pcl_eval_sparse_kernel (pattern-compiled, one wave per interval)" if ek == 70 else "pcl_eval_kernel (matrix cores)"}
         ms.close()
         del Zd, dd, mu, hv, cv
         # host-delivered: the host-pointer entry point the Julia glue calls (pcl_eval_jac: H2D of Z, kernel, delta + values

@@ -446,26 +446,6 @@ static inline std::string apply_functions(const SpPlan &P) {
         detail::emit_dot(s, tt, d, (int)P.mags.size());
         s += "}\n";
     }
-    // G_l x (not transposed) -> the wave's LDS tile: the column kernel of the Jacobian (pcl_kernel_jac_sparse.hpp); completed with -sgn
-    for (int l = 0; l < P.m; ++l) {
-        std::vector<Term> tn;
-        for (int k = P.doff[l]; k < P.doff[l + 1]; ++k) {
-            Term q = detail::term_n(P.drow[k], P.dcol[k], d, k);
-            q.neg = P.dneg[k] != 0;
-            q.mag = P.dmagi[k];
-            tn.push_back(q);
-        }
-        snprintf(buf, sizeof buf, "static __device__ __forceinline__ void sp_gl_%d(const double (&x)[SPD], const sp_mags &mg, double sgn, double *Tl, double *To) {\n", l);
-        s += buf;
-        detail::emit_groups(s, detail::emission_order(tn, d, kGroup), d, kGroup, "mg", 0, true);
-        s += "}\n";
-    }
-    s += "#define SP_GL_SWITCH(l, x, mg, sgn, Tl, To) switch (l) {";
-    for (int l = 0; l < P.m; ++l) {
-        snprintf(buf, sizeof buf, " case %d: sp_gl_%d(x, mg, sgn, Tl, To); break;", l, l);
-        s += buf;
-    }
-    s += " default: break; }\n";
     s += "template <int L> static __device__ __forceinline__ double sp_gltdot(const double (&x)[SPD], const double (&down)[SPD], const double (&doth)[SPD], const sp_mags &mg, double sgn) {\n";
     for (int l = 0; l < P.m; ++l) {
         snprintf(buf, sizeof buf, "    if constexpr (L == %d) return sp_gltdot_%d(x, down, doth, mg, sgn);\n", l, l);

@@ -69,12 +69,9 @@ struct pcl_ctx {
     int ellt_w = 0;
     int drives_antisym = 0;  // every G_l == -G_l^T exactly
     double *dug0 = nullptr;
-    double *dcompact = nullptr;  // general-order kernel: unique tiles before the expansion kernel replicates them
-    long long compact_cap = 0;
     int64_t opt_general_threads = 512;
     int64_t opt_general_version = 0;   // 0 auto (the lock-step kernel where it fits) | 1 reference formulation | 2 lock-step kernel or error
     int64_t opt_general_slices = 0;    // lock-step kernel: slices per interval (0 auto)
-    int64_t opt_general_two_step = 0;  // measured slower (the general-order kernel is compute-bound, not store-bound)
     double *dreduce = nullptr;  // staging of pcl_reduce_sum (host buffer)
     int64_t reduce_cap = 0;
     double *dexpm = nullptr, *dxout = nullptr;  // rollout scratch: propagators, staged output of the host-pointer call
@@ -89,8 +86,6 @@ struct pcl_ctx {
     long long sp_gvals_cap = 0;  // intervals the value table holds
     int sp_failed = 0;           // the source did not compile: the other kernels serve the context
     int sp_hess_unfit = 0;       // the Hessian kernel's tiles do not fit LDS (d = 32 with 5 or 6 drives)
-    hipFunction_t sp_fjac = nullptr, sp_fjval = nullptr;  // pattern-compiled column kernel of the Jacobian (+ the value-table kernel of its module)
-    int sp_jac_failed = 0;
     hipFunction_t sp_fval = nullptr, sp_fhess = nullptr, sp_feval = nullptr;  // compiled on first use, kept for the context's lifetime
     int *dsp_pos_n = nullptr;       // the same tables in the emission order of the residual kernel's products
     double *dsp_coef_n = nullptr;
@@ -103,7 +98,6 @@ struct pcl_ctx {
     int64_t opt_v4_variant = 0;     // PCL_PROFILE builds: timing variants of the generated product (wrong results)
     int64_t opt_v4_tail_mode = 3;   // kernel 4: who stores delta and the tails: 0 the writer wave | 1 ... nontemporal | 2 ... write-through | 3 the stream waves (default)
     int64_t opt_eval_kernel = 0;    // 0 auto | 1 matrix-core residual kernel | 2 pattern-compiled
-    int64_t opt_column_kernel = 1;  // fused residual + Jacobian, column work: 1 matrix cores (kernel 3's matrix role; default) | 2 pattern-compiled column kernel + stream-only kernel 3 (experimental: correct, not faster yet -- DESIGN 4.8)
     // staging for the host-pointer entry points
     double *dZ = nullptr, *dmu = nullptr, *ddelta = nullptr, *dvals = nullptr, *dhess = nullptr;
     // options
@@ -502,7 +496,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     void *ptrs[] = {ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
                     ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg, ctx->dellt_col, ctx->dellt_val,
-                    ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout, ctx->dreduce, ctx->dcompact};
+                    ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout, ctx->dreduce};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (ctx->dgoal) (void)hipFree(ctx->dgoal);
@@ -745,9 +739,9 @@ hipFunction_t jit_compile(int device, const std::string &key_, const std::string
     const size_t slash = dir.find_last_of('/');
     dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
     const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp",
-                           "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp", "pcl_kernel_eval_sparse.hpp", "pcl_kernel_jac_sparse.hpp",
+                           "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp", "pcl_kernel_eval_sparse.hpp",
                            "pcl_kernel_fused_sparse.hpp", "pcl_kernel_hess_sparse4.hpp"};
-    constexpr int NH = 10;
+    constexpr int NH = 9;
     std::string hdr[NH];
     const char *hdrp[NH];
     for (int i = 0; i < NH; ++i) {
@@ -801,11 +795,8 @@ hipFunction_t jit_function(int device, const char *instance) {
     return jit_compile(device, instance, src, instance, false);
 }
 // Source of the pattern-compiled kernels of one system (pcl_codegen.hpp)
-// (with_columns: the experimental column kernel of the Jacobian, option column_kernel = 2 -- a module of its own, so that nobody
-//  else pays for its compilation)
-std::string sparse_source(const pcl_codegen::SpPlan &plan, bool with_columns = false) {
-    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::apply_functions(plan) + "#include \"pcl_kernel_hessian_sparse.hpp\"\n#include \"pcl_kernel_eval_sparse.hpp\"\n" +
-           (with_columns ? "#include \"pcl_kernel_jac_sparse.hpp\"\n" : "");
+std::string sparse_source(const pcl_codegen::SpPlan &plan) {
+    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::apply_functions(plan) + "#include \"pcl_kernel_hessian_sparse.hpp\"\n#include \"pcl_kernel_eval_sparse.hpp\"\n";
 }
 // Source of the pattern-compiled fused residual + Jacobian kernel of one system at Pade order 2q (pcl_codegen_v4.hpp)
 // (np: tiles of the powers of G -- v4_power_tiles)
@@ -851,7 +842,7 @@ extern "C" int pcl_codegen_apply_v4(int d, int m, const double *G0, int n_g0, co
 extern "C" int pcl_codegen_source(int d, int m, const double *G0, const double *Gj, char *buf, int64_t cap, int64_t *needed) {
     if (d < 1 || d > 32 || m < 0 || m > 6 || !G0 || (m > 0 && !Gj) || !needed) return PCL_EINVAL;
     const pcl_codegen::SpPlan plan = pcl_codegen::make_plan(d, m, G0, 1, Gj);
-    const std::string src = sparse_source(plan, true);  // (every pattern-compiled kernel, the experimental column kernel included)
+    const std::string src = sparse_source(plan);
     *needed = (int64_t)src.size() + 1;
     if (buf && cap > 0) {
         const size_t nb = std::min<size_t>((size_t)cap - 1, src.size());
@@ -1200,32 +1191,8 @@ static int launch_pade_general(pcl_ctx *ctx, KParams &p, bool want_jac) {
     typedef void (*kern_t)(const KParams);
     kern_t kern = want_jac ? (kern_t)pcl_pade_kernel<true> : (kern_t)pcl_pade_kernel<false>;
     HIP_TRY(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // Option general_two_step (off: measured 7-50 % slower, the kernel is compute-bound): the kernel writes the unique tiles
-    // into a context scratch (compact layout: the powers of G are formed by slice 0 only) and the streaming expansion kernel
-    // replicates them
-    double *jac_full = nullptr;
-    if (want_jac && !p.compact && p.cols > 1 && ctx->opt_general_two_step) {
-        const long long need = (long long)p.batch * p.K * jac_per_compact(ctx);
-        if (ctx->compact_cap < need) {
-            if (ctx->dcompact) (void)hipFree(ctx->dcompact);
-            ctx->dcompact = nullptr;
-            ctx->compact_cap = 0;
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->dcompact, (size_t)need * sizeof(double)));
-            ctx->compact_cap = need;
-        }
-        jac_full = p.jac;
-        p.jac = ctx->dcompact;
-        p.compact = 1;
-        p.jac_per = jac_per_compact(ctx);
-    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)ctx->opt_general_threads), lds, ctx->stream, p);
     HIP_TRY(ctx, hipGetLastError());
-    if (jac_full) {
-        const long long n_bk = (long long)p.batch * p.K;
-        hipLaunchKernelGGL(pcl_expand_kernel, dim3((unsigned)(n_bk * p.cols)), dim3(256), 0, ctx->stream, (const double *)ctx->dcompact, jac_full,
-                           p.cols, p.n, p.m, n_bk, ctx->opt_nt == 1 ? 1 : 0);
-        HIP_TRY(ctx, hipGetLastError());
-    }
     ctx->last_kernel = 90 + p.q;
     ctx->last_n_stream = 0;
     return PCL_OK;
@@ -1315,55 +1282,6 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         if (p.contig && !p.all_matrix && g3 >= 2 && v3_role_split_fits(ctx)) {
             const long long want = ctx->opt_stream_wg < 0 ? g3 / 2 : ctx->opt_stream_wg;  // auto: half the workgroups stream
             if (want > 0) p.n_stream = (int)std::min<long long>(want, g3 - 1);
-        }
-        // Column work by the pattern-compiled kernel (sparse iso generators): one wave per interval forms delta and the
-        // tails; kernel 3 then runs with EVERY workgroup in the stream role (compact: the unique blocks only).
-        if (ctx->opt_column_kernel == 2 && p.contig && delta && !want_merit && ctx->sp_plan && !ctx->sp_failed && !ctx->sp_jac_failed && ctx->opt_jit) {
-            const pcl_codegen::SpPlan &sp = *ctx->sp_plan;
-            if (!ctx->sp_fjac) {
-                const std::string src = sparse_source(sp, true);
-                const std::string key = "sparse+columns:" + std::to_string(std::hash<std::string>{}(src));
-                ctx->sp_fjac = jit_compile(ctx->device, key, src, "pcl_jac_sparse_kernel", true);
-                if (ctx->sp_fjac) ctx->sp_fjval = jit_compile(ctx->device, key, src, "pcl_sparse_values_kernel", true);
-                if (!ctx->sp_fjac || !ctx->sp_fjval) {
-                    ctx->sp_fjac = nullptr;
-                    ctx->sp_jac_failed = 1;
-                }
-            }
-            if (ctx->sp_fjac) {
-                const long long n_int = (long long)p.batch * p.K;
-                if (ctx->sp_gvals_cap < (long long)ctx->desc.batch * p.K) {
-                    if (ctx->dsp_gvals) (void)hipFree(ctx->dsp_gvals);
-                    ctx->dsp_gvals = nullptr;
-                    ctx->sp_gvals_cap = 0;
-                    HIP_TRY(ctx, hipMalloc((void **)&ctx->dsp_gvals, ((size_t)ctx->desc.batch * p.K * sp.nzp + 32) * sizeof(double)));
-                    ctx->sp_gvals_cap = (long long)ctx->desc.batch * p.K;
-                }
-                // one workgroup of m + 2 waves per interval (one output vector per wave), every workgroup the same number of intervals
-                const long long ncu = std::max(ctx->n_cu, 1), roundsc = (n_int + ncu - 1) / ncu;
-                const int nw = sp.m + 2;  // one output vector per wave
-                const long long gridc = (n_int + roundsc - 1) / roundsc;
-                const size_t ldsc = (size_t)(sp.m + 2 + 4) * (sp.n + 1) * sp.d * sizeof(double);  // the waves' tiles + 2 x 2 staging tiles
-                {   // the intervals' value tables of G(u_k), in the emission order of sp_g
-                    void *argv[] = {(void *)&p, (void *)&ctx->dsp_pos_n, (void *)&ctx->dsp_coef_n, (void *)&ctx->dsp_gvals};
-                    HIP_TRY(ctx, hipModuleLaunchKernel(ctx->sp_fjval, (unsigned)n_int, 1, 1, 256, 1, 1, 0, ctx->stream, argv, nullptr));
-                }
-                void *args[] = {(void *)&p, (void *)&ctx->dsp_gvals, (void *)&ctx->dsp_glv};
-                HIP_TRY(ctx, hipModuleLaunchKernel(ctx->sp_fjac, (unsigned)gridc, 1, 1, 64 * nw, 1, 1, (unsigned)ldsc, ctx->stream, args, nullptr));
-                p.all_matrix = 0;
-                p.n_stream = (int)g3;  // every workgroup streams
-                p.delta = nullptr;
-                ctx->last_n_stream = p.n_stream;
-                ctx->last_kernel = 33;  // pattern-compiled columns + stream-only kernel 3
-                if (jitf) {
-                    void *args3[] = {(void *)&p};
-                    HIP_TRY(ctx, hipModuleLaunchKernel(jitf, (unsigned)g3, 1, 1, 512, 1, 1, (unsigned)lds3, ctx->stream, args3, nullptr));
-                    return PCL_OK;
-                }
-                hipLaunchKernelGGL(kern3, dim3((unsigned)g3), dim3(512), lds3, ctx->stream, p);
-                HIP_TRY(ctx, hipGetLastError());
-                return PCL_OK;
-            }
         }
         ctx->last_n_stream = p.n_stream;
         if (want_merit && (spec3 || jitf)) {
@@ -2369,18 +2287,12 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_general_version = v < 0 || v > 2 ? 0 : v;
     else if (!strcmp(key, "general_slices"))  // lock-step kernel: slices of state columns per interval (0 auto)
         ctx->opt_general_slices = v < 0 ? 0 : v;
-    else if (!strcmp(key, "general_two_step"))  // general-order kernel: 1 = unique tiles + expansion kernel, 0 (default) = one kernel writes every copy
-        ctx->opt_general_two_step = v != 0;
     else if (!strcmp(key, "general_pade_kernel"))  // 1: the general-order kernel also for pade_order 4
         ctx->opt_general = v != 0;
     else if (!strcmp(key, "stream_workgroups"))  // kernel 3, contiguous: > 0 = role split with this many stream-role workgroups
         ctx->opt_stream_wg = v;
     else if (!strcmp(key, "contiguous"))  // kernel 3: 1 = equal contiguous column ranges per workgroup (default), 0 = round-robin slices
         ctx->opt_contig = v < 0 ? -1 : (v != 0);
-    else if (!strcmp(key, "column_kernel")) {  // fused residual + Jacobian, column work: 1 kernel 3's matrix role (default), 2 pattern-compiled kernel + stream-only kernel 3 (experimental)
-        if (v < 1 || v > 2) return fail(ctx, PCL_EINVAL, "column_kernel must be 1 or 2");
-        ctx->opt_column_kernel = v;
-    }
     else if (!strcmp(key, "v4_tail_mode")) {  // kernel 4: 0 writer wave, plain stores | 1 nontemporal | 2 write-through | 3 the stream waves store the tails
         if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "v4_tail_mode must be 0 .. 3");
         ctx->opt_v4_tail_mode = v;
@@ -2463,8 +2375,6 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->opt_hess_kernel;
     else if (!strcmp(key, "eval_kernel"))
         *v = ctx->opt_eval_kernel;
-    else if (!strcmp(key, "column_kernel"))
-        *v = ctx->opt_column_kernel;
     else if (!strcmp(key, "last_hess_kernel"))
         *v = ctx->last_hess_kernel;
     else if (!strcmp(key, "ell_width_t"))

@@ -974,12 +974,10 @@ def test_general_pade_orders_vs_oracle(order, cfg, N):
     c.set_option("general_kernel_version", 1)  # the reference formulation: three Horner chains, one workgroup per slice
     for cps in (0, 1, 2, 5):
         c.set_option("cols_per_slice", cps)
-        for two_step in (0, 1):  # one kernel writes every copy (default) / unique tiles + expansion kernel
-            c.set_option("general_two_step", two_step)
-            delta, vals = c.eval_jac(Z)
-            assert c.get_option("last_kernel") == 90 + order // 2
-            close(delta, d_ref, 1e-11)
-            close(vals, j_ref, 1e-11)
+        delta, vals = c.eval_jac(Z)
+        assert c.get_option("last_kernel") == 90 + order // 2
+        close(delta, d_ref, 1e-11)
+        close(vals, j_ref, 1e-11)
         close(c.eval(Z), d_ref, 1e-11)
     if order == 4:
         close(delta, d4)
@@ -1488,60 +1486,6 @@ def test_fused_reduce_payload_equals_the_separate_kernels(M, N):
         for k_, v_ in (("contiguous", -1), ("stream_workgroups", -1), ("grid", 0), ("cols_per_slice", 0)):
             c.set_option(k_, v_)
     B.close()
-
-
-def test_pattern_compiled_column_kernel():
-    """`column_kernel` = 2 (experimental): delta and the Jacobian tails from the pattern-compiled column kernel (one
-    output vector per wave, sparse products with scalar-register coefficients), the -B+ / B- blocks from kernel 3 with every
-    workgroup in the stream role.  Full and compact layouts, multistart seeds and an ensemble with per-member drifts, against
-    the C oracle and against the default path (blocks bit-identical: same stream code)."""
-    osys, psys, lay, Z, traj = _config4_share(3, 9)
-    xd, K = lay.x_dim, lay.K
-    B = _fused_ensemble(psys, traj)
-    c = B.ctx
-    c.set_option("contiguous", 1)
-    d0, v0 = c.eval_jac(traj.datavec)
-    assert c.get_option("last_kernel") == 31
-    c.set_option("column_kernel", 2)
-    d1, v1 = c.eval_jac(traj.datavec)
-    assert c.get_option("last_kernel") == 33, "the pattern-compiled column kernel did not run"
-    per_d, per_j = xd * K, po.jac_nnz_per_interval(lay) * K
-    for i, s in enumerate(osys):
-        d_ref, j_ref = ref_lib.eval_jac(Z, lay, s.G_drift, np.array(s.G_drives), x_off=i * xd)
-        close(d1[i * per_d : (i + 1) * per_d], d_ref)
-        close(v1[i * per_j : (i + 1) * per_j], j_ref)
-    nb = 2 * lay.d * (2 * lay.d) ** 2
-    a0, a1 = v0.reshape(-1, po.jac_nnz_per_interval(lay)), v1.reshape(-1, po.jac_nnz_per_interval(lay))
-    assert np.array_equal(a0[:, :nb], a1[:, :nb])  # the streamed blocks: same code, same bits
-    close(a1[:, nb:], a0[:, nb:])
-    B.close()
-    # multistart seeds, compact layout
-    so = po.config_system(3)
-    Zs = [po.synthetic_trajectory(so, 7, seed=40 + i) for i in range(3)]
-    lay = Zs[0][1]
-    c = make_ctx(lay, so.G_drift, np.array(so.G_drives), batch=3, batch_mode=pa._lib.PCL_BATCH_TRAJ)
-    Zall = np.stack([z for z, _ in Zs])
-    import torch
-
-    c.set_stream(torch.cuda.current_stream().cuda_stream)
-    c.set_option("contiguous", 1)
-    Zd = torch.from_numpy(np.ascontiguousarray(Zall)).cuda()
-    dref, cref = torch.empty(c.n_rows, dtype=torch.float64, device="cuda"), torch.empty(c.compact_nnz, dtype=torch.float64, device="cuda")
-    d2, c2 = torch.zeros_like(dref), torch.zeros_like(cref)
-    c.eval_jac_compact_dev(Zd, dref, cref)
-    c.set_option("column_kernel", 2)
-    c.eval_jac_compact_dev(Zd, d2, c2)
-    torch.cuda.synchronize()
-    assert c.get_option("last_kernel") == 33
-    close(d2.cpu().numpy(), dref.cpu().numpy())
-    close(c2.cpu().numpy(), cref.cpu().numpy())
-    c.set_option("host_path", 1)  # full values over PCIe: the full-layout launch
-    d3, v3 = c.eval_jac(Zall)
-    assert c.get_option("last_kernel") == 33
-    refs = [ref_lib.eval_jac(z, lay, so.G_drift, np.array(so.G_drives)) for z, _ in Zs]
-    close(d3, np.concatenate([r[0].reshape(-1) for r in refs]))
-    close(v3, np.concatenate([r[1].reshape(-1) for r in refs]))
-    c.close()
 
 
 def test_fused_reduce_payload_other_shapes():
