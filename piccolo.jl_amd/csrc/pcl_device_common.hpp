@@ -71,6 +71,8 @@ struct KParams {
     double *mpart;       // v3, optional: per state column (b, k, c) the m + 2 dot products of the reduce payload (pcl_eval_jac_merit_dev)
     const double *mlam;  // ... against these multipliers (NULL: lam = delta, the constraint merit)
     int tail_mode;       // pattern-compiled fused kernel: who stores delta and the tails (option v4_tail_mode)
+    int v4_np;           // ... tiles of the ring of powers of G this launch rotates through (<= the SP4NP the module allocates)
+    int v4_flags;        // ... A/B switches (option v4_flags): 1 no raised priority for the P wave | 2 tails only behind the item's last block
 };
 
 // ------------------------------------------------------------------------------------------

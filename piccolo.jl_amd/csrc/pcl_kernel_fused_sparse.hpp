@@ -71,7 +71,10 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the role branches are uniform
     double *Dt = lds, *St = Dt + SP4TILE, *Wt = St + SP4TILE, *Vt = Wt + SP4TILE, *dWt = Vt + SP4TILE;
-    double *Pt = dWt + m * SP4TILE;  // SP4NP tiles: power j of item `it` lives in tile (it q + j - 1) mod SP4NP
+    double *Pt = dWt + m * SP4TILE;  // SP4NP tiles: power j of item `it` lives in tile (it q + j - 1) mod npw
+    // npw <= SP4NP tiles in use.  With all q powers of an item in flight the P wave runs a whole item ahead of the stream -- measured
+    // 8 % SLOWER on launches of several items per workgroup than a ring of q - 1 (the host picks; one-item launches take all q)
+    const int npw = p.v4_np;
     int *sync = (int *)(Pt + SP4NP * SP4TILE);
     for (int e = tid; e < SP4_NTILES * SP4TILE + SP4_SYNC_WORDS / 2; e += 64 * SP4_NWAVES) lds[e] = 0.0;  // (finite everywhere; counters zero)
     __syncthreads();  // the only workgroup barrier
@@ -181,7 +184,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
         };
         if (wave == 0) {
             // ---- P: powers of G(u_k), one tile of the ring per power -----------------------------------------------------------
-            __builtin_amdgcn_s_setprio(2);  // the stream waits for this chain
+            if (!(p.v4_flags & 1)) __builtin_amdgcn_s_setprio(2);  // the stream waits for this chain
             for (int it = 0; it < n_my; ++it) {
                 int c0, nce, k, b;
                 decode(it, c0, nce, k, b);
@@ -196,11 +199,11 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 const double bs = half ? -1.0 : 1.0;
                 {  // P_1 = G I: the unit vectors never touch LDS
                     const int L = it * q;
-                    double *Po = Pt + (L % SP4NP) * SP4TILE;
+                    double *Po = Pt + (L % npw) * SP4TILE;
                     double x[SPD];
 #pragma unroll
                     for (int i = 0; i < SPD; ++i) x[i] = (half == 0 && i == c) ? 1.0 : 0.0;
-                    for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_C + w, L - SP4NP + 1, gave_up);  // the stream has folded the power this tile held
+                    for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_C + w, L - npw + 1, gave_up);  // the stream has folded the power this tile held
                     if (act) sp4_product0(x, 0u, sp4_lds_off(Po + own), sp4_lds_off(Po + oth), 0.0, 1.0, bs, tab, cf);
                     sp4_post(sync + SP4_F_B, L + 1, lane);
                     SP4_STAMP();
@@ -208,9 +211,9 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
 #pragma unroll 1
                 for (int j = 2; j <= q; ++j) {
                     const int L = it * q + j - 1;
-                    const double *Pi = Pt + ((L - 1) % SP4NP) * SP4TILE;
-                    double *Po = Pt + (L % SP4NP) * SP4TILE;
-                    for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_C + w, L - SP4NP + 1, gave_up);
+                    const double *Pi = Pt + ((L - 1) % npw) * SP4TILE;
+                    double *Po = Pt + (L % npw) * SP4TILE;
+                    for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_C + w, L - npw + 1, gave_up);
                     double x[SPD];  // (read right before the product: 54 registers that nothing else should have to live beside)
                     if (act) {
 #pragma unroll
@@ -429,7 +432,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
 #pragma unroll 1
             for (int j = 1; j <= q; ++j) {
                 const int L = it * q + j - 1;
-                const double *T = Pt + (L % SP4NP) * SP4TILE;
+                const double *T = Pt + (L % npw) * SP4TILE;
                 hp *= h;
                 hm *= -h;
                 const double cp = p.pc[j] * hp, cm = p.pc[j] * hm;
@@ -487,7 +490,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                             }
                         }
                     }
-                    try_tails(false);
+                    if (!(p.v4_flags & 2)) try_tails(false);
                 }
             }
             try_tails(true);

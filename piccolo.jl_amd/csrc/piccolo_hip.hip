@@ -96,6 +96,7 @@ struct pcl_ctx {
     int v4_hess_failed = 0;
     int v4_failed = 0;
     int64_t opt_v4_variant = 0;     // PCL_PROFILE builds: timing variants of the generated product (wrong results)
+    int64_t opt_v4_flags = 0, opt_v4_np = 0;  // kernel 4 A/B switches (KParams::v4_flags); tiles of the powers of G (0 auto)
     int64_t opt_v4_tail_mode = 3;   // kernel 4: who stores delta and the tails: 0 the writer wave | 1 ... nontemporal | 2 ... write-through | 3 the stream waves (default)
     int64_t opt_eval_kernel = 0;    // 0 auto | 1 matrix-core residual kernel | 2 pattern-compiled
     // staging for the host-pointer entry points
@@ -1160,10 +1161,14 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact) {
     p.all_matrix = 0;
     p.n_stream = 0;
     p.tail_mode = (int)ctx->opt_v4_tail_mode;
+    p.v4_flags = (int)ctx->opt_v4_flags;
     const long long units = p.contig ? bk * d : bk * p.S;
     if (units > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
     const long long g = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, units) : std::min<long long>(units, ncu);
     const size_t lds = v4_lds_bytes(d, m, np);
+    // tiles of the ring in use: q - 1 when workgroups walk several items (the P wave must not run a whole item ahead: measured
+    // 8 % on 8 trajectories per launch), all the module has for one-item launches (0.4 us there); option v4_power_tiles overrides
+    p.v4_np = ctx->opt_v4_np > 0 ? (int)std::min<int64_t>(ctx->opt_v4_np, np) : (units > g ? std::max(1, std::min(np, p.q - 1)) : np);
     const double *tab = ctx->dv4_tab + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_drift_pad : 0);
     const double *dcf = ctx->dv4_dcf + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_dcf_pad : 0);
     void *args[] = {(void *)&p, (void *)&tab, (void *)&ctx->dv4_mags, (void *)&dcf};
@@ -1211,9 +1216,12 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     // streaming stores of the Jacobian blocks (auto): write-through while the launch's values fit the infinity cache with room to
     // spare (one trajectory of config 3: 133 MB), plain write-back above (see store2)
     if (ctx->opt_nt < 0 && want_jac && !compact && (long long)ctx->win_count * ctx->K * jac_per_full(ctx) * 8 <= (192LL << 20)) p.nt = 2;
-    // kernel_version 4: the pattern-compiled fused kernel (sparse iso generators, any order).  auto: every order but 4 (where
-    // the matrix-core kernel 3 measures the same or better: both run at the store stream's rate)
-    const bool v4_auto = ctx->opt_kernel == 0 && ctx->desc.pade_order != 4 && !ctx->opt_general && ctx->opt_general_version == 0;
+    // kernel_version 4: the pattern-compiled fused kernel (sparse iso generators, any order).  auto: every order but 4, and at
+    // order 4 the launches large enough for contiguous column ranges (8 trajectories of config 3: 184 us against 190 us of the
+    // matrix-core kernel 3 on the same box; below that size kernel 3 measures the same or up to 1 us better)
+    const bool v4_big = !compact && ctx->opt_contig < 0 && ctx->opt_cols_per_slice <= 0 && ctx->opt_stream_wg < 0 && ctx->opt_grid <= 0 && ctx->opt_use_mfma != 0 &&
+                        (long long)p.batch * p.K * p.d >= 28LL * std::max(ctx->n_cu, 1);
+    const bool v4_auto = ctx->opt_kernel == 0 && (ctx->desc.pade_order != 4 || v4_big) && !ctx->opt_general && ctx->opt_general_version == 0;
     if (want_jac && (ctx->opt_kernel == 4 || v4_auto)) {
         const bool want_merit = ctx->merit_want && !compact && delta && ctx->win_first == 0 && ctx->win_count == ctx->desc.batch;
         const int rc = want_merit ? PCL_ENOTIMPL : launch_fused_v4(ctx, p, compact);
@@ -2293,6 +2301,10 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_stream_wg = v;
     else if (!strcmp(key, "contiguous"))  // kernel 3: 1 = equal contiguous column ranges per workgroup (default), 0 = round-robin slices
         ctx->opt_contig = v < 0 ? -1 : (v != 0);
+    else if (!strcmp(key, "v4_flags"))  // kernel 4 A/B switches: 1 no raised priority for the P wave | 2 tails only behind the item's last block
+        ctx->opt_v4_flags = v;
+    else if (!strcmp(key, "v4_power_tiles"))  // kernel 4: LDS tiles the powers of G rotate through (0 auto: q - 1 for launches of several items per workgroup, else q)
+        ctx->opt_v4_np = v < 0 ? 0 : v;
     else if (!strcmp(key, "v4_tail_mode")) {  // kernel 4: 0 writer wave, plain stores | 1 nontemporal | 2 write-through | 3 the stream waves store the tails
         if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "v4_tail_mode must be 0 .. 3");
         ctx->opt_v4_tail_mode = v;

@@ -48,8 +48,8 @@ summary["pmc_per_dispatch"] = pmc
 traffic = {}
 for wl, units in (("single", 1), ("multistart", 8)):
     w, r = pmc.get(wl + "_write", {}), pmc.get(wl + "_fetch", {})
-    kw = [k for k in w if "pcl_fused_kernel_v3" in k and "WRITE_SIZE" in w[k]]
-    kr = [k for k in r if "pcl_fused_kernel_v3" in k and "FETCH_SIZE" in r[k]]
+    kw = [k for k in w if ("pcl_fused_kernel_v3" in k or "pcl_fused_sparse_kernel" in k) and "WRITE_SIZE" in w[k]]
+    kr = [k for k in r if ("pcl_fused_kernel_v3" in k or "pcl_fused_sparse_kernel" in k) and "FETCH_SIZE" in r[k]]
     if kw and kr:
         wr, rd = w[kw[0]]["WRITE_SIZE"]["avg"] * 1024.0, r[kr[0]]["FETCH_SIZE"]["avg"] * 1024.0
         traffic[wl] = dict(workload=wl, batch=units, knots=100, kernel=kw[0], write_bytes=wr, fetch_bytes_raw=rd, fetch_bytes_corrected=2.0 * rd,
