@@ -19,6 +19,7 @@ namespace pcl_codegen {
 
 constexpr int kV4Group = 3;    // output rows accumulated together (2 * kV4Group independent chains; the product is ONE asm statement of
                                // 54 + 7 kV4Group + ~13 vector registers next to whatever the role keeps live: 128 per lane at 14 waves per CU)
+constexpr int kV4Parts = 4;    // row ranges of the cooperative product (= the store-stream waves of the fused kernel)
 constexpr int kV4Chunk = 8;    // drift coefficients per scalar-load chunk (one s_load_dwordx16; two chunks of scalar registers in rotation)
 constexpr int kV4MaxCf = 16;   // resident drive coefficients (drive, magnitude) the product keeps in scalar registers
 constexpr int kV4MaxRes = 28;  // resident coefficients in all (scalar register pairs): the drives' first, then the drift's value classes by use
@@ -276,7 +277,8 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
     //      epilogues and never waits for LDS ------------------------------------------------------------------------------------
     const int n_drift = (int)P.drift_pos.size();
     const int n_chunks = (n_drift + kV4Chunk - 1) / kV4Chunk;
-    auto emit_product = [&](const char *name, bool with_y, bool transposed = false) {
+    // [grp_lo, grp_hi): the output row groups this statement covers (a part of the product: other waves take the other rows)
+    auto emit_product = [&](const char *name, bool with_y, bool transposed = false, int grp_lo = 0, int grp_hi = 1 << 20) {
         const std::vector<V4Term> &terms = transposed ? P.terms_t : P.terms;
         // Accumulators in two sets (group parity): a finished group is scaled in place (own value alpha Y + beta U in the U
         // register, betas V in the V register) and its LDS operations are issued BETWEEN the multiply-adds of the next group --
@@ -305,6 +307,10 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
         int ngroup = 0;
         for (int g0 = 0; g0 < d; g0 += G, ++ngroup) {
             const int g1 = std::min(d, g0 + G), st = ngroup & 1;
+            if (ngroup < grp_lo || ngroup >= grp_hi) {  // (parts exist for fully resident coefficients only: no chunk bookkeeping to skip)
+                while (ti < terms.size() && terms[ti].row >= g0 && terms[ti].row < g1) ++ti;
+                continue;
+            }
             if (with_y)  // this group's Y values
                 for (int o = g0; o < g1; ++o) {
                     snprintf(buf, sizeof buf, "        \"ds_read_b64 %%[yv%d], %%[vY] offset:%d\\n\\t\"\n", o - g0, 8 * o);
@@ -410,6 +416,35 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
     };
     emit_product("sp4_product", true);
     emit_product("sp4_product0", false);
+    // The product without Y in kV4Parts row ranges of about equal term counts (whole groups): the first item of a workgroup has its
+    // powers of G built by the store-stream waves together -- they have nothing to store yet -- a quarter of the rows each.
+    // Every row keeps the instruction sequence it has in sp4_product0: the same bits.
+    const int n_groups = (d + G - 1) / G;
+    const bool parts = n_chunks == 0 && n_groups >= kV4Parts;
+    snprintf(buf, sizeof buf, "#define SP4_COOP %d\n#define SP4_NPART %d\n", parts ? 1 : 0, kV4Parts);
+    s += buf;
+    if (parts) {
+        std::vector<size_t> cum(n_groups + 1, 0);
+        for (const V4Term &t : P.terms) cum[t.row / G + 1]++;
+        for (int g = 0; g < n_groups; ++g) cum[g + 1] += cum[g] + 4;  // (+ the group's epilogue)
+        int lo = 0;
+        for (int k = 0; k < kV4Parts; ++k) {
+            int hi = lo + 1;
+            const size_t want = cum[n_groups] * (k + 1) / kV4Parts;
+            while (hi < n_groups - (kV4Parts - 1 - k) && cum[hi] < want) ++hi;
+            if (k == kV4Parts - 1) hi = n_groups;
+            const std::string part_name = "sp4_product0_p" + std::to_string(k);  // (buf is the emitter's scratch)
+            emit_product(part_name.c_str(), false, false, lo, hi);
+            lo = hi;
+        }
+        s += "static __device__ __forceinline__ void sp4_product0_part(int part, const double (&x)[SPD], unsigned vO, unsigned vOo, double beta, double betas, sp_cptr tab, const sp4_cf &cf) {\n"
+             "    switch (part) {\n";
+        for (int k = 0; k < kV4Parts; ++k) {
+            snprintf(buf, sizeof buf, "    %s sp4_product0_p%d(x, 0u, vO, vOo, 0.0, beta, betas, tab, cf); break;\n", k == kV4Parts - 1 ? "default:" : ("case " + std::to_string(k) + ":").c_str(), k);
+            s += buf;
+        }
+        s += "    }\n}\n";
+    }
     if (with_hessian) {  // G(u)^T x for the Hessian of the Lagrangian: same statement shape, the transposed term tables
         emit_product("sp4_product_t", true, true);
         emit_product("sp4_product0_t", false, true);

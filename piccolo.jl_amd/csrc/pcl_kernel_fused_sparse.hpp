@@ -36,7 +36,7 @@
 // G + l levels of W the drive wave l has gathered | O + w items whose output chain w is complete
 // (one word per arriver wherever arrivers can run ahead of each other: a shared arrival count lies -- a fast wave's extra arrival
 //  stands in for a slow wave's missing one)
-enum { SP4_F_IN = 0, SP4_F_DW, SP4_F_DV, SP4_F_W, SP4_F_B, SP4_F_OC, SP4_F_G = 8, SP4_F_O = 16, SP4_F_C = 24 /* per stream wave */, SP4_F_TS = 28 /* per stream wave: items whose tails it has stored */ };
+enum { SP4_F_IN = 0, SP4_F_DW, SP4_F_DV, SP4_F_W, SP4_F_B, SP4_F_OC, SP4_F_CO /* cooperative first item: parts of powers done */, SP4_F_G = 8, SP4_F_O = 16, SP4_F_C = 24 /* per stream wave */, SP4_F_TS = 28 /* per stream wave: items whose tails it has stored */ };
 
 static __device__ __forceinline__ bool sp4_wait(int *sync, int word, int target, bool gave_up = false) {
     // Bounded: a logic error must not hang the device (the caller poisons the output instead; once a wave has given up it
@@ -76,8 +76,21 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     // 8 % SLOWER on launches of several items per workgroup than a ring of q - 1 (the host picks; one-item launches take all q)
     const int npw = p.v4_np;
     int *sync = (int *)(Pt + SP4NP * SP4TILE);
-    for (int e = tid; e < SP4_NTILES * SP4TILE + SP4_SYNC_WORDS / 2; e += 64 * SP4_NWAVES) lds[e] = 0.0;  // (finite everywhere; counters zero)
+#ifdef PCL_PROFILE
+    // 100 MHz wall stamps per workgroup (dbg[512 + 768 sel + 3 bx + {entry, tiles zeroed, last wave out}], sel = prof & 64): where
+    // the time between back-to-back launches goes
+    long long *wall_ = p.dbg ? p.dbg + 512 + ((p.prof & 64) ? 768 : 0) + 3 * (blockIdx.x & 255) : nullptr;
+    if (wall_ && tid == 0) wall_[0] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    // Counters zero.  The tiles start as whatever the previous workgroup left: every entry a wave reads has been written by the item
+    // that reads it (zeroing 150 KB took 0.84 us of a 24 us workgroup life).  v4_flags & 8 (tests): NaN everywhere first.
+    if (p.v4_flags & 8)
+        for (int e = tid; e < SP4_NTILES * SP4TILE; e += 64 * SP4_NWAVES) lds[e] = __builtin_nan("");
+    if (tid < SP4_SYNC_WORDS) sync[tid] = 0;
     __syncthreads();  // the only workgroup barrier
+#ifdef PCL_PROFILE
+    if (wall_ && tid == 0) wall_[1] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- work split (as kernel 3) ----------------------------------------------------------------------------------------
     const long long blk = p.compact ? (long long)nn : (long long)d * nn;  // size of the -B^+ / of the B^- segment
@@ -157,6 +170,33 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     constexpr bool no_blocks = false, no_chains = false, no_tails = false;
 #endif
 
+    // the drives' magnitudes and the per-item scalars (step, controls -> resident coefficients, the member's drift table), defined inside
+    // the roles that use them: at kernel scope their registers stay live across every role (139 spilled scalar registers)
+#define SP4_SCALARS_DEF()                                                                                         \
+    sp_cptr magc = (sp_cptr)mags_;                                                                                \
+    double mg[SP4NMAG];                                                                                           \
+    _Pragma("unroll") for (int g = 0; g < SP4NMAG; ++g) mg[g] = magc[g];                                          \
+    auto scalars = [&](int k, int b, double &h, sp4_cf &cf, sp_cptr &tab) {                                       \
+        sp_cptr zc = (sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim);                   \
+        double u[SPM > 0 ? SPM : 1];                                                                              \
+        _Pragma("unroll") for (int l = 0; l < SPM; ++l) u[l] = zc[p.u_off + l];                                   \
+        h = zc[p.dt_off];                                                                                         \
+        SP4_SET_CF(cf, u, mg);                                                                                    \
+        SP4_SET_DCF(cf, (sp_cptr)(dcf_tab + (p.g0_batch_stride ? (long long)b * SP4NDCFP : 0)));                  \
+        tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));                          \
+    }
+    // Cooperative first item: the store-stream waves build the powers of G of the workgroup's FIRST item themselves, a quarter of the
+    // output rows each (sp4_product0_part: nothing to store before the powers exist; a lone P wave takes 7.7 k cycles for G, G^2 at
+    // order 4 -- a fifth of a one-trajectory launch).  Needs every power of the item in its own tile (folded afterwards: the products'
+    // registers and the block registers never live side by side) and fully resident coefficients.  The P wave starts with item 1.
+    const bool coop = SP4_COOP && npw >= q && !(p.v4_flags & 4);
+    // ... and the chains of that item start behind them: twelve waves of products on four SIMDs ran the stream's parts three times
+    // slower (4.1 k cycles instead of 1.3 k), and the chains have the whole store phase to finish in
+    auto chains_may_start = [&](int it) {
+        if (coop && it == 0 && !(p.v4_flags & 16))
+            for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_C + w, q, gave_up);
+    };
+
     if (wave < SP4_WLOAD) {
         // ================================== column waves: one chain each ====================================================
         // Lane position, re-derived from an opaque copy of `lane` in every item: computed once, everything that depends on it (the
@@ -167,25 +207,11 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     const int half = ln_ >> 5, c = ln_ & 31;                                                \
     const int cc = c < d ? c : 0;                                                           \
     const int own = cc * SP4CS + half * d, oth = cc * SP4CS + (1 - half) * d
-        sp_cptr magc = (sp_cptr)mags_;
-        double mg[SP4NMAG];
-#pragma unroll
-        for (int g = 0; g < SP4NMAG; ++g) mg[g] = magc[g];
-        // per-item scalars: step, controls -> resident coefficients, the member's drift table
-        auto scalars = [&](int k, int b, double &h, sp4_cf &cf, sp_cptr &tab) {
-            sp_cptr zc = (sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim);
-            double u[SPM > 0 ? SPM : 1];
-#pragma unroll
-            for (int l = 0; l < SPM; ++l) u[l] = zc[p.u_off + l];
-            h = zc[p.dt_off];
-            SP4_SET_CF(cf, u, mg);
-            SP4_SET_DCF(cf, (sp_cptr)(dcf_tab + (p.g0_batch_stride ? (long long)b * SP4NDCFP : 0)));
-            tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
-        };
+        SP4_SCALARS_DEF();
         if (wave == 0) {
             // ---- P: powers of G(u_k), one tile of the ring per power -----------------------------------------------------------
             if (!(p.v4_flags & 1)) __builtin_amdgcn_s_setprio(2);  // the stream waits for this chain
-            for (int it = 0; it < n_my; ++it) {
+            for (int it = coop ? 1 : 0; it < n_my; ++it) {
                 int c0, nce, k, b;
                 decode(it, c0, nce, k, b);
                 SP4_LANEPOS();
@@ -250,6 +276,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 sp_cptr tab;
                 SP4_STAMP();
                 scalars(k, b, h, cf, tab);
+                chains_may_start(it);
                 gave_up = sp4_wait(sync, SP4_F_IN, it + 1, gave_up);
                 outputs_taken(it);  // the previous item has left this tile
                 SP4_STAMP();
@@ -400,12 +427,51 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             decode(it, c0, nce, k, b);
             // (an opaque copy per item: derived from `tid` directly, the tile addresses below are hoisted out of the item loop
             //  and spilled)
+            SP4_STAMP();
+#if SP4_COOP
+            if (it == 0 && coop) {
+                SP4_LANEPOS();
+                const bool act = c < d;
+                const double bs = half ? -1.0 : 1.0;
+                const int part = wave - SP4_WSTREAM;
+                SP4_SCALARS_DEF();
+                double hh;
+                sp4_cf cf;
+                sp_cptr tab;
+                scalars(k, b, hh, cf, tab);
+                {  // G itself: unit vectors (a block of its own: inside the loop the 27 constants are kept in a second register set)
+                    double *Po = Pt;
+                    double x[SPD];
+#pragma unroll
+                    for (int i = 0; i < SPD; ++i) x[i] = (half == 0 && i == c) ? 1.0 : 0.0;
+                    if (act) sp4_product0_part(part, x, sp4_lds_off(Po + own), sp4_lds_off(Po + oth), 1.0, bs, tab, cf);
+                    wave_lds_sync();
+                    sp4_arrive(sync + SP4_F_CO, lane);
+                    gave_up = sp4_wait(sync, SP4_F_CO, SP4_NSTREAM, gave_up);  // every row of this power is in the tile
+                    SP4_STAMP();
+                }
+#pragma unroll 1
+                for (int j = 2; j <= q; ++j) {
+                    double *Po = Pt + ((j - 1) % npw) * SP4TILE;
+                    const double *Pi = Pt + ((j - 2) % npw) * SP4TILE;
+                    double x[SPD];
+                    if (act) {
+#pragma unroll
+                        for (int i = 0; i < SPD; ++i) x[i] = Pi[own + i];
+                    }
+                    if (act) sp4_product0_part(part, x, sp4_lds_off(Po + own), sp4_lds_off(Po + oth), 1.0, bs, tab, cf);
+                    wave_lds_sync();
+                    sp4_arrive(sync + SP4_F_CO, lane);
+                    gave_up = sp4_wait(sync, SP4_F_CO, SP4_NSTREAM * j, gave_up);
+                    SP4_STAMP();
+                }
+            }
+#endif
             int stid = tid - 64 * SP4_WSTREAM;
-            asm volatile("" : "+v"(stid));
+            asm volatile("" : "+v"(stid));  // (after the cooperative products: nothing derived from it lives beside their registers)
             const int pi = 2 * (stid % hn), pj0 = stid / hn;
             const bool pact = pj0 < pstep;
             const double h = ((sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim))[p.dt_off];
-            SP4_STAMP();
             // -B^+ and B^- of this thread's positions, folded power by power as the P wave publishes them.  Entry (i, j) of the
             // n x n iso matrix [[A, -B], [B, A]] whose first d columns are a tile: j >= d mirrors into column j - d, rows i < d
             // from row i + d with the sign flipped, rows i >= d from row i - d.
@@ -436,7 +502,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 hp *= h;
                 hm *= -h;
                 const double cp = p.pc[j] * hp, cm = p.pc[j] * hm;
-                gave_up = sp4_wait(sync, SP4_F_B, L + 1, gave_up);
+                if (!(coop && it == 0)) gave_up = sp4_wait(sync, SP4_F_B, L + 1, gave_up);
                 double v[NSP][2];
 #pragma unroll
                 for (int r = 0; r < NSP; ++r)
@@ -504,6 +570,9 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
         }
     }
     if (gave_up && lane == 0) p.jac[0] = __builtin_nan("");  // a wait gave up: visible in the values instead of a hung device
+#ifdef PCL_PROFILE
+    if (wall_ && lane == 0) atomicMax((unsigned long long *)(wall_ + 2), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

@@ -912,6 +912,16 @@ def test_pattern_compiled_fused_kernel(order):
             if first is None:
                 first = (delta, vals)
             assert np.array_equal(delta, first[0]) and np.array_equal(vals, first[1])
+        # the cooperative first item (store-stream waves build the item's powers of G, a quarter of the rows each): same bits without
+        # it (4), without the chains waiting behind it (16), and with every LDS tile NaN at kernel start (8: the tiles are not
+        # initialised -- nothing may read an entry its item has not written)
+        c.set_option("contiguous", -1), c.set_option("cols_per_slice", 0), c.set_option("grid", 0)
+        c.set_option("v4_power_tiles", 0), c.set_option("v4_tail_mode", 3), c.set_option("host_path", 1)
+        for flags in (4, 16, 8, 8 | 4):
+            c.set_option("v4_flags", flags)
+            delta, vals = c.eval_jac(Z)
+            assert np.array_equal(delta, first[0]) and np.array_equal(vals, first[1]), flags
+        c.set_option("v4_flags", 0)
         close(c.jac(Z), j_ref, 1e-12)  # eval_jacobian alone: no residual is written
         c.close()
 
