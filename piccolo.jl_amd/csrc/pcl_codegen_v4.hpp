@@ -12,6 +12,7 @@
 //     nothing inside it.  The two halves are completed in LDS: the lane writes alpha Y + beta U into its own slot and adds
 //     -+ beta V into the other half's slot with ds_add_f64 (a wave's LDS operations complete in order).
 #pragma once
+#include <algorithm>
 
 #include "pcl_codegen.hpp"
 
@@ -235,7 +236,10 @@ static inline void v4_emit_chunk_loads(std::string &s, int chunk) {
 // np: LDS tiles the powers of G rotate through (>= 2 for q >= 2; q when they fit)
 // variant: timing experiments of the product (WRONG results unless 0): 1 no ds_add_f64 | 2 no LDS operation in the epilogues | 3 one
 // accumulator chain per output row group only half as deep (kV4Group rows -> plain v_mul of every term: no dependent chains)
-static inline std::string v4_functions(const V4Plan &P, int q, int np, int variant = 0, bool with_hessian = false) {
+static inline std::string v4_functions(const V4Plan &P, int q, int np, int variant_ = 0, bool with_hessian = false) {
+    const int variant = variant_ & 7;            // (of the product)
+    const int gdot_cols = (variant_ & 8) ? 9 : 32;  // columns of z per batch of the all-drive gather-dot: the whole half (nine at a time
+                                                    // measured 7 % slower on the Hessian kernel: 199.9 vs 184.8 us per 8 trajectories, order 8)
     using detail::v4_chunk_reg;
     const int d = P.d, G = kV4Group;
     std::string s;
@@ -579,6 +583,80 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
                 alt ^= 1;
             }
             s += "    return r0 + r1;\n}\n";
+        }
+        // ... and for EVERY drive at once: out[l] = this lane's part of <v, G_l z>.  The column of z is read once per half into registers
+        // (54 LDS reads instead of 54 per drive: six drive waves doing six gather-dots each kept the LDS pipe busy for most of an
+        // interval), the entries of a drive are summed per magnitude (one multiply-add per entry, the magnitudes applied at the end),
+        // the drives' chains interleaved.
+        {
+            s += "static __device__ __forceinline__ void sp4_gdot_all(const double *__restrict__ Zo, const double *__restrict__ Zx, const double (&v)[SPD], double sb, const double (&mg)[SP4NMAG], double (&out)[SPM > 0 ? SPM : 1]) {\n";
+            std::vector<std::vector<std::string>> fin(P.m);  // per drive: the final sum's terms
+            for (int part = 0; part < 2; ++part) {
+                bool any = false;
+                for (int l = 0; l < P.m; ++l)
+                    for (const V4GEnt &e : P.gl[l]) any = any || (e.isB == (part == 1));
+                if (!any) continue;
+                s += "    {\n";
+                // accumulators per (drive, magnitude); the entries of the drives interleaved
+                std::vector<std::vector<const V4GEnt *>> lists(P.m);
+                std::vector<std::vector<int>> mags_of(P.m);
+                for (int l = 0; l < P.m; ++l) {
+                    for (const V4GEnt &e : P.gl[l])
+                        if (e.isB == (part == 1)) {
+                            lists[l].push_back(&e);
+                            if (std::find(mags_of[l].begin(), mags_of[l].end(), e.mag) == mags_of[l].end()) mags_of[l].push_back(e.mag);
+                        }
+                    for (int g : mags_of[l]) {
+                        snprintf(buf, sizeof buf, "        double %c%d_%d = 0.0;\n", part ? 'b' : 'a', l, g);
+                        s += buf;
+                    }
+                }
+                for (int c0 = 0; c0 < d; c0 += gdot_cols) {
+                    const int c1 = std::min(d, c0 + gdot_cols);
+                    snprintf(buf, sizeof buf, "        {\n            double z_[32];\n#pragma unroll\n            for (int i = 0; i < %d; ++i) z_[i] = %s[%d + i];\n", c1 - c0, part ? "Zx" : "Zo", c0);
+                    s += buf;
+                    std::vector<size_t> pos(P.m, 0);
+                    bool more = true;
+                    while (more) {
+                        more = false;
+                        for (int l = 0; l < P.m; ++l) {
+                            while (pos[l] < lists[l].size() && !(lists[l][pos[l]]->col >= c0 && lists[l][pos[l]]->col < c1)) ++pos[l];
+                            if (pos[l] < lists[l].size()) {
+                                const V4GEnt &e = *lists[l][pos[l]++];
+                                snprintf(buf, sizeof buf, "            %c%d_%d = __builtin_fma(%sv[%d], z_[%d], %c%d_%d);\n", part ? 'b' : 'a', l, e.mag, e.neg ? "-" : "", e.row, e.col - c0, part ? 'b' : 'a', l, e.mag);
+                                s += buf;
+                                more = true;
+                            }
+                        }
+                    }
+                    s += "            asm volatile(\"\" ::: \"memory\");\n        }\n";
+                }
+                for (int l = 0; l < P.m; ++l) {
+                    if (mags_of[l].empty()) continue;
+                    std::string sum;
+                    for (int g : mags_of[l]) {
+                        snprintf(buf, sizeof buf, "%smg[%d] * %c%d_%d", sum.empty() ? "" : " + ", g, part ? 'b' : 'a', l, g);
+                        sum += buf;
+                    }
+                    snprintf(buf, sizeof buf, "        const double p%d_%d = %s;\n", part, l, sum.c_str());
+                    s += buf;
+                    snprintf(buf, sizeof buf, part ? "sb * p%d_%d" : "p%d_%d", part, l);
+                    fin[l].push_back(buf);
+                }
+                // (the results leave the block through out[]; a memory clobber keeps the other half's reads behind this half's arithmetic)
+                for (int l = 0; l < P.m; ++l)
+                    if (!mags_of[l].empty()) {
+                        snprintf(buf, sizeof buf, "        out[%d] %s %s;\n", l, (part == 1 && fin[l].size() == 2) ? "+=" : "=", fin[l].back().c_str());
+                        s += buf;
+                    }
+                s += "        asm volatile(\"\" ::: \"memory\");\n    }\n";
+            }
+            for (int l = 0; l < P.m; ++l)
+                if (fin[l].empty()) {
+                    snprintf(buf, sizeof buf, "    out[%d] = 0.0;\n", l);
+                    s += buf;
+                }
+            s += "    (void)Zo; (void)Zx; (void)v; (void)sb; (void)mg;\n}\n";
         }
         s += "#define SP4_GDOT_SWITCH(res, l, Zo, Zx, v, sb, mg) switch (l) {";
         for (int l = 0; l < P.m; ++l) {

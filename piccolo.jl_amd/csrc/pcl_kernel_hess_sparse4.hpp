@@ -22,7 +22,8 @@
 #define SH_NW (SPM + 1)                         // the W wave + one wave per drive (two drive chains per wave, four waves with the spills in
                                                 // the accumulator registers of the unified file, measured 2.6x slower)
 #define SH_NZ (SP4Q > 2 ? SP4Q - 2 : 0)        // stored power-chain levels beyond Y itself
-#define SH_NTILES (SPM + 3 + 2 * SH_NZ)         // W, V[m], D, S, ZD[SH_NZ], ZS[SH_NZ]
+#define SH_XR (SP4Q == 2 ? 1 : 0)              // order 4: the combined power-chain tile R has a tile of its own (above: the unused top-level tile)
+#define SH_NTILES (SPM + 3 + 2 * SH_NZ + SH_XR)  // W, V[m], D, S, ZD[SH_NZ], ZS[SH_NZ] (+ R)
 #define SH_NSC ((SPM + 1) * (SPM + 2) / 2)
 
 static __device__ __forceinline__ unsigned sp4_lds_off(const double *q) {
@@ -46,13 +47,26 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
     const int nc = p.nc;                       // state columns per slice (host: the tiles fit LDS)
     const int TS = nc * SP4CS;                 // doubles per tile
     double *Wt = lds, *Vt = Wt + TS, *Dt = Vt + m * TS, *St = Dt + TS, *ZDt = St + TS, *ZSt = ZDt + SH_NZ * TS;
-    double *scal = ZSt + SH_NZ * TS;           // [m + 1][m + 2] reduced sums of the interval (slot 0: the W chain, slot 1 + l: drive l)
+    // R_j = sum_b w(j + b + 1) Z_b(|Y_{j+b+1}|): every (u,u) term of chain level j is <V_{.,j}, G_i R_j> -- the sum over the power-chain
+    // levels b is taken ONCE per level (wave 0), not once per drive pair.  Its tile: Z_{q-2} is needed for Y_q only, i.e. for one
+    // parity -- the other top-level tile is never formed.
+    double *Rt = q >= 3 ? ((q & 1) ? ZDt : ZSt) + (SH_NZ - 1) * TS : ZSt + SH_NZ * TS;
+    double *scal = ZSt + (SH_NZ + SH_XR) * TS;  // [m + 1][m + 2] reduced sums of the interval (slot 0: the W chain, slot 1 + l: drive l)
     const long long xd = (long long)n * d;
     sp_cptr magc = (sp_cptr)mags_;
     double mg[SP4NMAG];
 #pragma unroll
     for (int g = 0; g < SP4NMAG; ++g) mg[g] = magc[g];
 
+#ifdef PCL_PROFILE
+    int stamp_ = 0;  // cycle stamps of workgroup 0, first 32 per wave (dbg[32 wave + i])
+#define SH_STAMP()                                                                                                           \
+    do {                                                                                                                     \
+        if (p.dbg && blockIdx.x == 0 && lane == 0 && stamp_ < 32) p.dbg[32 * wave + stamp_++] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define SH_STAMP() do { } while (0)
+#endif
     const int n_items = p.batch * p.K;
     const int item_lo = (int)((long long)n_items * blockIdx.x / gridDim.x), item_hi = (int)((long long)n_items * (blockIdx.x + 1) / gridDim.x);
     const int S = (d + nc - 1) / nc;
@@ -97,11 +111,13 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
                     }
                 }
             }
+            SH_STAMP();
             __syncthreads();
+            SH_STAMP();
             // ---- Z phase: Z_b(D) = G Z_{b-1}(D) by wave 0, Z_b(S) by wave 1 ---------------------------------------------------
 #pragma unroll 1
             for (int bb = 1; bb <= SH_NZ; ++bb) {
-                if (wave < 2) {
+                if (wave < 2 && !(bb == SH_NZ && wave == ((q & 1) ? 0 : 1))) {  // (top level: the parity of Y_q only)
                     const double *src = wave == 0 ? (bb == 1 ? Dt : ZDt + (bb - 2) * TS) : (bb == 1 ? St : ZSt + (bb - 2) * TS);
                     double *dst = (wave == 0 ? ZDt : ZSt) + (bb - 1) * TS;
                     double x[SPD];
@@ -113,6 +129,7 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
                 }
                 __syncthreads();
             }
+            SH_STAMP();
             // ---- V phase ------------------------------------------------------------------------------------------------------
             double *Xt = wave == 0 ? Wt : Vt + (wave - 1) * TS;   // this wave's chain tile
             const unsigned oX = sp4_lds_off(Xt + own), oXx = sp4_lds_off(Xt + oth);
@@ -134,7 +151,9 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
                         SP4_GATHER_T_SWITCH(wave - 1, Wt + own, Wt + oth, Xt + own, 1.0, (half ? -1.0 : 1.0), mg)
                     }
                     wave_lds_sync();
+                    SH_STAMP();
                     __syncthreads();  // every drive wave has read W_{j-1}
+                    SH_STAMP();
                     if (j > 1 && act) sp4_product_t(x, oX, oX, oXx, 1.0, 1.0, bt, tab_t, cf);
                 } else {
                     __syncthreads();
@@ -144,8 +163,28 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
                         for (int i = 0; i < SPD; ++i) x[i] = Xt[own + i];
                         sp4_product0_t(x, 0u, oX, oXx, 0.0, 1.0, bt, tab_t, cf);  // W_j = G^T W_{j-1}, in place
                     }
+                    // R_j, behind the barrier (until there the drive waves may still be reading R_{j-1}) and behind the product (formed in
+                    // registers ahead of the barrier, its 54 registers beside the output vectors cost 57 more spills: measured 16 % slower)
+                    if (act && j < q) {
+                        double r[SPD];
+#pragma unroll
+                        for (int i = 0; i < SPD; ++i) r[i] = 0.0;
+                        double hb = hp * h * h;  // h^jj for b = 0
+#pragma unroll 1
+                        for (int bb = 0; j + bb + 1 <= q; ++bb, hb *= h) {
+                            const int jj = j + bb + 1;
+                            const double *Zt = ((jj & 1) ? (bb == 0 ? St : ZSt + (bb - 1) * TS) : (bb == 0 ? Dt : ZDt + (bb - 1) * TS)) + own;
+                            const double wz = ((jj & 1) ? -1.0 : 1.0) * p.pc[jj] * hb;
+#pragma unroll
+                            for (int i = 0; i < SPD; ++i) r[i] = __builtin_fma(wz, Zt[i], r[i]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < SPD; ++i) Rt[own + i] = r[i];
+                    }
                 }
+                SH_STAMP();
                 __syncthreads();  // W_j and every V_{l,j} are in their tiles
+                SH_STAMP();
                 // ---- what level j contributes -------------------------------------------------------------------------------
                 const double cj = p.pc[j];
                 const double Tj = cj * hp * h, T1 = j * cj * hp, sg = (j & 1) ? -1.0 : 1.0;
@@ -185,23 +224,16 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
                         if (j >= 2) s_y = __builtin_fma(j * (j - 1) * cj * (hp / h), dy, s_y);  // T''_j = j (j-1) c_j h^(j-2)
                     } else {
                         s_y = __builtin_fma(T1, dy, s_y);
-                        // (u,u): <V_{l,j}, G_i Z_b(Y_jj)> for jj = j + b + 1 <= q, every drive i
-                        double hb = hp * h * h;  // h^jj for b = 0
-#pragma unroll 1
-                        for (int bb = 0; j + bb + 1 <= q; ++bb, hb *= h) {
-                            const int jj = j + bb + 1;
-                            const double *Zt = (jj & 1) ? (bb == 0 ? St : ZSt + (bb - 1) * TS) : (bb == 0 ? Dt : ZDt + (bb - 1) * TS);
-                            const double wz = ((jj & 1) ? -1.0 : 1.0) * p.pc[jj] * hb;
+                        // (u,u): <V_{l,j}, G_i R_j>, every drive i
+                        if (j < q) {
+                            double r6[SPM > 0 ? SPM : 1];
+                            sp4_gdot_all(Rt + own, Rt + oth, v, (half ? 1.0 : -1.0), mg, r6);
 #pragma unroll
-                            for (int i = 0; i < SPM; ++i) {  // (a clobber per drive: its reads of the Z column are not shared with the next one's)
-                                double r;
-                                SP4_GDOT_SWITCH(r, i, Zt + own, Zt + oth, v, (half ? 1.0 : -1.0), mg)
-                                s_uu[i] = __builtin_fma(wz, r, s_uu[i]);
-                                asm volatile("" ::: "memory");
-                            }
+                            for (int i = 0; i < SPM; ++i) s_uu[i] += r6[i];
                         }
                     }
                 }
+                SH_STAMP();
                 hp *= h;
             }
             __syncthreads();  // the chain tiles are free: the output vectors leave through them
@@ -225,11 +257,23 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
                     if (ln_ < n) {
                         double *ol = (pass ? o2 : o1) + (long long)c0 * n + ln_;
                         const double *Tl = Xt + ln_;
+#if defined(SH_VARIANT) && (SH_VARIANT & 16)
                         for (int cl = 0; cl < nce; ++cl) ol[cl * n] = Tl[cl * SP4CS];
+#else
+                        for (int cl0 = 0; cl0 < nce; cl0 += 9) {  // nine columns per batch: one LDS round trip, not nine
+                            double t_[9];
+#pragma unroll
+                            for (int u_ = 0; u_ < 9; ++u_) t_[u_] = Tl[min(cl0 + u_, nce - 1) * SP4CS];
+#pragma unroll
+                            for (int u_ = 0; u_ < 9; ++u_)
+                                if (cl0 + u_ < nce) ol[(cl0 + u_) * n] = t_[u_];
+                        }
+#endif
                     }
                     wave_lds_sync();
                 }
             }
+            SH_STAMP();
             __syncthreads();  // (the tiles are reloaded by the next slice / interval)
         }
         // ---- scalar entries of the interval: one reduction per wave, then a fixed assembly ----------------------------------------

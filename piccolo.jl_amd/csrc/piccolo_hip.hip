@@ -806,8 +806,8 @@ std::string v4_source(const pcl_codegen::V4Plan &plan, int q, int np, int varian
 }
 
 // ... and of the Hessian-of-the-Lagrangian kernel of the same family (pcl_kernel_hess_sparse4.hpp; any order)
-std::string v4_hess_source(const pcl_codegen::V4Plan &plan, int q) {
-    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q, 1, 0, true) + "#include \"pcl_kernel_hess_sparse4.hpp\"\n";
+std::string v4_hess_source(const pcl_codegen::V4Plan &plan, int q, int variant = 0) {  // variant (profile builds): SH_VARIANT of the kernel (bits >= 16), bit 8: the gather-dot reads nine columns at a time
+    return "#include \"pcl_device_common.hpp\"\n#define SH_VARIANT " + std::to_string(variant) + "\n" + pcl_codegen::v4_functions(plan, q, 1, variant & 8, true) + "#include \"pcl_kernel_hess_sparse4.hpp\"\n";
 }
 }  // namespace
 
@@ -1460,13 +1460,13 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
     if ((ctx->opt_hess_kernel == 7 || (ctx->opt_hess_kernel == 0 && ctx->desc.pade_order != 4 && !ctx->opt_general)) && v4_available(ctx) && !ctx->v4_hess_failed) {
         const pcl_codegen::V4Plan &v4 = *ctx->v4_plan;
         fill_pade(p, ctx->desc.pade_order);
-        const int nz = p.q > 2 ? p.q - 2 : 0, ntile = p.m + 3 + 2 * nz;
+        const int nz = p.q > 2 ? p.q - 2 : 0, ntile = p.m + 3 + 2 * nz + (p.q == 2 ? 1 : 0);  // (SH_NTILES)
         auto bytes = [&](int nc) { return ((size_t)ntile * nc * (p.n + 1) + (size_t)(p.m + 1) * (p.m + 2) + 8) * sizeof(double); };
         p.nc = p.d;
         while (p.nc > 1 && bytes(p.nc) > (size_t)ctx->max_lds) p.nc = (p.nc + 1) / 2;
         if (ctx->opt_cols_per_slice > 0) p.nc = (int)std::min<int64_t>(p.nc, ctx->opt_cols_per_slice);
         if (!ctx->v4_fhess) {
-            const std::string src = v4_hess_source(v4, p.q);
+            const std::string src = v4_hess_source(v4, p.q, (int)ctx->opt_v4_variant);
             const std::string key = "hess-sparse4:" + std::to_string(p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
             ctx->v4_fhess = jit_compile(ctx->device, key, src, "pcl_hess_sparse4_kernel", true);
             if (!ctx->v4_fhess) ctx->v4_hess_failed = 1;
@@ -2276,7 +2276,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_prof = v;
     else if (!strcmp(key, "v4_variant")) {  // timing variants of kernel 4's generated product (WRONG results); recompiles
         ctx->opt_v4_variant = v;
-        ctx->v4_f = ctx->v4_feval = nullptr;
+        ctx->v4_f = ctx->v4_feval = ctx->v4_fhess = nullptr;
     }
 #endif
     else if (!strcmp(key, "host_threads"))  // host-pointer entry points: threads expanding the compact values (0 = auto)
