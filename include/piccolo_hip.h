@@ -239,35 +239,54 @@ int pcl_comm_destroy(pcl_ctx *ctx);
 
 /* tuning / introspection ----------------------------------------------------
  * Defaults are what the benchmark runs; the other settings exist for A/B measurements and for the parity tests (every
- * setting produces the same results).  Experiments of earlier rounds (stream pieces, per-XCD roles, split producer /
- * expander kernels, ablation switches) are not part of the library any more.
- * set:  "kernel_version"     0 auto | 1 one workgroup per item | 2 persistent, two workgroups per CU | 3 persistent, one
- *                            workgroup per CU with stream / matrix roles (default where its specialised instance applies)
- *       "contiguous"         kernel 3: -1 auto by launch size | 0 round-robin column slices | 1 equal contiguous column ranges
+ * setting produces the same results up to the order of additions inside a kernel family; within a family every work split is
+ * bitwise equal).  Experiments of earlier rounds (stream pieces, per-XCD roles, split producer / expander kernels, the
+ * column kernel, the two-step general-order path, ablation switches) are not part of the library any more.
+ * set:  "kernel_version"     residual + Jacobian: 0 auto | 1 one workgroup per item | 2 persistent, two workgroups per CU | 3 persistent,
+ *                            one workgroup per CU with stream / matrix roles on the matrix cores (order 4; auto for its specialised
+ *                            instance on launches below 28 state columns per CU and for the payload-fused call) | 4 the
+ *                            PATTERN-COMPILED fused kernel, any Pade order: source generated from the sparsity pattern of the
+ *                            generators and compiled on first use, one wave per chain of the recursion, no workgroup barrier
+ *                            (auto at orders 2, 6, 8, 10 and for large launches at order 4; needs sparse exact-iso generators of a
+ *                            unitary problem, 9 <= d <= 32, 1..6 drives, jit = 1: PCL_ESHAPE when forced elsewhere)
+ *       "contiguous"         kernels 3 / 4: -1 auto by launch size | 0 round-robin column slices | 1 equal contiguous column ranges
  *       "stream_workgroups"  kernel 3, contiguous: -1 auto (half) | 0 both roles in every workgroup | n stream-role workgroups
- *       "cols_per_slice"     state columns per work item (0 = heuristic; forces the round-robin split in kernel 3)
+ *       "cols_per_slice"     state columns per work item (0 = heuristic; forces the round-robin split in kernels 3 / 4)
+ *       "v4_power_tiles"     kernel 4: LDS tiles the powers of G rotate through (0 auto: q - 1 for launches of several items per
+ *                            workgroup, all q for one-item launches)
+ *       "v4_tail_mode"       kernel 4, who stores delta and the d/du, d/dh block of an item: 3 the store-stream waves behind the
+ *                            item's blocks (default) | 0 a writer wave, plain stores | 1 nontemporal | 2 write-through
+ *       "v4_flags"           kernel 4 A/B switches (same values): 1 no raised priority for the powers' wave | 2 tails only behind the
+ *                            item's last block | 4 no cooperative first item | 8 every LDS tile NaN at kernel start (tests: nothing
+ *                            reads what its item has not written) | 16 the first item's chains do not wait for the cooperative products
  *       "hess_kernel"        0 auto | 1 one workgroup per interval | 2 persistent, column chunks (fallback) | 3 one workgroup per
- *                            interval, jobs split by drive (matrix cores; default for d >= 12 where kernel 4 does not apply) | 4 the
- *                            pattern-compiled kernel: source generated from the sparsity pattern of the generators and compiled
- *                            on first use (default for sparse exact-iso generators, odd 9 <= d <= 32, m <= 6; PCL_ESHAPE when
- *                            forced elsewhere); Pade orders other than 4 always run the general-order Hessian kernel
- *       "eval_kernel"        residual only: 0 auto | 1 the matrix-core residual kernel | 2 the pattern-compiled kernel (one wave per
- *                            interval; same applicability as hess_kernel 4; auto for launches with more intervals than CUs)
- *       "general_pade_kernel" 1: run the general-order kernel for pade_order 4 too (cross-check)
- *       "general_kernel_version" residual+Jacobian at pade_order != 4: 0 auto (the lock-step kernel where the shape fits: even
- *                             n <= 64 and LDS), 1 the reference formulation, 2 the lock-step kernel or PCL_ESHAPE
+ *                            interval, jobs split by drive (matrix cores; default for d >= 12 where the pattern-compiled kernels do
+ *                            not apply) | 4 the pattern-compiled order-4 kernel (default for sparse exact-iso generators, odd
+ *                            9 <= d <= 32, m <= 6; PCL_ESHAPE when forced elsewhere) | 7 the pattern-compiled kernel for ANY order
+ *                            (auto at orders 2, 6, 8, 10; same applicability as kernel_version 4); what neither takes runs the
+ *                            general-order Hessian kernel
+ *       "eval_kernel"        residual only: 0 auto | 1 the matrix-core residual kernel (order 4) | 2 the round-2 pattern-compiled kernel
+ *                            (order 4, per-interval value tables) | 3 the pattern-compiled kernel for any order, resident
+ *                            coefficients, one wave per interval (auto wherever kernel_version 4 applies)
+ *       "general_pade_kernel" 1: run the general-order kernels for pade_order 4 too (cross-check)
+ *       "general_kernel_version" residual+Jacobian at pade_order != 4 where kernel 4 does not apply: 0 auto (the lock-step kernel where
+ *                             the shape fits: even n <= 64 and LDS), 1 the reference formulation, 2 the lock-step kernel or PCL_ESHAPE
+ *                             (a non-zero value also keeps auto away from kernel 4)
  *       "general_slices"      lock-step kernel: slices of state columns per interval (0 auto)
- *       "general_threads" (256 / 512), "general_two_step" (1: unique tiles + expansion kernel)   reference formulation
- *       "jit"                1 (default): shapes outside the static instance table are compiled on first use with hiprtc
- *                            (Hessian kernel 2 for d >= 12; fused kernel 3 when kernel_version = 3); 0: run-time-shape instances
+ *       "general_threads" (256 / 512)   reference formulation
+ *       "jit"                1 (default): kernels generated or specialised per context are compiled on first use with hiprtc (the
+ *                            pattern-compiled kernels; Hessian kernel 2 for d >= 12; fused kernel 3 when kernel_version = 3);
+ *                            0: built-in instances only
  *       "use_mfma" (1/0: plain-VALU products in kernel 1), "nt_stores" (streaming stores of the Jacobian blocks: -1 auto by launch size | 0 plain | 1 nontemporal | 2 write-through), "specialize" (1/0: shape-specialised
  *       instances), "grid" (workgroups, 0 = one per CU), "host_threads" (host-pointer entry points: threads that expand the
  *       compact values into the caller's array, 0 = auto), "host_path" (0 auto | 1 full values over PCIe | 2 compact + host expansion),
- *       "column_kernel" (fused residual + Jacobian, the column work: 1 kernel 3's matrix role, default | 2 EXPERIMENTAL pattern-compiled
- *       column kernel + kernel 3 with every workgroup streaming: same values, not faster yet; needs sparse iso generators, contiguous ranges),
- *       "debug_timing" (PCL_ENOTIMPL unless the library was built with -DPCL_PROFILE)
- * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised; 33 pattern-compiled columns + stream-only kernel 3; 60 / 61 matrix-core residual kernel, 70 pattern-compiled residual kernel; 90 + q for the
- *       general-order kernel in the reference formulation, 190 + q for the lock-step general-order kernel), "last_stream_workgroups", "last_merit_fused", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3 static / compiled | 6: pattern-compiled | 90 + q), "jit_compiles", "n_cu", "iso_structured", "drives_antisymmetric",
+ *       "debug_timing", "profile_flags", "v4_variant" (PCL_ENOTIMPL / unknown unless the library was built with -DPCL_PROFILE)
+ * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised for kernels 1-3; 40 + q kernel 4 at order
+ *       2q; 60 / 61 matrix-core residual kernel, 70 round-2 pattern-compiled residual kernel, 80 + q pattern-compiled residual kernel
+ *       at order 2q; 90 + q general-order kernel in the reference formulation, 190 + q lock-step general-order kernel),
+ *       "last_stream_workgroups", "last_merit_fused", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3
+ *       static / compiled | 6: pattern-compiled order 4 | 70 + q: pattern-compiled, order 2q | 90 + q: general-order), "jit_compiles",
+ *       "n_cu", "iso_structured", "drives_antisymmetric",
  *       "ell_width", "ell_width_t", "union_width", "occupancy_v2".  Unknown keys return PCL_EINVAL. */
 int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t value);
 int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *value);
