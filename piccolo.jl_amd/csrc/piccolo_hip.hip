@@ -1148,7 +1148,9 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact) {
     const long long bk = (long long)p.batch * p.K, ncu = std::max(ctx->n_cu, 1);
     // contiguous column ranges once every CU has about an interval's worth of columns; below that round-robin slices of the
     // intervals (an explicit cols_per_slice or contiguous = 0 / 1 decides otherwise)
-    p.contig = ctx->opt_cols_per_slice > 0 ? 0 : (ctx->opt_contig >= 0 ? (int)ctx->opt_contig : (compact || bk * d >= 28 * ncu ? 1 : 0));
+    // (compact launches -- unique tiles only, the chains are all of the work -- deal the intervals round-robin: a contiguous range that
+    //  ends inside an interval runs that interval's chains in two workgroups; 62.2 against 66.8 us per 8 trajectories)
+    p.contig = ctx->opt_cols_per_slice > 0 ? 0 : (ctx->opt_contig >= 0 ? (int)ctx->opt_contig : (!compact && bk * d >= 28 * ncu ? 1 : 0));
     if (p.contig)
         p.nc = d;
     else if (ctx->opt_cols_per_slice > 0)
@@ -1162,6 +1164,9 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact) {
     p.n_stream = 0;
     p.tail_mode = (int)ctx->opt_v4_tail_mode;
     p.v4_flags = (int)ctx->opt_v4_flags;
+    // write-through block stores (auto, launches that fit the infinity cache) pay at orders 8 and 10 only: one trajectory, plain against
+    // write-through: 24.9 / 25.4 us at order 2, 27.2 / 27.6 at 4, 28.1 / 28.9 at 6, 32.4 / 31.9 at 8
+    if (ctx->opt_nt < 0 && p.q < 4) p.nt = 0;
     const long long units = p.contig ? bk * d : bk * p.S;
     if (units > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
     const long long g = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, units) : std::min<long long>(units, ncu);
@@ -1216,14 +1221,17 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     // streaming stores of the Jacobian blocks (auto): write-through while the launch's values fit the infinity cache with room to
     // spare (one trajectory of config 3: 133 MB), plain write-back above (see store2)
     if (ctx->opt_nt < 0 && want_jac && !compact && (long long)ctx->win_count * ctx->K * jac_per_full(ctx) * 8 <= (192LL << 20)) p.nt = 2;
-    // kernel_version 4: the pattern-compiled fused kernel (sparse iso generators, any order).  auto: every order but 4, and at
-    // order 4 the launches large enough for contiguous column ranges (8 trajectories of config 3: 184 us against 190 us of the
-    // matrix-core kernel 3 on the same box; below that size kernel 3 measures the same or up to 1 us better)
-    const bool v4_big = !compact && ctx->opt_contig < 0 && ctx->opt_cols_per_slice <= 0 && ctx->opt_stream_wg < 0 && ctx->opt_grid <= 0 && ctx->opt_use_mfma != 0 &&
-                        (long long)p.batch * p.K * p.d >= 28LL * std::max(ctx->n_cu, 1);
-    const bool v4_auto = ctx->opt_kernel == 0 && (ctx->desc.pade_order != 4 || v4_big) && !ctx->opt_general && ctx->opt_general_version == 0;
+    // kernel_version 4: the pattern-compiled fused kernel (sparse iso generators, any order).  auto: every order -- at order 4 it measures
+    // 27.2 against 27.4 us for one trajectory, 184 against 190 us for 8 and 7.8 against 10.6 us per evaluation for the compact launches
+    // of the host-delivery path (kernel 3 on the same box), and one kernel family behind every entry point keeps the full and the compact
+    // values bitwise equal.  Kernel 3 keeps the payload-fused call and contexts that set its own switches.
+    const bool v4_auto = ctx->opt_kernel == 0 && (ctx->desc.pade_order != 4 || (ctx->opt_stream_wg < 0 && ctx->opt_use_mfma != 0)) && !ctx->opt_general &&
+                         ctx->opt_general_version == 0;
     if (want_jac && (ctx->opt_kernel == 4 || v4_auto)) {
-        const bool want_merit = ctx->merit_want && !compact && delta && ctx->win_first == 0 && ctx->win_count == ctx->desc.batch;
+        // the payload-fused call rides kernel 3's MERIT instance where `auto` has one (order 4, the shape-specialised instances); everywhere
+        // else it launches what pcl_eval_jac_dev launches and the payload comes from its own kernels
+        const bool want_merit = ctx->merit_want && !compact && delta && ctx->win_first == 0 && ctx->win_count == ctx->desc.batch &&
+                                ctx->opt_kernel == 0 && ctx->desc.pade_order == 4 && v3_specialised(ctx) && ctx->opt_use_mfma != 0 && v3_supported(ctx);
         const int rc = want_merit ? PCL_ENOTIMPL : launch_fused_v4(ctx, p, compact);
         if (rc != PCL_ENOTIMPL) return rc;
         if (!want_merit && ctx->opt_kernel == 4) return fail(ctx, PCL_ESHAPE, "kernel_version=4 needs sparse exact-iso generators of a unitary problem (9 <= d, tiles within LDS), 1..6 drives and jit=1 (%s)", g_jit_note.c_str());

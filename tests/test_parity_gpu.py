@@ -36,13 +36,9 @@ def product_system(cfg):
 
 
 def _auto_large_launch(c):
-    """What `auto` picks at order 4: the pattern-compiled kernel 4 once the launch is large enough for contiguous column ranges
-    (28 columns per CU), the matrix-core kernel 3 with its role split below."""
-    lk = c.get_option("last_kernel")
-    big = c.batch * c.K * c.d >= 28 * c.get_option("n_cu")
-    assert lk == (42 if big else 31), (lk, big)
-    if lk == 31 and c.batch > 1:
-        assert c.get_option("last_stream_workgroups") > 0
+    """What `auto` picks at order 4 for sparse exact-iso generators: the pattern-compiled kernel 4 (the matrix-core kernel 3 keeps the
+    payload-fused call and contexts that ask for it)."""
+    assert c.get_option("last_kernel") == 42
 
 
 def make_ctx(lay, G0, Gj, **kw):
@@ -1635,8 +1631,8 @@ def test_device_entry_points_are_graph_capturable():
 
 def test_auto_kernel_policy_by_shape():
     """`auto` picks the kernel measured best per shape (scripts/small_d_probe*.py): one workgroup per item for small
-    Hilbert dimensions, the persistent two-workgroup kernels above, kernel 3 where its shape-specialised instance applies."""
-    expect = {1: 10, 2: 10, 3: 31}
+    Hilbert dimensions, the persistent two-workgroup kernels above, the pattern-compiled kernel 4 for sparse exact-iso generators with d >= 9."""
+    expect = {1: 10, 2: 10, 3: 42}
     for cfg, kid in expect.items():
         so = po.config_system(cfg)
         Z, lay = po.synthetic_trajectory(so, 8, seed=1)
@@ -1670,14 +1666,16 @@ def test_other_specialised_shapes(levels, batch):
         Z, lay = po.synthetic_trajectory(so, N, seed=60 + s)
         Zs.append(Z)
     c = make_ctx(lay, G0, Gj, batch=batch, batch_mode=pa._lib.PCL_BATCH_TRAJ)
-    delta, vals = c.eval_jac(np.stack(Zs))
-    if batch > 1:
-        _auto_large_launch(c)
-    else:
-        assert c.get_option("last_kernel") == 31
     refs = [ref_lib.eval_jac(Z, lay, G0, Gj) for Z in Zs]
-    close(delta, np.concatenate([r[0].reshape(-1) for r in refs]))
-    close(vals, np.concatenate([r[1].reshape(-1) for r in refs]))
+    for kv, kid in ((0, 42), (3, 31)):  # auto: the pattern-compiled kernel; kernel 3: its shape-specialised instance
+        c.set_option("kernel_version", kv)
+        delta, vals = c.eval_jac(np.stack(Zs))
+        assert c.get_option("last_kernel") == kid
+        if kv == 3 and batch > 1:
+            assert c.get_option("last_stream_workgroups") > 0
+        close(delta, np.concatenate([r[0].reshape(-1) for r in refs]))
+        close(vals, np.concatenate([r[1].reshape(-1) for r in refs]))
+    c.set_option("kernel_version", 0)
     mu = np.random.default_rng(1).standard_normal((batch, lay.K, lay.x_dim))
     h_ref = np.concatenate([ref_lib.hess(Z, mu[i], lay, G0, Gj).reshape(-1) for i, Z in enumerate(Zs)])
     hv = c.hess(np.stack(Zs), mu.reshape(-1))
