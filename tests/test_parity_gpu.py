@@ -922,6 +922,37 @@ def test_pattern_compiled_fused_kernel(order):
         c.close()
 
 
+def test_pattern_compiled_fused_kernel_soak():
+    """Kernel 4 synchronises its waves through LDS counters with bounded waits (a wait that gives up writes NaN): 300 launches per
+    shape of launch (one trajectory, four, compact, contiguous compact) -- every launch bitwise equal to the first, nothing NaN."""
+    import torch
+
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    for Bn, order in ((1, 4), (4, 8)):
+        Zs = [po.synthetic_trajectory(so, 100, seed=500 + s)[0] for s in range(Bn)]
+        lay = po.synthetic_trajectory(so, 100, seed=500)[1]
+        c = make_ctx(lay, G0, Gj, batch=Bn, batch_mode=pa._lib.PCL_BATCH_TRAJ, pade_order=order)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        Zd = torch.from_numpy(np.stack(Zs)).cuda()
+        dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
+        for compact, contig in ((False, -1), (True, -1), (True, 1)):
+            out = torch.empty(c.compact_nnz if compact else c.jac_nnz, dtype=torch.float64, device="cuda")
+            c.set_option("contiguous", contig)
+            call = (lambda: c.eval_jac_compact_dev(Zd, dd, out)) if compact else (lambda: c.eval_jac_dev(Zd, dd, out))
+            call()
+            torch.cuda.synchronize()
+            assert c.get_option("last_kernel") == 40 + order // 2
+            first, firstd = out.clone(), dd.clone()
+            assert bool(torch.isfinite(first).all()) and bool(torch.isfinite(firstd).all())
+            bad = torch.zeros((), dtype=torch.int64, device="cuda")
+            for _ in range(300):
+                call()
+                bad += (out != first).sum() + (dd != firstd).sum()
+            assert int(bad.item()) == 0, (Bn, order, compact, contig)
+        c.close()
+
+
 def test_pattern_compiled_fused_kernel_ensemble_and_shapes():
     """Kernel 4 on per-member drifts (BASELINE config 4's members: 27 drift value classes, the less used ones streamed through the
     chunk registers), on a member window, on TRAJ batches, and on other sparse shapes (two 5-level transmons, d = 25, m = 4)."""
