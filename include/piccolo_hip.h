@@ -243,11 +243,10 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  * bitwise equal).  Experiments of earlier rounds (stream pieces, per-XCD roles, split producer / expander kernels, the
  * column kernel, the two-step general-order path, ablation switches) are not part of the library any more.
  * set:  "kernel_version"     residual + Jacobian: 0 auto | 1 one workgroup per item | 2 persistent, two workgroups per CU | 3 persistent,
- *                            one workgroup per CU with stream / matrix roles on the matrix cores (order 4; auto only for the payload-fused
- *                            call pcl_eval_jac_merit_dev where a shape-specialised instance exists) | 4 the
+ *                            one workgroup per CU with stream / matrix roles on the matrix cores (order 4; on request only) | 4 the
  *                            PATTERN-COMPILED fused kernel, any Pade order: source generated from the sparsity pattern of the
  *                            generators and compiled on first use, one wave per chain of the recursion, no workgroup barrier
- *                            (auto at every order, full and compact values; needs sparse exact-iso generators of a
+ *                            (auto at every order: full values, compact values and the payload-fused call; needs sparse exact-iso generators of a
  *                            unitary problem, 9 <= d <= 32, 1..6 drives, jit = 1: PCL_ESHAPE when forced elsewhere)
  *       "contiguous"         kernels 3 / 4: -1 auto by launch size | 0 round-robin column slices | 1 equal contiguous column ranges
  *       "stream_workgroups"  kernel 3, contiguous: -1 auto (half) | 0 both roles in every workgroup | n stream-role workgroups

@@ -150,9 +150,8 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     const bool tails_by_stream = p.tail_mode == 3;
     // the chains may rewrite their tiles once item it - 1 has left them
     auto outputs_taken = [&](int it) {
-        if (!tails_by_stream) {
-            gave_up = sp4_wait(sync, SP4_F_OC, it, gave_up);
-        } else {
+        if (!tails_by_stream || p.mpart) gave_up = sp4_wait(sync, SP4_F_OC, it, gave_up);
+        if (tails_by_stream) {
             for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_TS + w, it, gave_up);
         }
     };
@@ -405,13 +404,45 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
         // One wave stores the item's nce (m + 1) n tail values (and its nce n residuals) as ONE contiguous run, 1 KiB per
         // instruction: written by the chains themselves, every store covered pieces of three 432-byte runs and neighbouring
         // runs came from different waves at different times (1.7 % of the bytes cost 10 % of the launch).
-        for (int it = 0; it < n_my && !no_chains && !tails_by_stream; ++it) {
+        // With the stream waves storing the tails (tail_mode 3) this wave only forms the reduce payload, when asked
+        // (pcl_eval_jac_merit_dev): per state column <d delta/d u_l, lam>, <d delta/d h, lam>, <delta, lam> (lam = delta: half the
+        // squared norm) while the vectors are still in their tiles -- the tails are never read back from memory.  Lane (half, c) adds
+        // its half of column c in row order, then the two halves: bitwise repeatable and independent of the work split.
+        for (int it = 0; it < n_my && !no_chains && (!tails_by_stream || p.mpart); ++it) {
             int c0, nce, k, b;
             decode(it, c0, nce, k, b);
             const long long bk = (long long)b * p.K + k;
             for (int w = 0; w < SP4_NOUT; ++w) gave_up = sp4_wait(sync, SP4_F_O + w, it + 1, gave_up);
             SP4_STAMP();
-            if (!no_tails) store_outputs(c0, nce, bk, 0, 1, p.tail_mode);
+            if (p.mpart) {
+                SP4_LANEPOS();
+                const bool act = c < nce;
+                double lam[SPD];
+                if (p.mlam) {
+                    const double *lg = p.mlam + bk * xd + (long long)(c0 + cc) * n + half * d;
+#pragma unroll
+                    for (int i = 0; i < SPD; ++i) lam[i] = act ? lg[i] : 0.0;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < SPD; ++i) lam[i] = Wt[own + i];
+                }
+#pragma unroll 1
+                for (int l = 0; l < m + 2; ++l) {
+                    const double *T = (l < m ? dWt + l * SP4TILE : (l == m ? Vt : Wt)) + own;
+                    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < SPD; ++i) {
+                        if (i & 1)
+                            a1 = __builtin_fma(T[i], lam[i], a1);
+                        else
+                            a0 = __builtin_fma(T[i], lam[i], a0);
+                    }
+                    double acc = a0 + a1;
+                    acc += __shfl_xor(acc, 32, 64);
+                    if (act && half == 0) p.mpart[(bk * d + c0 + c) * (m + 2) + l] = (l == m + 1 && !p.mlam) ? 0.5 * acc : acc;
+                }
+            }
+            if (!tails_by_stream && !no_tails) store_outputs(c0, nce, bk, 0, 1, p.tail_mode);
             wave_lds_sync();
             sp4_post(sync + SP4_F_OC, it + 1, lane);  // the chains may rewrite their tiles
             SP4_STAMP();

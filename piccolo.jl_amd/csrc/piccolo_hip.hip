@@ -1137,7 +1137,7 @@ static int launch_eval_v4(pcl_ctx *ctx, KParams &p) {
     ctx->last_n_stream = 0;
     return PCL_OK;
 }
-static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact) {
+static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_merit = false) {
     if (!v4_available(ctx) || !p.jac) return PCL_ENOTIMPL;
     const pcl_codegen::V4Plan &v4 = *ctx->v4_plan;
     fill_pade(p, ctx->desc.pade_order);
@@ -1174,6 +1174,12 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact) {
     // tiles of the ring in use: q - 1 when workgroups walk several items (the P wave must not run a whole item ahead: measured
     // 8 % on 8 trajectories per launch), all the module has for one-item launches (0.4 us there); option v4_power_tiles overrides
     p.v4_np = ctx->opt_v4_np > 0 ? (int)std::min<int64_t>(ctx->opt_v4_np, np) : (units > g ? std::max(1, std::min(np, p.q - 1)) : np);
+    if (want_merit && p.tail_mode == 3) {
+        if (!ctx->dmcols) HIP_TRY(ctx, hipMalloc((void **)&ctx->dmcols, (size_t)ctx->desc.batch * p.K * p.d * (p.m + 2) * sizeof(double)));
+        p.mpart = ctx->dmcols;
+        p.mlam = ctx->merit_lam;
+        ctx->merit_fused = 1;
+    }
     const double *tab = ctx->dv4_tab + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_drift_pad : 0);
     const double *dcf = ctx->dv4_dcf + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_dcf_pad : 0);
     void *args[] = {(void *)&p, (void *)&tab, (void *)&ctx->dv4_mags, (void *)&dcf};
@@ -1228,13 +1234,12 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
     const bool v4_auto = ctx->opt_kernel == 0 && (ctx->desc.pade_order != 4 || (ctx->opt_stream_wg < 0 && ctx->opt_use_mfma != 0)) && !ctx->opt_general &&
                          ctx->opt_general_version == 0;
     if (want_jac && (ctx->opt_kernel == 4 || v4_auto)) {
-        // the payload-fused call rides kernel 3's MERIT instance where `auto` has one (order 4, the shape-specialised instances); everywhere
-        // else it launches what pcl_eval_jac_dev launches and the payload comes from its own kernels
-        const bool want_merit = ctx->merit_want && !compact && delta && ctx->win_first == 0 && ctx->win_count == ctx->desc.batch &&
-                                ctx->opt_kernel == 0 && ctx->desc.pade_order == 4 && v3_specialised(ctx) && ctx->opt_use_mfma != 0 && v3_supported(ctx);
-        const int rc = want_merit ? PCL_ENOTIMPL : launch_fused_v4(ctx, p, compact);
+        // the payload-fused call (pcl_eval_jac_merit_dev): kernel 4's otherwise idle writer wave forms the payload's dot products per
+        // state column while the item's vectors are in their tiles -- any order
+        const bool want_merit = ctx->merit_want && !compact && delta && ctx->win_first == 0 && ctx->win_count == ctx->desc.batch;
+        const int rc = launch_fused_v4(ctx, p, compact, want_merit);
         if (rc != PCL_ENOTIMPL) return rc;
-        if (!want_merit && ctx->opt_kernel == 4) return fail(ctx, PCL_ESHAPE, "kernel_version=4 needs sparse exact-iso generators of a unitary problem (9 <= d, tiles within LDS), 1..6 drives and jit=1 (%s)", g_jit_note.c_str());
+        if (ctx->opt_kernel == 4) return fail(ctx, PCL_ESHAPE, "kernel_version=4 needs sparse exact-iso generators of a unitary problem (9 <= d, tiles within LDS), 1..6 drives and jit=1 (%s)", g_jit_note.c_str());
     }
     // residual only on the same products (eval_kernel 3; auto: every order -- measured against the other residual kernels)
     if (!want_jac && (ctx->opt_eval_kernel == 3 || (ctx->opt_eval_kernel == 0 && ctx->opt_kernel == 0 && !ctx->opt_general && ctx->opt_general_version == 0))) {

@@ -1469,9 +1469,10 @@ def test_fused_reduce_payload_equals_the_separate_kernels(M, N):
     """pcl_eval_jac_merit_dev: the fused kernel's matrix waves form the payload's dot products per state column while the
     column is in LDS.  delta / Jacobian values must be bit-identical to pcl_eval_jac_dev's, the payload equal to
     pcl_merit_grad_dev's (which the oracle's dense J^T lam pins in test_ensemble_merit_and_shared_gradient_on_device)
-    to summation-order rounding, for lam = delta and for given multipliers with weights; every work split of kernel 3
+    to summation-order rounding, for lam = delta and for given multipliers with weights; every work split of a kernel
     (role split at the shipped 8-member share, round-robin slices, contiguous ranges) gives the same bits; and the payload
-    itself against the C oracle's tails (J^T lam restricted to u_k, dt_k)."""
+    itself against the C oracle's tails (J^T lam restricted to u_k, dt_k).  Both carriers: the writer wave of kernel 4 (auto) and
+    the MERIT instance of kernel 3."""
     import torch
 
     osys, psys, lay, Z, traj = _config4_share(M, N)
@@ -1487,48 +1488,51 @@ def test_fused_reduce_payload_equals_the_separate_kernels(M, N):
     rng = np.random.default_rng(11)
     lam = torch.from_numpy(rng.standard_normal(c.n_rows)).cuda()
     w = 1.0 + 0.25 * np.arange(M)
-    c.set_option("kernel_version", 3)  # the payload rides kernel 3; at 8 members `auto` hands the plain launch to kernel 4 (other rounding)
-    c.eval_jac_dev(Zd, dd, vd)
-    for lam_d, weights in ((None, None), (lam, w)):
-        c.set_weights(weights)
-        ref = torch.empty(ln, dtype=torch.float64, device="cuda")
-        c.merit_grad_dev(dd, lam_d, vd, ref)
-        outs = []
-        splits = ((-1, -1, 0, 0),) if M == 8 else ((-1, -1, 0, 0), (0, -1, 0, 0), (0, -1, 5, 14), (1, 0, 7, 0), (1, 3, 9, 0))
-        for contig, sw, grid, cps in splits:
-            c.set_option("contiguous", contig)
-            c.set_option("stream_workgroups", sw)
-            c.set_option("grid", grid)
-            c.set_option("cols_per_slice", cps)
-            dd2.zero_(), vd2.zero_()
-            out = torch.full((ln,), float("nan"), dtype=torch.float64, device="cuda")
-            c.eval_jac_merit_dev(Zd, lam_d, dd2, vd2, out)
-            torch.cuda.synchronize()
-            assert c.get_option("last_kernel") == 31 and c.get_option("last_merit_fused") == 1
-            assert torch.equal(dd2, dd) and torch.equal(vd2, vd)
-            outs.append(out.cpu().numpy())
-        for o in outs:
-            assert np.array_equal(o, outs[0])  # per-column partials, added in a fixed order: independent of the work split
-        r = ref.cpu().numpy()
-        scale = max(1.0, float(np.abs(r).max()))
-        assert np.abs(outs[0] - r).max() <= 1e-12 * scale, np.abs(outs[0] - r).max()
-        # ... and against the C oracle: tails of the oracle's Jacobian dotted with the multipliers
-        per_d, per_j = xd * K, po.jac_nnz_per_interval(lay) * K
-        g = np.zeros((K, m + 1))
-        phi = 0.0
-        lam_h = None if lam_d is None else lam_d.cpu().numpy()
-        for i, s in enumerate(osys):
-            d_ref, j_ref = ref_lib.eval_jac(Z, lay, s.G_drift, np.array(s.G_drives), x_off=i * xd)
-            d_ref = np.asarray(d_ref).reshape(K, d, n)
-            li = d_ref if lam_h is None else lam_h[i * per_d : (i + 1) * per_d].reshape(K, d, n)
-            tails = np.asarray(j_ref).reshape(K, -1)[:, 2 * d * n * n :].reshape(K, d, m + 1, n)
-            wi = 1.0 if weights is None else weights[i]
-            g += wi * np.einsum("kcln,kcn->kl", tails, li)
-            phi += wi * (0.5 if lam_h is None else 1.0) * float((li * d_ref).sum())
-        o = outs[0]
-        assert abs(o[0] - phi) <= 1e-12 * max(1.0, abs(phi))
-        close(o[1 : 1 + K * m].reshape(K, m), g[:, :m], 1e-11)
-        close(o[1 + K * m :], g[:, m], 1e-11)
+    for kv, kid in ((0, 42), (3, 31)):  # auto: the writer wave of kernel 4; kernel_version 3: the MERIT instance of kernel 3
+        c.set_option("kernel_version", kv)
+        for k_, v_ in (("contiguous", -1), ("stream_workgroups", -1), ("grid", 0), ("cols_per_slice", 0)):
+            c.set_option(k_, v_)
+        c.eval_jac_dev(Zd, dd, vd)
+        for lam_d, weights in ((None, None), (lam, w)):
+            c.set_weights(weights)
+            ref = torch.empty(ln, dtype=torch.float64, device="cuda")
+            c.merit_grad_dev(dd, lam_d, vd, ref)
+            outs = []
+            splits = ((-1, -1, 0, 0),) if M == 8 else ((-1, -1, 0, 0), (0, -1, 0, 0), (0, -1, 5, 14), (1, 0 if kv else -1, 7, 0), (1, 3 if kv else -1, 9, 0))
+            for contig, sw, grid, cps in splits:
+                c.set_option("contiguous", contig)
+                c.set_option("stream_workgroups", sw)
+                c.set_option("grid", grid)
+                c.set_option("cols_per_slice", cps)
+                dd2.zero_(), vd2.zero_()
+                out = torch.full((ln,), float("nan"), dtype=torch.float64, device="cuda")
+                c.eval_jac_merit_dev(Zd, lam_d, dd2, vd2, out)
+                torch.cuda.synchronize()
+                assert c.get_option("last_kernel") == kid and c.get_option("last_merit_fused") == 1
+                assert torch.equal(dd2, dd) and torch.equal(vd2, vd)
+                outs.append(out.cpu().numpy())
+            for o in outs:
+                assert np.array_equal(o, outs[0])  # per-column partials, added in a fixed order: independent of the work split
+            r = ref.cpu().numpy()
+            scale = max(1.0, float(np.abs(r).max()))
+            assert np.abs(outs[0] - r).max() <= 1e-12 * scale, np.abs(outs[0] - r).max()
+            # ... and against the C oracle: tails of the oracle's Jacobian dotted with the multipliers
+            per_d, per_j = xd * K, po.jac_nnz_per_interval(lay) * K
+            g = np.zeros((K, m + 1))
+            phi = 0.0
+            lam_h = None if lam_d is None else lam_d.cpu().numpy()
+            for i, s in enumerate(osys):
+                d_ref, j_ref = ref_lib.eval_jac(Z, lay, s.G_drift, np.array(s.G_drives), x_off=i * xd)
+                d_ref = np.asarray(d_ref).reshape(K, d, n)
+                li = d_ref if lam_h is None else lam_h[i * per_d : (i + 1) * per_d].reshape(K, d, n)
+                tails = np.asarray(j_ref).reshape(K, -1)[:, 2 * d * n * n :].reshape(K, d, m + 1, n)
+                wi = 1.0 if weights is None else weights[i]
+                g += wi * np.einsum("kcln,kcn->kl", tails, li)
+                phi += wi * (0.5 if lam_h is None else 1.0) * float((li * d_ref).sum())
+            o = outs[0]
+            assert abs(o[0] - phi) <= 1e-12 * max(1.0, abs(phi))
+            close(o[1 : 1 + K * m].reshape(K, m), g[:, :m], 1e-11)
+            close(o[1 + K * m :], g[:, m], 1e-11)
     c.set_weights(None)
     # a member window is not fused: the two separate calls run, same payload layout
     if M > 1:
@@ -1538,8 +1542,9 @@ def test_fused_reduce_payload_equals_the_separate_kernels(M, N):
 
 
 def test_fused_reduce_payload_other_shapes():
-    """Shapes without a built-in MERIT instance: `auto` takes another kernel and pcl_eval_jac_merit_dev runs the two separate
-    calls (same outputs); with kernel_version = 3 the MERIT instance of the shape is compiled on first use."""
+    """Other shapes: where kernel 4 applies (d = 9) its writer wave forms the payload; where `auto` takes kernel 1 (d = 4)
+    pcl_eval_jac_merit_dev runs the two separate calls (same outputs); with kernel_version = 3 the MERIT instance of the shape is
+    compiled on first use."""
     import torch
 
     two3 = po.multi_transmon_system([4.0, 4.1], [0.2, 0.21], [[0, 0.01], [0.01, 0]], levels_per_transmon=3, drive_bounds=0.1)  # d = 9
@@ -1563,7 +1568,7 @@ def test_fused_reduce_payload_other_shapes():
                 c.eval_jac_merit_dev(Zd, lam_d, dd2, vd2, out)
                 torch.cuda.synchronize()
                 fused = c.get_option("last_merit_fused")
-                assert fused == (1 if c.get_option("last_kernel") == 32 else 0)
+                assert fused == (1 if c.get_option("last_kernel") in (32, 42) else 0)  # kernel 3 compiled for the shape / kernel 4
                 assert torch.equal(dd2, dd) and torch.equal(vd2, vd)
                 r, o = ref.cpu().numpy(), out.cpu().numpy()
                 assert np.abs(o - r).max() <= 1e-12 * max(1.0, float(np.abs(r).max()))
