@@ -247,7 +247,8 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *                            PATTERN-COMPILED fused kernel, any Pade order: source generated from the sparsity pattern of the
  *                            generators and compiled on first use, one wave per chain of the recursion, no workgroup barrier
  *                            (auto at every order: full values, compact values and the payload-fused call; needs sparse exact-iso generators of a
- *                            unitary problem, 9 <= d <= 32, 1..6 drives, jit = 1: PCL_ESHAPE when forced elsewhere)
+ *                            unitary problem, 9 <= d <= 32, 1..6 drives, jit = 1: PCL_ESHAPE when forced elsewhere) | 5 the
+ *                            small-system kernel: one wave per interval, any order (auto for n <= 8 rows, n * cols <= 64, m <= 8)
  *       "contiguous"         kernels 3 / 4: -1 auto by launch size | 0 round-robin column slices | 1 equal contiguous column ranges
  *       "stream_workgroups"  kernel 3, contiguous: -1 auto (half) | 0 both roles in every workgroup | n stream-role workgroups
  *       "cols_per_slice"     state columns per work item (0 = heuristic; forces the round-robin split in kernels 3 / 4)
@@ -281,7 +282,7 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *       compact values into the caller's array, 0 = auto), "host_path" (0 auto | 1 full values over PCIe | 2 compact + host expansion),
  *       "debug_timing", "profile_flags", "v4_variant" (PCL_ENOTIMPL / unknown unless the library was built with -DPCL_PROFILE)
  * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised for kernels 1-3; 40 + q kernel 4 at order
- *       2q; 60 / 61 matrix-core residual kernel, 70 round-2 pattern-compiled residual kernel, 80 + q pattern-compiled residual kernel
+ *       2q; 50 + q the small-system kernel; 60 / 61 matrix-core residual kernel, 70 round-2 pattern-compiled residual kernel, 80 + q pattern-compiled residual kernel
  *       at order 2q; 90 + q general-order kernel in the reference formulation, 190 + q lock-step general-order kernel),
  *       "last_stream_workgroups", "last_merit_fused", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3
  *       static / compiled | 6: pattern-compiled order 4 | 70 + q: pattern-compiled, order 2q | 90 + q: general-order), "jit_compiles",

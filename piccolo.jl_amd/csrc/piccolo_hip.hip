@@ -35,6 +35,7 @@
 #include "pcl_kernels_fused_v2.hpp"
 #include "pcl_kernel_fused_v3.hpp"
 #include "pcl_kernel_eval.hpp"
+#include "pcl_kernel_fused_small.hpp"
 #include "pcl_kernels_hessian.hpp"
 #include "pcl_kernel_hessian_v3.hpp"
 #include "pcl_kernels_misc.hpp"
@@ -57,6 +58,7 @@ struct pcl_ctx {
     hipStream_t stream = nullptr;
     // device copies
     double *dG0 = nullptr, *ducoef = nullptr, *dcsr_val = nullptr, *dcsc_val = nullptr;
+    double *dGjd = nullptr;  // small systems (n <= 8): the drives dense, [m][n*n] column-major (pcl_fused_small_kernel)
     int *dupos = nullptr, *dcsr_ptr = nullptr, *dcsr_col = nullptr, *dcsc_ptr = nullptr, *dcsc_row = nullptr, *dxoffs = nullptr;
     int n_upos = 0;
     int *dumap = nullptr, *dell_col = nullptr;
@@ -435,6 +437,10 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     }
     std::vector<double> g0(dsc->G0, dsc->G0 + nn * (dsc->per_member_G0 ? dsc->batch : 1));
     CREATE_TRY(upload(ctx, &ctx->dG0, g0));
+    if (n <= 8 && m >= 1) {
+        std::vector<double> gjd(dsc->Gj, dsc->Gj + nn * m);
+        CREATE_TRY(upload(ctx, &ctx->dGjd, gjd));
+    }
     CREATE_TRY(upload(ctx, &ctx->dupos, upos));
     CREATE_TRY(upload(ctx, &ctx->ducoef, ucoef));
     CREATE_TRY(upload(ctx, &ctx->dcsr_ptr, csr_ptr));
@@ -494,7 +500,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard dev_guard_(ctx->device);
     (void)pcl_comm_destroy(ctx);
-    void *ptrs[] = {ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
+    void *ptrs[] = {ctx->dGjd, ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
                     ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg, ctx->dellt_col, ctx->dellt_val,
                     ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout, ctx->dreduce};
@@ -1247,6 +1253,24 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         if (rc != PCL_ENOTIMPL) return rc;
         if (ctx->opt_eval_kernel == 3) return fail(ctx, PCL_ESHAPE, "eval_kernel=3 needs sparse exact-iso generators of a unitary problem (9 <= d, tiles within LDS), 1..6 drives and jit=1 (%s)", g_jit_note.c_str());
     }
+    // kernel_version 5 (auto wherever it applies: n <= 8 rows, n * cols <= 64, m <= 8 -- BASELINE configs 1 and 2, every order): one
+    // wave per interval, one round of global loads, everything else in registers and 5 KB of LDS (pcl_kernel_fused_small.hpp)
+    if ((ctx->opt_kernel == 5 || (ctx->opt_kernel == 0 && !ctx->opt_general && ctx->opt_general_version == 0)) && ctx->n <= 8 && ctx->n * ctx->cols <= 64 &&
+        p.m <= 8 && (p.m == 0 || ctx->dGjd)) {  // (the payload-fused call: this kernel + the separate payload kernels)
+        fill_pade(p, ctx->desc.pade_order);
+        const long long items = (long long)p.batch * p.K;
+        if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+        const long long grid = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, items) : std::min<long long>(items, 16LL * std::max(ctx->n_cu, 1));
+        if (want_jac)
+            hipLaunchKernelGGL(pcl_fused_small_kernel<true>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, p, (const double *)ctx->dGjd);
+        else
+            hipLaunchKernelGGL(pcl_fused_small_kernel<false>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, p, (const double *)ctx->dGjd);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->last_kernel = 50 + p.q;
+        ctx->last_n_stream = 0;
+        return PCL_OK;
+    }
+    if (ctx->opt_kernel == 5) return fail(ctx, PCL_ESHAPE, "kernel_version=5 (the small-system kernel) needs n <= 8 rows, n * cols <= 64 and at most 8 drives (n = %d, cols = %d, m = %d)", ctx->n, ctx->cols, p.m);
     if (ctx->desc.pade_order != 4 || ctx->opt_general || ctx->vec) return launch_pade_general(ctx, p, want_jac);
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
     // auto: kernel 3 where its shape-specialised instance applies (BASELINE configs 3/4/5); its run-time-shape instances
@@ -2344,7 +2368,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         }
     }
     else if (!strcmp(key, "kernel_version")) {
-        if (v < 0 || v > 4) return fail(ctx, PCL_EINVAL, "kernel_version must be 0 (auto), 1, 2, 3 or 4");
+        if (v < 0 || v > 5) return fail(ctx, PCL_EINVAL, "kernel_version must be 0 (auto), 1, 2, 3, 4 or 5");
         ctx->opt_kernel = v;
     }
     else

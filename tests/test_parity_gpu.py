@@ -542,7 +542,7 @@ def test_profiling_hooks_are_not_in_the_shipped_library():
         with pytest.raises(pa.PclError) as e:
             c.set_option(key, 1)
         assert e.value.code == pa._lib.PCL_EINVAL
-    for v in (5, 6):
+    for v in (6, 7):
         with pytest.raises(pa.PclError):
             c.set_option("kernel_version", v)
     c.close()
@@ -1049,6 +1049,16 @@ def test_general_pade_orders_vs_oracle(order, cfg, N):
         assert c.get_option("last_kernel") == 40 + order // 2
         close(delta, d_ref, 1e-11)
         close(vals, j_ref, 1e-11)
+    elif cfg in (1, 2) and order != 4:  # auto: the small-system kernel (n <= 8 rows), every order; full and compact values (order 4 runs with general_pade_kernel = 1 here)
+        assert c.get_option("last_kernel") == 50 + order // 2
+        close(delta, d_ref, 1e-11)
+        close(vals, j_ref, 1e-11)
+        close(c.eval(Z), d_ref, 1e-11)
+        assert c.get_option("last_kernel") == 50 + order // 2
+        c.set_option("host_path", 2)
+        d2, v2 = c.eval_jac(Z)
+        assert np.array_equal(d2, delta) and np.array_equal(v2, vals)
+        c.set_option("host_path", 1)
     else:
         assert c.get_option("last_kernel") == 190 + order // 2 and np.array_equal(vals, vals1)
     c.set_option("general_kernel_version", 2)  # (the device-pointer checks below: the lock-step kernel)
@@ -1666,9 +1676,10 @@ def test_device_entry_points_are_graph_capturable():
 
 
 def test_auto_kernel_policy_by_shape():
-    """`auto` picks the kernel measured best per shape (scripts/small_d_probe*.py): one workgroup per item for small
-    Hilbert dimensions, the persistent two-workgroup kernels above, the pattern-compiled kernel 4 for sparse exact-iso generators with d >= 9."""
-    expect = {1: 10, 2: 10, 3: 42}
+    """`auto` picks the kernel measured best per shape (scripts/small_d_probe*.py): the one-wave-per-interval
+    kernel for small systems (n <= 8), the persistent two-workgroup kernels for general generators, the pattern-compiled kernel 4 for
+    sparse exact-iso generators with d >= 9."""
+    expect = {1: 52, 2: 52, 3: 42}
     for cfg, kid in expect.items():
         so = po.config_system(cfg)
         Z, lay = po.synthetic_trajectory(so, 8, seed=1)
