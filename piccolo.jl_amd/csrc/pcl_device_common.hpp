@@ -30,6 +30,7 @@ struct KParams {
     const int *csc_row;
     const double *csc_val;
     const int *x_offs;     // per-member state offsets
+    int x_off0;            // >= 0: every unit of the launch has this state offset (no dependent load of x_offs); -1: per member
     const int *umap;       // n*n: index into the union-pattern coefficient table, or -1
     const double *ell_val; // ELL form of the drives: [m][n][ell_w] (row-major), zero padded
     const int *ell_col;

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(64) void pcl_fused_small_kernel(const KParams p, co
         const int k = item % p.K, b = item / p.K;
         // ---- every global load of the interval, issued together --------------------------------------------------------------
         const double *zc = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim;
-        const double *xk = zc + p.x_offs[p.z_batch_stride ? 0 : b];
+        const double *xk = zc + (p.x_off0 >= 0 ? p.x_off0 : p.x_offs[p.z_batch_stride ? 0 : b]);  // (a load the state loads would wait for)
         const double h = zc[p.dt_off];
         double u[PCL_SM_M], gl[PCL_SM_M];
 #pragma unroll

@@ -368,7 +368,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             int c0, nce, k, b;
             decode(it, c0, nce, k, b);
             SP4_STAMP();
-            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + p.x_offs[p.z_batch_stride ? 0 : b] + (long long)c0 * n + (lane < n ? lane : 0);
+            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + (p.x_off0 >= 0 ? p.x_off0 : p.x_offs[p.z_batch_stride ? 0 : b]) + (long long)c0 * n + (lane < n ? lane : 0);
             const double *zn = zk + p.z_dim;
             bool first = true;
             for (int cb = 0; cb < nce; cb += NB) {
@@ -643,7 +643,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4E_NW) void pcl_eval_sparse4_kern
         sp_cptr tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
         // the interval's states, lane = row (coalesced), every load in flight at once (one memory round trip) -> D, S tiles [column][row]
         {
-            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + p.x_offs[p.z_batch_stride ? 0 : b] + (ln_ < n ? ln_ : 0);
+            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + (p.x_off0 >= 0 ? p.x_off0 : p.x_offs[p.z_batch_stride ? 0 : b]) + (ln_ < n ? ln_ : 0);
             const double *zn = zk + p.z_dim;
             constexpr int NB = SPD;
 #pragma unroll

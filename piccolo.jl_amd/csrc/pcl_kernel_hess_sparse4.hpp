@@ -99,7 +99,7 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
             const int own = (act ? c : 0) * SP4CS + half * d, oth = (act ? c : 0) * SP4CS + (1 - half) * d;
             // ---- inputs: M -> W tile, D, S (lane = row, one column per load; the waves share the columns) ---------------------
             {
-                const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + p.x_offs[p.z_batch_stride ? 0 : b] + (long long)c0 * n + (ln_ < n ? ln_ : 0);
+                const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + (p.x_off0 >= 0 ? p.x_off0 : p.x_offs[p.z_batch_stride ? 0 : b]) + (long long)c0 * n + (ln_ < n ? ln_ : 0);
                 const double *zn = zk + p.z_dim;
                 const double *mu = p.mu + bk * xd + (long long)c0 * n + (ln_ < n ? ln_ : 0);
                 for (int cl = wave; cl < nce; cl += SH_NW) {

@@ -127,7 +127,7 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
         double pm[SPD], pxn[SPD], pxc[SPD];  // lane = row, one column per register
         auto request = [&](int item) {
             const int k = item % p.K, b = item / p.K;
-            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + p.x_offs[p.z_batch_stride ? 0 : b];
+            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + (p.x_off0 >= 0 ? p.x_off0 : p.x_offs[p.z_batch_stride ? 0 : b]);
             const double *mu = p.mu + ((long long)b * p.K + k) * SPXD;
             const double *mul = mu + lane, *zl = zk + lane, *zn = zk + p.z_dim + lane;
 #pragma unroll

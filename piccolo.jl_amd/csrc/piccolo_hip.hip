@@ -878,6 +878,7 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.csc_row = ctx->dcsc_row;
     p.csc_val = ctx->dcsc_val;
     p.x_offs = ctx->dxoffs + (D.batch_mode == PCL_BATCH_MEMBERS ? ctx->win_first : 0);
+    p.x_off0 = (D.batch_mode != PCL_BATCH_MEMBERS || ctx->win_count == 1) ? (int)ctx->x_offs[D.batch_mode == PCL_BATCH_MEMBERS ? ctx->win_first : 0] : -1;
     p.umap = ctx->dumap;
     p.uell_l = ctx->duell_l;
     p.uell_v = ctx->duell_v;
