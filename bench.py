@@ -356,6 +356,23 @@ def main():
                                      "batch8": {"evals_per_s": B * st / w8, "us_per_launch_kernel": d8 / st * 1e6,
                                                 "frac_of_hbm_peak": abytes * B / (d8 / st) / 1e9 / HBM_PEAK_GBS, "kernel_id": i8["kernel_id"]},
                                      "kernel": describe(i1["kernel_id"], 0)}
+        # one trajectory per launch (what a solver working on ONE problem calls): Hessian of the Lagrangian and residual only, orders 4 and 8
+        ex["single_trajectory"] = {}
+        for order in (4, 8):
+            ms1 = pa.HipPadeMultistart(G0, Gj, t0, 1, device=local, pade_order=order)
+            c1 = ms1.ctx
+            c1.set_stream(stream.cuda_stream)
+            Z1 = torch.from_numpy(seeds[0].datavec.copy()[None]).cuda()
+            d1_ = torch.empty(c1.n_rows, dtype=torch.float64, device="cuda")
+            mu1 = torch.randn(c1.n_rows, dtype=torch.float64, device="cuda")
+            h1 = torch.empty(c1.hess_nnz, dtype=torch.float64, device="cuda")
+            wh1, dh1 = time_steps(lambda: c1.hess_dev(Z1, mu1, h1), st, 5, torch, None)
+            we1, de1 = time_steps(lambda: c1.eval_dev(Z1, d1_), st, 5, torch, None)
+            ex["single_trajectory"]["order%d" % order] = {"hessian_of_lagrangian_us": dh1 / st * 1e6, "hess_kernel_id": c1.get_option("last_hess_kernel"),
+                                                          "residual_only_us": de1 / st * 1e6, "eval_kernel_id": c1.get_option("last_kernel"),
+                                                          "residual_four_waves_per_interval": bool(c1.get_option("last_eval_coop"))}
+            ms1.close()
+            del Z1, d1_, mu1, h1
         ms = pa.HipPadeMultistart(G0, Gj, t0, B, device=local)
         c = ms.ctx
         c.set_stream(stream.cuda_stream)

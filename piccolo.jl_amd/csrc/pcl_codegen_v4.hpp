@@ -428,6 +428,7 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
     snprintf(buf, sizeof buf, "#define SP4_COOP %d\n#define SP4_NPART %d\n", parts ? 1 : 0, kV4Parts);
     s += buf;
     if (parts) {
+        std::vector<std::pair<int, int>> part_rows;
         std::vector<size_t> cum(n_groups + 1, 0);
         for (const V4Term &t : P.terms) cum[t.row / G + 1]++;
         for (int g = 0; g < n_groups; ++g) cum[g + 1] += cum[g] + 4;  // (+ the group's epilogue)
@@ -439,12 +440,28 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
             if (k == kV4Parts - 1) hi = n_groups;
             const std::string part_name = "sp4_product0_p" + std::to_string(k);  // (buf is the emitter's scratch)
             emit_product(part_name.c_str(), false, false, lo, hi);
+            const std::string party_name = "sp4_product_p" + std::to_string(k);  // ... and with Y: the cooperative residual kernel
+            emit_product(party_name.c_str(), true, false, lo, hi);
+            part_rows.push_back({lo * G, std::min(d, hi * G)});
             lo = hi;
         }
         s += "static __device__ __forceinline__ void sp4_product0_part(int part, const double (&x)[SPD], unsigned vO, unsigned vOo, double beta, double betas, sp_cptr tab, const sp4_cf &cf) {\n"
              "    switch (part) {\n";
         for (int k = 0; k < kV4Parts; ++k) {
             snprintf(buf, sizeof buf, "    %s sp4_product0_p%d(x, 0u, vO, vOo, 0.0, beta, betas, tab, cf); break;\n", k == kV4Parts - 1 ? "default:" : ("case " + std::to_string(k) + ":").c_str(), k);
+            s += buf;
+        }
+        s += "    }\n}\n";
+        s += "static __device__ __forceinline__ void sp4_product_part(int part, const double (&x)[SPD], unsigned vY, unsigned vO, unsigned vOo, double alpha, double beta, double betas, sp_cptr tab, const sp4_cf &cf) {\n"
+             "    switch (part) {\n";
+        for (int k = 0; k < kV4Parts; ++k) {
+            snprintf(buf, sizeof buf, "    %s sp4_product_p%d(x, vY, vO, vOo, alpha, beta, betas, tab, cf); break;\n", k == kV4Parts - 1 ? "default:" : ("case " + std::to_string(k) + ":").c_str(), k);
+            s += buf;
+        }
+        s += "    }\n}\n";
+        s += "static __device__ __forceinline__ void sp4_part_rows(int part, int &r0, int &r1) {\n    switch (part) {\n";
+        for (int k = 0; k < kV4Parts; ++k) {
+            snprintf(buf, sizeof buf, "    %s r0 = %d; r1 = %d; break;\n", k == kV4Parts - 1 ? "default:" : ("case " + std::to_string(k) + ":").c_str(), part_rows[k].first, part_rows[k].second);
             s += buf;
         }
         s += "    }\n}\n";

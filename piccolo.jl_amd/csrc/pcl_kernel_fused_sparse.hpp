@@ -703,3 +703,102 @@ extern "C" __global__ __launch_bounds__(64 * SP4E_NW) void pcl_eval_sparse4_kern
         wave_lds_sync();  // (the tiles are rewritten by this wave's next interval)
     }
 }
+
+#if SP4_COOP
+// ------------------------------------------------------------------------------------------------------------------------------
+// Residual only, SMALL launches (fewer intervals than CUs: a line-search trial on one trajectory): the four waves of a workgroup share
+// ONE interval -- every product in four row ranges (sp4_product_part: the rows keep their instruction sequences, the same bits as the
+// one-wave kernel above), the result of a level double-buffered so that a level costs one workgroup barrier.  One wave per interval is
+// the longer chain there (8.8 us per launch for 99 intervals: q cold products of 3-4 k cycles each behind the loads).
+extern "C" __global__ __launch_bounds__(64 * SP4_NPART) void pcl_eval_sparse4c_kernel(const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ mags_, const double *__restrict__ dcf_tab) {
+    extern __shared__ double lds[];
+    constexpr int d = SPD, n = SPN, q = SP4Q;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *Dt = lds, *St = Dt + SP4TILE, *X0 = St + SP4TILE, *X1 = X0 + SP4TILE;
+    sp_cptr magc = (sp_cptr)mags_;
+    double mg[SP4NMAG];
+#pragma unroll
+    for (int g = 0; g < SP4NMAG; ++g) mg[g] = magc[g];
+    int pr0, pr1;
+    sp4_part_rows(wave, pr0, pr1);
+    const int n_items = p.batch * p.K;
+    const long long xd = (long long)n * d;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int k = item % p.K, b = item / p.K;
+        int ln_ = lane;
+        asm volatile("" : "+v"(ln_));
+        const int half = ln_ >> 5, c = ln_ & 31;
+        const bool act = c < d;
+        const int own = (act ? c : 0) * SP4CS + half * d, oth = (act ? c : 0) * SP4CS + (1 - half) * d;
+        sp_cptr zc = (sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim);
+        double u[SPM > 0 ? SPM : 1];
+#pragma unroll
+        for (int l = 0; l < SPM; ++l) u[l] = zc[p.u_off + l];
+        const double h = zc[p.dt_off];
+        sp4_cf cf;
+        SP4_SET_CF(cf, u, mg);
+        SP4_SET_DCF(cf, (sp_cptr)(dcf_tab + (p.g0_batch_stride ? (long long)b * SP4NDCFP : 0)));
+        sp_cptr tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
+        {  // the interval's states, lane = row, the waves share the columns: every load of a wave in flight at once
+            const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + (p.x_off0 >= 0 ? p.x_off0 : p.x_offs[p.z_batch_stride ? 0 : b]) + (ln_ < n ? ln_ : 0);
+            const double *zn = zk + p.z_dim;
+            constexpr int NB = (SPD + SP4_NPART - 1) / SP4_NPART;
+            double xc[NB], xn[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int cl = wave + SP4_NPART * j;
+                if (cl < SPD) {
+                    xc[j] = zk[cl * n];
+                    xn[j] = zn[cl * n];
+                }
+            }
+            if (ln_ < n) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int cl = wave + SP4_NPART * j;
+                    if (cl < SPD) {
+                        Dt[cl * SP4CS + ln_] = xn[j] - xc[j];
+                        St[cl * SP4CS + ln_] = xn[j] + xc[j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {  // level q: this wave's rows
+            const double *Yq = (q & 1) ? St : Dt;
+            const double aq = ((q & 1) ? -1.0 : 1.0) * p.pc[q];
+            if (act)
+                for (int i = pr0; i < pr1; ++i) X0[own + i] = aq * Yq[own + i];
+        }
+        __syncthreads();
+        const unsigned oD = sp4_lds_off(Dt + own), oS = sp4_lds_off(St + own);
+        const double hu = sp4_uniform(h);
+        double *Xc = X0, *Xn = X1;
+#pragma unroll 1
+        for (int s = 0; s < q; ++s) {
+            const int j = q - 1 - s;
+            const double alpha = sp4_uniform(((j & 1) ? -1.0 : 1.0) * p.pc[j]);
+            double x[SPD];
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) x[i] = Xc[own + i];
+                sp4_product_part(wave, x, (j & 1) ? oS : oD, sp4_lds_off(Xn + own), sp4_lds_off(Xn + oth), alpha, hu, half ? -hu : hu, tab, cf);
+            }
+            __syncthreads();  // every row of the level is in the other tile
+            double *t_ = Xc;
+            Xc = Xn;
+            Xn = t_;
+        }
+        {  // tile -> memory: the interval's n d residuals are one contiguous run, two rows per lane, a quarter per wave
+            double *dst = p.delta + (long long)item * xd;
+            for (int e2 = tid; e2 < d * d; e2 += 64 * SP4_NPART) {
+                const int cl = e2 / d, r0 = 2 * (e2 - cl * d);
+                const double *src = Xc + cl * SP4CS + r0;
+                store2(dst + 2 * e2, src[0], src[1], 0);
+            }
+        }
+        __syncthreads();  // (the tiles are rewritten by the next interval)
+    }
+}
+#endif

@@ -94,7 +94,8 @@ struct pcl_ctx {
     // pattern-compiled FUSED residual + Jacobian kernel (pcl_codegen_v4.hpp, any Pade order): plan, drift tables, magnitudes
     pcl_codegen::V4Plan *v4_plan = nullptr;
     double *dv4_tab = nullptr, *dv4_tab_t = nullptr, *dv4_mags = nullptr, *dv4_dcf = nullptr;
-    hipFunction_t v4_f = nullptr, v4_feval = nullptr, v4_fhess = nullptr;
+    hipFunction_t v4_f = nullptr, v4_feval = nullptr, v4_fevalc = nullptr /* cooperative residual kernel (optional) */, v4_fhess = nullptr;
+    int64_t opt_eval_coop = -1, last_eval_coop = 0;  // residual only: four waves per interval (-1 auto: launches of at most two intervals per CU)
     int v4_hess_failed = 0;
     int v4_failed = 0;
     int64_t opt_v4_variant = 0;     // PCL_PROFILE builds: timing variants of the generated product (wrong results)
@@ -1113,8 +1114,9 @@ static int v4_module(pcl_ctx *ctx, int q, int np) {
     const std::string key = "fused-sparse:" + std::to_string(q) + ":" + std::to_string(std::hash<std::string>{}(src));
     ctx->v4_f = jit_compile(ctx->device, key, src, "pcl_fused_sparse_kernel", true);
     ctx->v4_feval = ctx->v4_f ? jit_compile(ctx->device, key, src, "pcl_eval_sparse4_kernel", true) : nullptr;
+    ctx->v4_fevalc = (ctx->v4_feval && src.find("#define SP4_COOP 1") != std::string::npos) ? jit_compile(ctx->device, key, src, "pcl_eval_sparse4c_kernel", true) : nullptr;
     if (!ctx->v4_f || !ctx->v4_feval) {
-        ctx->v4_f = ctx->v4_feval = nullptr;
+        ctx->v4_f = ctx->v4_feval = ctx->v4_fevalc = nullptr;
         ctx->v4_failed = 1;
         return PCL_ENOTIMPL;
     }
@@ -1139,7 +1141,17 @@ static int launch_eval_v4(pcl_ctx *ctx, KParams &p) {
     const double *tab = ctx->dv4_tab + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_drift_pad : 0);
     const double *dcf = ctx->dv4_dcf + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_dcf_pad : 0);
     void *args[] = {(void *)&p, (void *)&tab, (void *)&ctx->dv4_mags, (void *)&dcf};
-    HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_feval, (unsigned)grid, 1, 1, 64 * nw, 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
+    // small launches (up to two intervals per CU: a line-search trial on one to four trajectories): four waves per interval, the products in
+    // four row ranges -- config 3, one trajectory: 8.7 -> 6.3 us per launch at order 4, 11.9 -> 7.8 at order 8; four trajectories 9.1 -> 7.9;
+    // eight: 10.0 -> 11.8, so one wave per interval above (option eval_coop: -1 auto | 0 | 1)
+    const bool coop = ctx->v4_fevalc && (ctx->opt_eval_coop == 1 || (ctx->opt_eval_coop < 0 && items <= 2LL * std::max(ctx->n_cu, 1)));
+    ctx->last_eval_coop = coop ? 1 : 0;
+    if (coop) {
+        const size_t ldsc = (size_t)4 * p.d * (p.n + 1) * sizeof(double);
+        const long long gc = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, items) : std::min<long long>(items, 3LL * std::max(ctx->n_cu, 1));
+        HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fevalc, (unsigned)gc, 1, 1, 64 * 4, 1, 1, (unsigned)ldsc, ctx->stream, args, nullptr));
+    } else
+        HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_feval, (unsigned)grid, 1, 1, 64 * nw, 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
     ctx->last_kernel = 80 + p.q;
     ctx->last_n_stream = 0;
     return PCL_OK;
@@ -2314,7 +2326,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_prof = v;
     else if (!strcmp(key, "v4_variant")) {  // timing variants of kernel 4's generated product (WRONG results); recompiles
         ctx->opt_v4_variant = v;
-        ctx->v4_f = ctx->v4_feval = ctx->v4_fhess = nullptr;
+        ctx->v4_f = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = nullptr;
     }
 #endif
     else if (!strcmp(key, "host_threads"))  // host-pointer entry points: threads expanding the compact values (0 = auto)
@@ -2348,6 +2360,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "v4_tail_mode must be 0 .. 3");
         ctx->opt_v4_tail_mode = v;
     }
+    else if (!strcmp(key, "eval_coop"))  // pattern-compiled residual kernel: four waves per interval (-1 auto by launch size | 0 | 1)
+        ctx->opt_eval_coop = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "eval_kernel")) {  // residual only: 0 auto, 1 matrix-core kernel, 2 pattern-compiled kernel
         if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "eval_kernel must be 0 .. 3");
         ctx->opt_eval_kernel = v;
@@ -2408,6 +2422,8 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->opt_kernel;
     else if (!strcmp(key, "last_kernel"))
         *v = ctx->last_kernel;
+    else if (!strcmp(key, "last_eval_coop"))
+        *v = ctx->last_eval_coop;
     else if (!strcmp(key, "last_merit_fused"))
         *v = ctx->merit_fused;
     else if (!strcmp(key, "contiguous"))

@@ -1886,16 +1886,22 @@ def test_residual_only_kernel():
         close(d, ref)
         assert np.array_equal(d, c.eval(np.stack(Zs)))
     # the residual kernel on the products of kernel 4 (resident coefficients, no per-interval table; auto for sparse iso generators)
+    # ... one wave per interval, or -- small launches -- four waves per interval with the products in four row ranges (eval_coop): the same bits
+    first = None
     for ek in (3, 0):
         c.set_option("eval_kernel", ek)
-        for grid in (0, 1, 2, 5, 1000):
-            c.set_option("grid", grid)
-            d = c.eval(np.stack(Zs))
-            assert c.get_option("last_kernel") == 82
-            close(d, ref)
-            assert np.array_equal(d, c.eval(np.stack(Zs)))
+        for coop in (-1, 0, 1):
+            c.set_option("eval_coop", coop)
+            for grid in (0, 1, 2, 5, 1000):
+                c.set_option("grid", grid)
+                d = c.eval(np.stack(Zs))
+                assert c.get_option("last_kernel") == 82 and c.get_option("last_eval_coop") == (0 if coop == 0 else 1)
+                close(d, ref)
+                first = d if first is None else first
+                assert np.array_equal(d, first)
     c.set_option("grid", 0)
     c.set_option("eval_kernel", 0)
+    c.set_option("eval_coop", -1)
     ms.close()
     big = [po.synthetic_trajectory(so, 100, seed=500 + s)[0] for s in range(3)]  # full size, auto
     layb = po.synthetic_trajectory(so, 100, seed=500)[1]
