@@ -268,6 +268,8 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *       "eval_kernel"        residual only: 0 auto | 1 the matrix-core residual kernel (order 4) | 2 the round-2 pattern-compiled kernel
  *                            (order 4, per-interval value tables) | 3 the pattern-compiled kernel for any order, resident
  *                            coefficients, one wave per interval (auto wherever kernel_version 4 applies)
+ *       "eval_coop"          eval_kernel 3: four waves per interval, the products in four row ranges (-1 auto: launches of at most two
+ *                            intervals per CU | 0 | 1); the same values
  *       "general_pade_kernel" 1: run the general-order kernels for pade_order 4 too (cross-check)
  *       "general_kernel_version" residual+Jacobian at pade_order != 4 where kernel 4 does not apply: 0 auto (the lock-step kernel where
  *                             the shape fits: even n <= 64 and LDS), 1 the reference formulation, 2 the lock-step kernel or PCL_ESHAPE
@@ -284,7 +286,7 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised for kernels 1-3; 40 + q kernel 4 at order
  *       2q; 50 + q the small-system kernel; 60 / 61 matrix-core residual kernel, 70 round-2 pattern-compiled residual kernel, 80 + q pattern-compiled residual kernel
  *       at order 2q; 90 + q general-order kernel in the reference formulation, 190 + q lock-step general-order kernel),
- *       "last_stream_workgroups", "last_merit_fused", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3
+ *       "last_stream_workgroups", "last_merit_fused", "last_eval_coop", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3
  *       static / compiled | 6: pattern-compiled order 4 | 70 + q: pattern-compiled, order 2q | 90 + q: general-order), "jit_compiles",
  *       "n_cu", "iso_structured", "drives_antisymmetric",
  *       "ell_width", "ell_width_t", "union_width", "occupancy_v2".  Unknown keys return PCL_EINVAL. */
