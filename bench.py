@@ -428,7 +428,8 @@ def main():
         d2 = torch.empty(i2.ctx.n_rows, dtype=torch.float64, device="cuda")
         v2 = torch.empty(i2.ctx.jac_nnz, dtype=torch.float64, device="cuda")
         w, dv = time_steps(lambda: i2.ctx.eval_jac_dev(Z2, d2, v2), 200, 20, torch, None)
-        ex["config2_cnot"] = {"evals_per_s": 200 / w, "us_per_eval_wall": w / 200 * 1e6, "us_per_eval_kernel": dv / 200 * 1e6}
+        ex["config2_cnot"] = {"evals_per_s": 200 / w, "us_per_eval_wall": w / 200 * 1e6, "us_per_eval_kernel": dv / 200 * 1e6, "kernel_id": i2.ctx.get_option("last_kernel"),
+                              "kernel": "pcl_fused_small_kernel (one wave per interval)" if i2.ctx.get_option("last_kernel") // 10 == 5 else "pcl_fused_kernel"}
         i2.close()
         out["other_rates"] = ex
     if rank == 0 and world == 1:

@@ -14,6 +14,8 @@ ALL="--steps 50 --warmup 5 --no-cpu-baseline"                                   
 SINGLE="--workload single --steps 50 --warmup 5 --no-cpu-baseline --no-extras"   # the headline launch only
 MULTI="--workload multistart --steps 30 --warmup 5 --no-cpu-baseline --no-extras"
 run trace "$ALL" --kernel-trace --stats
+run trace_single "$SINGLE" --kernel-trace --stats     # the headline launch alone: its average duration, unmixed with the compact launches of the same grid
+run trace_multistart "$MULTI" --kernel-trace --stats
 run single_write "$SINGLE" --pmc WRITE_SIZE
 run single_fetch "$SINGLE" --pmc FETCH_SIZE
 run multistart_write "$MULTI" --pmc WRITE_SIZE
