@@ -541,67 +541,10 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
             s += buf;
         }
         s += " default: break; }\n";
-        // <v, G_l z> = <G_l^T v, z>: this lane's part is  sum_j pa[j] zo[j] + sum_j pb[j] zx[j]  with pa = A_l^T v, pb = sb B_l^T v over its
-        // half-rows (z: this lane's own / other half of column c in LDS; sb = -1 in half 0, +1 in half 1 as in sp4_gather_<l>).
-        // sp4_gtv_<l> forms the parts a drive has (register arithmetic only, once per level); sp4_pdot_<l> is one dot product per
-        // power-chain level b -- one LDS read per multiply-add, none of them shared with another drive.
-        for (int l = 0; l < P.m; ++l) {
-            bool hasA = false, hasB = false;
-            for (const V4GEnt &e : P.gl[l]) (e.isB ? hasB : hasA) = true;
-            // nine rows of G_l^T v at a time (part = 0, 1, 2): the whole vector next to v and the two output vectors does not fit
-            snprintf(buf, sizeof buf, "template <int PART> static __device__ __forceinline__ void sp4_gtv_%d(const double (&v)[SPD], double sb, const double (&mg)[SP4NMAG], double (&pa)[9], double (&pb)[9]) {\n", l);
-            s += buf;
-            for (int part9 = 0; part9 * 9 < d; ++part9) {
-                snprintf(buf, sizeof buf, "    if constexpr (PART == %d) {\n", part9);
-                s += buf;
-                for (int part = 0; part < 2; ++part) {
-                    if (!(part ? hasB : hasA)) continue;
-                    for (int j = part9 * 9; j < std::min(d, part9 * 9 + 9); ++j) {  // (G_l^T v)_j over the entries of column j
-                        std::string ex;
-                        for (const V4GEnt &e : P.gl[l])
-                            if (e.col == j && e.isB == (part == 1)) {
-                                snprintf(buf, sizeof buf, "%smg[%d] * v[%d]", ex.empty() ? (e.neg ? "-" : "") : (e.neg ? " - " : " + "), e.mag, e.row);
-                                ex += buf;
-                            }
-                        if (ex.empty()) ex = "0.0";
-                        snprintf(buf, sizeof buf, part ? "        pb[%d] = sb * (%s);\n" : "        pa[%d] = %s;\n", j - part9 * 9, ex.c_str());
-                        s += buf;
-                    }
-                }
-                s += "    }\n";
-            }
-            s += "    (void)pa; (void)pb; (void)sb; (void)v; (void)mg;\n}\n";
-            snprintf(buf, sizeof buf, "template <int NR> static __device__ __forceinline__ double sp4_pdot_%d(const double (&pa)[9], const double (&pb)[9], const double *__restrict__ Zo, const double *__restrict__ Zx) {\n    double r0 = 0.0, r1 = 0.0;\n", l);
-            s += buf;
-            if (hasA) s += "#pragma unroll\n    for (int j = 0; j < NR; ++j) r0 = __builtin_fma(pa[j], Zo[j], r0);\n";
-            if (hasB) s += "#pragma unroll\n    for (int j = 0; j < NR; ++j) r1 = __builtin_fma(pb[j], Zx[j], r1);\n";
-            s += "    (void)pa; (void)pb; (void)Zo; (void)Zx;\n    return r0 + r1;\n}\n";
-        }
     }
     if (with_hessian) {
-        // this lane's part of <v, G_l z>: sum_i v[i] (G_l z)_i over its half-rows (z: this lane's own / other half of column c in LDS;
-        // sb = -1 in half 0, +1 in half 1 as in sp4_gather_<l>)
-        for (int l = 0; l < P.m; ++l) {
-            snprintf(buf, sizeof buf, "static __device__ __forceinline__ double sp4_gdot_%d(const double *__restrict__ Zo, const double *__restrict__ Zx, const double (&v)[SPD], double sb, const double (&mg)[SP4NMAG]) {\n    double r0 = 0.0, r1 = 0.0;\n", l);
-            s += buf;
-            int alt = 0;
-            for (int i = 0; i < d; ++i) {
-                std::string ea, eb;
-                for (const V4GEnt &e : P.gl[l])
-                    if (e.row == i) {
-                        std::string &dst = e.isB ? eb : ea;
-                        snprintf(buf, sizeof buf, "%smg[%d] * %s[%d]", dst.empty() ? (e.neg ? "-" : "") : (e.neg ? " - " : " + "), e.mag, e.isB ? "Zx" : "Zo", e.col);
-                        dst += buf;
-                    }
-                if (ea.empty() && eb.empty()) continue;
-                std::string g = eb.empty() ? "(" + ea + ")" : (ea.empty() ? "(sb * (" + eb + "))" : "((" + ea + ") + sb * (" + eb + "))");
-                snprintf(buf, sizeof buf, "    r%d = __builtin_fma(v[%d], %s, r%d);\n", alt, i, g.c_str(), alt);
-                s += buf;
-                alt ^= 1;
-            }
-            s += "    return r0 + r1;\n}\n";
-        }
-        // ... and for EVERY drive at once: out[l] = this lane's part of <v, G_l z>.  The column of z is read once per half into registers
+        // out[l] = this lane's part of <v, G_l z> = sum_i v[i] (G_l z)_i over its half-rows, for EVERY drive at once (z: this lane's own / other
+        // half of column c in LDS; sb = -1 in half 0, +1 in half 1 as in sp4_gather_<l>).  The column of z is read once per half into registers
         // (54 LDS reads instead of 54 per drive: six drive waves doing six gather-dots each kept the LDS pipe busy for most of an
         // interval), the entries of a drive are summed per magnitude (one multiply-add per entry, the magnitudes applied at the end),
         // the drives' chains interleaved.
@@ -675,25 +618,6 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
                 }
             s += "    (void)Zo; (void)Zx; (void)v; (void)sb; (void)mg;\n}\n";
         }
-        s += "#define SP4_GDOT_SWITCH(res, l, Zo, Zx, v, sb, mg) switch (l) {";
-        for (int l = 0; l < P.m; ++l) {
-            snprintf(buf, sizeof buf, " case %d: res = sp4_gdot_%d(Zo, Zx, v, sb, mg); break;", l, l);
-            s += buf;
-        }
-        s += " default: res = 0.0; break; }\n";
-    }
-    if (with_hessian) {
-        s += "template <int L, int PART> static __device__ __forceinline__ void sp4_gtv(const double (&v)[SPD], double sb, const double (&mg)[SP4NMAG], double (&pa)[9], double (&pb)[9]) {\n";
-        for (int l = 0; l < P.m; ++l) {
-            snprintf(buf, sizeof buf, "    if constexpr (L == %d) sp4_gtv_%d<PART>(v, sb, mg, pa, pb);\n", l, l);
-            s += buf;
-        }
-        s += "}\ntemplate <int L, int NR> static __device__ __forceinline__ double sp4_pdot(const double (&pa)[9], const double (&pb)[9], const double *Zo, const double *Zx) {\n";
-        for (int l = 0; l < P.m; ++l) {
-            snprintf(buf, sizeof buf, "    if constexpr (L == %d) return sp4_pdot_%d<NR>(pa, pb, Zo, Zx);\n", l, l);
-            s += buf;
-        }
-        s += "    return 0.0;\n}\n";
     }
     s += "#define SP4_GATHER_SWITCH(l, Wo, Wx, X, hs, sb, mg) switch (l) {";
     for (int l = 0; l < P.m; ++l) {

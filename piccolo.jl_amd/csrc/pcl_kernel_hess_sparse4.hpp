@@ -1,7 +1,7 @@
 // pcl_kernel_hess_sparse4.hpp -- Hessian of the Lagrangian at ANY diagonal Pade order 2q, PATTERN-COMPILED.
 // Included by generated source only (pcl_codegen_v4.hpp with the Hessian functions): SPD, SPM, SPN, SP4Q, the products
 // sp4_product_t / sp4_product0_t (G(u)^T x) and sp4_product0 (G(u) x), the gathers sp4_gather_t_<l> (G_l^T w) and the gather-dots
-// sp4_gdot_<l> (<v, G_l z>) are defined before this file.
+// sp4_gdot_all (<v, G_l z> for every drive l) are defined before this file.
 //
 // With M = mu_k (n x d), Y_j = (-1)^j X_{k+1} - X_k, T_j = c_j h^j, T'_j = j c_j h^(j-1), T''_j = j (j-1) c_j h^(j-2):
 //     W_0 = M, W_j = G^T W_{j-1}                        V_{l,j} = G^T V_{l,j-1} + G_l^T W_{j-1}  (V_{l,0} = 0)        Z_b(Y) = G^b Y

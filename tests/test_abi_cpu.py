@@ -282,16 +282,17 @@ def test_pattern_compiled_fused_and_hessian_sources(lib, tmp_path):
     whole = re.findall(pat, src[src.index("void sp4_product0("):src.index("#define SP4_COOP")])
     parts = []
     for k in range(4):
-        body = src[src.index("void sp4_product0_p%d(" % k):src.index("void sp4_product0_p%d(" % (k + 1)) if k < 3 else src.index("void sp4_product0_part(")]
-        parts.append(re.findall(pat, body))
-        assert len(parts[-1]) > nz // 8
+        a, b = src.index("void sp4_product0_p%d(" % k), src.index("void sp4_product_p%d(" % k)  # without Y | with Y (the cooperative residual kernel)
+        e = src.index("void sp4_product0_p%d(" % (k + 1)) if k < 3 else src.index("void sp4_product0_part(")
+        parts.append(re.findall(pat, src[a:b]))
+        assert len(parts[-1]) > nz // 8 and re.findall(pat, src[b:e]) == parts[-1]
     strip = lambda lines: [re.sub(r"a([UV])[01]_", r"a\1_", x) for x in lines]  # (the accumulator set alternates with the group's position)
     assert strip(sum(parts, [])) == strip(whole)
     members = synthetic.config4_members(0, 3)
     srcE = source([s.G_drift for s in members], 2, 0)
     assert "s_load_dwordx16" in srcE  # 27 value classes: the less used ones are streamed
     srcH = source([s3.G_drift], 4, 1)
-    assert "pcl_kernel_hess_sparse4.hpp" in srcH and "void sp4_product_t(" in srcH and "sp4_gdot_5(" in srcH and "void sp4_gdot_all(" in srcH
+    assert "pcl_kernel_hess_sparse4.hpp" in srcH and "void sp4_product_t(" in srcH and "void sp4_gdot_all(" in srcH and "sp4_gtv" not in srcH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     csrc = os.path.join(os.path.dirname(pa.__file__), "csrc")
     for name, text, kernels in (("fused", src, ("pcl_fused_sparse_kernel", "pcl_eval_sparse4_kernel")), ("fusedE", srcE, ("pcl_fused_sparse_kernel",)),
