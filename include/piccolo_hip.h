@@ -265,6 +265,9 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *                            9 <= d <= 32, m <= 6; PCL_ESHAPE when forced elsewhere) | 7 the pattern-compiled kernel for ANY order
  *                            (auto at orders 2, 6, 8, 10; same applicability as kernel_version 4); what neither takes runs the
  *                            general-order Hessian kernel
+ *       "hess_split"         hess_kernel 7: two workgroups per interval, half of the drive chains each, the scalar entries assembled by the
+ *                            one that arrives last (-1 auto: launches of at most n_cu / 2 intervals, and where it avoids column
+ *                            slices | 0 | 1); the same values
  *       "eval_kernel"        residual only: 0 auto | 1 the matrix-core residual kernel (order 4) | 2 the round-2 pattern-compiled kernel
  *                            (order 4, per-interval value tables) | 3 the pattern-compiled kernel for any order, resident
  *                            coefficients, one wave per interval (auto wherever kernel_version 4 applies)
@@ -286,7 +289,7 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised for kernels 1-3; 40 + q kernel 4 at order
  *       2q; 50 + q the small-system kernel; 60 / 61 matrix-core residual kernel, 70 round-2 pattern-compiled residual kernel, 80 + q pattern-compiled residual kernel
  *       at order 2q; 90 + q general-order kernel in the reference formulation, 190 + q lock-step general-order kernel),
- *       "last_stream_workgroups", "last_merit_fused", "last_eval_coop", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3
+ *       "last_stream_workgroups", "last_merit_fused", "last_eval_coop", "last_hess_split", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3
  *       static / compiled | 6: pattern-compiled order 4 | 70 + q: pattern-compiled, order 2q | 90 + q: general-order), "jit_compiles",
  *       "n_cu", "iso_structured", "drives_antisymmetric",
  *       "ell_width", "ell_width_t", "union_width", "occupancy_v2".  Unknown keys return PCL_EINVAL. */

@@ -19,11 +19,15 @@
 #pragma once
 
 #define SP4CS (SPN + 1)
-#define SH_NW (SPM + 1)                         // the W wave + one wave per drive (two drive chains per wave, four waves with the spills in
-                                                // the accumulator registers of the unified file, measured 2.6x slower)
+#ifndef SH_SPLIT
+#define SH_SPLIT 1                               // workgroups per interval: each takes SH_MH of the drives (and its own copy of the W and power chains)
+#endif
+#define SH_MH ((SPM + SH_SPLIT - 1) / SH_SPLIT)  // drives per workgroup
+#define SH_NW (SH_MH + 1)                        // the W wave + one wave per drive (two drive chains per wave, four waves with the spills in
+                                                 // the accumulator registers of the unified file, measured 2.6x slower)
 #define SH_NZ (SP4Q > 2 ? SP4Q - 2 : 0)        // stored power-chain levels beyond Y itself
 #define SH_XR (SP4Q == 2 ? 1 : 0)              // order 4: the combined power-chain tile R has a tile of its own (above: the unused top-level tile)
-#define SH_NTILES (SPM + 3 + 2 * SH_NZ + SH_XR)  // W, V[m], D, S, ZD[SH_NZ], ZS[SH_NZ] (+ R)
+#define SH_NTILES (SH_MH + 3 + 2 * SH_NZ + SH_XR)  // W, V[SH_MH], D, S, ZD[SH_NZ], ZS[SH_NZ] (+ R)
 #define SH_NSC ((SPM + 1) * (SPM + 2) / 2)
 
 static __device__ __forceinline__ unsigned sp4_lds_off(const double *q) {
@@ -38,15 +42,27 @@ static __device__ __forceinline__ void sp4_static_for(F f) {
     }
 }
 
+// Exchange between the SH_SPLIT workgroups of an interval (they may run on different XCDs, whose L2s are not coherent with each other):
+// write-through stores and cache-bypassing loads at system scope; no fence -- a release would write the workgroup's 160 KB of
+// output vectors back from L2 first (measured in round 2: 20-60 % of a launch).
+static __device__ __forceinline__ void sh_store_coherent(double *q, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(q), "v"(v) : "memory"); }
+static __device__ __forceinline__ double sh_load_coherent(const double *q) {
+    double v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(q) : "memory");
+    return v;
+}
+
 extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel(const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ drift_tab_t,
-                                                                                const double *__restrict__ mags_, const double *__restrict__ dcf_tab) {
+                                                                                const double *__restrict__ mags_, const double *__restrict__ dcf_tab,
+                                                                                double *xch /* SH_SPLIT > 1: [interval][workgroup][(SH_MH + 1)(m + 2)] reduced sums */,
+                                                                                unsigned int *xcnt /* ... [interval] arrivals (self-resetting) */) {
     extern __shared__ double lds[];
     constexpr int d = SPD, n = SPN, m = SPM, q = SP4Q;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nc = p.nc;                       // state columns per slice (host: the tiles fit LDS)
     const int TS = nc * SP4CS;                 // doubles per tile
-    double *Wt = lds, *Vt = Wt + TS, *Dt = Vt + m * TS, *St = Dt + TS, *ZDt = St + TS, *ZSt = ZDt + SH_NZ * TS;
+    double *Wt = lds, *Vt = Wt + TS, *Dt = Vt + SH_MH * TS, *St = Dt + TS, *ZDt = St + TS, *ZSt = ZDt + SH_NZ * TS;
     // R_j = sum_b w(j + b + 1) Z_b(|Y_{j+b+1}|): every (u,u) term of chain level j is <V_{.,j}, G_i R_j> -- the sum over the power-chain
     // levels b is taken ONCE per level (wave 0), not once per drive pair.  Its tile: Z_{q-2} is needed for Y_q only, i.e. for one
     // parity -- the other top-level tile is never formed.
@@ -67,10 +83,14 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
 #else
 #define SH_STAMP() do { } while (0)
 #endif
-    const int n_items = p.batch * p.K;
-    const int item_lo = (int)((long long)n_items * blockIdx.x / gridDim.x), item_hi = (int)((long long)n_items * (blockIdx.x + 1) / gridDim.x);
+    const int n_units = p.batch * p.K * SH_SPLIT;  // (interval, drive group)
+    const int unit_lo = (int)((long long)n_units * blockIdx.x / gridDim.x), unit_hi = (int)((long long)n_units * (blockIdx.x + 1) / gridDim.x);
     const int S = (d + nc - 1) / nc;
-    for (int item = item_lo; item < item_hi; ++item) {
+    for (int unit = unit_lo; unit < unit_hi; ++unit) {
+        const int item = unit / SH_SPLIT, grp = unit - item * SH_SPLIT;
+        const int dl = grp * SH_MH + wave - 1;          // this wave's drive (wave 0: the W chain)
+        const bool drv = wave > 0 && dl < m;            // (m odd: the last workgroup has a wave without a drive)
+        const bool wout = grp == 0;                     // the W chain's outputs leave through the first workgroup
         const int k = item % p.K, b = item / p.K;
         const long long bk = item;
         double *H = p.hess + bk * p.hess_per;
@@ -141,20 +161,21 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
 #pragma unroll 1
             for (int j = 1; j <= q; ++j) {
                 if (wave > 0) {  // V_{l,j} = G^T V_{l,j-1} + G_l^T W_{j-1}
+                    const bool on = act && drv;
                     double x[SPD];
-                    if (j > 1 && act) {
+                    if (j > 1 && on) {
 #pragma unroll
                         for (int i = 0; i < SPD; ++i) x[i] = Xt[own + i];
                     }
                     wave_lds_sync();
-                    if (act) {
-                        SP4_GATHER_T_SWITCH(wave - 1, Wt + own, Wt + oth, Xt + own, 1.0, (half ? -1.0 : 1.0), mg)
+                    if (on) {
+                        SP4_GATHER_T_SWITCH(dl, Wt + own, Wt + oth, Xt + own, 1.0, (half ? -1.0 : 1.0), mg)
                     }
                     wave_lds_sync();
                     SH_STAMP();
                     __syncthreads();  // every drive wave has read W_{j-1}
                     SH_STAMP();
-                    if (j > 1 && act) sp4_product_t(x, oX, oX, oXx, 1.0, 1.0, bt, tab_t, cf);
+                    if (j > 1 && on) sp4_product_t(x, oX, oX, oXx, 1.0, 1.0, bt, tab_t, cf);
                 } else {
                     __syncthreads();
                     double x[SPD];
@@ -188,7 +209,7 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
                 // ---- what level j contributes -------------------------------------------------------------------------------
                 const double cj = p.pc[j];
                 const double Tj = cj * hp * h, T1 = j * cj * hp, sg = (j & 1) ? -1.0 : 1.0;
-                if (act) {
+                if (act && (wave == 0 ? wout : drv)) {
                     // (memory clobbers between the stages: left alone, the compiler hoists every LDS read of the level to its top --
                     //  the Y column and the Z columns of six drives next to v and the two output vectors: hundreds of spills)
                     double v[SPD];
@@ -244,11 +265,12 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
                     o1 = H + SH_NSC + (long long)m * xd;
                     o2 = H + SH_NSC + (long long)(2 * m + 1) * xd;
                 } else {
-                    o1 = H + SH_NSC + (long long)(wave - 1) * xd;
-                    o2 = H + SH_NSC + (long long)(m + 1 + wave - 1) * xd;
+                    o1 = H + SH_NSC + (long long)dl * xd;
+                    o2 = H + SH_NSC + (long long)(m + 1 + dl) * xd;
                 }
+                const bool outw = wave == 0 ? wout : drv;  // (uniform per wave)
 #pragma unroll 1
-                for (int pass = 0; pass < 2; ++pass) {
+                for (int pass = 0; pass < 2 && outw; ++pass) {
                     if (act) {
 #pragma unroll
                         for (int i = 0; i < SPD; ++i) Xt[own + i] = pass ? accN[i] : accK[i];
@@ -287,6 +309,48 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
             }
         }
         __syncthreads();
+#if SH_SPLIT > 1
+        // the workgroups of the interval exchange their rows of reduced sums through memory; the one that arrives last assembles the
+        // entries.  Nobody waits for anybody: no assumption on which workgroups are resident together.
+        {
+            constexpr int XS = (SH_MH + 1) * (m + 2);
+            double *xrow = xch + ((long long)item * SH_SPLIT + grp) * XS;
+            if (wave == 0) {
+                if (lane < XS) sh_store_coherent(xrow + lane, scal[lane]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                unsigned old_ = 0;
+                if (lane == 0) old_ = __hip_atomic_fetch_add(xcnt + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                old_ = __builtin_amdgcn_readfirstlane(old_);
+                if (old_ == SH_SPLIT - 1) {  // every workgroup of the interval has stored its rows
+                    if (lane == 0) __hip_atomic_store(xcnt + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch)
+                    const double *xall = xch + (long long)item * SH_SPLIT * XS;
+                    for (int e = lane; e < (m + 1) * (m + 2); e += 64) {  // slot 0: the W chain (first workgroup); slot 1 + l: drive l
+                        const int slot = e / (m + 2), col = e - slot * (m + 2);
+                        const int g_ = slot == 0 ? 0 : (slot - 1) / SH_MH, r_ = slot == 0 ? 0 : 1 + (slot - 1) % SH_MH;
+                        scal[e] = sh_load_coherent(xall + (long long)g_ * XS + r_ * (m + 2) + col);
+                    }
+                    wave_lds_sync();
+                } else {
+                    old_ = 0xffffffffu;
+                }
+                if (old_ != 0xffffffffu && lane < SH_NSC) {
+                    // order: (u_i, u_j) for i = 0..m-1, j = 0..i | (h, u_j) j < m | (h, h)
+                    double v;
+                    if (lane < m * (m + 1) / 2) {
+                        int i = 0;
+                        while ((i + 1) * (i + 2) / 2 <= lane) ++i;
+                        const int j = lane - i * (i + 1) / 2;
+                        v = scal[(1 + i) * (m + 2) + 1 + j] + scal[(1 + j) * (m + 2) + 1 + i];  // S[i][j] + S[j][i]
+                    } else if (lane < m * (m + 1) / 2 + m) {
+                        v = scal[(1 + lane - m * (m + 1) / 2) * (m + 2)];
+                    } else {
+                        v = scal[0];
+                    }
+                    H[lane] = v;
+        }
+            }
+        }
+#else
         if (wave == 0 && lane < SH_NSC) {
             // order: (u_i, u_j) for i = 0..m-1, j = 0..i | (h, u_j) j < m | (h, h)
             double v;
@@ -302,6 +366,7 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
             }
             H[lane] = v;
         }
+#endif
         __syncthreads();
     }
 }

@@ -94,7 +94,11 @@ struct pcl_ctx {
     // pattern-compiled FUSED residual + Jacobian kernel (pcl_codegen_v4.hpp, any Pade order): plan, drift tables, magnitudes
     pcl_codegen::V4Plan *v4_plan = nullptr;
     double *dv4_tab = nullptr, *dv4_tab_t = nullptr, *dv4_mags = nullptr, *dv4_dcf = nullptr;
-    hipFunction_t v4_f = nullptr, v4_feval = nullptr, v4_fevalc = nullptr /* cooperative residual kernel (optional) */, v4_fhess = nullptr;
+    hipFunction_t v4_f = nullptr, v4_feval = nullptr, v4_fevalc = nullptr /* cooperative residual kernel (optional) */, v4_fhess = nullptr, v4_fhess2 = nullptr /* two workgroups per interval */;
+    double *dh4x = nullptr;        // general-order Hessian, two workgroups per interval: their rows of reduced sums ...
+    unsigned int *dh4c = nullptr;  // ... and the arrival counters (self-resetting)
+    long long h4_cap = 0;
+    int64_t opt_hess_split = -1, last_hess_split = 0;  // -1 auto (launches of at most n_cu / 2 intervals) | 0 | 1
     int64_t opt_eval_coop = -1, last_eval_coop = 0;  // residual only: four waves per interval (-1 auto: launches of at most two intervals per CU)
     int v4_hess_failed = 0;
     int v4_failed = 0;
@@ -501,7 +505,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard dev_guard_(ctx->device);
     (void)pcl_comm_destroy(ctx);
-    void *ptrs[] = {ctx->dGjd, ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
+    void *ptrs[] = {ctx->dh4x, ctx->dh4c, ctx->dGjd, ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
                     ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg, ctx->dellt_col, ctx->dellt_val,
                     ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout, ctx->dreduce};
@@ -813,8 +817,8 @@ std::string v4_source(const pcl_codegen::V4Plan &plan, int q, int np, int varian
 }
 
 // ... and of the Hessian-of-the-Lagrangian kernel of the same family (pcl_kernel_hess_sparse4.hpp; any order)
-std::string v4_hess_source(const pcl_codegen::V4Plan &plan, int q, int variant = 0) {  // variant (profile builds): SH_VARIANT of the kernel (bits >= 16), bit 8: the gather-dot reads nine columns at a time
-    return "#include \"pcl_device_common.hpp\"\n#define SH_VARIANT " + std::to_string(variant) + "\n" + pcl_codegen::v4_functions(plan, q, 1, variant & 8, true) + "#include \"pcl_kernel_hess_sparse4.hpp\"\n";
+std::string v4_hess_source(const pcl_codegen::V4Plan &plan, int q, int variant = 0, int split = 1) {  // variant (profile builds): SH_VARIANT of the kernel (bits >= 16), bit 8: the gather-dot reads nine columns at a time
+    return "#include \"pcl_device_common.hpp\"\n#define SH_VARIANT " + std::to_string(variant) + "\n#define SH_SPLIT " + std::to_string(split) + "\n" + pcl_codegen::v4_functions(plan, q, 1, variant & 8, true) + "#include \"pcl_kernel_hess_sparse4.hpp\"\n";
 }
 }  // namespace
 
@@ -1510,28 +1514,53 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
     if ((ctx->opt_hess_kernel == 7 || (ctx->opt_hess_kernel == 0 && ctx->desc.pade_order != 4 && !ctx->opt_general)) && v4_available(ctx) && !ctx->v4_hess_failed) {
         const pcl_codegen::V4Plan &v4 = *ctx->v4_plan;
         fill_pade(p, ctx->desc.pade_order);
-        const int nz = p.q > 2 ? p.q - 2 : 0, ntile = p.m + 3 + 2 * nz + (p.q == 2 ? 1 : 0);  // (SH_NTILES)
-        auto bytes = [&](int nc) { return ((size_t)ntile * nc * (p.n + 1) + (size_t)(p.m + 1) * (p.m + 2) + 8) * sizeof(double); };
-        p.nc = p.d;
-        while (p.nc > 1 && bytes(p.nc) > (size_t)ctx->max_lds) p.nc = (p.nc + 1) / 2;
+        // small launches (at most n_cu / 2 intervals: one trajectory): TWO workgroups per interval, each with half of the drive chains (and its
+        // own copy of the W and power chains) -- one wave per SIMD, 512 registers per lane instead of 256 (no spilled values), the 28 scalar
+        // entries assembled by the workgroup that arrives last (option hess_split: -1 auto | 0 | 1)
+        const long long items = (long long)p.batch * p.K;
+        if (items > 0x3fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+        const int nz = p.q > 2 ? p.q - 2 : 0;
+        auto bytes_ = [&](int mh_, int nc) { return ((size_t)(mh_ + 3 + 2 * nz + (p.q == 2 ? 1 : 0) /* SH_NTILES */) * nc * (p.n + 1) + (size_t)(p.m + 1) * (p.m + 2) + 8) * sizeof(double); };
+        auto cols_ = [&](int mh_) {
+            int nc = p.d;
+            while (nc > 1 && bytes_(mh_, nc) > (size_t)ctx->max_lds) nc = (nc + 1) / 2;
+            return nc;
+        };
+        // ... and at every size where one workgroup's tiles need column slices and half the drive chains' do not (config 3 at order 10:
+        // 15 tiles of 27 columns do not fit 160 KB, 12 do; 8 trajectories per launch 394 -> 267 us)
+        const bool split = p.m >= 2 && (ctx->opt_hess_split == 1 || (ctx->opt_hess_split < 0 && (2 * items <= std::max(ctx->n_cu, 1) || (cols_(p.m) < p.d && cols_((p.m + 1) / 2) == p.d))));
+        const int ns = split ? 2 : 1, mh = (p.m + ns - 1) / ns;
+        auto bytes = [&](int nc) { return bytes_(mh, nc); };
+        p.nc = cols_(mh);
         if (ctx->opt_cols_per_slice > 0) p.nc = (int)std::min<int64_t>(p.nc, ctx->opt_cols_per_slice);
-        if (!ctx->v4_fhess) {
-            const std::string src = v4_hess_source(v4, p.q, (int)ctx->opt_v4_variant);
-            const std::string key = "hess-sparse4:" + std::to_string(p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
-            ctx->v4_fhess = jit_compile(ctx->device, key, src, "pcl_hess_sparse4_kernel", true);
-            if (!ctx->v4_fhess) ctx->v4_hess_failed = 1;
+        hipFunction_t &fh = split ? ctx->v4_fhess2 : ctx->v4_fhess;
+        if (!fh) {
+            const std::string src = v4_hess_source(v4, p.q, (int)ctx->opt_v4_variant, ns);
+            const std::string key = "hess-sparse4:" + std::to_string(p.q) + ":" + std::to_string(ns) + ":" + std::to_string(std::hash<std::string>{}(src));
+            fh = jit_compile(ctx->device, key, src, "pcl_hess_sparse4_kernel", true);
+            if (!fh) ctx->v4_hess_failed = 1;
         }
-        if (ctx->v4_fhess && bytes(p.nc) <= (size_t)ctx->max_lds) {
-            const long long items = (long long)p.batch * p.K;
-            if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
-            const long long slots = std::max(ctx->n_cu, 1), rounds = (items + slots - 1) / slots;
-            long long grid = (items + rounds - 1) / rounds;  // every workgroup walks the same number of intervals
-            if (ctx->opt_grid > 0) grid = std::min<long long>(items, ctx->opt_grid);
+        if (fh && split && ctx->h4_cap < (long long)ctx->desc.batch * ctx->K) {
+            if (ctx->dh4x) (void)hipFree(ctx->dh4x);
+            if (ctx->dh4c) (void)hipFree(ctx->dh4c);
+            ctx->dh4x = nullptr, ctx->dh4c = nullptr, ctx->h4_cap = 0;
+            const long long cap = (long long)ctx->desc.batch * ctx->K;
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->dh4x, (size_t)cap * 2 * (mh + 1) * (p.m + 2) * sizeof(double)));
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->dh4c, (size_t)cap * sizeof(unsigned int)));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dh4c, 0, (size_t)cap * sizeof(unsigned int), ctx->stream));
+            ctx->h4_cap = cap;
+        }
+        if (fh && bytes(p.nc) <= (size_t)ctx->max_lds) {
+            const long long units = items * ns;
+            const long long slots = std::max(ctx->n_cu, 1), rounds = (units + slots - 1) / slots;
+            long long grid = (units + rounds - 1) / rounds;  // every workgroup walks the same number of (interval, drive group) units
+            if (ctx->opt_grid > 0) grid = std::min<long long>(units, ctx->opt_grid);
             const long long wo = ctx->desc.per_member_G0 ? (long long)ctx->win_first : 0;
             const double *tab = ctx->dv4_tab + wo * v4.n_drift_pad, *tab_t = ctx->dv4_tab_t + wo * v4.n_drift_pad, *dcf = ctx->dv4_dcf + wo * v4.n_dcf_pad;
-            void *args[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf};
-            HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhess, (unsigned)grid, 1, 1, 64 * (1 + p.m), 1, 1, (unsigned)bytes(p.nc), ctx->stream, args, nullptr));
+            void *args[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dh4x, (void *)&ctx->dh4c};
+            HIP_TRY(ctx, hipModuleLaunchKernel(fh, (unsigned)grid, 1, 1, 64 * (1 + mh), 1, 1, (unsigned)bytes(p.nc), ctx->stream, args, nullptr));
             ctx->last_hess_kernel = 70 + p.q;
+            ctx->last_hess_split = split ? 1 : 0;
             return PCL_OK;
         }
         if (ctx->opt_hess_kernel == 7) return fail(ctx, PCL_ESHAPE, "hess_kernel=7: the pattern-compiled general-order kernel is not available (%s)", g_jit_note.c_str());
@@ -2326,7 +2355,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_prof = v;
     else if (!strcmp(key, "v4_variant")) {  // timing variants of kernel 4's generated product (WRONG results); recompiles
         ctx->opt_v4_variant = v;
-        ctx->v4_f = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = nullptr;
+        ctx->v4_f = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = nullptr;
     }
 #endif
     else if (!strcmp(key, "host_threads"))  // host-pointer entry points: threads expanding the compact values (0 = auto)
@@ -2360,6 +2389,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "v4_tail_mode must be 0 .. 3");
         ctx->opt_v4_tail_mode = v;
     }
+    else if (!strcmp(key, "hess_split"))  // general-order pattern-compiled Hessian kernel: two workgroups per interval (-1 auto by launch size | 0 | 1)
+        ctx->opt_hess_split = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "eval_coop"))  // pattern-compiled residual kernel: four waves per interval (-1 auto by launch size | 0 | 1)
         ctx->opt_eval_coop = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "eval_kernel")) {  // residual only: 0 auto, 1 matrix-core kernel, 2 pattern-compiled kernel
@@ -2422,6 +2453,8 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->opt_kernel;
     else if (!strcmp(key, "last_kernel"))
         *v = ctx->last_kernel;
+    else if (!strcmp(key, "last_hess_split"))
+        *v = ctx->last_hess_split;
     else if (!strcmp(key, "last_eval_coop"))
         *v = ctx->last_eval_coop;
     else if (!strcmp(key, "last_merit_fused"))

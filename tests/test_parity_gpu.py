@@ -2010,13 +2010,24 @@ def test_pattern_compiled_general_order_hessian(order):
         ref = po.pade_hessian_values(Z, mu, lay, G0, Gj, order).reshape(-1)
         c = make_ctx(lay, G0, Gj, pade_order=order)
         c.set_option("hess_kernel", 7)
-        for cps, grid in (((0, 0), (9, 0), (5, 3), (0, 1)) if N == 4 else ((0, 0),)):
-            c.set_option("cols_per_slice", cps)
-            c.set_option("grid", grid)
-            h = c.hess(Z, mu.reshape(-1))
-            assert c.get_option("last_hess_kernel") == 70 + order // 2
-            close(h, ref, 1e-11)
-            assert np.array_equal(h, c.hess(Z, mu.reshape(-1)))
+        first = {}
+        for split in (0, 1, -1):  # one workgroup per interval | two, half of the drive chains each, the scalar entries assembled by the last to arrive | auto
+            c.set_option("hess_split", split)
+            for cps, grid in (((0, 0), (9, 0), (5, 3), (0, 1)) if N == 4 else ((0, 0),)):
+                c.set_option("cols_per_slice", cps)
+                c.set_option("grid", grid)
+                h = c.hess(Z, mu.reshape(-1))
+                assert c.get_option("last_hess_kernel") == 70 + order // 2
+                if split >= 0:
+                    assert c.get_option("last_hess_split") == split
+                close(h, ref, 1e-11)
+                for _ in range(3):  # (the arrival counters reset themselves)
+                    assert np.array_equal(h, c.hess(Z, mu.reshape(-1)))
+                nc_eff = cps if cps else lay.d
+                if nc_eff in first:  # the same column slices: the same bits from one and from two workgroups
+                    assert np.array_equal(h, first[nc_eff]) or (order == 10 and cps == 0)  # (order 10: one workgroup needs slices of 14 columns there)
+                first.setdefault(nc_eff, h)
+        c.set_option("hess_split", -1)
         if order != 4:  # auto
             c.set_option("hess_kernel", 0)
             c.set_option("cols_per_slice", 0)
@@ -2034,6 +2045,12 @@ def test_pattern_compiled_general_order_hessian(order):
         close(hE[i * per : (i + 1) * per], po.pade_hessian_values(ZE, muE[i], layE, s.G_drift, np.array(s.G_drives), order, x_off=i * layE.x_dim).reshape(-1), 1e-11)
     BE.ctx.set_member_window(1, 1)
     assert np.array_equal(BE.ctx.hess(trajE.datavec, muE[1].reshape(-1)), hE[per : 2 * per])
+    BE.ctx.set_member_window(0, 3)
+    BE.ctx.set_option("hess_split", 1)  # two workgroups per interval, per-member drifts
+    hE2 = BE.ctx.hess(trajE.datavec, muE.reshape(-1))
+    assert BE.ctx.get_option("last_hess_split") == 1
+    for i, s in enumerate(osys):
+        close(hE2[i * per : (i + 1) * per], po.pade_hessian_values(ZE, muE[i], layE, s.G_drift, np.array(s.G_drives), order, x_off=i * layE.x_dim).reshape(-1), 1e-11)
     BE.close()
 
 
@@ -2115,6 +2132,22 @@ def test_pattern_compiled_kernels_random_sparse_systems(d, m, Bn, N):
         close(c.eval(Zb), d_ref, 1e-12)
     c.set_option("hess_kernel", 3)  # the matrix-core kernel on the same system
     close(c.hess(Zb, mu.reshape(-1)), h_ref, 1e-11)
+    # the any-order kernel on the same system (where its resident coefficients fit), one and two workgroups per interval: odd and even
+    # numbers of drives (a two-workgroup launch of m = 3, 5 has a wave without a drive), the same bits from both
+    c.set_option("hess_kernel", 7)
+    try:
+        h7 = c.hess(Zb, mu.reshape(-1))
+    except pa.PclError as e:
+        assert e.code == pa._lib.PCL_ESHAPE
+        h7 = None
+    if h7 is not None:
+        assert c.get_option("last_hess_kernel") == 72
+        close(h7, h_ref, 1e-11)
+        for split in (0, 1):
+            c.set_option("hess_split", split)
+            h8 = c.hess(Zb, mu.reshape(-1))
+            assert c.get_option("last_hess_split") == (split if m >= 2 else 0)
+            assert np.array_equal(h8, h7) and np.array_equal(h8, c.hess(Zb, mu.reshape(-1)))
     c.close()
 
 
