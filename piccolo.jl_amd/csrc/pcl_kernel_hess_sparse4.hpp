@@ -19,6 +19,9 @@
 #pragma once
 
 #define SP4CS (SPN + 1)
+#ifndef SH_VARIANT
+#define SH_VARIANT 0
+#endif
 #ifndef SH_SPLIT
 #define SH_SPLIT 1                               // workgroups per interval: each takes SH_MH of the drives (and its own copy of the W and power chains)
 #endif
@@ -157,6 +160,25 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
 #pragma unroll
             for (int i = 0; i < SPD; ++i) accK[i] = accN[i] = 0.0;
             const double bt = half ? 1.0 : -1.0;  // G^T: the other half receives -V from half 0, +V from half 1
+            // R_j = sum_b w(j + b + 1) Z_b(|Y_{j+b+1}|), this lane's half rows of its column (wave 0), level by level.  (With two workgroups per
+            // interval the W wave -- its product AND this sum -- is the last to reach every level's barrier; issuing every read of the sum up
+            // front, and sharing the first W product with the idle drive waves in row ranges, both measured SLOWER: 34.7 -> 37.0 / 39.0 us.)
+            auto combine_R = [&](int j, double hp_) {
+                double r[SPD];
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) r[i] = 0.0;
+                double hb = hp_ * h * h;  // h^jj for b = 0
+#pragma unroll 1
+                for (int bb = 0; j + bb + 1 <= q; ++bb, hb *= h) {
+                    const int jj = j + bb + 1;
+                    const double *Zt = ((jj & 1) ? (bb == 0 ? St : ZSt + (bb - 1) * TS) : (bb == 0 ? Dt : ZDt + (bb - 1) * TS)) + own;
+                    const double wz = ((jj & 1) ? -1.0 : 1.0) * p.pc[jj] * hb;
+#pragma unroll
+                    for (int i = 0; i < SPD; ++i) r[i] = __builtin_fma(wz, Zt[i], r[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) Rt[own + i] = r[i];
+            };
             double hp = 1.0;                      // h^(j-1)
 #pragma unroll 1
             for (int j = 1; j <= q; ++j) {
@@ -186,22 +208,7 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
                     }
                     // R_j, behind the barrier (until there the drive waves may still be reading R_{j-1}) and behind the product (formed in
                     // registers ahead of the barrier, its 54 registers beside the output vectors cost 57 more spills: measured 16 % slower)
-                    if (act && j < q) {
-                        double r[SPD];
-#pragma unroll
-                        for (int i = 0; i < SPD; ++i) r[i] = 0.0;
-                        double hb = hp * h * h;  // h^jj for b = 0
-#pragma unroll 1
-                        for (int bb = 0; j + bb + 1 <= q; ++bb, hb *= h) {
-                            const int jj = j + bb + 1;
-                            const double *Zt = ((jj & 1) ? (bb == 0 ? St : ZSt + (bb - 1) * TS) : (bb == 0 ? Dt : ZDt + (bb - 1) * TS)) + own;
-                            const double wz = ((jj & 1) ? -1.0 : 1.0) * p.pc[jj] * hb;
-#pragma unroll
-                            for (int i = 0; i < SPD; ++i) r[i] = __builtin_fma(wz, Zt[i], r[i]);
-                        }
-#pragma unroll
-                        for (int i = 0; i < SPD; ++i) Rt[own + i] = r[i];
-                    }
+                    if (act && j < q) combine_R(j, hp);
                 }
                 SH_STAMP();
                 __syncthreads();  // W_j and every V_{l,j} are in their tiles

@@ -11,9 +11,10 @@ try:
     system = synthetic.config_system(3)
     m = system.n_drives
     order = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    split = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 1: two workgroups per interval
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        for B in (1, 8):
+        for B in ((1,) if split else (1, 8)):
             trajs = [synthetic.synthetic_trajectory(system, 100, seed=1000 + i) for i in range(B)]
             t0 = trajs[0]
             Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()
@@ -24,6 +25,7 @@ try:
                                                Gj=system.G_drives_array(), batch=B, batch_mode=pa._lib.PCL_BATCH_TRAJ, pade_order=order)
                 c.set_stream(stream.cuda_stream)
                 c.set_option("hess_kernel", 7)
+                c.set_option("hess_split", split)
                 c.set_option("v4_variant", var)
                 ctxs[var] = c
             mud = torch.randn(c.n_rows, dtype=torch.float64, device="cuda")
