@@ -78,6 +78,9 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
     for (int g = 0; g < SP4NMAG; ++g) mg[g] = magc[g];
 
 #ifdef PCL_PROFILE
+    // 100 MHz wall stamps per workgroup (dbg[512 + 768 sel + 3 bx + {entry, -, last wave out}], sel = prof & 64): the launch-to-launch period split
+    long long *wall_ = p.dbg ? p.dbg + 512 + ((p.prof & 64) ? 768 : 0) + 3 * (blockIdx.x & 255) : nullptr;
+    if (wall_ && tid == 0) wall_[0] = (long long)__builtin_amdgcn_s_memrealtime();
     int stamp_ = 0;  // cycle stamps of workgroup 0, first 32 per wave (dbg[32 wave + i])
 #define SH_STAMP()                                                                                                           \
     do {                                                                                                                     \
@@ -113,6 +116,7 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
 #pragma unroll
         for (int i = 0; i < SPM; ++i) s_uu[i] = 0.0;
 
+        unsigned xold_ = 0xffffffffu;  // (two workgroups per interval: what the interval's arrival counter held before this workgroup's increment)
         for (int sl = 0; sl < S; ++sl) {
             const int c0 = sl * nc, nce = min(nc, d - c0);
             int ln_ = lane;
@@ -264,7 +268,30 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
                 SH_STAMP();
                 hp *= h;
             }
+#if SH_SPLIT > 1
+            // Two workgroups per interval exchange their rows of reduced sums through memory (see below).  The rows leave BEFORE the output
+            // vectors (last slice): store, acknowledged, counter bumped -- two of the exchange's three memory round trips then run under the
+            // output stage instead of behind it.
+            if (sl == S - 1) {
+                const double ry = wave_sum(s_y);
+                if (lane == 0) scal[wave * (m + 2)] = ry;
+#pragma unroll
+                for (int i = 0; i < SPM; ++i) {
+                    const double r = wave_sum(s_uu[i]);
+                    if (lane == 0) scal[wave * (m + 2) + 1 + i] = r;
+                }
+            }
+#endif
             __syncthreads();  // the chain tiles are free: the output vectors leave through them
+#if SH_SPLIT > 1
+            if (sl == S - 1 && wave == 0) {
+                constexpr int XS = (SH_MH + 1) * (m + 2);
+                double *xrow = xch + ((long long)item * SH_SPLIT + grp) * XS;
+                if (lane < XS) sh_store_coherent(xrow + lane, scal[lane]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) xold_ = __hip_atomic_fetch_add(xcnt + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#endif
             // ---- output vectors: registers -> this wave's tile -> memory (lane = row, one column per store) -----------------
             {
                 double *o1, *o2;  // the wave's X_k / X_{k+1} blocks
@@ -306,6 +333,7 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
             __syncthreads();  // (the tiles are reloaded by the next slice / interval)
         }
         // ---- scalar entries of the interval: one reduction per wave, then a fixed assembly ----------------------------------------
+#if SH_SPLIT == 1
         {
             const double ry = wave_sum(s_y);
             if (lane == 0) scal[wave * (m + 2)] = ry;
@@ -316,18 +344,13 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
             }
         }
         __syncthreads();
-#if SH_SPLIT > 1
-        // the workgroups of the interval exchange their rows of reduced sums through memory; the one that arrives last assembles the
+#else
+        // the workgroups of the interval have exchanged their rows of reduced sums through memory; the one that arrived last assembles the
         // entries.  Nobody waits for anybody: no assumption on which workgroups are resident together.
         {
             constexpr int XS = (SH_MH + 1) * (m + 2);
-            double *xrow = xch + ((long long)item * SH_SPLIT + grp) * XS;
             if (wave == 0) {
-                if (lane < XS) sh_store_coherent(xrow + lane, scal[lane]);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                unsigned old_ = 0;
-                if (lane == 0) old_ = __hip_atomic_fetch_add(xcnt + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                old_ = __builtin_amdgcn_readfirstlane(old_);
+                unsigned old_ = __builtin_amdgcn_readfirstlane(xold_);
                 if (old_ == SH_SPLIT - 1) {  // every workgroup of the interval has stored its rows
                     if (lane == 0) __hip_atomic_store(xcnt + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch)
                     const double *xall = xch + (long long)item * SH_SPLIT * XS;
@@ -354,10 +377,11 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
                         v = scal[0];
                     }
                     H[lane] = v;
-        }
+                }
             }
         }
-#else
+#endif
+#if SH_SPLIT == 1
         if (wave == 0 && lane < SH_NSC) {
             // order: (u_i, u_j) for i = 0..m-1, j = 0..i | (h, u_j) j < m | (h, h)
             double v;
@@ -376,4 +400,7 @@ extern "C" __global__ __launch_bounds__(64 * SH_NW) void pcl_hess_sparse4_kernel
 #endif
         __syncthreads();
     }
+#ifdef PCL_PROFILE
+    if (wall_ && lane == 0) atomicMax((unsigned long long *)(wall_ + 2), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
 }
