@@ -258,7 +258,8 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *                            item's blocks (default) | 0 a writer wave, plain stores | 1 nontemporal | 2 write-through
  *       "v4_flags"           kernel 4 A/B switches (same values): 1 no raised priority for the powers' wave | 2 tails only behind the
  *                            item's last block | 4 no cooperative first item | 8 every LDS tile NaN at kernel start (tests: nothing
- *                            reads what its item has not written) | 16 the first item's chains do not wait for the cooperative products
+ *                            reads what its item has not written) | 16 the first item's chains do not wait for the cooperative products | 32 two slices of an
+ *                            odd number of columns keep 14 + 13 whole columns instead of sharing the middle column's two blocks
  *       "hess_kernel"        0 auto | 1 one workgroup per interval | 2 persistent, column chunks (fallback) | 3 one workgroup per
  *                            interval, jobs split by drive (matrix cores; default for d >= 12 where the pattern-compiled kernels do
  *                            not apply) | 4 the pattern-compiled order-4 kernel (default for sparse exact-iso generators, odd

@@ -73,7 +73,7 @@ struct KParams {
     const double *mlam;  // ... against these multipliers (NULL: lam = delta, the constraint merit)
     int tail_mode;       // pattern-compiled fused kernel: who stores delta and the tails (option v4_tail_mode)
     int v4_np;           // ... tiles of the ring of powers of G this launch rotates through (<= the SP4NP the module allocates)
-    int v4_flags;        // ... A/B switches (option v4_flags): 1 no raised priority for the P wave | 2 tails only behind the item's last block | 4 no cooperative first item | 8 tiles NaN at start | 16 chains do not wait
+    int v4_flags;        // ... A/B switches (option v4_flags): 1 no raised priority for the P wave | 2 tails only behind the item's last block | 4 no cooperative first item | 8 tiles NaN at start | 16 chains do not wait | 32 no balanced middle column
 };
 
 // ------------------------------------------------------------------------------------------

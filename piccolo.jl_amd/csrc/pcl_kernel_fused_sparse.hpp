@@ -575,15 +575,24 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                     cbeg = 0;
                     cend = (c0 == 0) ? 1 : 0;
                 }
+                // Two round-robin slices of an odd number of columns (one trajectory of config 3: 14 + 13): the -B^+ block of the first slice's
+                // last column stays there, its B^- block goes to the second slice -- 27 blocks each instead of 28 and 26: 0.2-0.35 us of a
+                // 28-32 us launch (v4_flags & 32 switches it off)
+                int half_col = -1;  // the column whose two blocks are shared between the interval's two slices
+                if (!(p.v4_flags & 32) && !p.contig && !p.compact && p.S == 2 && (d & 1)) {
+                    half_col = p.nc - 1;
+                    if (c0 > 0) cbeg = half_col;
+                }
                 double *o = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn + pi;
                 for (int cq = cbeg; cq < cend; ++cq, o += nn) {
                     if (pact && !no_blocks) {
+                        const bool sp_ = cq != half_col || c0 == 0, sm_ = cq != half_col || c0 > 0;
 #pragma unroll
                         for (int r = 0; r < NSP; ++r) {
                             const int j = pj0 + pstep * r;
                             if (j < n) {
-                                store2(o + n * j, bpr[r][0], bpr[r][1], p.nt);
-                                store2(o + blk + n * j, bmr[r][0], bmr[r][1], p.nt);
+                                if (sp_) store2(o + n * j, bpr[r][0], bpr[r][1], p.nt);
+                                if (sm_) store2(o + blk + n * j, bmr[r][0], bmr[r][1], p.nt);
                             }
                         }
                     }

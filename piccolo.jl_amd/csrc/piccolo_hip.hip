@@ -2381,7 +2381,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
     else if (!strcmp(key, "contiguous"))  // kernel 3: 1 = equal contiguous column ranges per workgroup (default), 0 = round-robin slices
         ctx->opt_contig = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "v4_flags"))  // kernel 4 A/B switches: 1 no raised priority for the P wave | 2 tails only behind the item's last block
-                                       // | 4 no cooperative first item | 8 LDS tiles NaN at kernel start (tests) | 16 the first item's chains do not wait for the cooperative products
+                                       // | 4 no cooperative first item | 8 LDS tiles NaN at kernel start (tests) | 16 the first item's chains do not wait for the cooperative products | 32 no balanced split of the middle column's two blocks between two slices
         ctx->opt_v4_flags = v;
     else if (!strcmp(key, "v4_power_tiles"))  // kernel 4: LDS tiles the powers of G rotate through (0 auto: q - 1 for launches of several items per workgroup, else q)
         ctx->opt_v4_np = v < 0 ? 0 : v;

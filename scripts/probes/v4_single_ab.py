@@ -16,7 +16,7 @@ with torch.cuda.stream(stream):
     ctxs = {}
     variants = [("v3", dict(kernel_version=0)) if order == 4 else ("v4-auto", dict()),
                 ("v4", dict(kernel_version=4)), ("v4-nocoop", dict(kernel_version=4, v4_flags=4)), ("v4-coop-nowait", dict(kernel_version=4, v4_flags=16)),
-                ("v4-contig", dict(kernel_version=4, contiguous=1)), ("v4-nt0", dict(kernel_version=4, nt_stores=0))]
+                ("v4-unbalanced", dict(kernel_version=4, v4_flags=32)), ("v4-nt0", dict(kernel_version=4, nt_stores=0))]
     for name, opts in variants:
         c = pa.integrators._PclContext(d=system.levels, m=system.n_drives, N=t0.N, z_dim=t0.dim, u_off=t0.components["u"].start,
                                        dt_off=t0.components["Δt"].start, x_offs=[t0.components[pa.trajectory.STATE].start], G0=system.G_drift,

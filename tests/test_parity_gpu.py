@@ -913,7 +913,7 @@ def test_pattern_compiled_fused_kernel(order):
         # initialised -- nothing may read an entry its item has not written)
         c.set_option("contiguous", -1), c.set_option("cols_per_slice", 0), c.set_option("grid", 0)
         c.set_option("v4_power_tiles", 0), c.set_option("v4_tail_mode", 3), c.set_option("host_path", 1)
-        for flags in (4, 16, 8, 8 | 4):
+        for flags in (4, 16, 8, 8 | 4, 32):
             c.set_option("v4_flags", flags)
             delta, vals = c.eval_jac(Z)
             assert np.array_equal(delta, first[0]) and np.array_equal(vals, first[1]), flags
