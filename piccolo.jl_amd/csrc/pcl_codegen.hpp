@@ -1,4 +1,4 @@
-// pcl_codegen.hpp -- host-only: source generator for the PATTERN-COMPILED kernels (DESIGN.md section 4.7).
+// pcl_codegen.hpp -- host-only: source generator for the PATTERN-COMPILED kernels (DESIGN.md section 4.4).
 //
 // The generators of the reference's systems are sparse (multilevel transmons, config 3: 614 of 2916 entries) and exact
 // iso(.) images  T = [[A, -B], [B, A]].  Every product of the Hessian of the Lagrangian acts on the state columns from the

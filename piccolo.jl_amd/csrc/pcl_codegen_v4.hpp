@@ -1,5 +1,5 @@
 // pcl_codegen_v4.hpp -- host-only: source generator for the pattern-compiled FUSED residual + Jacobian kernel (any diagonal
-// Pade order; DESIGN.md section 4.9, device side: pcl_kernel_fused_sparse.hpp).
+// Pade order; DESIGN.md sections 4.2-4.4, device side: pcl_kernel_fused_sparse.hpp).
 //
 // Same idea as pcl_codegen.hpp (lane (half, c) owns its half of state column c; G(u) x is a straight line of multiply-adds whose
 // register indices are the sparsity pattern), with two changes that remove every per-interval table from memory:

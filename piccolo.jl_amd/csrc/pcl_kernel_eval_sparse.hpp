@@ -1,4 +1,4 @@
-// pcl_kernel_eval_sparse.hpp -- residual only, PATTERN-COMPILED version (generated source only).
+// pcl_kernel_eval_sparse.hpp -- residual only, PATTERN-COMPILED version (round 2; superseded by pcl_eval_sparse4_kernel wherever kernel 4's tiles fit; generated source only).
 // delta_k = D - G Y,  Y = (h/2) S - (h^2/12) G D   (= D - (h/2) G S + (h^2/12) G^2 D with two products instead of three).
 // One WAVE per interval, no cooperation between waves (up to eight independent streams per workgroup): lane (half, c) holds its half
 // of column c of D and S in registers, applies G(u_k) twice as straight-line multiply-adds (sp_g) and leaves through its own

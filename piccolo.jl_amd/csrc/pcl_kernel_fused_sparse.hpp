@@ -1,4 +1,4 @@
-// pcl_kernel_fused_sparse.hpp -- fused residual + Jacobian, PATTERN-COMPILED, any diagonal Pade order 2q.
+// pcl_kernel_fused_sparse.hpp -- fused residual + Jacobian, PATTERN-COMPILED, any diagonal Pade order 2q (the residual-only kernels of section 4.3 at the end of the file).
 // Included by generated source only (pcl_codegen_v4.hpp): SPD (Hilbert dimension), SPM (drives), SPN = 2 SPD, SP4Q (q), SP4NP
 // (tiles of the powers of G), the resident-coefficient struct sp4_cf, the products sp4_product / sp4_product0 and the drives'
 // gathers sp4_gather_<l> are defined before this file.
@@ -14,9 +14,10 @@
 //     wave 1, 2         W, V
 //     wave 3 + l        dW_l
 //     wave 3 + m        loader: D, S of the next item (lane = row, coalesced) -> tiles [column][row]
-//     wave 4 + m        writer: delta and the tail block of a finished item, tiles -> memory as ONE contiguous run per item
+//     wave 4 + m        writer: the reduce payload's dot products per state column (pcl_eval_jac_merit_dev); delta and the tail block of a
+//                       finished item only in tail modes 0-2 (default: the stream waves store them behind the item's blocks)
 //     wave 5 + m .. +3  stream: fold every power into the item's -B^+ / B^- values in registers as it appears, then only issue the
-//                       replicated 16-byte stores
+//                       replicated 16-byte stores; the FIRST item's powers are built by these four waves themselves, in row ranges
 // No workgroup barrier after the start: point-to-point monotonic LDS counters (dependencies only point backwards; bounded waits).
 // Work items as in kernel 3: contiguous column ranges per workgroup (pieces of one interval), or round-robin slices.
 #pragma once

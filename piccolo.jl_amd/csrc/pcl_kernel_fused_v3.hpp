@@ -1,4 +1,4 @@
-// pcl_kernel_fused_v3.hpp -- the default fused residual + Jacobian kernel.
+// pcl_kernel_fused_v3.hpp -- the matrix-core fused residual + Jacobian kernel (the default of rounds 1-2, now kernel_version = 3).
 #pragma once
 
 // ------------------------------------------------------------------------------------------

@@ -1,4 +1,4 @@
-// pcl_kernel_hess_sparse4.hpp -- Hessian of the Lagrangian at ANY diagonal Pade order 2q, PATTERN-COMPILED (DESIGN.md section 4.10).
+// pcl_kernel_hess_sparse4.hpp -- Hessian of the Lagrangian at ANY diagonal Pade order 2q, PATTERN-COMPILED (DESIGN.md section 4.4).
 // Included by generated source only (pcl_codegen_v4.hpp with the Hessian functions): SPD, SPM, SPN, SP4Q, the products
 // sp4_product_t / sp4_product0_t (G(u)^T x) and sp4_product0 (G(u) x), the gathers sp4_gather_t_<l> (G_l^T w) and the gather-dots
 // sp4_gdot_all (<v, G_l z> for every drive l) are defined before this file.

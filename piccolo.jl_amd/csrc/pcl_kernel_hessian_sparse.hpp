@@ -1,4 +1,4 @@
-// pcl_kernel_hessian_sparse.hpp -- Hessian of the Lagrangian, PATTERN-COMPILED version.
+// pcl_kernel_hessian_sparse.hpp -- Hessian of the Lagrangian, PATTERN-COMPILED version (order 4).
 // Included by generated source only (pcl_codegen.hpp): SPD (Hilbert dimension d <= 32), SPM (drives <= 6), SPN = 2 SPD,
 // SPNZ / SPNZP and the straight-line functions sp_gt / sp_g / sp_glt_<l> / sp_gltdot<l> are defined before this file.
 //

@@ -1,4 +1,4 @@
-// pcl_kernel_hessian_v3.hpp -- Hessian of the Lagrangian, version 3 (DESIGN.md section 4.2): one persistent workgroup of
+// pcl_kernel_hessian_v3.hpp -- Hessian of the Lagrangian, version 3 (DESIGN.md section 4.5): one persistent workgroup of
 // eight wavefronts per CU, ONE workgroup per interval (no cross-workgroup reduction), jobs split BY DRIVE instead of by
 // state-column chunk so that every matrix-core pass uses all 16 operand columns and every output vector leaves the CU as
 // one contiguous slab of 16-byte stores.

@@ -1,4 +1,4 @@
-// pcl_kernels_hessian.hpp -- Hessian-of-the-Lagrangian kernels (DESIGN.md section 4.2).
+// pcl_kernels_hessian.hpp -- Hessian-of-the-Lagrangian kernels (DESIGN.md section 4.5).
 #pragma once
 
 // ------------------------------------------------------------------------------------------
