@@ -248,7 +248,8 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *                            generators and compiled on first use, one wave per chain of the recursion, no workgroup barrier
  *                            (auto at every order: full values, compact values and the payload-fused call; needs sparse exact-iso generators of a
  *                            unitary problem, 9 <= d <= 32, 1..6 drives, jit = 1: PCL_ESHAPE when forced elsewhere) | 5 the
- *                            small-system kernel: one wave per interval, any order (auto for n <= 8 rows, n * cols <= 64, m <= 8)
+ *                            small-system kernel: one wave per interval, any order, n <= 16 rows, at most 8 state columns and 8 drives (auto for n <= 8
+ *                            rows, and for the residual alone up to 16 rows)
  *       "contiguous"         kernels 3 / 4: -1 auto by launch size | 0 round-robin column slices | 1 equal contiguous column ranges
  *       "stream_workgroups"  kernel 3, contiguous: -1 auto (half) | 0 both roles in every workgroup | n stream-role workgroups
  *       "cols_per_slice"     state columns per work item (0 = heuristic; forces the round-robin split in kernels 3 / 4)

@@ -442,7 +442,7 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     }
     std::vector<double> g0(dsc->G0, dsc->G0 + nn * (dsc->per_member_G0 ? dsc->batch : 1));
     CREATE_TRY(upload(ctx, &ctx->dG0, g0));
-    if (n <= 8 && m >= 1) {
+    if (n <= 16 && m >= 1) {
         std::vector<double> gjd(dsc->Gj, dsc->Gj + nn * m);
         CREATE_TRY(upload(ctx, &ctx->dGjd, gjd));
     }
@@ -1270,24 +1270,27 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         if (rc != PCL_ENOTIMPL) return rc;
         if (ctx->opt_eval_kernel == 3) return fail(ctx, PCL_ESHAPE, "eval_kernel=3 needs sparse exact-iso generators of a unitary problem (9 <= d, tiles within LDS), 1..6 drives and jit=1 (%s)", g_jit_note.c_str());
     }
-    // kernel_version 5 (auto wherever it applies: n <= 8 rows, n * cols <= 64, m <= 8 -- BASELINE configs 1 and 2, every order): one
-    // wave per interval, one round of global loads, everything else in registers and 5 KB of LDS (pcl_kernel_fused_small.hpp)
-    if ((ctx->opt_kernel == 5 || (ctx->opt_kernel == 0 && !ctx->opt_general && ctx->opt_general_version == 0)) && ctx->n <= 8 && ctx->n * ctx->cols <= 64 &&
-        p.m <= 8 && (p.m == 0 || ctx->dGjd)) {  // (the payload-fused call: this kernel + the separate payload kernels)
+    // kernel_version 5 (auto wherever it applies: n <= 16 rows, at most 8 state columns, m <= 8 -- BASELINE configs 1 and 2, every system of the
+    // reference's docs with d <= 8; every order): one wave per interval, one round of global loads, everything else in registers and a few KB
+    // of LDS (pcl_kernel_fused_small.hpp)
+    // (9 .. 16 rows: four matrix entries per lane -- residual only 5.3 against 5.9 us at d = 5, but residual + Jacobian 11.2 against the 8.3 us of
+    //  kernel 1, so `auto` takes the 16-row instance for the residual alone; kernel_version = 5 forces it)
+    if ((ctx->opt_kernel == 5 || (ctx->opt_kernel == 0 && !ctx->opt_general && ctx->opt_general_version == 0 && (ctx->n <= 8 || !want_jac))) && ctx->n <= 16 &&
+        ctx->cols <= 8 && p.m <= 8 && (p.m == 0 || ctx->dGjd)) {  // (the payload-fused call: this kernel + the separate payload kernels)
         fill_pade(p, ctx->desc.pade_order);
         const long long items = (long long)p.batch * p.K;
         if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
         const long long grid = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, items) : std::min<long long>(items, 16LL * std::max(ctx->n_cu, 1));
-        if (want_jac)
-            hipLaunchKernelGGL(pcl_fused_small_kernel<true>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, p, (const double *)ctx->dGjd);
-        else
-            hipLaunchKernelGGL(pcl_fused_small_kernel<false>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, p, (const double *)ctx->dGjd);
+        typedef void (*ksm_t)(const KParams, const double *);
+        const ksm_t ksm = ctx->n <= 8 ? (want_jac ? (ksm_t)pcl_fused_small_kernel<true, 8> : (ksm_t)pcl_fused_small_kernel<false, 8>)
+                                      : (want_jac ? (ksm_t)pcl_fused_small_kernel<true, 16> : (ksm_t)pcl_fused_small_kernel<false, 16>);
+        hipLaunchKernelGGL(ksm, dim3((unsigned)grid), dim3(64), 0, ctx->stream, p, (const double *)ctx->dGjd);
         HIP_TRY(ctx, hipGetLastError());
         ctx->last_kernel = 50 + p.q;
         ctx->last_n_stream = 0;
         return PCL_OK;
     }
-    if (ctx->opt_kernel == 5) return fail(ctx, PCL_ESHAPE, "kernel_version=5 (the small-system kernel) needs n <= 8 rows, n * cols <= 64 and at most 8 drives (n = %d, cols = %d, m = %d)", ctx->n, ctx->cols, p.m);
+    if (ctx->opt_kernel == 5) return fail(ctx, PCL_ESHAPE, "kernel_version=5 (the small-system kernel) needs n <= 16 rows, at most 8 state columns and at most 8 drives (n = %d, cols = %d, m = %d)", ctx->n, ctx->cols, p.m);
     if (ctx->desc.pade_order != 4 || ctx->opt_general || ctx->vec) return launch_pade_general(ctx, p, want_jac);
     p.ell_lds = ell_fits_lds(ctx) ? 1 : 0;
     // auto: kernel 3 where its shape-specialised instance applies (BASELINE configs 3/4/5); its run-time-shape instances

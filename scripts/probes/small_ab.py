@@ -9,8 +9,16 @@ import piccolo_jl_amd as pa
 from piccolo_jl_amd import synthetic
 stream = torch.cuda.Stream()
 with torch.cuda.stream(stream):
-    for cfg, N in ((2, 100), (1, 50)):
-        system = synthetic.config_system(cfg)
+    from piccolo_jl_amd.quantum import MultiTransmonSystem
+    for cfg, N in ((2, 100), (1, 50), ("one 5-level transmon (d = 5)", 50), ("one 8-level transmon (d = 8)", 50), ("two transmons, 2 x 3 levels... (d = 6)", 50)):
+        if cfg in (1, 2):
+            system = synthetic.config_system(cfg)
+        elif "d = 5" in cfg:
+            system = MultiTransmonSystem([4.0], [0.2], [[0.0]], levels_per_transmon=5, drive_bounds=0.1)
+        elif "d = 8" in cfg:
+            system = MultiTransmonSystem([4.0], [0.2], [[0.0]], levels_per_transmon=8, drive_bounds=0.1)
+        else:
+            system = MultiTransmonSystem([4.0, 4.1], [0.2, 0.2], [[0, 0.1], [0.1, 0]], levels_per_transmon=[2, 3], drive_bounds=0.1) if False else MultiTransmonSystem([4.0], [0.2], [[0.0]], levels_per_transmon=6, drive_bounds=0.1)
         for order in (4, 8):
             t0 = synthetic.synthetic_trajectory(system, N, seed=7)
             Zd = torch.from_numpy(t0.datavec.copy()).cuda()
@@ -44,4 +52,4 @@ with torch.cuda.stream(stream):
                         res.setdefault((name, what, "id"), kid)
             for key, v in res.items():
                 if len(key) == 2:
-                    print("config %d order %d %-9s %-4s: median %.2f us per launch (kernel id %d)" % (cfg, order, key[0], key[1], np.median(v), res[key + ("id",)]), flush=True)
+                    print("config %s order %d %-9s %-4s: median %.2f us per launch (kernel id %d)" % (cfg, order, key[0], key[1], np.median(v), res[key + ("id",)]), flush=True)

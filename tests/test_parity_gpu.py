@@ -1701,6 +1701,59 @@ def test_auto_kernel_policy_by_shape():
     c.close()
 
 
+@pytest.mark.parametrize("d,m,order", [(1, 1, 4), (2, 2, 6), (3, 0, 4), (4, 4, 4), (4, 8, 10), (5, 2, 4), (5, 2, 8), (6, 3, 2), (8, 2, 4), (8, 8, 6)])
+def test_small_system_kernel(d, m, order):
+    """pcl_fused_small_kernel (kernel_version 5; one wave per interval): both instances (n <= 8 rows: one matrix entry per lane; n <= 16: four),
+    random dense generators, every Pade order, residual + Jacobian (full and compact), residual only, TRAJ batches, per-member drifts
+    (MEMBERS mode, own state offsets), any grid -- against the oracle, bitwise repeatable; and what `auto` takes at these sizes."""
+    rng = np.random.default_rng(97 * d + 7 * m + order)
+    lay, G0, Gj, Z = _random_case(d, m, 6, rng, x_off=2)
+    d_ref = po.pade_residual(Z, lay, G0, Gj, order).reshape(-1)
+    j_ref = po.pade_jacobian_values(Z, lay, G0, Gj, order).reshape(-1)
+    c = make_ctx(lay, G0, Gj, pade_order=order)
+    delta, vals = c.eval_jac(Z)
+    assert c.get_option("last_kernel") == (50 + order // 2 if d <= 4 else (10 if order == 4 else c.get_option("last_kernel")))  # auto: n <= 8 rows
+    close(c.eval(Z), d_ref, 1e-11)
+    assert c.get_option("last_kernel") == 50 + order // 2  # residual only: both instances
+    c.set_option("kernel_version", 5)
+    first = None
+    for grid, hp in ((0, 1), (1, 1), (3, 1), (1000, 1), (0, 2)):  # (host_path 2: the compact values + expansion)
+        c.set_option("grid", grid)
+        c.set_option("host_path", hp)
+        delta, vals = c.eval_jac(Z)
+        assert c.get_option("last_kernel") == 50 + order // 2
+        close(delta, d_ref, 1e-11)
+        close(vals, j_ref, 1e-11)
+        first = (delta, vals) if first is None else first
+        assert np.array_equal(delta, first[0]) and np.array_equal(vals, first[1])
+        assert np.array_equal(c.eval(Z), delta)
+    c.close()
+    # three trajectories per launch
+    Zs = [rng.standard_normal(Z.shape) for _ in range(3)]
+    for Zb in Zs:
+        Zb[:, lay.dt_off] = 0.05 + 0.1 * rng.random(lay.N)
+    cb = make_ctx(lay, G0, Gj, pade_order=order, batch=3, batch_mode=pa._lib.PCL_BATCH_TRAJ)
+    cb.set_option("kernel_version", 5)
+    db, vb = cb.eval_jac(np.stack(Zs))
+    close(db, np.concatenate([po.pade_residual(Zb, lay, G0, Gj, order).reshape(-1) for Zb in Zs]), 1e-11)
+    close(vb, np.concatenate([po.pade_jacobian_values(Zb, lay, G0, Gj, order).reshape(-1) for Zb in Zs]), 1e-11)
+    cb.close()
+    # two members with their own drifts and state offsets, shared controls (MEMBERS mode)
+    xd = 2 * d * d
+    layE = po.Layout(d=d, m=m, N=5, z_dim=2 * xd + 2 + m, x_off=0, u_off=2 * xd + 1, dt_off=2 * xd)
+    G0s = np.stack([G0, G0 + 0.1 * rng.standard_normal(G0.shape)])
+    ZE = rng.standard_normal((5, layE.z_dim))
+    ZE[:, layE.dt_off] = 0.05 + 0.1 * rng.random(5)
+    ce = pa.integrators._PclContext(d=d, m=m, N=5, z_dim=layE.z_dim, u_off=layE.u_off, dt_off=layE.dt_off, x_offs=[0, xd], G0=G0s, Gj=Gj, batch=2,
+                                    batch_mode=pa._lib.PCL_BATCH_MEMBERS, pade_order=order, per_member_G0=True)
+    ce.set_option("kernel_version", 5)
+    de, ve = ce.eval_jac(ZE)
+    assert ce.get_option("last_kernel") == 50 + order // 2
+    close(de, np.concatenate([po.pade_residual(ZE, layE, G0s[i], Gj, order, x_off=i * xd).reshape(-1) for i in range(2)]), 1e-11)
+    close(ve, np.concatenate([po.pade_jacobian_values(ZE, layE, G0s[i], Gj, order, x_off=i * xd).reshape(-1) for i in range(2)]), 1e-11)
+    ce.close()
+
+
 @pytest.mark.parametrize("levels,batch", [(5, 1), (5, 3), (4, 1)])
 def test_other_specialised_shapes(levels, batch):
     """Two 5-level (d = 25) and two 4-level (d = 16) transmons with four drives: the shape-specialised instances of
