@@ -27,8 +27,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) with the extra obje
   roofline      algorithmic HBM bytes per launch / measured kernel time (HIP events on the launch stream) vs 8 TB/s
   cpu_baseline  the oracle's C restatement (oracle/pade_ref.c, OpenMP) timed on this host (rank 0, N=1)
   other_rates   Hessian of the Lagrangian, compact Jacobian, residual only, host-delivered (both delivery paths), config 2.
-`vs_baseline` = value / cpu_baseline.value measured in the same run (BASELINE.md holds no published number; the
-north star's target is >= 50x the single-socket CPU path): null when the CPU baseline is skipped.
+`vs_baseline` is null (BASELINE.md holds no published number for this metric); `vs_cpu_baseline` = value / cpu_baseline.value measured in
+the same run (the north star's target is >= 50x the single-socket CPU path), absent when the CPU baseline is skipped.
 """
 import argparse
 import json
@@ -464,8 +464,9 @@ def main():
                 ref_lib.eval_jac(Z, lay, G0o, Gjo, nthreads=cores, out=outbuf)
                 n += 1
             el = time.perf_counter() - tc
-            out["vs_baseline"] = out["value"] / (n / el)
-            out["vs_baseline_note"] = "value / cpu_baseline.value of this run (no published number exists for this metric; north-star target: >= 50x)"
+            # (vs_baseline stays null: BASELINE.md holds no published number for this metric; the ratio to the CPU port of this run is its own key)
+            out["vs_cpu_baseline"] = out["value"] / (n / el)
+            out["vs_cpu_baseline_note"] = "value / cpu_baseline.value of this run (north-star target: >= 50x the single-socket CPU path; the port is far faster than the reference's ForwardDiff-through-expv path, which cannot run here)"
             out["cpu_baseline"] = {
                 "value": n / el,
                 "unit": "evals/s",
