@@ -37,7 +37,7 @@
 // G + l levels of W the drive wave l has gathered | O + w items whose output chain w is complete
 // (one word per arriver wherever arrivers can run ahead of each other: a shared arrival count lies -- a fast wave's extra arrival
 //  stands in for a slow wave's missing one)
-enum { SP4_F_IN = 0, SP4_F_DW, SP4_F_DV, SP4_F_W, SP4_F_B, SP4_F_OC, SP4_F_CO /* cooperative first item: parts of powers done */, SP4_F_G = 8, SP4_F_O = 16, SP4_F_C = 24 /* per stream wave */, SP4_F_TS = 28 /* per stream wave: items whose tails it has stored */ };
+enum { SP4_F_IN = 0, SP4_F_DW, SP4_F_DV, SP4_F_W, SP4_F_B, SP4_F_OC, SP4_F_CO /* cooperative first item: parts of powers done */, SP4_F_CX /* ... operands read (one-tile ring) */, SP4_F_G = 8, SP4_F_O = 16, SP4_F_C = 24 /* per stream wave */, SP4_F_TS = 28 /* per stream wave: items whose tails it has stored */ };
 
 static __device__ __forceinline__ bool sp4_wait(int *sync, int word, int target, bool gave_up = false) {
     // Bounded: a logic error must not hang the device (the caller poisons the output instead; once a wave has given up it
@@ -78,21 +78,24 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     const int npw = p.v4_np;
     int *sync = (int *)(Pt + SP4NP * SP4TILE);
 #ifdef PCL_PROFILE
+    // cycle stamps of workgroup 0: the first 32 per wave (dbg[32 wave + i]); experiment flags (results WRONG): prof & 2 no block
+    // stores, prof & 4 no column chains (P and the stream only), prof & 8 no tail / delta stores
+    int stamp_ = 0;
+#define SP4_STAMP()                                                                                                          \
+    do {                                                                                                                     \
+        if (p.dbg && blockIdx.x == 0 && lane == 0 && stamp_ < 32) p.dbg[32 * wave + stamp_++] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+    const bool no_blocks = p.prof & 2, no_chains = p.prof & 4, no_tails = p.prof & 8;
+#else
+#define SP4_STAMP() do { } while (0)
+    constexpr bool no_blocks = false, no_chains = false, no_tails = false;
+#endif
+#ifdef PCL_PROFILE
     // 100 MHz wall stamps per workgroup (dbg[512 + 768 sel + 3 bx + {entry, tiles zeroed, last wave out}], sel = prof & 64): where
     // the time between back-to-back launches goes
     long long *wall_ = p.dbg ? p.dbg + 512 + ((p.prof & 64) ? 768 : 0) + 3 * (blockIdx.x & 255) : nullptr;
     if (wall_ && tid == 0) wall_[0] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    // Counters zero.  The tiles start as whatever the previous workgroup left: every entry a wave reads has been written by the item
-    // that reads it (zeroing 150 KB took 0.84 us of a 24 us workgroup life).  v4_flags & 8 (tests): NaN everywhere first.
-    if (p.v4_flags & 8)
-        for (int e = tid; e < SP4_NTILES * SP4TILE; e += 64 * SP4_NWAVES) lds[e] = __builtin_nan("");
-    if (tid < SP4_SYNC_WORDS) sync[tid] = 0;
-    __syncthreads();  // the only workgroup barrier
-#ifdef PCL_PROFILE
-    if (wall_ && tid == 0) wall_[1] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
-
     // ---- work split (as kernel 3) ----------------------------------------------------------------------------------------
     const long long blk = p.compact ? (long long)nn : (long long)d * nn;  // size of the -B^+ / of the B^- segment
     const long long xd = (long long)n * d;
@@ -124,6 +127,22 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             b = item / (p.S * p.K);
         }
     };
+    // Counters zero.  The tiles start as whatever the previous workgroup left: every entry a wave reads has been written by the item
+    // that reads it (zeroing 150 KB took 0.84 us of a 24 us workgroup life).  v4_flags & 8 (tests): NaN everywhere first.
+    if (p.v4_flags & 8)
+        for (int e = tid; e < SP4_NTILES * SP4TILE; e += 64 * SP4_NWAVES) lds[e] = __builtin_nan("");
+#ifdef PCL_PROFILE
+    if (p.prof & 128) SP4_STAMP();
+#endif
+    if (tid < SP4_SYNC_WORDS) sync[tid] = 0;
+    __syncthreads();  // the only workgroup barrier
+#ifdef PCL_PROFILE
+    if (p.prof & 128) SP4_STAMP();
+#endif
+#ifdef PCL_PROFILE
+    if (wall_ && tid == 0) wall_[1] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+
     bool gave_up = false;
     // delta and the tail block of a finished item, tiles -> memory: the item's nce n residuals and its nce (m + 1) n tail values
     // are ONE contiguous run each, 1 KiB per instruction; `part` of `nparts` waves takes every nparts-th instruction.
@@ -156,19 +175,6 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_TS + w, it, gave_up);
         }
     };
-#ifdef PCL_PROFILE
-    // cycle stamps of workgroup 0: the first 32 per wave (dbg[32 wave + i]); experiment flags (results WRONG): prof & 2 no block
-    // stores, prof & 4 no column chains (P and the stream only), prof & 8 no tail / delta stores
-    int stamp_ = 0;
-#define SP4_STAMP()                                                                                                          \
-    do {                                                                                                                     \
-        if (p.dbg && blockIdx.x == 0 && lane == 0 && stamp_ < 32) p.dbg[32 * wave + stamp_++] = (long long)__builtin_amdgcn_s_memtime(); \
-    } while (0)
-    const bool no_blocks = p.prof & 2, no_chains = p.prof & 4, no_tails = p.prof & 8;
-#else
-#define SP4_STAMP() do { } while (0)
-    constexpr bool no_blocks = false, no_chains = false, no_tails = false;
-#endif
 
     // the drives' magnitudes and the per-item scalars (step, controls -> resident coefficients, the member's drift table), defined inside
     // the roles that use them: at kernel scope their registers stay live across every role (139 spilled scalar registers)
@@ -189,7 +195,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     // output rows each (sp4_product0_part: nothing to store before the powers exist; a lone P wave takes 7.7 k cycles for G, G^2 at
     // order 4 -- a fifth of a one-trajectory launch).  Needs every power of the item in its own tile (folded afterwards: the products'
     // registers and the block registers never live side by side) and fully resident coefficients.  The P wave starts with item 1.
-    const bool coop = SP4_COOP && npw >= q && !(p.v4_flags & 4);
+    const bool coop = SP4_COOP && !(p.v4_flags & 4);
     // ... and the chains of that item start behind them: twelve waves of products on four SIMDs ran the stream's parts three times
     // slower (4.1 k cycles instead of 1.3 k), and the chains have the whole store phase to finish in
     auto chains_may_start = [&](int it) {
@@ -197,16 +203,73 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_C + w, q, gave_up);
     };
 
-    if (wave < SP4_WLOAD) {
-        // ================================== column waves: one chain each ====================================================
-        // Lane position, re-derived from an opaque copy of `lane` in every item: computed once, everything that depends on it (the
-        // unit vectors, tile addresses, ...) is hoisted out of the item loops and spilled.
+    // Lane position, re-derived from an opaque copy of `lane` in every item: computed once, everything that depends on it (the
+    // unit vectors, tile addresses, ...) is hoisted out of the item loops and spilled.
 #define SP4_LANEPOS()                                                                       \
     int ln_ = lane;                                                                         \
     asm volatile("" : "+v"(ln_));                                                           \
     const int half = ln_ >> 5, c = ln_ & 31;                                                \
     const int cc = c < d ? c : 0;                                                           \
     const int own = cc * SP4CS + half * d, oth = cc * SP4CS + (1 - half) * d
+#if SP4_COOP
+    // ---- cooperative first item: waves 0 .. 3 (P and the first three chains: idle until the item's powers exist) build the powers of
+    //      G in four row ranges; the store-stream waves fold every power while the next one is being built.  (Until round 3 the stream
+    //      waves built them themselves and the fold of a power sat between two products of the same wave: 27.6 -> 25.7 us per
+    //      one-trajectory launch.  Nine parts on nine waves measured slower than four: 26.5 us -- a part's time is its cold start.)
+    if (coop && wave < SP4_NPART && n_my > 0) {
+        int c0, nce, k, b;
+        decode(0, c0, nce, k, b);
+        SP4_LANEPOS();
+        const bool act = c < d;
+        const double bs = half ? -1.0 : 1.0;
+        SP4_SCALARS_DEF();
+        double hh;
+        sp4_cf cf;
+        sp_cptr tab;
+        scalars(k, b, hh, cf, tab);
+#ifdef PCL_PROFILE
+        if (p.prof & 128) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            SP4_STAMP();
+        }
+#endif
+        {  // G itself: unit vectors (a block of its own: inside the loop the 27 constants are kept in a second register set)
+            double *Po = Pt;
+            double x[SPD];
+#pragma unroll
+            for (int i = 0; i < SPD; ++i) x[i] = (half == 0 && i == c) ? 1.0 : 0.0;
+            if (act) sp4_product0_part(wave, x, sp4_lds_off(Po + own), sp4_lds_off(Po + oth), 1.0, bs, tab, cf);
+            wave_lds_sync();
+            sp4_arrive(sync + SP4_F_CO, lane);
+            SP4_STAMP();
+        }
+#pragma unroll 1
+        for (int j = 2; j <= q; ++j) {
+            double *Po = Pt + ((j - 1) % npw) * SP4TILE;
+            const double *Pi = Pt + ((j - 2) % npw) * SP4TILE;
+            gave_up = sp4_wait(sync, SP4_F_CO, SP4_NPART * (j - 1), gave_up);  // every row of the previous power is in its tile
+            double x[SPD];
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) x[i] = Pi[own + i];
+            }
+            if (j > npw) {  // a ring shorter than q: the stream has folded the power this tile held ...
+                for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_C + w, j - npw, gave_up);
+                if (npw == 1) {  // ... and with ONE tile every part has its operand in registers before a row is rewritten
+                    wave_lds_sync();
+                    sp4_arrive(sync + SP4_F_CX, lane);
+                    gave_up = sp4_wait(sync, SP4_F_CX, SP4_NPART * (j - 1), gave_up);
+                }
+            }
+            if (act) sp4_product0_part(wave, x, sp4_lds_off(Po + own), sp4_lds_off(Po + oth), 1.0, bs, tab, cf);
+            wave_lds_sync();
+            sp4_arrive(sync + SP4_F_CO, lane);
+            SP4_STAMP();
+        }
+    }
+#endif
+    if (wave < SP4_WLOAD) {
+        // ================================== column waves: one chain each ====================================================
         SP4_SCALARS_DEF();
         if (wave == 0) {
             // ---- P: powers of G(u_k), one tile of the ring per power -----------------------------------------------------------
@@ -454,51 +517,15 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
         constexpr int hn = n >> 1;
         constexpr int pstep = (64 * SP4_NSTREAM) / hn > 0 ? (64 * SP4_NSTREAM) / hn : 1;
         constexpr int NSP = (n + pstep - 1) / pstep;  // column positions per thread
+#ifdef PCL_PROFILE
+        bool dry_ = (p.prof & 256) != 0;  // experiment (results WRONG): the first item twice, the first pass without stores -- the second pass shows the warm timings
+#endif
         for (int it = 0; it < n_my; ++it) {
             int c0, nce, k, b;
             decode(it, c0, nce, k, b);
             // (an opaque copy per item: derived from `tid` directly, the tile addresses below are hoisted out of the item loop
             //  and spilled)
             SP4_STAMP();
-#if SP4_COOP
-            if (it == 0 && coop) {
-                SP4_LANEPOS();
-                const bool act = c < d;
-                const double bs = half ? -1.0 : 1.0;
-                const int part = wave - SP4_WSTREAM;
-                SP4_SCALARS_DEF();
-                double hh;
-                sp4_cf cf;
-                sp_cptr tab;
-                scalars(k, b, hh, cf, tab);
-                {  // G itself: unit vectors (a block of its own: inside the loop the 27 constants are kept in a second register set)
-                    double *Po = Pt;
-                    double x[SPD];
-#pragma unroll
-                    for (int i = 0; i < SPD; ++i) x[i] = (half == 0 && i == c) ? 1.0 : 0.0;
-                    if (act) sp4_product0_part(part, x, sp4_lds_off(Po + own), sp4_lds_off(Po + oth), 1.0, bs, tab, cf);
-                    wave_lds_sync();
-                    sp4_arrive(sync + SP4_F_CO, lane);
-                    gave_up = sp4_wait(sync, SP4_F_CO, SP4_NSTREAM, gave_up);  // every row of this power is in the tile
-                    SP4_STAMP();
-                }
-#pragma unroll 1
-                for (int j = 2; j <= q; ++j) {
-                    double *Po = Pt + ((j - 1) % npw) * SP4TILE;
-                    const double *Pi = Pt + ((j - 2) % npw) * SP4TILE;
-                    double x[SPD];
-                    if (act) {
-#pragma unroll
-                        for (int i = 0; i < SPD; ++i) x[i] = Pi[own + i];
-                    }
-                    if (act) sp4_product0_part(part, x, sp4_lds_off(Po + own), sp4_lds_off(Po + oth), 1.0, bs, tab, cf);
-                    wave_lds_sync();
-                    sp4_arrive(sync + SP4_F_CO, lane);
-                    gave_up = sp4_wait(sync, SP4_F_CO, SP4_NSTREAM * j, gave_up);
-                    SP4_STAMP();
-                }
-            }
-#endif
             int stid = tid - 64 * SP4_WSTREAM;
             asm volatile("" : "+v"(stid));  // (after the cooperative products: nothing derived from it lives beside their registers)
             const int pi = 2 * (stid % hn), pj0 = stid / hn;
@@ -527,6 +554,9 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 }
             }
             double hp = 1.0, hm = 1.0;
+#ifdef PCL_PROFILE
+            if (p.prof & 128) SP4_STAMP();
+#endif
 #pragma unroll 1
             for (int j = 1; j <= q; ++j) {
                 const int L = it * q + j - 1;
@@ -534,7 +564,10 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 hp *= h;
                 hm *= -h;
                 const double cp = p.pc[j] * hp, cm = p.pc[j] * hm;
-                if (!(coop && it == 0)) gave_up = sp4_wait(sync, SP4_F_B, L + 1, gave_up);
+                if (coop && it == 0)
+                    gave_up = sp4_wait(sync, SP4_F_CO, SP4_NPART * j, gave_up);  // every part of this power (cooperative first item)
+                else
+                    gave_up = sp4_wait(sync, SP4_F_B, L + 1, gave_up);
                 double v[NSP][2];
 #pragma unroll
                 for (int r = 0; r < NSP; ++r)
@@ -556,6 +589,9 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             // has finished the item -- checked between two columns of blocks, never waited for before the last block is out (the
             // chains run several times faster than the stream; behind the last block the stores would lengthen a one-item launch)
             bool tails_out = !(tails_by_stream && !no_chains);
+#ifdef PCL_PROFILE
+            if (dry_) tails_out = true;
+#endif
             auto try_tails = [&](bool wait) {
                 if (tails_out) return;
                 if (wait) {
@@ -586,7 +622,12 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 }
                 double *o = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn + pi;
                 for (int cq = cbeg; cq < cend; ++cq, o += nn) {
+#ifdef PCL_PROFILE
+                    if (dry_ && cq >= cbeg + 2) break;
+                    if (pact && !no_blocks && !dry_) {
+#else
                     if (pact && !no_blocks) {
+#endif
                         const bool sp_ = cq != half_col || c0 == 0, sm_ = cq != half_col || c0 > 0;
 #pragma unroll
                         for (int r = 0; r < NSP; ++r) {
@@ -598,11 +639,19 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                         }
                     }
                     if (!(p.v4_flags & 2)) try_tails(false);
+#ifdef PCL_PROFILE
+                    if ((p.prof & 128) && cq < cbeg + 2) SP4_STAMP();
+#endif
                 }
             }
             try_tails(true);
             SP4_STAMP();
 #ifdef PCL_PROFILE
+            if (dry_) {
+                dry_ = false;
+                --it;
+                continue;
+            }
             if (p.prof & 16) {  // ... and gone
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 SP4_STAMP();
