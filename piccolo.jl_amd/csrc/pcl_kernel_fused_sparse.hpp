@@ -184,11 +184,12 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     _Pragma("unroll") for (int g = 0; g < SP4NMAG; ++g) mg[g] = magc[g];                                          \
     auto scalars = [&](int k, int b, double &h, sp4_cf &cf, sp_cptr &tab) {                                       \
         sp_cptr zc = (sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim);                   \
+        /* (the drift classes first: every load of the item is then requested before the first use -- one round trip instead of two) */ \
+        SP4_SET_DCF(cf, (sp_cptr)(dcf_tab + (p.g0_batch_stride ? (long long)b * SP4NDCFP : 0)));                  \
         double u[SPM > 0 ? SPM : 1];                                                                              \
         _Pragma("unroll") for (int l = 0; l < SPM; ++l) u[l] = zc[p.u_off + l];                                   \
         h = zc[p.dt_off];                                                                                         \
         SP4_SET_CF(cf, u, mg);                                                                                    \
-        SP4_SET_DCF(cf, (sp_cptr)(dcf_tab + (p.g0_batch_stride ? (long long)b * SP4NDCFP : 0)));                  \
         tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));                          \
     }
     // Cooperative first item: the store-stream waves build the powers of G of the workgroup's FIRST item themselves, a quarter of the
@@ -217,8 +218,17 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     //      waves built them themselves and the fold of a power sat between two products of the same wave: 27.6 -> 25.7 us per
     //      one-trajectory launch.  Nine parts on nine waves measured slower than four: 26.5 us -- a part's time is its cold start.)
     if (coop && wave < SP4_NPART && n_my > 0) {
+#ifdef PCL_PROFILE
+        if (p.prof & 128) SP4_STAMP();
+#endif
         int c0, nce, k, b;
         decode(0, c0, nce, k, b);
+#ifdef PCL_PROFILE
+        if (p.prof & 128) {
+            asm volatile("" ::"s"(k), "s"(b), "s"(c0));
+            SP4_STAMP();
+        }
+#endif
         SP4_LANEPOS();
         const bool act = c < d;
         const double bs = half ? -1.0 : 1.0;
@@ -513,6 +523,9 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
         }
     } else {
         // ================================== stream waves ========================================================================
+#ifdef PCL_PROFILE
+        if (p.prof & 128) SP4_STAMP();
+#endif
         __builtin_amdgcn_s_setprio(3);  // few instructions, each of them keeps the memory system busy
         constexpr int hn = n >> 1;
         constexpr int pstep = (64 * SP4_NSTREAM) / hn > 0 ? (64 * SP4_NSTREAM) / hn : 1;
