@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-shares", action="store_true", help="auto on 1 GPU: skip the multistart / ensemble share measurements")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl) even for one rank: exercises the multi-rank code path on one GPU")
+    ap.add_argument("--separate-objective", action="store_true", help="ensemble step: pcl_objective_dev + pcl_eval_jac_merit_dev (4 launches) instead of pcl_eval_jac_merit_objective_dev (2)")
     ap.add_argument("--separate-payload", action="store_true", help="ensemble step: pcl_eval_jac_dev + pcl_merit_grad_dev instead of the fused pcl_eval_jac_merit_dev")
     ap.add_argument("--no-extras", action="store_true", help="skip the Hessian / compact / residual-only / host-delivered / config-2 rates")
     args = ap.parse_args()
@@ -201,12 +202,16 @@ def main():
         reduce_ = dist is not None and use_dist
 
         def step():
-            J.value_and_gradient_dev(Zd, payload[:1], grad)
             if args.separate_payload:  # A/B: the payload kernels read the tails back from HBM
+                J.value_and_gradient_dev(Zd, payload[:1], grad)
                 c.eval_jac_dev(Zd, dd, vd)
                 c.merit_grad_dev(dd, None, vd, payload[1:])
-            else:  # the fused kernel's matrix waves form the payload's dot products while a column is in LDS
+            elif args.separate_objective:  # A/B: objective (2 launches) + fused kernel + payload finish (round-3 first half: 4 launches)
+                J.value_and_gradient_dev(Zd, payload[:1], grad)
                 c.eval_jac_merit_dev(Zd, None, dd, vd, payload[1:])
+            else:  # TWO launches: the fused kernel (its writer wave forms the payload's dot products while a column is in LDS), then one
+                # launch whose workgroups are the regulariser rows, the terminal infidelities and the payload's finish
+                J.step_dev(Zd, payload[:1], grad, dd, vd, payload[1:])
             if reduce_:
                 pd.reduce_payload(payload, dist)  # ONE sum all-reduce (RCCL over xGMI, on this stream): the one collective of the path
 
@@ -216,6 +221,7 @@ def main():
         info = dict(kernel_id=c.get_option("last_kernel"), stream_workgroups=c.get_option("last_stream_workgroups"),
                     payload_bytes=int(payload.numel() * 8), all_reduce=bool(reduce_), z_dim=int(traj.dim),
                     payload_fused=bool(c.get_option("last_merit_fused")) and not args.separate_payload,
+                    launches_per_step=(5 if args.separate_payload else 4) if (args.separate_payload or args.separate_objective) else int(c.get_option("last_step_launches")),
                     objective=float(chk[0]), merit=float(chk[1]))  # fmt: skip
         if reduce_:  # the collective alone (same payload, same stream), barrier-bracketed like the step
             wr, dr = time_steps(lambda: pd.reduce_payload(payload, dist), steps, min(warmup, 5), torch, dist)
@@ -284,7 +290,7 @@ def main():
         we, de = float(te[0]), float(te[1])
         out["ensemble_share"] = {"evals_per_s": world * B * args.steps / we, "us_per_step_kernel": de / args.steps * 1e6, "members_per_gpu": B,
                                  "members_total": B * world, "payload_bytes": ie["payload_bytes"], "all_reduce": ie["all_reduce"],
-                                 "rccl_ranks": ie.get("rccl_ranks"), "all_reduce_us": ie.get("all_reduce_us"), "payload_fused": ie["payload_fused"],
+                                 "rccl_ranks": ie.get("rccl_ranks"), "all_reduce_us": ie.get("all_reduce_us"), "payload_fused": ie["payload_fused"], "launches_per_step": ie["launches_per_step"],
                                  "note": "config 4: fused residual+Jacobian of this rank's members + objective + payload, then ONE RCCL sum all-reduce; max over ranks"}  # fmt: skip
     kernel_s = dev / args.steps  # HIP events on the launch stream around the K back-to-back steps
     out["roofline"] = {
@@ -319,7 +325,7 @@ def main():
         we, de, ie, ub = run_ensemble(B, st, 20, False)
         out["ensemble_share"] = {"evals_per_s": B * st / we, "us_per_step_kernel": de / st * 1e6, "members_per_step": B,
                                  "hbm_GBps": ub * B / (de / st) / 1e9, "payload_bytes": ie["payload_bytes"], "all_reduce": ie["all_reduce"],
-                                 "payload_fused": ie["payload_fused"],
+                                 "payload_fused": ie["payload_fused"], "launches_per_step": ie["launches_per_step"],
                                  "note": "config 4 share on one GPU: the step of the N > 1 default workload without the all-reduce"}  # fmt: skip
     if rank == 0 and world == 1 and args.workload == "auto" and not args.no_shares:
         # config 5 whole (64 seeds) on this one GPU in one launch: the N = 1 point of the multistart scaling curve

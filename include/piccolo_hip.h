@@ -216,6 +216,14 @@ int pcl_merit_grad_dev(pcl_ctx *ctx, const double *delta_dev, const double *lam_
  * shapes, Pade orders other than 4, a member window) run the two calls one after the other: same outputs, same layout.
  * get_option "last_merit_fused" tells which. */
 int pcl_eval_jac_merit_dev(pcl_ctx *ctx, const double *Z_dev, const double *lam_dev, double *delta_dev, double *vals_dev, double *out_dev);
+/* pcl_objective_dev + pcl_eval_jac_merit_dev -- everything a rank computes in one step of a sharded ensemble
+ * (SamplingProblem: weighted infidelities + regularisers with their gradient, the members' residuals and Jacobian values, the reduce
+ * payload) -- in TWO launches instead of four: the fused kernel, then one launch whose workgroups are the regulariser rows, the terminal
+ * infidelities and the payload's finish.  Outputs as the two calls write them (value_dev, grad_dev: pcl_objective_dev; the rest:
+ * pcl_eval_jac_merit_dev), bit for bit.  Falls back to the two calls where the fused payload does not apply, when grad_dev is NULL, or when a
+ * regulariser covers a state component. */
+int pcl_eval_jac_merit_objective_dev(pcl_ctx *ctx, const double *Z_dev, const double *lam_dev, double *delta_dev, double *vals_dev, double *out_dev, double Q,
+                                     double *value_dev, double *grad_dev);
 
 /* rollout for validation ------------------------------------------------------------------------
  *   unitary_rollout(traj, sys; interpolation = :constant)                       src/quantum/dynamics.jl:631-667
@@ -291,7 +299,7 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised for kernels 1-3; 40 + q kernel 4 at order
  *       2q; 50 + q the small-system kernel; 60 / 61 matrix-core residual kernel, 70 round-2 pattern-compiled residual kernel, 80 + q pattern-compiled residual kernel
  *       at order 2q; 90 + q general-order kernel in the reference formulation, 190 + q lock-step general-order kernel),
- *       "last_stream_workgroups", "last_merit_fused", "last_eval_coop", "last_hess_split", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3
+ *       "last_stream_workgroups", "last_merit_fused", "last_step_launches" (pcl_eval_jac_merit_objective_dev: 2 | 4), "last_eval_coop", "last_hess_split", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3
  *       static / compiled | 6: pattern-compiled order 4 | 70 + q: pattern-compiled, order 2q | 90 + q: general-order), "jit_compiles",
  *       "n_cu", "iso_structured", "drives_antisymmetric",
  *       "ell_width", "ell_width_t", "union_width", "occupancy_v2".  Unknown keys return PCL_EINVAL. */

@@ -30,7 +30,7 @@ EXPORTS = [
     "pcl_jac_compact_nnz", "pcl_eval_jac_compact_dev", "pcl_jac_expand_dev",
     "pcl_deriv_nnz", "pcl_deriv_structure", "pcl_deriv_eval_jac", "pcl_deriv_eval_jac_dev",
     "pcl_jac_dev", "pcl_set_member_window", "pcl_set_goal", "pcl_set_goal_subspace", "pcl_set_weights", "pcl_infidelity_dev", "pcl_add_regularizer",
-    "pcl_clear_regularizers", "pcl_objective_dev", "pcl_objective", "pcl_merit_grad_len", "pcl_merit_grad_dev", "pcl_eval_jac_merit_dev",
+    "pcl_clear_regularizers", "pcl_objective_dev", "pcl_objective", "pcl_merit_grad_len", "pcl_merit_grad_dev", "pcl_eval_jac_merit_dev", "pcl_eval_jac_merit_objective_dev",
     "pcl_rollout", "pcl_rollout_dev",
     "pcl_comm_get_unique_id", "pcl_comm_init", "pcl_reduce_sum_dev", "pcl_reduce_sum", "pcl_comm_destroy",
     "pcl_set_option", "pcl_get_option", "pcl_debug_timing", "pcl_codegen_source",
@@ -175,6 +175,7 @@ def load():
     L.pcl_merit_grad_len.argtypes = [vp, c_i64p, c_i64p]
     L.pcl_merit_grad_dev.argtypes = [vp, vp, vp, vp, vp]
     L.pcl_eval_jac_merit_dev.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.pcl_eval_jac_merit_objective_dev.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp]
     L.pcl_infidelity_dev.argtypes = [vp, vp, ctypes.c_double, vp, vp]
     L.pcl_rollout.argtypes = [vp, vp, vp]
     L.pcl_rollout_dev.argtypes = [vp, vp, vp]

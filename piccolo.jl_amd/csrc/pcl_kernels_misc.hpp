@@ -179,20 +179,27 @@ struct PclObjSum {
     const double *regval;   // [nbuf][N] per-knot regulariser values (written by the previous launch)
     unsigned int *ticket;   // zero between launches (the last arriver resets it)
     int batch, N, traj_mode;
+    int arrivals;           // workgroups that arrive at the ticket: batch (the infidelity launch), batch + nbuf N when the regulariser
+                            // workgroups run in the same launch (pcl_ens_tail_kernel: their values are then part of what the last arriver needs)
 };
 __device__ __forceinline__ double wave_sum_strided_fwd(const double *__restrict__ v, int count) {
     double s = 0.0;
-    for (int i = threadIdx.x & 63; i < count; i += 64) s += v[i];
+    for (int i = threadIdx.x & 63; i < count; i += 64) s += __hip_atomic_load(v + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (maybe written in this launch)
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     return s;  // valid in lane 0
 }
-__device__ __forceinline__ void objective_finish(const PclObjSum &fin, const double *member, double *red) {
+// light: the arriver has published its one value with an agent-scope atomic store (thread 0) and waits for that store alone -- a release
+// at agent scope writes the XCD's whole L2 back, and the regulariser workgroups (a hundred of them, each with a fresh gradient row in
+// the L2) would do so one after the other: 40 us for the launch instead of 10
+__device__ __forceinline__ void objective_finish(const PclObjSum &fin, const double *member, double *red, bool light = false) {
     if (!fin.out) return;
     __syncthreads();  // this workgroup's member[b] (thread 0) is written
     __shared__ int last;
     if (threadIdx.x == 0) {
-        const unsigned int t = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last = (t == (unsigned)fin.batch - 1u);
+        if (light) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = light ? __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                     : __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == (unsigned)fin.arrivals - 1u);
     }
     __syncthreads();
     if (!last) return;
@@ -214,19 +221,22 @@ __device__ __forceinline__ void objective_finish(const PclObjSum &fin, const dou
     }
 }
 
-__global__ __launch_bounds__(256) void pcl_infidelity_kernel(const double *__restrict__ Z, const double *__restrict__ goal,
-                                                             const int *__restrict__ sub, int ns,
-                                                             const int *__restrict__ x_offs, const double *__restrict__ weights,
-                                                             double *__restrict__ value, double *__restrict__ grad,
-                                                             long long grad_stride, int accumulate, double Q, int d, int N,
-                                                             int z_dim, long long z_batch_stride, PclObjSum fin) {
+__device__ __forceinline__ void pcl_infidelity_body(const int b, const double *__restrict__ Z, const double *__restrict__ goal,
+                                                    const int *__restrict__ sub, int ns,
+                                                    const int *__restrict__ x_offs, const double *__restrict__ weights,
+                                                    double *__restrict__ value, double *__restrict__ grad,
+                                                    long long grad_stride, int accumulate, double Q, int d, int N,
+                                                    int z_dim, long long z_batch_stride, PclObjSum fin) {
     extern __shared__ double lds[];
     __shared__ double red[8];
-    const int n = 2 * d, b = blockIdx.x, tid = threadIdx.x;
+    const int n = 2 * d, tid = threadIdx.x;
     const int xo = x_offs[z_batch_stride ? 0 : b];
     const double *x = Z + (long long)b * z_batch_stride + (long long)(N - 1) * z_dim + xo;
     const double Qw = Q * (weights ? weights[b] : 1.0);
+    // accumulate: 0 a per-member x_dim slot, overwritten | 1 the member's terminal block of the full gradient buffer, added to | 2 that
+    // block, overwritten (pcl_ens_tail_kernel: the regulariser workgroup of the last knot runs beside this one and leaves the block alone)
     double *g = grad ? grad + (long long)b * grad_stride + (accumulate ? (long long)(N - 1) * z_dim + xo : 0) : nullptr;
+    const bool add = accumulate == 1;
     if (ns <= 0) {
         double tr = 0.0, ti = 0.0;
         for (int e = tid; e < d * d; e += 256) {
@@ -240,13 +250,18 @@ __global__ __launch_bounds__(256) void pcl_infidelity_kernel(const double *__res
         const double inv = 1.0 / ((double)d * d);
         const double F = (tr * tr + ti * ti) * inv;
         const double sgn = (1.0 - F >= 0.0) ? 1.0 : -1.0;
-        if (tid == 0 && value) value[b] = Qw * fabs(1.0 - F);
+        if (tid == 0 && value) {
+        if (accumulate == 2)
+            __hip_atomic_store(value + b, Qw * fabs(1.0 - F), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            value[b] = Qw * fabs(1.0 - F);
+    }
         if (g) {
             for (int e = tid; e < d * d; e += 256) {
                 const int c = e / d, i = e - c * d;
                 const double gr = goal[c * n + i], gi = goal[c * n + d + i];
                 const double v0 = -sgn * Qw * 2.0 * (tr * gr - ti * gi) * inv, v1 = -sgn * Qw * 2.0 * (tr * gi + ti * gr) * inv;
-                if (accumulate) {
+                if (add) {
                     g[c * n + i] += v0;
                     g[c * n + d + i] += v1;
                 } else {
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(256) void pcl_infidelity_kernel(const double *__res
                 }
             }
         }
-        objective_finish(fin, value, red);
+        objective_finish(fin, value, red, accumulate == 2);
         return;
     }
     // ---- subspace (EmbeddedOperator) fidelity: ns x ns complex blocks in LDS: Us | Ug | M | W (re, im planes) ----
@@ -294,9 +309,14 @@ __global__ __launch_bounds__(256) void pcl_infidelity_kernel(const double *__res
     const double inv = 1.0 / ((double)ns * (ns + 1));
     const double F = (fabs(fro) + tr * tr + ti * ti) * inv;
     const double sgn = (1.0 - F >= 0.0) ? 1.0 : -1.0;
-    if (tid == 0 && value) value[b] = Qw * fabs(1.0 - F);
+    if (tid == 0 && value) {
+        if (accumulate == 2)
+            __hip_atomic_store(value + b, Qw * fabs(1.0 - F), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            value[b] = Qw * fabs(1.0 - F);
+    }
     if (g) {
-        if (!accumulate)
+        if (!add)
             for (int e = tid; e < n * d; e += 256) g[e] = 0.0;
         __syncthreads();
         for (int e = tid; e < nn; e += 256) {  // W = Ug M ; dF = (2 W + 2 t Ug) / (ns (ns+1))
@@ -314,7 +334,16 @@ __global__ __launch_bounds__(256) void pcl_infidelity_kernel(const double *__res
             g[sub[c] * n + d + sub[i]] += -sgn * Qw * di;
         }
     }
-    objective_finish(fin, value, red);
+    objective_finish(fin, value, red, accumulate == 2);
+}
+
+__global__ __launch_bounds__(256) void pcl_infidelity_kernel(const double *__restrict__ Z, const double *__restrict__ goal,
+                                                             const int *__restrict__ sub, int ns,
+                                                             const int *__restrict__ x_offs, const double *__restrict__ weights,
+                                                             double *__restrict__ value, double *__restrict__ grad,
+                                                             long long grad_stride, int accumulate, double Q, int d, int N,
+                                                             int z_dim, long long z_batch_stride, PclObjSum fin) {
+    pcl_infidelity_body((int)blockIdx.x, Z, goal, sub, ns, x_offs, weights, value, grad, grad_stride, accumulate, Q, d, N, z_dim, z_batch_stride, fin);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -328,13 +357,17 @@ struct PclReg {
 };
 #define PCL_MAX_REGS 8
 
-__global__ __launch_bounds__(256) void pcl_regularizer_kernel(const double *__restrict__ Z, const PclReg *__restrict__ regs, int n_regs,
-                                                              const double *__restrict__ Rv, double *__restrict__ grad,
-                                                              double *__restrict__ regval, int N, int z_dim, int dt_off,
-                                                              long long z_batch_stride) {
+__device__ __forceinline__ void pcl_regularizer_body(const int k, const int tb, const double *__restrict__ Z, const PclReg *__restrict__ regs, int n_regs,
+                                                     const double *__restrict__ Rv, double *__restrict__ grad,
+                                                     double *__restrict__ regval, int N, int z_dim, int dt_off,
+                                                     long long z_batch_stride, const PclObjSum fin, const double *__restrict__ member,
+                                                     int skip_lo = 0, int skip_hi = 0) {
+    // [skip_lo, skip_hi) (pcl_ens_tail_kernel): at the LAST knot these entries -- the terminal states, one contiguous run, written by the
+    // infidelity workgroups of the same launch -- are left alone (the host has checked that the states tile the run and that no
+    // regulariser covers them)
     __shared__ double red[8];
     __shared__ double sr[PCL_MAX_REGS];
-    const int k = blockIdx.x, tb = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const double *z = Z + (long long)tb * z_batch_stride + (long long)k * z_dim;
     double *g = grad ? grad + (long long)tb * (long long)z_dim * N + (long long)k * z_dim : nullptr;
     const double h = z[dt_off];
@@ -355,7 +388,10 @@ __global__ __launch_bounds__(256) void pcl_regularizer_kernel(const double *__re
     __syncthreads();
     if (g) {  // the knot's whole row: zeros first (no memset launch before this kernel), then the entries that carry a term; terms
               // that overlap are added in regulariser order by the same thread (a thread owns entry i of every regulariser)
-        {
+        if (skip_hi > skip_lo && k == N - 1) {
+            for (int i = tid; i < skip_lo; i += 256) g[i] = 0.0;
+            for (int i = skip_hi + tid; i < z_dim; i += 256) g[i] = 0.0;
+        } else {
             const bool al = ((reinterpret_cast<unsigned long long>(g) & 15) == 0);
             int i0 = 0;
             if (al) {
@@ -396,7 +432,19 @@ __global__ __launch_bounds__(256) void pcl_regularizer_kernel(const double *__re
             g[dt_off] = gi;
         }
     }
-    if (tid == 0) regval[(long long)tb * N + k] = val;
+    if (tid == 0) {
+        if (fin.out)
+            __hip_atomic_store(regval + (long long)tb * N + k, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+            regval[(long long)tb * N + k] = val;
+    }
+    objective_finish(fin, member, red, true);  // (fin.out NULL: a launch of its own, the infidelity launch behind it forms the sums)
+}
+__global__ __launch_bounds__(256) void pcl_regularizer_kernel(const double *__restrict__ Z, const PclReg *__restrict__ regs, int n_regs,
+                                                              const double *__restrict__ Rv, double *__restrict__ grad,
+                                                              double *__restrict__ regval, int N, int z_dim, int dt_off,
+                                                              long long z_batch_stride) {
+    pcl_regularizer_body((int)blockIdx.x, (int)blockIdx.y, Z, regs, n_regs, Rv, grad, regval, N, z_dim, dt_off, z_batch_stride, PclObjSum{}, nullptr);
 }
 
 // value[0] = sum_b member[b] + sum_k regval[k]   (MEMBERS), value[b] = member[b] + sum_k regval[b][k]   (TRAJ).
@@ -481,12 +529,14 @@ __global__ __launch_bounds__(512) void pcl_merit_part_kernel(const double *__res
 // sum in a fixed order (bitwise repeatable): workgroup k adds the columns of interval k per (member, l) in column order, then
 // the members with their weights in member order (same arithmetic as pcl_merit_sum_kernel) -> g_u[k,:], g_dt[k], phi_k; the
 // workgroup that arrives last at the agent-scope ticket (acquire-release) adds phi_k over the intervals.
-__global__ __launch_bounds__(256) void pcl_merit_finish_kernel(const double *__restrict__ pcol, const double *__restrict__ weights,
-                                                              double *__restrict__ out, double *__restrict__ phik, unsigned int *ticket,
-                                                              int batch, int K, int cols, int m, int traj_mode) {
+__device__ __forceinline__ void pcl_merit_finish_body(const int k, const double *__restrict__ pcol, const double *__restrict__ weights,
+                                                      double *__restrict__ out, double *__restrict__ phik, unsigned int *ticket,
+                                                      int batch, int K, int cols, int m, int traj_mode, bool light = false) {
+    // light (pcl_ens_tail_kernel): what the last arriver reads -- phi_k -- is published with agent-scope atomic stores; every thread waits
+    // for its own stores, the ticket is relaxed (no write-back of the whole L2 per workgroup beside the gradient rows of the same launch)
     extern __shared__ double part[];  // [batch][m + 2]
     __shared__ int last;
-    const int k = blockIdx.x, tid = threadIdx.x, m2 = m + 2;
+    const int tid = threadIdx.x, m2 = m + 2;
     const long long set_len = 1 + (long long)K * m + K;
     for (int e = tid; e < batch * m2; e += 256) {
         const int b = e / m2, l = e - b * m2;
@@ -526,9 +576,11 @@ __global__ __launch_bounds__(256) void pcl_merit_finish_kernel(const double *__r
         else
             __hip_atomic_store(phik + k, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (light) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int t = light ? __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                     : __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         last = (t == (unsigned)K - 1u);
     }
     __syncthreads();
@@ -543,6 +595,58 @@ __global__ __launch_bounds__(256) void pcl_merit_finish_kernel(const double *__r
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if ((tid & 63) == 0) out[(long long)set * set_len] = s;
     }
+}
+__global__ __launch_bounds__(256) void pcl_merit_finish_kernel(const double *__restrict__ pcol, const double *__restrict__ weights,
+                                                              double *__restrict__ out, double *__restrict__ phik, unsigned int *ticket,
+                                                              int batch, int K, int cols, int m, int traj_mode) {
+    pcl_merit_finish_body((int)blockIdx.x, pcol, weights, out, phik, ticket, batch, K, cols, m, traj_mode);
+}
+// The tail of an ensemble step in ONE launch (pcl_eval_jac_merit_objective_dev): what pcl_objective_dev (regulariser + infidelity
+// launches) and the payload's finish launch do, as three ranges of workgroups of one grid -- [0, nbuf N) regulariser rows,
+// [.., + batch) terminal infidelities, [.., + K) payload intervals.  Nothing here waits for anything: the objective's final sums are
+// formed by whichever regulariser / infidelity workgroup arrives last at their ticket, the payload's by its own last arriver; every sum
+// keeps its fixed order, so the outputs are bit for bit those of the separate launches.  Three small launches on a GPU whose every CU
+// the fused kernel has just occupied cost 8-9 us each, most of it dispatch.
+struct PclTailArgs {
+    // regulariser rows
+    const double *Z;
+    const PclReg *regs;
+    int n_regs;
+    const double *Rv;
+    double *grad, *regval;
+    int N, z_dim, dt_off, nbuf;
+    long long z_batch_stride;
+    // infidelities
+    const double *goal;
+    const int *sub;
+    int ns;
+    const int *x_offs;
+    const double *weights;
+    double *member;
+    long long grad_stride;
+    double Q;
+    int d, batch;
+    PclObjSum fin;
+    // payload
+    const double *pcol;
+    double *out, *phik;
+    unsigned int *mticket;
+    int K, cols, m, traj_mode;
+    int skip_lo, skip_hi;  // the terminal states' entries of a gradient row (regulariser rows leave them to the infidelity workgroups)
+};
+__global__ __launch_bounds__(256) void pcl_ens_tail_kernel(const PclTailArgs a) {
+    int j = (int)blockIdx.x;
+    const int n_reg = a.nbuf * a.N;
+    if (j < n_reg) {
+        pcl_regularizer_body(j % a.N, j / a.N, a.Z, a.regs, a.n_regs, a.Rv, a.grad, a.regval, a.N, a.z_dim, a.dt_off, a.z_batch_stride, a.fin, a.member, a.skip_lo, a.skip_hi);
+        return;
+    }
+    j -= n_reg;
+    if (j < a.batch) {
+        pcl_infidelity_body(j, a.Z, a.goal, a.sub, a.ns, a.x_offs, a.weights, a.member, a.grad, a.grad_stride, 2, a.Q, a.d, a.N, a.z_dim, a.z_batch_stride, a.fin);
+        return;
+    }
+    pcl_merit_finish_body(j - a.batch, a.pcol, a.weights, a.out, a.phik, a.mticket, a.batch, a.K, a.cols, a.m, a.traj_mode, true);
 }
 __global__ __launch_bounds__(1024) void pcl_merit_sum_kernel(const double *__restrict__ part, const double *__restrict__ weights,
                                                             double *__restrict__ out, double *__restrict__ phik, int batch, int K, int m,

@@ -103,6 +103,7 @@ struct pcl_ctx {
     int v4_hess_failed = 0;
     int v4_failed = 0;
     int64_t opt_v4_variant = 0;     // PCL_PROFILE builds: timing variants of the generated product (wrong results)
+    int last_step_launches = 0;  // what the last pcl_eval_jac_merit_objective_dev launched (get_option)
     int64_t opt_v4_flags = 0, opt_v4_np = 0;  // kernel 4 A/B switches (KParams::v4_flags); tiles of the powers of G (0 auto)
     int64_t opt_v4_tail_mode = 3;   // kernel 4: who stores delta and the tails: 0 the writer wave | 1 ... nontemporal | 2 ... write-through | 3 the stream waves (default)
     int64_t opt_eval_kernel = 0;    // 0 auto | 1 matrix-core residual kernel | 2 pattern-compiled
@@ -2115,21 +2116,16 @@ extern "C" int pcl_infidelity_dev(pcl_ctx *ctx, const double *Z, double Q, doubl
     const pcl_desc &D = ctx->desc;
     hipLaunchKernelGGL(pcl_infidelity_kernel, dim3((unsigned)D.batch), dim3(256), infidelity_lds(ctx), ctx->stream, Z, ctx->dgoal, ctx->dsub,
                        ctx->n_sub, ctx->dxoffs, ctx->dweights, value, grad, (long long)ctx->x_dim, 0, Q, D.d, D.N, D.z_dim,
-                       D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0LL, PclObjSum{nullptr, nullptr, nullptr, 0, 0, 0});
+                       D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0LL, PclObjSum{nullptr, nullptr, nullptr, 0, 0, 0, 0});
     HIP_TRY(ctx, hipGetLastError());
     return PCL_OK;
 }
 // Whole objective of the unitary templates: sum_b w_b Q |1 - F_b| + quadratic regularisers, value + full gradient.
-extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad) {
-    if (!ctx) return PCL_EINVAL;
-    if (!Z || !value) return fail(ctx, PCL_EINVAL, "pcl_objective_dev: NULL pointer");
-    if (!ctx->dgoal && ctx->regs.empty()) return fail(ctx, PCL_EINVAL, "pcl_objective_dev: no goal and no regulariser set");
-    if (ctx->dgoal) TRY(objective_unitary_only(ctx, "pcl_objective_dev"));
-    ON_DEVICE(ctx);
+// buffers, tickets and the regulariser table of the objective launches (pcl_objective_dev, pcl_eval_jac_merit_objective_dev)
+static int objective_prepare(pcl_ctx *ctx) {
     const pcl_desc &D = ctx->desc;
     const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
     const int nbuf = traj ? D.batch : 1;
-    const long long zs = traj ? (long long)D.z_dim * D.N : 0LL;
     if (!ctx->dobj) {  // [member terms | per-knot regulariser values | arrival ticket of the fused final sum]
         HIP_TRY(ctx, hipMalloc((void **)&ctx->dobj, ((size_t)D.batch + (size_t)nbuf * D.N + 1) * sizeof(double)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->dobj, 0, ((size_t)D.batch + (size_t)nbuf * D.N + 1) * sizeof(double), ctx->stream));
@@ -2153,6 +2149,19 @@ extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double
         }
         ctx->regs_dirty = false;
     }
+    return PCL_OK;
+}
+extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !value) return fail(ctx, PCL_EINVAL, "pcl_objective_dev: NULL pointer");
+    if (!ctx->dgoal && ctx->regs.empty()) return fail(ctx, PCL_EINVAL, "pcl_objective_dev: no goal and no regulariser set");
+    if (ctx->dgoal) TRY(objective_unitary_only(ctx, "pcl_objective_dev"));
+    ON_DEVICE(ctx);
+    const pcl_desc &D = ctx->desc;
+    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
+    const int nbuf = traj ? D.batch : 1;
+    const long long zs = traj ? (long long)D.z_dim * D.N : 0LL;
+    TRY(objective_prepare(ctx));
     double *member = ctx->dobj, *regval = ctx->dobj + D.batch;
     // Two launches: the regulariser kernel writes every knot's whole gradient row (zeros where no term applies) and the per-knot
     // values; the infidelity kernel adds the terminal-state blocks and its last-arriving workgroup forms the final sum(s).
@@ -2163,7 +2172,7 @@ extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double
         hipLaunchKernelGGL(pcl_infidelity_kernel, dim3((unsigned)D.batch), dim3(256), infidelity_lds(ctx), ctx->stream, Z, ctx->dgoal,
                            ctx->dsub, ctx->n_sub, ctx->dxoffs, ctx->dweights, member, grad, traj ? (long long)D.z_dim * D.N : 0LL, 1, Q, D.d,
                            D.N, D.z_dim, zs,
-                           PclObjSum{value, regval, reinterpret_cast<unsigned int *>(ctx->dobj + D.batch + (size_t)nbuf * D.N), D.batch, D.N, traj ? 1 : 0});
+                           PclObjSum{value, regval, reinterpret_cast<unsigned int *>(ctx->dobj + D.batch + (size_t)nbuf * D.N), D.batch, D.N, traj ? 1 : 0, D.batch});
         HIP_TRY(ctx, hipGetLastError());
         return PCL_OK;
     }
@@ -2242,6 +2251,99 @@ extern "C" int pcl_eval_jac_merit_dev(pcl_ctx *ctx, const double *Z, const doubl
     hipLaunchKernelGGL(pcl_merit_finish_kernel, dim3((unsigned)ctx->K), dim3(256), (size_t)D.batch * (m + 2) * sizeof(double), ctx->stream,
                        (const double *)ctx->dmcols, (const double *)ctx->dweights, out, phik, ctx->dmticket, D.batch, ctx->K, ctx->cols, m, traj ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
+    return PCL_OK;
+}
+// pcl_objective_dev + pcl_eval_jac_merit_dev as TWO launches instead of four: the fused kernel, then ONE launch whose workgroups are the
+// regulariser rows, the terminal infidelities and the payload's finish (pcl_ens_tail_kernel); the same bits as the separate calls.
+extern "C" int pcl_eval_jac_merit_objective_dev(pcl_ctx *ctx, const double *Z, const double *lam, double *delta, double *vals, double *out, double Q,
+                                                double *value, double *grad) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !delta || !vals || !out || !value) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_merit_objective_dev: NULL pointer");
+    if (!ctx->dgoal) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_merit_objective_dev: no goal set");
+    TRY(objective_unitary_only(ctx, "pcl_eval_jac_merit_objective_dev"));
+    int skip_lo = 0, skip_hi = 0;
+    {  // The separate calls: without a gradient buffer; when the members' states are not ONE contiguous run of a gradient row (the
+       // regulariser workgroup of the last knot leaves that run to the infidelity workgroups of the same launch); with a regulariser on a
+       // state component (its terminal-knot term and the infidelity's would meet in one entry: the launches have to stay in order).
+        const int nx = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? 1 : ctx->desc.batch;
+        long long lo = ctx->x_offs[0], hi = ctx->x_offs[0] + ctx->x_dim;
+        for (int b = 1; b < nx; ++b) {
+            lo = std::min<long long>(lo, ctx->x_offs[b]);
+            hi = std::max<long long>(hi, ctx->x_offs[b] + ctx->x_dim);
+        }
+        bool separate = grad == nullptr || hi - lo != (long long)nx * ctx->x_dim;  // (equal extents: distinct offsets tile the run exactly)
+        for (int b = 0; b < nx && !separate; ++b)
+            for (int b2 = 0; b2 < b; ++b2) separate = separate || ctx->x_offs[b] == ctx->x_offs[b2];
+        for (const PclReg &r : ctx->regs) separate = separate || (r.off < hi && lo < r.off + r.dim);
+        ctx->last_step_launches = 4;
+        if (separate) {
+            TRY(pcl_objective_dev(ctx, Z, Q, value, grad));
+            return pcl_eval_jac_merit_dev(ctx, Z, lam, delta, vals, out);
+        }
+        skip_lo = (int)lo;
+        skip_hi = (int)hi;
+    }
+    ctx->merit_want = 1;
+    ctx->merit_fused = 0;
+    ctx->merit_lam = lam;
+    const int rc = launch_fused(ctx, Z, delta, vals, false);
+    ctx->merit_want = 0;
+    ctx->merit_lam = nullptr;
+    if (rc != PCL_OK) return rc;
+    if (!ctx->merit_fused) {  // other kernels / member windows: the separate calls
+        TRY(pcl_merit_grad_dev(ctx, delta, lam, vals, out));
+        return pcl_objective_dev(ctx, Z, Q, value, grad);
+    }
+    ON_DEVICE(ctx);
+    const pcl_desc &D = ctx->desc;
+    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
+    const int sets = traj ? D.batch : 1, nbuf = sets;
+    const int m = D.n_drives;
+    const long long zs = traj ? (long long)D.z_dim * D.N : 0LL;
+    if (!ctx->dphik) HIP_TRY(ctx, hipMalloc((void **)&ctx->dphik, ((size_t)D.batch * ctx->K * (m + 2) + (size_t)sets * ctx->K) * sizeof(double)));
+    if (!ctx->dmticket) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->dmticket, 64));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dmticket, 0, 64, ctx->stream));
+    }
+    TRY(objective_prepare(ctx));  // (also re-zeroes both tickets after a switch of streams)
+    PclTailArgs a;
+    a.Z = Z;
+    a.regs = (const PclReg *)ctx->dregs;
+    a.n_regs = (int)ctx->regs.size();
+    a.Rv = ctx->dreg_R;
+    a.grad = grad;
+    a.regval = ctx->dobj + D.batch;
+    a.N = D.N;
+    a.z_dim = D.z_dim;
+    a.dt_off = D.dt_off;
+    a.nbuf = nbuf;
+    a.z_batch_stride = zs;
+    a.goal = ctx->dgoal;
+    a.sub = ctx->dsub;
+    a.ns = ctx->n_sub;
+    a.x_offs = ctx->dxoffs;
+    a.weights = ctx->dweights;
+    a.member = ctx->dobj;
+    a.grad_stride = traj ? (long long)D.z_dim * D.N : 0LL;
+    a.Q = Q;
+    a.d = D.d;
+    a.batch = D.batch;
+    a.fin = PclObjSum{value, ctx->dobj + D.batch, reinterpret_cast<unsigned int *>(ctx->dobj + D.batch + (size_t)nbuf * D.N), D.batch, D.N, traj ? 1 : 0,
+                      D.batch + nbuf * D.N};
+    a.pcol = ctx->dmcols;
+    a.out = out;
+    a.phik = ctx->dphik + (size_t)D.batch * ctx->K * (m + 2);
+    a.mticket = ctx->dmticket;
+    a.K = ctx->K;
+    a.cols = ctx->cols;
+    a.m = m;
+    a.traj_mode = traj ? 1 : 0;
+    a.skip_lo = skip_lo;
+    a.skip_hi = skip_hi;
+    const size_t lds = std::max((size_t)infidelity_lds(ctx), (size_t)D.batch * (m + 2) * sizeof(double));
+    hipLaunchKernelGGL(pcl_ens_tail_kernel, dim3((unsigned)(nbuf * D.N + D.batch + ctx->K)), dim3(256), lds, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->last_step_launches = 2;
     return PCL_OK;
 }
 extern "C" int pcl_merit_grad_len(const pcl_ctx *ctx, int64_t *len, int64_t *sets) {
@@ -2460,6 +2562,8 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->last_hess_split;
     else if (!strcmp(key, "last_eval_coop"))
         *v = ctx->last_eval_coop;
+    else if (!strcmp(key, "last_step_launches"))  // pcl_eval_jac_merit_objective_dev: 2 = fused kernel + one tail launch, 4 = the separate calls
+        *v = ctx->last_step_launches;
     else if (!strcmp(key, "last_merit_fused"))
         *v = ctx->merit_fused;
     else if (!strcmp(key, "contiguous"))

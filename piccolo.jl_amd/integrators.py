@@ -290,6 +290,11 @@ class _PclContext:
         forms the payload's dot products while a column's vectors are in LDS; same outputs as the two calls."""
         self._chk(self._L.pcl_eval_jac_merit_dev(self._h, _ptr(Z), _ptr(lam), _ptr(delta), _ptr(vals), _ptr(out)))
 
+    def eval_jac_merit_objective_dev(self, Z, lam, delta, vals, out, Q, value, grad):
+        """``objective_dev`` + ``eval_jac_merit_dev`` -- a rank's whole step of a sharded ensemble -- in two launches instead of four
+        (pcl_eval_jac_merit_objective_dev); the same bits."""
+        self._chk(self._L.pcl_eval_jac_merit_objective_dev(self._h, _ptr(Z), _ptr(lam), _ptr(delta), _ptr(vals), _ptr(out), float(Q), _ptr(value), _ptr(grad)))
+
     # -- rollout (exact piecewise-constant propagation from the knot-0 state) ----------------------------------------
     def rollout(self, Z, out=None):
         """[batch, N, x_dim] iso-vec states: X_{k+1} = exp(dt_k G(u_k)) X_k."""

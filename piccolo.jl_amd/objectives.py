@@ -157,6 +157,13 @@ class Objective:
                 grad = g.copy() if grad is None else grad + g
         return total, grad
 
+    def step_dev(self, Z_dev, value_dev, grad_dev, delta_dev, vals_dev, payload_dev, lam_dev=None):
+        """A rank's whole step of a sharded ensemble on the device: objective value and gradient (as ``value_and_gradient_dev``), the
+        members' residuals and Jacobian values and the reduce payload (as the context's ``eval_jac_merit_dev``) -- two launches."""
+        if len(self._bound) != 1:
+            raise NotImplementedError("device-resident step of an ensemble whose members have their own contexts")
+        self._ctx.eval_jac_merit_objective_dev(Z_dev, lam_dev, delta_dev, vals_dev, payload_dev, self._Q, value_dev, grad_dev)
+
     def value_and_gradient_dev(self, Z_dev, value_dev, grad_dev=None):
         if len(self._bound) != 1:
             raise NotImplementedError("device-resident objective of an ensemble whose members have their own contexts: use value_and_gradient")

@@ -1551,6 +1551,80 @@ def test_fused_reduce_payload_equals_the_separate_kernels(M, N):
     B.close()
 
 
+@pytest.mark.parametrize("M,N", [(8, 100), (3, 9)])
+def test_ensemble_step_in_two_launches_equals_the_separate_calls(M, N):
+    """pcl_eval_jac_merit_objective_dev (a rank's whole step of a sharded ensemble [REF sampling_problem.jl:381-387]: weighted
+    infidelities + regularisers with their gradient, residuals, Jacobian values, reduce payload): the fused kernel + ONE launch whose
+    workgroups are the regulariser rows, the terminal infidelities and the payload's finish.  Every output bit for bit what
+    pcl_objective_dev + pcl_eval_jac_merit_dev write (themselves pinned on the oracle above); plain and subspace goals, weights,
+    given multipliers, repeated calls; a regulariser on a state component keeps the launches apart -- same outputs."""
+    import torch
+
+    osys, psys, lay, Z, traj = _config4_share(M, N)
+    Bs = pa.BilinearIntegrator(psys, traj)
+    c = Bs[0].ensemble.ctx
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    d = lay.d
+    Zd = torch.from_numpy(traj.datavec).cuda()
+    ln, _ = c.merit_grad_len()
+    rng = np.random.default_rng(5)
+    lam = torch.from_numpy(rng.standard_normal(c.n_rows)).cuda()
+    w = (1.0 + 0.25 * np.arange(M)) / M
+    U = np.linalg.qr(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d)))[0]
+    names = [B.x_name for B in Bs]
+    goals = [U]
+    if d == 27:
+        sub = pa.get_subspace_indices([[0, 1]] * 3, [3, 3, 3])
+        goals.append(pa.EmbeddedOperator(np.linalg.qr(rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8)))[0], sub, [3, 3, 3]))
+    for goal in goals:
+        for weights, lam_d, extra in ((None, None, None), (w, lam, None), (w, None, names[0])):
+            J = pa.UnitaryInfidelityObjective(goal, names, traj, Q=100.0, weights=weights)
+            for nm, R in (("u", 1e-2), ("du", 2e-2), ("ddu", 3e-2)):
+                J = J + pa.QuadraticRegularizer(nm, traj, R)
+            if extra is not None:  # a term on a member's state: the merged launch does not apply
+                J = J + pa.QuadraticRegularizer(extra, traj, 1e-3, 0)
+            J.bind(Bs)
+            ref = [torch.full((k,), float("nan"), dtype=torch.float64, device="cuda") for k in (1, c.z_len, c.n_rows, c.jac_nnz, ln)]
+            J.value_and_gradient_dev(Zd, ref[0], ref[1])
+            c.eval_jac_merit_dev(Zd, lam_d, ref[2], ref[3], ref[4])
+            torch.cuda.synchronize()
+            assert c.get_option("last_merit_fused") == 1
+            for rep in range(3):
+                out = [torch.full_like(r, float("nan")) for r in ref]
+                J.step_dev(Zd, out[0], out[1], out[2], out[3], out[4], lam_dev=lam_d)
+                torch.cuda.synchronize()
+                assert c.get_option("last_step_launches") == (2 if extra is None else 4)
+                for a, b, nm in zip(out, ref, ("value", "gradient", "delta", "values", "payload")):
+                    assert torch.equal(a, b), (nm, rep, float((a - b).abs().max()))
+            assert np.isfinite(ref[0].item()) and ref[0].item() > 0
+    for B in Bs:
+        B.close()
+    if N < 20:  # a multistart context: one objective value, one gradient and one payload set per seed
+        S = 3
+        lay1 = po.Layout.smooth_pulse(d, lay.m, N)
+        Zs = [po.synthetic_trajectory(po.config_system(3), N, seed=300 + q)[0] for q in range(S)]
+        t1 = traj_from_Z(pa, Zs[0], lay1)
+        ms = pa.HipPadeMultistart(osys[0].G_drift, np.array(osys[0].G_drives), t1, S)
+        c = ms.ctx
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        J = (pa.UnitaryInfidelityObjective(U, "Ũ⃗", t1, Q=100.0) + pa.QuadraticRegularizer("u", t1, 1e-2) + pa.QuadraticRegularizer("ddu", t1, 1e-2)).bind(ms)
+        Zd = torch.from_numpy(np.stack(Zs)).cuda()
+        ln, sets = c.merit_grad_len()
+        assert sets == S
+        ref = [torch.full((k,), float("nan"), dtype=torch.float64, device="cuda") for k in (S, c.z_len, c.n_rows, c.jac_nnz, ln * S)]
+        J.value_and_gradient_dev(Zd, ref[0], ref[1])
+        c.eval_jac_merit_dev(Zd, None, ref[2], ref[3], ref[4])
+        torch.cuda.synchronize()
+        for rep in range(2):
+            out = [torch.full_like(r, float("nan")) for r in ref]
+            J.step_dev(Zd, out[0], out[1], out[2], out[3], out[4])
+            torch.cuda.synchronize()
+            assert c.get_option("last_step_launches") == 2
+            for a, b, nm in zip(out, ref, ("value", "gradient", "delta", "values", "payload")):
+                assert torch.equal(a, b), ("multistart", nm, rep)
+        ms.close()
+
+
 def test_fused_reduce_payload_other_shapes():
     """Other shapes: where kernel 4 applies (d = 9) its writer wave forms the payload; where `auto` takes kernel 1 (d = 4)
     pcl_eval_jac_merit_dev runs the two separate calls (same outputs); with kernel_version = 3 the MERIT instance of the shape is
