@@ -1198,6 +1198,9 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     // tiles of the ring in use: q - 1 when workgroups walk several items (the P wave must not run a whole item ahead: measured
     // 8 % on 8 trajectories per launch), all the module has for one-item launches (0.4 us there); option v4_power_tiles overrides
     p.v4_np = ctx->opt_v4_np > 0 ? (int)std::min<int64_t>(ctx->opt_v4_np, np) : (units > g ? std::max(1, std::min(np, p.q - 1)) : np);
+    // the cooperative first item (waves 0-3 build the powers, the stream waves fold) with a ring shorter than q: pays up to order 8 (one
+    // trajectory 31.4 -> 29.3-30.5 us), not at order 10 (five powers through three tiles: 35.5 against 34.1 us)
+    if (p.q >= 5 && p.v4_np < p.q) p.v4_flags |= 4;
     if (want_merit && p.tail_mode == 3) {
         if (!ctx->dmcols) HIP_TRY(ctx, hipMalloc((void **)&ctx->dmcols, (size_t)ctx->desc.batch * p.K * p.d * (p.m + 2) * sizeof(double)));
         p.mpart = ctx->dmcols;
