@@ -200,6 +200,8 @@ int pcl_set_weights(pcl_ctx *ctx, const double *weights);
 int pcl_infidelity_dev(pcl_ctx *ctx, const double *Z_dev, double Q, double *value_dev, double *grad_dev);
 int pcl_add_regularizer(pcl_ctx *ctx, int32_t off, int32_t dim, const double *R, int32_t dt_power);
 int pcl_clear_regularizers(pcl_ctx *ctx);
+/* (one launch -- regulariser rows and terminal infidelities as workgroups of one grid -- with a gradient buffer, the members' states one
+ *  contiguous run of a row and no regulariser on a state component; two launches otherwise; the same bits; option "objective_launches") */
 int pcl_objective_dev(pcl_ctx *ctx, const double *Z_dev, double Q, double *value_dev, double *grad_dev);
 int pcl_objective(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad);
 
@@ -299,7 +301,7 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised for kernels 1-3; 40 + q kernel 4 at order
  *       2q; 50 + q the small-system kernel; 60 / 61 matrix-core residual kernel, 70 round-2 pattern-compiled residual kernel, 80 + q pattern-compiled residual kernel
  *       at order 2q; 90 + q general-order kernel in the reference formulation, 190 + q lock-step general-order kernel),
- *       "last_stream_workgroups", "last_merit_fused", "last_step_launches" (pcl_eval_jac_merit_objective_dev: 2 | 4), "last_eval_coop", "last_hess_split", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3
+ *       "last_stream_workgroups", "last_merit_fused", "last_step_launches" (pcl_eval_jac_merit_objective_dev: 2 | 4), "last_objective_launches" (pcl_objective_dev: 1 | 2), "objective_launches" (set: 0 auto | 2 always two launches), "last_eval_coop", "last_hess_split", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3
  *       static / compiled | 6: pattern-compiled order 4 | 70 + q: pattern-compiled, order 2q | 90 + q: general-order), "jit_compiles",
  *       "n_cu", "iso_structured", "drives_antisymmetric",
  *       "ell_width", "ell_width_t", "union_width", "occupancy_v2".  Unknown keys return PCL_EINVAL. */

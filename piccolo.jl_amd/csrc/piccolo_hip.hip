@@ -103,6 +103,8 @@ struct pcl_ctx {
     int v4_hess_failed = 0;
     int v4_failed = 0;
     int64_t opt_v4_variant = 0;     // PCL_PROFILE builds: timing variants of the generated product (wrong results)
+    int last_objective_launches = 0;  // what the last pcl_objective_dev launched: 1 (one grid) | 2
+    int64_t opt_objective_launches = 0;  // 0 auto | 2: always the two launches (A/B, tests)
     int last_step_launches = 0;  // what the last pcl_eval_jac_merit_objective_dev launched (get_option)
     int64_t opt_v4_flags = 0, opt_v4_np = 0;  // kernel 4 A/B switches (KParams::v4_flags); tiles of the powers of G (0 auto)
     int64_t opt_v4_tail_mode = 3;   // kernel 4: who stores delta and the tails: 0 the writer wave | 1 ... nontemporal | 2 ... write-through | 3 the stream waves (default)
@@ -2154,6 +2156,8 @@ static int objective_prepare(pcl_ctx *ctx) {
     }
     return PCL_OK;
 }
+static bool tail_applies(const pcl_ctx *ctx, const double *grad, int &lo_, int &hi_);
+static int launch_tail(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad, int skip_lo, int skip_hi, double *merit_out);
 extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad) {
     if (!ctx) return PCL_EINVAL;
     if (!Z || !value) return fail(ctx, PCL_EINVAL, "pcl_objective_dev: NULL pointer");
@@ -2164,6 +2168,14 @@ extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double
     const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
     const int nbuf = traj ? D.batch : 1;
     const long long zs = traj ? (long long)D.z_dim * D.N : 0LL;
+    {  // ONE launch where it applies (regulariser rows and terminal infidelities as workgroups of one grid: 18 -> 10 us); the same bits
+        int lo = 0, hi = 0;
+        if (tail_applies(ctx, grad, lo, hi)) {
+            ctx->last_objective_launches = 1;
+            return launch_tail(ctx, Z, Q, value, grad, lo, hi, nullptr);
+        }
+    }
+    ctx->last_objective_launches = 2;
     TRY(objective_prepare(ctx));
     double *member = ctx->dobj, *regval = ctx->dobj + D.batch;
     // Two launches: the regulariser kernel writes every knot's whole gradient row (zeros where no term applies) and the per-knot
@@ -2256,57 +2268,40 @@ extern "C" int pcl_eval_jac_merit_dev(pcl_ctx *ctx, const double *Z, const doubl
     HIP_TRY(ctx, hipGetLastError());
     return PCL_OK;
 }
-// pcl_objective_dev + pcl_eval_jac_merit_dev as TWO launches instead of four: the fused kernel, then ONE launch whose workgroups are the
-// regulariser rows, the terminal infidelities and the payload's finish (pcl_ens_tail_kernel); the same bits as the separate calls.
-extern "C" int pcl_eval_jac_merit_objective_dev(pcl_ctx *ctx, const double *Z, const double *lam, double *delta, double *vals, double *out, double Q,
-                                                double *value, double *grad) {
-    if (!ctx) return PCL_EINVAL;
-    if (!Z || !delta || !vals || !out || !value) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_merit_objective_dev: NULL pointer");
-    if (!ctx->dgoal) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_merit_objective_dev: no goal set");
-    TRY(objective_unitary_only(ctx, "pcl_eval_jac_merit_objective_dev"));
-    int skip_lo = 0, skip_hi = 0;
-    {  // The separate calls: without a gradient buffer; when the members' states are not ONE contiguous run of a gradient row (the
-       // regulariser workgroup of the last knot leaves that run to the infidelity workgroups of the same launch); with a regulariser on a
-       // state component (its terminal-knot term and the infidelity's would meet in one entry: the launches have to stay in order).
-        const int nx = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? 1 : ctx->desc.batch;
-        long long lo = ctx->x_offs[0], hi = ctx->x_offs[0] + ctx->x_dim;
-        for (int b = 1; b < nx; ++b) {
-            lo = std::min<long long>(lo, ctx->x_offs[b]);
-            hi = std::max<long long>(hi, ctx->x_offs[b] + ctx->x_dim);
-        }
-        bool separate = grad == nullptr || hi - lo != (long long)nx * ctx->x_dim;  // (equal extents: distinct offsets tile the run exactly)
-        for (int b = 0; b < nx && !separate; ++b)
-            for (int b2 = 0; b2 < b; ++b2) separate = separate || ctx->x_offs[b] == ctx->x_offs[b2];
-        for (const PclReg &r : ctx->regs) separate = separate || (r.off < hi && lo < r.off + r.dim);
-        ctx->last_step_launches = 4;
-        if (separate) {
-            TRY(pcl_objective_dev(ctx, Z, Q, value, grad));
-            return pcl_eval_jac_merit_dev(ctx, Z, lam, delta, vals, out);
-        }
-        skip_lo = (int)lo;
-        skip_hi = (int)hi;
+// The one-launch tail (pcl_ens_tail_kernel: regulariser rows + terminal infidelities [+ the payload's finish]) applies with a gradient
+// buffer, when the members' states are ONE contiguous run of a gradient row (the regulariser workgroup of the last knot leaves that run to
+// the infidelity workgroups of the same launch) that no regulariser covers (its terminal-knot term and the infidelity's would meet in one
+// entry: the launches then have to stay in order).  [lo, hi) = that run.
+static bool tail_applies(const pcl_ctx *ctx, const double *grad, int &lo_, int &hi_) {
+    if (!grad || !ctx->dgoal || ctx->opt_objective_launches == 2) return false;
+    const int nx = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? 1 : ctx->desc.batch;
+    long long lo = ctx->x_offs[0], hi = ctx->x_offs[0] + ctx->x_dim;
+    for (int b = 1; b < nx; ++b) {
+        lo = std::min<long long>(lo, ctx->x_offs[b]);
+        hi = std::max<long long>(hi, ctx->x_offs[b] + ctx->x_dim);
     }
-    ctx->merit_want = 1;
-    ctx->merit_fused = 0;
-    ctx->merit_lam = lam;
-    const int rc = launch_fused(ctx, Z, delta, vals, false);
-    ctx->merit_want = 0;
-    ctx->merit_lam = nullptr;
-    if (rc != PCL_OK) return rc;
-    if (!ctx->merit_fused) {  // other kernels / member windows: the separate calls
-        TRY(pcl_merit_grad_dev(ctx, delta, lam, vals, out));
-        return pcl_objective_dev(ctx, Z, Q, value, grad);
-    }
-    ON_DEVICE(ctx);
+    if (hi - lo != (long long)nx * ctx->x_dim) return false;  // (equal extents: distinct offsets tile the run exactly)
+    for (int b = 0; b < nx; ++b)
+        for (int b2 = 0; b2 < b; ++b2)
+            if (ctx->x_offs[b] == ctx->x_offs[b2]) return false;
+    for (const PclReg &r : ctx->regs)
+        if (r.off < hi && lo < r.off + r.dim) return false;
+    lo_ = (int)lo;
+    hi_ = (int)hi;
+    return true;
+}
+static int launch_tail(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad, int skip_lo, int skip_hi, double *merit_out) {
     const pcl_desc &D = ctx->desc;
     const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
     const int sets = traj ? D.batch : 1, nbuf = sets;
     const int m = D.n_drives;
     const long long zs = traj ? (long long)D.z_dim * D.N : 0LL;
-    if (!ctx->dphik) HIP_TRY(ctx, hipMalloc((void **)&ctx->dphik, ((size_t)D.batch * ctx->K * (m + 2) + (size_t)sets * ctx->K) * sizeof(double)));
-    if (!ctx->dmticket) {
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->dmticket, 64));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->dmticket, 0, 64, ctx->stream));
+    if (merit_out) {
+        if (!ctx->dphik) HIP_TRY(ctx, hipMalloc((void **)&ctx->dphik, ((size_t)D.batch * ctx->K * (m + 2) + (size_t)sets * ctx->K) * sizeof(double)));
+        if (!ctx->dmticket) {
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->dmticket, 64));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->dmticket, 0, 64, ctx->stream));
+        }
     }
     TRY(objective_prepare(ctx));  // (also re-zeroes both tickets after a switch of streams)
     PclTailArgs a;
@@ -2334,18 +2329,48 @@ extern "C" int pcl_eval_jac_merit_objective_dev(pcl_ctx *ctx, const double *Z, c
     a.fin = PclObjSum{value, ctx->dobj + D.batch, reinterpret_cast<unsigned int *>(ctx->dobj + D.batch + (size_t)nbuf * D.N), D.batch, D.N, traj ? 1 : 0,
                       D.batch + nbuf * D.N};
     a.pcol = ctx->dmcols;
-    a.out = out;
-    a.phik = ctx->dphik + (size_t)D.batch * ctx->K * (m + 2);
+    a.out = merit_out;
+    a.phik = merit_out ? ctx->dphik + (size_t)D.batch * ctx->K * (m + 2) : nullptr;
     a.mticket = ctx->dmticket;
-    a.K = ctx->K;
+    a.K = merit_out ? ctx->K : 0;
     a.cols = ctx->cols;
     a.m = m;
     a.traj_mode = traj ? 1 : 0;
     a.skip_lo = skip_lo;
     a.skip_hi = skip_hi;
-    const size_t lds = std::max((size_t)infidelity_lds(ctx), (size_t)D.batch * (m + 2) * sizeof(double));
-    hipLaunchKernelGGL(pcl_ens_tail_kernel, dim3((unsigned)(nbuf * D.N + D.batch + ctx->K)), dim3(256), lds, ctx->stream, a);
+    const size_t lds = std::max((size_t)infidelity_lds(ctx), merit_out ? (size_t)D.batch * (m + 2) * sizeof(double) : (size_t)0);
+    hipLaunchKernelGGL(pcl_ens_tail_kernel, dim3((unsigned)(nbuf * D.N + D.batch + a.K)), dim3(256), lds, ctx->stream, a);
     HIP_TRY(ctx, hipGetLastError());
+    return PCL_OK;
+}
+// pcl_objective_dev + pcl_eval_jac_merit_dev as TWO launches instead of four: the fused kernel, then ONE launch whose workgroups are the
+// regulariser rows, the terminal infidelities and the payload's finish (pcl_ens_tail_kernel); the same bits as the separate calls.
+extern "C" int pcl_eval_jac_merit_objective_dev(pcl_ctx *ctx, const double *Z, const double *lam, double *delta, double *vals, double *out, double Q,
+                                                double *value, double *grad) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !delta || !vals || !out || !value) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_merit_objective_dev: NULL pointer");
+    if (!ctx->dgoal) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_merit_objective_dev: no goal set");
+    TRY(objective_unitary_only(ctx, "pcl_eval_jac_merit_objective_dev"));
+    int skip_lo = 0, skip_hi = 0;
+    ctx->last_step_launches = 4;
+    if (!tail_applies(ctx, grad, skip_lo, skip_hi)) {
+        TRY(pcl_objective_dev(ctx, Z, Q, value, grad));
+        ctx->last_step_launches = 2 + ctx->last_objective_launches;
+        return pcl_eval_jac_merit_dev(ctx, Z, lam, delta, vals, out);
+    }
+    ctx->merit_want = 1;
+    ctx->merit_fused = 0;
+    ctx->merit_lam = lam;
+    const int rc = launch_fused(ctx, Z, delta, vals, false);
+    ctx->merit_want = 0;
+    ctx->merit_lam = nullptr;
+    if (rc != PCL_OK) return rc;
+    if (!ctx->merit_fused) {  // other kernels / member windows: the separate calls
+        TRY(pcl_merit_grad_dev(ctx, delta, lam, vals, out));
+        return pcl_objective_dev(ctx, Z, Q, value, grad);
+    }
+    ON_DEVICE(ctx);
+    TRY(launch_tail(ctx, Z, Q, value, grad, skip_lo, skip_hi, out));
     ctx->last_step_launches = 2;
     return PCL_OK;
 }
@@ -2488,7 +2513,10 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_stream_wg = v;
     else if (!strcmp(key, "contiguous"))  // kernel 3: 1 = equal contiguous column ranges per workgroup (default), 0 = round-robin slices
         ctx->opt_contig = v < 0 ? -1 : (v != 0);
-    else if (!strcmp(key, "v4_flags"))  // kernel 4 A/B switches: 1 no raised priority for the P wave | 2 tails only behind the item's last block
+    else if (!strcmp(key, "objective_launches")) {  // 0 auto (one launch where it applies) | 2 always regulariser + infidelity launches
+        if (v != 0 && v != 2) return fail(ctx, PCL_EINVAL, "objective_launches must be 0 or 2");
+        ctx->opt_objective_launches = v;
+    } else if (!strcmp(key, "v4_flags"))  // kernel 4 A/B switches: 1 no raised priority for the P wave | 2 tails only behind the item's last block
                                        // | 4 no cooperative first item | 8 LDS tiles NaN at kernel start (tests) | 16 the first item's chains do not wait for the cooperative products | 32 no balanced split of the middle column's two blocks between two slices
         ctx->opt_v4_flags = v;
     else if (!strcmp(key, "v4_power_tiles"))  // kernel 4: LDS tiles the powers of G rotate through (0 auto: q - 1 for launches of several items per workgroup, else q)
@@ -2565,6 +2593,10 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->last_hess_split;
     else if (!strcmp(key, "last_eval_coop"))
         *v = ctx->last_eval_coop;
+    else if (!strcmp(key, "last_objective_launches"))
+        *v = ctx->last_objective_launches;
+    else if (!strcmp(key, "objective_launches"))
+        *v = ctx->opt_objective_launches;
     else if (!strcmp(key, "last_step_launches"))  // pcl_eval_jac_merit_objective_dev: 2 = fused kernel + one tail launch, 4 = the separate calls
         *v = ctx->last_step_launches;
     else if (!strcmp(key, "last_merit_fused"))

@@ -1585,10 +1585,17 @@ def test_ensemble_step_in_two_launches_equals_the_separate_calls(M, N):
                 J = J + pa.QuadraticRegularizer(extra, traj, 1e-3, 0)
             J.bind(Bs)
             ref = [torch.full((k,), float("nan"), dtype=torch.float64, device="cuda") for k in (1, c.z_len, c.n_rows, c.jac_nnz, ln)]
+            c.set_option("objective_launches", 2)  # the reference: regulariser launch, infidelity launch, fused kernel, payload finish
             J.value_and_gradient_dev(Zd, ref[0], ref[1])
             c.eval_jac_merit_dev(Zd, lam_d, ref[2], ref[3], ref[4])
             torch.cuda.synchronize()
-            assert c.get_option("last_merit_fused") == 1
+            assert c.get_option("last_merit_fused") == 1 and c.get_option("last_objective_launches") == 2
+            c.set_option("objective_launches", 0)
+            one = [torch.full_like(ref[0], float("nan")), torch.full_like(ref[1], float("nan"))]  # the objective alone: ONE launch where it applies
+            J.value_and_gradient_dev(Zd, one[0], one[1])
+            torch.cuda.synchronize()
+            assert c.get_option("last_objective_launches") == (1 if extra is None else 2)
+            assert torch.equal(one[0], ref[0]) and torch.equal(one[1], ref[1])
             for rep in range(3):
                 out = [torch.full_like(r, float("nan")) for r in ref]
                 J.step_dev(Zd, out[0], out[1], out[2], out[3], out[4], lam_dev=lam_d)
@@ -1612,9 +1619,15 @@ def test_ensemble_step_in_two_launches_equals_the_separate_calls(M, N):
         ln, sets = c.merit_grad_len()
         assert sets == S
         ref = [torch.full((k,), float("nan"), dtype=torch.float64, device="cuda") for k in (S, c.z_len, c.n_rows, c.jac_nnz, ln * S)]
+        c.set_option("objective_launches", 2)
         J.value_and_gradient_dev(Zd, ref[0], ref[1])
         c.eval_jac_merit_dev(Zd, None, ref[2], ref[3], ref[4])
         torch.cuda.synchronize()
+        c.set_option("objective_launches", 0)
+        one = [torch.full_like(ref[0], float("nan")), torch.full_like(ref[1], float("nan"))]
+        J.value_and_gradient_dev(Zd, one[0], one[1])
+        torch.cuda.synchronize()
+        assert c.get_option("last_objective_launches") == 1 and torch.equal(one[0], ref[0]) and torch.equal(one[1], ref[1])
         for rep in range(2):
             out = [torch.full_like(r, float("nan")) for r in ref]
             J.step_dev(Zd, out[0], out[1], out[2], out[3], out[4])
