@@ -482,14 +482,20 @@ def main():
                 "intervals, gcc -O3 -march=x86-64-v3), outputs preallocated, best of thread counts up to %d available cores"
                 % (n, N, el, avail),
             }
+    if dist is not None:  # (before the line: whatever the teardown prints must not come after it)
+        dist.destroy_process_group()
     if saved_stdout is not None:
         sys.stdout.flush()
+        try:  # librccl's banner sits in the C library's buffered stdout: out now, while fd 1 still points at stderr -- flushed at exit it
+            import ctypes  # would land on the real stdout BEHIND the JSON line
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
