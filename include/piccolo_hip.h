@@ -294,7 +294,7 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *       "jit"                1 (default): kernels generated or specialised per context are compiled on first use with hiprtc (the
  *                            pattern-compiled kernels; Hessian kernel 2 for d >= 12; fused kernel 3 when kernel_version = 3);
  *                            0: built-in instances only
- *       "use_mfma" (1/0: plain-VALU products in kernel 1), "nt_stores" (streaming stores of the Jacobian blocks: -1 auto by launch size | 0 plain | 1 nontemporal | 2 write-through), "specialize" (1/0: shape-specialised
+ *       "use_mfma" (1/0: plain-VALU products in kernel 1), "nt_stores" (streaming stores of the Jacobian blocks: -1 auto by launch size and order | 0 plain | 1 nontemporal | 2 write-through | 3 kernel 4: write-through on every other XCD's workgroups, plain on the others), "specialize" (1/0: shape-specialised
  *       instances), "grid" (workgroups, 0 = one per CU), "host_threads" (host-pointer entry points: threads that expand the
  *       compact values into the caller's array, 0 = auto), "host_path" (0 auto | 1 full values over PCIe | 2 compact + host expansion),
  *       "debug_timing", "profile_flags", "v4_variant" (PCL_ENOTIMPL / unknown unless the library was built with -DPCL_PROFILE)

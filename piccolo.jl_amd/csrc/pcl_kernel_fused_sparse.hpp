@@ -633,6 +633,11 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                     half_col = p.nc - 1;
                     if (c0 > 0) cbeg = half_col;
                 }
+                // nt 3: write-through on every other workgroup = every other XCD (workgroups are dispatched round-robin over the XCDs).  Plain stores
+                // leave up to 32 MB dirty in the L2s, written back behind the kernel's end (2 us of the gap between two launches); write-through
+                // everywhere makes the kernel itself 0.9 us longer.  Half of the XCDs each way: one trajectory 25.9 -> 25.3 us at order 4
+                // (contiguous halves of the XCDs, a quarter or all of them: 25.7).  A performance hint only: any placement gives the same values.
+                const int nt_b = p.nt == 3 ? ((bx & 1) ? 2 : 0) : p.nt;
                 double *o = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn + pi;
                 for (int cq = cbeg; cq < cend; ++cq, o += nn) {
 #ifdef PCL_PROFILE
@@ -646,8 +651,8 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                         for (int r = 0; r < NSP; ++r) {
                             const int j = pj0 + pstep * r;
                             if (j < n) {
-                                if (sp_) store2(o + n * j, bpr[r][0], bpr[r][1], p.nt);
-                                if (sm_) store2(o + blk + n * j, bmr[r][0], bmr[r][1], p.nt);
+                                if (sp_) store2(o + n * j, bpr[r][0], bpr[r][1], nt_b);
+                                if (sm_) store2(o + blk + n * j, bmr[r][0], bmr[r][1], nt_b);
                             }
                         }
                     }

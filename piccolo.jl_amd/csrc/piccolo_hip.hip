@@ -1191,8 +1191,10 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     p.tail_mode = (int)ctx->opt_v4_tail_mode;
     p.v4_flags = (int)ctx->opt_v4_flags;
     // write-through block stores (auto, launches that fit the infinity cache) pay at orders 8 and 10 only: one trajectory, plain against
-    // write-through: 24.9 / 25.4 us at order 2, 27.2 / 27.6 at 4, 28.1 / 28.9 at 6, 32.4 / 31.9 at 8
-    if (ctx->opt_nt < 0 && p.q < 4) p.nt = 0;
+    // write-through: 24.9 / 25.4 us at order 2, 27.2 / 27.6 at 4, 28.1 / 28.9 at 6, 32.4 / 31.9 at 8.  Orders 2 and 4: write-through on every
+    // other XCD's workgroups (nt 3, see the kernel) -- plain / write-through / mixed 23.3 / 23.7 / 22.7 us at order 2, 26.1 / 25.6 / 25.5 at 4,
+    // 26.2 / 27.2 / 26.5 at 6 (plain stays)
+    if (ctx->opt_nt < 0 && p.q < 4) p.nt = (p.nt == 2 && p.q <= 2) ? 3 : 0;
     const long long units = p.contig ? bk * d : bk * p.S;
     if (units > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
     const long long g = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, units) : std::min<long long>(units, ncu);
@@ -1270,6 +1272,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         if (rc != PCL_ENOTIMPL) return rc;
         if (ctx->opt_kernel == 4) return fail(ctx, PCL_ESHAPE, "kernel_version=4 needs sparse exact-iso generators of a unitary problem (9 <= d, tiles within LDS), 1..6 drives and jit=1 (%s)", g_jit_note.c_str());
     }
+    if (p.nt == 3) p.nt = 2;  // (the mixed mode is kernel 4's)
     // residual only on the same products (eval_kernel 3; auto: every order -- measured against the other residual kernels)
     if (!want_jac && (ctx->opt_eval_kernel == 3 || (ctx->opt_eval_kernel == 0 && ctx->opt_kernel == 0 && !ctx->opt_general && ctx->opt_general_version == 0))) {
         const int rc = launch_eval_v4(ctx, p);
@@ -2478,7 +2481,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
     } else if (!strcmp(key, "use_mfma"))
         ctx->opt_use_mfma = v != 0;
     else if (!strcmp(key, "nt_stores")) {  // -1 auto (by launch size) | 0 plain | 1 nontemporal | 2 write-through
-        if (v < -1 || v > 2) return fail(ctx, PCL_EINVAL, "nt_stores must be -1, 0, 1 or 2");
+        if (v < -1 || v > 3) return fail(ctx, PCL_EINVAL, "nt_stores must be -1, 0, 1, 2 or 3");
         ctx->opt_nt = v;
     }
     else if (!strcmp(key, "grid"))
