@@ -17,7 +17,8 @@
 //     wave 4 + m        writer: the reduce payload's dot products per state column (pcl_eval_jac_merit_dev); delta and the tail block of a
 //                       finished item only in tail modes 0-2 (default: the stream waves store them behind the item's blocks)
 //     wave 5 + m .. +3  stream: fold every power into the item's -B^+ / B^- values in registers as it appears, then only issue the
-//                       replicated 16-byte stores; the FIRST item's powers are built by these four waves themselves, in row ranges
+//                       replicated 16-byte stores
+//     (the FIRST item's powers are built by waves 0 .. 3 together, in four row ranges, before they take up the roles above)
 // No workgroup barrier after the start: point-to-point monotonic LDS counters (dependencies only point backwards; bounded waits).
 // Work items as in kernel 3: contiguous column ranges per workgroup (pieces of one interval), or round-robin slices.
 #pragma once
@@ -138,8 +139,6 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     __syncthreads();  // the only workgroup barrier
 #ifdef PCL_PROFILE
     if (p.prof & 128) SP4_STAMP();
-#endif
-#ifdef PCL_PROFILE
     if (wall_ && tid == 0) wall_[1] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
 
@@ -192,10 +191,10 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
         SP4_SET_CF(cf, u, mg);                                                                                    \
         tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));                          \
     }
-    // Cooperative first item: the store-stream waves build the powers of G of the workgroup's FIRST item themselves, a quarter of the
-    // output rows each (sp4_product0_part: nothing to store before the powers exist; a lone P wave takes 7.7 k cycles for G, G^2 at
-    // order 4 -- a fifth of a one-trajectory launch).  Needs every power of the item in its own tile (folded afterwards: the products'
-    // registers and the block registers never live side by side) and fully resident coefficients.  The P wave starts with item 1.
+    // Cooperative first item: the powers of G of the workgroup's FIRST item are built by four waves together, a quarter of the output rows
+    // each (sp4_product0_part: nobody can store before the powers exist; a lone P wave takes 7.7 k cycles for G, G^2 at order 4 -- a
+    // fifth of a one-trajectory launch).  Needs fully resident coefficients (the generator then emits the parts).  The P wave's own loop
+    // starts with item 1.
     const bool coop = SP4_COOP && !(p.v4_flags & 4);
     // ... and the chains of that item start behind them: twelve waves of products on four SIMDs ran the stream's parts three times
     // slower (4.1 k cycles instead of 1.3 k), and the chains have the whole store phase to finish in
