@@ -953,6 +953,44 @@ def test_pattern_compiled_fused_kernel_soak():
         c.close()
 
 
+def test_pattern_compiled_fused_kernel_store_modes_and_first_item():
+    """Kernel 4: the store modes of the block stream (plain, write-through, write-through on every other XCD's workgroups -- `auto` at
+    orders 2 and 4 for launches that fit the infinity cache) and the two ways the first item's powers of G come about (built by waves
+    0-3 together while the stream waves fold them, or by the P wave alone) are performance choices: the same bits, at the orders where
+    the ring of power tiles is as long as q (2, 4, 6), shorter (8) and where `auto` leaves the cooperative start off (10); one
+    trajectory per launch and three."""
+    import torch
+
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    for Bn in (1, 3):
+        Zs = [po.synthetic_trajectory(so, 100, seed=700 + s)[0] for s in range(Bn)]
+        lay = po.synthetic_trajectory(so, 100, seed=700)[1]
+        for order in (2, 4, 6, 8, 10):
+            c = make_ctx(lay, G0, Gj, batch=Bn, batch_mode=pa._lib.PCL_BATCH_TRAJ, pade_order=order)
+            c.set_stream(torch.cuda.current_stream().cuda_stream)
+            Zd = torch.from_numpy(np.stack(Zs)).cuda()
+            dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
+            out = torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")
+            ref = None
+            for nt, flags in ((-1, 0), (0, 0), (2, 0), (3, 0), (-1, 4), (3, 4)):
+                c.set_option("nt_stores", nt)
+                c.set_option("v4_flags", flags)
+                dd.fill_(float("nan")), out.fill_(float("nan"))
+                c.eval_jac_dev(Zd, dd, out)
+                torch.cuda.synchronize()
+                assert c.get_option("last_kernel") == 40 + order // 2
+                if ref is None:
+                    ref = (dd.clone(), out.clone())
+                    assert bool(torch.isfinite(ref[0]).all()) and bool(torch.isfinite(ref[1]).all())
+                    if Bn == 1 and order == 4:  # ... and against the C oracle once
+                        d_ref, j_ref = ref_lib.eval_jac(Zs[0], lay, G0, Gj)
+                        close(ref[0].cpu().numpy(), np.asarray(d_ref).reshape(-1))
+                        close(ref[1].cpu().numpy(), np.asarray(j_ref).reshape(-1))
+                assert torch.equal(dd, ref[0]) and torch.equal(out, ref[1]), (Bn, order, nt, flags)
+            c.close()
+
+
 def test_pattern_compiled_fused_kernel_ensemble_and_shapes():
     """Kernel 4 on per-member drifts (BASELINE config 4's members: 27 drift value classes, the less used ones streamed through the
     chunk registers), on a member window, on TRAJ batches, and on other sparse shapes (two 5-level transmons, d = 25, m = 4)."""
