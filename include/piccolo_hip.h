@@ -248,10 +248,14 @@ int pcl_reduce_sum(pcl_ctx *ctx, double *buf_host, int64_t n); /* same for a hos
 int pcl_comm_destroy(pcl_ctx *ctx);
 
 /* tuning / introspection ----------------------------------------------------
- * Defaults are what the benchmark runs; the other settings exist for A/B measurements and for the parity tests (every
- * setting produces the same results up to the order of additions inside a kernel family; within a family every work split is
- * bitwise equal).  Experiments of earlier rounds (stream pieces, per-XCD roles, split producer / expander kernels, the
- * column kernel, the two-step general-order path, ablation switches) are not part of the library any more.
+ * A DEPLOYMENT sets none of these, or only:  "jit" (0 where hiprtc must not run), "host_threads" / "host_path" (host-pointer entry
+ * points), "index_base" and "pade_order" (in pcl_desc).  Everything else below is a MEASUREMENT / TEST switch: the defaults are
+ * what the benchmark runs, every setting produces the same results up to the order of additions inside a kernel family, and within
+ * a family every work split is bitwise equal -- which is what the parity tests use them for.  The kernels behind "kernel_version"
+ * 1 / 2, "hess_kernel" 1 - 3 and the general-order kernels are not experiments: they serve the shapes the pattern-compiled kernels do
+ * not take (dense or non-iso generators, d < 9, more than 6 drives, kets and compact densities).
+ * Experiments of earlier rounds (stream pieces, per-XCD roles, split producer / expander kernels, the column kernel, the two-step
+ * general-order path, ablation switches) are not part of the library any more.
  * set:  "kernel_version"     residual + Jacobian: 0 auto | 1 one workgroup per item | 2 persistent, two workgroups per CU | 3 persistent,
  *                            one workgroup per CU with stream / matrix roles on the matrix cores (order 4; on request only) | 4 the
  *                            PATTERN-COMPILED fused kernel, any Pade order: source generated from the sparsity pattern of the
