@@ -120,12 +120,24 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             k = (int)(bk % p.K);
             b = (int)(bk / p.K);
         } else {
+            // (no division where the split has none to make -- one trajectory in two slices per interval is the launch whose start-up counts:
+            //  three integer divisions of cold code were 0.5 k cycles ahead of every role's first loads)
             const int item = bx + it * (int)gridDim.x;
-            const int s = item % p.S;
+            int s, ik;
+            if (p.S == 2) {
+                s = item & 1;
+                ik = item >> 1;
+            } else if (p.S == 1) {
+                s = 0;
+                ik = item;
+            } else {
+                ik = item / p.S;
+                s = item - ik * p.S;
+            }
             c0 = s * p.nc;
             nce = min(p.nc, d - c0);
-            k = (item / p.S) % p.K;
-            b = item / (p.S * p.K);
+            b = p.batch == 1 ? 0 : ik / p.K;
+            k = ik - b * p.K;
         }
     };
     // Counters zero.  The tiles start as whatever the previous workgroup left: every entry a wave reads has been written by the item
