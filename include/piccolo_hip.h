@@ -74,7 +74,9 @@ typedef enum pcl_status {
     PCL_EHIP = -3,    /* HIP runtime error (incl. "no GPU") */
     PCL_ERCCL = -4,   /* RCCL error */
     PCL_ESHAPE = -5,  /* shape outside what the kernels support (d > PCL_MAX_D, ...) */
-    PCL_ENOTIMPL = -6 /* valid request the library does not implement (e.g. an odd pade_order) */
+    PCL_ENOTIMPL = -6, /* valid request the library does not implement (e.g. an odd pade_order) */
+    PCL_EINTERNAL = -7 /* a kernel of this context reported a failure on the device (a bounded wait between its waves gave up): the
+                          outputs of that launch are incomplete; returned by the next evaluator entry point or pcl_sync, then cleared */
 } pcl_status;
 
 #define PCL_MAX_D 32 /* n = 2d <= 64: G(u_k), G^2 and the column tiles stay LDS-resident */

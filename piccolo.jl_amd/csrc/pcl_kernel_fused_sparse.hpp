@@ -20,7 +20,17 @@
 //                       replicated 16-byte stores
 //     (the FIRST item's powers are built by waves 0 .. 3 together, in four row ranges, before they take up the roles above)
 // No workgroup barrier after the start: point-to-point monotonic LDS counters (dependencies only point backwards; bounded waits).
-// Work items as in kernel 3: contiguous column ranges per workgroup (pieces of one interval), or round-robin slices.
+// Work items as in kernel 3: contiguous column ranges per workgroup (pieces of one interval), or round-robin slices -- or, for launches
+// of several trajectories, TICKETS (p.tick): every interval is ceil(d / tick_cpi) block tickets of tick_cpi state columns (the replicated
+// -B^+ / B^- blocks, through the P and stream waves) and one chain ticket (the whole interval's delta, d/du_l, d/dh and the reduce payload,
+// through the loader, W, V, dW_l and writer waves), each kind taken in order from its own device-wide counter by whichever workgroup's
+// pipeline of that kind is free (the P wave takes block tickets, the loader wave chain tickets).  The two pipelines of a workgroup share
+// nothing.  (One counter for both kinds, chain tickets queued behind the P wave: a workgroup's chains are 15-30 us per interval, its
+// queue filled while it kept taking block tickets -- 292 us per 8 trajectories, the last workgroup 80 us behind the median.)
+// Measured with the bare store pattern
+// (scripts/probes/wfront.hip, 8 trajectories, 8 separately allocated buffers): equal contiguous ranges 196.6 us median (163.7 ... 209.3 by
+// where the buffer's pages live), static round-robin 3-column items 229, tickets of 3 columns 173-177 on every buffer -- the write front stays
+// a few tens of MB wide and the workgroups of the XCDs the memory side serves first simply take more tickets.
 #pragma once
 
 #define SP4CS (SPN + 1)           // odd column stride: the lanes of a half wave, one column each, hit distinct banks
@@ -32,13 +42,13 @@
 #define SP4_NWAVES (SPM + 9)
 #define SP4_NOUT (SPM + 2)        // output chains: W (delta), V (d/dh), dW_l (d/du_l)
 #define SP4_NTILES (SPM + 4 + SP4NP)  // D, S, W, V, dW[m], P[SP4NP]
-#define SP4_SYNC_WORDS 32
+#define SP4_SYNC_WORDS 48        // 32 counters + the two ticket rings (4 block items with their steps, 4 chain items)
 // monotonic counters: IN items whose D, S are in LDS | DW, DV items whose D, S the W / V wave has finished with | W levels of W
 // published | B powers published (all items) | C + w powers folded by stream wave w | OC items the writer has taken out of the tiles |
 // G + l levels of W the drive wave l has gathered | O + w items whose output chain w is complete
 // (one word per arriver wherever arrivers can run ahead of each other: a shared arrival count lies -- a fast wave's extra arrival
 //  stands in for a slow wave's missing one)
-enum { SP4_F_IN = 0, SP4_F_DW, SP4_F_DV, SP4_F_W, SP4_F_B, SP4_F_OC, SP4_F_CO /* cooperative first item: parts of powers done */, SP4_F_CX /* ... operands read (one-tile ring) */, SP4_F_G = 8, SP4_F_O = 16, SP4_F_C = 24 /* per stream wave */, SP4_F_TS = 28 /* per stream wave: items whose tails it has stored */ };
+enum { SP4_F_IN = 0, SP4_F_DW, SP4_F_DV, SP4_F_W, SP4_F_B, SP4_F_OC, SP4_F_CO /* cooperative first item: parts of powers done */, SP4_F_CX /* ... operands read (one-tile ring) */, SP4_F_G = 8, SP4_F_BI = 14 /* ticket mode: block items published */, SP4_F_CI = 15 /* ... chain items published */, SP4_F_O = 16, SP4_F_C = 24 /* per stream wave */, SP4_F_TS = 28 /* per stream wave: items whose tails it has stored */ };
 
 static __device__ __forceinline__ bool sp4_wait(int *sync, int word, int target, bool gave_up = false) {
     // Bounded: a logic error must not hang the device (the caller poisons the output instead; once a wave has given up it
@@ -140,6 +150,60 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             k = ik - b * p.K;
         }
     };
+    // ---- ticket mode: the P wave takes the tickets and publishes them through two 4-entry rings in LDS (block items with their step h;
+    //      chain items, taken by the loader wave: the interval's index); every other wave reads its pipeline's ring.  Block ticket t:
+    //      interval t / ipi, columns [s cpi, s cpi + cpi) with s = t mod ipi.  A negative entry ends the pipeline.
+    const bool tick = p.tick != nullptr;
+    int *bdesc = sync + 32, *cdesc = sync + 36;
+    double *bdesc_h = (double *)(sync + 40);
+    const int t_ipi = tick ? (d + p.tick_cpi - 1) / p.tick_cpi : 1;
+    auto decode_ticket = [&](int t, int &c0, int &nce, int &k, int &b) {
+        const int iv = t / t_ipi, sub = t - iv * t_ipi;
+        b = p.batch == 1 ? 0 : iv / p.K;
+        k = iv - b * p.K;
+        c0 = sub * p.tick_cpi;
+        nce = min(p.tick_cpi, d - c0);
+    };
+    // a pipeline's last ticket has come back: the last of the 2 gridDim.x pipelines to leave re-zeroes the ticket words for the next launch
+    auto ticket_leave = [&](unsigned n) {
+        if (lane == 0) {
+            const unsigned gone = __hip_atomic_fetch_add(p.tick + 1, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gone + n == 2u * gridDim.x) {
+                __hip_atomic_store(p.tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.tick + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.tick + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    bool gave_up = false;
+    // item `it` of this workgroup's block pipeline (P, stream waves) / chain pipeline (W, V, dW_l, loader, writer): false = no more
+    auto block_item = [&](int it, int &c0, int &nce, int &k, int &b) -> bool {
+        if (!tick) {
+            if (it >= n_my) return false;
+            decode(it, c0, nce, k, b);
+            return true;
+        }
+        gave_up = sp4_wait(sync, SP4_F_BI, it + 1, gave_up);
+        const int t = __builtin_amdgcn_readfirstlane(__hip_atomic_load(bdesc + (it & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (t < 0 || gave_up) return false;
+        decode_ticket(t, c0, nce, k, b);
+        return true;
+    };
+    auto chain_item = [&](int it, int &c0, int &nce, int &k, int &b) -> bool {
+        if (!tick) {
+            if (it >= n_my) return false;
+            decode(it, c0, nce, k, b);
+            return true;
+        }
+        gave_up = sp4_wait(sync, SP4_F_CI, it + 1, gave_up);
+        const int iv = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cdesc + (it & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (iv < 0 || gave_up) return false;
+        b = p.batch == 1 ? 0 : iv / p.K;
+        k = iv - b * p.K;
+        c0 = 0;
+        nce = d;
+        return true;
+    };
     // Counters zero.  The tiles start as whatever the previous workgroup left: every entry a wave reads has been written by the item
     // that reads it (zeroing 150 KB took 0.84 us of a 24 us workgroup life).  v4_flags & 8 (tests): NaN everywhere first.
     if (p.v4_flags & 8)
@@ -154,7 +218,6 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     if (wall_ && tid == 0) wall_[1] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
 
-    bool gave_up = false;
     // delta and the tail block of a finished item, tiles -> memory: the item's nce n residuals and its nce (m + 1) n tail values
     // are ONE contiguous run each, 1 KiB per instruction; `part` of `nparts` waves takes every nparts-th instruction.
     // tail_mode: 0 the writer wave, plain stores | 1 nontemporal | 2 write-through | 3 the stream waves, behind the item's blocks
@@ -178,7 +241,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             store2(dst + 2 * e2, src[0], src[1], nt);
         }
     };
-    const bool tails_by_stream = p.tail_mode == 3;
+    const bool tails_by_stream = p.tail_mode == 3 && !tick;  // (ticket mode: the writer wave -- the item whose tails are ready is not the stream's)
     // the chains may rewrite their tiles once item it - 1 has left them
     auto outputs_taken = [&](int it) {
         if (!tails_by_stream || p.mpart) gave_up = sp4_wait(sync, SP4_F_OC, it, gave_up);
@@ -207,7 +270,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     // each (sp4_product0_part: nobody can store before the powers exist; a lone P wave takes 7.7 k cycles for G, G^2 at order 4 -- a
     // fifth of a one-trajectory launch).  Needs fully resident coefficients (the generator then emits the parts).  The P wave's own loop
     // starts with item 1.
-    const bool coop = SP4_COOP && !(p.v4_flags & 4);
+    const bool coop = SP4_COOP && !(p.v4_flags & 4) && !tick;
     // ... and the chains of that item start behind them: twelve waves of products on four SIMDs ran the stream's parts three times
     // slower (4.1 k cycles instead of 1.3 k), and the chains have the whole store phase to finish in
     auto chains_may_start = [&](int it) {
@@ -295,17 +358,60 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
         if (wave == 0) {
             // ---- P: powers of G(u_k), one tile of the ring per power -----------------------------------------------------------
             if (!(p.v4_flags & 1)) __builtin_amdgcn_s_setprio(2);  // the stream waits for this chain
-            for (int it = coop ? 1 : 0; it < n_my; ++it) {
-                int c0, nce, k, b;
-                decode(it, c0, nce, k, b);
+            // ticket mode: this wave takes the block tickets, one requested ahead of the one it works on (the atomic's round trip, 1-3 us under
+            // the store stream, hides behind an item's products)
+            const int n_tick = tick ? p.batch * p.K * t_ipi : 0;
+            unsigned tk_next = 0;
+            if (tick && lane == 0) tk_next = __hip_atomic_fetch_add(p.tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int it = coop ? 1 : 0;
+            for (;; ++it) {
+                int c0, nce, k, b, tcur = -1;
+                if (!tick) {
+                    if (it >= n_my) break;
+                    decode(it, c0, nce, k, b);
+                } else {
+                    tcur = (int)__builtin_amdgcn_readfirstlane(tk_next);
+                    SP4_STAMP();
+                    if (tcur >= n_tick || tcur < 0 || gave_up) break;
+                    if (lane == 0) tk_next = __hip_atomic_fetch_add(p.tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    decode_ticket(tcur, c0, nce, k, b);
+                }
                 SP4_LANEPOS();
                 const bool act = c < d;
                 double h;
                 sp4_cf cf;
                 sp_cptr tab;
                 SP4_STAMP();
+#ifdef PCL_PROFILE
+                if (p.prof & 512) {  // experiment (results WRONG): the P wave loads nothing and builds nothing -- tickets and block stores alone
+                    if (lane == 0) {
+                        bdesc[it & 3] = tcur;
+                        bdesc_h[it & 3] = 0.1;
+                    }
+                    wave_lds_sync();
+                    sp4_post(sync + SP4_F_BI, it + 1, lane);
+                    for (int j = 1; j <= q; ++j) {
+                        const int L = it * q + j - 1;
+                        for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_C + w, L - npw + 1, gave_up);
+                        sp4_post(sync + SP4_F_B, L + 1, lane);
+                    }
+                    continue;
+                }
+                if (p.prof & 1024) {  // experiment (results WRONG): the item's controls and step are those of interval 0 (cached: no load latency)
+                    k = 0;
+                    b = 0;
+                }
+#endif
                 scalars(k, b, h, cf, tab);
                 SP4_STAMP();
+                if (tick) {  // (the stream waves are inside item it - 2 at the earliest: the slot of item it - 4 is free)
+                    if (lane == 0) {
+                        bdesc[it & 3] = tcur;
+                        bdesc_h[it & 3] = h;
+                    }
+                    wave_lds_sync();
+                    sp4_post(sync + SP4_F_BI, it + 1, lane);
+                }
                 const double bs = half ? -1.0 : 1.0;
                 {  // P_1 = G I: the unit vectors never touch LDS
                     const int L = it * q;
@@ -344,13 +450,19 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                     SP4_STAMP();
                 }
             }
+            if (tick) {  // the block pipeline ends
+                if (lane == 0) bdesc[it & 3] = -1;
+                wave_lds_sync();
+                sp4_post(sync + SP4_F_BI, it + 1, lane);
+                ticket_leave(no_chains ? 2u : 1u);
+            }
         } else if (wave <= 2) {
             // ---- W (delta) and V (d delta / dh) --------------------------------------------------------------------------------
             const bool isW = wave == 1;
             double *Xt = isW ? Wt : Vt;
-            for (int it = 0; it < n_my && !no_chains; ++it) {
+            for (int it = 0; !no_chains; ++it) {
                 int c0, nce, k, b;
-                decode(it, c0, nce, k, b);
+                if (!chain_item(it, c0, nce, k, b)) break;
                 SP4_LANEPOS();
                 const unsigned oX = sp4_lds_off(Xt + own), oXx = sp4_lds_off(Xt + oth);
                 const unsigned oD = sp4_lds_off(Dt + own), oS = sp4_lds_off(St + own);
@@ -403,9 +515,9 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             // ---- dW_l (d delta / du_l) ----------------------------------------------------------------------------------------
             const int l = wave - 3;
             double *Xt = dWt + l * SP4TILE;
-            for (int it = 0; it < n_my && !no_chains; ++it) {
+            for (int it = 0; !no_chains; ++it) {
                 int c0, nce, k, b;
-                decode(it, c0, nce, k, b);
+                if (!chain_item(it, c0, nce, k, b)) break;
                 SP4_LANEPOS();
                 SP4_STAMP();
                 const unsigned oX = sp4_lds_off(Xt + own), oXx = sp4_lds_off(Xt + oth);
@@ -449,9 +561,27 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
     } else if (wave == SP4_WLOAD) {
         // ================================== loader: D, S of every item (lane = row) ============================================
         constexpr int NB = 9;  // columns per batch of loads
-        for (int it = 0; it < n_my && !no_chains; ++it) {
+        for (int it = 0; !no_chains; ++it) {
             int c0, nce, k, b;
-            decode(it, c0, nce, k, b);
+            if (tick) {  // the chain pipeline's own ticket: an interval's chains go to a workgroup whose chain waves are free
+                unsigned tk = 0;
+                if (lane == 0) tk = __hip_atomic_fetch_add(p.tick + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int iv = (int)__builtin_amdgcn_readfirstlane(tk);
+                const bool end = iv >= p.batch * p.K || iv < 0 || gave_up;
+                // (the writer is inside item it - 2 at the earliest: the slot of item it - 4 is free)
+                if (lane == 0) cdesc[it & 3] = end ? -1 : iv;
+                wave_lds_sync();
+                sp4_post(sync + SP4_F_CI, it + 1, lane);
+                if (end) {
+                    ticket_leave(1u);
+                    break;
+                }
+                b = p.batch == 1 ? 0 : iv / p.K;
+                k = iv - b * p.K;
+                c0 = 0;
+                nce = d;
+            } else if (!chain_item(it, c0, nce, k, b))
+                break;
             SP4_STAMP();
             const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + (p.x_off0 >= 0 ? p.x_off0 : p.x_offs[p.z_batch_stride ? 0 : b]) + (long long)c0 * n + (lane < n ? lane : 0);
             const double *zn = zk + p.z_dim;
@@ -493,9 +623,9 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
         // (pcl_eval_jac_merit_dev): per state column <d delta/d u_l, lam>, <d delta/d h, lam>, <delta, lam> (lam = delta: half the
         // squared norm) while the vectors are still in their tiles -- the tails are never read back from memory.  Lane (half, c) adds
         // its half of column c in row order, then the two halves: bitwise repeatable and independent of the work split.
-        for (int it = 0; it < n_my && !no_chains && (!tails_by_stream || p.mpart); ++it) {
+        for (int it = 0; !no_chains && (!tails_by_stream || p.mpart); ++it) {
             int c0, nce, k, b;
-            decode(it, c0, nce, k, b);
+            if (!chain_item(it, c0, nce, k, b)) break;
             const long long bk = (long long)b * p.K + k;
             for (int w = 0; w < SP4_NOUT; ++w) gave_up = sp4_wait(sync, SP4_F_O + w, it + 1, gave_up);
             SP4_STAMP();
@@ -544,9 +674,9 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
 #ifdef PCL_PROFILE
         bool dry_ = (p.prof & 256) != 0;  // experiment (results WRONG): the first item twice, the first pass without stores -- the second pass shows the warm timings
 #endif
-        for (int it = 0; it < n_my; ++it) {
+        for (int it = 0;; ++it) {
             int c0, nce, k, b;
-            decode(it, c0, nce, k, b);
+            if (!block_item(it, c0, nce, k, b)) break;
             // (an opaque copy per item: derived from `tid` directly, the tile addresses below are hoisted out of the item loop
             //  and spilled)
             SP4_STAMP();
@@ -554,7 +684,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             asm volatile("" : "+v"(stid));  // (after the cooperative products: nothing derived from it lives beside their registers)
             const int pi = 2 * (stid % hn), pj0 = stid / hn;
             const bool pact = pj0 < pstep;
-            const double h = ((sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim))[p.dt_off];
+            const double h = tick ? bdesc_h[it & 3] : ((sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim))[p.dt_off];
             // -B^+ and B^- of this thread's positions, folded power by power as the P wave publishes them.  Entry (i, j) of the
             // n x n iso matrix [[A, -B], [B, A]] whose first d columns are a tile: j >= d mirrors into column j - d, rows i < d
             // from row i + d with the sign flipped, rows i >= d from row i - d.
@@ -640,7 +770,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 // last column stays there, its B^- block goes to the second slice -- 27 blocks each instead of 28 and 26: 0.2-0.35 us of a
                 // 28-32 us launch (v4_flags & 32 switches it off)
                 int half_col = -1;  // the column whose two blocks are shared between the interval's two slices
-                if (!(p.v4_flags & 32) && !p.contig && !p.compact && p.S == 2 && (d & 1)) {
+                if (!(p.v4_flags & 32) && !p.contig && !p.compact && !tick && p.S == 2 && (d & 1)) {
                     half_col = p.nc - 1;
                     if (c0 > 0) cbeg = half_col;
                 }
@@ -688,7 +818,10 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
 #endif
         }
     }
-    if (gave_up && lane == 0) p.jac[0] = __builtin_nan("");  // a wait gave up: visible in the values instead of a hung device
+    if (gave_up && lane == 0) {  // a wait gave up: the context's error word (the next entry point or pcl_sync returns PCL_EINTERNAL) ...
+        if (p.err) __hip_atomic_fetch_or(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        p.jac[0] = __builtin_nan("");  // ... and visible in the values instead of a hung device
+    }
 #ifdef PCL_PROFILE
     if (wall_ && lane == 0) atomicMax((unsigned long long *)(wall_ + 2), (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif

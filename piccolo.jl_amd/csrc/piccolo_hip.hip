@@ -107,6 +107,11 @@ struct pcl_ctx {
     int64_t opt_objective_launches = 0;  // 0 auto | 2: always the two launches (A/B, tests)
     int last_step_launches = 0;  // what the last pcl_eval_jac_merit_objective_dev launched (get_option)
     int64_t opt_v4_flags = 0, opt_v4_np = 0;  // kernel 4 A/B switches (KParams::v4_flags); tiles of the powers of G (0 auto)
+    int64_t opt_v4_ticket = 0;      // kernel 4: work items by ticket (-1 auto: full-value launches of several intervals per CU | 0 static split (default until it wins) | 1)
+    int64_t opt_v4_ticket_cols = 0; // ... state columns per block ticket (0 auto by order)
+    int64_t last_v4_ticket = 0;     // state columns per block ticket of the last kernel-4 launch (0: static work split)
+    unsigned int *dv4_tick = nullptr;  // ... [block ticket, pipelines gone, chain ticket]: zero between launches (the last pipeline out resets them)
+    int *herr = nullptr, *derr = nullptr;  // device error word (host-mapped): a barrier-free kernel whose bounded wait gave up sets bit 0
     int64_t opt_v4_tail_mode = 3;   // kernel 4: who stores delta and the tails: 0 the writer wave | 1 ... nontemporal | 2 ... write-through | 3 the stream waves (default)
     int64_t opt_eval_kernel = 0;    // 0 auto | 1 matrix-core residual kernel | 2 pattern-compiled
     // staging for the host-pointer entry points
@@ -198,10 +203,11 @@ struct DeviceGuard {
     if (dev_guard_.err != hipSuccess) return fail(ctx, PCL_EHIP, "hipSetDevice(%d): %s", (ctx)->device, hipGetErrorString(dev_guard_.err))
 
 // LDS of the fused pattern-compiled kernel: m + 4 chain tiles (D, S, W, V, dW_l) + np tiles of the powers of G + counters
-static size_t v4_lds_bytes(int d, int m, int np) { return ((size_t)(m + 4 + np) * d * (2 * d + 1) + 16) * sizeof(double); }
-// tiles for the powers of G: all q when they fit (the stream never waits for the P wave), else as many as fit (>= 2)
+static size_t v4_lds_bytes(int d, int m, int np) { return ((size_t)(m + 4 + np) * d * (2 * d + 1) + 24) * sizeof(double); }
+// tiles for the powers of G: q + 1 when they fit (one-item launches use q: the stream never waits for the P wave; ticket launches let the
+// P wave start the next item's first power while the stream folds this item's last), else as many as fit (>= 2)
 static int v4_power_tiles(int d, int m, int q, size_t max_lds) {
-    int np = q;
+    int np = q + 1;
     while (np > 2 && v4_lds_bytes(d, m, np) > max_lds) --np;
     return v4_lds_bytes(d, m, np) <= max_lds ? np : 0;
 }
@@ -496,7 +502,13 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
         CREATE_TRY(upload(ctx, &ctx->dv4_tab_t, tab_t));
         CREATE_TRY(upload(ctx, &ctx->dv4_mags, mg));
         CREATE_TRY(upload(ctx, &ctx->dv4_dcf, v4.dcf_vals));
+        CREATE_HIP(hipMalloc((void **)&ctx->dv4_tick, 64));
+        CREATE_HIP(hipMemset(ctx->dv4_tick, 0, 64));
     }
+    // device error word, host-mapped: a kernel whose bounded wait gave up sets it; every evaluator entry point and pcl_sync look at it
+    CREATE_HIP(hipHostMalloc((void **)&ctx->herr, 64, hipHostMallocMapped));
+    *ctx->herr = 0;
+    CREATE_HIP(hipHostGetDevicePointer((void **)&ctx->derr, ctx->herr, 0));
 #undef CREATE_TRY
 #undef CREATE_HIP
     *out = ctx;
@@ -528,8 +540,9 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     for (void *q : {(void *)ctx->dsp_pos, (void *)ctx->dsp_coef, (void *)ctx->dsp_glv, (void *)ctx->dsp_gvals, (void *)ctx->dsp_pos_n, (void *)ctx->dsp_coef_n})
         if (q) (void)hipFree(q);
     delete ctx->sp_plan;
-    for (void *q : {(void *)ctx->dv4_tab, (void *)ctx->dv4_tab_t, (void *)ctx->dv4_mags, (void *)ctx->dv4_dcf})
+    for (void *q : {(void *)ctx->dv4_tab, (void *)ctx->dv4_tab_t, (void *)ctx->dv4_mags, (void *)ctx->dv4_dcf, (void *)ctx->dv4_tick})
         if (q) (void)hipFree(q);
+    if (ctx->herr) (void)hipHostFree(ctx->herr);
     delete ctx->v4_plan;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -917,6 +930,19 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.dbg = ctx->ddbg;
     p.prof = (int)ctx->opt_prof;
     p.hess_per = hess_per(ctx);
+    p.err = ctx->derr;
+}
+
+// A barrier-free kernel whose bounded wait gave up (a logic or timing failure: its outputs are partly stale) has set the context's
+// error word.  Looked at by every evaluator entry point before it launches and by every call that synchronises.
+static int check_device_error(pcl_ctx *ctx, const char *where) {
+    if (!ctx->herr) return PCL_OK;
+    const int w = __atomic_load_n(ctx->herr, __ATOMIC_ACQUIRE);
+    if (!w) return PCL_OK;
+    __atomic_store_n(ctx->herr, 0, __ATOMIC_RELEASE);
+    if (ctx->dv4_tick) (void)hipMemsetAsync(ctx->dv4_tick, 0, 64, ctx->stream);  // the launch may have left its ticket words behind
+    return fail(ctx, PCL_EINTERNAL, "%s: an earlier kernel of this context gave up a bounded wait between its waves (device error word 0x%x); "
+                "the outputs of that launch are incomplete", where, w);
 }
 
 static size_t fused_lds_bytes(const KParams &p, bool jac) {  // version-1 kernel
@@ -1177,6 +1203,20 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     // (compact launches -- unique tiles only, the chains are all of the work -- deal the intervals round-robin: a contiguous range that
     //  ends inside an interval runs that interval's chains in two workgroups; 62.2 against 66.8 us per 8 trajectories)
     p.contig = ctx->opt_cols_per_slice > 0 ? 0 : (ctx->opt_contig >= 0 ? (int)ctx->opt_contig : (!compact && bk * d >= 28 * ncu ? 1 : 0));
+    // TICKETS instead of a static split (launches of several trajectories; see the kernel's header): the front of addresses being written
+    // stays tight and the workgroups the memory side serves first take more work -- the time no longer depends on where the values
+    // array's pages live.  auto: wherever the static split would hand out contiguous ranges (an explicit contiguous / cols_per_slice wins).
+    const bool ticket = !compact && ctx->dv4_tick && ctx->opt_grid <= 0 &&
+                        (ctx->opt_v4_ticket == 1 || (ctx->opt_v4_ticket < 0 && p.contig && ctx->opt_contig < 0 && ctx->opt_cols_per_slice <= 0));
+    if (ticket) {
+        // state columns per block ticket: the P wave builds the item's q powers while the stream stores the previous item (a 3-column
+        // item is ~7 k cycles of stores, a product ~2 k): 3 columns up to order 4, 5 at order 6, 9 above
+        p.tick_cpi = ctx->opt_v4_ticket_cols > 0 ? (int)std::min<int64_t>(ctx->opt_v4_ticket_cols, d) : (p.q <= 2 ? std::min(3, d) : p.q == 3 ? std::min(5, d) : std::min(9, d));
+        p.tick = ctx->dv4_tick;
+        p.contig = 0;
+        if ((bk * ((d + p.tick_cpi - 1) / p.tick_cpi)) > 0x3fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+    }
+    ctx->last_v4_ticket = ticket ? p.tick_cpi : 0;
     if (p.contig)
         p.nc = d;
     else if (ctx->opt_cols_per_slice > 0)
@@ -1201,11 +1241,12 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     const size_t lds = v4_lds_bytes(d, m, np);
     // tiles of the ring in use: q - 1 when workgroups walk several items (the P wave must not run a whole item ahead: measured
     // 8 % on 8 trajectories per launch), all the module has for one-item launches (0.4 us there); option v4_power_tiles overrides
-    p.v4_np = ctx->opt_v4_np > 0 ? (int)std::min<int64_t>(ctx->opt_v4_np, np) : (units > g ? std::max(1, std::min(np, p.q - 1)) : np);
+    p.v4_np = ctx->opt_v4_np > 0 ? (int)std::min<int64_t>(ctx->opt_v4_np, np) : ticket ? np : (units > g ? std::max(1, std::min(np, p.q - 1)) : std::min(np, p.q));
     // the cooperative first item (waves 0-3 build the powers, the stream waves fold) with a ring shorter than q: pays up to order 8 (one
     // trajectory 31.4 -> 29.3-30.5 us), not at order 10 (five powers through three tiles: 35.5 against 34.1 us)
     if (p.q >= 5 && p.v4_np < p.q) p.v4_flags |= 4;
-    if (want_merit && p.tail_mode == 3) {
+    if (ticket) p.tail_mode = p.tail_mode == 3 ? 0 : p.tail_mode;  // (the writer wave stores delta and the tails of a chain ticket)
+    if (want_merit && (p.tail_mode == 3 || ticket)) {
         if (!ctx->dmcols) HIP_TRY(ctx, hipMalloc((void **)&ctx->dmcols, (size_t)ctx->desc.batch * p.K * p.d * (p.m + 2) * sizeof(double)));
         p.mpart = ctx->dmcols;
         p.mlam = ctx->merit_lam;
@@ -1247,6 +1288,7 @@ static int launch_pade_general(pcl_ctx *ctx, KParams &p, bool want_jac) {
 
 static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *jac, bool compact) {
     ON_DEVICE(ctx);
+    if (int rc = check_device_error(ctx, "pcl_eval / pcl_jac")) return rc;
     KParams p;
     fill_params(ctx, p);
     p.Z = Z + (ctx->desc.batch_mode == PCL_BATCH_TRAJ ? (long long)ctx->win_first * ctx->desc.z_dim * ctx->desc.N : 0);
@@ -1515,6 +1557,7 @@ static size_t hess2_lds_bytes(const KParams &p) {
 
 static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *hess) {
     ON_DEVICE(ctx);
+    if (int rc = check_device_error(ctx, "pcl_hess")) return rc;
     KParams p;
     fill_params(ctx, p);
     p.Z = Z + (ctx->desc.batch_mode == PCL_BATCH_TRAJ ? (long long)ctx->win_first * ctx->desc.z_dim * ctx->desc.N : 0);
@@ -1767,7 +1810,7 @@ extern "C" int pcl_reset_stream(pcl_ctx *ctx) {
 extern "C" int pcl_sync(pcl_ctx *ctx) {
     if (!ctx) return PCL_EINVAL;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PCL_OK;
+    return check_device_error(ctx, "pcl_sync");
 }
 extern "C" int pcl_eval_dev(pcl_ctx *ctx, const double *Z, double *delta) {
     if (!ctx) return PCL_EINVAL;
@@ -1881,7 +1924,7 @@ static int host_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *v
         if (delta) HIP_TRY(ctx, hipMemcpyAsync(delta, ctx->ddelta, n_rows(ctx) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         if (vals) HIP_TRY(ctx, hipMemcpyAsync(vals, ctx->dvals, nv * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        return PCL_OK;
+        return check_device_error(ctx, "pcl_eval_jac");
     }
     const long long cper = jac_per_compact(ctx), fper = jac_per_full(ctx);
     TRY(ensure(ctx, &ctx->dcomp_host, cper * nbk_all));
@@ -1920,7 +1963,7 @@ static int host_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *v
     if (rc != PCL_OK) return fail(ctx, PCL_EHIP, "hipEventSynchronize: %s", hipGetErrorString(hipGetLastError()));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (delta) memcpy(delta, ctx->hdelta, (size_t)n_rows(ctx) * sizeof(double));
-    return PCL_OK;
+    return check_device_error(ctx, "pcl_eval_jac");
 }
 extern "C" int pcl_eval(pcl_ctx *ctx, const double *Z, double *delta) {
     if (ctx && !delta) return fail(ctx, PCL_EINVAL, "pcl_eval: delta is NULL");
@@ -1947,7 +1990,7 @@ extern "C" int pcl_hess(pcl_ctx *ctx, const double *Z, const double *mu, double 
     TRY(launch_hess(ctx, ctx->dZ, ctx->dmu, ctx->dhess));
     HIP_TRY(ctx, hipMemcpyAsync(vals, ctx->dhess, nv * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PCL_OK;
+    return check_device_error(ctx, "pcl_hess");
 }
 
 extern "C" int pcl_rollout(pcl_ctx *ctx, const double *Z, double *X_out) {
@@ -2278,15 +2321,13 @@ extern "C" int pcl_eval_jac_merit_dev(pcl_ctx *ctx, const double *Z, const doubl
 static bool tail_applies(const pcl_ctx *ctx, const double *grad, int &lo_, int &hi_) {
     if (!grad || !ctx->dgoal || ctx->opt_objective_launches == 2) return false;
     const int nx = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? 1 : ctx->desc.batch;
-    long long lo = ctx->x_offs[0], hi = ctx->x_offs[0] + ctx->x_dim;
-    for (int b = 1; b < nx; ++b) {
-        lo = std::min<long long>(lo, ctx->x_offs[b]);
-        hi = std::max<long long>(hi, ctx->x_offs[b] + ctx->x_dim);
-    }
-    if (hi - lo != (long long)nx * ctx->x_dim) return false;  // (equal extents: distinct offsets tile the run exactly)
-    for (int b = 0; b < nx; ++b)
-        for (int b2 = 0; b2 < b; ++b2)
-            if (ctx->x_offs[b] == ctx->x_offs[b2]) return false;
+    // The members' states must TILE one run [lo, hi) of the knot's row: sorted, every neighbour exactly x_dim further (distinct offsets and
+    // a matching extent are not enough: x_dim = 4 with offsets {0, 2, 8} has both and leaves a gap behind two overlapping states)
+    std::vector<long long> xo(ctx->x_offs.begin(), ctx->x_offs.begin() + nx);
+    std::sort(xo.begin(), xo.end());
+    for (int b = 1; b < nx; ++b)
+        if (xo[b] - xo[b - 1] != (long long)ctx->x_dim) return false;
+    const long long lo = xo[0], hi = xo[nx - 1] + ctx->x_dim;
     for (const PclReg &r : ctx->regs)
         if (r.off < hi && lo < r.off + r.dim) return false;
     lo_ = (int)lo;
@@ -2522,6 +2563,10 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
     } else if (!strcmp(key, "v4_flags"))  // kernel 4 A/B switches: 1 no raised priority for the P wave | 2 tails only behind the item's last block
                                        // | 4 no cooperative first item | 8 LDS tiles NaN at kernel start (tests) | 16 the first item's chains do not wait for the cooperative products | 32 no balanced split of the middle column's two blocks between two slices
         ctx->opt_v4_flags = v;
+    else if (!strcmp(key, "v4_ticket"))  // kernel 4: work items by ticket (-1 auto: full-value launches of several intervals per CU | 0 static split | 1)
+        ctx->opt_v4_ticket = v < 0 ? -1 : (v != 0);
+    else if (!strcmp(key, "v4_ticket_cols"))  // ... state columns per block ticket (0 auto by order)
+        ctx->opt_v4_ticket_cols = v < 0 ? 0 : v;
     else if (!strcmp(key, "v4_power_tiles"))  // kernel 4: LDS tiles the powers of G rotate through (0 auto: q - 1 for launches of several items per workgroup, else q)
         ctx->opt_v4_np = v < 0 ? 0 : v;
     else if (!strcmp(key, "v4_tail_mode")) {  // kernel 4: 0 writer wave, plain stores | 1 nontemporal | 2 write-through | 3 the stream waves store the tails
@@ -2616,6 +2661,12 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->opt_stream_wg;
     else if (!strcmp(key, "last_stream_workgroups"))
         *v = ctx->last_n_stream;
+    else if (!strcmp(key, "v4_ticket"))
+        *v = ctx->opt_v4_ticket;
+    else if (!strcmp(key, "v4_ticket_cols"))
+        *v = ctx->opt_v4_ticket_cols;
+    else if (!strcmp(key, "last_v4_ticket"))
+        *v = ctx->last_v4_ticket;
     else if (!strcmp(key, "hess_kernel"))
         *v = ctx->opt_hess_kernel;
     else if (!strcmp(key, "eval_kernel"))
