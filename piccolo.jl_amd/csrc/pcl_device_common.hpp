@@ -74,8 +74,11 @@ struct KParams {
     int tail_mode;       // pattern-compiled fused kernel: who stores delta and the tails (option v4_tail_mode)
     int v4_np;           // ... tiles of the ring of powers of G this launch rotates through (<= the SP4NP the module allocates)
     int v4_flags;        // ... A/B switches (option v4_flags): 1 no raised priority for the P wave | 2 tails only behind the item's last block | 4 no cooperative first item | 8 tiles NaN at start | 16 chains do not wait | 32 no balanced middle column
-    unsigned int *tick;  // ... ticket mode (launches of several trajectories): [0] the next block ticket, [1] pipelines that have left, [2] the next chain ticket; all zero between launches
-    int tick_cpi;        // ... state columns per block ticket
+    unsigned int *tick;  // ... slice tickets (launches of several trajectories): [1] pipelines that have left, [2] the next chain ticket, [4 + i] the next
+                         //     slice of interval i; all zero between launches (the last pipeline out re-zeroes them)
+    int tick_cpi;        // ... state columns per slice
+    int tick_G;          // ... workgroups per group
+    int tick_ahead;      // ... slices the dispatcher may take ahead of the one the stream waves are storing (0 | 1)
     int *err;            // device error word of the context (host-mapped): bit 0 = a bounded wait of a barrier-free kernel gave up
 };
 

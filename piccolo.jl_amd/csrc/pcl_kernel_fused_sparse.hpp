@@ -21,16 +21,20 @@
 //     (the FIRST item's powers are built by waves 0 .. 3 together, in four row ranges, before they take up the roles above)
 // No workgroup barrier after the start: point-to-point monotonic LDS counters (dependencies only point backwards; bounded waits).
 // Work items as in kernel 3: contiguous column ranges per workgroup (pieces of one interval), or round-robin slices -- or, for launches
-// of several trajectories, TICKETS (p.tick): every interval is ceil(d / tick_cpi) block tickets of tick_cpi state columns (the replicated
-// -B^+ / B^- blocks, through the P and stream waves) and one chain ticket (the whole interval's delta, d/du_l, d/dh and the reduce payload,
-// through the loader, W, V, dW_l and writer waves), each kind taken in order from its own device-wide counter by whichever workgroup's
-// pipeline of that kind is free (the P wave takes block tickets, the loader wave chain tickets).  The two pipelines of a workgroup share
-// nothing.  (One counter for both kinds, chain tickets queued behind the P wave: a workgroup's chains are 15-30 us per interval, its
-// queue filled while it kept taking block tickets -- 292 us per 8 trajectories, the last workgroup 80 us behind the median.)
-// Measured with the bare store pattern
-// (scripts/probes/wfront.hip, 8 trajectories, 8 separately allocated buffers): equal contiguous ranges 196.6 us median (163.7 ... 209.3 by
-// where the buffer's pages live), static round-robin 3-column items 229, tickets of 3 columns 173-177 on every buffer -- the write front stays
-// a few tens of MB wide and the workgroups of the XCDs the memory side serves first simply take more tickets.
+// of several trajectories, GROUPS WITH SLICE TICKETS (p.tick):
+//   * the workgroups form groups of tick_G (8: one per XCD); group g walks the intervals g, g + n_groups, ... in a STATIC order, so the
+//     interval a workgroup works on next -- hence the controls and the powers of G it needs -- is known in advance;
+//   * inside an interval the group's members take slices of tick_cpi state columns (the replicated -B^+ / B^- blocks) from the interval's own
+//     counter, one at a time, each when its stream waves have issued the previous slice: the addresses are assigned LATE, the workgroups
+//     the memory side serves first take more slices, a member that finds an interval exhausted moves on;
+//   * an interval's chains (delta, d/du_l, d/dh, the reduce payload: loader, W, V, dW_l, writer waves) are a second pipeline with its own
+//     device-wide ticket counter, taken by whichever workgroup's chain waves are free.
+// One more wave, the dispatcher, does everything that waits for memory on behalf of the block pipeline: it takes the slice tickets and keeps
+// a ring of the group's next controls and steps in LDS.  Measured with the bare store pattern (scripts/probes/wfront.hip, 8 trajectories, 8
+// separately allocated buffers, one box): equal contiguous ranges 196.6 us median (163.7 ... 209.3 by where the buffer's pages live), static
+// round-robin items 199-229, items of 3 columns by ONE device-wide ticket 176, this scheme 177-182, on every buffer.  (The first version of
+// this round took device-wide block tickets in the P wave: parity-exact but 247 us -- every ticket's controls are a cold load behind the CU's
+// own stores, 3-8 us, and tickets taken early to hide it cost 5-10 us each: the write front is only as tight as the tickets are late.)
 #pragma once
 
 #define SP4CS (SPN + 1)           // odd column stride: the lanes of a half wave, one column each, hit distinct banks
@@ -39,7 +43,9 @@
 #define SP4_WWRITE (SPM + 4)
 #define SP4_WSTREAM (SPM + 5)
 #define SP4_NSTREAM 4
-#define SP4_NWAVES (SPM + 9)
+#define SP4_NWAVES (SPM + 9)      // static work splits; launches with slice tickets add the dispatcher wave
+#define SP4_WDISP (SPM + 9)
+#define SP4_UHR 128               // visits whose controls and step the dispatcher keeps in LDS (8 doubles each)
 #define SP4_NOUT (SPM + 2)        // output chains: W (delta), V (d/dh), dW_l (d/du_l)
 #define SP4_NTILES (SPM + 4 + SP4NP)  // D, S, W, V, dW[m], P[SP4NP]
 #define SP4_SYNC_WORDS 48        // 32 counters + the two ticket rings (4 block items with their steps, 4 chain items)
@@ -48,7 +54,8 @@
 // G + l levels of W the drive wave l has gathered | O + w items whose output chain w is complete
 // (one word per arriver wherever arrivers can run ahead of each other: a shared arrival count lies -- a fast wave's extra arrival
 //  stands in for a slow wave's missing one)
-enum { SP4_F_IN = 0, SP4_F_DW, SP4_F_DV, SP4_F_W, SP4_F_B, SP4_F_OC, SP4_F_CO /* cooperative first item: parts of powers done */, SP4_F_CX /* ... operands read (one-tile ring) */, SP4_F_G = 8, SP4_F_BI = 14 /* ticket mode: block items published */, SP4_F_CI = 15 /* ... chain items published */, SP4_F_O = 16, SP4_F_C = 24 /* per stream wave */, SP4_F_TS = 28 /* per stream wave: items whose tails it has stored */ };
+enum { SP4_F_IN = 0, SP4_F_DW, SP4_F_DV, SP4_F_W, SP4_F_B, SP4_F_OC, SP4_F_CO /* cooperative first item: parts of powers done */, SP4_F_CX /* ... operands read (one-tile ring) */, SP4_F_G = 8, SP4_F_BI = 14 /* tickets: slices published */, SP4_F_CI = 15 /* ... chain items published */, SP4_F_O = 16, SP4_F_C = 24 /* per stream wave */, SP4_F_TS = 28 /* per stream wave: items whose tails it has stored (tickets: slices whose stores it has issued) */,
+       SP4_F_V = 44 /* tickets: the visit of the oldest slice in flight */, SP4_F_VI = 45 /* ... visits whose controls are in the ring */, SP4_F_V2 = 46 /* ... the visit of the newest slice in flight */ };
 
 static __device__ __forceinline__ bool sp4_wait(int *sync, int word, int target, bool gave_up = false) {
     // Bounded: a logic error must not hang the device (the caller poisons the output instead; once a wave has given up it
@@ -67,6 +74,16 @@ static __device__ __forceinline__ bool sp4_wait(int *sync, int word, int target,
     }
     return it >= (1 << 18);
 }
+// the two hand-offs of a slice ticket (stream waves -> dispatcher -> stream waves) sit on every slice's critical path and are answered within
+// a few thousand cycles: short sleeps for that long, then the usual back-off
+static __device__ __forceinline__ bool sp4_wait_soon(int *sync, int word, int target, bool gave_up = false) {
+    if (gave_up) return true;
+    for (int it = 0; it < 128; ++it) {
+        if (__hip_atomic_load(sync + word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return sp4_wait(sync, word, target, false);
+}
 static __device__ __forceinline__ void sp4_post(int *w, int value, int lane) {  // after wave_lds_sync(): this wave's LDS traffic is complete
     if (lane == 0) __hip_atomic_store(w, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -77,7 +94,7 @@ static __device__ __forceinline__ unsigned sp4_lds_off(const double *q) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const double *)q;
 }
 
-extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_kernel(const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ mags_, const double *__restrict__ dcf_tab) {
+extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sparse_kernel(const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ mags_, const double *__restrict__ dcf_tab) {
     extern __shared__ double lds[];
     constexpr int d = SPD, n = SPN, m = SPM, q = SP4Q, nn = SPN * SPN;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -150,45 +167,30 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             k = ik - b * p.K;
         }
     };
-    // ---- ticket mode: the P wave takes the tickets and publishes them through two 4-entry rings in LDS (block items with their step h;
-    //      chain items, taken by the loader wave: the interval's index); every other wave reads its pipeline's ring.  Block ticket t:
-    //      interval t / ipi, columns [s cpi, s cpi + cpi) with s = t mod ipi.  A negative entry ends the pipeline.
+    // ---- slice tickets (see the head of the file): rings in LDS behind the counters -- the slice in flight (bdesc: 32 visit + slice), the visit
+    //      each of the P wave's last four builds holds (pvis), the chain items (cdesc: the interval), the controls and step of SP4_UHR visits (uhr)
     const bool tick = p.tick != nullptr;
-    int *bdesc = sync + 32, *cdesc = sync + 36;
-    double *bdesc_h = (double *)(sync + 40);
+    int *bdesc = sync + 32, *cdesc = sync + 36, *pvis = sync + 40;
+    double *uhr = (double *)(sync + SP4_SYNC_WORDS);
     const int t_ipi = tick ? (d + p.tick_cpi - 1) / p.tick_cpi : 1;
-    auto decode_ticket = [&](int t, int &c0, int &nce, int &k, int &b) {
-        const int iv = t / t_ipi, sub = t - iv * t_ipi;
-        b = p.batch == 1 ? 0 : iv / p.K;
-        k = iv - b * p.K;
-        c0 = sub * p.tick_cpi;
-        nce = min(p.tick_cpi, d - c0);
-    };
-    // a pipeline's last ticket has come back: the last of the 2 gridDim.x pipelines to leave re-zeroes the ticket words for the next launch
+    const int n_int = p.batch * p.K;
+    const int n_groups = tick ? (int)gridDim.x / p.tick_G : 1, grp = tick ? bx / p.tick_G : 0;
+    const int n_vis = tick && grp < n_int ? (n_int - grp + n_groups - 1) / n_groups : 0;  // intervals grp, grp + n_groups, ...
+    bool gave_up = false;
+    // a pipeline's last ticket has come back: the last of the 2 gridDim.x pipelines to leave re-zeroes the counters for the next launch
     auto ticket_leave = [&](unsigned n) {
-        if (lane == 0) {
-            const unsigned gone = __hip_atomic_fetch_add(p.tick + 1, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (gone + n == 2u * gridDim.x) {
-                __hip_atomic_store(p.tick, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned gone = 0;
+        if (lane == 0) gone = __hip_atomic_fetch_add(p.tick + 1, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gone = __builtin_amdgcn_readfirstlane(gone);
+        if (gone + n == 2u * gridDim.x) {
+            for (int i = lane; i < n_int; i += 64) __hip_atomic_store(p.tick + 4 + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
                 __hip_atomic_store(p.tick + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(p.tick + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
-    bool gave_up = false;
-    // item `it` of this workgroup's block pipeline (P, stream waves) / chain pipeline (W, V, dW_l, loader, writer): false = no more
-    auto block_item = [&](int it, int &c0, int &nce, int &k, int &b) -> bool {
-        if (!tick) {
-            if (it >= n_my) return false;
-            decode(it, c0, nce, k, b);
-            return true;
-        }
-        gave_up = sp4_wait(sync, SP4_F_BI, it + 1, gave_up);
-        const int t = __builtin_amdgcn_readfirstlane(__hip_atomic_load(bdesc + (it & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if (t < 0 || gave_up) return false;
-        decode_ticket(t, c0, nce, k, b);
-        return true;
-    };
+    // item `it` of this workgroup's chain pipeline (W, V, dW_l, writer; the loader takes the tickets): false = no more
     auto chain_item = [&](int it, int &c0, int &nce, int &k, int &b) -> bool {
         if (!tick) {
             if (it >= n_my) return false;
@@ -358,23 +360,28 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
         if (wave == 0) {
             // ---- P: powers of G(u_k), one tile of the ring per power -----------------------------------------------------------
             if (!(p.v4_flags & 1)) __builtin_amdgcn_s_setprio(2);  // the stream waits for this chain
-            // ticket mode: this wave takes the block tickets, one requested ahead of the one it works on (the atomic's round trip, 1-3 us under
-            // the store stream, hides behind an item's products)
-            const int n_tick = tick ? p.batch * p.K * t_ipi : 0;
-            unsigned tk_next = 0;
-            if (tick && lane == 0) tk_next = __hip_atomic_fetch_add(p.tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // slice tickets: the builds follow the group's static visit order, jumping to the visit the dispatcher is at when that is ahead (the
+            // intervals in between were exhausted before this workgroup got there); the controls and the step come from the dispatcher's ring
+            int pv = -1;
             int it = coop ? 1 : 0;
             for (;; ++it) {
-                int c0, nce, k, b, tcur = -1;
+                int c0, nce, k, b;
                 if (!tick) {
                     if (it >= n_my) break;
                     decode(it, c0, nce, k, b);
                 } else {
-                    tcur = (int)__builtin_amdgcn_readfirstlane(tk_next);
-                    SP4_STAMP();
-                    if (tcur >= n_tick || tcur < 0 || gave_up) break;
-                    if (lane == 0) tk_next = __hip_atomic_fetch_add(p.tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    decode_ticket(tcur, c0, nce, k, b);
+                    // the next build: the visit of the oldest slice in flight if that is still ahead, else of the newest one, else the visit after the
+                    // last build (the newest word first: it is written last, so the oldest read behind it is at least as new)
+                    const int vb = __hip_atomic_load(sync + SP4_F_V2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int va = __hip_atomic_load(sync + SP4_F_V, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    pv = pv < va ? va : (pv < vb ? vb : pv + 1);
+                    if (pv >= n_vis || gave_up) break;
+                    gave_up = sp4_wait(sync, SP4_F_VI, pv + 1, gave_up);
+                    const int iv = grp + pv * n_groups;
+                    b = p.batch == 1 ? 0 : iv / p.K;
+                    k = iv - b * p.K;
+                    c0 = 0;
+                    nce = d;
                 }
                 SP4_LANEPOS();
                 const bool act = c < d;
@@ -382,36 +389,20 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 sp4_cf cf;
                 sp_cptr tab;
                 SP4_STAMP();
-#ifdef PCL_PROFILE
-                if (p.prof & 512) {  // experiment (results WRONG): the P wave loads nothing and builds nothing -- tickets and block stores alone
-                    if (lane == 0) {
-                        bdesc[it & 3] = tcur;
-                        bdesc_h[it & 3] = 0.1;
-                    }
-                    wave_lds_sync();
-                    sp4_post(sync + SP4_F_BI, it + 1, lane);
-                    for (int j = 1; j <= q; ++j) {
-                        const int L = it * q + j - 1;
-                        for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_C + w, L - npw + 1, gave_up);
-                        sp4_post(sync + SP4_F_B, L + 1, lane);
-                    }
-                    continue;
+                if (!tick)
+                    scalars(k, b, h, cf, tab);
+                else {
+                    const double *ur = uhr + (pv & (SP4_UHR - 1)) * 8;
+                    SP4_SET_DCF(cf, (sp_cptr)(dcf_tab + (p.g0_batch_stride ? (long long)b * SP4NDCFP : 0)));
+                    double u[SPM > 0 ? SPM : 1];
+#pragma unroll
+                    for (int l = 0; l < SPM; ++l) u[l] = ur[l];
+                    h = ur[SPM];
+                    SP4_SET_CF(cf, u, mg);
+                    tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
+                    if (lane == 0) pvis[it & 3] = pv;  // (published with this build's first power)
                 }
-                if (p.prof & 1024) {  // experiment (results WRONG): the item's controls and step are those of interval 0 (cached: no load latency)
-                    k = 0;
-                    b = 0;
-                }
-#endif
-                scalars(k, b, h, cf, tab);
                 SP4_STAMP();
-                if (tick) {  // (the stream waves are inside item it - 2 at the earliest: the slot of item it - 4 is free)
-                    if (lane == 0) {
-                        bdesc[it & 3] = tcur;
-                        bdesc_h[it & 3] = h;
-                    }
-                    wave_lds_sync();
-                    sp4_post(sync + SP4_F_BI, it + 1, lane);
-                }
                 const double bs = half ? -1.0 : 1.0;
                 {  // P_1 = G I: the unit vectors never touch LDS
                     const int L = it * q;
@@ -449,12 +440,6 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                     sp4_post(sync + SP4_F_B, L + 1, lane);
                     SP4_STAMP();
                 }
-            }
-            if (tick) {  // the block pipeline ends
-                if (lane == 0) bdesc[it & 3] = -1;
-                wave_lds_sync();
-                sp4_post(sync + SP4_F_BI, it + 1, lane);
-                ticket_leave(no_chains ? 2u : 1u);
             }
         } else if (wave <= 2) {
             // ---- W (delta) and V (d delta / dh) --------------------------------------------------------------------------------
@@ -580,6 +565,9 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 k = iv - b * p.K;
                 c0 = 0;
                 nce = d;
+                // the chains follow the block front (a few visits ahead of it) instead of racing through the launch: their loads, products and
+                // tail stores are spread over the launch, and an interval's tails are written when its blocks are
+                if (!(p.v4_flags & 64)) gave_up = sp4_wait(sync, SP4_F_V, (iv - grp) / n_groups - 8, gave_up);
             } else if (!chain_item(it, c0, nce, k, b))
                 break;
             SP4_STAMP();
@@ -662,6 +650,64 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             sp4_post(sync + SP4_F_OC, it + 1, lane);  // the chains may rewrite their tiles
             SP4_STAMP();
         }
+    } else if (wave == SP4_WDISP) {
+        // ================================== dispatcher (launches with slice tickets only) ======================================
+        // Everything of the block pipeline that waits for memory: the slice tickets, each taken when every stream wave has issued the
+        // previous slice's stores (taken earlier, a ticket is an address range reserved for later: 5-10 us per ticket held in the bare
+        // store pattern), and the controls and steps of the group's next visits (64 visits per refill, two refills ahead).
+        auto fetch_chunk = [&](int ch) {  // visits [64 ch, 64 ch + 64): lane = 8 visit + component (u_0 .. u_{m-1}, h)
+            double val[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int v = ch * 64 + r * 8 + (lane >> 3), comp = lane & 7;
+                const int iv = grp + v * n_groups;
+                val[r] = 0.0;
+                if (v < n_vis && comp <= m) {
+                    const int b = p.batch == 1 ? 0 : iv / p.K, k = iv - b * p.K;
+                    val[r] = p.Z[(long long)b * p.z_batch_stride + (long long)k * p.z_dim + (comp < m ? p.u_off + comp : p.dt_off)];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) uhr[((ch * 64 + r * 8 + (lane >> 3)) & (SP4_UHR - 1)) * 8 + (lane & 7)] = val[r];
+            wave_lds_sync();
+            sp4_post(sync + SP4_F_VI, min((ch + 1) * 64, n_vis), lane);
+        };
+        int next_chunk = 0, v = 0, items = 0, v_last = 0;
+        for (; next_chunk < 2 && next_chunk * 64 < n_vis; ++next_chunk) fetch_chunk(next_chunk);
+        for (;;) {
+            SP4_STAMP();
+            for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait_soon(sync, SP4_F_TS + w, items - (p.tick_ahead == 1 ? 1 : 0), gave_up);
+            SP4_STAMP();
+            int sl = 0;
+            for (; v < n_vis && !gave_up; ++v) {  // this visit's interval, or the next one that has a slice left
+                unsigned t = 0;
+                if (lane == 0) t = __hip_atomic_fetch_add(p.tick + 4 + grp + v * n_groups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sl = (int)__builtin_amdgcn_readfirstlane(t);
+                if (sl >= 0 && sl < t_ipi) break;
+            }
+            SP4_STAMP();
+            if (v >= n_vis || gave_up) break;
+            // (the chunk a refill overwrites lies two behind the visit: nothing the stream or a useful build still reads)
+            while (next_chunk * 64 < n_vis && next_chunk * 64 <= v + 64) {
+                if (p.tick_ahead && next_chunk - 2 >= v_last / 64)  // (... nor the slice before this one, if it may still be in flight)
+                    for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_TS + w, items, gave_up);
+                fetch_chunk(next_chunk++);
+            }
+            if (lane == 0) bdesc[items & 3] = 32 * v + sl;
+            wave_lds_sync();
+            sp4_post(sync + SP4_F_V, p.tick_ahead ? v_last : v, lane);
+            sp4_post(sync + SP4_F_V2, v, lane);
+            sp4_post(sync + SP4_F_BI, ++items, lane);
+            v_last = v;
+        }
+        if (lane == 0) bdesc[items & 3] = -1;
+        wave_lds_sync();
+        for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_TS + w, items, gave_up);  // (the last slice's powers are folded)
+        sp4_post(sync + SP4_F_VI, n_vis, lane);
+        sp4_post(sync + SP4_F_V, n_vis, lane);
+        sp4_post(sync + SP4_F_V2, n_vis, lane);
+        sp4_post(sync + SP4_F_BI, items + 1, lane);
+        ticket_leave(no_chains ? 2u : 1u);
     } else {
         // ================================== stream waves ========================================================================
 #ifdef PCL_PROFILE
@@ -674,9 +720,39 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
 #ifdef PCL_PROFILE
         bool dry_ = (p.prof & 256) != 0;  // experiment (results WRONG): the first item twice, the first pass without stores -- the second pass shows the warm timings
 #endif
+        // -B^+ and B^- of this thread's positions (slice tickets: kept across the slices of one visit)
+        double bpr[NSP][2], bmr[NSP][2];
+        int cur_v = -1, itS = 0;  // slice tickets: the visit the values belong to, the P wave's next build to look at
         for (int it = 0;; ++it) {
-            int c0, nce, k, b;
-            if (!block_item(it, c0, nce, k, b)) break;
+            int c0, nce, k, b, fb = it;
+            bool refold = true;
+            double h = 0.0;
+            if (!tick) {
+                if (it >= n_my) break;
+                decode(it, c0, nce, k, b);
+                h = ((sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim))[p.dt_off];
+            } else {
+                gave_up = sp4_wait_soon(sync, SP4_F_BI, it + 1, gave_up);
+                const int t = __builtin_amdgcn_readfirstlane(__hip_atomic_load(bdesc + (it & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (t < 0 || gave_up) break;
+                const int v = t >> 5, sl = t & 31, iv = grp + v * n_groups;
+                b = p.batch == 1 ? 0 : iv / p.K;
+                k = iv - b * p.K;
+                c0 = sl * p.tick_cpi;
+                nce = min(p.tick_cpi, d - c0);
+                refold = v != cur_v;
+                if (refold) {  // the build that holds this visit's powers: builds of visits this workgroup found exhausted are let go unread
+                    for (;;) {
+                        gave_up = sp4_wait(sync, SP4_F_B, itS * q + 1, gave_up);
+                        if (gave_up || __builtin_amdgcn_readfirstlane(__hip_atomic_load(pvis + (itS & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= v) break;
+                        sp4_post(sync + SP4_F_C + (wave - SP4_WSTREAM), (itS + 1) * q, lane);
+                        ++itS;
+                    }
+                    fb = itS++;
+                    cur_v = v;
+                    h = uhr[(v & (SP4_UHR - 1)) * 8 + m];
+                }
+            }
             // (an opaque copy per item: derived from `tid` directly, the tile addresses below are hoisted out of the item loop
             //  and spilled)
             SP4_STAMP();
@@ -684,11 +760,10 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
             asm volatile("" : "+v"(stid));  // (after the cooperative products: nothing derived from it lives beside their registers)
             const int pi = 2 * (stid % hn), pj0 = stid / hn;
             const bool pact = pj0 < pstep;
-            const double h = tick ? bdesc_h[it & 3] : ((sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim))[p.dt_off];
-            // -B^+ and B^- of this thread's positions, folded power by power as the P wave publishes them.  Entry (i, j) of the
+            // the values, folded power by power as the P wave publishes them.  Entry (i, j) of the
             // n x n iso matrix [[A, -B], [B, A]] whose first d columns are a tile: j >= d mirrors into column j - d, rows i < d
             // from row i + d with the sign flipped, rows i >= d from row i - d.
-            double bpr[NSP][2], bmr[NSP][2];
+            if (refold) {
             int toff[NSP][2];
             unsigned flip = 0;  // bit 2 r + e: the mirrored entry changes sign
 #pragma unroll
@@ -713,7 +788,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
 #endif
 #pragma unroll 1
             for (int j = 1; j <= q; ++j) {
-                const int L = it * q + j - 1;
+                const int L = fb * q + j - 1;
                 const double *T = Pt + (L % npw) * SP4TILE;
                 hp *= h;
                 hm *= -h;
@@ -737,6 +812,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                     }
                 wave_lds_sync();
                 sp4_post(sync + SP4_F_C + (wave - SP4_WSTREAM), L + 1, lane);  // the P wave may rewrite this tile
+            }
             }
             SP4_STAMP();
             // tail_mode 3: this wave's share of the item's residuals and tails goes into its own store stream as soon as every chain
@@ -781,6 +857,8 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 const int nt_b = p.nt == 3 ? ((bx & 1) ? 2 : 0) : p.nt;
                 double *o = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn + pi;
                 for (int cq = cbeg; cq < cend; ++cq, o += nn) {
+                    // (tick_ahead 2: the dispatcher asks for the next slice while this one's last column goes out)
+                    if (tick && p.tick_ahead == 2 && cq == cend - 1) sp4_post(sync + SP4_F_TS + (wave - SP4_WSTREAM), it + 1, lane);
 #ifdef PCL_PROFILE
                     if (dry_ && cq >= cbeg + 2) break;
                     if (pact && !no_blocks && !dry_) {
@@ -804,6 +882,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
                 }
             }
             try_tails(true);
+            if (tick && p.tick_ahead != 2) sp4_post(sync + SP4_F_TS + (wave - SP4_WSTREAM), it + 1, lane);  // this slice's stores are issued: the dispatcher takes the next ticket
             SP4_STAMP();
 #ifdef PCL_PROFILE
             if (dry_) {
@@ -818,6 +897,7 @@ extern "C" __global__ __launch_bounds__(64 * SP4_NWAVES) void pcl_fused_sparse_k
 #endif
         }
     }
+    if (tick && wave >= SP4_WSTREAM && wave < SP4_WSTREAM + SP4_NSTREAM) sp4_post(sync + SP4_F_C + (wave - SP4_WSTREAM), 0x3fffffff, lane);  // (a build the P wave is still at)
     if (gave_up && lane == 0) {  // a wait gave up: the context's error word (the next entry point or pcl_sync returns PCL_EINTERNAL) ...
         if (p.err) __hip_atomic_fetch_or(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         p.jac[0] = __builtin_nan("");  // ... and visible in the values instead of a hung device

@@ -107,8 +107,10 @@ struct pcl_ctx {
     int64_t opt_objective_launches = 0;  // 0 auto | 2: always the two launches (A/B, tests)
     int last_step_launches = 0;  // what the last pcl_eval_jac_merit_objective_dev launched (get_option)
     int64_t opt_v4_flags = 0, opt_v4_np = 0;  // kernel 4 A/B switches (KParams::v4_flags); tiles of the powers of G (0 auto)
-    int64_t opt_v4_ticket = 0;      // kernel 4: work items by ticket (-1 auto: full-value launches of several intervals per CU | 0 static split (default until it wins) | 1)
-    int64_t opt_v4_ticket_cols = 0; // ... state columns per block ticket (0 auto by order)
+    int64_t opt_v4_ticket = -1;     // kernel 4: slice tickets (-1 auto: full-value launches of several intervals per CU at orders 2 and 4 | 0 static split | 1)
+    int64_t opt_v4_ticket_cols = 0; // ... state columns per slice ticket (0 auto: 3)
+    int64_t opt_v4_ticket_ahead = 2; // ... when the next slice is asked for: 0 when the stream waves have issued this one's stores | 1 a slice ahead | 2 at this one's last column (default)
+    int64_t opt_v4_group = 0;       // ... workgroups per group (0 auto: 8, one per XCD)
     int64_t last_v4_ticket = 0;     // state columns per block ticket of the last kernel-4 launch (0: static work split)
     unsigned int *dv4_tick = nullptr;  // ... [block ticket, pipelines gone, chain ticket]: zero between launches (the last pipeline out resets them)
     int *herr = nullptr, *derr = nullptr;  // device error word (host-mapped): a barrier-free kernel whose bounded wait gave up sets bit 0
@@ -291,6 +293,10 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     ctx->device = dsc->device_id;
     ctx->win_first = 0;
     ctx->win_count = dsc->batch;
+    if (const char *tk = getenv("PCL_V4_TICKET")) {  // default of option "v4_ticket" (A/B of whole programs: -1 auto | 0 static split | 1 slice tickets)
+        const long v = strtol(tk, nullptr, 10);
+        if (v >= -1 && v <= 1) ctx->opt_v4_ticket = v;
+    }
     if (const char *hp = getenv("PCL_HOST_PATH")) {  // default of option "host_path" (1: full values over PCIe, 2: compact + host expansion)
         const long v = strtol(hp, nullptr, 10);
         if (v >= 0 && v <= 2) ctx->opt_host_path = v;
@@ -502,8 +508,9 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
         CREATE_TRY(upload(ctx, &ctx->dv4_tab_t, tab_t));
         CREATE_TRY(upload(ctx, &ctx->dv4_mags, mg));
         CREATE_TRY(upload(ctx, &ctx->dv4_dcf, v4.dcf_vals));
-        CREATE_HIP(hipMalloc((void **)&ctx->dv4_tick, 64));
-        CREATE_HIP(hipMemset(ctx->dv4_tick, 0, 64));
+        const size_t tick_bytes = (4 + (size_t)dsc->batch * (dsc->N - 1)) * sizeof(unsigned int);
+        CREATE_HIP(hipMalloc((void **)&ctx->dv4_tick, tick_bytes));
+        CREATE_HIP(hipMemset(ctx->dv4_tick, 0, tick_bytes));
     }
     // device error word, host-mapped: a kernel whose bounded wait gave up sets it; every evaluator entry point and pcl_sync look at it
     CREATE_HIP(hipHostMalloc((void **)&ctx->herr, 64, hipHostMallocMapped));
@@ -940,7 +947,7 @@ static int check_device_error(pcl_ctx *ctx, const char *where) {
     const int w = __atomic_load_n(ctx->herr, __ATOMIC_ACQUIRE);
     if (!w) return PCL_OK;
     __atomic_store_n(ctx->herr, 0, __ATOMIC_RELEASE);
-    if (ctx->dv4_tick) (void)hipMemsetAsync(ctx->dv4_tick, 0, 64, ctx->stream);  // the launch may have left its ticket words behind
+    if (ctx->dv4_tick) (void)hipMemsetAsync(ctx->dv4_tick, 0, (4 + (size_t)ctx->desc.batch * ctx->K) * sizeof(unsigned int), ctx->stream);  // the launch may have left its counters behind
     return fail(ctx, PCL_EINTERNAL, "%s: an earlier kernel of this context gave up a bounded wait between its waves (device error word 0x%x); "
                 "the outputs of that launch are incomplete", where, w);
 }
@@ -1203,18 +1210,22 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     // (compact launches -- unique tiles only, the chains are all of the work -- deal the intervals round-robin: a contiguous range that
     //  ends inside an interval runs that interval's chains in two workgroups; 62.2 against 66.8 us per 8 trajectories)
     p.contig = ctx->opt_cols_per_slice > 0 ? 0 : (ctx->opt_contig >= 0 ? (int)ctx->opt_contig : (!compact && bk * d >= 28 * ncu ? 1 : 0));
-    // TICKETS instead of a static split (launches of several trajectories; see the kernel's header): the front of addresses being written
-    // stays tight and the workgroups the memory side serves first take more work -- the time no longer depends on where the values
-    // array's pages live.  auto: wherever the static split would hand out contiguous ranges (an explicit contiguous / cols_per_slice wins).
-    const bool ticket = !compact && ctx->dv4_tick && ctx->opt_grid <= 0 &&
-                        (ctx->opt_v4_ticket == 1 || (ctx->opt_v4_ticket < 0 && p.contig && ctx->opt_contig < 0 && ctx->opt_cols_per_slice <= 0));
+    // SLICE TICKETS instead of a static split (launches of several trajectories; see the head of pcl_kernel_fused_sparse.hpp): groups of
+    // workgroups walk the intervals in a static order and take slices of a few state columns from the interval's own counter, each when
+    // the previous slice's stores are issued -- the front of addresses being written stays tight and the workgroups the memory side
+    // serves first take more slices: the time no longer depends on where the values array's pages live.
+    const int tick_G = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_v4_group > 0 ? ctx->opt_v4_group : 8, ncu));
+    const bool ticket = !compact && ctx->dv4_tick && ctx->opt_grid <= 0 && m + 10 <= 16 && ncu % tick_G == 0 &&
+                        v4_lds_bytes(d, m, np) + 8 * 8 * 128 <= (size_t)ctx->max_lds &&
+                        (ctx->opt_v4_ticket == 1 || (ctx->opt_v4_ticket < 0 && p.q <= 2 && p.contig && ctx->opt_contig < 0 && ctx->opt_cols_per_slice <= 0));
+    // (orders 6-10: the P wave's q products per visit are the longer chain -- 8 trajectories at order 8: 246-254 against 232 us)
     if (ticket) {
-        // state columns per block ticket: the P wave builds the item's q powers while the stream stores the previous item (a 3-column
-        // item is ~7 k cycles of stores, a product ~2 k): 3 columns up to order 4, 5 at order 6, 9 above
-        p.tick_cpi = ctx->opt_v4_ticket_cols > 0 ? (int)std::min<int64_t>(ctx->opt_v4_ticket_cols, d) : (p.q <= 2 ? std::min(3, d) : p.q == 3 ? std::min(5, d) : std::min(9, d));
+        p.tick_cpi = ctx->opt_v4_ticket_cols > 0 ? (int)std::min<int64_t>(ctx->opt_v4_ticket_cols, d) : std::min(3, d);
+        while ((d + p.tick_cpi - 1) / p.tick_cpi > 31) ++p.tick_cpi;  // (the slice index travels in five bits)
         p.tick = ctx->dv4_tick;
+        p.tick_G = tick_G;
+        p.tick_ahead = (int)ctx->opt_v4_ticket_ahead;
         p.contig = 0;
-        if ((bk * ((d + p.tick_cpi - 1) / p.tick_cpi)) > 0x3fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
     }
     ctx->last_v4_ticket = ticket ? p.tick_cpi : 0;
     if (p.contig)
@@ -1238,7 +1249,7 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     const long long units = p.contig ? bk * d : bk * p.S;
     if (units > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
     const long long g = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, units) : std::min<long long>(units, ncu);
-    const size_t lds = v4_lds_bytes(d, m, np);
+    const size_t lds = v4_lds_bytes(d, m, np) + (ticket ? 8 * 8 * 128 : 0);  // (+ the dispatcher's ring of controls and steps)
     // tiles of the ring in use: q - 1 when workgroups walk several items (the P wave must not run a whole item ahead: measured
     // 8 % on 8 trajectories per launch), all the module has for one-item launches (0.4 us there); option v4_power_tiles overrides
     p.v4_np = ctx->opt_v4_np > 0 ? (int)std::min<int64_t>(ctx->opt_v4_np, np) : ticket ? np : (units > g ? std::max(1, std::min(np, p.q - 1)) : std::min(np, p.q));
@@ -1255,7 +1266,7 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     const double *tab = ctx->dv4_tab + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_drift_pad : 0);
     const double *dcf = ctx->dv4_dcf + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_dcf_pad : 0);
     void *args[] = {(void *)&p, (void *)&tab, (void *)&ctx->dv4_mags, (void *)&dcf};
-    HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_f, (unsigned)g, 1, 1, 64 * (m + 9), 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
+    HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_f, (unsigned)g, 1, 1, 64 * (m + 9 + (ticket ? 1 : 0)), 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
     ctx->last_kernel = 40 + p.q;
     ctx->last_n_stream = 0;
     return PCL_OK;
@@ -2565,8 +2576,12 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_v4_flags = v;
     else if (!strcmp(key, "v4_ticket"))  // kernel 4: work items by ticket (-1 auto: full-value launches of several intervals per CU | 0 static split | 1)
         ctx->opt_v4_ticket = v < 0 ? -1 : (v != 0);
-    else if (!strcmp(key, "v4_ticket_cols"))  // ... state columns per block ticket (0 auto by order)
+    else if (!strcmp(key, "v4_ticket_cols"))  // ... state columns per slice ticket (0 auto: 3)
         ctx->opt_v4_ticket_cols = v < 0 ? 0 : v;
+    else if (!strcmp(key, "v4_ticket_ahead"))  // ... slices taken ahead of the one being stored (0 | 1)
+        ctx->opt_v4_ticket_ahead = v < 0 || v > 2 ? 0 : v;
+    else if (!strcmp(key, "v4_group"))  // ... workgroups per group (0 auto: 8; must divide the grid)
+        ctx->opt_v4_group = v < 0 ? 0 : v;
     else if (!strcmp(key, "v4_power_tiles"))  // kernel 4: LDS tiles the powers of G rotate through (0 auto: q - 1 for launches of several items per workgroup, else q)
         ctx->opt_v4_np = v < 0 ? 0 : v;
     else if (!strcmp(key, "v4_tail_mode")) {  // kernel 4: 0 writer wave, plain stores | 1 nontemporal | 2 write-through | 3 the stream waves store the tails
@@ -2665,6 +2680,10 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->opt_v4_ticket;
     else if (!strcmp(key, "v4_ticket_cols"))
         *v = ctx->opt_v4_ticket_cols;
+    else if (!strcmp(key, "v4_group"))
+        *v = ctx->opt_v4_group;
+    else if (!strcmp(key, "v4_ticket_ahead"))
+        *v = ctx->opt_v4_ticket_ahead;
     else if (!strcmp(key, "last_v4_ticket"))
         *v = ctx->last_v4_ticket;
     else if (!strcmp(key, "hess_kernel"))

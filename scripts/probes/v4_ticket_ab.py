@@ -23,7 +23,7 @@ c.set_stream(stream.cuda_stream)
 Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()
 dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
 bufs = [torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda") for _ in range(nbuf)]
-DEFAULTS = {"v4_ticket": -1, "v4_ticket_cols": 0, "v4_power_tiles": 0, "contiguous": -1, "v4_tail_mode": 3, "v4_flags": 0, "nt_stores": -1}
+DEFAULTS = {"v4_ticket": 0, "v4_group": 0, "v4_ticket_ahead": 0, "v4_ticket_cols": 0, "v4_power_tiles": 0, "contiguous": -1, "v4_tail_mode": 3, "v4_flags": 0, "nt_stores": -1}
 
 
 def apply(opts):

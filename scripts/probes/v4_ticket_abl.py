@@ -39,8 +39,7 @@ try:
         c.set_option("profile_flags", 0)
         print("static split: %.1f us" % t())
         c.set_option("v4_ticket", 1)
-        FL = ((0, "everything"), (4, "no chains"), (4 + 1024, "no chains, P loads cached"), (4 + 512, "no chains, P idle (tickets + block stores)"), (6, "no chains, no block stores"),
-              (2, "no block stores"), (1024, "P loads cached"))
+        FL = ((0, "everything"), (4, "no chains"), (8, "no tail stores"), (6, "no chains, no block stores"), (2, "no block stores"))
         for cols in colss:
             for np_ in (0, 2):
                 c.set_option("v4_ticket_cols", cols)

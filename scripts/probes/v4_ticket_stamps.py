@@ -13,7 +13,7 @@ pa.build_library(force=True, profile=True)
 try:
     system = synthetic.config_system(3)
     m = system.n_drives
-    roles = ["P", "W", "V"] + ["dW%d" % l for l in range(m)] + ["load", "write"] + ["str%d" % i for i in range(4)]
+    roles = ["P", "W", "V"] + ["dW%d" % l for l in range(m)] + ["load", "write"] + ["str%d" % i for i in range(4)] + ["disp"]
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         trajs = [synthetic.synthetic_trajectory(system, 100, seed=1000 + i) for i in range(B)]
@@ -30,7 +30,7 @@ try:
             c.set_option(k, int(v))
         W = 64 + 2 * 1024
         out = (ctypes.c_int64 * W)()
-        for flags in (0, 6):
+        for flags in (0,):
             c.set_option("debug_timing", 1)
             c.set_option("profile_flags", flags)
             for _ in range(3):

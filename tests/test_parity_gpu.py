@@ -922,6 +922,101 @@ def test_pattern_compiled_fused_kernel(order):
         c.close()
 
 
+def test_slice_tickets_equal_the_static_split():
+    """Kernel 4, launches of several trajectories: groups of workgroups + slice tickets (`v4_ticket`; `auto` at orders 2 and 4 wherever the
+    static split would hand out contiguous ranges) against the static split -- the same bits for every group size, slice width and
+    request time, at an order `auto` leaves static (8), on TRAJ batches and on an ensemble with per-member drifts and the fused reduce
+    payload; against the C oracle once; 60 launches in a row all equal (the counters are re-zeroed by the last pipeline out); a launch
+    with fewer intervals than groups."""
+    import torch
+
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    for Bn, order in ((8, 4), (4, 2), (4, 8)):
+        Zs = [po.synthetic_trajectory(so, 100, seed=900 + s)[0] for s in range(Bn)]
+        lay = po.synthetic_trajectory(so, 100, seed=900)[1]
+        c = make_ctx(lay, G0, Gj, batch=Bn, batch_mode=pa._lib.PCL_BATCH_TRAJ, pade_order=order)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        Zd = torch.from_numpy(np.stack(Zs)).cuda()
+        dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
+        out = torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")
+
+        def run(**opts):
+            for k, v in dict(v4_ticket=-1, v4_group=0, v4_ticket_cols=0, v4_ticket_ahead=2, contiguous=-1).items():
+                c.set_option(k, v)
+            for k, v in opts.items():
+                c.set_option(k, v)
+            dd.fill_(float("nan")), out.fill_(float("nan"))
+            c.eval_jac_dev(Zd, dd, out)
+            c.sync()
+            assert c.get_option("last_kernel") == 40 + order // 2
+            return dd.clone(), out.clone()
+
+        ref = run(v4_ticket=0)
+        assert c.get_option("last_v4_ticket") == 0
+        assert bool(torch.isfinite(ref[0]).all()) and bool(torch.isfinite(ref[1]).all())
+        if order == 4:  # against the C oracle, one trajectory of the batch
+            d_ref, j_ref = ref_lib.eval_jac(Zs[Bn - 1], lay, G0, Gj)
+            close(ref[0].cpu().numpy().reshape(Bn, -1)[-1], np.asarray(d_ref).reshape(-1))
+            close(ref[1].cpu().numpy().reshape(Bn, -1)[-1], np.asarray(j_ref).reshape(-1))
+        got = run()  # auto
+        assert (c.get_option("last_v4_ticket") > 0) == (order <= 4 and Bn * 99 * 27 >= 28 * c.get_option("n_cu"))
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        for opts in (dict(v4_ticket=1), dict(v4_ticket=1, v4_group=16), dict(v4_ticket=1, v4_group=4, v4_ticket_cols=5), dict(v4_ticket=1, v4_ticket_cols=1),
+                     dict(v4_ticket=1, v4_ticket_cols=27, v4_group=2), dict(v4_ticket=1, v4_ticket_ahead=0), dict(v4_ticket=1, v4_ticket_ahead=1, v4_ticket_cols=2)):
+            got = run(**opts)
+            assert c.get_option("last_v4_ticket") == opts.get("v4_ticket_cols", 3)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (Bn, order, opts)
+        if order == 4:
+            run(v4_ticket=1)
+            bad = torch.zeros((), dtype=torch.int64, device="cuda")
+            for _ in range(60):
+                c.eval_jac_dev(Zd, dd, out)
+                bad += (out != ref[1]).sum() + (dd != ref[0]).sum()
+            assert int(bad.item()) == 0
+            vals = torch.full_like(out, float("nan"))
+            c.jac_dev(Zd, vals)  # eval_jacobian alone
+            c.sync()
+            assert torch.equal(vals, ref[1])
+        c.close()
+    # fewer intervals than groups (2 trajectories of 5 knots: 8 intervals, 32 groups), tickets forced
+    Zs = [po.synthetic_trajectory(so, 5, seed=950 + s)[0] for s in range(2)]
+    lay = po.synthetic_trajectory(so, 5, seed=950)[1]
+    c = make_ctx(lay, G0, Gj, batch=2, batch_mode=pa._lib.PCL_BATCH_TRAJ)
+    Zh = np.stack(Zs)
+    c.set_option("v4_ticket", 0)
+    d0, v0 = c.eval_jac(Zh)
+    c.set_option("v4_ticket", 1)
+    d1, v1 = c.eval_jac(Zh)
+    assert c.get_option("last_v4_ticket") == 3 and np.array_equal(d0, d1) and np.array_equal(v0, v1)
+    for b in range(2):
+        close(d1.reshape(2, -1)[b], po.pade_residual(Zs[b], lay, G0, Gj, 4).reshape(-1), 1e-12)
+        close(v1.reshape(2, -1)[b], po.pade_jacobian_values(Zs[b], lay, G0, Gj, 4).reshape(-1), 1e-12)
+    c.close()
+    # an ensemble (per-member drifts: the less used drift classes stream through the chunk registers) with the reduce payload formed
+    # by the writer wave of whichever workgroup takes an interval's chains
+    osys, psys, lay, Z, traj = _config4_share(8, 100)
+    B = _fused_ensemble(psys, traj)
+    ce = B.ctx
+    ce.set_stream(torch.cuda.current_stream().cuda_stream)
+    Zd = torch.from_numpy(traj.datavec).cuda()
+    ln, _ = ce.merit_grad_len()
+    res = []
+    for tk in (0, 1, -1):
+        ce.set_option("v4_ticket", tk)
+        dd = torch.full((ce.n_rows,), float("nan"), dtype=torch.float64, device="cuda")
+        out = torch.full((ce.jac_nnz,), float("nan"), dtype=torch.float64, device="cuda")
+        pay = torch.full((ln,), float("nan"), dtype=torch.float64, device="cuda")
+        ce.eval_jac_merit_dev(Zd, None, dd, out, pay)
+        ce.sync()
+        assert ce.get_option("last_kernel") == 42 and ce.get_option("last_merit_fused") == 1 and (ce.get_option("last_v4_ticket") > 0) == (tk != 0)
+        res.append((dd, out, pay))
+    for r in res[1:]:
+        assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
+    B.close()
+
+
+
 def test_pattern_compiled_fused_kernel_soak():
     """Kernel 4 synchronises its waves through LDS counters with bounded waits (a wait that gives up writes NaN): 300 launches per
     shape of launch (one trajectory, four, compact, contiguous compact) -- every launch bitwise equal to the first, nothing NaN."""
