@@ -43,6 +43,10 @@ sys.path.insert(0, ROOT)
 # Host-side completion waits poll instead of sleeping on an interrupt: the timed region ends with a synchronize, and with K = 20
 # steps of 27 us an interrupt wake-up is a visible share of it (measured: 32.3 -> 31.8 us per step).  Must be set before HIP starts.
 os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+# Multi-process GPU work on this pool needs dmabuf IPC (the build environment's notes: without it RCCL / cross-process CUDA tensors fail with
+# `hipIpcGetMemHandle: invalid argument`); the launcher's environment normally carries it already.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s achievable
 
@@ -52,6 +56,14 @@ def algorithmic_bytes_per_eval(d, m, N, z_dim):
     n, xd, K = 2 * d, 2 * d * d, N - 1
     per_interval = z_dim * 8 + xd * 8 + (2 * d * n * n + xd * (m + 1)) * 8
     return per_interval * K
+
+
+def units_of_rank(total, rank, world):
+    """The units (multistart seeds / ensemble members) of BASELINE configs 4 / 5 this rank owns: unit b lives on rank b mod world
+    (piccolo.jl_amd.distributed.shard_indices)."""
+    from piccolo_jl_amd import distributed as pd
+
+    return pd.shard_indices(total, rank, world)
 
 
 def time_steps(launch, steps, warmup, torch, dist):
@@ -153,16 +165,20 @@ def main():
             " (persistent; 1 workgroup/CU; 4 MFMA waves + 4 store-stream waves; one barrier per item)" if lk // 10 == 3 else
             " (persistent; 2 workgroups/CU; 4 MFMA waves + 4 store-stream waves each)")  # fmt: skip
 
-    # multistart seeds s = 0..: default_rng(1000 + s)  (SURVEY 8(d)); this rank owns seeds rank*B .. rank*B+B-1
-    seeds = [synthetic.synthetic_trajectory(system, N, seed=1000 + rank * B + i) for i in range(B if (workload == "multistart" or world == 1) else 1)]
+    # multistart seeds s = 0..: default_rng(1000 + s)  (SURVEY 8(d)); this rank owns the seeds s with s mod world == rank
+    my_units = units_of_rank(B * world, rank, world)
+    seeds = [synthetic.synthetic_trajectory(system, N, seed=1000 + my_units[i]) for i in range(B if (workload == "multistart" or world == 1) else 1)]
+    NBUF = 8  # separately allocated values arrays the share measurements are taken on (the time of a static split depends on where the pages live)
     strong = world > 1 and workload in ("multistart", "ensemble") and args.batch <= 0  # the job's total is fixed (64): strong scaling
     t0 = seeds[0]
     abytes = algorithmic_bytes_per_eval(d, m, N, t0.dim)
 
-    def run_multistart(batch, steps, warmup, use_dist, order=4):
-        """`batch` independent trajectories in one launch per step (batch 1 = BASELINE config 3 strictly)."""
+    def run_multistart(batch, steps, warmup, use_dist, order=4, nbuf=1):
+        """`batch` independent trajectories in one launch per step (batch 1 = BASELINE config 3 strictly).  nbuf > 1: the same launch on
+        nbuf separately allocated values arrays, one after the other; returns the per-array times as info["per_buffer_us"] and the
+        MEDIAN array's (wall, device) times."""
         while len(seeds) < batch:
-            seeds.append(synthetic.synthetic_trajectory(system, N, seed=1000 + rank * batch + len(seeds)))
+            seeds.append(synthetic.synthetic_trajectory(system, N, seed=1000 + units_of_rank(batch * world, rank, world)[len(seeds)]))
         ms = pa.HipPadeMultistart(G0, Gj, t0, batch, device=local, pade_order=order)
         c = ms.ctx
         if args.cols_per_slice:
@@ -170,19 +186,24 @@ def main():
         c.set_stream(stream.cuda_stream)
         Zd = torch.from_numpy(np.stack([t.datavec for t in seeds[:batch]])).cuda()
         dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
-        vd = torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")
-        wall, dev = time_steps(lambda: c.eval_jac_dev(Zd, dd, vd), steps, warmup, torch, dist if use_dist else None)
+        vds = [torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda") for _ in range(max(1, nbuf))]
+        res = [time_steps(lambda vd=vd: c.eval_jac_dev(Zd, dd, vd), steps, warmup, torch, dist if use_dist else None) for vd in vds]
+        order_ = sorted(range(len(res)), key=lambda i: res[i][1])
+        wall, dev = res[order_[len(order_) // 2]]
         chk = float(dd.abs().max().item())
         assert np.isfinite(chk) and chk > 0
         info = dict(cols_per_slice=c.get_option("effective_cols_per_slice"), kernel_id=c.get_option("last_kernel"),
-                    stream_workgroups=c.get_option("last_stream_workgroups"))  # fmt: skip
+                    stream_workgroups=c.get_option("last_stream_workgroups"), slice_ticket_cols=c.get_option("last_v4_ticket"))  # fmt: skip
+        if nbuf > 1:
+            info["per_buffer_us"] = [r[1] / steps * 1e6 for r in res]
         ms.close()
-        del Zd, dd, vd
+        del Zd, dd, vds
         return wall, dev, info
 
-    def run_ensemble(M, steps, warmup, use_dist):
-        """Config 4 share: members rank*M .. rank*M+M-1 of the 64, shared controls, objective + reduce payload + all-reduce."""
-        members = synthetic.config4_members(rank * M, M)
+    def run_ensemble(M, steps, warmup, use_dist, nbuf=1):
+        """Config 4 share: the members i with i mod world == rank of the M * world, shared controls, objective + reduce payload + all-reduce.
+        nbuf > 1: as run_multistart."""
+        members = synthetic.config4_members(0, 0, indices=units_of_rank(M * world, rank, world))
         traj = synthetic.synthetic_ensemble(members, N, seed=20260929 + 4)  # the same shared controls on every rank
         Bs = pa.BilinearIntegrator(members, traj, device=local)
         core = Bs[0].ensemble
@@ -195,13 +216,14 @@ def main():
         J.bind(Bs)
         Zd = torch.from_numpy(traj.datavec).cuda()
         dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
-        vd = torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")
+        vds = [torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda") for _ in range(max(1, nbuf))]
+        vd = vds[0]
         ln, _ = c.merit_grad_len()
         payload = torch.empty(ln + 1, dtype=torch.float64, device="cuda")  # [objective | merit | J^T delta on u | on dt]
         grad = torch.empty(c.z_len, dtype=torch.float64, device="cuda")
         reduce_ = dist is not None and use_dist
 
-        def step():
+        def step(vd=vd):
             if args.separate_payload:  # A/B: the payload kernels read the tails back from HBM
                 J.value_and_gradient_dev(Zd, payload[:1], grad)
                 c.eval_jac_dev(Zd, dd, vd)
@@ -215,21 +237,25 @@ def main():
             if reduce_:
                 pd.reduce_payload(payload, dist)  # ONE sum all-reduce (RCCL over xGMI, on this stream): the one collective of the path
 
-        wall, dev = time_steps(step, steps, warmup, torch, dist if use_dist else None)
+        res = [time_steps(lambda vd=vd: step(vd), steps, warmup, torch, dist if use_dist else None) for vd in vds]
+        order_ = sorted(range(len(res)), key=lambda i: res[i][1])
+        wall, dev = res[order_[len(order_) // 2]]
         chk = payload.cpu().numpy()
         assert np.isfinite(chk).all() and chk[1] > 0
         info = dict(kernel_id=c.get_option("last_kernel"), stream_workgroups=c.get_option("last_stream_workgroups"),
                     payload_bytes=int(payload.numel() * 8), all_reduce=bool(reduce_), z_dim=int(traj.dim),
                     payload_fused=bool(c.get_option("last_merit_fused")) and not args.separate_payload,
                     launches_per_step=(5 if args.separate_payload else 4) if (args.separate_payload or args.separate_objective) else int(c.get_option("last_step_launches")),
-                    objective=float(chk[0]), merit=float(chk[1]))  # fmt: skip
+                    objective=float(chk[0]), merit=float(chk[1]), slice_ticket_cols=c.get_option("last_v4_ticket"))  # fmt: skip
+        if nbuf > 1:
+            info["per_buffer_us"] = [r[1] / steps * 1e6 for r in res]
         if reduce_:  # the collective alone (same payload, same stream), barrier-bracketed like the step
             wr, dr = time_steps(lambda: pd.reduce_payload(payload, dist), steps, min(warmup, 5), torch, dist)
             info["all_reduce_us"] = dr / steps * 1e6
             info["rccl_ranks"] = int(dist.get_world_size())
         for b in Bs:
             b.close()
-        del Zd, dd, vd, grad
+        del Zd, dd, vd, vds, grad
         return wall, dev, info, abytes - t0.dim * 8 * (N - 1) + traj.dim * 8 * (N - 1) // M  # bytes per member eval (Z shared by M members)
 
     units = 1 if workload == "single" else B
@@ -292,6 +318,8 @@ def main():
                                  "members_total": B * world, "payload_bytes": ie["payload_bytes"], "all_reduce": ie["all_reduce"],
                                  "rccl_ranks": ie.get("rccl_ranks"), "all_reduce_us": ie.get("all_reduce_us"), "payload_fused": ie["payload_fused"], "launches_per_step": ie["launches_per_step"],
                                  "note": "config 4: fused residual+Jacobian of this rank's members + objective + payload, then ONE RCCL sum all-reduce; max over ranks"}  # fmt: skip
+    if world > 1:  # ranks the one collective of the path ran over (the ensemble step's all-reduce), at the top level of the line
+        out["rccl_ranks"] = (out.get("ensemble_share") or {}).get("rccl_ranks") or info.get("rccl_ranks") or int(dist.get_world_size())
     kernel_s = dev / args.steps  # HIP events on the launch stream around the K back-to-back steps
     out["roofline"] = {
         "bound": "hbm",
@@ -318,20 +346,24 @@ def main():
 
     if rank == 0 and world == 1 and args.workload == "auto" and not args.no_shares:
         st = max(20, min(args.steps, 100))
-        w8, d8, i8 = run_multistart(B, st, 20, False)
-        out["multistart_share"] = {"evals_per_s": B * st / w8, "us_per_launch_kernel": d8 / st * 1e6, "seeds_per_launch": B,
+        def spread(info):  # min / median / max over the separately allocated values arrays
+            t = sorted(info.get("per_buffer_us", []))
+            return {"buffers": len(t), "us_min": t[0], "us_median": t[len(t) // 2], "us_max": t[-1]} if t else {}
+
+        w8, d8, i8 = run_multistart(B, st, 20, False, nbuf=NBUF)
+        out["multistart_share"] = {"evals_per_s": B * st / w8, "us_per_launch_kernel": d8 / st * 1e6, "seeds_per_launch": B, **spread(i8), "slice_ticket_cols": i8["slice_ticket_cols"],
                                    "hbm_GBps": abytes * B / (d8 / st) / 1e9, "frac_of_hbm_peak": abytes * B / (d8 / st) / 1e9 / HBM_PEAK_GBS,
                                    "kernel": describe(i8["kernel_id"], i8["stream_workgroups"])}  # fmt: skip
-        we, de, ie, ub = run_ensemble(B, st, 20, False)
-        out["ensemble_share"] = {"evals_per_s": B * st / we, "us_per_step_kernel": de / st * 1e6, "members_per_step": B,
+        we, de, ie, ub = run_ensemble(B, st, 20, False, nbuf=NBUF)
+        out["ensemble_share"] = {"evals_per_s": B * st / we, "us_per_step_kernel": de / st * 1e6, "members_per_step": B, **spread(ie), "slice_ticket_cols": ie["slice_ticket_cols"],
                                  "hbm_GBps": ub * B / (de / st) / 1e9, "payload_bytes": ie["payload_bytes"], "all_reduce": ie["all_reduce"],
                                  "payload_fused": ie["payload_fused"], "launches_per_step": ie["launches_per_step"],
                                  "note": "config 4 share on one GPU: the step of the N > 1 default workload without the all-reduce"}  # fmt: skip
     if rank == 0 and world == 1 and args.workload == "auto" and not args.no_shares:
         # config 5 whole (64 seeds) on this one GPU in one launch: the N = 1 point of the multistart scaling curve
         T = args.total_units
-        w64, d64, i64 = run_multistart(T, 10, 3, False)
-        out["multistart_64"] = {"evals_per_s": T * 10 / w64, "us_per_launch_kernel": d64 / 10 * 1e6, "seeds_per_launch": T,
+        w64, d64, i64 = run_multistart(T, 10, 3, False, nbuf=NBUF)
+        out["multistart_64"] = {"evals_per_s": T * 10 / w64, "us_per_launch_kernel": d64 / 10 * 1e6, "seeds_per_launch": T, **spread(i64), "slice_ticket_cols": i64["slice_ticket_cols"],
                                 "frac_of_hbm_peak": abytes * T / (d64 / 10) / 1e9 / HBM_PEAK_GBS,
                                 "note": "the value an N-GPU run of this script reports is the same 64 seeds with 64 / N per GPU"}
     if rank == 0 and world == 1 and not args.no_extras:

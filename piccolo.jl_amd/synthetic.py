@@ -41,8 +41,8 @@ def synthetic_trajectory(system, N, seed, dt=0.1, u_scale=0.02, noise=1e-3):
     return NamedTrajectory(comps, controls=("ddu", "Δt"), timestep="Δt")
 
 
-def config4_members(first, count):
-    """Members first..first+count-1 of BASELINE config 4: H_drift_i = H_drift + eps_i * 2 pi * sum_q a_q' a_q,
+def config4_members(first, count, indices=None):
+    """Members first..first+count-1 (or the members `indices`: a rank's round-robin share) of BASELINE config 4: H_drift_i = H_drift + eps_i * 2 pi * sum_q a_q' a_q,
     eps_i ~ U(-1e-3, 1e-3) GHz from default_rng(2000 + i) -- a frequency-drift perturbation in the spirit of
     [REF docs/literate/robust_control.jl:82-83].  The drive Hamiltonians are shared."""
     from .quantum import annihilate, lift_operator
@@ -52,7 +52,7 @@ def config4_members(first, count):
     a = annihilate(lv[0])
     num = sum(lift_operator(a.conj().T @ a, q, lv) for q in range(1, len(lv) + 1))
     out = []
-    for i in range(first, first + count):
+    for i in (indices if indices is not None else range(first, first + count)):
         eps = np.random.default_rng(2000 + i).uniform(-1e-3, 1e-3)
         out.append(QuantumSystem(base.H_drift + eps * 2 * np.pi * num, base.H_drives, base.drive_bounds))
     return out

@@ -134,3 +134,28 @@ def test_single_process_reduce_is_identity():
     phi, gu, gdt = torch.tensor(2.0, dtype=torch.float64), torch.ones(3, 2, dtype=torch.float64), torch.zeros(3, dtype=torch.float64)
     a, b, c = pd.reduce_merit_and_gradient(phi, gu, gdt, None)
     assert a.item() == 2.0 and torch.equal(b, gu) and torch.equal(c, gdt)
+
+
+def test_every_unit_has_exactly_one_rank():
+    """BASELINE configs 4 / 5: 64 members / seeds over 1, 2, 4, 8 ranks -- unit b on rank b mod world, the
+    ranks' shares are disjoint, equal in size and cover 0..63; bench.py shards with the same function."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for world in (1, 2, 4, 8):
+        shares = [pd.shard_indices(64, r, world) for r in range(world)]
+        assert sorted(u for s in shares for u in s) == list(range(64))
+        assert all(len(s) == 64 // world for s in shares)
+        assert all(u % world == r for r, s in enumerate(shares) for u in s)
+        assert [bench.units_of_rank(64, r, world) for r in range(world)] == shares
+    with pytest.raises(ValueError):
+        pd.shard_indices(64, 8, 8)
+    # the members a rank builds are those of its share (per-member perturbations are seeded by the member's index)
+    from piccolo_jl_amd import synthetic
+
+    a = synthetic.config4_members(0, 0, indices=[1, 9])
+    b = synthetic.config4_members(1, 1) + synthetic.config4_members(9, 1)
+    assert all(np.array_equal(x.G_drift, y.G_drift) for x, y in zip(a, b))
