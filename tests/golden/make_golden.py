@@ -12,8 +12,9 @@ does not exist on the GPU box).  Two kinds of fixture:
    convention through the reference's own exp constraint
    [REF docs/src/concepts/index.md:21].
 2. ``vec_<name>.npz`` -- seeded inputs (Z, G0, Gj, mu) and the numpy oracle's
-   outputs (delta, Jacobian values, Hessian values) for the Pade-4 evaluator,
-   in the triplet orders documented in include/piccolo_hip.h.
+   outputs (delta, Jacobian values, Hessian values) for the Pade-4 evaluator
+   and for orders 8 and 10 (``delta8 / jac8 / hess8``, ``... 10``), in the
+   triplet orders documented in include/piccolo_hip.h.
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -73,6 +74,14 @@ def oracle_vectors():
             jac=po.pade_jacobian_values(Z, lay, G0, Gj, 4),
             hess=po.pade4_hessian_values(Z, mu, lay, G0, Gj),
             delta6=po.pade_residual(Z, lay, G0, Gj, 6),
+            # the orders that reach the reference's exp constraint at config 3: what the shipped default kernels
+            # (pattern-compiled 44 / 45 / 74 / 75, small-system 54 / 55) are compared with in tests/test_parity_gpu.py
+            delta8=po.pade_residual(Z, lay, G0, Gj, 8),
+            jac8=po.pade_jacobian_values(Z, lay, G0, Gj, 8),
+            hess8=po.pade_hessian_values(Z, mu, lay, G0, Gj, 8),
+            delta10=po.pade_residual(Z, lay, G0, Gj, 10),
+            jac10=po.pade_jacobian_values(Z, lay, G0, Gj, 10),
+            hess10=po.pade_hessian_values(Z, mu, lay, G0, Gj, 10),
         )
         meta[name] = dict(config=cfg, d=lay.d, m=lay.m, N=N, z_dim=lay.z_dim, x_off=lay.x_off, u_off=lay.u_off, dt_off=lay.dt_off)
     return meta

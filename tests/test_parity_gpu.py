@@ -55,7 +55,8 @@ def make_ctx(lay, G0, Gj, **kw):
 # kernel variants: (kernel_version, use_mfma).  (3,1) is the default: one persistent, wave-specialised,
 # software-pipelined workgroup per CU; (2,1) persistent, 2 workgroups per CU (fallback); (1,1) the
 # single-role MFMA kernel, (1,0) the plain-VALU kernel.
-VARIANTS = [(2, 1), (3, 1), (1, 1), (1, 0)]
+# (0, 1) is `auto`: what ships -- the pattern-compiled kernel 4 at config 3, the small-system kernel at configs 1 and 2.
+VARIANTS = [(2, 1), (3, 1), (1, 1), (1, 0), (0, 1)]
 
 
 def set_variant(c, variant):
@@ -82,6 +83,29 @@ def test_golden_vectors(name, variant, host_path, golden, golden_meta):
     c.close()
 
 
+@pytest.mark.parametrize("name", ["config1", "config2", "config3"])
+@pytest.mark.parametrize("order", [8, 10])
+@pytest.mark.parametrize("host_path", [1, 2])
+def test_golden_vectors_orders_8_and_10(name, order, host_path, golden, golden_meta):
+    """The committed order-8 and order-10 vectors (the orders that reach the reference's exp constraint at config 3) through the kernels
+    `auto` launches: pattern-compiled residual + Jacobian 44 / 45 and Hessian 74 / 75 at config 3, the small-system kernel at 1 and 2."""
+    v = golden("vec_" + name)
+    m = golden_meta["oracle_vectors"][name]
+    lay = po.Layout(d=m["d"], m=m["m"], N=m["N"], z_dim=m["z_dim"], x_off=m["x_off"], u_off=m["u_off"], dt_off=m["dt_off"])
+    c = make_ctx(lay, v["G0"], v["Gj"], host_path=host_path, pade_order=order)
+    delta, vals = c.eval_jac(v["Z"])
+    if name == "config3":
+        assert c.get_option("last_kernel") == 40 + order // 2
+    close(delta, v["delta%d" % order], 1e-12)
+    close(vals, v["jac%d" % order], 1e-12)
+    close(c.eval(v["Z"]), v["delta%d" % order], 1e-12)
+    close(c.jac(v["Z"]), v["jac%d" % order], 1e-12)
+    close(c.hess(v["Z"], v["mu"]), v["hess%d" % order], 1e-11)
+    if name == "config3":
+        assert c.get_option("last_hess_kernel") == 70 + order // 2
+    c.close()
+
+
 # ---- seeded inputs vs the oracle, every slicing of the state columns ------------------------------
 @pytest.mark.parametrize("cfg,N", [(1, 50), (2, 100), (3, 5)])
 def test_seeded_vs_oracle_all_slicings(cfg, N):
@@ -91,7 +115,7 @@ def test_seeded_vs_oracle_all_slicings(cfg, N):
     G0, Gj = so.G_drift, np.array(so.G_drives)
     d_ref, j_ref = ref_lib.eval_jac(Z, lay, G0, Gj)
     c = make_ctx(lay, G0, Gj)
-    for variant in VARIANTS[:4]:
+    for variant in VARIANTS:
         set_variant(c, variant)
         for nc in sorted({0, 1, 2, 3, 5, lay.d}):
             if nc > lay.d:
@@ -1014,6 +1038,42 @@ def test_slice_tickets_equal_the_static_split():
     for r in res[1:]:
         assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
     B.close()
+
+
+
+def test_multistart_64_equals_64_single_launches():
+    """BASELINE config 5 whole on one GPU -- 64 seeds in ONE launch (8.5 GB of values; the N = 1 point of the scaling curve, slice
+    tickets) -- against 64 launches of one trajectory each (static split), compared on the device, bitwise: a lane's arithmetic depends
+    on its state column only.  One seed against the C oracle."""
+    import torch
+
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    T = 64
+    Zs = [po.synthetic_trajectory(so, 100, seed=1000 + s)[0] for s in range(T)]
+    lay = po.synthetic_trajectory(so, 100, seed=1000)[1]
+    c64 = make_ctx(lay, G0, Gj, batch=T, batch_mode=pa._lib.PCL_BATCH_TRAJ)
+    c1 = make_ctx(lay, G0, Gj, batch=1, batch_mode=pa._lib.PCL_BATCH_TRAJ)
+    st = torch.cuda.current_stream().cuda_stream
+    c64.set_stream(st), c1.set_stream(st)
+    Zd = torch.from_numpy(np.stack(Zs)).cuda()
+    dd = torch.full((c64.n_rows,), float("nan"), dtype=torch.float64, device="cuda")
+    out = torch.full((c64.jac_nnz,), float("nan"), dtype=torch.float64, device="cuda")
+    c64.eval_jac_dev(Zd, dd, out)
+    c64.sync()
+    assert c64.get_option("last_kernel") == 42 and c64.get_option("last_v4_ticket") > 0
+    d1 = torch.empty(c1.n_rows, dtype=torch.float64, device="cuda")
+    o1 = torch.empty(c1.jac_nnz, dtype=torch.float64, device="cuda")
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")
+    for s_ in range(T):
+        c1.eval_jac_dev(Zd[s_], d1, o1)
+        bad += (out.view(T, -1)[s_] != o1).sum() + (dd.view(T, -1)[s_] != d1).sum()
+    c1.sync()
+    assert c1.get_option("last_v4_ticket") == 0 and int(bad.item()) == 0
+    d_ref, j_ref = ref_lib.eval_jac(Zs[37], lay, G0, Gj)
+    close(dd.view(T, -1)[37].cpu().numpy(), np.asarray(d_ref).reshape(-1))
+    close(out.view(T, -1)[37].cpu().numpy(), np.asarray(j_ref).reshape(-1))
+    c64.close(), c1.close()
 
 
 
