@@ -188,11 +188,23 @@ __device__ __forceinline__ double wave_sum_strided_fwd(const double *__restrict_
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     return s;  // valid in lane 0
 }
+// HARDWARE ASSUMPTION of the "light" arrivals (here, in pcl_merit_finish_body and in the sc0 sc1 exchange of pcl_hess_sparse4): data published
+// with a relaxed agent-scope atomic store (lowered to a write-through `sc1` store on gfx942 / gfx950), then `s_waitcnt vmcnt(0)`, then a
+// RELAXED ticket RMW -- no release.  Under the HIP / HSA memory model that is a data race; it is correct on gfx942 / gfx950 because an sc1
+// store is performed at the memory side (past the XCD's L2) once vmcnt has counted it, the ticket RMW is performed there too and the reader
+// loads with agent scope (sc1: L1 bypassed).  Gated below: any other target takes the acquire-release ticket.  Looped against the
+// two-launch result in tests/test_parity_gpu.py (test_ensemble_step_in_two_launches_equals_the_separate_calls).
+#if defined(__gfx950__) || defined(__gfx942__)
+#define PCL_LIGHT_ARRIVALS 1
+#else
+#define PCL_LIGHT_ARRIVALS 0
+#endif
 // light: the arriver has published its one value with an agent-scope atomic store (thread 0) and waits for that store alone -- a release
 // at agent scope writes the XCD's whole L2 back, and the regulariser workgroups (a hundred of them, each with a fresh gradient row in
 // the L2) would do so one after the other: 40 us for the launch instead of 10
 __device__ __forceinline__ void objective_finish(const PclObjSum &fin, const double *member, double *red, bool light = false) {
     if (!fin.out) return;
+    light = light && PCL_LIGHT_ARRIVALS;
     __syncthreads();  // this workgroup's member[b] (thread 0) is written
     __shared__ int last;
     if (threadIdx.x == 0) {

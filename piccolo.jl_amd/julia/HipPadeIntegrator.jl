@@ -321,8 +321,17 @@ function _bind_to_directtrajopt!()
     end
     for nm in (:hessian_of_lagrangian!, :eval_hessian_of_lagrangian!, :hessian_of_lagrangian_values!)
         isdefined(DirectTrajOpt, nm) || continue
-        @eval DirectTrajOpt.$nm(vals::AbstractVector{Float64}, B::HipPadeIntegrator, traj, μ::AbstractVector{Float64}, args...) =
-            eval_hessian_of_lagrangian!(vals isa Vector{Float64} ? vals : (vals .= vals; vals), B, Vector{Float64}($z_of(traj)), Vector{Float64}(μ))
+        @eval function DirectTrajOpt.$nm(vals::AbstractVector{Float64}, B::HipPadeIntegrator, traj, μ::AbstractVector{Float64}, args...)
+            # the C entry point fills a dense Vector{Float64}: a view (or any other AbstractVector) is filled through a temporary
+            if vals isa Vector{Float64}
+                eval_hessian_of_lagrangian!(vals, B, Vector{Float64}($z_of(traj)), Vector{Float64}(μ))
+            else
+                tmp = Vector{Float64}(undef, length(vals))
+                eval_hessian_of_lagrangian!(tmp, B, Vector{Float64}($z_of(traj)), Vector{Float64}(μ))
+                copyto!(vals, tmp)
+            end
+            return nothing
+        end
         push!(BOUND_GENERICS, nm)
     end
     for nm in (:hessian_of_lagrangian, :eval_hessian_of_lagrangian)

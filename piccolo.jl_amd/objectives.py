@@ -102,9 +102,11 @@ class Objective:
         if len(members) > 1 and not shared and any(hasattr(b, "ensemble") for b in members):
             raise ValueError("the integrator list mixes members of different ensembles")
         if shared:
+            # any member (or sub-list) of an ensemble binds the ONE batched context all members share; an infidelity term then has to
+            # name every member's state (checked below) -- regulariser-only objectives need no more than the context
             core = members[0].ensemble
-            if len(members) != core.M:
-                raise ValueError("%d integrators of an ensemble of %d members" % (len(members), core.M))
+            if inf and len(members) != core.M:
+                raise ValueError("the infidelity term needs the whole ensemble: %d integrators of %d members" % (len(members), core.M))
             ctxs = [core.ctx]
         else:
             ctxs = [b.ctx for b in members]
@@ -136,7 +138,8 @@ class Objective:
                     ctx.set_weights(None)
                     w_host = 1.0 if t.weights is None else float(t.weights[i])
                 self._Q = t.Q
-            self._bound.append((ctx, w_host))
+            if inf or i == 0:  # (a context that carries no term -- regularisers live on the first one -- is not evaluated)
+                self._bound.append((ctx, w_host))
         self._ctx = ctxs[0]
         return self
 
@@ -150,7 +153,7 @@ class Objective:
             return (float(v[0]) if v.size == 1 else v), g
         # independent contexts: member i contributes w_i Q |1 - F_i| (+ the regularisers, registered on member 0 only)
         total, grad = 0.0, None
-        for i, (ctx, w) in enumerate(self._bound):
+        for ctx, w in self._bound:
             v, g = ctx.objective(Z, self._Q * w, want_grad)
             total += float(v[0])
             if want_grad:
