@@ -15,10 +15,10 @@ SO_PATH = os.path.join(CSRC, "libpiccolo_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 PCL_OK = 0
-PCL_EINVAL, PCL_ENOMEM, PCL_EHIP, PCL_ERCCL, PCL_ESHAPE, PCL_ENOTIMPL = -1, -2, -3, -4, -5, -6
+PCL_EINVAL, PCL_ENOMEM, PCL_EHIP, PCL_ERCCL, PCL_ESHAPE, PCL_ENOTIMPL, PCL_EINTERNAL = -1, -2, -3, -4, -5, -6, -7
 PCL_BATCH_MEMBERS, PCL_BATCH_TRAJ = 0, 1
 PCL_STATE_VECTOR = -1  # pcl_desc.state_cols: general real d x d generator on one real column (compact density vectors)
-_STATUS_NAMES = {0: "PCL_OK", -1: "PCL_EINVAL", -2: "PCL_ENOMEM", -3: "PCL_EHIP", -4: "PCL_ERCCL", -5: "PCL_ESHAPE", -6: "PCL_ENOTIMPL"}
+_STATUS_NAMES = {0: "PCL_OK", -1: "PCL_EINVAL", -2: "PCL_ENOMEM", -3: "PCL_EHIP", -4: "PCL_ERCCL", -5: "PCL_ESHAPE", -6: "PCL_ENOTIMPL", -7: "PCL_EINTERNAL"}
 
 # every symbol include/piccolo_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
@@ -34,7 +34,7 @@ EXPORTS = [
     "pcl_rollout", "pcl_rollout_dev",
     "pcl_comm_get_unique_id", "pcl_comm_init", "pcl_reduce_sum_dev", "pcl_reduce_sum", "pcl_comm_destroy",
     "pcl_set_option", "pcl_get_option", "pcl_debug_timing", "pcl_codegen_source",
-    "pcl_codegen_source_v4", "pcl_codegen_apply_v4",
+    "pcl_codegen_source_v4", "pcl_codegen_apply_v4", "pcl_jit_prebuild",
 ]  # fmt: skip
 
 
@@ -192,3 +192,27 @@ def load():
     L.pcl_codegen_apply_v4.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int]
     _lib = L
     return L
+
+
+def prebuild_kernels(G_drifts, G_drives, orders=(4,), hessian=True, out_dir=None):
+    """Compile the pattern-compiled modules a context of this system (one drift, or the per-member drifts of an ensemble) would compile
+    with hiprtc on first use, into ``csrc/prebuilt/`` (or ``out_dir``) under their content hashes -- a fresh process (every rank of a job)
+    then loads them instead of compiling.  No device needed.  Returns the number of modules asked for."""
+    import numpy as np
+
+    L = load()
+    G0 = np.ascontiguousarray(np.stack([np.asarray(g, dtype=np.float64).T for g in (G_drifts if np.ndim(G_drifts) == 3 else [G_drifts])]))
+    Gj = np.ascontiguousarray(np.stack([np.asarray(g, dtype=np.float64).T for g in G_drives])) if len(G_drives) else np.zeros((0, 1, 1))
+    n = G0.shape[-1]
+    d, m = n // 2, len(G_drives)
+    od = out_dir.encode() if out_dir else None
+    L.pcl_jit_prebuild.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    count = 0
+    for order in orders:
+        whats = [0] + (([3] if order == 4 else []) + [1, 2] if hessian else [])
+        for what in whats:
+            rc = L.pcl_jit_prebuild(d, m, G0.ctypes.data, G0.shape[0], Gj.ctypes.data if m else None, order // 2, what, od)
+            if rc != 0:
+                raise PclError(rc, L.pcl_last_error(None).decode())
+            count += 1
+    return count

@@ -22,6 +22,8 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "piccolo_hip.h"
 #include "pcl_codegen.hpp"
@@ -150,6 +152,8 @@ struct pcl_ctx {
     double *dgrad = nullptr, *dval = nullptr;  // staging of the host-pointer objective call
     int64_t opt_specialize = 1;
     int64_t opt_jit = 1;      // compile shape-specialised instances on first use (hiprtc) for shapes outside the static table
+    int64_t opt_require_jit = 0;  // 1: a pattern-compiled kernel that cannot be had (no libhiprtc, no headers, compile error) is an error, not a fallback
+    int64_t jit_fallbacks = 0;    // pattern-compiled kernels this context wanted and did not get (the matrix-core / general kernels serve it)
     int64_t opt_general = 0;  // 1: run the general-order kernel also for pade_order 4 (cross-check)
     int64_t opt_contig = -1;     // v3: contiguous column ranges per workgroup (-1: auto by launch size)
     int64_t opt_stream_wg = -1;  // v3, contiguous: stream-role workgroups (-1: auto = half, 0: every workgroup does both)
@@ -703,12 +707,78 @@ struct HiprtcApi {
     int (*GetProgramLogSize)(void *, size_t *) = nullptr;
     int (*GetProgramLog)(void *, char *) = nullptr;
     int (*DestroyProgram)(void **) = nullptr;
+    int (*Version)(int *, int *) = nullptr;
 };
 std::mutex g_jit_mutex;
 std::map<std::string, JitKernel> g_jit;  // key: device | template instance
 HiprtcApi g_rtc;
-int64_t g_jit_compiles = 0;
+int64_t g_jit_compiles = 0, g_jit_cache_hits = 0, g_jit_fallbacks = 0;
 std::string g_jit_note;
+
+// ---- persistent code objects --------------------------------------------------------------------------------------------------
+// A compiled module is kept on disk under the hash of everything it was compiled from (generated source, the kernel headers it
+// includes, the compiler options, the hiprtc version): <library dir>/prebuilt/<hash>.hsaco (written by pcl_jit_prebuild -- what
+// __graft_entry__.build() fills for the BASELINE configs; travels with the library) is looked at first, then the user's cache
+// ($PCL_JIT_CACHE_DIR, else $XDG_CACHE_HOME/piccolo_hip, else ~/.cache/piccolo_hip), which every run-time compilation also writes
+// (temporary file + rename: ranks of one job may compile the same module at the same time).  PCL_JIT_CACHE=0 switches both off.
+struct Hash128 {
+    uint64_t a = 0xcbf29ce484222325ull, b = 0x84222325cbf29ce4ull;
+    void add(const void *p_, size_t n) {
+        const unsigned char *p = (const unsigned char *)p_;
+        for (size_t i = 0; i < n; ++i) {
+            a = (a ^ p[i]) * 0x100000001b3ull;
+            b = (b ^ p[i]) * 0x9e3779b97f4a7c15ull + (b >> 29);
+        }
+    }
+    void add(const std::string &x) {
+        add(x.data(), x.size());
+        const unsigned char z = 0;
+        add(&z, 1);
+    }
+    std::string hex() const {
+        char buf[40];
+        snprintf(buf, sizeof buf, "%016llx%016llx", (unsigned long long)a, (unsigned long long)b);
+        return buf;
+    }
+};
+bool cache_enabled() {
+    const char *e = getenv("PCL_JIT_CACHE");
+    return !(e && e[0] == '0');
+}
+std::string user_cache_dir() {
+    if (const char *e = getenv("PCL_JIT_CACHE_DIR")) return e;
+    if (const char *x = getenv("XDG_CACHE_HOME"))
+        if (x[0]) return std::string(x) + "/piccolo_hip";
+    if (const char *h = getenv("HOME"))
+        if (h[0]) return std::string(h) + "/.cache/piccolo_hip";
+    return "/tmp/piccolo_hip_cache";
+}
+bool read_file(const std::string &path, std::vector<char> &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    out.clear();
+    char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.insert(out.end(), buf, buf + n);
+    fclose(f);
+    return !out.empty();
+}
+void mkdir_p(const std::string &dir);
+bool write_file_atomic(const std::string &dir, const std::string &name, const std::vector<char> &data) {
+    mkdir_p(dir);
+    char tmpl[64];
+    snprintf(tmpl, sizeof tmpl, ".tmp.%ld.%p", (long)getpid(), (const void *)&data);
+    const std::string tmp = dir + "/" + name + tmpl, fin = dir + "/" + name;
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), fin.c_str()) != 0) {
+        remove(tmp.c_str());
+        return false;
+    }
+    return true;
+}
 
 bool rtc_load() {
     if (g_rtc.h) return true;
@@ -730,6 +800,7 @@ bool rtc_load() {
     RTC_SYM(GetProgramLogSize, "hiprtcGetProgramLogSize");
     RTC_SYM(GetProgramLog, "hiprtcGetProgramLog");
     RTC_SYM(DestroyProgram, "hiprtcDestroyProgram");
+    RTC_SYM(Version, "hiprtcVersion");
 #undef RTC_SYM
     if (!a.CreateProgram || !a.AddNameExpression || !a.CompileProgram || !a.GetLoweredName || !a.GetCodeSize || !a.GetCode || !a.DestroyProgram) {
         g_jit_note = "libhiprtc lacks the expected symbols";
@@ -750,6 +821,77 @@ bool slurp(const std::string &path, std::string &out) {
     return !out.empty();
 }
 
+
+void mkdir_p(const std::string &dir) {
+    for (size_t i = 1; i <= dir.size(); ++i)
+        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0777);
+}
+#ifdef PCL_PROFILE
+static const char *const kJitOpts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-DPCL_PROFILE"};
+#else
+static const char *const kJitOpts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+#endif
+std::string jit_cache_key(const std::string &source, const std::string *hdr, int nh, const char *name_expr) {
+    Hash128 h;
+    h.add(std::string("pcl-jit-1"));
+    h.add(source);
+    for (int i = 0; i < nh; ++i) h.add(hdr[i]);
+    for (const char *o : kJitOpts) h.add(std::string(o));
+    h.add(std::string(name_expr ? name_expr : ""));
+    int ver = 0;
+    (void)hipRuntimeGetVersion(&ver);  // the ROCm release (hiprtc ships with it); asked of the runtime that is loaded anyway -- a cache hit never opens libhiprtc
+    h.add(std::to_string(ver));
+    return h.hex();
+}
+// on disk: "PCLJ" | uint32 length of the kernel's (lowered) name | name | code object
+std::vector<char> pack_module(const std::vector<char> &code, const std::string &lname) {
+    std::vector<char> out;
+    const uint32_t n = (uint32_t)lname.size();
+    out.insert(out.end(), {'P', 'C', 'L', 'J'});
+    out.insert(out.end(), (const char *)&n, (const char *)&n + 4);
+    out.insert(out.end(), lname.begin(), lname.end());
+    out.insert(out.end(), code.begin(), code.end());
+    return out;
+}
+bool unpack_module(const std::vector<char> &blob, std::vector<char> &code, std::string &lname, bool plain_name) {
+    if (blob.size() < 8 || memcmp(blob.data(), "PCLJ", 4) != 0) return false;
+    uint32_t n;
+    memcpy(&n, blob.data() + 4, 4);
+    if (blob.size() < 8 + (size_t)n + 16) return false;
+    if (!plain_name) lname.assign(blob.data() + 8, n);
+    code.assign(blob.begin() + 8 + n, blob.end());
+    return true;
+}
+bool rtc_compile(const std::string &source, const char **hdrp, const char *const *names, int nh, const char *name_expr, bool plain_name, const std::string &what,
+                 std::vector<char> &code, std::string &lname) {
+    void *prog = nullptr;
+    if (g_rtc.CreateProgram(&prog, source.c_str(), "pcl_jit.hip", nh, hdrp, (const char **)names) != 0) {
+        g_jit_note = "hiprtcCreateProgram failed";
+        return false;
+    }
+    if (!plain_name) g_rtc.AddNameExpression(prog, name_expr);
+    if (g_rtc.CompileProgram(prog, (int)(sizeof kJitOpts / sizeof kJitOpts[0]), (const char **)kJitOpts) != 0) {
+        size_t ls = 0;
+        g_jit_note = std::string("hiprtcCompileProgram failed for ") + what;
+        if (g_rtc.GetProgramLogSize && g_rtc.GetProgramLog && g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
+            std::string log(ls, '\0');
+            g_rtc.GetProgramLog(prog, &log[0]);
+            g_jit_note += ": " + log.substr(0, 400);
+        }
+        g_rtc.DestroyProgram(&prog);
+        return false;
+    }
+    const char *lowered = nullptr;
+    size_t cs = 0;
+    if (!plain_name) g_rtc.GetLoweredName(prog, name_expr, &lowered);
+    g_rtc.GetCodeSize(prog, &cs);
+    code.resize(cs);
+    g_rtc.GetCode(prog, code.data());
+    lname = plain_name ? std::string(name_expr) : (lowered ? lowered : "");
+    g_rtc.DestroyProgram(&prog);
+    return !lname.empty() && cs > 0;
+}
+
 // Compile (once per process, device and key) `source` against the kernel headers next to the library and return the kernel
 // `name_expr` names (a template instance such as "pcl_hess_kernel_v2<2, 4, 24, true>", or an extern "C" kernel of the source).
 hipFunction_t jit_compile(int device, const std::string &key_, const std::string &source, const char *name_expr, bool plain_name) {
@@ -764,7 +906,6 @@ hipFunction_t jit_compile(int device, const std::string &key_, const std::string
     }
     JitKernel &jk = g_jit[key];
     jk.failed = true;
-    if (!rtc_load()) return nullptr;
     Dl_info info;
     if (!dladdr((const void *)&pcl_version, &info) || !info.dli_fname) {
         g_jit_note = "dladdr failed";
@@ -786,42 +927,28 @@ hipFunction_t jit_compile(int device, const std::string &key_, const std::string
         }
         hdrp[i] = hdr[i].c_str();
     }
-    void *prog = nullptr;
-    if (g_rtc.CreateProgram(&prog, source.c_str(), "pcl_jit.hip", NH, hdrp, names) != 0) {
-        g_jit_note = "hiprtcCreateProgram failed";
-        return nullptr;
+    std::vector<char> code;
+    std::string lname = plain_name ? std::string(name_expr) : std::string();
+    const std::string ckey = jit_cache_key(source, hdr, NH, plain_name ? "" : name_expr);
+    bool from_cache = false;
+    if (cache_enabled()) {
+        std::vector<char> blob;
+        if (read_file(dir + "/prebuilt/" + ckey + ".hsaco", blob) || read_file(user_cache_dir() + "/" + ckey + ".hsaco", blob)) from_cache = unpack_module(blob, code, lname, plain_name);
     }
-    if (!plain_name) g_rtc.AddNameExpression(prog, name_expr);
-#ifdef PCL_PROFILE
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-DPCL_PROFILE"};
-#else
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-#endif
-    if (g_rtc.CompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts) != 0) {
-        size_t ls = 0;
-        g_jit_note = std::string("hiprtcCompileProgram failed for ") + key_;
-        if (g_rtc.GetProgramLogSize && g_rtc.GetProgramLog && g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
-            std::string log(ls, '\0');
-            g_rtc.GetProgramLog(prog, &log[0]);
-            g_jit_note += ": " + log.substr(0, 400);
-        }
-        g_rtc.DestroyProgram(&prog);
-        return nullptr;
+    if (!from_cache) {
+        if (!rtc_load()) return nullptr;
+        if (!rtc_compile(source, hdrp, names, NH, name_expr, plain_name, key_, code, lname)) return nullptr;
+        if (cache_enabled()) (void)write_file_atomic(user_cache_dir(), ckey + ".hsaco", pack_module(code, lname));
     }
-    const char *lowered = nullptr;
-    size_t cs = 0;
-    if (!plain_name) g_rtc.GetLoweredName(prog, name_expr, &lowered);
-    g_rtc.GetCodeSize(prog, &cs);
-    std::vector<char> code(cs);
-    g_rtc.GetCode(prog, code.data());
-    const std::string lname = plain_name ? std::string(name_expr) : (lowered ? lowered : "");
-    g_rtc.DestroyProgram(&prog);
     if (lname.empty() || hipModuleLoadData(&jk.mod, code.data()) != hipSuccess || hipModuleGetFunction(&jk.fn, jk.mod, lname.c_str()) != hipSuccess) {
         g_jit_note = "hipModuleLoadData / hipModuleGetFunction failed";
         return nullptr;
     }
     jk.failed = false;
-    ++g_jit_compiles;
+    if (from_cache)
+        ++g_jit_cache_hits;
+    else
+        ++g_jit_compiles;
     return jk.fn;
 }
 hipFunction_t jit_function(int device, const char *instance) {
@@ -844,6 +971,72 @@ std::string v4_hess_source(const pcl_codegen::V4Plan &plan, int q, int variant =
     return "#include \"pcl_device_common.hpp\"\n#define SH_VARIANT " + std::to_string(variant) + "\n#define SH_SPLIT " + std::to_string(split) + "\n" + pcl_codegen::v4_functions(plan, q, 1, variant & 8, true) + "#include \"pcl_kernel_hess_sparse4.hpp\"\n";
 }
 }  // namespace
+
+// Compile `source` (a generated module) with hiprtc and leave the code object in `out_dir` under its content hash: no device needed.
+static int prebuild_source(const std::string &source, const char *name_expr, const char *out_dir, std::string &err) {
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    Dl_info info;
+    if (!dladdr((const void *)&pcl_version, &info) || !info.dli_fname) {
+        err = "dladdr failed";
+        return PCL_EHIP;
+    }
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+    const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp",
+                           "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp", "pcl_kernel_eval_sparse.hpp",
+                           "pcl_kernel_fused_sparse.hpp", "pcl_kernel_hess_sparse4.hpp"};
+    constexpr int NH = 9;
+    std::string hdr[NH];
+    const char *hdrp[NH];
+    for (int i = 0; i < NH; ++i) {
+        if (!slurp(dir + "/" + names[i], hdr[i])) {
+            err = "kernel header not found next to the library: " + dir + "/" + names[i];
+            return PCL_EHIP;
+        }
+        hdrp[i] = hdr[i].c_str();
+    }
+    const std::string ckey = jit_cache_key(source, hdr, NH, "");
+    const std::string odir = out_dir && out_dir[0] ? std::string(out_dir) : dir + "/prebuilt";
+    std::vector<char> blob;
+    if (read_file(odir + "/" + ckey + ".hsaco", blob)) return PCL_OK;  // already there
+    if (!rtc_load()) {
+        err = g_jit_note;
+        return PCL_EHIP;
+    }
+    std::vector<char> code;
+    std::string lname;
+    if (!rtc_compile(source, hdrp, names, NH, name_expr, true, "prebuild", code, lname)) {
+        err = g_jit_note;
+        return PCL_EHIP;
+    }
+    if (!write_file_atomic(odir, ckey + ".hsaco", pack_module(code, lname))) {
+        err = "cannot write " + odir + "/" + ckey + ".hsaco";
+        return PCL_EHIP;
+    }
+    return PCL_OK;
+}
+// the pattern-compiled modules of one system, as a context of that system would compile them on first use (no device needed):
+//   what 0  fused residual + Jacobian + residual-only kernels at order 2q | 1  general-order Hessian, one workgroup per interval |
+//        2  ... two workgroups per interval | 3  the order-4 Hessian / value-table module (q ignored)
+extern "C" int pcl_jit_prebuild(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what, const char *out_dir) {
+    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || what < 0 || what > 3 || !G0 || (m > 0 && !Gj)) return fail(nullptr, PCL_EINVAL, "pcl_jit_prebuild: bad argument");
+    std::string src, err;
+    const char *kernel = "pcl_fused_sparse_kernel";
+    if (what == 3) {
+        src = sparse_source(pcl_codegen::make_plan(d, m, G0, n_g0, Gj));
+        kernel = "pcl_hess_sparse_kernel";
+    } else {
+        const pcl_codegen::V4Plan plan = pcl_codegen::make_v4_plan(d, m, G0, n_g0, Gj);
+        if (!plan.ok) return fail(nullptr, PCL_ESHAPE, "pcl_jit_prebuild: the pattern-compiled kernels do not take this system");
+        const int np = v4_power_tiles(d, m, q, 160 * 1024);
+        if (!np) return fail(nullptr, PCL_ESHAPE, "pcl_jit_prebuild: tiles exceed LDS");
+        src = what == 0 ? v4_source(plan, q, np) : v4_hess_source(plan, q, 0, what);
+        if (what) kernel = "pcl_hess_sparse4_kernel";
+    }
+    const int rc = prebuild_source(src, kernel, out_dir, err);
+    return rc == PCL_OK ? rc : fail(nullptr, rc, "pcl_jit_prebuild: %s", err.c_str());
+}
 
 // Inspection hooks of the fused pattern-compiled kernel (no device needed): its generated source, and the generator's term
 // tables applied on the host to one column (y = G(u) x; n_g0 drifts span the union pattern, the first one is applied).
@@ -938,6 +1131,21 @@ static void fill_params(const pcl_ctx *ctx, KParams &p) {
     p.prof = (int)ctx->opt_prof;
     p.hess_per = hess_per(ctx);
     p.err = ctx->derr;
+}
+
+// A pattern-compiled kernel was wanted (jit = 1, the shape applies) and could not be had: the slower kernel families serve the context
+// (1.5-2.2x for residual + Jacobian, 25-30x for the Hessian at orders 6-10) -- never silently: the note is what pcl_last_error returns
+// until the next failure, "jit_fallbacks" counts, and with option require_jit = 1 the call fails instead.
+static int jit_fell_back(pcl_ctx *ctx, const char *what) {
+    ++ctx->jit_fallbacks;
+    {
+        std::lock_guard<std::mutex> lock(g_jit_mutex);
+        ++g_jit_fallbacks;
+    }
+    fail(ctx, PCL_EHIP, "%s: the pattern-compiled kernel is not available (%s); %s", what, g_jit_note.c_str(),
+         ctx->opt_require_jit ? "require_jit = 1" : "falling back to the built-in kernels (slower; set option require_jit = 1 to make this an error)");
+    if (getenv("PCL_VERBOSE")) fprintf(stderr, "piccolo_hip: %s\n", ctx->err.c_str());
+    return ctx->opt_require_jit ? PCL_EHIP : PCL_ENOTIMPL;
 }
 
 // A barrier-free kernel whose bounded wait gave up (a logic or timing failure: its outputs are partly stale) has set the context's
@@ -1158,7 +1366,7 @@ static int v4_module(pcl_ctx *ctx, int q, int np) {
     if (!ctx->v4_f || !ctx->v4_feval) {
         ctx->v4_f = ctx->v4_feval = ctx->v4_fevalc = nullptr;
         ctx->v4_failed = 1;
-        return PCL_ENOTIMPL;
+        return jit_fell_back(ctx, "residual + Jacobian");
     }
     return PCL_OK;
 }
@@ -1169,7 +1377,7 @@ static int launch_eval_v4(pcl_ctx *ctx, KParams &p) {
     fill_pade(p, ctx->desc.pade_order);
     const int np = v4_power_tiles(p.d, p.m, p.q, (size_t)ctx->max_lds);
     if (!np) return PCL_ENOTIMPL;
-    if (v4_module(ctx, p.q, np) != PCL_OK) return PCL_ENOTIMPL;
+    if (int rc = v4_module(ctx, p.q, np)) return rc;  // (PCL_ENOTIMPL: the caller goes on to the other kernels)
     const long long items = (long long)p.batch * p.K;
     if (items > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
     const int nw = 4;
@@ -1202,7 +1410,7 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     fill_pade(p, ctx->desc.pade_order);
     const int np = v4_power_tiles(p.d, p.m, p.q, (size_t)ctx->max_lds);
     if (!np) return PCL_ENOTIMPL;
-    if (v4_module(ctx, p.q, np) != PCL_OK) return PCL_ENOTIMPL;
+    if (int rc = v4_module(ctx, p.q, np)) return rc;
     const int d = p.d, m = p.m;
     const long long bk = (long long)p.batch * p.K, ncu = std::max(ctx->n_cu, 1);
     // contiguous column ranges once every CU has about an interval's worth of columns; below that round-robin slices of the
@@ -1439,7 +1647,10 @@ not_v3:
             const std::string src = sparse_source(sp);
             const std::string key = "sparse:" + std::to_string(std::hash<std::string>{}(src));
             ctx->sp_feval = jit_compile(ctx->device, key, src, "pcl_eval_sparse_kernel", true);
-            if (!ctx->sp_feval) ctx->sp_failed = 1;
+            if (!ctx->sp_feval) {
+                ctx->sp_failed = 1;
+                if (int rc = jit_fell_back(ctx, "residual"); rc != PCL_ENOTIMPL) return rc;
+            }
         }
         if (ctx->sp_feval) {
             if (ctx->sp_gvals_cap < (long long)ctx->desc.batch * p.K) {
@@ -1604,7 +1815,10 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             const std::string src = v4_hess_source(v4, p.q, (int)ctx->opt_v4_variant, ns);
             const std::string key = "hess-sparse4:" + std::to_string(p.q) + ":" + std::to_string(ns) + ":" + std::to_string(std::hash<std::string>{}(src));
             fh = jit_compile(ctx->device, key, src, "pcl_hess_sparse4_kernel", true);
-            if (!fh) ctx->v4_hess_failed = 1;
+            if (!fh) {
+                ctx->v4_hess_failed = 1;
+                if (int rc = jit_fell_back(ctx, "Hessian of the Lagrangian"); rc != PCL_ENOTIMPL) return rc;
+            }
         }
         if (fh && split && ctx->h4_cap < (long long)ctx->desc.batch * ctx->K) {
             if (ctx->dh4x) (void)hipFree(ctx->dh4x);
@@ -1691,8 +1905,10 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
         }
         if (ldsp > (size_t)ctx->max_lds)
             ctx->sp_hess_unfit = 1;  // (the residual kernel of the same source needs one tile per wave and stays available)
-        else
+        else {
             ctx->sp_failed = 1;
+            if (int rc = jit_fell_back(ctx, "Hessian of the Lagrangian (order 4)"); rc != PCL_ENOTIMPL) return rc;
+        }
         if (ctx->opt_hess_kernel == 4)
             return fail(ctx, PCL_ESHAPE, "hess_kernel=4: the pattern-compiled kernel is not available (%zu B of LDS needed, %d available; %s)", ldsp, ctx->max_lds,
                         g_jit_note.c_str());
@@ -2556,6 +2772,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_specialize = v != 0;
     else if (!strcmp(key, "jit"))  // 1 (default): compile the context's shape on first use when no static instance matches
         ctx->opt_jit = v != 0;
+    else if (!strcmp(key, "require_jit"))  // 1: a pattern-compiled kernel that is wanted and cannot be had is an error (PCL_EHIP), not a fallback
+        ctx->opt_require_jit = v != 0;
     else if (!strcmp(key, "general_threads"))  // general-order kernel: 256 or 512 (default) threads per workgroup
         ctx->opt_general_threads = v == 256 ? 256 : 512;
     else if (!strcmp(key, "general_kernel_version"))  // general-order residual+Jacobian: 0 auto | 1 reference formulation | 2 lock-step kernel (error where it does not fit)
@@ -2668,10 +2886,16 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->opt_contig;
     else if (!strcmp(key, "jit"))
         *v = ctx->opt_jit;
-    else if (!strcmp(key, "jit_compiles")) {
+    else if (!strcmp(key, "jit_compiles")) {  // modules this process compiled with hiprtc
         std::lock_guard<std::mutex> lock(g_jit_mutex);
         *v = g_jit_compiles;
-    }
+    } else if (!strcmp(key, "jit_cache_hits")) {  // ... and loaded from the prebuilt directory or the on-disk cache instead
+        std::lock_guard<std::mutex> lock(g_jit_mutex);
+        *v = g_jit_cache_hits;
+    } else if (!strcmp(key, "jit_fallbacks"))  // pattern-compiled kernels this context wanted and did not get
+        *v = ctx->jit_fallbacks;
+    else if (!strcmp(key, "require_jit"))
+        *v = ctx->opt_require_jit;
     else if (!strcmp(key, "stream_workgroups"))
         *v = ctx->opt_stream_wg;
     else if (!strcmp(key, "last_stream_workgroups"))

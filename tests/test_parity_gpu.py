@@ -7,6 +7,8 @@ summation orders (MFMA 4-wide k-blocks / FMA contraction), so agreement is to ro
 (observed ~1e-15 .. 1e-14).  The Pade-vs-exp deviation is a modelling difference, not an
 error of the kernel, and is asserted separately per order in tests/test_oracle_pins.py.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1083,6 +1085,53 @@ def test_multistart_64_equals_64_single_launches():
     close(dd.view(T, -1)[37].cpu().numpy(), np.asarray(d_ref).reshape(-1))
     close(out.view(T, -1)[37].cpu().numpy(), np.asarray(j_ref).reshape(-1))
     c64.close(), c1.close()
+
+
+
+def test_code_objects_persist_across_processes(tmp_path):
+    """The run-time compiled modules are kept on disk under the hash of their sources: a fresh process finds the BASELINE config-3 modules
+    in csrc/prebuilt (written by __graft_entry__.build(), no hiprtc at run time) and anything else in the user's cache once ONE process
+    has compiled it -- `jit_compiles` == 0 in the second process, same values; with the cache switched off it compiles again."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import json, sys, time, numpy as np
+sys.path.insert(0, %r)
+import piccolo_jl_amd as pa
+from oracle import pade_oracle as po
+order = int(sys.argv[1])
+so = po.config_system(3)
+Z, lay = po.synthetic_trajectory(so, 6, seed=5)
+c = pa.integrators._PclContext(d=lay.d, m=lay.m, N=lay.N, z_dim=lay.z_dim, u_off=lay.u_off, dt_off=lay.dt_off, x_offs=[lay.x_off], G0=so.G_drift,
+                               Gj=np.array(so.G_drives), batch=1, batch_mode=pa._lib.PCL_BATCH_MEMBERS, pade_order=order)
+c.set_option("host_path", 1)
+c.set_option("require_jit", 1)
+t0 = time.perf_counter()
+delta, vals = c.eval_jac(Z)
+t1 = time.perf_counter() - t0
+h = c.hess(Z, np.ones(c.n_rows))
+print(json.dumps(dict(compiles=c.get_option("jit_compiles"), hits=c.get_option("jit_cache_hits"), kernel=c.get_option("last_kernel"), first_call_ms=t1 * 1e3,
+                      checksum=float(np.abs(vals).sum() + np.abs(delta).sum() + np.abs(h).sum()))))
+""" % root
+
+    def run(order, **env):
+        e = dict(os.environ, PCL_JIT_CACHE_DIR=str(tmp_path / "cache"), **env)
+        out = subprocess.run([sys.executable, "-c", code, str(order)], env=e, capture_output=True, text=True, check=True).stdout
+        return json.loads(out.strip().splitlines()[-1])
+
+    pre = os.path.join(root, "piccolo.jl_amd", "csrc", "prebuilt")
+    if os.path.isdir(pre) and any(f.endswith(".hsaco") for f in os.listdir(pre)):
+        a = run(4)  # config 3, order 4: prebuilt
+        assert a["kernel"] == 42 and a["compiles"] == 0 and a["hits"] >= 2, a
+    first, second = run(6), run(6)  # order 6 is not prebuilt: compiled once, then read back
+    assert first["kernel"] == 43 and first["compiles"] >= 2 and second["compiles"] == 0 and second["hits"] >= 2, (first, second)
+    assert first["checksum"] == second["checksum"]
+    assert second["first_call_ms"] < first["first_call_ms"]
+    off = run(6, PCL_JIT_CACHE="0")
+    assert off["compiles"] >= 2 and off["hits"] == 0 and off["checksum"] == first["checksum"]
 
 
 
