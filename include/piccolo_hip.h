@@ -98,7 +98,8 @@ typedef struct pcl_desc {
     int32_t dt_off;      /* 0-based offset of the timestep component */
     int32_t batch;       /* number of members / seeds (>= 1) */
     int32_t batch_mode;  /* PCL_BATCH_MEMBERS or PCL_BATCH_TRAJ */
-    int32_t pade_order;  /* diagonal Pade order p of B^{+-}_p: 2, 4 (the tuned path), 6, 8 or 10 */
+    int32_t pade_order;  /* diagonal Pade order p of B^{+-}_p: 2, 4, 6, 8 or 10; 0: the smallest order whose deviation from the reference's
+                            exp constraint is below a tolerance -- pcl_set_order_policy, or the first host-pointer call decides */
     int32_t device_id;   /* HIP device ordinal */
     int32_t index_base;  /* 0 (C/Python) or 1 (Julia/MOI) for the emitted structure */
     int32_t per_member_G0; /* 0: one G0 for all members; 1: G0 holds batch matrices (per-member H_drift) */
@@ -121,6 +122,14 @@ void pcl_destroy(pcl_ctx *ctx);
 /* Message of the last failure on ctx (ctx == NULL: last failure of pcl_create on this thread). */
 const char *pcl_last_error(const pcl_ctx *ctx);
 const char *pcl_version(void);
+
+/* Order policy.  The reference's constraint is x_{k+1} = exp(dt_k G(u_k)) x_k (docs/src/concepts/index.md:21); the Pade-2q residual deviates from
+ * it by kappa_q theta^(2q+1), theta = |dt_k G(u_k)|_2, kappa_q = (q!)^2 / ((2q)! (2q+1)!) (1.6e-5 at order 4, 1.6e-11 at
+ * order 8 for BASELINE config 3).  Sets the context's order to the smallest one whose bound at theta = dt_max (|G_drift|_2 + sum_l u_max[l] |G_l|_2)
+ * is <= tol and reports it (also: get_option "pade_order").  A context created with pade_order = 0 that never sees this call takes
+ * theta = 1.5 x the maximum over the first trajectory a host-pointer entry point is given, tol = 1e-10; its device-pointer entry points
+ * return PCL_EINVAL until an order exists. */
+int pcl_set_order_policy(pcl_ctx *ctx, double dt_max, const double *u_max /* n_drives */, double tol, int32_t *order_out);
 
 /* dimensions --------------------------------------------------------------- */
 /* n_rows = batch*x_dim*(N-1); n_cols = z_dim*N*(TRAJ ? batch : 1) + global_dim. Any out pointer may be NULL. */

@@ -164,6 +164,9 @@ struct pcl_ctx {
     const void *lds_kern[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // last MaxDynamicSharedMemorySize set per kernel variant
     int max_lds = 0;
     int n_cu = 0;
+    // order policy (pade_order = 0 in the descriptor): host copies of the generators for the norm bound, the tolerance, what was found
+    std::vector<double> hG0, hGj;
+    double order_tol = 1e-10, order_theta = 0.0;
     mutable std::string err;
 };
 
@@ -259,8 +262,8 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     if (n > 2 * PCL_MAX_D)
         return fail(nullptr, PCL_ESHAPE, "pcl_create: generator dimension %d exceeds %d (LDS-resident tiles; d <= %d)", n, 2 * PCL_MAX_D, PCL_MAX_D);
     if (m > 24) return fail(nullptr, PCL_ESHAPE, "pcl_create: n_drives=%d exceeds 24", m);
-    if (dsc->pade_order != 2 && dsc->pade_order != 4 && dsc->pade_order != 6 && dsc->pade_order != 8 && dsc->pade_order != 10)
-        return fail(nullptr, PCL_ENOTIMPL, "pcl_create: pade_order=%d; diagonal Pade orders 2, 4, 6, 8, 10 are implemented", dsc->pade_order);
+    if (dsc->pade_order != 0 && dsc->pade_order != 2 && dsc->pade_order != 4 && dsc->pade_order != 6 && dsc->pade_order != 8 && dsc->pade_order != 10)
+        return fail(nullptr, PCL_ENOTIMPL, "pcl_create: pade_order=%d; diagonal Pade orders 2, 4, 6, 8, 10 are implemented (0: chosen by pcl_set_order_policy)", dsc->pade_order);
     if (dsc->index_base != 0 && dsc->index_base != 1) return fail(nullptr, PCL_EINVAL, "pcl_create: index_base must be 0 or 1");
     if (dsc->batch_mode != PCL_BATCH_MEMBERS && dsc->batch_mode != PCL_BATCH_TRAJ)
         return fail(nullptr, PCL_EINVAL, "pcl_create: unknown batch_mode %d", dsc->batch_mode);
@@ -292,6 +295,8 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     ctx->cols = cols;
     ctx->vec = vec ? 1 : 0;
     ctx->x_offs.assign(dsc->x_offs, dsc->x_offs + n_off);
+    ctx->hG0.assign(dsc->G0, dsc->G0 + (size_t)n * n * (dsc->per_member_G0 ? dsc->batch : 1));
+    if (m > 0) ctx->hGj.assign(dsc->Gj, dsc->Gj + (size_t)m * n * n);
     ctx->desc.x_offs = nullptr;
     ctx->desc.G0 = ctx->desc.Gj = nullptr;
     ctx->device = dsc->device_id;
@@ -457,7 +462,7 @@ extern "C" int pcl_create(const pcl_desc *dsc, pcl_ctx **out) {
     }
     if (ctx->sp_plan) {  // the fused kernel of the same family: one LDS tile per chain (m + 7 tiles of d (n + 1) doubles)
         pcl_codegen::V4Plan v4 = pcl_codegen::make_v4_plan(d, m, dsc->G0, dsc->per_member_G0 ? dsc->batch : 1, dsc->Gj);
-        if (v4.ok && v4_power_tiles(d, m, dsc->pade_order / 2, (size_t)ctx->max_lds) > 0) ctx->v4_plan = new pcl_codegen::V4Plan(std::move(v4));
+        if (v4.ok && v4_power_tiles(d, m, std::max(dsc->pade_order, 2) / 2, (size_t)ctx->max_lds) > 0) ctx->v4_plan = new pcl_codegen::V4Plan(std::move(v4));
     }
     std::vector<double> g0(dsc->G0, dsc->G0 + nn * (dsc->per_member_G0 ? dsc->batch : 1));
     CREATE_TRY(upload(ctx, &ctx->dG0, g0));
@@ -1505,9 +1510,11 @@ static int launch_pade_general(pcl_ctx *ctx, KParams &p, bool want_jac) {
     return PCL_OK;
 }
 
+static int resolve_order(pcl_ctx *ctx, const double *Z_host, const char *where);
 static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *jac, bool compact) {
     ON_DEVICE(ctx);
     if (int rc = check_device_error(ctx, "pcl_eval / pcl_jac")) return rc;
+    if (int rc = resolve_order(ctx, nullptr, "pcl_eval / pcl_jac")) return rc;
     KParams p;
     fill_params(ctx, p);
     p.Z = Z + (ctx->desc.batch_mode == PCL_BATCH_TRAJ ? (long long)ctx->win_first * ctx->desc.z_dim * ctx->desc.N : 0);
@@ -1780,6 +1787,7 @@ static size_t hess2_lds_bytes(const KParams &p) {
 static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *hess) {
     ON_DEVICE(ctx);
     if (int rc = check_device_error(ctx, "pcl_hess")) return rc;
+    if (int rc = resolve_order(ctx, nullptr, "pcl_hess")) return rc;
     KParams p;
     fill_params(ctx, p);
     p.Z = Z + (ctx->desc.batch_mode == PCL_BATCH_TRAJ ? (long long)ctx->win_first * ctx->desc.z_dim * ctx->desc.N : 0);
@@ -2021,6 +2029,94 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
     return PCL_OK;
 }
 
+// --- order policy ---------------------------------------------------------------------------------
+// The reference's constraint is x_{k+1} = exp(dt_k G(u_k)) x_k (docs/src/concepts/index.md:21); the diagonal Pade residual of order 2q
+// deviates from it by  kappa_q theta^(2q+1) (1 + O(theta^2)) |x|,  theta = |dt_k G(u_k)|_2,  kappa_q = (q!)^2 / ((2q)! (2q+1)!)  -- the
+// leading term of exp - r_qq.  (Measured with the oracle on exp-feasible trajectories, profiles/pade_vs_exp.json: config 3, theta = 0.438:
+// 1.6e-5 / 1.6e-11 / 7.9e-15 at orders 4 / 8 / 10 against 2.2e-5 / 2.3e-11 / 1.1e-14 from this bound.)  pade_order = 0 asks for the
+// smallest order whose bound is below a tolerance, theta from the problem's bounds (pcl_set_order_policy) or, failing that, from the
+// first trajectory a host-pointer entry point sees (with a margin of 1.5 on theta: later iterates move inside their bounds).
+static double spectral_norm(const double *A, int n) {  // power iteration on A^T A (n <= 64: microseconds)
+    std::vector<double> x(n, 1.0), y(n), z(n);
+    double s = 0.0;
+    for (int it = 0; it < 60; ++it) {
+        for (int i = 0; i < n; ++i) {
+            double a = 0.0;
+            for (int j = 0; j < n; ++j) a += A[i + (size_t)n * j] * x[j];
+            y[i] = a;
+        }
+        for (int j = 0; j < n; ++j) {
+            double a = 0.0;
+            for (int i = 0; i < n; ++i) a += A[i + (size_t)n * j] * y[i];
+            z[j] = a;
+        }
+        double nz = 0.0, nx = 0.0;
+        for (int j = 0; j < n; ++j) nz += z[j] * z[j], nx += x[j] * x[j];
+        if (nz == 0.0) return 0.0;
+        const double s1 = std::sqrt(std::sqrt(nz) / std::sqrt(nx));
+        nz = std::sqrt(nz);
+        for (int j = 0; j < n; ++j) x[j] = z[j] / nz;
+        if (std::fabs(s1 - s) <= 1e-12 * s1) return s1;
+        s = s1;
+    }
+    return s * 1.01;  // (not converged to round-off: a hair on the safe side)
+}
+static int order_for(double theta, double tol) {
+    double fact[12];
+    fact[0] = 1.0;
+    for (int i = 1; i < 12; ++i) fact[i] = fact[i - 1] * i;
+    for (int q = 1; q <= 5; ++q) {
+        const double kappa = fact[q] * fact[q] / (fact[2 * q] * fact[2 * q + 1]);
+        if (kappa * std::pow(theta, 2 * q + 1) <= tol) return 2 * q;
+    }
+    return 10;
+}
+static void set_order(pcl_ctx *ctx, int order, double theta) {
+    if (ctx->desc.pade_order != order) {  // (modules are per order: the handles of the previous one are dropped, the modules stay cached)
+        ctx->v4_f = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = nullptr;
+        ctx->v4_failed = ctx->v4_hess_failed = 0;
+    }
+    ctx->desc.pade_order = order;
+    ctx->order_theta = theta;
+}
+extern "C" int pcl_set_order_policy(pcl_ctx *ctx, double dt_max, const double *u_max, double tol, int32_t *order_out) {
+    if (!ctx) return PCL_EINVAL;
+    if (!(dt_max > 0.0) || !(tol > 0.0) || (ctx->desc.n_drives > 0 && !u_max)) return fail(ctx, PCL_EINVAL, "pcl_set_order_policy: need dt_max > 0, tol > 0 and the drives' bounds");
+    const int n = ctx->n, m = ctx->desc.n_drives;
+    double gd = 0.0;
+    for (int l = 0; l < m; ++l) gd += std::fabs(u_max[l]) * spectral_norm(ctx->hGj.data() + (size_t)l * n * n, n);
+    double theta = 0.0;
+    for (size_t b = 0; b * n * n < ctx->hG0.size(); ++b) theta = std::max(theta, dt_max * (spectral_norm(ctx->hG0.data() + b * n * n, n) + gd));
+    ctx->order_tol = tol;
+    set_order(ctx, order_for(theta, tol), theta);
+    if (order_out) *order_out = ctx->desc.pade_order;
+    return PCL_OK;
+}
+// pade_order = 0 and no policy yet: the first trajectory on the host decides (host-pointer entry points); device-pointer entry points
+// have nothing to look at
+static int resolve_order(pcl_ctx *ctx, const double *Z_host, const char *where) {
+    if (ctx->desc.pade_order != 0) return PCL_OK;
+    if (!Z_host) return fail(ctx, PCL_EINVAL, "%s: the context was created with pade_order = 0; call pcl_set_order_policy (or a host-pointer entry point) first", where);
+    const pcl_desc &D = ctx->desc;
+    const int n = ctx->n, m = D.n_drives;
+    const int nbuf = D.batch_mode == PCL_BATCH_TRAJ ? D.batch : 1;
+    std::vector<double> G((size_t)n * n);
+    double theta = 0.0;
+    for (size_t g0 = 0; g0 * n * n < ctx->hG0.size(); ++g0)
+        for (int b = 0; b < nbuf; ++b)
+            for (int k = 0; k + 1 < D.N; ++k) {
+                const double *z = Z_host + ((size_t)b * D.N + k) * D.z_dim;
+                for (size_t e = 0; e < (size_t)n * n; ++e) {
+                    double a = ctx->hG0[g0 * n * n + e];
+                    for (int l = 0; l < m; ++l) a += z[D.u_off + l] * ctx->hGj[(size_t)l * n * n + e];
+                    G[e] = a;
+                }
+                theta = std::max(theta, std::fabs(z[D.dt_off]) * spectral_norm(G.data(), n));
+            }
+    set_order(ctx, order_for(1.5 * theta, ctx->order_tol), 1.5 * theta);
+    return PCL_OK;
+}
+
 // --- device-pointer API -----------------------------------------------------------------------
 extern "C" int pcl_set_stream(pcl_ctx *ctx, void *s) {
     if (!ctx) return PCL_EINVAL;
@@ -2137,6 +2233,7 @@ static int host_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *v
     if (!ctx) return PCL_EINVAL;
     if (!Z || (!delta && !vals)) return fail(ctx, PCL_EINVAL, "NULL pointer");
     ON_DEVICE(ctx);
+    TRY(resolve_order(ctx, Z, "pcl_eval_jac"));
     const long long nbk = (long long)ctx->win_count * ctx->K, nbk_all = (long long)ctx->desc.batch * ctx->K;
     const long long nv = jac_per_full(ctx) * nbk;
     const bool compact_path = vals && ctx->cols > 1 && ctx->opt_host_path != 1;
@@ -2208,6 +2305,7 @@ extern "C" int pcl_hess(pcl_ctx *ctx, const double *Z, const double *mu, double 
     if (!ctx) return PCL_EINVAL;
     if (!Z || !mu || !vals) return fail(ctx, PCL_EINVAL, "pcl_hess: NULL pointer");
     ON_DEVICE(ctx);
+    TRY(resolve_order(ctx, Z, "pcl_hess"));
     const long long nv = hess_per(ctx) * ctx->win_count * ctx->K;
     TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
     TRY(ensure(ctx, &ctx->dmu, n_rows_all(ctx)));
@@ -2896,6 +2994,10 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->jit_fallbacks;
     else if (!strcmp(key, "require_jit"))
         *v = ctx->opt_require_jit;
+    else if (!strcmp(key, "pade_order"))  // the order in use (0: pade_order = 0 at creation and nothing has chosen yet)
+        *v = ctx->desc.pade_order;
+    else if (!strcmp(key, "order_theta_1e9"))  // 1e9 x the bound on |dt G|_2 the order policy worked with
+        *v = (int64_t)(ctx->order_theta * 1e9);
     else if (!strcmp(key, "stream_workgroups"))
         *v = ctx->opt_stream_wg;
     else if (!strcmp(key, "last_stream_workgroups"))

@@ -96,6 +96,20 @@ class _PclContext:
         if rc != 0:
             raise PclError(rc, (self._L.pcl_last_error(self._h) or b"").decode())
 
+    def set_order_policy(self, dt_max, u_max, tol=1e-10):
+        """The smallest diagonal Pade order whose deviation from the reference's exp constraint, ``kappa_q theta^(2q+1)`` with
+        ``theta = dt_max (|G_drift|_2 + sum_l u_max_l |G_l|_2)``, is below ``tol``; becomes the context's order.  Returns it."""
+        um = np.ascontiguousarray(np.broadcast_to(np.abs(np.asarray(u_max, dtype=np.float64)), (max(self.m, 1),)))
+        out = ctypes.c_int32()
+        self._L.pcl_set_order_policy.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_int32)]
+        self._chk(self._L.pcl_set_order_policy(self._h, float(dt_max), um.ctypes.data, float(tol), ctypes.byref(out)))
+        return out.value
+
+    @property
+    def pade_order(self):
+        """The order in use (0: a context created with ``pade_order=0`` that has not seen a policy or a trajectory yet)."""
+        return self.get_option("pade_order")
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.pcl_destroy(self._h)
@@ -343,7 +357,9 @@ class HipPadeIntegrator:
     in order -- the row order here is identical: member-major).
     """
 
-    def __init__(self, G_drift, G_drives, traj, x_name=STATE, u_name="u", *, device=0, index_base=0, pade_order=4):
+    def __init__(self, G_drift, G_drives, traj, x_name=STATE, u_name="u", *, device=0, index_base=0, pade_order=4, order_tol=1e-10):
+        """``pade_order=0``: the smallest order whose deviation from the reference's exp constraint stays below ``order_tol`` over the
+        trajectory's bounds on ``u`` and the timestep (``traj.bounds``); without bounds, over the first trajectory evaluated (x 1.5)."""
         x_names = [x_name] if isinstance(x_name, str) else list(x_name)
         G_drives = np.asarray(G_drives, dtype=np.float64)
         G_drift = np.asarray(G_drift, dtype=np.float64)
@@ -374,7 +390,6 @@ class HipPadeIntegrator:
         self.u_name = u_name
         self.G_drift, self.G_drives = G_drift, G_drives.reshape(m, n, n)
         self._sig = (traj.dim, traj.N)
-        self.pade_order = pade_order
         self._ctx = _PclContext(
             d=d, m=m, N=traj.N, z_dim=traj.dim, u_off=traj.components[u_name].start,
             dt_off=traj.components[traj.timestep].start, x_offs=[traj.components[nm].start for nm in x_names],
@@ -382,6 +397,11 @@ class HipPadeIntegrator:
             global_dim=traj.global_dim, device=device, index_base=index_base, pade_order=pade_order,
             state_cols=_lib.PCL_STATE_VECTOR if vec else cols,
         )  # fmt: skip
+        if pade_order == 0:
+            ub, tb = traj.bounds.get(u_name), traj.bounds.get(traj.timestep)
+            if ub is not None and tb is not None and m:
+                umax = np.max(np.abs(np.broadcast_to(np.asarray(ub, dtype=np.float64), (2, len(traj.components[u_name])))), axis=0)[:m]
+                self._ctx.set_order_policy(float(np.max(np.abs(np.asarray(tb, dtype=np.float64)))), umax, order_tol)
         self._state_cols = _lib.PCL_STATE_VECTOR if vec else cols
         self.x_dim = self._ctx.x_dim * len(x_names) if len(x_names) > 1 else self._ctx.x_dim
         self.dim = self._ctx.n_rows
@@ -391,6 +411,10 @@ class HipPadeIntegrator:
     @property
     def ctx(self):
         return self._ctx
+
+    @property
+    def pade_order(self):
+        return self._ctx.pade_order
 
     def _check(self, traj):
         if (traj.dim, traj.N) != self._sig:

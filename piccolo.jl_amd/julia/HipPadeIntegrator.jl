@@ -133,12 +133,28 @@ function _generators(sys)
     return G0, Gj
 end
 
+# pcl_set_order_policy with dt_max and |u|_max from traj.bounds (both bounds must exist; otherwise the first trajectory the
+# host-pointer entry points see decides, include/piccolo_hip.h).  Returns the order in use (0: not decided yet).
+function _order_from_bounds!(core::PclCore, traj::NamedTrajectory, u_name::Symbol, m::Int, tol::Float64)
+    (haskey(traj.bounds, u_name) && haskey(traj.bounds, traj.timestep)) || return 0
+    ub = traj.bounds[u_name]; tb = traj.bounds[traj.timestep]
+    umax = Float64[max(abs(ub[1][j]), abs(ub[2][j])) for j in 1:m]
+    dtmax = Float64(maximum(abs, vcat(collect(tb[1]), collect(tb[2]))))
+    order = Ref{Int32}(0)
+    GC.@preserve umax check(core.ctx, ccall((:pcl_set_order_policy, LIB), Cint, (Ptr{Cvoid}, Float64, Ptr{Float64}, Float64, Ref{Int32}),
+                                           core.ctx, dtmax, umax, tol, order))
+    return Int(order[])
+end
+
 function _integrators(G0s, Gj, traj::NamedTrajectory, names::Vector{Symbol}, u_name::Symbol;
-                      state_cols::Integer = 0, pade_order::Integer = 4, kwargs...)
+                      state_cols::Integer = 0, pade_order::Integer = 4, order_tol::Float64 = 1e-10, kwargs...)
     x_offs = Int32[traj.components[nm][1] - 1 for nm in names]
     core, n_vars = _create_core(G0s, Gj, traj.N, traj.dim, traj.components[u_name][1] - 1,
                                 traj.components[traj.timestep][1] - 1, x_offs, traj.global_dim;
                                 state_cols = state_cols, pade_order = pade_order, kwargs...)
+    if pade_order == 0   # the smallest order that matches the reference's exp constraint to order_tol over the trajectory's bounds
+        pade_order = _order_from_bounds!(core, traj, u_name, length(Gj), order_tol)
+    end
     Bs = HipPadeIntegrator[]
     for (i, nm) in enumerate(names)
         jr, jc, hr, hc = _member_structure(core, i)

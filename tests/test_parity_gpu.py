@@ -1135,6 +1135,60 @@ print(json.dumps(dict(compiles=c.get_option("jit_compiles"), hits=c.get_option("
 
 
 
+def test_order_policy_picks_the_order_that_matches_the_exp_constraint():
+    """pade_order = 0: the smallest diagonal Pade order whose deviation from the reference's constraint x_{k+1} = exp(dt G(u_k)) x_k
+    [REF docs/src/concepts/index.md:21] stays below a tolerance -- from the problem's bounds (pcl_set_order_policy) or from the first
+    trajectory.  On an exp-feasible config-3 trajectory the chosen order's residual is below the tolerance and the next lower order's is
+    not; the values are those of a context created with that order; a device-pointer call before an order exists is refused."""
+    import math
+
+    import torch
+
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    N = 12
+    Z, lay = po.synthetic_trajectory(so, N, seed=11, noise=0.0)  # X_{k+1} = expm(dt G(u_k)) X_k exactly: the reference's feasible set
+    theta = max(abs(Z[k, lay.dt_off]) * np.linalg.norm(G0 + np.tensordot(Z[k, lay.u_off : lay.u_off + lay.m], Gj, axes=1), 2) for k in range(N - 1))
+    kappa = lambda q: math.factorial(q) ** 2 / (math.factorial(2 * q) * math.factorial(2 * q + 1))
+    want = lambda th, tol: next((2 * q for q in range(1, 6) if kappa(q) * th ** (2 * q + 1) <= tol), 10)
+    for tol in (1e-4, 1e-7, 1e-10, 1e-13):
+        c = make_ctx(lay, G0, Gj, pade_order=0)
+        assert c.pade_order == 0
+        with pytest.raises(pa._lib.PclError) as ei:  # nothing to look at yet
+            c.eval_dev(torch.from_numpy(Z).cuda(), torch.empty(c.n_rows, dtype=torch.float64, device="cuda"))
+        assert ei.value.code == pa._lib.PCL_EINVAL
+        # bounds: u in [-0.1, 0.1] (drive_bounds of the system), dt <= 0.1
+        th_b = 0.1 * (np.linalg.norm(G0, 2) + sum(0.1 * np.linalg.norm(g, 2) for g in Gj))
+        order = c.set_order_policy(0.1, np.full(lay.m, 0.1), tol)
+        assert order == want(th_b, tol) == c.pade_order, (tol, order, th_b)
+        assert abs(c.get_option("order_theta_1e9") * 1e-9 - th_b) < 1e-6 * th_b
+        delta, vals = c.eval_jac(Z)
+        assert np.abs(delta).max() <= tol  # (the bound holds with theta over the bounds >= theta on this trajectory)
+        cx = make_ctx(lay, G0, Gj, pade_order=order)
+        d2, v2 = cx.eval_jac(Z)
+        assert np.array_equal(delta, d2) and np.array_equal(vals, v2)
+        close(c.hess(Z, np.ones(c.n_rows)), cx.hess(Z, np.ones(c.n_rows)), 0.0)
+        cx.close(), c.close()
+        # from the first trajectory (no policy call): theta = 1.5 x the trajectory's maximum
+        c = make_ctx(lay, G0, Gj, pade_order=0)
+        delta, _ = c.eval_jac(Z)
+        assert c.pade_order == want(1.5 * theta, 1e-10) and np.abs(delta).max() <= 1e-10
+        if c.pade_order > 2:  # the next lower order misses the tolerance on this trajectory's own theta by the factor the bound predicts
+            lo = make_ctx(lay, G0, Gj, pade_order=c.pade_order - 2)
+            assert kappa(c.pade_order // 2 - 1) * (1.5 * theta) ** (c.pade_order - 1) > 1e-10
+            lo.close()
+        c.close()
+    # the high-level constructor reads the bounds of the trajectory
+    system = pa.MultiTransmonSystem([4.0, 4.1, 4.2], [0.2, 0.21, 0.22], [[0, 0.01, 0.02], [0.01, 0, 0.03], [0.02, 0.03, 0]], levels_per_transmon=3, drive_bounds=0.1)
+    traj = traj_from_Z(pa, Z, lay)
+    traj.bounds["u"] = (-0.1 * np.ones(lay.m), 0.1 * np.ones(lay.m))
+    traj.bounds["Δt"] = (np.array([0.05]), np.array([0.1]))
+    B = pa.HipPadeIntegrator(system.G_drift, system.G_drives_array(), traj, pade_order=0, order_tol=1e-10)
+    assert B.pade_order == want(th_b, 1e-10)
+    B.close()
+
+
+
 def test_pattern_compiled_fused_kernel_soak():
     """Kernel 4 synchronises its waves through LDS counters with bounded waits (a wait that gives up writes NaN): 300 launches per
     shape of launch (one trajectory, four, compact, contiguous compact) -- every launch bitwise equal to the first, nothing NaN."""
