@@ -216,6 +216,26 @@ int pcl_clear_regularizers(pcl_ctx *ctx);
 int pcl_objective_dev(pcl_ctx *ctx, const double *Z_dev, double Q, double *value_dev, double *grad_dev);
 int pcl_objective(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad);
 
+/* Terminal losses of the other state types, and any loss of the shape  Q w |1 - F(x)|,  F(x) = c'x + sum_r (A_r'x)^2 :
+ *   KetInfidelityObjective                        F = |<g|psi>|^2                          src/control/objectives.jl:24-60    (2 rows)
+ *   CoherentKetInfidelityObjective                F = |sum_i w_i <g_i|psi_i> / sum w|^2    src/control/objectives.jl:96-200   (2 rows, joint)
+ *   DensityMatrix[PureState]InfidelityObjective   F = Re tr(rho rho_goal)                  src/control/objectives.jl:387-435  (linear)
+ * x = one member's terminal state (scope 0: a term per member / seed with the weights of pcl_set_weights; A is R x x_dim, row-major, c
+ * x_dim doubles or NULL) or the terminal states of ALL members of a MEMBERS context in member order (scope 1: one term; A is
+ * R x (batch x_dim)).  The host mirror builds A and c from the goals (piccolo.jl_amd/objectives.py).  Replaces a goal set with
+ * pcl_set_goal[_subspace]; pcl_objective[_dev] then evaluates it (three small launches). */
+int pcl_set_goal_form(pcl_ctx *ctx, int32_t scope, int32_t R, const double *A, const double *c);
+
+/* Hessian of the objective: sigma * grad^2 f, the part of eval_hessian_lagrangian that pcl_hess does not cover (eval_hessian = true,
+ * src/control/templates/spline_pulse_problem.jl:96).  Terminal loss (any goal above, pcl_set_goal and pcl_set_goal_subspace included): per
+ * term the lower triangle of -s w Q sigma (2 sum_r A_r A_r'), s = sign(1 - F) -- the Gram triangle is formed once per goal, an evaluation
+ * is a scaled copy.  Regularisers: d2/dv_i^2 = dt^p R_i, d2/ddt dv_i = p dt^(p-1) R_i v_i, d2/ddt^2 = p (p - 1) / 2 dt^(p-2) sum_i R_i v_i^2.
+ * Each entry once as (max index, min index); the order is reported by pcl_objective_hess_structure (index_base as in pcl_desc). */
+int pcl_objective_hess_nnz(const pcl_ctx *ctx, int64_t *nnz);
+int pcl_objective_hess_structure(const pcl_ctx *ctx, int64_t *rows, int64_t *cols);
+int pcl_objective_hess_dev(pcl_ctx *ctx, const double *Z_dev, double Q, double sigma, double *vals_dev);
+int pcl_objective_hess(pcl_ctx *ctx, const double *Z, double Q, double sigma, double *vals);
+
 /* what a sharded ensemble exchanges: out = [phi | g_u (K x m, interval-major) | g_dt (K)] with
  *   phi = sum_b w_b <lam_b, delta_b>  (lam_dev == NULL: lam = delta and phi = 1/2 sum_b w_b |delta_b|^2, the constraint merit),
  *   g = J^T (w lam) restricted to the SHARED variables u_k, dt_k -- the only part of the Lagrangian gradient to which other

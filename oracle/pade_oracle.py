@@ -737,6 +737,57 @@ def unitary_infidelity_gradient(Uvec, U_goal, Q=100.0, subspace=None):
     return operator_to_iso_vec_parts(g.real, g.imag)
 
 
+# ---- terminal losses of the other state types (complex arithmetic, as the reference writes them) --------------------------------
+def ket_fidelity_loss(psi_iso, psi_goal):
+    """|<goal|psi>|^2  [REF src/control/objectives.jl:24-27]."""
+    return abs(np.vdot(np.asarray(psi_goal, complex), iso_to_ket(psi_iso))) ** 2
+
+
+def coherent_ket_fidelity(psi_isos, psi_goals, weights=None):
+    """|sum_i w_i <g_i|psi_i> / sum w|^2; uniform (or no) weights take the unweighted path |sum / n|^2  [REF objectives.jl:96-121]."""
+    n = len(psi_isos)
+    ov = [np.vdot(np.asarray(g, complex), iso_to_ket(x)) for g, x in zip(psi_goals, psi_isos)]
+    if weights is None or len(set(float(w) for w in weights)) == 1:
+        return abs(sum(ov) / n) ** 2
+    return abs(sum(w * o for w, o in zip(weights, ov)) / sum(weights)) ** 2
+
+
+def density_matrix_infidelity_loss(rho_compact, rho_goal):
+    """|1 - Re tr(rho rho_goal)|, rho from the compact iso vector  [REF objectives.jl:387-395]."""
+    return abs(1.0 - np.trace(compact_iso_to_density(rho_compact) @ np.asarray(rho_goal, complex)).real)
+
+
+def density_matrix_pure_state_infidelity_loss(rho_compact, psi):
+    """|1 - Re <psi|rho|psi>|  [REF objectives.jl:416-424]."""
+    psi = np.asarray(psi, complex)
+    return abs(1.0 - np.vdot(psi, compact_iso_to_density(rho_compact) @ psi).real)
+
+
+def numerical_gradient(f, x, h=1e-6):
+    """Central differences (test infrastructure for the losses above: the reference differentiates them with ForwardDiff)."""
+    x = np.asarray(x, float)
+    g = np.zeros_like(x)
+    for i in range(x.size):
+        e = np.zeros_like(x)
+        e[i] = h
+        g[i] = (f(x + e) - f(x - e)) / (2 * h)
+    return g
+
+
+def quadratic_hessian(F, L):
+    """Hessian of a function that is at most quadratic, from its values at 0, e_i, e_i + e_j: exact up to rounding."""
+    F0 = F(np.zeros(L))
+    Fi = np.array([F(np.eye(L)[i]) for i in range(L)])
+    H = np.zeros((L, L))
+    for i in range(L):
+        for j in range(i + 1):
+            e = np.zeros(L)
+            e[i] += 1.0
+            e[j] += 1.0
+            H[i, j] = H[j, i] = F(e) - Fi[i] - Fi[j] + F0
+    return H
+
+
 def operator_to_iso_vec_parts(re, im):
     """iso-vec layout (column c = [Re U[:,c]; Im U[:,c]]) from separate real / imaginary parts."""
     lv = re.shape[0]

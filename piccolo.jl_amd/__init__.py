@@ -20,7 +20,8 @@ from .integrators import (
     unitary_rollout,
     unitary_rollout_fidelity,
 )
-from .objectives import EmbeddedOperator, Objective, QuadraticRegularizer, UnitaryInfidelityObjective, get_subspace_indices
+from .objectives import (CoherentKetInfidelityObjective, DensityMatrixInfidelityObjective, DensityMatrixPureStateInfidelityObjective, EmbeddedOperator,
+                         KetInfidelityObjective, Objective, QuadraticRegularizer, UnitaryInfidelityObjective, get_subspace_indices)
 from .quantum import (
     GATES,
     PAULIS,

@@ -41,6 +41,7 @@
 #include "pcl_kernels_hessian.hpp"
 #include "pcl_kernel_hessian_v3.hpp"
 #include "pcl_kernels_misc.hpp"
+#include "pcl_kernels_objective.hpp"
 #include "pcl_host_expand.hpp"
 
 // ------------------------------------------------------------------------------------------
@@ -136,6 +137,11 @@ struct pcl_ctx {
     int *dsub = nullptr;      // subspace indices of an embedded goal
     int n_sub = 0;            // 0: full-space fidelity
     double *dweights = nullptr;  // per member / seed weights of the objective (NULL: ones)
+    // the terminal loss in its general form F = c'x + sum_r (A_r'x)^2 (pcl_kernels_objective.hpp): set by pcl_set_goal_form (form_user: value and
+    // gradient go through it too) or derived from the unitary goal (for the Hessian of the objective only)
+    double *dformA = nullptr, *dformc = nullptr, *dgram = nullptr, *dcoef = nullptr;
+    int form_R = 0, form_L = 0, form_scope = 0;
+    bool form_user = false, gram_ready = false;
     std::vector<PclReg> regs;    // quadratic regularisers (pcl_add_regularizer)
     std::vector<double> reg_R;
     PclReg *dregs = nullptr;
@@ -550,6 +556,8 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     if (ctx->dcomp_host) (void)hipFree(ctx->dcomp_host);
     for (hipEvent_t e : ctx->ev_chunk)
         if (e) (void)hipEventDestroy(e);
+    for (void *q : {(void *)ctx->dformA, (void *)ctx->dformc, (void *)ctx->dgram, (void *)ctx->dcoef})
+        if (q) (void)hipFree(q);
     for (void *q : {(void *)ctx->dsub, (void *)ctx->dweights, (void *)ctx->dregs, (void *)ctx->dreg_R, (void *)ctx->dobj, (void *)ctx->dphik, (void *)ctx->dmcols, (void *)ctx->dmticket,
                     (void *)ctx->dgrad, (void *)ctx->dval})
         if (q) (void)hipFree(q);
@@ -2411,6 +2419,77 @@ static int objective_unitary_only(const pcl_ctx *ctx, const char *who) {
     if (ctx->vec || ctx->cols != ctx->desc.d) return fail(ctx, PCL_ENOTIMPL, "%s: unitary (n x d) states only", who);
     return PCL_OK;
 }
+// (re)place the general form of the terminal loss; the Gram triangle of the Hessian is formed at the first Hessian call
+static int set_form(pcl_ctx *ctx, int scope, int R, const double *A, const double *c, bool user) {
+    const long long L = scope ? (long long)ctx->desc.batch * ctx->x_dim : ctx->x_dim;
+    for (double **q : {&ctx->dformA, &ctx->dformc, &ctx->dgram, &ctx->dcoef}) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    ctx->form_R = ctx->form_L = 0;
+    ctx->gram_ready = false;
+    ctx->form_user = false;
+    if (R < 0 || (R > 0 && !A) || (R == 0 && !c)) return fail(ctx, PCL_EINVAL, "terminal form: need rows or a linear part");
+    if (R > 0) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->dformA, (size_t)R * L * sizeof(double)));
+        HIP_TRY(ctx, hipMemcpy(ctx->dformA, A, (size_t)R * L * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (c) {
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->dformc, (size_t)L * sizeof(double)));
+        HIP_TRY(ctx, hipMemcpy(ctx->dformc, c, (size_t)L * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->dcoef, (size_t)std::max(ctx->desc.batch, 1) * sizeof(double)));
+    ctx->form_R = R;
+    ctx->form_L = (int)L;
+    ctx->form_scope = scope;
+    ctx->form_user = user;
+    return PCL_OK;
+}
+// F = |tr(G'U)|^2 / d^2 = (a'x)^2 + (b'x)^2 with a = iso_vec(G) / d, b = iso_vec(iG) / d   (objectives.jl:330-337)
+static int unitary_form(pcl_ctx *ctx, const double *g) {
+    const int d = ctx->desc.d, n = ctx->n;
+    std::vector<double> A((size_t)2 * ctx->x_dim);
+    for (int c = 0; c < d; ++c)
+        for (int i = 0; i < d; ++i) {
+            const double gr = g[c * n + i], gi = g[c * n + d + i];
+            A[c * n + i] = gr / d, A[c * n + d + i] = gi / d;
+            A[ctx->x_dim + c * n + i] = -gi / d, A[ctx->x_dim + c * n + d + i] = gr / d;
+        }
+    return set_form(ctx, 0, 2, A.data(), nullptr, false);
+}
+// F = (|M|_F^2 + |tr M|^2) / (ns (ns + 1)), M = G_s' U[sub, sub]: a row pair per entry of M and one for the trace   (objectives.jl:339-345)
+static int subspace_form(pcl_ctx *ctx, const double *gs, const int32_t *sub, int ns) {
+    const int d = ctx->desc.d, n = ctx->n;
+    const long long L = ctx->x_dim;
+    const int R = 2 * ns * ns + 2;
+    std::vector<double> A((size_t)R * L, 0.0);
+    const double sc = 1.0 / std::sqrt((double)ns * (ns + 1));
+    double *tr_re = A.data() + (size_t)(R - 2) * L, *tr_im = A.data() + (size_t)(R - 1) * L;
+    for (int i = 0; i < ns; ++i)
+        for (int j = 0; j < ns; ++j) {
+            double *re = A.data() + (size_t)(2 * (i * ns + j)) * L, *im = re + L;
+            for (int k = 0; k < ns; ++k) {
+                const double gr = gs[i * 2 * ns + k] * sc, gi = gs[i * 2 * ns + ns + k] * sc;  // G_s[k, i]
+                const long long xr = (long long)sub[j] * n + sub[k], xi = xr + d;               // U[sub_k, sub_j]
+                re[xr] += gr, re[xi] += gi;
+                im[xi] += gr, im[xr] -= gi;
+                if (i == j) tr_re[xr] += gr, tr_re[xi] += gi, tr_im[xi] += gr, tr_im[xr] -= gi;
+            }
+        }
+    return set_form(ctx, 0, R, A.data(), nullptr, false);
+}
+extern "C" int pcl_set_goal_form(pcl_ctx *ctx, int32_t scope, int32_t R, const double *A, const double *c) {
+    if (!ctx) return PCL_EINVAL;
+    if (scope != 0 && scope != 1) return fail(ctx, PCL_EINVAL, "pcl_set_goal_form: scope must be 0 (per member) or 1 (joint)");
+    if (scope == 1 && ctx->desc.batch_mode != PCL_BATCH_MEMBERS) return fail(ctx, PCL_EINVAL, "pcl_set_goal_form: a joint term needs the members of ONE trajectory buffer");
+    if (R > 4096) return fail(ctx, PCL_ESHAPE, "pcl_set_goal_form: at most 4096 rows");
+    ON_DEVICE(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->dgoal) (void)hipFree(ctx->dgoal);  // (replaces a unitary goal)
+    if (ctx->dsub) (void)hipFree(ctx->dsub);
+    ctx->dgoal = nullptr, ctx->dsub = nullptr, ctx->n_sub = 0;
+    return set_form(ctx, scope, R, A, c, true);
+}
 extern "C" int pcl_set_goal(pcl_ctx *ctx, const double *goal_iso_vec) {
     if (!ctx) return PCL_EINVAL;
     if (!goal_iso_vec) return fail(ctx, PCL_EINVAL, "pcl_set_goal: NULL");
@@ -2423,7 +2502,7 @@ extern "C" int pcl_set_goal(pcl_ctx *ctx, const double *goal_iso_vec) {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dgoal, goal_iso_vec, (size_t)ctx->x_dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_sub = 0;
-    return PCL_OK;
+    return unitary_form(ctx, goal_iso_vec);
 }
 extern "C" int pcl_set_goal_subspace(pcl_ctx *ctx, const double *goal_sub_iso_vec, const int32_t *subspace, int32_t ns) {
     if (!ctx) return PCL_EINVAL;
@@ -2448,7 +2527,7 @@ extern "C" int pcl_set_goal_subspace(pcl_ctx *ctx, const double *goal_sub_iso_ve
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dsub, subspace, (size_t)ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_sub = ns;
-    return PCL_OK;
+    return subspace_form(ctx, goal_sub_iso_vec, subspace, ns);
 }
 extern "C" int pcl_set_weights(pcl_ctx *ctx, const double *w) {
     if (!ctx) return PCL_EINVAL;
@@ -2532,13 +2611,30 @@ static int launch_tail(pcl_ctx *ctx, const double *Z, double Q, double *value, d
 extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad) {
     if (!ctx) return PCL_EINVAL;
     if (!Z || !value) return fail(ctx, PCL_EINVAL, "pcl_objective_dev: NULL pointer");
-    if (!ctx->dgoal && ctx->regs.empty()) return fail(ctx, PCL_EINVAL, "pcl_objective_dev: no goal and no regulariser set");
+    if (!ctx->dgoal && !ctx->form_user && ctx->regs.empty()) return fail(ctx, PCL_EINVAL, "pcl_objective_dev: no goal and no regulariser set");
     if (ctx->dgoal) TRY(objective_unitary_only(ctx, "pcl_objective_dev"));
     ON_DEVICE(ctx);
     const pcl_desc &D = ctx->desc;
     const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
     const int nbuf = traj ? D.batch : 1;
     const long long zs = traj ? (long long)D.z_dim * D.N : 0LL;
+    if (ctx->form_user) {  // a terminal loss in the general form (kets, coherent kets, densities): regulariser rows, the terms, the sums
+        ctx->last_objective_launches = 3;
+        TRY(objective_prepare(ctx));
+        double *member = ctx->dobj, *regval = ctx->dobj + D.batch;
+        hipLaunchKernelGGL(pcl_regularizer_kernel, dim3((unsigned)D.N, (unsigned)nbuf), dim3(256), 0, ctx->stream, Z, (const PclReg *)ctx->dregs,
+                           (int)ctx->regs.size(), (const double *)ctx->dreg_R, grad, regval, D.N, D.z_dim, D.dt_off, zs);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemsetAsync(member, 0, (size_t)D.batch * sizeof(double), ctx->stream));
+        const PclForm f{ctx->dformA, ctx->dformc, ctx->form_R, ctx->form_L, ctx->form_scope};
+        hipLaunchKernelGGL(pcl_form_kernel, dim3(ctx->form_scope ? 1u : (unsigned)D.batch), dim3(256), (size_t)std::max(ctx->form_R, 1) * sizeof(double), ctx->stream, Z, f,
+                           (const int *)ctx->dxoffs, (const double *)ctx->dweights, Q, 1.0, (int)ctx->x_dim, D.N, D.z_dim, zs, (long long)D.z_dim * D.N, member, grad, (double *)nullptr);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(pcl_objective_sum_kernel, dim3(traj ? (unsigned)D.batch : 1u), dim3(64), 0, ctx->stream, (const double *)member, (const double *)regval, value,
+                           D.batch, D.N, traj ? 1 : 0);
+        HIP_TRY(ctx, hipGetLastError());
+        return PCL_OK;
+    }
     {  // ONE launch where it applies (regulariser rows and terminal infidelities as workgroups of one grid: 18 -> 10 us); the same bits
         int lo = 0, hi = 0;
         if (tail_applies(ctx, grad, lo, hi)) {
@@ -2643,6 +2739,107 @@ extern "C" int pcl_eval_jac_merit_dev(pcl_ctx *ctx, const double *Z, const doubl
 // buffer, when the members' states are ONE contiguous run of a gradient row (the regulariser workgroup of the last knot leaves that run to
 // the infidelity workgroups of the same launch) that no regulariser covers (its terminal-knot term and the infidelity's would meet in one
 // entry: the launches then have to stay in order).  [lo, hi) = that run.
+// --- Hessian of the objective (what eval_hessian_lagrangian adds to the constraints' term: sigma * grad^2 f) -----------------------------
+// values: [terminal blocks: per term the lower triangle (i, j <= i) of its L x L block] [per buffer, knot, regulariser:
+// d2/dv_i^2 (dim) | d2/ddt dv_i (dim, dt_power >= 1) | d2/ddt^2 (dt_power 2)]; the structure says where each value belongs.
+static long long obj_hess_terms(const pcl_ctx *ctx) { return (ctx->dformA || ctx->dformc) ? (ctx->form_scope ? 1 : ctx->desc.batch) : 0; }
+static long long obj_hess_tri(const pcl_ctx *ctx) { return ctx->form_R > 0 ? (long long)ctx->form_L * (ctx->form_L + 1) / 2 : 0; }  // (a linear form has no second derivative)
+static long long obj_hess_per_knot(const pcl_ctx *ctx) {
+    long long n = 0;
+    for (const PclReg &r : ctx->regs) n += (long long)r.dim * (r.pw >= 1 ? 2 : 1) + (r.pw == 2 ? 1 : 0);
+    return n;
+}
+extern "C" int pcl_objective_hess_nnz(const pcl_ctx *ctx, int64_t *nnz) {
+    if (!ctx || !nnz) return PCL_EINVAL;
+    const int nbuf = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? ctx->desc.batch : 1;
+    *nnz = obj_hess_terms(ctx) * obj_hess_tri(ctx) + (long long)nbuf * ctx->desc.N * obj_hess_per_knot(ctx);
+    return PCL_OK;
+}
+extern "C" int pcl_objective_hess_structure(const pcl_ctx *ctx, int64_t *rows, int64_t *cols) {
+    if (!ctx || !rows || !cols) return PCL_EINVAL;
+    const pcl_desc &D = ctx->desc;
+    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
+    const int nbuf = traj ? D.batch : 1;
+    const long long base = D.index_base, zn = (long long)D.z_dim * D.N;
+    long long e = 0;
+    auto put = [&](long long a, long long b) {
+        rows[e] = std::max(a, b) + base;
+        cols[e] = std::min(a, b) + base;
+        ++e;
+    };
+    auto var = [&](long long t, long long i) {  // element i of term t's argument
+        const long long mem = ctx->form_scope ? i / ctx->x_dim : t, r = ctx->form_scope ? i - mem * ctx->x_dim : i;
+        return (traj ? mem * zn + ctx->x_offs[0] : (long long)ctx->x_offs[mem]) + (long long)(D.N - 1) * D.z_dim + r;
+    };
+    if (obj_hess_tri(ctx))
+        for (long long t = 0; t < obj_hess_terms(ctx); ++t)
+            for (long long i = 0; i < ctx->form_L; ++i)
+                for (long long j = 0; j <= i; ++j) put(var(t, i), var(t, j));
+    for (int b = 0; b < nbuf; ++b)
+        for (int k = 0; k < D.N; ++k) {
+            const long long z0 = (long long)b * zn + (long long)k * D.z_dim;
+            for (const PclReg &r : ctx->regs) {
+                for (int i = 0; i < r.dim; ++i) put(z0 + r.off + i, z0 + r.off + i);
+                if (r.pw >= 1)
+                    for (int i = 0; i < r.dim; ++i) put(z0 + D.dt_off, z0 + r.off + i);
+                if (r.pw == 2) put(z0 + D.dt_off, z0 + D.dt_off);
+            }
+        }
+    return PCL_OK;
+}
+extern "C" int pcl_objective_hess_dev(pcl_ctx *ctx, const double *Z, double Q, double sigma, double *vals) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !vals) return fail(ctx, PCL_EINVAL, "pcl_objective_hess_dev: NULL pointer");
+    ON_DEVICE(ctx);
+    const pcl_desc &D = ctx->desc;
+    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
+    const int nbuf = traj ? D.batch : 1;
+    const long long zs = traj ? (long long)D.z_dim * D.N : 0LL;
+    const long long nT = obj_hess_tri(ctx), nterm = obj_hess_terms(ctx);
+    if (nT) {
+        const PclForm f{ctx->dformA, ctx->dformc, ctx->form_R, ctx->form_L, ctx->form_scope};
+        if (!ctx->gram_ready) {  // T = 2 sum_r A_r A_r', once per goal
+            if (!ctx->dgram) HIP_TRY(ctx, hipMalloc((void **)&ctx->dgram, (size_t)nT * sizeof(double)));
+            hipLaunchKernelGGL(pcl_gram_kernel, dim3((unsigned)std::min<long long>((nT + 255) / 256, 4096)), dim3(256), 0, ctx->stream, f, ctx->dgram);
+            HIP_TRY(ctx, hipGetLastError());
+            ctx->gram_ready = true;
+        }
+        hipLaunchKernelGGL(pcl_form_kernel, dim3((unsigned)nterm), dim3(256), (size_t)std::max(ctx->form_R, 1) * sizeof(double), ctx->stream, Z, f, (const int *)ctx->dxoffs,
+                           (const double *)ctx->dweights, Q, sigma, (int)ctx->x_dim, D.N, D.z_dim, zs, (long long)D.z_dim * D.N, (double *)nullptr, (double *)nullptr, ctx->dcoef);
+        HIP_TRY(ctx, hipGetLastError());
+        hipLaunchKernelGGL(pcl_scale_kernel, dim3((unsigned)std::min<long long>((nT * nterm + 255) / 256, 8192)), dim3(256), 0, ctx->stream, (const double *)ctx->dgram,
+                           (const double *)ctx->dcoef, nT, (int)nterm, vals);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    const long long pk = obj_hess_per_knot(ctx);
+    if (pk) {
+        TRY(objective_prepare(ctx));
+        hipLaunchKernelGGL(pcl_reg_hess_kernel, dim3((unsigned)D.N, (unsigned)nbuf), dim3(256), 0, ctx->stream, Z, (const PclReg *)ctx->dregs, (int)ctx->regs.size(),
+                           (const double *)ctx->dreg_R, sigma, D.N, D.z_dim, D.dt_off, zs, pk, vals + nT * nterm);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return PCL_OK;
+}
+extern "C" int pcl_objective_hess(pcl_ctx *ctx, const double *Z, double Q, double sigma, double *vals) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !vals) return fail(ctx, PCL_EINVAL, "pcl_objective_hess: NULL pointer");
+    ON_DEVICE(ctx);
+    int64_t nnz = 0;
+    TRY(pcl_objective_hess_nnz(ctx, &nnz));
+    if (nnz == 0) return PCL_OK;
+    TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
+    double *dv = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&dv, (size_t)nnz * sizeof(double)));
+    int rc = PCL_OK;
+    if (hipMemcpyAsync(ctx->dZ, Z, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = PCL_EHIP;
+    if (rc == PCL_OK) rc = pcl_objective_hess_dev(ctx, ctx->dZ, Q, sigma, dv);
+    if (rc == PCL_OK && hipMemcpyAsync(vals, dv, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = PCL_EHIP;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == PCL_OK) rc = PCL_EHIP;
+    (void)hipFree(dv);
+    if (rc == PCL_EHIP) return fail(ctx, PCL_EHIP, "pcl_objective_hess: HIP error %s", hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
 static bool tail_applies(const pcl_ctx *ctx, const double *grad, int &lo_, int &hi_) {
     if (!grad || !ctx->dgoal || ctx->opt_objective_launches == 2) return false;
     const int nx = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? 1 : ctx->desc.batch;

@@ -260,6 +260,35 @@ class _PclContext:
             raise ValueError("subspace goal iso-vec has %d entries, expected %d" % (g.size, 2 * sub.size * sub.size))
         self._chk(self._L.pcl_set_goal_subspace(self._h, _ptr(g), sub.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), sub.size))
 
+    def set_goal_form(self, scope, A, c):
+        """Terminal loss ``Q w |1 - F(x)|``, ``F = c'x + sum_r (A_r'x)^2`` (``pcl_set_goal_form``): scope 0 per member, 1 joint."""
+        L = self.x_dim * (self.batch if scope else 1)
+        A = None if A is None else np.ascontiguousarray(A, dtype=np.float64).reshape(-1, L)
+        c = None if c is None else np.ascontiguousarray(c, dtype=np.float64).reshape(L)
+        self._L.pcl_set_goal_form.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(self._L.pcl_set_goal_form(self._h, int(scope), 0 if A is None else A.shape[0], None if A is None else A.ctypes.data, None if c is None else c.ctypes.data))
+
+    def objective_hess_structure(self):
+        n = ctypes.c_int64()
+        self._chk(self._L.pcl_objective_hess_nnz(self._h, ctypes.byref(n)))
+        rows, cols = np.empty(n.value, dtype=np.int64), np.empty(n.value, dtype=np.int64)
+        self._L.pcl_objective_hess_structure.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self._chk(self._L.pcl_objective_hess_structure(self._h, rows.ctypes.data, cols.ctypes.data))
+        return rows, cols
+
+    def objective_hess(self, Z, Q, sigma=1.0):
+        Z = self._z(Z)
+        n = ctypes.c_int64()
+        self._chk(self._L.pcl_objective_hess_nnz(self._h, ctypes.byref(n)))
+        vals = np.empty(n.value)
+        self._L.pcl_objective_hess.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+        self._chk(self._L.pcl_objective_hess(self._h, Z.ctypes.data, float(Q), float(sigma), vals.ctypes.data))
+        return vals
+
+    def objective_hess_dev(self, Z, Q, sigma, vals):
+        self._L.pcl_objective_hess_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+        self._chk(self._L.pcl_objective_hess_dev(self._h, _ptr(Z), float(Q), float(sigma), _ptr(vals)))
+
     def set_weights(self, weights):
         if weights is None:
             self._chk(self._L.pcl_set_weights(self._h, None))

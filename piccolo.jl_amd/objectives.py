@@ -12,9 +12,10 @@ an objective on the host.
 """
 import numpy as np
 
-from .quantum import operator_to_iso_vec
+from .quantum import compact_iso_to_density, operator_to_iso_vec
 
-__all__ = ["EmbeddedOperator", "UnitaryInfidelityObjective", "QuadraticRegularizer", "Objective", "get_subspace_indices"]
+__all__ = ["EmbeddedOperator", "UnitaryInfidelityObjective", "QuadraticRegularizer", "Objective", "get_subspace_indices",
+           "KetInfidelityObjective", "CoherentKetInfidelityObjective", "DensityMatrixInfidelityObjective", "DensityMatrixPureStateInfidelityObjective"]  # fmt: skip
 
 
 def get_subspace_indices(subspaces, subsystem_levels):
@@ -66,6 +67,87 @@ class UnitaryInfidelityObjective(_Term):
         self.weights = None if weights is None else np.asarray(weights, dtype=np.float64)
 
 
+def _ket_rows(goal):
+    """<g|psi> = a'x + i b'x for x = [Re psi; Im psi]."""
+    g = np.asarray(goal, dtype=complex).reshape(-1)
+    return np.concatenate([g.real, g.imag]), np.concatenate([-g.imag, g.real])
+
+
+class _FormTerm(_Term):
+    """A terminal loss ``Q |1 - F(x)|`` with ``F(x) = c'x + sum_r (A_r'x)^2`` (``pcl_set_goal_form``): ``form(x_dim, n_members)`` returns
+    ``(scope, A, c)`` -- scope 0: one term per member named in ``names``, 1: ONE term over all of them concatenated."""
+
+    Q = 100.0
+    names = ()
+    weights = None
+
+
+class KetInfidelityObjective(_FormTerm):
+    """``Q |1 - |<goal|psi_N>|^2|`` on the ket component(s) ``names`` [REF src/control/objectives.jl:24-60] (several names: the members
+    of an ensemble, one term each with optional ``weights`` -- the SamplingProblem sum)."""
+
+    def __init__(self, psi_goal, names, traj=None, Q=100.0, weights=None):
+        self.goal, self.Q = np.asarray(psi_goal, dtype=complex), float(Q)
+        self.names = [names] if isinstance(names, str) else list(names)
+        self.weights = None if weights is None else np.asarray(weights, dtype=np.float64)
+
+    def form(self, x_dim, n_members):
+        a, b = _ket_rows(self.goal)
+        if a.size != x_dim:
+            raise ValueError("goal ket has %d amplitudes, the state component %d reals" % (self.goal.size, x_dim))
+        return 0, np.stack([a, b]), None
+
+
+class CoherentKetInfidelityObjective(_FormTerm):
+    """``Q |1 - |sum_i w_i <g_i|psi_i> / sum_i w_i|^2|`` over the kets ``names`` -- ONE term: the overlaps must share a phase
+    [REF src/control/objectives.jl:96-200].  Uniform weights (or none) are the unweighted mean."""
+
+    def __init__(self, psi_goals, names, traj=None, Q=100.0, weights=None):
+        self.goals = [np.asarray(g, dtype=complex) for g in psi_goals]
+        self.names, self.Q = list(names), float(Q)
+        if len(self.goals) != len(self.names):
+            raise ValueError("number of names must match number of goals")
+        w = None if weights is None else np.asarray(weights, dtype=np.float64)
+        if w is not None:
+            if w.size != len(self.goals) or (w < 0).any() or w.sum() <= 0:
+                raise ValueError("weights: one non-negative weight per state, not all zero")
+            w = None if np.all(w == w[0]) else w / w.sum()  # [REF objectives.jl:137-143]: uniform weights are the unweighted path
+        self.coherent_weights = w
+        self.weights = None  # (no per-term weights: there is one term)
+
+    def form(self, x_dim, n_members):
+        n = len(self.goals)
+        if n != n_members:
+            raise ValueError("the coherent term names %d kets, the integrator list evaluates %d" % (n, n_members))
+        w = np.full(n, 1.0 / n) if self.coherent_weights is None else self.coherent_weights
+        rows = [_ket_rows(g) for g in self.goals]
+        return 1, np.stack([np.concatenate([w[i] * rows[i][0] for i in range(n)]), np.concatenate([w[i] * rows[i][1] for i in range(n)])]), None
+
+
+class DensityMatrixInfidelityObjective(_FormTerm):
+    """``Q |1 - Re tr(rho_N rho_goal)|`` on the compact-iso density component ``name`` [REF src/control/objectives.jl:387-411]: linear in
+    the state, ``c_e = Re tr(E_e rho_goal)`` with ``E_e`` the density the e-th unit vector stands for."""
+
+    def __init__(self, names, rho_goal, traj=None, Q=100.0, weights=None):
+        self.rho_goal, self.Q = np.asarray(rho_goal, dtype=complex), float(Q)
+        self.names = [names] if isinstance(names, str) else list(names)
+        self.weights = None if weights is None else np.asarray(weights, dtype=np.float64)
+
+    def form(self, x_dim, n_members):
+        if self.rho_goal.shape != (int(round(np.sqrt(x_dim))),) * 2:
+            raise ValueError("goal density is %r, the compact state has %d entries" % (self.rho_goal.shape, x_dim))
+        c = np.array([np.trace(compact_iso_to_density(e) @ self.rho_goal).real for e in np.eye(x_dim)])
+        return 0, None, c
+
+
+class DensityMatrixPureStateInfidelityObjective(DensityMatrixInfidelityObjective):
+    """``Q |1 - Re <psi|rho_N|psi>|`` [REF src/control/objectives.jl:413-435]."""
+
+    def __init__(self, names, psi_goal, traj=None, Q=100.0, weights=None):
+        psi = np.asarray(psi_goal, dtype=complex).reshape(-1)
+        super().__init__(names, np.outer(psi, psi.conj()), traj, Q, weights)
+
+
 class QuadraticRegularizer(_Term):
     """``1/2 sum_k dt_k^p sum_i R_i v_{k,i}^2`` on component ``name``; ``R`` a scalar or one weight per entry.
     ``dt_power`` = 2 is the DirectTrajOpt / QuantumCollocation form (r = dt v), 0 the plain knot-point form."""
@@ -94,7 +176,7 @@ class Objective:
         generators too) binds every member's context with its own weight and sums on the host; the regularisers -- terms
         of the shared controls -- are registered once, on the first member."""
         members = list(B) if isinstance(B, (list, tuple)) else [B]
-        inf = [t for t in self.terms if isinstance(t, UnitaryInfidelityObjective)]
+        inf = [t for t in self.terms if isinstance(t, (UnitaryInfidelityObjective, _FormTerm))]
         if len(inf) > 1:
             raise NotImplementedError("one terminal infidelity term per problem")
         cores = {id(b.ensemble) for b in members if hasattr(b, "ensemble")}
@@ -126,7 +208,15 @@ class Objective:
                     if isinstance(t, QuadraticRegularizer):
                         ctx.add_regularizer(t.off, t.dim, t.R, t.dt_power)
             w_host = 1.0
-            if inf:
+            if inf and isinstance(inf[0], _FormTerm):
+                t = inf[0]
+                if len(ctxs) != 1:
+                    raise NotImplementedError("ket / density losses on members with contexts of their own")
+                scope, A, c = t.form(ctx.x_dim, ctx.batch)
+                ctx.set_goal_form(scope, A, c)
+                ctx.set_weights(t.weights)
+                self._Q = t.Q
+            elif inf:
                 t = inf[0]
                 if isinstance(t.goal, EmbeddedOperator):
                     ctx.set_goal_subspace(operator_to_iso_vec(t.goal.unembed()), t.goal.subspace)
@@ -159,6 +249,19 @@ class Objective:
             if want_grad:
                 grad = g.copy() if grad is None else grad + g
         return total, grad
+
+    def hessian_structure(self):
+        """(rows, cols) of the objective's Hessian values (each entry once, row >= col; the context's index base)."""
+        if len(self._bound) != 1:
+            raise NotImplementedError("Hessian of an objective spread over several contexts")
+        return self._ctx.objective_hess_structure()
+
+    def hessian(self, traj_or_Z, sigma=1.0):
+        """sigma * grad^2 J in the order of ``hessian_structure`` -- what ``eval_hessian_lagrangian`` adds to ``pcl_hess``'s term."""
+        if len(self._bound) != 1:
+            raise NotImplementedError("Hessian of an objective spread over several contexts")
+        Z = traj_or_Z.datavec if hasattr(traj_or_Z, "datavec") else traj_or_Z
+        return self._ctx.objective_hess(Z, self._Q, sigma)
 
     def step_dev(self, Z_dev, value_dev, grad_dev, delta_dev, vals_dev, payload_dev, lam_dev=None):
         """A rank's whole step of a sharded ensemble on the device: objective value and gradient (as ``value_and_gradient_dev``), the

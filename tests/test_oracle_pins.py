@@ -481,3 +481,60 @@ def test_oracle_general_order_hessian(order):
     Hfd = _fd_jac(g, Z.reshape(-1).copy())
     assert np.abs(Hd - Hfd).max() < 2e-7
     assert np.abs(Hd - Hd.T).max() == 0
+
+
+def test_ket_and_density_loss_literals_of_the_reference():
+    """The terminal losses of the other state types, on the literals of the reference's own tests: coherent ket fidelity with weights
+    [REF src/control/objectives.jl:636-667: |0.9 + 0.1/2|^2 = 0.9025, |0.1 + 0.9/2|^2 = 0.3025, only ratios matter, uniform weights are the
+    unweighted value bit for bit, also where 1/n is not exact], the objective values 100 (1 - F) [REF :585-603], F = 1 on the goals
+    [REF :616-634]; ket fidelity [REF :24-27]; density losses on pure states [REF :387-424]."""
+    k = po.ket_to_iso
+    psi0, psi1 = np.array([1.0, 0.0], complex), np.array([0.0, 1.0], complex)
+    goals = [psi1, psi0]
+    xs = [k(psi1), k(0.5 * psi0)]
+    assert abs(po.coherent_ket_fidelity(xs, goals, [0.9, 0.1]) - 0.9025) < 1e-15
+    assert abs(po.coherent_ket_fidelity(xs, goals, [0.1, 0.9]) - 0.3025) < 1e-15
+    assert abs(po.coherent_ket_fidelity(xs, goals, [9.0, 1.0]) - po.coherent_ket_fidelity(xs, goals, [0.9, 0.1])) < 1e-15
+    assert abs(100.0 * abs(1 - po.coherent_ket_fidelity(xs, goals, [0.9, 0.1])) - 100.0 * (1 - 0.9025)) < 1e-12
+    xs3, goals3 = [k(psi1), k(0.5 * psi0), k(0.25 * psi1)], [psi1, psi0, psi1]
+    plain = po.coherent_ket_fidelity(xs3, goals3)
+    assert po.coherent_ket_fidelity(xs3, goals3, None) == plain == po.coherent_ket_fidelity(xs3, goals3, [1 / 3] * 3) == po.coherent_ket_fidelity(xs3, goals3, [1.0] * 3)
+    assert abs(po.coherent_ket_fidelity([k(psi1), k(psi0)], goals) - 1.0) < 1e-15
+    assert po.ket_fidelity_loss(k(psi1), psi1) == 1.0 and po.ket_fidelity_loss(k(psi0), psi1) == 0.0
+    plus = np.array([1.0, 1.0j]) / np.sqrt(2)
+    assert abs(po.ket_fidelity_loss(k(psi0), plus) - 0.5) < 1e-15 and abs(po.ket_fidelity_loss(k(np.exp(0.7j) * plus), plus) - 1.0) < 1e-15
+    rho = np.outer(plus, plus.conj())
+    x = po.density_to_compact_iso(rho)
+    assert po.density_matrix_pure_state_infidelity_loss(x, plus) < 1e-15 and abs(po.density_matrix_pure_state_infidelity_loss(x, psi0) - 0.5) < 1e-15
+    assert abs(po.density_matrix_infidelity_loss(x, np.outer(psi1, psi1.conj())) - 0.5) < 1e-15
+
+
+def test_terminal_loss_forms_of_the_host_mirror():
+    """Every terminal loss of the reference is Q |1 - F|, F = c'x + sum_r (A_r'x)^2: the rows and linear parts piccolo.jl_amd/objectives.py
+    hands to pcl_set_goal_form reproduce the oracle's restatement of the reference's formulas on random states (no GPU involved)."""
+    import piccolo_jl_amd as pa
+
+    rng = np.random.default_rng(8)
+    d = 5
+    F_of = lambda A, c, x: (0.0 if c is None else c @ x) + (0.0 if A is None else ((A @ x) ** 2).sum())
+    g = rng.standard_normal(d) + 1j * rng.standard_normal(d)
+    g /= np.linalg.norm(g)
+    scope, A, c = pa.KetInfidelityObjective(g, "ψ̃").form(2 * d, 1)
+    for _ in range(3):
+        x = rng.standard_normal(2 * d)
+        assert scope == 0 and abs(F_of(A, c, x) - po.ket_fidelity_loss(x, g)) < 1e-13
+    goals = [rng.standard_normal(d) + 1j * rng.standard_normal(d) for _ in range(3)]
+    for w in (None, [1.0, 1.0, 1.0], [0.9, 0.1, 0.4]):
+        scope, A, c = pa.CoherentKetInfidelityObjective(goals, ["a", "b", "c"], weights=w).form(2 * d, 3)
+        xs = [rng.standard_normal(2 * d) for _ in range(3)]
+        assert scope == 1 and abs(F_of(A, c, np.concatenate(xs)) - po.coherent_ket_fidelity(xs, goals, w)) < 1e-12
+    n = 3
+    M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    rho_goal = M @ M.conj().T
+    rho_goal /= np.trace(rho_goal).real
+    scope, A, c = pa.DensityMatrixInfidelityObjective("ρ", rho_goal).form(n * n, 1)
+    x = rng.standard_normal(n * n)
+    assert A is None and abs(abs(1 - F_of(A, c, x)) - po.density_matrix_infidelity_loss(x, rho_goal)) < 1e-13
+    psi = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    scope, A, c = pa.DensityMatrixPureStateInfidelityObjective("ρ", psi).form(n * n, 1)
+    assert abs(abs(1 - F_of(A, c, x)) - po.density_matrix_pure_state_infidelity_loss(x, psi)) < 1e-12

@@ -1189,6 +1189,203 @@ def test_order_policy_picks_the_order_that_matches_the_exp_constraint():
 
 
 
+def _dense_from_triplets(rows, cols, vals, nvar):
+    H = np.zeros((nvar, nvar))
+    np.add.at(H, (rows, cols), vals)
+    return H + np.tril(H, -1).T
+
+
+def test_ket_coherent_ket_and_density_objectives_on_the_device():
+    """The terminal losses of the other state types [REF src/control/objectives.jl:24-60, 96-200, 387-435] through pcl_set_goal_form:
+    value and gradient of the whole objective (loss + regularisers) against the oracle's restatement of the reference's formulas
+    (gradients: central differences of it, as the reference takes them with ForwardDiff), the reference's literal 100 (1 - 0.9025), and
+    the objective's Hessian against the exact second differences of the oracle's (at most quadratic) fidelity and of the regularisers."""
+    rng = np.random.default_rng(31)
+    d, m, N, Kk = 3, 2, 4, 3
+    n = 2 * d
+    Hd = rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))
+    Hs = [(lambda A: A + A.conj().T)(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d))) for _ in range(m)]
+    so = po.quantum_system(0.3 * (Hd + Hd.conj().T), Hs, [1.0] * m)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    z_dim = Kk * n + 2 + m
+    Z = 0.4 * rng.standard_normal((N, z_dim))
+    Z[:, Kk * n] = 0.05 + 0.05 * rng.random(N)
+    comps = {"ψ̃%d" % (i + 1): Z[:, i * n : (i + 1) * n].T for i in range(Kk)}
+    comps["Δt"], comps["t"], comps["u"] = Z[:, Kk * n][None], Z[:, Kk * n + 1][None], Z[:, Kk * n + 2 :].T
+    traj = pa.NamedTrajectory(comps, controls=("u", "Δt"), timestep="Δt")
+    names = ["ψ̃%d" % (i + 1) for i in range(Kk)]
+    B = pa.HipPadeIntegrator(G0, Gj, traj, names)
+    goals = [(lambda v: v / np.linalg.norm(v))(rng.standard_normal(d) + 1j * rng.standard_normal(d)) for _ in range(Kk)]
+    Q, Ru = 100.0, np.array([0.3, 0.7])
+    u_off, dt_off = Kk * n + 2, Kk * n
+    nvar = N * z_dim
+
+    def reg(Zf, pw):
+        Zm = Zf.reshape(N, z_dim)
+        return po.quadratic_regularizer(Zm, u_off, m, Ru, dt_off, pw)
+
+    def check(J, loss, pw):
+        """loss(Z [N, z_dim]) -> the terminal term; the regulariser on u with dt_power pw rides along."""
+        total = lambda zf: loss(zf.reshape(N, z_dim)) + reg(zf, pw)
+        val, grad = J.value_and_gradient(traj)
+        z0 = traj.datavec.copy()
+        assert abs(val - total(z0)) < 1e-11 * max(1.0, abs(val))
+        close(grad, po.numerical_gradient(total, z0, 1e-6), 2e-6)
+        rows, cols = J.hessian_structure()
+        assert (rows >= cols).all() and len(set(zip(rows.tolist(), cols.tolist()))) >= len(rows) - N  # ((dt, dt) repeats per regulariser only)
+        Hn = np.zeros((nvar, nvar))
+        for i in range(nvar):  # central differences of the oracle's (numerical) gradient, column by column
+            e = np.zeros(nvar)
+            e[i] = 1e-4
+            Hn[:, i] = (po.numerical_gradient(total, z0 + e, 1e-4) - po.numerical_gradient(total, z0 - e, 1e-4)) / 2e-4
+        for sigma in (1.0, 0.37):
+            H = _dense_from_triplets(rows, cols, J.hessian(traj, sigma), nvar)
+            assert np.abs(H - sigma * 0.5 * (Hn + Hn.T)).max() < 2e-4 * max(1.0, np.abs(H).max()), (sigma, np.abs(H - sigma * Hn).max())
+        return val
+
+    last = lambda Zm, i: Zm[-1, i * n : (i + 1) * n]
+    for pw in (2, 1):
+        # one ket term per member (a SamplingProblem-style weighted sum over the kets)
+        w = np.array([0.5, 0.3, 0.2])
+        J = (pa.KetInfidelityObjective(goals[0], names, traj, Q=Q, weights=w) + pa.QuadraticRegularizer("u", traj, Ru, pw)).bind(B)
+        check(J, lambda Zm: sum(w[i] * Q * abs(1 - po.ket_fidelity_loss(last(Zm, i), goals[0])) for i in range(Kk)), pw)
+        # ONE coherent term over the three kets, weighted and unweighted
+        for cw in (None, [0.9, 0.1, 0.4]):
+            J = (pa.CoherentKetInfidelityObjective(goals, names, traj, Q=Q, weights=cw) + pa.QuadraticRegularizer("u", traj, Ru, pw)).bind(B)
+            check(J, lambda Zm: Q * abs(1 - po.coherent_ket_fidelity([last(Zm, i) for i in range(Kk)], goals, cw)), pw)
+    # exact Hessian of the coherent term: -s Q times the second differences of the quadratic fidelity
+    J = pa.Objective([pa.CoherentKetInfidelityObjective(goals, names, traj, Q=Q, weights=[0.9, 0.1, 0.4])]).bind(B)
+    rows, cols = J.hessian_structure()
+    H = _dense_from_triplets(rows, cols, J.hessian(traj, 1.0), nvar)
+    t0 = (N - 1) * z_dim
+    Fq = lambda x: po.coherent_ket_fidelity([x[i * n : (i + 1) * n] for i in range(Kk)], goals, [0.9, 0.1, 0.4])
+    sgn = 1.0 if Fq(Z[-1, : Kk * n]) <= 1 else -1.0
+    close(H[t0 : t0 + Kk * n, t0 : t0 + Kk * n], -sgn * Q * po.quadratic_hessian(Fq, Kk * n), 1e-11)
+    assert np.abs(H).sum() == np.abs(H[t0 : t0 + Kk * n, t0 : t0 + Kk * n]).sum()
+    B.close()
+    # the reference's own literal [REF objectives.jl:585-603]: <psi1|psi1> = 1, <psi0|psi0/2> = 1/2, weights (0.9, 0.1): 100 (1 - 0.9025)
+    psi0, psi1 = np.array([1.0, 0.0], complex), np.array([0.0, 1.0], complex)
+    Nl = 4
+    c2 = {"ψ̃1": np.tile(po.ket_to_iso(psi1)[:, None], (1, Nl)), "ψ̃2": np.tile(po.ket_to_iso(0.5 * psi0)[:, None], (1, Nl)),
+          "u": rng.standard_normal((1, Nl)), "Δt": np.full((1, Nl), 0.1)}  # fmt: skip
+    t2 = pa.NamedTrajectory(c2, controls=("u", "Δt"), timestep="Δt")
+    s2 = po.quantum_system(np.diag([0.0, 1.0]).astype(complex), [np.array([[0, 1], [1, 0]], complex)], [1.0])
+    B2 = pa.HipPadeIntegrator(s2.G_drift, np.array(s2.G_drives), t2, ["ψ̃1", "ψ̃2"])
+    for wts, F in (([0.9, 0.1], 0.9025), ([0.1, 0.9], 0.3025)):
+        v, _ = pa.Objective([pa.CoherentKetInfidelityObjective([psi1, psi0], ["ψ̃1", "ψ̃2"], t2, Q=100.0, weights=wts)]).bind(B2).value_and_gradient(t2)
+        assert abs(v - 100.0 * (1 - F)) < 1e-12
+    vu, _ = pa.Objective([pa.CoherentKetInfidelityObjective([psi1, psi0], ["ψ̃1", "ψ̃2"], t2, Q=100.0)]).bind(B2).value_and_gradient(t2)
+    vw, _ = pa.Objective([pa.CoherentKetInfidelityObjective([psi1, psi0], ["ψ̃1", "ψ̃2"], t2, Q=100.0, weights=[0.5, 0.5])]).bind(B2).value_and_gradient(t2)
+    assert vu == vw  # uniform weights are the unweighted path
+    B2.close()
+    # a density: compact iso vector under the compact Lindbladian; both density losses are linear in the state
+    nl = 3
+    H0 = rng.standard_normal((nl, nl)) + 1j * rng.standard_normal((nl, nl))
+    a = pa.annihilate(nl)
+    sys_ = pa.OpenQuantumSystem(0.5 * (H0 + H0.conj().T), [a + a.conj().T], [1.0], [0.3 * a])
+    psi = rng.standard_normal(nl) + 1j * rng.standard_normal(nl)
+    psi /= np.linalg.norm(psi)
+    times = np.cumsum(np.concatenate(([0.0], 0.05 + 0.05 * rng.random(N - 1))))
+    trd = pa.density_trajectory(sys_, 0.5 * rng.standard_normal((1, N)), times, np.outer(psi, psi.conj()), np.outer(psi, psi.conj()))
+    Bd = pa.BilinearIntegrator(sys_, trd)
+    gpsi = rng.standard_normal(nl) + 1j * rng.standard_normal(nl)
+    gpsi /= np.linalg.norm(gpsi)
+    Mg = rng.standard_normal((nl, nl)) + 1j * rng.standard_normal((nl, nl))
+    rho_g = Mg @ Mg.conj().T / np.trace(Mg @ Mg.conj().T).real
+    xo = trd.components[Bd.x_name].start
+    for J, loss in ((pa.DensityMatrixPureStateInfidelityObjective(Bd.x_name, gpsi, trd, Q=Q), lambda x: Q * po.density_matrix_pure_state_infidelity_loss(x, gpsi)),
+                    (pa.DensityMatrixInfidelityObjective(Bd.x_name, rho_g, trd, Q=Q), lambda x: Q * po.density_matrix_infidelity_loss(x, rho_g))):
+        Jb = pa.Objective([J]).bind(Bd)
+        val, grad = Jb.value_and_gradient(trd)
+        xN = trd.datavec.reshape(N, trd.dim)[-1, xo : xo + nl * nl]
+        assert abs(val - loss(xN)) < 1e-12 * max(1.0, abs(val))
+        gref = np.zeros((N, trd.dim))
+        gref[-1, xo : xo + nl * nl] = po.numerical_gradient(loss, xN, 1e-6)
+        close(grad, gref.reshape(-1), 1e-7)
+        assert Jb.hessian(trd).size == 0  # linear in the state: no second derivative
+    Bd.close()
+
+
+@pytest.mark.parametrize("sub", [False, True])
+def test_objective_hessian_of_the_unitary_problem(sub):
+    """sigma grad^2 f of the unitary templates' objective (terminal infidelity, plain or on an EmbeddedOperator's subspace, + the three
+    quadratic regularisers) -- the part of eval_hessian_lagrangian that pcl_hess leaves to the objective [REF spline_pulse_problem.jl:96,
+    objectives.jl:330-356]: the terminal block against the exact second differences of the oracle's (quadratic) fidelity, the
+    regulariser entries against their closed forms, the structure's index pairs each once (lower triangle); an ensemble with weights
+    and a multistart batch."""
+    rng = np.random.default_rng(17)
+    so = po.config_system(2)
+    d, m, N = so.levels, so.n_drives, 5
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    Z, lay = po.synthetic_trajectory(so, N, seed=3)
+    Z[:, lay.dt_off] = 0.1 + 0.05 * rng.random(N)
+    traj = traj_from_Z(pa, Z, lay)
+    B = pa.HipPadeIntegrator(G0, Gj, traj)
+    if sub:
+        idx = pa.get_subspace_indices([[0, 1], [0]], [2, 2])
+        Us = np.linalg.qr(rng.standard_normal((len(idx), len(idx))) + 1j * rng.standard_normal((len(idx), len(idx))))[0]
+        goal = pa.EmbeddedOperator(Us, idx, [2, 2])
+        Ufull, subspace = goal.operator, idx
+    else:
+        goal = np.linalg.qr(rng.standard_normal((d, d)) + 1j * rng.standard_normal((d, d)))[0]
+        Ufull, subspace = goal, None
+    Q, regs = 100.0, (("u", 1e-2, 2), ("du", np.linspace(0.5, 2.0, m), 1), ("ddu", 3.0, 0))
+    J = pa.UnitaryInfidelityObjective(goal, "Ũ⃗", traj, Q=Q)
+    for nm, R, pw in regs:
+        J = J + pa.QuadraticRegularizer(nm, traj, R, pw)
+    J.bind(B)
+    rows, cols = J.hessian_structure()
+    nvar = N * lay.z_dim
+    assert (rows >= cols).all() and rows.max() < nvar
+    xd = lay.x_dim
+    Fq = lambda x: po.unitary_fidelity_loss(x, Ufull, subspace)
+    for sigma in (1.0, 2.5):
+        H = _dense_from_triplets(rows, cols, J.hessian(traj, sigma), nvar)
+        t0 = (N - 1) * lay.z_dim + lay.x_off
+        sgn = 1.0 if Fq(Z[-1, lay.x_off : lay.x_off + xd]) <= 1 else -1.0
+        close(H[t0 : t0 + xd, t0 : t0 + xd], -sgn * sigma * Q * po.quadratic_hessian(Fq, xd), 1e-10)
+        Href = np.zeros((nvar, nvar))
+        Href[t0 : t0 + xd, t0 : t0 + xd] = H[t0 : t0 + xd, t0 : t0 + xd]
+        for k in range(N):
+            z0, h = k * lay.z_dim, Z[k, lay.dt_off]
+            for (nm, R, pw), off in zip(regs, (lay.u_off, lay.u_off + m, lay.u_off + 2 * m)):
+                Rv = np.broadcast_to(np.asarray(R, float), (m,))
+                v = Z[k, off : off + m]
+                for i in range(m):
+                    Href[z0 + off + i, z0 + off + i] += sigma * h**pw * Rv[i]
+                    if pw >= 1:
+                        c = sigma * pw * h ** (pw - 1) * Rv[i] * v[i]
+                        Href[z0 + off + i, z0 + lay.dt_off] += c
+                        Href[z0 + lay.dt_off, z0 + off + i] += c
+                if pw == 2:
+                    Href[z0 + lay.dt_off, z0 + lay.dt_off] += sigma * (Rv * v * v).sum()
+        close(H, Href, 1e-11)
+    # the Hessian is the derivative of the gradient the same context returns
+    z0 = traj.datavec.copy()
+    H = _dense_from_triplets(rows, cols, J.hessian(traj, 1.0), nvar)
+    for i in rng.choice(nvar, 12, replace=False):
+        e = np.zeros(nvar)
+        e[i] = 1e-6
+        gp, gm = J.value_and_gradient(z0 + e)[1], J.value_and_gradient(z0 - e)[1]
+        assert np.abs((gp - gm) / 2e-6 - H[:, i]).max() < 1e-5 * max(1.0, np.abs(H[:, i]).max())
+    B.close()
+    # a multistart batch: one block per seed, offset by the seed's variables
+    S = 3
+    Zs = [po.synthetic_trajectory(so, N, seed=40 + q)[0] for q in range(S)]
+    ms = pa.HipPadeMultistart(G0, Gj, traj, S)
+    Jm = (pa.UnitaryInfidelityObjective(goal, "Ũ⃗", traj, Q=Q) + pa.QuadraticRegularizer("u", traj, 1e-2, 2)).bind(ms)
+    rows, cols = Jm.hessian_structure()
+    vals = Jm.hessian(np.stack(Zs), 1.0)
+    Hm = _dense_from_triplets(rows, cols, vals, S * nvar)
+    for q in range(S):
+        t0 = q * nvar + (N - 1) * lay.z_dim + lay.x_off
+        sgn = 1.0 if Fq(Zs[q][-1, lay.x_off : lay.x_off + xd]) <= 1 else -1.0
+        close(Hm[t0 : t0 + xd, t0 : t0 + xd], -sgn * Q * po.quadratic_hessian(Fq, xd), 1e-10)
+    assert np.abs(Hm[:nvar, nvar:]).max() == 0.0
+    ms.close()
+
+
+
 def test_pattern_compiled_fused_kernel_soak():
     """Kernel 4 synchronises its waves through LDS counters with bounded waits (a wait that gives up writes NaN): 300 launches per
     shape of launch (one trajectory, four, compact, contiguous compact) -- every launch bitwise equal to the first, nothing NaN."""
