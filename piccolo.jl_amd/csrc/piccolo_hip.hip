@@ -2040,7 +2040,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
 // --- order policy ---------------------------------------------------------------------------------
 // The reference's constraint is x_{k+1} = exp(dt_k G(u_k)) x_k (docs/src/concepts/index.md:21); the diagonal Pade residual of order 2q
 // deviates from it by  kappa_q theta^(2q+1) (1 + O(theta^2)) |x|,  theta = |dt_k G(u_k)|_2,  kappa_q = (q!)^2 / ((2q)! (2q+1)!)  -- the
-// leading term of exp - r_qq.  (Measured with the oracle on exp-feasible trajectories, profiles/pade_vs_exp.json: config 3, theta = 0.438:
+// leading term of exp - r_qq.  (Measured on exp-feasible trajectories, scripts/pade_vs_exp.py -> profiles/pade_vs_exp.json: config 3, theta = 0.438:
 // 1.6e-5 / 1.6e-11 / 7.9e-15 at orders 4 / 8 / 10 against 2.2e-5 / 2.3e-11 / 1.1e-14 from this bound.)  pade_order = 0 asks for the
 // smallest order whose bound is below a tolerance, theta from the problem's bounds (pcl_set_order_policy) or, failing that, from the
 // first trajectory a host-pointer entry point sees (with a margin of 1.5 on theta: later iterates move inside their bounds).
