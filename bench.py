@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="seeds (multistart) or members (ensemble) per GPU; default: 8 on one GPU (the 8-GPU share), 64 // N on N > 1 GPUs")
     ap.add_argument("--total-units", type=int, default=64, help="BASELINE configs 4 / 5: members / seeds of the whole job")
     ap.add_argument("--knots", type=int, default=100)
+    ap.add_argument("--order", type=int, default=4, help="diagonal Pade order of the timed workload (profiling passes of orders 8 / 10; the headline `value` is order 4)")
     ap.add_argument("--cols-per-slice", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shares", action="store_true", help="auto on 1 GPU: skip the multistart / ensemble share measurements")
@@ -262,7 +263,7 @@ def main():
     if workload == "ensemble":
         wall, dev, info, ubytes = run_ensemble(B, args.steps, args.warmup, True)
     else:
-        wall, dev, info = run_multistart(units, args.steps, args.warmup, True)
+        wall, dev, info = run_multistart(units, args.steps, args.warmup, True, args.order)
         ubytes = abytes
     t = torch.tensor([wall, dev], dtype=torch.float64, device="cuda")
     if dist is not None:
@@ -303,7 +304,7 @@ def main():
     pve = os.path.join(ROOT, "profiles", "pade_vs_exp.json")
     if os.path.exists(pve):  # deviation of the Pade-p constraint from the reference's exp constraint, per config (scripts/pade_vs_exp.py)
         try:
-            out["config"]["pade_order"] = 4
+            out["config"]["pade_order"] = args.order
             out["config"]["pade_vs_exp"] = {k: {kk: vv for kk, vv in v.items() if kk.startswith("order_") or kk == "max_norm_dtG"}
                                             for k, v in json.load(open(pve))["configs"].items()}
         except Exception:

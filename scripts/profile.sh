@@ -25,5 +25,12 @@ run all_sq1 "$ALL" --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_W
 run all_sq2 "$ALL" --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS
 run single_tcc "$SINGLE" --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum
 run single_tcc2 "$SINGLE" --pmc TCC_EA0_WRREQ_STALL_sum TCC_EA0_WR_UNCACHED_32B_sum TCC_EA0_WRREQ_64B_sum
+run multistart_tcc2 "$MULTI" --pmc TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
+PCL_V4_TICKET=0 run multistart_static_tcc2 "$MULTI" --pmc TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum   # the static split beside the slice tickets
+PCL_V4_TICKET=0 run trace_multistart_static "$MULTI" --kernel-trace --stats
+# the order that matches the reference's exp constraint at config 3, with passes of its own
+run trace_single_order8 "$SINGLE --order 8" --kernel-trace --stats
+run single_order8_write "$SINGLE --order 8" --pmc WRITE_SIZE
+run single_order8_sq "$SINGLE --order 8" --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS
 cd $ROOT
 python scripts/summarize_profile.py $OUT gpurun_out/profiles_$TAG $TAG
