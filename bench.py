@@ -446,7 +446,7 @@ def main():
                                      ("compact_32_threads", 2, 32), ("compact_64_threads", 2, 64)):
             it.ctx.set_option("host_path", path)
             it.ctx.set_option("host_threads", threads)
-            for _ in range(3):
+            for _ in range(14 if (path == 2 and threads == 0) else 3):  # (auto: the context samples six thread counts over its first twelve calls)
                 it.ctx.eval_jac(t0.datavec, hd, hvals)
             th = time.perf_counter()
             for _ in range(8):
@@ -455,8 +455,16 @@ def main():
             hres[label] = {"evals_per_s": 1.0 / th, "ms_per_eval": th * 1e3, "delivered_GBps": hvals.nbytes / th / 1e9,
                            "threads": it.ctx.get_option("host_threads") if path == 2 else 0}
         best = max(hres, key=lambda k: hres[k]["evals_per_s"])
-        ex["host_delivered"] = dict(hres["compact_plus_host_expansion"], note="default path (pcl_eval_jac on pageable numpy arrays)",
-                                    paths=hres, best=best)
+        it.ctx.set_option("host_threads", 0)
+        it.ctx.set_option("host_path", 2)
+        # the host's own write bandwidth beside it: the same bytes written by numpy into the same array (one thread; STREAM-style fill)
+        tf = time.perf_counter()
+        for _ in range(4):
+            hvals.fill(1.0)
+        fill_GBps = 4 * hvals.nbytes / (time.perf_counter() - tf) / 1e9
+        ex["host_delivered"] = dict(hres["compact_plus_host_expansion"], note="default path (pcl_eval_jac on pageable numpy arrays); threads chosen by a sweep over the context's first twelve calls",
+                                    paths=hres, best=best, tuned_threads=it.ctx.get_option("host_threads"), tuned_call_GBps=it.ctx.get_option("host_expand_MBps") / 1e3,
+                                    host_fill_GBps_one_thread=fill_GBps)
         it.close()
         # BASELINE config 2 (CNOT, d=4, N=100): launch-bound, report us/eval
         s2 = synthetic.config_system(2)

@@ -129,6 +129,10 @@ struct pcl_ctx {
     hipEvent_t ev_chunk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int64_t opt_prof = 0;  // -DPCL_PROFILE builds only
     int64_t opt_host_threads = 0, opt_host_path = 0, opt_host_chunks = 4;
+    int host_threads_tuned = 0;       // auto: the thread count the sweep over the context's first host-delivered calls found fastest
+    int host_tune_calls = 0;          // ... calls sampled so far
+    double host_tune_t[8] = {1e300, 1e300, 1e300, 1e300, 1e300, 1e300, 1e300, 1e300};
+    double host_expand_GBps = 0.0;    // ... the delivered rate of the fastest sampled call
     int win_first = 0, win_count = 0;  // member window (pcl_set_member_window): the members / seeds the evaluator entry points cover
     int64_t opt_cols_per_slice = 0, opt_use_mfma = 1, opt_nt = -1 /* auto by launch size */, opt_kernel = 0;  // 0 = auto: 3 where its specialised instance applies, else 1 / 2 by shape
     long long *ddbg = nullptr;
@@ -700,6 +704,7 @@ extern "C" int pcl_hess_structure_i64(const pcl_ctx *ctx, int64_t *rows, int64_t
 // no SGPR spills).  A few shapes are instantiated statically; any other shape is compiled on first use from the kernel
 // headers that sit next to this library (pcl_*.hpp, located with dladdr) -- about 1.5 s, cached for the process.
 // libhiprtc is opened lazily; when it or the headers are missing the run-time-shape instances are used (same results).
+#include <chrono>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -2226,10 +2231,18 @@ static int ensure_pinned(pcl_ctx *ctx, double **buf, long long count) {
     if (e != hipSuccess) return fail(ctx, PCL_ENOMEM, "hipHostMalloc(%lld doubles): %s", count, hipGetErrorString(e));
     return PCL_OK;
 }
+// Auto thread count of the host expansion: the first 2 x 6 host-delivered calls of a context (launches worth it) are each run at one of six
+// candidate counts -- real calls, real results -- and the count whose fastest call was shortest serves the context from then on.  The
+// right fraction of the cores differs by host and cannot be read off the expansion alone (it overlaps the chunked copy over PCIe:
+// expansion-only sweeps picked 24 threads where the whole call is fastest at 32; 64 beat a fixed 48 by 18 % on another box of the pool).
+static const int kHostTuneCand[] = {16, 24, 32, 48, 64, 96};
+static const int kHostTuneN = 6;
 static int host_threads(const pcl_ctx *ctx) {
     if (ctx->opt_host_threads > 0) return (int)std::min<int64_t>(ctx->opt_host_threads, 256);
-    const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(hw ? hw / 2 : 8u, 48u));  // memory-write-bound: a fraction of the cores saturates it
+    if (ctx->host_threads_tuned > 0) return ctx->host_threads_tuned;
+    const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+    if (ctx->host_tune_calls < 2 * kHostTuneN) return (int)std::min<unsigned>((unsigned)kHostTuneCand[ctx->host_tune_calls % kHostTuneN], hw);
+    return (int)std::max(1u, std::min(hw / 2, 48u));
 }
 
 // Host-pointer evaluation.  Two ways to deliver the Jacobian values into the caller's (pageable) array:
@@ -2242,6 +2255,7 @@ static int host_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *v
     if (!Z || (!delta && !vals)) return fail(ctx, PCL_EINVAL, "NULL pointer");
     ON_DEVICE(ctx);
     TRY(resolve_order(ctx, Z, "pcl_eval_jac"));
+    const auto t_begin = std::chrono::steady_clock::now();
     const long long nbk = (long long)ctx->win_count * ctx->K, nbk_all = (long long)ctx->desc.batch * ctx->K;
     const long long nv = jac_per_full(ctx) * nbk;
     const bool compact_path = vals && ctx->cols > 1 && ctx->opt_host_path != 1;
@@ -2273,6 +2287,8 @@ static int host_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *v
         HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[c], ctx->stream));
     }
     if (delta) HIP_TRY(ctx, hipMemcpyAsync(ctx->hdelta, ctx->ddelta, n_rows(ctx) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    const bool tuning = ctx->opt_host_threads <= 0 && ctx->host_threads_tuned == 0 && ctx->host_tune_calls < 2 * kHostTuneN && nv * 8 >= (32LL << 20);
+    if (!tuning && ctx->opt_host_threads <= 0 && ctx->host_threads_tuned == 0) ctx->host_tune_calls = 2 * kHostTuneN;  // (small launches: the default count)
     const int want_threads = host_threads(ctx);
     if (!ctx->pool || ctx->pool->size() != want_threads - 1) {
         delete ctx->pool;
@@ -2295,6 +2311,18 @@ static int host_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *v
     if (rc != PCL_OK) return fail(ctx, PCL_EHIP, "hipEventSynchronize: %s", hipGetErrorString(hipGetLastError()));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (delta) memcpy(delta, ctx->hdelta, (size_t)n_rows(ctx) * sizeof(double));
+    if (tuning) {  // this call was one sample of the sweep
+        const double t_call = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        const int ci = ctx->host_tune_calls % kHostTuneN;
+        ctx->host_tune_t[ci] = std::min(ctx->host_tune_t[ci], t_call);
+        if (++ctx->host_tune_calls == 2 * kHostTuneN) {
+            int bi = 0;
+            for (int c = 1; c < kHostTuneN; ++c)
+                if (ctx->host_tune_t[c] < ctx->host_tune_t[bi]) bi = c;
+            ctx->host_threads_tuned = std::min(kHostTuneCand[bi], (int)std::max(2u, std::thread::hardware_concurrency()));
+            ctx->host_expand_GBps = (double)nv * 8.0 / ctx->host_tune_t[bi] / 1e9;
+        }
+    }
     return check_device_error(ctx, "pcl_eval_jac");
 }
 extern "C" int pcl_eval(pcl_ctx *ctx, const double *Z, double *delta) {
@@ -3157,6 +3185,8 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->n_cu;
     else if (!strcmp(key, "host_threads"))
         *v = host_threads(ctx);
+    else if (!strcmp(key, "host_expand_MBps"))  // delivered rate of the fastest call of the thread-count sweep (0 before it has finished)
+        *v = (int64_t)(ctx->host_expand_GBps * 1e3);
     else if (!strcmp(key, "host_path"))
         *v = ctx->opt_host_path;
     else if (!strcmp(key, "host_chunks"))
