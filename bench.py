@@ -74,7 +74,7 @@ def time_steps(launch, steps, warmup, torch, dist):
     for _ in range(warmup):
         launch()
     # torch creates the underlying hipEvent at an event's FIRST record: recorded once here, the two events exist before the timed
-    # region (created inside it they cost 1-2 us per step of a 20-step region: scripts/probes/bench_fixed_latency.py)
+    # region (created inside it they cost 1-2 us per step of a 20-step region: lab/probes/bench_fixed_latency.py)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     ev1.record()
@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="seeds (multistart) or members (ensemble) per GPU; default: 8 on one GPU (the 8-GPU share), 64 // N on N > 1 GPUs")
     ap.add_argument("--total-units", type=int, default=64, help="BASELINE configs 4 / 5: members / seeds of the whole job")
     ap.add_argument("--knots", type=int, default=100)
+    ap.add_argument("--kernel-version", type=int, default=0, help="force a kernel family for the timed workload (3: the matrix-core kernel; profiling passes of the MFMA A/B)")
     ap.add_argument("--order", type=int, default=4, help="diagonal Pade order of the timed workload (profiling passes of orders 8 / 10; the headline `value` is order 4)")
     ap.add_argument("--cols-per-slice", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -174,7 +175,7 @@ def main():
     t0 = seeds[0]
     abytes = algorithmic_bytes_per_eval(d, m, N, t0.dim)
 
-    def run_multistart(batch, steps, warmup, use_dist, order=4, nbuf=1):
+    def run_multistart(batch, steps, warmup, use_dist, order=4, nbuf=1, kernel_version=0):
         """`batch` independent trajectories in one launch per step (batch 1 = BASELINE config 3 strictly).  nbuf > 1: the same launch on
         nbuf separately allocated values arrays, one after the other; returns the per-array times as info["per_buffer_us"] and the
         MEDIAN array's (wall, device) times."""
@@ -184,6 +185,8 @@ def main():
         c = ms.ctx
         if args.cols_per_slice:
             c.set_option("cols_per_slice", args.cols_per_slice)
+        if kernel_version:
+            c.set_option("kernel_version", kernel_version)
         c.set_stream(stream.cuda_stream)
         Zd = torch.from_numpy(np.stack([t.datavec for t in seeds[:batch]])).cuda()
         dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
@@ -263,7 +266,7 @@ def main():
     if workload == "ensemble":
         wall, dev, info, ubytes = run_ensemble(B, args.steps, args.warmup, True)
     else:
-        wall, dev, info = run_multistart(units, args.steps, args.warmup, True, args.order)
+        wall, dev, info = run_multistart(units, args.steps, args.warmup, True, args.order, kernel_version=args.kernel_version)
         ubytes = abytes
     t = torch.tensor([wall, dev], dtype=torch.float64, device="cuda")
     if dist is not None:
@@ -335,6 +338,20 @@ def main():
         "algorithmic_bytes_per_launch": ubytes * units,
         "note": "kernel_us is the HIP-event time of one step" + (" (fused kernel + objective + payload kernels + all-reduce)" if workload == "ensemble" else " = one launch of the fused kernel"),
     }
+    # north_star: "MFMA utilisation reported against gfx950 peak".  The benchmarked kernel issues no MFMA (SQ_INSTS_VALU_MFMA_MOPS_F64 = 0 in
+    # the committed counter pass): on gfx950 the f64 MFMA issues at the f64 vector rate and the generators are 21 % dense, so the products
+    # are straight-line v_fma_f64 on the sparsity pattern.  The matrix-core kernel (kernel_version 3) is timed beside it.
+    out["roofline"]["mfma_util"] = 0.0
+    mf = os.path.join(ROOT, "profiles", "mfma_ab.json")
+    if os.path.exists(mf):
+        try:
+            out["roofline"]["mfma_path"] = json.load(open(mf))
+        except Exception:
+            pass
+    if rank == 0 and world == 1 and workload == "single" and not args.no_extras and not args.kernel_version:
+        w3, d3, i3 = run_multistart(1, max(20, min(args.steps, 100)), 10, False, 4, kernel_version=3)
+        out["roofline"].setdefault("mfma_path", {})["kernel3_us_per_launch_this_run"] = d3 / max(20, min(args.steps, 100)) * 1e6
+        out["roofline"]["mfma_path"]["kernel3_id"] = i3["kernel_id"]
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):  # HBM bytes per launch from the rocprofv3 --pmc passes (scripts/profile.sh), per workload
         try:

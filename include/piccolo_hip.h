@@ -278,68 +278,19 @@ int pcl_reduce_sum_dev(pcl_ctx *ctx, double *buf_dev, int64_t n);
 int pcl_reduce_sum(pcl_ctx *ctx, double *buf_host, int64_t n); /* same for a host buffer (staged; returns after the sum) */
 int pcl_comm_destroy(pcl_ctx *ctx);
 
-/* tuning / introspection ----------------------------------------------------
- * A DEPLOYMENT sets none of these, or only:  "jit" (0 where hiprtc must not run), "host_threads" / "host_path" (host-pointer entry
- * points), "index_base" and "pade_order" (in pcl_desc).  Everything else below is a MEASUREMENT / TEST switch: the defaults are
- * what the benchmark runs, every setting produces the same results up to the order of additions inside a kernel family, and within
- * a family every work split is bitwise equal -- which is what the parity tests use them for.  The kernels behind "kernel_version"
- * 1 / 2, "hess_kernel" 1 - 3 and the general-order kernels are not experiments: they serve the shapes the pattern-compiled kernels do
- * not take (dense or non-iso generators, d < 9, more than 6 drives, kets and compact densities).
- * Experiments of earlier rounds (stream pieces, per-XCD roles, split producer / expander kernels, the column kernel, the two-step
- * general-order path, ablation switches) are not part of the library any more.
- * set:  "kernel_version"     residual + Jacobian: 0 auto | 1 one workgroup per item | 2 persistent, two workgroups per CU | 3 persistent,
- *                            one workgroup per CU with stream / matrix roles on the matrix cores (order 4; on request only) | 4 the
- *                            PATTERN-COMPILED fused kernel, any Pade order: source generated from the sparsity pattern of the
- *                            generators and compiled on first use, one wave per chain of the recursion, no workgroup barrier
- *                            (auto at every order: full values, compact values and the payload-fused call; needs sparse exact-iso generators of a
- *                            unitary problem, 9 <= d <= 32, 1..6 drives, jit = 1: PCL_ESHAPE when forced elsewhere) | 5 the
- *                            small-system kernel: one wave per interval, any order, n <= 16 rows, at most 8 state columns and 8 drives (auto for n <= 8
- *                            rows, and for the residual alone up to 16 rows)
- *       "contiguous"         kernels 3 / 4: -1 auto by launch size | 0 round-robin column slices | 1 equal contiguous column ranges
- *       "stream_workgroups"  kernel 3, contiguous: -1 auto (half) | 0 both roles in every workgroup | n stream-role workgroups
- *       "cols_per_slice"     state columns per work item (0 = heuristic; forces the round-robin split in kernels 3 / 4)
- *       "v4_power_tiles"     kernel 4: LDS tiles the powers of G rotate through (0 auto: q - 1 for launches of several items per
- *                            workgroup, all q for one-item launches)
- *       "v4_tail_mode"       kernel 4, who stores delta and the d/du, d/dh block of an item: 3 the store-stream waves behind the
- *                            item's blocks (default) | 0 a writer wave, plain stores | 1 nontemporal | 2 write-through
- *       "v4_flags"           kernel 4 A/B switches (same values): 1 no raised priority for the powers' wave | 2 tails only behind the
- *                            item's last block | 4 no cooperative first item | 8 every LDS tile NaN at kernel start (tests: nothing
- *                            reads what its item has not written) | 16 the first item's chains do not wait for the cooperative products | 32 two slices of an
- *                            odd number of columns keep 14 + 13 whole columns instead of sharing the middle column's two blocks
- *       "hess_kernel"        0 auto | 1 one workgroup per interval | 2 persistent, column chunks (fallback) | 3 one workgroup per
- *                            interval, jobs split by drive (matrix cores; default for d >= 12 where the pattern-compiled kernels do
- *                            not apply) | 4 the pattern-compiled order-4 kernel (default for sparse exact-iso generators, odd
- *                            9 <= d <= 32, m <= 6; PCL_ESHAPE when forced elsewhere) | 7 the pattern-compiled kernel for ANY order
- *                            (auto at orders 2, 6, 8, 10; same applicability as kernel_version 4); what neither takes runs the
- *                            general-order Hessian kernel
- *       "hess_split"         hess_kernel 7: two workgroups per interval, half of the drive chains each, the scalar entries assembled by the
- *                            one that arrives last (-1 auto: launches of at most n_cu / 2 intervals, and where it avoids column
- *                            slices | 0 | 1); the same values
- *       "eval_kernel"        residual only: 0 auto | 1 the matrix-core residual kernel (order 4) | 2 the round-2 pattern-compiled kernel
- *                            (order 4, per-interval value tables) | 3 the pattern-compiled kernel for any order, resident
- *                            coefficients, one wave per interval (auto wherever kernel_version 4 applies)
- *       "eval_coop"          eval_kernel 3: four waves per interval, the products in four row ranges (-1 auto: launches of at most two
- *                            intervals per CU | 0 | 1); the same values
- *       "general_pade_kernel" 1: run the general-order kernels for pade_order 4 too (cross-check)
- *       "general_kernel_version" residual+Jacobian at pade_order != 4 where kernel 4 does not apply: 0 auto (the lock-step kernel where
- *                             the shape fits: even n <= 64 and LDS), 1 the reference formulation, 2 the lock-step kernel or PCL_ESHAPE
- *                             (a non-zero value also keeps auto away from kernel 4)
- *       "general_slices"      lock-step kernel: slices of state columns per interval (0 auto)
- *       "general_threads" (256 / 512)   reference formulation
- *       "jit"                1 (default): kernels generated or specialised per context are compiled on first use with hiprtc (the
- *                            pattern-compiled kernels; Hessian kernel 2 for d >= 12; fused kernel 3 when kernel_version = 3);
- *                            0: built-in instances only
- *       "use_mfma" (1/0: plain-VALU products in kernel 1), "nt_stores" (streaming stores of the Jacobian blocks: -1 auto by launch size and order | 0 plain | 1 nontemporal | 2 write-through | 3 kernel 4: write-through on every other XCD's workgroups, plain on the others), "specialize" (1/0: shape-specialised
- *       instances), "grid" (workgroups, 0 = one per CU), "host_threads" (host-pointer entry points: threads that expand the
- *       compact values into the caller's array, 0 = auto), "host_path" (0 auto | 1 full values over PCIe | 2 compact + host expansion),
- *       "debug_timing", "profile_flags", "v4_variant" (PCL_ENOTIMPL / unknown unless the library was built with -DPCL_PROFILE)
- * get:  the above, and "effective_cols_per_slice", "last_kernel" (10*version + specialised for kernels 1-3; 40 + q kernel 4 at order
- *       2q; 50 + q the small-system kernel; 60 / 61 matrix-core residual kernel, 70 round-2 pattern-compiled residual kernel, 80 + q pattern-compiled residual kernel
- *       at order 2q; 90 + q general-order kernel in the reference formulation, 190 + q lock-step general-order kernel),
- *       "last_stream_workgroups", "last_merit_fused", "last_step_launches" (pcl_eval_jac_merit_objective_dev: 2 | 4), "last_objective_launches" (pcl_objective_dev: 1 | 2), "objective_launches" (set: 0 auto | 2 always two launches), "last_eval_coop", "last_hess_split", "last_hess_kernel" (1, 2 | 3: kernel 2 compiled on first use | 4, 5: kernel 3
- *       static / compiled | 6: pattern-compiled order 4 | 70 + q: pattern-compiled, order 2q | 90 + q: general-order), "jit_compiles",
- *       "n_cu", "iso_structured", "drives_antisymmetric",
- *       "ell_width", "ell_width_t", "union_width", "occupancy_v2".  Unknown keys return PCL_EINVAL. */
+/* options --------------------------------------------------------------------
+ * A DEPLOYMENT sets none, or only these (everything else is a measurement / test switch, listed with its meaning in OPTIONS.md; every
+ * setting gives the same results up to the order of additions inside a kernel family, and inside a family every work split is bitwise
+ * equal -- which is what the parity tests use the switches for):
+ *   "jit"           1 (default): the pattern-compiled kernels are taken from csrc/prebuilt, from the on-disk cache, or compiled with hiprtc on
+ *                   first use; 0: built-in kernel families only
+ *   "require_jit"   1: a pattern-compiled kernel that is wanted and cannot be had is PCL_EHIP instead of a (noted, counted) fallback
+ *   "host_threads"  threads that expand the compact values into the caller's array in the host-pointer entry points (0 = auto: a sweep over
+ *                   the context's first twelve calls), "host_path" (0 auto | 1 full values over PCIe | 2 compact + host expansion)
+ *   "v4_ticket"     launches of several trajectories: -1 auto | 0 static split | 1 groups of workgroups + slice tickets
+ * and reads: "pade_order" (the order in use), "last_kernel" / "last_hess_kernel" (which kernel family ran), "jit_compiles", "jit_cache_hits",
+ * "jit_fallbacks", "n_cu".  Unknown keys return PCL_EINVAL.  Environment: PCL_JIT_CACHE=0, PCL_JIT_CACHE_DIR, PCL_HOST_PATH, PCL_V4_TICKET,
+ * PCL_VERBOSE (see OPTIONS.md). */
 int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t value);
 int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *value);
 /* Profiling aid (libraries built with -DPCL_PROFILE only): after pcl_set_option(ctx, "debug_timing", 1), up to 64

@@ -1,9 +1,9 @@
 #!/bin/bash
-# kernel trace of the pattern-compiled column kernel + stream-only kernel 3 (scripts/probes/col_sparse_probe.py)
+# kernel trace of the pattern-compiled column kernel + stream-only kernel 3 (lab/probes/col_sparse_probe.py)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/col_trace; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/t -o t -- python $R/scripts/probes/col_sparse_probe.py ${1:-8} > $O/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/t -o t -- python $R/lab/probes/col_sparse_probe.py ${1:-8} > $O/log.txt 2>&1
 f=$(find $O/t -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'P'
 import csv, sys

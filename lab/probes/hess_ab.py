@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of versions of the pattern-compiled Hessian kernel header (put them under scripts/probes/ab/<name>.hpp) on one box: each version runs in its
+"""A/B of versions of the pattern-compiled Hessian kernel header (put them under lab/probes/ab/<name>.hpp) on one box: each version runs in its
 own process (the generated module is cached per process), alternating, 8 and 16 trajectories per launch."""
 import os, subprocess, sys, shutil
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

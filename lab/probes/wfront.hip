@@ -8,7 +8,7 @@
 //   mode 4  as mode 1, the workgroup index permuted so that the workgroups of one XCD (bx mod 8) take neighbouring items
 // and against waves per workgroup (4 ... 16: one column per group of four waves at a time) and the store flavour (plain / nt / sc0 sc1).
 // Bare fills (hipMemsetAsync, one 16 KB tile per workgroup) on the same buffers beside them.
-//   hipcc --offload-arch=gfx950 -O3 -o scripts/probes/wfront scripts/probes/wfront.hip ;  wfront [buffers] [trajectories]
+//   hipcc --offload-arch=gfx950 -O3 -o lab/probes/wfront lab/probes/wfront.hip ;  wfront [buffers] [trajectories]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>

@@ -1,6 +1,6 @@
 // Bare store patterns against the placement of the buffer: (a) grid-stride fill, (b) one contiguous range per workgroup, (c) two streams per
 // workgroup 630 KB apart inside 1.34 MB records (the fused kernel's), (d) block-cyclic chunks of C bytes per workgroup.
-// hipcc --offload-arch=gfx950 -O3 -o scripts/probes/wpattern scripts/probes/wpattern.hip
+// hipcc --offload-arch=gfx950 -O3 -o lab/probes/wpattern lab/probes/wpattern.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

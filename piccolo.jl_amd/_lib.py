@@ -91,7 +91,7 @@ def build_library(force=False, verbose=False, profile=False):
     The library is rebuilt whenever the digest of its sources and flags differs from the one recorded next to the
     shared object (``libpiccolo_hip.so.digest``: source digest + digest of the binary) -- modification times play no part, so a stale binary is never
     reused after an edit, a checkout or a copy to another box.  ``profile=True`` adds ``-DPCL_PROFILE`` (cycle stamps
-    inside the kernels for scripts/probes; never the shipped build)."""
+    inside the kernels for lab/probes; never the shipped build)."""
     src = os.path.join(CSRC, "piccolo_hip.hip")
     deps = [src, os.path.join(INCLUDE, "piccolo_hip.h")] + sorted(
         os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))  # the kernel families are headers of this one TU

@@ -30,7 +30,7 @@
 //   * an interval's chains (delta, d/du_l, d/dh, the reduce payload: loader, W, V, dW_l, writer waves) are a second pipeline with its own
 //     device-wide ticket counter, taken by whichever workgroup's chain waves are free.
 // One more wave, the dispatcher, does everything that waits for memory on behalf of the block pipeline: it takes the slice tickets and keeps
-// a ring of the group's next controls and steps in LDS.  Measured with the bare store pattern (scripts/probes/wfront.hip, 8 trajectories, 8
+// a ring of the group's next controls and steps in LDS.  Measured with the bare store pattern (lab/probes/wfront.hip, 8 trajectories, 8
 // separately allocated buffers, one box): equal contiguous ranges 196.6 us median (163.7 ... 209.3 by where the buffer's pages live), static
 // round-robin items 199-229, items of 3 columns by ONE device-wide ticket 176, this scheme 177-182, on every buffer.  (The first version of
 // this round took device-wide block tickets in the P wave: parity-exact but 247 us -- every ticket's controls are a cold load behind the CU's

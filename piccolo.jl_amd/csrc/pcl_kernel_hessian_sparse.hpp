@@ -105,7 +105,7 @@ extern "C" __global__ __launch_bounds__(64 * (SPM + 2)) void pcl_hess_sparse_ker
 #endif
     // tile -> global: lane = row, one column (SPN consecutive doubles) per store instruction; every address is a per-lane base plus an
     // immediate (index arithmetic on `lane + 64 i` gets hoisted out of the interval loop: 23 registers per tile, spilled).  Row pairs
-    // with 16-byte stores measured 5 % slower (A/B on one box, scripts/probes/hess_ab.py).
+    // with 16-byte stores measured 5 % slower (A/B on one box, lab/probes/hess_ab.py).
     auto flush = [&](const double *T, double *out) {
         wave_lds_sync();
         if (lane < SPN) {

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 cd /tmp
 for W in hess:4 hess:3 eval:2 eval:1; do
   what=${W%%:*}; kern=${W##*:}
-  script=$ROOT/scripts/probes/${what}_sparse_run.py
+  script=$ROOT/lab/probes/${what}_sparse_run.py
   name=${what}_k${kern}
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${name}_trace -o $name -- python $script 8 $kern > /dev/null 2>&1
   i=0

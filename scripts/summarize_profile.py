@@ -29,7 +29,7 @@ for f in find("trace", "*kernel_trace.csv"):
         meta[key] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size_X", "Grid_Size_X")}
     summary["kernel_trace"] = {k: dict(calls=len(v), avg_us=sum(v) / len(v) / 1e3, min_us=min(v) / 1e3, max_us=max(v) / 1e3, **meta[k])
                                for k, v in dur.items() if "pcl_" in k}
-for wl in ("single", "multistart", "multistart_static", "single_order8"):  # the headline launches alone (the full trace mixes them with compact launches of the same grid)
+for wl in ("single", "multistart", "multistart_static", "single_order8", "single_k3"):  # the headline launches alone (the full trace mixes them with compact launches of the same grid)
     for f in find("trace_" + wl, "*kernel_trace.csv"):
         dur = defaultdict(list)
         for r in csv.DictReader(open(f)):
@@ -65,6 +65,21 @@ for wl, units in (("single", 1), ("multistart", 8)):
         traffic[wl] = dict(workload=wl, batch=units, knots=100, kernel=kw[0], write_bytes=wr, fetch_bytes_raw=rd, fetch_bytes_corrected=2.0 * rd,
                            hbm_bytes_per_launch=wr + 2.0 * rd, source="rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes), " + tag)
 summary["hbm_traffic"] = traffic
+# MFMA A/B: the benchmarked kernel against the matrix-core kernel (kernel_version 3), per dispatch.  Utilisation = MFMA busy cycles / (SIMDs x
+# kernel time x clock): SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs; 256 CUs x 4 SIMDs at 2.4 GHz.
+ab = {}
+for tagk, run, tr in (("benchmarked_kernel", "single_mfma", "kernel_trace_single"), ("kernel3_matrix_cores", "single_k3_mfma", "kernel_trace_single_k3")):
+    for kname, cs in pmc.get(run, {}).items():
+        if "pcl_fused" not in kname:
+            continue
+        t_us = next((v["avg_us"] for k, v in summary.get(tr, {}).items() if k == kname), None)
+        busy = cs.get("SQ_VALU_MFMA_BUSY_CYCLES", {}).get("avg", 0.0)
+        ab[tagk] = dict(kernel=kname, us_per_launch=t_us, mfma_mops_f64=cs.get("SQ_INSTS_VALU_MFMA_MOPS_F64", {}).get("avg"), mfma_busy_cycles=busy,
+                        valu_insts=cs.get("SQ_INSTS_VALU", {}).get("avg"),
+                        mfma_util=(busy / (256 * 4 * t_us * 1e-6 * 2.4e9)) if t_us else None, source="rocprofv3 --pmc (own pass), " + tag)
+if ab:
+    json.dump(ab, open(os.path.join(dst, "mfma_ab.json"), "w"), indent=1)
+    summary["mfma_ab"] = ab
 if traffic:
     json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 for f in glob.glob(os.path.join(src, "trace.log")):
