@@ -460,10 +460,10 @@ def main():
         hvals = np.empty(it.ctx.jac_nnz)
         hres = {}
         for label, path, threads in (("full_over_pcie", 1, 0), ("compact_plus_host_expansion", 2, 0), ("compact_16_threads", 2, 16),
-                                     ("compact_32_threads", 2, 32), ("compact_64_threads", 2, 64)):
+                                     ("compact_32_threads", 2, 32), ("compact_64_threads", 2, 64), ("compact_swept_threads", 2, -1)):
             it.ctx.set_option("host_path", path)
             it.ctx.set_option("host_threads", threads)
-            for _ in range(14 if (path == 2 and threads == 0) else 3):  # (auto: the context samples six thread counts over its first twelve calls)
+            for _ in range(14 if threads < 0 else 3):  # (-1: the context samples six thread counts over its first twelve calls)
                 it.ctx.eval_jac(t0.datavec, hd, hvals)
             th = time.perf_counter()
             for _ in range(8):
@@ -472,16 +472,13 @@ def main():
             hres[label] = {"evals_per_s": 1.0 / th, "ms_per_eval": th * 1e3, "delivered_GBps": hvals.nbytes / th / 1e9,
                            "threads": it.ctx.get_option("host_threads") if path == 2 else 0}
         best = max(hres, key=lambda k: hres[k]["evals_per_s"])
-        it.ctx.set_option("host_threads", 0)
-        it.ctx.set_option("host_path", 2)
         # the host's own write bandwidth beside it: the same bytes written by numpy into the same array (one thread; STREAM-style fill)
         tf = time.perf_counter()
         for _ in range(4):
             hvals.fill(1.0)
         fill_GBps = 4 * hvals.nbytes / (time.perf_counter() - tf) / 1e9
-        ex["host_delivered"] = dict(hres["compact_plus_host_expansion"], note="default path (pcl_eval_jac on pageable numpy arrays); threads chosen by a sweep over the context's first twelve calls",
-                                    paths=hres, best=best, tuned_threads=it.ctx.get_option("host_threads"), tuned_call_GBps=it.ctx.get_option("host_expand_MBps") / 1e3,
-                                    host_fill_GBps_one_thread=fill_GBps)
+        ex["host_delivered"] = dict(hres["compact_plus_host_expansion"], note="default path (pcl_eval_jac on pageable numpy arrays; min(cores / 2, 32) threads expand the compact values)",
+                                    paths=hres, best=best, swept_threads=it.ctx.get_option("host_threads"), host_fill_GBps_one_thread=fill_GBps)
         it.close()
         # BASELINE config 2 (CNOT, d=4, N=100): launch-bound, report us/eval
         s2 = synthetic.config_system(2)
@@ -517,22 +514,24 @@ def main():
             for nt in sorted({1, 8, 16, 32, 64, min(avail, lay.K)}):
                 if nt > avail:
                     continue
-                t1 = time.perf_counter()
-                for _ in range(2):
+                for _ in range(4):  # the fastest of four calls per count: one slow call (a neighbour on the host) must not pick the count
+                    t1 = time.perf_counter()
                     ref_lib.eval_jac(Z, lay, G0o, Gjo, nthreads=nt, out=outbuf)
-                t1 = (time.perf_counter() - t1) / 2
-                if t1 < best_t:
-                    best_t, cores = t1, nt
+                    t1 = time.perf_counter() - t1
+                    if t1 < best_t:
+                        best_t, cores = t1, nt
             n, tc = 0, time.perf_counter()
             while time.perf_counter() - tc < args.cpu_seconds:
                 ref_lib.eval_jac(Z, lay, G0o, Gjo, nthreads=cores, out=outbuf)
                 n += 1
             el = time.perf_counter() - tc
+            cpu_rate = max(n / el, 1.0 / best_t)  # the better of the sustained rate and the fastest single call: the ratio below is never flattered by a noisy host
             # (vs_baseline stays null: BASELINE.md holds no published number for this metric; the ratio to the CPU port of this run is its own key)
-            out["vs_cpu_baseline"] = out["value"] / (n / el)
+            out["vs_cpu_baseline"] = out["value"] / cpu_rate
             out["vs_cpu_baseline_note"] = "value / cpu_baseline.value of this run (north-star target: >= 50x the single-socket CPU path; the port is far faster than the reference's ForwardDiff-through-expv path, which cannot run here)"
             out["cpu_baseline"] = {
-                "value": n / el,
+                "value": cpu_rate,
+                "sustained": n / el,
                 "unit": "evals/s",
                 "cores": cores,
                 "kind": "port",

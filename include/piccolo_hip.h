@@ -285,8 +285,8 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  *   "jit"           1 (default): the pattern-compiled kernels are taken from csrc/prebuilt, from the on-disk cache, or compiled with hiprtc on
  *                   first use; 0: built-in kernel families only
  *   "require_jit"   1: a pattern-compiled kernel that is wanted and cannot be had is PCL_EHIP instead of a (noted, counted) fallback
- *   "host_threads"  threads that expand the compact values into the caller's array in the host-pointer entry points (0 = auto: a sweep over
- *                   the context's first twelve calls), "host_path" (0 auto | 1 full values over PCIe | 2 compact + host expansion)
+ *   "host_threads"  threads that expand the compact values into the caller's array in the host-pointer entry points (0 = min(cores / 2, 32);
+ *                   -1 = a sweep over the context's first twelve calls), "host_path" (0 auto | 1 full values over PCIe | 2 compact + host expansion)
  *   "v4_ticket"     launches of several trajectories: -1 auto | 0 static split | 1 groups of workgroups + slice tickets
  * and reads: "pade_order" (the order in use), "last_kernel" / "last_hess_kernel" (which kernel family ran), "jit_compiles", "jit_cache_hits",
  * "jit_fallbacks", "n_cu".  Unknown keys return PCL_EINVAL.  Environment: PCL_JIT_CACHE=0, PCL_JIT_CACHE_DIR, PCL_HOST_PATH, PCL_V4_TICKET,

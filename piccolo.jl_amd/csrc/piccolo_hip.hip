@@ -2231,18 +2231,19 @@ static int ensure_pinned(pcl_ctx *ctx, double **buf, long long count) {
     if (e != hipSuccess) return fail(ctx, PCL_ENOMEM, "hipHostMalloc(%lld doubles): %s", count, hipGetErrorString(e));
     return PCL_OK;
 }
-// Auto thread count of the host expansion: the first 2 x 6 host-delivered calls of a context (launches worth it) are each run at one of six
-// candidate counts -- real calls, real results -- and the count whose fastest call was shortest serves the context from then on.  The
-// right fraction of the cores differs by host and cannot be read off the expansion alone (it overlaps the chunked copy over PCIe:
-// expansion-only sweeps picked 24 threads where the whole call is fastest at 32; 64 beat a fixed 48 by 18 % on another box of the pool).
+// Thread count of the host expansion.  Default (0): min(cores / 2, 32) -- the path is bound by the host's memory writes into the caller's
+// pageable array, 16 ... 64 threads deliver 1.0-1.3 k evaluations per second on the boxes of the pool, which count is best changes from box to
+// box and from run to run (page placement of the caller's array, neighbours).  host_threads = -1 asks for a sweep: the context's first 2 x 6
+// host-delivered calls are each run at one of six candidate counts -- real calls, real results -- and the count whose fastest call was
+// shortest serves the context from then on (measured: 1.6 k on one box, no better than the default on two others; hence opt-in).
 static const int kHostTuneCand[] = {16, 24, 32, 48, 64, 96};
 static const int kHostTuneN = 6;
 static int host_threads(const pcl_ctx *ctx) {
     if (ctx->opt_host_threads > 0) return (int)std::min<int64_t>(ctx->opt_host_threads, 256);
     if (ctx->host_threads_tuned > 0) return ctx->host_threads_tuned;
     const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-    if (ctx->host_tune_calls < 2 * kHostTuneN) return (int)std::min<unsigned>((unsigned)kHostTuneCand[ctx->host_tune_calls % kHostTuneN], hw);
-    return (int)std::max(1u, std::min(hw / 2, 48u));
+    if (ctx->opt_host_threads < 0 && ctx->host_tune_calls < 2 * kHostTuneN) return (int)std::min<unsigned>((unsigned)kHostTuneCand[ctx->host_tune_calls % kHostTuneN], hw);
+    return (int)std::max(1u, std::min(hw / 2, 32u));
 }
 
 // Host-pointer evaluation.  Two ways to deliver the Jacobian values into the caller's (pageable) array:
@@ -2287,8 +2288,7 @@ static int host_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *v
         HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[c], ctx->stream));
     }
     if (delta) HIP_TRY(ctx, hipMemcpyAsync(ctx->hdelta, ctx->ddelta, n_rows(ctx) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    const bool tuning = ctx->opt_host_threads <= 0 && ctx->host_threads_tuned == 0 && ctx->host_tune_calls < 2 * kHostTuneN && nv * 8 >= (32LL << 20);
-    if (!tuning && ctx->opt_host_threads <= 0 && ctx->host_threads_tuned == 0) ctx->host_tune_calls = 2 * kHostTuneN;  // (small launches: the default count)
+    const bool tuning = ctx->opt_host_threads < 0 && ctx->host_threads_tuned == 0 && ctx->host_tune_calls < 2 * kHostTuneN && nv * 8 >= (32LL << 20);
     const int want_threads = host_threads(ctx);
     if (!ctx->pool || ctx->pool->size() != want_threads - 1) {
         delete ctx->pool;
@@ -3086,7 +3086,12 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
     }
 #endif
     else if (!strcmp(key, "host_threads"))  // host-pointer entry points: threads expanding the compact values (0 = auto)
-        ctx->opt_host_threads = v < 0 ? 0 : v;
+    {
+        ctx->opt_host_threads = v < 0 ? -1 : v;  // (0 default count | n | -1 sweep over the context's first twelve calls)
+        ctx->host_threads_tuned = 0;
+        ctx->host_tune_calls = 0;
+        for (double &t : ctx->host_tune_t) t = 1e300;
+    }
     else if (!strcmp(key, "host_path"))  // 0 auto | 1 full values over PCIe | 2 compact values + host expansion
         ctx->opt_host_path = v < 0 || v > 2 ? 0 : v;
     else if (!strcmp(key, "host_chunks"))  // interval chunks of the compact D2H copy that overlap with the expansion (1..8)
