@@ -137,6 +137,7 @@ __global__ __launch_bounds__(64 * NW) void emu(const Prm p) {
                     __syncthreads();
                     if (s_ >= (unsigned)ipi) break;
                     run(bk * ipi + s_);
+                    for (int g_ = 0; g_ < p.gap; g_ += 16) __builtin_amdgcn_s_sleep(16);
                 }
             }
         } else if (p.mode >= 10) {  // tickets taken (mode - 10) items before they are stored (the fused kernel's P wave holds a few)
@@ -213,6 +214,8 @@ int main(int argc, char **argv) {
         int mode, cpi, grid, nw, nt, tails;
     };
     std::vector<V> vs = {
+        {"tick3-gap6k", 2, 3, 256, 4, 0, 1 + 2 * 6}, {"tick3-gap8k", 2, 3, 256, 4, 0, 1 + 2 * 8}, {"tick3-gap12k", 2, 3, 256, 4, 0, 1 + 2 * 12},
+        {"grp8-3-gap4k", 7, 3, 256, 4, 108, 1 + 2 * 4}, {"grp8-3-gap8k", 7, 3, 256, 4, 108, 1 + 2 * 8}, {"grp8-3-gap12k", 7, 3, 256, 4, 108, 1 + 2 * 12},
         {"grp8-3", 7, 3, 256, 4, 108, 1}, {"grp8-2", 7, 2, 256, 4, 108, 1}, {"grp8-5", 7, 5, 256, 4, 108, 1}, {"grp4-3", 7, 3, 256, 4, 104, 1}, {"grp16-3", 7, 3, 256, 4, 116, 1}, {"grp32-3", 7, 3, 256, 4, 132, 1},
         {"grp8-3w", 8, 3, 256, 5, 108, 1}, {"grp16-3w", 8, 3, 256, 5, 116, 1}, {"grp8-1w", 8, 1, 256, 5, 108, 1}, {"grp8-1", 7, 1, 256, 4, 108, 1},
         {"tick6-gap1k", 2, 6, 256, 4, 0, 1 + 2 * 1}, {"tick6-gap2k", 2, 6, 256, 4, 0, 1 + 2 * 2}, {"tick6-gap4k", 2, 6, 256, 4, 0, 1 + 2 * 4}, {"tick6-gap8k", 2, 6, 256, 4, 0, 1 + 2 * 8},
