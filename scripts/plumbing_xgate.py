@@ -17,7 +17,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import piccolo_jl_amd as pa
 
 
-def solve(N=50, T=10.0, Q=100.0, R=1e-2, seed=0, max_iter=300, verbose=0):
+def solve(N=50, T=10.0, Q=100.0, R=1e-2, seed=0, max_iter=300, verbose=0, exact_hessian=False, callbacks_only=False):
+    """exact_hessian: the objective's Hessian from the device too (pcl_objective_hess) -- with the constraints' term (pcl_hess) the solver
+    then works on the exact Hessian of the Lagrangian, the reference's `eval_hessian = true` [REF spline_pulse_problem.jl:96]; otherwise a
+    BFGS model of the objective.  (scipy's trust-constr has no inertia correction: on the exact, indefinite Hessian of Q |1 - F| it stops
+    at an infeasible stationary point of this problem -- fidelity 1, violation 0.8 -- where Ipopt would regularise; the BFGS model is what
+    the plumbing test solves with.  callbacks_only: return the callbacks instead of solving: tests/test_plumbing_gpu.py checks that the
+    device's Hessian of the Lagrangian is the derivative of the device's gradient of the Lagrangian.)"""
     system = pa.QuantumSystem(0.5 * pa.PAULIS["Z"], [pa.PAULIS["X"], pa.PAULIS["Y"]], [1.0, 1.0])  # first_gate.jl:42-48
     U_goal = pa.GATES["X"]
     rng = np.random.default_rng(seed)
@@ -74,6 +80,14 @@ def solve(N=50, T=10.0, Q=100.0, R=1e-2, seed=0, max_iter=300, verbose=0):
     def obj(z):
         return J.value_and_gradient(z)
 
+    hr, hc = J.hessian_structure()
+
+    def obj_hess(z):  # sigma grad^2 f, lower triangle from the device -> symmetric sparse matrix
+        L = sp.csr_matrix((J.hessian(z, 1.0), (hr, hc)), shape=(nv, nv))
+        return L + sp.tril(L, -1).T
+
+    if callbacks_only:
+        return dict(z0=traj.datavec.copy(), obj=obj, obj_hess=obj_hess, cons=cons, cons_jac=cons_jac, cons_hess=cons_hess, n_rows=int(offs[-1]), close=B.close)
     lb, ub = np.full(nv, -np.inf), np.full(nv, np.inf)
     for k in range(N):
         o = k * traj.dim
@@ -89,7 +103,7 @@ def solve(N=50, T=10.0, Q=100.0, R=1e-2, seed=0, max_iter=300, verbose=0):
         lb[s] = ub[s] = 0.0
     z0 = np.clip(z0, lb, ub)
     nc_rows = int(offs[-1])
-    res = minimize(obj, z0, jac=True, method="trust-constr", hess=BFGS(), bounds=Bounds(lb, ub, keep_feasible=False),
+    res = minimize(obj, z0, jac=True, method="trust-constr", hess=obj_hess if exact_hessian else BFGS(), bounds=Bounds(lb, ub, keep_feasible=False),
                    constraints=[NonlinearConstraint(cons, np.zeros(nc_rows), np.zeros(nc_rows), jac=cons_jac, hess=cons_hess)],
                    options=dict(maxiter=max_iter, gtol=1e-8, xtol=1e-12, verbose=verbose, sparse_jacobian=True))  # fmt: skip
     traj.update(res.x)

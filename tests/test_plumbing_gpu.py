@@ -19,3 +19,26 @@ def test_xgate_plumbing_solve():
     assert r["n_vars"] == 16 * 50 and r["n_rows"] == (8 + 2 + 2 + 1) * 49
     assert r["fidelity"] > 0.9, r
     assert r["max_violation"] < 1e-2, r
+
+
+def test_hessian_of_the_lagrangian_is_complete_on_the_device():
+    """MOI.eval_hessian_lagrangian = sigma grad^2 f + sum_i mu_i grad^2 g_i [REF spline_pulse_problem.jl:96 `eval_hessian = true`]: both
+    terms come from the device (pcl_objective_hess: terminal infidelity block + regulariser entries; pcl_hess + the derivative rows) and
+    their sum is the derivative of the device's own gradient of the Lagrangian, grad f + J' mu, along random directions."""
+    import numpy as np
+
+    import plumbing_xgate
+
+    cb = plumbing_xgate.solve(N=12, callbacks_only=True)
+    rng = np.random.default_rng(3)
+    z = cb["z0"] + 0.05 * rng.standard_normal(cb["z0"].size)
+    mu = rng.standard_normal(cb["n_rows"])
+    gradL = lambda zz: cb["obj"](zz)[1] + cb["cons_jac"](zz).T @ mu
+    H = (cb["obj_hess"](z) + cb["cons_hess"](z, mu)).toarray()
+    assert np.abs(H - H.T).max() < 1e-12 * np.abs(H).max()
+    for _ in range(6):
+        e = rng.standard_normal(z.size)
+        e /= np.linalg.norm(e)
+        fd = (gradL(z + 1e-6 * e) - gradL(z - 1e-6 * e)) / 2e-6
+        assert np.abs(H @ e - fd).max() < 1e-6 * max(1.0, np.abs(fd).max())
+    cb["close"]()
