@@ -160,6 +160,41 @@ __global__ __launch_bounds__(64 * NW) void emu(const Prm p) {
     }
 }
 
+// group mode with TWO-wave workgroups (two per CU: while one is between two slices -- ticket, fold -- the other stores): 128 threads cover
+// 4 columns of a block per step, 14 steps per block
+__global__ __launch_bounds__(128) void emu2(const Prm p) {
+    const int tid = threadIdx.x;
+    const int pi = 2 * (tid % HN), pj0 = tid / HN;
+    const int ipi = (D + p.cpi - 1) / p.cpi;
+    const int n_groups = gridDim.x / p.G, g = blockIdx.x / p.G;
+    __shared__ unsigned sl;
+    for (long long bk = g; bk < p.n_int; bk += n_groups) {
+        for (;;) {
+            if (tid == 0) sl = atomicAdd(p.cnt + bk, 1u);
+            __syncthreads();
+            const unsigned s_ = sl;
+            __syncthreads();
+            if (s_ >= (unsigned)ipi) break;
+            const int c0 = s_ * p.cpi, ncols = std::min(p.cpi, D - c0);
+            double *base = p.jac + bk * JAC_PER;
+            for (int cq = c0; cq < c0 + ncols; ++cq) {
+                double *o = base + (long long)cq * NN;
+                if (pj0 < 4)
+                    for (int r = 0; r < 14; ++r) {
+                        const int j = pj0 + 4 * r;
+                        if (j < N) {
+                            st2<0>(o + N * j + pi, 1.0 + tid, 2.0);
+                            st2<0>(o + BLK + N * j + pi, 3.0, 4.0 + r);
+                        }
+                    }
+            }
+            double *t = base + 2 * BLK + (long long)c0 * (M + 1) * N;
+            for (int e2 = tid; e2 < ncols * (M + 1) * HN; e2 += 128) st2<0>(t + 2 * e2, 1.0, 2.0);
+            for (int g_ = 0; g_ < p.gap; g_ += 16) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+}
+
 template <int U, int NT>
 __global__ __launch_bounds__(NT) void fill_tile(d2 *p, size_t n2) {
     const size_t t0 = (size_t)blockIdx.x * NT * U;
@@ -214,6 +249,9 @@ int main(int argc, char **argv) {
         int mode, cpi, grid, nw, nt, tails;
     };
     std::vector<V> vs = {
+        {"grp8-3-g128", 7, 3, 128, 4, 108, 1}, {"grp8-3-g160", 7, 3, 160, 4, 108, 1}, {"grp8-3-g192", 7, 3, 192, 4, 108, 1}, {"grp8-3-g224", 7, 3, 224, 4, 108, 1},
+        {"grp8-3-g192-gap8k", 7, 3, 192, 4, 108, 1 + 2 * 8}, {"grp8-3-g128-gap8k", 7, 3, 128, 4, 108, 1 + 2 * 8}, {"tick3-g192", 2, 3, 192, 4, 0, 1}, {"tick3-g128", 2, 3, 128, 4, 0, 1},
+        {"half16-3", 9, 3, 512, 2, 116, 1}, {"half16-3-gap8k", 9, 3, 512, 2, 116, 1 + 2 * 8}, {"half16-3-gap12k", 9, 3, 512, 2, 116, 1 + 2 * 12}, {"half16-3-gap16k", 9, 3, 512, 2, 116, 1 + 2 * 16},
         {"tick3-gap6k", 2, 3, 256, 4, 0, 1 + 2 * 6}, {"tick3-gap8k", 2, 3, 256, 4, 0, 1 + 2 * 8}, {"tick3-gap12k", 2, 3, 256, 4, 0, 1 + 2 * 12},
         {"grp8-3-gap4k", 7, 3, 256, 4, 108, 1 + 2 * 4}, {"grp8-3-gap8k", 7, 3, 256, 4, 108, 1 + 2 * 8}, {"grp8-3-gap12k", 7, 3, 256, 4, 108, 1 + 2 * 12},
         {"grp8-3", 7, 3, 256, 4, 108, 1}, {"grp8-2", 7, 2, 256, 4, 108, 1}, {"grp8-5", 7, 5, 256, 4, 108, 1}, {"grp4-3", 7, 3, 256, 4, 104, 1}, {"grp16-3", 7, 3, 256, 4, 116, 1}, {"grp32-3", 7, 3, 256, 4, 132, 1},
@@ -261,12 +299,14 @@ int main(int argc, char **argv) {
     for (const V &v : vs) {
         row(v.name, [&](double *p) {
             Prm prm{p, n_int, v.mode, v.cpi, v.tails & 1, ticket, cnt, v.nt >= 100 ? v.nt - 100 : 8, (v.tails >> 1) * 16};
-            if (v.mode == 7 || v.mode == 8) hipMemsetAsync(cnt, 0, 4 * (size_t)n_int, 0);
+            if (v.mode == 7 || v.mode == 8 || v.mode == 9) hipMemsetAsync(cnt, 0, 4 * (size_t)n_int, 0);
             int grid = v.grid;
             if (v.mode == 3) grid = n_int * ((D + v.cpi - 1) / v.cpi);
             if (v.mode == 2 || v.mode == 5 || v.mode >= 10) hipMemsetAsync(ticket, 0, 4, 0);
 #define L(NT_, NW_) emu<NT_, NW_><<<grid, 64 * NW_>>>(prm)
-            if (v.mode == 8)
+            if (v.mode == 9)
+                emu2<<<grid, 128>>>(prm);
+            else if (v.mode == 8)
                 L(0, 5);
             else if (v.mode == 7)
                 L(0, 4);

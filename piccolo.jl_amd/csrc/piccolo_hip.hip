@@ -114,6 +114,7 @@ struct pcl_ctx {
     int64_t opt_v4_ticket_cols = 0; // ... state columns per slice ticket (0 auto: 3)
     int64_t opt_v4_ticket_ahead = 2; // ... when the next slice is asked for: 0 when the stream waves have issued this one's stores | 1 a slice ahead | 2 at this one's last column (default)
     int64_t opt_v4_group = 0;       // ... workgroups per group (0 auto: 8, one per XCD)
+    bool ticket_launched = false;   // a launch with slice tickets has been enqueued on the current stream (see change_stream)
     int64_t last_v4_ticket = 0;     // state columns per block ticket of the last kernel-4 launch (0: static work split)
     unsigned int *dv4_tick = nullptr;  // ... [block ticket, pipelines gone, chain ticket]: zero between launches (the last pipeline out resets them)
     int *herr = nullptr, *derr = nullptr;  // device error word (host-mapped): a barrier-free kernel whose bounded wait gave up sets bit 0
@@ -1495,6 +1496,7 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_f, (unsigned)g, 1, 1, 64 * (m + 9 + (ticket ? 1 : 0)), 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
     ctx->last_kernel = 40 + p.q;
     ctx->last_n_stream = 0;
+    if (ticket) ctx->ticket_launched = true;
     return PCL_OK;
 }
 
@@ -2131,17 +2133,25 @@ static int resolve_order(pcl_ctx *ctx, const double *Z_host, const char *where) 
 }
 
 // --- device-pointer API -----------------------------------------------------------------------
-extern "C" int pcl_set_stream(pcl_ctx *ctx, void *s) {
-    if (!ctx) return PCL_EINVAL;
-    ctx->stream = (hipStream_t)s;  // NULL is HIP's legacy default stream
+// A launch with slice tickets leaves its counters zero only when it has finished: a launch on ANOTHER stream must not start before that
+// (launches on one stream are ordered anyway).  Switching streams therefore waits for the old one if such a launch may be in flight.
+static int change_stream(pcl_ctx *ctx, hipStream_t s) {
+    if (s != ctx->stream && ctx->ticket_launched) {
+        ON_DEVICE(ctx);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->ticket_launched = false;
+    }
+    ctx->stream = s;
     ctx->tickets_dirty = true;
     return PCL_OK;
 }
+extern "C" int pcl_set_stream(pcl_ctx *ctx, void *s) {
+    if (!ctx) return PCL_EINVAL;
+    return change_stream(ctx, (hipStream_t)s);  // NULL is HIP's legacy default stream
+}
 extern "C" int pcl_reset_stream(pcl_ctx *ctx) {
     if (!ctx) return PCL_EINVAL;
-    ctx->stream = ctx->own_stream;
-    ctx->tickets_dirty = true;
-    return PCL_OK;
+    return change_stream(ctx, ctx->own_stream);
 }
 extern "C" int pcl_sync(pcl_ctx *ctx) {
     if (!ctx) return PCL_EINVAL;

@@ -1013,6 +1013,17 @@ def test_slice_tickets_equal_the_static_split():
             c.jac_dev(Zd, vals)  # eval_jacobian alone
             c.sync()
             assert torch.equal(vals, ref[1])
+            # a switch of streams with a ticket launch in flight waits for it (its counters are zero only once it has finished)
+            s2 = torch.cuda.Stream()
+            out2 = torch.full_like(out, float("nan"))
+            for _ in range(5):
+                c.set_stream(torch.cuda.current_stream().cuda_stream)
+                c.eval_jac_dev(Zd, dd, out)
+                c.set_stream(s2.cuda_stream)
+                c.eval_jac_dev(Zd, dd, out2)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref[1]) and torch.equal(out2, ref[1])
+            c.set_stream(torch.cuda.current_stream().cuda_stream)
         c.close()
     # fewer intervals than groups (2 trajectories of 5 knots: 8 intervals, 32 groups), tickets forced
     Zs = [po.synthetic_trajectory(so, 5, seed=950 + s)[0] for s in range(2)]
