@@ -210,7 +210,7 @@ def prebuild_kernels(G_drifts, G_drives, orders=(4,), hessian=True, out_dir=None
     L.pcl_jit_prebuild.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
     count = 0
     for order in orders:
-        whats = [0] + (([3] if order == 4 else []) + [1, 2] if hessian else [])
+        whats = [0] + ([4] if order <= 4 else []) + (([3] if order == 4 else []) + [1, 2] if hessian else [])  # (4: the fused module with the slice-ticket roles)
         for what in whats:
             rc = L.pcl_jit_prebuild(d, m, G0.ctypes.data, G0.shape[0], Gj.ctypes.data if m else None, order // 2, what, od)
             if rc != 0:

@@ -37,6 +37,9 @@
 // own stores, 3-8 us, and tickets taken early to hide it cost 5-10 us each: the write front is only as tight as the tickets are late.)
 #pragma once
 
+#ifndef SP4_TICKETS
+#define SP4_TICKETS 1             // 0: the module of the static work splits (no dispatcher, no ticket branches: 10 KB less code for the launches whose start-up counts)
+#endif
 #define SP4CS (SPN + 1)           // odd column stride: the lanes of a half wave, one column each, hit distinct banks
 #define SP4TILE (SP4CS * SPD)
 #define SP4_WLOAD (SPM + 3)
@@ -169,7 +172,7 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
     };
     // ---- slice tickets (see the head of the file): rings in LDS behind the counters -- the slice in flight (bdesc: 32 visit + slice), the visit
     //      each of the P wave's last four builds holds (pvis), the chain items (cdesc: the interval), the controls and step of SP4_UHR visits (uhr)
-    const bool tick = p.tick != nullptr;
+    const bool tick = SP4_TICKETS && p.tick != nullptr;
     int *bdesc = sync + 32, *cdesc = sync + 36, *pvis = sync + 40;
     double *uhr = (double *)(sync + SP4_SYNC_WORDS);
     const int t_ipi = tick ? (d + p.tick_cpi - 1) / p.tick_cpi : 1;
@@ -650,7 +653,7 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
             sp4_post(sync + SP4_F_OC, it + 1, lane);  // the chains may rewrite their tiles
             SP4_STAMP();
         }
-    } else if (wave == SP4_WDISP) {
+    } else if (SP4_TICKETS && wave == SP4_WDISP) {
         // ================================== dispatcher (launches with slice tickets only) ======================================
         // Everything of the block pipeline that waits for memory: the slice tickets, each taken when every stream wave has issued the
         // previous slice's stores (taken earlier, a ticket is an address range reserved for later: 5-10 us per ticket held in the bare

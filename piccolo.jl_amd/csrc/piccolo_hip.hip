@@ -97,6 +97,7 @@ struct pcl_ctx {
     // pattern-compiled FUSED residual + Jacobian kernel (pcl_codegen_v4.hpp, any Pade order): plan, drift tables, magnitudes
     pcl_codegen::V4Plan *v4_plan = nullptr;
     double *dv4_tab = nullptr, *dv4_tab_t = nullptr, *dv4_mags = nullptr, *dv4_dcf = nullptr;
+    hipFunction_t v4_ft = nullptr;  // the fused kernel of the module WITH the slice-ticket roles (launches of several trajectories)
     hipFunction_t v4_f = nullptr, v4_feval = nullptr, v4_fevalc = nullptr /* cooperative residual kernel (optional) */, v4_fhess = nullptr, v4_fhess2 = nullptr /* two workgroups per interval */;
     double *dh4x = nullptr;        // general-order Hessian, two workgroups per interval: their rows of reduced sums ...
     unsigned int *dh4c = nullptr;  // ... and the arrival counters (self-resetting)
@@ -981,8 +982,8 @@ std::string sparse_source(const pcl_codegen::SpPlan &plan) {
 }
 // Source of the pattern-compiled fused residual + Jacobian kernel of one system at Pade order 2q (pcl_codegen_v4.hpp)
 // (np: tiles of the powers of G -- v4_power_tiles)
-std::string v4_source(const pcl_codegen::V4Plan &plan, int q, int np, int variant = 0) {
-    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q, np, variant) + "#include \"pcl_kernel_fused_sparse.hpp\"\n";
+std::string v4_source(const pcl_codegen::V4Plan &plan, int q, int np, int variant = 0, int tickets = 0) {
+    return std::string("#include \"pcl_device_common.hpp\"\n#define SP4_TICKETS ") + (tickets ? "1\n" : "0\n") + pcl_codegen::v4_functions(plan, q, np, variant) + "#include \"pcl_kernel_fused_sparse.hpp\"\n";
 }
 
 // ... and of the Hessian-of-the-Lagrangian kernel of the same family (pcl_kernel_hess_sparse4.hpp; any order)
@@ -1039,7 +1040,7 @@ static int prebuild_source(const std::string &source, const char *name_expr, con
 //   what 0  fused residual + Jacobian + residual-only kernels at order 2q | 1  general-order Hessian, one workgroup per interval |
 //        2  ... two workgroups per interval | 3  the order-4 Hessian / value-table module (q ignored)
 extern "C" int pcl_jit_prebuild(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what, const char *out_dir) {
-    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || what < 0 || what > 3 || !G0 || (m > 0 && !Gj)) return fail(nullptr, PCL_EINVAL, "pcl_jit_prebuild: bad argument");
+    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || what < 0 || what > 4 || !G0 || (m > 0 && !Gj)) return fail(nullptr, PCL_EINVAL, "pcl_jit_prebuild: bad argument");
     std::string src, err;
     const char *kernel = "pcl_fused_sparse_kernel";
     if (what == 3) {
@@ -1050,8 +1051,8 @@ extern "C" int pcl_jit_prebuild(int d, int m, const double *G0, int n_g0, const 
         if (!plan.ok) return fail(nullptr, PCL_ESHAPE, "pcl_jit_prebuild: the pattern-compiled kernels do not take this system");
         const int np = v4_power_tiles(d, m, q, 160 * 1024);
         if (!np) return fail(nullptr, PCL_ESHAPE, "pcl_jit_prebuild: tiles exceed LDS");
-        src = what == 0 ? v4_source(plan, q, np) : v4_hess_source(plan, q, 0, what);
-        if (what) kernel = "pcl_hess_sparse4_kernel";
+        src = what == 0 ? v4_source(plan, q, np) : what == 4 ? v4_source(plan, q, np, 0, 1) : v4_hess_source(plan, q, 0, what);
+        if (what && what != 4) kernel = "pcl_hess_sparse4_kernel";
     }
     const int rc = prebuild_source(src, kernel, out_dir, err);
     return rc == PCL_OK ? rc : fail(nullptr, rc, "pcl_jit_prebuild: %s", err.c_str());
@@ -1493,7 +1494,17 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     const double *tab = ctx->dv4_tab + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_drift_pad : 0);
     const double *dcf = ctx->dv4_dcf + (ctx->desc.per_member_G0 ? (long long)ctx->win_first * v4.n_dcf_pad : 0);
     void *args[] = {(void *)&p, (void *)&tab, (void *)&ctx->dv4_mags, (void *)&dcf};
-    HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_f, (unsigned)g, 1, 1, 64 * (m + 9 + (ticket ? 1 : 0)), 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
+    hipFunction_t fk = ctx->v4_f;
+    if (ticket) {  // (a module of its own: the static launches -- one trajectory: the start-up counts -- run without the ticket roles' code)
+        if (!ctx->v4_ft) {
+            const std::string src = v4_source(*ctx->v4_plan, p.q, np, (int)ctx->opt_v4_variant, 1);
+            const std::string key = "fused-sparse-tickets:" + std::to_string(p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
+            ctx->v4_ft = jit_compile(ctx->device, key, src, "pcl_fused_sparse_kernel", true);
+            if (!ctx->v4_ft) return jit_fell_back(ctx, "residual + Jacobian (slice tickets)") == PCL_EHIP ? PCL_EHIP : fail(ctx, PCL_EHIP, "the slice-ticket module did not compile (%s)", g_jit_note.c_str());
+        }
+        fk = ctx->v4_ft;
+    }
+    HIP_TRY(ctx, hipModuleLaunchKernel(fk, (unsigned)g, 1, 1, 64 * (m + 9 + (ticket ? 1 : 0)), 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
     ctx->last_kernel = 40 + p.q;
     ctx->last_n_stream = 0;
     if (ticket) ctx->ticket_launched = true;
@@ -2088,7 +2099,7 @@ static int order_for(double theta, double tol) {
 }
 static void set_order(pcl_ctx *ctx, int order, double theta) {
     if (ctx->desc.pade_order != order) {  // (modules are per order: the handles of the previous one are dropped, the modules stay cached)
-        ctx->v4_f = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = nullptr;
+        ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = nullptr;
         ctx->v4_failed = ctx->v4_hess_failed = 0;
     }
     ctx->desc.pade_order = order;
@@ -3092,7 +3103,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_prof = v;
     else if (!strcmp(key, "v4_variant")) {  // timing variants of kernel 4's generated product (WRONG results); recompiles
         ctx->opt_v4_variant = v;
-        ctx->v4_f = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = nullptr;
+        ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = nullptr;
     }
 #endif
     else if (!strcmp(key, "host_threads"))  // host-pointer entry points: threads expanding the compact values (0 = auto)
