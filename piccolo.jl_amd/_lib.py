@@ -210,7 +210,8 @@ def prebuild_kernels(G_drifts, G_drives, orders=(4,), hessian=True, out_dir=None
     L.pcl_jit_prebuild.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
     count = 0
     for order in orders:
-        whats = [0] + ([4] if order <= 4 else []) + (([3] if order == 4 else []) + [1, 2] if hessian else [])  # (4: the fused module with the slice-ticket roles)
+        # 0 fused | 4 fused with the slice-ticket roles | 3 the order-4 Hessian module | 5 the column-group Hessian kernel (`auto` at the other orders)
+        whats = [0] + ([4] if order <= 4 else []) + (([3] if order == 4 else [5]) if hessian else [])
         for what in whats:
             rc = L.pcl_jit_prebuild(d, m, G0.ctypes.data, G0.shape[0], Gj.ctypes.data if m else None, order // 2, what, od)
             if rc != 0:

@@ -233,6 +233,15 @@ static inline void v4_emit_chunk_loads(std::string &s, int chunk) {
 }  // namespace detail
 
 // The generated definitions: shape macros, the resident-coefficient struct, the product, the drives' gathers.
+// terms per output row of the drives' transposed gathers (SP4_GTK of the generated source: the entry table of pcl_kernel_hess_cols.hpp)
+static inline int v4_gather_terms(const V4Plan &P) {
+    int gtk = 1;
+    for (int l = 0; l < P.m; ++l) {
+        std::vector<int> cnt(P.d, 0);
+        for (const V4GEnt &e : P.gl[l]) gtk = std::max(gtk, ++cnt[e.col]);
+    }
+    return gtk;
+}
 // np: LDS tiles the powers of G rotate through (>= 2 for q >= 2; q when they fit)
 // variant: timing experiments of the product (WRONG results unless 0): 1 no ds_add_f64 | 2 no LDS operation in the epilogues | 3 one
 // accumulator chain per output row group only half as deep (kV4Group rows -> plain v_mul of every term: no dependent chains)
@@ -356,8 +365,14 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
             while (pend_i < pending.size()) s += pending[pend_i++];
             pending.clear();
             pend_i = 0;
-            // finish the group in place (with Y: its values -- and whatever else this wave has in flight -- have landed)
-            if (with_y) s += "        \"s_waitcnt lgkmcnt(0)\\n\\t\"\n";
+            // finish the group in place.  With Y: its values have landed -- a wave's LDS operations complete in order, so it is enough that
+            // no more operations are in flight than were issued behind the Y reads (the previous group's writes and adds, `npend` of them:
+            // waiting for those too cost a lone wave ~100 cycles per group, a third of the product; a scalar load in flight only makes
+            // the wait longer, never shorter)
+            if (with_y) {
+                snprintf(buf, sizeof buf, "        \"s_waitcnt lgkmcnt(%zu)\\n\\t\"\n", std::min<size_t>(npend, 15));
+                s += buf;
+            }
             for (int o = g0; o < g1; ++o) {
                 const int gi = o - g0;
                 if (seenU[gi]) {
@@ -534,6 +549,34 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
                 s += buf;
             }
             s += "}\n";
+        }
+        // The same gathers as ONE table for lanes that belong to different drives (pcl_kernel_hess_cols.hpp): entry [drive][half][row][term]
+        // = (source row of the w column, 0 .. n-1) << 8 | coefficient index (0: none; 1 + 2 g: +mags[g]; 2 + 2 g: -mags[g]), the half's sign
+        // of the B entries folded in (sb = +1 in half 0, -1 in half 1); SP4_GTK terms per row.
+        if (P.m > 0) {
+            std::vector<std::vector<unsigned>> rows((size_t)P.m * 2 * d);
+            size_t gtk = 1;
+            for (int l = 0; l < P.m; ++l)
+                for (int hf = 0; hf < 2; ++hf)
+                    for (int i = 0; i < d; ++i) {
+                        std::vector<unsigned> &r = rows[((size_t)l * 2 + hf) * d + i];
+                        for (int pass = 0; pass < 2; ++pass)  // the A entries first, as the generated functions add them
+                            for (const V4GEnt &e : P.gl[l])
+                                if (e.col == i && e.isB == (pass == 1)) {
+                                    const bool neg = e.neg != (e.isB && hf == 1);
+                                    const unsigned src = (unsigned)((e.isB ? 1 - hf : hf) * d + e.row);
+                                    r.push_back(src << 8 | (unsigned)(1 + 2 * e.mag + (neg ? 1 : 0)));
+                                }
+                        gtk = std::max(gtk, r.size());
+                    }
+            snprintf(buf, sizeof buf, "#define SP4_GTK %zu\nstatic __device__ const unsigned short sp4_gt_tab[%zu] = {", gtk, rows.size() * gtk);
+            s += buf;
+            for (size_t r = 0; r < rows.size(); ++r)
+                for (size_t k = 0; k < gtk; ++k) {
+                    snprintf(buf, sizeof buf, "%s%u", (r || k) ? "," : "", k < rows[r].size() ? rows[r][k] : 0u);
+                    s += buf;
+                }
+            s += "};\n";
         }
         s += "#define SP4_GATHER_T_SWITCH(l, Wo, Wx, X, hs, sb, mg) switch (l) {";
         for (int l = 0; l < P.m; ++l) {

@@ -1,0 +1,376 @@
+// pcl_kernel_hess_cols.hpp -- Hessian of the Lagrangian at ANY diagonal Pade order 2q, pattern-compiled, ONE WAVE PER GROUP OF STATE COLUMNS
+// (DESIGN.md section 4.4, round 4).  Included by generated source only (pcl_codegen_v4.hpp with the Hessian functions), like
+// pcl_kernel_hess_sparse4.hpp, whose formulas it shares:
+//     W_0 = M, W_j = G^T W_{j-1}          V_{l,j} = G^T V_{l,j-1} + G_l^T W_{j-1}  (V_{l,0} = 0)          Z_b(Y) = G^b Y
+//     d2/du_l dX_k = -sum_j T_j V_{l,j}   d2/du_l dX_{k+1} = sum_j T_j (-1)^j V_{l,j}   (the same with W_j, T'_j for d2/dh dX)
+//     (h,h) = sum_j T''_j <W_j, Y_j>      (h,u_l) = sum_j T'_j <V_{l,j}, Y_j>
+//     (u_i,u_l) = sum_a ( <V_{i,a}, G_l R_a> + <V_{l,a}, G_i R_a> ),   R_a = sum_b (+-T_{a+b+1}) Z_b(|Y_{a+b+1}|)
+// Every chain is a product with G or G^T applied to the n x d state tile COLUMN BY COLUMN: the chains of one state column need nothing of
+// another column; only the 28 scalar entries sum over the columns.  pcl_hess_sparse4_kernel gives a wave to a chain (all columns) and keeps
+// the waves of an interval in lock step behind two workgroup barriers per level -- 93 k cycles per interval at order 8 where the multiply-adds
+// need 14 k.  Here a wave takes ALL m + 1 chains of HC_CPW = 32 / (m + 1) state columns:
+//     lane = (half, chain, column):  half = lane / 32 (top / bottom rows, as in the products), slot = lane % 32 = chain * HC_CPW + column
+// and is a workgroup of its own: no barrier, no other wave's data, its LDS (chain slots, D, S, R_1 .. R_{q-1} of its columns: 21 KB at order 8)
+// lets seven of them share a CU, each at its own place in its own interval -- what one waits for, another computes.  The products are the
+// generated sp4_product_t / sp4_product0 unchanged (a lane's LDS offsets are operands); the W lanes read their `Y term' from a strip of zeros.
+// What the layout costs: the drives' gathers G_l^T W come from an entry table (the lanes of a wave belong to different drives), the chain of the
+// R_a uses HC_CPW of the 32 slots, and level 1 runs the product for the W lanes only (7 q + 7 (q - 2) product passes per interval instead of
+// 9 q - 11).
+// The reduced sums of a wave ((m + 1) x (m + 1): per chain <chain, Y> and the row of (u,u) sums) leave through memory; the wave of the
+// interval that arrives last adds the HC_NG rows in a fixed order and writes the entries -- nobody waits for anybody, the same bits for
+// every launch geometry (the exchange of pcl_hess_sparse4_kernel's two-workgroup mode: write-through stores, a relaxed arrival counter,
+// cache-bypassing loads; no fence).
+#pragma once
+
+#define SP4CS (SPN + 1)
+#ifndef HC_SWITCH_GATHER
+#define HC_SWITCH_GATHER 0  // 1: the drives' gathers as a switch over the generated functions (six passes under the lanes' masks: 8 k cycles per level)
+#endif
+#define HC_NCH (SPM + 1)                      // chains per state column: W, V_1 .. V_m
+#define HC_CPW (32 / HC_NCH)                  // state columns per wave
+#define HC_NG ((SPD + HC_CPW - 1) / HC_CPW)   // waves per interval
+#define HC_NSLOT (HC_NCH * HC_CPW)
+#define HC_NR (SP4Q > 1 ? SP4Q - 1 : 0)       // R_1 .. R_{q-1}
+#define HC_NT ((HC_CPW * SPN + 63) / 64)      // passes of the flat (lane = element) copies of a wave's HC_CPW contiguous columns
+#define HC_ROW (SPM + 1)                      // reduced sums per chain: <chain, Y>, row of (u,u)
+#define HC_XS (HC_NCH * HC_ROW)               // ... per wave
+#define HC_NSC ((SPM + 1) * (SPM + 2) / 2)
+#define HC_GCH 5                                                        // rows per batch of the table-driven gathers
+#define HC_NCFT 24                                                      // coefficient table of the gathers: 0, +-mags[g]
+#define HC_GT_DOUBLES ((SPM * 2 * SPD * SP4_GTK * 2 + 7) / 8)            // the gathers' entry table (sp4_gt_tab), unsigned short
+#define HC_LDS_DOUBLES ((HC_NSLOT + (2 + HC_NR) * HC_CPW) * SP4CS + 32 + HC_NCFT + HC_GT_DOUBLES)
+static_assert(1 + 2 * SP4NMAG <= HC_NCFT, "coefficient table of the gathers");
+static_assert(HC_CPW >= 1 && SPM >= 1, "chains per column");
+static_assert(HC_XS <= 64 && HC_ROW <= SPD, "one lane per reduced sum");
+
+static __device__ __forceinline__ unsigned hc_lds_off(const double *q) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const double *)q;
+}
+static __device__ __forceinline__ void hc_store_coherent(double *q, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(q), "v"(v) : "memory"); }
+static __device__ __forceinline__ double hc_load_coherent(const double *q) {
+    double v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(q) : "memory");
+    return v;
+}
+
+extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(2, 2))) void pcl_hess_cols_kernel(
+    const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ drift_tab_t, const double *__restrict__ mags_, const double *__restrict__ dcf_tab,
+    double *xch /* [interval][HC_NG][HC_XS] reduced sums */, unsigned int *xcnt /* [interval] arrivals (self-resetting) */) {
+    extern __shared__ double lds[];
+    constexpr int d = SPD, n = SPN, m = SPM, q = SP4Q;
+    constexpr int CB = HC_CPW * SP4CS;  // doubles per block of HC_CPW columns
+    double *slots = lds, *Dt = slots + HC_NSLOT * SP4CS, *St = Dt + CB, *Rt = St + CB, *zero = Rt + HC_NR * CB, *cft = zero + 32;
+    unsigned short *gtab = (unsigned short *)(cft + HC_NCFT);
+    const long long xd = (long long)n * d;
+    const int item = blockIdx.x / HC_NG, grp = blockIdx.x - item * HC_NG;
+    const int k = item % p.K, b = item / p.K;
+    const int c0 = grp * HC_CPW, nce = min(HC_CPW, d - c0), ne = nce * n;
+    double *H = p.hess + (long long)item * p.hess_per;
+    sp_cptr magc = (sp_cptr)mags_;
+    double mg[SP4NMAG];
+#pragma unroll
+    for (int g = 0; g < SP4NMAG; ++g) mg[g] = magc[g];
+#ifdef PCL_PROFILE
+    int stamp_ = 0;  // cycle stamps of the first wave of the launch (dbg[i])
+#define HC_STAMP()                                                                                                 \
+    do {                                                                                                           \
+        if (p.dbg && blockIdx.x == (unsigned)p.prof && threadIdx.x == 0 && stamp_ < 32) p.dbg[stamp_++] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define HC_STAMP() do { } while (0)
+#endif
+    HC_STAMP();
+    int ln_ = threadIdx.x;
+    asm volatile("" : "+v"(ln_));
+    const int half = ln_ >> 5, s = ln_ & 31;
+    const int ch = s / HC_CPW, col = s - ch * HC_CPW;  // chain (0: W, 1 + l: V_l), column of the group
+    const bool inr = s < HC_NSLOT, act = inr && col < nce, isV = ch > 0;
+    const int own = half * d, oth = (1 - half) * d;
+    double *Xs = slots + (inr ? s : 0) * SP4CS;  // this lane's chain column
+    const double *Wc = slots + col * SP4CS;      // the W chain's column
+    const int cb = col * SP4CS;
+
+    // ---- inputs, first half: every load of the wave is requested before anything waits (lane = element of the wave's contiguous columns) --
+    const long long xo = p.x_off0 >= 0 ? p.x_off0 : p.x_offs[p.z_batch_stride ? 0 : b];
+    const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + xo + (long long)c0 * n;
+    const double *zn = zk + p.z_dim;
+    const double *mu = p.mu + (long long)item * xd + (long long)c0 * n;
+    // (every load of the wave first: the state columns, then the tables)
+    double xc_[HC_NT], xn_[HC_NT], mv_[HC_NT];
+#pragma unroll
+    for (int t = 0; t < HC_NT; ++t) {
+        const int e = ln_ + 64 * t < ne ? ln_ + 64 * t : 0;
+        xc_[t] = zk[e], xn_[t] = zn[e], mv_[t] = mu[e];
+    }
+    constexpr int GTW = (SPM * 2 * SPD * SP4_GTK + 1) / 2;  // the gathers' entry table, in dwords
+    unsigned gw_[(GTW + 63) / 64];
+#pragma unroll
+    for (int t = 0; t < (GTW + 63) / 64; ++t) gw_[t] = ((const unsigned *)sp4_gt_tab)[ln_ + 64 * t < GTW ? ln_ + 64 * t : 0];
+    // scalars of the interval
+    sp_cptr zc = (sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim);
+    double u[SPM];
+#pragma unroll
+    for (int l = 0; l < SPM; ++l) u[l] = zc[p.u_off + l];
+    const double h = zc[p.dt_off];
+    sp4_cf cf;
+    SP4_SET_CF(cf, u, mg);
+    SP4_SET_DCF(cf, (sp_cptr)(dcf_tab + (p.g0_batch_stride ? (long long)b * SP4NDCFP : 0)));
+    sp_cptr tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
+    sp_cptr tab_t = (sp_cptr)(drift_tab_t + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
+    double pw[SP4Q + 1];  // h^j, multiplied up as pcl_hess_sparse4_kernel does (the same bits)
+    pw[0] = 1.0;
+#pragma unroll
+    for (int j = 1; j <= q; ++j) pw[j] = pw[j - 1] * h;
+    // +-T_jj: the weight of Z_b(|Y_jj|) in R_{jj-b-1}  (wgt: jj known at compile time; wgt_at: not -- no indexed register array)
+    auto wgt = [&](int jj) { return ((jj & 1) ? -1.0 : 1.0) * p.pc[jj] * pw[jj]; };
+    auto wgt_at = [&](int jj) {
+        double hj = 1.0;
+        for (int t = 0; t < jj; ++t) hj *= h;
+        return ((jj & 1) ? -1.0 : 1.0) * p.pc[jj] * hj;
+    };
+
+    // ---- inputs, second half: M -> the W slots, D, S, R_{q-1}; the tables of the gathers --------------------------------------------------
+    {
+        if (ln_ < 32) zero[ln_] = 0.0;
+        if (ln_ < 1 + 2 * SP4NMAG) cft[ln_] = ln_ == 0 ? 0.0 : ((ln_ & 1) ? magc[(ln_ - 1) >> 1] : -magc[(ln_ - 2) >> 1]);
+#pragma unroll
+        for (int t = 0; t < (GTW + 63) / 64; ++t)
+            if (ln_ + 64 * t < GTW) ((unsigned *)gtab)[ln_ + 64 * t] = gw_[t];
+#pragma unroll
+        for (int t = 0; t < HC_NT; ++t) {
+            const int e = ln_ + 64 * t;
+            if (e < ne) {
+                const int cc = e / n, o = cc * SP4CS + (e - cc * n);
+                const double dv = xn_[t] - xc_[t], sv = xn_[t] + xc_[t];
+                slots[o] = mv_[t];
+                Dt[o] = dv;
+                St[o] = sv;
+                if constexpr (q > 1) Rt[(q - 2) * CB + o] = wgt(q) * ((q & 1) ? sv : dv);  // R_{q-1}
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+    HC_STAMP();
+    // ---- R_a = sum_b (+-T_{a+b+1}) G^b |Y_{a+b+1}|, the operands of the (u,u) sums, as ONE chain per state column from the top:
+    //      R_{q-1} = +-T_q |Y_q| (stored with the inputs),  R_a = +-T_{a+1} |Y_{a+1}| + G R_{a+1}   (q - 2 products; lanes (half, column)) -----
+    if constexpr (q > 2) {
+        const bool ract = s < HC_CPW && s < nce;  // (slot = column)
+        const int rb = (s < HC_CPW ? s : 0) * SP4CS;
+#pragma unroll 1
+        for (int a = q - 2; a >= 1; --a) {
+            if (ract) {
+                const double *src = Rt + a * CB + rb + own;  // R_{a+1}
+                double x[SPD];
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) x[i] = src[i];
+                double *dst = Rt + (a - 1) * CB + rb;
+                const double *Y = (((a + 1) & 1) ? St : Dt) + rb + own;
+                sp4_product(x, hc_lds_off(Y), hc_lds_off(dst + own), hc_lds_off(dst + oth), sp4_uniform(wgt_at(a + 1)), 1.0, half ? -1.0 : 1.0, tab, cf);
+            }
+            HC_STAMP();
+        }
+    }
+    HC_STAMP();
+    // ---- the chains, level by level ---------------------------------------------------------------------------------------------------
+    const unsigned oX = hc_lds_off(Xs + own), oXx = hc_lds_off(Xs + oth);
+    const unsigned oY = isV ? oX : hc_lds_off(zero);  // the W lanes have no Y term
+    const double bt = half ? 1.0 : -1.0;               // G^T: the other half receives -V from half 0, +V from half 1
+    double x[SPD], accK[SPD], accN[SPD];               // chain value; the two output vectors of this lane's chain (X_k / X_{k+1} blocks), its rows
+#pragma unroll
+    for (int i = 0; i < SPD; ++i) accK[i] = accN[i] = 0.0;
+    if (act && !isV) {
+#pragma unroll
+        for (int i = 0; i < SPD; ++i) x[i] = Xs[own + i];  // W_0 = M
+    } else {
+#pragma unroll
+        for (int i = 0; i < SPD; ++i) x[i] = 0.0;  // V_{l,0} = 0
+    }
+    double s_y = 0.0, s_uu[SPM];
+#pragma unroll
+    for (int i = 0; i < SPM; ++i) s_uu[i] = 0.0;
+    double hp = 1.0;  // h^(j-1)
+#pragma unroll 1
+    for (int j = 1; j <= q; ++j) {
+        if (act && isV) {  // the Y term of V_{l,j}: G_l^T W_{j-1}, into this lane's own rows (its chain value is in registers)
+#if HC_SWITCH_GATHER
+            SP4_GATHER_T_SWITCH(ch - 1, Wc + own, Wc + oth, Xs + own, 1.0, (half ? -1.0 : 1.0), mg)
+#else
+            // the lanes of a wave belong to different drives: the entries come from the table (one instruction stream for every drive).
+            // HC_GCH rows at a time, staged by hand -- every entry of the batch, then every operand, then the sums: left to itself the
+            // compiler keeps two or three rows in flight and the wave waits out an LDS round trip per row (6.3 k cycles per level)
+            const unsigned short *gt = gtab + ((ch - 1) * 2 + half) * (SPD * SP4_GTK);
+            double *Xo = Xs + own;
+#pragma unroll
+            for (int i0 = 0; i0 < SPD; i0 += HC_GCH) {
+                unsigned e_[HC_GCH][SP4_GTK];
+#pragma unroll
+                for (int i = 0; i < HC_GCH; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < SP4_GTK; ++kk) e_[i][kk] = gt[(i0 + i < SPD ? i0 + i : SPD - 1) * SP4_GTK + kk];
+                double w_[HC_GCH][SP4_GTK], c_[HC_GCH][SP4_GTK];
+#pragma unroll
+                for (int i = 0; i < HC_GCH; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < SP4_GTK; ++kk) {
+                        w_[i][kk] = Wc[e_[i][kk] >> 8];
+                        c_[i][kk] = cft[e_[i][kk] & 255u];
+                    }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < HC_GCH; ++i)
+                    if (i0 + i < SPD) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int kk = 0; kk < SP4_GTK; ++kk) t = __builtin_fma(c_[i][kk], w_[i][kk], t);
+                        Xo[i0 + i] = t;
+                    }
+                asm volatile("" ::: "memory");
+            }
+#endif
+        }
+        asm volatile("" ::: "memory");
+        HC_STAMP();
+        if (act) sp4_product_t(x, oY, oX, oXx, 1.0, 1.0, bt, tab_t, cf);  // W_j = G^T W_{j-1} | V_{l,j} = G^T V_{l,j-1} + Y, in place
+        HC_STAMP();
+        // ---- what level j contributes ----
+        const double cj = p.pc[j];
+        const double Tj = cj * hp * h, T1 = j * cj * hp, sg = (j & 1) ? -1.0 : 1.0;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < SPD; ++i) x[i] = Xs[own + i];
+            const double wK = isV ? Tj : T1;  // the weight of this level in the lane's output vectors
+#pragma unroll
+            for (int i = 0; i < SPD; ++i) {
+                accK[i] = __builtin_fma(-wK, x[i], accK[i]);
+                accN[i] = __builtin_fma(wK * sg, x[i], accN[i]);
+            }
+            asm volatile("" ::: "memory");
+            const double *Yj = ((j & 1) ? St : Dt) + cb + own;  // Y_j = D (j even) | -S (j odd)
+            double dot0 = 0.0, dot1 = 0.0;
+            {
+                double y[SPD];  // (one LDS round trip; the additions in the order of pcl_hess_sparse4_kernel)
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) y[i] = Yj[i];
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) {
+                    if ((i % 9) & 1)
+                        dot1 = __builtin_fma(x[i], y[i], dot1);
+                    else
+                        dot0 = __builtin_fma(x[i], y[i], dot0);
+                }
+                asm volatile("" ::: "memory");
+            }
+            const double dy = sg * (dot0 + dot1);  // <chain_j, Y_j>
+            if (!isV) {
+                if (j >= 2) s_y = __builtin_fma(j * (j - 1) * cj * (hp / h), dy, s_y);  // T''_j = j (j-1) c_j h^(j-2)
+            } else {
+                s_y = __builtin_fma(T1, dy, s_y);
+                if (j < q) {  // (u,u): <V_{l,j}, G_i R_j>, every drive i
+                    const double *Rj = Rt + (j - 1) * CB + cb;
+                    double r6[SPM];
+                    sp4_gdot_all(Rj + own, Rj + oth, x, (half ? 1.0 : -1.0), mg, r6);
+#pragma unroll
+                    for (int i = 0; i < SPM; ++i) s_uu[i] += r6[i];
+                }
+            }
+        }
+        hp *= h;
+        HC_STAMP();
+    }
+    // ---- the reduced sums of the wave: every lane parks its 1 + m sums in its chain slot (rows 0 .. m of its half; slots of columns
+    //      past the end hold zeros); lane e < HC_XS adds the 2 HC_CPW parts of (chain, value) in a fixed order ------------------------------
+    asm volatile("" ::: "memory");
+    if (inr) {
+        Xs[own] = s_y;
+#pragma unroll
+        for (int i = 0; i < SPM; ++i) Xs[own + 1 + i] = s_uu[i];
+    }
+    asm volatile("" ::: "memory");
+    unsigned xold = 0xffffffffu;
+    {
+        double r = 0.0;
+        if (ln_ < HC_XS) {
+            const int chn = ln_ / HC_ROW, val = ln_ - chn * HC_ROW;
+#pragma unroll
+            for (int cc = 0; cc < HC_CPW; ++cc) {
+                r += slots[(chn * HC_CPW + cc) * SP4CS + val];
+                r += slots[(chn * HC_CPW + cc) * SP4CS + d + val];
+            }
+            hc_store_coherent(xch + ((long long)item * HC_NG + grp) * HC_XS + ln_, r);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    HC_STAMP();
+    // ---- output vectors: registers -> the lane's chain slot -> memory (lane = element: a chain's HC_CPW columns are contiguous) ----------
+    // (lane = a PAIR of elements: 16-byte stores -- a wave's 8-byte stores are bound by their issue, 100 cycles each)
+    typedef double hc_d2 __attribute__((ext_vector_type(2)));
+    constexpr int NT2 = (HC_CPW * SPN + 127) / 128;
+    static_assert(SPN % 2 == 0, "pairs of rows");
+    int eo[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+        const int e = 2 * ln_ + 128 * t, cc = e / n;
+        eo[t] = e < ne ? cc * SP4CS + (e - cc * n) : -1;
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < SPD; ++i) Xs[own + i] = pass ? accN[i] : accK[i];
+        }
+        asm volatile("" ::: "memory");
+        hc_d2 t_[HC_NCH][NT2];  // (every read of the pass, then the stores: two LDS round trips per pass, not one per chain)
+#pragma unroll
+        for (int c2 = 0; c2 < HC_NCH; ++c2)
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) {
+                const double *src = slots + c2 * CB + (eo[t] >= 0 ? eo[t] : 0);
+                t_[c2][t].x = src[0], t_[c2][t].y = src[1];
+            }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c2 = 0; c2 < HC_NCH; ++c2) {
+            // chain 0 (W): the h blocks m | 2 m + 1;  chain 1 + l: l | m + 1 + l
+            const int vec = c2 == 0 ? (pass ? 2 * m + 1 : m) : (pass ? m + c2 : c2 - 1);
+            double *o = H + HC_NSC + (long long)vec * xd + (long long)c0 * n + 2 * ln_;
+#pragma unroll
+            for (int t = 0; t < NT2; ++t)
+                if (eo[t] >= 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(o + 128 * t), "v"(t_[c2][t]) : "memory");
+        }
+        asm volatile("" ::: "memory");
+    }
+    HC_STAMP();
+    // ---- the scalar entries of the interval: the wave that arrived last adds the rows of all HC_NG waves in a fixed order.  (The row left
+    //      before the output vectors: its write has been acknowledged by the time theirs have.) ---------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ln_ == 0) xold = __hip_atomic_fetch_add(xcnt + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    xold = __builtin_amdgcn_readfirstlane(xold);
+    if (xold == HC_NG - 1) {
+        if (ln_ == 0) __hip_atomic_store(xcnt + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch)
+        double *tot = slots;  // [chain][value]
+        if (ln_ < HC_XS) {
+            const double *xall = xch + (long long)item * HC_NG * HC_XS + ln_;
+            double r = 0.0;
+#pragma unroll 1
+            for (int g = 0; g < HC_NG; ++g) r += hc_load_coherent(xall + g * HC_XS);
+            tot[ln_] = r;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (ln_ < HC_NSC) {
+            // order: (u_i, u_j) for i = 0..m-1, j = 0..i | (h, u_j) j < m | (h, h);   S[i][j] = tot[(1 + i) HC_ROW + 1 + j]
+            double v;
+            if (ln_ < m * (m + 1) / 2) {
+                int i = 0;
+                while ((i + 1) * (i + 2) / 2 <= ln_) ++i;
+                const int j = ln_ - i * (i + 1) / 2;
+                v = tot[(1 + i) * HC_ROW + 1 + j] + tot[(1 + j) * HC_ROW + 1 + i];
+            } else if (ln_ < m * (m + 1) / 2 + m) {
+                v = tot[(1 + ln_ - m * (m + 1) / 2) * HC_ROW];
+            } else {
+                v = tot[0];
+            }
+            H[ln_] = v;
+        }
+    }
+    HC_STAMP();
+}

@@ -99,6 +99,11 @@ struct pcl_ctx {
     double *dv4_tab = nullptr, *dv4_tab_t = nullptr, *dv4_mags = nullptr, *dv4_dcf = nullptr;
     hipFunction_t v4_ft = nullptr;  // the fused kernel of the module WITH the slice-ticket roles (launches of several trajectories)
     hipFunction_t v4_f = nullptr, v4_feval = nullptr, v4_fevalc = nullptr /* cooperative residual kernel (optional) */, v4_fhess = nullptr, v4_fhess2 = nullptr /* two workgroups per interval */;
+    hipFunction_t v4_fhessc = nullptr;  // general-order Hessian, one wave per group of state columns (pcl_kernel_hess_cols.hpp)
+    double *dhcx = nullptr;             // ... the waves' rows of reduced sums and the intervals' arrival counters (self-resetting)
+    unsigned int *dhcc = nullptr;
+    long long hc_cap = 0;
+    int v4_hessc_failed = 0;
     double *dh4x = nullptr;        // general-order Hessian, two workgroups per interval: their rows of reduced sums ...
     unsigned int *dh4c = nullptr;  // ... and the arrival counters (self-resetting)
     long long h4_cap = 0;
@@ -548,7 +553,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard dev_guard_(ctx->device);
     (void)pcl_comm_destroy(ctx);
-    void *ptrs[] = {ctx->dh4x, ctx->dh4c, ctx->dGjd, ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
+    void *ptrs[] = {ctx->dhcx, ctx->dhcc, ctx->dh4x, ctx->dh4c, ctx->dGjd, ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
                     ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg, ctx->dellt_col, ctx->dellt_val,
                     ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout, ctx->dreduce};
@@ -936,8 +941,8 @@ hipFunction_t jit_compile(int device, const std::string &key_, const std::string
     dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
     const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp",
                            "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp", "pcl_kernel_eval_sparse.hpp",
-                           "pcl_kernel_fused_sparse.hpp", "pcl_kernel_hess_sparse4.hpp"};
-    constexpr int NH = 9;
+                           "pcl_kernel_fused_sparse.hpp", "pcl_kernel_hess_sparse4.hpp", "pcl_kernel_hess_cols.hpp"};
+    constexpr int NH = 10;
     std::string hdr[NH];
     const char *hdrp[NH];
     for (int i = 0; i < NH; ++i) {
@@ -990,6 +995,14 @@ std::string v4_source(const pcl_codegen::V4Plan &plan, int q, int np, int varian
 std::string v4_hess_source(const pcl_codegen::V4Plan &plan, int q, int variant = 0, int split = 1) {  // variant (profile builds): SH_VARIANT of the kernel (bits >= 16), bit 8: the gather-dot reads nine columns at a time
     return "#include \"pcl_device_common.hpp\"\n#define SH_VARIANT " + std::to_string(variant) + "\n#define SH_SPLIT " + std::to_string(split) + "\n" + pcl_codegen::v4_functions(plan, q, 1, variant & 8, true) + "#include \"pcl_kernel_hess_sparse4.hpp\"\n";
 }
+// ... one wave per group of state columns (pcl_kernel_hess_cols.hpp; any order)
+std::string v4_hess_cols_source(const pcl_codegen::V4Plan &plan, int q, int variant = 0) {
+    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q, 1, (variant & 7) | 8, true) + "#include \"pcl_kernel_hess_cols.hpp\"\n";
+}
+static size_t hess_cols_lds_bytes(int d, int m, int q, int gtk) {  // HC_LDS_DOUBLES of the kernel
+    const int cpw = 32 / (m + 1);
+    return ((size_t)((m + 1) * cpw + (2 + (q > 1 ? q - 1 : 0)) * cpw) * (2 * d + 1) + 32 + 24 + ((size_t)m * 2 * d * gtk * 2 + 7) / 8) * sizeof(double);
+}
 }  // namespace
 
 // Compile `source` (a generated module) with hiprtc and leave the code object in `out_dir` under its content hash: no device needed.
@@ -1005,8 +1018,8 @@ static int prebuild_source(const std::string &source, const char *name_expr, con
     dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
     const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp",
                            "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp", "pcl_kernel_eval_sparse.hpp",
-                           "pcl_kernel_fused_sparse.hpp", "pcl_kernel_hess_sparse4.hpp"};
-    constexpr int NH = 9;
+                           "pcl_kernel_fused_sparse.hpp", "pcl_kernel_hess_sparse4.hpp", "pcl_kernel_hess_cols.hpp"};
+    constexpr int NH = 10;
     std::string hdr[NH];
     const char *hdrp[NH];
     for (int i = 0; i < NH; ++i) {
@@ -1038,9 +1051,10 @@ static int prebuild_source(const std::string &source, const char *name_expr, con
 }
 // the pattern-compiled modules of one system, as a context of that system would compile them on first use (no device needed):
 //   what 0  fused residual + Jacobian + residual-only kernels at order 2q | 1  general-order Hessian, one workgroup per interval |
-//        2  ... two workgroups per interval | 3  the order-4 Hessian / value-table module (q ignored)
+//        2  ... two workgroups per interval | 3  the order-4 Hessian / value-table module (q ignored) | 4  the fused module with the slice-ticket
+//        roles | 5  general-order Hessian, one wave per group of state columns
 extern "C" int pcl_jit_prebuild(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what, const char *out_dir) {
-    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || what < 0 || what > 4 || !G0 || (m > 0 && !Gj)) return fail(nullptr, PCL_EINVAL, "pcl_jit_prebuild: bad argument");
+    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || what < 0 || what > 5 || !G0 || (m > 0 && !Gj)) return fail(nullptr, PCL_EINVAL, "pcl_jit_prebuild: bad argument");
     std::string src, err;
     const char *kernel = "pcl_fused_sparse_kernel";
     if (what == 3) {
@@ -1051,8 +1065,8 @@ extern "C" int pcl_jit_prebuild(int d, int m, const double *G0, int n_g0, const 
         if (!plan.ok) return fail(nullptr, PCL_ESHAPE, "pcl_jit_prebuild: the pattern-compiled kernels do not take this system");
         const int np = v4_power_tiles(d, m, q, 160 * 1024);
         if (!np) return fail(nullptr, PCL_ESHAPE, "pcl_jit_prebuild: tiles exceed LDS");
-        src = what == 0 ? v4_source(plan, q, np) : what == 4 ? v4_source(plan, q, np, 0, 1) : v4_hess_source(plan, q, 0, what);
-        if (what && what != 4) kernel = "pcl_hess_sparse4_kernel";
+        src = what == 0 ? v4_source(plan, q, np) : what == 4 ? v4_source(plan, q, np, 0, 1) : what == 5 ? v4_hess_cols_source(plan, q) : v4_hess_source(plan, q, 0, what);
+        if (what && what != 4) kernel = what == 5 ? "pcl_hess_cols_kernel" : "pcl_hess_sparse4_kernel";
     }
     const int rc = prebuild_source(src, kernel, out_dir, err);
     return rc == PCL_OK ? rc : fail(nullptr, rc, "pcl_jit_prebuild: %s", err.c_str());
@@ -1820,7 +1834,50 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
     p.mu = mu;
     p.hess = hess;
     const bool mf = ctx->opt_use_mfma != 0;
-    // hess_kernel 7 (auto at every order but 4): the pattern-compiled kernel on the products of fused kernel 4 -- any order,
+    // hess_kernel 8 (auto at every order but 4): the pattern-compiled kernel with ONE WAVE PER GROUP OF STATE COLUMNS (pcl_kernel_hess_cols.hpp): every
+    // wave a workgroup of its own with all m + 1 chains of 32 / (m + 1) columns, the scalar entries assembled by the wave of the interval
+    // that arrives last
+    const bool cols_auto = ctx->opt_hess_kernel == 0 && ctx->desc.pade_order != 4 && !ctx->opt_general;  // (order 4: the tuned kernel 6 below stays ahead)
+    if ((ctx->opt_hess_kernel == 8 || cols_auto) && v4_available(ctx) && !ctx->v4_hessc_failed && p.m >= 1) {
+        const pcl_codegen::V4Plan &v4 = *ctx->v4_plan;
+        fill_pade(p, ctx->desc.pade_order);
+        const long long items = (long long)p.batch * p.K;
+        const int cpw = 32 / (p.m + 1), ng = (p.d + cpw - 1) / cpw;
+        if (items * ng > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+        const size_t ldsc = hess_cols_lds_bytes(p.d, p.m, p.q, pcl_codegen::v4_gather_terms(v4));
+        if (!ctx->v4_fhessc && ldsc <= (size_t)ctx->max_lds) {
+            const std::string src = v4_hess_cols_source(v4, p.q, (int)ctx->opt_v4_variant);
+            const std::string key = "hess-cols:" + std::to_string(p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
+            ctx->v4_fhessc = jit_compile(ctx->device, key, src, "pcl_hess_cols_kernel", true);
+            if (!ctx->v4_fhessc) {
+                ctx->v4_hessc_failed = 1;
+                if (int rc = jit_fell_back(ctx, "Hessian of the Lagrangian (column groups)"); rc != PCL_ENOTIMPL) return rc;
+            }
+        }
+        if (ctx->v4_fhessc) {
+            const long long cap = (long long)ctx->desc.batch * ctx->K;
+            if (ctx->hc_cap < cap) {
+                if (ctx->dhcx) (void)hipFree(ctx->dhcx);
+                if (ctx->dhcc) (void)hipFree(ctx->dhcc);
+                ctx->dhcx = nullptr, ctx->dhcc = nullptr, ctx->hc_cap = 0;
+                HIP_TRY(ctx, hipMalloc((void **)&ctx->dhcx, (size_t)cap * ng * (p.m + 1) * (p.m + 1) * sizeof(double)));
+                HIP_TRY(ctx, hipMalloc((void **)&ctx->dhcc, (size_t)cap * sizeof(unsigned int)));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->dhcc, 0, (size_t)cap * sizeof(unsigned int), ctx->stream));
+                ctx->hc_cap = cap;
+            }
+            const long long wo = ctx->desc.per_member_G0 ? (long long)ctx->win_first : 0;
+            const double *tab = ctx->dv4_tab + wo * v4.n_drift_pad, *tab_t = ctx->dv4_tab_t + wo * v4.n_drift_pad, *dcf = ctx->dv4_dcf + wo * v4.n_dcf_pad;
+            void *args[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dhcx, (void *)&ctx->dhcc};
+            HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhessc, (unsigned)(items * ng), 1, 1, 64, 1, 1, (unsigned)ldsc, ctx->stream, args, nullptr));
+            ctx->last_hess_kernel = 80 + p.q;
+            ctx->last_hess_split = 0;
+            return PCL_OK;
+        }
+        if (ctx->opt_hess_kernel == 8) return fail(ctx, PCL_ESHAPE, "hess_kernel=8: the column-group kernel is not available (%s)", g_jit_note.c_str());
+    } else if (ctx->opt_hess_kernel == 8) {
+        return fail(ctx, PCL_ESHAPE, "hess_kernel=8 needs sparse exact-iso generators of a unitary problem (9 <= d <= 32), 1..6 drives and jit=1");
+    }
+    // hess_kernel 7 (auto where kernel 8 is not available): the pattern-compiled kernel on the products of fused kernel 4 -- any order,
     // one workgroup of m + 1 waves per interval (column slices where the m + 3 + 2 (q - 2) tiles do not fit LDS)
     if ((ctx->opt_hess_kernel == 7 || (ctx->opt_hess_kernel == 0 && ctx->desc.pade_order != 4 && !ctx->opt_general)) && v4_available(ctx) && !ctx->v4_hess_failed) {
         const pcl_codegen::V4Plan &v4 = *ctx->v4_plan;
@@ -2099,8 +2156,8 @@ static int order_for(double theta, double tol) {
 }
 static void set_order(pcl_ctx *ctx, int order, double theta) {
     if (ctx->desc.pade_order != order) {  // (modules are per order: the handles of the previous one are dropped, the modules stay cached)
-        ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = nullptr;
-        ctx->v4_failed = ctx->v4_hess_failed = 0;
+        ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = ctx->v4_fhessc = nullptr;
+        ctx->v4_failed = ctx->v4_hess_failed = ctx->v4_hessc_failed = 0;
     }
     ctx->desc.pade_order = order;
     ctx->order_theta = theta;
@@ -3103,7 +3160,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_prof = v;
     else if (!strcmp(key, "v4_variant")) {  // timing variants of kernel 4's generated product (WRONG results); recompiles
         ctx->opt_v4_variant = v;
-        ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = nullptr;
+        ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = ctx->v4_fhessc = nullptr;
     }
 #endif
     else if (!strcmp(key, "host_threads"))  // host-pointer entry points: threads expanding the compact values (0 = auto)
@@ -3164,7 +3221,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_eval_kernel = v;
     }
     else if (!strcmp(key, "hess_kernel")) {  // 0: auto, 1: one workgroup per interval, 2: persistent wave-synchronous kernel
-        if ((v < 0 || v > 4) && v != 7) return fail(ctx, PCL_EINVAL, "hess_kernel must be 0 .. 4 or 7");
+        if ((v < 0 || v > 4) && v != 7 && v != 8) return fail(ctx, PCL_EINVAL, "hess_kernel must be 0 .. 4, 7 or 8");
         ctx->opt_hess_kernel = v;
     }
     else if (!strcmp(key, "debug_timing")) {  // profiling aid: cycle stamps of workgroup 0 (pcl_debug_timing reads them)

@@ -90,7 +90,7 @@ def test_golden_vectors(name, variant, host_path, golden, golden_meta):
 @pytest.mark.parametrize("host_path", [1, 2])
 def test_golden_vectors_orders_8_and_10(name, order, host_path, golden, golden_meta):
     """The committed order-8 and order-10 vectors (the orders that reach the reference's exp constraint at config 3) through the kernels
-    `auto` launches: pattern-compiled residual + Jacobian 44 / 45 and Hessian 74 / 75 at config 3, the small-system kernel at 1 and 2."""
+    `auto` launches: pattern-compiled residual + Jacobian 44 / 45 and Hessian 84 / 85 at config 3, the small-system kernel at 1 and 2."""
     v = golden("vec_" + name)
     m = golden_meta["oracle_vectors"][name]
     lay = po.Layout(d=m["d"], m=m["m"], N=m["N"], z_dim=m["z_dim"], x_off=m["x_off"], u_off=m["u_off"], dt_off=m["dt_off"])
@@ -104,6 +104,9 @@ def test_golden_vectors_orders_8_and_10(name, order, host_path, golden, golden_m
     close(c.jac(v["Z"]), v["jac%d" % order], 1e-12)
     close(c.hess(v["Z"], v["mu"]), v["hess%d" % order], 1e-11)
     if name == "config3":
+        assert c.get_option("last_hess_kernel") == 80 + order // 2  # the column-group kernel
+        c.set_option("hess_kernel", 7)  # ... and the chain-per-wave kernel it replaced as the `auto` choice
+        close(c.hess(v["Z"], v["mu"]), v["hess%d" % order], 1e-11)
         assert c.get_option("last_hess_kernel") == 70 + order // 2
     c.close()
 
@@ -2659,7 +2662,7 @@ def test_hessian_of_the_lagrangian_at_every_pade_order(order):
 
 @pytest.mark.parametrize("order", [2, 4, 6, 8, 10])
 def test_pattern_compiled_general_order_hessian(order):
-    """pcl_hess_sparse4_kernel (hess_kernel 7; auto at every order but 4): the Hessian of the Lagrangian at BASELINE config 3 against
+    """pcl_hess_sparse4_kernel (hess_kernel 7; `auto` until round 4): the Hessian of the Lagrangian at BASELINE config 3 against
     the oracle's general-order formulas (pinned by the complex-step derivative of the Frechet-pinned Jacobian), every column
     slicing and grid (the 28 scalar entries are summed over the slices in registers), repeatable bits, full size at order 8,
     and per-member drifts on a member window."""
@@ -2695,7 +2698,7 @@ def test_pattern_compiled_general_order_hessian(order):
             c.set_option("cols_per_slice", 0)
             c.set_option("grid", 0)
             close(c.hess(Z, mu.reshape(-1)), ref, 1e-11)
-            assert c.get_option("last_hess_kernel") == 70 + order // 2
+            assert c.get_option("last_hess_kernel") == 80 + order // 2  # (the column-group kernel: test_column_group_hessian_kernel)
         c.close()
     osys, psys, layE, ZE, trajE = _config4_share(3, 4)
     BE = pa.HipPadeIntegrator(np.array([s.G_drift for s in psys]), psys[0].G_drives_array(), trajE, ["Ũ⃗1", "Ũ⃗2", "Ũ⃗3"], pade_order=order)
@@ -2714,6 +2717,63 @@ def test_pattern_compiled_general_order_hessian(order):
     for i, s in enumerate(osys):
         close(hE2[i * per : (i + 1) * per], po.pade_hessian_values(ZE, muE[i], layE, s.G_drift, np.array(s.G_drives), order, x_off=i * layE.x_dim).reshape(-1), 1e-11)
     BE.close()
+
+
+@pytest.mark.parametrize("order", [2, 4, 6, 8, 10])
+def test_column_group_hessian_kernel(order):
+    """pcl_hess_cols_kernel (hess_kernel 8; `auto` at every order but 4): one wave = all m + 1 chains of four state columns, a workgroup of
+    its own; the scalar entries assembled by the wave of the interval that arrives last.  BASELINE config 3 against the oracle's
+    general-order formulas and the chain-per-wave kernel, repeatable bits (the arrival counters reset themselves), full size at order 8,
+    per-member drifts and a member window, 8 seeds in one launch against 8 launches."""
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    for N in ((4, 100) if order == 8 else (4,)):
+        Z, lay = po.synthetic_trajectory(so, N, seed=79)
+        Z[:, lay.dt_off] = 0.1 + 0.05 * np.random.default_rng(3).random(N)
+        mu = np.random.default_rng(5).standard_normal((lay.K, lay.x_dim))
+        ref = po.pade_hessian_values(Z, mu, lay, G0, Gj, order).reshape(-1)
+        c = make_ctx(lay, G0, Gj, pade_order=order)
+        c.set_option("hess_kernel", 8)
+        h = c.hess(Z, mu.reshape(-1))
+        assert c.get_option("last_hess_kernel") == 80 + order // 2
+        close(h, ref, 1e-11)
+        for _ in range(3):
+            assert np.array_equal(h, c.hess(Z, mu.reshape(-1)))
+        c.set_option("hess_kernel", 7)
+        close(h, c.hess(Z, mu.reshape(-1)), 1e-13)
+        c.set_option("hess_kernel", 0)
+        h0 = c.hess(Z, mu.reshape(-1))
+        assert c.get_option("last_hess_kernel") == (6 if order == 4 else 80 + order // 2)
+        if order != 4:
+            assert np.array_equal(h, h0)
+        c.close()
+    osys, psys, layE, ZE, trajE = _config4_share(3, 4)
+    BE = pa.HipPadeIntegrator(np.array([s.G_drift for s in psys]), psys[0].G_drives_array(), trajE, ["Ũ⃗1", "Ũ⃗2", "Ũ⃗3"], pade_order=order)
+    BE.ctx.set_option("hess_kernel", 8)
+    muE = np.random.default_rng(6).standard_normal((3, layE.K, layE.x_dim))
+    hE = BE.ctx.hess(trajE.datavec, muE.reshape(-1))
+    assert BE.ctx.get_option("last_hess_kernel") == 80 + order // 2
+    per = po.hess_nnz_per_interval(layE) * layE.K
+    for i, s in enumerate(osys):
+        close(hE[i * per : (i + 1) * per], po.pade_hessian_values(ZE, muE[i], layE, s.G_drift, np.array(s.G_drives), order, x_off=i * layE.x_dim).reshape(-1), 1e-11)
+    BE.ctx.set_member_window(1, 1)
+    assert np.array_equal(BE.ctx.hess(trajE.datavec, muE[1].reshape(-1)), hE[per : 2 * per])
+    BE.ctx.set_member_window(0, 3)
+    BE.close()
+    if order == 8:  # seeds: one launch of 8 trajectories = 8 launches of one (a wave's arithmetic depends on its interval and columns only)
+        N = 12
+        Zs = [po.synthetic_trajectory(so, N, seed=300 + i)[0] for i in range(8)]
+        lay = po.synthetic_trajectory(so, N, seed=300)[1]
+        mus = np.random.default_rng(8).standard_normal((8, lay.K, lay.x_dim))
+        cb = make_ctx(lay, G0, Gj, pade_order=order, batch=8, batch_mode=pa._lib.PCL_BATCH_TRAJ)
+        c1 = make_ctx(lay, G0, Gj, pade_order=order)
+        for cc in (cb, c1):
+            cc.set_option("hess_kernel", 8)
+        hb = cb.hess(np.stack(Zs), mus.reshape(-1)).reshape(8, -1)
+        for i in range(8):
+            assert np.array_equal(hb[i], c1.hess(Zs[i], mus[i].reshape(-1)))
+        cb.close()
+        c1.close()
 
 
 def _random_sparse_iso_system(d, m, rng, n_mags=3):
@@ -2810,6 +2870,15 @@ def test_pattern_compiled_kernels_random_sparse_systems(d, m, Bn, N):
             h8 = c.hess(Zb, mu.reshape(-1))
             assert c.get_option("last_hess_split") == (split if m >= 2 else 0)
             assert np.array_equal(h8, h7) and np.array_equal(h8, c.hess(Zb, mu.reshape(-1)))
+        # the column-group kernel on the same system: 16 / 10 / 8 / 6 / 5 / 4 state columns per wave for 1 .. 6 drives, last waves with
+        # fewer columns, entries of both blocks and three magnitudes in the gathers' table
+        c.set_option("hess_kernel", 8)
+        hc = c.hess(Zb, mu.reshape(-1))
+        assert c.get_option("last_hess_kernel") == 82
+        close(hc, h_ref, 1e-11)
+        close(hc, h7, 1e-13)
+        assert np.array_equal(hc, c.hess(Zb, mu.reshape(-1)))
+        close(c.hess(Zb2, mu.reshape(-1)), h_ref2, 1e-11)
     c.close()
 
 
