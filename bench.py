@@ -405,7 +405,8 @@ def main():
             mso.close()
             del Zo, do_, muo, ho
             ex["order%d" % order] = {"hessian_of_lagrangian": {"us_per_eval_kernel": dh / 20 / B * 1e6, "batch": B, "kernel_id": hko,
-                                                               "kernel": "pcl_hess_sparse4_kernel (pattern-compiled, any order)" if hko // 10 == 7 else "general-order kernel"},
+                                                               "kernel": "pcl_hess_cols_kernel (pattern-compiled, any order: one wave per group of state columns)" if hko // 10 == 8 else
+                                                                         "pcl_hess_sparse4_kernel (pattern-compiled, any order)" if hko // 10 == 7 else "general-order kernel"},
                                      "residual_only": {"us_per_eval_kernel": de_ / st / B * 1e6, "batch": B, "kernel_id": eko},
                                      "single": {"evals_per_s": st / w1, "us_per_launch_kernel": d1 / st * 1e6, "frac_of_hbm_peak": abytes / (d1 / st) / 1e9 / HBM_PEAK_GBS,
                                                 "kernel_id": i1["kernel_id"]},

@@ -12,7 +12,7 @@
 //     lane = (half, chain, column):  half = lane / 32 (top / bottom rows, as in the products), slot = lane % 32 = chain * HC_CPW + column
 // and is a workgroup of its own: no barrier, no other wave's data, its LDS (chain slots, D, S, R_1 .. R_{q-1} of its columns: 21 KB at order 8)
 // lets seven of them share a CU, each at its own place in its own interval -- what one waits for, another computes.  The products are the
-// generated sp4_product_t / sp4_product0 unchanged (a lane's LDS offsets are operands); the W lanes read their `Y term' from a strip of zeros.
+// generated sp4_product0_t / sp4_product unchanged (a lane's LDS offsets are operands).
 // What the layout costs: the drives' gathers G_l^T W come from an entry table (the lanes of a wave belong to different drives), the chain of the
 // R_a uses HC_CPW of the 32 slots, and level 1 runs the product for the W lanes only (7 q + 7 (q - 2) product passes per interval instead of
 // 9 q - 11).
@@ -171,11 +171,14 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         }
     }
     HC_STAMP();
-    // ---- the chains, level by level ---------------------------------------------------------------------------------------------------
+    // ---- the chains, pass by pass.  In pass jp the V lanes are at level jp and the W lanes ONE LEVEL BEHIND, at jp - 1:
+    //          jp >= 2:  product in place (no Y term)   V: G^T V_{l,jp-1}      W: W_{jp-1} = G^T W_{jp-2}
+    //          then the W slots hold W_{jp-1} (jp = 1: M), what the V lanes' gathers need:   V_{l,jp} = G^T V_{l,jp-1} + G_l^T W_{jp-1}
+    //      -- added in registers behind the product, so the Y term never passes through LDS (a write and a read per row and level, and
+    //      the product's wait for them).  Pass 1 has no product (V_{l,0} = 0), pass q + 1 the W lanes' last one. --------------------------
     const unsigned oX = hc_lds_off(Xs + own), oXx = hc_lds_off(Xs + oth);
-    const unsigned oY = isV ? oX : hc_lds_off(zero);  // the W lanes have no Y term
-    const double bt = half ? 1.0 : -1.0;               // G^T: the other half receives -V from half 0, +V from half 1
-    double x[SPD], accK[SPD], accN[SPD];               // chain value; the two output vectors of this lane's chain (X_k / X_{k+1} blocks), its rows
+    const double bt = half ? 1.0 : -1.0;  // G^T: the other half receives -V from half 0, +V from half 1
+    double x[SPD], accK[SPD], accN[SPD];  // chain value; the two output vectors of this lane's chain (X_k / X_{k+1} blocks), its rows
 #pragma unroll
     for (int i = 0; i < SPD; ++i) accK[i] = accN[i] = 0.0;
     if (act && !isV) {
@@ -188,18 +191,29 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     double s_y = 0.0, s_uu[SPM];
 #pragma unroll
     for (int i = 0; i < SPM; ++i) s_uu[i] = 0.0;
-    double hp = 1.0;  // h^(j-1)
+    double hpV = 1.0, hpW = 1.0;  // h^(level - 1) of the V lanes' and of the W lanes' level
 #pragma unroll 1
-    for (int j = 1; j <= q; ++j) {
-        if (act && isV) {  // the Y term of V_{l,j}: G_l^T W_{j-1}, into this lane's own rows (its chain value is in registers)
+    for (int jp = 1; jp <= q + 1; ++jp) {
+        const bool on = act && (isV ? jp <= q : jp >= 2);  // lanes with a level in this pass
+        if (jp >= 2) {
+            if (on) {
+                sp4_product0_t(x, 0u, oX, oXx, 0.0, 1.0, bt, tab_t, cf);
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) x[i] = Xs[own + i];
+            }
+            asm volatile("" ::: "memory");
+        }
+        HC_STAMP();
+        if (on && isV) {  // + G_l^T W_{jp-1}
 #if HC_SWITCH_GATHER
             SP4_GATHER_T_SWITCH(ch - 1, Wc + own, Wc + oth, Xs + own, 1.0, (half ? -1.0 : 1.0), mg)
+#pragma unroll
+            for (int i = 0; i < SPD; ++i) x[i] += Xs[own + i];
 #else
             // the lanes of a wave belong to different drives: the entries come from the table (one instruction stream for every drive).
             // HC_GCH rows at a time, staged by hand -- every entry of the batch, then every operand, then the sums: left to itself the
             // compiler keeps two or three rows in flight and the wave waits out an LDS round trip per row (6.3 k cycles per level)
             const unsigned short *gt = gtab + ((ch - 1) * 2 + half) * (SPD * SP4_GTK);
-            double *Xo = Xs + own;
 #pragma unroll
             for (int i0 = 0; i0 < SPD; i0 += HC_GCH) {
                 unsigned e_[HC_GCH][SP4_GTK];
@@ -219,25 +233,19 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
 #pragma unroll
                 for (int i = 0; i < HC_GCH; ++i)
                     if (i0 + i < SPD) {
-                        double t = 0.0;
 #pragma unroll
-                        for (int kk = 0; kk < SP4_GTK; ++kk) t = __builtin_fma(c_[i][kk], w_[i][kk], t);
-                        Xo[i0 + i] = t;
+                        for (int kk = 0; kk < SP4_GTK; ++kk) x[i0 + i] = __builtin_fma(c_[i][kk], w_[i][kk], x[i0 + i]);
                     }
-                asm volatile("" ::: "memory");
             }
 #endif
         }
         asm volatile("" ::: "memory");
         HC_STAMP();
-        if (act) sp4_product_t(x, oY, oX, oXx, 1.0, 1.0, bt, tab_t, cf);  // W_j = G^T W_{j-1} | V_{l,j} = G^T V_{l,j-1} + Y, in place
-        HC_STAMP();
-        // ---- what level j contributes ----
-        const double cj = p.pc[j];
-        const double Tj = cj * hp * h, T1 = j * cj * hp, sg = (j & 1) ? -1.0 : 1.0;
-        if (act) {
-#pragma unroll
-            for (int i = 0; i < SPD; ++i) x[i] = Xs[own + i];
+        // ---- what the lane's level contributes ----
+        const int jl = isV ? jp : jp - 1;
+        const double cj = isV ? p.pc[jp <= q ? jp : q] : p.pc[jp - 1], hp = isV ? hpV : hpW;
+        const double Tj = cj * hp * h, T1 = jl * cj * hp, sg = (jl & 1) ? -1.0 : 1.0;
+        if (on) {
             const double wK = isV ? Tj : T1;  // the weight of this level in the lane's output vectors
 #pragma unroll
             for (int i = 0; i < SPD; ++i) {
@@ -245,7 +253,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
                 accN[i] = __builtin_fma(wK * sg, x[i], accN[i]);
             }
             asm volatile("" ::: "memory");
-            const double *Yj = ((j & 1) ? St : Dt) + cb + own;  // Y_j = D (j even) | -S (j odd)
+            const double *Yj = ((jl & 1) ? St : Dt) + cb + own;  // Y_j = D (j even) | -S (j odd)
             double dot0 = 0.0, dot1 = 0.0;
             {
                 double y[SPD];  // (one LDS round trip; the additions in the order of pcl_hess_sparse4_kernel)
@@ -262,11 +270,11 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
             }
             const double dy = sg * (dot0 + dot1);  // <chain_j, Y_j>
             if (!isV) {
-                if (j >= 2) s_y = __builtin_fma(j * (j - 1) * cj * (hp / h), dy, s_y);  // T''_j = j (j-1) c_j h^(j-2)
+                if (jl >= 2) s_y = __builtin_fma(jl * (jl - 1) * cj * (hp / h), dy, s_y);  // T''_j = j (j-1) c_j h^(j-2)
             } else {
                 s_y = __builtin_fma(T1, dy, s_y);
-                if (j < q) {  // (u,u): <V_{l,j}, G_i R_j>, every drive i
-                    const double *Rj = Rt + (j - 1) * CB + cb;
+                if (jp < q) {  // (u,u): <V_{l,j}, G_i R_j>, every drive i
+                    const double *Rj = Rt + (jp - 1) * CB + cb;
                     double r6[SPM];
                     sp4_gdot_all(Rj + own, Rj + oth, x, (half ? 1.0 : -1.0), mg, r6);
 #pragma unroll
@@ -274,7 +282,8 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
                 }
             }
         }
-        hp *= h;
+        hpW = hpV;
+        hpV *= h;
         HC_STAMP();
     }
     // ---- the reduced sums of the wave: every lane parks its 1 + m sums in its chain slot (rows 0 .. m of its half; slots of columns
@@ -304,6 +313,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     // ---- output vectors: registers -> the lane's chain slot -> memory (lane = element: a chain's HC_CPW columns are contiguous) ----------
     // (lane = a PAIR of elements: 16-byte stores -- a wave's 8-byte stores are bound by their issue, 100 cycles each)
     typedef double hc_d2 __attribute__((ext_vector_type(2)));
+    typedef double hc_d2u __attribute__((ext_vector_type(2), aligned(8)));  // (a vector of the output starts on an 8-byte boundary)
     constexpr int NT2 = (HC_CPW * SPN + 127) / 128;
     static_assert(SPN % 2 == 0, "pairs of rows");
     int eo[NT2];
@@ -335,7 +345,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
             double *o = H + HC_NSC + (long long)vec * xd + (long long)c0 * n + 2 * ln_;
 #pragma unroll
             for (int t = 0; t < NT2; ++t)
-                if (eo[t] >= 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(o + 128 * t), "v"(t_[c2][t]) : "memory");
+                if (eo[t] >= 0) *(hc_d2u *)(o + 128 * t) = t_[c2][t];
         }
         asm volatile("" ::: "memory");
     }
