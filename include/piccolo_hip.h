@@ -311,7 +311,8 @@ int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, const double
  * hash in out_dir (NULL: <library directory>/prebuilt, which every context looks at before the user's cache and before hiprtc).  Needs
  * libhiprtc, no device.  what: 0 fused residual + Jacobian (+ residual only) at order 2q | 1 general-order Hessian, one workgroup per
  * interval | 2 ... two workgroups per interval | 3 the order-4 Hessian / value-table module (q ignored) | 4 the fused module with the
- * slice-ticket roles (launches of several trajectories). */
+ * slice-ticket roles (launches of several trajectories) | 5 general-order Hessian, one wave per group of state columns (`auto` at every
+ * order but 4). */
 int pcl_jit_prebuild(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what, const char *out_dir);
 int pcl_codegen_apply_v4(int d, int m, const double *G0, int n_g0, const double *Gj, const double *u, const double *x, double *y, int transposed /* 1: y = G(u)^T x */);
 

@@ -161,6 +161,9 @@ __device__ __forceinline__ void gemm_lds(const double *A, int lda, const double 
 // nt: 0 plain | 1 nontemporal | 2 write-through at system scope (sc0 sc1).  Write-through halves the rate of launches whose
 // output exceeds the 256 MB infinity cache (1.08 GB: 191 -> 379 us) but is 0.7 us faster for one trajectory (135 MB, 27.3 ->
 // 26.6 us): the host picks it by launch size.
+// (The write-through store is a hand-written instruction the compiler does not see as a store: it must never be followed closely by a
+//  write of its data registers -- pcl_hess_cols_kernel lost a few lines per launch that way with plain hand-written 16-byte stores.  The
+//  callers pass long-lived accumulators: the nearest overwrite in the generated code is 27 instructions behind, checked in the ISA.)
 __device__ __forceinline__ void store2(double *p, double a, double b, int nt) {
     double2_t v = {a, b};
     if (nt == 2)
