@@ -36,5 +36,39 @@ run single_order8_sq "$SINGLE --order 8" --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_C
 run trace_single_k3 "$SINGLE --kernel-version 3" --kernel-trace --stats
 run single_k3_mfma "$SINGLE --kernel-version 3" --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU
 run single_mfma "$SINGLE" --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU
+# the Hessian of the Lagrangian at order 8, 8 trajectories per launch: the column-group kernel and the kernel it replaced
+runpy() { name=$1; args=$2; shift 2; rocprofv3 "$@" --output-format csv -d $OUT/$name -o $name -- python $ROOT/lab/probes/hess_cols_run.py $args > $OUT/$name.log 2> $OUT/$name.err; echo "$name rc=$?"; }
+runpy trace_hess8 "8 8 8" --kernel-trace --stats
+runpy trace_hess8_chains "8 7 8" --kernel-trace --stats
+runpy hess8_sq1 "8 8 8" --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS
+runpy hess8_sq2 "8 8 8" --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_SALU
+runpy hess8_write "8 8 8" --pmc WRITE_SIZE
+runpy hess8_fetch "8 8 8" --pmc FETCH_SIZE
 cd $ROOT
 python scripts/summarize_profile.py $OUT gpurun_out/profiles_$TAG $TAG
+python - $OUT gpurun_out/profiles_$TAG $TAG <<'PY'
+# <tag>_hess_order8.json: per-dispatch averages of the order-8 Hessian kernels (trace) and of the counter passes
+import csv, glob, json, sys, collections
+out, dst, tag = sys.argv[1:4]
+res = {"workload": "Hessian of the Lagrangian, config 3, order 8, 8 trajectories per launch (lab/probes/hess_cols_run.py)", "kernels": {}, "counters_per_dispatch": {}}
+for name in ("trace_hess8", "trace_hess8_chains"):
+    for f in glob.glob("%s/%s/**/*kernel_stats.csv" % (out, name), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "hess" in r["Name"]:
+                res["kernels"][r["Name"] + (" (hess_kernel 7)" if name.endswith("chains") else "")] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
+        for f2 in glob.glob("%s/%s/**/*kernel_stats.csv" % (out, name), recursive=True):
+            import shutil; shutil.copy(f2, "%s/%s_%s_kernel_stats.csv" % (dst, tag, name.replace("trace_", "")))
+tot, n = collections.defaultdict(float), collections.defaultdict(int)
+for name in ("hess8_sq1", "hess8_sq2", "hess8_write", "hess8_fetch"):
+    for f in glob.glob("%s/%s/**/*counter_collection.csv" % (out, name), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "hess" in r["Kernel_Name"]:
+                tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+for k in sorted(tot): res["counters_per_dispatch"][k] = tot[k] / n[k]
+c = res["counters_per_dispatch"]
+if "WRITE_SIZE" in c: res["write_MB_per_dispatch"] = c["WRITE_SIZE"] * 1024 / 1e6  # (KiB)
+if "FETCH_SIZE" in c: res["fetch_MB_per_dispatch"] = 2 * c["FETCH_SIZE"] * 1024 / 1e6  # (KiB, tallied at half the line size on gfx950: doubled)
+res["algorithmic_MB_per_dispatch"] = 8 * 99 * 20440 * 8 / 1e6
+json.dump(res, open("%s/%s_hess_order8.json" % (dst, tag), "w"), indent=1)
+print(json.dumps(res["kernels"]))
+PY
