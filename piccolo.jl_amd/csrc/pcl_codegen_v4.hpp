@@ -551,7 +551,7 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
             s += "}\n";
         }
         // The same gathers as ONE table for lanes that belong to different drives (pcl_kernel_hess_cols.hpp): entry [drive][half][row][term]
-        // = (source row of the w column, 0 .. n-1) << 8 | coefficient index (0: none; 1 + 2 g: +mags[g]; 2 + 2 g: -mags[g]), the half's sign
+        // = (source row of the w column, 0 .. n-1) << 4 | coefficient index (0: none; 1 + 2 g: +mags[g]; 2 + 2 g: -mags[g]), the half's sign
         // of the B entries folded in (sb = +1 in half 0, -1 in half 1); SP4_GTK terms per row.
         if (P.m > 0) {
             std::vector<std::vector<unsigned>> rows((size_t)P.m * 2 * d);
@@ -565,17 +565,27 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
                                 if (e.col == i && e.isB == (pass == 1)) {
                                     const bool neg = e.neg != (e.isB && hf == 1);
                                     const unsigned src = (unsigned)((e.isB ? 1 - hf : hf) * d + e.row);
-                                    r.push_back(src << 8 | (unsigned)(1 + 2 * e.mag + (neg ? 1 : 0)));
+                                    r.push_back(src << 4 | (unsigned)(1 + 2 * e.mag + (neg ? 1 : 0)));
                                 }
                         gtk = std::max(gtk, r.size());
                     }
-            snprintf(buf, sizeof buf, "#define SP4_GTK %zu\nstatic __device__ const unsigned short sp4_gt_tab[%zu] = {", gtk, rows.size() * gtk);
+            // three 10-bit entries per dword, a whole number of dwords per (drive, half)
+            const size_t wpc = ((size_t)d * gtk + 2) / 3;
+            snprintf(buf, sizeof buf, "#define SP4_GTK %zu\nstatic __device__ const unsigned sp4_gt_tab[%zu] = {", gtk, (size_t)P.m * 2 * wpc);
             s += buf;
-            for (size_t r = 0; r < rows.size(); ++r)
-                for (size_t k = 0; k < gtk; ++k) {
-                    snprintf(buf, sizeof buf, "%s%u", (r || k) ? "," : "", k < rows[r].size() ? rows[r][k] : 0u);
+            for (size_t cls = 0; cls < (size_t)P.m * 2; ++cls) {
+                std::vector<unsigned> words(wpc, 0u);
+                for (int i = 0; i < d; ++i)
+                    for (size_t k = 0; k < gtk; ++k) {
+                        const std::vector<unsigned> &r = rows[cls * d + i];
+                        const size_t en = (size_t)i * gtk + k;
+                        words[en / 3] |= (k < r.size() ? r[k] : 0u) << (10 * (en % 3));
+                    }
+                for (size_t w = 0; w < wpc; ++w) {
+                    snprintf(buf, sizeof buf, "%s%uu", (cls || w) ? "," : "", words[w]);
                     s += buf;
                 }
+            }
             s += "};\n";
         }
         s += "#define SP4_GATHER_T_SWITCH(l, Wo, Wx, X, hs, sb, mg) switch (l) {";

@@ -10,8 +10,8 @@
 // the waves of an interval in lock step behind two workgroup barriers per level -- 93 k cycles per interval at order 8 where the multiply-adds
 // need 14 k.  Here a wave takes ALL m + 1 chains of HC_CPW = 32 / (m + 1) state columns:
 //     lane = (half, chain, column):  half = lane / 32 (top / bottom rows, as in the products), slot = lane % 32 = chain * HC_CPW + column
-// and is a workgroup of its own: no barrier, no other wave's data, its LDS (chain slots, D, S, R_1 .. R_{q-1} of its columns: 21 KB at order 8)
-// lets seven of them share a CU, each at its own place in its own interval -- what one waits for, another computes.  The products are the
+// and is a workgroup of its own: no barrier, no other wave's data, its LDS (chain slots, D, S, R_1 .. R_{q-2} of its columns: 20.4 KB at order 8)
+// lets eight of them share a CU, each at its own place in its own interval -- what one waits for, another computes.  The products are the
 // generated sp4_product0_t / sp4_product unchanged (a lane's LDS offsets are operands).
 // What the layout costs: the drives' gathers G_l^T W come from an entry table (the lanes of a wave belong to different drives), the chain of the
 // R_a uses HC_CPW of the 32 slots, and level 1 runs the product for the W lanes only (7 q + 7 (q - 2) product passes per interval instead of
@@ -30,16 +30,19 @@
 #define HC_CPW (32 / HC_NCH)                  // state columns per wave
 #define HC_NG ((SPD + HC_CPW - 1) / HC_CPW)   // waves per interval
 #define HC_NSLOT (HC_NCH * HC_CPW)
-#define HC_NR (SP4Q > 1 ? SP4Q - 1 : 0)       // R_1 .. R_{q-1}
+#define HC_NR (SP4Q > 2 ? SP4Q - 2 : 0)       // stored: R_1 .. R_{q-2}  (R_{q-1} = +-T_q |Y_q| is the D or the S tile times a number)
 #define HC_NT ((HC_CPW * SPN + 63) / 64)      // passes of the flat (lane = element) copies of a wave's HC_CPW contiguous columns
 #define HC_ROW (SPM + 1)                      // reduced sums per chain: <chain, Y>, row of (u,u)
 #define HC_XS (HC_NCH * HC_ROW)               // ... per wave
 #define HC_NSC ((SPM + 1) * (SPM + 2) / 2)
 #define HC_GCH 5                                                        // rows per batch of the table-driven gathers
 #define HC_NCFT 24                                                      // coefficient table of the gathers: 0, +-mags[g]
-#define HC_GT_DOUBLES ((SPM * 2 * SPD * SP4_GTK * 2 + 7) / 8)            // the gathers' entry table (sp4_gt_tab), unsigned short
-#define HC_LDS_DOUBLES ((HC_NSLOT + (2 + HC_NR) * HC_CPW) * SP4CS + 32 + HC_NCFT + HC_GT_DOUBLES)
-static_assert(1 + 2 * SP4NMAG <= HC_NCFT, "coefficient table of the gathers");
+#define HC_GT_WPC ((SPD * SP4_GTK + 2) / 3)                             // the gathers' entry table (sp4_gt_tab): three 10-bit entries per dword, per (drive, half)
+#define HC_GT_DOUBLES ((SPM * 2 * HC_GT_WPC + 1) / 2)
+// 20,416 bytes at config 3, order 8: EIGHT of these workgroups share a CU's 160 KB (22.9 KB with R_{q-1} stored, a strip of zeros for the W lanes'
+// Y term and 16-bit entries: seven; 64 trajectories per launch 807 -> 784 us)
+#define HC_LDS_DOUBLES ((HC_NSLOT + (2 + HC_NR) * HC_CPW) * SP4CS + HC_NCFT + HC_GT_DOUBLES)
+static_assert(1 + 2 * SP4NMAG <= 16 && 16 <= HC_NCFT && SPN <= 64, "10-bit entries of the gathers' table: source row (6 bits), coefficient index (4 bits)");
 static_assert(HC_CPW >= 1 && SPM >= 1, "chains per column");
 static_assert(HC_XS <= 64 && HC_ROW <= SPD, "one lane per reduced sum");
 
@@ -59,8 +62,8 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     extern __shared__ double lds[];
     constexpr int d = SPD, n = SPN, m = SPM, q = SP4Q;
     constexpr int CB = HC_CPW * SP4CS;  // doubles per block of HC_CPW columns
-    double *slots = lds, *Dt = slots + HC_NSLOT * SP4CS, *St = Dt + CB, *Rt = St + CB, *zero = Rt + HC_NR * CB, *cft = zero + 32;
-    unsigned short *gtab = (unsigned short *)(cft + HC_NCFT);
+    double *slots = lds, *Dt = slots + HC_NSLOT * SP4CS, *St = Dt + CB, *Rt = St + CB, *cft = Rt + HC_NR * CB;
+    unsigned *gtab = (unsigned *)(cft + HC_NCFT);
     const long long xd = (long long)n * d;
     const int item = blockIdx.x / HC_NG, grp = blockIdx.x - item * HC_NG;
     const int k = item % p.K, b = item / p.K;
@@ -102,10 +105,10 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         const int e = ln_ + 64 * t < ne ? ln_ + 64 * t : 0;
         xc_[t] = zk[e], xn_[t] = zn[e], mv_[t] = mu[e];
     }
-    constexpr int GTW = (SPM * 2 * SPD * SP4_GTK + 1) / 2;  // the gathers' entry table, in dwords
+    constexpr int GTW = SPM * 2 * HC_GT_WPC;  // the gathers' entry table, in dwords
     unsigned gw_[(GTW + 63) / 64];
 #pragma unroll
-    for (int t = 0; t < (GTW + 63) / 64; ++t) gw_[t] = ((const unsigned *)sp4_gt_tab)[ln_ + 64 * t < GTW ? ln_ + 64 * t : 0];
+    for (int t = 0; t < (GTW + 63) / 64; ++t) gw_[t] = sp4_gt_tab[ln_ + 64 * t < GTW ? ln_ + 64 * t : 0];
     // scalars of the interval
     sp_cptr zc = (sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim);
     double u[SPM];
@@ -131,11 +134,10 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
 
     // ---- inputs, second half: M -> the W slots, D, S, R_{q-1}; the tables of the gathers --------------------------------------------------
     {
-        if (ln_ < 32) zero[ln_] = 0.0;
         if (ln_ < 1 + 2 * SP4NMAG) cft[ln_] = ln_ == 0 ? 0.0 : ((ln_ & 1) ? magc[(ln_ - 1) >> 1] : -magc[(ln_ - 2) >> 1]);
 #pragma unroll
         for (int t = 0; t < (GTW + 63) / 64; ++t)
-            if (ln_ + 64 * t < GTW) ((unsigned *)gtab)[ln_ + 64 * t] = gw_[t];
+            if (ln_ + 64 * t < GTW) gtab[ln_ + 64 * t] = gw_[t];
 #pragma unroll
         for (int t = 0; t < HC_NT; ++t) {
             const int e = ln_ + 64 * t;
@@ -145,7 +147,6 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
                 slots[o] = mv_[t];
                 Dt[o] = dv;
                 St[o] = sv;
-                if constexpr (q > 1) Rt[(q - 2) * CB + o] = wgt(q) * ((q & 1) ? sv : dv);  // R_{q-1}
             }
         }
     }
@@ -159,10 +160,17 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
 #pragma unroll 1
         for (int a = q - 2; a >= 1; --a) {
             if (ract) {
-                const double *src = Rt + a * CB + rb + own;  // R_{a+1}
-                double x[SPD];
+                double x[SPD];  // R_{a+1}
+                if (a == q - 2) {  // R_{q-1} = +-T_q |Y_q|
+                    const double *src = ((q & 1) ? St : Dt) + rb + own;
+                    const double wq = wgt(q);
 #pragma unroll
-                for (int i = 0; i < SPD; ++i) x[i] = src[i];
+                    for (int i = 0; i < SPD; ++i) x[i] = wq * src[i];
+                } else {
+                    const double *src = Rt + a * CB + rb + own;
+#pragma unroll
+                    for (int i = 0; i < SPD; ++i) x[i] = src[i];
+                }
                 double *dst = Rt + (a - 1) * CB + rb;
                 const double *Y = (((a + 1) & 1) ? St : Dt) + rb + own;
                 sp4_product(x, hc_lds_off(Y), hc_lds_off(dst + own), hc_lds_off(dst + oth), sp4_uniform(wgt_at(a + 1)), 1.0, half ? -1.0 : 1.0, tab, cf);
@@ -213,21 +221,24 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
             // the lanes of a wave belong to different drives: the entries come from the table (one instruction stream for every drive).
             // HC_GCH rows at a time, staged by hand -- every entry of the batch, then every operand, then the sums: left to itself the
             // compiler keeps two or three rows in flight and the wave waits out an LDS round trip per row (6.3 k cycles per level)
-            const unsigned short *gt = gtab + ((ch - 1) * 2 + half) * (SPD * SP4_GTK);
+            const unsigned *gt = gtab + ((ch - 1) * 2 + half) * HC_GT_WPC;
 #pragma unroll
             for (int i0 = 0; i0 < SPD; i0 += HC_GCH) {
                 unsigned e_[HC_GCH][SP4_GTK];
 #pragma unroll
                 for (int i = 0; i < HC_GCH; ++i)
 #pragma unroll
-                    for (int kk = 0; kk < SP4_GTK; ++kk) e_[i][kk] = gt[(i0 + i < SPD ? i0 + i : SPD - 1) * SP4_GTK + kk];
+                    for (int kk = 0; kk < SP4_GTK; ++kk) {
+                        const int en = (i0 + i < SPD ? i0 + i : SPD - 1) * SP4_GTK + kk;  // entry number: word en / 3, bits 10 (en % 3) ...
+                        e_[i][kk] = (gt[en / 3] >> (10 * (en % 3))) & 1023u;
+                    }
                 double w_[HC_GCH][SP4_GTK], c_[HC_GCH][SP4_GTK];
 #pragma unroll
                 for (int i = 0; i < HC_GCH; ++i)
 #pragma unroll
                     for (int kk = 0; kk < SP4_GTK; ++kk) {
-                        w_[i][kk] = Wc[e_[i][kk] >> 8];
-                        c_[i][kk] = cft[e_[i][kk] & 255u];
+                        w_[i][kk] = Wc[e_[i][kk] >> 4];
+                        c_[i][kk] = cft[e_[i][kk] & 15u];
                     }
                 asm volatile("" ::: "memory");
 #pragma unroll
@@ -274,11 +285,13 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
             } else {
                 s_y = __builtin_fma(T1, dy, s_y);
                 if (jp < q) {  // (u,u): <V_{l,j}, G_i R_j>, every drive i
-                    const double *Rj = Rt + (jp - 1) * CB + cb;
+                    // R_jp; the top one is +-T_q |Y_q|: the D or the S tile, the number applied to the sums
+                    const double *Rj = (jp == q - 1 ? ((q & 1) ? St : Dt) : Rt + (jp - 1) * CB) + cb;
+                    const double wr = jp == q - 1 ? wgt(q) : 1.0;
                     double r6[SPM];
                     sp4_gdot_all(Rj + own, Rj + oth, x, (half ? 1.0 : -1.0), mg, r6);
 #pragma unroll
-                    for (int i = 0; i < SPM; ++i) s_uu[i] += r6[i];
+                    for (int i = 0; i < SPM; ++i) s_uu[i] = __builtin_fma(wr, r6[i], s_uu[i]);
                 }
             }
         }

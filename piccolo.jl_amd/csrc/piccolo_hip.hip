@@ -1001,7 +1001,7 @@ std::string v4_hess_cols_source(const pcl_codegen::V4Plan &plan, int q, int vari
 }
 static size_t hess_cols_lds_bytes(int d, int m, int q, int gtk) {  // HC_LDS_DOUBLES of the kernel
     const int cpw = 32 / (m + 1);
-    return ((size_t)((m + 1) * cpw + (2 + (q > 1 ? q - 1 : 0)) * cpw) * (2 * d + 1) + 32 + 24 + ((size_t)m * 2 * d * gtk * 2 + 7) / 8) * sizeof(double);
+    return ((size_t)((m + 1) * cpw + (2 + (q > 2 ? q - 2 : 0)) * cpw) * (2 * d + 1) + 24 + ((size_t)m * 2 * (((size_t)d * gtk + 2) / 3) + 1) / 2) * sizeof(double);
 }
 }  // namespace
 
