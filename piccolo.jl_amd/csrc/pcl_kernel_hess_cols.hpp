@@ -199,7 +199,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     double s_y = 0.0, s_uu[SPM];
 #pragma unroll
     for (int i = 0; i < SPM; ++i) s_uu[i] = 0.0;
-    double hpV = 1.0, hpW = 1.0;  // h^(level - 1) of the V lanes' and of the W lanes' level
+    double hpV = 1.0, hpW = 1.0, hpW2 = 1.0;  // h^(level - 1) of the V lanes' and of the W lanes' level; h^(level - 2) of the W lanes'
 #pragma unroll 1
     for (int jp = 1; jp <= q + 1; ++jp) {
         const bool on = act && (isV ? jp <= q : jp >= 2);  // lanes with a level in this pass
@@ -266,22 +266,25 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
             asm volatile("" ::: "memory");
             const double *Yj = ((jl & 1) ? St : Dt) + cb + own;  // Y_j = D (j even) | -S (j odd)
             double dot0 = 0.0, dot1 = 0.0;
-            {
-                double y[SPD];  // (one LDS round trip; the additions in the order of pcl_hess_sparse4_kernel)
 #pragma unroll
-                for (int i = 0; i < SPD; ++i) y[i] = Yj[i];
+            for (int i0 = 0; i0 < SPD; i0 += 9) {  // (nine rows at a time: the whole column next to x and the output vectors spills the scalar sums)
+                double y[9];
 #pragma unroll
-                for (int i = 0; i < SPD; ++i) {
-                    if ((i % 9) & 1)
-                        dot1 = __builtin_fma(x[i], y[i], dot1);
-                    else
-                        dot0 = __builtin_fma(x[i], y[i], dot0);
-                }
+                for (int i = 0; i < 9; ++i)
+                    if (i0 + i < SPD) y[i] = Yj[i0 + i];
+#pragma unroll
+                for (int i = 0; i < 9; ++i)
+                    if (i0 + i < SPD) {
+                        if (i & 1)
+                            dot1 = __builtin_fma(x[i0 + i], y[i], dot1);
+                        else
+                            dot0 = __builtin_fma(x[i0 + i], y[i], dot0);
+                    }
                 asm volatile("" ::: "memory");
             }
             const double dy = sg * (dot0 + dot1);  // <chain_j, Y_j>
             if (!isV) {
-                if (jl >= 2) s_y = __builtin_fma(jl * (jl - 1) * cj * (hp / h), dy, s_y);  // T''_j = j (j-1) c_j h^(j-2)
+                if (jl >= 2) s_y = __builtin_fma(jl * (jl - 1) * cj * hpW2, dy, s_y);  // T''_j = j (j-1) c_j h^(j-2)
             } else {
                 s_y = __builtin_fma(T1, dy, s_y);
                 if (jp < q) {  // (u,u): <V_{l,j}, G_i R_j>, every drive i
@@ -295,6 +298,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
                 }
             }
         }
+        hpW2 = hpW;
         hpW = hpV;
         hpV *= h;
         HC_STAMP();
