@@ -399,14 +399,27 @@ def main():
             do_ = torch.empty(co.n_rows, dtype=torch.float64, device="cuda")
             muo = torch.randn(co.n_rows, dtype=torch.float64, device="cuda")
             ho = torch.empty(co.hess_nnz, dtype=torch.float64, device="cuda")
-            wh, dh = time_steps(lambda: co.hess_dev(Zo, muo, ho), 20, 3, torch, None)
+            wh, dh = time_steps(lambda: co.hess_dev(Zo, muo, ho), 20, 30, torch, None)  # (30 untimed launches: the context was just created, the clocks are down)
             we, de_ = time_steps(lambda: co.eval_dev(Zo, do_), st, 5, torch, None)
             hko, eko = co.get_option("last_hess_kernel"), co.get_option("last_kernel")
             mso.close()
             del Zo, do_, muo, ho
+            h64 = None
+            if order == 8:  # the same Hessian with 64 trajectories per launch (config 5 whole: every round of waves full)
+                ms64 = pa.HipPadeMultistart(G0, Gj, t0, 64, device=local, pade_order=order)
+                c64 = ms64.ctx
+                c64.set_stream(stream.cuda_stream)
+                Z64 = torch.from_numpy(np.stack([synthetic.synthetic_trajectory(system, N, seed=1000 + i).datavec for i in range(64)])).cuda()
+                mu64 = torch.randn(c64.n_rows, dtype=torch.float64, device="cuda")
+                hv64 = torch.empty(c64.hess_nnz, dtype=torch.float64, device="cuda")
+                _, dh64 = time_steps(lambda: c64.hess_dev(Z64, mu64, hv64), 10, 10, torch, None)
+                h64 = {"us_per_eval_kernel": dh64 / 10 / 64 * 1e6, "batch": 64, "kernel_id": c64.get_option("last_hess_kernel")}
+                ms64.close()
+                del Z64, mu64, hv64
             ex["order%d" % order] = {"hessian_of_lagrangian": {"us_per_eval_kernel": dh / 20 / B * 1e6, "batch": B, "kernel_id": hko,
                                                                "kernel": "pcl_hess_cols_kernel (pattern-compiled, any order: one wave per group of state columns)" if hko // 10 == 8 else
                                                                          "pcl_hess_sparse4_kernel (pattern-compiled, any order)" if hko // 10 == 7 else "general-order kernel"},
+                                     **({"hessian_of_lagrangian_64": h64} if h64 else {}),
                                      "residual_only": {"us_per_eval_kernel": de_ / st / B * 1e6, "batch": B, "kernel_id": eko},
                                      "single": {"evals_per_s": st / w1, "us_per_launch_kernel": d1 / st * 1e6, "frac_of_hbm_peak": abytes / (d1 / st) / 1e9 / HBM_PEAK_GBS,
                                                 "kernel_id": i1["kernel_id"]},
