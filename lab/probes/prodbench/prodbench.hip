@@ -1,11 +1,14 @@
 // Micro-benchmark of the generated product G(u)^T x (config 3, order 8 module: gen_cfg3_q4.inc = the generated functions of
 // pcl_codegen_source_v4(what = 1) without their includes): cycles per call for ONE wave per CU / per SIMD, 1 .. 4 waves per SIMD.
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -o prodbench prodbench.hip && ./prodbench
+// python make_inc.py && hipcc --offload-arch=gfx950 -O3 -std=c++17 -o prodbench prodbench.hip && ./prodbench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#include "gen_cfg3_q4.inc"
+#ifndef PRODBENCH_INC
+#define PRODBENCH_INC "gen_cfg3_q4.inc"  // (make_inc.py writes it; -DPRODBENCH_INC='"gen_noadd.inc"': without the products' ds_add_f64)
+#endif
+#include PRODBENCH_INC
 #define CS (SPN + 1)
 template <int MODE>
 __global__ void bench(const double *mags_, const double *dcf_tab, const double *u_, long long *out, int reps) {
