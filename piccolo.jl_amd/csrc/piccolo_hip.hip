@@ -706,414 +706,7 @@ extern "C" int pcl_hess_structure_i64(const pcl_ctx *ctx, int64_t *rows, int64_t
     return hess_structure_impl<int64_t>(ctx, rows, cols);
 }
 
-// --- run-time shape specialisation (hiprtc) -----------------------------------------------------------------------
-// The wave-synchronous kernels are 1.3-3x faster with compile-time Hilbert dimension / drive count (constant LDS strides,
-// no SGPR spills).  A few shapes are instantiated statically; any other shape is compiled on first use from the kernel
-// headers that sit next to this library (pcl_*.hpp, located with dladdr) -- about 1.5 s, cached for the process.
-// libhiprtc is opened lazily; when it or the headers are missing the run-time-shape instances are used (same results).
-#include <chrono>
-#include <functional>
-#include <map>
-#include <mutex>
-namespace {
-struct JitKernel {
-    hipModule_t mod = nullptr;
-    hipFunction_t fn = nullptr;
-    bool failed = false;
-};
-struct HiprtcApi {
-    void *h = nullptr;
-    int (*CreateProgram)(void **, const char *, const char *, int, const char **, const char **) = nullptr;
-    int (*AddNameExpression)(void *, const char *) = nullptr;
-    int (*CompileProgram)(void *, int, const char **) = nullptr;
-    int (*GetLoweredName)(void *, const char *, const char **) = nullptr;
-    int (*GetCodeSize)(void *, size_t *) = nullptr;
-    int (*GetCode)(void *, char *) = nullptr;
-    int (*GetProgramLogSize)(void *, size_t *) = nullptr;
-    int (*GetProgramLog)(void *, char *) = nullptr;
-    int (*DestroyProgram)(void **) = nullptr;
-    int (*Version)(int *, int *) = nullptr;
-};
-std::mutex g_jit_mutex;
-std::map<std::string, JitKernel> g_jit;  // key: device | template instance
-HiprtcApi g_rtc;
-int64_t g_jit_compiles = 0, g_jit_cache_hits = 0, g_jit_fallbacks = 0;
-std::string g_jit_note;
-
-// ---- persistent code objects --------------------------------------------------------------------------------------------------
-// A compiled module is kept on disk under the hash of everything it was compiled from (generated source, the kernel headers it
-// includes, the compiler options, the hiprtc version): <library dir>/prebuilt/<hash>.hsaco (written by pcl_jit_prebuild -- what
-// __graft_entry__.build() fills for the BASELINE configs; travels with the library) is looked at first, then the user's cache
-// ($PCL_JIT_CACHE_DIR, else $XDG_CACHE_HOME/piccolo_hip, else ~/.cache/piccolo_hip), which every run-time compilation also writes
-// (temporary file + rename: ranks of one job may compile the same module at the same time).  PCL_JIT_CACHE=0 switches both off.
-struct Hash128 {
-    uint64_t a = 0xcbf29ce484222325ull, b = 0x84222325cbf29ce4ull;
-    void add(const void *p_, size_t n) {
-        const unsigned char *p = (const unsigned char *)p_;
-        for (size_t i = 0; i < n; ++i) {
-            a = (a ^ p[i]) * 0x100000001b3ull;
-            b = (b ^ p[i]) * 0x9e3779b97f4a7c15ull + (b >> 29);
-        }
-    }
-    void add(const std::string &x) {
-        add(x.data(), x.size());
-        const unsigned char z = 0;
-        add(&z, 1);
-    }
-    std::string hex() const {
-        char buf[40];
-        snprintf(buf, sizeof buf, "%016llx%016llx", (unsigned long long)a, (unsigned long long)b);
-        return buf;
-    }
-};
-bool cache_enabled() {
-    const char *e = getenv("PCL_JIT_CACHE");
-    return !(e && e[0] == '0');
-}
-std::string user_cache_dir() {
-    if (const char *e = getenv("PCL_JIT_CACHE_DIR")) return e;
-    if (const char *x = getenv("XDG_CACHE_HOME"))
-        if (x[0]) return std::string(x) + "/piccolo_hip";
-    if (const char *h = getenv("HOME"))
-        if (h[0]) return std::string(h) + "/.cache/piccolo_hip";
-    return "/tmp/piccolo_hip_cache";
-}
-bool read_file(const std::string &path, std::vector<char> &out) {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    out.clear();
-    char buf[65536];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.insert(out.end(), buf, buf + n);
-    fclose(f);
-    return !out.empty();
-}
-void mkdir_p(const std::string &dir);
-bool write_file_atomic(const std::string &dir, const std::string &name, const std::vector<char> &data) {
-    mkdir_p(dir);
-    char tmpl[64];
-    snprintf(tmpl, sizeof tmpl, ".tmp.%ld.%p", (long)getpid(), (const void *)&data);
-    const std::string tmp = dir + "/" + name + tmpl, fin = dir + "/" + name;
-    FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f) return false;
-    const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
-    fclose(f);
-    if (!ok || rename(tmp.c_str(), fin.c_str()) != 0) {
-        remove(tmp.c_str());
-        return false;
-    }
-    return true;
-}
-
-bool rtc_load() {
-    if (g_rtc.h) return true;
-    void *h = dlopen("libhiprtc.so", RTLD_NOW | RTLD_LOCAL);
-    if (!h) h = dlopen("libhiprtc.so.7", RTLD_NOW | RTLD_LOCAL);
-    if (!h) {
-        g_jit_note = std::string("dlopen(libhiprtc.so): ") + dlerror();
-        return false;
-    }
-    HiprtcApi a;
-    a.h = h;
-#define RTC_SYM(field, name) a.field = (decltype(a.field))dlsym(h, name)
-    RTC_SYM(CreateProgram, "hiprtcCreateProgram");
-    RTC_SYM(AddNameExpression, "hiprtcAddNameExpression");
-    RTC_SYM(CompileProgram, "hiprtcCompileProgram");
-    RTC_SYM(GetLoweredName, "hiprtcGetLoweredName");
-    RTC_SYM(GetCodeSize, "hiprtcGetCodeSize");
-    RTC_SYM(GetCode, "hiprtcGetCode");
-    RTC_SYM(GetProgramLogSize, "hiprtcGetProgramLogSize");
-    RTC_SYM(GetProgramLog, "hiprtcGetProgramLog");
-    RTC_SYM(DestroyProgram, "hiprtcDestroyProgram");
-    RTC_SYM(Version, "hiprtcVersion");
-#undef RTC_SYM
-    if (!a.CreateProgram || !a.AddNameExpression || !a.CompileProgram || !a.GetLoweredName || !a.GetCodeSize || !a.GetCode || !a.DestroyProgram) {
-        g_jit_note = "libhiprtc lacks the expected symbols";
-        return false;
-    }
-    g_rtc = a;
-    return true;
-}
-
-bool slurp(const std::string &path, std::string &out) {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    char buf[65536];
-    size_t n;
-    out.clear();
-    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
-    fclose(f);
-    return !out.empty();
-}
-
-
-void mkdir_p(const std::string &dir) {
-    for (size_t i = 1; i <= dir.size(); ++i)
-        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0777);
-}
-#ifdef PCL_PROFILE
-static const char *const kJitOpts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-DPCL_PROFILE"};
-#else
-static const char *const kJitOpts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-#endif
-std::string jit_cache_key(const std::string &source, const std::string *hdr, int nh, const char *name_expr) {
-    Hash128 h;
-    h.add(std::string("pcl-jit-1"));
-    h.add(source);
-    for (int i = 0; i < nh; ++i) h.add(hdr[i]);
-    for (const char *o : kJitOpts) h.add(std::string(o));
-    h.add(std::string(name_expr ? name_expr : ""));
-    int ver = 0;
-    (void)hipRuntimeGetVersion(&ver);  // the ROCm release (hiprtc ships with it); asked of the runtime that is loaded anyway -- a cache hit never opens libhiprtc
-    h.add(std::to_string(ver));
-    return h.hex();
-}
-// on disk: "PCLJ" | uint32 length of the kernel's (lowered) name | name | code object
-std::vector<char> pack_module(const std::vector<char> &code, const std::string &lname) {
-    std::vector<char> out;
-    const uint32_t n = (uint32_t)lname.size();
-    out.insert(out.end(), {'P', 'C', 'L', 'J'});
-    out.insert(out.end(), (const char *)&n, (const char *)&n + 4);
-    out.insert(out.end(), lname.begin(), lname.end());
-    out.insert(out.end(), code.begin(), code.end());
-    return out;
-}
-bool unpack_module(const std::vector<char> &blob, std::vector<char> &code, std::string &lname, bool plain_name) {
-    if (blob.size() < 8 || memcmp(blob.data(), "PCLJ", 4) != 0) return false;
-    uint32_t n;
-    memcpy(&n, blob.data() + 4, 4);
-    if (blob.size() < 8 + (size_t)n + 16) return false;
-    if (!plain_name) lname.assign(blob.data() + 8, n);
-    code.assign(blob.begin() + 8 + n, blob.end());
-    return true;
-}
-bool rtc_compile(const std::string &source, const char **hdrp, const char *const *names, int nh, const char *name_expr, bool plain_name, const std::string &what,
-                 std::vector<char> &code, std::string &lname) {
-    void *prog = nullptr;
-    if (g_rtc.CreateProgram(&prog, source.c_str(), "pcl_jit.hip", nh, hdrp, (const char **)names) != 0) {
-        g_jit_note = "hiprtcCreateProgram failed";
-        return false;
-    }
-    if (!plain_name) g_rtc.AddNameExpression(prog, name_expr);
-    if (g_rtc.CompileProgram(prog, (int)(sizeof kJitOpts / sizeof kJitOpts[0]), (const char **)kJitOpts) != 0) {
-        size_t ls = 0;
-        g_jit_note = std::string("hiprtcCompileProgram failed for ") + what;
-        if (g_rtc.GetProgramLogSize && g_rtc.GetProgramLog && g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
-            std::string log(ls, '\0');
-            g_rtc.GetProgramLog(prog, &log[0]);
-            g_jit_note += ": " + log.substr(0, 400);
-        }
-        g_rtc.DestroyProgram(&prog);
-        return false;
-    }
-    const char *lowered = nullptr;
-    size_t cs = 0;
-    if (!plain_name) g_rtc.GetLoweredName(prog, name_expr, &lowered);
-    g_rtc.GetCodeSize(prog, &cs);
-    code.resize(cs);
-    g_rtc.GetCode(prog, code.data());
-    lname = plain_name ? std::string(name_expr) : (lowered ? lowered : "");
-    g_rtc.DestroyProgram(&prog);
-    return !lname.empty() && cs > 0;
-}
-
-// Compile (once per process, device and key) `source` against the kernel headers next to the library and return the kernel
-// `name_expr` names (a template instance such as "pcl_hess_kernel_v2<2, 4, 24, true>", or an extern "C" kernel of the source).
-hipFunction_t jit_compile(int device, const std::string &key_, const std::string &source, const char *name_expr, bool plain_name) {
-    const std::string key = std::to_string(device) + "|" + key_;
-    std::lock_guard<std::mutex> lock(g_jit_mutex);
-    auto it = g_jit.find(key);
-    if (it != g_jit.end()) {
-        if (it->second.failed) return nullptr;
-        if (!plain_name) return it->second.fn;
-        hipFunction_t f = nullptr;  // several kernels of one generated module
-        return hipModuleGetFunction(&f, it->second.mod, name_expr) == hipSuccess ? f : nullptr;
-    }
-    JitKernel &jk = g_jit[key];
-    jk.failed = true;
-    Dl_info info;
-    if (!dladdr((const void *)&pcl_version, &info) || !info.dli_fname) {
-        g_jit_note = "dladdr failed";
-        return nullptr;
-    }
-    std::string dir(info.dli_fname);
-    const size_t slash = dir.find_last_of('/');
-    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
-    const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp",
-                           "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp", "pcl_kernel_eval_sparse.hpp",
-                           "pcl_kernel_fused_sparse.hpp", "pcl_kernel_hess_sparse4.hpp", "pcl_kernel_hess_cols.hpp"};
-    constexpr int NH = 10;
-    std::string hdr[NH];
-    const char *hdrp[NH];
-    for (int i = 0; i < NH; ++i) {
-        if (!slurp(dir + "/" + names[i], hdr[i])) {
-            g_jit_note = "kernel header not found next to the library: " + dir + "/" + names[i];
-            return nullptr;
-        }
-        hdrp[i] = hdr[i].c_str();
-    }
-    std::vector<char> code;
-    std::string lname = plain_name ? std::string(name_expr) : std::string();
-    const std::string ckey = jit_cache_key(source, hdr, NH, plain_name ? "" : name_expr);
-    bool from_cache = false;
-    if (cache_enabled()) {
-        std::vector<char> blob;
-        if (read_file(dir + "/prebuilt/" + ckey + ".hsaco", blob) || read_file(user_cache_dir() + "/" + ckey + ".hsaco", blob)) from_cache = unpack_module(blob, code, lname, plain_name);
-    }
-    if (!from_cache) {
-        if (!rtc_load()) return nullptr;
-        if (!rtc_compile(source, hdrp, names, NH, name_expr, plain_name, key_, code, lname)) return nullptr;
-        if (cache_enabled()) (void)write_file_atomic(user_cache_dir(), ckey + ".hsaco", pack_module(code, lname));
-    }
-    if (lname.empty() || hipModuleLoadData(&jk.mod, code.data()) != hipSuccess || hipModuleGetFunction(&jk.fn, jk.mod, lname.c_str()) != hipSuccess) {
-        g_jit_note = "hipModuleLoadData / hipModuleGetFunction failed";
-        return nullptr;
-    }
-    jk.failed = false;
-    if (from_cache)
-        ++g_jit_cache_hits;
-    else
-        ++g_jit_compiles;
-    return jk.fn;
-}
-hipFunction_t jit_function(int device, const char *instance) {
-    static const std::string src = "#include \"pcl_device_common.hpp\"\n#include \"pcl_kernels_fused_v2.hpp\"\n#include \"pcl_kernel_fused_v3.hpp\"\n"
-                                   "#include \"pcl_kernels_hessian.hpp\"\n#include \"pcl_kernel_hessian_v3.hpp\"\n";
-    return jit_compile(device, instance, src, instance, false);
-}
-// Source of the pattern-compiled kernels of one system (pcl_codegen.hpp)
-std::string sparse_source(const pcl_codegen::SpPlan &plan) {
-    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::apply_functions(plan) + "#include \"pcl_kernel_hessian_sparse.hpp\"\n#include \"pcl_kernel_eval_sparse.hpp\"\n";
-}
-// Source of the pattern-compiled fused residual + Jacobian kernel of one system at Pade order 2q (pcl_codegen_v4.hpp)
-// (np: tiles of the powers of G -- v4_power_tiles)
-std::string v4_source(const pcl_codegen::V4Plan &plan, int q, int np, int variant = 0, int tickets = 0) {
-    return std::string("#include \"pcl_device_common.hpp\"\n#define SP4_TICKETS ") + (tickets ? "1\n" : "0\n") + pcl_codegen::v4_functions(plan, q, np, variant) + "#include \"pcl_kernel_fused_sparse.hpp\"\n";
-}
-
-// ... and of the Hessian-of-the-Lagrangian kernel of the same family (pcl_kernel_hess_sparse4.hpp; any order)
-std::string v4_hess_source(const pcl_codegen::V4Plan &plan, int q, int variant = 0, int split = 1) {  // variant (profile builds): SH_VARIANT of the kernel (bits >= 16), bit 8: the gather-dot reads nine columns at a time
-    return "#include \"pcl_device_common.hpp\"\n#define SH_VARIANT " + std::to_string(variant) + "\n#define SH_SPLIT " + std::to_string(split) + "\n" + pcl_codegen::v4_functions(plan, q, 1, variant & 8, true) + "#include \"pcl_kernel_hess_sparse4.hpp\"\n";
-}
-// ... one wave per group of state columns (pcl_kernel_hess_cols.hpp; any order)
-std::string v4_hess_cols_source(const pcl_codegen::V4Plan &plan, int q, int variant = 0) {
-    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q, 1, (variant & 7) | 8, true) + "#include \"pcl_kernel_hess_cols.hpp\"\n";
-}
-static size_t hess_cols_lds_bytes(int d, int m, int q, int gtk) {  // HC_LDS_DOUBLES of the kernel
-    const int cpw = 32 / (m + 1);
-    return ((size_t)((m + 1) * cpw + (2 + (q > 2 ? q - 2 : 0)) * cpw) * (2 * d + 1) + 24 + ((size_t)m * 2 * (((size_t)d * gtk + 2) / 3) + 1) / 2) * sizeof(double);
-}
-}  // namespace
-
-// Compile `source` (a generated module) with hiprtc and leave the code object in `out_dir` under its content hash: no device needed.
-static int prebuild_source(const std::string &source, const char *name_expr, const char *out_dir, std::string &err) {
-    std::lock_guard<std::mutex> lock(g_jit_mutex);
-    Dl_info info;
-    if (!dladdr((const void *)&pcl_version, &info) || !info.dli_fname) {
-        err = "dladdr failed";
-        return PCL_EHIP;
-    }
-    std::string dir(info.dli_fname);
-    const size_t slash = dir.find_last_of('/');
-    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
-    const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp",
-                           "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp", "pcl_kernel_eval_sparse.hpp",
-                           "pcl_kernel_fused_sparse.hpp", "pcl_kernel_hess_sparse4.hpp", "pcl_kernel_hess_cols.hpp"};
-    constexpr int NH = 10;
-    std::string hdr[NH];
-    const char *hdrp[NH];
-    for (int i = 0; i < NH; ++i) {
-        if (!slurp(dir + "/" + names[i], hdr[i])) {
-            err = "kernel header not found next to the library: " + dir + "/" + names[i];
-            return PCL_EHIP;
-        }
-        hdrp[i] = hdr[i].c_str();
-    }
-    const std::string ckey = jit_cache_key(source, hdr, NH, "");
-    const std::string odir = out_dir && out_dir[0] ? std::string(out_dir) : dir + "/prebuilt";
-    std::vector<char> blob;
-    if (read_file(odir + "/" + ckey + ".hsaco", blob)) return PCL_OK;  // already there
-    if (!rtc_load()) {
-        err = g_jit_note;
-        return PCL_EHIP;
-    }
-    std::vector<char> code;
-    std::string lname;
-    if (!rtc_compile(source, hdrp, names, NH, name_expr, true, "prebuild", code, lname)) {
-        err = g_jit_note;
-        return PCL_EHIP;
-    }
-    if (!write_file_atomic(odir, ckey + ".hsaco", pack_module(code, lname))) {
-        err = "cannot write " + odir + "/" + ckey + ".hsaco";
-        return PCL_EHIP;
-    }
-    return PCL_OK;
-}
-// the pattern-compiled modules of one system, as a context of that system would compile them on first use (no device needed):
-//   what 0  fused residual + Jacobian + residual-only kernels at order 2q | 1  general-order Hessian, one workgroup per interval |
-//        2  ... two workgroups per interval | 3  the order-4 Hessian / value-table module (q ignored) | 4  the fused module with the slice-ticket
-//        roles | 5  general-order Hessian, one wave per group of state columns
-extern "C" int pcl_jit_prebuild(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what, const char *out_dir) {
-    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || what < 0 || what > 5 || !G0 || (m > 0 && !Gj)) return fail(nullptr, PCL_EINVAL, "pcl_jit_prebuild: bad argument");
-    std::string src, err;
-    const char *kernel = "pcl_fused_sparse_kernel";
-    if (what == 3) {
-        src = sparse_source(pcl_codegen::make_plan(d, m, G0, n_g0, Gj));
-        kernel = "pcl_hess_sparse_kernel";
-    } else {
-        const pcl_codegen::V4Plan plan = pcl_codegen::make_v4_plan(d, m, G0, n_g0, Gj);
-        if (!plan.ok) return fail(nullptr, PCL_ESHAPE, "pcl_jit_prebuild: the pattern-compiled kernels do not take this system");
-        const int np = v4_power_tiles(d, m, q, 160 * 1024);
-        if (!np) return fail(nullptr, PCL_ESHAPE, "pcl_jit_prebuild: tiles exceed LDS");
-        src = what == 0 ? v4_source(plan, q, np) : what == 4 ? v4_source(plan, q, np, 0, 1) : what == 5 ? v4_hess_cols_source(plan, q) : v4_hess_source(plan, q, 0, what);
-        if (what && what != 4) kernel = what == 5 ? "pcl_hess_cols_kernel" : "pcl_hess_sparse4_kernel";
-    }
-    const int rc = prebuild_source(src, kernel, out_dir, err);
-    return rc == PCL_OK ? rc : fail(nullptr, rc, "pcl_jit_prebuild: %s", err.c_str());
-}
-
-// Inspection hooks of the fused pattern-compiled kernel (no device needed): its generated source, and the generator's term
-// tables applied on the host to one column (y = G(u) x; n_g0 drifts span the union pattern, the first one is applied).
-extern "C" int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what, char *buf, int64_t cap, int64_t *needed) {
-    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || what < 0 || what > 1 || !G0 || (m > 0 && !Gj) || !needed) return PCL_EINVAL;
-    const pcl_codegen::V4Plan plan = pcl_codegen::make_v4_plan(d, m, G0, n_g0, Gj);
-    if (!plan.ok) return PCL_ESHAPE;
-    const int np = v4_power_tiles(d, m, q, 160 * 1024);
-    if (!np) return PCL_ESHAPE;
-    const std::string src = what == 1 ? v4_hess_source(plan, q) : v4_source(plan, q, np);
-    *needed = (int64_t)src.size() + 1;
-    if (buf && cap > 0) {
-        const size_t nb = std::min<size_t>((size_t)cap - 1, src.size());
-        memcpy(buf, src.data(), nb);
-        buf[nb] = '\0';
-    }
-    return PCL_OK;
-}
-extern "C" int pcl_codegen_apply_v4(int d, int m, const double *G0, int n_g0, const double *Gj, const double *u, const double *x, double *y, int transposed) {
-    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || !G0 || (m > 0 && (!Gj || !u)) || !x || !y) return PCL_EINVAL;
-    const pcl_codegen::V4Plan plan = pcl_codegen::make_v4_plan(d, m, G0, n_g0, Gj);
-    if (!plan.ok) return PCL_ESHAPE;
-    if (transposed)
-        pcl_codegen::v4_reference_apply_t(plan, G0, u, x, y);
-    else
-        pcl_codegen::v4_reference_apply(plan, G0, Gj, u, x, y);
-    return PCL_OK;
-}
-
-// Inspection hook: the generated source of the pattern-compiled kernels for a system (needs no device).
-extern "C" int pcl_codegen_source(int d, int m, const double *G0, const double *Gj, char *buf, int64_t cap, int64_t *needed) {
-    if (d < 1 || d > 32 || m < 0 || m > 6 || !G0 || (m > 0 && !Gj) || !needed) return PCL_EINVAL;
-    const pcl_codegen::SpPlan plan = pcl_codegen::make_plan(d, m, G0, 1, Gj);
-    const std::string src = sparse_source(plan);
-    *needed = (int64_t)src.size() + 1;
-    if (buf && cap > 0) {
-        const size_t nb = std::min<size_t>((size_t)cap - 1, src.size());
-        memcpy(buf, src.data(), nb);
-        buf[nb] = '\0';
-    }
-    return PCL_OK;
-}
-
+#include "pcl_host_jit.hpp"
 // --- launch helpers -------------------------------------------------------------------------
 // LD = (n rounded up to 4) + 2  ==  2*odd: conflict-free ds_read_b64 of the MFMA b operand
 // (16 columns x 2 k-rows per half-wave land on 32 distinct 8-byte bank pairs).
@@ -2446,909 +2039,6 @@ extern "C" int pcl_rollout(pcl_ctx *ctx, const double *Z, double *X_out) {
     return PCL_OK;
 }
 
-// --- DerivativeIntegrator / time-consistency rows ---------------------------
-static int deriv_check(const pcl_ctx *ctx, int x_off, int dx_off, int dim) {
-    const int zd = ctx->desc.z_dim;
-    if (dim < 1 || x_off < 0 || x_off + dim > zd || (dx_off >= 0 && dx_off + dim > zd))
-        return fail(ctx, PCL_EINVAL, "derivative rows: components outside the knot (x_off=%d dx_off=%d dim=%d z_dim=%d)", x_off, dx_off, dim, zd);
-    return PCL_OK;
-}
-extern "C" int pcl_deriv_nnz(const pcl_ctx *ctx, int32_t dx_off, int32_t dim, int64_t *rows, int64_t *nnz) {
-    if (!ctx) return PCL_EINVAL;
-    const long long nb = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? ctx->desc.batch : 1;
-    if (rows) *rows = nb * ctx->K * dim;
-    if (nnz) *nnz = nb * ctx->K * dim * (dx_off >= 0 ? 4 : 3);
-    return PCL_OK;
-}
-extern "C" int pcl_deriv_structure(const pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim, int64_t *rows, int64_t *cols) {
-    if (!ctx) return PCL_EINVAL;
-    if (!rows || !cols) return fail(ctx, PCL_EINVAL, "pcl_deriv_structure: NULL output");
-    TRY(deriv_check(ctx, x_off, dx_off, dim));
-    const pcl_desc &D = ctx->desc;
-    const long long nb = D.batch_mode == PCL_BATCH_TRAJ ? D.batch : 1, zd = D.z_dim, base = D.index_base;
-    const int nseg = dx_off >= 0 ? 4 : 3;
-    long long p = 0;
-    for (long long b = 0; b < nb; ++b)
-        for (long long k = 0; k < ctx->K; ++k) {
-            const long long v0 = b * zd * D.N + k * zd + base, r0 = (b * ctx->K + k) * dim + base;
-            for (int seg = 0; seg < nseg; ++seg)
-                for (long long r = 0; r < dim; ++r, ++p) {
-                    rows[p] = r0 + r;
-                    cols[p] = seg == 0 ? v0 + x_off + r : seg == 1 ? v0 + zd + x_off + r : (seg == 2 && dx_off >= 0) ? v0 + dx_off + r : v0 + D.dt_off;
-                }
-        }
-    return PCL_OK;
-}
-extern "C" int pcl_deriv_eval_jac_dev(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim, const double *Z, double *delta,
-                                      double *vals) {
-    if (!ctx) return PCL_EINVAL;
-    if (!Z || (!delta && !vals)) return fail(ctx, PCL_EINVAL, "pcl_deriv_eval_jac_dev: NULL pointer");
-    TRY(deriv_check(ctx, x_off, dx_off, dim));
-    ON_DEVICE(ctx);
-    const pcl_desc &D = ctx->desc;
-    const long long nb = D.batch_mode == PCL_BATCH_TRAJ ? D.batch : 1;
-    const long long total = nb * ctx->K * dim;
-    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(pcl_deriv_kernel, dim3(grid), dim3(256), 0, ctx->stream, Z, delta, vals, ctx->K, D.z_dim, x_off, dx_off, dim,
-                       D.dt_off, D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0LL, total);
-    HIP_TRY(ctx, hipGetLastError());
-    return PCL_OK;
-}
-extern "C" int pcl_deriv_eval_jac(pcl_ctx *ctx, int32_t x_off, int32_t dx_off, int32_t dim, const double *Z, double *delta, double *vals) {
-    if (!ctx) return PCL_EINVAL;
-    if (!Z || (!delta && !vals)) return fail(ctx, PCL_EINVAL, "pcl_deriv_eval_jac: NULL pointer");
-    TRY(deriv_check(ctx, x_off, dx_off, dim));
-    ON_DEVICE(ctx);
-    int64_t nr = 0, nz = 0;
-    pcl_deriv_nnz(ctx, dx_off, dim, &nr, &nz);
-    double *dd = nullptr, *dv = nullptr;
-    TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
-    HIP_TRY(ctx, hipMalloc((void **)&dd, (size_t)nr * sizeof(double)));
-    if (hipMalloc((void **)&dv, (size_t)nz * sizeof(double)) != hipSuccess) {
-        (void)hipFree(dd);
-        return fail(ctx, PCL_ENOMEM, "pcl_deriv_eval_jac: device allocation failed");
-    }
-    int rc = PCL_OK;
-    if (hipMemcpyAsync(ctx->dZ, Z, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = PCL_EHIP;
-    if (rc == PCL_OK) rc = pcl_deriv_eval_jac_dev(ctx, x_off, dx_off, dim, ctx->dZ, dd, dv);
-    if (rc == PCL_OK && delta && hipMemcpyAsync(delta, dd, (size_t)nr * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = PCL_EHIP;
-    if (rc == PCL_OK && vals && hipMemcpyAsync(vals, dv, (size_t)nz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = PCL_EHIP;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == PCL_OK) rc = PCL_EHIP;
-    (void)hipFree(dd);
-    (void)hipFree(dv);
-    if (rc == PCL_EHIP) return fail(ctx, PCL_EHIP, "pcl_deriv_eval_jac: HIP error %s", hipGetErrorString(hipGetLastError()));
-    return rc;
-}
-
-// --- terminal infidelity objective ----------------------------------------------
-static int objective_unitary_only(const pcl_ctx *ctx, const char *who) {
-    if (ctx->vec || ctx->cols != ctx->desc.d) return fail(ctx, PCL_ENOTIMPL, "%s: unitary (n x d) states only", who);
-    return PCL_OK;
-}
-// (re)place the general form of the terminal loss; the Gram triangle of the Hessian is formed at the first Hessian call
-static int set_form(pcl_ctx *ctx, int scope, int R, const double *A, const double *c, bool user) {
-    const long long L = scope ? (long long)ctx->desc.batch * ctx->x_dim : ctx->x_dim;
-    for (double **q : {&ctx->dformA, &ctx->dformc, &ctx->dgram, &ctx->dcoef}) {
-        if (*q) (void)hipFree(*q);
-        *q = nullptr;
-    }
-    ctx->form_R = ctx->form_L = 0;
-    ctx->gram_ready = false;
-    ctx->form_user = false;
-    if (R < 0 || (R > 0 && !A) || (R == 0 && !c)) return fail(ctx, PCL_EINVAL, "terminal form: need rows or a linear part");
-    if (R > 0) {
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->dformA, (size_t)R * L * sizeof(double)));
-        HIP_TRY(ctx, hipMemcpy(ctx->dformA, A, (size_t)R * L * sizeof(double), hipMemcpyHostToDevice));
-    }
-    if (c) {
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->dformc, (size_t)L * sizeof(double)));
-        HIP_TRY(ctx, hipMemcpy(ctx->dformc, c, (size_t)L * sizeof(double), hipMemcpyHostToDevice));
-    }
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->dcoef, (size_t)std::max(ctx->desc.batch, 1) * sizeof(double)));
-    ctx->form_R = R;
-    ctx->form_L = (int)L;
-    ctx->form_scope = scope;
-    ctx->form_user = user;
-    return PCL_OK;
-}
-// F = |tr(G'U)|^2 / d^2 = (a'x)^2 + (b'x)^2 with a = iso_vec(G) / d, b = iso_vec(iG) / d   (objectives.jl:330-337)
-static int unitary_form(pcl_ctx *ctx, const double *g) {
-    const int d = ctx->desc.d, n = ctx->n;
-    std::vector<double> A((size_t)2 * ctx->x_dim);
-    for (int c = 0; c < d; ++c)
-        for (int i = 0; i < d; ++i) {
-            const double gr = g[c * n + i], gi = g[c * n + d + i];
-            A[c * n + i] = gr / d, A[c * n + d + i] = gi / d;
-            A[ctx->x_dim + c * n + i] = -gi / d, A[ctx->x_dim + c * n + d + i] = gr / d;
-        }
-    return set_form(ctx, 0, 2, A.data(), nullptr, false);
-}
-// F = (|M|_F^2 + |tr M|^2) / (ns (ns + 1)), M = G_s' U[sub, sub]: a row pair per entry of M and one for the trace   (objectives.jl:339-345)
-static int subspace_form(pcl_ctx *ctx, const double *gs, const int32_t *sub, int ns) {
-    const int d = ctx->desc.d, n = ctx->n;
-    const long long L = ctx->x_dim;
-    const int R = 2 * ns * ns + 2;
-    std::vector<double> A((size_t)R * L, 0.0);
-    const double sc = 1.0 / std::sqrt((double)ns * (ns + 1));
-    double *tr_re = A.data() + (size_t)(R - 2) * L, *tr_im = A.data() + (size_t)(R - 1) * L;
-    for (int i = 0; i < ns; ++i)
-        for (int j = 0; j < ns; ++j) {
-            double *re = A.data() + (size_t)(2 * (i * ns + j)) * L, *im = re + L;
-            for (int k = 0; k < ns; ++k) {
-                const double gr = gs[i * 2 * ns + k] * sc, gi = gs[i * 2 * ns + ns + k] * sc;  // G_s[k, i]
-                const long long xr = (long long)sub[j] * n + sub[k], xi = xr + d;               // U[sub_k, sub_j]
-                re[xr] += gr, re[xi] += gi;
-                im[xi] += gr, im[xr] -= gi;
-                if (i == j) tr_re[xr] += gr, tr_re[xi] += gi, tr_im[xi] += gr, tr_im[xr] -= gi;
-            }
-        }
-    return set_form(ctx, 0, R, A.data(), nullptr, false);
-}
-extern "C" int pcl_set_goal_form(pcl_ctx *ctx, int32_t scope, int32_t R, const double *A, const double *c) {
-    if (!ctx) return PCL_EINVAL;
-    if (scope != 0 && scope != 1) return fail(ctx, PCL_EINVAL, "pcl_set_goal_form: scope must be 0 (per member) or 1 (joint)");
-    if (scope == 1 && ctx->desc.batch_mode != PCL_BATCH_MEMBERS) return fail(ctx, PCL_EINVAL, "pcl_set_goal_form: a joint term needs the members of ONE trajectory buffer");
-    if (R > 4096) return fail(ctx, PCL_ESHAPE, "pcl_set_goal_form: at most 4096 rows");
-    ON_DEVICE(ctx);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->dgoal) (void)hipFree(ctx->dgoal);  // (replaces a unitary goal)
-    if (ctx->dsub) (void)hipFree(ctx->dsub);
-    ctx->dgoal = nullptr, ctx->dsub = nullptr, ctx->n_sub = 0;
-    return set_form(ctx, scope, R, A, c, true);
-}
-extern "C" int pcl_set_goal(pcl_ctx *ctx, const double *goal_iso_vec) {
-    if (!ctx) return PCL_EINVAL;
-    if (!goal_iso_vec) return fail(ctx, PCL_EINVAL, "pcl_set_goal: NULL");
-    TRY(objective_unitary_only(ctx, "pcl_set_goal"));
-    ON_DEVICE(ctx);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the context's stream is non-blocking: nothing else orders a launch in flight)
-    if (ctx->dgoal) (void)hipFree(ctx->dgoal);
-    ctx->dgoal = nullptr;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->dgoal, (size_t)ctx->x_dim * sizeof(double)));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dgoal, goal_iso_vec, (size_t)ctx->x_dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->n_sub = 0;
-    return unitary_form(ctx, goal_iso_vec);
-}
-extern "C" int pcl_set_goal_subspace(pcl_ctx *ctx, const double *goal_sub_iso_vec, const int32_t *subspace, int32_t ns) {
-    if (!ctx) return PCL_EINVAL;
-    if (!goal_sub_iso_vec || !subspace) return fail(ctx, PCL_EINVAL, "pcl_set_goal_subspace: NULL");
-    TRY(objective_unitary_only(ctx, "pcl_set_goal_subspace"));
-    if (ns < 1 || ns > ctx->desc.d) return fail(ctx, PCL_EINVAL, "pcl_set_goal_subspace: ns=%d outside 1..d=%d", ns, ctx->desc.d);
-    for (int i = 0; i < ns; ++i) {
-        if (subspace[i] < 0 || subspace[i] >= ctx->desc.d) return fail(ctx, PCL_EINVAL, "pcl_set_goal_subspace: index %d outside 0..d-1", subspace[i]);
-        for (int j = 0; j < i; ++j)
-            if (subspace[j] == subspace[i]) return fail(ctx, PCL_EINVAL, "pcl_set_goal_subspace: index %d repeated", subspace[i]);
-    }
-    ON_DEVICE(ctx);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->dgoal) (void)hipFree(ctx->dgoal);
-    if (ctx->dsub) (void)hipFree(ctx->dsub);
-    ctx->dgoal = nullptr;
-    ctx->dsub = nullptr;
-    ctx->n_sub = 0;
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->dgoal, (size_t)2 * ns * ns * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->dsub, (size_t)ns * sizeof(int)));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dgoal, goal_sub_iso_vec, (size_t)2 * ns * ns * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dsub, subspace, (size_t)ns * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->n_sub = ns;
-    return subspace_form(ctx, goal_sub_iso_vec, subspace, ns);
-}
-extern "C" int pcl_set_weights(pcl_ctx *ctx, const double *w) {
-    if (!ctx) return PCL_EINVAL;
-    ON_DEVICE(ctx);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (!w) {
-        if (ctx->dweights) (void)hipFree(ctx->dweights);
-        ctx->dweights = nullptr;
-        return PCL_OK;
-    }
-    if (!ctx->dweights) HIP_TRY(ctx, hipMalloc((void **)&ctx->dweights, (size_t)ctx->desc.batch * sizeof(double)));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dweights, w, (size_t)ctx->desc.batch * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PCL_OK;
-}
-extern "C" int pcl_add_regularizer(pcl_ctx *ctx, int32_t off, int32_t dim, const double *R, int32_t dt_power) {
-    if (!ctx) return PCL_EINVAL;
-    if (!R || dim < 1 || off < 0 || off + dim > ctx->desc.z_dim) return fail(ctx, PCL_EINVAL, "pcl_add_regularizer: component [%d, %d) outside the knot (z_dim=%d)", off, off + dim, ctx->desc.z_dim);
-    if (dt_power < 0 || dt_power > 2) return fail(ctx, PCL_EINVAL, "pcl_add_regularizer: dt_power must be 0, 1 or 2");
-    if ((int)ctx->regs.size() >= PCL_MAX_REGS) return fail(ctx, PCL_ESHAPE, "pcl_add_regularizer: at most %d regularisers", PCL_MAX_REGS);
-    PclReg r{off, dim, dt_power, (int)ctx->reg_R.size()};
-    ctx->regs.push_back(r);
-    ctx->reg_R.insert(ctx->reg_R.end(), R, R + dim);
-    ctx->regs_dirty = true;
-    return PCL_OK;
-}
-extern "C" int pcl_clear_regularizers(pcl_ctx *ctx) {
-    if (!ctx) return PCL_EINVAL;
-    ctx->regs.clear();
-    ctx->reg_R.clear();
-    ctx->regs_dirty = true;
-    return PCL_OK;
-}
-static unsigned infidelity_lds(const pcl_ctx *ctx) { return (unsigned)(6 * (size_t)ctx->n_sub * ctx->n_sub * sizeof(double)); }
-extern "C" int pcl_infidelity_dev(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad) {
-    if (!ctx) return PCL_EINVAL;
-    if (!Z || (!value && !grad)) return fail(ctx, PCL_EINVAL, "pcl_infidelity_dev: NULL pointer");
-    if (!ctx->dgoal) return fail(ctx, PCL_EINVAL, "pcl_infidelity_dev: call pcl_set_goal first");
-    TRY(objective_unitary_only(ctx, "pcl_infidelity_dev"));
-    ON_DEVICE(ctx);
-    const pcl_desc &D = ctx->desc;
-    hipLaunchKernelGGL(pcl_infidelity_kernel, dim3((unsigned)D.batch), dim3(256), infidelity_lds(ctx), ctx->stream, Z, ctx->dgoal, ctx->dsub,
-                       ctx->n_sub, ctx->dxoffs, ctx->dweights, value, grad, (long long)ctx->x_dim, 0, Q, D.d, D.N, D.z_dim,
-                       D.batch_mode == PCL_BATCH_TRAJ ? (long long)D.z_dim * D.N : 0LL, PclObjSum{nullptr, nullptr, nullptr, 0, 0, 0, 0});
-    HIP_TRY(ctx, hipGetLastError());
-    return PCL_OK;
-}
-// Whole objective of the unitary templates: sum_b w_b Q |1 - F_b| + quadratic regularisers, value + full gradient.
-// buffers, tickets and the regulariser table of the objective launches (pcl_objective_dev, pcl_eval_jac_merit_objective_dev)
-static int objective_prepare(pcl_ctx *ctx) {
-    const pcl_desc &D = ctx->desc;
-    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
-    const int nbuf = traj ? D.batch : 1;
-    if (!ctx->dobj) {  // [member terms | per-knot regulariser values | arrival ticket of the fused final sum]
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->dobj, ((size_t)D.batch + (size_t)nbuf * D.N + 1) * sizeof(double)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->dobj, 0, ((size_t)D.batch + (size_t)nbuf * D.N + 1) * sizeof(double), ctx->stream));
-    }
-    if (ctx->tickets_dirty) {  // (a switch of streams may have left the initial memset pending on the old one)
-        HIP_TRY(ctx, hipMemsetAsync(ctx->dobj + D.batch + (size_t)nbuf * D.N, 0, sizeof(double), ctx->stream));
-        if (ctx->dmticket) HIP_TRY(ctx, hipMemsetAsync(ctx->dmticket, 0, 64, ctx->stream));
-        ctx->tickets_dirty = false;
-    }
-    if (ctx->regs_dirty) {  // (re)upload the table; rare
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->dregs) (void)hipFree(ctx->dregs);
-        if (ctx->dreg_R) (void)hipFree(ctx->dreg_R);
-        ctx->dregs = nullptr;
-        ctx->dreg_R = nullptr;
-        if (!ctx->regs.empty()) {
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->dregs, ctx->regs.size() * sizeof(PclReg)));
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->dreg_R, ctx->reg_R.size() * sizeof(double)));
-            HIP_TRY(ctx, hipMemcpy(ctx->dregs, ctx->regs.data(), ctx->regs.size() * sizeof(PclReg), hipMemcpyHostToDevice));
-            HIP_TRY(ctx, hipMemcpy(ctx->dreg_R, ctx->reg_R.data(), ctx->reg_R.size() * sizeof(double), hipMemcpyHostToDevice));
-        }
-        ctx->regs_dirty = false;
-    }
-    return PCL_OK;
-}
-static bool tail_applies(const pcl_ctx *ctx, const double *grad, int &lo_, int &hi_);
-static int launch_tail(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad, int skip_lo, int skip_hi, double *merit_out);
-extern "C" int pcl_objective_dev(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad) {
-    if (!ctx) return PCL_EINVAL;
-    if (!Z || !value) return fail(ctx, PCL_EINVAL, "pcl_objective_dev: NULL pointer");
-    if (!ctx->dgoal && !ctx->form_user && ctx->regs.empty()) return fail(ctx, PCL_EINVAL, "pcl_objective_dev: no goal and no regulariser set");
-    if (ctx->dgoal) TRY(objective_unitary_only(ctx, "pcl_objective_dev"));
-    ON_DEVICE(ctx);
-    const pcl_desc &D = ctx->desc;
-    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
-    const int nbuf = traj ? D.batch : 1;
-    const long long zs = traj ? (long long)D.z_dim * D.N : 0LL;
-    if (ctx->form_user) {  // a terminal loss in the general form (kets, coherent kets, densities): regulariser rows, the terms, the sums
-        ctx->last_objective_launches = 3;
-        TRY(objective_prepare(ctx));
-        double *member = ctx->dobj, *regval = ctx->dobj + D.batch;
-        hipLaunchKernelGGL(pcl_regularizer_kernel, dim3((unsigned)D.N, (unsigned)nbuf), dim3(256), 0, ctx->stream, Z, (const PclReg *)ctx->dregs,
-                           (int)ctx->regs.size(), (const double *)ctx->dreg_R, grad, regval, D.N, D.z_dim, D.dt_off, zs);
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipMemsetAsync(member, 0, (size_t)D.batch * sizeof(double), ctx->stream));
-        const PclForm f{ctx->dformA, ctx->dformc, ctx->form_R, ctx->form_L, ctx->form_scope};
-        hipLaunchKernelGGL(pcl_form_kernel, dim3(ctx->form_scope ? 1u : (unsigned)D.batch), dim3(256), (size_t)std::max(ctx->form_R, 1) * sizeof(double), ctx->stream, Z, f,
-                           (const int *)ctx->dxoffs, (const double *)ctx->dweights, Q, 1.0, (int)ctx->x_dim, D.N, D.z_dim, zs, (long long)D.z_dim * D.N, member, grad, (double *)nullptr);
-        HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(pcl_objective_sum_kernel, dim3(traj ? (unsigned)D.batch : 1u), dim3(64), 0, ctx->stream, (const double *)member, (const double *)regval, value,
-                           D.batch, D.N, traj ? 1 : 0);
-        HIP_TRY(ctx, hipGetLastError());
-        return PCL_OK;
-    }
-    {  // ONE launch where it applies (regulariser rows and terminal infidelities as workgroups of one grid: 18 -> 10 us); the same bits
-        int lo = 0, hi = 0;
-        if (tail_applies(ctx, grad, lo, hi)) {
-            ctx->last_objective_launches = 1;
-            return launch_tail(ctx, Z, Q, value, grad, lo, hi, nullptr);
-        }
-    }
-    ctx->last_objective_launches = 2;
-    TRY(objective_prepare(ctx));
-    double *member = ctx->dobj, *regval = ctx->dobj + D.batch;
-    // Two launches: the regulariser kernel writes every knot's whole gradient row (zeros where no term applies) and the per-knot
-    // values; the infidelity kernel adds the terminal-state blocks and its last-arriving workgroup forms the final sum(s).
-    hipLaunchKernelGGL(pcl_regularizer_kernel, dim3((unsigned)D.N, (unsigned)nbuf), dim3(256), 0, ctx->stream, Z, (const PclReg *)ctx->dregs,
-                       (int)ctx->regs.size(), (const double *)ctx->dreg_R, grad, regval, D.N, D.z_dim, D.dt_off, zs);
-    HIP_TRY(ctx, hipGetLastError());
-    if (ctx->dgoal) {
-        hipLaunchKernelGGL(pcl_infidelity_kernel, dim3((unsigned)D.batch), dim3(256), infidelity_lds(ctx), ctx->stream, Z, ctx->dgoal,
-                           ctx->dsub, ctx->n_sub, ctx->dxoffs, ctx->dweights, member, grad, traj ? (long long)D.z_dim * D.N : 0LL, 1, Q, D.d,
-                           D.N, D.z_dim, zs,
-                           PclObjSum{value, regval, reinterpret_cast<unsigned int *>(ctx->dobj + D.batch + (size_t)nbuf * D.N), D.batch, D.N, traj ? 1 : 0, D.batch});
-        HIP_TRY(ctx, hipGetLastError());
-        return PCL_OK;
-    }
-    HIP_TRY(ctx, hipMemsetAsync(member, 0, (size_t)D.batch * sizeof(double), ctx->stream));  // regularisers only
-    hipLaunchKernelGGL(pcl_objective_sum_kernel, dim3(traj ? (unsigned)D.batch : 1u), dim3(64), 0, ctx->stream, (const double *)member, (const double *)regval, value,
-                       D.batch, D.N, traj ? 1 : 0);
-    HIP_TRY(ctx, hipGetLastError());
-    return PCL_OK;
-}
-extern "C" int pcl_objective(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad) {
-    if (!ctx) return PCL_EINVAL;
-    if (!Z || !value) return fail(ctx, PCL_EINVAL, "pcl_objective: NULL pointer");
-    ON_DEVICE(ctx);
-    const int nval = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? ctx->desc.batch : 1;
-    TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
-    TRY(ensure(ctx, &ctx->dgrad, z_len(ctx)));
-    TRY(ensure(ctx, &ctx->dval, nval));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dZ, Z, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    TRY(pcl_objective_dev(ctx, ctx->dZ, Q, ctx->dval, ctx->dgrad));
-    HIP_TRY(ctx, hipMemcpyAsync(value, ctx->dval, (size_t)nval * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (grad) HIP_TRY(ctx, hipMemcpyAsync(grad, ctx->dgrad, z_len(ctx) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PCL_OK;
-}
-// [phi | J^T lam on the shared controls and time steps]: the payload of the one collective (pcl_reduce_sum_dev)
-extern "C" int pcl_merit_grad_dev(pcl_ctx *ctx, const double *delta, const double *lam, const double *vals, double *out) {
-    if (!ctx) return PCL_EINVAL;
-    if (!delta || !vals || !out) return fail(ctx, PCL_EINVAL, "pcl_merit_grad_dev: NULL pointer");
-    ON_DEVICE(ctx);
-    const pcl_desc &D = ctx->desc;
-    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
-    const int sets = traj ? D.batch : 1;
-    const int m = D.n_drives;
-    if (!ctx->dphik) HIP_TRY(ctx, hipMalloc((void **)&ctx->dphik, ((size_t)D.batch * ctx->K * (m + 2) + (size_t)sets * ctx->K) * sizeof(double)));
-    double *part = ctx->dphik, *phik = ctx->dphik + (size_t)D.batch * ctx->K * (m + 2);
-    hipLaunchKernelGGL(pcl_merit_part_kernel, dim3((unsigned)ctx->K, (unsigned)D.batch), dim3(512), 0, ctx->stream, delta, lam, vals, part,
-                       ctx->K, ctx->cols, ctx->n, m, jac_per_full(ctx), 2LL * ctx->cols * ctx->n * ctx->n);
-    HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(pcl_merit_sum_kernel, dim3((unsigned)sets), dim3(1024), 0, ctx->stream, (const double *)part,
-                       (const double *)ctx->dweights, out, phik, D.batch, ctx->K, m, traj ? 1 : 0);
-    HIP_TRY(ctx, hipGetLastError());
-    return PCL_OK;
-}
-// fused residual + Jacobian + reduce payload: one pass over the state columns (the tails are not read back from HBM)
-extern "C" int pcl_eval_jac_merit_dev(pcl_ctx *ctx, const double *Z, const double *lam, double *delta, double *vals, double *out) {
-    if (!ctx) return PCL_EINVAL;
-    if (!Z || !delta || !vals || !out) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_merit_dev: NULL pointer");
-    ctx->merit_want = 1;
-    ctx->merit_fused = 0;
-    ctx->merit_lam = lam;
-    const int rc = launch_fused(ctx, Z, delta, vals, false);
-    ctx->merit_want = 0;
-    ctx->merit_lam = nullptr;
-    if (rc != PCL_OK) return rc;
-    if (!ctx->merit_fused) return pcl_merit_grad_dev(ctx, delta, lam, vals, out);  // other kernels / member windows: the separate payload kernels
-    ON_DEVICE(ctx);
-    const pcl_desc &D = ctx->desc;
-    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
-    const int sets = traj ? D.batch : 1;
-    const int m = D.n_drives;
-    if (!ctx->dphik) HIP_TRY(ctx, hipMalloc((void **)&ctx->dphik, ((size_t)D.batch * ctx->K * (m + 2) + (size_t)sets * ctx->K) * sizeof(double)));
-    double *phik = ctx->dphik + (size_t)D.batch * ctx->K * (m + 2);
-    if (!ctx->dmticket) {
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->dmticket, 64));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->dmticket, 0, 64, ctx->stream));
-    } else if (ctx->tickets_dirty) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->dmticket, 0, 64, ctx->stream));
-        if (ctx->dobj) {
-            const int nbuf_ = traj ? D.batch : 1;
-            HIP_TRY(ctx, hipMemsetAsync(ctx->dobj + D.batch + (size_t)nbuf_ * D.N, 0, sizeof(double), ctx->stream));
-        }
-        ctx->tickets_dirty = false;
-    }
-    // ONE launch: a workgroup per interval adds the columns, then the members (weights, member order); the workgroup that
-    // arrives last adds phi over the intervals
-    hipLaunchKernelGGL(pcl_merit_finish_kernel, dim3((unsigned)ctx->K), dim3(256), (size_t)D.batch * (m + 2) * sizeof(double), ctx->stream,
-                       (const double *)ctx->dmcols, (const double *)ctx->dweights, out, phik, ctx->dmticket, D.batch, ctx->K, ctx->cols, m, traj ? 1 : 0);
-    HIP_TRY(ctx, hipGetLastError());
-    return PCL_OK;
-}
-// The one-launch tail (pcl_ens_tail_kernel: regulariser rows + terminal infidelities [+ the payload's finish]) applies with a gradient
-// buffer, when the members' states are ONE contiguous run of a gradient row (the regulariser workgroup of the last knot leaves that run to
-// the infidelity workgroups of the same launch) that no regulariser covers (its terminal-knot term and the infidelity's would meet in one
-// entry: the launches then have to stay in order).  [lo, hi) = that run.
-// --- Hessian of the objective (what eval_hessian_lagrangian adds to the constraints' term: sigma * grad^2 f) -----------------------------
-// values: [terminal blocks: per term the lower triangle (i, j <= i) of its L x L block] [per buffer, knot, regulariser:
-// d2/dv_i^2 (dim) | d2/ddt dv_i (dim, dt_power >= 1) | d2/ddt^2 (dt_power 2)]; the structure says where each value belongs.
-static long long obj_hess_terms(const pcl_ctx *ctx) { return (ctx->dformA || ctx->dformc) ? (ctx->form_scope ? 1 : ctx->desc.batch) : 0; }
-static long long obj_hess_tri(const pcl_ctx *ctx) { return ctx->form_R > 0 ? (long long)ctx->form_L * (ctx->form_L + 1) / 2 : 0; }  // (a linear form has no second derivative)
-static long long obj_hess_per_knot(const pcl_ctx *ctx) {
-    long long n = 0;
-    for (const PclReg &r : ctx->regs) n += (long long)r.dim * (r.pw >= 1 ? 2 : 1) + (r.pw == 2 ? 1 : 0);
-    return n;
-}
-extern "C" int pcl_objective_hess_nnz(const pcl_ctx *ctx, int64_t *nnz) {
-    if (!ctx || !nnz) return PCL_EINVAL;
-    const int nbuf = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? ctx->desc.batch : 1;
-    *nnz = obj_hess_terms(ctx) * obj_hess_tri(ctx) + (long long)nbuf * ctx->desc.N * obj_hess_per_knot(ctx);
-    return PCL_OK;
-}
-extern "C" int pcl_objective_hess_structure(const pcl_ctx *ctx, int64_t *rows, int64_t *cols) {
-    if (!ctx || !rows || !cols) return PCL_EINVAL;
-    const pcl_desc &D = ctx->desc;
-    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
-    const int nbuf = traj ? D.batch : 1;
-    const long long base = D.index_base, zn = (long long)D.z_dim * D.N;
-    long long e = 0;
-    auto put = [&](long long a, long long b) {
-        rows[e] = std::max(a, b) + base;
-        cols[e] = std::min(a, b) + base;
-        ++e;
-    };
-    auto var = [&](long long t, long long i) {  // element i of term t's argument
-        const long long mem = ctx->form_scope ? i / ctx->x_dim : t, r = ctx->form_scope ? i - mem * ctx->x_dim : i;
-        return (traj ? mem * zn + ctx->x_offs[0] : (long long)ctx->x_offs[mem]) + (long long)(D.N - 1) * D.z_dim + r;
-    };
-    if (obj_hess_tri(ctx))
-        for (long long t = 0; t < obj_hess_terms(ctx); ++t)
-            for (long long i = 0; i < ctx->form_L; ++i)
-                for (long long j = 0; j <= i; ++j) put(var(t, i), var(t, j));
-    for (int b = 0; b < nbuf; ++b)
-        for (int k = 0; k < D.N; ++k) {
-            const long long z0 = (long long)b * zn + (long long)k * D.z_dim;
-            for (const PclReg &r : ctx->regs) {
-                for (int i = 0; i < r.dim; ++i) put(z0 + r.off + i, z0 + r.off + i);
-                if (r.pw >= 1)
-                    for (int i = 0; i < r.dim; ++i) put(z0 + D.dt_off, z0 + r.off + i);
-                if (r.pw == 2) put(z0 + D.dt_off, z0 + D.dt_off);
-            }
-        }
-    return PCL_OK;
-}
-extern "C" int pcl_objective_hess_dev(pcl_ctx *ctx, const double *Z, double Q, double sigma, double *vals) {
-    if (!ctx) return PCL_EINVAL;
-    if (!Z || !vals) return fail(ctx, PCL_EINVAL, "pcl_objective_hess_dev: NULL pointer");
-    ON_DEVICE(ctx);
-    const pcl_desc &D = ctx->desc;
-    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
-    const int nbuf = traj ? D.batch : 1;
-    const long long zs = traj ? (long long)D.z_dim * D.N : 0LL;
-    const long long nT = obj_hess_tri(ctx), nterm = obj_hess_terms(ctx);
-    if (nT) {
-        const PclForm f{ctx->dformA, ctx->dformc, ctx->form_R, ctx->form_L, ctx->form_scope};
-        if (!ctx->gram_ready) {  // T = 2 sum_r A_r A_r', once per goal
-            if (!ctx->dgram) HIP_TRY(ctx, hipMalloc((void **)&ctx->dgram, (size_t)nT * sizeof(double)));
-            hipLaunchKernelGGL(pcl_gram_kernel, dim3((unsigned)std::min<long long>((nT + 255) / 256, 4096)), dim3(256), 0, ctx->stream, f, ctx->dgram);
-            HIP_TRY(ctx, hipGetLastError());
-            ctx->gram_ready = true;
-        }
-        hipLaunchKernelGGL(pcl_form_kernel, dim3((unsigned)nterm), dim3(256), (size_t)std::max(ctx->form_R, 1) * sizeof(double), ctx->stream, Z, f, (const int *)ctx->dxoffs,
-                           (const double *)ctx->dweights, Q, sigma, (int)ctx->x_dim, D.N, D.z_dim, zs, (long long)D.z_dim * D.N, (double *)nullptr, (double *)nullptr, ctx->dcoef);
-        HIP_TRY(ctx, hipGetLastError());
-        hipLaunchKernelGGL(pcl_scale_kernel, dim3((unsigned)std::min<long long>((nT * nterm + 255) / 256, 8192)), dim3(256), 0, ctx->stream, (const double *)ctx->dgram,
-                           (const double *)ctx->dcoef, nT, (int)nterm, vals);
-        HIP_TRY(ctx, hipGetLastError());
-    }
-    const long long pk = obj_hess_per_knot(ctx);
-    if (pk) {
-        TRY(objective_prepare(ctx));
-        hipLaunchKernelGGL(pcl_reg_hess_kernel, dim3((unsigned)D.N, (unsigned)nbuf), dim3(256), 0, ctx->stream, Z, (const PclReg *)ctx->dregs, (int)ctx->regs.size(),
-                           (const double *)ctx->dreg_R, sigma, D.N, D.z_dim, D.dt_off, zs, pk, vals + nT * nterm);
-        HIP_TRY(ctx, hipGetLastError());
-    }
-    return PCL_OK;
-}
-extern "C" int pcl_objective_hess(pcl_ctx *ctx, const double *Z, double Q, double sigma, double *vals) {
-    if (!ctx) return PCL_EINVAL;
-    if (!Z || !vals) return fail(ctx, PCL_EINVAL, "pcl_objective_hess: NULL pointer");
-    ON_DEVICE(ctx);
-    int64_t nnz = 0;
-    TRY(pcl_objective_hess_nnz(ctx, &nnz));
-    if (nnz == 0) return PCL_OK;
-    TRY(ensure(ctx, &ctx->dZ, z_len(ctx)));
-    double *dv = nullptr;
-    HIP_TRY(ctx, hipMalloc((void **)&dv, (size_t)nnz * sizeof(double)));
-    int rc = PCL_OK;
-    if (hipMemcpyAsync(ctx->dZ, Z, z_len(ctx) * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = PCL_EHIP;
-    if (rc == PCL_OK) rc = pcl_objective_hess_dev(ctx, ctx->dZ, Q, sigma, dv);
-    if (rc == PCL_OK && hipMemcpyAsync(vals, dv, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = PCL_EHIP;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == PCL_OK) rc = PCL_EHIP;
-    (void)hipFree(dv);
-    if (rc == PCL_EHIP) return fail(ctx, PCL_EHIP, "pcl_objective_hess: HIP error %s", hipGetErrorString(hipGetLastError()));
-    return rc;
-}
-
-static bool tail_applies(const pcl_ctx *ctx, const double *grad, int &lo_, int &hi_) {
-    if (!grad || !ctx->dgoal || ctx->opt_objective_launches == 2) return false;
-    const int nx = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? 1 : ctx->desc.batch;
-    // The members' states must TILE one run [lo, hi) of the knot's row: sorted, every neighbour exactly x_dim further (distinct offsets and
-    // a matching extent are not enough: x_dim = 4 with offsets {0, 2, 8} has both and leaves a gap behind two overlapping states)
-    std::vector<long long> xo(ctx->x_offs.begin(), ctx->x_offs.begin() + nx);
-    std::sort(xo.begin(), xo.end());
-    for (int b = 1; b < nx; ++b)
-        if (xo[b] - xo[b - 1] != (long long)ctx->x_dim) return false;
-    const long long lo = xo[0], hi = xo[nx - 1] + ctx->x_dim;
-    for (const PclReg &r : ctx->regs)
-        if (r.off < hi && lo < r.off + r.dim) return false;
-    lo_ = (int)lo;
-    hi_ = (int)hi;
-    return true;
-}
-static int launch_tail(pcl_ctx *ctx, const double *Z, double Q, double *value, double *grad, int skip_lo, int skip_hi, double *merit_out) {
-    const pcl_desc &D = ctx->desc;
-    const bool traj = D.batch_mode == PCL_BATCH_TRAJ;
-    const int sets = traj ? D.batch : 1, nbuf = sets;
-    const int m = D.n_drives;
-    const long long zs = traj ? (long long)D.z_dim * D.N : 0LL;
-    if (merit_out) {
-        if (!ctx->dphik) HIP_TRY(ctx, hipMalloc((void **)&ctx->dphik, ((size_t)D.batch * ctx->K * (m + 2) + (size_t)sets * ctx->K) * sizeof(double)));
-        if (!ctx->dmticket) {
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->dmticket, 64));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->dmticket, 0, 64, ctx->stream));
-        }
-    }
-    TRY(objective_prepare(ctx));  // (also re-zeroes both tickets after a switch of streams)
-    PclTailArgs a;
-    a.Z = Z;
-    a.regs = (const PclReg *)ctx->dregs;
-    a.n_regs = (int)ctx->regs.size();
-    a.Rv = ctx->dreg_R;
-    a.grad = grad;
-    a.regval = ctx->dobj + D.batch;
-    a.N = D.N;
-    a.z_dim = D.z_dim;
-    a.dt_off = D.dt_off;
-    a.nbuf = nbuf;
-    a.z_batch_stride = zs;
-    a.goal = ctx->dgoal;
-    a.sub = ctx->dsub;
-    a.ns = ctx->n_sub;
-    a.x_offs = ctx->dxoffs;
-    a.weights = ctx->dweights;
-    a.member = ctx->dobj;
-    a.grad_stride = traj ? (long long)D.z_dim * D.N : 0LL;
-    a.Q = Q;
-    a.d = D.d;
-    a.batch = D.batch;
-    a.fin = PclObjSum{value, ctx->dobj + D.batch, reinterpret_cast<unsigned int *>(ctx->dobj + D.batch + (size_t)nbuf * D.N), D.batch, D.N, traj ? 1 : 0,
-                      D.batch + nbuf * D.N};
-    a.pcol = ctx->dmcols;
-    a.out = merit_out;
-    a.phik = merit_out ? ctx->dphik + (size_t)D.batch * ctx->K * (m + 2) : nullptr;
-    a.mticket = ctx->dmticket;
-    a.K = merit_out ? ctx->K : 0;
-    a.cols = ctx->cols;
-    a.m = m;
-    a.traj_mode = traj ? 1 : 0;
-    a.skip_lo = skip_lo;
-    a.skip_hi = skip_hi;
-    const size_t lds = std::max((size_t)infidelity_lds(ctx), merit_out ? (size_t)D.batch * (m + 2) * sizeof(double) : (size_t)0);
-    hipLaunchKernelGGL(pcl_ens_tail_kernel, dim3((unsigned)(nbuf * D.N + D.batch + a.K)), dim3(256), lds, ctx->stream, a);
-    HIP_TRY(ctx, hipGetLastError());
-    return PCL_OK;
-}
-// pcl_objective_dev + pcl_eval_jac_merit_dev as TWO launches instead of four: the fused kernel, then ONE launch whose workgroups are the
-// regulariser rows, the terminal infidelities and the payload's finish (pcl_ens_tail_kernel); the same bits as the separate calls.
-extern "C" int pcl_eval_jac_merit_objective_dev(pcl_ctx *ctx, const double *Z, const double *lam, double *delta, double *vals, double *out, double Q,
-                                                double *value, double *grad) {
-    if (!ctx) return PCL_EINVAL;
-    if (!Z || !delta || !vals || !out || !value) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_merit_objective_dev: NULL pointer");
-    if (!ctx->dgoal) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_merit_objective_dev: no goal set");
-    TRY(objective_unitary_only(ctx, "pcl_eval_jac_merit_objective_dev"));
-    int skip_lo = 0, skip_hi = 0;
-    ctx->last_step_launches = 4;
-    if (!tail_applies(ctx, grad, skip_lo, skip_hi)) {
-        TRY(pcl_objective_dev(ctx, Z, Q, value, grad));
-        ctx->last_step_launches = 2 + ctx->last_objective_launches;
-        return pcl_eval_jac_merit_dev(ctx, Z, lam, delta, vals, out);
-    }
-    ctx->merit_want = 1;
-    ctx->merit_fused = 0;
-    ctx->merit_lam = lam;
-    const int rc = launch_fused(ctx, Z, delta, vals, false);
-    ctx->merit_want = 0;
-    ctx->merit_lam = nullptr;
-    if (rc != PCL_OK) return rc;
-    if (!ctx->merit_fused) {  // other kernels / member windows: the separate calls
-        TRY(pcl_merit_grad_dev(ctx, delta, lam, vals, out));
-        return pcl_objective_dev(ctx, Z, Q, value, grad);
-    }
-    ON_DEVICE(ctx);
-    TRY(launch_tail(ctx, Z, Q, value, grad, skip_lo, skip_hi, out));
-    ctx->last_step_launches = 2;
-    return PCL_OK;
-}
-extern "C" int pcl_merit_grad_len(const pcl_ctx *ctx, int64_t *len, int64_t *sets) {
-    if (!ctx) return PCL_EINVAL;
-    if (len) *len = 1 + (int64_t)ctx->K * ctx->desc.n_drives + ctx->K;
-    if (sets) *sets = ctx->desc.batch_mode == PCL_BATCH_TRAJ ? ctx->desc.batch : 1;
-    return PCL_OK;
-}
-
-// --- RCCL sum-reduce of the shared-control payload -----------------------------
-// librccl is opened lazily with dlopen so that single-GPU users never load it.  ncclUniqueId is 128 opaque bytes;
-// ncclDataType_t ncclFloat64 = 8, ncclRedOp_t ncclSum = 0 (rccl.h of ROCm 7.x).
-namespace {
-struct RcclApi {
-    void *h = nullptr;
-    int (*GetUniqueId)(void *) = nullptr;
-    int (*CommInitRank)(void **, int, pcl_comm_id, int) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*CommDestroy)(void *) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-};
-RcclApi g_rccl;
-int rccl_load(const pcl_ctx *ctx) {
-    if (g_rccl.h) return PCL_OK;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!h) return fail(ctx, PCL_ERCCL, "dlopen(librccl.so): %s", dlerror());
-    RcclApi a;
-    a.h = h;
-    a.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
-    a.CommInitRank = (int (*)(void **, int, pcl_comm_id, int))dlsym(h, "ncclCommInitRank");
-    a.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
-    a.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
-    a.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
-    if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy) return fail(ctx, PCL_ERCCL, "librccl lacks the expected symbols");
-    g_rccl = a;
-    return PCL_OK;
-}
-int rccl_fail(const pcl_ctx *ctx, const char *what, int rc) {
-    return fail(ctx, PCL_ERCCL, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
-}
-}  // namespace
-
-extern "C" int pcl_comm_get_unique_id(pcl_comm_id *out) {
-    if (!out) return fail(nullptr, PCL_EINVAL, "pcl_comm_get_unique_id: NULL");
-    int rc = rccl_load(nullptr);
-    if (rc != PCL_OK) return rc;
-    int nrc = g_rccl.GetUniqueId(out);
-    return nrc == 0 ? PCL_OK : rccl_fail(nullptr, "ncclGetUniqueId", nrc);
-}
-extern "C" int pcl_comm_init(pcl_ctx *ctx, const pcl_comm_id *id, int32_t rank, int32_t nranks) {
-    if (!ctx || !id) return PCL_EINVAL;
-    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, PCL_EINVAL, "pcl_comm_init: rank %d of %d", rank, nranks);
-    if (ctx->comm) return fail(ctx, PCL_EINVAL, "pcl_comm_init: communicator already initialised");
-    TRY(rccl_load(ctx));
-    ON_DEVICE(ctx);
-    int nrc = g_rccl.CommInitRank(&ctx->comm, nranks, *id, rank);
-    if (nrc != 0) {
-        ctx->comm = nullptr;
-        return rccl_fail(ctx, "ncclCommInitRank", nrc);
-    }
-    return PCL_OK;
-}
-extern "C" int pcl_reduce_sum_dev(pcl_ctx *ctx, double *buf_dev, int64_t n) {
-    if (!ctx) return PCL_EINVAL;
-    if (!buf_dev || n < 0) return fail(ctx, PCL_EINVAL, "pcl_reduce_sum_dev: bad buffer");
-    if (!ctx->comm) return fail(ctx, PCL_ERCCL, "pcl_reduce_sum_dev: call pcl_comm_init first");
-    ON_DEVICE(ctx);
-    int nrc = g_rccl.AllReduce(buf_dev, buf_dev, (size_t)n, /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
-    return nrc == 0 ? PCL_OK : rccl_fail(ctx, "ncclAllReduce", nrc);
-}
-extern "C" int pcl_reduce_sum(pcl_ctx *ctx, double *buf, int64_t n) {  // host buffer, staged through device memory; synchronous
-    if (!ctx) return PCL_EINVAL;
-    if (!buf || n < 0) return fail(ctx, PCL_EINVAL, "pcl_reduce_sum: bad buffer");
-    if (!ctx->comm) return fail(ctx, PCL_ERCCL, "pcl_reduce_sum: call pcl_comm_init first");
-    if (n == 0) return PCL_OK;
-    ON_DEVICE(ctx);
-    if (ctx->reduce_cap < n) {
-        if (ctx->dreduce) (void)hipFree(ctx->dreduce);
-        ctx->dreduce = nullptr;
-        ctx->reduce_cap = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->dreduce, (size_t)n * sizeof(double)));
-        ctx->reduce_cap = n;
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->dreduce, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = pcl_reduce_sum_dev(ctx, ctx->dreduce, n)) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(buf, ctx->dreduce, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PCL_OK;
-}
-extern "C" int pcl_comm_destroy(pcl_ctx *ctx) {
-    if (!ctx) return PCL_EINVAL;
-    if (ctx->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
-    ctx->comm = nullptr;
-    return PCL_OK;
-}
-
-// --- options ---------------------------------------------------------------------------------
-extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
-    if (!ctx || !key) return PCL_EINVAL;
-    if (!strcmp(key, "cols_per_slice")) {
-        if (v < 0) return fail(ctx, PCL_EINVAL, "cols_per_slice must be >= 0");
-        ctx->opt_cols_per_slice = v;
-    } else if (!strcmp(key, "use_mfma"))
-        ctx->opt_use_mfma = v != 0;
-    else if (!strcmp(key, "nt_stores")) {  // -1 auto (by launch size) | 0 plain | 1 nontemporal | 2 write-through
-        if (v < -1 || v > 3) return fail(ctx, PCL_EINVAL, "nt_stores must be -1, 0, 1, 2 or 3");
-        ctx->opt_nt = v;
-    }
-    else if (!strcmp(key, "grid"))
-        ctx->opt_grid = v;
-#ifdef PCL_PROFILE
-    else if (!strcmp(key, "profile_flags"))  // profiling experiments (results may be WRONG); not present in the shipped library
-        ctx->opt_prof = v;
-    else if (!strcmp(key, "v4_variant")) {  // timing variants of kernel 4's generated product (WRONG results); recompiles
-        ctx->opt_v4_variant = v;
-        ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = ctx->v4_fhessc = nullptr;
-    }
-#endif
-    else if (!strcmp(key, "host_threads"))  // host-pointer entry points: threads expanding the compact values (0 = auto)
-    {
-        ctx->opt_host_threads = v < 0 ? -1 : v;  // (0 default count | n | -1 sweep over the context's first twelve calls)
-        ctx->host_threads_tuned = 0;
-        ctx->host_tune_calls = 0;
-        for (double &t : ctx->host_tune_t) t = 1e300;
-    }
-    else if (!strcmp(key, "host_path"))  // 0 auto | 1 full values over PCIe | 2 compact values + host expansion
-        ctx->opt_host_path = v < 0 || v > 2 ? 0 : v;
-    else if (!strcmp(key, "host_chunks"))  // interval chunks of the compact D2H copy that overlap with the expansion (1..8)
-        ctx->opt_host_chunks = v < 1 ? 1 : (v > 8 ? 8 : v);
-    else if (!strcmp(key, "specialize"))  // 0: always the run-time-shape kernel instances
-        ctx->opt_specialize = v != 0;
-    else if (!strcmp(key, "jit"))  // 1 (default): compile the context's shape on first use when no static instance matches
-        ctx->opt_jit = v != 0;
-    else if (!strcmp(key, "require_jit"))  // 1: a pattern-compiled kernel that is wanted and cannot be had is an error (PCL_EHIP), not a fallback
-        ctx->opt_require_jit = v != 0;
-    else if (!strcmp(key, "general_threads"))  // general-order kernel: 256 or 512 (default) threads per workgroup
-        ctx->opt_general_threads = v == 256 ? 256 : 512;
-    else if (!strcmp(key, "general_kernel_version"))  // general-order residual+Jacobian: 0 auto | 1 reference formulation | 2 lock-step kernel (error where it does not fit)
-        ctx->opt_general_version = v < 0 || v > 2 ? 0 : v;
-    else if (!strcmp(key, "general_slices"))  // lock-step kernel: slices of state columns per interval (0 auto)
-        ctx->opt_general_slices = v < 0 ? 0 : v;
-    else if (!strcmp(key, "general_pade_kernel"))  // 1: the general-order kernel also for pade_order 4
-        ctx->opt_general = v != 0;
-    else if (!strcmp(key, "stream_workgroups"))  // kernel 3, contiguous: > 0 = role split with this many stream-role workgroups
-        ctx->opt_stream_wg = v;
-    else if (!strcmp(key, "contiguous"))  // kernel 3: 1 = equal contiguous column ranges per workgroup (default), 0 = round-robin slices
-        ctx->opt_contig = v < 0 ? -1 : (v != 0);
-    else if (!strcmp(key, "objective_launches")) {  // 0 auto (one launch where it applies) | 2 always regulariser + infidelity launches
-        if (v != 0 && v != 2) return fail(ctx, PCL_EINVAL, "objective_launches must be 0 or 2");
-        ctx->opt_objective_launches = v;
-    } else if (!strcmp(key, "v4_flags"))  // kernel 4 A/B switches: 1 no raised priority for the P wave | 2 tails only behind the item's last block
-                                       // | 4 no cooperative first item | 8 LDS tiles NaN at kernel start (tests) | 16 the first item's chains do not wait for the cooperative products | 32 no balanced split of the middle column's two blocks between two slices
-        ctx->opt_v4_flags = v;
-    else if (!strcmp(key, "v4_ticket"))  // kernel 4: work items by ticket (-1 auto: full-value launches of several intervals per CU | 0 static split | 1)
-        ctx->opt_v4_ticket = v < 0 ? -1 : (v != 0);
-    else if (!strcmp(key, "v4_ticket_cols"))  // ... state columns per slice ticket (0 auto: 3)
-        ctx->opt_v4_ticket_cols = v < 0 ? 0 : v;
-    else if (!strcmp(key, "v4_ticket_ahead"))  // ... slices taken ahead of the one being stored (0 | 1)
-        ctx->opt_v4_ticket_ahead = v < 0 || v > 2 ? 0 : v;
-    else if (!strcmp(key, "v4_group"))  // ... workgroups per group (0 auto: 8; must divide the grid)
-        ctx->opt_v4_group = v < 0 ? 0 : v;
-    else if (!strcmp(key, "v4_power_tiles"))  // kernel 4: LDS tiles the powers of G rotate through (0 auto: q - 1 for launches of several items per workgroup, else q)
-        ctx->opt_v4_np = v < 0 ? 0 : v;
-    else if (!strcmp(key, "v4_tail_mode")) {  // kernel 4: 0 writer wave, plain stores | 1 nontemporal | 2 write-through | 3 the stream waves store the tails
-        if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "v4_tail_mode must be 0 .. 3");
-        ctx->opt_v4_tail_mode = v;
-    }
-    else if (!strcmp(key, "hess_split"))  // general-order pattern-compiled Hessian kernel: two workgroups per interval (-1 auto by launch size | 0 | 1)
-        ctx->opt_hess_split = v < 0 ? -1 : (v != 0);
-    else if (!strcmp(key, "eval_coop"))  // pattern-compiled residual kernel: four waves per interval (-1 auto by launch size | 0 | 1)
-        ctx->opt_eval_coop = v < 0 ? -1 : (v != 0);
-    else if (!strcmp(key, "eval_kernel")) {  // residual only: 0 auto, 1 matrix-core kernel, 2 pattern-compiled kernel
-        if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "eval_kernel must be 0 .. 3");
-        ctx->opt_eval_kernel = v;
-    }
-    else if (!strcmp(key, "hess_kernel")) {  // 0: auto, 1: one workgroup per interval, 2: persistent wave-synchronous kernel
-        if ((v < 0 || v > 4) && v != 7 && v != 8) return fail(ctx, PCL_EINVAL, "hess_kernel must be 0 .. 4, 7 or 8");
-        ctx->opt_hess_kernel = v;
-    }
-    else if (!strcmp(key, "debug_timing")) {  // profiling aid: cycle stamps of workgroup 0 (pcl_debug_timing reads them)
-#ifndef PCL_PROFILE
-        if (v) return fail(ctx, PCL_ENOTIMPL, "debug_timing needs a library built with -DPCL_PROFILE (the shipped kernels carry no stamps)");
-#endif
-        if (v && !ctx->ddbg) {
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->ddbg, PCL_DBG_WORDS * sizeof(long long)));
-            HIP_TRY(ctx, hipMemset(ctx->ddbg, 0, PCL_DBG_WORDS * sizeof(long long)));
-        } else if (!v && ctx->ddbg) {
-            (void)hipFree(ctx->ddbg);
-            ctx->ddbg = nullptr;
-        }
-    }
-    else if (!strcmp(key, "kernel_version")) {
-        if (v < 0 || v > 5) return fail(ctx, PCL_EINVAL, "kernel_version must be 0 (auto), 1, 2, 3, 4 or 5");
-        ctx->opt_kernel = v;
-    }
-    else
-        return fail(ctx, PCL_EINVAL, "unknown option '%s'", key);
-    return PCL_OK;
-}
-extern "C" int pcl_debug_timing(pcl_ctx *ctx, int64_t *out, int64_t cap) {
-    if (!ctx || !out || cap < 0) return PCL_EINVAL;
-    if (!ctx->ddbg) return fail(ctx, PCL_EINVAL, "pcl_debug_timing: set option debug_timing first");
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out, ctx->ddbg, (size_t)std::min<int64_t>(cap, PCL_DBG_WORDS) * sizeof(long long), hipMemcpyDeviceToHost));
-    return PCL_OK;
-}
-
-extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
-    if (!ctx || !key || !v) return PCL_EINVAL;
-    if (!strcmp(key, "cols_per_slice"))
-        *v = ctx->opt_cols_per_slice;
-    else if (!strcmp(key, "use_mfma"))
-        *v = ctx->opt_use_mfma;
-    else if (!strcmp(key, "nt_stores"))
-        *v = ctx->opt_nt;
-    else if (!strcmp(key, "effective_cols_per_slice"))
-        *v = ((ctx->opt_kernel == 3 || (ctx->opt_kernel == 0 && v3_specialised(ctx))) && ctx->opt_use_mfma && v3_supported(ctx) && !ctx->vec && ctx->cols == ctx->desc.d)
-                 ? (v3_contiguous(ctx) ? ctx->desc.d : choose_cols_v3(ctx))
-                 : choose_cols_per_slice(ctx, true);
-    else if (!strcmp(key, "n_cu"))
-        *v = ctx->n_cu;
-    else if (!strcmp(key, "host_threads"))
-        *v = host_threads(ctx);
-    else if (!strcmp(key, "host_expand_MBps"))  // delivered rate of the fastest call of the thread-count sweep (0 before it has finished)
-        *v = (int64_t)(ctx->host_expand_GBps * 1e3);
-    else if (!strcmp(key, "host_path"))
-        *v = ctx->opt_host_path;
-    else if (!strcmp(key, "host_chunks"))
-        *v = ctx->opt_host_chunks;
-    else if (!strcmp(key, "kernel_version"))
-        *v = ctx->opt_kernel;
-    else if (!strcmp(key, "last_kernel"))
-        *v = ctx->last_kernel;
-    else if (!strcmp(key, "last_hess_split"))
-        *v = ctx->last_hess_split;
-    else if (!strcmp(key, "last_eval_coop"))
-        *v = ctx->last_eval_coop;
-    else if (!strcmp(key, "last_objective_launches"))
-        *v = ctx->last_objective_launches;
-    else if (!strcmp(key, "objective_launches"))
-        *v = ctx->opt_objective_launches;
-    else if (!strcmp(key, "last_step_launches"))  // pcl_eval_jac_merit_objective_dev: 2 = fused kernel + one tail launch, 4 = the separate calls
-        *v = ctx->last_step_launches;
-    else if (!strcmp(key, "last_merit_fused"))
-        *v = ctx->merit_fused;
-    else if (!strcmp(key, "contiguous"))
-        *v = ctx->opt_contig;
-    else if (!strcmp(key, "jit"))
-        *v = ctx->opt_jit;
-    else if (!strcmp(key, "jit_compiles")) {  // modules this process compiled with hiprtc
-        std::lock_guard<std::mutex> lock(g_jit_mutex);
-        *v = g_jit_compiles;
-    } else if (!strcmp(key, "jit_cache_hits")) {  // ... and loaded from the prebuilt directory or the on-disk cache instead
-        std::lock_guard<std::mutex> lock(g_jit_mutex);
-        *v = g_jit_cache_hits;
-    } else if (!strcmp(key, "jit_fallbacks"))  // pattern-compiled kernels this context wanted and did not get
-        *v = ctx->jit_fallbacks;
-    else if (!strcmp(key, "require_jit"))
-        *v = ctx->opt_require_jit;
-    else if (!strcmp(key, "pade_order"))  // the order in use (0: pade_order = 0 at creation and nothing has chosen yet)
-        *v = ctx->desc.pade_order;
-    else if (!strcmp(key, "order_theta_1e9"))  // 1e9 x the bound on |dt G|_2 the order policy worked with
-        *v = (int64_t)(ctx->order_theta * 1e9);
-    else if (!strcmp(key, "stream_workgroups"))
-        *v = ctx->opt_stream_wg;
-    else if (!strcmp(key, "last_stream_workgroups"))
-        *v = ctx->last_n_stream;
-    else if (!strcmp(key, "v4_ticket"))
-        *v = ctx->opt_v4_ticket;
-    else if (!strcmp(key, "v4_ticket_cols"))
-        *v = ctx->opt_v4_ticket_cols;
-    else if (!strcmp(key, "v4_group"))
-        *v = ctx->opt_v4_group;
-    else if (!strcmp(key, "v4_ticket_ahead"))
-        *v = ctx->opt_v4_ticket_ahead;
-    else if (!strcmp(key, "last_v4_ticket"))
-        *v = ctx->last_v4_ticket;
-    else if (!strcmp(key, "hess_kernel"))
-        *v = ctx->opt_hess_kernel;
-    else if (!strcmp(key, "eval_kernel"))
-        *v = ctx->opt_eval_kernel;
-    else if (!strcmp(key, "last_hess_kernel"))
-        *v = ctx->last_hess_kernel;
-    else if (!strcmp(key, "ell_width_t"))
-        *v = ctx->ellt_w;
-    else if (!strcmp(key, "drives_antisymmetric"))
-        *v = ctx->drives_antisym;
-    else if (!strcmp(key, "occupancy_v2")) {
-        KParams p;
-        fill_params(ctx, p);
-        p.nc = choose_cols_per_slice(ctx, true);
-        const size_t lds = fused2_lds_bytes(p, true, ell_fits_lds(ctx));
-        int nb = 0;
-        (void)hipFuncSetAttribute((const void *)pcl_fused_kernel_v2<true, 1, 0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pcl_fused_kernel_v2<true, 1, 0, 0, 0>, 512, lds) != hipSuccess) nb = -1;
-        *v = nb * 1000000LL + (long long)lds;
-    }
-    else if (!strcmp(key, "iso_structured"))
-        *v = ctx->iso;
-    else if (!strcmp(key, "ell_width"))
-        *v = ctx->ell_w;
-    else if (!strcmp(key, "union_width"))
-        *v = ctx->uell_w;
-    else
-        return fail(ctx, PCL_EINVAL, "unknown option '%s'", key);
-    return PCL_OK;
-}
+#include "pcl_host_objective.hpp"
+#include "pcl_host_comm.hpp"
+#include "pcl_host_options.hpp"
