@@ -233,14 +233,17 @@ static inline void v4_emit_chunk_loads(std::string &s, int chunk) {
 }  // namespace detail
 
 // The generated definitions: shape macros, the resident-coefficient struct, the product, the drives' gathers.
-// terms per output row of the drives' transposed gathers (SP4_GTK of the generated source: the entry table of pcl_kernel_hess_cols.hpp)
-static inline int v4_gather_terms(const V4Plan &P) {
-    int gtk = 1;
+// entries per (drive, half) of the drives' transposed gathers' table (SP4_GT_TOTAL of the generated source: pcl_kernel_hess_cols.hpp): per output
+// row the most terms any drive has there
+static inline int v4_gather_total(const V4Plan &P) {
+    std::vector<int> mx(P.d, 0);
     for (int l = 0; l < P.m; ++l) {
         std::vector<int> cnt(P.d, 0);
-        for (const V4GEnt &e : P.gl[l]) gtk = std::max(gtk, ++cnt[e.col]);
+        for (const V4GEnt &e : P.gl[l]) mx[e.col] = std::max(mx[e.col], ++cnt[e.col]);
     }
-    return gtk;
+    int tot = 0;
+    for (int v : mx) tot += v;
+    return tot;
 }
 // np: LDS tiles the powers of G rotate through (>= 2 for q >= 2; q when they fit)
 // variant: timing experiments of the product (WRONG results unless 0): 1 no ds_add_f64 | 2 no LDS operation in the epilogues | 3 one
@@ -552,7 +555,7 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
         }
         // The same gathers as ONE table for lanes that belong to different drives (pcl_kernel_hess_cols.hpp): entry [drive][half][row][term]
         // = (source row of the w column, 0 .. n-1) << 4 | coefficient index (0: none; 1 + 2 g: +mags[g]; 2 + 2 g: -mags[g]), the half's sign
-        // of the B entries folded in (sb = +1 in half 0, -1 in half 1); SP4_GTK terms per row.
+        // of the B entries folded in (sb = +1 in half 0, -1 in half 1); sp4_gt_cnt(row) terms in row `row` (at most SP4_GTK), from entry sp4_gt_off(row).
         if (P.m > 0) {
             std::vector<std::vector<unsigned>> rows((size_t)P.m * 2 * d);
             size_t gtk = 1;
@@ -569,16 +572,33 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
                                 }
                         gtk = std::max(gtk, r.size());
                     }
+            // row i takes cnt[i] entries in every (drive, half): the most any of them has there (the lanes of a wave run one instruction stream);
             // three 10-bit entries per dword, a whole number of dwords per (drive, half)
-            const size_t wpc = ((size_t)d * gtk + 2) / 3;
-            snprintf(buf, sizeof buf, "#define SP4_GTK %zu\nstatic __device__ const unsigned sp4_gt_tab[%zu] = {", gtk, (size_t)P.m * 2 * wpc);
+            std::vector<size_t> cnt(d, 0), off(d + 1, 0);
+            for (size_t cls = 0; cls < (size_t)P.m * 2; ++cls)
+                for (int i = 0; i < d; ++i) cnt[i] = std::max(cnt[i], rows[cls * d + i].size());
+            for (int i = 0; i < d; ++i) off[i + 1] = off[i] + cnt[i];
+            const size_t wpc = (off[d] + 2) / 3;
+            snprintf(buf, sizeof buf, "#define SP4_GTK %zu\n#define SP4_GT_TOTAL %zu\n", gtk, off[d]);
+            s += buf;
+            s += "static __device__ constexpr int sp4_gt_cnt(int i) { constexpr int t_[SPD] = {";
+            for (int i = 0; i < d; ++i) {
+                snprintf(buf, sizeof buf, "%s%zu", i ? "," : "", cnt[i]);
+                s += buf;
+            }
+            s += "}; return t_[i]; }\nstatic __device__ constexpr int sp4_gt_off(int i) { constexpr int t_[SPD + 1] = {";
+            for (int i = 0; i <= d; ++i) {
+                snprintf(buf, sizeof buf, "%s%zu", i ? "," : "", off[i]);
+                s += buf;
+            }
+            snprintf(buf, sizeof buf, "}; return t_[i]; }\nstatic __device__ const unsigned sp4_gt_tab[%zu] = {", std::max<size_t>((size_t)P.m * 2 * wpc, 1));
             s += buf;
             for (size_t cls = 0; cls < (size_t)P.m * 2; ++cls) {
                 std::vector<unsigned> words(wpc, 0u);
                 for (int i = 0; i < d; ++i)
-                    for (size_t k = 0; k < gtk; ++k) {
+                    for (size_t k = 0; k < cnt[i]; ++k) {
                         const std::vector<unsigned> &r = rows[cls * d + i];
-                        const size_t en = (size_t)i * gtk + k;
+                        const size_t en = off[i] + k;
                         words[en / 3] |= (k < r.size() ? r[k] : 0u) << (10 * (en % 3));
                     }
                 for (size_t w = 0; w < wpc; ++w) {
@@ -586,6 +606,7 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
                     s += buf;
                 }
             }
+            if ((size_t)P.m * 2 * wpc == 0) s += "0u";
             s += "};\n";
         }
         s += "#define SP4_GATHER_T_SWITCH(l, Wo, Wx, X, hs, sb, mg) switch (l) {";

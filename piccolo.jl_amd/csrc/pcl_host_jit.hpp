@@ -294,9 +294,9 @@ std::string v4_hess_source(const pcl_codegen::V4Plan &plan, int q, int variant =
 std::string v4_hess_cols_source(const pcl_codegen::V4Plan &plan, int q, int variant = 0) {
     return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q, 1, (variant & 7) | 8, true) + "#include \"pcl_kernel_hess_cols.hpp\"\n";
 }
-static size_t hess_cols_lds_bytes(int d, int m, int q, int gtk) {  // HC_LDS_DOUBLES of the kernel
+static size_t hess_cols_lds_bytes(int d, int m, int q, int gt_total) {  // HC_LDS_DOUBLES of the kernel
     const int cpw = 32 / (m + 1);
-    return ((size_t)((m + 1) * cpw + (2 + (q > 2 ? q - 2 : 0)) * cpw) * (2 * d + 1) + 24 + ((size_t)m * 2 * (((size_t)d * gtk + 2) / 3) + 1) / 2) * sizeof(double);
+    return ((size_t)((m + 1) * cpw + (2 + (q > 2 ? q - 2 : 0)) * cpw) * (2 * d + 1) + 24 + ((size_t)m * 2 * (((size_t)gt_total + 2) / 3) + 1) / 2) * sizeof(double);
 }
 }  // namespace
 

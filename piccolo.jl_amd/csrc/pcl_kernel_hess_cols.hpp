@@ -37,7 +37,7 @@
 #define HC_NSC ((SPM + 1) * (SPM + 2) / 2)
 #define HC_GCH 5                                                        // rows per batch of the table-driven gathers
 #define HC_NCFT 24                                                      // coefficient table of the gathers: 0, +-mags[g]
-#define HC_GT_WPC ((SPD * SP4_GTK + 2) / 3)                             // the gathers' entry table (sp4_gt_tab): three 10-bit entries per dword, per (drive, half)
+#define HC_GT_WPC ((SP4_GT_TOTAL + 2) / 3)                             // the gathers' entry table (sp4_gt_tab): three 10-bit entries per dword, per (drive, half)
 #define HC_GT_DOUBLES ((SPM * 2 * HC_GT_WPC + 1) / 2)
 // 20,416 bytes at config 3, order 8: EIGHT of these workgroups share a CU's 160 KB (22.9 KB with R_{q-1} stored, a strip of zeros for the W lanes'
 // Y term and 16-bit entries: seven; 64 trajectories per launch 807 -> 784 us)
@@ -229,23 +229,26 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
                 for (int i = 0; i < HC_GCH; ++i)
 #pragma unroll
                     for (int kk = 0; kk < SP4_GTK; ++kk) {
-                        const int en = (i0 + i < SPD ? i0 + i : SPD - 1) * SP4_GTK + kk;  // entry number: word en / 3, bits 10 (en % 3) ...
-                        e_[i][kk] = (gt[en / 3] >> (10 * (en % 3))) & 1023u;
+                        const int row = i0 + i < SPD ? i0 + i : SPD - 1;
+                        const int en = sp4_gt_off(row) + (kk < sp4_gt_cnt(row) ? kk : 0);  // entry number: word en / 3, bits 10 (en % 3) ...
+                        e_[i][kk] = kk < sp4_gt_cnt(row) ? (gt[en / 3] >> (10 * (en % 3))) & 1023u : 0u;
                     }
                 double w_[HC_GCH][SP4_GTK], c_[HC_GCH][SP4_GTK];
 #pragma unroll
                 for (int i = 0; i < HC_GCH; ++i)
 #pragma unroll
-                    for (int kk = 0; kk < SP4_GTK; ++kk) {
-                        w_[i][kk] = Wc[e_[i][kk] >> 4];
-                        c_[i][kk] = cft[e_[i][kk] & 15u];
-                    }
+                    for (int kk = 0; kk < SP4_GTK; ++kk)
+                        if (kk < sp4_gt_cnt(i0 + i < SPD ? i0 + i : SPD - 1)) {  // (a row takes as many terms as the drive with the most there)
+                            w_[i][kk] = Wc[e_[i][kk] >> 4];
+                            c_[i][kk] = cft[e_[i][kk] & 15u];
+                        }
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int i = 0; i < HC_GCH; ++i)
                     if (i0 + i < SPD) {
 #pragma unroll
-                        for (int kk = 0; kk < SP4_GTK; ++kk) x[i0 + i] = __builtin_fma(c_[i][kk], w_[i][kk], x[i0 + i]);
+                        for (int kk = 0; kk < SP4_GTK; ++kk)
+                            if (kk < sp4_gt_cnt(i0 + i)) x[i0 + i] = __builtin_fma(c_[i][kk], w_[i][kk], x[i0 + i]);
                     }
             }
 #endif

@@ -1437,7 +1437,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
         const long long items = (long long)p.batch * p.K;
         const int cpw = 32 / (p.m + 1), ng = (p.d + cpw - 1) / cpw;
         if (items * ng > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
-        const size_t ldsc = hess_cols_lds_bytes(p.d, p.m, p.q, pcl_codegen::v4_gather_terms(v4));
+        const size_t ldsc = hess_cols_lds_bytes(p.d, p.m, p.q, pcl_codegen::v4_gather_total(v4));
         if (!ctx->v4_fhessc && ldsc <= (size_t)ctx->max_lds) {
             const std::string src = v4_hess_cols_source(v4, p.q, (int)ctx->opt_v4_variant);
             const std::string key = "hess-cols:" + std::to_string(p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
