@@ -49,11 +49,13 @@ static_assert(HC_XS <= 64 && HC_ROW <= SPD, "one lane per reduced sum");
 static __device__ __forceinline__ unsigned hc_lds_off(const double *q) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const double *)q;
 }
-static __device__ __forceinline__ void hc_store_coherent(double *q, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(q), "v"(v) : "memory"); }
+// The rows of reduced sums cross XCDs (whose L2s are not coherent with each other): write-through stores and cache-bypassing loads at system scope
+// (sc0 sc1), as relaxed atomics -- the compiler sees them, so the loads of a row are all in flight together and no register is reused under a store.
+static __device__ __forceinline__ void hc_store_coherent(double *q, double v) {
+    __hip_atomic_store((unsigned long long *)q, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 static __device__ __forceinline__ double hc_load_coherent(const double *q) {
-    double v;
-    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(q) : "memory");
-    return v;
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
 }
 
 extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(2, 2))) void pcl_hess_cols_kernel(
@@ -380,9 +382,11 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         double *tot = slots;  // [chain][value]
         if (ln_ < HC_XS) {
             const double *xall = xch + (long long)item * HC_NG * HC_XS + ln_;
-            double r = 0.0;
-#pragma unroll 1
-            for (int g = 0; g < HC_NG; ++g) r += hc_load_coherent(xall + g * HC_XS);
+            double v_[HC_NG], r = 0.0;  // (every row requested, then added in the order of the waves)
+#pragma unroll
+            for (int g = 0; g < HC_NG; ++g) v_[g] = hc_load_coherent(xall + g * HC_XS);
+#pragma unroll
+            for (int g = 0; g < HC_NG; ++g) r += v_[g];
             tot[ln_] = r;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
