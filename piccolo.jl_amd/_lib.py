@@ -211,7 +211,7 @@ def prebuild_kernels(G_drifts, G_drives, orders=(4,), hessian=True, out_dir=None
     count = 0
     for order in orders:
         # 0 fused | 4 fused with the slice-ticket roles | 3 the order-4 Hessian module | 5 the column-group Hessian kernel (`auto` at the other orders)
-        whats = [0] + ([4] if order <= 4 else []) + (([3] if order == 4 else [5]) if hessian else [])
+        whats = [0] + ([4] if order <= 4 else []) + (([3, 5] if order == 4 else [5]) if hessian else [])  # (order 4: kernel 6, and the column-group kernel for one trajectory)
         for what in whats:
             rc = L.pcl_jit_prebuild(d, m, G0.ctypes.data, G0.shape[0], Gj.ctypes.data if m else None, order // 2, what, od)
             if rc != 0:

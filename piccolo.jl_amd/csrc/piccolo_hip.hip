@@ -1430,7 +1430,10 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
     // hess_kernel 8 (auto at every order but 4): the pattern-compiled kernel with ONE WAVE PER GROUP OF STATE COLUMNS (pcl_kernel_hess_cols.hpp): every
     // wave a workgroup of its own with all m + 1 chains of 32 / (m + 1) columns, the scalar entries assembled by the wave of the interval
     // that arrives last
-    const bool cols_auto = ctx->opt_hess_kernel == 0 && ctx->desc.pade_order != 4 && !ctx->opt_general;  // (order 4: the tuned kernel 6 below stays ahead)
+    // (order 4: the tuned kernel 6 below stays ahead from two trajectories per launch on -- 22.6 against 23.8 us, 56 against 60 at eight; one
+    //  trajectory, i.e. at most n_cu / 2 intervals: 18.4 against 20.0 us -- kernel 6 needs its value-table launch first)
+    const bool cols_auto = ctx->opt_hess_kernel == 0 && !ctx->opt_general &&
+                           (ctx->desc.pade_order != 4 || 2LL * p.batch * p.K <= std::max(ctx->n_cu, 1));
     if ((ctx->opt_hess_kernel == 8 || cols_auto) && v4_available(ctx) && !ctx->v4_hessc_failed && p.m >= 1) {
         const pcl_codegen::V4Plan &v4 = *ctx->v4_plan;
         fill_pade(p, ctx->desc.pade_order);

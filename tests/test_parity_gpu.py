@@ -807,7 +807,8 @@ def test_hessian_kernel_variants(cfg, N, batch):
     c = make_ctx(lay, G0, Gj, batch=batch, batch_mode=pa._lib.PCL_BATCH_TRAJ, x_offs=[lay.x_off])
     Zb, mub = np.stack(Zs), np.concatenate([m_.reshape(-1) for m_ in mus])
     h_auto = c.hess(Zb, mub)
-    assert c.get_option("last_hess_kernel") == (6 if cfg == 3 else 2)  # 6: the pattern-compiled kernel (sparse iso generators, 9 <= d <= 32)
+    # 6: the pattern-compiled order-4 kernel (sparse iso generators, 9 <= d <= 32); 82: the column-group kernel, `auto` for launches of at most n_cu / 2 intervals
+    assert c.get_option("last_hess_kernel") in ((6, 82) if cfg == 3 else (2,))
     close(h_auto, ref, 1e-11)
     if cfg == 3:
         c.set_option("hess_kernel", 4)
@@ -2391,7 +2392,7 @@ def test_other_specialised_shapes(levels, batch):
     mu = np.random.default_rng(1).standard_normal((batch, lay.K, lay.x_dim))
     h_ref = np.concatenate([ref_lib.hess(Z, mu[i], lay, G0, Gj).reshape(-1) for i, Z in enumerate(Zs)])
     hv = c.hess(np.stack(Zs), mu.reshape(-1))
-    assert c.get_option("last_hess_kernel") == 6  # the pattern-compiled kernel (sparse iso generators, 9 <= d <= 32)
+    assert c.get_option("last_hess_kernel") in (6, 82)  # the pattern-compiled kernels (sparse iso generators, 9 <= d <= 32; 82: small launches)
     close(hv, h_ref, 1e-10)
     c.set_option("hess_kernel", 3)
     hv = c.hess(np.stack(Zs), mu.reshape(-1))
@@ -2743,8 +2744,9 @@ def test_column_group_hessian_kernel(order):
         close(h, c.hess(Z, mu.reshape(-1)), 1e-13)
         c.set_option("hess_kernel", 0)
         h0 = c.hess(Z, mu.reshape(-1))
-        assert c.get_option("last_hess_kernel") == (6 if order == 4 else 80 + order // 2)
-        if order != 4:
+        # (order 4: kernel 6 from two trajectories per launch on, the column-group kernel for launches of at most n_cu / 2 intervals)
+        assert c.get_option("last_hess_kernel") == ((82 if 2 * lay.K <= c.get_option("n_cu") else 6) if order == 4 else 80 + order // 2)
+        if c.get_option("last_hess_kernel") // 10 == 8:
             assert np.array_equal(h, h0)
         c.close()
     osys, psys, layE, ZE, trajE = _config4_share(3, 4)
@@ -2760,6 +2762,19 @@ def test_column_group_hessian_kernel(order):
     assert np.array_equal(BE.ctx.hess(trajE.datavec, muE[1].reshape(-1)), hE[per : 2 * per])
     BE.ctx.set_member_window(0, 3)
     BE.close()
+    if order == 4:  # `auto` at order 4: the column-group kernel for one trajectory (99 intervals <= n_cu / 2), kernel 6 from two on
+        N = 100
+        Zs = [po.synthetic_trajectory(so, N, seed=310 + i)[0] for i in range(2)]
+        lay = po.synthetic_trajectory(so, N, seed=310)[1]
+        mus = np.random.default_rng(9).standard_normal((2, lay.K, lay.x_dim))
+        c2, c1 = make_ctx(lay, G0, Gj, batch=2, batch_mode=pa._lib.PCL_BATCH_TRAJ), make_ctx(lay, G0, Gj)
+        h2 = c2.hess(np.stack(Zs), mus.reshape(-1)).reshape(2, -1)
+        assert c2.get_option("last_hess_kernel") == 6
+        h1 = c1.hess(Zs[0], mus[0].reshape(-1))
+        assert c1.get_option("last_hess_kernel") == (82 if 2 * lay.K <= c1.get_option("n_cu") else 6)
+        close(h1, h2[0], 1e-12)
+        c2.close()
+        c1.close()
     if order in (2, 8):  # seeds: one launch of 8 trajectories = 8 launches of one (a wave's arithmetic depends on its interval and columns only)
         # (order 2 at full length: 5544 short waves per launch -- the launch that showed a store hazard of hand-written 16-byte stores, a few
         #  wrong lines per launch at random places; the stores are the compiler's since)
@@ -2830,7 +2845,7 @@ def test_pattern_compiled_kernels_random_sparse_systems(d, m, Bn, N):
     d_ref = np.concatenate([po.pade_residual(Z, lay, G0, Gj, 4).reshape(-1) for Z in Zs])
     Zb = np.stack(Zs)
     h = c.hess(Zb, mu.reshape(-1))
-    assert c.get_option("last_hess_kernel") == 6  # auto
+    assert c.get_option("last_hess_kernel") in (6, 82)  # auto (82: the column-group kernel where the any-order generator takes the system, small launches)
     close(h, h_ref, 1e-11)
     c.set_option("hess_kernel", 4)
     c.set_option("eval_kernel", 2)
