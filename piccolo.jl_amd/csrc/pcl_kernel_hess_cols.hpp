@@ -344,14 +344,13 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         const int e = 2 * ln_ + 128 * t, cc = e / n;
         eo[t] = e < ne ? cc * SP4CS + (e - cc * n) : -1;
     }
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
+    hc_d2 t_[HC_NCH][NT2];
+    auto pass_lds = [&](int pass) {  // the lane's output vector of the pass -> its chain slot; then every read of the pass (two LDS round trips per pass, not one per chain)
         if (act) {
 #pragma unroll
             for (int i = 0; i < SPD; ++i) Xs[own + i] = pass ? accN[i] : accK[i];
         }
         asm volatile("" ::: "memory");
-        hc_d2 t_[HC_NCH][NT2];  // (every read of the pass, then the stores: two LDS round trips per pass, not one per chain)
 #pragma unroll
         for (int c2 = 0; c2 < HC_NCH; ++c2)
 #pragma unroll
@@ -360,6 +359,8 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
                 t_[c2][t].x = src[0], t_[c2][t].y = src[1];
             }
         asm volatile("" ::: "memory");
+    };
+    auto pass_store = [&](int pass) {
 #pragma unroll
         for (int c2 = 0; c2 < HC_NCH; ++c2) {
             // chain 0 (W): the h blocks m | 2 m + 1;  chain 1 + l: l | m + 1 + l
@@ -370,12 +371,18 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
                 if (eo[t] >= 0) *(hc_d2u *)(o + 128 * t) = t_[c2][t];
         }
         asm volatile("" ::: "memory");
-    }
-    HC_STAMP();
-    // ---- the scalar entries of the interval: the wave that arrived last adds the rows of all HC_NG waves in a fixed order.  (The row left
-    //      before the output vectors: its write has been acknowledged by the time theirs have.) ---------------------------------------------
+    };
+    pass_lds(0);
+    pass_store(0);
+    pass_lds(1);
+    // ---- the wave is counted in BETWEEN the passes: its row of sums left before the first pass's stores and has been acknowledged by now (or
+    //      nearly: waiting for it behind the last store, and then for the counter, cost a wave 8 k cycles at its end, 4 k here); the output
+    //      vectors need no order with the counter -- the wave that arrives last reads rows of sums only ----------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (ln_ == 0) xold = __hip_atomic_fetch_add(xcnt + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pass_store(1);
+    HC_STAMP();
+    // ---- the scalar entries of the interval: the wave that arrived last adds the rows of all HC_NG waves in a fixed order ----------------
     xold = __builtin_amdgcn_readfirstlane(xold);
     if (xold == HC_NG - 1) {
         if (ln_ == 0) __hip_atomic_store(xcnt + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch)
