@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""CPU baseline of bench.py: the oracle's plain-C restatement (oracle/pade_ref.c, analytic Pade-4, OpenMP over the K = N - 1 intervals) timed on
+ONE SOCKET of this host, as its own process (bench.py starts it; never part of the product path).
+
+    python bench/cpu_baseline.py [--seconds 12] [--knots 100]      ->  one JSON object on stdout
+
+What makes the number a measurement (round-4 review, item 5):
+  * the process is pinned (sched_setaffinity) to the physical cores of ONE socket -- the socket of the first allowed CPU, one hardware thread per
+    core -- before the OpenMP runtime starts; OMP_PROC_BIND=close, OMP_PLACES=cores, OMP_WAIT_POLICY=active are set before libgomp loads;
+  * the line records sockets, cores per socket, the cgroup's cpu.max, the last-level cache of the socket and the thread count used;
+  * every call of the 10-30 s sample is timed: p10 / p50 / p90 / mean are reported, `value` = 1 / p50;
+  * a COLD-OUTPUT variant rotates over output buffers that together exceed the socket's last-level cache (what a solver sees when anything
+    else touches memory between two evaluations): the warm variant's outputs (135 MB) can live in a 256-768 MB LLC across calls.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def topology():
+    """{socket: {core_id: [cpus]}} of the CPUs this process may run on, from sysfs."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except Exception:
+        allowed = list(range(os.cpu_count() or 1))
+    socks = {}
+    for c in allowed:
+        base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+        try:
+            pkg = int(open(base + "physical_package_id").read())
+            core = int(open(base + "core_id").read())
+        except Exception:
+            pkg, core = 0, c
+        socks.setdefault(pkg, {}).setdefault(core, []).append(c)
+    return allowed, socks
+
+
+def llc_bytes(cpus):
+    """Bytes of last-level cache reachable from `cpus` (sum over the distinct L3 instances)."""
+    seen, total = set(), 0
+    for c in cpus:
+        for idx in glob.glob("/sys/devices/system/cpu/cpu%d/cache/index*" % c):
+            try:
+                if open(idx + "/level").read().strip() != "3":
+                    continue
+                shared = open(idx + "/shared_cpu_list").read().strip()
+                if shared in seen:
+                    continue
+                seen.add(shared)
+                sz = open(idx + "/size").read().strip()
+                total += int(sz[:-1]) * (1 << 10 if sz[-1] == "K" else 1 << 20 if sz[-1] == "M" else 1) if sz[-1] in "KM" else int(sz)
+            except Exception:
+                pass
+    return total, len(seen)
+
+
+def cgroup_cpu_max():
+    for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            return open(p).read().strip()
+        except Exception:
+            pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=12.0)
+    ap.add_argument("--knots", type=int, default=100)
+    args = ap.parse_args()
+
+    allowed, socks = topology()
+    first_pkg = next(p for p, cores in sorted(socks.items()) if allowed[0] in [c for cs in cores.values() for c in cs])
+    cores = socks[first_pkg]
+    pin = sorted(min(cs) for cs in cores.values())  # one hardware thread per physical core of that socket
+    try:
+        os.sched_setaffinity(0, pin)
+        pinned = True
+    except Exception:
+        pinned = False
+    # before libgomp loads (it reads these at start-up and lays its places over the affinity mask of that moment)
+    os.environ["OMP_PROC_BIND"] = "close"
+    os.environ["OMP_PLACES"] = "cores"
+    os.environ["OMP_WAIT_POLICY"] = "active"
+    os.environ.setdefault("OMP_DYNAMIC", "false")
+
+    sys.path.insert(0, ROOT)
+    import numpy as np
+
+    from oracle import pade_oracle as po
+    from oracle import ref_lib
+
+    so = po.config_system(3)
+    d, m, N = so.levels, len(so.G_drives), args.knots
+    lay = po.Layout.smooth_pulse(d, m, N)
+    Z, _ = po.synthetic_trajectory(so, N, seed=1000)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    per = po.jac_nnz_per_interval(lay)
+
+    def alloc():
+        o = (np.empty((lay.K, lay.x_dim)), np.empty((lay.K, per)))
+        o[0].fill(0.0), o[1].fill(0.0)  # first touch here, on the pinned cores
+        return o
+
+    warm = alloc()
+    nthr_max = min(len(pin), lay.K)
+    ref_lib.eval_jac(Z, lay, G0, Gj, nthreads=nthr_max, out=warm)
+    # the port is memory-write-bound and parallel over K = 99 intervals: the best thread count of a short sweep (fastest of four calls each)
+    best_t, nthr = 1e9, 1
+    for nt in sorted({1, 8, 16, 24, 32, 48, 64, nthr_max}):
+        if nt > nthr_max:
+            continue
+        for _ in range(4):
+            t1 = time.perf_counter()
+            ref_lib.eval_jac(Z, lay, G0, Gj, nthreads=nt, out=warm)
+            t1 = time.perf_counter() - t1
+            if t1 < best_t:
+                best_t, nthr = t1, nt
+
+    def sample(buffers, seconds):
+        calls, i, t0 = [], 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            t1 = time.perf_counter()
+            ref_lib.eval_jac(Z, lay, G0, Gj, nthreads=nthr, out=buffers[i % len(buffers)])
+            calls.append(time.perf_counter() - t1)
+            i += 1
+        el = time.perf_counter() - t0
+        c = np.sort(np.array(calls))
+        return {"calls": len(c), "seconds": el, "p10_ms": float(c[int(0.1 * (len(c) - 1))]) * 1e3, "p50_ms": float(np.median(c)) * 1e3,
+                "p90_ms": float(c[int(0.9 * (len(c) - 1))]) * 1e3, "mean_ms": float(c.mean()) * 1e3, "max_ms": float(c[-1]) * 1e3,
+                "min_ms": float(c[0]) * 1e3, "sustained_evals_per_s": len(c) / el}, calls
+
+    w, wcalls = sample([warm], 0.6 * args.seconds)
+    llc, n_l3 = llc_bytes(pin)
+    out_bytes = warm[0].nbytes + warm[1].nbytes
+    n_cold = max(2, min(24, int(np.ceil(2.0 * max(llc, 64 << 20) / out_bytes))))
+    cold_bufs = [warm] + [alloc() for _ in range(n_cold - 1)]
+    for b in cold_bufs:  # one untimed pass: page faults of the new arrays are not the port's time
+        ref_lib.eval_jac(Z, lay, G0, Gj, nthreads=nthr, out=b)
+    c, _ = sample(cold_bufs, 0.4 * args.seconds)
+    # where a mean far above the median comes from: the share of the wall time spent in calls slower than 3 x the median
+    wc = np.array(wcalls)
+    slow = wc > 3.0 * np.median(wc)
+    res = {
+        "value": 1e3 / w["p50_ms"],
+        "unit": "evals/s",
+        "value_is": "1 / median call time, outputs re-used (warm in the socket's last-level cache where it holds them)",
+        "cores": nthr,
+        "kind": "port",
+        "warm": w,
+        "cold_output": dict(c, buffers=n_cold, evals_per_s_p50=1e3 / c["p50_ms"],
+                            note="outputs rotate over %d buffer pairs = %.0f MB > 2 x the socket's last-level cache" % (n_cold, n_cold * out_bytes / 1e6)),
+        "slow_calls": {"share_of_calls": float(slow.mean()), "share_of_wall_time": float(wc[slow].sum() / wc.sum()),
+                       "note": "calls slower than 3 x the median: what lifts the mean above the median (other tenants of a shared host; not the port)"},
+        "host": {"sockets_visible": len(socks), "socket_used": first_pkg, "physical_cores_of_socket_allowed": len(pin), "hw_threads_allowed": len(allowed),
+                 "pinned": pinned, "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_WAIT_POLICY")},
+                 "cgroup_cpu_max": cgroup_cpu_max(), "llc_bytes_of_socket": llc, "l3_instances": n_l3, "os_cpu_count": os.cpu_count()},
+        "sample": "%d warm + %d cold-output evals of one config-3 trajectory (N=%d) in %.1f s; oracle/pade_ref.c (analytic Pade-4, OpenMP over intervals, "
+        "gcc -O3 -march=x86-64-v3), outputs preallocated and first-touched on the pinned cores; %d threads = best of a sweep up to the %d physical cores of socket %d"
+        % (w["calls"], c["calls"], N, w["seconds"] + c["seconds"], nthr, len(pin), first_pkg),
+    }
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -130,6 +130,12 @@ const char *pcl_version(void);
  * theta = 1.5 x the maximum over the first trajectory a host-pointer entry point is given, tol = 1e-10; its device-pointer entry points
  * return PCL_EINVAL until an order exists. */
 int pcl_set_order_policy(pcl_ctx *ctx, double dt_max, const double *u_max /* n_drives */, double tol, int32_t *order_out);
+/* The same decision from a trajectory on the HOST (the one the integrator is constructed with -- the reference's constructor,
+ * src/control/integrators.jl:35-51, takes it too): theta = 1.5 x max_k |dt_k G(u_k)|_2 over Z_host, tol as set by pcl_set_order_policy
+ * (default 1e-10; tol > 0 here overrides).  What a binding calls at construction when the trajectory carries no bounds on u and dt, so that
+ * the scalar form B.f, the device-pointer entry points and the host-pointer ones all evaluate ONE order from the first call on.
+ * option "order_tol_met" reads 0 (and pcl_last_error carries a note) when even order 10 exceeds the tolerance. */
+int pcl_set_order_from_trajectory(pcl_ctx *ctx, const double *Z_host, double tol, int32_t *order_out);
 
 /* dimensions --------------------------------------------------------------- */
 /* n_rows = batch*x_dim*(N-1); n_cols = z_dim*N*(TRAJ ? batch : 1) + global_dim. Any out pointer may be NULL. */

@@ -10,7 +10,7 @@ from piccolo_jl_amd import synthetic
 
 system = synthetic.config_system(3)
 t0_ = synthetic.synthetic_trajectory(system, 100, seed=1000)
-ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), t0_, 1)
+ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), t0_, 1, pade_order=4)
 c = ms.ctx
 stream = torch.cuda.Stream()
 torch.cuda.set_stream(stream)

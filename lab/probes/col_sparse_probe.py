@@ -25,7 +25,7 @@ def timeit(f, steps=40, warm=6):
 
 for B in [int(a) for a in sys.argv[1:]] or [8, 1, 16]:
     trajs = [synthetic.synthetic_trajectory(system, 100, seed=1000 + i) for i in range(B)]
-    ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], B)
+    ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], B, pade_order=4)
     c = ms.ctx
     c.set_stream(torch.cuda.current_stream().cuda_stream)
     Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()

@@ -10,7 +10,7 @@ stream = torch.cuda.Stream()
 with torch.cuda.stream(stream):
     for batch in (1, 8, 64):
         trajs = [synthetic.synthetic_trajectory(s2, 100, seed=i) for i in range(batch)]
-        ms = pa.HipPadeMultistart(s2.G_drift, s2.G_drives_array(), t2, batch)
+        ms = pa.HipPadeMultistart(s2.G_drift, s2.G_drives_array(), t2, batch, pade_order=4)
         c = ms.ctx
         c.set_stream(stream.cuda_stream)
         Z = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()

@@ -10,7 +10,7 @@ from piccolo_jl_amd import synthetic
 M, N = 8, 100
 members = synthetic.config4_members(0, M)
 traj = synthetic.synthetic_ensemble(members, N, seed=20260929 + 4)
-Bs = pa.BilinearIntegrator(members, traj, device=0)
+Bs = pa.BilinearIntegrator(members, traj, device=0, pade_order=4)
 c = Bs[0].ensemble.ctx
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)

@@ -20,7 +20,7 @@ M, N = 8, 100
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
 members = synthetic.config4_members(0, M)
 traj = synthetic.synthetic_ensemble(members, N, seed=1)
-Bs = pa.BilinearIntegrator(members, traj)
+Bs = pa.BilinearIntegrator(members, traj, pade_order=4)
 c = Bs[0].ensemble.ctx
 c.set_stream(stream.cuda_stream)
 J = pa.UnitaryInfidelityObjective(np.eye(27, dtype=complex), [b.x_name for b in Bs], traj, Q=100.0, weights=np.full(M, 1 / M))
@@ -44,7 +44,7 @@ print("hess us:", timeit(lambda: c.hess_dev(Zd, mu, hv)))
 # same shapes as independent trajectories (shared drift)
 sysm = synthetic.config_system(3)
 t0 = synthetic.synthetic_trajectory(sysm, N, seed=1)
-ms = pa.HipPadeMultistart(sysm.G_drift, sysm.G_drives_array(), t0, M)
+ms = pa.HipPadeMultistart(sysm.G_drift, sysm.G_drives_array(), t0, M, pade_order=4)
 c2 = ms.ctx; c2.set_stream(stream.cuda_stream)
 Z2 = torch.from_numpy(np.stack([t0.datavec] * M)).cuda()
 d2 = torch.empty(c2.n_rows, dtype=torch.float64, device="cuda")

@@ -26,7 +26,7 @@ def bench(fn, stream, reps=300):
 for cfg in (2, 3):
     system = synthetic.config_system(cfg)
     traj = synthetic.synthetic_trajectory(system, 100, seed=20260929 + cfg)
-    B = pa.HipPadeIntegrator(system.G_drift, system.G_drives_array(), traj)
+    B = pa.HipPadeIntegrator(system.G_drift, system.G_drives_array(), traj, pade_order=4)
     c = B.ctx
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):

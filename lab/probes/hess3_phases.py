@@ -10,7 +10,7 @@ try:
     system = synthetic.config_system(3)
     for batch in (8, 1):
         trajs = [synthetic.synthetic_trajectory(system, 100, seed=1000 + i) for i in range(batch)]
-        ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], batch)
+        ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], batch, pade_order=4)
         c = ms.ctx
         Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()
         mu = torch.randn(c.n_rows, dtype=torch.float64, device="cuda")

@@ -9,7 +9,7 @@ from piccolo_jl_amd import synthetic
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 system = synthetic.config_system(3)
 trajs = [synthetic.synthetic_trajectory(system, 100, seed=1000 + i) for i in range(B)]
-ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], B)
+ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], B, pade_order=4)
 c = ms.ctx
 c.set_option("hess_kernel", 2); c.set_option("debug_timing", 1)
 Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()

@@ -12,7 +12,7 @@ stream = torch.cuda.Stream()
 with torch.cuda.stream(stream):
     for batch, reps in ((8, 3000), (1, 6000), (3, 3000)):
         trajs = [synthetic.synthetic_trajectory(system, 100, seed=1000 + i) for i in range(batch)]
-        ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], batch)
+        ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], batch, pade_order=4)
         c = ms.ctx
         c.set_stream(stream.cuda_stream)
         Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()

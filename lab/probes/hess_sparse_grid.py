@@ -16,7 +16,7 @@ def tm(c, Zd, mu, hv, reps=20):
     return e0.elapsed_time(e1) * 1e3 / reps
 for batch in (1, 8, 12, 16):
     trajs = [synthetic.synthetic_trajectory(system, 100, seed=1000 + i) for i in range(batch)]
-    ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], batch)
+    ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], batch, pade_order=4)
     c = ms.ctx
     Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()
     mu = torch.randn(c.n_rows, dtype=torch.float64, device="cuda")

@@ -12,7 +12,7 @@ for levels in (4, 5, 3):
     d, m = G0.shape[0] // 2, len(Gj)
     for batch, N in ((1, 12), (3, 30)):
         trajs = [synthetic.synthetic_trajectory(so, N, seed=60 + s) for s in range(batch)]
-        ms = pa.HipPadeMultistart(G0, Gj, trajs[0], batch)
+        ms = pa.HipPadeMultistart(G0, Gj, trajs[0], batch, pade_order=4)
         c = ms.ctx
         Zb = np.stack([t.datavec for t in trajs])
         mu = np.random.default_rng(1).standard_normal(c.n_rows)

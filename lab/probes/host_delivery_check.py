@@ -5,7 +5,7 @@ import pade_oracle as po
 from piccolo_jl_amd import synthetic
 so = synthetic.config_system(3)
 trajs = [synthetic.synthetic_trajectory(so, 6, seed=900 + s) for s in range(3)]
-ms = pa.HipPadeMultistart(so.G_drift, so.G_drives_array(), trajs[0], 3)
+ms = pa.HipPadeMultistart(so.G_drift, so.G_drives_array(), trajs[0], 3, pade_order=4)
 c = ms.ctx
 Zb = np.stack([t.datavec for t in trajs])
 c.set_option("host_path", 1)

@@ -23,7 +23,7 @@ with torch.cuda.stream(stream):
         xd = 2 * d * d
         comps = {"Ũ⃗": 0.1 * rng.standard_normal((xd, N)), "Δt": np.full((1, N), 0.1), "t": 0.1 * np.arange(N)[None], "u": 0.1 * rng.standard_normal((m, N))}
         traj = pa.NamedTrajectory(comps, controls=("u", "Δt"), timestep="Δt")
-        ms = pa.HipPadeMultistart(G0, Gj, traj, batch)
+        ms = pa.HipPadeMultistart(G0, Gj, traj, batch, pade_order=4)
         c = ms.ctx
         c.set_stream(stream.cuda_stream)
         Z = torch.from_numpy(np.tile(traj.datavec, batch)).cuda()

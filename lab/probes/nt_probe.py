@@ -9,7 +9,7 @@ system = synthetic.config_system(3)
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
 for batch in (8, 1):
     trajs = [synthetic.synthetic_trajectory(system, 100, seed=1000 + i) for i in range(batch)]
-    ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], batch)
+    ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], batch, pade_order=4)
     c = ms.ctx; c.set_stream(stream.cuda_stream)
     Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()
     dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda"); vd = torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")

@@ -11,7 +11,7 @@ nc = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # 0: contiguous column ranges
 ab = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 system = synthetic.config_system(3)
 trajs = [synthetic.synthetic_trajectory(system, 100, seed=1000 + i) for i in range(B)]
-ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], B)
+ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], B, pade_order=4)
 c = ms.ctx
 c.set_option("kernel_version", 3); c.set_option("cols_per_slice", nc); c.set_option("debug_timing", 1); c.set_option("debug_ablate", ab)
 Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()

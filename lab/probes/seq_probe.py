@@ -9,7 +9,7 @@ def ens(tag):
     M, N = 8, 100
     members = synthetic.config4_members(0, M)
     traj = synthetic.synthetic_ensemble(members, N, seed=1)
-    Bs = pa.BilinearIntegrator(members, traj)
+    Bs = pa.BilinearIntegrator(members, traj, pade_order=4)
     c = Bs[0].ensemble.ctx; c.set_stream(stream.cuda_stream)
     J = pa.UnitaryInfidelityObjective(np.eye(27, dtype=complex), [b.x_name for b in Bs], traj, Q=100.0, weights=np.full(M, 1 / M))
     for nm in ("u", "du", "ddu"): J = J + pa.QuadraticRegularizer(nm, traj, 1e-2)
@@ -28,7 +28,7 @@ def ens(tag):
 ens("fresh")
 t0 = synthetic.synthetic_trajectory(system, 100, seed=1)
 for batch in (1, 8):
-    ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), t0, batch)
+    ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), t0, batch, pade_order=4)
     c = ms.ctx; c.set_stream(stream.cuda_stream)
     Zd = torch.from_numpy(np.stack([t0.datavec] * batch)).cuda()
     dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda"); vd = torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")

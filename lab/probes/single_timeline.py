@@ -10,7 +10,7 @@ pa.build_library(force=True, profile=True)
 try:
     system = synthetic.config_system(3)
     t0 = synthetic.synthetic_trajectory(system, 100, seed=1000)
-    ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), t0, 1)
+    ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), t0, 1, pade_order=4)
     c = ms.ctx
     c.set_stream(torch.cuda.current_stream().cuda_stream)
     Zd = torch.from_numpy(t0.datavec[None]).cuda()

@@ -20,7 +20,7 @@ with torch.cuda.stream(stream):
         sys_ = pa.QuantumSystem(0.3 * (Hd + Hd.conj().T), Hs, [1.0] * m)
         traj = pa.unitary_trajectory(sys_, 0.1 * rng.standard_normal((m, N)), 0.1 * np.arange(N), np.eye(d))
         for batch in (1, 16):
-            ms = pa.HipPadeMultistart(sys_.G_drift, sys_.G_drives_array(), traj, batch)
+            ms = pa.HipPadeMultistart(sys_.G_drift, sys_.G_drives_array(), traj, batch, pade_order=4)
             c = ms.ctx
             c.set_stream(stream.cuda_stream)
             Z = torch.from_numpy(np.tile(traj.datavec, batch)).cuda()

@@ -19,7 +19,7 @@ with torch.cuda.stream(stream):
         for batch in (1, 8):
             if d * d * 4 * d * 99 * batch * 8 > 3e9:
                 continue
-            ms = pa.HipPadeMultistart(sys_.G_drift, sys_.G_drives_array(), traj, batch)
+            ms = pa.HipPadeMultistart(sys_.G_drift, sys_.G_drives_array(), traj, batch, pade_order=4)
             c = ms.ctx
             c.set_stream(stream.cuda_stream)
             Z = torch.from_numpy(np.tile(traj.datavec, batch)).cuda()

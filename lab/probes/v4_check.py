@@ -66,7 +66,7 @@ for M, N in ((3, 6), (8, 100)):
     lay = po.Layout(d=27, m=6, N=N, z_dim=traj.dim, x_off=0, u_off=traj.components["u"].start, dt_off=traj.components["Δt"].start)
     Z = traj.datavec.reshape(N, traj.dim)
     names = ["Ũ⃗%d" % (i + 1) for i in range(M)]
-    Bi = pa.HipPadeIntegrator(np.array([s.G_drift for s in psys]), psys[0].G_drives_array(), traj, names)
+    Bi = pa.HipPadeIntegrator(np.array([s.G_drift for s in psys]), psys[0].G_drives_array(), traj, names, pade_order=4)
     c = Bi.ctx
     c.set_option("host_path", 1)
     per_d, per_j = xd * lay.K, po.jac_nnz_per_interval(lay) * lay.K

@@ -12,7 +12,7 @@ members = synthetic.config4_members(0, M)
 traj = synthetic.synthetic_ensemble(members, N, seed=20260929 + 4)
 stream = torch.cuda.Stream()
 with torch.cuda.stream(stream):
-    Bs = pa.BilinearIntegrator(members, traj, device=0)
+    Bs = pa.BilinearIntegrator(members, traj, device=0, pade_order=4)
     c = Bs[0].ensemble.ctx
     c.set_stream(stream.cuda_stream)
     Zd = torch.from_numpy(traj.datavec).cuda()

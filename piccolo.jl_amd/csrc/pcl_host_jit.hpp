@@ -41,6 +41,9 @@ std::string g_jit_note;
 // __graft_entry__.build() fills for the BASELINE configs; travels with the library) is looked at first, then the user's cache
 // ($PCL_JIT_CACHE_DIR, else $XDG_CACHE_HOME/piccolo_hip, else ~/.cache/piccolo_hip), which every run-time compilation also writes
 // (temporary file + rename: ranks of one job may compile the same module at the same time).  PCL_JIT_CACHE=0 switches both off.
+// The user's cache is only used when it is the user's: no HOME / XDG_CACHE_HOME / PCL_JIT_CACHE_DIR means no user cache (never a shared /tmp
+// path), the directory is created 0700 and must belong to this user and be closed to group and others, a file must belong to this user;
+// every file carries its payload's length and a checksum, and one that does not unpack or load is removed and compiled afresh.
 struct Hash128 {
     uint64_t a = 0xcbf29ce484222325ull, b = 0x84222325cbf29ce4ull;
     void add(const void *p_, size_t n) {
@@ -71,7 +74,14 @@ std::string user_cache_dir() {
         if (x[0]) return std::string(x) + "/piccolo_hip";
     if (const char *h = getenv("HOME"))
         if (h[0]) return std::string(h) + "/.cache/piccolo_hip";
-    return "/tmp/piccolo_hip_cache";
+    return std::string();  // nowhere that is this user's: no user cache (a predictable world-writable path could be pre-planted)
+}
+// the directory is this user's and nobody else can write to it; `file` (when given) inside it is this user's too
+bool user_cache_trusted(const std::string &dir, const std::string &file = std::string()) {
+    struct stat st;
+    if (dir.empty() || stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return false;
+    if (file.empty()) return true;
+    return lstat((dir + "/" + file).c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid();
 }
 bool read_file(const std::string &path, std::vector<char> &out) {
     FILE *f = fopen(path.c_str(), "rb");
@@ -91,8 +101,8 @@ bool write_file_atomic(const std::string &dir, const std::string &name, const st
     const std::string tmp = dir + "/" + name + tmpl, fin = dir + "/" + name;
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return false;
-    const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
-    fclose(f);
+    bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+    ok = (fclose(f) == 0) && ok;  // (a short write may only show at close: the file must be whole before it gets its name)
     if (!ok || rename(tmp.c_str(), fin.c_str()) != 0) {
         remove(tmp.c_str());
         return false;
@@ -142,9 +152,9 @@ bool slurp(const std::string &path, std::string &out) {
 }
 
 
-void mkdir_p(const std::string &dir) {
+void mkdir_p(const std::string &dir) {  // (the leaf -- the cache itself -- for this user only)
     for (size_t i = 1; i <= dir.size(); ++i)
-        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), 0777);
+        if (i == dir.size() || dir[i] == '/') (void)mkdir(dir.substr(0, i).c_str(), i == dir.size() ? 0700 : 0755);
 }
 #ifdef PCL_PROFILE
 static const char *const kJitOpts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-DPCL_PROFILE"};
@@ -153,7 +163,7 @@ static const char *const kJitOpts[] = {"--offload-arch=gfx950", "-O3", "-std=c++
 #endif
 std::string jit_cache_key(const std::string &source, const std::string *hdr, int nh, const char *name_expr) {
     Hash128 h;
-    h.add(std::string("pcl-jit-1"));
+    h.add(std::string("pcl-jit-2"));
     h.add(source);
     for (int i = 0; i < nh; ++i) h.add(hdr[i]);
     for (const char *o : kJitOpts) h.add(std::string(o));
@@ -163,23 +173,36 @@ std::string jit_cache_key(const std::string &source, const std::string *hdr, int
     h.add(std::to_string(ver));
     return h.hex();
 }
-// on disk: "PCLJ" | uint32 length of the kernel's (lowered) name | name | code object
+// on disk: "PCL2" | uint32 length of the kernel's (lowered) name | uint64 length of the code object | uint64 checksum of name + code | name | code object
+static uint64_t module_checksum(const char *name, size_t nn, const char *code, size_t nc) {
+    Hash128 h;
+    h.add(name, nn);
+    h.add(code, nc);
+    return h.a ^ (h.b << 1);
+}
 std::vector<char> pack_module(const std::vector<char> &code, const std::string &lname) {
     std::vector<char> out;
     const uint32_t n = (uint32_t)lname.size();
-    out.insert(out.end(), {'P', 'C', 'L', 'J'});
+    const uint64_t nc = (uint64_t)code.size(), ck = module_checksum(lname.data(), lname.size(), code.data(), code.size());
+    out.insert(out.end(), {'P', 'C', 'L', '2'});
     out.insert(out.end(), (const char *)&n, (const char *)&n + 4);
+    out.insert(out.end(), (const char *)&nc, (const char *)&nc + 8);
+    out.insert(out.end(), (const char *)&ck, (const char *)&ck + 8);
     out.insert(out.end(), lname.begin(), lname.end());
     out.insert(out.end(), code.begin(), code.end());
     return out;
 }
 bool unpack_module(const std::vector<char> &blob, std::vector<char> &code, std::string &lname, bool plain_name) {
-    if (blob.size() < 8 || memcmp(blob.data(), "PCLJ", 4) != 0) return false;
+    if (blob.size() < 24 || memcmp(blob.data(), "PCL2", 4) != 0) return false;
     uint32_t n;
+    uint64_t nc, ck;
     memcpy(&n, blob.data() + 4, 4);
-    if (blob.size() < 8 + (size_t)n + 16) return false;
-    if (!plain_name) lname.assign(blob.data() + 8, n);
-    code.assign(blob.begin() + 8 + n, blob.end());
+    memcpy(&nc, blob.data() + 8, 8);
+    memcpy(&ck, blob.data() + 16, 8);
+    if (nc < 16 || (uint64_t)blob.size() != 24 + (uint64_t)n + nc) return false;  // truncated or padded
+    if (module_checksum(blob.data() + 24, n, blob.data() + 24 + n, (size_t)nc) != ck) return false;
+    if (!plain_name) lname.assign(blob.data() + 24, n);
+    code.assign(blob.begin() + 24 + n, blob.end());
     return true;
 }
 bool rtc_compile(const std::string &source, const char **hdrp, const char *const *names, int nh, const char *name_expr, bool plain_name, const std::string &what,
@@ -251,18 +274,50 @@ hipFunction_t jit_compile(int device, const std::string &key_, const std::string
     std::string lname = plain_name ? std::string(name_expr) : std::string();
     const std::string ckey = jit_cache_key(source, hdr, NH, plain_name ? "" : name_expr);
     bool from_cache = false;
+    std::string cache_file;  // the user-cache file the module came from (removed if it turns out not to load)
+    const std::string ucd = cache_enabled() ? user_cache_dir() : std::string();
     if (cache_enabled()) {
         std::vector<char> blob;
-        if (read_file(dir + "/prebuilt/" + ckey + ".hsaco", blob) || read_file(user_cache_dir() + "/" + ckey + ".hsaco", blob)) from_cache = unpack_module(blob, code, lname, plain_name);
+        if (read_file(dir + "/prebuilt/" + ckey + ".hsaco", blob))
+            from_cache = unpack_module(blob, code, lname, plain_name);
+        if (!from_cache && user_cache_trusted(ucd, ckey + ".hsaco") && read_file(ucd + "/" + ckey + ".hsaco", blob)) {
+            cache_file = ucd + "/" + ckey + ".hsaco";
+            from_cache = unpack_module(blob, code, lname, plain_name);
+            if (!from_cache) {  // truncated / corrupt / older format: away with it
+                (void)remove(cache_file.c_str());
+                cache_file.clear();
+            }
+        }
     }
-    if (!from_cache) {
+    auto load = [&]() {
+        jk.mod = nullptr;
+        jk.fn = nullptr;
+        if (lname.empty() || hipModuleLoadData(&jk.mod, code.data()) != hipSuccess) return false;
+        if (hipModuleGetFunction(&jk.fn, jk.mod, lname.c_str()) != hipSuccess) {
+            (void)hipModuleUnload(jk.mod);
+            jk.mod = nullptr;
+            return false;
+        }
+        return true;
+    };
+    bool loaded = from_cache && load();
+    if (from_cache && !loaded) {  // a cached code object the driver does not take (other ROCm build, damaged file): compile instead of failing for good
+        if (!cache_file.empty()) (void)remove(cache_file.c_str());
+        from_cache = false;
+        code.clear();
+        if (!plain_name) lname.clear();
+    }
+    if (!loaded) {
         if (!rtc_load()) return nullptr;
         if (!rtc_compile(source, hdrp, names, NH, name_expr, plain_name, key_, code, lname)) return nullptr;
-        if (cache_enabled()) (void)write_file_atomic(user_cache_dir(), ckey + ".hsaco", pack_module(code, lname));
-    }
-    if (lname.empty() || hipModuleLoadData(&jk.mod, code.data()) != hipSuccess || hipModuleGetFunction(&jk.fn, jk.mod, lname.c_str()) != hipSuccess) {
-        g_jit_note = "hipModuleLoadData / hipModuleGetFunction failed";
-        return nullptr;
+        if (!ucd.empty()) {
+            mkdir_p(ucd);
+            if (user_cache_trusted(ucd)) (void)write_file_atomic(ucd, ckey + ".hsaco", pack_module(code, lname));
+        }
+        if (!load()) {
+            g_jit_note = "hipModuleLoadData / hipModuleGetFunction failed";
+            return nullptr;
+        }
     }
     jk.failed = false;
     if (from_cache)
@@ -327,7 +382,11 @@ static int prebuild_source(const std::string &source, const char *name_expr, con
     const std::string ckey = jit_cache_key(source, hdr, NH, "");
     const std::string odir = out_dir && out_dir[0] ? std::string(out_dir) : dir + "/prebuilt";
     std::vector<char> blob;
-    if (read_file(odir + "/" + ckey + ".hsaco", blob)) return PCL_OK;  // already there
+    {
+        std::vector<char> code0;
+        std::string name0;
+        if (read_file(odir + "/" + ckey + ".hsaco", blob) && unpack_module(blob, code0, name0, false)) return PCL_OK;  // already there, and whole
+    }
     if (!rtc_load()) {
         err = g_jit_note;
         return PCL_EHIP;

@@ -166,6 +166,8 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->opt_require_jit;
     else if (!strcmp(key, "pade_order"))  // the order in use (0: pade_order = 0 at creation and nothing has chosen yet)
         *v = ctx->desc.pade_order;
+    else if (!strcmp(key, "order_tol_met"))  // 1 unless the order policy settled for order 10 with its bound above the tolerance
+        *v = ctx->order_tol_met;
     else if (!strcmp(key, "order_theta_1e9"))  // 1e9 x the bound on |dt G|_2 the order policy worked with
         *v = (int64_t)(ctx->order_theta * 1e9);
     else if (!strcmp(key, "stream_workgroups"))

@@ -4,30 +4,50 @@
 
 // ------------------------------------------------------------------------------------------
 // Expansion kernel: compact -> full triplet order (replicate the unique blocks d times).
-// grid.x = batch*K*d ; each block copies one (b,k,c) pair of n*n blocks; block c==0 also copies the tail.
+// Short-lived workgroups in address order (the hardware's dispatcher keeps the front of addresses being written tight):
+//   per interval (b,k): 2 S block workgroups -- (sign, slice of cpi state columns): every thread requests its <= 8 element pairs of the
+//   n x n tile at once (one round trip; the first version loaded a pair, stored it twice, loaded the next: 2.9 TB/s, bound by that chain),
+//   then only issues the 16-byte stores of the slice's copies -- and T tail workgroups (2048 element pairs each of the d/du_l, d/dh run).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pcl_expand_kernel(const double *__restrict__ compact, double *__restrict__ full,
-                                                         int d, int n, int m, long long n_bk, int nt) {
+                                                         int d, int n, int m, long long n_bk, int cpi, int nt) {
     const long long nn = (long long)n * n, xd = (long long)n * d;
     const long long cper = 2 * nn + xd * (m + 1), fper = 2 * d * nn + xd * (m + 1);
-    const long long bid = blockIdx.x;
-    const int c = (int)(bid % d);
-    const long long bk = bid / d;
+    const int S = (d + cpi - 1) / cpi;
+    const long long tail2 = (xd * (m + 1)) >> 1;  // element pairs of the tail run
+    const int T = (int)((tail2 + 2047) / 2048);
+    const int per_bk = 2 * S + T;
+    const long long bk = blockIdx.x / per_bk;
+    const int r = (int)(blockIdx.x - bk * per_bk);
     if (bk >= n_bk) return;
     const double *src = compact + bk * cper;
     double *dst = full + bk * fper;
-    for (long long q = threadIdx.x; q < (nn >> 1); q += blockDim.x) {
-        const double2_t v0 = *reinterpret_cast<const double2_t *>(src + 2 * q);
-        const double2_t v1 = *reinterpret_cast<const double2_t *>(src + nn + 2 * q);
-        store2(dst + c * nn + 2 * q, v0[0], v0[1], nt);
-        store2(dst + (d + c) * nn + 2 * q, v1[0], v1[1], nt);
-    }
-    if (c == 0) {
-        const long long tail = xd * (m + 1);
-        for (long long q = threadIdx.x; q < (tail >> 1); q += blockDim.x) {
-            const double2_t v = *reinterpret_cast<const double2_t *>(src + 2 * nn + 2 * q);
-            store2(dst + 2 * d * nn + 2 * q, v[0], v[1], nt);
+    const int tid = threadIdx.x;
+    double2_t v[8];
+    if (r < 2 * S) {
+        const int sign = r / S, sl = r - sign * S;
+        const int c0 = sl * cpi, c1 = min(d, c0 + cpi);
+        const int nn2 = (int)(nn >> 1);  // n <= 64: at most 2048 pairs = 8 per thread
+        src += sign * nn;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (tid + 256 * q < nn2) v[q] = *reinterpret_cast<const double2_t *>(src + 2 * (tid + 256 * q));
+        double *o = dst + ((long long)sign * d + c0) * nn;
+        for (int c = c0; c < c1; ++c, o += nn) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (tid + 256 * q < nn2) store2(o + 2 * (tid + 256 * q), v[q][0], v[q][1], nt);
         }
+    } else {
+        const long long e0 = (long long)(r - 2 * S) * 2048;
+        src += 2 * nn;
+        dst += 2 * d * nn;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (e0 + tid + 256 * q < tail2) v[q] = *reinterpret_cast<const double2_t *>(src + 2 * (e0 + tid + 256 * q));
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (e0 + tid + 256 * q < tail2) store2(dst + 2 * (e0 + tid + 256 * q), v[q][0], v[q][1], nt);
     }
 }
 

@@ -98,6 +98,7 @@ struct pcl_ctx {
     pcl_codegen::V4Plan *v4_plan = nullptr;
     double *dv4_tab = nullptr, *dv4_tab_t = nullptr, *dv4_mags = nullptr, *dv4_dcf = nullptr;
     hipFunction_t v4_ft = nullptr;  // the fused kernel of the module WITH the slice-ticket roles (launches of several trajectories)
+    int v4_ft_failed = 0;           // ... could not be had: those launches take the static split of v4_f (same bits)
     hipFunction_t v4_f = nullptr, v4_feval = nullptr, v4_fevalc = nullptr /* cooperative residual kernel (optional) */, v4_fhess = nullptr, v4_fhess2 = nullptr /* two workgroups per interval */;
     hipFunction_t v4_fhessc = nullptr;  // general-order Hessian, one wave per group of state columns (pcl_kernel_hess_cols.hpp)
     double *dhcx = nullptr;             // ... the waves' rows of reduced sums and the intervals' arrival counters (self-resetting)
@@ -120,7 +121,7 @@ struct pcl_ctx {
     int64_t opt_v4_ticket_cols = 0; // ... state columns per slice ticket (0 auto: 3)
     int64_t opt_v4_ticket_ahead = 2; // ... when the next slice is asked for: 0 when the stream waves have issued this one's stores | 1 a slice ahead | 2 at this one's last column (default)
     int64_t opt_v4_group = 0;       // ... workgroups per group (0 auto: 8, one per XCD)
-    bool ticket_launched = false;   // a launch with slice tickets has been enqueued on the current stream (see change_stream)
+    bool ticket_launched = false;   // a launch that works on the context's self-resetting device counters (slice tickets; the arrival counters and exchange rows of the split / column-group Hessian kernels) has been enqueued on the current stream (see change_stream)
     int64_t last_v4_ticket = 0;     // state columns per block ticket of the last kernel-4 launch (0: static work split)
     unsigned int *dv4_tick = nullptr;  // ... [block ticket, pipelines gone, chain ticket]: zero between launches (the last pipeline out resets them)
     int *herr = nullptr, *derr = nullptr;  // device error word (host-mapped): a barrier-free kernel whose bounded wait gave up sets bit 0
@@ -184,6 +185,7 @@ struct pcl_ctx {
     // order policy (pade_order = 0 in the descriptor): host copies of the generators for the norm bound, the tolerance, what was found
     std::vector<double> hG0, hGj;
     double order_tol = 1e-10, order_theta = 0.0;
+    int order_tol_met = 1;  // 0: the order policy had to settle for order 10 above its tolerance (note_order)
     mutable std::string err;
 };
 
@@ -1031,7 +1033,18 @@ static int launch_eval_v4(pcl_ctx *ctx, KParams &p) {
     ctx->last_n_stream = 0;
     return PCL_OK;
 }
-static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_merit = false) {
+static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_merit = false);
+// (the slice-ticket module could not be had: the same launch with the static split, from a fresh parameter block)
+static int launch_fused_v4_static(pcl_ctx *ctx, KParams &p, bool compact, bool want_merit) {
+    const int64_t keep = ctx->opt_v4_ticket;
+    ctx->opt_v4_ticket = 0;
+    p.tick = nullptr;
+    p.tick_cpi = p.tick_G = p.tick_ahead = 0;
+    const int rc = launch_fused_v4(ctx, p, compact, want_merit);
+    ctx->opt_v4_ticket = keep;
+    return rc;
+}
+static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_merit) {
     if (!v4_available(ctx) || !p.jac) return PCL_ENOTIMPL;
     const pcl_codegen::V4Plan &v4 = *ctx->v4_plan;
     fill_pade(p, ctx->desc.pade_order);
@@ -1050,7 +1063,7 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     // the previous slice's stores are issued -- the front of addresses being written stays tight and the workgroups the memory side
     // serves first take more slices: the time no longer depends on where the values array's pages live.
     const int tick_G = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_v4_group > 0 ? ctx->opt_v4_group : 8, ncu));
-    const bool ticket = !compact && ctx->dv4_tick && ctx->opt_grid <= 0 && m + 10 <= 16 && ncu % tick_G == 0 &&
+    const bool ticket = !compact && ctx->dv4_tick && !ctx->v4_ft_failed && ctx->opt_grid <= 0 && m + 10 <= 16 && ncu % tick_G == 0 &&
                         v4_lds_bytes(d, m, np) + 8 * 8 * 128 <= (size_t)ctx->max_lds &&
                         (ctx->opt_v4_ticket == 1 || (ctx->opt_v4_ticket < 0 && p.q <= 2 && p.contig && ctx->opt_contig < 0 && ctx->opt_cols_per_slice <= 0));
     // (orders 6-10: the P wave's q products per visit are the longer chain -- 8 trajectories at order 8: 246-254 against 232 us)
@@ -1103,13 +1116,20 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     void *args[] = {(void *)&p, (void *)&tab, (void *)&ctx->dv4_mags, (void *)&dcf};
     hipFunction_t fk = ctx->v4_f;
     if (ticket) {  // (a module of its own: the static launches -- one trajectory: the start-up counts -- run without the ticket roles' code)
-        if (!ctx->v4_ft) {
+        if (!ctx->v4_ft && !ctx->v4_ft_failed) {
             const std::string src = v4_source(*ctx->v4_plan, p.q, np, (int)ctx->opt_v4_variant, 1);
             const std::string key = "fused-sparse-tickets:" + std::to_string(p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
             ctx->v4_ft = jit_compile(ctx->device, key, src, "pcl_fused_sparse_kernel", true);
-            if (!ctx->v4_ft) return jit_fell_back(ctx, "residual + Jacobian (slice tickets)") == PCL_EHIP ? PCL_EHIP : fail(ctx, PCL_EHIP, "the slice-ticket module did not compile (%s)", g_jit_note.c_str());
+            if (!ctx->v4_ft) {
+                ctx->v4_ft_failed = 1;
+                // the static-split module computes the same bits: noted once, an error only under require_jit
+                if (jit_fell_back(ctx, "residual + Jacobian (slice tickets; the static split runs instead)") == PCL_EHIP) return PCL_EHIP;
+            }
         }
-        fk = ctx->v4_ft;
+        if (ctx->v4_ft)
+            fk = ctx->v4_ft;
+        else
+            return launch_fused_v4_static(ctx, p, compact, want_merit);
     }
     HIP_TRY(ctx, hipModuleLaunchKernel(fk, (unsigned)g, 1, 1, 64 * (m + 9 + (ticket ? 1 : 0)), 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
     ctx->last_kernel = 40 + p.q;
@@ -1463,6 +1483,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             }
             const long long wo = ctx->desc.per_member_G0 ? (long long)ctx->win_first : 0;
             const double *tab = ctx->dv4_tab + wo * v4.n_drift_pad, *tab_t = ctx->dv4_tab_t + wo * v4.n_drift_pad, *dcf = ctx->dv4_dcf + wo * v4.n_dcf_pad;
+            ctx->ticket_launched = true;  // (arrival counters + exchange rows: a launch on another stream must not overlap this one)
             void *args[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dhcx, (void *)&ctx->dhcc};
             HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhessc, (unsigned)(items * ng), 1, 1, 64, 1, 1, (unsigned)ldsc, ctx->stream, args, nullptr));
             ctx->last_hess_kernel = 80 + p.q;
@@ -1524,6 +1545,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             if (ctx->opt_grid > 0) grid = std::min<long long>(units, ctx->opt_grid);
             const long long wo = ctx->desc.per_member_G0 ? (long long)ctx->win_first : 0;
             const double *tab = ctx->dv4_tab + wo * v4.n_drift_pad, *tab_t = ctx->dv4_tab_t + wo * v4.n_drift_pad, *dcf = ctx->dv4_dcf + wo * v4.n_dcf_pad;
+            ctx->ticket_launched = true;
             void *args[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dh4x, (void *)&ctx->dh4c};
             HIP_TRY(ctx, hipModuleLaunchKernel(fh, (unsigned)grid, 1, 1, 64 * (1 + mh), 1, 1, (unsigned)bytes(p.nc), ctx->stream, args, nullptr));
             ctx->last_hess_kernel = 70 + p.q;
@@ -1715,45 +1737,83 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
 // 1.6e-5 / 1.6e-11 / 7.9e-15 at orders 4 / 8 / 10 against 2.2e-5 / 2.3e-11 / 1.1e-14 from this bound.)  pade_order = 0 asks for the
 // smallest order whose bound is below a tolerance, theta from the problem's bounds (pcl_set_order_policy) or, failing that, from the
 // first trajectory a host-pointer entry point sees (with a margin of 1.5 on theta: later iterates move inside their bounds).
-static double spectral_norm(const double *A, int n) {  // power iteration on A^T A (n <= 64: microseconds)
-    std::vector<double> x(n, 1.0), y(n), z(n);
-    double s = 0.0;
-    for (int it = 0; it < 60; ++it) {
-        for (int i = 0; i < n; ++i) {
-            double a = 0.0;
-            for (int j = 0; j < n; ++j) a += A[i + (size_t)n * j] * x[j];
-            y[i] = a;
-        }
+static double spectral_norm(const double *A, int n) {
+    // Power iteration on A^T A (n <= 64: microseconds) from two generic, non-symmetric start vectors -- a symmetric one (all ones) is
+    // annihilated by generators whose rows sum to zero and can sit orthogonal to the top singular vector -- the larger result counts; the
+    // guaranteed bound sqrt(|A|_1 |A|_inf) >= |A|_2 stands in when the iteration has nothing to say and caps a result that exceeds it.
+    double n1 = 0.0, ninf = 0.0;
+    {
+        std::vector<double> rs(n, 0.0);
         for (int j = 0; j < n; ++j) {
-            double a = 0.0;
-            for (int i = 0; i < n; ++i) a += A[i + (size_t)n * j] * y[i];
-            z[j] = a;
+            double cs = 0.0;
+            for (int i = 0; i < n; ++i) cs += std::fabs(A[i + (size_t)n * j]), rs[i] += std::fabs(A[i + (size_t)n * j]);
+            n1 = std::max(n1, cs);
         }
-        double nz = 0.0, nx = 0.0;
-        for (int j = 0; j < n; ++j) nz += z[j] * z[j], nx += x[j] * x[j];
-        if (nz == 0.0) return 0.0;
-        const double s1 = std::sqrt(std::sqrt(nz) / std::sqrt(nx));
-        nz = std::sqrt(nz);
-        for (int j = 0; j < n; ++j) x[j] = z[j] / nz;
-        if (std::fabs(s1 - s) <= 1e-12 * s1) return s1;
-        s = s1;
+        for (int i = 0; i < n; ++i) ninf = std::max(ninf, rs[i]);
     }
-    return s * 1.01;  // (not converged to round-off: a hair on the safe side)
+    const double upper = std::sqrt(n1 * ninf);
+    if (upper == 0.0) return 0.0;
+    std::vector<double> x(n), y(n), z(n);
+    double best = 0.0;
+    for (int seed = 0; seed < 2; ++seed) {
+        for (int j = 0; j < n; ++j) x[j] = 1.0 + 0.61803398875 * std::sin(1.0 + (seed ? 2.39996323 : 1.0) * (j + 1)) + (seed ? 0.25 * ((j * 7 + 3) % 5) : 0.0);
+        double s = 0.0;
+        bool converged = false;
+        for (int it = 0; it < 200 && !converged; ++it) {
+            for (int i = 0; i < n; ++i) {
+                double a = 0.0;
+                for (int j = 0; j < n; ++j) a += A[i + (size_t)n * j] * x[j];
+                y[i] = a;
+            }
+            for (int j = 0; j < n; ++j) {
+                double a = 0.0;
+                for (int i = 0; i < n; ++i) a += A[i + (size_t)n * j] * y[i];
+                z[j] = a;
+            }
+            double nz = 0.0, nx = 0.0;
+            for (int j = 0; j < n; ++j) nz += z[j] * z[j], nx += x[j] * x[j];
+            if (nz == 0.0) {
+                s = 0.0;
+                break;
+            }
+            const double s1 = std::sqrt(std::sqrt(nz) / std::sqrt(nx));
+            nz = std::sqrt(nz);
+            for (int j = 0; j < n; ++j) x[j] = z[j] / nz;
+            converged = it >= 8 && std::fabs(s1 - s) <= 1e-12 * s1;  // (a plateau in the first steps may be a sub-dominant singular value)
+            s = s1;
+        }
+        best = std::max(best, converged ? s : s * 1.01);  // (not converged to round-off: a hair on the safe side)
+    }
+    if (best == 0.0) return upper;
+    return std::min(best, upper);
 }
-static int order_for(double theta, double tol) {
+// the smallest diagonal Pade order whose bound is below tol; *met (when given) says whether any order up to 10 is
+static int order_for(double theta, double tol, bool *met = nullptr) {
     double fact[12];
     fact[0] = 1.0;
     for (int i = 1; i < 12; ++i) fact[i] = fact[i - 1] * i;
+    if (met) *met = true;
     for (int q = 1; q <= 5; ++q) {
         const double kappa = fact[q] * fact[q] / (fact[2 * q] * fact[2 * q + 1]);
         if (kappa * std::pow(theta, 2 * q + 1) <= tol) return 2 * q;
     }
+    if (met) *met = false;
     return 10;
+}
+// (order 10 chosen although its bound exceeds the tolerance: said in pcl_last_error's text -- no error code -- and readable as option order_tol_met)
+static void note_order(pcl_ctx *ctx, double theta, bool met) {
+    ctx->order_tol_met = met ? 1 : 0;
+    if (!met) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "order policy: |dt G| <= %.3g is too large for any diagonal Pade order up to 10 to stay within %.3g of the exp constraint; order 10 is used (option order_tol_met = 0)", theta, ctx->order_tol);
+        ctx->err = buf;
+        if (getenv("PCL_VERBOSE")) fprintf(stderr, "piccolo_hip: %s\n", buf);
+    }
 }
 static void set_order(pcl_ctx *ctx, int order, double theta) {
     if (ctx->desc.pade_order != order) {  // (modules are per order: the handles of the previous one are dropped, the modules stay cached)
         ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = ctx->v4_fhessc = nullptr;
-        ctx->v4_failed = ctx->v4_hess_failed = ctx->v4_hessc_failed = 0;
+        ctx->v4_failed = ctx->v4_hess_failed = ctx->v4_hessc_failed = ctx->v4_ft_failed = 0;
     }
     ctx->desc.pade_order = order;
     ctx->order_theta = theta;
@@ -1767,7 +1827,9 @@ extern "C" int pcl_set_order_policy(pcl_ctx *ctx, double dt_max, const double *u
     double theta = 0.0;
     for (size_t b = 0; b * n * n < ctx->hG0.size(); ++b) theta = std::max(theta, dt_max * (spectral_norm(ctx->hG0.data() + b * n * n, n) + gd));
     ctx->order_tol = tol;
-    set_order(ctx, order_for(theta, tol), theta);
+    bool met = true;
+    set_order(ctx, order_for(theta, tol, &met), theta);
+    note_order(ctx, theta, met);
     if (order_out) *order_out = ctx->desc.pade_order;
     return PCL_OK;
 }
@@ -1792,13 +1854,32 @@ static int resolve_order(pcl_ctx *ctx, const double *Z_host, const char *where) 
                 }
                 theta = std::max(theta, std::fabs(z[D.dt_off]) * spectral_norm(G.data(), n));
             }
-    set_order(ctx, order_for(1.5 * theta, ctx->order_tol), 1.5 * theta);
+    bool met = true;
+    set_order(ctx, order_for(1.5 * theta, ctx->order_tol, &met), 1.5 * theta);
+    note_order(ctx, 1.5 * theta, met);
+    return PCL_OK;
+}
+
+extern "C" int pcl_set_order_from_trajectory(pcl_ctx *ctx, const double *Z_host, double tol, int32_t *order_out) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z_host) return fail(ctx, PCL_EINVAL, "pcl_set_order_from_trajectory: NULL trajectory");
+    if (tol > 0.0) ctx->order_tol = tol;
+    const int keep = ctx->desc.pade_order;
+    ctx->desc.pade_order = 0;  // (resolve_order decides for contexts without an order; set_order drops the previous order's module handles)
+    const int rc = resolve_order(ctx, Z_host, "pcl_set_order_from_trajectory");
+    if (rc != PCL_OK) {
+        ctx->desc.pade_order = keep;
+        return rc;
+    }
+    if (order_out) *order_out = ctx->desc.pade_order;
     return PCL_OK;
 }
 
 // --- device-pointer API -----------------------------------------------------------------------
-// A launch with slice tickets leaves its counters zero only when it has finished: a launch on ANOTHER stream must not start before that
-// (launches on one stream are ordered anyway).  Switching streams therefore waits for the old one if such a launch may be in flight.
+// A launch with slice tickets leaves its counters zero only when it has finished, and so do the Hessian kernels that exchange rows of sums through
+// per-context arrival counters (column groups, two workgroups per interval): a launch on ANOTHER stream must not start before that (launches on
+// one stream are ordered anyway; the counters' first-use memset is ordered on the stream of that moment too).  Switching streams therefore waits
+// for the old one if such a launch may be in flight.
 static int change_stream(pcl_ctx *ctx, hipStream_t s) {
     if (s != ctx->stream && ctx->ticket_launched) {
         ON_DEVICE(ctx);
@@ -1847,14 +1928,19 @@ extern "C" int pcl_jac_expand_dev(pcl_ctx *ctx, const double *compact, double *v
     if (!compact || !vals) return fail(ctx, PCL_EINVAL, "pcl_jac_expand_dev: NULL pointer");
     ON_DEVICE(ctx);
     const long long n_bk = (long long)ctx->win_count * ctx->K;
-    const long long grid = n_bk * ctx->cols;
-    if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "pcl_jac_expand_dev: %lld work items exceed the grid limit", grid);
     if (ctx->cols == 1) {  // one state column (kets, compact density vectors): the compact layout IS the full layout
         HIP_TRY(ctx, hipMemcpyAsync(vals, compact, (size_t)(n_bk * jac_per_full(ctx)) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         return PCL_OK;
     }
+    // slices of 3 state columns (70 KB per workgroup at config 3), the option cols_per_slice overrides
+    const int cpi = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_cols_per_slice > 0 ? ctx->opt_cols_per_slice : 3, ctx->cols));
+    const long long tail2 = ((long long)ctx->x_dim * (ctx->desc.n_drives + 1)) >> 1;
+    const long long per_bk = 2LL * ((ctx->cols + cpi - 1) / cpi) + (tail2 + 2047) / 2048;
+    const long long grid = n_bk * per_bk;
+    if (grid > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "pcl_jac_expand_dev: %lld work items exceed the grid limit", grid);
+    if ((ctx->n & 1) || ((long long)ctx->x_dim * (ctx->desc.n_drives + 1)) % 2) return fail(ctx, PCL_ESHAPE, "pcl_jac_expand_dev: odd block sizes");
     hipLaunchKernelGGL(pcl_expand_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, compact, vals, ctx->cols, ctx->n,
-                       ctx->desc.n_drives, n_bk, ctx->opt_nt == 1 ? 1 : 0);
+                       ctx->desc.n_drives, n_bk, cpi, (int)(ctx->opt_nt > 0 ? ctx->opt_nt : 0));
     HIP_TRY(ctx, hipGetLastError());
     return PCL_OK;
 }

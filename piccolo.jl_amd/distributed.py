@@ -67,17 +67,31 @@ def reduce_merit_and_gradient(phi, g_u, g_dt, dist=None):
     """One sum all_reduce of [phi | g_u | g_dt] over the ranks; returns the reduced pieces."""
     buf = torch.cat([phi.reshape(1), g_u.reshape(-1), g_dt.reshape(-1)])
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(buf, dist)
     K, m = g_u.shape
     return buf[0], buf[1 : 1 + K * m].view(K, m), buf[1 + K * m :]
+
+
+def _all_reduce_sum(t, dist):
+    """Sum all-reduce in place.  RCCL ("nccl") takes device tensors; a gloo group (CPU tests, or several ranks sharing one GPU) is
+    handed a host copy."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
 
 
 def reduce_payload(payload, dist=None):
     """The all-reduce of a sharded ensemble step: ``payload`` = ``[objective | merit | J^T lam on u | on dt]`` as filled on
     the device by ``pcl_objective_dev`` + ``pcl_merit_grad_dev`` (each rank: its own members, weights w_i of the WHOLE
-    ensemble; the shared regularisers are bound on rank 0 only, or with R / world everywhere).  In place; one sum."""
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(payload, op=dist.ReduceOp.SUM)
+    ensemble; the shared regularisers are bound on rank 0 only, or with R / world everywhere).  In place; one sum.
+    Issued whenever a process group exists -- also over ONE rank, so that a single-GPU run under the launcher executes the
+    collective's whole code path."""
+    if dist is not None and dist.is_initialized():
+        _all_reduce_sum(payload, dist)
     return payload
 
 
@@ -87,5 +101,5 @@ def gather_per_unit(values, total, rank, world, dist=None):
     idx = shard_indices(total, rank, world)
     out[idx] = values
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(out, dist)
     return out

@@ -105,6 +105,20 @@ class _PclContext:
         self._chk(self._L.pcl_set_order_policy(self._h, float(dt_max), um.ctypes.data, float(tol), ctypes.byref(out)))
         return out.value
 
+    def set_order_from_trajectory(self, Z, tol=1e-10):
+        """The same decision from a trajectory on the host (``theta = 1.5 max_k |dt_k G(u_k)|``): what a constructor calls when the
+        trajectory carries no bounds on the drives and the timestep.  Returns the order."""
+        Z = self._z(Z)
+        out = ctypes.c_int32()
+        self._L.pcl_set_order_from_trajectory.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_int32)]
+        self._chk(self._L.pcl_set_order_from_trajectory(self._h, _ptr(Z), float(tol), ctypes.byref(out)))
+        return out.value
+
+    @property
+    def order_tol_met(self):
+        """False when the order policy had to settle for order 10 with its bound above the tolerance."""
+        return bool(self.get_option("order_tol_met"))
+
     @property
     def pade_order(self):
         """The order in use (0: a context created with ``pade_order=0`` that has not seen a policy or a trajectory yet)."""
@@ -377,6 +391,24 @@ class _PclContext:
         return v.value
 
 
+def _decide_order(ctx, traj, u_name, m, tol, copies=1):
+    """``pade_order = 0`` at construction: the order policy over the trajectory's bounds, else over the trajectory itself."""
+    ub, tb = traj.bounds.get(u_name), traj.bounds.get(traj.timestep)
+    if ub is not None and tb is not None and m:
+        umax = np.max(np.abs(np.broadcast_to(np.asarray(ub, dtype=np.float64), (2, len(traj.components[u_name])))), axis=0)[:m]
+        return ctx.set_order_policy(float(np.max(np.abs(np.asarray(tb, dtype=np.float64)))), umax, tol)
+    Z = np.ascontiguousarray(traj.datavec, dtype=np.float64).reshape(-1)
+    return ctx.set_order_from_trajectory(np.tile(Z, copies) if copies > 1 else Z, tol)
+
+
+def _resolved_order(ctx):
+    """The order a secondary context (the scalar form ``f``) must be created with: the main context's, never 0."""
+    order = ctx.pade_order
+    if order == 0:
+        raise PclError(-1, "the Pade order of this integrator is not decided yet (pade_order = 0 and no policy / trajectory seen)")
+    return order
+
+
 class HipPadeIntegrator:
     """Drop-in for ``DirectTrajOpt.BilinearIntegrator`` on the unitary path.
 
@@ -386,9 +418,12 @@ class HipPadeIntegrator:
     in order -- the row order here is identical: member-major).
     """
 
-    def __init__(self, G_drift, G_drives, traj, x_name=STATE, u_name="u", *, device=0, index_base=0, pade_order=4, order_tol=1e-10):
-        """``pade_order=0``: the smallest order whose deviation from the reference's exp constraint stays below ``order_tol`` over the
-        trajectory's bounds on ``u`` and the timestep (``traj.bounds``); without bounds, over the first trajectory evaluated (x 1.5)."""
+    def __init__(self, G_drift, G_drives, traj, x_name=STATE, u_name="u", *, device=0, index_base=0, pade_order=0, order_tol=1e-10):
+        """``pade_order=0`` (the default): the smallest diagonal Pade order whose deviation from the reference's exp constraint
+        [REF docs/src/concepts/index.md:21] stays below ``order_tol`` over the trajectory's bounds on ``u`` and the timestep
+        (``traj.bounds``); without bounds, over ``traj`` itself (x 1.5).  Decided HERE, so every entry point -- host or device
+        pointers, the scalar form ``f`` -- evaluates one order from the first call on.  ``pade_order=2..10`` pins the order
+        (BASELINE.json's metric is quoted on 4, which deviates from the exp constraint by 1.6e-5 at config 3)."""
         x_names = [x_name] if isinstance(x_name, str) else list(x_name)
         G_drives = np.asarray(G_drives, dtype=np.float64)
         G_drift = np.asarray(G_drift, dtype=np.float64)
@@ -427,10 +462,7 @@ class HipPadeIntegrator:
             state_cols=_lib.PCL_STATE_VECTOR if vec else cols,
         )  # fmt: skip
         if pade_order == 0:
-            ub, tb = traj.bounds.get(u_name), traj.bounds.get(traj.timestep)
-            if ub is not None and tb is not None and m:
-                umax = np.max(np.abs(np.broadcast_to(np.asarray(ub, dtype=np.float64), (2, len(traj.components[u_name])))), axis=0)[:m]
-                self._ctx.set_order_policy(float(np.max(np.abs(np.asarray(tb, dtype=np.float64)))), umax, order_tol)
+            _decide_order(self._ctx, traj, u_name, m, order_tol)
         self._state_cols = _lib.PCL_STATE_VECTOR if vec else cols
         self.x_dim = self._ctx.x_dim * len(x_names) if len(x_names) > 1 else self._ctx.x_dim
         self.dim = self._ctx.n_rows
@@ -458,7 +490,7 @@ class HipPadeIntegrator:
         if self._f_ctx is None:
             self._f_ctx = _PclContext(d=c.d, m=c.m, N=2, z_dim=c.x_dim + 1 + c.m, u_off=c.x_dim + 1, dt_off=c.x_dim,
                                       x_offs=[0], G0=self.G_drift, Gj=self.G_drives, batch=1,
-                                      batch_mode=PCL_BATCH_MEMBERS, state_cols=self._state_cols, pade_order=self.pade_order)  # fmt: skip
+                                      batch_mode=PCL_BATCH_MEMBERS, state_cols=self._state_cols, pade_order=_resolved_order(c))  # fmt: skip
         z = np.zeros((2, c.x_dim + 1 + c.m))
         z[0, : c.x_dim], z[0, c.x_dim], z[0, c.x_dim + 1 :] = x, dt, np.asarray(u)[: c.m]
         z[1, : c.x_dim] = x_next
@@ -577,11 +609,11 @@ class HipPadeMemberIntegrator:
     member's own system), with the reference's properties ``dim == x_dim*(N-1)``, ``x_dim``, ``x_name``, ``f``.  All members
     of one vector evaluate through a shared batched context (``ensemble``)."""
 
-    def __init__(self, core, i, x_name, G_drift, G_drives, u_name, sig, pade_order):
+    def __init__(self, core, i, x_name, G_drift, G_drives, u_name, sig):
         self.ensemble, self.member = core, i
         self.x_name, self.x_names, self.u_name = x_name, [x_name], u_name
         self.G_drift, self.G_drives = G_drift, G_drives
-        self._sig, self.pade_order = sig, pade_order
+        self._sig = sig
         self._view = _MemberView(core, i)
         self.x_dim = core.ctx.x_dim
         self.dim = core.per_rows
@@ -591,6 +623,10 @@ class HipPadeMemberIntegrator:
     def ctx(self):
         return self._view
 
+    @property
+    def pade_order(self):  # (read from the shared context: never a stale copy of the constructor's argument)
+        return self.ensemble.ctx.pade_order
+
     _check = HipPadeIntegrator._check
 
     def f(self, x_next, x, u, dt):
@@ -599,7 +635,7 @@ class HipPadeMemberIntegrator:
         if self._f_ctx is None:
             self._f_ctx = _PclContext(d=c.d, m=c.m, N=2, z_dim=c.x_dim + 1 + c.m, u_off=c.x_dim + 1, dt_off=c.x_dim, x_offs=[0],
                                       G0=self.G_drift, Gj=self.G_drives, batch=1, batch_mode=PCL_BATCH_MEMBERS,
-                                      state_cols=self.ensemble.fused._state_cols, pade_order=self.pade_order)  # fmt: skip
+                                      state_cols=self.ensemble.fused._state_cols, pade_order=_resolved_order(c))  # fmt: skip
         z = np.zeros((2, c.x_dim + 1 + c.m))
         z[0, : c.x_dim], z[0, c.x_dim], z[0, c.x_dim + 1 :] = x, dt, np.asarray(u)[: c.m]
         z[1, : c.x_dim] = x_next
@@ -618,7 +654,7 @@ class HipPadeMultistart:
     seeds; BASELINE.json config 5).  Not a reference type: the reference has no multistart
     facility; each seed is its own NLP and owns rows/columns ``b``-major."""
 
-    def __init__(self, G_drift, G_drives, traj, batch, x_name=STATE, u_name="u", *, device=0, index_base=0, pade_order=4):
+    def __init__(self, G_drift, G_drives, traj, batch, x_name=STATE, u_name="u", *, device=0, index_base=0, pade_order=0, order_tol=1e-10):
         G_drives = np.asarray(G_drives, dtype=np.float64)
         n = np.asarray(G_drift).shape[-1]
         m = G_drives.shape[0] if G_drives.size else 0
@@ -631,6 +667,8 @@ class HipPadeMultistart:
             Gj=G_drives.reshape(m, n, n), batch=batch, batch_mode=PCL_BATCH_TRAJ, device=device, index_base=index_base,
             state_cols=xlen // n, pade_order=pade_order,
         )  # fmt: skip
+        if pade_order == 0:  # (decided from the bounds, else from `traj` -- the shape-defining seed -- as HipPadeIntegrator does)
+            _decide_order(self._ctx, traj, u_name, m, order_tol, batch)
         self.batch = batch
         self.x_name = x_name
         self.x_dim = self._ctx.x_dim
@@ -722,7 +760,7 @@ def BilinearIntegrator(system, traj, x_name=None, u_name="u", **kw):
         def fused_members(idx):  # one batched context over the (member, sub-state) pairs `idx` that share drive generators
             fused = HipPadeIntegrator(np.array([systems[owner[j]].G_drift for j in idx]), Gd[owner[idx[0]]], traj, [flat[j] for j in idx], u_name, **kw)
             core = _EnsembleCore(fused, len(idx))
-            return [HipPadeMemberIntegrator(core, a, flat[j], systems[owner[j]].G_drift, fused.G_drives, u_name, fused._sig, fused.pade_order)
+            return [HipPadeMemberIntegrator(core, a, flat[j], systems[owner[j]].G_drift, fused.G_drives, u_name, fused._sig)
                     for a, j in enumerate(idx)]  # fmt: skip
 
         if all(np.array_equal(Gd[0], g) for g in Gd[1:]):

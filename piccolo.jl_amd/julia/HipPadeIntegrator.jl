@@ -133,10 +133,28 @@ function _generators(sys)
     return G0, Gj
 end
 
-# pcl_set_order_policy with dt_max and |u|_max from traj.bounds (both bounds must exist; otherwise the first trajectory the
-# host-pointer entry points see decides, include/piccolo_hip.h).  Returns the order in use (0: not decided yet).
+# The order in use, asked of the context (never a cached copy of a constructor argument): 0 = not decided yet.
+function _order_in_use(core::PclCore)
+    v = Ref{Int64}(0)
+    check(core.ctx, ccall((:pcl_get_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Ref{Int64}), core.ctx, "pade_order", v))
+    return Int(v[])
+end
+
+# pade_order = 0 (the default): pcl_set_order_policy with dt_max and |u|_max from traj.bounds when both bounds exist, else
+# pcl_set_order_from_trajectory on the trajectory the integrator is constructed with (theta = 1.5 max_k |dt_k G(u_k)|).  Either way the
+# order is decided HERE, so B.f, evaluate! and eval_jacobian evaluate one and the same constraint from the first call on.
+function _decide_order!(core::PclCore, traj::NamedTrajectory, u_name::Symbol, m::Int, tol::Float64)
+    order = _order_from_bounds!(core, traj, u_name, m, tol)
+    order != 0 && return order
+    Z = Vector{Float64}(traj.datavec)
+    out = Ref{Int32}(0)
+    GC.@preserve Z check(core.ctx, ccall((:pcl_set_order_from_trajectory, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Float64, Ref{Int32}),
+                                         core.ctx, Z, tol, out))
+    return Int(out[])
+end
+
 function _order_from_bounds!(core::PclCore, traj::NamedTrajectory, u_name::Symbol, m::Int, tol::Float64)
-    (haskey(traj.bounds, u_name) && haskey(traj.bounds, traj.timestep)) || return 0
+    (m > 0 && haskey(traj.bounds, u_name) && haskey(traj.bounds, traj.timestep)) || return 0
     ub = traj.bounds[u_name]; tb = traj.bounds[traj.timestep]
     umax = Float64[max(abs(ub[1][j]), abs(ub[2][j])) for j in 1:m]
     dtmax = Float64(maximum(abs, vcat(collect(tb[1]), collect(tb[2]))))
@@ -147,14 +165,16 @@ function _order_from_bounds!(core::PclCore, traj::NamedTrajectory, u_name::Symbo
 end
 
 function _integrators(G0s, Gj, traj::NamedTrajectory, names::Vector{Symbol}, u_name::Symbol;
-                      state_cols::Integer = 0, pade_order::Integer = 4, order_tol::Float64 = 1e-10, kwargs...)
+                      state_cols::Integer = 0, pade_order::Integer = 0, order_tol::Float64 = 1e-10, kwargs...)
     x_offs = Int32[traj.components[nm][1] - 1 for nm in names]
     core, n_vars = _create_core(G0s, Gj, traj.N, traj.dim, traj.components[u_name][1] - 1,
                                 traj.components[traj.timestep][1] - 1, x_offs, traj.global_dim;
                                 state_cols = state_cols, pade_order = pade_order, kwargs...)
-    if pade_order == 0   # the smallest order that matches the reference's exp constraint to order_tol over the trajectory's bounds
-        pade_order = _order_from_bounds!(core, traj, u_name, length(Gj), order_tol)
-    end
+    # pade_order = 0 (default): the smallest order that matches the reference's exp constraint [REF docs/src/concepts/index.md:21] to
+    # order_tol over the trajectory's bounds (else over the trajectory itself); 2 ... 10 pins the order (BASELINE's metric is quoted on 4)
+    pade_order == 0 && _decide_order!(core, traj, u_name, length(Gj), order_tol)
+    pade_order = _order_in_use(core)   # read back: the struct never holds a stale 0
+    pade_order == 0 && error("HipPadeIntegrator: the Pade order could not be decided")
     Bs = HipPadeIntegrator[]
     for (i, nm) in enumerate(names)
         jr, jc, hr, hc = _member_structure(core, i)
@@ -370,7 +390,7 @@ function _f(B::HipPadeIntegrator, x_next::AbstractVector, x::AbstractVector, u::
     fc = getfield(B, :fcore)
     if fc === nothing
         fc, _ = _create_core([getfield(B, :G0)], Gj, 2, xd + 1 + m, xd + 1, xd, Int32[0], 0;
-                             state_cols = getfield(B, :state_cols), pade_order = getfield(B, :pade_order))
+                             state_cols = getfield(B, :state_cols), pade_order = _order_in_use(getfield(B, :core)))   # the main context's order, read back
         setfield!(B, :fcore, fc)
     end
     z = zeros(2 * (xd + 1 + m))
@@ -384,8 +404,10 @@ end
 function Base.getproperty(B::HipPadeIntegrator, s::Symbol)
     s === :f && return (x_next, x, u, Δt) -> _f(B, x_next, x, u, Δt)
     s === :ctx && return getfield(B, :core).ctx
+    s === :pade_order && return _order_in_use(getfield(B, :core))   # asked of the context: never a stale copy
     return getfield(B, s)
 end
+Base.propertynames(B::HipPadeIntegrator, private::Bool = false) = (fieldnames(HipPadeIntegrator)..., :f, :ctx)
 
 export HipPadeIntegrator
 end # module

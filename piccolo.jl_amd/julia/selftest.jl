@@ -3,9 +3,12 @@
 #     PICCOLO_HIP_LIB=/path/to/libpiccolo_hip.so julia --project=<env with Piccolo> selftest.jl
 #
 # NOT EXECUTED in the build container (no Julia there).  What it does, in order:
-#   1. prints the DirectTrajOpt version and every DirectTrajOpt name that looks like part of the integrator interface
-#      (the glue had to GUESS some of them: the package is not vendored with Piccolo) together with the methods defined
-#      for DirectTrajOpt.BilinearIntegrator -- compare with the section "names to be matched" of HipPadeIntegrator.jl;
+#   1. prints the DirectTrajOpt version and every DirectTrajOpt name that looks like part of the integrator interface, then CHECKS the
+#      installed interface against dto_interface_expected.jl and FAILS (error, exit code 1) when
+#        * a required role (evaluate!, eval_jacobian, test_integrator) has no generic or HipPadeIntegrator no method of the listed shape,
+#        * an optional role's generic exists in the installed DirectTrajOpt but the binder attached nothing to it,
+#        * DirectTrajOpt implements a function for its own BilinearIntegrator that has no method accepting a HipPadeIntegrator in the
+#          same argument position (constructors and Base.show aside) -- the list of exactly what the glue still has to provide;
 #   2. checks the glue with DirectTrajOpt's own `test_integrator` (the finite-difference gate the reference applies to
 #      its integrators, [REF src/control/integrators.jl:359,382,413]);
 #   3. compares `evaluate!` / `eval_jacobian` of the glue with DirectTrajOpt's BilinearIntegrator on the same trajectory:
@@ -32,6 +35,46 @@ for mth in methodswith(DirectTrajOpt.BilinearIntegrator; supertypes = true)
     println("  ", mth)
 end
 println("\n-- fields of DirectTrajOpt.BilinearIntegrator --\n  ", fieldnames(DirectTrajOpt.BilinearIntegrator))
+
+# ---- the interface check: red / green in one command ------------------------------------------------------------------------------
+include(joinpath(@__DIR__, "dto_interface_expected.jl"))
+println("\n-- generics the binder attached methods to --\n  ", HipPade.BOUND_GENERICS)
+problems = String[]
+_shape(sh) = Tuple{map(a -> a === :B ? HipPade.HipPadeIntegrator : (a === :traj ? NamedTrajectory : a), sh)...}
+for e in DTO_EXPECTED_INTERFACE
+    defined = [nm for nm in e.names if isdefined(DirectTrajOpt, nm)]
+    if isempty(defined)
+        e.required && push!(problems, "role $(e.role): DirectTrajOpt $(pkgversion(DirectTrajOpt)) defines none of $(e.names)  [pin: $(e.pin)]")
+        continue
+    end
+    ok = any(nm -> hasmethod(getfield(DirectTrajOpt, nm), _shape(e.shape)) ||
+                   (e.role == :hessian_values && hasmethod(getfield(DirectTrajOpt, nm), Tuple{AbstractVector{Float64},HipPade.HipPadeIntegrator,NamedTrajectory,AbstractVector{Float64}})),
+             defined)
+    ok || push!(problems, "role $(e.role): $(defined) exist in DirectTrajOpt but none has a method of shape $(e.shape) for HipPadeIntegrator  [pin: $(e.pin)]")
+end
+# every function DirectTrajOpt implements for its own BilinearIntegrator must answer a HipPadeIntegrator in the same position
+for mth in methodswith(DirectTrajOpt.BilinearIntegrator; supertypes = false)
+    mth.name in (:BilinearIntegrator, :show, :print, :summary) && continue
+    f = try getfield(mth.module, mth.name) catch; nothing end
+    f isa Function || continue
+    sig = Base.unwrap_unionall(mth.sig)
+    params = collect(sig.parameters)[2:end]
+    any(p -> p isa Type && p <: DirectTrajOpt.BilinearIntegrator, params) || continue
+    swapped = map(p -> (p isa Type && p <: DirectTrajOpt.BilinearIntegrator) ? HipPade.HipPadeIntegrator : (p isa TypeVar ? Any : p), params)
+    hasmethod(f, Tuple{swapped...}) || push!(problems, "$(mth.module).$(mth.name)$(Tuple(params)) has no counterpart accepting a HipPadeIntegrator")
+end
+let B0 = HipPadeIntegrator(UnitaryTrajectory(QuantumSystem(GATES[:Z], [GATES[:X], GATES[:Y]], [1.0, 1.0]),
+                                              ZeroOrderPulse(zeros(2, 5), collect(range(0, 1.0, length = 5))), GATES[:X]), 5)
+    for pr in DTO_EXPECTED_PROPERTIES
+        hasproperty(B0, pr) || push!(problems, "property $pr is read by the reference and missing on HipPadeIntegrator")
+    end
+end
+if !isempty(problems)
+    println("\n== INTERFACE CHECK FAILED ==")
+    foreach(p -> println("  * ", p), problems)
+    error("HipPadeIntegrator does not yet answer the installed DirectTrajOpt's integrator interface ($(length(problems)) item(s) above)")
+end
+println("\n== interface check passed: every role of dto_interface_expected.jl is answered ==")
 
 @testset "HipPadeIntegrator vs DirectTrajOpt" begin
     # the reference's own dispatch test case [REF src/control/integrators.jl:335-360]

@@ -20,7 +20,7 @@ def main():
     torch.cuda.set_stream(stream)
     for batch in (8, 1):
         trajs = [synthetic.synthetic_trajectory(system, 100, seed=1000 + i) for i in range(batch)]
-        ms = pa.HipPadeMultistart(G0, Gj, trajs[0], batch)
+        ms = pa.HipPadeMultistart(G0, Gj, trajs[0], batch, pade_order=4)
         c = ms.ctx
         c.set_stream(stream.cuda_stream)
         Zd = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()

@@ -33,7 +33,7 @@ for order in (6, 8, 10):
     print("order", order, "jac kernel", jk, "residual kernel", c.get_option("last_kernel"), "hess kernel", c.get_option("last_hess_kernel"), flush=True)
     it.close()
     del dd, vd, hv, mu
-it = pa.HipPadeIntegrator(G0, Gj, t0)
+it = pa.HipPadeIntegrator(G0, Gj, t0, pade_order=4)
 c = it.ctx
 roll = torch.empty(t0.N * 2 * system.levels ** 2, dtype=torch.float64, device="cuda")
 for _ in range(REP):

@@ -37,7 +37,7 @@ def solve(N=50, T=10.0, Q=100.0, R=1e-2, seed=0, max_iter=300, verbose=0, exact_
         if k + 1 < N:
             U = scipy.linalg.expm(-1j * (times[k + 1] - times[k]) * system.H(u0[:, k])) @ U
     traj = pa.unitary_trajectory(system, u0, times, U_goal, states=states)
-    B = pa.BilinearIntegrator(system, traj)
+    B = pa.BilinearIntegrator(system, traj, pade_order=4)
     rows = [B, pa.DerivativeIntegrator("u", "du", traj, like=B), pa.DerivativeIntegrator("du", "ddu", traj, like=B),
             pa.DerivativeIntegrator("t", None, traj, like=B)]  # fmt: skip
     nv = traj.dim * traj.N

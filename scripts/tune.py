@@ -35,7 +35,7 @@ abytes = (zd * 8 + 2 * d * d * 8 + (2 * d * 4 * d * d + 2 * d * d * (m + 1)) * 8
 stream = torch.cuda.Stream()
 with torch.cuda.stream(stream):
     for B in args.batch:
-        ms = pa.HipPadeMultistart(G0, Gj, trajs[0], B)
+        ms = pa.HipPadeMultistart(G0, Gj, trajs[0], B, pade_order=4)
         c = ms.ctx
         c.set_stream(stream.cuda_stream)
         Zd = torch.from_numpy(np.stack([t.datavec for t in trajs[:B]])).cuda()

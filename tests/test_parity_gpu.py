@@ -158,7 +158,7 @@ def test_integrator_interface_pins():
     N = 10
     rng = np.random.default_rng(0)
     t = pa.unitary_trajectory(s, 0.02 * rng.standard_normal((4, N)), np.linspace(0, 1, N), pa.GATES["CX"])
-    B = pa.BilinearIntegrator(s, t)
+    B = pa.BilinearIntegrator(s, t, pade_order=4)
     assert B.x_dim == 32 and B.dim == 32 * (N - 1) and B.x_name == "Ũ⃗" and B.x_names == ["Ũ⃗"]
     delta = np.zeros(B.dim)
     pa.evaluate_(delta, B, t)
@@ -182,7 +182,7 @@ def test_test_integrator_style_finite_differences():
     rng = np.random.default_rng(5)
     states = [np.linalg.qr(rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2)))[0] for _ in range(N)]
     t = pa.unitary_trajectory(s, 0.3 * rng.standard_normal((2, N)), np.cumsum(0.1 + 0.05 * rng.random(N)), pa.GATES["X"], states=states)
-    B = pa.BilinearIntegrator(s, t)
+    B = pa.BilinearIntegrator(s, t, pade_order=4)
     J = pa.eval_jacobian(B, t).toarray()
     z0 = t.datavec.copy()
 
@@ -245,7 +245,7 @@ def test_reference_solved_ensembles(name, golden, golden_meta):
     M = len(systems)
     psys = [pa.QuantumSystem(s.H_drift, s.H_drives, [1.0, 1.0]) for s in systems]
     traj = traj_from_Z(pa, Z, lay, n_members=M)
-    Bs = pa.BilinearIntegrator(psys, traj)
+    Bs = pa.BilinearIntegrator(psys, traj, pade_order=4)
     assert isinstance(Bs, list) and len(Bs) == M
     core = Bs[0].ensemble
     per_d, per = lay.x_dim * lay.K, po.jac_nnz_per_interval(lay) * lay.K
@@ -308,7 +308,7 @@ def test_ensemble_with_per_member_drive_generators():
     osys = [po.quantum_system(0.5 * po.PAULIS["Z"], [(1 + 0.02 * i) * po.PAULIS["X"], po.PAULIS["Y"]], [1.0, 1.0]) for i in range(M)]
     psys = [pa.QuantumSystem(s.H_drift, s.H_drives, [1.0, 1.0]) for s in osys]
     traj = traj_from_Z(pa, Z, lay, n_members=M)
-    Bs = pa.BilinearIntegrator(psys, traj)
+    Bs = pa.BilinearIntegrator(psys, traj, pade_order=4)
     assert isinstance(Bs, list) and len(Bs) == M
     for i, (B, s) in enumerate(zip(Bs, osys)):
         assert B.x_name == "Ũ⃗%d" % (i + 1) and B.dim == lay.x_dim * lay.K
@@ -412,7 +412,7 @@ def test_multistart_batch_matches_single():
         Z, lay = po.synthetic_trajectory(so, N, seed=1000 + s)
         Zs.append(Z)
     t = traj_from_Z(pa, Zs[0], lay)
-    ms = pa.HipPadeMultistart(G0, Gj, t, Bn)
+    ms = pa.HipPadeMultistart(G0, Gj, t, Bn, pade_order=4)
     delta, vals = ms.ctx.eval_jac(np.stack(Zs))
     per_d, per_j = lay.x_dim * lay.K, po.jac_nnz_per_interval(lay) * lay.K
     for s in range(Bn):
@@ -502,7 +502,7 @@ def test_ensemble_merit_and_shared_gradient_on_device():
     osys = [po.System(base.H_drift + 0.01 * i * np.diag(np.arange(d)).astype(complex), base.H_drives, base.drive_bounds) for i in range(M)]
     psys = [pa.QuantumSystem(s.H_drift, s.H_drives, [b[1] for b in s.drive_bounds]) for s in osys]
     traj = traj_from_Z(pa, Z, lay, n_members=M)
-    B = pa.BilinearIntegrator(psys, traj)[0].ensemble.fused  # the batched context the per-member integrators share
+    B = pa.BilinearIntegrator(psys, traj, pade_order=4)[0].ensemble.fused  # the batched context the per-member integrators share
     Zd = torch.from_numpy(traj.datavec).cuda()
     dd = torch.empty(B.dim, dtype=torch.float64, device="cuda")
     vd = torch.empty(B.ctx.jac_nnz, dtype=torch.float64, device="cuda")
@@ -583,7 +583,7 @@ def test_derivative_and_time_consistency_rows(golden, golden_meta):
     systems, lay, _ = ref_case("two_qubit_zoh", golden_meta)
     Z = golden("ref_two_qubit_zoh")["Z"]
     traj = traj_from_Z(pa, Z, lay)
-    B = pa.BilinearIntegrator(product_system(2), traj)
+    B = pa.BilinearIntegrator(product_system(2), traj, pade_order=4)
     m = lay.m
     for x, dx in (("u", "du"), ("du", "ddu")):
         D = pa.DerivativeIntegrator(x, dx, traj, like=B)
@@ -649,7 +649,7 @@ def test_terminal_infidelity_objective_on_device():
         Z, lay = po.synthetic_trajectory(so, N, seed=50 + s_, noise=5e-2)
         Zs.append(Z)
     t = traj_from_Z(pa, Zs[0], lay)
-    ms = pa.HipPadeMultistart(so.G_drift, np.array(so.G_drives), t, Bn)
+    ms = pa.HipPadeMultistart(so.G_drift, np.array(so.G_drives), t, Bn, pade_order=4)
     Ug = po.PAULIS["X"]
     Ug = np.kron(np.diag([1, 0]), np.eye(2)) + np.kron(np.diag([0, 1]), Ug)  # CX
     Ug = Ug @ np.diag(np.exp(1j * rng.random(d)))
@@ -698,7 +698,7 @@ def test_subspace_fidelity_regularisers_and_weighted_ensemble_objective():
     comps["u"], comps["du"], comps["ddu"] = Z[:, o + 2 : o + 2 + m].T, Z[:, o + 2 + m : o + 2 + 2 * m].T, Z[:, o + 2 + 2 * m :].T
     traj = pa.NamedTrajectory(comps, controls=("ddu", "Δt"), timestep="Δt")
     assert np.array_equal(traj.datavec, Z.reshape(-1))
-    Bs = pa.BilinearIntegrator(psys, traj)
+    Bs = pa.BilinearIntegrator(psys, traj, pade_order=4)
     w = np.array([0.5, 0.3, 0.2])
     Q = 100.0
     Ru, Rdu, Rddu = 1e-2, np.linspace(0.5, 2.0, m), 3.0
@@ -736,7 +736,7 @@ def test_subspace_fidelity_regularisers_and_weighted_ensemble_objective():
         Zq[:, :xd] = Z[:, q * xd : (q + 1) * xd]
     lay1 = po.Layout.smooth_pulse(d, m, N)
     t1 = traj_from_Z(pa, Zs[0], lay1)
-    ms = pa.HipPadeMultistart(osys[0].G_drift, np.array(osys[0].G_drives), t1, 2)
+    ms = pa.HipPadeMultistart(osys[0].G_drift, np.array(osys[0].G_drives), t1, 2, pade_order=4)
     J1 = (pa.UnitaryInfidelityObjective(pa.EmbeddedOperator(Gs, sub, [3, 3]), "Ũ⃗", t1, Q=Q) + pa.QuadraticRegularizer("u", t1, Ru)).bind(ms)
     vals, grads = J1.value_and_gradient(np.stack(Zs))
     for q, Zq in enumerate(Zs):
@@ -772,7 +772,7 @@ def test_ket_variant(d, m, N):
              "du": Z[:, xd + 2 + m : xd + 2 + 2 * m].T, "ddu": Z[:, xd + 2 + 2 * m :].T}  # fmt: skip
     traj = pa.NamedTrajectory(comps, controls=("ddu", "Δt"), timestep="Δt")
     assert np.array_equal(traj.datavec, Z.reshape(-1))
-    B = pa.BilinearIntegrator(psys, traj, x_name="ψ̃")
+    B = pa.BilinearIntegrator(psys, traj, x_name="ψ̃", pade_order=4)
     assert B.x_dim == n and B.dim == n * (N - 1) and B.ctx.jac_per == 2 * n * n + n * (m + 1)
     delta = pa.evaluate_(np.zeros(B.dim), B, traj)
     close(delta, po.pade_residual(Z, lay, G0, Gj, 4), 1e-11)
@@ -854,7 +854,7 @@ def test_contiguous_column_ranges_any_grid():
     for s in range(Bn):
         Z, lay = po.synthetic_trajectory(so, N, seed=300 + s)
         Zs.append(Z)
-    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn)
+    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn, pade_order=4)
     c = ms.ctx
     refs = [ref_lib.eval_jac(Z, lay, G0, Gj) for Z in Zs]
     d_ref = np.concatenate([r[0].reshape(-1) for r in refs])
@@ -896,7 +896,7 @@ def test_config5_share_default_path(Bn):
     for s in range(Bn):
         Z, lay = po.synthetic_trajectory(so, N, seed=1000 + s)
         Zs.append(Z)
-    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn)
+    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn, pade_order=4)
     c = ms.ctx
     c.set_option("host_path", 1)  # the full-values launch (the default host delivery launches the compact kernel)
     delta, vals = c.eval_jac(np.stack(Zs))
@@ -1229,7 +1229,7 @@ def test_ket_coherent_ket_and_density_objectives_on_the_device():
     comps["Δt"], comps["t"], comps["u"] = Z[:, Kk * n][None], Z[:, Kk * n + 1][None], Z[:, Kk * n + 2 :].T
     traj = pa.NamedTrajectory(comps, controls=("u", "Δt"), timestep="Δt")
     names = ["ψ̃%d" % (i + 1) for i in range(Kk)]
-    B = pa.HipPadeIntegrator(G0, Gj, traj, names)
+    B = pa.HipPadeIntegrator(G0, Gj, traj, names, pade_order=4)
     goals = [(lambda v: v / np.linalg.norm(v))(rng.standard_normal(d) + 1j * rng.standard_normal(d)) for _ in range(Kk)]
     Q, Ru = 100.0, np.array([0.3, 0.7])
     u_off, dt_off = Kk * n + 2, Kk * n
@@ -1285,7 +1285,7 @@ def test_ket_coherent_ket_and_density_objectives_on_the_device():
           "u": rng.standard_normal((1, Nl)), "Δt": np.full((1, Nl), 0.1)}  # fmt: skip
     t2 = pa.NamedTrajectory(c2, controls=("u", "Δt"), timestep="Δt")
     s2 = po.quantum_system(np.diag([0.0, 1.0]).astype(complex), [np.array([[0, 1], [1, 0]], complex)], [1.0])
-    B2 = pa.HipPadeIntegrator(s2.G_drift, np.array(s2.G_drives), t2, ["ψ̃1", "ψ̃2"])
+    B2 = pa.HipPadeIntegrator(s2.G_drift, np.array(s2.G_drives), t2, ["ψ̃1", "ψ̃2"], pade_order=4)
     for wts, F in (([0.9, 0.1], 0.9025), ([0.1, 0.9], 0.3025)):
         v, _ = pa.Objective([pa.CoherentKetInfidelityObjective([psi1, psi0], ["ψ̃1", "ψ̃2"], t2, Q=100.0, weights=wts)]).bind(B2).value_and_gradient(t2)
         assert abs(v - 100.0 * (1 - F)) < 1e-12
@@ -1302,7 +1302,7 @@ def test_ket_coherent_ket_and_density_objectives_on_the_device():
     psi /= np.linalg.norm(psi)
     times = np.cumsum(np.concatenate(([0.0], 0.05 + 0.05 * rng.random(N - 1))))
     trd = pa.density_trajectory(sys_, 0.5 * rng.standard_normal((1, N)), times, np.outer(psi, psi.conj()), np.outer(psi, psi.conj()))
-    Bd = pa.BilinearIntegrator(sys_, trd)
+    Bd = pa.BilinearIntegrator(sys_, trd, pade_order=4)
     gpsi = rng.standard_normal(nl) + 1j * rng.standard_normal(nl)
     gpsi /= np.linalg.norm(gpsi)
     Mg = rng.standard_normal((nl, nl)) + 1j * rng.standard_normal((nl, nl))
@@ -1335,7 +1335,7 @@ def test_objective_hessian_of_the_unitary_problem(sub):
     Z, lay = po.synthetic_trajectory(so, N, seed=3)
     Z[:, lay.dt_off] = 0.1 + 0.05 * rng.random(N)
     traj = traj_from_Z(pa, Z, lay)
-    B = pa.HipPadeIntegrator(G0, Gj, traj)
+    B = pa.HipPadeIntegrator(G0, Gj, traj, pade_order=4)
     if sub:
         idx = pa.get_subspace_indices([[0, 1], [0]], [2, 2])
         Us = np.linalg.qr(rng.standard_normal((len(idx), len(idx))) + 1j * rng.standard_normal((len(idx), len(idx))))[0]
@@ -1387,7 +1387,7 @@ def test_objective_hessian_of_the_unitary_problem(sub):
     # a multistart batch: one block per seed, offset by the seed's variables
     S = 3
     Zs = [po.synthetic_trajectory(so, N, seed=40 + q)[0] for q in range(S)]
-    ms = pa.HipPadeMultistart(G0, Gj, traj, S)
+    ms = pa.HipPadeMultistart(G0, Gj, traj, S, pade_order=4)
     Jm = (pa.UnitaryInfidelityObjective(goal, "Ũ⃗", traj, Q=Q) + pa.QuadraticRegularizer("u", traj, 1e-2, 2)).bind(ms)
     rows, cols = Jm.hessian_structure()
     vals = Jm.hessian(np.stack(Zs), 1.0)
@@ -1708,7 +1708,7 @@ def test_rollout_interface_ensemble_ket_and_large_steps():
     G0, Gj = so.G_drift, np.array(so.G_drives)
     psys = product_system(3)
     traj = traj_from_Z(pa, Z, lay)
-    B = pa.BilinearIntegrator(psys, traj)
+    B = pa.BilinearIntegrator(psys, traj, pade_order=4)
     X = pa.unitary_rollout(B, traj)
     assert X.shape == (lay.x_dim, lay.N)
     close(X.T, po.exact_rollout(Z, lay, G0, Gj), 1e-10)
@@ -1723,7 +1723,7 @@ def test_rollout_interface_ensemble_ket_and_large_steps():
     ZE = 0.3 * rng.standard_normal((9, layE.z_dim))
     ZE[:, layE.dt_off] = 0.1 + 0.1 * rng.random(9)
     trajE = traj_from_Z(pa, ZE, layE, n_members=M)
-    BEs = pa.BilinearIntegrator([pa.QuantumSystem(s_.H_drift, s_.H_drives, [1.0, 1.0]) for s_ in systems], trajE)
+    BEs = pa.BilinearIntegrator([pa.QuantumSystem(s_.H_drift, s_.H_drives, [1.0, 1.0]) for s_ in systems], trajE, pade_order=4)
     XE = pa.unitary_rollout(BEs[0].ensemble.fused, trajE)
     for i, s_ in enumerate(systems):
         close(XE[i].T, po.exact_rollout(ZE, layE, s_.G_drift, np.array(s_.G_drives), x_off=i * xd), 1e-11)
@@ -1765,7 +1765,7 @@ def test_multi_ket_integrator():
     traj = pa.NamedTrajectory(comps, controls=("u", "Δt"), timestep="Δt")
     assert np.array_equal(traj.datavec, Z.reshape(-1))
     names = ["ψ̃%d" % (i + 1) for i in range(Kk)]
-    B = pa.HipPadeIntegrator(G0, Gj, traj, names)
+    B = pa.HipPadeIntegrator(G0, Gj, traj, names, pade_order=4)
     assert B.dim == Kk * n * (N - 1)
     delta, vals = B.ctx.eval_jac(traj.datavec)
     rows, cols = pa.jacobian_structure(B)
@@ -1830,7 +1830,7 @@ def test_sampling_over_density_and_multi_state_bases(base):
     traj = pa.NamedTrajectory(comps, controls=("u", "Δt"), timestep="Δt")
     assert np.array_equal(traj.datavec, Z.reshape(-1))
     lay = po.Layout(m=m, N=N, z_dim=z_dim, x_off=0, u_off=o + 2, dt_off=o, **lay_kw)
-    Bs = pa.BilinearIntegrator(systems, traj, x_name=names if subs > 1 or dens else names)
+    Bs = pa.BilinearIntegrator(systems, traj, x_name=names if subs > 1 or dens else names, pade_order=4)
     assert len(Bs) == n_states and len({id(b.ensemble) for b in Bs}) == 1
     flat = [nm for p_ in names for nm in ([p_] if isinstance(p_, str) else p_)]
     for q, B in enumerate(Bs):
@@ -1931,7 +1931,7 @@ def _config4_share(M, N, first=0):
 def _fused_ensemble(psys, traj):
     """One batched context for all members (what the per-member integrators of BilinearIntegrator([...]) share)."""
     names = ["Ũ⃗%d" % (i + 1) for i in range(len(psys))]
-    return pa.HipPadeIntegrator(np.array([s.G_drift for s in psys]), psys[0].G_drives_array(), traj, names)
+    return pa.HipPadeIntegrator(np.array([s.G_drift for s in psys]), psys[0].G_drives_array(), traj, names, pade_order=4)
 
 
 @pytest.mark.parametrize("M", [4, 8])
@@ -2078,7 +2078,7 @@ def test_ensemble_step_in_two_launches_equals_the_separate_calls(M, N):
     import torch
 
     osys, psys, lay, Z, traj = _config4_share(M, N)
-    Bs = pa.BilinearIntegrator(psys, traj)
+    Bs = pa.BilinearIntegrator(psys, traj, pade_order=4)
     c = Bs[0].ensemble.ctx
     c.set_stream(torch.cuda.current_stream().cuda_stream)
     d = lay.d
@@ -2137,7 +2137,7 @@ def test_ensemble_step_in_two_launches_equals_the_separate_calls(M, N):
         lay1 = po.Layout.smooth_pulse(d, lay.m, N)
         Zs = [po.synthetic_trajectory(po.config_system(3), N, seed=300 + q)[0] for q in range(S)]
         t1 = traj_from_Z(pa, Zs[0], lay1)
-        ms = pa.HipPadeMultistart(osys[0].G_drift, np.array(osys[0].G_drives), t1, S)
+        ms = pa.HipPadeMultistart(osys[0].G_drift, np.array(osys[0].G_drives), t1, S, pade_order=4)
         c = ms.ctx
         c.set_stream(torch.cuda.current_stream().cuda_stream)
         J = (pa.UnitaryInfidelityObjective(U, "Ũ⃗", t1, Q=100.0) + pa.QuadraticRegularizer("u", t1, 1e-2) + pa.QuadraticRegularizer("ddu", t1, 1e-2)).bind(ms)
@@ -2463,7 +2463,7 @@ def test_host_delivery_paths_agree_bitwise():
     for s in range(Bn):
         Z, lay = po.synthetic_trajectory(so, N, seed=900 + s)
         Zs.append(Z)
-    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn)
+    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn, pade_order=4)
     c = ms.ctx
     c.set_option("host_path", 1)
     d_full, v_full = c.eval_jac(np.stack(Zs))
@@ -2527,7 +2527,7 @@ def test_residual_only_kernel():
         Z, lay = po.synthetic_trajectory(so, N, seed=400 + s)
         Z[:, lay.dt_off] = 0.08 + 0.04 * rng.random(N)
         Zs.append(Z)
-    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn)
+    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn, pade_order=4)
     c = ms.ctx
     ref = np.concatenate([po.pade_residual(Z, lay, G0, Gj, 4).reshape(-1) for Z in Zs])
     c.set_option("eval_kernel", 1)  # the matrix-core residual kernel (any generators)
@@ -2571,7 +2571,7 @@ def test_residual_only_kernel():
     ms.close()
     big = [po.synthetic_trajectory(so, 100, seed=500 + s)[0] for s in range(3)]  # full size, auto
     layb = po.synthetic_trajectory(so, 100, seed=500)[1]
-    msb = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, big[0], layb), 3)
+    msb = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, big[0], layb), 3, pade_order=4)
     db = msb.ctx.eval(np.stack(big))
     assert msb.ctx.get_option("last_kernel") == 82
     close(db, np.concatenate([po.pade_residual(Z, layb, G0, Gj, 4).reshape(-1) for Z in big]))
