@@ -24,14 +24,14 @@ for what in whats:
         assert rc == 0, L.pcl_last_error(None).decode()
         for f in glob.glob(td + "/*.hsaco"):
             blob = open(f, "rb").read()
-            n = int.from_bytes(blob[4:8], "little")
+            n = int.from_bytes(blob[4:8], "little")  # "PCL2" | u32 name length | u64 code length | u64 checksum | name | code
             co = f + ".co"
-            open(co, "wb").write(blob[8 + n:])
+            open(co, "wb").write(blob[24 + n:])
             notes = subprocess.run([readelf, "--notes", co], capture_output=True, text=True).stdout
             keep = [l.strip() for l in notes.splitlines() if any(k in l for k in (".vgpr_count", ".sgpr_count", "spill_count", ".group_segment_fixed_size", ".private_segment_fixed_size", ".name:"))]
             secs = subprocess.run([readelf, "-S", co], capture_output=True, text=True).stdout
             text = [l for l in secs.splitlines() if " .text " in l]
             if os.environ.get("KEEP"):
-                open(os.environ["KEEP"], "wb").write(blob[8 + n:])  # the code object, for llvm-objdump -d
+                open(os.environ["KEEP"], "wb").write(blob[24 + n:])  # the code object, for llvm-objdump -d
             print("what %d:" % what, "; ".join(keep))
             print("   ", text[0].split()[-6:] if text else "")

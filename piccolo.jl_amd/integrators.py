@@ -98,7 +98,7 @@ class _PclContext:
 
     def set_order_policy(self, dt_max, u_max, tol=1e-10):
         """The smallest diagonal Pade order whose deviation from the reference's exp constraint, ``kappa_q theta^(2q+1)`` with
-        ``theta = dt_max (|G_drift|_2 + sum_l u_max_l |G_l|_2)``, is below ``tol``; becomes the context's order.  Returns it."""
+        ``theta = dt_max max_{|u_l| <= u_max_l} |G_drift + sum_l u_l G_l|_2`` (the maximum over the box of controls), is below ``tol``; becomes the context's order.  Returns it."""
         um = np.ascontiguousarray(np.broadcast_to(np.abs(np.asarray(u_max, dtype=np.float64)), (max(self.m, 1),)))
         out = ctypes.c_int32()
         self._L.pcl_set_order_policy.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.POINTER(ctypes.c_int32)]

@@ -30,30 +30,47 @@ def _free_port():
 
 def test_default_constructor_matches_the_exp_constraint_at_config3():
     """The drop-in's DEFAULT (no pade_order argument) is the order policy at 1e-10 [REF docs/src/concepts/index.md:21: the reference's
-    constraint is the exponential]: on BASELINE config 3's bounds (|u| <= 0.1, dt <= 0.1) it picks order 8, and a trajectory that is
-    feasible for the reference's exp constraint has |delta|_inf <= 1e-10 -- where the order-4 residual is ~1e-5.  Without bounds the order
-    is decided at construction from the trajectory, so device-pointer calls and the scalar form f work at once and agree with evaluate!."""
+    constraint is the exponential]: theta = dt_max x the maximum of |G(u)|_2 over the box of controls.  On BASELINE config 3's bounds
+    (|u| <= 0.1 on all six drives, dt <= 0.1) that is 0.686 -> order 10 (order 8 bounds the deviation by 1.3e-9 there; round 4 reported 8
+    because its norm estimate was low -- the ADVICE item), with |u| <= 0.02 order 8; a trajectory that is feasible for the reference's exp
+    constraint has |delta|_inf <= 1e-10 at the chosen order -- where the order-4 residual is ~1e-5.  Without bounds the order is decided at
+    construction from the trajectory, so device-pointer calls and the scalar form f work at once and agree with evaluate!."""
+    import itertools
+    import math
+
     import torch
 
     so = po.config_system(3)
     N = 16
     Z, lay = po.synthetic_trajectory(so, N, seed=5, noise=0.0)  # X_{k+1} = expm(dt G(u_k)) X_k exactly
     system = synthetic.config_system(3)
+    G0, Gj = system.G_drift, system.G_drives_array()
+    kappa = lambda q: math.factorial(q) ** 2 / (math.factorial(2 * q) * math.factorial(2 * q + 1))
+    want = lambda th, tol: next((2 * q for q in range(1, 6) if kappa(q) * th ** (2 * q + 1) <= tol), 10)
+    box = lambda um: 0.1 * max(np.linalg.norm(G0 + np.tensordot(um * np.array(sg), Gj, axes=1), 2) for sg in itertools.product((-1.0, 1.0), repeat=lay.m))
     traj = traj_from_Z(pa, Z, lay)
     traj.bounds["u"] = (-0.1 * np.ones(lay.m), 0.1 * np.ones(lay.m))
     traj.bounds["Δt"] = (np.array([0.05]), np.array([0.1]))
     B = pa.BilinearIntegrator(system, traj)  # default order
-    assert B.pade_order == 8 and B.ctx.order_tol_met
+    th = B.ctx.get_option("order_theta_1e9") * 1e-9
+    assert abs(th - box(0.1)) <= 1e-6 * th and 0.68 < th < 0.69, (th, box(0.1))
+    assert B.pade_order == want(th, 1e-10) == 10 and B.ctx.order_tol_met
     delta = np.empty(B.dim)
     pa.evaluate_(delta, B, traj)
     assert np.abs(delta).max() <= 1e-10, np.abs(delta).max()
+    trajs = traj_from_Z(pa, Z, lay)  # tighter drive bounds (the synthetic trajectories' own scale): order 8
+    trajs.bounds["u"] = (-0.02 * np.ones(lay.m), 0.02 * np.ones(lay.m))
+    trajs.bounds["Δt"] = (np.array([0.05]), np.array([0.1]))
+    B8 = pa.BilinearIntegrator(system, trajs)
+    assert B8.pade_order == want(box(0.02), 1e-10) == 8
+    B8.close()
     B4 = pa.BilinearIntegrator(system, traj, pade_order=4)
     d4 = B4.ctx.eval(traj.datavec)
     assert 1e-7 < np.abs(d4).max() < 1e-3  # the metric's order deviates from the reference's constraint by the truncation error
     B4.close()
     # the multistart wrapper takes the same default
     ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), traj, 2)
-    assert ms.ctx.pade_order == 8
+    assert ms.ctx.pade_order == 10
     ms.close()
     B.close()
     # no bounds: decided at construction from the trajectory (theta x 1.5), device pointers accepted immediately, f == a row block of evaluate!
