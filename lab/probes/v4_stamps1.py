@@ -15,7 +15,7 @@ try:
     with torch.cuda.stream(stream):
         t0 = synthetic.synthetic_trajectory(system, 100, seed=1000)
         Zd = torch.from_numpy(t0.datavec.copy()).cuda()
-        for order in (4, 8):
+        for order in (4, 8, 10):
             for extra in sys.argv[1:] or ["-"]:
                 opts = {} if extra == "-" else {kv.split("=")[0]: int(kv.split("=")[1]) for kv in extra.split(",")}
                 c = pa.integrators._PclContext(d=system.levels, m=m, N=t0.N, z_dim=t0.dim, u_off=t0.components["u"].start,

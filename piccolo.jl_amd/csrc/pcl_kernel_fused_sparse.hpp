@@ -226,6 +226,7 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
     // delta and the tail block of a finished item, tiles -> memory: the item's nce n residuals and its nce (m + 1) n tail values
     // are ONE contiguous run each, 1 KiB per instruction; `part` of `nparts` waves takes every nparts-th instruction.
     // tail_mode: 0 the writer wave, plain stores | 1 nontemporal | 2 write-through | 3 the stream waves, behind the item's blocks
+    const double *Wres = Wt;  // where a finished item's delta stands (the W chain's other tile for one-item launches at odd q: set below)
     auto store_outputs = [&](int c0, int nce, long long bk, int part, int nparts, int nt) {
         int l0 = lane + 64 * part;
         asm volatile("" : "+v"(l0));
@@ -233,7 +234,7 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
             double *dst = p.delta + bk * xd + (long long)c0 * n;
             for (int e2 = l0; e2 < nce * d; e2 += 64 * nparts) {
                 const int cl = e2 / d, r0 = 2 * (e2 - cl * d);
-                const double *src = Wt + cl * SP4CS + r0;
+                const double *src = Wres + cl * SP4CS + r0;
                 store2(dst + 2 * e2, src[0], src[1], nt);
             }
         }
@@ -276,6 +277,24 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
     // fifth of a one-trajectory launch).  Needs fully resident coefficients (the generator then emits the parts).  The P wave's own loop
     // starts with item 1.
     const bool coop = SP4_COOP && !(p.v4_flags & 4) && !tick;
+    // ... with ALL q powers resident even where the ring is shorter (orders 8 and 10 at config 3: three power tiles): the chains of the first
+    // item start behind the stream's folds anyway (chains_may_start), so until then their dW tiles are free -- powers npw + 1 .. q of the FIRST
+    // item live there.  No product waits for a fold, no fold for a tile (order 10 ran without the cooperative start before: five powers
+    // through three tiles were slower than a lone P wave).  Needs q - npw <= m and the chains held back (v4_flags & 16 off).
+    const bool borrow = coop && q > npw && q - npw <= m && !(p.v4_flags & 16);
+    // ONE-item workgroups (one trajectory per launch) at orders 8 and 10 are bound by the CHAINS, not by the stores: W's level s + 1 overwrites
+    // the tile the m drive waves gather level s from, so W and the dW_l advance in lock step -- q x (W product + gather + dW product), 44 k cycles
+    // at order 8 against 33 k of block stores (stamps, round 5).  With nothing behind the first item the power tiles are free once the stream has
+    // folded them: W alternates between its tile and power tile 0 and runs a level ahead of the gathers; the dW chains no longer wait for it.
+    // (measured, one trajectory per launch, with / without: order 10 29.5 / 32.0 us, order 8 27.7 / 28.1, order 6 26.2 / 25.7, order 4 equal: from order 8 on;
+    //  v4_flags & 64 switches it off)
+    const bool pingpong = coop && n_my == 1 && !(p.v4_flags & (16 | 64)) && q >= 4;
+    double *const Walt = pingpong ? Pt : Wt;                   // W after an odd number of steps
+    const double *const Wfin = (pingpong && (q & 1)) ? Pt : Wt;  // delta = W after q steps
+    Wres = Wfin;
+    auto first_tile = [&](int jm1) -> double * {  // tile of power jm1 + 1 of the workgroup's FIRST item
+        return borrow ? (jm1 < npw ? Pt + jm1 * SP4TILE : dWt + (jm1 - npw) * SP4TILE) : Pt + (jm1 % npw) * SP4TILE;
+    };
     // ... and the chains of that item start behind them: twelve waves of products on four SIMDs ran the stream's parts three times
     // slower (4.1 k cycles instead of 1.3 k), and the chains have the whole store phase to finish in
     auto chains_may_start = [&](int it) {
@@ -334,15 +353,15 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
         }
 #pragma unroll 1
         for (int j = 2; j <= q; ++j) {
-            double *Po = Pt + ((j - 1) % npw) * SP4TILE;
-            const double *Pi = Pt + ((j - 2) % npw) * SP4TILE;
+            double *Po = first_tile(j - 1);
+            const double *Pi = first_tile(j - 2);
             gave_up = sp4_wait(sync, SP4_F_CO, SP4_NPART * (j - 1), gave_up);  // every row of the previous power is in its tile
             double x[SPD];
             if (act) {
 #pragma unroll
                 for (int i = 0; i < SPD; ++i) x[i] = Pi[own + i];
             }
-            if (j > npw) {  // a ring shorter than q: the stream has folded the power this tile held ...
+            if (j > npw && !borrow) {  // a ring shorter than q: the stream has folded the power this tile held ...
                 for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_C + w, j - npw, gave_up);
                 if (npw == 1) {  // ... and with ONE tile every part has its operand in registers before a row is rewritten
                     wave_lds_sync();
@@ -480,8 +499,11 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
 #pragma unroll 1
                 for (int s = 0; s < q; ++s) {
                     const int j = q - 1 - s;
-                    if (isW) {  // every drive wave has gathered the level this product overwrites
-                        for (int l = 0; l < SPM; ++l) gave_up = sp4_wait(sync, SP4_F_G + l, it * q + s + 1, gave_up);
+                    const bool pp = isW && pingpong;  // W alternates between two tiles: this step reads `src`, writes `dst`
+                    const double *Xsrc = pp && (s & 1) ? Walt : Xt;
+                    double *Xdst = pp && !(s & 1) ? Walt : Xt;
+                    if (isW) {  // every drive wave has gathered the level this product overwrites (two tiles: the level before it)
+                        for (int l = 0; l < SPM; ++l) gave_up = sp4_wait(sync, SP4_F_G + l, it * q + s + (pp ? 0 : 1), gave_up);
                     }
                     const double alpha = sp4_uniform(((j & 1) ? -1.0 : 1.0) * p.pc[j] * (isW ? 1.0 : (double)j));
                     const double beta = sp4_uniform((!isW && j == 0) ? 1.0 : h);
@@ -489,9 +511,9 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
                     double x[SPD];  // (read right before the product: 54 registers that nothing else should have to live beside)
                     if (act) {
 #pragma unroll
-                        for (int i = 0; i < SPD; ++i) x[i] = Xt[own + i];
+                        for (int i = 0; i < SPD; ++i) x[i] = Xsrc[own + i];
                     }
-                    if (act) sp4_product(x, (j & 1) ? oS : oD, oX, oXx, alpha, beta, half ? -beta : beta, tab, cf);
+                    if (act) sp4_product(x, (j & 1) ? oS : oD, pp ? sp4_lds_off(Xdst + own) : oX, pp ? sp4_lds_off(Xdst + oth) : oXx, alpha, beta, half ? -beta : beta, tab, cf);
                     SP4_STAMP();
                     if (isW && j >= 1) sp4_post(sync + SP4_F_W, it * q + s + 2, lane);
                 }
@@ -518,7 +540,7 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
                 // level q - 1: dW = h G_l W_q
                 gave_up = sp4_wait(sync, SP4_F_W, it * q + 1, gave_up);
                 outputs_taken(it);  // the previous item has left this tile
-                if (act) {
+                if (act) {  // (step 0: W's level q stands in its own tile)
                     SP4_GATHER_SWITCH(l, Wt + own, Wt + oth, Xt + own, h, sb, mg)
                 }
                 wave_lds_sync();
@@ -534,7 +556,8 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
                     }
                     wave_lds_sync();  // (x is in registers before the gather rewrites the tile)
                     if (act) {
-                        SP4_GATHER_SWITCH(l, Wt + own, Wt + oth, Xt + own, h, sb, mg)
+                        const double *Ws = (s & 1) ? Walt : Wt;  // W after s steps
+                        SP4_GATHER_SWITCH(l, Ws + own, Ws + oth, Xt + own, h, sb, mg)
                     }
                     wave_lds_sync();
                     sp4_post(sync + SP4_F_G + l, it * q + s + 1, lane);
@@ -630,11 +653,11 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
                     for (int i = 0; i < SPD; ++i) lam[i] = act ? lg[i] : 0.0;
                 } else {
 #pragma unroll
-                    for (int i = 0; i < SPD; ++i) lam[i] = Wt[own + i];
+                    for (int i = 0; i < SPD; ++i) lam[i] = Wres[own + i];
                 }
 #pragma unroll 1
                 for (int l = 0; l < m + 2; ++l) {
-                    const double *T = (l < m ? dWt + l * SP4TILE : (l == m ? Vt : Wt)) + own;
+                    const double *T = (l < m ? dWt + l * SP4TILE : (l == m ? Vt : Wres)) + own;
                     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
                     for (int i = 0; i < SPD; ++i) {
@@ -792,7 +815,7 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
 #pragma unroll 1
             for (int j = 1; j <= q; ++j) {
                 const int L = fb * q + j - 1;
-                const double *T = Pt + (L % npw) * SP4TILE;
+                const double *T = (coop && it == 0) ? first_tile(j - 1) : Pt + (L % npw) * SP4TILE;
                 hp *= h;
                 hm *= -h;
                 const double cp = p.pc[j] * hp, cm = p.pc[j] * hm;

@@ -1103,7 +1103,8 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     p.v4_np = ctx->opt_v4_np > 0 ? (int)std::min<int64_t>(ctx->opt_v4_np, np) : ticket ? np : (units > g ? std::max(1, std::min(np, p.q - 1)) : std::min(np, p.q));
     // the cooperative first item (waves 0-3 build the powers, the stream waves fold) with a ring shorter than q: pays up to order 8 (one
     // trajectory 31.4 -> 29.3-30.5 us), not at order 10 (five powers through three tiles: 35.5 against 34.1 us)
-    if (p.q >= 5 && p.v4_np < p.q) p.v4_flags |= 4;
+    // (since round 5 the first item's powers beyond the ring borrow the chains' dW tiles -- q - v4_np <= m -- and every order starts cooperatively)
+    if (p.q >= 5 && p.v4_np < p.q && (p.q - p.v4_np > m || (p.v4_flags & 16))) p.v4_flags |= 4;
     if (ticket) p.tail_mode = p.tail_mode == 3 ? 0 : p.tail_mode;  // (the writer wave stores delta and the tails of a chain ticket)
     if (want_merit && (p.tail_mode == 3 || ticket)) {
         if (!ctx->dmcols) HIP_TRY(ctx, hipMalloc((void **)&ctx->dmcols, (size_t)ctx->desc.batch * p.K * p.d * (p.m + 2) * sizeof(double)));
