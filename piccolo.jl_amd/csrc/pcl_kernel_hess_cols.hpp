@@ -67,7 +67,21 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     double *slots = lds, *Dt = slots + HC_NSLOT * SP4CS, *St = Dt + CB, *Rt = St + CB, *cft = Rt + HC_NR * CB;
     unsigned *gtab = (unsigned *)(cft + HC_NCFT);
     const long long xd = (long long)n * d;
-    const int item = blockIdx.x / HC_NG, grp = blockIdx.x - item * HC_NG;
+    // Which (interval, column group) this wave takes.  The HC_NG waves of an interval write neighbouring 1,728-byte runs of every output vector: their
+    // first and last 128-byte lines are shared.  Workgroups go to the XCDs round-robin (blockIdx mod 8), and each XCD has its own write-back L2:
+    // dealt in blockIdx order the waves of an interval sit on HC_NG different XCDs and every shared line goes to memory twice, partly filled
+    // (round 4: 168 MB written for 129.5 MB of values).  With p.S = 8 (the host's choice; 1: blockIdx order) the waves of an interval take
+    // blockIdx values that are equal mod 8 -- one XCD, one L2, where the partial lines merge; the grid is padded to a multiple of 8 intervals.
+    int item, grp;
+    if (p.S > 1) {
+        const int x = blockIdx.x % p.S, r = blockIdx.x / p.S;
+        item = (r / HC_NG) * p.S + x;
+        grp = r - (r / HC_NG) * HC_NG;
+        if (item >= p.batch * p.K) return;
+    } else {
+        item = blockIdx.x / HC_NG;
+        grp = blockIdx.x - item * HC_NG;
+    }
     const int k = item % p.K, b = item / p.K;
     const int c0 = grp * HC_CPW, nce = min(HC_CPW, d - c0), ne = nce * n;
     double *H = p.hess + (long long)item * p.hess_per;

@@ -109,6 +109,7 @@ struct pcl_ctx {
     unsigned int *dh4c = nullptr;  // ... and the arrival counters (self-resetting)
     long long h4_cap = 0;
     int64_t opt_hess_split = -1, last_hess_split = 0;  // -1 auto (launches of at most n_cu / 2 intervals) | 0 | 1
+    int64_t opt_hess_xcd = -1;  // column-group Hessian kernel: the waves of an interval on one XCD (-1 auto: 8 | 0 / 1 blockIdx order | n)
     int64_t opt_eval_coop = -1, last_eval_coop = 0;  // residual only: four waves per interval (-1 auto: launches of at most two intervals per CU)
     int v4_hess_failed = 0;
     int v4_failed = 0;
@@ -1486,7 +1487,13 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             const double *tab = ctx->dv4_tab + wo * v4.n_drift_pad, *tab_t = ctx->dv4_tab_t + wo * v4.n_drift_pad, *dcf = ctx->dv4_dcf + wo * v4.n_dcf_pad;
             ctx->ticket_launched = true;  // (arrival counters + exchange rows: a launch on another stream must not overlap this one)
             void *args[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dhcx, (void *)&ctx->dhcc};
-            HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhessc, (unsigned)(items * ng), 1, 1, 64, 1, 1, (unsigned)ldsc, ctx->stream, args, nullptr));
+            // the waves of an interval on ONE XCD (blockIdx equal mod 8: the lines their neighbouring output runs share merge in that XCD's L2);
+            // option hess_xcd: -1 auto (on) | 0 blockIdx order | n: the modulus
+            const int nx = ctx->opt_hess_xcd < 0 ? 8 : (int)std::max<int64_t>(1, ctx->opt_hess_xcd);
+            p.S = nx;
+            const long long grid_hc = nx > 1 ? ((items + nx - 1) / nx) * nx * ng : items * ng;
+            if (grid_hc > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
+            HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhessc, (unsigned)grid_hc, 1, 1, 64, 1, 1, (unsigned)ldsc, ctx->stream, args, nullptr));
             ctx->last_hess_kernel = 80 + p.q;
             ctx->last_hess_split = 0;
             return PCL_OK;
