@@ -8,7 +8,8 @@ What makes the number a measurement (round-4 review, item 5):
   * the process is pinned (sched_setaffinity) to the physical cores of ONE socket -- the socket of the first allowed CPU, one hardware thread per
     core -- before the OpenMP runtime starts; OMP_PROC_BIND=close, OMP_PLACES=cores, OMP_WAIT_POLICY=active are set before libgomp loads;
   * the line records sockets, cores per socket, the cgroup's cpu.max, the last-level cache of the socket and the thread count used;
-  * every call of the 10-30 s sample is timed: p10 / p50 / p90 / mean are reported, `value` = 1 / p50;
+  * every call of the 10-30 s sample is timed: p10 / p50 / p90 / mean are reported, `value` = 1 / p50 at the thread count whose SUSTAINED rate is best
+    (the cgroup's CPU quota, cpu.max, is recorded: a team above it wins single calls and loses the run to throttling -- `burst` keeps that figure);
   * a COLD-OUTPUT variant rotates over output buffers that together exceed the socket's last-level cache (what a solver sees when anything
     else touches memory between two evaluations): the warm variant's outputs (135 MB) can live in a 256-768 MB LLC across calls.
 """
@@ -110,17 +111,37 @@ def main():
     warm = alloc()
     nthr_max = min(len(pin), lay.K)
     ref_lib.eval_jac(Z, lay, G0, Gj, nthreads=nthr_max, out=warm)
-    # the port is memory-write-bound and parallel over K = 99 intervals: the best thread count of a short sweep (fastest of four calls each)
-    best_t, nthr = 1e9, 1
-    for nt in sorted({1, 8, 16, 24, 32, 48, 64, nthr_max}):
-        if nt > nthr_max:
-            continue
-        for _ in range(4):
+    # The container may be granted fewer CPUs than it can see (cgroup cpu.max = quota / period): a team larger than the quota finishes single
+    # calls faster and is then throttled -- on a box of this pool (256 hardware threads visible, quota 16 CPUs) 64 threads gave a median call of
+    # 0.41 ms and a SUSTAINED rate of 324 evaluations/s, 3 % of the calls (stalls of up to 184 ms) taking 87 % of the wall time.  A solver runs
+    # thousands of evaluations: the thread count is the one with the best sustained rate of a sweep (about a second each), its median call the value.
+    cm = cgroup_cpu_max()
+    quota_cpus = None
+    try:
+        q_, p_ = cm.split()
+        if q_ != "max":
+            quota_cpus = float(q_) / float(p_)
+    except Exception:
+        pass
+    sweep = []
+
+    def short_sample(nt, seconds):
+        calls, t0 = [], time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
             t1 = time.perf_counter()
             ref_lib.eval_jac(Z, lay, G0, Gj, nthreads=nt, out=warm)
-            t1 = time.perf_counter() - t1
-            if t1 < best_t:
-                best_t, nthr = t1, nt
+            calls.append(time.perf_counter() - t1)
+        el = time.perf_counter() - t0
+        return {"threads": nt, "p50_ms": float(np.median(calls)) * 1e3, "sustained_evals_per_s": len(calls) / el, "calls": len(calls)}
+
+    cands = sorted({1, 4, 8, 12, 16, 24, 32, 48, 64, nthr_max} | ({max(1, int(quota_cpus))} if quota_cpus else set()))
+    per_s = min(1.2, 0.35 * args.seconds / max(1, len([c_ for c_ in cands if c_ <= nthr_max])))
+    for nt in cands:
+        if nt <= nthr_max:
+            sweep.append(short_sample(nt, per_s))
+    best = max(sweep, key=lambda r: r["sustained_evals_per_s"])
+    nthr = best["threads"]
+    burst = min(sweep, key=lambda r: r["p50_ms"])  # the fastest single call (more threads than the quota sustains, where there is one)
 
     def sample(buffers, seconds):
         calls, i, t0 = [], 0, time.perf_counter()
@@ -135,23 +156,27 @@ def main():
                 "p90_ms": float(c[int(0.9 * (len(c) - 1))]) * 1e3, "mean_ms": float(c.mean()) * 1e3, "max_ms": float(c[-1]) * 1e3,
                 "min_ms": float(c[0]) * 1e3, "sustained_evals_per_s": len(c) / el}, calls
 
-    w, wcalls = sample([warm], 0.6 * args.seconds)
+    w, wcalls = sample([warm], 0.4 * args.seconds)
     llc, n_l3 = llc_bytes(pin)
     out_bytes = warm[0].nbytes + warm[1].nbytes
     n_cold = max(2, min(24, int(np.ceil(2.0 * max(llc, 64 << 20) / out_bytes))))
     cold_bufs = [warm] + [alloc() for _ in range(n_cold - 1)]
     for b in cold_bufs:  # one untimed pass: page faults of the new arrays are not the port's time
         ref_lib.eval_jac(Z, lay, G0, Gj, nthreads=nthr, out=b)
-    c, _ = sample(cold_bufs, 0.4 * args.seconds)
+    c, _ = sample(cold_bufs, 0.25 * args.seconds)
     # where a mean far above the median comes from: the share of the wall time spent in calls slower than 3 x the median
     wc = np.array(wcalls)
     slow = wc > 3.0 * np.median(wc)
     res = {
         "value": 1e3 / w["p50_ms"],
         "unit": "evals/s",
-        "value_is": "1 / median call time, outputs re-used (warm in the socket's last-level cache where it holds them)",
+        "value_is": "1 / median call time at the thread count with the best sustained rate, outputs re-used (warm in the socket's last-level cache where it holds them)",
         "cores": nthr,
         "kind": "port",
+        "sustained": w["sustained_evals_per_s"],
+        "thread_sweep": sweep,
+        "burst": {"threads": burst["threads"], "evals_per_s_p50": 1e3 / burst["p50_ms"], "sustained_evals_per_s": burst["sustained_evals_per_s"],
+                  "note": "the thread count with the fastest median call; where it exceeds the cgroup's CPU quota its sustained rate falls below its median (throttling)"},
         "warm": w,
         "cold_output": dict(c, buffers=n_cold, evals_per_s_p50=1e3 / c["p50_ms"],
                             note="outputs rotate over %d buffer pairs = %.0f MB > 2 x the socket's last-level cache" % (n_cold, n_cold * out_bytes / 1e6)),
@@ -159,10 +184,10 @@ def main():
                        "note": "calls slower than 3 x the median: what lifts the mean above the median (other tenants of a shared host; not the port)"},
         "host": {"sockets_visible": len(socks), "socket_used": first_pkg, "physical_cores_of_socket_allowed": len(pin), "hw_threads_allowed": len(allowed),
                  "pinned": pinned, "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_WAIT_POLICY")},
-                 "cgroup_cpu_max": cgroup_cpu_max(), "llc_bytes_of_socket": llc, "l3_instances": n_l3, "os_cpu_count": os.cpu_count()},
+                 "cgroup_cpu_max": cm, "cgroup_quota_cpus": quota_cpus, "llc_bytes_of_socket": llc, "l3_instances": n_l3, "os_cpu_count": os.cpu_count()},
         "sample": "%d warm + %d cold-output evals of one config-3 trajectory (N=%d) in %.1f s; oracle/pade_ref.c (analytic Pade-4, OpenMP over intervals, "
-        "gcc -O3 -march=x86-64-v3), outputs preallocated and first-touched on the pinned cores; %d threads = best of a sweep up to the %d physical cores of socket %d"
-        % (w["calls"], c["calls"], N, w["seconds"] + c["seconds"], nthr, len(pin), first_pkg),
+        "gcc -O3 -march=x86-64-v3), outputs preallocated and first-touched on the pinned cores; %d threads = best SUSTAINED rate of a sweep up to the %d physical cores of socket %d%s"
+        % (w["calls"], c["calls"], N, w["seconds"] + c["seconds"], nthr, len(pin), first_pkg, (" (cgroup quota: %.1f CPUs)" % quota_cpus) if quota_cpus else ""),
     }
     print(json.dumps(res), flush=True)
 

@@ -13,21 +13,45 @@
 
 namespace pcl_host {
 
+typedef double v2d __attribute__((ext_vector_type(2)));
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v8d __attribute__((ext_vector_type(8)));
 
-// dst[0..n) = src[0..n) with non-temporal stores (dst is written once and not read back by this library)
-static inline void stream_copy(double *__restrict__ dst, const double *__restrict__ src, size_t n) {
+// dst[0..n) = src[0..n) with non-temporal stores (dst is written once and not read back by this library).  One instance per store width: the
+// translation unit is built for the x86-64 baseline, where a 32-byte vector store becomes two 16-byte movntps (what rounds 2-4 ran: four stores
+// per cache line); the instances below are compiled for AVX2 / AVX-512 (function target attributes) and picked once at run time -- one full
+// 64-byte line per store on hosts that have AVX-512, two 32-byte halves with AVX2.
+template <class V, int W>
+static inline __attribute__((always_inline)) void stream_copy_impl(double *__restrict__ dst, const double *__restrict__ src, size_t n) {
     size_t i = 0;
-    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & 31)) {
+    while (i < n && (reinterpret_cast<uintptr_t>(dst + i) & (sizeof(V) - 1))) {
         dst[i] = src[i];
         ++i;
     }
-    for (; i + 4 <= n; i += 4) {
-        v4d v;
+    for (; i + W <= n; i += W) {
+        V v;
         __builtin_memcpy(&v, src + i, sizeof v);
-        __builtin_nontemporal_store(v, reinterpret_cast<v4d *>(dst + i));
+        __builtin_nontemporal_store(v, reinterpret_cast<V *>(dst + i));
     }
     for (; i < n; ++i) dst[i] = src[i];
+}
+static void stream_copy_sse2(double *__restrict__ dst, const double *__restrict__ src, size_t n) { stream_copy_impl<v2d, 2>(dst, src, n); }
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("avx2"))) static void stream_copy_avx2(double *__restrict__ dst, const double *__restrict__ src, size_t n) { stream_copy_impl<v4d, 4>(dst, src, n); }
+__attribute__((target("avx512f"))) static void stream_copy_avx512(double *__restrict__ dst, const double *__restrict__ src, size_t n) { stream_copy_impl<v8d, 8>(dst, src, n); }
+#endif
+typedef void (*stream_copy_fn)(double *__restrict__, const double *__restrict__, size_t);
+// width: 0 the widest the host has | 16 | 32 | 64 bytes per store (option host_store_bytes; a width the host lacks falls back to the next one down)
+static inline stream_copy_fn pick_stream_copy(int width, int *chosen) {
+    stream_copy_fn f = stream_copy_sse2;
+    int w = 16;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_cpu_init();
+    if ((width == 0 || width >= 32) && __builtin_cpu_supports("avx2")) f = stream_copy_avx2, w = 32;
+    if ((width == 0 || width >= 64) && __builtin_cpu_supports("avx512f")) f = stream_copy_avx512, w = 64;
+#endif
+    if (chosen) *chosen = w;
+    return f;
 }
 
 // Persistent workers.  run(): jobs 0..total-1; a job may start once `published` has passed its index (the caller publishes
@@ -108,13 +132,34 @@ class Pool {
 
 // One interval's compact block [-B^+ (nn) | B^- (nn) | tail] -> full block [-B^+ x cols | B^- x cols | tail]; `half`
 // selects the -B^+ copies (0) or the B^- copies and the tail (1) so that two threads can share an interval.
-static inline void expand_interval(double *__restrict__ full, const double *__restrict__ compact, int cols, long long nn, long long tail, int half) {
+static inline void expand_interval(double *__restrict__ full, const double *__restrict__ compact, int cols, long long nn, long long tail, int half, stream_copy_fn copy) {
     if (half == 0) {
-        for (int c = 0; c < cols; ++c) stream_copy(full + (long long)c * nn, compact, (size_t)nn);
+        for (int c = 0; c < cols; ++c) copy(full + (long long)c * nn, compact, (size_t)nn);
     } else {
-        for (int c = 0; c < cols; ++c) stream_copy(full + (long long)(cols + c) * nn, compact + nn, (size_t)nn);
-        stream_copy(full + 2LL * cols * nn, compact + 2 * nn, (size_t)tail);
+        for (int c = 0; c < cols; ++c) copy(full + (long long)(cols + c) * nn, compact + nn, (size_t)nn);
+        copy(full + 2LL * cols * nn, compact + 2 * nn, (size_t)tail);
     }
+}
+
+// CPUs the cgroup grants this process (cpu.max = "quota period", cgroup v2; cfs_quota_us / cfs_period_us, v1); 0: no quota.  A container may see
+// 256 hardware threads and be allowed 16 CPUs' worth of time: a team above the quota wins single calls and is throttled over a run.
+static inline double cgroup_quota_cpus() {
+    double q = 0.0, p = 0.0;
+    char a[64] = {0};
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        if (fscanf(f, "%63s %lf", a, &p) == 2 && strcmp(a, "max") != 0) q = atof(a);
+        fclose(f);
+    } else {
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(g, "%lf", &q) != 1) q = 0.0;
+            fclose(g);
+        }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(g, "%lf", &p) != 1) p = 0.0;
+            fclose(g);
+        }
+    }
+    return (q > 0.0 && p > 0.0) ? q / p : 0.0;
 }
 
 }  // namespace pcl_host

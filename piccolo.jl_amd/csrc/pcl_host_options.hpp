@@ -72,6 +72,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "v4_tail_mode must be 0 .. 3");
         ctx->opt_v4_tail_mode = v;
     }
+    else if (!strcmp(key, "host_store_bytes"))  // host expansion: bytes per streaming store (0 the widest the host has | 16 | 32 | 64)
+        ctx->opt_host_store_bytes = (v == 16 || v == 32 || v == 64) ? v : 0;
     else if (!strcmp(key, "hess_xcd"))  // column-group Hessian kernel: the waves of an interval take blockIdx values equal mod n = one XCD (-1 auto: 8 | 0, 1: blockIdx order)
         ctx->opt_hess_xcd = v < 0 ? -1 : v;
     else if (!strcmp(key, "hess_split"))  // general-order pattern-compiled Hessian kernel: two workgroups per interval (-1 auto by launch size | 0 | 1)
@@ -142,6 +144,10 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->last_kernel;
     else if (!strcmp(key, "hess_xcd"))
         *v = ctx->opt_hess_xcd;
+    else if (!strcmp(key, "host_store_bytes"))  // the width the last host expansion used
+        *v = ctx->last_host_store_bytes;
+    else if (!strcmp(key, "cgroup_quota_cpus_x100"))  // 100 x the CPUs the cgroup grants the process (cpu.max); 0: no quota
+        *v = (int64_t)(pcl_host::cgroup_quota_cpus() * 100.0 + 0.5);
     else if (!strcmp(key, "last_hess_split"))
         *v = ctx->last_hess_split;
     else if (!strcmp(key, "last_eval_coop"))

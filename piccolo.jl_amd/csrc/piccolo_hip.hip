@@ -138,6 +138,7 @@ struct pcl_ctx {
     hipEvent_t ev_chunk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int64_t opt_prof = 0;  // -DPCL_PROFILE builds only
     int64_t opt_host_threads = 0, opt_host_path = 0, opt_host_chunks = 4;
+    int64_t opt_host_store_bytes = 0, last_host_store_bytes = 0;  // streaming-store width of the host expansion: 0 the widest the host has | 16 | 32 | 64
     int host_threads_tuned = 0;       // auto: the thread count the sweep over the context's first host-delivered calls found fastest
     int host_tune_calls = 0;          // ... calls sampled so far
     double host_tune_t[8] = {1e300, 1e300, 1e300, 1e300, 1e300, 1e300, 1e300, 1e300};
@@ -2093,9 +2094,12 @@ static int host_eval_jac(pcl_ctx *ctx, const double *Z, double *delta, double *v
     const int cols = ctx->cols;
     const long long nn = (long long)ctx->n * ctx->n, tail = ctx->x_dim * (ctx->desc.n_drives + 1);
     const double *hc = ctx->hcompact;
+    int store_w = 0;
+    const pcl_host::stream_copy_fn copy = pcl_host::pick_stream_copy((int)ctx->opt_host_store_bytes, &store_w);
+    ctx->last_host_store_bytes = store_w;
     ctx->pool->begin(2 * nbk, [=](long long job) {
         const long long bk = job >> 1;
-        pcl_host::expand_interval(vals + bk * fper, hc + bk * cper, cols, nn, tail, (int)(job & 1));
+        pcl_host::expand_interval(vals + bk * fper, hc + bk * cper, cols, nn, tail, (int)(job & 1), copy);
     });
     int rc = PCL_OK;
     for (int c = 0; c < n_chunks; ++c) {
