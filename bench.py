@@ -584,7 +584,7 @@ def main():
         for _ in range(4):
             hvals.fill(1.0)
         fill_GBps = 4 * hvals.nbytes / (time.perf_counter() - tf) / 1e9
-        ex["host_delivered"] = dict(hres["compact_plus_host_expansion"], note="default path (pcl_eval_jac on pageable numpy arrays; min(cores / 2, 32) threads expand the compact values with the widest "
+        ex["host_delivered"] = dict(hres["compact_plus_host_expansion"], note="default path (pcl_eval_jac on pageable numpy arrays; min(cores / 2, 32, the cgroup's CPU quota) threads expand the compact values with the widest "
                                     "streaming stores the host has); evals_per_s = 1 / median call, sustained_* = calls / wall time of the sample",
                                     paths=hres, best=best, swept_threads=it.ctx.get_option("host_threads"), host_fill_GBps_one_thread=fill_GBps, cgroup_quota_cpus=quota or None)
         it.close()

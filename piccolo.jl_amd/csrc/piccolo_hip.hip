@@ -2039,7 +2039,13 @@ static int host_threads(const pcl_ctx *ctx) {
     if (ctx->host_threads_tuned > 0) return ctx->host_threads_tuned;
     const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
     if (ctx->opt_host_threads < 0 && ctx->host_tune_calls < 2 * kHostTuneN) return (int)std::min<unsigned>((unsigned)kHostTuneCand[ctx->host_tune_calls % kHostTuneN], hw);
-    return (int)std::max(1u, std::min(hw / 2, 32u));
+    // ... and never more than the CPUs the cgroup grants (cpu.max): a container that sees 256 hardware threads and is allowed 16 CPUs delivered
+    // 1,390 evaluations/s sustained with 16 threads and 650-1,000 with 32 (1,570 per median call: the team wins single calls and is throttled
+    // over a run -- round 5, bench.py other_rates.host_delivered.paths)
+    unsigned def = std::max(1u, std::min(hw / 2, 32u));
+    static const double quota = pcl_host::cgroup_quota_cpus();
+    if (quota >= 1.0) def = std::min(def, (unsigned)quota);
+    return (int)std::max(1u, def);
 }
 
 // Host-pointer evaluation.  Two ways to deliver the Jacobian values into the caller's (pageable) array:
