@@ -29,7 +29,7 @@ for f in find("trace", "*kernel_trace.csv"):
         meta[key] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size_X", "Grid_Size_X")}
     summary["kernel_trace"] = {k: dict(calls=len(v), avg_us=sum(v) / len(v) / 1e3, min_us=min(v) / 1e3, max_us=max(v) / 1e3, **meta[k])
                                for k, v in dur.items() if "pcl_" in k}
-for wl in ("single", "multistart", "multistart_static", "single_order8", "single_k3"):  # the headline launches alone (the full trace mixes them with compact launches of the same grid)
+for wl in ("single", "multistart", "multistart_static", "single_order8", "single_order10", "single_k3"):  # the headline launches alone (the full trace mixes them with compact launches of the same grid)
     for f in find("trace_" + wl, "*kernel_trace.csv"):
         dur = defaultdict(list)
         for r in csv.DictReader(open(f)):
@@ -89,7 +89,7 @@ for f in glob.glob(os.path.join(src, "trace.log")):
 json.dump(summary, open(os.path.join(dst, "%s_summary.json" % tag), "w"), indent=1)
 for k, v in sorted(summary.get("kernel_trace", {}).items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["calls"]):
     print("%-100s calls=%4d avg=%9.2f us (min %.2f max %.2f)" % (k[:100], v["calls"], v["avg_us"], v["min_us"], v["max_us"]))
-for wl in ("single", "multistart", "multistart_static", "single_order8"):
+for wl in ("single", "multistart", "multistart_static", "single_order8", "single_order10"):
     for k, v in summary.get("kernel_trace_" + wl, {}).items():
         print("%-11s alone: %-70s calls=%4d avg=%9.2f us (min %.2f max %.2f)" % (wl, k[:70], v["calls"], v["avg_us"], v["min_us"], v["max_us"]))
 for wl, t in traffic.items():
