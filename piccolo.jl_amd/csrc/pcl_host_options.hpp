@@ -72,6 +72,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         if (v < 0 || v > 3) return fail(ctx, PCL_EINVAL, "v4_tail_mode must be 0 .. 3");
         ctx->opt_v4_tail_mode = v;
     }
+    else if (!strcmp(key, "v4_tune"))  // v4_ticket auto: 1 decide static split / slice tickets per values array by timing both on it | 0 always tickets
+        ctx->opt_v4_tune = v != 0;
     else if (!strcmp(key, "host_store_bytes"))  // host expansion: bytes per streaming store (0 the widest the host has | 16 | 32 | 64)
         ctx->opt_host_store_bytes = (v == 16 || v == 32 || v == 64) ? v : 0;
     else if (!strcmp(key, "hess_xcd"))  // column-group Hessian kernel: the waves of an interval take blockIdx values equal mod n = one XCD (-1 auto: 8 | 0, 1: blockIdx order)
@@ -144,6 +146,14 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->last_kernel;
     else if (!strcmp(key, "hess_xcd"))
         *v = ctx->opt_hess_xcd;
+    else if (!strcmp(key, "v4_tune"))
+        *v = ctx->opt_v4_tune;
+    else if (!strcmp(key, "last_v4_tune_choice"))  // of the array the last multi-trajectory launch wrote: -1 still sampling | 0 static split | 1 slice tickets
+        *v = ctx->last_v4_tune_choice;
+    else if (!strcmp(key, "last_v4_tune_static_ns"))  // best timed launch of each variant on the last decided array
+        *v = ctx->last_v4_tune_static_us;
+    else if (!strcmp(key, "last_v4_tune_ticket_ns"))
+        *v = ctx->last_v4_tune_ticket_us;
     else if (!strcmp(key, "host_store_bytes"))  // the width the last host expansion used
         *v = ctx->last_host_store_bytes;
     else if (!strcmp(key, "cgroup_quota_cpus_x100"))  // 100 x the CPUs the cgroup grants the process (cpu.max); 0: no quota

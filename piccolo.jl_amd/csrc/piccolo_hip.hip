@@ -99,6 +99,21 @@ struct pcl_ctx {
     double *dv4_tab = nullptr, *dv4_tab_t = nullptr, *dv4_mags = nullptr, *dv4_dcf = nullptr;
     hipFunction_t v4_ft = nullptr;  // the fused kernel of the module WITH the slice-ticket roles (launches of several trajectories)
     int v4_ft_failed = 0;           // ... could not be had: those launches take the static split of v4_f (same bits)
+    // v4_ticket = -1 (auto), launches of several trajectories: static split or slice tickets, decided PER VALUES ARRAY by timing both on it (the
+    // two give the same bits).  The static split's time depends on where the array's pages live (181-228 us per 8 seeds by array and box), the
+    // tickets' hardly (193-217): neither wins everywhere.  Per array: 2 untimed launches, then 3 + 3 timed ones alternating (events on the launch
+    // stream, read back without blocking), then the faster variant for good (tickets unless the static split is 2 % ahead).
+    struct V4Tune {
+        const void *key = nullptr;
+        long long units = 0;
+        int calls = 0, choice = -1, done[2] = {0, 0}, pend_variant[8] = {0};
+        float best[2] = {1e30f, 1e30f};
+        hipEvent_t ev[8][2] = {};
+        bool pend[8] = {false};
+        unsigned long long stamp = 0;
+    } v4_tune[4];
+    unsigned long long v4_tune_clock = 0;
+    int64_t last_v4_tune_choice = -1, last_v4_tune_static_us = 0, last_v4_tune_ticket_us = 0;
     hipFunction_t v4_f = nullptr, v4_feval = nullptr, v4_fevalc = nullptr /* cooperative residual kernel (optional) */, v4_fhess = nullptr, v4_fhess2 = nullptr /* two workgroups per interval */;
     hipFunction_t v4_fhessc = nullptr;  // general-order Hessian, one wave per group of state columns (pcl_kernel_hess_cols.hpp)
     double *dhcx = nullptr;             // ... the waves' rows of reduced sums and the intervals' arrival counters (self-resetting)
@@ -109,6 +124,7 @@ struct pcl_ctx {
     unsigned int *dh4c = nullptr;  // ... and the arrival counters (self-resetting)
     long long h4_cap = 0;
     int64_t opt_hess_split = -1, last_hess_split = 0;  // -1 auto (launches of at most n_cu / 2 intervals) | 0 | 1
+    int64_t opt_v4_tune = 1;  // v4_ticket auto: 1 the static split or the slice tickets by timing both on the values array | 0 always tickets (round 4)
     int64_t opt_hess_xcd = -1;  // column-group Hessian kernel: the waves of an interval on one XCD (-1 auto: 8 | 0 / 1 blockIdx order | n)
     int64_t opt_eval_coop = -1, last_eval_coop = 0;  // residual only: four waves per interval (-1 auto: launches of at most two intervals per CU)
     int v4_hess_failed = 0;
@@ -571,6 +587,10 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     if (ctx->dcomp_host) (void)hipFree(ctx->dcomp_host);
     for (hipEvent_t e : ctx->ev_chunk)
         if (e) (void)hipEventDestroy(e);
+    for (auto &t : ctx->v4_tune)
+        for (auto &pr : t.ev)
+            for (hipEvent_t e : pr)
+                if (e) (void)hipEventDestroy(e);
     for (void *q : {(void *)ctx->dformA, (void *)ctx->dformc, (void *)ctx->dgram, (void *)ctx->dcoef})
         if (q) (void)hipFree(q);
     for (void *q : {(void *)ctx->dsub, (void *)ctx->dweights, (void *)ctx->dregs, (void *)ctx->dreg_R, (void *)ctx->dobj, (void *)ctx->dphik, (void *)ctx->dmcols, (void *)ctx->dmticket,
@@ -1065,9 +1085,54 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     // the previous slice's stores are issued -- the front of addresses being written stays tight and the workgroups the memory side
     // serves first take more slices: the time no longer depends on where the values array's pages live.
     const int tick_G = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_v4_group > 0 ? ctx->opt_v4_group : 8, ncu));
-    const bool ticket = !compact && ctx->dv4_tick && !ctx->v4_ft_failed && ctx->opt_grid <= 0 && m + 10 <= 16 && ncu % tick_G == 0 &&
-                        v4_lds_bytes(d, m, np) + 8 * 8 * 128 <= (size_t)ctx->max_lds &&
-                        (ctx->opt_v4_ticket == 1 || (ctx->opt_v4_ticket < 0 && p.q <= 2 && p.contig && ctx->opt_contig < 0 && ctx->opt_cols_per_slice <= 0));
+    const bool ticket_ok = !compact && ctx->dv4_tick && !ctx->v4_ft_failed && ctx->opt_grid <= 0 && m + 10 <= 16 && ncu % tick_G == 0 &&
+                           v4_lds_bytes(d, m, np) + 8 * 8 * 128 <= (size_t)ctx->max_lds;
+    const bool ticket_auto = ticket_ok && ctx->opt_v4_ticket < 0 && p.q <= 2 && p.contig && ctx->opt_contig < 0 && ctx->opt_cols_per_slice <= 0;
+    // auto: which of the two this values array gets (see v4_tune); timed launches are bracketed by events below
+    pcl_ctx::V4Tune *tune = nullptr;
+    int tune_slot = -1, tune_variant = 1;
+    if (ticket_auto && ctx->opt_v4_tune != 0) {
+        pcl_ctx::V4Tune *T = nullptr;
+        for (auto &t : ctx->v4_tune)
+            if (t.key == (const void *)p.jac && t.units == bk) T = &t;
+        if (!T) {  // the least recently used entry makes room
+            T = &ctx->v4_tune[0];
+            for (auto &t : ctx->v4_tune)
+                if (t.stamp < T->stamp) T = &t;
+            for (int i = 0; i < 8; ++i) T->pend[i] = false;
+            T->key = (const void *)p.jac, T->units = bk, T->calls = 0, T->choice = -1, T->done[0] = T->done[1] = 0, T->best[0] = T->best[1] = 1e30f;
+        }
+        T->stamp = ++ctx->v4_tune_clock;
+        if (T->choice < 0) {
+            for (int i = 0; i < 8; ++i)  // timings that have come back
+                if (T->pend[i] && hipEventQuery(T->ev[i][1]) == hipSuccess) {
+                    float ms = 0.f;
+                    if (hipEventElapsedTime(&ms, T->ev[i][0], T->ev[i][1]) == hipSuccess && ms > 0.f) {
+                        T->best[T->pend_variant[i]] = std::min(T->best[T->pend_variant[i]], ms);
+                        ++T->done[T->pend_variant[i]];
+                    }
+                    T->pend[i] = false;
+                }
+            (void)hipGetLastError();  // (hipErrorNotReady of a query is not an error of this call)
+            if (T->done[0] >= 3 && T->done[1] >= 3) {
+                T->choice = (T->best[0] * 1.02f < T->best[1]) ? 0 : 1;
+                ctx->last_v4_tune_static_us = (int64_t)(T->best[0] * 1e6f), ctx->last_v4_tune_ticket_us = (int64_t)(T->best[1] * 1e6f);  // (ns)
+            } else if (T->calls >= 40)
+                T->choice = 1;  // (timings that never come back: tickets)
+        }
+        if (T->choice >= 0)
+            tune_variant = T->choice;
+        else {
+            tune_variant = T->calls < 2 ? 1 : (T->calls & 1);
+            if (T->calls >= 2 && T->done[tune_variant] < 3)
+                for (int i = 0; i < 8 && tune_slot < 0; ++i)
+                    if (!T->pend[i]) tune_slot = i;
+            ++T->calls;
+            tune = T;
+        }
+        ctx->last_v4_tune_choice = T->choice;
+    }
+    const bool ticket = ticket_ok && (ctx->opt_v4_ticket == 1 || (ticket_auto && tune_variant == 1));
     // (orders 6-10: the P wave's q products per visit are the longer chain -- 8 trajectories at order 8: 246-254 against 232 us)
     if (ticket) {
         p.tick_cpi = ctx->opt_v4_ticket_cols > 0 ? (int)std::min<int64_t>(ctx->opt_v4_ticket_cols, d) : std::min(3, d);
@@ -1134,7 +1199,18 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
         else
             return launch_fused_v4_static(ctx, p, compact, want_merit);
     }
+    bool timed = false;
+    if (tune && tune_slot >= 0) {  // one timed sample of the per-array choice
+        bool ok = true;
+        for (int e = 0; e < 2 && ok; ++e)
+            if (!tune->ev[tune_slot][e]) ok = hipEventCreate(&tune->ev[tune_slot][e]) == hipSuccess;
+        timed = ok && hipEventRecord(tune->ev[tune_slot][0], ctx->stream) == hipSuccess;
+    }
     HIP_TRY(ctx, hipModuleLaunchKernel(fk, (unsigned)g, 1, 1, 64 * (m + 9 + (ticket ? 1 : 0)), 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
+    if (timed && hipEventRecord(tune->ev[tune_slot][1], ctx->stream) == hipSuccess) {
+        tune->pend[tune_slot] = true;
+        tune->pend_variant[tune_slot] = ticket ? 1 : 0;
+    }
     ctx->last_kernel = 40 + p.q;
     ctx->last_n_stream = 0;
     if (ticket) ctx->ticket_launched = true;

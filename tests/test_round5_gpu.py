@@ -251,3 +251,47 @@ def test_world2_gpu_kernels_plus_collective_equal_the_unsharded_step():
         assert p.exitcode == 0
     for rank, err, scale in res:
         assert err <= 1e-12 * max(1.0, scale), (rank, err, scale)
+
+
+def test_static_split_or_tickets_is_decided_per_values_array():
+    """`v4_ticket` auto (round 5): on every values array the context times the static split and the slice tickets (three launches each, alternating,
+    events on the launch stream) and keeps the faster one -- the two give the same bits, so the sampling launches are ordinary evaluations.  After a
+    dozen launches the choice exists, the timings are plausible, every launch gave the forced variants' bits, and a second array is sampled afresh."""
+    import torch
+
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    Bn = 8
+    Zs = [po.synthetic_trajectory(so, 100, seed=1000 + i)[0] for i in range(Bn)]
+    lay = po.synthetic_trajectory(so, 100, seed=1000)[1]
+    t0 = traj_from_Z(pa, Zs[0], lay)
+    ms = pa.HipPadeMultistart(G0, Gj, t0, Bn, pade_order=4)
+    c = ms.ctx
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    Zd = torch.from_numpy(np.stack(Zs)).cuda()
+    dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
+    bufs = [torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda") for _ in range(2)]
+    c.set_option("v4_ticket", 0)
+    c.eval_jac_dev(Zd, dd, bufs[0])
+    c.sync()
+    ref_d, ref_v = dd.clone(), bufs[0].clone()
+    c.set_option("v4_ticket", -1)
+    for vd in bufs:
+        seen = set()
+        for i in range(16):
+            vd.fill_(float("nan"))
+            c.eval_jac_dev(Zd, dd, vd)
+            c.sync()
+            seen.add(c.get_option("last_v4_ticket") > 0)
+            assert torch.equal(vd, ref_v) and torch.equal(dd, ref_d), i
+        assert seen == {True, False}  # both variants were sampled on this array
+        ch = c.get_option("last_v4_tune_choice")
+        ts, tt = c.get_option("last_v4_tune_static_ns"), c.get_option("last_v4_tune_ticket_ns")
+        assert ch in (0, 1) and 100_000 < ts < 1_000_000 and 100_000 < tt < 1_000_000, (ch, ts, tt)
+        assert ch == (0 if ts * 1.02 < tt else 1)
+        c.eval_jac_dev(Zd, dd, vd)
+        assert (c.get_option("last_v4_ticket") > 0) == (ch == 1)
+    c.set_option("v4_tune", 0)  # round 4's rule: always tickets
+    c.eval_jac_dev(Zd, dd, bufs[0])
+    assert c.get_option("last_v4_ticket") > 0
+    ms.close()
