@@ -212,9 +212,27 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
 #pragma unroll
         for (int i = 0; i < SPD; ++i) x[i] = 0.0;  // V_{l,0} = 0
     }
-    double s_y = 0.0, s_uu[SPM];
+    // The reduced sums of a lane's chain -- <chain, Y> and the m (u,u) sums -- are added over the HC_CPW columns of the chain IN EVERY PASS (the lanes of a
+    // (half, chain) are neighbours: quads at HC_CPW = 4; two DPP steps, the same bits in every lane of the group) and lane `col` keeps the running totals of
+    // the values col and col + HC_CPW only: two accumulators per lane instead of 1 + m.  (Round 4 kept all seven per lane: the compiler held them in
+    // scratch across the product, the gather and the contributions -- 7 stores + 7 loads per pass, and 27 MB of scratch write-back per 8-seed launch.)
+    static_assert(HC_CPW == 4 || HC_CPW == 2 || HC_CPW == 1, "the column lanes of a chain form a DPP quad, a pair or a single lane");
+    static_assert(HC_ROW <= 2 * HC_CPW || HC_CPW < 4, "two running totals per lane cover the 1 + m values of a chain");
+    constexpr int HC_NACC = (HC_ROW + HC_CPW - 1) / HC_CPW;
+    double s_acc[HC_NACC];
 #pragma unroll
-    for (int i = 0; i < SPM; ++i) s_uu[i] = 0.0;
+    for (int i = 0; i < HC_NACC; ++i) s_acc[i] = 0.0;
+    auto group_sum = [&](double v) {  // sum over the HC_CPW column lanes of this lane's (half, chain), the same in each of them
+        if constexpr (HC_CPW >= 2) {
+            const int lo = __double2loint(v), hi = __double2hiint(v);
+            v += __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xB1, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+        }
+        if constexpr (HC_CPW >= 4) {
+            const int lo = __double2loint(v), hi = __double2hiint(v);
+            v += __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+        }
+        return v;
+    };
     double hpV = 1.0, hpW = 1.0, hpW2 = 1.0;  // h^(level - 1) of the V lanes' and of the W lanes' level; h^(level - 2) of the W lanes'
 #pragma unroll 1
     for (int jp = 1; jp <= q + 1; ++jp) {
@@ -275,6 +293,9 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         const int jl = isV ? jp : jp - 1;
         const double cj = isV ? p.pc[jp <= q ? jp : q] : p.pc[jp - 1], hp = isV ? hpV : hpW;
         const double Tj = cj * hp * h, T1 = jl * cj * hp, sg = (jl & 1) ? -1.0 : 1.0;
+        double cv[HC_ROW];
+#pragma unroll
+        for (int v = 0; v < HC_ROW; ++v) cv[v] = 0.0;
         if (on) {
             const double wK = isV ? Tj : T1;  // the weight of this level in the lane's output vectors
 #pragma unroll
@@ -302,20 +323,24 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
                 asm volatile("" ::: "memory");
             }
             const double dy = sg * (dot0 + dot1);  // <chain_j, Y_j>
-            if (!isV) {
-                if (jl >= 2) s_y = __builtin_fma(jl * (jl - 1) * cj * hpW2, dy, s_y);  // T''_j = j (j-1) c_j h^(j-2)
-            } else {
-                s_y = __builtin_fma(T1, dy, s_y);
-                if (jp < q) {  // (u,u): <V_{l,j}, G_i R_j>, every drive i
-                    // R_jp; the top one is +-T_q |Y_q|: the D or the S tile, the number applied to the sums
-                    const double *Rj = (jp == q - 1 ? ((q & 1) ? St : Dt) : Rt + (jp - 1) * CB) + cb;
-                    const double wr = jp == q - 1 ? wgt(q) : 1.0;
-                    double r6[SPM];
-                    sp4_gdot_all(Rj + own, Rj + oth, x, (half ? 1.0 : -1.0), mg, r6);
+            cv[0] = !isV ? (jl >= 2 ? jl * (jl - 1) * cj * hpW2 * dy : 0.0)  // T''_j = j (j-1) c_j h^(j-2)
+                         : T1 * dy;
+            if (isV && jp < q) {  // (u,u): <V_{l,j}, G_i R_j>, every drive i
+                // R_jp; the top one is +-T_q |Y_q|: the D or the S tile, the number applied to the sums
+                const double *Rj = (jp == q - 1 ? ((q & 1) ? St : Dt) : Rt + (jp - 1) * CB) + cb;
+                const double wr = jp == q - 1 ? wgt(q) : 1.0;
+                double r6[SPM];
+                sp4_gdot_all(Rj + own, Rj + oth, x, (half ? 1.0 : -1.0), mg, r6);
 #pragma unroll
-                    for (int i = 0; i < SPM; ++i) s_uu[i] = __builtin_fma(wr, r6[i], s_uu[i]);
-                }
+                for (int i = 0; i < SPM; ++i) cv[1 + i] = wr * r6[i];
             }
+        }
+        // this pass's 1 + m values of the chain, summed over its columns; lane `col` adds the values col, col + HC_CPW, ... to its running totals
+        // (every lane of the wave takes part in the DPP steps: lanes without a level contribute zeros)
+#pragma unroll
+        for (int v = 0; v < HC_ROW; ++v) {
+            const double tot = group_sum(cv[v]);
+            if (col == v % HC_CPW) s_acc[v / HC_CPW] += tot;
         }
         hpW2 = hpW;
         hpW = hpV;
@@ -325,22 +350,17 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     // ---- the reduced sums of the wave: every lane parks its 1 + m sums in its chain slot (rows 0 .. m of its half; slots of columns
     //      past the end hold zeros); lane e < HC_XS adds the 2 HC_CPW parts of (chain, value) in a fixed order ------------------------------
     asm volatile("" ::: "memory");
-    if (inr) {
-        Xs[own] = s_y;
+    if (inr) {  // lane (half, chain, col) parks the totals of the values col, col + HC_CPW, ... in rows 0, 1, ... of its half of its chain slot
 #pragma unroll
-        for (int i = 0; i < SPM; ++i) Xs[own + 1 + i] = s_uu[i];
+        for (int i = 0; i < HC_NACC; ++i) Xs[own + i] = s_acc[i];
     }
     asm volatile("" ::: "memory");
     unsigned xold = 0xffffffffu;
     {
-        double r = 0.0;
-        if (ln_ < HC_XS) {
+        if (ln_ < HC_XS) {  // lane = (chain, value): the two halves' totals, top first
             const int chn = ln_ / HC_ROW, val = ln_ - chn * HC_ROW;
-#pragma unroll
-            for (int cc = 0; cc < HC_CPW; ++cc) {
-                r += slots[(chn * HC_CPW + cc) * SP4CS + val];
-                r += slots[(chn * HC_CPW + cc) * SP4CS + d + val];
-            }
+            const double *sl_ = slots + (chn * HC_CPW + val % HC_CPW) * SP4CS + val / HC_CPW;
+            const double r = sl_[0] + sl_[d];
             hc_store_coherent(xch + ((long long)item * HC_NG + grp) * HC_XS + ln_, r);
         }
     }
