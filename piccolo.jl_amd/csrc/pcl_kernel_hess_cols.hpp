@@ -35,7 +35,7 @@
 #define HC_ROW (SPM + 1)                      // reduced sums per chain: <chain, Y>, row of (u,u)
 #define HC_XS (HC_NCH * HC_ROW)               // ... per wave
 #define HC_NSC ((SPM + 1) * (SPM + 2) / 2)
-#define HC_GCH 5                                                        // rows per batch of the table-driven gathers
+#define HC_GCH 7                                                        // rows per batch of the table-driven gathers (7, 9: 105 us per 8 seeds at order 8, 5: 110)
 #define HC_NCFT 24                                                      // coefficient table of the gathers: 0, +-mags[g]
 #define HC_GT_WPC ((SP4_GT_TOTAL + 2) / 3)                             // the gathers' entry table (sp4_gt_tab): three 10-bit entries per dword, per (drive, half)
 #define HC_GT_DOUBLES ((SPM * 2 * HC_GT_WPC + 1) / 2)
