@@ -483,7 +483,7 @@ def main():
     if rank == 0 and world == 1 and args.workload == "auto" and not args.no_shares:
         # config 5 whole (64 seeds) on this one GPU in one launch: the N = 1 point of the multistart scaling curve
         T = args.total_units
-        w64, d64, i64 = run_multistart(T, 10, 3, False, nbuf=NBUF, ab=("static",))
+        w64, d64, i64 = run_multistart(T, 10, 10, False, nbuf=NBUF, ab=("static",))  # (10 untimed launches: the per-array choice of v4_tune is made in them)
         out["multistart_64"] = {"evals_per_s": T * 10 / w64, "us_per_launch_kernel": d64 / 10 * 1e6, "seeds_per_launch": T, **spread_us(i64.get("per_buffer_us", [])), "slice_ticket_cols": i64["slice_ticket_cols"], "auto_choice_per_buffer": i64.get("auto_choice_per_buffer"),
                                 "frac_of_hbm_peak": abytes * T / (d64 / 10) / 1e9 / HBM_PEAK_GBS, "ab": i64.get("ab"),
                                 "note": "the value an N-GPU run of this script reports is the same 64 seeds with 64 / N per GPU"}
