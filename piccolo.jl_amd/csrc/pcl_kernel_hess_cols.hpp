@@ -216,9 +216,10 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     // (half, chain) are neighbours: quads at HC_CPW = 4; two DPP steps, the same bits in every lane of the group) and lane `col` keeps the running totals of
     // the values col and col + HC_CPW only: two accumulators per lane instead of 1 + m.  (Round 4 kept all seven per lane: the compiler held them in
     // scratch across the product, the gather and the contributions -- 7 stores + 7 loads per pass, and 27 MB of scratch write-back per 8-seed launch.)
-    static_assert(HC_CPW == 4 || HC_CPW == 2 || HC_CPW == 1, "the column lanes of a chain form a DPP quad, a pair or a single lane");
-    static_assert(HC_ROW <= 2 * HC_CPW || HC_CPW < 4, "two running totals per lane cover the 1 + m values of a chain");
-    constexpr int HC_NACC = (HC_ROW + HC_CPW - 1) / HC_CPW;
+    // (HC_CPW = 4 -- six drives, every transmon system of the reference: the column lanes of a chain are a DPP quad.  Other drive counts keep the
+    //  1 + m sums per lane and add them over the columns once, at the end.)
+    constexpr bool HC_GROUPSUM = HC_CPW == 4 && HC_ROW <= 2 * HC_CPW;
+    constexpr int HC_NACC = HC_GROUPSUM ? (HC_ROW + HC_CPW - 1) / HC_CPW : HC_ROW;
     double s_acc[HC_NACC];
 #pragma unroll
     for (int i = 0; i < HC_NACC; ++i) s_acc[i] = 0.0;
@@ -339,8 +340,11 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         // (every lane of the wave takes part in the DPP steps: lanes without a level contribute zeros)
 #pragma unroll
         for (int v = 0; v < HC_ROW; ++v) {
-            const double tot = group_sum(cv[v]);
-            if (col == v % HC_CPW) s_acc[v / HC_CPW] += tot;
+            if constexpr (HC_GROUPSUM) {
+                const double tot = group_sum(cv[v]);
+                if (col == v % HC_CPW) s_acc[v / HC_CPW] += tot;
+            } else
+                s_acc[v] += cv[v];
         }
         hpW2 = hpW;
         hpW = hpV;
@@ -357,10 +361,19 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     asm volatile("" ::: "memory");
     unsigned xold = 0xffffffffu;
     {
-        if (ln_ < HC_XS) {  // lane = (chain, value): the two halves' totals, top first
+        if (ln_ < HC_XS) {  // lane = (chain, value): the two halves' totals, top first (without the per-pass sums: the 2 HC_CPW parts, column by column)
             const int chn = ln_ / HC_ROW, val = ln_ - chn * HC_ROW;
-            const double *sl_ = slots + (chn * HC_CPW + val % HC_CPW) * SP4CS + val / HC_CPW;
-            const double r = sl_[0] + sl_[d];
+            double r = 0.0;
+            if constexpr (HC_GROUPSUM) {
+                const double *sl_ = slots + (chn * HC_CPW + val % HC_CPW) * SP4CS + val / HC_CPW;
+                r = sl_[0] + sl_[d];
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < HC_CPW; ++cc) {
+                    r += slots[(chn * HC_CPW + cc) * SP4CS + val];
+                    r += slots[(chn * HC_CPW + cc) * SP4CS + d + val];
+                }
+            }
             hc_store_coherent(xch + ((long long)item * HC_NG + grp) * HC_XS + ln_, r);
         }
     }
