@@ -295,3 +295,36 @@ def test_static_split_or_tickets_is_decided_per_values_array():
     c.eval_jac_dev(Zd, dd, bufs[0])
     assert c.get_option("last_v4_ticket") > 0
     ms.close()
+
+
+def test_host_store_widths_and_hessian_wave_placement_give_the_same_bits():
+    """Two performance switches of round 5 that must not change a bit: the streaming-store width of the host expansion (16 / 32 / 64 bytes per
+    store, picked at run time by what the host's CPU has) and the placement of an interval's Hessian waves on one XCD (`hess_xcd`)."""
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    Z, lay = po.synthetic_trajectory(so, 9, seed=21)
+    t = traj_from_Z(pa, Z, lay)
+    B = pa.HipPadeIntegrator(G0, Gj, t, pade_order=8)
+    c = B.ctx
+    c.set_option("host_path", 2)
+    ref = None
+    for w in (16, 32, 64, 0):
+        c.set_option("host_store_bytes", w)
+        d_, v_ = c.eval_jac(Z)
+        used = c.get_option("host_store_bytes")
+        assert used in (16, 32, 64) and (w == 0 or used <= w)
+        if ref is None:
+            ref = (d_.copy(), v_.copy())
+            close_ = np.abs(v_ - po.pade_jacobian_values(Z, lay, G0, Gj, 8).reshape(-1)).max()
+            assert close_ <= 1e-12 * max(1.0, np.abs(v_).max())
+        else:
+            assert np.array_equal(d_, ref[0]) and np.array_equal(v_, ref[1]), w
+    mu = np.random.default_rng(3).standard_normal(c.n_rows)
+    c.set_option("hess_kernel", 8)
+    hs = []
+    for x in (0, 8, 3):
+        c.set_option("hess_xcd", x)
+        hs.append(c.hess(Z, mu))
+        assert c.get_option("last_hess_kernel") == 84
+    assert np.array_equal(hs[0], hs[1]) and np.array_equal(hs[0], hs[2])
+    B.close()
