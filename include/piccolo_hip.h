@@ -137,6 +137,10 @@ int pcl_set_order_policy(pcl_ctx *ctx, double dt_max, const double *u_max /* n_d
  * the scalar form B.f, the device-pointer entry points and the host-pointer ones all evaluate ONE order from the first call on.
  * option "order_tol_met" reads 0 (and pcl_last_error carries a note) when even order 10 exceeds the tolerance. */
 int pcl_set_order_from_trajectory(pcl_ctx *ctx, const double *Z_host, double tol, int32_t *order_out);
+/* The policy itself, without a context or a device: n x n generators (column-major; n = 2 d for unitary and ket problems), n_g0 drifts, m drives.
+ * theta_out / order_out / met_out (0: even order 10 exceeds tol) may be NULL. */
+int pcl_order_for_bounds(int32_t n, int32_t m, const double *G0, int32_t n_g0, const double *Gj, double dt_max, const double *u_max, double tol,
+                         double *theta_out, int32_t *order_out, int32_t *met_out);
 
 /* dimensions --------------------------------------------------------------- */
 /* n_rows = batch*x_dim*(N-1); n_cols = z_dim*N*(TRAJ ? batch : 1) + global_dim. Any out pointer may be NULL. */

@@ -34,7 +34,7 @@ EXPORTS = [
     "pcl_rollout", "pcl_rollout_dev",
     "pcl_comm_get_unique_id", "pcl_comm_init", "pcl_reduce_sum_dev", "pcl_reduce_sum", "pcl_comm_destroy",
     "pcl_set_option", "pcl_get_option", "pcl_debug_timing", "pcl_codegen_source",
-    "pcl_codegen_source_v4", "pcl_codegen_apply_v4", "pcl_jit_prebuild", "pcl_set_order_policy", "pcl_set_order_from_trajectory",
+    "pcl_codegen_source_v4", "pcl_codegen_apply_v4", "pcl_jit_prebuild", "pcl_set_order_policy", "pcl_set_order_from_trajectory", "pcl_order_for_bounds",
     "pcl_set_goal_form", "pcl_objective_hess_nnz", "pcl_objective_hess_structure", "pcl_objective_hess_dev", "pcl_objective_hess",
 ]  # fmt: skip
 

@@ -1903,27 +1903,24 @@ static void set_order(pcl_ctx *ctx, int order, double theta) {
     ctx->desc.pade_order = order;
     ctx->order_theta = theta;
 }
-extern "C" int pcl_set_order_policy(pcl_ctx *ctx, double dt_max, const double *u_max, double tol, int32_t *order_out) {
-    if (!ctx) return PCL_EINVAL;
-    if (!(dt_max > 0.0) || !(tol > 0.0) || (ctx->desc.n_drives > 0 && !u_max)) return fail(ctx, PCL_EINVAL, "pcl_set_order_policy: need dt_max > 0, tol > 0 and the drives' bounds");
-    const int n = ctx->n, m = ctx->desc.n_drives;
+// theta = dt_max max_{|u_l| <= u_max_l} |G_drift + sum_l u_l G_l|_2 over n_g0 drifts (n x n, column-major; any real generators).  The norm is convex
+// in u, so the maximum over the box sits at a vertex: all 2^m sign patterns are tried (m <= 10; 64 norms of a 54 x 54 matrix at config 3: tens of
+// ms, once per context).  The triangle inequality |G_drift| + sum_l u_max_l |G_l| -- what rounds 3-4 used, and the fallback for m > 10 -- overshoots
+// by half where the drives act on different subsystems (config 3: 10.5 against 6.86) and would ask for an order that no trajectory in the box needs.
+// Further drifts (ensemble members): |G_drift_b + D| <= max_vertex |G_drift_0 + D| + |G_drift_b - G_drift_0|.
+static double policy_theta(int n, int m, const double *G0, size_t n_g0, const double *Gj, double dt_max, const double *u_max) {
     const size_t nn = (size_t)n * n;
-    // theta = dt_max max_{|u_l| <= u_max_l} |G_drift + sum_l u_l G_l|_2.  The norm is convex in u, so the maximum over the box sits at a
-    // vertex: all 2^m sign patterns are tried (m <= 10; 64 norms of a 54 x 54 matrix at config 3: tens of ms, once per context).  The
-    // triangle inequality |G_drift| + sum_l u_max_l |G_l| -- what rounds 3-4 used, and the fallback for m > 10 -- overshoots by half where the
-    // drives act on different subsystems (config 3: 10.5 against 6.86) and would ask for an order that no trajectory in the box needs.
-    // Further members' drifts (ensembles): |G_drift_b + D| <= max_vertex |G_drift_0 + D| + |G_drift_b - G_drift_0|.
     double gd = 0.0;
-    for (int l = 0; l < m; ++l) gd += std::fabs(u_max[l]) * spectral_norm(ctx->hGj.data() + (size_t)l * nn, n);
-    const double tri0 = spectral_norm(ctx->hG0.data(), n) + gd;
+    for (int l = 0; l < m; ++l) gd += std::fabs(u_max[l]) * spectral_norm(Gj + (size_t)l * nn, n);
+    const double tri0 = spectral_norm(G0, n) + gd;
     double vmax = tri0;
     if (m <= 10) {
         std::vector<double> G(nn);
         vmax = 0.0;
         for (unsigned sgn = 0; sgn < (1u << m); ++sgn) {
             for (size_t e = 0; e < nn; ++e) {
-                double a = ctx->hG0[e];
-                for (int l = 0; l < m; ++l) a += ((sgn >> l) & 1u ? -1.0 : 1.0) * std::fabs(u_max[l]) * ctx->hGj[(size_t)l * nn + e];
+                double a = G0[e];
+                for (int l = 0; l < m; ++l) a += ((sgn >> l) & 1u ? -1.0 : 1.0) * std::fabs(u_max[l]) * Gj[(size_t)l * nn + e];
                 G[e] = a;
             }
             vmax = std::max(vmax, spectral_norm(G.data(), n));
@@ -1931,13 +1928,31 @@ extern "C" int pcl_set_order_policy(pcl_ctx *ctx, double dt_max, const double *u
         vmax = std::min(vmax, tri0);
     }
     double theta = dt_max * vmax;
-    if (ctx->hG0.size() > nn) {
-        std::vector<double> Dm(nn);
-        for (size_t b = 1; b * nn < ctx->hG0.size(); ++b) {
-            for (size_t e = 0; e < nn; ++e) Dm[e] = ctx->hG0[b * nn + e] - ctx->hG0[e];
-            theta = std::max(theta, dt_max * (vmax + spectral_norm(Dm.data(), n)));
-        }
+    std::vector<double> Dm(nn);
+    for (size_t b = 1; b < n_g0; ++b) {
+        for (size_t e = 0; e < nn; ++e) Dm[e] = G0[b * nn + e] - G0[e];
+        theta = std::max(theta, dt_max * (vmax + spectral_norm(Dm.data(), n)));
     }
+    return theta;
+}
+// The policy without a context or a device (what pcl_set_order_policy applies; the CPU tests pin it): n = generator dimension (2 d for unitary / ket
+// problems), n_g0 drifts.  order_out: the smallest diagonal Pade order whose bound kappa_q theta^(2q+1) is <= tol (10 when none is: *met_out = 0).
+extern "C" int pcl_order_for_bounds(int32_t n, int32_t m, const double *G0, int32_t n_g0, const double *Gj, double dt_max, const double *u_max, double tol,
+                                    double *theta_out, int32_t *order_out, int32_t *met_out) {
+    if (n < 1 || n > 4096 || m < 0 || n_g0 < 1 || !G0 || (m > 0 && (!Gj || !u_max)) || !(dt_max > 0.0) || !(tol > 0.0)) return PCL_EINVAL;
+    const double theta = policy_theta(n, m, G0, (size_t)n_g0, Gj, dt_max, u_max);
+    bool met = true;
+    const int order = order_for(theta, tol, &met);
+    if (theta_out) *theta_out = theta;
+    if (order_out) *order_out = order;
+    if (met_out) *met_out = met ? 1 : 0;
+    return PCL_OK;
+}
+extern "C" int pcl_set_order_policy(pcl_ctx *ctx, double dt_max, const double *u_max, double tol, int32_t *order_out) {
+    if (!ctx) return PCL_EINVAL;
+    if (!(dt_max > 0.0) || !(tol > 0.0) || (ctx->desc.n_drives > 0 && !u_max)) return fail(ctx, PCL_EINVAL, "pcl_set_order_policy: need dt_max > 0, tol > 0 and the drives' bounds");
+    const int n = ctx->n, m = ctx->desc.n_drives;
+    const double theta = policy_theta(n, m, ctx->hG0.data(), ctx->hG0.size() / ((size_t)n * n), ctx->hGj.data(), dt_max, u_max);
     ctx->order_tol = tol;
     bool met = true;
     set_order(ctx, order_for(theta, tol, &met), theta);

@@ -309,3 +309,56 @@ def test_pattern_compiled_fused_and_hessian_sources(lib, tmp_path):
         if name != "hess":
             scratch = [int(x) for x in re.findall(r"; ScratchSize: (\d+)", asm)]
             assert max(scratch) <= 64
+
+
+def test_order_policy_without_a_device(lib):
+    """pcl_order_for_bounds (what pcl_set_order_policy applies): theta is the exact maximum of |G(u)|_2 over the box of controls -- a vertex --
+    times dt_max, never the triangle bound; a generator whose rows sum to zero is not mistaken for zero (round-4 ADVICE: power iteration from the
+    all-ones vector); BASELINE config 3's bounds give order 10 at 1e-10 and order 8 at the synthetic trajectories' own scale; a tolerance no order
+    up to 10 meets is reported."""
+    import ctypes
+    import itertools
+    import math
+
+    from piccolo_jl_amd import synthetic
+
+    lib.pcl_order_for_bounds.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p,
+                                         ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    kappa = lambda q: math.factorial(q) ** 2 / (math.factorial(2 * q) * math.factorial(2 * q + 1))
+    want = lambda th, tol: next((2 * q for q in range(1, 6) if kappa(q) * th ** (2 * q + 1) <= tol), 10)
+
+    def policy(G0s, Gj, dt, um, tol):
+        G0s = np.atleast_3d(np.asarray(G0s, dtype=np.float64).reshape(-1, G0s.shape[-1], G0s.shape[-1]))
+        n, m = G0s.shape[-1], len(Gj)
+        g0 = np.ascontiguousarray(np.stack([g.T for g in G0s]))
+        gj = np.ascontiguousarray(np.stack([g.T for g in Gj])) if m else np.zeros(1)
+        u = np.ascontiguousarray(np.broadcast_to(np.asarray(um, dtype=np.float64), (max(m, 1),)))
+        th, od, met = ctypes.c_double(), ctypes.c_int32(), ctypes.c_int32()
+        rc = lib.pcl_order_for_bounds(n, m, g0.ctypes.data, len(G0s), gj.ctypes.data, dt, u.ctypes.data, tol, ctypes.byref(th), ctypes.byref(od), ctypes.byref(met))
+        assert rc == 0
+        return th.value, od.value, met.value
+
+    s3 = synthetic.config_system(3)
+    G0, Gj = s3.G_drift, s3.G_drives_array()
+    box = lambda um: 0.1 * max(np.linalg.norm(G0 + np.tensordot(um * np.array(sg), Gj, axes=1), 2) for sg in itertools.product((-1.0, 1.0), repeat=len(Gj)))
+    tri = 0.1 * (np.linalg.norm(G0, 2) + 0.1 * sum(np.linalg.norm(g, 2) for g in Gj))
+    th, od, met = policy(G0, Gj, 0.1, 0.1, 1e-10)
+    assert abs(th - box(0.1)) <= 1e-8 * th and th < 0.7 * tri and (od, met) == (10, 1) == (want(th, 1e-10), 1)
+    th, od, met = policy(G0, Gj, 0.1, 0.02, 1e-10)
+    assert abs(th - box(0.02)) <= 1e-8 * th and (od, met) == (8, 1)
+    assert policy(G0, Gj, 0.1, 0.1, 1e-13)[1:] == (10, 0)  # kappa_5 theta^11 = 1.6e-12 > 1e-13: said, not hidden
+    assert policy(G0, Gj, 0.01, 0.1, 1e-10)[1] == want(0.1 * box(0.1), 1e-10)
+    # per-member drifts: theta covers every member (the bound used: vertex maximum of member 0 + |G0_b - G0_0|)
+    members = synthetic.config4_members(0, 3)
+    th_m = policy(np.stack([s.G_drift for s in members]), Gj, 0.1, 0.1, 1e-10)[0]
+    exact = max(0.1 * max(np.linalg.norm(s.G_drift + np.tensordot(0.1 * np.array(sg), Gj, axes=1), 2) for sg in itertools.product((-1.0, 1.0), repeat=len(Gj))) for s in members)
+    assert exact <= th_m * (1 + 1e-12) and th_m <= exact * 1.01
+    # rows that sum to zero
+    H = 3.0 * np.array([[1.0, -1.0], [-1.0, 1.0]], dtype=complex)
+    sz = pa.QuantumSystem(H, [pa.PAULIS["X"]], [1.0])
+    th, od, _ = policy(sz.G_drift, sz.G_drives_array(), 0.1, 0.0, 1e-10)
+    true = 0.1 * np.linalg.norm(sz.G_drift, 2)
+    assert abs(th - true) <= 1e-8 * true and od == want(true, 1e-10)
+    # no drives
+    th, od, _ = policy(sz.G_drift, [], 0.2, 0.0, 1e-6)
+    assert abs(th - 2 * true) <= 1e-8 * true and od == want(2 * true, 1e-6)
