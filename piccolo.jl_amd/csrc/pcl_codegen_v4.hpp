@@ -20,7 +20,7 @@ namespace pcl_codegen {
 
 constexpr int kV4Group = 3;    // output rows accumulated together (2 * kV4Group independent chains; the product is ONE asm statement of
                                // 54 + 7 kV4Group + ~13 vector registers next to whatever the role keeps live: 128 per lane at 14 waves per CU)
-constexpr int kV4Parts = 4;    // row ranges of the cooperative product (= the store-stream waves of the fused kernel)
+constexpr int kV4Parts = 4;    // row ranges of the cooperative product (default; v4_parts() decides per system and order)
 constexpr int kV4Chunk = 8;    // drift coefficients per scalar-load chunk (one s_load_dwordx16; two chunks of scalar registers in rotation)
 constexpr int kV4MaxCf = 16;   // resident drive coefficients (drive, magnitude) the product keeps in scalar registers
 constexpr int kV4MaxRes = 28;  // resident coefficients in all (scalar register pairs): the drives' first, then the drift's value classes by use
@@ -245,6 +245,15 @@ static inline int v4_gather_total(const V4Plan &P) {
     for (int v : mx) tot += v;
     return tot;
 }
+// Row ranges (= waves) of the cooperative product of a system at order 2q: whole groups of kV4Group output rows, at most the m + 3 column waves
+// that are idle while a workgroup's first powers are built (P, W, V, dW_l).  PCL_V4_PARTS overrides (measurements).
+static inline int v4_parts(const V4Plan &P, int q) {
+    (void)q;
+    const int n_groups = (P.d + kV4Group - 1) / kV4Group;
+    int want = kV4Parts;
+    if (const char *e = getenv("PCL_V4_PARTS")) want = atoi(e);
+    return std::max(1, std::min(std::min(want, P.m + 3), n_groups));
+}
 // np: LDS tiles the powers of G rotate through (>= 2 for q >= 2; q when they fit)
 // variant: timing experiments of the product (WRONG results unless 0): 1 no ds_add_f64 | 2 no LDS operation in the epilogues | 3 one
 // accumulator chain per output row group only half as deep (kV4Group rows -> plain v_mul of every term: no dependent chains)
@@ -442,8 +451,9 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
     // powers of G built by the store-stream waves together -- they have nothing to store yet -- a quarter of the rows each.
     // Every row keeps the instruction sequence it has in sp4_product0: the same bits.
     const int n_groups = (d + G - 1) / G;
-    const bool parts = n_chunks == 0 && n_groups >= kV4Parts;
-    snprintf(buf, sizeof buf, "#define SP4_COOP %d\n#define SP4_NPART %d\n", parts ? 1 : 0, kV4Parts);
+    const int nparts = v4_parts(P, q);
+    const bool parts = n_chunks == 0 && n_groups >= nparts && nparts >= 2;
+    snprintf(buf, sizeof buf, "#define SP4_COOP %d\n#define SP4_NPART %d\n", parts ? 1 : 0, nparts);
     s += buf;
     if (parts) {
         std::vector<std::pair<int, int>> part_rows;
@@ -451,11 +461,11 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
         for (const V4Term &t : P.terms) cum[t.row / G + 1]++;
         for (int g = 0; g < n_groups; ++g) cum[g + 1] += cum[g] + 4;  // (+ the group's epilogue)
         int lo = 0;
-        for (int k = 0; k < kV4Parts; ++k) {
+        for (int k = 0; k < nparts; ++k) {
             int hi = lo + 1;
-            const size_t want = cum[n_groups] * (k + 1) / kV4Parts;
-            while (hi < n_groups - (kV4Parts - 1 - k) && cum[hi] < want) ++hi;
-            if (k == kV4Parts - 1) hi = n_groups;
+            const size_t want = cum[n_groups] * (k + 1) / nparts;
+            while (hi < n_groups - (nparts - 1 - k) && cum[hi] < want) ++hi;
+            if (k == nparts - 1) hi = n_groups;
             const std::string part_name = "sp4_product0_p" + std::to_string(k);  // (buf is the emitter's scratch)
             emit_product(part_name.c_str(), false, false, lo, hi);
             const std::string party_name = "sp4_product_p" + std::to_string(k);  // ... and with Y: the cooperative residual kernel
@@ -465,21 +475,21 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
         }
         s += "static __device__ __forceinline__ void sp4_product0_part(int part, const double (&x)[SPD], unsigned vO, unsigned vOo, double beta, double betas, sp_cptr tab, const sp4_cf &cf) {\n"
              "    switch (part) {\n";
-        for (int k = 0; k < kV4Parts; ++k) {
-            snprintf(buf, sizeof buf, "    %s sp4_product0_p%d(x, 0u, vO, vOo, 0.0, beta, betas, tab, cf); break;\n", k == kV4Parts - 1 ? "default:" : ("case " + std::to_string(k) + ":").c_str(), k);
+        for (int k = 0; k < nparts; ++k) {
+            snprintf(buf, sizeof buf, "    %s sp4_product0_p%d(x, 0u, vO, vOo, 0.0, beta, betas, tab, cf); break;\n", k == nparts - 1 ? "default:" : ("case " + std::to_string(k) + ":").c_str(), k);
             s += buf;
         }
         s += "    }\n}\n";
         s += "static __device__ __forceinline__ void sp4_product_part(int part, const double (&x)[SPD], unsigned vY, unsigned vO, unsigned vOo, double alpha, double beta, double betas, sp_cptr tab, const sp4_cf &cf) {\n"
              "    switch (part) {\n";
-        for (int k = 0; k < kV4Parts; ++k) {
-            snprintf(buf, sizeof buf, "    %s sp4_product_p%d(x, vY, vO, vOo, alpha, beta, betas, tab, cf); break;\n", k == kV4Parts - 1 ? "default:" : ("case " + std::to_string(k) + ":").c_str(), k);
+        for (int k = 0; k < nparts; ++k) {
+            snprintf(buf, sizeof buf, "    %s sp4_product_p%d(x, vY, vO, vOo, alpha, beta, betas, tab, cf); break;\n", k == nparts - 1 ? "default:" : ("case " + std::to_string(k) + ":").c_str(), k);
             s += buf;
         }
         s += "    }\n}\n";
         s += "static __device__ __forceinline__ void sp4_part_rows(int part, int &r0, int &r1) {\n    switch (part) {\n";
-        for (int k = 0; k < kV4Parts; ++k) {
-            snprintf(buf, sizeof buf, "    %s r0 = %d; r1 = %d; break;\n", k == kV4Parts - 1 ? "default:" : ("case " + std::to_string(k) + ":").c_str(), part_rows[k].first, part_rows[k].second);
+        for (int k = 0; k < nparts; ++k) {
+            snprintf(buf, sizeof buf, "    %s r0 = %d; r1 = %d; break;\n", k == nparts - 1 ? "default:" : ("case " + std::to_string(k) + ":").c_str(), part_rows[k].first, part_rows[k].second);
             s += buf;
         }
         s += "    }\n}\n";

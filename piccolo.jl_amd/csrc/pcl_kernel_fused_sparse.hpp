@@ -356,11 +356,20 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
             double *Po = first_tile(j - 1);
             const double *Pi = first_tile(j - 2);
             gave_up = sp4_wait(sync, SP4_F_CO, SP4_NPART * (j - 1), gave_up);  // every row of the previous power is in its tile
+#ifdef PCL_PROFILE
+            if (p.prof & 512) SP4_STAMP();  // (fine stamps of a cooperative level: wait | operand in registers | product | arrived)
+#endif
             double x[SPD];
             if (act) {
 #pragma unroll
                 for (int i = 0; i < SPD; ++i) x[i] = Pi[own + i];
             }
+#ifdef PCL_PROFILE
+            if (p.prof & 512) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                SP4_STAMP();
+            }
+#endif
             if (j > npw && !borrow) {  // a ring shorter than q: the stream has folded the power this tile held ...
                 for (int w = 0; w < SP4_NSTREAM; ++w) gave_up = sp4_wait(sync, SP4_F_C + w, j - npw, gave_up);
                 if (npw == 1) {  // ... and with ONE tile every part has its operand in registers before a row is rewritten
@@ -370,6 +379,9 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
                 }
             }
             if (act) sp4_product0_part(wave, x, sp4_lds_off(Po + own), sp4_lds_off(Po + oth), 1.0, bs, tab, cf);
+#ifdef PCL_PROFILE
+            if (p.prof & 512) SP4_STAMP();
+#endif
             wave_lds_sync();
             sp4_arrive(sync + SP4_F_CO, lane);
             SP4_STAMP();

@@ -1048,7 +1048,7 @@ static int launch_eval_v4(pcl_ctx *ctx, KParams &p) {
     if (coop) {
         const size_t ldsc = (size_t)4 * p.d * (p.n + 1) * sizeof(double);
         const long long gc = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, items) : std::min<long long>(items, 3LL * std::max(ctx->n_cu, 1));
-        HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fevalc, (unsigned)gc, 1, 1, 64 * 4, 1, 1, (unsigned)ldsc, ctx->stream, args, nullptr));
+        HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fevalc, (unsigned)gc, 1, 1, 64 * pcl_codegen::v4_parts(v4, p.q), 1, 1, (unsigned)ldsc, ctx->stream, args, nullptr));
     } else
         HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_feval, (unsigned)grid, 1, 1, 64 * nw, 1, 1, (unsigned)lds, ctx->stream, args, nullptr));
     ctx->last_kernel = 80 + p.q;
