@@ -2423,11 +2423,12 @@ def test_runtime_compiled_shape_instances():
         Zs.append(Z)
     c = make_ctx(lay, 0.2 * G0, Gj, batch=Bn, batch_mode=pa._lib.PCL_BATCH_TRAJ)
     G0 = 0.2 * G0
-    n0 = c.get_option("jit_compiles")
+    loaded = lambda cc: cc.get_option("jit_compiles") + cc.get_option("jit_cache_hits")  # (compiled here, or taken from the user's code-object cache of an earlier run on this box)
+    n0 = loaded(c)
     c.set_option("kernel_version", 3)  # fused: the compiled instance replaces the run-time-shape instance of kernel 3
     delta, vals = c.eval_jac(np.stack(Zs))
     assert c.get_option("last_kernel") == 32 and c.get_option("last_stream_workgroups") > 0
-    assert c.get_option("jit_compiles") == n0 + 1
+    assert loaded(c) == n0 + 1
     refs = [ref_lib.eval_jac(Z, lay, G0, Gj) for Z in Zs]
     d_ref = np.concatenate([r[0].reshape(-1) for r in refs])
     j_ref = np.concatenate([r[1].reshape(-1) for r in refs])
@@ -2435,7 +2436,7 @@ def test_runtime_compiled_shape_instances():
     close(vals, j_ref, 1e-11)
     mu = rng.standard_normal((Bn, lay.K, lay.x_dim))
     hv = c.hess(np.stack(Zs), mu.reshape(-1))
-    assert c.get_option("last_hess_kernel") == 5 and c.get_option("jit_compiles") == n0 + 2  # one compile per template instance
+    assert c.get_option("last_hess_kernel") == 5 and loaded(c) == n0 + 2  # one module per template instance
     h_ref = np.concatenate([ref_lib.hess(Z, mu[i], lay, G0, Gj).reshape(-1) for i, Z in enumerate(Zs)])
     close(hv, h_ref, 1e-10)
     c.set_option("jit", 0)
@@ -2451,7 +2452,7 @@ def test_runtime_compiled_shape_instances():
     c2 = make_ctx(lay, G0, Gj, batch=Bn, batch_mode=pa._lib.PCL_BATCH_TRAJ)  # same shape again: served from the process cache
     c2.set_option("kernel_version", 3)
     c2.eval_jac(np.stack(Zs))
-    assert c2.get_option("last_kernel") == 32 and c2.get_option("jit_compiles") == n0 + 2
+    assert c2.get_option("last_kernel") == 32 and loaded(c2) == n0 + 2
     c2.close()
 
 
