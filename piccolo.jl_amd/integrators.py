@@ -391,12 +391,33 @@ class _PclContext:
         return v.value
 
 
+def _abs_bound(b, n):
+    """max(|lower|, |upper|) per component of a bounds entry, in the shapes the mirror and the reference use: ``(lower_vec, upper_vec)`` (NamedTrajectory
+    [REF named_trajectory_conversion.jl:331-332]), a list of ``(lo, hi)`` pairs per component (``system.drive_bounds``), one ``(lo, hi)`` pair, a symmetric
+    bound per component, or a scalar."""
+    if isinstance(b, tuple) and len(b) == 2 and all(np.ndim(x) <= 1 for x in b):  # (lower, upper): vectors or scalars
+        lo, hi = (np.broadcast_to(np.asarray(x, dtype=np.float64), (n,)) for x in b)
+        return np.maximum(np.abs(lo), np.abs(hi))
+    a = np.asarray(b, dtype=np.float64)
+    if a.ndim == 0:
+        return np.full(n, abs(float(a)))
+    if a.shape == (n, 2):  # pairs per component
+        return np.max(np.abs(a), axis=1)
+    if a.shape == (2, n):
+        return np.max(np.abs(a), axis=0)
+    if a.shape == (n,):
+        return np.abs(a)
+    if a.shape == (2,):
+        return np.full(n, np.max(np.abs(a)))
+    raise ValueError("bounds of shape %r for a component of dimension %d" % (a.shape, n))
+
+
 def _decide_order(ctx, traj, u_name, m, tol, copies=1):
     """``pade_order = 0`` at construction: the order policy over the trajectory's bounds, else over the trajectory itself."""
     ub, tb = traj.bounds.get(u_name), traj.bounds.get(traj.timestep)
     if ub is not None and tb is not None and m:
-        umax = np.max(np.abs(np.broadcast_to(np.asarray(ub, dtype=np.float64), (2, len(traj.components[u_name])))), axis=0)[:m]
-        return ctx.set_order_policy(float(np.max(np.abs(np.asarray(tb, dtype=np.float64)))), umax, tol)
+        umax = _abs_bound(ub, len(traj.components[u_name]))[:m]
+        return ctx.set_order_policy(float(np.max(_abs_bound(tb, len(traj.components[traj.timestep])))), umax, tol)
     Z = np.ascontiguousarray(traj.datavec, dtype=np.float64).reshape(-1)
     return ctx.set_order_from_trajectory(np.tile(Z, copies) if copies > 1 else Z, tol)
 

@@ -362,3 +362,17 @@ def test_order_policy_without_a_device(lib):
     # no drives
     th, od, _ = policy(sz.G_drift, [], 0.2, 0.0, 1e-6)
     assert abs(th - 2 * true) <= 1e-8 * true and od == want(2 * true, 1e-6)
+
+
+def test_bounds_formats_of_the_order_policy():
+    """The order policy reads max(|lower|, |upper|) per drive from the trajectory's bounds in every shape the mirror and the reference hand them over in."""
+    from piccolo_jl_amd.integrators import _abs_bound
+
+    assert np.array_equal(_abs_bound((-0.1 * np.ones(6), 0.2 * np.ones(6)), 6), np.full(6, 0.2))  # (lower_vec, upper_vec): NamedTrajectory.bounds
+    assert np.array_equal(_abs_bound([(-0.1, 0.2)] * 6, 6), np.full(6, 0.2))  # system.drive_bounds: a pair per drive
+    assert np.array_equal(_abs_bound([(-0.3, 0.1), (-0.1, 0.2)], 2), [0.3, 0.2])
+    assert np.array_equal(_abs_bound((np.array([-0.3, -0.1]), np.array([0.2, 0.4])), 2), [0.3, 0.4])
+    assert np.array_equal(_abs_bound(0.3, 3), np.full(3, 0.3)) and np.array_equal(_abs_bound((0.05, 0.1), 1), [0.1])
+    assert np.array_equal(_abs_bound(np.array([0.1, 0.2, 0.3]), 3), [0.1, 0.2, 0.3])
+    with pytest.raises(ValueError):
+        _abs_bound(np.zeros((3, 3)), 4)
