@@ -60,7 +60,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_v4_flags = v;
     else if (!strcmp(key, "v4_ticket"))  // kernel 4: work items by ticket (-1 auto: full-value launches of several intervals per CU | 0 static split | 1)
         ctx->opt_v4_ticket = v < 0 ? -1 : (v != 0);
-    else if (!strcmp(key, "v4_ticket_cols"))  // ... state columns per slice ticket (0 auto: 3)
+    else if (!strcmp(key, "v4_ticket_cols"))  // ... state columns per slice ticket (0 auto: 4 since round 5; 3 in round 4)
         ctx->opt_v4_ticket_cols = v < 0 ? 0 : v;
     else if (!strcmp(key, "v4_ticket_ahead"))  // ... slices taken ahead of the one being stored (0 | 1)
         ctx->opt_v4_ticket_ahead = v < 0 || v > 2 ? 0 : v;

@@ -1135,7 +1135,8 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     const bool ticket = ticket_ok && (ctx->opt_v4_ticket == 1 || (ticket_auto && tune_variant == 1));
     // (orders 6-10: the P wave's q products per visit are the longer chain -- 8 trajectories at order 8: 246-254 against 232 us)
     if (ticket) {
-        p.tick_cpi = ctx->opt_v4_ticket_cols > 0 ? (int)std::min<int64_t>(ctx->opt_v4_ticket_cols, d) : std::min(3, d);
+        // (slices of 4 state columns: 201.7 against 203.7 us per 8 seeds and 1.500 against 1.508 ms per 64 for slices of 3, the round-4 default; 5 the same, 2 / 7 / 9 slower: round 5)
+        p.tick_cpi = ctx->opt_v4_ticket_cols > 0 ? (int)std::min<int64_t>(ctx->opt_v4_ticket_cols, d) : std::min(4, d);
         while ((d + p.tick_cpi - 1) / p.tick_cpi > 31) ++p.tick_cpi;  // (the slice index travels in five bits)
         p.tick = ctx->dv4_tick;
         p.tick_G = tick_G;

@@ -1004,7 +1004,7 @@ def test_slice_tickets_equal_the_static_split():
         for opts in (dict(v4_ticket=1), dict(v4_ticket=1, v4_group=16), dict(v4_ticket=1, v4_group=4, v4_ticket_cols=5), dict(v4_ticket=1, v4_ticket_cols=1),
                      dict(v4_ticket=1, v4_ticket_cols=27, v4_group=2), dict(v4_ticket=1, v4_ticket_ahead=0), dict(v4_ticket=1, v4_ticket_ahead=1, v4_ticket_cols=2)):
             got = run(**opts)
-            assert c.get_option("last_v4_ticket") == opts.get("v4_ticket_cols", 3)
+            assert c.get_option("last_v4_ticket") == opts.get("v4_ticket_cols", 4)
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (Bn, order, opts)
         if order == 4:
             run(v4_ticket=1)
@@ -1038,7 +1038,7 @@ def test_slice_tickets_equal_the_static_split():
     d0, v0 = c.eval_jac(Zh)
     c.set_option("v4_ticket", 1)
     d1, v1 = c.eval_jac(Zh)
-    assert c.get_option("last_v4_ticket") == 3 and np.array_equal(d0, d1) and np.array_equal(v0, v1)
+    assert c.get_option("last_v4_ticket") == 4 and np.array_equal(d0, d1) and np.array_equal(v0, v1)
     for b in range(2):
         close(d1.reshape(2, -1)[b], po.pade_residual(Zs[b], lay, G0, Gj, 4).reshape(-1), 1e-12)
         close(v1.reshape(2, -1)[b], po.pade_jacobian_values(Zs[b], lay, G0, Gj, 4).reshape(-1), 1e-12)
