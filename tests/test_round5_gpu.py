@@ -328,3 +328,48 @@ def test_host_store_widths_and_hessian_wave_placement_give_the_same_bits():
         assert c.get_option("last_hess_kernel") == 84
     assert np.array_equal(hs[0], hs[1]) and np.array_equal(hs[0], hs[2])
     B.close()
+
+
+@pytest.mark.parametrize("order", [8, 10])
+def test_one_item_workgroups_at_high_order_with_the_payload(order):
+    """Round 5, one-item workgroups at orders 8 / 10: powers beyond the ring stand in borrowed dW tiles and W alternates between two tiles -- so at odd
+    q the residual ends in the power tile the writer wave reads it from.  A two-member ensemble (198 items: one per workgroup) through the payload-fused
+    launch: residual, values and the reduce payload bitwise equal to the launch without the cooperative start (v4_flags 4) and without the second W tile
+    (64); the values against the oracle, the payload against the separate payload kernels."""
+    import torch
+
+    from test_parity_gpu import _config4_share
+
+    osys, psys, lay, Z, traj = _config4_share(2, 100)
+    names = ["Ũ⃗%d" % (i + 1) for i in range(2)]
+    B = pa.HipPadeIntegrator(np.array([s.G_drift for s in psys]), psys[0].G_drives_array(), traj, names, pade_order=order)
+    c = B.ctx
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    Zd = torch.from_numpy(traj.datavec).cuda()
+    ln, _ = c.merit_grad_len()
+    res = []
+    for flags in (0, 64, 4):
+        c.set_option("v4_flags", flags)
+        dd = torch.full((c.n_rows,), float("nan"), dtype=torch.float64, device="cuda")
+        out = torch.full((c.jac_nnz,), float("nan"), dtype=torch.float64, device="cuda")
+        pay = torch.full((ln,), float("nan"), dtype=torch.float64, device="cuda")
+        c.eval_jac_merit_dev(Zd, None, dd, out, pay)
+        c.sync()
+        assert c.get_option("last_kernel") == 40 + order // 2 and c.get_option("last_merit_fused") == 1
+        res.append((dd, out, pay))
+    for r in res[1:]:
+        assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
+    xd = lay.x_dim
+    per = c.jac_nnz // 2
+    for i, s in enumerate(osys):
+        G0, Gj = s.G_drift, np.array(s.G_drives)
+        d_ref = po.pade_residual(Z, lay, G0, Gj, order, x_off=i * xd).reshape(-1)
+        j_ref = po.pade_jacobian_values(Z, lay, G0, Gj, order, x_off=i * xd).reshape(-1)
+        assert np.abs(res[0][0].cpu().numpy().reshape(2, -1)[i] - d_ref).max() <= 1e-12
+        assert np.abs(res[0][1][i * per : (i + 1) * per].cpu().numpy() - j_ref).max() <= 1e-12 * max(1.0, np.abs(j_ref).max())
+    sep = torch.empty(ln, dtype=torch.float64, device="cuda")  # the separate payload kernels read delta and the tails back from memory
+    c.merit_grad_dev(res[0][0], None, res[0][1], sep)
+    c.sync()
+    a, b = res[0][2].cpu().numpy(), sep.cpu().numpy()
+    assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+    B.close()
