@@ -488,7 +488,7 @@ def main():
                                 "frac_of_hbm_peak": abytes * T / (d64 / 10) / 1e9 / HBM_PEAK_GBS, "ab": i64.get("ab"),
                                 "note": "the value an N-GPU run of this script reports is the same 64 seeds with 64 / N per GPU"}
         # config 4 whole (64 members, ONE trajectory buffer of z_dim 93,332) on this one GPU: the N = 1 point of the ensemble's curve
-        we64, de64, ie64, ub64 = run_ensemble(T, 5, 3, False, nbuf=2)
+        we64, de64, ie64, ub64 = run_ensemble(T, 5, 10, False, nbuf=2)  # (10 untimed steps: the per-array choice of v4_tune is made in them)
         out["ensemble_64"] = {"evals_per_s": T * 5 / we64, "us_per_step_kernel": de64 / 5 * 1e6, "members_per_step": T, "z_dim": ie64["z_dim"], **spread_us(ie64.get("per_buffer_us", [])),
                               "frac_of_hbm_peak": ub64 * T / (de64 / 5) / 1e9 / HBM_PEAK_GBS, "launches_per_step": ie64["launches_per_step"], "payload_fused": ie64["payload_fused"],
                               "note": "BASELINE config 4 at its real size (sampling_trajectory.jl:207-237 layout): fused residual+Jacobian of 64 members + objective + payload, no all-reduce (one rank)"}
