@@ -888,11 +888,13 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
                     half_col = p.nc - 1;
                     if (c0 > 0) cbeg = half_col;
                 }
-                // nt 3: write-through on every other workgroup = every other XCD (workgroups are dispatched round-robin over the XCDs).  Plain stores
+                // nt 3: write-through on every other workgroup = every other XCD (workgroups are dispatched round-robin over the XCDs; the even ones since round 5).  Plain stores
                 // leave up to 32 MB dirty in the L2s, written back behind the kernel's end (2 us of the gap between two launches); write-through
                 // everywhere makes the kernel itself 0.9 us longer.  Half of the XCDs each way: one trajectory 25.9 -> 25.3 us at order 4
                 // (contiguous halves of the XCDs, a quarter or all of them: 25.7).  A performance hint only: any placement gives the same values.
-                const int nt_b = p.nt == 3 ? ((bx & 1) ? 2 : 0) : p.nt;
+                // (round 5: the EVEN workgroups -- the XCDs the memory side serves first -- take the write-through stores: 24.67 against 25.06 us per one-trajectory launch
+                //  at order 4 with the odd ones, three alternating rounds on one box, twice; 3 or 5 of 8 XCDs, 2 of 8, 6 of 8: 25.0-25.2)
+                const int nt_b = p.nt == 3 ? ((bx & 1) ? 0 : 2) : p.nt;
                 double *o = p.jac + ((long long)b * p.K + k) * p.jac_per + (long long)cbeg * nn + pi;
                 for (int cq = cbeg; cq < cend; ++cq, o += nn) {
                     // (tick_ahead 2: the dispatcher asks for the next slice while this one's last column goes out)
