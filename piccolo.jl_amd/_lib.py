@@ -35,6 +35,7 @@ EXPORTS = [
     "pcl_comm_get_unique_id", "pcl_comm_init", "pcl_reduce_sum_dev", "pcl_reduce_sum", "pcl_comm_destroy",
     "pcl_set_option", "pcl_get_option", "pcl_debug_timing", "pcl_codegen_source",
     "pcl_codegen_source_v4", "pcl_codegen_apply_v4", "pcl_jit_prebuild", "pcl_set_order_policy", "pcl_set_order_from_trajectory", "pcl_order_for_bounds",
+    "pcl_resident_start", "pcl_resident_post", "pcl_resident_wait", "pcl_resident_stop", "pcl_resident_completed", "pcl_resident_stamps",
     "pcl_set_goal_form", "pcl_objective_hess_nnz", "pcl_objective_hess_structure", "pcl_objective_hess_dev", "pcl_objective_hess",
 ]  # fmt: skip
 
@@ -166,6 +167,12 @@ def load():
     L.pcl_deriv_eval_jac_dev.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp]
     L.pcl_set_goal.argtypes = [vp, vp]
     L.pcl_jac_dev.argtypes = [vp, vp, vp]
+    L.pcl_resident_start.argtypes = [vp, vp, vp, vp]
+    L.pcl_resident_post.argtypes = [vp, ctypes.c_int32]
+    L.pcl_resident_wait.argtypes = [vp, ctypes.c_double]
+    L.pcl_resident_stop.argtypes = [vp]
+    L.pcl_resident_completed.argtypes = [vp, c_i64p]
+    L.pcl_resident_stamps.argtypes = [vp, vp, ctypes.c_int64]
     L.pcl_set_member_window.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
     L.pcl_set_goal_subspace.argtypes = [vp, vp, c_i32p, ctypes.c_int32]
     L.pcl_set_weights.argtypes = [vp, vp]
@@ -195,7 +202,7 @@ def load():
     return L
 
 
-def prebuild_kernels(G_drifts, G_drives, orders=(4,), hessian=True, out_dir=None):
+def prebuild_kernels(G_drifts, G_drives, orders=(4,), hessian=True, out_dir=None, resident=False):
     """Compile the pattern-compiled modules a context of this system (one drift, or the per-member drifts of an ensemble) would compile
     with hiprtc on first use, into ``csrc/prebuilt/`` (or ``out_dir``) under their content hashes -- a fresh process (every rank of a job)
     then loads them instead of compiling.  No device needed.  Returns the number of modules asked for."""
@@ -212,6 +219,7 @@ def prebuild_kernels(G_drifts, G_drives, orders=(4,), hessian=True, out_dir=None
     for order in orders:
         # 0 fused | 4 fused with the slice-ticket roles | 3 the order-4 Hessian module | 5 the column-group Hessian kernel (`auto` at the other orders)
         whats = [0] + ([4] if order <= 4 else []) + (([3, 5] if order == 4 else [5]) if hessian else [])  # (order 4: kernel 6, and the column-group kernel for one trajectory)
+        whats += [6] if resident else []  # the resident evaluator's module
         for what in whats:
             rc = L.pcl_jit_prebuild(d, m, G0.ctypes.data, G0.shape[0], Gj.ctypes.data if m else None, order // 2, what, od)
             if rc != 0:

@@ -338,7 +338,8 @@ std::string sparse_source(const pcl_codegen::SpPlan &plan) {
 // Source of the pattern-compiled fused residual + Jacobian kernel of one system at Pade order 2q (pcl_codegen_v4.hpp)
 // (np: tiles of the powers of G -- v4_power_tiles)
 std::string v4_source(const pcl_codegen::V4Plan &plan, int q, int np, int variant = 0, int tickets = 0) {
-    return std::string("#include \"pcl_device_common.hpp\"\n#define SP4_TICKETS ") + (tickets ? "1\n" : "0\n") + pcl_codegen::v4_functions(plan, q, np, variant) + "#include \"pcl_kernel_fused_sparse.hpp\"\n";
+    // tickets: 0 the static work splits | 1 with the slice-ticket roles | 2 the resident evaluator (static split, the evaluation as a device function)
+    return std::string("#include \"pcl_device_common.hpp\"\n#define SP4_TICKETS ") + (tickets == 1 ? "1\n" : "0\n") + (tickets == 2 ? "#define SP4_RESIDENT 1\n" : "") + pcl_codegen::v4_functions(plan, q, np, variant) + "#include \"pcl_kernel_fused_sparse.hpp\"\n";
 }
 
 // ... and of the Hessian-of-the-Lagrangian kernel of the same family (pcl_kernel_hess_sparse4.hpp; any order)
@@ -406,9 +407,9 @@ static int prebuild_source(const std::string &source, const char *name_expr, con
 // the pattern-compiled modules of one system, as a context of that system would compile them on first use (no device needed):
 //   what 0  fused residual + Jacobian + residual-only kernels at order 2q | 1  general-order Hessian, one workgroup per interval |
 //        2  ... two workgroups per interval | 3  the order-4 Hessian / value-table module (q ignored) | 4  the fused module with the slice-ticket
-//        roles | 5  general-order Hessian, one wave per group of state columns
+//        roles | 5  general-order Hessian, one wave per group of state columns | 6  the fused module of the resident evaluator
 extern "C" int pcl_jit_prebuild(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what, const char *out_dir) {
-    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || what < 0 || what > 5 || !G0 || (m > 0 && !Gj)) return fail(nullptr, PCL_EINVAL, "pcl_jit_prebuild: bad argument");
+    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || what < 0 || what > 6 || !G0 || (m > 0 && !Gj)) return fail(nullptr, PCL_EINVAL, "pcl_jit_prebuild: bad argument");
     std::string src, err;
     const char *kernel = "pcl_fused_sparse_kernel";
     if (what == 3) {
@@ -419,8 +420,11 @@ extern "C" int pcl_jit_prebuild(int d, int m, const double *G0, int n_g0, const 
         if (!plan.ok) return fail(nullptr, PCL_ESHAPE, "pcl_jit_prebuild: the pattern-compiled kernels do not take this system");
         const int np = v4_power_tiles(d, m, q, 160 * 1024);
         if (!np) return fail(nullptr, PCL_ESHAPE, "pcl_jit_prebuild: tiles exceed LDS");
-        src = what == 0 ? v4_source(plan, q, np) : what == 4 ? v4_source(plan, q, np, 0, 1) : what == 5 ? v4_hess_cols_source(plan, q) : v4_hess_source(plan, q, 0, what);
-        if (what && what != 4) kernel = what == 5 ? "pcl_hess_cols_kernel" : "pcl_hess_sparse4_kernel";
+        src = what == 0 ? v4_source(plan, q, np) : what == 4 ? v4_source(plan, q, np, 0, 1) : what == 6 ? v4_source(plan, q, np, 0, 2) : what == 5 ? v4_hess_cols_source(plan, q) : v4_hess_source(plan, q, 0, what);
+        if (what == 6)
+            kernel = "pcl_fused_sparse_resident";
+        else if (what && what != 4)
+            kernel = what == 5 ? "pcl_hess_cols_kernel" : "pcl_hess_sparse4_kernel";
     }
     const int rc = prebuild_source(src, kernel, out_dir, err);
     return rc == PCL_OK ? rc : fail(nullptr, rc, "pcl_jit_prebuild: %s", err.c_str());

@@ -76,6 +76,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_v4_tune = v != 0;
     else if (!strcmp(key, "host_store_bytes"))  // host expansion: bytes per streaming store (0 the widest the host has | 16 | 32 | 64)
         ctx->opt_host_store_bytes = (v == 16 || v == 32 || v == 64) ? v : 0;
+    else if (!strcmp(key, "resident_idle_us"))  // resident evaluator: the kernel leaves after this long without a request (10 .. 2 000 000)
+        ctx->opt_resident_idle_us = v < 10 ? 10 : (v > 2000000 ? 2000000 : v);
     else if (!strcmp(key, "hess_xcd"))  // column-group Hessian kernel: the waves of an interval take blockIdx values equal mod n = one XCD (-1 auto: 8 | 0, 1: blockIdx order)
         ctx->opt_hess_xcd = v < 0 ? -1 : v;
     else if (!strcmp(key, "hess_split"))  // general-order pattern-compiled Hessian kernel: two workgroups per interval (-1 auto by launch size | 0 | 1)
@@ -146,6 +148,10 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->last_kernel;
     else if (!strcmp(key, "hess_xcd"))
         *v = ctx->opt_hess_xcd;
+    else if (!strcmp(key, "resident_idle_us"))
+        *v = ctx->opt_resident_idle_us;
+    else if (!strcmp(key, "resident_launches"))  // starts of the resident kernel since pcl_create (1 + the times it had left when a request came)
+        *v = ctx->res.launches;
     else if (!strcmp(key, "v4_tune"))
         *v = ctx->opt_v4_tune;
     else if (!strcmp(key, "last_v4_tune_choice"))  // of the array the last multi-trajectory launch wrote: -1 still sampling | 0 static split | 1 slice tickets

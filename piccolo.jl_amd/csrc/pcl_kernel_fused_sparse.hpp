@@ -97,7 +97,15 @@ static __device__ __forceinline__ unsigned sp4_lds_off(const double *q) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const double *)q;
 }
 
+#ifndef SP4_RESIDENT
+#define SP4_RESIDENT 0            // 1: the module of the RESIDENT evaluator (pcl_resident_*): the evaluation below as a device function, called once per posted request
+#endif
+#if SP4_RESIDENT
+extern "C" {  // (the dynamic LDS array is declared by extern "C" kernels too: one language linkage)
+static __device__ __forceinline__ void sp4_fused_body(const KParams &p, const double *__restrict__ drift_tab, const double *__restrict__ mags_, const double *__restrict__ dcf_tab) {
+#else
 extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sparse_kernel(const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ mags_, const double *__restrict__ dcf_tab) {
+#endif
     extern __shared__ double lds[];
     constexpr int d = SPD, n = SPN, m = SPM, q = SP4Q, nn = SPN * SPN;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -950,6 +958,146 @@ extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sp
     if (wall_ && lane == 0) atomicMax((unsigned long long *)(wall_ + 2), (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #endif
 }
+#if SP4_RESIDENT
+}
+#endif
+
+#if SP4_RESIDENT
+// ------------------------------------------------------------------------------------------------------------------------------
+// RESIDENT evaluator (pcl_resident_start / _post / _wait / _stop): the same workgroups, one per CU, stay on the device and run the
+// evaluation above once per request -- no launch, no kernel boundary between two evaluations of one solver iteration after the other.
+// The trajectory, residual and values arrays are fixed at start (KParams); a request is a number:
+//     hbox (host memory, mapped):   [0] requests posted by the host | [1] stop | [16] evaluations complete (written by the device) | [17] workgroup 0 has left
+//     dbox (device memory):         [0] requests forwarded | [1] stop | [2] evaluations complete | [16], [17] workgroups that have finished
+//                                   an evaluation, by its parity | [32] workgroups gone | [40], [41] address of hbox | [42] the launch's first evaluation |
+//                                   [43] idle limit, 100 MHz ticks | [44] the evaluation the launch ends before
+// Workgroup 0 reads the host's words (one reader on the bus, not 256) and forwards them; every workgroup starts evaluation e once it is
+// posted and evaluation e - 2 is complete everywhere: a workgroup that finishes early starts the next evaluation while others still store
+// (its own column range only: nobody writes anybody else's values), and never runs more than one ahead, so two arrival words suffice.
+// Between two evaluations: the trajectory may have been rewritten (by a copy engine, by another queue) -- vector L1 / L2 lines of other
+// agents' data and the scalar cache are invalidated before, the workgroup's stores are written back behind.  A workgroup leaves when
+// told to, after `idle_ticks` (100 MHz) without a request (workgroup 0 decides, the others follow its stop word; their own limit is eight
+// times as long), or after max_evals evaluations -- the kernel ENDS by itself whatever the host does.
+// ------------------------------------------------------------------------------------------------------------------------------
+extern "C" {
+static __device__ __forceinline__ double *sp4_dyn_lds() {
+    extern __shared__ double lds[];
+    return lds;
+}
+}
+// (Nothing of the request loop may live in registers across the evaluation: the evaluation's resident coefficients take every scalar register
+//  there is -- the first version kept its pointers and counters in ten of them and the evaluation ran 9 us longer, 85 more spilled scalars.
+//  The loop's state is in LDS behind the evaluation's words and in dbox [40 ...]: the host words' address, the idle limit, the first evaluation.)
+#define SP4R_FLAG (2 * SP4_NTILES * SP4TILE + SP4_SYNC_WORDS)  // int index into the dynamic LDS: [0] go | [1] the evaluation's number | [2], [3] posted / complete as read beside the last arrival | [4] ... are there
+extern "C" __global__ __launch_bounds__(64 * (SP4_NWAVES + 1)) void pcl_fused_sparse_resident(const KParams *pdev, const double *__restrict__ drift_tab, const double *__restrict__ mags_, const double *__restrict__ dcf_tab,
+                                                                                           unsigned *dbox) {
+    typedef const KParams __attribute__((address_space(4))) *kp_cptr;
+    const int v4_flags = ((kp_cptr)pdev)->v4_flags;
+    if (threadIdx.x == 0) {
+        ((volatile int *)sp4_dyn_lds())[SP4R_FLAG + 1] = (int)__hip_atomic_load(dbox + 42, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ((volatile int *)sp4_dyn_lds())[SP4R_FLAG + 4] = 0;
+    }
+    for (;;) {
+        if (threadIdx.x == 0) {
+            volatile int *flag = (volatile int *)sp4_dyn_lds() + SP4R_FLAG;
+            const unsigned e = (unsigned)flag[1];
+            unsigned *hbox = (unsigned *)(((unsigned long long)__hip_atomic_load(dbox + 41, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32) | __hip_atomic_load(dbox + 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const unsigned idle_ticks = __hip_atomic_load(dbox + 43, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int go = 0;
+            const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+            const long long limit = blockIdx.x == 0 ? (long long)idle_ticks : 8LL * idle_ticks;
+            for (int poll = 0;; ++poll) {
+                const bool early = poll == 0 && flag[4] != 0;  // the words as read beside the last arrival (older than a fresh read, never newer: a request they show is there)
+                unsigned posted = early ? (unsigned)flag[2] : __hip_atomic_load(dbox + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (blockIdx.x == 0 && (int)(posted - e) <= 0) {  // the forwarder: the host's words, read only when this workgroup would wait (a read takes 1-2 us)
+                    const unsigned hp = __hip_atomic_load(hbox + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((int)(hp - posted) > 0) {
+                        __hip_atomic_store(dbox + 0, hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        posted = hp;
+                    } else if (__hip_atomic_load(hbox + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))
+                        __hip_atomic_store(dbox + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const unsigned done = early ? (unsigned)flag[3] : __hip_atomic_load(dbox + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(posted - e) > 0 && (int)(done + 1 - e) >= 0) {
+                    go = 1;
+                    break;
+                }
+                if (__hip_atomic_load(dbox + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > limit) {
+                    if (blockIdx.x == 0) __hip_atomic_store(dbox + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (a request that arrives now is the next start's)
+                    break;
+                }
+                if (poll < 16)
+                    __builtin_amdgcn_s_sleep(4);
+                else
+                    __builtin_amdgcn_s_sleep(16);
+            }
+            if (go && !(v4_flags & 128)) {
+                if (v4_flags & 512)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                else
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // other agents' writes (the trajectory) since the last evaluation
+                __builtin_amdgcn_s_dcache_inv();                    // ... which this kernel reads through the scalar cache
+            }
+            if ((v4_flags & 2048) && e - __hip_atomic_load(dbox + 42, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 16)  // (debugging: 100 MHz stamps per evaluation and workgroup)
+                ((long long *)(dbox + 64))[((e - __hip_atomic_load(dbox + 42, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) * 256 + (blockIdx.x & 255)) * 4 + 0] = (long long)__builtin_amdgcn_s_memrealtime();
+            flag[0] = go;
+        }
+        __syncthreads();
+        const int go = ((volatile int *)sp4_dyn_lds())[SP4R_FLAG];
+        __syncthreads();  // (the evaluation's first act is to write LDS words)
+        if (!go) break;
+        {  // (the parameter block is read where it is used, in every evaluation anew: hoisted out of the request loop its fields are live everywhere)
+            kp_cptr pp = (kp_cptr)pdev;
+            asm volatile("" : "+s"(pp));
+            sp4_fused_body(*(const KParams *)pp, drift_tab, mags_, dcf_tab);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the L2
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            volatile int *flag = (volatile int *)sp4_dyn_lds() + SP4R_FLAG;
+            const unsigned e = (unsigned)flag[1];
+            long long *st_ = nullptr;
+            if (v4_flags & 2048) {
+                const unsigned e0 = __hip_atomic_load(dbox + 42, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (e - e0 < 16) st_ = (long long *)(dbox + 64) + ((e - e0) * 256 + (blockIdx.x & 255)) * 4;
+            }
+            if (st_) st_[2] = (long long)__builtin_amdgcn_s_memrealtime();
+            if (!(v4_flags & 256)) {
+                if (v4_flags & 1024)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                else
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // ... and memory
+            }
+            // (relaxed behind the release fence: the next request's polls are in flight beside it -- one round trip to the memory side instead of
+            //  two.  What the last arrival publishes is already in memory: every workgroup's fence stands before its arrival.)
+            const unsigned a = __hip_atomic_fetch_add(dbox + 16 + (e & 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned posted_next = __hip_atomic_load(dbox + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned done_next = __hip_atomic_load(dbox + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag[2] = (int)posted_next, flag[3] = (int)done_next;
+            if (a + 1 == gridDim.x) {  // the last workgroup of evaluation e
+                unsigned *hbox = (unsigned *)(((unsigned long long)__hip_atomic_load(dbox + 41, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32) | __hip_atomic_load(dbox + 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                __hip_atomic_store(dbox + 16 + (e & 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dbox + 2, e + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(hbox + 16, e + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (st_) st_[3] = (long long)__builtin_amdgcn_s_memrealtime();
+            flag[1] = (int)(e + 1);
+            flag[4] = 1;
+            if (e + 1 == __hip_atomic_load(dbox + 44, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) flag[0] = 0;  // the launch's last evaluation (2^30 after its first: the kernel ends whatever happens)
+        }
+        __syncthreads();
+        if (!((volatile int *)sp4_dyn_lds())[SP4R_FLAG]) break;
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(dbox + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x == 0) {  // the host starts the kernel again before it posts
+            unsigned *hbox = (unsigned *)(((unsigned long long)__hip_atomic_load(dbox + 41, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32) | __hip_atomic_load(dbox + 40, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            __hip_atomic_store(hbox + 17, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Residual only (what the solver calls in every line-search trial), any order: delta = W_0 of the recursion above, q products.

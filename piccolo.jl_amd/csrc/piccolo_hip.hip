@@ -142,6 +142,24 @@ struct pcl_ctx {
     int64_t last_v4_ticket = 0;     // state columns per block ticket of the last kernel-4 launch (0: static work split)
     unsigned int *dv4_tick = nullptr;  // ... [block ticket, pipelines gone, chain ticket]: zero between launches (the last pipeline out resets them)
     int *herr = nullptr, *derr = nullptr;  // device error word (host-mapped): a barrier-free kernel whose bounded wait gave up sets bit 0
+    // RESIDENT evaluator (pcl_resident_*; pcl_kernel_fused_sparse.hpp, SP4_RESIDENT): kernel 4's workgroups stay on the device and run one
+    // evaluation per posted request
+    struct Resident {
+        hipStream_t stream = nullptr;  // its own: work queued behind a resident kernel waits for it to leave
+        hipFunction_t f = nullptr;
+        unsigned *hbox = nullptr, *hbox_dev = nullptr, *dbox = nullptr;  // the host's words (mapped) and the device's (layout: see the kernel)
+        unsigned *hinit = nullptr;                                        // pinned source of the device words' start values
+        KParams *dparams = nullptr, *hparams = nullptr;                   // the evaluation's parameter block in device memory (the kernel reads it per request, where it is used) and its pinned source
+        KParams p;
+        const double *tab = nullptr, *dcf = nullptr;
+        long long grid = 0;
+        size_t lds = 0;
+        unsigned block = 0, posted = 0;
+        bool active = false, launched = false;
+        int64_t launches = 0;
+    } res;
+    bool res_capture = false;            // launch_fused_v4 fills `res` instead of launching
+    int64_t opt_resident_idle_us = 5000; // the resident kernel leaves after this long without a request (the next request starts it again)
     int64_t opt_v4_tail_mode = 3;   // kernel 4: who stores delta and the tails: 0 the writer wave | 1 ... nontemporal | 2 ... write-through | 3 the stream waves (default)
     int64_t opt_eval_kernel = 0;    // 0 auto | 1 matrix-core residual kernel | 2 pattern-compiled
     // staging for the host-pointer entry points
@@ -601,6 +619,13 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     delete ctx->sp_plan;
     for (void *q : {(void *)ctx->dv4_tab, (void *)ctx->dv4_tab_t, (void *)ctx->dv4_mags, (void *)ctx->dv4_dcf, (void *)ctx->dv4_tick})
         if (q) (void)hipFree(q);
+    if (ctx->res.active) (void)pcl_resident_stop(ctx);
+    if (ctx->res.stream) (void)hipStreamDestroy(ctx->res.stream);
+    if (ctx->res.hbox) (void)hipHostFree(ctx->res.hbox);
+    if (ctx->res.hinit) (void)hipHostFree(ctx->res.hinit);
+    if (ctx->res.hparams) (void)hipHostFree(ctx->res.hparams);
+    if (ctx->res.dparams) (void)hipFree(ctx->res.dparams);
+    if (ctx->res.dbox) (void)hipFree(ctx->res.dbox);
     if (ctx->herr) (void)hipHostFree(ctx->herr);
     delete ctx->v4_plan;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -1085,7 +1110,7 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     // the previous slice's stores are issued -- the front of addresses being written stays tight and the workgroups the memory side
     // serves first take more slices: the time no longer depends on where the values array's pages live.
     const int tick_G = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->opt_v4_group > 0 ? ctx->opt_v4_group : 8, ncu));
-    const bool ticket_ok = !compact && ctx->dv4_tick && !ctx->v4_ft_failed && ctx->opt_grid <= 0 && m + 10 <= 16 && ncu % tick_G == 0 &&
+    const bool ticket_ok = !ctx->res_capture && !compact && ctx->dv4_tick && !ctx->v4_ft_failed && ctx->opt_grid <= 0 && m + 10 <= 16 && ncu % tick_G == 0 &&
                            v4_lds_bytes(d, m, np) + 8 * 8 * 128 <= (size_t)ctx->max_lds;
     const bool ticket_auto = ticket_ok && ctx->opt_v4_ticket < 0 && p.q <= 2 && p.contig && ctx->opt_contig < 0 && ctx->opt_cols_per_slice <= 0;
     // auto: which of the two this values array gets (see v4_tune); timed launches are bracketed by events below
@@ -1161,7 +1186,10 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     // write-through: 24.9 / 25.4 us at order 2, 27.2 / 27.6 at 4, 28.1 / 28.9 at 6, 32.4 / 31.9 at 8.  Orders 2 and 4: write-through on every
     // other XCD's workgroups (nt 3, see the kernel) -- plain / write-through / mixed 23.3 / 23.7 / 22.7 us at order 2, 26.1 / 25.6 / 25.5 at 4,
     // 26.2 / 27.2 / 26.5 at 6 (plain stays)
-    if (ctx->opt_nt < 0 && p.q < 4) p.nt = (p.nt == 2 && p.q <= 2) ? 3 : 0;
+    if (ctx->opt_nt < 0 && p.q < 4 && !ctx->res_capture) p.nt = (p.nt == 2 && p.q <= 2) ? 3 : 0;
+    // (the resident evaluator: write-through everywhere -- every request ends with a write-back of the L2, and dirty lines of plain stores make
+    //  that 10 us per request: 41 against 32 us per evaluation at config 3)
+    if (ctx->opt_nt < 0 && ctx->res_capture) p.nt = 2;
     const long long units = p.contig ? bk * d : bk * p.S;
     if (units > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
     const long long g = ctx->opt_grid > 0 ? std::min<long long>(ctx->opt_grid, units) : std::min<long long>(units, ncu);
@@ -1199,6 +1227,11 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
             fk = ctx->v4_ft;
         else
             return launch_fused_v4_static(ctx, p, compact, want_merit);
+    }
+    if (ctx->res_capture) {  // pcl_resident_start: the launch as data
+        ctx->res.p = p, ctx->res.tab = tab, ctx->res.dcf = dcf, ctx->res.grid = g, ctx->res.lds = lds, ctx->res.block = 64u * (unsigned)(m + 9);
+        ctx->res_capture = false;
+        return PCL_OK;
     }
     bool timed = false;
     if (tune && tune_slot >= 0) {  // one timed sample of the per-array choice
@@ -1273,6 +1306,7 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         if (rc != PCL_ENOTIMPL) return rc;
         if (ctx->opt_kernel == 4) return fail(ctx, PCL_ESHAPE, "kernel_version=4 needs sparse exact-iso generators of a unitary problem (9 <= d, tiles within LDS), 1..6 drives and jit=1 (%s)", g_jit_note.c_str());
     }
+    if (ctx->res_capture) return fail(ctx, PCL_ESHAPE, "pcl_resident_start: the resident evaluator is kernel 4's (sparse exact-iso generators of a unitary problem, 9 <= d, tiles within LDS, 1..6 drives, jit = 1; kernel_version 0 or 4)");
     if (p.nt == 3) p.nt = 2;  // (the mixed mode is kernel 4's)
     // residual only on the same products (eval_kernel 3; auto: every order -- measured against the other residual kernels)
     if (!want_jac && (ctx->opt_eval_kernel == 3 || (ctx->opt_eval_kernel == 0 && ctx->opt_kernel == 0 && !ctx->opt_general && ctx->opt_general_version == 0))) {
@@ -2041,6 +2075,131 @@ extern "C" int pcl_eval_jac_dev(pcl_ctx *ctx, const double *Z, double *delta, do
     if (!Z || !vals) return fail(ctx, PCL_EINVAL, "pcl_eval_jac_dev: NULL pointer");
     return launch_fused(ctx, Z, delta, vals, false);
 }
+
+// ---- resident evaluator ------------------------------------------------------------------------------------------------------------
+static bool res_running(pcl_ctx *ctx) {
+    if (!ctx->res.launched) return false;
+    const hipError_t e = hipStreamQuery(ctx->res.stream);
+    (void)hipGetLastError();
+    return e == hipErrorNotReady;
+}
+// (re)start the kernel at the first evaluation that is not complete; requests already posted stay posted
+static int res_launch(pcl_ctx *ctx) {
+    pcl_ctx::Resident &R = ctx->res;
+    HIP_TRY(ctx, hipStreamSynchronize(R.stream));  // (the previous resident kernel has left: its last words are written)
+    const unsigned done = __atomic_load_n(R.hbox + 16, __ATOMIC_ACQUIRE);
+    __atomic_store_n(R.hbox + 1, 0u, __ATOMIC_RELEASE);
+    __atomic_store_n(R.hbox + 17, 0u, __ATOMIC_RELEASE);
+    memset(R.hinit, 0, 64 * sizeof(unsigned));
+    R.hinit[0] = done, R.hinit[2] = done;
+    R.hinit[40] = (unsigned)((unsigned long long)R.hbox_dev & 0xffffffffu), R.hinit[41] = (unsigned)((unsigned long long)R.hbox_dev >> 32);
+    R.hinit[42] = done;
+    R.hinit[43] = (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_resident_idle_us, 10), 2000000) * 100u;  // 100 MHz ticks
+    R.hinit[44] = done + (1u << 30);
+    HIP_TRY(ctx, hipMemcpyAsync(R.dbox, R.hinit, 64 * sizeof(unsigned), hipMemcpyHostToDevice, R.stream));
+    *R.hparams = R.p;
+    HIP_TRY(ctx, hipMemcpyAsync(R.dparams, R.hparams, sizeof(KParams), hipMemcpyHostToDevice, R.stream));
+    void *args[] = {(void *)&R.dparams, (void *)&R.tab, (void *)&ctx->dv4_mags, (void *)&R.dcf, (void *)&R.dbox};
+    HIP_TRY(ctx, hipModuleLaunchKernel(R.f, (unsigned)R.grid, 1, 1, R.block, 1, 1, (unsigned)(R.lds + 32), R.stream, args, nullptr));
+    R.launched = true;
+    ++R.launches;
+    return PCL_OK;
+}
+extern "C" int pcl_resident_start(pcl_ctx *ctx, const double *Z, double *delta, double *vals) {
+    if (!ctx) return PCL_EINVAL;
+    if (!Z || !vals) return fail(ctx, PCL_EINVAL, "pcl_resident_start: NULL pointer");
+    if (ctx->res.active) return fail(ctx, PCL_EINVAL, "pcl_resident_start: already started (pcl_resident_stop first)");
+    ON_DEVICE(ctx);
+    pcl_ctx::Resident &R = ctx->res;
+    ctx->res_capture = true;
+    const int rc = launch_fused(ctx, Z, delta, vals, false);
+    ctx->res_capture = false;
+    if (rc != PCL_OK) return rc;
+    if (R.lds + 32 > (size_t)ctx->max_lds) return fail(ctx, PCL_ESHAPE, "pcl_resident_start: no LDS word left for the request flag");
+    if (R.grid > std::max(ctx->n_cu, 1)) return fail(ctx, PCL_ESHAPE, "pcl_resident_start: more workgroups than CUs");
+    if (!R.f) {
+        const int np = v4_power_tiles(R.p.d, R.p.m, R.p.q, (size_t)ctx->max_lds);
+        const std::string src = v4_source(*ctx->v4_plan, R.p.q, np, (int)ctx->opt_v4_variant, 2);
+        const std::string key = "fused-sparse-resident:" + std::to_string(R.p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
+        R.f = jit_compile(ctx->device, key, src, "pcl_fused_sparse_resident", true);
+        if (!R.f) return fail(ctx, PCL_EHIP, "pcl_resident_start: the resident module did not compile (%s)", g_jit_note.c_str());
+    }
+    if (!R.stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+    if (!R.hbox) {
+        HIP_TRY(ctx, hipHostMalloc((void **)&R.hbox, 64 * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void **)&R.hbox_dev, R.hbox, 0));
+        HIP_TRY(ctx, hipHostMalloc((void **)&R.hinit, 64 * sizeof(unsigned), hipHostMallocDefault));
+        HIP_TRY(ctx, hipHostMalloc((void **)&R.hparams, sizeof(KParams), hipHostMallocDefault));
+        HIP_TRY(ctx, hipMalloc((void **)&R.dparams, sizeof(KParams)));
+        HIP_TRY(ctx, hipMalloc((void **)&R.dbox, 64 * sizeof(unsigned) + 16 * 256 * 4 * sizeof(long long)));  // (+ the debugging stamps of v4_flags & 2048)
+        HIP_TRY(ctx, hipMemset(R.dbox, 0, 64 * sizeof(unsigned) + 16 * 256 * 4 * sizeof(long long)));
+    }
+    for (int i = 0; i < 64; ++i) __atomic_store_n(R.hbox + i, 0u, __ATOMIC_RELAXED);
+    R.posted = 0;
+    R.launched = false;
+    R.active = true;
+    // what the trajectory and the outputs' earlier writers have queued on the context's stream comes first
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return res_launch(ctx);
+}
+extern "C" int pcl_resident_post(pcl_ctx *ctx, int32_t count) {
+    if (!ctx) return PCL_EINVAL;
+    if (!ctx->res.active) return fail(ctx, PCL_EINVAL, "pcl_resident_post: not started");
+    if (count < 1 || count > (1 << 20)) return fail(ctx, PCL_EINVAL, "pcl_resident_post: count %d", (int)count);
+    ON_DEVICE(ctx);
+    pcl_ctx::Resident &R = ctx->res;
+    R.posted += (unsigned)count;
+    __atomic_store_n(R.hbox + 0, R.posted, __ATOMIC_RELEASE);
+    // (it has left -- idle for longer than resident_idle_us -- or is leaving: workgroup 0 says so in a host word; no runtime call on the way of a request)
+    if (__atomic_load_n(R.hbox + 17, __ATOMIC_ACQUIRE)) return res_launch(ctx);
+    return PCL_OK;
+}
+extern "C" int pcl_resident_wait(pcl_ctx *ctx, double timeout_s) {
+    if (!ctx) return PCL_EINVAL;
+    if (!ctx->res.active) return fail(ctx, PCL_EINVAL, "pcl_resident_wait: not started");
+    ON_DEVICE(ctx);
+    pcl_ctx::Resident &R = ctx->res;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long long spin = 0;; ++spin) {
+        if (__atomic_load_n(R.hbox + 16, __ATOMIC_ACQUIRE) == R.posted) break;
+        if ((spin & 1023) == 1023) {
+            if (!res_running(ctx)) {  // left with requests outstanding (it decided to leave as they arrived): again from the first incomplete one
+                if (__atomic_load_n(R.hbox + 16, __ATOMIC_ACQUIRE) == R.posted) break;
+                if (int rc = res_launch(ctx)) return rc;
+            }
+            if (timeout_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+                __atomic_store_n(R.hbox + 1, 1u, __ATOMIC_RELEASE);
+                return fail(ctx, PCL_EINTERNAL, "pcl_resident_wait: %u of %u requests complete after %.3f s (the kernel has been told to leave)", __atomic_load_n(R.hbox + 16, __ATOMIC_ACQUIRE), R.posted, timeout_s);
+            }
+        }
+    }
+    return check_device_error(ctx, "pcl_resident_wait");
+}
+extern "C" int pcl_resident_stop(pcl_ctx *ctx) {
+    if (!ctx) return PCL_EINVAL;
+    pcl_ctx::Resident &R = ctx->res;
+    if (!R.active) return PCL_OK;
+    ON_DEVICE(ctx);
+    __atomic_store_n(R.hbox + 1, 1u, __ATOMIC_RELEASE);
+    R.active = false;
+    HIP_TRY(ctx, hipStreamSynchronize(R.stream));
+    R.launched = false;
+    return check_device_error(ctx, "pcl_resident_stop");
+}
+// debugging (option v4_flags & 2048 at pcl_resident_start): 100 MHz stamps [evaluation 0 .. 15 since the last start][workgroup][request seen, last block
+// store issued, workgroup drained, arrival counted]; call after pcl_resident_stop
+extern "C" int pcl_resident_stamps(pcl_ctx *ctx, int64_t *out, int64_t count) {
+    if (!ctx || !out || !ctx->res.dbox) return PCL_EINVAL;
+    ON_DEVICE(ctx);
+    HIP_TRY(ctx, hipMemcpy(out, ctx->res.dbox + 64, (size_t)std::min<int64_t>(count, 16 * 256 * 4) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return PCL_OK;
+}
+extern "C" int pcl_resident_completed(const pcl_ctx *ctx, int64_t *count) {
+    if (!ctx || !count) return PCL_EINVAL;
+    *count = ctx->res.hbox ? (int64_t)__atomic_load_n(ctx->res.hbox + 16, __ATOMIC_ACQUIRE) : -1;
+    return PCL_OK;
+}
+
 extern "C" int pcl_jac_dev(pcl_ctx *ctx, const double *Z, double *vals) {  // eval_jacobian alone: no residual is written
     if (!ctx) return PCL_EINVAL;
     if (!Z || !vals) return fail(ctx, PCL_EINVAL, "pcl_jac_dev: NULL pointer");
