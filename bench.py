@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--separate-objective", action="store_true", help="ensemble step: pcl_objective_dev + pcl_eval_jac_merit_dev (4 launches) instead of pcl_eval_jac_merit_objective_dev (2)")
     ap.add_argument("--separate-payload", action="store_true", help="ensemble step: pcl_eval_jac_dev + pcl_merit_grad_dev instead of the fused pcl_eval_jac_merit_dev")
     ap.add_argument("--no-extras", action="store_true", help="skip the Hessian / compact / residual-only / host-delivered / config-2 rates")
+    ap.add_argument("--no-resident", action="store_true", help="skip other_rates.resident_evaluator (profiling passes: a kernel that stays on the device is no dispatch to average)")
     args = ap.parse_args()
 
     import torch
@@ -555,6 +556,8 @@ def main():
         # request.  Host wall clock (there is no launch to bracket with events): requests posted ahead against launches queued ahead, and the round
         # trip of ONE request (post + wait) against launch + stream synchronise -- same process, same arrays, alternating.
         try:
+            if args.no_resident:
+                raise RuntimeError("skipped (--no-resident)")
             msr = pa.HipPadeMultistart(G0, Gj, t0, 1, device=local, pade_order=4)
             cr = msr.ctx
             cr.set_stream(stream.cuda_stream)

@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 run() { name=$1; args=$2; shift 2; rocprofv3 "$@" --output-format csv -d $OUT/$name -o $name -- python $ROOT/bench.py $args > $OUT/$name.log 2> $OUT/$name.err; echo "$name rc=$?"; }
-ALL="--steps 50 --warmup 5 --no-cpu-baseline"                                   # headline + shares + the other rates: every kernel of the path
+ALL="--steps 50 --warmup 5 --no-cpu-baseline --no-resident"                                   # headline + shares + the other rates: every kernel of the path
 SINGLE="--workload single --steps 50 --warmup 5 --no-cpu-baseline --no-extras"   # the headline launch only
 MULTI="--workload multistart --steps 30 --warmup 5 --no-cpu-baseline --no-extras"
 run trace "$ALL" --kernel-trace --stats
