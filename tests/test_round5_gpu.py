@@ -452,6 +452,34 @@ def test_resident_evaluator_is_bitwise_the_launched_kernel(order):
     ms.close()  # (pcl_destroy stops a resident kernel)
 
 
+def test_resident_evaluator_with_several_trajectories_per_request():
+    """The resident kernel is whatever pcl_eval_jac_dev would launch with the static work split -- also for a context of several trajectories
+    (contiguous column ranges, several intervals per workgroup): 5 trajectories of 40 knots per request, bitwise the launched values."""
+    import torch
+
+    system = synthetic.config_system(3)
+    trajs = [synthetic.synthetic_trajectory(system, 40, seed=70 + i) for i in range(5)]
+    ms = pa.HipPadeMultistart(system.G_drift, system.G_drives_array(), trajs[0], 5, pade_order=4)
+    c = ms.ctx
+    c.set_option("v4_ticket", 0)  # (the launched reference: the static split too -- the slice tickets give the same bits, asserted elsewhere)
+    Z = torch.from_numpy(np.stack([t.datavec for t in trajs])).cuda()
+    dd = torch.empty(c.n_rows, dtype=torch.float64, device="cuda")
+    vd = torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")
+    c.eval_jac_dev(Z, dd, vd)
+    c.sync()
+    ref = (dd.clone(), vd.clone())
+    dr = torch.full_like(dd, float("nan"))
+    vr = torch.full_like(vd, float("nan"))
+    torch.cuda.synchronize()
+    c.resident_start(Z, dr, vr)
+    c.resident_post(3)
+    c.resident_wait(10.0)
+    assert c.resident_completed() == 3
+    c.resident_stop()
+    assert torch.equal(dr, ref[0]) and torch.equal(vr, ref[1])
+    ms.close()
+
+
 def test_resident_evaluator_refuses_what_kernel_4_does_not_take():
     """Systems outside kernel 4 (here: d = 2, the small-system kernel's) get PCL_ESHAPE from pcl_resident_start, and nothing is launched."""
     import torch
