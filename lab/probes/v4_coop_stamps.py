@@ -23,6 +23,8 @@ try:
         vd = torch.empty(c.jac_nnz, dtype=torch.float64, device="cuda")
         c.set_option("debug_timing", 1)
         c.set_option("profile_flags", 512)
+        for kv in sys.argv[2:]:
+            c.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         for _ in range(20):
             c.eval_jac_dev(Zd, dd, vd)
         stream.synchronize()
