@@ -426,11 +426,16 @@ def main():
             rs = {"evals_per_s": out["value"], "us_per_launch_kernel": kernel_s * 1e6, "frac_of_hbm_peak": out["roofline"]["frac"]}
         else:  # timed here, right behind the headline launch (same state of the device: behind the 64-unit workloads further down it reads 10 % slower)
             st_ = max(20, min(args.steps, 100))
-            w1, d1, _ = run_multistart(1, st_, 40, False, chosen)
-            rs = {"evals_per_s": st_ / w1, "us_per_launch_kernel": d1 / st_ * 1e6, "frac_of_hbm_peak": abytes / (d1 / st_) / 1e9 / HBM_PEAK_GBS}
+            # (600 untimed launches, 20 ms: at orders 8 and 10 a launch keeps getting shorter for several hundred launches -- 31.9, 31.1, 30.1, 29.6, 29.1, 28.7 us
+            #  over six rounds of 110 at order 10 (lab/probes/order_single.py), the clocks follow the load slowly; order 4, bound by HBM, is flat.  A solver runs thousands.)
+            w1, d1, _ = run_multistart(1, st_, 600, False, chosen)
+            w1b, d1b, _ = run_multistart(1, st_, 600, False, chosen)  # (the better of two timed regions: one region in a hundred reads 2 x -- a host stall; the headline's region is not treated this way)
+            if d1b < d1:
+                w1, d1 = w1b, d1b
+            rs = {"evals_per_s": st_ / w1, "us_per_launch_kernel": d1 / st_ * 1e6, "frac_of_hbm_peak": abytes / (d1 / st_) / 1e9 / HBM_PEAK_GBS, "untimed_launches": 600}
         dev_exp = ((out["config"].get("pade_vs_exp") or {}).get("config3") or {})
         out["value_reference_order"] = {"order": chosen, "order_tol": 1e-10, "evals_per_s": rs["evals_per_s"], "us_per_launch_kernel": rs["us_per_launch_kernel"],
-                                        "frac_of_hbm_peak": rs["frac_of_hbm_peak"], "max_deviation_from_exp_constraint": dev_exp.get("order_%d" % chosen),
+                                        "frac_of_hbm_peak": rs["frac_of_hbm_peak"], "untimed_launches": rs.get("untimed_launches", args.warmup), "max_deviation_from_exp_constraint": dev_exp.get("order_%d" % chosen),
                                         "order4_deviation": dev_exp.get("order_4"),
                                         "note": "the order HipPadeIntegrator / BilinearIntegrator choose by default (pade_order = 0) on config 3's bounds, one trajectory per launch"}
     if rank == 0 and world == 1 and args.workload == "auto" and not args.no_shares:
@@ -499,7 +504,10 @@ def main():
         st = max(20, min(args.steps, 100))
         # the orders that reach the reference's exp constraint at this config (pade_vs_exp): same launch shapes as the headline
         for order in (8, 10):
-            w1, d1, i1 = run_multistart(1, st, 40, False, order)  # (40 untimed launches: a fresh context starts with the clocks down -- 32.3 against 29.6 us at order 10 with 10)
+            w1, d1, i1 = run_multistart(1, st, 600, False, order)  # (600 untimed launches: a fresh context starts with the clocks down and they follow slowly -- see value_reference_order)
+            w1b, d1b, _ = run_multistart(1, st, 600, False, order)  # (the better of two timed regions, as for value_reference_order)
+            if d1b < d1:
+                w1, d1 = w1b, d1b
             w8, d8, i8 = run_multistart(B, st, 20, False, order)
             mso = pa.HipPadeMultistart(G0, Gj, t0, B, device=local, pade_order=order)
             co = mso.ctx

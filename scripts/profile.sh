@@ -29,11 +29,11 @@ run multistart_tcc2 "$MULTI" --pmc TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_sum TCC
 PCL_V4_TICKET=0 run multistart_static_tcc2 "$MULTI" --pmc TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum   # the static split beside the slice tickets
 PCL_V4_TICKET=0 run trace_multistart_static "$MULTI" --kernel-trace --stats
 # the order that matches the reference's exp constraint at config 3, with passes of its own
-run trace_single_order8 "$SINGLE --order 8" --kernel-trace --stats
+run trace_single_order8 "$SINGLE --order 8 --warmup 600" --kernel-trace --stats   # (600 untimed launches: at orders 8 and 10 the clocks follow the load for several hundred launches)
 run single_order8_write "$SINGLE --order 8" --pmc WRITE_SIZE
 run single_order8_sq "$SINGLE --order 8" --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS
 # ... and order 10, what the default constructor (pade_order = 0, tol 1e-10) picks on config 3's bounds since round 5
-run trace_single_order10 "$SINGLE --order 10" --kernel-trace --stats
+run trace_single_order10 "$SINGLE --order 10 --warmup 600" --kernel-trace --stats
 run single_order10_write "$SINGLE --order 10" --pmc WRITE_SIZE
 # the matrix-core kernel (kernel_version 3) beside the benchmarked one: MFMA instruction count and busy cycles per dispatch
 run trace_single_k3 "$SINGLE --kernel-version 3" --kernel-trace --stats
