@@ -618,6 +618,7 @@ def main():
                                         "order": 4, "clock": "host wall clock, best of 3 samples",
                                         "note": "one trajectory of config 3; the resident kernel is the benchmarked kernel's code compiled as a function inside a request loop (write-through "
                                                 "stores, a write-back / invalidate of the caches and three device-scope round trips per request); see DESIGN.md section 4.2.2"}
+            ex["resident_single"] = ex["resident_evaluator"]  # (the name the round-4 review asked for)
             msr.close()
             del Zr, dr, vr, ref_r
         except Exception as exc:  # (reported, not hidden: the headline does not depend on it)
