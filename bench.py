@@ -20,7 +20,7 @@ Workloads (`--workload`, default `auto`):
               (STRONG scaling: the total is fixed at 64; no data-path collective), and `ensemble_share` = config 4's 64 members
               with 64 / N per GPU, whose step contains the ONE RCCL all-reduce (`rccl_ranks`, `all_reduce_us` alone beside it).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W]      (N > 1 without a launcher: bench.py starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (contract in the task statement) with the extra objects
@@ -96,6 +96,33 @@ def time_steps(launch, steps, warmup, torch, dist):
     return wall, ev0.elapsed_time(ev1) * 1e-3
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: re-run this very command line under `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N` (one rank per GPU, rendezvous on 127.0.0.1 at a free port, dmabuf IPC), hand the ranks'
+    stdout through unchanged -- rank 0's ONE JSON line -- and return the launcher's exit status.  Refuses, with the reason, when
+    the node shows fewer than N devices."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n_gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible to this process (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)\n" % (n_gpus, have))
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")  # what the launcher would set (and warn about) itself; the CPU baseline runs in its own process with its own count
+    env["PCL_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]  # fmt: skip
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,9 +154,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" not in os.environ and (args.gpus > 1 or args.force_dist):
+        # started bare (`python bench.py --gpus N`): this process becomes the launcher of its own N ranks
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the evaluator has no CPU path)")
@@ -371,6 +399,7 @@ def main():
                                  "members_total": B * world, "payload_bytes": ie["payload_bytes"], "all_reduce": ie["all_reduce"],
                                  "rccl_ranks": ie.get("rccl_ranks"), "all_reduce_us": ie.get("all_reduce_us"), "payload_fused": ie["payload_fused"], "launches_per_step": ie["launches_per_step"],
                                  "note": "config 4: fused residual+Jacobian of this rank's members + objective + payload, then ONE RCCL sum all-reduce; max over ranks"}  # fmt: skip
+    out["launcher"] = "self" if os.environ.get("PCL_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if "RANK" in os.environ else "none")
     if dist is not None:  # ranks the one collective of the path ran over (the ensemble step's all-reduce), at the top level of the line
         out["rccl_ranks"] = (out.get("ensemble_share") or {}).get("rccl_ranks") or info.get("rccl_ranks") or int(dist.get_world_size())
     kernel_s = dev / args.steps  # HIP events on the launch stream around the K back-to-back steps

@@ -159,3 +159,17 @@ def test_every_unit_has_exactly_one_rank():
     a = synthetic.config4_members(0, 0, indices=[1, 9])
     b = synthetic.config4_members(1, 1) + synthetic.config4_members(9, 1)
     assert all(np.array_equal(x.G_drift, y.G_drift) for x, y in zip(a, b))
+
+
+def test_bench_without_launcher_refuses_when_the_devices_are_missing():
+    """`python bench.py --gpus 2` started bare takes the self-launch branch (bench.self_launch); on a box without two GPUs it must stop
+    with status 2 and the reason -- not spawn ranks that die one by one."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs: the refusal branch is not reachable")
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert pr.returncode == 2 and pr.stdout.strip() == b"" and b"GPU(s) visible" in pr.stderr
