@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--separate-objective", action="store_true", help="ensemble step: pcl_objective_dev + pcl_eval_jac_merit_dev (4 launches) instead of pcl_eval_jac_merit_objective_dev (2)")
     ap.add_argument("--separate-payload", action="store_true", help="ensemble step: pcl_eval_jac_dev + pcl_merit_grad_dev instead of the fused pcl_eval_jac_merit_dev")
     ap.add_argument("--no-extras", action="store_true", help="skip the Hessian / compact / residual-only / host-delivered / config-2 rates")
-    ap.add_argument("--no-resident", action="store_true", help="skip other_rates.resident_evaluator (profiling passes: a kernel that stays on the device is no dispatch to average)")
+    ap.add_argument("--no-resident", action="store_true", help="accepted and ignored (round 5's resident evaluator is a lab build now)")
     args = ap.parse_args()
 
     import torch
@@ -589,69 +589,7 @@ def main():
                                                           "residual_four_waves_per_interval": bool(c1.get_option("last_eval_coop"))}
             ms1.close()
             del Z1, d1_, mu1, h1
-        # RESIDENT evaluator (pcl_resident_*; round-4 review, item 4): kernel 4's workgroups stay on the device and run one evaluation per posted
-        # request.  Host wall clock (there is no launch to bracket with events): requests posted ahead against launches queued ahead, and the round
-        # trip of ONE request (post + wait) against launch + stream synchronise -- same process, same arrays, alternating.
-        try:
-            if args.no_resident:
-                raise RuntimeError("skipped (--no-resident)")
-            msr = pa.HipPadeMultistart(G0, Gj, t0, 1, device=local, pade_order=4)
-            cr = msr.ctx
-            cr.set_stream(stream.cuda_stream)
-            Zr = torch.from_numpy(seeds[0].datavec.copy()[None]).cuda()
-            dr = torch.empty(cr.n_rows, dtype=torch.float64, device="cuda")
-            vr = torch.empty(cr.jac_nnz, dtype=torch.float64, device="cuda")
-            cr.eval_jac_dev(Zr, dr, vr)
-            cr.sync()
-            ref_r = (dr.clone(), vr.clone())
-            nres = 200
-
-            def wall_us(fn):
-                t_ = time.perf_counter()
-                fn()
-                return (time.perf_counter() - t_) / nres * 1e6
-
-            def launches_ahead():
-                for _ in range(nres):
-                    cr.eval_jac_dev(Zr, dr, vr)
-                cr.sync()
-
-            def launches_rt():
-                for _ in range(nres):
-                    cr.eval_jac_dev(Zr, dr, vr)
-                    cr.sync()
-
-            def res_ahead():
-                cr.resident_post(nres)
-                cr.resident_wait(10.0)
-
-            def res_rt():
-                for _ in range(nres):
-                    cr.resident_post(1)
-                    cr.resident_wait(10.0)
-
-            la = min(wall_us(launches_ahead) for _ in range(3))
-            lr = min(wall_us(launches_rt) for _ in range(3))
-            dr.fill_(float("nan"))
-            vr.fill_(float("nan"))
-            stream.synchronize()
-            cr.resident_start(Zr, dr, vr)
-            cr.resident_eval(10.0)
-            same = bool(torch.equal(dr, ref_r[0]) and torch.equal(vr, ref_r[1]))
-            ra = min(wall_us(res_ahead) for _ in range(3))
-            rr = min(wall_us(res_rt) for _ in range(3))
-            starts = cr.get_option("resident_launches")
-            cr.resident_stop()
-            ex["resident_evaluator"] = {"us_per_eval_requests_posted_ahead": ra, "us_per_eval_launches_queued_ahead": la, "us_per_request_round_trip": rr,
-                                        "us_per_launch_plus_synchronise": lr, "bitwise_equal_to_launch": same, "kernel_starts": starts, "requests_per_sample": nres,
-                                        "order": 4, "clock": "host wall clock, best of 3 samples",
-                                        "note": "one trajectory of config 3; the resident kernel is the benchmarked kernel's code compiled as a function inside a request loop (write-through "
-                                                "stores, a write-back / invalidate of the caches and three device-scope round trips per request); see DESIGN.md section 4.2.2"}
-            ex["resident_single"] = ex["resident_evaluator"]  # (the name the round-4 review asked for)
-            msr.close()
-            del Zr, dr, vr, ref_r
-        except Exception as exc:  # (reported, not hidden: the headline does not depend on it)
-            ex["resident_evaluator"] = {"error": repr(exc)}
+        # (the resident evaluator of round 5 lost and left the shipped library: include/piccolo_hip_lab.h, lab/probes/resident_probe.py)
         ms = pa.HipPadeMultistart(G0, Gj, t0, B, device=local, pade_order=4)
         c = ms.ctx
         c.set_stream(stream.cuda_stream)

@@ -172,31 +172,6 @@ int pcl_eval_jac_dev(pcl_ctx *ctx, const double *Z_dev, double *delta_dev, doubl
 int pcl_jac_dev(pcl_ctx *ctx, const double *Z_dev, double *vals_dev); /* eval_jacobian alone (integrators.jl:780) */
 int pcl_hess_dev(pcl_ctx *ctx, const double *Z_dev, const double *mu_dev, double *vals_dev);
 
-/* RESIDENT evaluator -- pcl_eval_jac_dev without a launch per evaluation.  What it replaces on the reference's side is still
- * evaluate! + eval_jacobian of the dynamics constraint (src/control/integrators.jl:620-640, 780-790; the solver calls them back to back
- * once per iteration): a solver iteration is a request, not a kernel launch.
- *   pcl_resident_start   kernel 4's workgroups (one per CU) go resident on a stream of their own and wait for requests; Z_dev, delta_dev
- *                        (may be NULL) and vals_dev are fixed until pcl_resident_stop -- the caller rewrites Z_dev IN PLACE between requests
- *                        (after pcl_resident_wait; copies and kernels on other streams are seen: the caches are invalidated per request)
- *   pcl_resident_post    `count` more evaluations of the CURRENT Z_dev (asynchronous; count > 1 only makes sense for measurements)
- *   pcl_resident_wait    returns when every posted evaluation is complete and its delta / vals are visible to the host, to copies and to kernels
- *                        of any stream (spins on a host word the device writes; timeout_s <= 0: none)
- *   pcl_resident_stop    the workgroups leave; the context is as before
- * delta and vals are bitwise those of pcl_eval_jac_dev (same code, compiled as a function).  The kernel leaves by itself after
- * option resident_idle_us (default 5000) without a request -- a blocked host never hangs the device -- and the next post starts it
- * again (get_option resident_launches counts the starts).  While it is resident other kernels find the CUs' LDS taken: launches of
- * this context on its own stream (pcl_hess_dev ...) run when a CU can hold them beside it or when it leaves; calls that synchronise the
- * DEVICE (hipMalloc, hipFree, hipDeviceSynchronize) wait for it to leave.  Needs what kernel 4 needs (PCL_ESHAPE otherwise).
- * MEASURED (MI355X, config 3, one trajectory, order 4): 29.5-32.6 us per evaluation with requests posted ahead against 24.2 for launches queued
- * ahead, 37.8-39.5 us per request round trip against 36 for launch + pcl_sync -- the hand-over of a request costs what a launch costs; the
- * entry points exist so that this can be reproduced, nothing takes them by default. */
-int pcl_resident_start(pcl_ctx *ctx, const double *Z_dev, double *delta_dev, double *vals_dev);
-int pcl_resident_post(pcl_ctx *ctx, int32_t count);
-int pcl_resident_wait(pcl_ctx *ctx, double timeout_s);
-int pcl_resident_stop(pcl_ctx *ctx);
-int pcl_resident_stamps(pcl_ctx *ctx, int64_t *out, int64_t count); /* debugging: see piccolo_hip.hip */
-int pcl_resident_completed(const pcl_ctx *ctx, int64_t *count); /* evaluations complete since pcl_resident_start (-1: never started) */
-
 /* Member window: restrict the evaluator entry points (pcl_eval*, pcl_jac*, pcl_hess*, pcl_rollout*, their nnz / structure
  * queries and pcl_constraint_dim's row count) to members / seeds [first, first+count) of the context.  Inputs stay the full
  * buffers (Z of every member; TRAJ mode: of every seed); outputs, multipliers and structure rows are those of the window,
@@ -329,9 +304,6 @@ int pcl_comm_destroy(pcl_ctx *ctx);
  * PCL_VERBOSE (see OPTIONS.md). */
 int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t value);
 int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *value);
-/* Profiling aid (libraries built with -DPCL_PROFILE only): after pcl_set_option(ctx, "debug_timing", 1), up to 64
- * s_memtime stamps written by workgroup 0 at its phase boundaries during the last launch. */
-int pcl_debug_timing(pcl_ctx *ctx, int64_t *out, int64_t cap);
 
 /* Inspection hook (needs no device): the HIP source the library generates and compiles on first use for the
  * pattern-compiled kernels of a system with Hilbert dimension d <= 32 and m <= 6 drives whose generators are exact iso(.)
@@ -339,8 +311,7 @@ int pcl_debug_timing(pcl_ctx *ctx, int64_t *out, int64_t cap);
 int pcl_codegen_source(int d, int m, const double *G0, const double *Gj, char *buf, int64_t cap, int64_t *needed);
 /* The same for the pattern-compiled FUSED residual + Jacobian kernel (kernel_version 4) at diagonal Pade order 2q, q = 1..5
  * (n_g0 drifts G0[b] span the union pattern: an ensemble's members); PCL_ESHAPE when the drives need more resident
- * coefficients than the kernel keeps.  pcl_codegen_apply_v4 applies the generator's term tables on the host to one column:
- * y = (G0[0] + sum_l u_l G_l) x, x and y of length n = 2d -- what the generated product computes, checkable without a GPU. */
+ * coefficients than the kernel keeps. */
 int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what /* 0 fused residual + Jacobian (+ residual only), 1 Hessian of the Lagrangian */,
                           char *buf, int64_t cap, int64_t *needed);
 /* Compile the pattern-compiled module(s) a context of this system would compile on first use and leave the code object under its content
@@ -348,9 +319,8 @@ int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, const double
  * libhiprtc, no device.  what: 0 fused residual + Jacobian (+ residual only) at order 2q | 1 general-order Hessian, one workgroup per
  * interval | 2 ... two workgroups per interval | 3 the order-4 Hessian / value-table module (q ignored) | 4 the fused module with the
  * slice-ticket roles (launches of several trajectories) | 5 general-order Hessian, one wave per group of state columns (`auto` at every
- * order but 4) | 6 the fused module of the resident evaluator (pcl_resident_start). */
+ * order but 4).  (6, the resident evaluator's module, in lab builds only: piccolo_hip_lab.h.) */
 int pcl_jit_prebuild(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what, const char *out_dir);
-int pcl_codegen_apply_v4(int d, int m, const double *G0, int n_g0, const double *Gj, const double *u, const double *x, double *y, int transposed /* 1: y = G(u)^T x */);
 
 #ifdef __cplusplus
 }

@@ -5,6 +5,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import piccolo_jl_amd as pa
+from piccolo_jl_amd import _lib
+_lib.build_library(lab=True)  # include/piccolo_hip_lab.h: the resident evaluator is not in the shipped library
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import resident_methods
+resident_methods.attach()
 from piccolo_jl_amd import synthetic
 
 order = int(sys.argv[1]) if len(sys.argv) > 1 else 4

@@ -33,11 +33,16 @@ EXPORTS = [
     "pcl_clear_regularizers", "pcl_objective_dev", "pcl_objective", "pcl_merit_grad_len", "pcl_merit_grad_dev", "pcl_eval_jac_merit_dev", "pcl_eval_jac_merit_objective_dev",
     "pcl_rollout", "pcl_rollout_dev",
     "pcl_comm_get_unique_id", "pcl_comm_init", "pcl_reduce_sum_dev", "pcl_reduce_sum", "pcl_comm_destroy",
-    "pcl_set_option", "pcl_get_option", "pcl_debug_timing", "pcl_codegen_source",
-    "pcl_codegen_source_v4", "pcl_codegen_apply_v4", "pcl_jit_prebuild", "pcl_set_order_policy", "pcl_set_order_from_trajectory", "pcl_order_for_bounds",
-    "pcl_resident_start", "pcl_resident_post", "pcl_resident_wait", "pcl_resident_stop", "pcl_resident_completed", "pcl_resident_stamps",
+    "pcl_set_option", "pcl_get_option", "pcl_codegen_source",
+    "pcl_codegen_source_v4", "pcl_jit_prebuild", "pcl_set_order_policy", "pcl_set_order_from_trajectory", "pcl_order_for_bounds",
     "pcl_set_goal_form", "pcl_objective_hess_nnz", "pcl_objective_hess_structure", "pcl_objective_hess_dev", "pcl_objective_hess",
 ]  # fmt: skip
+
+
+# include/piccolo_hip_lab.h: lab builds only (-DPCL_LAB -> libpiccolo_hip_lab.so); the shipped library must NOT export these
+LAB_EXPORTS = ["pcl_resident_start", "pcl_resident_post", "pcl_resident_wait", "pcl_resident_stop", "pcl_resident_completed", "pcl_resident_stamps",
+               "pcl_debug_timing", "pcl_codegen_apply_v4"]  # fmt: skip
+SO_PATH_LAB = os.path.join(CSRC, "libpiccolo_hip_lab.so")
 
 
 class PclError(RuntimeError):
@@ -86,38 +91,47 @@ def _file_digest(path):
         return hashlib.sha256(f.read()).hexdigest()
 
 
-def build_library(force=False, verbose=False, profile=False):
+def build_library(force=False, verbose=False, profile=False, lab=False):
     """Compile csrc/piccolo_hip.hip for gfx950 into csrc/libpiccolo_hip.so (in-tree).
 
     The library is rebuilt whenever the digest of its sources and flags differs from the one recorded next to the
     shared object (``libpiccolo_hip.so.digest``: source digest + digest of the binary) -- modification times play no part, so a stale binary is never
-    reused after an edit, a checkout or a copy to another box.  ``profile=True`` adds ``-DPCL_PROFILE`` (cycle stamps
-    inside the kernels for lab/probes; never the shipped build)."""
+    reused after an edit, a checkout or a copy to another box.  ``lab=True`` adds ``-DPCL_LAB`` (the entry points of include/piccolo_hip_lab.h),
+    ``profile=True`` adds ``-DPCL_PROFILE -DPCL_LAB`` (cycle stamps inside the kernels for lab/probes); both write ``libpiccolo_hip_lab.so`` --
+    never the shipped file -- and make this process's ``load()`` take that library."""
+    global _variant_path
+    lab = lab or profile
+    out = SO_PATH_LAB if lab else SO_PATH
     src = os.path.join(CSRC, "piccolo_hip.hip")
-    deps = [src, os.path.join(INCLUDE, "piccolo_hip.h")] + sorted(
+    deps = [src, os.path.join(INCLUDE, "piccolo_hip.h"), os.path.join(INCLUDE, "piccolo_hip_lab.h")] + sorted(
         os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))  # the kernel families are headers of this one TU
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread"] + (["-DPCL_PROFILE"] if profile else [])
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread"] + (["-DPCL_LAB"] if lab else []) + (["-DPCL_PROFILE"] if profile else [])
     digest = _source_digest(deps, flags)
-    stamp = SO_PATH + ".digest"
-    if not force and os.path.exists(SO_PATH) and os.path.exists(stamp):
+    stamp = out + ".digest"
+    if lab:
+        if _lib is not None and _variant_path != out:
+            raise RuntimeError("the shipped library is already loaded in this process: build the lab variant before the first load()")
+        _variant_path = out
+    if not force and os.path.exists(out) and os.path.exists(stamp):
         with open(stamp) as f:
             rec = f.read().split()
         # the record names the sources AND the binary built from them: a stamp restored by a checkout next to a binary built
         # from other sources (it happened: an experiment survived its revert) does not pass
-        if len(rec) == 2 and rec[0] == digest and rec[1] == _file_digest(SO_PATH):
-            return SO_PATH
+        if len(rec) == 2 and rec[0] == digest and rec[1] == _file_digest(out):
+            return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
-        raise FileNotFoundError("%s not found and %s is stale or missing (sources changed since it was built)" % (hipcc, SO_PATH))
-    cmd = [hipcc] + flags + ["-I", INCLUDE, "-o", SO_PATH, src]
+        raise FileNotFoundError("%s not found and %s is stale or missing (sources changed since it was built)" % (hipcc, out))
+    cmd = [hipcc] + flags + ["-I", INCLUDE, "-o", out, src]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     with open(stamp, "w") as f:
-        f.write(digest + " " + _file_digest(SO_PATH) + "\n")
-    return SO_PATH
+        f.write(digest + " " + _file_digest(out) + "\n")
+    return out
 
 
+_variant_path = None  # set by build_library(lab=True / profile=True): what load() opens in this process
 _lib = None
 
 
@@ -126,12 +140,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(SO_PATH):
+    path = _variant_path or SO_PATH
+    if not os.path.exists(path):
         raise FileNotFoundError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path
         )
-    L = ctypes.CDLL(SO_PATH)
+    L = ctypes.CDLL(path)
     c_i64p = ctypes.POINTER(ctypes.c_int64)
     c_i32p = ctypes.POINTER(ctypes.c_int32)
     vp = ctypes.c_void_p
@@ -167,12 +182,6 @@ def load():
     L.pcl_deriv_eval_jac_dev.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp]
     L.pcl_set_goal.argtypes = [vp, vp]
     L.pcl_jac_dev.argtypes = [vp, vp, vp]
-    L.pcl_resident_start.argtypes = [vp, vp, vp, vp]
-    L.pcl_resident_post.argtypes = [vp, ctypes.c_int32]
-    L.pcl_resident_wait.argtypes = [vp, ctypes.c_double]
-    L.pcl_resident_stop.argtypes = [vp]
-    L.pcl_resident_completed.argtypes = [vp, c_i64p]
-    L.pcl_resident_stamps.argtypes = [vp, vp, ctypes.c_int64]
     L.pcl_set_member_window.argtypes = [vp, ctypes.c_int32, ctypes.c_int32]
     L.pcl_set_goal_subspace.argtypes = [vp, vp, c_i32p, ctypes.c_int32]
     L.pcl_set_weights.argtypes = [vp, vp]
@@ -194,15 +203,22 @@ def load():
     L.pcl_comm_destroy.argtypes = [vp]
     L.pcl_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
     L.pcl_get_option.argtypes = [vp, ctypes.c_char_p, c_i64p]
-    L.pcl_debug_timing.argtypes = [vp, c_i64p, ctypes.c_int64]
     L.pcl_codegen_source.argtypes = [ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_char_p, ctypes.c_int64, c_i64p]
     L.pcl_codegen_source_v4.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, c_i64p]
-    L.pcl_codegen_apply_v4.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int]
+    if path == SO_PATH_LAB:  # include/piccolo_hip_lab.h
+        L.pcl_resident_start.argtypes = [vp, vp, vp, vp]
+        L.pcl_resident_post.argtypes = [vp, ctypes.c_int32]
+        L.pcl_resident_wait.argtypes = [vp, ctypes.c_double]
+        L.pcl_resident_stop.argtypes = [vp]
+        L.pcl_resident_completed.argtypes = [vp, c_i64p]
+        L.pcl_resident_stamps.argtypes = [vp, vp, ctypes.c_int64]
+        L.pcl_debug_timing.argtypes = [vp, c_i64p, ctypes.c_int64]
+        L.pcl_codegen_apply_v4.argtypes = [ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int]
     _lib = L
     return L
 
 
-def prebuild_kernels(G_drifts, G_drives, orders=(4,), hessian=True, out_dir=None, resident=False):
+def prebuild_kernels(G_drifts, G_drives, orders=(4,), hessian=True, out_dir=None, resident=False):  # (resident: lab builds only)
     """Compile the pattern-compiled modules a context of this system (one drift, or the per-member drifts of an ensemble) would compile
     with hiprtc on first use, into ``csrc/prebuilt/`` (or ``out_dir``) under their content hashes -- a fresh process (every rank of a job)
     then loads them instead of compiling.  No device needed.  Returns the number of modules asked for."""

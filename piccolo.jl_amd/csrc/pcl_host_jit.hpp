@@ -410,6 +410,9 @@ static int prebuild_source(const std::string &source, const char *name_expr, con
 //        roles | 5  general-order Hessian, one wave per group of state columns | 6  the fused module of the resident evaluator
 extern "C" int pcl_jit_prebuild(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what, const char *out_dir) {
     if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || what < 0 || what > 6 || !G0 || (m > 0 && !Gj)) return fail(nullptr, PCL_EINVAL, "pcl_jit_prebuild: bad argument");
+#ifndef PCL_LAB
+    if (what == 6) return fail(nullptr, PCL_ENOTIMPL, "pcl_jit_prebuild: the resident evaluator's module belongs to lab builds (-DPCL_LAB)");
+#endif
     std::string src, err;
     const char *kernel = "pcl_fused_sparse_kernel";
     if (what == 3) {
@@ -447,6 +450,7 @@ extern "C" int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, c
     }
     return PCL_OK;
 }
+#ifdef PCL_LAB  // include/piccolo_hip_lab.h (tests/test_abi_cpu.py checks the term tables through a host-only shim of the same two functions)
 extern "C" int pcl_codegen_apply_v4(int d, int m, const double *G0, int n_g0, const double *Gj, const double *u, const double *x, double *y, int transposed) {
     if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || !G0 || (m > 0 && (!Gj || !u)) || !x || !y) return PCL_EINVAL;
     const pcl_codegen::V4Plan plan = pcl_codegen::make_v4_plan(d, m, G0, n_g0, Gj);
@@ -457,6 +461,7 @@ extern "C" int pcl_codegen_apply_v4(int d, int m, const double *G0, int n_g0, co
         pcl_codegen::v4_reference_apply(plan, G0, Gj, u, x, y);
     return PCL_OK;
 }
+#endif
 
 // Inspection hook: the generated source of the pattern-compiled kernels for a system (needs no device).
 extern "C" int pcl_codegen_source(int d, int m, const double *G0, const double *Gj, char *buf, int64_t cap, int64_t *needed) {

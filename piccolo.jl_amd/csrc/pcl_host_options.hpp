@@ -76,8 +76,10 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_v4_tune = v != 0;
     else if (!strcmp(key, "host_store_bytes"))  // host expansion: bytes per streaming store (0 the widest the host has | 16 | 32 | 64)
         ctx->opt_host_store_bytes = (v == 16 || v == 32 || v == 64) ? v : 0;
+#ifdef PCL_LAB
     else if (!strcmp(key, "resident_idle_us"))  // resident evaluator: the kernel leaves after this long without a request (10 .. 2 000 000)
         ctx->opt_resident_idle_us = v < 10 ? 10 : (v > 2000000 ? 2000000 : v);
+#endif
     else if (!strcmp(key, "hess_xcd"))  // column-group Hessian kernel: the waves of an interval take blockIdx values equal mod n = one XCD (-1 auto: 8 | 0, 1: blockIdx order)
         ctx->opt_hess_xcd = v < 0 ? -1 : v;
     else if (!strcmp(key, "hess_split"))  // general-order pattern-compiled Hessian kernel: two workgroups per interval (-1 auto by launch size | 0 | 1)
@@ -112,6 +114,7 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         return fail(ctx, PCL_EINVAL, "unknown option '%s'", key);
     return PCL_OK;
 }
+#ifdef PCL_LAB  // include/piccolo_hip_lab.h; the stamps themselves need -DPCL_PROFILE as well
 extern "C" int pcl_debug_timing(pcl_ctx *ctx, int64_t *out, int64_t cap) {
     if (!ctx || !out || cap < 0) return PCL_EINVAL;
     if (!ctx->ddbg) return fail(ctx, PCL_EINVAL, "pcl_debug_timing: set option debug_timing first");
@@ -119,6 +122,7 @@ extern "C" int pcl_debug_timing(pcl_ctx *ctx, int64_t *out, int64_t cap) {
     HIP_TRY(ctx, hipMemcpy(out, ctx->ddbg, (size_t)std::min<int64_t>(cap, PCL_DBG_WORDS) * sizeof(long long), hipMemcpyDeviceToHost));
     return PCL_OK;
 }
+#endif
 
 extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
     if (!ctx || !key || !v) return PCL_EINVAL;
@@ -148,10 +152,12 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->last_kernel;
     else if (!strcmp(key, "hess_xcd"))
         *v = ctx->opt_hess_xcd;
+#ifdef PCL_LAB
     else if (!strcmp(key, "resident_idle_us"))
         *v = ctx->opt_resident_idle_us;
     else if (!strcmp(key, "resident_launches"))  // starts of the resident kernel since pcl_create (1 + the times it had left when a request came)
         *v = ctx->res.launches;
+#endif
     else if (!strcmp(key, "v4_tune"))
         *v = ctx->opt_v4_tune;
     else if (!strcmp(key, "last_v4_tune_choice"))  // of the array the last multi-trajectory launch wrote: -1 still sampling | 0 static split | 1 slice tickets

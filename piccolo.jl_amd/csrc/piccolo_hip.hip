@@ -26,6 +26,9 @@
 #include <unistd.h>
 
 #include "piccolo_hip.h"
+#ifdef PCL_LAB
+#include "piccolo_hip_lab.h"
+#endif
 #include "pcl_codegen.hpp"
 #include "pcl_codegen_v4.hpp"
 
@@ -142,6 +145,7 @@ struct pcl_ctx {
     int64_t last_v4_ticket = 0;     // state columns per block ticket of the last kernel-4 launch (0: static work split)
     unsigned int *dv4_tick = nullptr;  // ... [block ticket, pipelines gone, chain ticket]: zero between launches (the last pipeline out resets them)
     int *herr = nullptr, *derr = nullptr;  // device error word (host-mapped): a barrier-free kernel whose bounded wait gave up sets bit 0
+#ifdef PCL_LAB
     // RESIDENT evaluator (pcl_resident_*; pcl_kernel_fused_sparse.hpp, SP4_RESIDENT): kernel 4's workgroups stay on the device and run one
     // evaluation per posted request
     struct Resident {
@@ -160,6 +164,9 @@ struct pcl_ctx {
     } res;
     bool res_capture = false;            // launch_fused_v4 fills `res` instead of launching
     int64_t opt_resident_idle_us = 5000; // the resident kernel leaves after this long without a request (the next request starts it again)
+#else
+    static constexpr bool res_capture = false;  // (the shipped library has no resident evaluator: include/piccolo_hip_lab.h)
+#endif
     int64_t opt_v4_tail_mode = 3;   // kernel 4: who stores delta and the tails: 0 the writer wave | 1 ... nontemporal | 2 ... write-through | 3 the stream waves (default)
     int64_t opt_eval_kernel = 0;    // 0 auto | 1 matrix-core residual kernel | 2 pattern-compiled
     // staging for the host-pointer entry points
@@ -590,6 +597,9 @@ extern "C" int pcl_comm_destroy(pcl_ctx *ctx);
 extern "C" void pcl_destroy(pcl_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard dev_guard_(ctx->device);
+#ifdef PCL_LAB
+    if (ctx->res.active) (void)pcl_resident_stop(ctx);  // before any buffer it reads on each request is freed
+#endif
     (void)pcl_comm_destroy(ctx);
     void *ptrs[] = {ctx->dhcx, ctx->dhcc, ctx->dh4x, ctx->dh4c, ctx->dGjd, ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
@@ -619,13 +629,14 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     delete ctx->sp_plan;
     for (void *q : {(void *)ctx->dv4_tab, (void *)ctx->dv4_tab_t, (void *)ctx->dv4_mags, (void *)ctx->dv4_dcf, (void *)ctx->dv4_tick})
         if (q) (void)hipFree(q);
-    if (ctx->res.active) (void)pcl_resident_stop(ctx);
+#ifdef PCL_LAB
     if (ctx->res.stream) (void)hipStreamDestroy(ctx->res.stream);
     if (ctx->res.hbox) (void)hipHostFree(ctx->res.hbox);
     if (ctx->res.hinit) (void)hipHostFree(ctx->res.hinit);
     if (ctx->res.hparams) (void)hipHostFree(ctx->res.hparams);
     if (ctx->res.dparams) (void)hipFree(ctx->res.dparams);
     if (ctx->res.dbox) (void)hipFree(ctx->res.dbox);
+#endif
     if (ctx->herr) (void)hipHostFree(ctx->herr);
     delete ctx->v4_plan;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -1116,7 +1127,15 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
     // auto: which of the two this values array gets (see v4_tune); timed launches are bracketed by events below
     pcl_ctx::V4Tune *tune = nullptr;
     int tune_slot = -1, tune_variant = 1;
-    if (ticket_auto && ctx->opt_v4_tune != 0) {
+    // (a stream that is being captured into a graph takes no part in the sampling: event records would become graph nodes and a query is illegal
+    //  there; the launch gets the array's decided variant, else the tickets, and nothing of the sampling state moves)
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    const bool capturing = ticket_auto && ctx->opt_v4_tune != 0 && (hipStreamIsCapturing(ctx->stream, &cap_status) != hipSuccess || cap_status != hipStreamCaptureStatusNone);
+    if (capturing) {
+        (void)hipGetLastError();
+        for (auto &t : ctx->v4_tune)
+            if (t.key == (const void *)p.jac && t.units == bk && t.choice >= 0) tune_variant = t.choice;
+    } else if (ticket_auto && ctx->opt_v4_tune != 0) {
         pcl_ctx::V4Tune *T = nullptr;
         for (auto &t : ctx->v4_tune)
             if (t.key == (const void *)p.jac && t.units == bk) T = &t;
@@ -1228,11 +1247,13 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
         else
             return launch_fused_v4_static(ctx, p, compact, want_merit);
     }
+#ifdef PCL_LAB
     if (ctx->res_capture) {  // pcl_resident_start: the launch as data
         ctx->res.p = p, ctx->res.tab = tab, ctx->res.dcf = dcf, ctx->res.grid = g, ctx->res.lds = lds, ctx->res.block = 64u * (unsigned)(m + 9);
         ctx->res_capture = false;
         return PCL_OK;
     }
+#endif
     bool timed = false;
     if (tune && tune_slot >= 0) {  // one timed sample of the per-array choice
         bool ok = true;
@@ -1306,7 +1327,9 @@ static int launch_fused(pcl_ctx *ctx, const double *Z, double *delta, double *ja
         if (rc != PCL_ENOTIMPL) return rc;
         if (ctx->opt_kernel == 4) return fail(ctx, PCL_ESHAPE, "kernel_version=4 needs sparse exact-iso generators of a unitary problem (9 <= d, tiles within LDS), 1..6 drives and jit=1 (%s)", g_jit_note.c_str());
     }
+#ifdef PCL_LAB
     if (ctx->res_capture) return fail(ctx, PCL_ESHAPE, "pcl_resident_start: the resident evaluator is kernel 4's (sparse exact-iso generators of a unitary problem, 9 <= d, tiles within LDS, 1..6 drives, jit = 1; kernel_version 0 or 4)");
+#endif
     if (p.nt == 3) p.nt = 2;  // (the mixed mode is kernel 4's)
     // residual only on the same products (eval_kernel 3; auto: every order -- measured against the other residual kernels)
     if (!want_jac && (ctx->opt_eval_kernel == 3 || (ctx->opt_eval_kernel == 0 && ctx->opt_kernel == 0 && !ctx->opt_general && ctx->opt_general_version == 0))) {
@@ -1934,6 +1957,9 @@ static void set_order(pcl_ctx *ctx, int order, double theta) {
     if (ctx->desc.pade_order != order) {  // (modules are per order: the handles of the previous one are dropped, the modules stay cached)
         ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = ctx->v4_fhessc = nullptr;
         ctx->v4_failed = ctx->v4_hess_failed = ctx->v4_hessc_failed = ctx->v4_ft_failed = 0;
+#ifdef PCL_LAB
+        ctx->res.f = nullptr;  // (the resident module bakes the order in as well)
+#endif
     }
     ctx->desc.pade_order = order;
     ctx->order_theta = theta;
@@ -1986,6 +2012,9 @@ extern "C" int pcl_order_for_bounds(int32_t n, int32_t m, const double *G0, int3
 extern "C" int pcl_set_order_policy(pcl_ctx *ctx, double dt_max, const double *u_max, double tol, int32_t *order_out) {
     if (!ctx) return PCL_EINVAL;
     if (!(dt_max > 0.0) || !(tol > 0.0) || (ctx->desc.n_drives > 0 && !u_max)) return fail(ctx, PCL_EINVAL, "pcl_set_order_policy: need dt_max > 0, tol > 0 and the drives' bounds");
+#ifdef PCL_LAB
+    if (ctx->res.active) return fail(ctx, PCL_EINVAL, "pcl_set_order_policy: a resident evaluator is running (pcl_resident_stop first)");
+#endif
     const int n = ctx->n, m = ctx->desc.n_drives;
     const double theta = policy_theta(n, m, ctx->hG0.data(), ctx->hG0.size() / ((size_t)n * n), ctx->hGj.data(), dt_max, u_max);
     ctx->order_tol = tol;
@@ -2006,7 +2035,9 @@ static int resolve_order(pcl_ctx *ctx, const double *Z_host, const char *where) 
     std::vector<double> G((size_t)n * n);
     double theta = 0.0;
     for (size_t g0 = 0; g0 * n * n < ctx->hG0.size(); ++g0)
-        for (int b = 0; b < nbuf; ++b)
+        for (int b = 0; b < nbuf; ++b) {
+            // (a multistart constructed from ONE trajectory tiled `batch` times: one pass of norms, not `batch`)
+            if (b > 0 && !memcmp(Z_host + (size_t)b * D.N * D.z_dim, Z_host, (size_t)D.N * D.z_dim * sizeof(double))) continue;
             for (int k = 0; k + 1 < D.N; ++k) {
                 const double *z = Z_host + ((size_t)b * D.N + k) * D.z_dim;
                 for (size_t e = 0; e < (size_t)n * n; ++e) {
@@ -2016,6 +2047,7 @@ static int resolve_order(pcl_ctx *ctx, const double *Z_host, const char *where) 
                 }
                 theta = std::max(theta, std::fabs(z[D.dt_off]) * spectral_norm(G.data(), n));
             }
+        }
     bool met = true;
     set_order(ctx, order_for(1.5 * theta, ctx->order_tol, &met), 1.5 * theta);
     note_order(ctx, 1.5 * theta, met);
@@ -2025,6 +2057,9 @@ static int resolve_order(pcl_ctx *ctx, const double *Z_host, const char *where) 
 extern "C" int pcl_set_order_from_trajectory(pcl_ctx *ctx, const double *Z_host, double tol, int32_t *order_out) {
     if (!ctx) return PCL_EINVAL;
     if (!Z_host) return fail(ctx, PCL_EINVAL, "pcl_set_order_from_trajectory: NULL trajectory");
+#ifdef PCL_LAB
+    if (ctx->res.active) return fail(ctx, PCL_EINVAL, "pcl_set_order_from_trajectory: a resident evaluator is running (pcl_resident_stop first)");
+#endif
     if (tol > 0.0) ctx->order_tol = tol;
     const int keep = ctx->desc.pade_order;
     ctx->desc.pade_order = 0;  // (resolve_order decides for contexts without an order; set_order drops the previous order's module handles)
@@ -2076,129 +2111,9 @@ extern "C" int pcl_eval_jac_dev(pcl_ctx *ctx, const double *Z, double *delta, do
     return launch_fused(ctx, Z, delta, vals, false);
 }
 
-// ---- resident evaluator ------------------------------------------------------------------------------------------------------------
-static bool res_running(pcl_ctx *ctx) {
-    if (!ctx->res.launched) return false;
-    const hipError_t e = hipStreamQuery(ctx->res.stream);
-    (void)hipGetLastError();
-    return e == hipErrorNotReady;
-}
-// (re)start the kernel at the first evaluation that is not complete; requests already posted stay posted
-static int res_launch(pcl_ctx *ctx) {
-    pcl_ctx::Resident &R = ctx->res;
-    HIP_TRY(ctx, hipStreamSynchronize(R.stream));  // (the previous resident kernel has left: its last words are written)
-    const unsigned done = __atomic_load_n(R.hbox + 16, __ATOMIC_ACQUIRE);
-    __atomic_store_n(R.hbox + 1, 0u, __ATOMIC_RELEASE);
-    __atomic_store_n(R.hbox + 17, 0u, __ATOMIC_RELEASE);
-    memset(R.hinit, 0, 64 * sizeof(unsigned));
-    R.hinit[0] = done, R.hinit[2] = done;
-    R.hinit[40] = (unsigned)((unsigned long long)R.hbox_dev & 0xffffffffu), R.hinit[41] = (unsigned)((unsigned long long)R.hbox_dev >> 32);
-    R.hinit[42] = done;
-    R.hinit[43] = (unsigned)std::min<int64_t>(std::max<int64_t>(ctx->opt_resident_idle_us, 10), 2000000) * 100u;  // 100 MHz ticks
-    R.hinit[44] = done + (1u << 30);
-    HIP_TRY(ctx, hipMemcpyAsync(R.dbox, R.hinit, 64 * sizeof(unsigned), hipMemcpyHostToDevice, R.stream));
-    *R.hparams = R.p;
-    HIP_TRY(ctx, hipMemcpyAsync(R.dparams, R.hparams, sizeof(KParams), hipMemcpyHostToDevice, R.stream));
-    void *args[] = {(void *)&R.dparams, (void *)&R.tab, (void *)&ctx->dv4_mags, (void *)&R.dcf, (void *)&R.dbox};
-    HIP_TRY(ctx, hipModuleLaunchKernel(R.f, (unsigned)R.grid, 1, 1, R.block, 1, 1, (unsigned)(R.lds + 32), R.stream, args, nullptr));
-    R.launched = true;
-    ++R.launches;
-    return PCL_OK;
-}
-extern "C" int pcl_resident_start(pcl_ctx *ctx, const double *Z, double *delta, double *vals) {
-    if (!ctx) return PCL_EINVAL;
-    if (!Z || !vals) return fail(ctx, PCL_EINVAL, "pcl_resident_start: NULL pointer");
-    if (ctx->res.active) return fail(ctx, PCL_EINVAL, "pcl_resident_start: already started (pcl_resident_stop first)");
-    ON_DEVICE(ctx);
-    pcl_ctx::Resident &R = ctx->res;
-    ctx->res_capture = true;
-    const int rc = launch_fused(ctx, Z, delta, vals, false);
-    ctx->res_capture = false;
-    if (rc != PCL_OK) return rc;
-    if (R.lds + 32 > (size_t)ctx->max_lds) return fail(ctx, PCL_ESHAPE, "pcl_resident_start: no LDS word left for the request flag");
-    if (R.grid > std::max(ctx->n_cu, 1)) return fail(ctx, PCL_ESHAPE, "pcl_resident_start: more workgroups than CUs");
-    if (!R.f) {
-        const int np = v4_power_tiles(R.p.d, R.p.m, R.p.q, (size_t)ctx->max_lds);
-        const std::string src = v4_source(*ctx->v4_plan, R.p.q, np, (int)ctx->opt_v4_variant, 2);
-        const std::string key = "fused-sparse-resident:" + std::to_string(R.p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
-        R.f = jit_compile(ctx->device, key, src, "pcl_fused_sparse_resident", true);
-        if (!R.f) return fail(ctx, PCL_EHIP, "pcl_resident_start: the resident module did not compile (%s)", g_jit_note.c_str());
-    }
-    if (!R.stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
-    if (!R.hbox) {
-        HIP_TRY(ctx, hipHostMalloc((void **)&R.hbox, 64 * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent));
-        HIP_TRY(ctx, hipHostGetDevicePointer((void **)&R.hbox_dev, R.hbox, 0));
-        HIP_TRY(ctx, hipHostMalloc((void **)&R.hinit, 64 * sizeof(unsigned), hipHostMallocDefault));
-        HIP_TRY(ctx, hipHostMalloc((void **)&R.hparams, sizeof(KParams), hipHostMallocDefault));
-        HIP_TRY(ctx, hipMalloc((void **)&R.dparams, sizeof(KParams)));
-        HIP_TRY(ctx, hipMalloc((void **)&R.dbox, 64 * sizeof(unsigned) + 16 * 256 * 4 * sizeof(long long)));  // (+ the debugging stamps of v4_flags & 2048)
-        HIP_TRY(ctx, hipMemset(R.dbox, 0, 64 * sizeof(unsigned) + 16 * 256 * 4 * sizeof(long long)));
-    }
-    for (int i = 0; i < 64; ++i) __atomic_store_n(R.hbox + i, 0u, __ATOMIC_RELAXED);
-    R.posted = 0;
-    R.launched = false;
-    R.active = true;
-    // what the trajectory and the outputs' earlier writers have queued on the context's stream comes first
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return res_launch(ctx);
-}
-extern "C" int pcl_resident_post(pcl_ctx *ctx, int32_t count) {
-    if (!ctx) return PCL_EINVAL;
-    if (!ctx->res.active) return fail(ctx, PCL_EINVAL, "pcl_resident_post: not started");
-    if (count < 1 || count > (1 << 20)) return fail(ctx, PCL_EINVAL, "pcl_resident_post: count %d", (int)count);
-    ON_DEVICE(ctx);
-    pcl_ctx::Resident &R = ctx->res;
-    R.posted += (unsigned)count;
-    __atomic_store_n(R.hbox + 0, R.posted, __ATOMIC_RELEASE);
-    // (it has left -- idle for longer than resident_idle_us -- or is leaving: workgroup 0 says so in a host word; no runtime call on the way of a request)
-    if (__atomic_load_n(R.hbox + 17, __ATOMIC_ACQUIRE)) return res_launch(ctx);
-    return PCL_OK;
-}
-extern "C" int pcl_resident_wait(pcl_ctx *ctx, double timeout_s) {
-    if (!ctx) return PCL_EINVAL;
-    if (!ctx->res.active) return fail(ctx, PCL_EINVAL, "pcl_resident_wait: not started");
-    ON_DEVICE(ctx);
-    pcl_ctx::Resident &R = ctx->res;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned long long spin = 0;; ++spin) {
-        if (__atomic_load_n(R.hbox + 16, __ATOMIC_ACQUIRE) == R.posted) break;
-        if ((spin & 1023) == 1023) {
-            if (!res_running(ctx)) {  // left with requests outstanding (it decided to leave as they arrived): again from the first incomplete one
-                if (__atomic_load_n(R.hbox + 16, __ATOMIC_ACQUIRE) == R.posted) break;
-                if (int rc = res_launch(ctx)) return rc;
-            }
-            if (timeout_s > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
-                __atomic_store_n(R.hbox + 1, 1u, __ATOMIC_RELEASE);
-                return fail(ctx, PCL_EINTERNAL, "pcl_resident_wait: %u of %u requests complete after %.3f s (the kernel has been told to leave)", __atomic_load_n(R.hbox + 16, __ATOMIC_ACQUIRE), R.posted, timeout_s);
-            }
-        }
-    }
-    return check_device_error(ctx, "pcl_resident_wait");
-}
-extern "C" int pcl_resident_stop(pcl_ctx *ctx) {
-    if (!ctx) return PCL_EINVAL;
-    pcl_ctx::Resident &R = ctx->res;
-    if (!R.active) return PCL_OK;
-    ON_DEVICE(ctx);
-    __atomic_store_n(R.hbox + 1, 1u, __ATOMIC_RELEASE);
-    R.active = false;
-    HIP_TRY(ctx, hipStreamSynchronize(R.stream));
-    R.launched = false;
-    return check_device_error(ctx, "pcl_resident_stop");
-}
-// debugging (option v4_flags & 2048 at pcl_resident_start): 100 MHz stamps [evaluation 0 .. 15 since the last start][workgroup][request seen, last block
-// store issued, workgroup drained, arrival counted]; call after pcl_resident_stop
-extern "C" int pcl_resident_stamps(pcl_ctx *ctx, int64_t *out, int64_t count) {
-    if (!ctx || !out || !ctx->res.dbox) return PCL_EINVAL;
-    ON_DEVICE(ctx);
-    HIP_TRY(ctx, hipMemcpy(out, ctx->res.dbox + 64, (size_t)std::min<int64_t>(count, 16 * 256 * 4) * sizeof(int64_t), hipMemcpyDeviceToHost));
-    return PCL_OK;
-}
-extern "C" int pcl_resident_completed(const pcl_ctx *ctx, int64_t *count) {
-    if (!ctx || !count) return PCL_EINVAL;
-    *count = ctx->res.hbox ? (int64_t)__atomic_load_n(ctx->res.hbox + 16, __ATOMIC_ACQUIRE) : -1;
-    return PCL_OK;
-}
+#ifdef PCL_LAB
+#include "pcl_host_resident.hpp"  // pcl_resident_* (include/piccolo_hip_lab.h): measured, loses, kept for the record
+#endif
 
 extern "C" int pcl_jac_dev(pcl_ctx *ctx, const double *Z, double *vals) {  // eval_jacobian alone: no residual is written
     if (!ctx) return PCL_EINVAL;

@@ -209,31 +209,6 @@ class _PclContext:
     def eval_jac_dev(self, Z, delta, vals):
         self._chk(self._L.pcl_eval_jac_dev(self._h, _ptr(Z), _ptr(delta), _ptr(vals)))
 
-    # -- resident evaluator (include/piccolo_hip.h: pcl_resident_*): eval_jac_dev as requests to workgroups that stay on the device
-    def resident_start(self, Z, delta, vals):
-        self._chk(self._L.pcl_resident_start(self._h, _ptr(Z), _ptr(delta) if delta is not None else None, _ptr(vals)))
-        self._resident_keep = (Z, delta, vals)  # the kernel holds their addresses
-
-    def resident_post(self, count=1):
-        self._chk(self._L.pcl_resident_post(self._h, int(count)))
-
-    def resident_wait(self, timeout_s=10.0):
-        self._chk(self._L.pcl_resident_wait(self._h, float(timeout_s)))
-
-    def resident_eval(self, timeout_s=10.0):
-        """One evaluation of the trajectory array as it stands now: post + wait."""
-        self.resident_post(1)
-        self.resident_wait(timeout_s)
-
-    def resident_stop(self):
-        self._chk(self._L.pcl_resident_stop(self._h))
-        self._resident_keep = None
-
-    def resident_completed(self):
-        v = ctypes.c_int64()
-        self._chk(self._L.pcl_resident_completed(self._h, ctypes.byref(v)))
-        return v.value
-
     def eval_jac_compact_dev(self, Z, delta, compact):
         self._chk(self._L.pcl_eval_jac_compact_dev(self._h, _ptr(Z), _ptr(delta), _ptr(compact)))
 
