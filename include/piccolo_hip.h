@@ -312,7 +312,7 @@ int pcl_codegen_source(int d, int m, const double *G0, const double *Gj, char *b
 /* The same for the pattern-compiled FUSED residual + Jacobian kernel (kernel_version 4) at diagonal Pade order 2q, q = 1..5
  * (n_g0 drifts G0[b] span the union pattern: an ensemble's members); PCL_ESHAPE when the drives need more resident
  * coefficients than the kernel keeps. */
-int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what /* 0 fused residual + Jacobian (+ residual only), 1 Hessian of the Lagrangian */,
+int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what /* 0 fused residual + Jacobian (+ residual only), 1 Hessian of the Lagrangian (one wave per chain), 5 ... (one wave per group of state columns) */,
                           char *buf, int64_t cap, int64_t *needed);
 /* Compile the pattern-compiled module(s) a context of this system would compile on first use and leave the code object under its content
  * hash in out_dir (NULL: <library directory>/prebuilt, which every context looks at before the user's cache and before hiprtc).  Needs

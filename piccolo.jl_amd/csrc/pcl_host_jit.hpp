@@ -436,12 +436,12 @@ extern "C" int pcl_jit_prebuild(int d, int m, const double *G0, int n_g0, const 
 // Inspection hooks of the fused pattern-compiled kernel (no device needed): its generated source, and the generator's term
 // tables applied on the host to one column (y = G(u) x; n_g0 drifts span the union pattern, the first one is applied).
 extern "C" int pcl_codegen_source_v4(int d, int m, const double *G0, int n_g0, const double *Gj, int q, int what, char *buf, int64_t cap, int64_t *needed) {
-    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || what < 0 || what > 1 || !G0 || (m > 0 && !Gj) || !needed) return PCL_EINVAL;
+    if (d < 1 || d > 32 || m < 0 || m > 6 || n_g0 < 1 || q < 1 || q > 5 || (what != 0 && what != 1 && what != 5) || !G0 || (m > 0 && !Gj) || !needed) return PCL_EINVAL;
     const pcl_codegen::V4Plan plan = pcl_codegen::make_v4_plan(d, m, G0, n_g0, Gj);
     if (!plan.ok) return PCL_ESHAPE;
     const int np = v4_power_tiles(d, m, q, 160 * 1024);
     if (!np) return PCL_ESHAPE;
-    const std::string src = what == 1 ? v4_hess_source(plan, q) : v4_source(plan, q, np);
+    const std::string src = what == 5 ? v4_hess_cols_source(plan, q) : what == 1 ? v4_hess_source(plan, q) : v4_source(plan, q, np);
     *needed = (int64_t)src.size() + 1;
     if (buf && cap > 0) {
         const size_t nb = std::min<size_t>((size_t)cap - 1, src.size());
