@@ -686,7 +686,10 @@ def main():
                 roof = HBM_PEAK_GBS * 1e9 / abytes
                 out["vs_cpu_baseline_note"] = ("value / cpu_baseline.value (median call of the C port on one pinned socket of this host); the HBM roofline itself (%.0f evals/s) is %.0f x "
                                                "this port: the north star's >= 50 x cannot be met device-resident against it when that ratio is below 50.  The port is analytic and far "
-                                               "faster than the reference's ForwardDiff-through-expv path (bench/reference_cpu.jl), which cannot run here" % (roof, roof / cb["value"]))
+                                               "faster than the reference's ForwardDiff-through-expv path (bench/reference_cpu.jl, which cannot run here; its algorithm restated in C is cpu_baseline.reference_algorithm)" % (roof, roof / cb["value"]))
+                ra = cb.get("reference_algorithm") or {}
+                if ra.get("evals_per_s"):  # the reference's ALGORITHM (expv + forward-mode duals), ported: the other comparator north_star's words name
+                    out["vs_reference_algorithm_port"] = out["value"] / ra["evals_per_s"]
                 hd = (out.get("other_rates") or {}).get("host_delivered")
                 if hd:  # the drop-in's real position for a host-resident consumer: the delivered evaluation against the port's call
                     hd["cpu_port_ms_per_eval_p50"] = cb["warm"]["p50_ms"]

@@ -4,14 +4,22 @@
 // pcl_eval_jac) and checks the device-pointer path against the host-pointer path bit for bit.
 //   python bench/make_abi_inputs.py                       # writes bench/config3_inputs.bin (numpy only)
 //   hipcc -O2 -std=c++17 -I include -o bench/bench_abi bench/bench_abi.cpp -L piccolo.jl_amd/csrc -lpiccolo_hip -Wl,-rpath,'$ORIGIN/../piccolo.jl_amd/csrc'
-//   bench/bench_abi [inputs.bin] [steps] [warmup]
+//   bench/bench_abi [inputs.bin] [steps] [warmup] [--ranks N]
+// --ranks N (N >= 1): the path's ONE collective through the C ABI as well -- pcl_comm_get_unique_id (rank 0; the 128 bytes travel through a file) ->
+// pcl_comm_init -> pcl_reduce_sum_dev of a payload of the shared controls' size (1 + (N-1)(m+1) doubles) behind every evaluation ->
+// pcl_comm_destroy.  One PROCESS per device: the parent is rank 0 and starts ranks 1 .. N-1 as copies of itself (--rank r --id-file f), rank r on
+// device r.  N = 1 runs the same calls over one rank (what a 1-GPU box can execute); the sum is checked on every rank: rank r contributes r + 1.
 #include <hip/hip_runtime.h>
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "piccolo_hip.h"
@@ -34,8 +42,63 @@
     } while (0)
 
 int main(int argc, char **argv) {
-    const char *path = argc > 1 ? argv[1] : "bench/config3_inputs.bin";
-    const int steps = argc > 2 ? atoi(argv[2]) : 200, warmup = argc > 3 ? atoi(argv[3]) : 20;
+    int nranks = 0, rank = 0;  // nranks 0: no collective (the default)
+    const char *id_file = nullptr;
+    std::vector<char *> pos;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--ranks") && i + 1 < argc)
+            nranks = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--rank") && i + 1 < argc)
+            rank = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--id-file") && i + 1 < argc)
+            id_file = argv[++i];
+        else
+            pos.push_back(argv[i]);
+    }
+    const char *path = pos.size() > 0 ? pos[0] : "bench/config3_inputs.bin";
+    const int steps = pos.size() > 1 ? atoi(pos[1]) : 200, warmup = pos.size() > 2 ? atoi(pos[2]) : 20;
+    if (nranks < 0 || rank < 0 || (nranks > 0 && rank >= nranks)) {
+        fprintf(stderr, "--ranks %d --rank %d\n", nranks, rank);
+        return 1;
+    }
+    int n_dev = 0;
+    HIPCHK(hipGetDeviceCount(&n_dev));
+    if (nranks > n_dev) {
+        fprintf(stderr, "--ranks %d asked for, %d device(s) visible\n", nranks, n_dev);
+        return 1;
+    }
+    // rank 0 of a multi-rank run: the id (written to a file the children poll), then the children
+    pcl_comm_id comm_id;
+    std::string idf;
+    std::vector<pid_t> kids;
+    if (nranks > 0 && rank == 0) {
+        if (pcl_comm_get_unique_id(&comm_id) != PCL_OK) {
+            fprintf(stderr, "pcl_comm_get_unique_id: %s\n", pcl_last_error(nullptr));
+            return 3;
+        }
+        if (nranks > 1) {
+            idf = std::string("/tmp/bench_abi_id_") + std::to_string((long long)getpid());
+            FILE *g = fopen((idf + ".tmp").c_str(), "wb");
+            if (!g || fwrite(&comm_id, sizeof comm_id, 1, g) != 1) return 1;
+            fclose(g);
+            if (rename((idf + ".tmp").c_str(), idf.c_str()) != 0) return 1;
+            for (int r = 1; r < nranks; ++r) {
+                const pid_t pid = fork();
+                if (pid == 0) {
+                    const std::string rs = std::to_string(r), ns = std::to_string(nranks), st = std::to_string(steps), wu = std::to_string(warmup);
+                    execl("/proc/self/exe", argv[0], path, st.c_str(), wu.c_str(), "--ranks", ns.c_str(), "--rank", rs.c_str(), "--id-file", idf.c_str(), (char *)nullptr);
+                    _exit(127);
+                }
+                kids.push_back(pid);
+            }
+        }
+    } else if (nranks > 0) {
+        if (!id_file) return 1;
+        FILE *g = nullptr;
+        for (int tries = 0; tries < 600 && !(g = fopen(id_file, "rb")); ++tries) usleep(100000);
+        if (!g || fread(&comm_id, sizeof comm_id, 1, g) != 1) return 1;
+        fclose(g);
+    }
     FILE *f = fopen(path, "rb");
     if (!f) {
         fprintf(stderr, "cannot open %s (run: python bench/make_abi_inputs.py)\n", path);
@@ -62,6 +125,7 @@ int main(int argc, char **argv) {
     desc.batch_mode = PCL_BATCH_MEMBERS;
     desc.pade_order = 4;
     desc.index_base = 1;  // what a Julia / MOI host asks for
+    desc.device_id = nranks > 0 ? rank : 0;  // one process per device
     desc.G0 = G0.data();
     desc.Gj = Gj.data();
     desc.x_offs = &x_off;
@@ -80,7 +144,7 @@ int main(int argc, char **argv) {
         rmax = rows[i] > rmax ? rows[i] : rmax;
         cmax = cols[i] > cmax ? cols[i] : cmax;
     }
-    printf("%s | d %d m %d N %d | rows %lld cols %lld nnz %lld (%lld per interval) | structure 1-based, max (row, col) = (%d, %d)\n", pcl_version(), d, m, N,
+    if (rank == 0) printf("%s | d %d m %d N %d | rows %lld cols %lld nnz %lld (%lld per interval) | structure 1-based, max (row, col) = (%d, %d)\n", pcl_version(), d, m, N,
            (long long)n_rows, (long long)n_cols, (long long)nnz, (long long)per, rmax, cmax);
     if (rmax != n_rows || cmax > n_cols) {
         fprintf(stderr, "structure out of range\n");
@@ -110,6 +174,43 @@ int main(int argc, char **argv) {
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     const double bytes = ((double)z_dim * 8 + (double)x_dim * 8 + (double)per * 8) * (N - 1);  // algorithmic bytes per evaluation
 
+    // the path's one collective through the C ABI: a payload of the shared controls' size summed over the ranks behind every evaluation
+    double red_us = -1.0, alone_us = -1.0;
+    bool red_ok = true;
+    const int64_t npay = 1 + (int64_t)(N - 1) * (m + 1);
+    if (nranks > 0) {
+        PCLCHK(pcl_comm_init(ctx, &comm_id, rank, nranks));
+        double *dp;
+        HIPCHK(hipMalloc((void **)&dp, (size_t)npay * 8));
+        std::vector<double> hp((size_t)npay, (double)(rank + 1));
+        auto reset_payload = [&]() { return hipMemcpyAsync(dp, hp.data(), (size_t)npay * 8, hipMemcpyHostToDevice, stream); };
+        HIPCHK(reset_payload());
+        PCLCHK(pcl_reduce_sum_dev(ctx, dp, npay));  // (the first one builds the rings)
+        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<double> got((size_t)npay);
+        HIPCHK(hipMemcpy(got.data(), dp, (size_t)npay * 8, hipMemcpyDeviceToHost));
+        const double want = 0.5 * nranks * (nranks + 1);  // sum over ranks of (rank + 1)
+        for (double v : got) red_ok = red_ok && v == want;
+        HIPCHK(hipEventRecord(e0, stream));
+        for (int i = 0; i < steps; ++i) {
+            PCLCHK(pcl_eval_jac_dev(ctx, dZ, dd, dv));
+            PCLCHK(pcl_reduce_sum_dev(ctx, dp, npay));
+        }
+        HIPCHK(hipEventRecord(e1, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        float rms = 0.f;
+        HIPCHK(hipEventElapsedTime(&rms, e0, e1));
+        red_us = rms * 1e3 / steps;
+        HIPCHK(hipEventRecord(e0, stream));
+        for (int i = 0; i < steps; ++i) PCLCHK(pcl_reduce_sum_dev(ctx, dp, npay));
+        HIPCHK(hipEventRecord(e1, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipEventElapsedTime(&rms, e0, e1));
+        alone_us = rms * 1e3 / steps;
+        PCLCHK(pcl_comm_destroy(ctx));
+        (void)hipFree(dp);
+    }
+
     // the host-pointer entry point (what the Julia glue calls) must deliver the same bits
     std::vector<double> hd((size_t)n_rows), hv((size_t)nnz), gd((size_t)n_rows), gv((size_t)nnz);
     PCLCHK(pcl_reset_stream(ctx));
@@ -125,7 +226,7 @@ int main(int argc, char **argv) {
     const double hwall = std::chrono::duration<double>(std::chrono::steady_clock::now() - h0).count();
     int64_t lk = 0;
     PCLCHK(pcl_get_option(ctx, "last_kernel", &lk));
-    printf("{\"client\": \"bench_abi.cpp (C ABI only)\", \"metric\": \"constraint+Jacobian evals/sec, 3-transmon d=27 unitary, T=100 knots\", \"value\": %.1f, "
+    if (rank == 0) printf("{\"client\": \"bench_abi.cpp (C ABI only)\", \"metric\": \"constraint+Jacobian evals/sec, 3-transmon d=27 unitary, T=100 knots\", \"value\": %.1f, "
            "\"unit\": \"evals/s\", \"steps\": %d, \"warmup\": %d, \"us_per_eval_wall\": %.2f, \"us_per_eval_kernel\": %.2f, \"hbm_GBps\": %.1f, "
            "\"host_delivered_evals_per_s\": %.1f, \"device_and_host_paths_bitwise_equal\": %s, \"max_abs_delta\": %.3e, \"last_kernel\": %lld}\n",
            steps / wall, steps, warmup, wall / steps * 1e6, ms * 1e3 / steps, bytes / (ms * 1e-3 / steps) / 1e9, hreps / hwall, same ? "true" : "false", dmax, (long long)lk);
@@ -133,5 +234,20 @@ int main(int argc, char **argv) {
     (void)hipFree(dZ);
     (void)hipFree(dd);
     (void)hipFree(dv);
-    return same && std::isfinite(dmax) && dmax > 0.0 ? 0 : 5;
+    int rc = same && std::isfinite(dmax) && dmax > 0.0 ? 0 : 5;
+    if (nranks > 0) {
+        if (!red_ok) rc = 6;
+        int kids_ok = 1;
+        for (pid_t pid : kids) {
+            int st = 0;
+            if (waitpid(pid, &st, 0) != pid || !WIFEXITED(st) || WEXITSTATUS(st) != 0) kids_ok = 0;
+        }
+        if (!idf.empty()) (void)unlink(idf.c_str());
+        if (!kids_ok) rc = rc ? rc : 7;
+        if (rank == 0)  // (one more line, after the evaluation's: the collective)
+            printf("{\"client\": \"bench_abi.cpp (C ABI only)\", \"rccl_ranks\": %d, \"payload_doubles\": %lld, \"sum_exact_on_rank0\": %s, \"other_ranks_ok\": %s, "
+                   "\"us_per_eval_plus_reduce\": %.2f, \"us_per_reduce_alone\": %.2f, \"evals_per_s_all_ranks\": %.1f}\n",
+                   nranks, (long long)npay, red_ok ? "true" : "false", kids_ok ? "true" : "false", red_us, alone_us, nranks * 1e6 / red_us);
+    }
+    return rc;
 }

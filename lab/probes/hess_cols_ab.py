@@ -25,6 +25,8 @@ with torch.cuda.stream(stream):
             mud = torch.randn(c.n_rows, dtype=torch.float64, device="cuda")
             hv = torch.empty(c.hess_nnz, dtype=torch.float64, device="cuda")
             variants = [("chains", 7, 0), ("columns", 8, 0)] + ([("chains/2", 7, 1)] if B == 1 else []) + ([("kernel 6", 0, 0)] if order == 4 else [])
+            if os.environ.get("HC_ONLY"):  # the column-group kernel alone (A/B of its header variants: lab/probes/ab_jit_headers.sh)
+                variants = [("columns", 8, 0)]
             res, outs = {v[0]: [] for v in variants}, {}
             for rnd in range(5):
                 for name, hk, sp in (variants if rnd % 2 == 0 else variants[::-1]):
@@ -42,6 +44,11 @@ with torch.cuda.stream(stream):
                     e1.record(stream)
                     stream.synchronize()
                     res[name].append(e0.elapsed_time(e1) / 20 * 1e3)
+            if os.environ.get("HC_ONLY"):
+                print("order %2d B=%d: columns %.1f us (%.2f/eval) min %.1f, nan %d" % (order, B, np.median(res["columns"]), np.median(res["columns"]) / B, min(res["columns"]),
+                                                                                         int(torch.isnan(outs["columns"]).sum().item())), flush=True)
+                c.close()
+                continue
             a, bb = outs["chains"].view(B * (t0.N - 1), -1), outs["columns"].view(B * (t0.N - 1), -1)
             nsc = (system.n_drives + 1) * (system.n_drives + 2) // 2
             scale = a.abs().max().item()

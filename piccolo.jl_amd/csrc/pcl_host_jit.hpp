@@ -167,6 +167,7 @@ std::string jit_cache_key(const std::string &source, const std::string *hdr, int
     h.add(source);
     for (int i = 0; i < nh; ++i) h.add(hdr[i]);
     for (const char *o : kJitOpts) h.add(std::string(o));
+    if (const char *e = getenv("PCL_JIT_OPTS")) h.add(std::string(e));
     h.add(std::string(name_expr ? name_expr : ""));
     int ver = 0;
     (void)hipRuntimeGetVersion(&ver);  // the ROCm release (hiprtc ships with it); asked of the runtime that is loaded anyway -- a cache hit never opens libhiprtc
@@ -213,7 +214,29 @@ bool rtc_compile(const std::string &source, const char **hdrp, const char *const
         return false;
     }
     if (!plain_name) g_rtc.AddNameExpression(prog, name_expr);
-    if (g_rtc.CompileProgram(prog, (int)(sizeof kJitOpts / sizeof kJitOpts[0]), (const char **)kJitOpts) != 0) {
+    // per-module compiler options: the leading lines `// pcl-jit-opt: <tokens>` of the generated source (part of the source, so part of the cache key),
+    // then the tokens of the environment variable PCL_JIT_OPTS (experiments; jit_cache_key hashes it)
+    std::vector<std::string> extra;
+    auto add_tokens = [&](const std::string &line) {
+        size_t i = 0;
+        while (i < line.size()) {
+            while (i < line.size() && (line[i] == ' ' || line[i] == '\t')) ++i;
+            size_t j = i;
+            while (j < line.size() && line[j] != ' ' && line[j] != '\t') ++j;
+            if (j > i) extra.push_back(line.substr(i, j - i));
+            i = j;
+        }
+    };
+    for (size_t pos = 0; source.compare(pos, 16, "// pcl-jit-opt: ") == 0;) {
+        const size_t eol = source.find('\n', pos);
+        add_tokens(source.substr(pos + 16, (eol == std::string::npos ? source.size() : eol) - pos - 16));
+        if (eol == std::string::npos) break;
+        pos = eol + 1;
+    }
+    if (const char *e = getenv("PCL_JIT_OPTS")) add_tokens(e);
+    std::vector<const char *> opts(kJitOpts, kJitOpts + sizeof kJitOpts / sizeof kJitOpts[0]);
+    for (const std::string &o : extra) opts.push_back(o.c_str());
+    if (g_rtc.CompileProgram(prog, (int)opts.size(), opts.data()) != 0) {
         size_t ls = 0;
         g_jit_note = std::string("hiprtcCompileProgram failed for ") + what;
         if (g_rtc.GetProgramLogSize && g_rtc.GetProgramLog && g_rtc.GetProgramLogSize(prog, &ls) == 0 && ls > 1) {
@@ -342,17 +365,23 @@ std::string v4_source(const pcl_codegen::V4Plan &plan, int q, int np, int varian
     return std::string("#include \"pcl_device_common.hpp\"\n#define SP4_TICKETS ") + (tickets == 1 ? "1\n" : "0\n") + (tickets == 2 ? "#define SP4_RESIDENT 1\n" : "") + pcl_codegen::v4_functions(plan, q, np, variant) + "#include \"pcl_kernel_fused_sparse.hpp\"\n";
 }
 
+// The general-order Hessian kernels live at the register limit (256 per lane: a chain column, two output vectors, the product's accumulators).  With the
+// scheduler's default pressure estimate the allocator spills and, worse, rotates whole register sets to open a slot (137 v_mov_b64 per pass of
+// pcl_hess_cols_kernel at config 3); with the GCN pressure trackers the same source compiles without scratch and with 21 moves per pass
+// (lab/probes/hc_isa/hc_isa_stats.py).  The fused kernels are not register-bound and compile to the same code either way.
+static const char kHessJitOpt[] = "// pcl-jit-opt: -mllvm -amdgpu-use-amdgpu-trackers=1\n";
+
 // ... and of the Hessian-of-the-Lagrangian kernel of the same family (pcl_kernel_hess_sparse4.hpp; any order)
 std::string v4_hess_source(const pcl_codegen::V4Plan &plan, int q, int variant = 0, int split = 1) {  // variant (profile builds): SH_VARIANT of the kernel (bits >= 16), bit 8: the gather-dot reads nine columns at a time
-    return "#include \"pcl_device_common.hpp\"\n#define SH_VARIANT " + std::to_string(variant) + "\n#define SH_SPLIT " + std::to_string(split) + "\n" + pcl_codegen::v4_functions(plan, q, 1, variant & 8, true) + "#include \"pcl_kernel_hess_sparse4.hpp\"\n";
+    return std::string(kHessJitOpt) + "#include \"pcl_device_common.hpp\"\n#define SH_VARIANT " + std::to_string(variant) + "\n#define SH_SPLIT " + std::to_string(split) + "\n" + pcl_codegen::v4_functions(plan, q, 1, variant & 8, true) + "#include \"pcl_kernel_hess_sparse4.hpp\"\n";
 }
 // ... one wave per group of state columns (pcl_kernel_hess_cols.hpp; any order)
 std::string v4_hess_cols_source(const pcl_codegen::V4Plan &plan, int q, int variant = 0) {
-    return "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q, 1, (variant & 7) | 8, true) + "#include \"pcl_kernel_hess_cols.hpp\"\n";
+    return std::string(kHessJitOpt) + "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q, 1, (variant & 7) | 8, true) + "#include \"pcl_kernel_hess_cols.hpp\"\n";
 }
 static size_t hess_cols_lds_bytes(int d, int m, int q, int gt_total) {  // HC_LDS_DOUBLES of the kernel
     const int cpw = 32 / (m + 1);
-    return ((size_t)((m + 1) * cpw + (2 + (q > 2 ? q - 2 : 0)) * cpw) * (2 * d + 1) + 24 + ((size_t)m * 2 * (((size_t)gt_total + 2) / 3) + 1) / 2) * sizeof(double);
+    return ((size_t)((m + 1) * cpw + (2 + (q > 2 ? q - 2 : 0)) * cpw) * (2 * d + 1) + 16 + ((size_t)m * 2 * (((size_t)gt_total + 2) / 3) + 1) / 2) * sizeof(double);
 }
 }  // namespace
 

@@ -36,16 +36,24 @@
 #define HC_XS (HC_NCH * HC_ROW)               // ... per wave
 #define HC_NSC ((SPM + 1) * (SPM + 2) / 2)
 #define HC_GCH 7                                                        // rows per batch of the table-driven gathers (7, 9: 105 us per 8 seeds at order 8, 5: 110)
-#define HC_NCFT 24                                                      // coefficient table of the gathers: 0, +-mags[g]
+#define HC_NCFT 16                                                      // coefficient table of the gathers: 0, +-mags[g]
+// The addresses of the drives' gathers come out of a table: per entry one v_bfe_u32 + one v_lshl_add_u32 for the W row (by hand -- the compiler turns
+// the extraction into shift, mask, add) and shift + mask for the coefficient, whose table sits at a constant offset the load takes as its immediate
+// (round 5: 6 instructions per entry, 256 per pass for 46 multiply-adds; now 4).  MEASURED AND DROPPED (round 6): W columns on 512-byte boundaries,
+// so that the address is (row << 3) | base in one v_and_or_b32 -- the four columns of a chain then share their LDS banks and an 8-seed launch at
+// order 8 went from 106 to 134 us (profiles/r06_hess_variants_3.log): the kernel is bound by the LDS, not by the vector instructions it issues.
+#define HC_WS SP4CS                                                     // doubles per W column (the slots' stride)
+#define HC_CFT_IN_TAIL 0
 #define HC_GT_WPC ((SP4_GT_TOTAL + 2) / 3)                             // the gathers' entry table (sp4_gt_tab): three 10-bit entries per dword, per (drive, half)
 #define HC_GT_DOUBLES ((SPM * 2 * HC_GT_WPC + 1) / 2)
 // 20,416 bytes at config 3, order 8: EIGHT of these workgroups share a CU's 160 KB (22.9 KB with R_{q-1} stored, a strip of zeros for the W lanes'
 // Y term and 16-bit entries: seven; 64 trajectories per launch 807 -> 784 us)
-#define HC_LDS_DOUBLES ((HC_NSLOT + (2 + HC_NR) * HC_CPW) * SP4CS + HC_NCFT + HC_GT_DOUBLES)
-static_assert(1 + 2 * SP4NMAG <= 16 && 16 <= HC_NCFT && SPN <= 64, "10-bit entries of the gathers' table: source row (6 bits), coefficient index (4 bits)");
+#define HC_LDS_DOUBLES (HC_CPW * HC_WS + (HC_NSLOT - HC_CPW + (2 + HC_NR) * HC_CPW) * SP4CS + (HC_CFT_IN_TAIL ? 0 : HC_NCFT) + HC_GT_DOUBLES)
+static_assert(1 + 2 * SP4NMAG <= 16 && 16 <= HC_NCFT && SPN <= HC_WS, "10-bit entries of the gathers' table: source row (6 bits), coefficient index (4 bits)");
 static_assert(HC_CPW >= 1 && SPM >= 1, "chains per column");
 static_assert(HC_XS <= 64 && HC_ROW <= SPD, "one lane per reduced sum");
 
+template <bool B> struct hc_bool { static constexpr bool value = B; };
 static __device__ __forceinline__ unsigned hc_lds_off(const double *q) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const double *)q;
 }
@@ -64,8 +72,13 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     extern __shared__ double lds[];
     constexpr int d = SPD, n = SPN, m = SPM, q = SP4Q;
     constexpr int CB = HC_CPW * SP4CS;  // doubles per block of HC_CPW columns
-    double *slots = lds, *Dt = slots + HC_NSLOT * SP4CS, *St = Dt + CB, *Rt = St + CB, *cft = Rt + HC_NR * CB;
-    unsigned *gtab = (unsigned *)(cft + HC_NCFT);
+    // LDS: [W columns | the V chains' slots | D | S | R_1 .. R_{q-2} | coefficient table | the gathers' entry table]
+    double *Wreg = lds, *vslots = Wreg + HC_CPW * HC_WS, *Dt = vslots + (HC_NSLOT - HC_CPW) * SP4CS, *St = Dt + CB, *Rt = St + CB;
+    double *cft = HC_CFT_IN_TAIL ? Wreg + SPN : Rt + HC_NR * CB;
+    unsigned *gtab = (unsigned *)(Rt + HC_NR * CB + (HC_CFT_IN_TAIL ? 0 : HC_NCFT));
+    // column `cc` of chain `chn`
+    if (hc_lds_off(lds) != 0u) __builtin_trap();  // (the gathers' addresses are built as integers on that base)
+    auto chain_col = [&](int chn, int cc) -> double * { return chn == 0 ? Wreg + cc * HC_WS : vslots + ((chn - 1) * HC_CPW + cc) * SP4CS; };
     const long long xd = (long long)n * d;
     // Which (interval, column group) this wave takes.  The HC_NG waves of an interval write neighbouring 1,728-byte runs of every output vector: their
     // first and last 128-byte lines are shared.  Workgroups go to the XCDs round-robin (blockIdx mod 8), and each XCD has its own write-back L2:
@@ -98,6 +111,12 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
 #else
 #define HC_STAMP() do { } while (0)
 #endif
+#ifdef HC_MARKS  // (lab/probes/hc_isa/hc_isa_stats.py compiles with -DHC_MARKS: a comment in the ISA at every phase boundary; never in a launched module --
+                 //  the statement orders the compiler's memory operations, and that alone cost 20 % of an 8-seed launch when it was left in)
+#define HC_MARK(name) asm volatile("; hc_mark " name ::: "memory")
+#else
+#define HC_MARK(name) do { } while (0)
+#endif
     HC_STAMP();
     int ln_ = threadIdx.x;
     asm volatile("" : "+v"(ln_));
@@ -105,8 +124,8 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     const int ch = s / HC_CPW, col = s - ch * HC_CPW;  // chain (0: W, 1 + l: V_l), column of the group
     const bool inr = s < HC_NSLOT, act = inr && col < nce, isV = ch > 0;
     const int own = half * d, oth = (1 - half) * d;
-    double *Xs = slots + (inr ? s : 0) * SP4CS;  // this lane's chain column
-    const double *Wc = slots + col * SP4CS;      // the W chain's column
+    double *Xs = chain_col(inr ? ch : 0, inr ? col : 0);  // this lane's chain column
+    const double *Wc = Wreg + col * HC_WS;                // the W chain's column
     const int cb = col * SP4CS;
 
     // ---- inputs, first half: every load of the wave is requested before anything waits (lane = element of the wave's contiguous columns) --
@@ -160,7 +179,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
             if (e < ne) {
                 const int cc = e / n, o = cc * SP4CS + (e - cc * n);
                 const double dv = xn_[t] - xc_[t], sv = xn_[t] + xc_[t];
-                slots[o] = mv_[t];
+                Wreg[cc * HC_WS + (e - cc * n)] = mv_[t];
                 Dt[o] = dv;
                 St[o] = sv;
             }
@@ -171,10 +190,12 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     // ---- R_a = sum_b (+-T_{a+b+1}) G^b |Y_{a+b+1}|, the operands of the (u,u) sums, as ONE chain per state column from the top:
     //      R_{q-1} = +-T_q |Y_q| (stored with the inputs),  R_a = +-T_{a+1} |Y_{a+1}| + G R_{a+1}   (q - 2 products; lanes (half, column)) -----
     if constexpr (q > 2) {
+        HC_MARK("rsetup");
         const bool ract = s < HC_CPW && s < nce;  // (slot = column)
         const int rb = (s < HC_CPW ? s : 0) * SP4CS;
 #pragma unroll 1
         for (int a = q - 2; a >= 1; --a) {
+            HC_MARK("rchain");
             if (ract) {
                 double x[SPD];  // R_{a+1}
                 if (a == q - 2) {  // R_{q-1} = +-T_q |Y_q|
@@ -200,11 +221,16 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     //          then the W slots hold W_{jp-1} (jp = 1: M), what the V lanes' gathers need:   V_{l,jp} = G^T V_{l,jp-1} + G_l^T W_{jp-1}
     //      -- added in registers behind the product, so the Y term never passes through LDS (a write and a read per row and level, and
     //      the product's wait for them).  Pass 1 has no product (V_{l,0} = 0), pass q + 1 the W lanes' last one. --------------------------
+    HC_MARK("setup");
     const unsigned oX = hc_lds_off(Xs + own), oXx = hc_lds_off(Xs + oth);
     const double bt = half ? 1.0 : -1.0;  // G^T: the other half receives -V from half 0, +V from half 1
-    double x[SPD], accK[SPD], accN[SPD];  // chain value; the two output vectors of this lane's chain (X_k / X_{k+1} blocks), its rows
+    // chain value; the lane's two output vectors (X_k block: -sum_j w_j chain_j, X_{k+1} block: sum_j (-1)^j w_j chain_j) as the sums over its even and
+    // its odd levels.  In pass jp the V lanes are at level jp and the W lanes at jp - 1 -- opposite parities -- so with (accA, accB) = (even, odd) in the V
+    // lanes and (odd, even) in the W lanes EVERY lane adds to accB in odd passes and to accA in even ones: one multiply-add per row and pass (round 5
+    // updated both output vectors in every pass: two), the vectors are formed at the end: -(A + B) and +-(A - B).
+    double x[SPD], accA[SPD], accB[SPD];
 #pragma unroll
-    for (int i = 0; i < SPD; ++i) accK[i] = accN[i] = 0.0;
+    for (int i = 0; i < SPD; ++i) accA[i] = accB[i] = 0.0;
     if (act && !isV) {
 #pragma unroll
         for (int i = 0; i < SPD; ++i) x[i] = Xs[own + i];  // W_0 = M
@@ -235,9 +261,12 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         return v;
     };
     double hpV = 1.0, hpW = 1.0, hpW2 = 1.0;  // h^(level - 1) of the V lanes' and of the W lanes' level; h^(level - 2) of the W lanes'
-#pragma unroll 1
-    for (int jp = 1; jp <= q + 1; ++jp) {
+    // (the body of a pass, compiled twice: for odd and for even passes -- which of the two accumulators a pass adds to is then a matter of the code, not of
+    //  a branch; with a branch inside ONE body the compiler copied the 27 accumulators aside and back around it)
+    auto pass_body = [&](const int jp, auto odd_) __attribute__((always_inline)) {
+        constexpr bool odd_pass = decltype(odd_)::value;
         const bool on = act && (isV ? jp <= q : jp >= 2);  // lanes with a level in this pass
+        HC_MARK("pass_product");
         if (jp >= 2) {
             if (on) {
                 sp4_product0_t(x, 0u, oX, oXx, 0.0, 1.0, bt, tab_t, cf);
@@ -247,6 +276,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
             asm volatile("" ::: "memory");
         }
         HC_STAMP();
+        HC_MARK("pass_gather");
         if (on && isV) {  // + G_l^T W_{jp-1}
 #if HC_SWITCH_GATHER
             SP4_GATHER_T_SWITCH(ch - 1, Wc + own, Wc + oth, Xs + own, 1.0, (half ? -1.0 : 1.0), mg)
@@ -257,6 +287,10 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
             // HC_GCH rows at a time, staged by hand -- every entry of the batch, then every operand, then the sums: left to itself the
             // compiler keeps two or three rows in flight and the wave waits out an LDS round trip per row (6.3 k cycles per level)
             const unsigned *gt = gtab + ((ch - 1) * 2 + half) * HC_GT_WPC;
+            // (the module has no static LDS: the wave's dynamic LDS starts at offset 0 -- checked once at the top of the kernel -- so the coefficient
+            //  table's offset is a constant of the layout)
+            const unsigned wcol_off = (unsigned)col * (HC_WS * 8u);
+            constexpr unsigned cft_off = (HC_CFT_IN_TAIL ? SPN : HC_CPW * HC_WS + (HC_NSLOT - HC_CPW + (2 + HC_NR) * HC_CPW) * SP4CS) * 8u;
 #pragma unroll
             for (int i0 = 0; i0 < SPD; i0 += HC_GCH) {
                 unsigned e_[HC_GCH][SP4_GTK];
@@ -266,7 +300,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
                     for (int kk = 0; kk < SP4_GTK; ++kk) {
                         const int row = i0 + i < SPD ? i0 + i : SPD - 1;
                         const int en = sp4_gt_off(row) + (kk < sp4_gt_cnt(row) ? kk : 0);  // entry number: word en / 3, bits 10 (en % 3) ...
-                        e_[i][kk] = kk < sp4_gt_cnt(row) ? (gt[en / 3] >> (10 * (en % 3))) & 1023u : 0u;
+                        e_[i][kk] = kk < sp4_gt_cnt(row) ? gt[en / 3] : 0u;                 // (the dword; the fields come out of it with one v_bfe_u32 each)
                     }
                 double w_[HC_GCH][SP4_GTK], c_[HC_GCH][SP4_GTK];
 #pragma unroll
@@ -274,8 +308,14 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
 #pragma unroll
                     for (int kk = 0; kk < SP4_GTK; ++kk)
                         if (kk < sp4_gt_cnt(i0 + i < SPD ? i0 + i : SPD - 1)) {  // (a row takes as many terms as the drive with the most there)
-                            w_[i][kk] = Wc[e_[i][kk] >> 4];
-                            c_[i][kk] = cft[e_[i][kk] & 15u];
+                            const int row = i0 + i < SPD ? i0 + i : SPD - 1;
+                            const unsigned sh = 10u * (unsigned)((sp4_gt_off(row) + kk) % 3);
+                            // (addresses as integers: the W column's base has no bit below 512, the tables' bases are constants of the layout)
+                            unsigned aw;  // the W row's address: (bits sh + 4 .. sh + 9) << 3 + the column's
+                            asm("v_bfe_u32 %0, %1, %2, 6\n\tv_lshl_add_u32 %0, %0, 3, %3" : "=&v"(aw) : "v"(e_[i][kk]), "n"(sh + 4u), "v"(wcol_off));
+                            const unsigned fc = sh >= 3u ? (e_[i][kk] >> (sh - 3u)) & 0x78u : (e_[i][kk] << (3u - sh)) & 0x78u;  // coefficient index << 3
+                            w_[i][kk] = *(const __attribute__((address_space(3))) double *)(size_t)aw;
+                            c_[i][kk] = *(const __attribute__((address_space(3))) double *)(size_t)(fc + cft_off);
                         }
                 asm volatile("" ::: "memory");
 #pragma unroll
@@ -291,6 +331,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         asm volatile("" ::: "memory");
         HC_STAMP();
         // ---- what the lane's level contributes ----
+        HC_MARK("pass_contrib");
         const int jl = isV ? jp : jp - 1;
         const double cj = isV ? p.pc[jp <= q ? jp : q] : p.pc[jp - 1], hp = isV ? hpV : hpW;
         const double Tj = cj * hp * h, T1 = jl * cj * hp, sg = (jl & 1) ? -1.0 : 1.0;
@@ -299,10 +340,12 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         for (int v = 0; v < HC_ROW; ++v) cv[v] = 0.0;
         if (on) {
             const double wK = isV ? Tj : T1;  // the weight of this level in the lane's output vectors
+            if constexpr (odd_pass) {
 #pragma unroll
-            for (int i = 0; i < SPD; ++i) {
-                accK[i] = __builtin_fma(-wK, x[i], accK[i]);
-                accN[i] = __builtin_fma(wK * sg, x[i], accN[i]);
+                for (int i = 0; i < SPD; ++i) accB[i] = __builtin_fma(wK, x[i], accB[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) accA[i] = __builtin_fma(wK, x[i], accA[i]);
             }
             asm volatile("" ::: "memory");
             const double *Yj = ((jl & 1) ? St : Dt) + cb + own;  // Y_j = D (j even) | -S (j odd)
@@ -336,6 +379,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
                 for (int i = 0; i < SPM; ++i) cv[1 + i] = wr * r6[i];
             }
         }
+        HC_MARK("pass_sums");
         // this pass's 1 + m values of the chain, summed over its columns; lane `col` adds the values col, col + HC_CPW, ... to its running totals
         // (every lane of the wave takes part in the DPP steps: lanes without a level contribute zeros)
 #pragma unroll
@@ -350,7 +394,13 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         hpW = hpV;
         hpV *= h;
         HC_STAMP();
+    };
+#pragma unroll 1
+    for (int jp = 1; jp <= q + 1; jp += 2) {
+        pass_body(jp, hc_bool<true>{});
+        if (jp + 1 <= q + 1) pass_body(jp + 1, hc_bool<false>{});
     }
+    HC_MARK("tail");
     // ---- the reduced sums of the wave: every lane parks its 1 + m sums in its chain slot (rows 0 .. m of its half; slots of columns
     //      past the end hold zeros); lane e < HC_XS adds the 2 HC_CPW parts of (chain, value) in a fixed order ------------------------------
     asm volatile("" ::: "memory");
@@ -365,13 +415,13 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
             const int chn = ln_ / HC_ROW, val = ln_ - chn * HC_ROW;
             double r = 0.0;
             if constexpr (HC_GROUPSUM) {
-                const double *sl_ = slots + (chn * HC_CPW + val % HC_CPW) * SP4CS + val / HC_CPW;
+                const double *sl_ = chain_col(chn, val % HC_CPW) + val / HC_CPW;
                 r = sl_[0] + sl_[d];
             } else {
 #pragma unroll
                 for (int cc = 0; cc < HC_CPW; ++cc) {
-                    r += slots[(chn * HC_CPW + cc) * SP4CS + val];
-                    r += slots[(chn * HC_CPW + cc) * SP4CS + d + val];
+                    r += chain_col(chn, cc)[val];
+                    r += chain_col(chn, cc)[d + val];
                 }
             }
             hc_store_coherent(xch + ((long long)item * HC_NG + grp) * HC_XS + ln_, r);
@@ -385,24 +435,25 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     typedef double hc_d2u __attribute__((ext_vector_type(2), aligned(8)));  // (a vector of the output starts on an 8-byte boundary)
     constexpr int NT2 = (HC_CPW * SPN + 127) / 128;
     static_assert(SPN % 2 == 0, "pairs of rows");
-    int eo[NT2];
+    int eo[NT2], eoW[NT2];  // offsets of the lane's pair of elements in a V chain's block of columns | in the W columns
 #pragma unroll
     for (int t = 0; t < NT2; ++t) {
         const int e = 2 * ln_ + 128 * t, cc = e / n;
         eo[t] = e < ne ? cc * SP4CS + (e - cc * n) : -1;
+        eoW[t] = e < ne ? cc * HC_WS + (e - cc * n) : 0;
     }
     hc_d2 t_[HC_NCH][NT2];
     auto pass_lds = [&](int pass) {  // the lane's output vector of the pass -> its chain slot; then every read of the pass (two LDS round trips per pass, not one per chain)
         if (act) {
 #pragma unroll
-            for (int i = 0; i < SPD; ++i) Xs[own + i] = pass ? accN[i] : accK[i];
+            for (int i = 0; i < SPD; ++i) Xs[own + i] = pass ? (isV ? accA[i] - accB[i] : accB[i] - accA[i]) : -(accA[i] + accB[i]);
         }
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int c2 = 0; c2 < HC_NCH; ++c2)
 #pragma unroll
             for (int t = 0; t < NT2; ++t) {
-                const double *src = slots + c2 * CB + (eo[t] >= 0 ? eo[t] : 0);
+                const double *src = c2 == 0 ? Wreg + eoW[t] : vslots + (c2 - 1) * CB + (eo[t] >= 0 ? eo[t] : 0);
                 t_[c2][t].x = src[0], t_[c2][t].y = src[1];
             }
         asm volatile("" ::: "memory");
@@ -433,7 +484,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     xold = __builtin_amdgcn_readfirstlane(xold);
     if (xold == HC_NG - 1) {
         if (ln_ == 0) __hip_atomic_store(xcnt + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch)
-        double *tot = slots;  // [chain][value]
+        double *tot = vslots;  // [chain][value]
         if (ln_ < HC_XS) {
             const double *xall = xch + (long long)item * HC_NG * HC_XS + ln_;
             double v_[HC_NG], r = 0.0;  // (every row requested, then added in the order of the waves)

@@ -538,3 +538,31 @@ def test_terminal_loss_forms_of_the_host_mirror():
     psi = rng.standard_normal(n) + 1j * rng.standard_normal(n)
     scope, A, c = pa.DensityMatrixPureStateInfidelityObjective("ρ", psi).form(n * n, 1)
     assert abs(abs(1 - F_of(A, c, x)) - po.density_matrix_pure_state_infidelity_loss(x, psi)) < 1e-12
+
+
+def test_reference_algorithm_port_expv_with_forward_mode_duals():
+    """oracle/expv_ref.c -- what bench.py reports as cpu_baseline.reference_algorithm: the reference's constraint delta = x_{k+1} - expv(dt, Ghat(u), x_k)
+    [REF docs/src/concepts/index.md:21; src/control/integrators.jl:48] by Al-Mohy & Higham's truncated Taylor action (ExponentialAction.jl's algorithm) and
+    its Jacobian by forward-mode dual numbers pushed through expv in chunks, as ForwardDiff does [REF integrators.jl:282-285].  Against scipy's expm /
+    expm_frechet (the oracle's exp_jacobian_values, the function the Pade Jacobian is pinned on) to 1e-13, every chunk size, entries outside the block
+    structure exactly zero, a sub-range of intervals leaves the others untouched."""
+    from oracle import ref_lib
+
+    so = po.config_system(2)
+    Z, lay = po.synthetic_trajectory(so, 7, seed=11)
+    Z[:, lay.dt_off] = 0.05 + 0.1 * np.random.default_rng(2).random(7)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    d_ref, j_ref = po.exp_residual(Z, lay, G0, Gj), po.exp_jacobian_values(Z, lay, G0, Gj)
+    for chunk in (1, 5, 12, 64):
+        dl, jc, info = ref_lib.expv_eval_jac(Z, lay, G0, Gj, nthreads=2, chunk=chunk)
+        assert np.abs(dl - d_ref).max() < 1e-13 and np.abs(jc - j_ref).max() < 1e-13 and info["off_structure_max"] == 0.0, chunk
+        assert info["taylor_terms"] >= lay.K * 5
+    dl, jc, _ = ref_lib.expv_eval_jac(Z, lay, G0, Gj, nthreads=1, k_first=2, k_count=3)
+    assert np.isnan(jc[:2]).all() and np.isnan(jc[5:]).all() and np.abs(jc[2:5] - j_ref[2:5]).max() < 1e-13 and np.abs(dl[2:5] - d_ref[2:5]).max() < 1e-13
+    # BASELINE config 3, one interval of a longer time step (|dt G|_1 ~ 2: two scaling steps)
+    so3 = po.config_system(3)
+    Z3, lay3 = po.synthetic_trajectory(so3, 3, seed=5)
+    Z3[:, lay3.dt_off] = 0.2
+    G03, Gj3 = so3.G_drift, np.array(so3.G_drives)
+    dl, jc, info = ref_lib.expv_eval_jac(Z3, lay3, G03, Gj3, nthreads=4, k_first=0, k_count=1)
+    assert np.abs(jc[0] - po.exp_jacobian_values(Z3, lay3, G03, Gj3)[0]).max() < 1e-12 and np.abs(dl[0] - po.exp_residual(Z3, lay3, G03, Gj3)[0]).max() < 1e-13
