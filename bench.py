@@ -457,15 +457,16 @@ def main():
             st_ = max(20, min(args.steps, 100))
             # (600 untimed launches, 20 ms: at orders 8 and 10 a launch keeps getting shorter for several hundred launches -- 31.9, 31.1, 30.1, 29.6, 29.1, 28.7 us
             #  over six rounds of 110 at order 10 (lab/probes/order_single.py), the clocks follow the load slowly; order 4, bound by HBM, is flat.  A solver runs thousands.)
+            # (round-5 review: timed EXACTLY like `value` -- the same warm-up, the same number of steps, one region; the steady state behind 600 untimed
+            #  launches -- at orders 8 and 10 a launch keeps getting shorter for several hundred launches, the clocks follow the load slowly -- beside it, not instead of it)
+            w0, d0, _ = run_multistart(1, args.steps, args.warmup, False, chosen)
             w1, d1, _ = run_multistart(1, st_, 600, False, chosen)
-            w1b, d1b, _ = run_multistart(1, st_, 600, False, chosen)  # (the better of two timed regions: one region in a hundred reads 2 x -- a host stall; the headline's region is not treated this way)
-            if d1b < d1:
-                w1, d1 = w1b, d1b
-            rs = {"evals_per_s": st_ / w1, "us_per_launch_kernel": d1 / st_ * 1e6, "frac_of_hbm_peak": abytes / (d1 / st_) / 1e9 / HBM_PEAK_GBS, "untimed_launches": 600}
+            rs = {"evals_per_s": args.steps / w0, "us_per_launch_kernel": d0 / args.steps * 1e6, "frac_of_hbm_peak": abytes / (d0 / args.steps) / 1e9 / HBM_PEAK_GBS, "untimed_launches": args.warmup,
+                  "steady_state": {"evals_per_s": st_ / w1, "us_per_launch_kernel": d1 / st_ * 1e6, "frac_of_hbm_peak": abytes / (d1 / st_) / 1e9 / HBM_PEAK_GBS, "untimed_launches": 600, "steps": st_}}
         dev_exp = ((out["config"].get("pade_vs_exp") or {}).get("config3") or {})
         out["value_reference_order"] = {"order": chosen, "order_tol": 1e-10, "evals_per_s": rs["evals_per_s"], "us_per_launch_kernel": rs["us_per_launch_kernel"],
                                         "frac_of_hbm_peak": rs["frac_of_hbm_peak"], "untimed_launches": rs.get("untimed_launches", args.warmup), "max_deviation_from_exp_constraint": dev_exp.get("order_%d" % chosen),
-                                        "order4_deviation": dev_exp.get("order_4"),
+                                        "order4_deviation": dev_exp.get("order_4"), "steady_state": rs.get("steady_state"), "steps": args.steps,
                                         "note": "the order HipPadeIntegrator / BilinearIntegrator choose by default (pade_order = 0) on config 3's bounds, one trajectory per launch"}
     if rank == 0 and world == 1 and args.workload == "auto" and not args.no_shares:
         st = max(20, min(args.steps, 100))
@@ -533,10 +534,8 @@ def main():
         st = max(20, min(args.steps, 100))
         # the orders that reach the reference's exp constraint at this config (pade_vs_exp): same launch shapes as the headline
         for order in (8, 10):
-            w1, d1, i1 = run_multistart(1, st, 600, False, order)  # (600 untimed launches: a fresh context starts with the clocks down and they follow slowly -- see value_reference_order)
-            w1b, d1b, _ = run_multistart(1, st, 600, False, order)  # (the better of two timed regions, as for value_reference_order)
-            if d1b < d1:
-                w1, d1 = w1b, d1b
+            w1p, d1p, i1 = run_multistart(1, args.steps, args.warmup, False, order)  # (timed like `value`: the same warm-up and steps, one region)
+            w1, d1, _ = run_multistart(1, st, 600, False, order)  # (and the steady state behind 600 untimed launches: the clocks follow the load slowly -- see value_reference_order)
             w8, d8, i8 = run_multistart(B, st, 20, False, order)
             mso = pa.HipPadeMultistart(G0, Gj, t0, B, device=local, pade_order=order)
             co = mso.ctx
@@ -547,11 +546,11 @@ def main():
             ho = torch.empty(co.hess_nnz, dtype=torch.float64, device="cuda")
             wh, dh = time_steps(lambda: co.hess_dev(Zo, muo, ho), 20, 30, torch, None)  # (30 untimed launches: the context was just created, the clocks are down)
             we, de_ = time_steps(lambda: co.eval_dev(Zo, do_), st, 5, torch, None)
-            hko, eko = co.get_option("last_hess_kernel"), co.get_option("last_kernel")
+            hko, eko, hrp = co.get_option("last_hess_kernel"), co.get_option("last_kernel"), co.get_option("last_hess_rpre")
             mso.close()
             del Zo, do_, muo, ho
             h64 = None
-            if order == 8:  # the same Hessian with 64 trajectories per launch (config 5 whole: every round of waves full)
+            if order in (8, 10):  # the same Hessian with 64 trajectories per launch (config 5 whole: every round of waves full)
                 ms64 = pa.HipPadeMultistart(G0, Gj, t0, 64, device=local, pade_order=order)
                 c64 = ms64.ctx
                 c64.set_stream(stream.cuda_stream)
@@ -562,19 +561,21 @@ def main():
                 h64 = {"us_per_eval_kernel": dh64 / 10 / 64 * 1e6, "batch": 64, "kernel_id": c64.get_option("last_hess_kernel")}
                 ms64.close()
                 del Z64, mu64, hv64
-            ex["order%d" % order] = {"hessian_of_lagrangian": {"us_per_eval_kernel": dh / 20 / B * 1e6, "batch": B, "kernel_id": hko,
+            ex["order%d" % order] = {"hessian_of_lagrangian": {"us_per_eval_kernel": dh / 20 / B * 1e6, "batch": B, "kernel_id": hko, "r_chain_waves": hrp,
                                                                "kernel": "pcl_hess_cols_kernel (pattern-compiled, any order: one wave per group of state columns)" if hko // 10 == 8 else
                                                                          "pcl_hess_sparse4_kernel (pattern-compiled, any order)" if hko // 10 == 7 else "general-order kernel"},
                                      **({"hessian_of_lagrangian_64": h64} if h64 else {}),
                                      "residual_only": {"us_per_eval_kernel": de_ / st / B * 1e6, "batch": B, "kernel_id": eko},
-                                     "single": {"evals_per_s": st / w1, "us_per_launch_kernel": d1 / st * 1e6, "frac_of_hbm_peak": abytes / (d1 / st) / 1e9 / HBM_PEAK_GBS,
-                                                "kernel_id": i1["kernel_id"]},
+                                     "single": {"evals_per_s": args.steps / w1p, "us_per_launch_kernel": d1p / args.steps * 1e6, "frac_of_hbm_peak": abytes / (d1p / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                                "kernel_id": i1["kernel_id"], "timed_like": "value (the run's --warmup and --steps, one region)",
+                                                "steady_state": {"evals_per_s": st / w1, "us_per_launch_kernel": d1 / st * 1e6, "frac_of_hbm_peak": abytes / (d1 / st) / 1e9 / HBM_PEAK_GBS, "untimed_launches": 600}},
                                      "batch8": {"evals_per_s": B * st / w8, "us_per_launch_kernel": d8 / st * 1e6,
                                                 "frac_of_hbm_peak": abytes * B / (d8 / st) / 1e9 / HBM_PEAK_GBS, "kernel_id": i8["kernel_id"]},
                                      "kernel": describe(i1["kernel_id"], 0)}
-        # one trajectory per launch (what a solver working on ONE problem calls): Hessian of the Lagrangian and residual only, orders 4 and 8
+        # one trajectory per launch (what a solver working on ONE problem calls): Hessian of the Lagrangian and residual only, orders 4, 8 and 10 (10: the
+        # order the default constructor picks on config 3's bounds -- the call a default-constructed solve makes every iteration)
         ex["single_trajectory"] = {}
-        for order in (4, 8):
+        for order in (4, 8, 10):
             ms1 = pa.HipPadeMultistart(G0, Gj, t0, 1, device=local, pade_order=order)
             c1 = ms1.ctx
             c1.set_stream(stream.cuda_stream)

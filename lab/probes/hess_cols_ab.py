@@ -22,6 +22,8 @@ with torch.cuda.stream(stream):
                                            dt_off=t0.components["Δt"].start, x_offs=[t0.components[pa.trajectory.STATE].start], G0=system.G_drift,
                                            Gj=system.G_drives_array(), batch=B, batch_mode=pa._lib.PCL_BATCH_TRAJ, pade_order=order)
             c.set_stream(stream.cuda_stream)
+            for kv in os.environ.get("HC_OPTS", "").split():  # e.g. HC_OPTS="hess_rpre=0"
+                c.set_option(kv.split("=")[0], int(kv.split("=")[1]))
             mud = torch.randn(c.n_rows, dtype=torch.float64, device="cuda")
             hv = torch.empty(c.hess_nnz, dtype=torch.float64, device="cuda")
             variants = [("chains", 7, 0), ("columns", 8, 0)] + ([("chains/2", 7, 1)] if B == 1 else []) + ([("kernel 6", 0, 0)] if order == 4 else [])

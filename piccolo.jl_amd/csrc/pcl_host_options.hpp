@@ -82,6 +82,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
 #endif
     else if (!strcmp(key, "hess_xcd"))  // column-group Hessian kernel: the waves of an interval take blockIdx values equal mod n = one XCD (-1 auto: 8 | 0, 1: blockIdx order)
         ctx->opt_hess_xcd = v < 0 ? -1 : v;
+    else if (!strcmp(key, "hess_rpre"))  // column-group Hessian kernel: the chain of the R_a in a launch of its own in front (-1 auto | 0 | 1)
+        ctx->opt_hess_rpre = v < 0 ? -1 : (v > 2 ? 2 : v);
     else if (!strcmp(key, "hess_split"))  // general-order pattern-compiled Hessian kernel: two workgroups per interval (-1 auto by launch size | 0 | 1)
         ctx->opt_hess_split = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "eval_coop"))  // pattern-compiled residual kernel: four waves per interval (-1 auto by launch size | 0 | 1)
@@ -152,6 +154,10 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->last_kernel;
     else if (!strcmp(key, "hess_xcd"))
         *v = ctx->opt_hess_xcd;
+    else if (!strcmp(key, "hess_rpre"))
+        *v = ctx->opt_hess_rpre;
+    else if (!strcmp(key, "last_hess_rpre"))
+        *v = ctx->last_hess_rpre;
 #ifdef PCL_LAB
     else if (!strcmp(key, "resident_idle_us"))
         *v = ctx->opt_resident_idle_us;

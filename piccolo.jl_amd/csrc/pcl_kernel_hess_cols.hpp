@@ -65,12 +65,123 @@ static __device__ __forceinline__ void hc_store_coherent(double *q, double v) {
 static __device__ __forceinline__ double hc_load_coherent(const double *q) {
     return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
 }
+// The R-chain wave of an interval and the interval's column-group waves run on ONE XCD (blockIdx equal mod 8: the host launches chain waves only with
+// that placement), so their exchange needs the XCD's L2 and no more: device-scope stores and loads (past the CU's vector cache, served by the L2) -- at
+// system scope every wave paid a round trip to memory for its tiles and the chain waves bought 3 % instead of 12.
+static __device__ __forceinline__ void hc_store_xcd(double *q, double v) {
+    __hip_atomic_store((unsigned long long *)q, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ double hc_load_xcd(const double *q) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// One R-chain wave: ALL d state columns of interval `item`, lane = (half, column) -- 2 d of 64 lanes.  The lane keeps its half column of D and of S in
+// registers (a chain wave has no output vectors to hold), so the only LDS it needs is ONE tile of d columns for the product's exchange of the halves
+// (11.9 KB at config 3: inside a column-group wave's 20 KB):
+//     R_{q-1} = +-T_q |Y_q| (registers);   a = q-2 .. 1:  tile <- G R_{a+1} (sp4_product0: own half written, the partner's half added),
+//                                                          R_a = tile + (+-T_{a+1}) |Y_{a+1}|  (registers), -> tile -> memory, lane = element (coalesced).
+// (The column-group waves' own chain adds the Y term before the partner's half, this one behind it: the (u,u) entries of the two modes differ in the
+//  last bit; the output vectors do not depend on R.)
+static_assert(SPD <= 32, "lane = (half, column)");
+#define HR_T ((SPD * SPN + 63) / 64)
+static __device__ __forceinline__ void hc_rchain_role(const KParams &p, const double *__restrict__ drift_tab, const double *__restrict__ mags_, const double *__restrict__ dcf_tab,
+                                                      double *rout, unsigned int *rflag, int item, double *lds) {
+    constexpr int d = SPD, n = SPN, q = SP4Q;
+    double *Rt = lds;  // [column][SP4CS]
+    if (item >= p.batch * p.K) return;
+    const int k = item % p.K, b = item / p.K;
+    const long long xd = (long long)n * d;
+    int ln_ = threadIdx.x;
+    asm volatile("" : "+v"(ln_));
+    const int half = ln_ >> 5, col = ln_ & 31;
+    const bool act = col < d;
+    const int own = half * d, oth = (1 - half) * d, cb = (act ? col : 0) * SP4CS;
+    const long long xo = p.x_off0 >= 0 ? p.x_off0 : p.x_offs[p.z_batch_stride ? 0 : b];
+    const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + xo + (long long)(act ? col : 0) * n + own;  // the lane's half column: d contiguous doubles
+    const double *zn = zk + p.z_dim;
+    double Dv[SPD], Sv[SPD];
+#pragma unroll
+    for (int i = 0; i < SPD; ++i) Dv[i] = zk[i], Sv[i] = zn[i];
+    sp_cptr magc = (sp_cptr)mags_;
+    double mg[SP4NMAG];
+#pragma unroll
+    for (int g = 0; g < SP4NMAG; ++g) mg[g] = magc[g];
+    sp_cptr zc = (sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim);
+    double u[SPM];
+#pragma unroll
+    for (int l = 0; l < SPM; ++l) u[l] = zc[p.u_off + l];
+    const double h = zc[p.dt_off];
+    sp4_cf cf;
+    SP4_SET_CF(cf, u, mg);
+    SP4_SET_DCF(cf, (sp_cptr)(dcf_tab + (p.g0_batch_stride ? (long long)b * SP4NDCFP : 0)));
+    sp_cptr tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
+#pragma unroll
+    for (int i = 0; i < SPD; ++i) {
+        const double xc = Dv[i], xn = Sv[i];
+        Dv[i] = xn - xc, Sv[i] = xn + xc;
+    }
+    auto wgt_at = [&](int jj) {  // +-T_jj as the column-group waves form it
+        double hj = 1.0;
+        for (int t = 0; t < jj; ++t) hj *= h;
+        return ((jj & 1) ? -1.0 : 1.0) * p.pc[jj] * hj;
+    };
+    double pwq = 1.0;
+#pragma unroll
+    for (int j = 1; j <= q; ++j) pwq *= h;
+    const double wq = ((q & 1) ? -1.0 : 1.0) * p.pc[q] * pwq;
+    double x[SPD];  // R_{a+1}, this lane's half column
+#pragma unroll
+    for (int i = 0; i < SPD; ++i) x[i] = wq * ((q & 1) ? Sv[i] : Dv[i]);
+    double *rg = rout + (long long)item * HC_NR * xd;
+#pragma unroll 1
+    for (int a = q - 2; a >= 1; --a) {
+        if (act) sp4_product0(x, 0u, hc_lds_off(Rt + cb + own), hc_lds_off(Rt + cb + oth), 0.0, 1.0, half ? -1.0 : 1.0, tab, cf);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const double wa = wgt_at(a + 1);
+        if (act) {
+            const bool odd = (a + 1) & 1;
+#pragma unroll
+            for (int i = 0; i < SPD; ++i) x[i] = __builtin_fma(wa, odd ? Sv[i] : Dv[i], Rt[cb + own + i]);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < SPD; ++i) Rt[cb + own + i] = x[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double *ro = rg + (long long)(a - 1) * xd;  // R_a -> the XCD's L2, lane = element (its readers run on this XCD)
+#pragma unroll
+        for (int t = 0; t < HR_T; ++t) {
+            const int e = ln_ + 64 * t;
+            if (e < d * n) {
+                const int cc = e / n;
+                hc_store_xcd(ro + e, Rt[cc * SP4CS + (e - cc * n)]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the tile is read before the next product writes it)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the tiles are acknowledged by the L2)
+    if (ln_ == 0 && rflag) __hip_atomic_fetch_add(rflag + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(2, 2))) void pcl_hess_cols_kernel(
     const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ drift_tab_t, const double *__restrict__ mags_, const double *__restrict__ dcf_tab,
-    double *xch /* [interval][HC_NG][HC_XS] reduced sums */, unsigned int *xcnt /* [interval] arrivals (self-resetting) */) {
+    double *xch /* [interval][HC_NG][HC_XS] reduced sums */, unsigned int *xcnt /* [interval] arrivals (self-resetting) */,
+    double *rpre /* NULL, or [interval][HC_NR][d][n]: R_1 .. R_{q-2} of every state column, formed by R-chain waves (below) or by pcl_hess_rchain_kernel */,
+    unsigned int *rflag /* NULL (rpre was written by the launch in front), or [interval]: R-chain waves that have delivered (self-resetting) */) {
     extern __shared__ double lds[];
     constexpr int d = SPD, n = SPN, m = SPM, q = SP4Q;
+    // ---- R-CHAIN WAVES (p.n_stream of them, the FIRST workgroups of the grid, one per interval; launches of several trajectories): R_{q-2} .. R_1 of
+    //      ALL of an interval's state columns, lane = (half, column) -- the same q - 2 products that every column-group wave of round 5 ran on its own
+    //      four columns at 8 of 64 lanes (15 % of an 8-seed launch at order 8), here once per interval.  They are dispatched in front of the
+    //      column-group waves, write their tiles through to memory and count themselves in; a column-group wave looks at its interval's count with
+    //      its first loads and, where the chain has arrived (it started earlier), requests its columns' tiles together with its other inputs.
+    unsigned bid = blockIdx.x;
+    if constexpr (HC_NR > 0) {
+        if (bid < (unsigned)p.n_stream) {
+            hc_rchain_role(p, drift_tab, mags_, dcf_tab, rpre, rflag, (int)bid, lds);
+            return;
+        }
+        bid -= (unsigned)p.n_stream;
+    }
     constexpr int CB = HC_CPW * SP4CS;  // doubles per block of HC_CPW columns
     // LDS: [W columns | the V chains' slots | D | S | R_1 .. R_{q-2} | coefficient table | the gathers' entry table]
     double *Wreg = lds, *vslots = Wreg + HC_CPW * HC_WS, *Dt = vslots + (HC_NSLOT - HC_CPW) * SP4CS, *St = Dt + CB, *Rt = St + CB;
@@ -87,13 +198,19 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     // blockIdx values that are equal mod 8 -- one XCD, one L2, where the partial lines merge; the grid is padded to a multiple of 8 intervals.
     int item, grp;
     if (p.S > 1) {
-        const int x = blockIdx.x % p.S, r = blockIdx.x / p.S;
+        const int x = bid % p.S, r = bid / p.S;
         item = (r / HC_NG) * p.S + x;
         grp = r - (r / HC_NG) * HC_NG;
         if (item >= p.batch * p.K) return;
     } else {
-        item = blockIdx.x / HC_NG;
-        grp = blockIdx.x - item * HC_NG;
+        item = bid / HC_NG;
+        grp = bid - item * HC_NG;
+    }
+    // (the chain wave's count FIRST, in front of every other load: loads return in order, so the wave can look at it while its inputs are still on their
+    //  way and request its columns' tiles behind them -- requested behind the inputs' arrival they cost every wave a second round trip)
+    unsigned rfl_ = 0u;
+    if constexpr (HC_NR > 0) {
+        if (rpre && rflag) rfl_ = __hip_atomic_load(rflag + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const int k = item % p.K, b = item / p.K;
     const int c0 = grp * HC_CPW, nce = min(HC_CPW, d - c0), ne = nce * n;
@@ -140,6 +257,28 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         const int e = ln_ + 64 * t < ne ? ln_ + 64 * t : 0;
         xc_[t] = zk[e], xn_[t] = zn[e], mv_[t] = mu[e];
     }
+    // R_1 .. R_{q-2} of the wave's columns, where the launch before this one has formed them for every column of the interval (pcl_hess_rchain_kernel)
+    double rp_[HC_NR > 0 ? HC_NR : 1][HC_NT];
+    bool r_early = false;  // the chain's tiles were requested with the inputs
+    if constexpr (HC_NR > 0) {
+        if (rpre && !rflag) {
+            const double *rg = rpre + ((long long)item * HC_NR * d + c0) * n;
+#pragma unroll
+            for (int a = 0; a < HC_NR; ++a)
+#pragma unroll
+                for (int t = 0; t < HC_NT; ++t) rp_[a][t] = rg[(long long)a * xd + (ln_ + 64 * t < ne ? ln_ + 64 * t : 0)];
+            r_early = true;
+        } else if (rpre) {
+            r_early = __builtin_amdgcn_readfirstlane((int)rfl_) >= 1;
+            if (r_early) {
+                const double *rg = rpre + ((long long)item * HC_NR * d + c0) * n;
+#pragma unroll
+                for (int a = 0; a < HC_NR; ++a)
+#pragma unroll
+                    for (int t = 0; t < HC_NT; ++t) rp_[a][t] = hc_load_xcd(rg + (long long)a * xd + (ln_ + 64 * t < ne ? ln_ + 64 * t : 0));
+            }
+        }
+    }
     constexpr int GTW = SPM * 2 * HC_GT_WPC;  // the gathers' entry table, in dwords
     unsigned gw_[(GTW + 63) / 64];
 #pragma unroll
@@ -182,6 +321,36 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
                 Wreg[cc * HC_WS + (e - cc * n)] = mv_[t];
                 Dt[o] = dv;
                 St[o] = sv;
+                if constexpr (HC_NR > 0) {
+                    if (r_early) {
+#pragma unroll
+                        for (int a = 0; a < HC_NR; ++a) Rt[a * CB + o] = rp_[a][t];
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (HC_NR > 0) {
+        if (rpre && rflag && !r_early) {  // the interval's R-chain wave had not arrived at the start: wait for it (bounded), then the wave's columns from memory (written through by another XCD's wave)
+            unsigned got = 0;
+            for (int it = 0; it < (1 << 20); ++it) {
+                got = __hip_atomic_load(rflag + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (got >= 1u) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            const double *rg = rpre + ((long long)item * HC_NR * d + c0) * n;
+#pragma unroll
+            for (int a = 0; a < HC_NR; ++a)
+#pragma unroll
+                for (int t = 0; t < HC_NT; ++t) rp_[a][t] = got >= 1u ? hc_load_xcd(rg + (long long)a * xd + (ln_ + 64 * t < ne ? ln_ + 64 * t : 0)) : __builtin_nan("");  // (a wait that gave up poisons the output)
+#pragma unroll
+            for (int t = 0; t < HC_NT; ++t) {
+                const int e = ln_ + 64 * t;
+                if (e < ne) {
+                    const int cc = e / n, o = cc * SP4CS + (e - cc * n);
+#pragma unroll
+                    for (int a = 0; a < HC_NR; ++a) Rt[a * CB + o] = rp_[a][t];
+                }
             }
         }
     }
@@ -189,7 +358,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     HC_STAMP();
     // ---- R_a = sum_b (+-T_{a+b+1}) G^b |Y_{a+b+1}|, the operands of the (u,u) sums, as ONE chain per state column from the top:
     //      R_{q-1} = +-T_q |Y_q| (stored with the inputs),  R_a = +-T_{a+1} |Y_{a+1}| + G R_{a+1}   (q - 2 products; lanes (half, column)) -----
-    if constexpr (q > 2) {
+    if (q > 2 && !rpre) {
         HC_MARK("rsetup");
         const bool ract = s < HC_CPW && s < nce;  // (slot = column)
         const int rb = (s < HC_CPW ? s : 0) * SP4CS;
@@ -484,6 +653,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     xold = __builtin_amdgcn_readfirstlane(xold);
     if (xold == HC_NG - 1) {
         if (ln_ == 0) __hip_atomic_store(xcnt + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch)
+        if (ln_ == 0 && rflag) __hip_atomic_store(rflag + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every wave of the interval has taken its tiles)
         double *tot = vslots;  // [chain][value]
         if (ln_ < HC_XS) {
             const double *xall = xch + (long long)item * HC_NG * HC_XS + ln_;
@@ -512,4 +682,12 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         }
     }
     HC_STAMP();
+}
+
+// ---- the chain wave as a launch of its own in front of pcl_hess_cols_kernel (option hess_rpre 2): the same role, no counter (the stream orders the two launches,
+//      the column-group waves request the tiles with their other inputs).  Measured against the chain waves inside the launch: profiles/r06_hess_rpre_*.log.
+extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64))) void pcl_hess_rchain_kernel(
+    const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ mags_, const double *__restrict__ dcf_tab, double *__restrict__ rout /* [interval][HC_NR][d][n] */) {
+    extern __shared__ double lds[];
+    if constexpr (HC_NR > 0) hc_rchain_role(p, drift_tab, mags_, dcf_tab, rout, nullptr, (int)blockIdx.x, lds);
 }

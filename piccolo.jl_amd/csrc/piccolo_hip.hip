@@ -122,6 +122,12 @@ struct pcl_ctx {
     double *dhcx = nullptr;             // ... the waves' rows of reduced sums and the intervals' arrival counters (self-resetting)
     unsigned int *dhcc = nullptr;
     long long hc_cap = 0;
+    hipFunction_t v4_fhessr = nullptr;  // ... its launch in front for several trajectories: R_1 .. R_{q-2} of every state column, one wave per interval (pcl_hess_rchain_kernel)
+    double *dhcr = nullptr;             // ... [interval][q - 2][d][n]
+    unsigned int *dhcf = nullptr;       // ... [interval] R-chain waves that have delivered (self-resetting)
+    long long hcr_cap = 0;
+    int64_t opt_hess_rpre = -1;         // -1 auto (launches of more than n_cu / 2 intervals: 1) | 0 the chain inside the column-group waves | 1 R-chain waves in the same launch | 2 a launch in front
+    int64_t last_hess_rpre = 0;
     int v4_hessc_failed = 0;
     double *dh4x = nullptr;        // general-order Hessian, two workgroups per interval: their rows of reduced sums ...
     unsigned int *dh4c = nullptr;  // ... and the arrival counters (self-resetting)
@@ -601,7 +607,7 @@ extern "C" void pcl_destroy(pcl_ctx *ctx) {
     if (ctx->res.active) (void)pcl_resident_stop(ctx);  // before any buffer it reads on each request is freed
 #endif
     (void)pcl_comm_destroy(ctx);
-    void *ptrs[] = {ctx->dhcx, ctx->dhcc, ctx->dh4x, ctx->dh4c, ctx->dGjd, ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
+    void *ptrs[] = {ctx->dhcr, ctx->dhcf, ctx->dhcx, ctx->dhcc, ctx->dh4x, ctx->dh4c, ctx->dGjd, ctx->dG0, ctx->ducoef, ctx->dcsr_val, ctx->dcsc_val, ctx->dupos, ctx->dcsr_ptr, ctx->dcsr_col,
                     ctx->dcsc_ptr, ctx->dcsc_row, ctx->dxoffs, ctx->dZ, ctx->dmu, ctx->ddelta, ctx->dvals, ctx->dhess,
                     ctx->dumap, ctx->dell_col, ctx->dell_val, ctx->duell_l, ctx->duell_v, ctx->ddbg, ctx->dellt_col, ctx->dellt_val,
                     ctx->dhpart, ctx->dhcnt, ctx->dug0, ctx->dexpm, ctx->dxout, ctx->dreduce};
@@ -1602,6 +1608,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             const std::string src = v4_hess_cols_source(v4, p.q, (int)ctx->opt_v4_variant);
             const std::string key = "hess-cols:" + std::to_string(p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
             ctx->v4_fhessc = jit_compile(ctx->device, key, src, "pcl_hess_cols_kernel", true);
+            if (ctx->v4_fhessc) ctx->v4_fhessr = jit_compile(ctx->device, key, src, "pcl_hess_rchain_kernel", true);  // (the same module)
             if (!ctx->v4_fhessc) {
                 ctx->v4_hessc_failed = 1;
                 if (int rc = jit_fell_back(ctx, "Hessian of the Lagrangian (column groups)"); rc != PCL_ENOTIMPL) return rc;
@@ -1621,12 +1628,56 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             const long long wo = ctx->desc.per_member_G0 ? (long long)ctx->win_first : 0;
             const double *tab = ctx->dv4_tab + wo * v4.n_drift_pad, *tab_t = ctx->dv4_tab_t + wo * v4.n_drift_pad, *dcf = ctx->dv4_dcf + wo * v4.n_dcf_pad;
             ctx->ticket_launched = true;  // (arrival counters + exchange rows: a launch on another stream must not overlap this one)
-            void *args[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dhcx, (void *)&ctx->dhcc};
+            // Launches of several trajectories: the chain R_{q-2} .. R_1 is formed ONCE per interval by R-chain waves -- the first `intervals`
+            // workgroups of the same launch (pcl_kernel_hess_cols.hpp: hc_rchain_role), lane = (half, column) -- instead of inside each of the interval's
+            // column-group waves at 8 of 64 lanes: 15 % of an 8-seed launch at order 8 (profiles/r06_hess_ablations_4.log).  The tiles travel through
+            // memory (written through; a counter per interval, reset by the interval's last column-group wave).  One trajectory keeps the chain inside
+            // the waves (99 intervals: every wave starts at once, there is nothing to hide the chain waves behind).
+            // option hess_rpre: -1 auto | 0 never | 1 R-chain waves | 2 the same waves as a launch of its own in front (pcl_hess_rchain_kernel: measured, the same within 1 %)
+            // MEASURED (config 3, one box, alternating): 8 seeds 102-107 against 105 us at order 8, 130-134 against 136-138 at order 10; 64 seeds 630-640 against
+            // 648-652 and 805-814 against 850-854 -- 3-5 %, not the 15 % the chain costs inside the waves: a chain wave is 20 k cycles of latency in a wave slot
+            // and every column-group wave pays a flag and a tile round trip at its start.
+            double *rpre = nullptr;
+            unsigned int *rflag = nullptr;
+            ctx->last_hess_rpre = 0;
+            const size_t lds_r = (size_t)p.d * (p.n + 1) * sizeof(double);  // (one tile of d columns: the chain wave's exchange of the halves)
+            // (auto: orders 8 and 10 -- two and three products in the chain; at order 6 the one product a wave saves is worth less than the chain waves cost:
+            //  64 seeds 523 against 505 us; profiles/r06_hess_rpre_*.log)
+            int rmode = ctx->opt_hess_rpre >= 0 ? (int)ctx->opt_hess_rpre : ((2 * items > std::max(ctx->n_cu, 1) && p.q >= 4) ? 1 : 0);
+            if (p.q <= 2) rmode = 0;
+            const int nx_ = ctx->opt_hess_xcd < 0 ? 8 : (int)std::max<int64_t>(1, ctx->opt_hess_xcd);
+            if (rmode == 1 && (lds_r > ldsc || nx_ != 8)) rmode = 0;  // (the chain wave and its readers share an XCD's L2: blockIdx equal mod 8)
+            if (rmode) {
+                const size_t per_item = (size_t)(p.q - 2) * p.d * p.n;
+                if (ctx->hcr_cap < cap * (long long)per_item || !ctx->dhcf) {
+                    if (ctx->dhcr) (void)hipFree(ctx->dhcr);
+                    if (ctx->dhcf) (void)hipFree(ctx->dhcf);
+                    ctx->dhcr = nullptr, ctx->dhcf = nullptr, ctx->hcr_cap = 0;
+                    HIP_TRY(ctx, hipMalloc((void **)&ctx->dhcr, (size_t)cap * per_item * sizeof(double)));
+                    HIP_TRY(ctx, hipMalloc((void **)&ctx->dhcf, (size_t)cap * sizeof(unsigned int)));
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->dhcf, 0, (size_t)cap * sizeof(unsigned int), ctx->stream));
+                    ctx->hcr_cap = cap * (long long)per_item;
+                }
+                rpre = ctx->dhcr;
+                if (rmode == 2) {
+                    const size_t ldsr = lds_r;
+                    if (ctx->v4_fhessr && ldsr <= (size_t)ctx->max_lds) {
+                        void *rargs[] = {(void *)&p, (void *)&tab, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dhcr};
+                        HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhessr, (unsigned)items, 1, 1, 64, 1, 1, (unsigned)ldsr, ctx->stream, rargs, nullptr));
+                    } else
+                        rpre = nullptr, rmode = 0;
+                } else
+                    rflag = ctx->dhcf;
+                ctx->last_hess_rpre = rmode;
+            }
+            const long long n_rblk = rflag ? (items + 7) / 8 * 8 : 0;  // (one chain wave per interval; a multiple of 8: the column-group waves keep their XCDs)
+            p.n_stream = (int)n_rblk;
+            void *args[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dhcx, (void *)&ctx->dhcc, (void *)&rpre, (void *)&rflag};
             // the waves of an interval on ONE XCD (blockIdx equal mod 8: the lines their neighbouring output runs share merge in that XCD's L2);
             // option hess_xcd: -1 auto (on) | 0 blockIdx order | n: the modulus
             const int nx = ctx->opt_hess_xcd < 0 ? 8 : (int)std::max<int64_t>(1, ctx->opt_hess_xcd);
             p.S = nx;
-            const long long grid_hc = nx > 1 ? ((items + nx - 1) / nx) * nx * ng : items * ng;
+            const long long grid_hc = n_rblk + (nx > 1 ? ((items + nx - 1) / nx) * nx * ng : items * ng);
             if (grid_hc > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
             HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhessc, (unsigned)grid_hc, 1, 1, 64, 1, 1, (unsigned)ldsc, ctx->stream, args, nullptr));
             ctx->last_hess_kernel = 80 + p.q;
@@ -1955,7 +2006,7 @@ static void note_order(pcl_ctx *ctx, double theta, bool met) {
 }
 static void set_order(pcl_ctx *ctx, int order, double theta) {
     if (ctx->desc.pade_order != order) {  // (modules are per order: the handles of the previous one are dropped, the modules stay cached)
-        ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = ctx->v4_fhessc = nullptr;
+        ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = ctx->v4_fhessc = ctx->v4_fhessr = nullptr;
         ctx->v4_failed = ctx->v4_hess_failed = ctx->v4_hessc_failed = ctx->v4_ft_failed = 0;
 #ifdef PCL_LAB
         ctx->res.f = nullptr;  // (the resident module bakes the order in as well)

@@ -47,31 +47,37 @@ runpy hess8_sq1 "8 8 8" --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY
 runpy hess8_sq2 "8 8 8" --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_SALU
 runpy hess8_write "8 8 8" --pmc WRITE_SIZE
 runpy hess8_fetch "8 8 8" --pmc FETCH_SIZE
+# ... and at order 10, the order the default constructor picks on config 3's bounds (round-5 review)
+runpy trace_hess10 "8 8 10" --kernel-trace --stats
+runpy hess10_sq1 "8 8 10" --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS
+runpy hess10_sq2 "8 8 10" --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_SALU
+runpy hess10_write "8 8 10" --pmc WRITE_SIZE
+runpy hess10_fetch "8 8 10" --pmc FETCH_SIZE
 cd $ROOT
 python scripts/summarize_profile.py $OUT gpurun_out/profiles_$TAG $TAG
 python - $OUT gpurun_out/profiles_$TAG $TAG <<'PY'
-# <tag>_hess_order8.json: per-dispatch averages of the order-8 Hessian kernels (trace) and of the counter passes
-import csv, glob, json, sys, collections
+# <tag>_hess_order8.json, <tag>_hess_order10.json: per-dispatch averages of the general-order Hessian kernels (trace) and of the counter passes
+import csv, glob, json, sys, collections, shutil
 out, dst, tag = sys.argv[1:4]
-res = {"workload": "Hessian of the Lagrangian, config 3, order 8, 8 trajectories per launch (lab/probes/hess_cols_run.py)", "kernels": {}, "counters_per_dispatch": {}}
-for name in ("trace_hess8", "trace_hess8_chains"):
-    for f in glob.glob("%s/%s/**/*kernel_stats.csv" % (out, name), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "hess" in r["Name"]:
-                res["kernels"][r["Name"] + (" (hess_kernel 7)" if name.endswith("chains") else "")] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
-        for f2 in glob.glob("%s/%s/**/*kernel_stats.csv" % (out, name), recursive=True):
-            import shutil; shutil.copy(f2, "%s/%s_%s_kernel_stats.csv" % (dst, tag, name.replace("trace_", "")))
-tot, n = collections.defaultdict(float), collections.defaultdict(int)
-for name in ("hess8_sq1", "hess8_sq2", "hess8_write", "hess8_fetch"):
-    for f in glob.glob("%s/%s/**/*counter_collection.csv" % (out, name), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "hess" in r["Kernel_Name"]:
-                tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
-for k in sorted(tot): res["counters_per_dispatch"][k] = tot[k] / n[k]
-c = res["counters_per_dispatch"]
-if "WRITE_SIZE" in c: res["write_MB_per_dispatch"] = c["WRITE_SIZE"] * 1024 / 1e6  # (KiB)
-if "FETCH_SIZE" in c: res["fetch_MB_per_dispatch"] = 2 * c["FETCH_SIZE"] * 1024 / 1e6  # (KiB, tallied at half the line size on gfx950: doubled)
-res["algorithmic_MB_per_dispatch"] = 8 * 99 * 20440 * 8 / 1e6
-json.dump(res, open("%s/%s_hess_order8.json" % (dst, tag), "w"), indent=1)
-print(json.dumps(res["kernels"]))
+for order in (8, 10):
+    res = {"workload": "Hessian of the Lagrangian, config 3, order %d, 8 trajectories per launch (lab/probes/hess_cols_run.py)" % order, "kernels": {}, "counters_per_dispatch": {}}
+    for name in ("trace_hess%d" % order,) + (("trace_hess8_chains",) if order == 8 else ()):
+        for f in glob.glob("%s/%s/**/*kernel_stats.csv" % (out, name), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "hess" in r["Name"]:
+                    res["kernels"][r["Name"] + (" (hess_kernel 7)" if name.endswith("chains") else "")] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
+            shutil.copy(f, "%s/%s_%s_kernel_stats.csv" % (dst, tag, name.replace("trace_", "")))
+    tot, n = collections.defaultdict(float), collections.defaultdict(int)
+    for name in ("hess%d_sq1" % order, "hess%d_sq2" % order, "hess%d_write" % order, "hess%d_fetch" % order):
+        for f in glob.glob("%s/%s/**/*counter_collection.csv" % (out, name), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "hess_cols" in r["Kernel_Name"]:
+                    tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+    for k in sorted(tot): res["counters_per_dispatch"][k] = tot[k] / n[k]
+    c = res["counters_per_dispatch"]
+    if "WRITE_SIZE" in c: res["write_MB_per_dispatch"] = c["WRITE_SIZE"] * 1024 / 1e6  # (KiB)
+    if "FETCH_SIZE" in c: res["fetch_MB_per_dispatch"] = 2 * c["FETCH_SIZE"] * 1024 / 1e6  # (KiB, tallied at half the line size on gfx950: doubled)
+    res["algorithmic_MB_per_dispatch"] = 8 * 99 * 20440 * 8 / 1e6
+    json.dump(res, open("%s/%s_hess_order%d.json" % (dst, tag, order), "w"), indent=1)
+    print(order, json.dumps(res["kernels"]))
 PY

@@ -79,3 +79,55 @@ def test_multi_seed_launch_is_graph_capturable_while_the_per_array_choice_is_ope
             stream.synchronize()
         assert c.get_option("last_v4_tune_choice") in (0, 1) and torch.equal(vd, ref[1])
     ms.close()
+
+
+@pytest.mark.parametrize("order", [6, 8, 10])
+def test_hessian_r_chain_in_front_gives_the_same_bits(order):
+    """Round 6: launches of several trajectories form R_{q-2} .. R_1 of every state column ONCE per 14 columns -- in R-chain waves at the head of the same
+    launch (`hess_rpre` 1: lane = (half, column), tiles through memory, a self-resetting counter per interval) or in a launch of their own in front (2:
+    measured slower) -- instead of inside each of the interval's seven column-group waves at 8 of 64 lanes (0).  Same arithmetic per column: bitwise the
+    same values, `auto` takes the chain waves from more than n_cu / 2 intervals on, and the oracle agrees at 1e-11."""
+    import torch
+
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    Bn, N = 3, 60
+    Zs = [po.synthetic_trajectory(so, N, seed=400 + i)[0] for i in range(Bn)]
+    lay = po.synthetic_trajectory(so, N, seed=400)[1]
+    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn, pade_order=order)
+    c = ms.ctx
+    Zd = torch.from_numpy(np.stack(Zs)).cuda()
+    mu = np.random.default_rng(12).standard_normal((Bn, lay.K, lay.x_dim))
+    mud = torch.from_numpy(mu.reshape(-1)).cuda()
+    hv = torch.empty(c.hess_nnz, dtype=torch.float64, device="cuda")
+    out = {}
+    for mode in (0, 1, 2, -1, 1, 1):  # (twice more with the chain waves: their counters reset themselves)
+        c.set_option("hess_rpre", mode)
+        hv.fill_(float("nan"))
+        torch.cuda.synchronize()  # (the context launches on a stream of its own: the fill must have finished)
+        c.hess_dev(Zd, mud, hv)
+        c.sync()
+        assert c.get_option("last_hess_kernel") == 80 + order // 2
+        assert c.get_option("last_hess_rpre") == ((1 if order >= 8 else 0) if mode < 0 else mode)  # (auto: 177 intervals > n_cu / 2 -> chain waves in the same launch at orders 8, 10)
+        if mode in out:
+            assert torch.equal(out[mode], hv), (mode, int((out[mode] != hv).sum()))  # (repeatable bits in every mode)
+        out[mode] = hv.clone()
+    # the chain waves (1, 2) add a step's Y term behind the partner's half of the product, the column-group waves' own chain (0) before it:
+    # the output vectors do not depend on R (bitwise), the (u,u) entries agree to rounding
+    nsc = (lay.m + 1) * (lay.m + 2) // 2
+    assert torch.equal(out[1], out[2]) and torch.equal(out[1 if order >= 8 else 0], out[-1])  # (2: the same chain wave as a launch of its own)
+    a0, a1 = out[0].view(Bn * lay.K, -1), out[1].view(Bn * lay.K, -1)
+    assert torch.equal(a0[:, nsc:], a1[:, nsc:])
+    assert float((a0[:, :nsc] - a1[:, :nsc]).abs().max()) <= 1e-13 * max(1.0, float(a0[:, :nsc].abs().max()))
+    per = c.hess_nnz // Bn
+    ref = po.pade_hessian_values(Zs[1], mu[1], lay, G0, Gj, order).reshape(-1)
+    got = out[1][per : 2 * per].cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    # one trajectory: the chain stays inside the waves
+    ms1 = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), 1, pade_order=order)
+    h1 = torch.empty(ms1.ctx.hess_nnz, dtype=torch.float64, device="cuda")
+    ms1.ctx.hess_dev(Zd[:1].contiguous(), mud[: lay.K * lay.x_dim].contiguous(), h1)
+    ms1.ctx.sync()
+    assert ms1.ctx.get_option("last_hess_rpre") == 0 and torch.equal(h1, out[0][:per])
+    ms1.close()
+    ms.close()
