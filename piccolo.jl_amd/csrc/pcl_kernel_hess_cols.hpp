@@ -338,6 +338,8 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
                 if (got >= 1u) break;
                 __builtin_amdgcn_s_sleep(8);
             }
+            // (a wait that gave up: the output is poisoned below AND the context's error word is set -- the next call that looks at it returns PCL_EINTERNAL)
+            if (got < 1u && ln_ == 0 && p.err) __hip_atomic_fetch_or(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             const double *rg = rpre + ((long long)item * HC_NR * d + c0) * n;
 #pragma unroll
             for (int a = 0; a < HC_NR; ++a)
