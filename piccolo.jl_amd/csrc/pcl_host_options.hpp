@@ -169,9 +169,9 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
     else if (!strcmp(key, "last_v4_tune_choice"))  // of the array the last multi-trajectory launch wrote: -1 still sampling | 0 static split | 1 slice tickets
         *v = ctx->last_v4_tune_choice;
     else if (!strcmp(key, "last_v4_tune_static_ns"))  // best timed launch of each variant on the last decided array
-        *v = ctx->last_v4_tune_static_us;
+        *v = ctx->last_v4_tune_static_ns;
     else if (!strcmp(key, "last_v4_tune_ticket_ns"))
-        *v = ctx->last_v4_tune_ticket_us;
+        *v = ctx->last_v4_tune_ticket_ns;
     else if (!strcmp(key, "host_store_bytes"))  // the width the last host expansion used
         *v = ctx->last_host_store_bytes;
     else if (!strcmp(key, "cgroup_quota_cpus_x100"))  // 100 x the CPUs the cgroup grants the process (cpu.max); 0: no quota

@@ -116,7 +116,7 @@ struct pcl_ctx {
         unsigned long long stamp = 0;
     } v4_tune[4];
     unsigned long long v4_tune_clock = 0;
-    int64_t last_v4_tune_choice = -1, last_v4_tune_static_us = 0, last_v4_tune_ticket_us = 0;
+    int64_t last_v4_tune_choice = -1, last_v4_tune_static_ns = 0, last_v4_tune_ticket_ns = 0;
     hipFunction_t v4_f = nullptr, v4_feval = nullptr, v4_fevalc = nullptr /* cooperative residual kernel (optional) */, v4_fhess = nullptr, v4_fhess2 = nullptr /* two workgroups per interval */;
     hipFunction_t v4_fhessc = nullptr;  // general-order Hessian, one wave per group of state columns (pcl_kernel_hess_cols.hpp)
     double *dhcx = nullptr;             // ... the waves' rows of reduced sums and the intervals' arrival counters (self-resetting)
@@ -1166,7 +1166,7 @@ static int launch_fused_v4(pcl_ctx *ctx, KParams &p, bool compact, bool want_mer
             (void)hipGetLastError();  // (hipErrorNotReady of a query is not an error of this call)
             if (T->done[0] >= 3 && T->done[1] >= 3) {
                 T->choice = (T->best[0] * 1.02f < T->best[1]) ? 0 : 1;
-                ctx->last_v4_tune_static_us = (int64_t)(T->best[0] * 1e6f), ctx->last_v4_tune_ticket_us = (int64_t)(T->best[1] * 1e6f);  // (ns)
+                ctx->last_v4_tune_static_ns = (int64_t)(T->best[0] * 1e6f), ctx->last_v4_tune_ticket_ns = (int64_t)(T->best[1] * 1e6f);  // (ns)
             } else if (T->calls >= 40)
                 T->choice = 1;  // (timings that never come back: tickets)
         }

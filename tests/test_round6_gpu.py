@@ -131,3 +131,58 @@ def test_hessian_r_chain_in_front_gives_the_same_bits(order):
     assert ms1.ctx.get_option("last_hess_rpre") == 0 and torch.equal(h1, out[0][:per])
     ms1.close()
     ms.close()
+
+
+@pytest.mark.parametrize("order", [8, 10])
+def test_r_chain_waves_on_other_shapes(order):
+    """The R-chain waves (`hess_rpre` 1) where `auto` would not take them, against the in-wave chain and the oracle: an ensemble with PER-MEMBER drifts (the chain
+    wave reads its member's drift table), a member window on it, a two-transmon system (d = 9, m = 4: six columns per column-group wave, two waves per interval),
+    and launches of a single interval."""
+    import torch
+    from test_parity_gpu import _config4_share
+
+    nsc = lambda lay: (lay.m + 1) * (lay.m + 2) // 2
+
+    def both(c, run):
+        outs = []
+        for mode in (0, 1):
+            c.set_option("hess_rpre", mode)
+            outs.append(run())
+            assert c.get_option("last_hess_kernel") == 80 + order // 2 and c.get_option("last_hess_rpre") == mode
+        return outs
+
+    def same(h0, h1, lay, n_items):
+        a0, a1 = h0.reshape(n_items, -1), h1.reshape(n_items, -1)
+        assert np.array_equal(a0[:, nsc(lay):], a1[:, nsc(lay):])  # the output vectors do not depend on R
+        assert np.abs(a0[:, : nsc(lay)] - a1[:, : nsc(lay)]).max() <= 1e-13 * max(1.0, np.abs(a0[:, : nsc(lay)]).max())
+
+    # ensemble, per-member drifts
+    osys, psys, layE, ZE, trajE = _config4_share(3, 5)
+    BE = pa.HipPadeIntegrator(np.array([s.G_drift for s in psys]), psys[0].G_drives_array(), trajE, ["Ũ⃗1", "Ũ⃗2", "Ũ⃗3"], pade_order=order)
+    BE.ctx.set_option("hess_kernel", 8)
+    muE = np.random.default_rng(16).standard_normal((3, layE.K, layE.x_dim))
+    h0, h1 = both(BE.ctx, lambda: BE.ctx.hess(trajE.datavec, muE.reshape(-1)))
+    same(h0, h1, layE, 3 * layE.K)
+    per = po.hess_nnz_per_interval(layE) * layE.K
+    for i, s in enumerate(osys):
+        ref = po.pade_hessian_values(ZE, muE[i], layE, s.G_drift, np.array(s.G_drives), order, x_off=i * layE.x_dim).reshape(-1)
+        assert np.abs(h1[i * per : (i + 1) * per] - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    BE.ctx.set_member_window(2, 1)
+    w0, w1 = both(BE.ctx, lambda: BE.ctx.hess(trajE.datavec, muE[2].reshape(-1)))
+    assert np.array_equal(w1, h1[2 * per : 3 * per]) and np.array_equal(w0, h0[2 * per : 3 * per])
+    BE.ctx.set_member_window(0, 3)
+    BE.close()
+    # two transmons, three levels each: d = 9, m = 4
+    s2 = po.multi_transmon_system([4.0, 4.1], [0.2, 0.21], [[0, 0.02], [0.02, 0]], levels_per_transmon=3, drive_bounds=0.1)
+    for N in (2, 9):
+        Z, lay = po.synthetic_trajectory(s2, N, seed=21)
+        Z[:, lay.dt_off] = 0.1 + 0.1 * np.random.default_rng(4).random(N)
+        mu = np.random.default_rng(5).standard_normal((lay.K, lay.x_dim))
+        G0, Gj = s2.G_drift, np.array(s2.G_drives)
+        ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Z, lay), 1, pade_order=order)
+        ms.ctx.set_option("hess_kernel", 8)
+        g0, g1 = both(ms.ctx, lambda: ms.ctx.hess(Z[None].copy(), mu.reshape(-1)))
+        same(g0, g1, lay, lay.K)
+        ref = po.pade_hessian_values(Z, mu, lay, G0, Gj, order).reshape(-1)
+        assert np.abs(g1 - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+        ms.close()
