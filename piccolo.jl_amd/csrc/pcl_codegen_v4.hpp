@@ -259,7 +259,7 @@ static inline int v4_parts(const V4Plan &P, int q) {
 // accumulator chain per output row group only half as deep (kV4Group rows -> plain v_mul of every term: no dependent chains)
 static inline std::string v4_functions(const V4Plan &P, int q, int np, int variant_ = 0, bool with_hessian = false) {
     const int variant = variant_ & 7;            // (of the product)
-    const int gdot_cols = (variant_ & 16) ? 14 : (variant_ & 8) ? 7 : 32;  // columns of z per batch of the all-drive gather-dot: the whole half (nine at a time
+    const int gdot_cols = (variant_ & 8) ? 7 : 32;  // columns of z per batch of the all-drive gather-dot: the whole half (nine at a time
                                                     // measured 7 % slower on the Hessian kernel: 199.9 vs 184.8 us per 8 trajectories, order 8)
     using detail::v4_chunk_reg;
     const int d = P.d, G = kV4Group;

@@ -377,10 +377,7 @@ std::string v4_hess_source(const pcl_codegen::V4Plan &plan, int q, int variant =
 }
 // ... one wave per group of state columns (pcl_kernel_hess_cols.hpp; any order)
 std::string v4_hess_cols_source(const pcl_codegen::V4Plan &plan, int q, int variant = 0) {
-    // columns of R per batch of the gather-dot: 7 (default) | 14 | 32 = the whole half (environment PCL_HC_GDOT_COLS: experiments, part of the source and so of the cache key)
-    const char *e = getenv("PCL_HC_GDOT_COLS");
-    const int gd = e ? atoi(e) : 7, gbits = gd >= 27 ? 0 : gd >= 14 ? 16 : 8;
-    return std::string(kHessJitOpt) + "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q, 1, (variant & 7) | gbits, true) + "#include \"pcl_kernel_hess_cols.hpp\"\n";
+    return std::string(kHessJitOpt) + "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q, 1, (variant & 7) | 8, true) + "#include \"pcl_kernel_hess_cols.hpp\"\n";
 }
 static size_t hess_cols_lds_bytes(int d, int m, int q, int gt_total) {  // HC_LDS_DOUBLES of the kernel
     const int cpw = 32 / (m + 1);
