@@ -186,3 +186,60 @@ def test_r_chain_waves_on_other_shapes(order):
         ref = po.pade_hessian_values(Z, mu, lay, G0, Gj, order).reshape(-1)
         assert np.abs(g1 - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
         ms.close()
+
+
+def test_default_order_hessian_at_full_size_is_linear_in_the_multipliers():
+    """BASELINE config 5's per-GPU share at the order the default constructor picks (order 10; 8 seeds x 99 intervals in one launch, R-chain waves): size-independent
+    properties of the Hessian of the Lagrangian where the oracle is too slow to follow -- exact scaling by powers of two in the multipliers (every operation on the way is
+    linear in mu, and a factor 2 or 1/4 commutes with every rounding), linearity H(mu1 + mu2) = H(mu1) + H(mu2) to rounding, no dependence of a seed's values on its
+    neighbours in the launch (seed 3 alone, with the in-wave chain, agrees to rounding in the (u,u) entries and bitwise elsewhere), and two intervals against the oracle."""
+    import torch
+
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    Bn, N, order = 8, 100, 10
+    Zs = [po.synthetic_trajectory(so, N, seed=1000 + i)[0] for i in range(Bn)]
+    lay = po.synthetic_trajectory(so, N, seed=1000)[1]
+    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), Bn, pade_order=order)
+    c = ms.ctx
+    stream = torch.cuda.current_stream()
+    c.set_stream(stream.cuda_stream)
+    Zd = torch.from_numpy(np.stack(Zs)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    mu1 = torch.randn(c.n_rows, dtype=torch.float64, device="cuda", generator=g)
+    mu2 = torch.randn(c.n_rows, dtype=torch.float64, device="cuda", generator=g)
+
+    def H(mu):
+        out = torch.empty(c.hess_nnz, dtype=torch.float64, device="cuda")
+        c.hess_dev(Zd, mu.contiguous(), out)
+        torch.cuda.synchronize()
+        return out
+
+    h1, h2 = H(mu1), H(mu2)
+    assert c.get_option("last_hess_kernel") == 85 and c.get_option("last_hess_rpre") == 1
+    assert torch.isfinite(h1).all() and float(h1.abs().max()) > 0
+    assert torch.equal(H(2.0 * mu1), 2.0 * h1) and torch.equal(H(0.25 * mu1), 0.25 * h1)
+    h12 = H(mu1 + mu2)
+    scale = float(torch.maximum(h1.abs(), h2.abs()).max())
+    assert float((h12 - (h1 + h2)).abs().max()) <= 1e-12 * scale
+    # seed 3 alone (one trajectory per launch: the chain inside the waves)
+    per = c.hess_nnz // Bn
+    rows = c.n_rows // Bn
+    ms1 = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[3], lay), 1, pade_order=order)
+    ms1.ctx.set_stream(stream.cuda_stream)
+    s3 = torch.empty(per, dtype=torch.float64, device="cuda")
+    ms1.ctx.hess_dev(Zd[3:4].contiguous(), mu1[3 * rows : 4 * rows].contiguous(), s3)
+    torch.cuda.synchronize()
+    assert ms1.ctx.get_option("last_hess_rpre") == 0
+    nsc = (lay.m + 1) * (lay.m + 2) // 2
+    a, b = h1[3 * per : 4 * per].view(lay.K, -1), s3.view(lay.K, -1)
+    assert torch.equal(a[:, nsc:], b[:, nsc:]) and float((a[:, :nsc] - b[:, :nsc]).abs().max()) <= 1e-13 * max(1.0, float(a[:, :nsc].abs().max()))
+    ms1.close()
+    # two intervals of seed 5 against the oracle (a 3-knot cut of the trajectory: intervals 40, 41)
+    Zc = Zs[5][40:43].copy()
+    layc = po.Layout.smooth_pulse(lay.d, lay.m, 3)
+    muc = mu1[5 * rows : 6 * rows].view(lay.K, -1)[40:42].cpu().numpy()
+    ref = po.pade_hessian_values(Zc, muc, layc, G0, Gj, order)
+    got = h1[5 * per : 6 * per].view(lay.K, -1)[40:42].cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    ms.close()
