@@ -243,3 +243,40 @@ def test_default_order_hessian_at_full_size_is_linear_in_the_multipliers():
     got = h1[5 * per : 6 * per].view(lay.K, -1)[40:42].cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
     ms.close()
+
+
+@pytest.mark.parametrize("order", [8, 10])
+def test_config3_full_size_at_the_orders_that_match_the_exp_constraint(order):
+    """BASELINE config 3 at its real size (d = 27, N = 100) at the orders the policy picks (10 on config 3's bounds, 8 at the synthetic trajectories' scale) against the
+    numpy oracle's general-order formulas: the residual, ALL 16,599,330 Jacobian values, the Hessian of the Lagrangian of one trajectory (the chain inside the waves) and
+    of the same trajectory as seed 2 of a 4-seed launch (R-chain waves) -- the C oracle is order 4 only, so until round 6 these orders were checked at N = 4."""
+    import torch
+
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    N = 100
+    Zs = [po.synthetic_trajectory(so, N, seed=1000 + i)[0] for i in range(4)]
+    lay = po.synthetic_trajectory(so, N, seed=1000)[1]
+    Z = Zs[2]
+    d_ref = po.pade_residual(Z, lay, G0, Gj, order).reshape(-1)
+    j_ref = po.pade_jacobian_values(Z, lay, G0, Gj, order).reshape(-1)
+    mu = np.random.default_rng(31).standard_normal((lay.K, lay.x_dim))
+    h_ref = po.pade_hessian_values(Z, mu, lay, G0, Gj, order).reshape(-1)
+    tol = lambda got, ref, t: np.abs(got - ref).max() <= t * max(1.0, np.abs(ref).max())
+    ms1 = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Z, lay), 1, pade_order=order)
+    c = ms1.ctx
+    assert c.jac_nnz == 16599330
+    delta, vals = c.eval_jac(Z[None].copy())
+    assert c.get_option("last_kernel") == 40 + order // 2
+    assert tol(delta, d_ref, 1e-12) and tol(vals, j_ref, 1e-12)
+    h = c.hess(Z[None].copy(), mu.reshape(-1))
+    assert c.get_option("last_hess_kernel") == 80 + order // 2 and c.get_option("last_hess_rpre") == 0 and tol(h, h_ref, 1e-11)
+    ms1.close()
+    ms4 = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Zs[0], lay), 4, pade_order=order)
+    mu4 = np.random.default_rng(32).standard_normal((4, lay.K, lay.x_dim))
+    mu4[2] = mu
+    h4 = ms4.ctx.hess(np.stack(Zs), mu4.reshape(-1)).reshape(4, -1)
+    assert ms4.ctx.get_option("last_hess_rpre") == 1 and tol(h4[2], h_ref, 1e-11)
+    d4, v4 = ms4.ctx.eval_jac(np.stack(Zs))
+    assert np.array_equal(v4.reshape(4, -1)[2], vals) and np.array_equal(d4.reshape(4, -1)[2], delta)  # (a seed's values do not depend on the launch it is in)
+    ms4.close()
