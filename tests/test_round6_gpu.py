@@ -280,3 +280,40 @@ def test_config3_full_size_at_the_orders_that_match_the_exp_constraint(order):
     d4, v4 = ms4.ctx.eval_jac(np.stack(Zs))
     assert np.array_equal(v4.reshape(4, -1)[2], vals) and np.array_equal(d4.reshape(4, -1)[2], delta)  # (a seed's values do not depend on the launch it is in)
     ms4.close()
+
+
+def test_config4_share_at_the_default_order():
+    """BASELINE config 4's per-GPU share (8 perturbed-drift members in ONE trajectory buffer, shared controls, N = 100) at order 10 -- the order the default
+    constructor picks on config 3 / 4 / 5's bounds: residual + Jacobian of two sampled members and the Hessian of the Lagrangian of one (member window; the launch of
+    all eight: R-chain waves reading their member's drift table) against the numpy oracle with the member's own drift."""
+    from piccolo_jl_amd import synthetic
+
+    M, N, order = 8, 100, 10
+    members = synthetic.config4_members(0, M)
+    traj = synthetic.synthetic_ensemble(members, N, seed=20260929 + 4)
+    d, m = members[0].levels, members[0].n_drives
+    xd = 2 * d * d
+    names = ["Ũ⃗%d" % (i + 1) for i in range(M)]
+    Gj = members[0].G_drives_array()
+    B = pa.HipPadeIntegrator(np.array([s.G_drift for s in members]), Gj, traj, names, pade_order=order)
+    c = B.ctx
+    delta, vals = c.eval_jac(traj.datavec)
+    assert c.get_option("last_kernel") == 45
+    per_v, per_d = c.jac_nnz // M, c.n_rows // M
+    Z2 = traj.datavec.reshape(N, traj.dim)
+    lay = po.Layout(d=d, m=m, N=N, z_dim=traj.dim, x_off=0, u_off=traj.components["u"].start, dt_off=traj.components["Δt"].start)
+    tol = lambda got, ref, t: np.abs(got - ref).max() <= t * max(1.0, np.abs(ref).max())
+    for i in (1, 6):
+        d_ref = po.pade_residual(Z2, lay, members[i].G_drift, np.array(Gj), order, x_off=i * xd).reshape(-1)
+        j_ref = po.pade_jacobian_values(Z2, lay, members[i].G_drift, np.array(Gj), order, x_off=i * xd).reshape(-1)
+        assert tol(delta[i * per_d : (i + 1) * per_d], d_ref, 1e-12) and tol(vals[i * per_v : (i + 1) * per_v], j_ref, 1e-12)
+    mu = np.random.default_rng(41).standard_normal((M, lay.K, lay.x_dim))
+    h = c.hess(traj.datavec, mu.reshape(-1)).reshape(M, -1)
+    assert c.get_option("last_hess_kernel") == 85 and c.get_option("last_hess_rpre") == 1
+    h_ref = po.pade_hessian_values(Z2, mu[6], lay, members[6].G_drift, np.array(Gj), order, x_off=6 * xd).reshape(-1)
+    assert tol(h[6], h_ref, 1e-11)
+    c.set_member_window(6, 1)
+    hw = c.hess(traj.datavec, mu[6].reshape(-1))
+    assert c.get_option("last_hess_rpre") == 0 and tol(hw, h_ref, 1e-11)
+    c.set_member_window(0, M)
+    B.close()
