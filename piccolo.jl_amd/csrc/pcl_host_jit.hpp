@@ -282,8 +282,8 @@ hipFunction_t jit_compile(int device, const std::string &key_, const std::string
     dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
     const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp",
                            "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp", "pcl_kernel_eval_sparse.hpp",
-                           "pcl_kernel_fused_sparse.hpp", "pcl_kernel_hess_sparse4.hpp", "pcl_kernel_hess_cols.hpp"};
-    constexpr int NH = 10;
+                           "pcl_kernel_fused_sparse.hpp", "pcl_kernel_hess_sparse4.hpp", "pcl_kernel_hess_cols.hpp", "pcl_kernel_hess_cols_parts.hpp"};
+    constexpr int NH = 11;
     std::string hdr[NH];
     const char *hdrp[NH];
     for (int i = 0; i < NH; ++i) {
@@ -398,8 +398,8 @@ static int prebuild_source(const std::string &source, const char *name_expr, con
     dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
     const char *names[] = {"pcl_device_common.hpp", "pcl_kernels_fused_v2.hpp", "pcl_kernel_fused_v3.hpp", "pcl_kernels_hessian.hpp",
                            "pcl_kernel_hessian_v3.hpp", "pcl_kernel_hessian_sparse.hpp", "pcl_kernel_eval_sparse.hpp",
-                           "pcl_kernel_fused_sparse.hpp", "pcl_kernel_hess_sparse4.hpp", "pcl_kernel_hess_cols.hpp"};
-    constexpr int NH = 10;
+                           "pcl_kernel_fused_sparse.hpp", "pcl_kernel_hess_sparse4.hpp", "pcl_kernel_hess_cols.hpp", "pcl_kernel_hess_cols_parts.hpp"};
+    constexpr int NH = 11;
     std::string hdr[NH];
     const char *hdrp[NH];
     for (int i = 0; i < NH; ++i) {

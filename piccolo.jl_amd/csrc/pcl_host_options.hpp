@@ -84,6 +84,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
         ctx->opt_hess_xcd = v < 0 ? -1 : v;
     else if (!strcmp(key, "hess_rpre"))  // column-group Hessian kernel: the chain of the R_a in a launch of its own in front (-1 auto | 0 | 1)
         ctx->opt_hess_rpre = v < 0 ? -1 : (v > 2 ? 2 : v);
+    else if (!strcmp(key, "hess_pair"))  // column-group Hessian kernel: a chain wave and a contribution wave per column group (-1 auto: launches of at most n_cu / 2 intervals | 0 | 1)
+        ctx->opt_hess_pair = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "hess_split"))  // general-order pattern-compiled Hessian kernel: two workgroups per interval (-1 auto by launch size | 0 | 1)
         ctx->opt_hess_split = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "eval_coop"))  // pattern-compiled residual kernel: four waves per interval (-1 auto by launch size | 0 | 1)
@@ -158,6 +160,10 @@ extern "C" int pcl_get_option(const pcl_ctx *ctx, const char *key, int64_t *v) {
         *v = ctx->opt_hess_rpre;
     else if (!strcmp(key, "last_hess_rpre"))
         *v = ctx->last_hess_rpre;
+    else if (!strcmp(key, "hess_pair"))
+        *v = ctx->opt_hess_pair;
+    else if (!strcmp(key, "last_hess_pair"))
+        *v = ctx->last_hess_pair;
 #ifdef PCL_LAB
     else if (!strcmp(key, "resident_idle_us"))
         *v = ctx->opt_resident_idle_us;

@@ -361,30 +361,9 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     // ---- R_a = sum_b (+-T_{a+b+1}) G^b |Y_{a+b+1}|, the operands of the (u,u) sums, as ONE chain per state column from the top:
     //      R_{q-1} = +-T_q |Y_q| (stored with the inputs),  R_a = +-T_{a+1} |Y_{a+1}| + G R_{a+1}   (q - 2 products; lanes (half, column)) -----
     if (q > 2 && !rpre) {
-        HC_MARK("rsetup");
-        const bool ract = s < HC_CPW && s < nce;  // (slot = column)
-        const int rb = (s < HC_CPW ? s : 0) * SP4CS;
-#pragma unroll 1
-        for (int a = q - 2; a >= 1; --a) {
-            HC_MARK("rchain");
-            if (ract) {
-                double x[SPD];  // R_{a+1}
-                if (a == q - 2) {  // R_{q-1} = +-T_q |Y_q|
-                    const double *src = ((q & 1) ? St : Dt) + rb + own;
-                    const double wq = wgt(q);
-#pragma unroll
-                    for (int i = 0; i < SPD; ++i) x[i] = wq * src[i];
-                } else {
-                    const double *src = Rt + a * CB + rb + own;
-#pragma unroll
-                    for (int i = 0; i < SPD; ++i) x[i] = src[i];
-                }
-                double *dst = Rt + (a - 1) * CB + rb;
-                const double *Y = (((a + 1) & 1) ? St : Dt) + rb + own;
-                sp4_product(x, hc_lds_off(Y), hc_lds_off(dst + own), hc_lds_off(dst + oth), sp4_uniform(wgt_at(a + 1)), 1.0, half ? -1.0 : 1.0, tab, cf);
-            }
-            HC_STAMP();
-        }
+#define HC_PART_RCHAIN
+#include "pcl_kernel_hess_cols_parts.hpp"
+#undef HC_PART_RCHAIN
     }
     HC_STAMP();
     // ---- the chains, pass by pass.  In pass jp the V lanes are at level jp and the W lanes ONE LEVEL BEHIND, at jp - 1:
@@ -415,22 +394,9 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     // scratch across the product, the gather and the contributions -- 7 stores + 7 loads per pass, and 27 MB of scratch write-back per 8-seed launch.)
     // (HC_CPW = 4 -- six drives, every transmon system of the reference: the column lanes of a chain are a DPP quad.  Other drive counts keep the
     //  1 + m sums per lane and add them over the columns once, at the end.)
-    constexpr bool HC_GROUPSUM = HC_CPW == 4 && HC_ROW <= 2 * HC_CPW;
-    constexpr int HC_NACC = HC_GROUPSUM ? (HC_ROW + HC_CPW - 1) / HC_CPW : HC_ROW;
-    double s_acc[HC_NACC];
-#pragma unroll
-    for (int i = 0; i < HC_NACC; ++i) s_acc[i] = 0.0;
-    auto group_sum = [&](double v) {  // sum over the HC_CPW column lanes of this lane's (half, chain), the same in each of them
-        if constexpr (HC_CPW >= 2) {
-            const int lo = __double2loint(v), hi = __double2hiint(v);
-            v += __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xB1, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
-        }
-        if constexpr (HC_CPW >= 4) {
-            const int lo = __double2loint(v), hi = __double2hiint(v);
-            v += __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
-        }
-        return v;
-    };
+#define HC_PART_GROUPSUM
+#include "pcl_kernel_hess_cols_parts.hpp"
+#undef HC_PART_GROUPSUM
     double hpV = 1.0, hpW = 1.0, hpW2 = 1.0;  // h^(level - 1) of the V lanes' and of the W lanes' level; h^(level - 2) of the W lanes'
     // (the body of a pass, compiled twice: for odd and for even passes -- which of the two accumulators a pass adds to is then a matter of the code, not of
     //  a branch; with a branch inside ONE body the compiler copied the 27 accumulators aside and back around it)
@@ -448,122 +414,20 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         }
         HC_STAMP();
         HC_MARK("pass_gather");
-        if (on && isV) {  // + G_l^T W_{jp-1}
-#if HC_SWITCH_GATHER
-            SP4_GATHER_T_SWITCH(ch - 1, Wc + own, Wc + oth, Xs + own, 1.0, (half ? -1.0 : 1.0), mg)
-#pragma unroll
-            for (int i = 0; i < SPD; ++i) x[i] += Xs[own + i];
-#else
-            // the lanes of a wave belong to different drives: the entries come from the table (one instruction stream for every drive).
-            // HC_GCH rows at a time, staged by hand -- every entry of the batch, then every operand, then the sums: left to itself the
-            // compiler keeps two or three rows in flight and the wave waits out an LDS round trip per row (6.3 k cycles per level)
-            const unsigned *gt = gtab + ((ch - 1) * 2 + half) * HC_GT_WPC;
-            // (the module has no static LDS: the wave's dynamic LDS starts at offset 0 -- checked once at the top of the kernel -- so the coefficient
-            //  table's offset is a constant of the layout)
-            const unsigned wcol_off = (unsigned)col * (HC_WS * 8u);
-            constexpr unsigned cft_off = (HC_CFT_IN_TAIL ? SPN : HC_CPW * HC_WS + (HC_NSLOT - HC_CPW + (2 + HC_NR) * HC_CPW) * SP4CS) * 8u;
-#pragma unroll
-            for (int i0 = 0; i0 < SPD; i0 += HC_GCH) {
-                unsigned e_[HC_GCH][SP4_GTK];
-#pragma unroll
-                for (int i = 0; i < HC_GCH; ++i)
-#pragma unroll
-                    for (int kk = 0; kk < SP4_GTK; ++kk) {
-                        const int row = i0 + i < SPD ? i0 + i : SPD - 1;
-                        const int en = sp4_gt_off(row) + (kk < sp4_gt_cnt(row) ? kk : 0);  // entry number: word en / 3, bits 10 (en % 3) ...
-                        e_[i][kk] = kk < sp4_gt_cnt(row) ? gt[en / 3] : 0u;                 // (the dword; the fields come out of it with one v_bfe_u32 each)
-                    }
-                double w_[HC_GCH][SP4_GTK], c_[HC_GCH][SP4_GTK];
-#pragma unroll
-                for (int i = 0; i < HC_GCH; ++i)
-#pragma unroll
-                    for (int kk = 0; kk < SP4_GTK; ++kk)
-                        if (kk < sp4_gt_cnt(i0 + i < SPD ? i0 + i : SPD - 1)) {  // (a row takes as many terms as the drive with the most there)
-                            const int row = i0 + i < SPD ? i0 + i : SPD - 1;
-                            const unsigned sh = 10u * (unsigned)((sp4_gt_off(row) + kk) % 3);
-                            // (addresses as integers: the W column's base has no bit below 512, the tables' bases are constants of the layout)
-                            unsigned aw;  // the W row's address: (bits sh + 4 .. sh + 9) << 3 + the column's
-                            asm("v_bfe_u32 %0, %1, %2, 6\n\tv_lshl_add_u32 %0, %0, 3, %3" : "=&v"(aw) : "v"(e_[i][kk]), "n"(sh + 4u), "v"(wcol_off));
-                            const unsigned fc = sh >= 3u ? (e_[i][kk] >> (sh - 3u)) & 0x78u : (e_[i][kk] << (3u - sh)) & 0x78u;  // coefficient index << 3
-                            w_[i][kk] = *(const __attribute__((address_space(3))) double *)(size_t)aw;
-                            c_[i][kk] = *(const __attribute__((address_space(3))) double *)(size_t)(fc + cft_off);
-                        }
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int i = 0; i < HC_GCH; ++i)
-                    if (i0 + i < SPD) {
-#pragma unroll
-                        for (int kk = 0; kk < SP4_GTK; ++kk)
-                            if (kk < sp4_gt_cnt(i0 + i)) x[i0 + i] = __builtin_fma(c_[i][kk], w_[i][kk], x[i0 + i]);
-                    }
-            }
-#endif
-        }
+        // (the module has no static LDS: the wave's dynamic LDS starts at offset 0 -- checked once at the top of the kernel -- so the coefficient
+        //  table's offset is a constant of the layout)
+        const unsigned wcol_off = (unsigned)col * (HC_WS * 8u);
+        constexpr unsigned cft_off = (HC_CFT_IN_TAIL ? SPN : HC_CPW * HC_WS + (HC_NSLOT - HC_CPW + (2 + HC_NR) * HC_CPW) * SP4CS) * 8u;
+#define HC_PART_GATHER
+#include "pcl_kernel_hess_cols_parts.hpp"
+#undef HC_PART_GATHER
         asm volatile("" ::: "memory");
         HC_STAMP();
         // ---- what the lane's level contributes ----
         HC_MARK("pass_contrib");
-        const int jl = isV ? jp : jp - 1;
-        const double cj = isV ? p.pc[jp <= q ? jp : q] : p.pc[jp - 1], hp = isV ? hpV : hpW;
-        const double Tj = cj * hp * h, T1 = jl * cj * hp, sg = (jl & 1) ? -1.0 : 1.0;
-        double cv[HC_ROW];
-#pragma unroll
-        for (int v = 0; v < HC_ROW; ++v) cv[v] = 0.0;
-        if (on) {
-            const double wK = isV ? Tj : T1;  // the weight of this level in the lane's output vectors
-            if constexpr (odd_pass) {
-#pragma unroll
-                for (int i = 0; i < SPD; ++i) accB[i] = __builtin_fma(wK, x[i], accB[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < SPD; ++i) accA[i] = __builtin_fma(wK, x[i], accA[i]);
-            }
-            asm volatile("" ::: "memory");
-            const double *Yj = ((jl & 1) ? St : Dt) + cb + own;  // Y_j = D (j even) | -S (j odd)
-            double dot0 = 0.0, dot1 = 0.0;
-#pragma unroll
-            for (int i0 = 0; i0 < SPD; i0 += 9) {  // (nine rows at a time: the whole column next to x and the output vectors spills the scalar sums)
-                double y[9];
-#pragma unroll
-                for (int i = 0; i < 9; ++i)
-                    if (i0 + i < SPD) y[i] = Yj[i0 + i];
-#pragma unroll
-                for (int i = 0; i < 9; ++i)
-                    if (i0 + i < SPD) {
-                        if (i & 1)
-                            dot1 = __builtin_fma(x[i0 + i], y[i], dot1);
-                        else
-                            dot0 = __builtin_fma(x[i0 + i], y[i], dot0);
-                    }
-                asm volatile("" ::: "memory");
-            }
-            const double dy = sg * (dot0 + dot1);  // <chain_j, Y_j>
-            cv[0] = !isV ? (jl >= 2 ? jl * (jl - 1) * cj * hpW2 * dy : 0.0)  // T''_j = j (j-1) c_j h^(j-2)
-                         : T1 * dy;
-            if (isV && jp < q) {  // (u,u): <V_{l,j}, G_i R_j>, every drive i
-                // R_jp; the top one is +-T_q |Y_q|: the D or the S tile, the number applied to the sums
-                const double *Rj = (jp == q - 1 ? ((q & 1) ? St : Dt) : Rt + (jp - 1) * CB) + cb;
-                const double wr = jp == q - 1 ? wgt(q) : 1.0;
-                double r6[SPM];
-                sp4_gdot_all(Rj + own, Rj + oth, x, (half ? 1.0 : -1.0), mg, r6);
-#pragma unroll
-                for (int i = 0; i < SPM; ++i) cv[1 + i] = wr * r6[i];
-            }
-        }
-        HC_MARK("pass_sums");
-        // this pass's 1 + m values of the chain, summed over its columns; lane `col` adds the values col, col + HC_CPW, ... to its running totals
-        // (every lane of the wave takes part in the DPP steps: lanes without a level contribute zeros)
-#pragma unroll
-        for (int v = 0; v < HC_ROW; ++v) {
-            if constexpr (HC_GROUPSUM) {
-                const double tot = group_sum(cv[v]);
-                if (col == v % HC_CPW) s_acc[v / HC_CPW] += tot;
-            } else
-                s_acc[v] += cv[v];
-        }
-        hpW2 = hpW;
-        hpW = hpV;
-        hpV *= h;
+#define HC_PART_CONTRIB
+#include "pcl_kernel_hess_cols_parts.hpp"
+#undef HC_PART_CONTRIB
         HC_STAMP();
     };
 #pragma unroll 1
@@ -572,117 +436,9 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         if (jp + 1 <= q + 1) pass_body(jp + 1, hc_bool<false>{});
     }
     HC_MARK("tail");
-    // ---- the reduced sums of the wave: every lane parks its 1 + m sums in its chain slot (rows 0 .. m of its half; slots of columns
-    //      past the end hold zeros); lane e < HC_XS adds the 2 HC_CPW parts of (chain, value) in a fixed order ------------------------------
-    asm volatile("" ::: "memory");
-    if (inr) {  // lane (half, chain, col) parks the totals of the values col, col + HC_CPW, ... in rows 0, 1, ... of its half of its chain slot
-#pragma unroll
-        for (int i = 0; i < HC_NACC; ++i) Xs[own + i] = s_acc[i];
-    }
-    asm volatile("" ::: "memory");
-    unsigned xold = 0xffffffffu;
-    {
-        if (ln_ < HC_XS) {  // lane = (chain, value): the two halves' totals, top first (without the per-pass sums: the 2 HC_CPW parts, column by column)
-            const int chn = ln_ / HC_ROW, val = ln_ - chn * HC_ROW;
-            double r = 0.0;
-            if constexpr (HC_GROUPSUM) {
-                const double *sl_ = chain_col(chn, val % HC_CPW) + val / HC_CPW;
-                r = sl_[0] + sl_[d];
-            } else {
-#pragma unroll
-                for (int cc = 0; cc < HC_CPW; ++cc) {
-                    r += chain_col(chn, cc)[val];
-                    r += chain_col(chn, cc)[d + val];
-                }
-            }
-            hc_store_coherent(xch + ((long long)item * HC_NG + grp) * HC_XS + ln_, r);
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    HC_STAMP();
-    // ---- output vectors: registers -> the lane's chain slot -> memory (lane = element: a chain's HC_CPW columns are contiguous) ----------
-    // (lane = a PAIR of elements: 16-byte stores -- a wave's 8-byte stores are bound by their issue, 100 cycles each)
-    typedef double hc_d2 __attribute__((ext_vector_type(2)));
-    typedef double hc_d2u __attribute__((ext_vector_type(2), aligned(8)));  // (a vector of the output starts on an 8-byte boundary)
-    constexpr int NT2 = (HC_CPW * SPN + 127) / 128;
-    static_assert(SPN % 2 == 0, "pairs of rows");
-    int eo[NT2], eoW[NT2];  // offsets of the lane's pair of elements in a V chain's block of columns | in the W columns
-#pragma unroll
-    for (int t = 0; t < NT2; ++t) {
-        const int e = 2 * ln_ + 128 * t, cc = e / n;
-        eo[t] = e < ne ? cc * SP4CS + (e - cc * n) : -1;
-        eoW[t] = e < ne ? cc * HC_WS + (e - cc * n) : 0;
-    }
-    hc_d2 t_[HC_NCH][NT2];
-    auto pass_lds = [&](int pass) {  // the lane's output vector of the pass -> its chain slot; then every read of the pass (two LDS round trips per pass, not one per chain)
-        if (act) {
-#pragma unroll
-            for (int i = 0; i < SPD; ++i) Xs[own + i] = pass ? (isV ? accA[i] - accB[i] : accB[i] - accA[i]) : -(accA[i] + accB[i]);
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int c2 = 0; c2 < HC_NCH; ++c2)
-#pragma unroll
-            for (int t = 0; t < NT2; ++t) {
-                const double *src = c2 == 0 ? Wreg + eoW[t] : vslots + (c2 - 1) * CB + (eo[t] >= 0 ? eo[t] : 0);
-                t_[c2][t].x = src[0], t_[c2][t].y = src[1];
-            }
-        asm volatile("" ::: "memory");
-    };
-    auto pass_store = [&](int pass) {
-#pragma unroll
-        for (int c2 = 0; c2 < HC_NCH; ++c2) {
-            // chain 0 (W): the h blocks m | 2 m + 1;  chain 1 + l: l | m + 1 + l
-            const int vec = c2 == 0 ? (pass ? 2 * m + 1 : m) : (pass ? m + c2 : c2 - 1);
-            double *o = H + HC_NSC + (long long)vec * xd + (long long)c0 * n + 2 * ln_;
-#pragma unroll
-            for (int t = 0; t < NT2; ++t)
-                if (eo[t] >= 0) *(hc_d2u *)(o + 128 * t) = t_[c2][t];
-        }
-        asm volatile("" ::: "memory");
-    };
-    pass_lds(0);
-    pass_store(0);
-    pass_lds(1);
-    // ---- the wave is counted in BETWEEN the passes: its row of sums left before the first pass's stores and has been acknowledged by now (or
-    //      nearly: waiting for it behind the last store, and then for the counter, cost a wave 8 k cycles at its end, 4 k here); the output
-    //      vectors need no order with the counter -- the wave that arrives last reads rows of sums only ----------------------------------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (ln_ == 0) xold = __hip_atomic_fetch_add(xcnt + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    pass_store(1);
-    HC_STAMP();
-    // ---- the scalar entries of the interval: the wave that arrived last adds the rows of all HC_NG waves in a fixed order ----------------
-    xold = __builtin_amdgcn_readfirstlane(xold);
-    if (xold == HC_NG - 1) {
-        if (ln_ == 0) __hip_atomic_store(xcnt + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch)
-        if (ln_ == 0 && rflag) __hip_atomic_store(rflag + item, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every wave of the interval has taken its tiles)
-        double *tot = vslots;  // [chain][value]
-        if (ln_ < HC_XS) {
-            const double *xall = xch + (long long)item * HC_NG * HC_XS + ln_;
-            double v_[HC_NG], r = 0.0;  // (every row requested, then added in the order of the waves)
-#pragma unroll
-            for (int g = 0; g < HC_NG; ++g) v_[g] = hc_load_coherent(xall + g * HC_XS);
-#pragma unroll
-            for (int g = 0; g < HC_NG; ++g) r += v_[g];
-            tot[ln_] = r;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (ln_ < HC_NSC) {
-            // order: (u_i, u_j) for i = 0..m-1, j = 0..i | (h, u_j) j < m | (h, h);   S[i][j] = tot[(1 + i) HC_ROW + 1 + j]
-            double v;
-            if (ln_ < m * (m + 1) / 2) {
-                int i = 0;
-                while ((i + 1) * (i + 2) / 2 <= ln_) ++i;
-                const int j = ln_ - i * (i + 1) / 2;
-                v = tot[(1 + i) * HC_ROW + 1 + j] + tot[(1 + j) * HC_ROW + 1 + i];
-            } else if (ln_ < m * (m + 1) / 2 + m) {
-                v = tot[(1 + ln_ - m * (m + 1) / 2) * HC_ROW];
-            } else {
-                v = tot[0];
-            }
-            H[ln_] = v;
-        }
-    }
+#define HC_PART_TAIL
+#include "pcl_kernel_hess_cols_parts.hpp"
+#undef HC_PART_TAIL
     HC_STAMP();
 }
 
@@ -692,4 +448,228 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64))) void 
     const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ mags_, const double *__restrict__ dcf_tab, double *__restrict__ rout /* [interval][HC_NR][d][n] */) {
     extern __shared__ double lds[];
     if constexpr (HC_NR > 0) hc_rchain_role(p, drift_tab, mags_, dcf_tab, rout, nullptr, (int)blockIdx.x, lds);
+}
+
+// ---- ONE TRAJECTORY PER LAUNCH: a chain wave and a contribution wave per column group (round 6) ---------------------------------------------------------
+// A launch of at most n_cu / 2 intervals runs every wave at once, one or two per SIMD: its time is the LATENCY of one wave -- q + 1 dependent passes of product,
+// gather and contributions (~10 k cycles each) behind the R chain.  Only product and gather are the chain; what a level contributes to the output vectors
+// and to the scalar entries (accumulation, the Y dot, the gather-dot: 40 % of a pass) feeds nothing later.  So the column group gets a workgroup of TWO waves:
+//     wave 0 (chain):         pass jp:  product (into buffer jp & 1 of the chain slots) -> read-back -> gathers -> the level's column back into its slot -> ready = jp
+//     wave 1 (contributions): D, S, the R chain (while wave 0 loads, stages and runs its first pass), then per level: wait ready >= jp, the level's column from the slot
+//                             -> consumed = jp -> accumulation, Y dot, gather-dot, the sums over the columns; at the end the sums' exchange and the output vectors
+//     (the chain wave is the longer of the two: with the Y dot moved over to it -- the parts file can split a level's contributions -- one trajectory at order 10 took
+//      30.5 instead of 29.3 us)
+// with two buffers of chain slots (wave 0 writes level jp + 1 while wave 1 reads level jp; it waits for consumed >= jp before it writes level jp + 2) and the
+// phases' text shared with pcl_hess_cols_kernel (pcl_kernel_hess_cols_parts.hpp): the same arithmetic in the same order, bitwise the same values.
+// LDS: [slots 0 | slots 1 | D | S | R_1 .. R_{q-2} | coefficient table | entry table | 2 sync words]: 34 KB at config 3 -- a launch of this kind has LDS to spare.
+#define HP_SLOTS (HC_NSLOT * SP4CS)
+#define HP_LDS_DOUBLES (2 * HP_SLOTS + (2 + HC_NR) * HC_CPW * SP4CS + HC_NCFT + HC_GT_DOUBLES + 2 + 64)
+static __device__ __forceinline__ void hp_wait(int *w, int target) {  // bounded: a logic error must not hang the device (the caller's values are then wrong: the launch's error word is set)
+    for (int it = 0; it < (1 << 22); ++it) {
+        if (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(128, 128), amdgpu_waves_per_eu(2, 2))) void pcl_hess_cols_pair_kernel(
+    const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ drift_tab_t, const double *__restrict__ mags_, const double *__restrict__ dcf_tab,
+    double *xch /* [interval][HC_NG][HC_XS] reduced sums */, unsigned int *xcnt /* [interval] arrivals (self-resetting) */) {
+    extern __shared__ double lds[];
+    constexpr int d = SPD, n = SPN, m = SPM, q = SP4Q;
+    constexpr int CB = HC_CPW * SP4CS;
+    double *Dt = lds + 2 * HP_SLOTS, *St = Dt + CB, *Rt = St + CB, *cft = Rt + HC_NR * CB;
+    unsigned *gtab = (unsigned *)(cft + HC_NCFT);
+    int *sync = (int *)(cft + HC_NCFT + HC_GT_DOUBLES);  // [0] levels the chain wave has published | [1] levels the contribution wave has taken | [2] D, S staged | [3] the chain wave's sums parked
+    if (hc_lds_off(lds) != 0u) __builtin_trap();
+    const long long xd = (long long)n * d;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (threadIdx.x < 4) sync[threadIdx.x] = 0;
+    __syncthreads();  // (the only barrier: the sync words exist)
+    const unsigned bid = blockIdx.x;
+    int item, grp;
+    if (p.S > 1) {
+        const int x = bid % p.S, r = bid / p.S;
+        item = (r / HC_NG) * p.S + x;
+        grp = r - (r / HC_NG) * HC_NG;
+        if (item >= p.batch * p.K) return;
+    } else {
+        item = bid / HC_NG;
+        grp = bid - item * HC_NG;
+    }
+    const int k = item % p.K, b = item / p.K;
+    const int c0 = grp * HC_CPW, nce = min(HC_CPW, d - c0), ne = nce * n;
+    double *H = p.hess + (long long)item * p.hess_per;
+    sp_cptr magc = (sp_cptr)mags_;
+    double mg[SP4NMAG];
+#pragma unroll
+    for (int g = 0; g < SP4NMAG; ++g) mg[g] = magc[g];
+#ifdef PCL_PROFILE
+    int stamp_ = 32;  // (no stamps in this kernel)
+#endif
+    int ln_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(ln_));
+    const int half = ln_ >> 5, s = ln_ & 31;
+    const int ch = s / HC_CPW, col = s - ch * HC_CPW;
+    const bool inr = s < HC_NSLOT, act = inr && col < nce, isV = ch > 0;
+    const int own = half * d, oth = (1 - half) * d;
+    const int cb = col * SP4CS;
+    const int my_slot = (inr ? s : 0) * SP4CS;  // (the W chain's columns are slots 0 .. HC_CPW - 1, as in pcl_hess_cols_kernel: HC_WS == SP4CS)
+    static_assert(HC_WS == SP4CS && !HC_CFT_IN_TAIL, "the pair kernel's slots are one array per buffer");
+    const long long xo = p.x_off0 >= 0 ? p.x_off0 : p.x_offs[p.z_batch_stride ? 0 : b];
+    const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + xo + (long long)c0 * n;
+    const double *zn = zk + p.z_dim;
+    const double *mu = p.mu + (long long)item * xd + (long long)c0 * n;
+    sp_cptr zc = (sp_cptr)(p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim);
+    double u[SPM];
+#pragma unroll
+    for (int l = 0; l < SPM; ++l) u[l] = zc[p.u_off + l];
+    const double h = zc[p.dt_off];
+    sp4_cf cf;
+    SP4_SET_CF(cf, u, mg);
+    SP4_SET_DCF(cf, (sp_cptr)(dcf_tab + (p.g0_batch_stride ? (long long)b * SP4NDCFP : 0)));
+    sp_cptr tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
+    sp_cptr tab_t = (sp_cptr)(drift_tab_t + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
+    double x[SPD];
+    constexpr unsigned cft_off = (2 * HP_SLOTS + (2 + HC_NR) * HC_CPW * SP4CS) * 8u;
+
+    if (wave == 0) {
+        // ================================================= the chain wave =================================================
+        double mv_[HC_NT];
+#pragma unroll
+        for (int t = 0; t < HC_NT; ++t) mv_[t] = mu[ln_ + 64 * t < ne ? ln_ + 64 * t : 0];
+        constexpr int GTW = SPM * 2 * HC_GT_WPC;
+        unsigned gw_[(GTW + 63) / 64];
+#pragma unroll
+        for (int t = 0; t < (GTW + 63) / 64; ++t) gw_[t] = sp4_gt_tab[ln_ + 64 * t < GTW ? ln_ + 64 * t : 0];
+        if (ln_ < 1 + 2 * SP4NMAG) cft[ln_] = ln_ == 0 ? 0.0 : ((ln_ & 1) ? magc[(ln_ - 1) >> 1] : -magc[(ln_ - 2) >> 1]);
+#pragma unroll
+        for (int t = 0; t < (GTW + 63) / 64; ++t)
+            if (ln_ + 64 * t < GTW) gtab[ln_ + 64 * t] = gw_[t];
+        double *W1 = lds + HP_SLOTS;  // M = W_0 goes where the first pass's gathers look for it: the W slots of buffer 1
+#pragma unroll
+        for (int t = 0; t < HC_NT; ++t) {
+            const int e = ln_ + 64 * t;
+            if (e < ne) {
+                const int cc = e / n;
+                W1[cc * SP4CS + (e - cc * n)] = mv_[t];
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (act && !isV) {
+#pragma unroll
+            for (int i = 0; i < SPD; ++i) x[i] = W1[my_slot + own + i];  // W_0 = M
+        } else {
+#pragma unroll
+            for (int i = 0; i < SPD; ++i) x[i] = 0.0;  // V_{l,0} = 0
+        }
+        const double bt = half ? 1.0 : -1.0;
+        // (this wave holds no output vectors: it has the registers to keep its (drive, half)'s table words for all passes and to gather 14 rows at a time)
+        unsigned gtw_[HC_GT_WPC];
+        {
+            const unsigned *g0 = sp4_gt_tab + ((isV ? ch - 1 : 0) * 2 + half) * HC_GT_WPC;
+#pragma unroll
+            for (int t = 0; t < HC_GT_WPC; ++t) gtw_[t] = g0[t];
+        }
+#pragma unroll 1
+        for (int jp = 1; jp <= q + 1; ++jp) {
+            const bool on = act && (isV ? jp <= q : jp >= 2);
+            double *slots = lds + (jp & 1) * HP_SLOTS;
+            double *Xs = slots + my_slot;
+            const double *Wc = slots + cb;
+            if (jp >= 3) hp_wait(sync + 1, jp - 2);  // (the contribution wave has taken level jp - 2 out of this buffer)
+            if (jp >= 2) {
+                if (on) {
+                    sp4_product0_t(x, 0u, hc_lds_off(Xs + own), hc_lds_off(Xs + oth), 0.0, 1.0, bt, tab_t, cf);
+#pragma unroll
+                    for (int i = 0; i < SPD; ++i) x[i] = Xs[own + i];
+                }
+                asm volatile("" ::: "memory");
+            }
+            const unsigned wcol_off = hc_lds_off(Wc);
+#pragma push_macro("HC_GCH")
+#undef HC_GCH
+#define HC_GCH 14
+#define HC_GT_WORD(w) gtw_[w]
+#define HC_PART_GATHER
+#include "pcl_kernel_hess_cols_parts.hpp"
+#undef HC_PART_GATHER
+#undef HC_GT_WORD
+#pragma pop_macro("HC_GCH")
+            asm volatile("" ::: "memory");
+            if (on && isV) {  // the level's column where the contribution wave finds it (the W lanes' is there: the product's read-back)
+#pragma unroll
+                for (int i = 0; i < SPD; ++i) Xs[own + i] = x[i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (ln_ == 0) __hip_atomic_store(sync + 0, jp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    // ================================================= the contribution wave =================================================
+    double xc_[HC_NT], xn_[HC_NT];
+#pragma unroll
+    for (int t = 0; t < HC_NT; ++t) {
+        const int e = ln_ + 64 * t < ne ? ln_ + 64 * t : 0;
+        xc_[t] = zk[e], xn_[t] = zn[e];
+    }
+    double pw[SP4Q + 1];
+    pw[0] = 1.0;
+#pragma unroll
+    for (int j = 1; j <= q; ++j) pw[j] = pw[j - 1] * h;
+    auto wgt = [&](int jj) { return ((jj & 1) ? -1.0 : 1.0) * p.pc[jj] * pw[jj]; };
+    auto wgt_at = [&](int jj) {
+        double hj = 1.0;
+        for (int t = 0; t < jj; ++t) hj *= h;
+        return ((jj & 1) ? -1.0 : 1.0) * p.pc[jj] * hj;
+    };
+#pragma unroll
+    for (int t = 0; t < HC_NT; ++t) {
+        const int e = ln_ + 64 * t;
+        if (e < ne) {
+            const int cc = e / n, o = cc * SP4CS + (e - cc * n);
+            Dt[o] = xn_[t] - xc_[t];
+            St[o] = xn_[t] + xc_[t];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (ln_ == 0) __hip_atomic_store(sync + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (q > 2) {
+#define HC_PART_RCHAIN
+#include "pcl_kernel_hess_cols_parts.hpp"
+#undef HC_PART_RCHAIN
+    }
+    double accA[SPD], accB[SPD];
+#pragma unroll
+    for (int i = 0; i < SPD; ++i) accA[i] = accB[i] = 0.0;
+#define HC_PART_GROUPSUM
+#include "pcl_kernel_hess_cols_parts.hpp"
+#undef HC_PART_GROUPSUM
+    double hpV = 1.0, hpW = 1.0, hpW2 = 1.0;
+    auto level = [&](const int jp, auto odd_) __attribute__((always_inline)) {
+        constexpr bool odd_pass = decltype(odd_)::value;
+        const bool on = act && (isV ? jp <= q : jp >= 2);
+        const double *Xl = lds + (jp & 1) * HP_SLOTS + my_slot;
+        hp_wait(sync + 0, jp);
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < SPD; ++i) x[i] = Xl[own + i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (ln_ == 0) __hip_atomic_store(sync + 1, jp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#define HC_PART_CONTRIB
+#include "pcl_kernel_hess_cols_parts.hpp"
+#undef HC_PART_CONTRIB
+    };
+#pragma unroll 1
+    for (int jp = 1; jp <= q + 1; jp += 2) {
+        level(jp, hc_bool<true>{});
+        if (jp + 1 <= q + 1) level(jp + 1, hc_bool<false>{});
+    }
+    // the tail works in buffer 0 (the chain wave has published its last level: it writes nothing any more)
+    double *Wreg = lds, *vslots = lds + HC_CPW * HC_WS;
+    auto chain_col = [&](int chn, int cc) -> double * { return chn == 0 ? Wreg + cc * HC_WS : vslots + ((chn - 1) * HC_CPW + cc) * SP4CS; };
+    double *Xs = lds + my_slot;
+    unsigned int *rflag = nullptr;
+#define HC_PART_TAIL
+#include "pcl_kernel_hess_cols_parts.hpp"
+#undef HC_PART_TAIL
 }

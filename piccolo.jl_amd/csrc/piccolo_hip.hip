@@ -128,6 +128,9 @@ struct pcl_ctx {
     long long hcr_cap = 0;
     int64_t opt_hess_rpre = -1;         // -1 auto (launches of more than n_cu / 2 intervals: 1) | 0 the chain inside the column-group waves | 1 R-chain waves in the same launch | 2 a launch in front
     int64_t last_hess_rpre = 0;
+    hipFunction_t v4_fhessp = nullptr;  // ... launches of at most n_cu / 2 intervals (one trajectory): a chain wave and a contribution wave per column group (pcl_hess_cols_pair_kernel)
+    int64_t opt_hess_pair = -1;         // -1 auto (on for such launches) | 0 one wave per column group | 1 wherever the kernel fits
+    int64_t last_hess_pair = 0;
     int v4_hessc_failed = 0;
     double *dh4x = nullptr;        // general-order Hessian, two workgroups per interval: their rows of reduced sums ...
     unsigned int *dh4c = nullptr;  // ... and the arrival counters (self-resetting)
@@ -1609,6 +1612,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             const std::string key = "hess-cols:" + std::to_string(p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
             ctx->v4_fhessc = jit_compile(ctx->device, key, src, "pcl_hess_cols_kernel", true);
             if (ctx->v4_fhessc) ctx->v4_fhessr = jit_compile(ctx->device, key, src, "pcl_hess_rchain_kernel", true);  // (the same module)
+            if (ctx->v4_fhessc) ctx->v4_fhessp = jit_compile(ctx->device, key, src, "pcl_hess_cols_pair_kernel", true);
             if (!ctx->v4_fhessc) {
                 ctx->v4_hessc_failed = 1;
                 if (int rc = jit_fell_back(ctx, "Hessian of the Lagrangian (column groups)"); rc != PCL_ENOTIMPL) return rc;
@@ -1643,7 +1647,9 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             const size_t lds_r = (size_t)p.d * (p.n + 1) * sizeof(double);  // (one tile of d columns: the chain wave's exchange of the halves)
             // (auto: orders 8 and 10 -- two and three products in the chain; at order 6 the one product a wave saves is worth less than the chain waves cost:
             //  64 seeds 523 against 505 us; profiles/r06_hess_rpre_*.log)
-            int rmode = ctx->opt_hess_rpre >= 0 ? (int)ctx->opt_hess_rpre : ((2 * items > std::max(ctx->n_cu, 1) && p.q >= 4) ? 1 : 0);
+            // (... and launches of more column-group waves than the device has wave slots -- 8 per CU: below that a launch is the latency of its waves and the
+            //  chain waves only add to it: two trajectories at order 8 42.5 against 39.4 us)
+            int rmode = ctx->opt_hess_rpre >= 0 ? (int)ctx->opt_hess_rpre : ((items * ng > 8LL * std::max(ctx->n_cu, 1) && p.q >= 4) ? 1 : 0);
             if (p.q <= 2) rmode = 0;
             const int nx_ = ctx->opt_hess_xcd < 0 ? 8 : (int)std::max<int64_t>(1, ctx->opt_hess_xcd);
             if (rmode == 1 && (lds_r > ldsc || nx_ != 8)) rmode = 0;  // (the chain wave and its readers share an XCD's L2: blockIdx equal mod 8)
@@ -1679,7 +1685,18 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             p.S = nx;
             const long long grid_hc = n_rblk + (nx > 1 ? ((items + nx - 1) / nx) * nx * ng : items * ng);
             if (grid_hc > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
-            HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhessc, (unsigned)grid_hc, 1, 1, 64, 1, 1, (unsigned)ldsc, ctx->stream, args, nullptr));
+            // One trajectory per launch (at most n_cu / 2 intervals: every wave runs at once, the launch's time is ONE wave's latency): two waves per column
+            // group -- the chain (product, gathers) in one, what a level contributes in the other, two buffers of chain slots between them.  Same values, bitwise.
+            // MEASURED (config 3, one trajectory, one box, alternating; profiles/r06_hess_pair_*.log): order 4 17.6 -> 16.7 us, order 6 24.0 -> 20.4, order 8 29.1 -> 24.1,
+            // order 10 36.0 -> 27.6.
+            const size_t ldsp = ldsc + ((size_t)(p.m + 1) * cpw * (p.n + 1) + 2 + 64) * sizeof(double);  // (a second buffer of chain slots + the sync words + the chain wave's sums)
+            const bool pair = ctx->v4_fhessp && !rmode && ldsp <= (size_t)ctx->max_lds && (ctx->opt_hess_pair == 1 || (ctx->opt_hess_pair < 0 && p.q >= 2 && 2 * items <= std::max(ctx->n_cu, 1)));  // (order 2: one pass with a product -- nothing to overlap: 13.4 against 13.2 us)
+            ctx->last_hess_pair = pair ? 1 : 0;
+            if (pair) {
+                void *pargs[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dhcx, (void *)&ctx->dhcc};
+                HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhessp, (unsigned)grid_hc, 1, 1, 128, 1, 1, (unsigned)ldsp, ctx->stream, pargs, nullptr));
+            } else
+                HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhessc, (unsigned)grid_hc, 1, 1, 64, 1, 1, (unsigned)ldsc, ctx->stream, args, nullptr));
             ctx->last_hess_kernel = 80 + p.q;
             ctx->last_hess_split = 0;
             return PCL_OK;
@@ -2006,7 +2023,7 @@ static void note_order(pcl_ctx *ctx, double theta, bool met) {
 }
 static void set_order(pcl_ctx *ctx, int order, double theta) {
     if (ctx->desc.pade_order != order) {  // (modules are per order: the handles of the previous one are dropped, the modules stay cached)
-        ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = ctx->v4_fhessc = ctx->v4_fhessr = nullptr;
+        ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = ctx->v4_fhessc = ctx->v4_fhessr = ctx->v4_fhessp = nullptr;
         ctx->v4_failed = ctx->v4_hess_failed = ctx->v4_hessc_failed = ctx->v4_ft_failed = 0;
 #ifdef PCL_LAB
         ctx->res.f = nullptr;  // (the resident module bakes the order in as well)

@@ -108,14 +108,14 @@ def test_hessian_r_chain_in_front_gives_the_same_bits(order):
         c.hess_dev(Zd, mud, hv)
         c.sync()
         assert c.get_option("last_hess_kernel") == 80 + order // 2
-        assert c.get_option("last_hess_rpre") == ((1 if order >= 8 else 0) if mode < 0 else mode)  # (auto: 177 intervals > n_cu / 2 -> chain waves in the same launch at orders 8, 10)
+        assert c.get_option("last_hess_rpre") == (0 if mode < 0 else mode)  # (auto: 177 intervals x 7 waves fit the device's wave slots -> the chain stays inside the waves)
         if mode in out:
             assert torch.equal(out[mode], hv), (mode, int((out[mode] != hv).sum()))  # (repeatable bits in every mode)
         out[mode] = hv.clone()
     # the chain waves (1, 2) add a step's Y term behind the partner's half of the product, the column-group waves' own chain (0) before it:
     # the output vectors do not depend on R (bitwise), the (u,u) entries agree to rounding
     nsc = (lay.m + 1) * (lay.m + 2) // 2
-    assert torch.equal(out[1], out[2]) and torch.equal(out[1 if order >= 8 else 0], out[-1])  # (2: the same chain wave as a launch of its own)
+    assert torch.equal(out[1], out[2]) and torch.equal(out[0], out[-1])  # (2: the same chain wave as a launch of its own)
     a0, a1 = out[0].view(Bn * lay.K, -1), out[1].view(Bn * lay.K, -1)
     assert torch.equal(a0[:, nsc:], a1[:, nsc:])
     assert float((a0[:, :nsc] - a1[:, :nsc]).abs().max()) <= 1e-13 * max(1.0, float(a0[:, :nsc].abs().max()))
@@ -317,3 +317,42 @@ def test_config4_share_at_the_default_order():
     assert c.get_option("last_hess_rpre") == 0 and tol(hw, h_ref, 1e-11)
     c.set_member_window(0, M)
     B.close()
+
+
+@pytest.mark.parametrize("order", [2, 4, 6, 8, 10])
+def test_one_trajectory_hessian_with_a_chain_wave_and_a_contribution_wave(order):
+    """Round 6: launches of at most n_cu / 2 intervals (one trajectory) give every column group a workgroup of TWO waves -- the chain (product, gathers) in one, what a
+    level contributes (accumulation, Y dot, gather-dot, sums; the R chain at the start; the output at the end) in the other, two buffers of chain slots and two LDS
+    words between them (pcl_hess_cols_pair_kernel).  The phases' text is shared with the one-wave kernel: BITWISE the same values, repeatably; `auto` takes it for one
+    trajectory and not for eight; the oracle agrees."""
+    import torch
+
+    so = po.config_system(3)
+    G0, Gj = so.G_drift, np.array(so.G_drives)
+    N = 100
+    Z, lay = po.synthetic_trajectory(so, N, seed=1003)
+    Z[:, lay.dt_off] = 0.08 + 0.04 * np.random.default_rng(1).random(N)
+    mu = np.random.default_rng(51).standard_normal((lay.K, lay.x_dim))
+    ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Z, lay), 1, pade_order=order)
+    c = ms.ctx
+    c.set_option("hess_kernel", 8)
+    out = {}
+    for mode in (0, 1, -1, 1, 1):
+        c.set_option("hess_pair", mode)
+        h = c.hess(Z[None].copy(), mu.reshape(-1))
+        assert c.get_option("last_hess_kernel") == 80 + order // 2 and c.get_option("last_hess_pair") == (0 if mode == 0 or (mode < 0 and order == 2) else 1)
+        if mode in out:
+            assert np.array_equal(out[mode], h)
+        out[mode] = h.copy()
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[1], out[-1])  # (auto: the pair from order 4 on)
+    ref = po.pade_hessian_values(Z, mu, lay, G0, Gj, order).reshape(-1)
+    assert np.abs(out[1] - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    ms.close()
+    if order == 8:  # eight trajectories per launch: one wave per column group (and the R-chain waves), as before
+        ms8 = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Z, lay), 8, pade_order=order)
+        h8 = ms8.ctx.hess(np.stack([Z] * 8), np.tile(mu.reshape(-1), 8))
+        assert ms8.ctx.get_option("last_hess_pair") == 0 and ms8.ctx.get_option("last_hess_rpre") == 1
+        nsc = (lay.m + 1) * (lay.m + 2) // 2
+        a, b = h8.reshape(8 * lay.K, -1), np.tile(out[1].reshape(lay.K, -1), (8, 1))
+        assert np.array_equal(a[:, nsc:], b[:, nsc:]) and np.abs(a[:, :nsc] - b[:, :nsc]).max() <= 1e-13 * max(1.0, np.abs(b[:, :nsc]).max())
+        ms8.close()
