@@ -463,7 +463,10 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64))) void 
 // phases' text shared with pcl_hess_cols_kernel (pcl_kernel_hess_cols_parts.hpp): the same arithmetic in the same order, bitwise the same values.
 // LDS: [slots 0 | slots 1 | D | S | R_1 .. R_{q-2} | coefficient table | entry table | 2 sync words]: 34 KB at config 3 -- a launch of this kind has LDS to spare.
 #define HP_SLOTS (HC_NSLOT * SP4CS)
-#define HP_LDS_DOUBLES (2 * HP_SLOTS + (2 + HC_NR) * HC_CPW * SP4CS + HC_NCFT + HC_GT_DOUBLES + 2 + 64)
+#ifndef HP_NBUF
+#define HP_NBUF 3  // buffers of chain slots between the two waves (2: the chain wave waits for the other one at every level: 27.6 us at order 10; 3: see profiles/r06_hess_pair_*.log)
+#endif
+#define HP_LDS_DOUBLES (HP_NBUF * HP_SLOTS + (2 + HC_NR) * HC_CPW * SP4CS + HC_NCFT + HC_GT_DOUBLES + 2)
 static __device__ __forceinline__ void hp_wait(int *w, int target) {  // bounded: a logic error must not hang the device (the caller's values are then wrong: the launch's error word is set)
     for (int it = 0; it < (1 << 22); ++it) {
         if (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return;
@@ -476,7 +479,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(128, 128), amdg
     extern __shared__ double lds[];
     constexpr int d = SPD, n = SPN, m = SPM, q = SP4Q;
     constexpr int CB = HC_CPW * SP4CS;
-    double *Dt = lds + 2 * HP_SLOTS, *St = Dt + CB, *Rt = St + CB, *cft = Rt + HC_NR * CB;
+    double *Dt = lds + HP_NBUF * HP_SLOTS, *St = Dt + CB, *Rt = St + CB, *cft = Rt + HC_NR * CB;
     unsigned *gtab = (unsigned *)(cft + HC_NCFT);
     int *sync = (int *)(cft + HC_NCFT + HC_GT_DOUBLES);  // [0] levels the chain wave has published | [1] levels the contribution wave has taken | [2] D, S staged | [3] the chain wave's sums parked
     if (hc_lds_off(lds) != 0u) __builtin_trap();
@@ -529,7 +532,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(128, 128), amdg
     sp_cptr tab = (sp_cptr)(drift_tab + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
     sp_cptr tab_t = (sp_cptr)(drift_tab_t + (p.g0_batch_stride ? (long long)b * SP4NDRIFT : 0));
     double x[SPD];
-    constexpr unsigned cft_off = (2 * HP_SLOTS + (2 + HC_NR) * HC_CPW * SP4CS) * 8u;
+    constexpr unsigned cft_off = (HP_NBUF * HP_SLOTS + (2 + HC_NR) * HC_CPW * SP4CS) * 8u;
 
     if (wave == 0) {
         // ================================================= the chain wave =================================================
@@ -544,7 +547,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(128, 128), amdg
 #pragma unroll
         for (int t = 0; t < (GTW + 63) / 64; ++t)
             if (ln_ + 64 * t < GTW) gtab[ln_ + 64 * t] = gw_[t];
-        double *W1 = lds + HP_SLOTS;  // M = W_0 goes where the first pass's gathers look for it: the W slots of buffer 1
+        double *W1 = lds + (1 % HP_NBUF) * HP_SLOTS;  // M = W_0 goes where the first pass's gathers look for it: the W slots of level 1's buffer
 #pragma unroll
         for (int t = 0; t < HC_NT; ++t) {
             const int e = ln_ + 64 * t;
@@ -563,19 +566,26 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(128, 128), amdg
         }
         const double bt = half ? 1.0 : -1.0;
         // (this wave holds no output vectors: it has the registers to keep its (drive, half)'s table words for all passes and to gather 14 rows at a time)
-        unsigned gtw_[HC_GT_WPC];
+        unsigned pk_[SP4_GT_TOTAL];  // per entry: W row << 3 | (the coefficient's LDS address) << 16 -- decoded ONCE (the one-wave kernel decodes in every pass: no registers)
         {
             const unsigned *g0 = sp4_gt_tab + ((isV ? ch - 1 : 0) * 2 + half) * HC_GT_WPC;
+            unsigned gtw_[HC_GT_WPC];
 #pragma unroll
             for (int t = 0; t < HC_GT_WPC; ++t) gtw_[t] = g0[t];
+#pragma unroll
+            for (int en = 0; en < SP4_GT_TOTAL; ++en) {
+                const unsigned e = (gtw_[en / 3] >> (10 * (en % 3))) & 1023u;
+                pk_[en] = ((e >> 4) << 3) | ((((e & 15u) << 3) + cft_off) << 16);
+            }
         }
+        static_assert(HP_LDS_DOUBLES * 8 < 65536, "16-bit LDS addresses in pk_");
 #pragma unroll 1
         for (int jp = 1; jp <= q + 1; ++jp) {
             const bool on = act && (isV ? jp <= q : jp >= 2);
-            double *slots = lds + (jp & 1) * HP_SLOTS;
+            double *slots = lds + (jp % HP_NBUF) * HP_SLOTS;
             double *Xs = slots + my_slot;
             const double *Wc = slots + cb;
-            if (jp >= 3) hp_wait(sync + 1, jp - 2);  // (the contribution wave has taken level jp - 2 out of this buffer)
+            if (jp > HP_NBUF) hp_wait(sync + 1, jp - HP_NBUF);  // (the contribution wave has taken level jp - HP_NBUF out of this buffer)
             if (jp >= 2) {
                 if (on) {
                     sp4_product0_t(x, 0u, hc_lds_off(Xs + own), hc_lds_off(Xs + oth), 0.0, 1.0, bt, tab_t, cf);
@@ -588,11 +598,11 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(128, 128), amdg
 #pragma push_macro("HC_GCH")
 #undef HC_GCH
 #define HC_GCH 14
-#define HC_GT_WORD(w) gtw_[w]
+#define HC_GT_PREDECODED
 #define HC_PART_GATHER
 #include "pcl_kernel_hess_cols_parts.hpp"
 #undef HC_PART_GATHER
-#undef HC_GT_WORD
+#undef HC_GT_PREDECODED
 #pragma pop_macro("HC_GCH")
             asm volatile("" ::: "memory");
             if (on && isV) {  // the level's column where the contribution wave finds it (the W lanes' is there: the product's read-back)
@@ -647,7 +657,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(128, 128), amdg
     auto level = [&](const int jp, auto odd_) __attribute__((always_inline)) {
         constexpr bool odd_pass = decltype(odd_)::value;
         const bool on = act && (isV ? jp <= q : jp >= 2);
-        const double *Xl = lds + (jp & 1) * HP_SLOTS + my_slot;
+        const double *Xl = lds + (jp % HP_NBUF) * HP_SLOTS + my_slot;
         hp_wait(sync + 0, jp);
         if (on) {
 #pragma unroll

@@ -69,7 +69,12 @@
                     for (int kk = 0; kk < SP4_GTK; ++kk) {
                         const int row = i0 + i < SPD ? i0 + i : SPD - 1;
                         const int en = sp4_gt_off(row) + (kk < sp4_gt_cnt(row) ? kk : 0);  // entry number: word en / 3, bits 10 (en % 3) ...
+#ifdef HC_GT_PREDECODED
+                        e_[i][kk] = 0u;
+                        (void)en;
+#else
                         e_[i][kk] = kk < sp4_gt_cnt(row) ? HC_GT_WORD(en / 3) : 0u;                 // (the dword; the fields come out of it with one v_bfe_u32 each)
+#endif
                     }
                 double w_[HC_GCH][SP4_GTK], c_[HC_GCH][SP4_GTK];
 #pragma unroll
@@ -78,6 +83,11 @@
                     for (int kk = 0; kk < SP4_GTK; ++kk)
                         if (kk < sp4_gt_cnt(i0 + i < SPD ? i0 + i : SPD - 1)) {  // (a row takes as many terms as the drive with the most there)
                             const int row = i0 + i < SPD ? i0 + i : SPD - 1;
+#ifdef HC_GT_PREDECODED  // the includer holds every entry's two addresses in a register: pk_[entry] = W row << 3 | (coefficient's address in LDS) << 16
+                            const unsigned pk = pk_[sp4_gt_off(row) + kk];
+                            w_[i][kk] = *(const __attribute__((address_space(3))) double *)(size_t)((pk & 0xffffu) + wcol_off);
+                            c_[i][kk] = *(const __attribute__((address_space(3))) double *)(size_t)(pk >> 16);
+#else
                             const unsigned sh = 10u * (unsigned)((sp4_gt_off(row) + kk) % 3);
                             // (addresses as integers: the W column's base has no bit below 512, the tables' bases are constants of the layout)
                             unsigned aw;  // the W row's address: (bits sh + 4 .. sh + 9) << 3 + the column's
@@ -85,6 +95,7 @@
                             const unsigned fc = sh >= 3u ? (e_[i][kk] >> (sh - 3u)) & 0x78u : (e_[i][kk] << (3u - sh)) & 0x78u;  // coefficient index << 3
                             w_[i][kk] = *(const __attribute__((address_space(3))) double *)(size_t)aw;
                             c_[i][kk] = *(const __attribute__((address_space(3))) double *)(size_t)(fc + cft_off);
+#endif
                         }
                 asm volatile("" ::: "memory");
 #pragma unroll
