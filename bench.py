@@ -403,6 +403,8 @@ def main():
     if dist is not None:  # ranks the one collective of the path ran over (the ensemble step's all-reduce), at the top level of the line
         out["rccl_ranks"] = (out.get("ensemble_share") or {}).get("rccl_ranks") or info.get("rccl_ranks") or int(dist.get_world_size())
     kernel_s = dev / args.steps  # HIP events on the launch stream around the K back-to-back steps
+    if wall > 1.5 * dev + 1e-3:  # wall clock of the region far above its HIP-event time: the host stalled inside it (reported, not hidden)
+        out["host_stall_in_timed_region"] = {"wall_s": wall, "hip_event_s": dev}
     out["roofline"] = {
         "bound": "hbm",
         "achieved": ubytes * units / kernel_s / 1e9,
@@ -467,6 +469,9 @@ def main():
         out["value_reference_order"] = {"order": chosen, "order_tol": 1e-10, "evals_per_s": rs["evals_per_s"], "us_per_launch_kernel": rs["us_per_launch_kernel"],
                                         "frac_of_hbm_peak": rs["frac_of_hbm_peak"], "untimed_launches": rs.get("untimed_launches", args.warmup), "max_deviation_from_exp_constraint": dev_exp.get("order_%d" % chosen),
                                         "order4_deviation": dev_exp.get("order_4"), "steady_state": rs.get("steady_state"), "steps": args.steps,
+                                        # (evals_per_s is wall-clock over the one region, like `value`; a host stall inside it -- other tenants, the cgroup's CPU quota --
+                                        #  shows as wall time far above the HIP-event time of the same region, and is flagged instead of hidden)
+                                        "host_stall_in_region": bool(rs["evals_per_s"] * rs["us_per_launch_kernel"] * 1e-6 < 0.67),
                                         "note": "the order HipPadeIntegrator / BilinearIntegrator choose by default (pade_order = 0) on config 3's bounds, one trajectory per launch"}
     if rank == 0 and world == 1 and args.workload == "auto" and not args.no_shares:
         st = max(20, min(args.steps, 100))
