@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostics of the R-chain modes of the column-group Hessian kernel (hess_rpre 0 in-wave | 1 chain waves in the launch | 2 a launch in front): repeatability and
+"""Diagnostics of the R-chain modes of the column-group Hessian kernel (hess_rpre 0 in-wave | 1 chain waves in the launch; 2, a launch in front, was removed after the measurement): repeatability and
 where the modes differ.  usage: hess_rpre_diag.py [order=6] [B=3] [N=60]"""
 import os, sys
 import numpy as np
@@ -19,7 +19,7 @@ hv = torch.empty(c.hess_nnz, dtype=torch.float64, device="cuda")
 K = N - 1
 nsc = 28
 outs = {}
-for mode in (0, 1, 2, -1, 1, 1, 0, 1):
+for mode in (0, 1, -1, 1, 1, 0, 1):
     c.set_option("hess_rpre", mode)
     hv.fill_(float("nan"))
     torch.cuda.synchronize()  # (the context launches on a stream of its own: the fill must have finished)

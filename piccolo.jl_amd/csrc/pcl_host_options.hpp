@@ -82,8 +82,8 @@ extern "C" int pcl_set_option(pcl_ctx *ctx, const char *key, int64_t v) {
 #endif
     else if (!strcmp(key, "hess_xcd"))  // column-group Hessian kernel: the waves of an interval take blockIdx values equal mod n = one XCD (-1 auto: 8 | 0, 1: blockIdx order)
         ctx->opt_hess_xcd = v < 0 ? -1 : v;
-    else if (!strcmp(key, "hess_rpre"))  // column-group Hessian kernel: the chain of the R_a in a launch of its own in front (-1 auto | 0 | 1)
-        ctx->opt_hess_rpre = v < 0 ? -1 : (v > 2 ? 2 : v);
+    else if (!strcmp(key, "hess_rpre"))  // column-group Hessian kernel: the chain of the R_a in R-chain waves at the head of the launch (-1 auto | 0 | 1)
+        ctx->opt_hess_rpre = v < 0 ? -1 : (v ? 1 : 0);
     else if (!strcmp(key, "hess_pair"))  // column-group Hessian kernel: a chain wave and a contribution wave per column group (-1 auto: launches of at most n_cu / 2 intervals | 0 | 1)
         ctx->opt_hess_pair = v < 0 ? -1 : (v != 0);
     else if (!strcmp(key, "hess_split"))  // general-order pattern-compiled Hessian kernel: two workgroups per interval (-1 auto by launch size | 0 | 1)

@@ -165,8 +165,8 @@ static __device__ __forceinline__ void hc_rchain_role(const KParams &p, const do
 extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(2, 2))) void pcl_hess_cols_kernel(
     const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ drift_tab_t, const double *__restrict__ mags_, const double *__restrict__ dcf_tab,
     double *xch /* [interval][HC_NG][HC_XS] reduced sums */, unsigned int *xcnt /* [interval] arrivals (self-resetting) */,
-    double *rpre /* NULL, or [interval][HC_NR][d][n]: R_1 .. R_{q-2} of every state column, formed by R-chain waves (below) or by pcl_hess_rchain_kernel */,
-    unsigned int *rflag /* NULL (rpre was written by the launch in front), or [interval]: R-chain waves that have delivered (self-resetting) */) {
+    double *rpre /* NULL, or [interval][HC_NR][d][n]: R_1 .. R_{q-2} of every state column, formed by the R-chain waves at the head of this launch (below) */,
+    unsigned int *rflag /* with rpre: [interval]: R-chain waves that have delivered (self-resetting) */) {
     extern __shared__ double lds[];
     constexpr int d = SPD, n = SPN, m = SPM, q = SP4Q;
     // ---- R-CHAIN WAVES (p.n_stream of them, the FIRST workgroups of the grid, one per interval; launches of several trajectories): R_{q-2} .. R_1 of
@@ -257,18 +257,11 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         const int e = ln_ + 64 * t < ne ? ln_ + 64 * t : 0;
         xc_[t] = zk[e], xn_[t] = zn[e], mv_[t] = mu[e];
     }
-    // R_1 .. R_{q-2} of the wave's columns, where the launch before this one has formed them for every column of the interval (pcl_hess_rchain_kernel)
+    // R_1 .. R_{q-2} of the wave's columns, where the interval's R-chain wave (at the head of this launch) has already delivered them for every column
     double rp_[HC_NR > 0 ? HC_NR : 1][HC_NT];
     bool r_early = false;  // the chain's tiles were requested with the inputs
     if constexpr (HC_NR > 0) {
-        if (rpre && !rflag) {
-            const double *rg = rpre + ((long long)item * HC_NR * d + c0) * n;
-#pragma unroll
-            for (int a = 0; a < HC_NR; ++a)
-#pragma unroll
-                for (int t = 0; t < HC_NT; ++t) rp_[a][t] = rg[(long long)a * xd + (ln_ + 64 * t < ne ? ln_ + 64 * t : 0)];
-            r_early = true;
-        } else if (rpre) {
+        if (rpre) {
             r_early = __builtin_amdgcn_readfirstlane((int)rfl_) >= 1;
             if (r_early) {
                 const double *rg = rpre + ((long long)item * HC_NR * d + c0) * n;
@@ -440,14 +433,6 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
 #include "pcl_kernel_hess_cols_parts.hpp"
 #undef HC_PART_TAIL
     HC_STAMP();
-}
-
-// ---- the chain wave as a launch of its own in front of pcl_hess_cols_kernel (option hess_rpre 2): the same role, no counter (the stream orders the two launches,
-//      the column-group waves request the tiles with their other inputs).  Measured against the chain waves inside the launch: profiles/r06_hess_rpre_*.log.
-extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64))) void pcl_hess_rchain_kernel(
-    const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ mags_, const double *__restrict__ dcf_tab, double *__restrict__ rout /* [interval][HC_NR][d][n] */) {
-    extern __shared__ double lds[];
-    if constexpr (HC_NR > 0) hc_rchain_role(p, drift_tab, mags_, dcf_tab, rout, nullptr, (int)blockIdx.x, lds);
 }
 
 // ---- ONE TRAJECTORY PER LAUNCH: a chain wave and a contribution wave per column group (round 6) ---------------------------------------------------------

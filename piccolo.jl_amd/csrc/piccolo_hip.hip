@@ -122,11 +122,10 @@ struct pcl_ctx {
     double *dhcx = nullptr;             // ... the waves' rows of reduced sums and the intervals' arrival counters (self-resetting)
     unsigned int *dhcc = nullptr;
     long long hc_cap = 0;
-    hipFunction_t v4_fhessr = nullptr;  // ... its launch in front for several trajectories: R_1 .. R_{q-2} of every state column, one wave per interval (pcl_hess_rchain_kernel)
     double *dhcr = nullptr;             // ... [interval][q - 2][d][n]
     unsigned int *dhcf = nullptr;       // ... [interval] R-chain waves that have delivered (self-resetting)
     long long hcr_cap = 0;
-    int64_t opt_hess_rpre = -1;         // -1 auto (launches of more than n_cu / 2 intervals: 1) | 0 the chain inside the column-group waves | 1 R-chain waves in the same launch | 2 a launch in front
+    int64_t opt_hess_rpre = -1;         // -1 auto (launches of more than n_cu / 2 intervals: 1) | 0 the chain inside the column-group waves | 1 R-chain waves in the same launch
     int64_t last_hess_rpre = 0;
     hipFunction_t v4_fhessp = nullptr;  // ... launches of at most n_cu / 2 intervals (one trajectory): a chain wave and a contribution wave per column group (pcl_hess_cols_pair_kernel)
     int64_t opt_hess_pair = -1;         // -1 auto (on for such launches) | 0 one wave per column group | 1 wherever the kernel fits
@@ -1611,7 +1610,6 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             const std::string src = v4_hess_cols_source(v4, p.q, (int)ctx->opt_v4_variant);
             const std::string key = "hess-cols:" + std::to_string(p.q) + ":" + std::to_string(std::hash<std::string>{}(src));
             ctx->v4_fhessc = jit_compile(ctx->device, key, src, "pcl_hess_cols_kernel", true);
-            if (ctx->v4_fhessc) ctx->v4_fhessr = jit_compile(ctx->device, key, src, "pcl_hess_rchain_kernel", true);  // (the same module)
             if (ctx->v4_fhessc) ctx->v4_fhessp = jit_compile(ctx->device, key, src, "pcl_hess_cols_pair_kernel", true);
             if (!ctx->v4_fhessc) {
                 ctx->v4_hessc_failed = 1;
@@ -1637,7 +1635,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             // column-group waves at 8 of 64 lanes: 15 % of an 8-seed launch at order 8 (profiles/r06_hess_ablations_4.log).  The tiles travel through
             // memory (written through; a counter per interval, reset by the interval's last column-group wave).  One trajectory keeps the chain inside
             // the waves (99 intervals: every wave starts at once, there is nothing to hide the chain waves behind).
-            // option hess_rpre: -1 auto | 0 never | 1 R-chain waves | 2 the same waves as a launch of its own in front (pcl_hess_rchain_kernel: measured, the same within 1 %)
+            // option hess_rpre: -1 auto | 0 never | 1 R-chain waves  (the same waves as a launch of its own in front measured the same within 1 %: removed; profiles/r06_hess_rpre_*.log)
             // MEASURED (config 3, one box, alternating): 8 seeds 102-107 against 105 us at order 8, 130-134 against 136-138 at order 10; 64 seeds 630-640 against
             // 648-652 and 805-814 against 850-854 -- 3-5 %, not the 15 % the chain costs inside the waves: a chain wave is 20 k cycles of latency in a wave slot
             // and every column-group wave pays a flag and a tile round trip at its start.
@@ -1649,10 +1647,10 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             //  64 seeds 523 against 505 us; profiles/r06_hess_rpre_*.log)
             // (... and launches of more column-group waves than the device has wave slots -- 8 per CU: below that a launch is the latency of its waves and the
             //  chain waves only add to it: two trajectories at order 8 42.5 against 39.4 us)
-            int rmode = ctx->opt_hess_rpre >= 0 ? (int)ctx->opt_hess_rpre : ((items * ng > 8LL * std::max(ctx->n_cu, 1) && p.q >= 4) ? 1 : 0);
+            int rmode = ctx->opt_hess_rpre >= 0 ? (ctx->opt_hess_rpre ? 1 : 0) : ((items * ng > 8LL * std::max(ctx->n_cu, 1) && p.q >= 4) ? 1 : 0);
             if (p.q <= 2) rmode = 0;
             const int nx_ = ctx->opt_hess_xcd < 0 ? 8 : (int)std::max<int64_t>(1, ctx->opt_hess_xcd);
-            if (rmode == 1 && (lds_r > ldsc || nx_ != 8)) rmode = 0;  // (the chain wave and its readers share an XCD's L2: blockIdx equal mod 8)
+            if (rmode && (lds_r > ldsc || nx_ != 8)) rmode = 0;  // (the chain wave and its readers share an XCD's L2: blockIdx equal mod 8)
             if (rmode) {
                 const size_t per_item = (size_t)(p.q - 2) * p.d * p.n;
                 if (ctx->hcr_cap < cap * (long long)per_item || !ctx->dhcf) {
@@ -1665,16 +1663,8 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
                     ctx->hcr_cap = cap * (long long)per_item;
                 }
                 rpre = ctx->dhcr;
-                if (rmode == 2) {
-                    const size_t ldsr = lds_r;
-                    if (ctx->v4_fhessr && ldsr <= (size_t)ctx->max_lds) {
-                        void *rargs[] = {(void *)&p, (void *)&tab, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dhcr};
-                        HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhessr, (unsigned)items, 1, 1, 64, 1, 1, (unsigned)ldsr, ctx->stream, rargs, nullptr));
-                    } else
-                        rpre = nullptr, rmode = 0;
-                } else
-                    rflag = ctx->dhcf;
-                ctx->last_hess_rpre = rmode;
+                rflag = ctx->dhcf;
+                ctx->last_hess_rpre = 1;
             }
             const long long n_rblk = rflag ? (items + 7) / 8 * 8 : 0;  // (one chain wave per interval; a multiple of 8: the column-group waves keep their XCDs)
             p.n_stream = (int)n_rblk;
@@ -2023,7 +2013,7 @@ static void note_order(pcl_ctx *ctx, double theta, bool met) {
 }
 static void set_order(pcl_ctx *ctx, int order, double theta) {
     if (ctx->desc.pade_order != order) {  // (modules are per order: the handles of the previous one are dropped, the modules stay cached)
-        ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = ctx->v4_fhessc = ctx->v4_fhessr = ctx->v4_fhessp = nullptr;
+        ctx->v4_f = ctx->v4_ft = ctx->v4_feval = ctx->v4_fevalc = ctx->v4_fhess = ctx->v4_fhess2 = ctx->v4_fhessc = ctx->v4_fhessp = nullptr;
         ctx->v4_failed = ctx->v4_hess_failed = ctx->v4_hessc_failed = ctx->v4_ft_failed = 0;
 #ifdef PCL_LAB
         ctx->res.f = nullptr;  // (the resident module bakes the order in as well)
