@@ -1677,10 +1677,11 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             if (grid_hc > 0x7fffffffLL) return fail(ctx, PCL_ESHAPE, "too many work items");
             // One trajectory per launch (at most n_cu / 2 intervals: every wave runs at once, the launch's time is ONE wave's latency): two waves per column
             // group -- the chain (product, gathers) in one, what a level contributes in the other, two buffers of chain slots between them.  Same values, bitwise.
+            // (auto also asks that every workgroup of the launch is resident at once -- LDS decides: 47.5 KB at config 3, order 10: three per CU -- or the launch is two rounds of latencies)
             // MEASURED (config 3, one trajectory, one box, alternating; profiles/r06_hess_pair_*.log): order 4 17.6 -> 16.7 us, order 6 24.0 -> 20.4, order 8 29.1 -> 24.1,
             // order 10 36.0 -> 27.6.
             const size_t ldsp = ldsc + ((size_t)2 * (p.m + 1) * cpw * (p.n + 1) + 2) * sizeof(double);  // (HP_NBUF = 3 buffers of chain slots instead of one + the sync words)
-            const bool pair = ctx->v4_fhessp && !rmode && ldsp <= (size_t)ctx->max_lds && (ctx->opt_hess_pair == 1 || (ctx->opt_hess_pair < 0 && p.q >= 2 && 2 * items <= std::max(ctx->n_cu, 1)));  // (order 2: one pass with a product -- nothing to overlap: 13.4 against 13.2 us)
+            const bool pair = ctx->v4_fhessp && !rmode && ldsp <= (size_t)ctx->max_lds && (ctx->opt_hess_pair == 1 || (ctx->opt_hess_pair < 0 && p.q >= 2 && 2 * items <= std::max(ctx->n_cu, 1) && items * ng <= (long long)std::max(ctx->n_cu, 1) * (long long)((size_t)ctx->max_lds / ldsp)));  // (order 2: one pass with a product -- nothing to overlap: 13.4 against 13.2 us)
             ctx->last_hess_pair = pair ? 1 : 0;
             if (pair) {
                 void *pargs[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dhcx, (void *)&ctx->dhcc};
