@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A few launches of the general-order Hessian kernels at a given order (target of rocprofv3 passes): hess_cols_run.py [batch=8] [hess_kernel=8] [order=8] [key=value ...]"""
+"""A few launches of the general-order Hessian kernels at a given order (target of rocprofv3 passes): hess_cols_run.py [batch=8] [hess_kernel=8] [order=8] [key=value ...] [launches=12]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -19,8 +19,12 @@ mu = torch.randn(c.n_rows, dtype=torch.float64, device="cuda")
 hv = torch.empty(c.hess_nnz, dtype=torch.float64, device="cuda")
 c.set_stream(torch.cuda.current_stream().cuda_stream)
 c.set_option("hess_kernel", hk)
+launches = 12
 for kv in sys.argv[4:]:
-    c.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-for _ in range(12): c.hess_dev(Zd, mu, hv)
+    if kv.startswith("launches="):
+        launches = int(kv.split("=")[1])
+    else:
+        c.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+for _ in range(launches): c.hess_dev(Zd, mu, hv)
 torch.cuda.synchronize()
 c.close()
