@@ -355,3 +355,47 @@ def test_one_trajectory_hessian_with_a_chain_wave_and_a_contribution_wave(order)
         a, b = h8.reshape(8 * lay.K, -1), np.tile(out[1].reshape(lay.K, -1), (8, 1))
         assert np.array_equal(a[:, nsc:], b[:, nsc:]) and np.abs(a[:, :nsc] - b[:, :nsc]).max() <= 1e-13 * max(1.0, np.abs(b[:, :nsc]).max())
         ms8.close()
+
+
+@pytest.mark.parametrize("order", [4, 10])
+def test_two_wave_hessian_kernel_on_other_shapes(order):
+    """pcl_hess_cols_pair_kernel where config 3 does not take it: an ensemble with PER-MEMBER drifts (both waves read their member's tables), a member window on it,
+    a two-transmon system (d = 9, m = 4: six columns per column group, two groups per interval) at one and at eight intervals.  Bitwise the one-wave kernel's
+    values on every shape (`hess_pair` 0 / 1; `auto` = 1 on all of them), and the oracle's at 1e-11."""
+    from test_parity_gpu import _config4_share
+
+    def both(c, run):
+        outs = []
+        for mode in (0, 1, -1):
+            c.set_option("hess_pair", mode)
+            outs.append(run())
+            assert c.get_option("last_hess_kernel") == 80 + order // 2 and c.get_option("last_hess_pair") == (0 if mode == 0 else 1) and c.get_option("last_hess_rpre") == 0
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+        return outs[1]
+
+    osys, psys, layE, ZE, trajE = _config4_share(3, 5)
+    BE = pa.HipPadeIntegrator(np.array([s.G_drift for s in psys]), psys[0].G_drives_array(), trajE, ["Ũ⃗1", "Ũ⃗2", "Ũ⃗3"], pade_order=order)
+    BE.ctx.set_option("hess_kernel", 8)
+    muE = np.random.default_rng(16).standard_normal((3, layE.K, layE.x_dim))
+    h = both(BE.ctx, lambda: BE.ctx.hess(trajE.datavec, muE.reshape(-1)))
+    per = po.hess_nnz_per_interval(layE) * layE.K
+    for i, s in enumerate(osys):
+        ref = po.pade_hessian_values(ZE, muE[i], layE, s.G_drift, np.array(s.G_drives), order, x_off=i * layE.x_dim).reshape(-1)
+        assert np.abs(h[i * per : (i + 1) * per] - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+    BE.ctx.set_member_window(1, 2)
+    w = both(BE.ctx, lambda: BE.ctx.hess(trajE.datavec, muE[1:].reshape(-1)))
+    assert np.array_equal(w, h[per:])
+    BE.ctx.set_member_window(0, 3)
+    BE.close()
+    s2 = po.multi_transmon_system([4.0, 4.1], [0.2, 0.21], [[0, 0.02], [0.02, 0]], levels_per_transmon=3, drive_bounds=0.1)
+    for N in (2, 9):
+        Z, lay = po.synthetic_trajectory(s2, N, seed=21)
+        Z[:, lay.dt_off] = 0.1 + 0.1 * np.random.default_rng(4).random(N)
+        mu = np.random.default_rng(5).standard_normal((lay.K, lay.x_dim))
+        G0, Gj = s2.G_drift, np.array(s2.G_drives)
+        ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Z, lay), 1, pade_order=order)
+        ms.ctx.set_option("hess_kernel", 8)
+        g = both(ms.ctx, lambda: ms.ctx.hess(Z[None].copy(), mu.reshape(-1)))
+        ref = po.pade_hessian_values(Z, mu, lay, G0, Gj, order).reshape(-1)
+        assert np.abs(g - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+        ms.close()
