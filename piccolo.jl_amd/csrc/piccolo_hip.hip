@@ -851,6 +851,11 @@ static int check_device_error(pcl_ctx *ctx, const char *where) {
     if (!w) return PCL_OK;
     __atomic_store_n(ctx->herr, 0, __ATOMIC_RELEASE);
     if (ctx->dv4_tick) (void)hipMemsetAsync(ctx->dv4_tick, 0, (4 + (size_t)ctx->desc.batch * ctx->K) * sizeof(unsigned int), ctx->stream);  // the launch may have left its counters behind
+    // ... and the self-resetting arrival counters of the Hessian kernels (a wave that gave up never made its arrival: the interval's counter -- and the R-chain
+    // waves' delivery word, whose stale 1 would pass the NEXT launch the old tiles -- would stay where they are)
+    if (ctx->dhcc && ctx->hc_cap > 0) (void)hipMemsetAsync(ctx->dhcc, 0, (size_t)ctx->hc_cap * sizeof(unsigned int), ctx->stream);
+    if (ctx->dhcf) (void)hipMemsetAsync(ctx->dhcf, 0, (size_t)ctx->desc.batch * ctx->K * sizeof(unsigned int), ctx->stream);
+    if (ctx->dh4c && ctx->h4_cap > 0) (void)hipMemsetAsync(ctx->dh4c, 0, (size_t)ctx->h4_cap * sizeof(unsigned int), ctx->stream);
     return fail(ctx, PCL_EINTERNAL, "%s: an earlier kernel of this context gave up a bounded wait between its waves (device error word 0x%x); "
                 "the outputs of that launch are incomplete", where, w);
 }
