@@ -303,7 +303,8 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
     const int n_drift = (int)P.drift_pos.size();
     const int n_chunks = (n_drift + kV4Chunk - 1) / kV4Chunk;
     // [grp_lo, grp_hi): the output row groups this statement covers (a part of the product: other waves take the other rows)
-    auto emit_product = [&](const char *name, bool with_y, bool transposed = false, int grp_lo = 0, int grp_hi = 1 << 20) {
+    // unit_beta: every caller passes beta = 1 (the transposed product of the Hessian kernels): no multiply of the own half's rows, no scalar operand for it
+    auto emit_product = [&](const char *name, bool with_y, bool transposed = false, int grp_lo = 0, int grp_hi = 1 << 20, bool unit_beta = false) {
         const std::vector<V4Term> &terms = transposed ? P.terms_t : P.terms;
         // Accumulators in two sets (group parity): a finished group is scaled in place (own value alpha Y + beta U in the U
         // register, betas V in the V register) and its LDS operations are issued BETWEEN the multiply-adds of the next group --
@@ -324,6 +325,8 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
             }
         s += ";\n";
         if (!with_y) s += "    (void)vY;\n    (void)alpha;\n";
+        if (unit_beta) s += "    (void)beta;  // (== 1 at every call)\n";
+        if (n_chunks == 0) s += "    (void)tab;  // (every coefficient is resident)\n";
         s += "    asm volatile(\n";
         if (n_chunks > 0) detail::v4_emit_chunk_loads(s, 0);
         size_t ti = 0;
@@ -388,8 +391,10 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
             for (int o = g0; o < g1; ++o) {
                 const int gi = o - g0;
                 if (seenU[gi]) {
-                    snprintf(buf, sizeof buf, "        \"v_mul_f64 %%[aU%d_%d], %%[beta], %%[aU%d_%d]\\n\\t\"\n", st, gi, st, gi);
-                    s += buf;
+                    if (!(unit_beta && !with_y)) {
+                        snprintf(buf, sizeof buf, "        \"v_mul_f64 %%[aU%d_%d], %%[beta], %%[aU%d_%d]\\n\\t\"\n", st, gi, st, gi);
+                        s += buf;
+                    }
                     if (with_y) {
                         snprintf(buf, sizeof buf, "        \"v_fmac_f64 %%[aU%d_%d], %%[alpha], %%[yv%d]\\n\\t\"\n", st, gi, gi);
                         s += buf;
@@ -429,7 +434,9 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
             s += buf;
         }
         if (with_y) s += ", [vY] \"v\"(vY), [alpha] \"s\"(alpha)";
-        s += ", [vO] \"v\"(vO), [vOo] \"v\"(vOo), [beta] \"s\"(beta), [betas] \"v\"(betas), [tab] \"s\"(tab)";
+        s += ", [vO] \"v\"(vO), [vOo] \"v\"(vOo), [betas] \"v\"(betas)";
+        if (!(unit_beta && !with_y)) s += ", [beta] \"s\"(beta)";
+        if (n_chunks > 0) s += ", [tab] \"s\"(tab)";
         for (size_t k = 0; k < std::max<size_t>(P.cf_l.size(), 1); ++k) {
             snprintf(buf, sizeof buf, ", [cf%zu] \"s\"(cf.c%zu)", k, k);
             s += buf;
@@ -496,7 +503,7 @@ static inline std::string v4_functions(const V4Plan &P, int q, int np, int varia
     }
     if (with_hessian) {  // G(u)^T x for the Hessian of the Lagrangian: same statement shape, the transposed term tables
         emit_product("sp4_product_t", true, true);
-        emit_product("sp4_product0_t", false, true);
+        emit_product("sp4_product0_t", false, true, 0, 1 << 20, true);
     }
 
     // ---- the drives' gathers: X[own + i] = hs * (G_l w)_i for this lane's half-rows; Wo / Wx = this lane's own / other half of

@@ -379,9 +379,15 @@ std::string v4_hess_source(const pcl_codegen::V4Plan &plan, int q, int variant =
 std::string v4_hess_cols_source(const pcl_codegen::V4Plan &plan, int q, int variant = 0) {
     return std::string(kHessJitOpt) + "#include \"pcl_device_common.hpp\"\n" + pcl_codegen::v4_functions(plan, q, 1, (variant & 7) | 8, true) + "#include \"pcl_kernel_hess_cols.hpp\"\n";
 }
-static size_t hess_cols_lds_bytes(int d, int m, int q, int gt_total) {  // HC_LDS_DOUBLES of the kernel
+static size_t hess_cols_rtile_doubles(int d, int m) {  // HC_RTS of the kernel: a column group's R tile, in LDS and in memory
     const int cpw = 32 / (m + 1);
-    return ((size_t)((m + 1) * cpw + (2 + (q > 2 ? q - 2 : 0)) * cpw) * (2 * d + 1) + 16 + ((size_t)m * 2 * (((size_t)gt_total + 2) / 3) + 1) / 2) * sizeof(double);
+    return ((size_t)cpw * (2 * d + 1) + 1) & ~(size_t)1;
+}
+// HC_RT_OFF + n_tiles HC_RTS of the kernel (n_tiles < 0: HC_NR, the wave forms the chain of the R_a itself; 1: R-chain waves leave them in memory)
+static size_t hess_cols_lds_bytes(int d, int m, int q, int gt_total, int n_tiles = -1) {
+    const int cpw = 32 / (m + 1);
+    const size_t rt_off = ((size_t)((m + 1) * cpw + 2 * cpw) * (2 * d + 1) + 16 + ((size_t)m * 2 * (((size_t)gt_total + 2) / 3) + 1) / 2 + 1 + 1) & ~(size_t)1;  // (+ 1: the state word)
+    return (rt_off + (size_t)(n_tiles < 0 ? (q > 2 ? q - 2 : 0) : n_tiles) * hess_cols_rtile_doubles(d, m)) * sizeof(double);
 }
 }  // namespace
 

@@ -43,12 +43,18 @@
 // so that the address is (row << 3) | base in one v_and_or_b32 -- the four columns of a chain then share their LDS banks and an 8-seed launch at
 // order 8 went from 106 to 134 us (profiles/r06_hess_variants_3.log): the kernel is bound by the LDS, not by the vector instructions it issues.
 #define HC_WS SP4CS                                                     // doubles per W column (the slots' stride)
-#define HC_CFT_IN_TAIL 0
 #define HC_GT_WPC ((SP4_GT_TOTAL + 2) / 3)                             // the gathers' entry table (sp4_gt_tab): three 10-bit entries per dword, per (drive, half)
 #define HC_GT_DOUBLES ((SPM * 2 * HC_GT_WPC + 1) / 2)
 // 20,416 bytes at config 3, order 8: EIGHT of these workgroups share a CU's 160 KB (22.9 KB with R_{q-1} stored, a strip of zeros for the W lanes'
 // Y term and 16-bit entries: seven; 64 trajectories per launch 807 -> 784 us)
-#define HC_LDS_DOUBLES (HC_CPW * HC_WS + (HC_NSLOT - HC_CPW + (2 + HC_NR) * HC_CPW) * SP4CS + (HC_CFT_IN_TAIL ? 0 : HC_NCFT) + HC_GT_DOUBLES)
+// The R tiles lie LAST, and how many there are is the launch's choice: HC_NR where the wave forms the chain itself, ONE where the interval's R-chain wave has
+// left them in memory -- pass jp reads R_jp only, so the tile of the next pass is copied in behind the current one's last use (global_load_lds: no registers,
+// a pass of latency to hide in).  At config 3, order 10 that is 18.7 KB instead of 22.2: EIGHT waves per CU instead of seven (profiles/r06_hess_occupancy_37.log:
+// seven against eight waves per CU cost 6 % at order 8).
+#define HC_RTS ((HC_CPW * SP4CS + 1) & ~1)                              // doubles per R tile (even: whole 16-byte pieces for the copy)
+#define HC_RST_OFF (HC_CPW * HC_WS + (HC_NSLOT - HC_CPW + 2 * HC_CPW) * SP4CS + HC_NCFT + HC_GT_DOUBLES)  // one 64-bit word of state: see rtile_copy below
+#define HC_RT_OFF ((HC_RST_OFF + 1 + 1) & ~1)
+#define HC_LDS_DOUBLES (HC_RT_OFF + HC_NR * HC_RTS)
 static_assert(1 + 2 * SP4NMAG <= 16 && 16 <= HC_NCFT && SPN <= HC_WS, "10-bit entries of the gathers' table: source row (6 bits), coefficient index (4 bits)");
 static_assert(HC_CPW >= 1 && SPM >= 1, "chains per column");
 static_assert(HC_XS <= 64 && HC_ROW <= SPD, "one lane per reduced sum");
@@ -83,7 +89,6 @@ static __device__ __forceinline__ double hc_load_xcd(const double *q) {
 // (The column-group waves' own chain adds the Y term before the partner's half, this one behind it: the (u,u) entries of the two modes differ in the
 //  last bit; the output vectors do not depend on R.)
 static_assert(SPD <= 32, "lane = (half, column)");
-#define HR_T ((SPD * SPN + 63) / 64)
 static __device__ __forceinline__ void hc_rchain_role(const KParams &p, const double *__restrict__ drift_tab, const double *__restrict__ mags_, const double *__restrict__ dcf_tab,
                                                       double *rout, unsigned int *rflag, int item, double *lds) {
     constexpr int d = SPD, n = SPN, q = SP4Q;
@@ -132,7 +137,7 @@ static __device__ __forceinline__ void hc_rchain_role(const KParams &p, const do
     double x[SPD];  // R_{a+1}, this lane's half column
 #pragma unroll
     for (int i = 0; i < SPD; ++i) x[i] = wq * ((q & 1) ? Sv[i] : Dv[i]);
-    double *rg = rout + (long long)item * HC_NR * xd;
+    double *rg = rout + (long long)item * HC_NR * (HC_NG * HC_RTS);  // [a][column group][HC_RTS]: a column group's tile as it lies in its wave's LDS (columns past the last one: zeros, never written)
 #pragma unroll 1
     for (int a = q - 2; a >= 1; --a) {
         if (act) sp4_product0(x, 0u, hc_lds_off(Rt + cb + own), hc_lds_off(Rt + cb + oth), 0.0, 1.0, half ? -1.0 : 1.0, tab, cf);
@@ -147,14 +152,14 @@ static __device__ __forceinline__ void hc_rchain_role(const KParams &p, const do
             for (int i = 0; i < SPD; ++i) Rt[cb + own + i] = x[i];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        double *ro = rg + (long long)(a - 1) * xd;  // R_a -> the XCD's L2, lane = element (its readers run on this XCD)
+        double *ro = rg + (long long)(a - 1) * (HC_NG * HC_RTS);  // R_a -> the XCD's L2, lane = element (its readers run on this XCD)
+        // (the tile goes out AS IT LIES: [column][SP4CS], the columns' padding row included -- nobody reads it -- so that lane = element on both sides with constant
+        //  offsets; per-element index arithmetic here, hoisted out of the chain's loop by the compiler, cost 150 spilled registers)
+        constexpr int RPAD = HC_RTS - HC_CPW * SP4CS;  // (0 unless HC_CPW SP4CS is odd)
 #pragma unroll
-        for (int t = 0; t < HR_T; ++t) {
+        for (int t = 0; t < (d * SP4CS + 63) / 64; ++t) {
             const int e = ln_ + 64 * t;
-            if (e < d * n) {
-                const int cc = e / n;
-                hc_store_xcd(ro + e, Rt[cc * SP4CS + (e - cc * n)]);
-            }
+            if (e < d * SP4CS) hc_store_xcd(ro + e + (RPAD ? (e / (HC_CPW * SP4CS)) * RPAD : 0), Rt[e]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the tile is read before the next product writes it)
     }
@@ -162,11 +167,32 @@ static __device__ __forceinline__ void hc_rchain_role(const KParams &p, const do
     if (ln_ == 0 && rflag) __hip_atomic_fetch_add(rflag + item, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- an R tile from memory into LDS by the memory pipe itself (global_load_lds_dwordx4: lane = 16-byte piece, no data registers): `g` is wave-uniform (scalar
+//      registers), the LDS address an immediate.  M0 (the copy's LDS base) is not saved: nothing else in this module uses it (the compiler sets M0 only in front of its
+//      own M0 instructions -- none here).  The s_waitcnt in front: the tile's last readers (the same wave's ds_reads) have their data.
+#define HC_RTILE_NT ((HC_RTS / 2 + 63) / 64)
+template <int LDS_BYTES, int T>
+static __device__ __forceinline__ void hc_rtile_dma(const double *g, int ln_) {
+    if constexpr (T < HC_RTILE_NT) {
+        if (64 * (T + 1) <= HC_RTS / 2 || ln_ + 64 * T < HC_RTS / 2)  // (a full piece: every lane, no mask)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" ::"v"((unsigned)(16 * ln_ + 1024 * T)), "s"(g), "n"(LDS_BYTES + 1024 * T) : "memory");
+        hc_rtile_dma<LDS_BYTES, T + 1>(g, ln_);
+    }
+}
+template <int A>
+static __device__ __forceinline__ void hc_rtile_all(const double *base, int ln_) {  // R_{A+1} .. R_{q-2} into tiles A .. HC_NR - 1
+    if constexpr (A < HC_NR) {
+        hc_rtile_dma<(HC_RT_OFF + A * HC_RTS) * 8, 0>(base + (long long)A * (HC_NG * HC_RTS), ln_);
+        hc_rtile_all<A + 1>(base, ln_);
+    }
+}
+
 extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(2, 2))) void pcl_hess_cols_kernel(
     const KParams p, const double *__restrict__ drift_tab, const double *__restrict__ drift_tab_t, const double *__restrict__ mags_, const double *__restrict__ dcf_tab,
     double *xch /* [interval][HC_NG][HC_XS] reduced sums */, unsigned int *xcnt /* [interval] arrivals (self-resetting) */,
     double *rpre /* NULL, or [interval][HC_NR][d][n]: R_1 .. R_{q-2} of every state column, formed by the R-chain waves at the head of this launch (below) */,
-    unsigned int *rflag /* with rpre: [interval]: R-chain waves that have delivered (self-resetting) */) {
+    unsigned int *rflag /* with rpre: [interval]: R-chain waves that have delivered (self-resetting) */,
+    const int rt_all /* with rpre: the launch's LDS holds all HC_NR tiles (they are all copied in at the start) | 0: ONE tile, R_{jp+1} copied in behind R_jp's last use */) {
     extern __shared__ double lds[];
     constexpr int d = SPD, n = SPN, m = SPM, q = SP4Q;
     // ---- R-CHAIN WAVES (p.n_stream of them, the FIRST workgroups of the grid, one per interval; launches of several trajectories): R_{q-2} .. R_1 of
@@ -184,9 +210,9 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     }
     constexpr int CB = HC_CPW * SP4CS;  // doubles per block of HC_CPW columns
     // LDS: [W columns | the V chains' slots | D | S | R_1 .. R_{q-2} | coefficient table | the gathers' entry table]
-    double *Wreg = lds, *vslots = Wreg + HC_CPW * HC_WS, *Dt = vslots + (HC_NSLOT - HC_CPW) * SP4CS, *St = Dt + CB, *Rt = St + CB;
-    double *cft = HC_CFT_IN_TAIL ? Wreg + SPN : Rt + HC_NR * CB;
-    unsigned *gtab = (unsigned *)(Rt + HC_NR * CB + (HC_CFT_IN_TAIL ? 0 : HC_NCFT));
+    double *Wreg = lds, *vslots = Wreg + HC_CPW * HC_WS, *Dt = vslots + (HC_NSLOT - HC_CPW) * SP4CS, *St = Dt + CB, *Rt = lds + HC_RT_OFF;
+    double *cft = St + CB;
+    unsigned *gtab = (unsigned *)(cft + HC_NCFT);
     // column `cc` of chain `chn`
     if (hc_lds_off(lds) != 0u) __builtin_trap();  // (the gathers' addresses are built as integers on that base)
     auto chain_col = [&](int chn, int cc) -> double * { return chn == 0 ? Wreg + cc * HC_WS : vslots + ((chn - 1) * HC_CPW + cc) * SP4CS; };
@@ -257,20 +283,23 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         const int e = ln_ + 64 * t < ne ? ln_ + 64 * t : 0;
         xc_[t] = zk[e], xn_[t] = zn[e], mv_[t] = mu[e];
     }
-    // R_1 .. R_{q-2} of the wave's columns, where the interval's R-chain wave (at the head of this launch) has already delivered them for every column
-    double rp_[HC_NR > 0 ? HC_NR : 1][HC_NT];
-    bool r_early = false;  // the chain's tiles were requested with the inputs
+    // ---- the R tiles of a launch with R-chain waves: R_a of this wave's columns lies in memory as it lies in LDS (hc_rchain_role), and pass jp reads R_jp only:
+    //      ONE tile in LDS, copied in by the memory pipe itself (global_load_lds_dwordx4, lane = 16-byte piece; through the XCD's L2 -- sc1 -- where the chain wave
+    //      left it) behind the previous tile's last use, a pass ahead of its first.  No registers, no staging writes, and 3.5 KB of LDS less at order 10.
+    // (between two copies the tiles' base lives in an LDS word, not in registers: the kernel sits at the 256-register limit and the product takes ~100 scalar
+    //  operands -- a per-lane pointer held across the passes cost 54 vector moves per pass, a scalar one 36 v_readlane of spilled scalars per product.
+    //  The word: the base while tile-by-tile copies are on, else 0.)
+    unsigned long long *rstate = (unsigned long long *)(lds + HC_RST_OFF);
+    bool rtile_on = false;  // wave-uniform
+    auto rtile_start = [&]() __attribute__((always_inline)) {  // the chain wave has delivered: R_1 (or all of them) on their way, the state word set
+        const double *base = rpre + ((long long)item * HC_NR * HC_NG + grp) * HC_RTS;
+        hc_rtile_dma<HC_RT_OFF * 8, 0>(base, ln_);
+        if (rt_all) hc_rtile_all<1>(base, ln_);
+        if (ln_ == 0) *rstate = rt_all ? 0ull : (unsigned long long)base;
+    };
+    if (ln_ == 0) *rstate = 0ull;
     if constexpr (HC_NR > 0) {
-        if (rpre) {
-            r_early = __builtin_amdgcn_readfirstlane((int)rfl_) >= 1;
-            if (r_early) {
-                const double *rg = rpre + ((long long)item * HC_NR * d + c0) * n;
-#pragma unroll
-                for (int a = 0; a < HC_NR; ++a)
-#pragma unroll
-                    for (int t = 0; t < HC_NT; ++t) rp_[a][t] = hc_load_xcd(rg + (long long)a * xd + (ln_ + 64 * t < ne ? ln_ + 64 * t : 0));
-            }
-        }
+        if (rpre) rtile_start();  // (requested with the inputs, whether or not the chain wave has delivered: the count -- loaded in front -- tells below)
     }
     constexpr int GTW = SPM * 2 * HC_GT_WPC;  // the gathers' entry table, in dwords
     unsigned gw_[(GTW + 63) / 64];
@@ -314,45 +343,33 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
                 Wreg[cc * HC_WS + (e - cc * n)] = mv_[t];
                 Dt[o] = dv;
                 St[o] = sv;
-                if constexpr (HC_NR > 0) {
-                    if (r_early) {
-#pragma unroll
-                        for (int a = 0; a < HC_NR; ++a) Rt[a * CB + o] = rp_[a][t];
-                    }
-                }
             }
         }
     }
     if constexpr (HC_NR > 0) {
-        if (rpre && rflag && !r_early) {  // the interval's R-chain wave had not arrived at the start: wait for it (bounded), then the wave's columns from memory (written through by another XCD's wave)
-            unsigned got = 0;
-            for (int it = 0; it < (1 << 20); ++it) {
-                got = __hip_atomic_load(rflag + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (got >= 1u) break;
+        if (rpre && __builtin_amdgcn_readfirstlane((int)rfl_) < 1) {  // the interval's R-chain wave had not arrived at the start: wait for it (bounded), the tiles again
+            unsigned got = 0u;
+            for (int it = 0; got < 1u && it < (1 << 20); ++it) {
                 __builtin_amdgcn_s_sleep(8);
+                got = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(rflag + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
-            // (a wait that gave up: the output is poisoned below AND the context's error word is set -- the next call that looks at it returns PCL_EINTERNAL)
-            if (got < 1u && ln_ == 0 && p.err) __hip_atomic_fetch_or(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            const double *rg = rpre + ((long long)item * HC_NR * d + c0) * n;
-#pragma unroll
-            for (int a = 0; a < HC_NR; ++a)
-#pragma unroll
-                for (int t = 0; t < HC_NT; ++t) rp_[a][t] = got >= 1u ? hc_load_xcd(rg + (long long)a * xd + (ln_ + 64 * t < ne ? ln_ + 64 * t : 0)) : __builtin_nan("");  // (a wait that gave up poisons the output)
-#pragma unroll
-            for (int t = 0; t < HC_NT; ++t) {
-                const int e = ln_ + 64 * t;
-                if (e < ne) {
-                    const int cc = e / n, o = cc * SP4CS + (e - cc * n);
-#pragma unroll
-                    for (int a = 0; a < HC_NR; ++a) Rt[a * CB + o] = rp_[a][t];
-                }
+            rtile_on = got >= 1u;
+            if (rtile_on)
+                rtile_start();
+            else {  // (a wait that gave up: the tile is poisoned -- and with it the output -- AND the context's error word is set: the next call that looks at it returns PCL_EINTERNAL)
+                if (ln_ == 0 && p.err) __hip_atomic_fetch_or(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int e = ln_; e < (rt_all ? HC_NR : 1) * HC_RTS; e += 64) Rt[e] = __builtin_nan("");
             }
         }
+    }
+    if constexpr (HC_NR > 0) {
+        if (rpre && rt_all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (all tiles were requested with the inputs)
     }
     asm volatile("" ::: "memory");
     HC_STAMP();
     // ---- R_a = sum_b (+-T_{a+b+1}) G^b |Y_{a+b+1}|, the operands of the (u,u) sums, as ONE chain per state column from the top:
     //      R_{q-1} = +-T_q |Y_q| (stored with the inputs),  R_a = +-T_{a+1} |Y_{a+1}| + G R_{a+1}   (q - 2 products; lanes (half, column)) -----
+#define HC_RSTRIDE HC_RTS
     if (q > 2 && !rpre) {
 #define HC_PART_RCHAIN
 #include "pcl_kernel_hess_cols_parts.hpp"
@@ -410,7 +427,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         // (the module has no static LDS: the wave's dynamic LDS starts at offset 0 -- checked once at the top of the kernel -- so the coefficient
         //  table's offset is a constant of the layout)
         const unsigned wcol_off = (unsigned)col * (HC_WS * 8u);
-        constexpr unsigned cft_off = (HC_CFT_IN_TAIL ? SPN : HC_CPW * HC_WS + (HC_NSLOT - HC_CPW + (2 + HC_NR) * HC_CPW) * SP4CS) * 8u;
+        constexpr unsigned cft_off = (HC_CPW * HC_WS + (HC_NSLOT - HC_CPW + 2 * HC_CPW) * SP4CS) * 8u;
 #define HC_PART_GATHER
 #include "pcl_kernel_hess_cols_parts.hpp"
 #undef HC_PART_GATHER
@@ -418,9 +435,32 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         HC_STAMP();
         // ---- what the lane's level contributes ----
         HC_MARK("pass_contrib");
+// (R_jp: with R-chain waves the ONE tile -- its copy has landed: requested a pass ago -- and R_{jp+1} is requested behind its last use)
+#define HC_RSTATE_U(lo_, hi_)                                                \
+    const unsigned long long w_ = *rstate;                                    \
+    const unsigned lo_ = (unsigned)__builtin_amdgcn_readfirstlane((int)w_), hi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(w_ >> 32))
+#define HC_RTILE_WAIT(jp)                                                                       \
+    bool r1_ = false;                                                                           \
+    if constexpr (HC_NR > 0) {                                                                  \
+        HC_RSTATE_U(lo_, hi_);                                                                  \
+        r1_ = (lo_ | hi_) != 0u;                                                                \
+        if (r1_ && (jp) <= q - 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              \
+    }
+#define HC_RTILE(jp) (r1_ ? Rt : Rt + ((jp) - 1) * HC_RSTRIDE)
+#define HC_RTILE_NEXT(jp)                                                                                                                   \
+    do {                                                                                                                                    \
+        if (HC_NR > 0 && (jp) + 1 <= q - 2) {                                                                                               \
+            HC_RSTATE_U(lo_, hi_);                                                                                                          \
+            if (lo_ | hi_) hc_rtile_dma<HC_RT_OFF * 8, 0>((const double *)(((unsigned long long)hi_ << 32) | lo_) + (long long)(jp) * (HC_NG * HC_RTS), ln_); \
+        }                                                                                                                                   \
+    } while (0)
 #define HC_PART_CONTRIB
 #include "pcl_kernel_hess_cols_parts.hpp"
 #undef HC_PART_CONTRIB
+#undef HC_RTILE
+#undef HC_RTILE_WAIT
+#undef HC_RTILE_NEXT
+#undef HC_RSTATE_U
         HC_STAMP();
     };
 #pragma unroll 1
@@ -428,6 +468,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
         pass_body(jp, hc_bool<true>{});
         if (jp + 1 <= q + 1) pass_body(jp + 1, hc_bool<false>{});
     }
+#undef HC_RSTRIDE
     HC_MARK("tail");
 #define HC_PART_TAIL
 #include "pcl_kernel_hess_cols_parts.hpp"
@@ -501,7 +542,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(128, 128), amdg
     const int own = half * d, oth = (1 - half) * d;
     const int cb = col * SP4CS;
     const int my_slot = (inr ? s : 0) * SP4CS;  // (the W chain's columns are slots 0 .. HC_CPW - 1, as in pcl_hess_cols_kernel: HC_WS == SP4CS)
-    static_assert(HC_WS == SP4CS && !HC_CFT_IN_TAIL, "the pair kernel's slots are one array per buffer");
+    static_assert(HC_WS == SP4CS, "the pair kernel's slots are one array per buffer");
     const long long xo = p.x_off0 >= 0 ? p.x_off0 : p.x_offs[p.z_batch_stride ? 0 : b];
     const double *zk = p.Z + (long long)b * p.z_batch_stride + (long long)k * p.z_dim + xo + (long long)c0 * n;
     const double *zn = zk + p.z_dim;
@@ -627,6 +668,11 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(128, 128), amdg
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (ln_ == 0) __hip_atomic_store(sync + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+// (this kernel always forms the chain itself: HC_NR tiles of CB doubles)
+#define HC_RSTRIDE CB
+#define HC_RTILE(jp) (Rt + ((jp) - 1) * CB)
+#define HC_RTILE_WAIT(jp)
+#define HC_RTILE_NEXT(jp) do { } while (0)
     if (q > 2) {
 #define HC_PART_RCHAIN
 #include "pcl_kernel_hess_cols_parts.hpp"
@@ -659,6 +705,10 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(128, 128), amdg
         level(jp, hc_bool<true>{});
         if (jp + 1 <= q + 1) level(jp + 1, hc_bool<false>{});
     }
+#undef HC_RSTRIDE
+#undef HC_RTILE
+#undef HC_RTILE_WAIT
+#undef HC_RTILE_NEXT
     // the tail works in buffer 0 (the chain wave has published its last level: it writes nothing any more)
     double *Wreg = lds, *vslots = lds + HC_CPW * HC_WS;
     auto chain_col = [&](int chn, int cc) -> double * { return chn == 0 ? Wreg + cc * HC_WS : vslots + ((chn - 1) * HC_CPW + cc) * SP4CS; };

@@ -17,11 +17,11 @@
 #pragma unroll
                     for (int i = 0; i < SPD; ++i) x[i] = wq * src[i];
                 } else {
-                    const double *src = Rt + a * CB + rb + own;
+                    const double *src = Rt + a * HC_RSTRIDE + rb + own;
 #pragma unroll
                     for (int i = 0; i < SPD; ++i) x[i] = src[i];
                 }
-                double *dst = Rt + (a - 1) * CB + rb;
+                double *dst = Rt + (a - 1) * HC_RSTRIDE + rb;
                 const double *Y = (((a + 1) & 1) ? St : Dt) + rb + own;
                 sp4_product(x, hc_lds_off(Y), hc_lds_off(dst + own), hc_lds_off(dst + oth), sp4_uniform(wgt_at(a + 1)), 1.0, half ? -1.0 : 1.0, tab, cf);
             }
@@ -163,15 +163,22 @@
 #ifndef HC_CONTRIB_NO_G
             if (isV && jp < q) {  // (u,u): <V_{l,j}, G_i R_j>, every drive i
                 // R_jp; the top one is +-T_q |Y_q|: the D or the S tile, the number applied to the sums
-                const double *Rj = (jp == q - 1 ? ((q & 1) ? St : Dt) : Rt + (jp - 1) * CB) + cb;
+                HC_RTILE_WAIT(jp)  // (where R-chain waves deliver the tiles: which tile, and that its copy has landed)
+                const double *Rj = (jp == q - 1 ? ((q & 1) ? St : Dt) : HC_RTILE(jp)) + cb;
                 const double wr = jp == q - 1 ? wgt(q) : 1.0;
                 double r6[SPM];
-                sp4_gdot_all(Rj + own, Rj + oth, x, (half ? 1.0 : -1.0), mg, r6);
+                // (the magnitudes from the scalar cache again -- ten scalar registers that need not live across the product, whose ~100 scalar operands fill the file:
+                //  held, they pushed 18 coefficient pairs into vector-register lanes, read back with v_readlane in front of every product)
+                double mgl_[SP4NMAG];
+#pragma unroll
+                for (int g = 0; g < SP4NMAG; ++g) mgl_[g] = magc[g];
+                sp4_gdot_all(Rj + own, Rj + oth, x, (half ? 1.0 : -1.0), mgl_, r6);
 #pragma unroll
                 for (int i = 0; i < SPM; ++i) cv[1 + i] = wr * r6[i];
             }
 #endif
         }
+        HC_RTILE_NEXT(jp);
         HC_MARK("pass_sums");
         // this pass's 1 + m values of the chain, summed over its columns; lane `col` adds the values col, col + HC_CPW, ... to its running totals
         // (every lane of the wave takes part in the DPP steps: lanes without a level contribute zeros)

@@ -1655,14 +1655,21 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             int rmode = ctx->opt_hess_rpre >= 0 ? (ctx->opt_hess_rpre ? 1 : 0) : ((items * ng > 8LL * std::max(ctx->n_cu, 1) && p.q >= 4) ? 1 : 0);
             if (p.q <= 2) rmode = 0;
             const int nx_ = ctx->opt_hess_xcd < 0 ? 8 : (int)std::max<int64_t>(1, ctx->opt_hess_xcd);
-            if (rmode && (lds_r > ldsc || nx_ != 8)) rmode = 0;  // (the chain wave and its readers share an XCD's L2: blockIdx equal mod 8)
+            // (with them a column-group wave holds ONE tile of the R_a -- the next pass's is copied in behind the current one's last use -- instead of q - 2:
+            //  18.7 instead of 22.2 KB at config 3, order 10: eight waves per CU instead of seven)
+            //  -- where all q - 2 fit without costing a wave per CU (order 8: 20.4 KB, eight either way) they are all copied in at the start: 2 % faster than tile by tile)
+            const size_t lds1_ = std::max(hess_cols_lds_bytes(p.d, p.m, p.q, pcl_codegen::v4_gather_total(v4), 1), lds_r), ldsa_ = std::max(ldsc, lds_r);
+            const int rt_all = std::min<size_t>(8, (size_t)ctx->max_lds / ldsa_) >= std::min<size_t>(8, (size_t)ctx->max_lds / lds1_) ? 1 : 0;
+            const size_t ldsc1 = rt_all ? ldsa_ : lds1_;
+            if (rmode && (ldsc1 > (size_t)ctx->max_lds || nx_ != 8)) rmode = 0;  // (the chain wave and its readers share an XCD's L2: blockIdx equal mod 8)
             if (rmode) {
-                const size_t per_item = (size_t)(p.q - 2) * p.d * p.n;
+                const size_t per_item = (size_t)(p.q - 2) * ng * hess_cols_rtile_doubles(p.d, p.m);  // [a][column group][tile as it lies in LDS]
                 if (ctx->hcr_cap < cap * (long long)per_item || !ctx->dhcf) {
                     if (ctx->dhcr) (void)hipFree(ctx->dhcr);
                     if (ctx->dhcf) (void)hipFree(ctx->dhcf);
                     ctx->dhcr = nullptr, ctx->dhcf = nullptr, ctx->hcr_cap = 0;
                     HIP_TRY(ctx, hipMalloc((void **)&ctx->dhcr, (size_t)cap * per_item * sizeof(double)));
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->dhcr, 0, (size_t)cap * per_item * sizeof(double), ctx->stream));  // (a group past its last column: zeros, never written -- copied along)
                     HIP_TRY(ctx, hipMalloc((void **)&ctx->dhcf, (size_t)cap * sizeof(unsigned int)));
                     HIP_TRY(ctx, hipMemsetAsync(ctx->dhcf, 0, (size_t)cap * sizeof(unsigned int), ctx->stream));
                     ctx->hcr_cap = cap * (long long)per_item;
@@ -1673,7 +1680,7 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
             }
             const long long n_rblk = rflag ? (items + 7) / 8 * 8 : 0;  // (one chain wave per interval; a multiple of 8: the column-group waves keep their XCDs)
             p.n_stream = (int)n_rblk;
-            void *args[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dhcx, (void *)&ctx->dhcc, (void *)&rpre, (void *)&rflag};
+            void *args[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dhcx, (void *)&ctx->dhcc, (void *)&rpre, (void *)&rflag, (void *)&rt_all};
             // the waves of an interval on ONE XCD (blockIdx equal mod 8: the lines their neighbouring output runs share merge in that XCD's L2);
             // option hess_xcd: -1 auto (on) | 0 blockIdx order | n: the modulus
             const int nx = ctx->opt_hess_xcd < 0 ? 8 : (int)std::max<int64_t>(1, ctx->opt_hess_xcd);
@@ -1692,7 +1699,10 @@ static int launch_hess(pcl_ctx *ctx, const double *Z, const double *mu, double *
                 void *pargs[] = {(void *)&p, (void *)&tab, (void *)&tab_t, (void *)&ctx->dv4_mags, (void *)&dcf, (void *)&ctx->dhcx, (void *)&ctx->dhcc};
                 HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhessp, (unsigned)grid_hc, 1, 1, 128, 1, 1, (unsigned)ldsp, ctx->stream, pargs, nullptr));
             } else
-                HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhessc, (unsigned)grid_hc, 1, 1, 64, 1, 1, (unsigned)ldsc, ctx->stream, args, nullptr));
+            {
+                static const size_t lds_pad = getenv("PCL_HC_LDS_PAD") ? (size_t)atol(getenv("PCL_HC_LDS_PAD")) : 0;  // (occupancy experiment: lab/probes/README.md, round 6)
+                HIP_TRY(ctx, hipModuleLaunchKernel(ctx->v4_fhessc, (unsigned)grid_hc, 1, 1, 64, 1, 1, (unsigned)((rflag ? ldsc1 : ldsc) + lds_pad), ctx->stream, args, nullptr));
+            }
             ctx->last_hess_kernel = 80 + p.q;
             ctx->last_hess_split = 0;
             return PCL_OK;
