@@ -399,3 +399,33 @@ def test_two_wave_hessian_kernel_on_other_shapes(order):
         ref = po.pade_hessian_values(Z, mu, lay, G0, Gj, order).reshape(-1)
         assert np.abs(g - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
         ms.close()
+
+
+def test_r_tile_copy_with_an_odd_tile_size_five_drives():
+    """The R tiles travel as whole 16-byte pieces (global_load_lds_dwordx4): with five drives a column group has 5 columns x 55 doubles -- an odd count, padded to
+    even in memory and in LDS (HC_RTS).  Three transmons with one drive dropped (d = 27, m = 5), orders 8 and 10, R-chain waves forced, against the in-wave chain
+    and the oracle."""
+    so = po.config_system(3)
+    s5 = po.System(so.H_drift, list(so.H_drives)[:5], list(so.drive_bounds)[:5], so.subsystem_levels)
+    G0, Gj = s5.G_drift, np.array(s5.G_drives)
+    for order in (8, 10):
+        N = 5
+        Z5, lay5 = po.synthetic_trajectory(s5, N, seed=77)
+        Z5[:, lay5.dt_off] = 0.08 + 0.04 * np.random.default_rng(2).random(N)
+        mu = np.random.default_rng(9).standard_normal((lay5.K, lay5.x_dim))
+        ms = pa.HipPadeMultistart(G0, Gj, traj_from_Z(pa, Z5, lay5), 1, pade_order=order)
+        c = ms.ctx
+        c.set_option("hess_kernel", 8)
+        c.set_option("hess_pair", 0)
+        outs = []
+        for mode in (0, 1, 1):
+            c.set_option("hess_rpre", mode)
+            outs.append(c.hess(Z5[None].copy(), mu.reshape(-1)))
+            assert c.get_option("last_hess_kernel") == 80 + order // 2 and c.get_option("last_hess_rpre") == mode
+        assert np.array_equal(outs[1], outs[2])
+        nsc = (lay5.m + 1) * (lay5.m + 2) // 2
+        a0, a1 = outs[0].reshape(lay5.K, -1), outs[1].reshape(lay5.K, -1)
+        assert np.array_equal(a0[:, nsc:], a1[:, nsc:]) and np.abs(a0[:, :nsc] - a1[:, :nsc]).max() <= 1e-13 * max(1.0, np.abs(a0[:, :nsc]).max())
+        ref = po.pade_hessian_values(Z5, mu, lay5, G0, Gj, order).reshape(-1)
+        assert np.abs(outs[1] - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+        ms.close()
