@@ -72,13 +72,10 @@ static __device__ __forceinline__ double hc_load_coherent(const double *q) {
     return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
 }
 // The R-chain wave of an interval and the interval's column-group waves run on ONE XCD (blockIdx equal mod 8: the host launches chain waves only with
-// that placement), so their exchange needs the XCD's L2 and no more: device-scope stores and loads (past the CU's vector cache, served by the L2) -- at
-// system scope every wave paid a round trip to memory for its tiles and the chain waves bought 3 % instead of 12.
+// that placement), so their exchange needs the XCD's L2 and no more: device-scope stores here, the column-group waves' copies (global_load_lds ... sc1) past the CU's vector
+// cache, served by the L2 -- at system scope every wave paid a round trip to memory for its tiles and the chain waves bought 3 % instead of 12.
 static __device__ __forceinline__ void hc_store_xcd(double *q, double v) {
     __hip_atomic_store((unsigned long long *)q, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-static __device__ __forceinline__ double hc_load_xcd(const double *q) {
-    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
 // One R-chain wave: ALL d state columns of interval `item`, lane = (half, column) -- 2 d of 64 lanes.  The lane keeps its half column of D and of S in
@@ -199,7 +196,7 @@ extern "C" __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu
     //      ALL of an interval's state columns, lane = (half, column) -- the same q - 2 products that every column-group wave of round 5 ran on its own
     //      four columns at 8 of 64 lanes (15 % of an 8-seed launch at order 8), here once per interval.  They are dispatched in front of the
     //      column-group waves, write their tiles through to memory and count themselves in; a column-group wave looks at its interval's count with
-    //      its first loads and, where the chain has arrived (it started earlier), requests its columns' tiles together with its other inputs.
+    //      its first loads and requests its columns' first tile (or all of them: rt_all) together with its other inputs -- straight into LDS (hc_rtile_dma).
     unsigned bid = blockIdx.x;
     if constexpr (HC_NR > 0) {
         if (bid < (unsigned)p.n_stream) {
