@@ -161,6 +161,12 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the evaluator has no CPU path)")
+    # (tests/test_round6_gpu.py only: every rank on device 0 over gloo, so that the world > 1 branches of this script -- shares per rank, the strong-scaling
+    #  labels, the ensemble step beside the multistart line, the max over ranks -- run once on a 1-GPU box before the first multi-GPU lease; RCCL refuses two
+    #  ranks on one device.  The line then says so: "collective_backend": "gloo (test)".)
+    one_device_test = os.environ.get("PCL_BENCH_TEST_ONE_DEVICE") == "1"
+    if one_device_test:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     saved_stdout = None
@@ -173,7 +179,10 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_device_test:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     stream = torch.cuda.Stream()  # the launch stream; HIP events below are recorded on it
     torch.cuda.set_stream(stream)
@@ -400,6 +409,8 @@ def main():
                                  "rccl_ranks": ie.get("rccl_ranks"), "all_reduce_us": ie.get("all_reduce_us"), "payload_fused": ie["payload_fused"], "launches_per_step": ie["launches_per_step"],
                                  "note": "config 4: fused residual+Jacobian of this rank's members + objective + payload, then ONE RCCL sum all-reduce; max over ranks"}  # fmt: skip
     out["launcher"] = "self" if os.environ.get("PCL_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if "RANK" in os.environ else "none")
+    if one_device_test:
+        out["collective_backend"] = "gloo (test: every rank on device 0)"
     if dist is not None:  # ranks the one collective of the path ran over (the ensemble step's all-reduce), at the top level of the line
         out["rccl_ranks"] = (out.get("ensemble_share") or {}).get("rccl_ranks") or info.get("rccl_ranks") or int(dist.get_world_size())
     kernel_s = dev / args.steps  # HIP events on the launch stream around the K back-to-back steps

@@ -429,3 +429,30 @@ def test_r_tile_copy_with_an_odd_tile_size_five_drives():
         ref = po.pade_hessian_values(Z5, mu, lay5, G0, Gj, order).reshape(-1)
         assert np.abs(outs[1] - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
         ms.close()
+
+
+def test_bench_with_two_ranks_on_one_device():
+    """bench.py with WORLD_SIZE = 2 for real -- the branches only a world > 1 takes: 64 / N seeds per rank (strong scaling), the ensemble step with its
+    all-reduce beside the multistart line, the max over ranks, one JSON line from rank 0.  RCCL refuses two ranks on one device, so the test hook
+    (PCL_BENCH_TEST_ONE_DEVICE: every rank on device 0, gloo) carries the collective; the kernels and the script's logic are the production ones."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.update(PCL_BENCH_TEST_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]  # fmt: skip
+    pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=1500)
+    assert pr.returncode == 0, pr.stderr.decode()[-3000:]
+    lines = [ln for ln in pr.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["collective_backend"].startswith("gloo")
+    cfg = out["config"]
+    assert cfg["workload_id"] == "multistart" and cfg["units_per_gpu"] == 32 and cfg["total_units"] == 64
+    assert out["value"] > 0 and out["steps"] == 3 and 0 < out["roofline"]["frac"] < 1
+    es = out["ensemble_share"]
+    assert es["members_per_gpu"] == 32 and es["members_total"] == 64 and es["all_reduce"] is True and es["rccl_ranks"] == 2 and es["all_reduce_us"] > 0
+    assert out["rccl_ranks"] == 2
