@@ -41,4 +41,4 @@ from .quantum import (
 )
 from .trajectory import NamedTrajectory, add_control_derivatives, density_trajectory, ket_trajectory, sampling_trajectory, unitary_trajectory
 
-__version__ = "0.3.1"
+__version__ = "0.4.0"

@@ -32,7 +32,7 @@
 #include "pcl_codegen.hpp"
 #include "pcl_codegen_v4.hpp"
 
-#define PCL_VERSION_STR "piccolo_hip 0.3.1 (gfx950, pade 2/4/6/8/10)"
+#define PCL_VERSION_STR "piccolo_hip 0.4.0 (gfx950, pade 2/4/6/8/10)"
 
 #include "pcl_device_common.hpp"
 #include "pcl_kernels_reference.hpp"
